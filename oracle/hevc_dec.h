@@ -1,0 +1,19 @@
+/* ORACLE — test infrastructure only. Decoder API of the CPU restatement (see hevc_dec.c). */
+#ifndef ORACLE_HEVC_DEC_H
+#define ORACLE_HEVC_DEC_H
+#include "hevc_common.h"
+#include "hevc_recon.h"
+
+typedef struct oracle_hevc_decoder oracle_hevc_decoder;
+
+oracle_hevc_decoder* oracle_hevc_dec_create(void);
+void oracle_hevc_dec_destroy(oracle_hevc_decoder* d);
+/* Decodes a complete Annex-B elementary stream. Returns 0 on success (<0: error). Frames are kept in decode order
+ * (== output order for the low-delay I/P structures this path handles). */
+int oracle_hevc_dec_decode(oracle_hevc_decoder* d, const uint8_t* annexb, size_t n);
+int oracle_hevc_dec_num_frames(const oracle_hevc_decoder* d);
+const hevc_frame* oracle_hevc_dec_frame(const oracle_hevc_decoder* d, int i);
+/* number of pictures whose MD5 SEI was checked / failed */
+int oracle_hevc_dec_md5_checked(const oracle_hevc_decoder* d);
+int oracle_hevc_dec_md5_failed(const oracle_hevc_decoder* d);
+#endif

@@ -1,0 +1,1049 @@
+/* ORACLE — test infrastructure only (see oracle/README.md). Never linked into the product library.
+ *
+ * CPU restatement of the HEVC encode the reference performs through libavcodec -> libx265
+ * (PCCTranscoder.cpp:548-592 encodeVideo, :825-904 setEncoderOptions). libx265 is a system dependency absent from
+ * /root/reference and its mode decision is not normative, so this file DEFINES the encoder the
+ * MI355X path implements ("RBT-E1") and is the bit-exact oracle for it:
+ *   - closed GOPs: gop=2 -> IDR,P pairs (P predicts from its IDR with zero motion: V-PCC map D1/T1 vs D0/T0),
+ *     gop=1 -> all IDR (occupancy); parameter sets repeated with every IDR.
+ *   - CQP: P slices at qp, I slices at qp + i_qp_offset (x265 CQP with ipratio 1.4 => -3).
+ *   - one slice per `ctb_rows_per_slice` CTB rows so entropy coding and intra reconstruction parallelise per row.
+ *   - I pictures: CU quadtree 32/16/8 chosen bottom-up from open-loop (source-neighbour) intra SAD, 11 candidate
+ *     modes, TU = CU, chroma DM; dead-zone quantiser 171/512.
+ *   - P pictures: 16x16 CUs merged (zero MV) + residual, skip when all levels are zero, skips merged up the tree;
+ *     dead-zone 85/512.
+ *   - lossless (occupancy): cu_transquant_bypass, same quadtree/mode analysis.
+ *   - deblocking on (off for lossless), SAO off.
+ * stress_seed != 0 turns the same bitstream writer into a seeded random-syntax generator that exercises the decoder
+ * tools of the CTC input streams the product encoder never emits (all 35 intra modes, NxN, TU trees, transform skip,
+ * AMP, AMVP, TMVP, SAO, cu_qp_delta, sign data hiding, multiple slices).
+ */
+#include "hevc_enc.h"
+
+#define ENC_ERR(...) do { fprintf(stderr, "[oracle hevc_enc] " __VA_ARGS__); fprintf(stderr, "\n"); } while (0)
+
+/* lambda_sad * 16 for qp' = qp + 6*(bitDepth-8): round(16*sqrt(0.57*2^((qp'-12)/3))) */
+static const uint16_t k_lambda16[76] = {3,    3,    4,    4,    5,    5,    6,    7,    8,    9,    10,   11,   12,
+                                        14,   15,   17,   19,   22,   24,   27,   30,   34,   38,   43,   48,   54,
+                                        61,   68,   77,   86,   97,   108,  122,  137,  153,  172,  193,  217,  244,
+                                        273,  307,  344,  387,  434,  487,  547,  614,  689,  773,  868,  974,  1093,
+                                        1227, 1378, 1546, 1736, 1948, 2187, 2454, 2755, 3092, 3471, 3896, 4373, 4909,
+                                        5510, 6185, 6942, 7792, 8747, 9818, 11020, 12370, 13884, 15585, 17493};
+static const uint8_t k_intra_cand[11] = {0, 1, 26, 10, 2, 6, 14, 18, 22, 30, 34};
+#define SPLIT_BITS 24
+
+/* ================================================================================================ CABAC encoder (9.3.4.x) */
+typedef struct { bitwriter w; uint32_t low, range; int outstanding, first; uint8_t st[CTX_COUNT]; } cabac_enc;
+static void ce_put(cabac_enc* c, int b) {
+  if (c->first) c->first = 0; else bw_bit(&c->w, b);
+  while (c->outstanding > 0) { bw_bit(&c->w, 1 - b); c->outstanding--; }
+}
+static void ce_renorm(cabac_enc* c) {
+  while (c->range < 256) {
+    if (c->low < 256) ce_put(c, 0);
+    else if (c->low >= 512) { c->low -= 512; ce_put(c, 1); }
+    else { c->low -= 256; c->outstanding++; }
+    c->range <<= 1; c->low <<= 1;
+  }
+}
+static void ce_start(cabac_enc* c) { c->low = 0; c->range = 510; c->first = 1; c->outstanding = 0; }
+static void ce_init_ctx(cabac_enc* c, int init_type, int qp) {
+  qp = clip3(0, 51, qp);
+  for (int i = 0; i < CTX_COUNT; i++) {
+    int iv = k_ctx_init[init_type][i];
+    int m = (iv >> 4) * 5 - 45, n = ((iv & 15) << 3) - 16;
+    int pre = clip3(1, 126, ((m * qp) >> 4) + n);
+    int mps = pre <= 63 ? 0 : 1;
+    c->st[i] = (uint8_t)(((mps ? pre - 64 : 63 - pre) << 1) | mps);
+  }
+}
+static void ce_bin(cabac_enc* c, int ctx, int bin) {
+  int s = c->st[ctx] >> 1, mps = c->st[ctx] & 1;
+  uint32_t lps = k_range_lps[s][(c->range >> 6) & 3];
+  c->range -= lps;
+  if (bin != mps) { c->low += c->range; c->range = lps; if (s == 0) mps = 1 - mps; s = k_next_lps[s]; }
+  else s = hevc_next_mps(s);
+  c->st[ctx] = (uint8_t)((s << 1) | mps);
+  ce_renorm(c);
+}
+static void ce_bypass(cabac_enc* c, int bin) {
+  c->low <<= 1;
+  if (bin) c->low += c->range;
+  if (c->low >= 1024) { ce_put(c, 1); c->low -= 1024; }
+  else if (c->low < 512) ce_put(c, 0);
+  else { c->low -= 512; c->outstanding++; }
+}
+static void ce_bypass_n(cabac_enc* c, uint32_t v, int n) { for (int i = n - 1; i >= 0; i--) ce_bypass(c, (v >> i) & 1); }
+static void ce_terminate(cabac_enc* c, int bin) {
+  c->range -= 2;
+  if (bin) {
+    c->low += c->range; c->range = 2; ce_renorm(c);
+    ce_put(c, (c->low >> 9) & 1); bw_u(&c->w, ((c->low >> 7) & 3) | 1, 2);
+  } else ce_renorm(c);
+}
+
+/* ================================================================================================ encoder state */
+typedef struct { uint32_t s; } rng;
+static uint32_t rnd(rng* r) { uint32_t x = r->s; x ^= x << 13; x ^= x >> 17; x ^= x << 5; r->s = x; return x; }
+static int rndn(rng* r, int n) { return (int)(rnd(r) % (uint32_t)n); }
+static int rndp(rng* r, int pct) { return rndn(r, 100) < pct; }
+
+typedef struct { uint8_t split, cbf_y, cbf_cb, cbf_cr, ts[3], chroma_here; int16_t x, y; uint8_t log2; int8_t qp_delta; uint8_t has_qp_delta; } tnode;
+typedef struct { int x, y, w, h, merge, merge_idx, ref_idx, mvp_flag, mvd_x, mvd_y; hevc_mvcand mv; } pu_t;
+
+typedef struct {
+  oracle_enc_params p;
+  hevc_sps sps; hevc_pps pps;
+  /* stream-level stress options */
+  int two_refs, max_merge_cand, temporal_mvp, cabac_init_present;
+  rng r; int stress;
+  /* per picture */
+  const hevc_frame* src; hevc_frame* rec; hevc_meta* m;
+  const hevc_frame* ref[2]; const hevc_colinfo* refcol[2]; int ref_poc[2]; int n_ref;
+  int poc, slice_type, slice_qp, slice_idx, is_idr;
+  hevc_slice_hdr sh;
+  hevc_mvpred mp;
+  cabac_enc c;
+  int qp_y, qp_pred, qp_y_prev, is_cu_qp_delta_coded, cu_qp_delta_val;
+  uint8_t scan[3][4][64];
+  /* current CU */
+  int cu_x, cu_y, cu_log2, cu_pred_mode, cu_part_mode, cu_tq_bypass, cu_skip;
+  int intra_luma[4], intra_chroma, intra_chroma_idx;
+  pu_t pu[4]; int n_pu;
+  int rqt_root_cbf, max_trafo_depth;
+  tnode nodes[400]; int n_nodes, rd_node;
+  int16_t lvl[3][64 * 64];     /* levels of the current CU, plane stride 64 */
+  /* product-mode analysis of the current CTB */
+  uint8_t an_mode[4][64]; int an_cost[4][64]; uint8_t an_split[4][64];   /* [size idx 0:8 1:16 2:32 3:64][block] */
+  /* history */
+  hevc_frame* dpb[2]; hevc_colinfo dpbcol[2]; int dpb_poc[2]; int n_dpb;
+} enc;
+
+static void build_scans(enc* e) {
+  for (int l = 0; l <= 3; l++) {
+    int n = 1 << l, i = 0, x = 0, y = 0, stop = 0;
+    while (!stop) {
+      while (y >= 0) { if (x < n && y < n) e->scan[0][l][i++] = (uint8_t)(x | (y << 4)); y--; x++; }
+      y = x; x = 0; if (i >= n * n) stop = 1;
+    }
+    i = 0; for (y = 0; y < n; y++) for (x = 0; x < n; x++) e->scan[1][l][i++] = (uint8_t)(x | (y << 4));
+    i = 0; for (x = 0; x < n; x++) for (y = 0; y < n; y++) e->scan[2][l][i++] = (uint8_t)(x | (y << 4));
+  }
+}
+static inline void set_rect8(uint8_t* a, int w4, int x, int y, int w, int h, int v) {
+  for (int j = y >> 2; j < (y + h) >> 2; j++) memset(a + (size_t)j * w4 + (x >> 2), v, (size_t)(w >> 2));
+}
+
+/* ================================================================================================ NAL output */
+static void emit_nal(bytebuf* out, int type, const uint8_t* rbsp, size_t n, int long_sc) {
+  if (long_sc) bb_put(out, 0);
+  bb_put(out, 0); bb_put(out, 0); bb_put(out, 1);
+  bb_put(out, (uint8_t)(type << 1)); bb_put(out, 1);
+  int z = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (z >= 2 && rbsp[i] <= 3) { bb_put(out, 3); z = 0; }
+    bb_put(out, rbsp[i]);
+    z = rbsp[i] == 0 ? z + 1 : 0;
+  }
+}
+static void write_ptl(bitwriter* w, int bit_depth) {
+  int profile = bit_depth > 8 ? 2 : 1;
+  bw_u(w, 0, 2); bw_u(w, 0, 1); bw_u(w, profile, 5);
+  for (int i = 0; i < 32; i++) bw_bit(w, i == profile || (profile == 1 && i == 2));
+  bw_bit(w, 1); bw_bit(w, 0); bw_bit(w, 0); bw_bit(w, 1);
+  bw_u(w, 0, 32); bw_u(w, 0, 11); bw_bit(w, 0);
+  bw_u(w, 153, 8);
+}
+static void write_rps_set(bitwriter* w, int idx, int nneg) {
+  if (idx) bw_bit(w, 0);
+  bw_ue(w, nneg); bw_ue(w, 0);
+  for (int i = 0; i < nneg; i++) { bw_ue(w, 0); bw_bit(w, 1); }
+}
+static void write_param_sets(enc* e, bytebuf* out) {
+  hevc_sps* s = &e->sps; hevc_pps* p = &e->pps;
+  bitwriter w; memset(&w, 0, sizeof(w));
+  /* VPS */
+  bw_u(&w, 0, 4); bw_u(&w, 3, 2); bw_u(&w, 0, 6); bw_u(&w, 0, 3); bw_bit(&w, 1); bw_u(&w, 0xFFFF, 16);
+  write_ptl(&w, s->bit_depth);
+  bw_bit(&w, 1); bw_ue(&w, s->max_dec_pic_buffering - 1); bw_ue(&w, 0); bw_ue(&w, 0);
+  bw_u(&w, 0, 6); bw_ue(&w, 0); bw_bit(&w, 0); bw_bit(&w, 0); bw_trailing(&w);
+  emit_nal(out, NAL_VPS, w.bb.d, w.bb.n, 1);
+  /* SPS */
+  w.bb.n = 0;
+  bw_u(&w, 0, 4); bw_u(&w, 0, 3); bw_bit(&w, 1);
+  write_ptl(&w, s->bit_depth);
+  bw_ue(&w, 0); bw_ue(&w, 1); bw_ue(&w, s->width); bw_ue(&w, s->height); bw_bit(&w, 0);
+  bw_ue(&w, s->bit_depth - 8); bw_ue(&w, s->bit_depth - 8); bw_ue(&w, s->log2_max_poc_lsb - 4);
+  bw_bit(&w, 1); bw_ue(&w, s->max_dec_pic_buffering - 1); bw_ue(&w, 0); bw_ue(&w, 0);
+  bw_ue(&w, s->log2_min_cb - 3); bw_ue(&w, s->log2_diff_max_min_cb); bw_ue(&w, s->log2_min_tb - 2); bw_ue(&w, s->log2_diff_max_min_tb);
+  bw_ue(&w, s->max_th_depth_inter); bw_ue(&w, s->max_th_depth_intra);
+  bw_bit(&w, 0); bw_bit(&w, s->amp_enabled); bw_bit(&w, s->sao_enabled); bw_bit(&w, 0);
+  bw_ue(&w, s->num_st_rps);
+  for (int i = 0; i < s->num_st_rps; i++) write_rps_set(&w, i, i + 1);
+  bw_bit(&w, 0); bw_bit(&w, s->temporal_mvp_enabled); bw_bit(&w, s->strong_intra_smoothing);
+  bw_bit(&w, 0); bw_bit(&w, 0); bw_trailing(&w);
+  emit_nal(out, NAL_SPS, w.bb.d, w.bb.n, 1);
+  /* PPS */
+  w.bb.n = 0;
+  bw_ue(&w, 0); bw_ue(&w, 0); bw_bit(&w, 0); bw_bit(&w, 0); bw_u(&w, 0, 3);
+  bw_bit(&w, p->sign_data_hiding); bw_bit(&w, p->cabac_init_present);
+  bw_ue(&w, p->num_ref_idx_default[0] - 1); bw_ue(&w, 0);
+  bw_se(&w, p->init_qp - 26); bw_bit(&w, p->constrained_intra_pred); bw_bit(&w, p->transform_skip_enabled);
+  bw_bit(&w, p->cu_qp_delta_enabled); if (p->cu_qp_delta_enabled) bw_ue(&w, p->diff_cu_qp_delta_depth);
+  bw_se(&w, p->cb_qp_offset); bw_se(&w, p->cr_qp_offset); bw_bit(&w, p->slice_chroma_qp_offsets_present);
+  bw_bit(&w, 0); bw_bit(&w, 0);
+  bw_bit(&w, p->transquant_bypass_enabled); bw_bit(&w, 0); bw_bit(&w, 0);
+  bw_bit(&w, p->loop_filter_across_slices);
+  bw_bit(&w, p->deblocking_control_present);
+  if (p->deblocking_control_present) {
+    bw_bit(&w, p->deblocking_override_enabled); bw_bit(&w, p->pps_deblocking_disabled);
+    if (!p->pps_deblocking_disabled) { bw_se(&w, p->beta_offset_div2); bw_se(&w, p->tc_offset_div2); }
+  }
+  bw_bit(&w, 0); bw_bit(&w, 0); bw_ue(&w, 0); bw_bit(&w, 0); bw_bit(&w, 0); bw_trailing(&w);
+  emit_nal(out, NAL_PPS, w.bb.d, w.bb.n, 1);
+  free(w.bb.d);
+}
+static int ceil_log2(unsigned v) { int n = 0; while ((1u << n) < v) n++; return n; }
+static void write_slice_header(enc* e, bitwriter* w, int first, int ctb_addr) {
+  hevc_sps* s = &e->sps; hevc_pps* p = &e->pps; hevc_slice_hdr* h = &e->sh;
+  bw_bit(w, first);
+  if (e->is_idr) bw_bit(w, 0);
+  bw_ue(w, 0);
+  if (!first) bw_u(w, ctb_addr, ceil_log2(s->pic_w_ctb * s->pic_h_ctb));
+  bw_ue(w, h->slice_type);
+  if (!e->is_idr) {
+    bw_u(w, e->poc & ((1 << s->log2_max_poc_lsb) - 1), s->log2_max_poc_lsb);
+    bw_bit(w, 1);
+    if (s->num_st_rps > 1) bw_u(w, h->st_rps_idx, ceil_log2(s->num_st_rps));
+    if (s->temporal_mvp_enabled) bw_bit(w, h->temporal_mvp);
+  }
+  if (s->sao_enabled) { bw_bit(w, h->sao_luma); bw_bit(w, h->sao_chroma); }
+  if (h->slice_type == SLICE_P) {
+    int ovr = h->num_ref_idx[0] != p->num_ref_idx_default[0];
+    bw_bit(w, ovr); if (ovr) bw_ue(w, h->num_ref_idx[0] - 1);
+    if (p->cabac_init_present) bw_bit(w, h->cabac_init_flag);
+    if (h->temporal_mvp && h->num_ref_idx[0] > 1) bw_ue(w, h->collocated_ref_idx);
+    bw_ue(w, 5 - h->max_merge_cand);
+  }
+  bw_se(w, h->qp - p->init_qp);
+  if (p->slice_chroma_qp_offsets_present) { bw_se(w, h->cb_qp_offset); bw_se(w, h->cr_qp_offset); }
+  if (p->deblocking_override_enabled) {
+    int ovr = h->deblocking_disabled != p->pps_deblocking_disabled || h->beta_offset_div2 != p->beta_offset_div2 || h->tc_offset_div2 != p->tc_offset_div2;
+    bw_bit(w, ovr);
+    if (ovr) { bw_bit(w, h->deblocking_disabled); if (!h->deblocking_disabled) { bw_se(w, h->beta_offset_div2); bw_se(w, h->tc_offset_div2); } }
+  }
+  if (p->loop_filter_across_slices && (h->sao_luma || h->sao_chroma || !h->deblocking_disabled)) bw_bit(w, h->loop_filter_across_slices);
+  bw_bit(w, 1); bw_align_zero(w);
+}
+
+/* ================================================================================================ residual writer (7.3.8.11) */
+static const uint8_t k_group_idx[32] = {0, 1, 2, 3, 4, 4, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9, 9, 9};
+static const uint8_t k_min_in_group[10] = {0, 1, 2, 3, 4, 6, 8, 12, 16, 24};
+
+/* coeff: N x N levels with stride `st`. With sign data hiding the caller has already made parities consistent. */
+static void write_residual(enc* e, int log2, int c_idx, int scan_idx, const int16_t* coeff, int st, int ts_flag) {
+  cabac_enc* c = &e->c;
+  if (e->pps.transform_skip_enabled && !e->cu_tq_bypass && log2 <= 2) ce_bin(c, CTX_TRANSFORM_SKIP + (c_idx ? 1 : 0), ts_flag);
+  const uint8_t* sb_scan = e->scan[scan_idx][log2 - 2];
+  const uint8_t* pos_scan = e->scan[scan_idx][2];
+  int n_sb = 1 << (2 * (log2 - 2));
+  int last_sb = -1, last_pos = -1;
+  for (int i = n_sb - 1; i >= 0 && last_sb < 0; i--) {
+    int xs = sb_scan[i] & 15, ys = sb_scan[i] >> 4;
+    for (int n = 15; n >= 0; n--) {
+      int xc = (xs << 2) + (pos_scan[n] & 15), yc = (ys << 2) + (pos_scan[n] >> 4);
+      if (coeff[yc * st + xc]) { last_sb = i; last_pos = n; break; }
+    }
+  }
+  int lx = ((sb_scan[last_sb] & 15) << 2) + (pos_scan[last_pos] & 15), ly = ((sb_scan[last_sb] >> 4) << 2) + (pos_scan[last_pos] >> 4);
+  int cx = lx, cy = ly;
+  if (scan_idx == 2) { cx = ly; cy = lx; }
+  int ctx_off, ctx_shift;
+  if (c_idx == 0) { ctx_off = 3 * (log2 - 2) + ((log2 - 1) >> 2); ctx_shift = (log2 + 1) >> 2; }
+  else { ctx_off = 15; ctx_shift = log2 - 2; }
+  int maxp = (log2 << 1) - 1;
+  int px = k_group_idx[cx], py = k_group_idx[cy];
+  for (int i = 0; i < px; i++) ce_bin(c, CTX_LAST_X + ctx_off + (i >> ctx_shift), 1);
+  if (px < maxp) ce_bin(c, CTX_LAST_X + ctx_off + (px >> ctx_shift), 0);
+  for (int i = 0; i < py; i++) ce_bin(c, CTX_LAST_Y + ctx_off + (i >> ctx_shift), 1);
+  if (py < maxp) ce_bin(c, CTX_LAST_Y + ctx_off + (py >> ctx_shift), 0);
+  if (px > 3) ce_bypass_n(c, cx - k_min_in_group[px], (px >> 1) - 1);
+  if (py > 3) ce_bypass_n(c, cy - k_min_in_group[py], (py >> 1) - 1);
+  uint8_t csbf[8][8]; memset(csbf, 0, sizeof(csbf));
+  int sbw = 1 << (log2 - 2);
+  int greater1_ctx = 1, first_sb_done = 0;
+  int sign_hiding = e->pps.sign_data_hiding && !e->cu_tq_bypass;
+  for (int i = last_sb; i >= 0; i--) {
+    int xs = sb_scan[i] & 15, ys = sb_scan[i] >> 4;
+    int right = xs + 1 < sbw ? csbf[ys][xs + 1] : 0, below = ys + 1 < sbw ? csbf[ys + 1][xs] : 0;
+    int any = 0;
+    for (int n = 0; n < 16; n++) any |= coeff[((ys << 2) + (pos_scan[n] >> 4)) * st + (xs << 2) + (pos_scan[n] & 15)] != 0;
+    int infer_dc = 0, coded;
+    if (i < last_sb && i > 0) { coded = any; ce_bin(c, CTX_CSBF + imin(right + below, 1) + (c_idx ? 2 : 0), coded); infer_dc = 1; }
+    else coded = 1;
+    csbf[ys][xs] = (uint8_t)coded;
+    if (!coded) continue;
+    int sig_pos[16], nsig = 0, vals[16];
+    int start = i == last_sb ? last_pos - 1 : 15;
+    if (i == last_sb) sig_pos[nsig++] = last_pos;
+    int prev_csbf = right | (below << 1);
+    for (int n = start; n >= 0; n--) {
+      int xp = pos_scan[n] & 15, yp = pos_scan[n] >> 4;
+      int xc = (xs << 2) + xp, yc = (ys << 2) + yp;
+      int sig = coeff[yc * st + xc] != 0;
+      if (n > 0 || !infer_dc) {
+        int sc;
+        if (log2 == 2) sc = k_sig_ctx_4x4[(yc << 2) + xc];
+        else if (xc + yc == 0) sc = 0;
+        else {
+          if (prev_csbf == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
+          else if (prev_csbf == 1) sc = yp == 0 ? 2 : (yp == 1 ? 1 : 0);
+          else if (prev_csbf == 2) sc = xp == 0 ? 2 : (xp == 1 ? 1 : 0);
+          else sc = 2;
+          if (c_idx == 0) { if (xs || ys) sc += 3; sc += log2 == 3 ? (scan_idx == 0 ? 9 : 15) : 21; }
+          else sc += log2 == 3 ? 9 : 12;
+        }
+        ce_bin(c, CTX_SIG + (c_idx == 0 ? sc : 27 + sc), sig);
+        if (sig) infer_dc = 0;
+      }
+      if (sig) sig_pos[nsig++] = n;
+    }
+    for (int k = 0; k < nsig; k++) { int n = sig_pos[k]; vals[k] = coeff[((ys << 2) + (pos_scan[n] >> 4)) * st + (xs << 2) + (pos_scan[n] & 15)]; }
+    int ctx_set = (i == 0 || c_idx > 0) ? 0 : 2;
+    if (first_sb_done && greater1_ctx == 0) ctx_set++;
+    first_sb_done = 1; greater1_ctx = 1;
+    int first_g1 = -1, n8 = imin(nsig, 8);
+    for (int k = 0; k < n8; k++) {
+      int g1 = iabs(vals[k]) > 1;
+      ce_bin(c, CTX_GT1 + (ctx_set << 2) + greater1_ctx + (c_idx ? 16 : 0), g1);
+      if (g1) { greater1_ctx = 0; if (first_g1 < 0) first_g1 = k; }
+      else if (greater1_ctx > 0 && greater1_ctx < 3) greater1_ctx++;
+    }
+    if (first_g1 >= 0) ce_bin(c, CTX_GT2 + ctx_set + (c_idx ? 4 : 0), iabs(vals[first_g1]) > 2);
+    int hidden = sign_hiding && (sig_pos[0] - sig_pos[nsig - 1] > 3);
+    int nsign = nsig - (hidden ? 1 : 0);
+    for (int k = 0; k < nsign; k++) ce_bypass(c, vals[k] < 0);
+    int rice = 0;
+    for (int k = 0; k < nsig; k++) {
+      int a = iabs(vals[k]);
+      int base = k < 8 ? (k == first_g1 ? 3 : 2) : 1;
+      if (a >= base) {
+        int v = a - base;
+        if (v < (4 << rice)) { int pre = v >> rice; for (int t = 0; t < pre; t++) ce_bypass(c, 1); ce_bypass(c, 0); ce_bypass_n(c, v & ((1 << rice) - 1), rice); }
+        else {
+          /* prefix p >= 4: values [((1<<(p-3))+2)<<rice, ((1<<(p-2))+2)<<rice) */
+          int p = 4; while (v >= (((1 << (p - 2)) + 2) << rice)) p++;
+          for (int t = 0; t < p; t++) ce_bypass(c, 1);
+          ce_bypass(c, 0);
+          ce_bypass_n(c, (uint32_t)(v - (((1 << (p - 3)) + 2) << rice)), p - 3 + rice);
+        }
+        if (a > 3 * (1 << rice)) rice = imin(rice + 1, 4);
+      }
+    }
+  }
+}
+
+/* scan index of a TB (7.4.9.11) */
+static int tb_scan_idx(int pred_mode, int log2, int c_idx, int intra_mode) {
+  if (pred_mode == MODE_INTRA && (log2 == 2 || (log2 == 3 && c_idx == 0))) {
+    if (intra_mode >= 6 && intra_mode <= 14) return 2;
+    if (intra_mode >= 22 && intra_mode <= 30) return 1;
+  }
+  return 0;
+}
+/* make the sign of the lowest-frequency coefficient of each coefficient group follow the parity rule (9.3.4.3 / 7.4.9.11) */
+static void apply_sign_hiding(enc* e, int log2, int scan_idx, int16_t* coeff, int st) {
+  const uint8_t* sb_scan = e->scan[scan_idx][log2 - 2];
+  const uint8_t* pos_scan = e->scan[scan_idx][2];
+  int n_sb = 1 << (2 * (log2 - 2));
+  for (int i = 0; i < n_sb; i++) {
+    int xs = sb_scan[i] & 15, ys = sb_scan[i] >> 4, first = -1, last = -1, sum = 0;
+    for (int n = 0; n < 16; n++) {
+      int v = coeff[((ys << 2) + (pos_scan[n] >> 4)) * st + (xs << 2) + (pos_scan[n] & 15)];
+      if (v) { if (first < 0) first = n; last = n; sum += iabs(v); }
+    }
+    if (first >= 0 && last - first > 3) {
+      int16_t* q = &coeff[((ys << 2) + (pos_scan[first] >> 4)) * st + (xs << 2) + (pos_scan[first] & 15)];
+      int a = iabs(*q); *q = (int16_t)((sum & 1) ? -a : a);
+    }
+  }
+}
+
+/* ================================================================================================ TU reconstruction */
+static int chroma_qp_of(enc* e, int c_idx) {
+  int off = c_idx == 1 ? e->pps.cb_qp_offset + e->sh.cb_qp_offset : e->pps.cr_qp_offset + e->sh.cr_qp_offset;
+  int bdo = 6 * (e->sps.bit_depth - 8);
+  int qpi = clip3(-bdo, 57, e->qp_y + off);
+  int qpc = qpi < 0 ? qpi : hevc_chroma_qp(qpi);
+  return qpc + bdo;
+}
+static void random_levels(enc* e, int log2, int16_t* lv, int st) {
+  int N = 1 << log2;
+  for (int y = 0; y < N; y++) memset(lv + y * st, 0, sizeof(int16_t) * N);
+  if (rndp(&e->r, 35)) return;
+  int k = 1 + rndn(&e->r, rndp(&e->r, 15) ? imin(N * N, 40) : 5);
+  int big = e->cu_tq_bypass ? 0 : rndp(&e->r, 6);
+  for (int i = 0; i < k; i++) {
+    int span = rndp(&e->r, 75) ? imin(N, 4) : N;
+    int x = rndn(&e->r, span), y = rndn(&e->r, span);
+    int v = 1 + rndn(&e->r, rndp(&e->r, 80) ? 2 : 9);
+    if (big && rndp(&e->r, 30)) v = 20 + rndn(&e->r, e->cu_tq_bypass ? 10 : 2500);
+    if (e->cu_tq_bypass) v = 1 + rndn(&e->r, 6);
+    lv[y * st + x] = (int16_t)(rndp(&e->r, 50) ? -v : v);
+  }
+}
+/* predicts (intra), derives levels (product: residual->T->Q; stress: random) and reconstructs one TB.
+ * Returns cbf. Levels are left in e->lvl[c_idx] at the TB's offset inside the CU (stride 64). */
+static int recon_tb(enc* e, int c_idx, int x0, int y0, int log2, int intra_mode, int* ts_out) {
+  hevc_frame* f = e->rec; int N = 1 << log2, pw = c_idx ? f->cw : f->w, bd = f->bit_depth, maxv = (1 << bd) - 1;
+  int sh = c_idx ? 1 : 0;
+  int16_t* lv = e->lvl[c_idx] + ((y0 - (e->cu_y >> sh)) * 64 + (x0 - (e->cu_x >> sh)));
+  uint16_t* p = f->p[c_idx] + (size_t)y0 * pw + x0;
+  if (e->cu_pred_mode == MODE_INTRA) hevc_intra_pred(f, e->m, c_idx, x0, y0, log2, intra_mode);
+  int is_dst = c_idx == 0 && log2 == 2 && e->cu_pred_mode == MODE_INTRA;
+  int qp = c_idx ? chroma_qp_of(e, c_idx) : e->qp_y + 6 * (bd - 8);
+  int16_t res[32 * 32], coef[32 * 32], lq[32 * 32], dq[32 * 32];
+  int ts = 0, cbf = 0;
+  if (e->stress) {
+    random_levels(e, log2, lv, 64);
+    if (e->pps.transform_skip_enabled && !e->cu_tq_bypass && log2 == 2) ts = rndp(&e->r, 30);
+    int scan_idx = tb_scan_idx(e->cu_pred_mode, log2, c_idx, intra_mode);
+    if (e->pps.sign_data_hiding && !e->cu_tq_bypass) apply_sign_hiding(e, log2, scan_idx, lv, 64);
+    for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) { lq[y * N + x] = lv[y * 64 + x]; cbf |= lq[y * N + x] != 0; }
+  } else {
+    const uint16_t* sp = e->src->p[c_idx] + (size_t)y0 * pw + x0;
+    for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) res[y * N + x] = (int16_t)((int)sp[(size_t)y * pw + x] - (int)p[(size_t)y * pw + x]);
+    if (e->cu_tq_bypass) { memcpy(lq, res, sizeof(int16_t) * N * N); for (int i = 0; i < N * N; i++) cbf |= lq[i] != 0; }
+    else { hevc_fwd_transform(res, coef, log2, is_dst, bd); cbf = hevc_quant(coef, lq, log2, qp, bd, e->cu_pred_mode == MODE_INTRA) != 0; }
+    for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) lv[y * 64 + x] = lq[y * N + x];
+  }
+  *ts_out = ts;
+  if (!cbf) return 0;
+  if (e->cu_tq_bypass) memcpy(res, lq, sizeof(int16_t) * N * N);
+  else {
+    hevc_dequant(lq, dq, log2, qp, bd);
+    if (ts) hevc_inv_transform_skip(dq, res, log2, bd); else hevc_inv_transform(dq, res, log2, is_dst, bd);
+  }
+  for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) p[(size_t)y * pw + x] = (uint16_t)clip3(0, maxv, p[(size_t)y * pw + x] + res[y * N + x]);
+  return 1;
+}
+
+static int wrap_qp(enc* e, int v) { int bdo = 6 * (e->sps.bit_depth - 8); return ((v + 52 + 2 * bdo) % (52 + bdo)) - bdo; }
+static void start_quant_group(enc* e, int xqg, int yqg) {
+  hevc_meta* m = e->m; int ctb_mask = ~((1 << e->sps.log2_ctb) - 1);
+  e->qp_y_prev = e->qp_y; e->is_cu_qp_delta_coded = 0; e->cu_qp_delta_val = 0;
+  int qa = e->qp_y_prev, qb = e->qp_y_prev;
+  if (xqg > 0 && ((xqg - 1) & ctb_mask) == (xqg & ctb_mask) && hevc_avail_cu(m, xqg, yqg, xqg - 1, yqg)) qa = m->qp[meta_idx(m, xqg - 1, yqg)];
+  if (yqg > 0 && ((yqg - 1) & ctb_mask) == (yqg & ctb_mask) && hevc_avail_cu(m, xqg, yqg, xqg, yqg - 1)) qb = m->qp[meta_idx(m, xqg, yqg - 1)];
+  e->qp_pred = (qa + qb + 1) >> 1;
+}
+
+/* recon phase of the transform tree; returns node index. Parent cbf_cb/cbf_cr = OR over children. */
+static int tt_recon(enc* e, int x0, int y0, int xb, int yb, int log2, int depth, int blk, int* cb_out, int* cr_out) {
+  hevc_meta* m = e->m; const hevc_sps* sps = &e->sps;
+  int ni = e->n_nodes++; tnode* nd = &e->nodes[ni]; memset(nd, 0, sizeof(*nd));
+  nd->x = (int16_t)x0; nd->y = (int16_t)y0; nd->log2 = (uint8_t)log2;
+  int intra_split = e->cu_pred_mode == MODE_INTRA && e->cu_part_mode == PART_NxN;
+  int inter_split = sps->max_th_depth_inter == 0 && e->cu_pred_mode != MODE_INTRA && e->cu_part_mode != PART_2Nx2N && depth == 0;
+  int split;
+  if (log2 <= sps->log2_max_tb && log2 > sps->log2_min_tb && depth < e->max_trafo_depth && !(intra_split && depth == 0))
+    split = e->stress ? rndp(&e->r, 35) : 0;
+  else split = (log2 > sps->log2_max_tb || (intra_split && depth == 0) || inter_split) ? 1 : 0;
+  nd->split = (uint8_t)split;
+  if (split) {
+    int h = 1 << (log2 - 1), cb = 0, cr = 0, a, b;
+    tt_recon(e, x0, y0, x0, y0, log2 - 1, depth + 1, 0, &a, &b); cb |= a; cr |= b;
+    tt_recon(e, x0 + h, y0, x0, y0, log2 - 1, depth + 1, 1, &a, &b); cb |= a; cr |= b;
+    tt_recon(e, x0, y0 + h, x0, y0, log2 - 1, depth + 1, 2, &a, &b); cb |= a; cr |= b;
+    tt_recon(e, x0 + h, y0 + h, x0, y0, log2 - 1, depth + 1, 3, &a, &b); cb |= a; cr |= b;
+    nd = &e->nodes[ni]; nd->cbf_cb = (uint8_t)cb; nd->cbf_cr = (uint8_t)cr;
+    *cb_out = cb; *cr_out = cr;
+    return ni;
+  }
+  int N = 1 << log2, part = 0, ts;
+  if (intra_split) part = ((y0 - e->cu_y) >= (1 << (e->cu_log2 - 1)) ? 2 : 0) + ((x0 - e->cu_x) >= (1 << (e->cu_log2 - 1)) ? 1 : 0);
+  for (int i = 0; i < N; i += 4) { m->edge_v[meta_idx(m, x0, y0 + i)] |= 1; m->edge_h[meta_idx(m, x0 + i, y0)] |= 1; }
+  nd->cbf_y = (uint8_t)recon_tb(e, 0, x0, y0, log2, e->intra_luma[part], &ts); nd->ts[0] = (uint8_t)ts;
+  set_rect8(m->nz, m->w4, x0, y0, N, N, nd->cbf_y);
+  if (e->cu_pred_mode == MODE_INTRA) set_rect8(m->done, m->w4, x0, y0, N, N, 1);
+  int chroma_here = log2 > 2 || blk == 3;
+  nd->chroma_here = (uint8_t)chroma_here;
+  int cb = 0, cr = 0;
+  if (chroma_here) {
+    int xc = (log2 > 2 ? x0 : xb) >> 1, yc = (log2 > 2 ? y0 : yb) >> 1, l2c = log2 > 2 ? log2 - 1 : 2;
+    cb = recon_tb(e, 1, xc, yc, l2c, e->intra_chroma, &ts); nd->ts[1] = (uint8_t)ts;
+    cr = recon_tb(e, 2, xc, yc, l2c, e->intra_chroma, &ts); nd->ts[2] = (uint8_t)ts;
+  }
+  nd->cbf_cb = (uint8_t)cb; nd->cbf_cr = (uint8_t)cr;
+  *cb_out = cb; *cr_out = cr;
+  return ni;
+}
+
+/* write phase of the transform tree: consumes e->nodes in the order tt_recon produced them */
+static void tt_write(enc* e, int depth, int pcb, int pcr) {
+  cabac_enc* c = &e->c; const hevc_sps* sps = &e->sps;
+  tnode* nd = &e->nodes[e->rd_node++];
+  int log2 = nd->log2;
+  int intra_split = e->cu_pred_mode == MODE_INTRA && e->cu_part_mode == PART_NxN;
+  if (log2 <= sps->log2_max_tb && log2 > sps->log2_min_tb && depth < e->max_trafo_depth && !(intra_split && depth == 0))
+    ce_bin(c, CTX_SPLIT_TRANSFORM + 5 - log2, nd->split);
+  int cbf_cb = pcb, cbf_cr = pcr;
+  if (log2 > 2) {
+    cbf_cb = cbf_cr = 0;
+    if (depth == 0 || pcb) { cbf_cb = nd->cbf_cb; ce_bin(c, CTX_CBF_CHROMA + depth, cbf_cb); }
+    if (depth == 0 || pcr) { cbf_cr = nd->cbf_cr; ce_bin(c, CTX_CBF_CHROMA + depth, cbf_cr); }
+  }
+  if (nd->split) { for (int i = 0; i < 4; i++) tt_write(e, depth + 1, cbf_cb, cbf_cr); return; }
+  if (e->cu_pred_mode == MODE_INTRA || depth != 0 || cbf_cb || cbf_cr) ce_bin(c, CTX_CBF_LUMA + (depth == 0 ? 1 : 0), nd->cbf_y);
+  if ((nd->cbf_y || cbf_cb || cbf_cr) && e->pps.cu_qp_delta_enabled && !e->is_cu_qp_delta_coded) {
+    int v = e->cu_qp_delta_val, a = iabs(v);
+    for (int i = 0; i < imin(a, 5); i++) ce_bin(c, CTX_CU_QP_DELTA + (i ? 1 : 0), 1);
+    if (a < 5) ce_bin(c, CTX_CU_QP_DELTA + (a ? 1 : 0), 0);
+    else { int r = a - 5, k = 0; while (r >= (1 << k)) { ce_bypass(c, 1); r -= 1 << k; k++; } ce_bypass(c, 0); ce_bypass_n(c, (uint32_t)r, k); }
+    if (a) ce_bypass(c, v < 0);
+    e->is_cu_qp_delta_coded = 1;
+  }
+  int part = 0;
+  if (intra_split) part = ((nd->y - e->cu_y) >= (1 << (e->cu_log2 - 1)) ? 2 : 0) + ((nd->x - e->cu_x) >= (1 << (e->cu_log2 - 1)) ? 1 : 0);
+  if (nd->cbf_y)
+    write_residual(e, log2, 0, tb_scan_idx(e->cu_pred_mode, log2, 0, e->intra_luma[part]), e->lvl[0] + (nd->y - e->cu_y) * 64 + (nd->x - e->cu_x), 64, nd->ts[0]);
+  if (nd->chroma_here) {
+    int l2c = log2 > 2 ? log2 - 1 : 2;
+    int xo = ((log2 > 2 ? nd->x : nd->x - 4) - e->cu_x) >> 1, yo = ((log2 > 2 ? nd->y : nd->y - 4) - e->cu_y) >> 1;
+    int sc = tb_scan_idx(e->cu_pred_mode, l2c, 1, e->intra_chroma);
+    if (cbf_cb && nd->cbf_cb) write_residual(e, l2c, 1, sc, e->lvl[1] + yo * 64 + xo, 64, nd->ts[1]);
+    if (cbf_cr && nd->cbf_cr) write_residual(e, l2c, 2, sc, e->lvl[2] + yo * 64 + xo, 64, nd->ts[2]);
+  }
+}
+
+/* ================================================================================================ prediction units */
+static void write_mvd_comp_flags(cabac_enc* c, int dx, int dy) {
+  ce_bin(c, CTX_MVD_GT0, dx != 0); ce_bin(c, CTX_MVD_GT0, dy != 0);
+  if (dx) ce_bin(c, CTX_MVD_GT1, iabs(dx) > 1);
+  if (dy) ce_bin(c, CTX_MVD_GT1, iabs(dy) > 1);
+}
+static void write_mvd_comp_rest(cabac_enc* c, int d) {
+  if (!d) return;
+  int a = iabs(d);
+  if (a > 1) { int r = a - 2, k = 1; while (r >= (1 << k)) { ce_bypass(c, 1); r -= 1 << k; k++; } ce_bypass(c, 0); ce_bypass_n(c, (uint32_t)r, k); }
+  ce_bypass(c, d < 0);
+}
+/* decides (stress: random; product: merge idx 0 = zero motion) and performs prediction of one PU */
+static void pu_decide_predict(enc* e, pu_t* pu, int part_idx, int skip) {
+  hevc_meta* m = e->m;
+  e->mp.part_mode = e->cu_part_mode;
+  pu->merge = skip ? 1 : (e->stress ? rndp(&e->r, 50) : 1);
+  if (pu->merge) {
+    pu->merge_idx = e->stress ? rndn(&e->r, e->sh.max_merge_cand) : 0;
+    pu->mv = hevc_merge_candidate(&e->mp, pu->x, pu->y, pu->w, pu->h, part_idx, pu->merge_idx);
+    if (!e->stress && (pu->mv.x || pu->mv.y || pu->mv.ref)) ENC_ERR("product encoder: merge candidate 0 is not zero motion");
+  } else {
+    pu->ref_idx = rndn(&e->r, e->sh.num_ref_idx[0]); pu->mvp_flag = rndn(&e->r, 2);
+    hevc_mvcand p = hevc_amvp_candidate(&e->mp, pu->x, pu->y, pu->w, pu->h, pu->ref_idx, pu->mvp_flag);
+    int big = rndp(&e->r, 10);
+    int tx = rndp(&e->r, 30) ? 0 : rndn(&e->r, big ? 400 : 40) - (big ? 200 : 20), ty = rndp(&e->r, 30) ? 0 : rndn(&e->r, big ? 400 : 40) - (big ? 200 : 20);
+    /* keep the resulting vector modest so that reference fetches stay near the picture */
+    int mx = clip3(-600, 600, p.x + tx), my = clip3(-600, 600, p.y + ty);
+    pu->mvd_x = mx - p.x; pu->mvd_y = my - p.y;
+    pu->mv.x = (int16_t)mx; pu->mv.y = (int16_t)my; pu->mv.ref = pu->ref_idx;
+  }
+  for (int j = pu->y >> 2; j < (pu->y + pu->h) >> 2; j++)
+    for (int i = pu->x >> 2; i < (pu->x + pu->w) >> 2; i++) {
+      int k = j * m->w4 + i; m->mv[2 * k] = pu->mv.x; m->mv[2 * k + 1] = pu->mv.y; m->ref_idx[k] = (int8_t)pu->mv.ref; m->pred_mode[k] = (uint8_t)(skip ? MODE_SKIP : MODE_INTER);
+    }
+  for (int i = 0; i < pu->h; i += 4) m->edge_v[meta_idx(m, pu->x, pu->y + i)] |= 2;
+  for (int i = 0; i < pu->w; i += 4) m->edge_h[meta_idx(m, pu->x + i, pu->y)] |= 2;
+  hevc_inter_pred(e->rec, e->ref[pu->mv.ref], pu->x, pu->y, pu->w, pu->h, pu->mv.x, pu->mv.y);
+}
+static void pu_write(enc* e, const pu_t* pu, int skip) {
+  cabac_enc* c = &e->c;
+  if (!skip) ce_bin(c, CTX_MERGE_FLAG, pu->merge);
+  if (pu->merge) {
+    if (e->sh.max_merge_cand > 1) {
+      ce_bin(c, CTX_MERGE_IDX, pu->merge_idx > 0);
+      if (pu->merge_idx > 0) { for (int i = 1; i < pu->merge_idx; i++) ce_bypass(c, 1); if (pu->merge_idx < e->sh.max_merge_cand - 1) ce_bypass(c, 0); }
+    }
+  } else {
+    if (e->sh.num_ref_idx[0] > 1) {
+      int mx = e->sh.num_ref_idx[0] - 1;
+      for (int i = 0; i < pu->ref_idx; i++) { if (i < 2) ce_bin(c, CTX_REF_IDX + i, 1); else ce_bypass(c, 1); }
+      if (pu->ref_idx < mx) { if (pu->ref_idx < 2) ce_bin(c, CTX_REF_IDX + pu->ref_idx, 0); else ce_bypass(c, 0); }
+    }
+    write_mvd_comp_flags(c, pu->mvd_x, pu->mvd_y);
+    write_mvd_comp_rest(c, pu->mvd_x); write_mvd_comp_rest(c, pu->mvd_y);
+    ce_bin(c, CTX_MVP_FLAG, pu->mvp_flag);
+  }
+}
+
+/* ================================================================================================ coding unit */
+typedef struct { int pred_mode, part_mode, skip, tq_bypass; int intra_luma[4]; int intra_chroma_idx; } cu_decision;
+
+static void encode_cu(enc* e, int x0, int y0, int log2, int depth, const cu_decision* d) {
+  cabac_enc* c = &e->c; hevc_meta* m = e->m; const hevc_sps* sps = &e->sps;
+  int N = 1 << log2;
+  e->cu_x = x0; e->cu_y = y0; e->cu_log2 = log2; e->cu_pred_mode = d->skip ? MODE_SKIP : d->pred_mode; e->cu_part_mode = d->part_mode;
+  e->cu_tq_bypass = d->tq_bypass; e->cu_skip = d->skip;
+  /* ---- recon phase ---- */
+  int trial_delta = 0, qp_trial = 0;
+  if (e->pps.cu_qp_delta_enabled) {
+    e->qp_y = wrap_qp(e, e->qp_pred + e->cu_qp_delta_val);
+    if (!e->is_cu_qp_delta_coded && e->stress && !d->skip) { trial_delta = rndn(&e->r, 9) - 4; qp_trial = 1; e->qp_y = wrap_qp(e, e->qp_pred + trial_delta); }
+  }
+  set_rect8(m->cu_depth, m->w4, x0, y0, N, N, depth);
+  set_rect8(m->tq_bypass, m->w4, x0, y0, N, N, e->cu_tq_bypass);
+  for (int i = 0; i < N; i += 4) { m->edge_v[meta_idx(m, x0, y0 + i)] |= 3; m->edge_h[meta_idx(m, x0 + i, y0)] |= 3; }
+  e->n_pu = 0; e->n_nodes = 0; e->rd_node = 0; e->rqt_root_cbf = 0;
+  int ctx_skip = 0;
+  if (e->sh.slice_type != SLICE_I) {
+    int cl = hevc_avail_cu(m, x0, y0, x0 - 1, y0) && m->pred_mode[meta_idx(m, x0 - 1, y0)] == MODE_SKIP;
+    int ca = hevc_avail_cu(m, x0, y0, x0, y0 - 1) && m->pred_mode[meta_idx(m, x0, y0 - 1)] == MODE_SKIP;
+    ctx_skip = cl + ca;
+  }
+  int mpm[4][3];
+  if (e->cu_pred_mode == MODE_INTRA) {
+    set_rect8(m->pred_mode, m->w4, x0, y0, N, N, MODE_INTRA);
+    int np = d->part_mode == PART_NxN ? 4 : 1, pb = N >> (np == 4);
+    for (int i = 0; i < np; i++) {
+      int xp = x0 + (i & 1) * pb, yp = y0 + (i >> 1) * pb;
+      hevc_intra_mpm(m, xp, yp, mpm[i]);
+      e->intra_luma[i] = d->intra_luma[i];
+      set_rect8(m->intra_mode, m->w4, xp, yp, pb, pb, d->intra_luma[i]);
+    }
+    static const int cm[4] = {0, 26, 10, 1};
+    e->intra_chroma_idx = d->intra_chroma_idx;
+    if (d->intra_chroma_idx == 4) e->intra_chroma = e->intra_luma[0];
+    else e->intra_chroma = cm[d->intra_chroma_idx] == e->intra_luma[0] ? 34 : cm[d->intra_chroma_idx];
+  } else {
+    int h2 = N >> 1, q = N >> 2;
+    int geo[8][4][4] = {{{0, 0, N, N}}, {{0, 0, N, h2}, {0, h2, N, h2}}, {{0, 0, h2, N}, {h2, 0, h2, N}},
+                        {{0, 0, h2, h2}, {h2, 0, h2, h2}, {0, h2, h2, h2}, {h2, h2, h2, h2}},
+                        {{0, 0, N, q}, {0, q, N, N - q}}, {{0, 0, N, N - q}, {0, N - q, N, q}},
+                        {{0, 0, q, N}, {q, 0, N - q, N}}, {{0, 0, N - q, N}, {N - q, 0, q, N}}};
+    int np = d->part_mode == PART_2Nx2N ? 1 : (d->part_mode == PART_NxN ? 4 : 2);
+    for (int i = 0; i < np; i++) {
+      pu_t* pu = &e->pu[e->n_pu++]; memset(pu, 0, sizeof(*pu));
+      pu->x = x0 + geo[d->part_mode][i][0]; pu->y = y0 + geo[d->part_mode][i][1]; pu->w = geo[d->part_mode][i][2]; pu->h = geo[d->part_mode][i][3];
+      pu_decide_predict(e, pu, i, d->skip);
+    }
+  }
+  int any_cbf = 0;
+  if (!d->skip) {
+    e->max_trafo_depth = e->cu_pred_mode == MODE_INTRA ? sps->max_th_depth_intra + (d->part_mode == PART_NxN) : sps->max_th_depth_inter;
+    int want_tree = 1;
+    if (e->cu_pred_mode != MODE_INTRA && e->stress && !(d->part_mode == PART_2Nx2N && e->pu[0].merge)) want_tree = rndp(&e->r, 70);
+    if (want_tree) {
+      int cb, cr;
+      tt_recon(e, x0, y0, x0, y0, log2, 0, 0, &cb, &cr);
+      for (int i = 0; i < e->n_nodes; i++) if (!e->nodes[i].split) any_cbf |= e->nodes[i].cbf_y | e->nodes[i].cbf_cb | e->nodes[i].cbf_cr;
+    }
+    e->rqt_root_cbf = e->cu_pred_mode == MODE_INTRA ? 1 : any_cbf;
+    if (e->cu_pred_mode != MODE_INTRA && !any_cbf) {
+      /* no residual: a 2Nx2N merge CU must then be coded as skip (product), others use rqt_root_cbf = 0 */
+      if (d->part_mode == PART_2Nx2N && e->pu[0].merge) {
+        e->cu_skip = 1; e->cu_pred_mode = MODE_SKIP;
+        set_rect8(m->pred_mode, m->w4, x0, y0, N, N, MODE_SKIP);
+      }
+      set_rect8(m->nz, m->w4, x0, y0, N, N, 0);
+      /* TU edges inside the CU were marked by tt_recon; without a transform tree the decoder has none */
+      for (int j = 0; j < N; j += 4) for (int i = 0; i < N; i += 4) {
+        if (i) m->edge_v[meta_idx(m, x0 + i, y0 + j)] &= ~1;
+        if (j) m->edge_h[meta_idx(m, x0 + i, y0 + j)] &= ~1;
+      }
+    }
+  }
+  if (qp_trial) {
+    if (any_cbf) { e->cu_qp_delta_val = trial_delta; }
+    else e->qp_y = wrap_qp(e, e->qp_pred + e->cu_qp_delta_val);
+  }
+  set_rect8((uint8_t*)m->qp, m->w4, x0, y0, N, N, (uint8_t)(int8_t)e->qp_y);
+  set_rect8(m->done, m->w4, x0, y0, N, N, 1);
+  /* ---- write phase ---- */
+  if (e->pps.transquant_bypass_enabled) ce_bin(c, CTX_CU_TQ_BYPASS, e->cu_tq_bypass);
+  if (e->sh.slice_type != SLICE_I) ce_bin(c, CTX_CU_SKIP + ctx_skip, e->cu_skip);
+  if (e->cu_skip) { pu_write(e, &e->pu[0], 1); return; }
+  if (e->sh.slice_type != SLICE_I) ce_bin(c, CTX_PRED_MODE, e->cu_pred_mode == MODE_INTRA);
+  int pm = d->part_mode;
+  if (e->cu_pred_mode == MODE_INTRA) {
+    if (log2 == sps->log2_min_cb) ce_bin(c, CTX_PART_MODE, pm == PART_2Nx2N);
+    int np = pm == PART_NxN ? 4 : 1;
+    int prev[4], idx[4];
+    for (int i = 0; i < np; i++) {
+      prev[i] = 0; idx[i] = 0;
+      for (int k = 0; k < 3; k++) if (mpm[i][k] == e->intra_luma[i]) { prev[i] = 1; idx[i] = k; }
+      ce_bin(c, CTX_PREV_INTRA_LUMA, prev[i]);
+    }
+    for (int i = 0; i < np; i++) {
+      if (prev[i]) { ce_bypass(c, idx[i] > 0); if (idx[i] > 0) ce_bypass(c, idx[i] > 1); }
+      else {
+        int cand[3] = {mpm[i][0], mpm[i][1], mpm[i][2]};
+        if (cand[0] > cand[1]) { int t = cand[0]; cand[0] = cand[1]; cand[1] = t; }
+        if (cand[0] > cand[2]) { int t = cand[0]; cand[0] = cand[2]; cand[2] = t; }
+        if (cand[1] > cand[2]) { int t = cand[1]; cand[1] = cand[2]; cand[2] = t; }
+        int rem = e->intra_luma[i];
+        for (int k = 2; k >= 0; k--) if (rem > cand[k]) rem--;
+        ce_bypass_n(c, (uint32_t)rem, 5);
+      }
+    }
+    ce_bin(c, CTX_INTRA_CHROMA, e->intra_chroma_idx != 4);
+    if (e->intra_chroma_idx != 4) ce_bypass_n(c, (uint32_t)e->intra_chroma_idx, 2);
+  } else {
+    if (pm == PART_2Nx2N) ce_bin(c, CTX_PART_MODE, 1);
+    else {
+      ce_bin(c, CTX_PART_MODE, 0);
+      if (log2 == sps->log2_min_cb) {
+        if (log2 == 3) ce_bin(c, CTX_PART_MODE + 1, pm == PART_2NxN);
+        else { ce_bin(c, CTX_PART_MODE + 1, pm == PART_2NxN); if (pm != PART_2NxN) ce_bin(c, CTX_PART_MODE + 2, pm == PART_Nx2N); }
+      } else if (!sps->amp_enabled) ce_bin(c, CTX_PART_MODE + 1, pm == PART_2NxN);
+      else {
+        int hor = pm == PART_2NxN || pm == PART_2NxnU || pm == PART_2NxnD;
+        ce_bin(c, CTX_PART_MODE + 1, hor);
+        int sym = pm == PART_2NxN || pm == PART_Nx2N;
+        ce_bin(c, CTX_PART_MODE + 3, sym);
+        if (!sym) ce_bypass(c, pm == PART_2NxnD || pm == PART_nRx2N);
+      }
+    }
+    for (int i = 0; i < e->n_pu; i++) pu_write(e, &e->pu[i], 0);
+    if (!(pm == PART_2Nx2N && e->pu[0].merge)) ce_bin(c, CTX_RQT_ROOT_CBF, e->rqt_root_cbf);
+  }
+  if (e->rqt_root_cbf) {
+    /* the write phase must see is_cu_qp_delta_coded as it was before this CU's recon phase */
+    int coded_after = e->is_cu_qp_delta_coded || (qp_trial && any_cbf);
+    if (qp_trial) e->is_cu_qp_delta_coded = 0;
+    tt_write(e, 0, 0, 0);
+    e->is_cu_qp_delta_coded = coded_after;
+  }
+}
+
+/* ================================================================================================ product-mode analysis */
+/* z-order availability at the granularity of the analysed block is realised by marking m->done block by block. */
+static void analyse_ctb_intra(enc* e, int cx, int cy) {
+  hevc_meta* m = e->m; const hevc_sps* sps = &e->sps;
+  int ctb = 1 << sps->log2_ctb;
+  hevc_frame srcview = *e->src;   /* intra prediction from SOURCE neighbours (open loop) */
+  uint16_t pred[32 * 32];
+  for (int si = 0; si < 3; si++) {
+    int S = 8 << si; if (S > ctb) break;
+    int nb = ctb / S;
+    /* visit blocks of size S in z-order */
+    for (int z = 0; z < nb * nb; z++) {
+      int bx = 0, by = 0;
+      for (int b = 0; b < 4; b++) { bx |= ((z >> (2 * b)) & 1) << b; by |= ((z >> (2 * b + 1)) & 1) << b; }
+      int x0 = cx + bx * S, y0 = cy + by * S;
+      int bi = by * nb + bx;
+      e->an_cost[si][bi] = 0x7FFFFFFF; e->an_mode[si][bi] = 0;
+      if (x0 >= sps->width || y0 >= sps->height) { e->an_cost[si][bi] = 0; continue; }
+      if (x0 + S > sps->width || y0 + S > sps->height) { e->an_cost[si][bi] = 0x3FFFFFFF; continue; }
+      for (int k = 0; k < 11; k++) {
+        int mode = k_intra_cand[k];
+        hevc_intra_pred_buf(&srcview, m, 0, x0, y0, 3 + si, mode, pred);
+        int sad = 0;
+        const uint16_t* sp = e->src->p[0] + (size_t)y0 * e->src->w + x0;
+        for (int y = 0; y < S; y++) for (int x = 0; x < S; x++) sad += iabs((int)sp[(size_t)y * e->src->w + x] - (int)pred[y * S + x]);
+        if (sad < e->an_cost[si][bi]) { e->an_cost[si][bi] = sad; e->an_mode[si][bi] = (uint8_t)mode; }
+      }
+      set_rect8(m->done, m->w4, x0, y0, S, S, 1);
+    }
+    set_rect8(m->done, m->w4, cx, cy, imin(ctb, sps->width - cx), imin(ctb, sps->height - cy), 0);
+  }
+  /* bottom-up split decisions */
+  int lam = k_lambda16[clip3(0, 75, e->slice_qp + 6 * (sps->bit_depth - 8))];
+  int pen = (lam * SPLIT_BITS) >> 4;
+  for (int si = 1; si < 3; si++) {
+    int S = 8 << si; if (S > ctb) break;
+    int nb = ctb / S, nbc = nb * 2;
+    for (int by = 0; by < nb; by++) for (int bx = 0; bx < nb; bx++) {
+      int bi = by * nb + bx;
+      int child = e->an_cost[si - 1][(2 * by) * nbc + 2 * bx] + e->an_cost[si - 1][(2 * by) * nbc + 2 * bx + 1] +
+                  e->an_cost[si - 1][(2 * by + 1) * nbc + 2 * bx] + e->an_cost[si - 1][(2 * by + 1) * nbc + 2 * bx + 1] + pen;
+      int split = child < e->an_cost[si][bi];
+      e->an_split[si][bi] = (uint8_t)split;
+      if (split) e->an_cost[si][bi] = child;
+    }
+  }
+}
+
+/* ================================================================================================ quadtree */
+static void encode_quadtree(enc* e, int x0, int y0, int log2, int depth, int cx, int cy);
+
+/* P pictures, product mode: returns 1 if the whole node was coded as skip-able (all levels zero).
+ * The node is first evaluated as a tree of 16x16 CUs on a scratch copy of the CABAC/picture state. */
+static void encode_quadtree(enc* e, int x0, int y0, int log2, int depth, int cx, int cy) {
+  cabac_enc* c = &e->c; hevc_meta* m = e->m; const hevc_sps* sps = &e->sps;
+  int N = 1 << log2;
+  int can_flag = x0 + N <= sps->width && y0 + N <= sps->height && log2 > sps->log2_min_cb;
+  int split;
+  cu_decision d; memset(&d, 0, sizeof(d));
+  d.tq_bypass = e->p.lossless ? 1 : 0; d.intra_chroma_idx = 4; d.pred_mode = MODE_INTRA;
+  if (e->stress) {
+    split = can_flag ? rndp(&e->r, log2 >= 5 ? 70 : (log2 == 4 ? 45 : 30)) : 0;
+  } else if (e->sh.slice_type == SLICE_I) {
+    if (log2 > 5) split = 1;
+    else if (log2 == 3) split = 0;
+    else { int S = N, nb = (1 << sps->log2_ctb) / S; split = e->an_split[log2 - 3][((y0 - cy) / S) * nb + (x0 - cx) / S]; }
+  } else {
+    /* P: decided by the caller through e->an_split[log2-3] filled by analyse_ctb_inter */
+    int S = N, nb = (1 << sps->log2_ctb) / S;
+    split = log2 > 4 ? e->an_split[log2 - 3][((y0 - cy) / S) * nb + (x0 - cx) / S] : 0;
+  }
+  if (!can_flag) split = log2 > sps->log2_min_cb;
+  if (can_flag) {
+    int cl = hevc_avail_cu(m, x0, y0, x0 - 1, y0) && m->cu_depth[meta_idx(m, x0 - 1, y0)] > depth;
+    int ca = hevc_avail_cu(m, x0, y0, x0, y0 - 1) && m->cu_depth[meta_idx(m, x0, y0 - 1)] > depth;
+    ce_bin(c, CTX_SPLIT_CU + cl + ca, split);
+  }
+  if (e->pps.cu_qp_delta_enabled && log2 >= sps->log2_ctb - e->pps.diff_cu_qp_delta_depth) start_quant_group(e, x0, y0);
+  if (split) {
+    int h = N >> 1;
+    encode_quadtree(e, x0, y0, log2 - 1, depth + 1, cx, cy);
+    if (x0 + h < sps->width) encode_quadtree(e, x0 + h, y0, log2 - 1, depth + 1, cx, cy);
+    if (y0 + h < sps->height) encode_quadtree(e, x0, y0 + h, log2 - 1, depth + 1, cx, cy);
+    if (x0 + h < sps->width && y0 + h < sps->height) encode_quadtree(e, x0 + h, y0 + h, log2 - 1, depth + 1, cx, cy);
+    return;
+  }
+  if (e->stress) {
+    rng* r = &e->r;
+    d.tq_bypass = e->pps.transquant_bypass_enabled ? rndp(r, 20) : 0;
+    int inter = e->sh.slice_type == SLICE_P && rndp(r, 70);
+    if (inter) {
+      d.skip = rndp(r, 25); d.pred_mode = MODE_INTER; d.part_mode = PART_2Nx2N;
+      if (!d.skip && rndp(r, 55)) {
+        if (log2 == sps->log2_min_cb) { int ch[3] = {PART_2NxN, PART_Nx2N, PART_NxN}; d.part_mode = ch[rndn(r, log2 == 3 ? 2 : 3)]; }
+        else if (sps->amp_enabled) { int ch[6] = {PART_2NxN, PART_Nx2N, PART_2NxnU, PART_2NxnD, PART_nLx2N, PART_nRx2N}; d.part_mode = ch[rndn(r, 6)]; }
+        else d.part_mode = rndp(r, 50) ? PART_2NxN : PART_Nx2N;
+      }
+    } else {
+      d.pred_mode = MODE_INTRA;
+      d.part_mode = (log2 == sps->log2_min_cb && log2 > sps->log2_min_tb && rndp(r, 40)) ? PART_NxN : PART_2Nx2N;
+      for (int i = 0; i < 4; i++) d.intra_luma[i] = rndp(r, 25) ? rndn(r, 2) : rndn(r, 35);
+      d.intra_chroma_idx = rndn(r, 5);
+    }
+  } else if (e->sh.slice_type == SLICE_I) {
+    int S = N, nb = (1 << sps->log2_ctb) / S;
+    d.intra_luma[0] = e->an_mode[log2 - 3][((y0 - cy) / S) * nb + (x0 - cx) / S];
+  } else { d.pred_mode = MODE_INTER; d.part_mode = PART_2Nx2N; d.skip = log2 > 4; }
+  encode_cu(e, x0, y0, log2, depth, &d);
+}
+
+/* P pictures (product): zero-motion prediction from the reference; a 16x16 CU is a skip when all its quantised
+ * levels are zero; nodes whose four children are all skips become one skip CU. Evaluated on the reconstructed
+ * reference, so it needs no sequential state: an_cost[1][b] = 1 if 16x16 block b has any non-zero level. */
+static void analyse_ctb_inter(enc* e, int cx, int cy) {
+  const hevc_sps* sps = &e->sps; int ctb = 1 << sps->log2_ctb, bd = sps->bit_depth;
+  int nb16 = ctb / 16;
+  int16_t res[16 * 16], coef[16 * 16], lq[16 * 16];
+  int qp_save = e->qp_y; e->qp_y = e->slice_qp;
+  for (int by = 0; by < nb16; by++) for (int bx = 0; bx < nb16; bx++) {
+    int x0 = cx + bx * 16, y0 = cy + by * 16, nz = 0;
+    if (x0 >= sps->width || y0 >= sps->height) { e->an_cost[1][by * nb16 + bx] = 0; continue; }
+    for (int ci = 0; ci < 3; ci++) {
+      int sh = ci ? 1 : 0, S = 16 >> sh, l2 = 4 - sh, pw = ci ? e->src->cw : e->src->w;
+      const uint16_t* sp = e->src->p[ci] + (size_t)(y0 >> sh) * pw + (x0 >> sh);
+      const uint16_t* rp = e->ref[0]->p[ci] + (size_t)(y0 >> sh) * pw + (x0 >> sh);
+      for (int y = 0; y < S; y++) for (int x = 0; x < S; x++) res[y * S + x] = (int16_t)((int)sp[(size_t)y * pw + x] - (int)rp[(size_t)y * pw + x]);
+      hevc_fwd_transform(res, coef, l2, 0, bd);
+      int qp = ci ? chroma_qp_of(e, ci) : e->qp_y + 6 * (bd - 8);
+      nz |= hevc_quant(coef, lq, l2, qp, bd, 0) != 0;
+    }
+    e->an_cost[1][by * nb16 + bx] = nz;
+  }
+  e->qp_y = qp_save;
+  for (int si = 2; si <= 3; si++) {
+    int S = 8 << si; if (S > ctb) break;
+    int nb = ctb / S, nbc = nb * 2;
+    for (int by = 0; by < nb; by++) for (int bx = 0; bx < nb; bx++) {
+      int any = e->an_cost[si - 1][(2 * by) * nbc + 2 * bx] | e->an_cost[si - 1][(2 * by) * nbc + 2 * bx + 1] |
+                e->an_cost[si - 1][(2 * by + 1) * nbc + 2 * bx] | e->an_cost[si - 1][(2 * by + 1) * nbc + 2 * bx + 1];
+      e->an_cost[si][by * nb + bx] = any; e->an_split[si][by * nb + bx] = (uint8_t)(any != 0);
+    }
+  }
+}
+
+/* ================================================================================================ SAO syntax (stress only) */
+static void write_sao(enc* e, int rx, int ry) {
+  hevc_meta* m = e->m; cabac_enc* c = &e->c; rng* r = &e->r;
+  hevc_sao* p = &m->sao[ry * m->w_ctb + rx];
+  memset(p, 0, sizeof(*p));
+  if (!e->sh.sao_luma && !e->sh.sao_chroma) return;
+  int can_left = rx > 0 && m->ctb_slice[ry * m->w_ctb + rx - 1] == e->slice_idx;
+  int can_up = ry > 0 && m->ctb_slice[(ry - 1) * m->w_ctb + rx] == e->slice_idx;
+  int merge_left = can_left && rndp(r, 25), merge_up = 0;
+  if (can_left) ce_bin(c, CTX_SAO_MERGE, merge_left);
+  if (can_up && !merge_left) { merge_up = rndp(r, 25); ce_bin(c, CTX_SAO_MERGE, merge_up); }
+  if (merge_left) { *p = m->sao[ry * m->w_ctb + rx - 1]; return; }
+  if (merge_up) { *p = m->sao[(ry - 1) * m->w_ctb + rx]; return; }
+  int bd = e->sps.bit_depth, cmax = (1 << (imin(bd, 10) - 5)) - 1;
+  for (int ci = 0; ci < 3; ci++) {
+    if ((ci == 0 && !e->sh.sao_luma) || (ci > 0 && !e->sh.sao_chroma)) continue;
+    if (ci == 2) p->type[2] = p->type[1];
+    else {
+      int t = rndn(r, 3); p->type[ci] = (uint8_t)t;
+      ce_bin(c, CTX_SAO_TYPE, t != 0); if (t) ce_bypass(c, t == 2);
+    }
+    if (!p->type[ci]) continue;
+    int absv[4];
+    for (int i = 0; i < 4; i++) { absv[i] = rndn(r, imin(cmax, 7) + 1); for (int k = 0; k < absv[i]; k++) ce_bypass(c, 1); if (absv[i] < cmax) ce_bypass(c, 0); }
+    if (p->type[ci] == 1) {
+      for (int i = 0; i < 4; i++) if (absv[i]) { int neg = rndp(r, 50); ce_bypass(c, neg); if (neg) absv[i] = -absv[i]; }
+      p->band_pos[ci] = (uint8_t)rndn(r, 32); ce_bypass_n(c, p->band_pos[ci], 5);
+    } else {
+      absv[2] = -absv[2]; absv[3] = -absv[3];
+      if (ci == 0) { p->eo_class[0] = (uint8_t)rndn(r, 4); ce_bypass_n(c, p->eo_class[0], 2); }
+      else if (ci == 1) { p->eo_class[1] = (uint8_t)rndn(r, 4); ce_bypass_n(c, p->eo_class[1], 2); }
+      else p->eo_class[2] = p->eo_class[1];
+    }
+    for (int i = 0; i < 4; i++) p->offset[ci][i] = (int8_t)(absv[i] * (1 << (bd - imin(bd, 10))));
+  }
+}
+
+/* ================================================================================================ pictures */
+static void setup_stream(enc* e) {
+  hevc_sps* s = &e->sps; hevc_pps* p = &e->pps; const oracle_enc_params* q = &e->p;
+  memset(s, 0, sizeof(*s)); memset(p, 0, sizeof(*p));
+  s->width = q->width; s->height = q->height; s->bit_depth = s->bit_depth_c = q->bit_depth; s->chroma_format_idc = 1;
+  s->log2_max_poc_lsb = 8; s->max_dec_pic_buffering = 3;
+  s->log2_ctb = q->log2_ctb ? q->log2_ctb : 5;
+  s->log2_min_cb = 3; s->log2_diff_max_min_cb = s->log2_ctb - 3;
+  s->log2_min_tb = 2; s->log2_max_tb = imin(5, s->log2_ctb); s->log2_diff_max_min_tb = s->log2_max_tb - 2;
+  s->num_st_rps = 1; p->num_ref_idx_default[0] = p->num_ref_idx_default[1] = 1;
+  p->init_qp = clip3(0, 51, q->qp); p->loop_filter_across_slices = 1;
+  e->max_merge_cand = 1;
+  if (q->lossless) { p->transquant_bypass_enabled = 1; p->deblocking_control_present = 1; p->pps_deblocking_disabled = 1; p->loop_filter_across_slices = 0; }
+  if (e->stress) {
+    rng* r = &e->r;
+    s->log2_ctb = q->log2_ctb ? q->log2_ctb : 4 + rndn(r, 3);
+    s->log2_min_cb = 3 + (s->log2_ctb > 3 ? rndn(r, imin(2, s->log2_ctb - 3 + 1)) : 0); if (s->log2_min_cb > s->log2_ctb) s->log2_min_cb = s->log2_ctb;
+    while ((s->width & ((1 << s->log2_min_cb) - 1)) || (s->height & ((1 << s->log2_min_cb) - 1))) s->log2_min_cb--;
+    s->log2_diff_max_min_cb = s->log2_ctb - s->log2_min_cb;
+    s->log2_min_tb = 2 + (rndp(r, 25) ? 1 : 0); if (s->log2_min_tb >= s->log2_min_cb) s->log2_min_tb = s->log2_min_cb - 1;
+    s->log2_max_tb = imin(5, s->log2_ctb) - (rndp(r, 25) ? 1 : 0); if (s->log2_max_tb < s->log2_min_tb) s->log2_max_tb = s->log2_min_tb;
+    if (s->log2_max_tb < imin(s->log2_ctb, 5) && s->log2_ctb - s->log2_max_tb > 1) s->log2_max_tb = s->log2_ctb - 1;   /* CtbLog2 - MaxTbLog2 <= 1 is not required, but keep trees shallow */
+    s->log2_diff_max_min_tb = s->log2_max_tb - s->log2_min_tb;
+    s->max_th_depth_inter = rndn(r, 3); s->max_th_depth_intra = rndn(r, 3);
+    s->amp_enabled = rndp(r, 60); s->sao_enabled = rndp(r, 60); s->strong_intra_smoothing = rndp(r, 60); s->temporal_mvp_enabled = rndp(r, 60);
+    e->two_refs = rndp(r, 50); s->num_st_rps = 2; s->max_dec_pic_buffering = 4;
+    p->sign_data_hiding = rndp(r, 50); p->cabac_init_present = rndp(r, 40);
+    p->constrained_intra_pred = rndp(r, 20); p->transform_skip_enabled = rndp(r, 50);
+    p->cu_qp_delta_enabled = rndp(r, 40); p->diff_cu_qp_delta_depth = p->cu_qp_delta_enabled ? rndn(r, s->log2_diff_max_min_cb + 1) : 0;
+    p->cb_qp_offset = rndn(r, 7) - 3; p->cr_qp_offset = rndn(r, 7) - 3; p->slice_chroma_qp_offsets_present = rndp(r, 30);
+    p->transquant_bypass_enabled = rndp(r, 30); p->loop_filter_across_slices = rndp(r, 70);
+    p->deblocking_control_present = rndp(r, 50);
+    if (p->deblocking_control_present) { p->deblocking_override_enabled = rndp(r, 60); p->pps_deblocking_disabled = rndp(r, 15); if (!p->pps_deblocking_disabled) { p->beta_offset_div2 = rndn(r, 7) - 3; p->tc_offset_div2 = rndn(r, 7) - 3; } }
+    p->init_qp = 20 + rndn(r, 15);
+    e->max_merge_cand = 1 + rndn(r, 5);
+    p->num_ref_idx_default[0] = 1 + (e->two_refs && rndp(r, 50));
+  }
+  s->pic_w_ctb = (s->width + (1 << s->log2_ctb) - 1) >> s->log2_ctb; s->pic_h_ctb = (s->height + (1 << s->log2_ctb) - 1) >> s->log2_ctb;
+}
+
+static void encode_picture(enc* e, const hevc_frame* src, int idx, bytebuf* out, hevc_frame** recon_out) {
+  hevc_sps* s = &e->sps; hevc_pps* p = &e->pps; hevc_meta* m = e->m; rng* r = &e->r;
+  int is_i;
+  if (e->stress) is_i = idx == 0 || (idx % 5 == 0 && (e->p.stress_seed & 1));
+  else is_i = e->p.gop <= 1 || (idx % e->p.gop) == 0;
+  e->is_idr = is_i; e->slice_type = is_i ? SLICE_I : SLICE_P;
+  if (is_i) { e->poc = 0; e->n_dpb = 0; write_param_sets(e, out); } else e->poc++;
+  e->src = src; e->rec = hevc_frame_alloc(s->width, s->height, s->bit_depth);
+  hevc_meta_reset(m);
+  m->constrained_intra_pred = p->constrained_intra_pred; m->cb_qp_offset = p->cb_qp_offset; m->cr_qp_offset = p->cr_qp_offset; m->strong_intra_smoothing = s->strong_intra_smoothing;
+  /* reference list */
+  e->n_ref = 0;
+  int st_rps_idx = 0;
+  if (!is_i) {
+    int nref_avail = imin(e->n_dpb, e->two_refs ? 2 : 1);
+    st_rps_idx = nref_avail - 1;
+    for (int i = 0; i < nref_avail; i++) { e->ref[i] = e->dpb[i]; e->refcol[i] = &e->dpbcol[i]; e->ref_poc[i] = e->dpb_poc[i]; }
+    e->n_ref = nref_avail;
+  }
+  int n_ctb = s->pic_w_ctb * s->pic_h_ctb, ctb = 1 << s->log2_ctb;
+  int addr = 0;
+  /* picture-level choices that must agree across the slices of a picture */
+  int pic_num_ref = p->num_ref_idx_default[0], pic_tmvp = 0, pic_col = 0;
+  if (e->stress && !is_i) {
+    pic_num_ref = 1 + rndn(r, imin(2, e->n_ref));
+    pic_tmvp = s->temporal_mvp_enabled ? rndp(r, 70) : 0;
+    pic_col = (pic_tmvp && pic_num_ref > 1) ? rndn(r, pic_num_ref) : 0;
+  }
+  while (addr < n_ctb) {
+    /* slice extent */
+    int end_addr;
+    if (e->stress) end_addr = rndp(r, 50) ? n_ctb : imin(n_ctb, addr + 1 + rndn(r, n_ctb));
+    else if (e->p.ctb_rows_per_slice > 0) end_addr = imin(n_ctb, (addr / s->pic_w_ctb + e->p.ctb_rows_per_slice) * s->pic_w_ctb);
+    else end_addr = n_ctb;
+    hevc_slice_hdr* h = &e->sh; memset(h, 0, sizeof(*h));
+    h->slice_type = e->slice_type; h->st_rps_idx = st_rps_idx;
+    h->num_ref_idx[0] = p->num_ref_idx_default[0]; h->max_merge_cand = e->max_merge_cand;
+    h->deblocking_disabled = p->pps_deblocking_disabled; h->beta_offset_div2 = p->beta_offset_div2; h->tc_offset_div2 = p->tc_offset_div2;
+    h->loop_filter_across_slices = p->loop_filter_across_slices;
+    if (e->stress) {
+      h->qp = clip3(4, 48, p->init_qp + rndn(r, 21) - 10);
+      if (!is_i) { h->num_ref_idx[0] = pic_num_ref; h->temporal_mvp = pic_tmvp; h->collocated_ref_idx = pic_col; }
+      if (s->sao_enabled) { h->sao_luma = rndp(r, 70); h->sao_chroma = rndp(r, 70); }
+      if (p->cabac_init_present && !is_i) h->cabac_init_flag = rndp(r, 50);
+      if (p->slice_chroma_qp_offsets_present) { h->cb_qp_offset = rndn(r, 5) - 2; h->cr_qp_offset = rndn(r, 5) - 2; }
+      if (p->deblocking_override_enabled && rndp(r, 50)) { h->deblocking_disabled = rndp(r, 20); if (!h->deblocking_disabled) { h->beta_offset_div2 = rndn(r, 9) - 4; h->tc_offset_div2 = rndn(r, 9) - 4; } else { h->beta_offset_div2 = p->beta_offset_div2; h->tc_offset_div2 = p->tc_offset_div2; } }
+      if (p->loop_filter_across_slices && (h->sao_luma || h->sao_chroma || !h->deblocking_disabled)) h->loop_filter_across_slices = rndp(r, 70);
+    } else h->qp = clip3(0, 51, is_i ? e->p.qp + e->p.i_qp_offset : e->p.qp);
+    e->slice_qp = h->qp; e->slice_idx = m->n_slices++;
+    hevc_slice_meta* sm = &m->slices[e->slice_idx]; memset(sm, 0, sizeof(*sm));
+    sm->deblocking_disabled = (uint8_t)h->deblocking_disabled; sm->loop_filter_across = (uint8_t)h->loop_filter_across_slices;
+    sm->sao_luma = (uint8_t)h->sao_luma; sm->sao_chroma = (uint8_t)h->sao_chroma; sm->beta_offset_div2 = (int8_t)h->beta_offset_div2; sm->tc_offset_div2 = (int8_t)h->tc_offset_div2;
+    sm->slice_type = (int8_t)h->slice_type;
+    for (int i = 0; i < h->num_ref_idx[0]; i++) sm->ref_poc[i] = e->ref_poc[i];
+    e->mp.m = m; e->mp.max_merge_cand = h->max_merge_cand; e->mp.num_ref_idx = h->num_ref_idx[0]; e->mp.ref_poc = e->ref_poc; e->mp.cur_poc = e->poc;
+    e->mp.col = (h->temporal_mvp && !is_i) ? e->refcol[h->collocated_ref_idx] : NULL; e->mp.log2_ctb = s->log2_ctb; e->mp.pic_w = s->width; e->mp.pic_h = s->height;
+    e->c.w.bb.n = 0; e->c.w.acc = 0; e->c.w.nacc = 0;
+    write_slice_header(e, &e->c.w, addr == 0, addr);
+    ce_init_ctx(&e->c, is_i ? 0 : (h->cabac_init_flag ? 2 : 1), h->qp);
+    ce_start(&e->c);
+    e->qp_y = h->qp; e->qp_pred = h->qp; e->is_cu_qp_delta_coded = 0; e->cu_qp_delta_val = 0;
+    for (int a = addr; a < end_addr; a++) {
+      int rx = a % s->pic_w_ctb, ry = a / s->pic_w_ctb;
+      m->ctb_slice[a] = (uint16_t)e->slice_idx;
+      if (e->stress) write_sao(e, rx, ry);
+      else { if (is_i) analyse_ctb_intra(e, rx * ctb, ry * ctb); else analyse_ctb_inter(e, rx * ctb, ry * ctb); }
+      encode_quadtree(e, rx * ctb, ry * ctb, s->log2_ctb, 0, rx * ctb, ry * ctb);
+      ce_terminate(&e->c, a == end_addr - 1);
+    }
+    bw_align_zero(&e->c.w);
+    emit_nal(out, is_i ? NAL_IDR_W_RADL : NAL_TRAIL_R, e->c.w.bb.d, e->c.w.bb.n, addr == 0);
+    addr = end_addr;
+  }
+  /* collocated motion of this picture, loop filters, hash */
+  hevc_colinfo ci; ci.poc = e->poc; ci.w4 = m->w4; ci.h4 = m->h4;
+  size_t n4 = (size_t)m->w4 * m->h4;
+  ci.mv = (int16_t*)malloc(n4 * 4); ci.refpoc = (int32_t*)malloc(n4 * 4); memcpy(ci.mv, m->mv, n4 * 4);
+  for (int y = 0; y < m->h4; y++) for (int x = 0; x < m->w4; x++) {
+    size_t i = (size_t)y * m->w4 + x;
+    ci.refpoc[i] = (m->pred_mode[i] == MODE_INTRA || m->pred_mode[i] == META_UNDECODED) ? (int32_t)0x80000000 : m->slices[meta_slice_at(m, x * 4, y * 4)].ref_poc[m->ref_idx[i]];
+  }
+  hevc_deblock(e->rec, m);
+  int any_sao = 0; for (int i = 0; i < m->n_slices; i++) any_sao |= m->slices[i].sao_luma | m->slices[i].sao_chroma;
+  if (any_sao) { hevc_frame* t = hevc_frame_alloc(s->width, s->height, s->bit_depth); hevc_sao_apply(t, e->rec, m); hevc_frame_copy(e->rec, t); hevc_frame_free(t); }
+  if (e->p.md5_sei) {
+    uint8_t sei[2 + 49 + 1]; sei[0] = 132; sei[1] = 49; sei[2] = 0;
+    for (int c = 0; c < 3; c++) oracle_md5_plane(e->rec->p[c], c ? e->rec->cw : e->rec->w, c ? e->rec->ch : e->rec->h, s->bit_depth, sei + 3 + 16 * c);
+    sei[51] = 0x80;
+    emit_nal(out, NAL_SEI_SUFFIX, sei, 52, 0);
+  }
+  /* DPB: newest first */
+  if (e->n_dpb == 2) { if (e->dpb[1] != NULL && !recon_out) hevc_frame_free(e->dpb[1]); free(e->dpbcol[1].mv); free(e->dpbcol[1].refpoc); e->n_dpb = 1; }
+  if (e->n_dpb == 1) { e->dpb[1] = e->dpb[0]; e->dpbcol[1] = e->dpbcol[0]; e->dpb_poc[1] = e->dpb_poc[0]; }
+  e->dpb[0] = e->rec; e->dpbcol[0] = ci; e->dpb_poc[0] = e->poc; e->n_dpb = imin(2, e->n_dpb + 1);
+  if (recon_out) recon_out[idx] = e->rec;
+}
+
+int oracle_hevc_encode(const oracle_enc_params* p, const hevc_frame* const* frames, int n, bytebuf* out, hevc_frame** recon) {
+  if (p->width % 8 || p->height % 8 || p->width > HEVC_MAX_W || p->height > HEVC_MAX_H) { ENC_ERR("picture size must be a multiple of 8"); return -1; }
+  if (!p->stress_seed && p->gop > 1 && (p->width % 16 || p->height % 16)) { ENC_ERR("gop=2 needs a picture size that is a multiple of 16"); return -1; }
+  enc* e = (enc*)calloc(1, sizeof(enc));
+  e->p = *p; e->stress = p->stress_seed != 0; e->r.s = p->stress_seed ? p->stress_seed : 1;
+  build_scans(e); setup_stream(e);
+  e->m = hevc_meta_alloc(p->width, p->height, e->sps.log2_ctb);
+  /* frames freed here unless handed to the caller: keep a list */
+  hevc_frame** owned = (hevc_frame**)calloc((size_t)n, sizeof(void*));
+  for (int i = 0; i < n; i++) { encode_picture(e, frames[i], i, out, owned); }
+  if (recon) memcpy(recon, owned, sizeof(void*) * (size_t)n); else for (int i = 0; i < n; i++) hevc_frame_free(owned[i]);
+  for (int i = 0; i < e->n_dpb; i++) { free(e->dpbcol[i].mv); free(e->dpbcol[i].refpoc); }
+  free(owned); free(e->c.w.bb.d); hevc_meta_free(e->m); free(e);
+  return 0;
+}

@@ -1,0 +1,23 @@
+/* ORACLE — test infrastructure only. Encoder API of the CPU restatement (see hevc_enc.c). */
+#ifndef ORACLE_HEVC_ENC_H
+#define ORACLE_HEVC_ENC_H
+#include "hevc_common.h"
+#include "hevc_recon.h"
+
+typedef struct {
+  int width, height, bit_depth;
+  int qp;                   /* CQP as x265 `qp=`: P slices use qp, I slices qp + i_qp_offset (x265 ipratio 1.4 -> -3) */
+  int i_qp_offset;
+  int gop;                  /* 1: all intra (occupancy, PCCTranscoder.cpp:835);  2: I,P pairs (PCCTranscoder.cpp:849) */
+  int lossless;             /* x265 lossless=1 (PCCTranscoder.cpp:841): cu_transquant_bypass for every CU */
+  int log2_ctb;             /* 4..6 */
+  int ctb_rows_per_slice;   /* 0 = one slice per picture */
+  int md5_sei;              /* emit decoded-picture-hash SEI */
+  uint32_t stress_seed;     /* 0 = product decisions; != 0 = random-syntax generator for decoder test streams */
+} oracle_enc_params;
+
+/* Encodes n frames; appends an Annex-B stream to out. If recon != NULL it receives n newly allocated reconstructed
+ * pictures (post loop filter). Returns 0 on success. */
+int oracle_hevc_encode(const oracle_enc_params* p, const hevc_frame* const* frames, int n, bytebuf* out, hevc_frame** recon);
+
+#endif

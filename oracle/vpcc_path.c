@@ -1,0 +1,169 @@
+/* ORACLE — test infrastructure only (see oracle/README.md). Never linked into the product library.
+ *
+ * CPU restatement of the reference's own code on the hot path:
+ *   PCCVideoBitstream::sampleStreamToByteStream  source/lib/PccLibBitstreamCommon/source/PCCVideoBitstream.cpp:114-172
+ *   PCCVideoBitstream::byteStreamToSampleStream  :85-112, getEndOfNaluPosition :174-184
+ *   PCCTranscoder::resize_frame2                 source/lib/PccLibTranscoder/source/PCCTranscoder.cpp:594-646
+ *   PCCTranscoder::transcodeVideo                :374-546 (decode loop :428-448, pool :466, encoder options :825-904)
+ * The first three are pinned against the compiled reference (oracle/_ref, tests/golden/stream_conv_*.bin).
+ */
+#include "vpcc_path.h"
+#include "hevc_dec.h"
+#include "hevc_enc.h"
+
+void oracle_free(void* p) { free(p); }
+
+/* PCCVideoBitstream.cpp:174-184 */
+static size_t end_of_nalu(const uint8_t* d, size_t size, size_t start) {
+  if (size < start + 4) return size;
+  for (size_t i = start; i < size - 4; i++)
+    if (d[i] == 0 && d[i + 1] == 0 && (d[i + 2] == 1 || (d[i + 2] == 0 && d[i + 3] == 1))) return i;
+  return size;
+}
+/* PCCVideoBitstream.cpp:85-112 (precision 4, emulationPreventionBytes = false) */
+int oracle_byte_to_sample_stream(const uint8_t* in, size_t n, uint8_t** out, size_t* n_out) {
+  bytebuf b = {0, 0, 0};
+  size_t start = 0, end = 0;
+  if (n < 4) { *out = NULL; *n_out = 0; return -1; }
+  do {
+    size_t sc = in[start + 2] == 0 ? 4 : 3;
+    end = end_of_nalu(in, n, start + sc);
+    size_t hdr = b.n;
+    for (int i = 0; i < 4; i++) bb_put(&b, 0);
+    for (size_t i = start + sc; i < end; i++) bb_put(&b, in[i]);
+    size_t sz = b.n - (hdr + 4);
+    for (int i = 0; i < 4; i++) b.d[hdr + i] = (uint8_t)(sz >> (8 * (4 - (i + 1))));
+    start = end;
+  } while (end < n);
+  *out = b.d; *n_out = b.n; return 0;
+}
+/* PCCVideoBitstream.cpp:114-172 (isAvc = isVvc = false, precision 4, no emulation prevention) */
+int oracle_sample_to_byte_stream(const uint8_t* in, size_t n, uint8_t** out, size_t* n_out) {
+  bytebuf b = {0, 0, 0};
+  size_t sc = 4, start = 0, end = 0;
+  int new_frame = 1;
+  if (n < 4) { *out = NULL; *n_out = 0; return -1; }
+  do {
+    int32_t sz = 0;
+    for (int i = 0; i < 4; i++) sz = (sz << 8) + in[start + i];
+    end = start + 4 + (size_t)sz;
+    if (end > n) { free(b.d); *out = NULL; *n_out = 0; return -1; }
+    for (size_t i = 0; i < sc - 1; i++) bb_put(&b, 0);
+    bb_put(&b, 1);
+    for (size_t i = start + 4; i < end; i++) bb_put(&b, in[i]);
+    start = end;
+    if (start + 4 < n) {
+      int use_long;
+      new_frame = 0;
+      int type = (in[start + 4] & 126) >> 1;
+      use_long = new_frame || (type >= 32 && type < 41);
+      if (type < 12) new_frame = 1;
+      sc = use_long ? 4 : 3;
+    }
+  } while (end < n);
+  (void)new_frame;
+  *out = b.d; *n_out = b.n; return 0;
+}
+
+/* PCCTranscoder.cpp:615-637 */
+void oracle_or_pool(const uint16_t* in, int w, int h, int factor, uint16_t* out) {
+  int ow = w / factor, oh = h / factor;
+  for (int v = 0; v < oh; v++)
+    for (int u = 0; u < ow; u++) {
+      int any = 0;
+      for (int v1 = 0; v1 < factor; v1++) for (int u1 = 0; u1 < factor; u1++) if (in[(size_t)(v * factor + v1) * w + u * factor + u1] > 0) any = 1;
+      out[(size_t)v * ow + u] = (uint16_t)(any ? 1 : 0);
+    }
+}
+
+int oracle_decode(const uint8_t* annexb, size_t n, oracle_video* out) {
+  memset(out, 0, sizeof(*out));
+  oracle_hevc_decoder* d = oracle_hevc_dec_create();
+  int rc = oracle_hevc_dec_decode(d, annexb, n);
+  int nf = oracle_hevc_dec_num_frames(d);
+  if (rc == 0 && nf > 0) {
+    const hevc_frame* f0 = oracle_hevc_dec_frame(d, 0);
+    out->w = f0->w; out->h = f0->h; out->bit_depth = f0->bit_depth; out->n_frames = nf;
+    size_t fs = (size_t)f0->w * f0->h * 3 / 2;
+    out->data = (uint16_t*)malloc(fs * 2 * (size_t)nf);
+    for (int i = 0; i < nf; i++) {
+      const hevc_frame* f = oracle_hevc_dec_frame(d, i);
+      if (f->w != f0->w || f->h != f0->h) { rc = -2; break; }
+      uint16_t* o = out->data + fs * (size_t)i;
+      memcpy(o, f->p[0], (size_t)f->w * f->h * 2); memcpy(o + (size_t)f->w * f->h, f->p[1], (size_t)f->cw * f->ch * 2);
+      memcpy(o + (size_t)f->w * f->h + (size_t)f->cw * f->ch, f->p[2], (size_t)f->cw * f->ch * 2);
+    }
+  }
+  out->md5_checked = oracle_hevc_dec_md5_checked(d); out->md5_failed = oracle_hevc_dec_md5_failed(d);
+  oracle_hevc_dec_destroy(d);
+  return rc;
+}
+
+static hevc_frame* frame_from_yuv(const uint16_t* yuv, int w, int h, int bd) {
+  hevc_frame* f = hevc_frame_alloc(w, h, bd);
+  memcpy(f->p[0], yuv, (size_t)w * h * 2); memcpy(f->p[1], yuv + (size_t)w * h, (size_t)f->cw * f->ch * 2);
+  memcpy(f->p[2], yuv + (size_t)w * h + (size_t)f->cw * f->ch, (size_t)f->cw * f->ch * 2);
+  return f;
+}
+int oracle_encode(int w, int h, int bit_depth, int qp, int i_qp_offset, int gop, int lossless, int log2_ctb, int rows_per_slice,
+                  int md5_sei, uint32_t stress_seed, const uint16_t* yuv, int n_frames, uint8_t** out, size_t* n_out, uint16_t* recon) {
+  oracle_enc_params p; memset(&p, 0, sizeof(p));
+  p.width = w; p.height = h; p.bit_depth = bit_depth; p.qp = qp; p.i_qp_offset = i_qp_offset; p.gop = gop; p.lossless = lossless;
+  p.log2_ctb = log2_ctb; p.ctb_rows_per_slice = rows_per_slice; p.md5_sei = md5_sei; p.stress_seed = stress_seed;
+  size_t fs = (size_t)w * h * 3 / 2;
+  hevc_frame** fr = (hevc_frame**)calloc((size_t)n_frames, sizeof(void*));
+  hevc_frame** rc_fr = (hevc_frame**)calloc((size_t)n_frames, sizeof(void*));
+  for (int i = 0; i < n_frames; i++) fr[i] = frame_from_yuv(yuv + fs * (size_t)i, w, h, bit_depth);
+  bytebuf bb = {0, 0, 0};
+  int rc = oracle_hevc_encode(&p, (const hevc_frame* const*)fr, n_frames, &bb, rc_fr);
+  for (int i = 0; i < n_frames; i++) {
+    if (rc == 0 && recon) {
+      uint16_t* o = recon + fs * (size_t)i; hevc_frame* f = rc_fr[i];
+      memcpy(o, f->p[0], (size_t)w * h * 2); memcpy(o + (size_t)w * h, f->p[1], (size_t)f->cw * f->ch * 2);
+      memcpy(o + (size_t)w * h + (size_t)f->cw * f->ch, f->p[2], (size_t)f->cw * f->ch * 2);
+    }
+    hevc_frame_free(fr[i]); hevc_frame_free(rc_fr[i]);
+  }
+  free(fr); free(rc_fr);
+  *out = bb.d; *n_out = bb.n;
+  return rc;
+}
+
+int oracle_transcode_substream(const uint8_t* annexb, size_t n, const oracle_transcode_params* p, uint8_t** out, size_t* n_out) {
+  *out = NULL; *n_out = 0;
+  oracle_hevc_decoder* d = oracle_hevc_dec_create();
+  if (oracle_hevc_dec_decode(d, annexb, n) || oracle_hevc_dec_md5_failed(d)) { oracle_hevc_dec_destroy(d); return -1; }
+  int nf = oracle_hevc_dec_num_frames(d);
+  if (nf <= 0) { oracle_hevc_dec_destroy(d); return -1; }
+  const hevc_frame* f0 = oracle_hevc_dec_frame(d, 0);
+  oracle_enc_params ep; memset(&ep, 0, sizeof(ep));
+  ep.bit_depth = f0->bit_depth; ep.qp = p->qp; ep.log2_ctb = p->log2_ctb; ep.ctb_rows_per_slice = p->ctb_rows_per_slice; ep.md5_sei = p->md5_sei;
+  hevc_frame** src = (hevc_frame**)calloc((size_t)nf, sizeof(void*));
+  int own = 0;
+  if (p->video_type == 0) {
+    /* occupancy: lossless all-intra (PCCTranscoder.cpp:835-843); OR-pool when precision == 4 (:466, :830-831) */
+    int factor = p->occupancy_precision / 2; if (factor < 1) factor = 1;
+    ep.gop = 1; ep.lossless = 1; ep.width = f0->w / factor; ep.height = f0->h / factor;
+    if (p->occupancy_precision == 4) {
+      own = 1;
+      for (int i = 0; i < nf; i++) {
+        const hevc_frame* f = oracle_hevc_dec_frame(d, i);
+        src[i] = hevc_frame_alloc(ep.width, ep.height, f->bit_depth);
+        oracle_or_pool(f->p[0], f->w, f->h, 2, src[i]->p[0]);
+        /* the reference leaves the pooled chroma planes unwritten (:638-641); this restatement defines them as mid-grey */
+        for (int c = 1; c < 3; c++) for (size_t k = 0; k < (size_t)src[i]->cw * src[i]->ch; k++) src[i]->p[c][k] = (uint16_t)(1 << (f->bit_depth - 1));
+      }
+    } else for (int i = 0; i < nf; i++) src[i] = (hevc_frame*)oracle_hevc_dec_frame(d, i);
+  } else {
+    /* geometry / attribute: gop 2, no B frames, CQP (PCCTranscoder.cpp:847-851, :883-895) */
+    ep.gop = 2; ep.i_qp_offset = -3; ep.width = f0->w; ep.height = f0->h;
+    for (int i = 0; i < nf; i++) src[i] = (hevc_frame*)oracle_hevc_dec_frame(d, i);
+  }
+  bytebuf bb = {0, 0, 0};
+  int rc = oracle_hevc_encode(&ep, (const hevc_frame* const*)src, nf, &bb, NULL);
+  if (own) for (int i = 0; i < nf; i++) hevc_frame_free(src[i]);
+  free(src); oracle_hevc_dec_destroy(d);
+  if (rc) { free(bb.d); return rc; }
+  *out = bb.d; *n_out = bb.n;
+  return 0;
+}

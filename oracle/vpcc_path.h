@@ -1,0 +1,38 @@
+/* ORACLE — test infrastructure only (see oracle/README.md). Never linked into the product library.
+ * Flat C entry points (ctypes-friendly) of the CPU restatement of the transcode hot path. */
+#ifndef ORACLE_VPCC_PATH_H
+#define ORACLE_VPCC_PATH_H
+#include <stddef.h>
+#include <stdint.h>
+
+typedef struct {
+  int w, h, bit_depth, n_frames;
+  uint16_t* data;             /* n_frames x planar 4:2:0 (Y w*h, Cb, Cr), malloc'd */
+  int md5_checked, md5_failed;
+} oracle_video;
+
+typedef struct {
+  int video_type;             /* PCCVideoType: 0 occupancy, 1 geometry, 19 attribute (PCCBitstreamCommon.h:79-118) */
+  int qp;                     /* geometryQP_ / attributeQP_ / occupancyMapQP_ (PCCTranscoderParameters.h:58-80) */
+  int occupancy_precision;    /* occupancyPrecision_: 4 -> 2x2 OR-pool (PCCTranscoder.cpp:466), else untouched */
+  int log2_ctb;               /* implementation parameter of the RBT-E1 encoder (0 = default 5) */
+  int ctb_rows_per_slice;     /* implementation parameter (0 = one slice per picture) */
+  int md5_sei;
+} oracle_transcode_params;
+
+/* PCCVideoBitstream::sampleStreamToByteStream / byteStreamToSampleStream (PCCVideoBitstream.cpp:85-172), HEVC case,
+ * precision 4, no emulation-prevention handling (the defaults the transcoder uses, PCCTranscoder.cpp:152,517) */
+int oracle_sample_to_byte_stream(const uint8_t* in, size_t n, uint8_t** out, size_t* n_out);
+int oracle_byte_to_sample_stream(const uint8_t* in, size_t n, uint8_t** out, size_t* n_out);
+
+/* resize_frame2 (PCCTranscoder.cpp:594-646) == resizeOccupancyMap (:341-372): out = any(in block > 0) ? 1 : 0 */
+void oracle_or_pool(const uint16_t* in, int w, int h, int factor, uint16_t* out);
+
+int oracle_decode(const uint8_t* annexb, size_t n, oracle_video* out);
+/* encode: yuv = n_frames x planar 4:2:0 uint16; params as oracle_enc_params fields */
+int oracle_encode(int w, int h, int bit_depth, int qp, int i_qp_offset, int gop, int lossless, int log2_ctb, int rows_per_slice,
+                  int md5_sei, uint32_t stress_seed, const uint16_t* yuv, int n_frames, uint8_t** out, size_t* n_out, uint16_t* recon);
+/* PCCTranscoder::transcodeVideo (PCCTranscoder.cpp:374-546) on an Annex-B sub-bitstream */
+int oracle_transcode_substream(const uint8_t* annexb, size_t n, const oracle_transcode_params* p, uint8_t** out, size_t* n_out);
+void oracle_free(void* p);
+#endif

@@ -1,0 +1,116 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE ONLY (the CPU checker).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB = None
+
+
+class OracleVideo(C.Structure):
+    _fields_ = [("w", C.c_int), ("h", C.c_int), ("bit_depth", C.c_int), ("n_frames", C.c_int),
+                ("data", C.POINTER(C.c_uint16)), ("md5_checked", C.c_int), ("md5_failed", C.c_int)]
+
+
+class TranscodeParams(C.Structure):
+    _fields_ = [("video_type", C.c_int), ("qp", C.c_int), ("occupancy_precision", C.c_int), ("log2_ctb", C.c_int),
+                ("ctb_rows_per_slice", C.c_int), ("md5_sei", C.c_int)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.oracle_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(OracleVideo)]
+        L.oracle_encode.argtypes = [C.c_int] * 10 + [C.c_uint32, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
+        L.oracle_transcode_substream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(TranscodeParams), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.oracle_sample_to_byte_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.oracle_byte_to_sample_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.oracle_or_pool.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_md5.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+        L.oracle_free.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _take(ptr, n):
+    out = C.string_at(ptr, n.value) if ptr.value else b""
+    lib().oracle_free(ptr)
+    return out
+
+
+def decode(stream: bytes):
+    """-> (frames uint16 [n, w*h*3/2], w, h, bit_depth, md5_checked, md5_failed)"""
+    v = OracleVideo()
+    rc = lib().oracle_decode(stream, len(stream), C.byref(v))
+    if rc != 0:
+        raise RuntimeError(f"oracle decode failed rc={rc}")
+    fs = v.w * v.h * 3 // 2
+    arr = np.ctypeslib.as_array(v.data, shape=(v.n_frames, fs)).copy()
+    lib().oracle_free(v.data)
+    return arr, v.w, v.h, v.bit_depth, v.md5_checked, v.md5_failed
+
+
+def encode(frames: np.ndarray, w, h, bit_depth, qp, gop=2, i_qp_offset=-3, lossless=0, log2_ctb=5, rows_per_slice=1,
+           md5_sei=1, stress_seed=0, want_recon=True):
+    frames = np.ascontiguousarray(frames, dtype=np.uint16)
+    n = frames.shape[0]
+    assert frames.shape[1] == w * h * 3 // 2
+    out = C.c_void_p()
+    n_out = C.c_size_t()
+    recon = np.zeros_like(frames) if want_recon else None
+    rc = lib().oracle_encode(w, h, bit_depth, qp, i_qp_offset, gop, lossless, log2_ctb, rows_per_slice, md5_sei, stress_seed,
+                             frames.ctypes.data, n, C.byref(out), C.byref(n_out), recon.ctypes.data if want_recon else None)
+    if rc != 0:
+        raise RuntimeError(f"oracle encode failed rc={rc}")
+    return _take(out, n_out), recon
+
+
+def transcode_substream(stream: bytes, video_type, qp, occupancy_precision=4, log2_ctb=5, rows_per_slice=1, md5_sei=1):
+    p = TranscodeParams(video_type, qp, occupancy_precision, log2_ctb, rows_per_slice, md5_sei)
+    out = C.c_void_p()
+    n_out = C.c_size_t()
+    rc = lib().oracle_transcode_substream(stream, len(stream), C.byref(p), C.byref(out), C.byref(n_out))
+    if rc != 0:
+        raise RuntimeError(f"oracle transcode failed rc={rc}")
+    return _take(out, n_out)
+
+
+def sample_to_byte_stream(b: bytes):
+    out = C.c_void_p(); n = C.c_size_t()
+    if lib().oracle_sample_to_byte_stream(b, len(b), C.byref(out), C.byref(n)) != 0:
+        raise RuntimeError("bad sample stream")
+    return _take(out, n)
+
+
+def byte_to_sample_stream(b: bytes):
+    out = C.c_void_p(); n = C.c_size_t()
+    if lib().oracle_byte_to_sample_stream(b, len(b), C.byref(out), C.byref(n)) != 0:
+        raise RuntimeError("bad byte stream")
+    return _take(out, n)
+
+
+def or_pool(plane: np.ndarray, factor=2):
+    plane = np.ascontiguousarray(plane, dtype=np.uint16)
+    h, w = plane.shape
+    out = np.zeros((h // factor, w // factor), dtype=np.uint16)
+    lib().oracle_or_pool(plane.ctypes.data, w, h, factor, out.ctypes.data)
+    return out
+
+
+def md5(b: bytes):
+    out = C.create_string_buffer(16)
+    lib().oracle_md5(b, len(b), out)
+    return out.raw
