@@ -1,0 +1,93 @@
+// ORACLE — test infrastructure only. Harness around the REFERENCE's own HEVC high-level-syntax parser
+// (/root/reference/dependencies/PccLibHevcParser, compiled in place by oracle/ref_build.sh into oracle/_ref/).
+// It exists to pin the restatement:
+//   tables            -> dumps the normative ROM the reference carries (PccHevcTComRom.cpp:457-465,471-616,635-642,700-709)
+//   hls <annexb file> -> parses every VPS/SPS/PPS of an Annex-B stream with the reference's TDecCavlc
+//                        (PccHevcTDecCAVLC.cpp:189 parsePPS, :651 parseSPS, :1043 parseVPS) and prints the fields
+// No reference source is copied: the reference files are compiled from where they lie.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "PccHevcParser.h"
+#include "PccHevcTComRom.h"
+#include "PccHevcContextTables.h"
+using namespace pcc_hevc;
+// The reference defines its ROM tables at global scope as `const` (PccHevcTComRom.cpp:99 `using namespace`), i.e. with
+// internal linkage, so they cannot be linked against: compile that translation unit as part of this one instead
+// (ref_build.sh passes -I<reference>/dependencies/PccLibHevcParser/source and leaves its object out of the link).
+#include "PccHevcTComRom.cpp"
+
+static std::vector<uint8_t> readFile(const char* p) {
+  std::vector<uint8_t> v; FILE* f = fopen(p, "rb"); if (!f) { perror(p); exit(2); }
+  fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); v.resize(n); if (fread(v.data(), 1, n, f) != (size_t)n) exit(2); fclose(f); return v;
+}
+template <class T> static void dumpArr(const char* name, const T* p, int n, bool last = false) {
+  printf("\"%s\": [", name); for (int i = 0; i < n; i++) printf("%s%d", i ? "," : "", (int)p[i]); printf("]%s\n", last ? "" : ",");
+}
+#define DUMP_INIT(name) dumpArr(#name, &name[0][0], (int)(sizeof(name) / sizeof(name[0][0])))
+
+int main(int argc, char** argv) {
+  if (argc >= 2 && !strcmp(argv[1], "tables")) {
+    printf("{\n");
+    dumpArr("T4", &::gPccHevc_aiT4[0][0][0], 16); dumpArr("T8", &::gPccHevc_aiT8[0][0][0], 64);
+    dumpArr("T16", &::gPccHevc_aiT16[0][0][0], 256); dumpArr("T32", &::gPccHevc_aiT32[0][0][0], 1024);
+    dumpArr("DST4", &::gPccHevc_as_DST_MAT_4[0][0][0], 16);
+    dumpArr("quantScales", ::gPccHevc_quantScales, 6); dumpArr("invQuantScales", ::gPccHevc_invQuantScales, 6);
+    dumpArr("chromaScale420", ::gPccHevc_aucChromaScale[1], 58);
+    dumpArr("ctxIndMap4x4", ::ctxIndMap4x4, 16); dumpArr("groupIdx", ::gPccHevc_uiGroupIdx, 32); dumpArr("minInGroup", ::gPccHevc_uiMinInGroup, 10);
+    // CABAC initValues, rows B,P,I (PccHevcContextTables.h:186-573)
+    DUMP_INIT(INIT_CU_TRANSQUANT_BYPASS_FLAG); DUMP_INIT(INIT_SPLIT_FLAG); DUMP_INIT(INIT_SKIP_FLAG); DUMP_INIT(INIT_MERGE_FLAG_EXT);
+    DUMP_INIT(INIT_MERGE_IDX_EXT); DUMP_INIT(INIT_PART_SIZE); DUMP_INIT(INIT_PRED_MODE); DUMP_INIT(INIT_INTRA_PRED_MODE);
+    DUMP_INIT(INIT_CHROMA_PRED_MODE); DUMP_INIT(INIT_INTER_DIR); DUMP_INIT(INIT_MVD); DUMP_INIT(INIT_REF_PIC); DUMP_INIT(INIT_DQP);
+    DUMP_INIT(INIT_QT_CBF); DUMP_INIT(INIT_QT_ROOT_CBF); DUMP_INIT(INIT_LAST); DUMP_INIT(INIT_SIG_CG_FLAG); DUMP_INIT(INIT_SIG_FLAG);
+    DUMP_INIT(INIT_ONE_FLAG); DUMP_INIT(INIT_ABS_FLAG); DUMP_INIT(INIT_MVP_IDX); DUMP_INIT(INIT_SAO_MERGE_FLAG); DUMP_INIT(INIT_SAO_TYPE_IDX);
+    DUMP_INIT(INIT_TRANS_SUBDIV_FLAG); DUMP_INIT(INIT_TRANSFORMSKIP_FLAG);
+    // coefficient scan orders (PccHevcTComRom.cpp:137-390): [scan type diag/hor/ver][log2 size 2..5] -> raster positions
+    ::initROMPccHevc();
+    const int types[3] = {SCAN_DIAG, SCAN_HOR, SCAN_VER}; const char* tn[3] = {"diag", "hor", "ver"};
+    for (int t = 0; t < 3; t++) for (int l = 1; l <= 5; l++) {
+      char nm[64]; snprintf(nm, sizeof nm, "scan_%s_%d", tn[t], l);
+      dumpArr(nm, gPccHevc_scanOrder[SCAN_GROUPED_4x4][types[t]][l][l], 1 << (2 * l));
+    }
+    printf("\"end\": [0]\n}\n");
+    return 0;
+  }
+  if (argc >= 3 && !strcmp(argv[1], "hls")) {
+    std::vector<uint8_t> buf = readFile(argv[2]);
+    const int size = (int)buf.size(); const uint8_t* data = buf.data();
+    TDecCavlc* dec = new TDecCavlc();
+    int index = 0, sc = data[2] == 0 ? 4 : 3, n = 0;
+    printf("[\n");
+    for (int i = sc; i <= size; i++) {
+      if (i == size || (i + 3 < size && data[i] == 0 && data[i + 1] == 0 && ((data[i + 2] == 0 && data[i + 3] == 1) || data[i + 2] == 1))) {
+        int type = (data[index + sc] & 126) >> 1;
+        // strip emulation prevention before handing the payload to the reference reader
+        std::vector<uint8_t> rb; int z = 0;
+        for (int k = index + sc + 2; k < i; k++) { if (z >= 2 && data[k] == 3) { z = 0; continue; } z = data[k] == 0 ? z + 1 : 0; rb.push_back(data[k]); }
+        dec->setBuffer((UChar*)rb.data(), (int)rb.size());
+        if (type == NAL_UNIT_VPS) { TComVPS vps; dec->parseVPS(&vps); printf("%s{\"nal\":\"VPS\",\"max_dec_pic_buffering\":%d,\"num_reorder\":%d}\n", n++ ? "," : "", vps.getMaxDecPicBuffering(0), vps.getNumReorderPics(0)); }
+        if (type == NAL_UNIT_SPS) {
+          TComSPS* s = dec->getSPS(); dec->parseSPS(s);
+          // the reference's parseSPS stops storing fields after bit_depth_chroma (PccHevcTDecCAVLC.cpp:734: rest commented out)
+          printf("%s{\"nal\":\"SPS\",\"width\":%d,\"height\":%d,\"bit_depth\":%d,\"bit_depth_c\":%d,\"chroma_format\":%d}\n", n++ ? "," : "",
+                 (int)s->getPicWidthInLumaSamples(), (int)s->getPicHeightInLumaSamples(), s->getBitDepth(CHANNEL_TYPE_LUMA), s->getBitDepth(CHANNEL_TYPE_CHROMA), (int)s->getChromaFormatIdc());
+        }
+        if (type == NAL_UNIT_PPS) {
+          TComPPS* p = dec->getPPS(); dec->parsePPS(p);
+          printf("%s{\"nal\":\"PPS\",\"init_qp\":%d,\"sign_hiding\":%d,\"cabac_init_present\":%d,\"num_ref_idx_l0\":%d,\"cip\":%d,\"transform_skip\":%d,"
+                 "\"cu_qp_delta\":%d,\"tq_bypass\":%d,\"lf_across_slices\":%d,\"deblock_ctrl\":%d,\"deblock_disabled\":%d,\"log2_par_mrg\":%d}\n", n++ ? "," : "",
+                 26 + p->getPicInitQPMinus26(), (int)p->getSignDataHidingEnabledFlag(), (int)p->getCabacInitPresentFlag(), (int)p->getNumRefIdxL0DefaultActive(),
+                 (int)p->getConstrainedIntraPred(), (int)p->getUseTransformSkip(), (int)p->getUseDQP(), (int)p->getTransquantBypassEnabledFlag(),
+                 (int)p->getLoopFilterAcrossSlicesEnabledFlag(), (int)p->getDeblockingFilterControlPresentFlag(), (int)p->getPPSDeblockingFilterDisabledFlag(),
+                 2 + (int)p->getLog2ParallelMergeLevelMinus2());
+        }
+        if (i < size) { sc = data[i + 2] == 0 ? 4 : 3; index = i; i += sc; }
+      }
+    }
+    printf("]\n");
+    delete dec;
+    return 0;
+  }
+  fprintf(stderr, "usage: %s tables | hls <annexb>\n", argv[0]);
+  return 1;
+}

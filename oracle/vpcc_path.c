@@ -167,3 +167,30 @@ int oracle_transcode_substream(const uint8_t* annexb, size_t n, const oracle_tra
   *out = bb.d; *n_out = bb.n;
   return 0;
 }
+
+/* ---- table accessors for tests/test_oracle_tables.py (pinning against the reference ROM) ---- */
+int oracle_dct_coef(int N, int k, int n) { return hevc_dct_coef(N, k, n); }
+int oracle_dst_coef(int k, int n) { return k_dst4[k][n]; }
+int oracle_quant_scale(int i) { return k_quant_scale[i]; }
+int oracle_dequant_scale(int i) { return k_dequant_scale[i]; }
+int oracle_chroma_qp(int qpi) { return hevc_chroma_qp(qpi); }
+int oracle_ctx_count(void) { return CTX_COUNT; }
+int oracle_ctx_init(int init_type, int idx) { return k_ctx_init[init_type][idx]; }
+int oracle_sig_ctx_4x4(int i) { return k_sig_ctx_4x4[i]; }
+/* full-block coefficient scan (4x4 coefficient groups): raster index of scan position i */
+int oracle_scan_raster(int scan_idx, int log2, int i) {
+  static uint8_t sc[3][4][64]; static int ready = 0;
+  if (!ready) {
+    for (int l = 0; l <= 3; l++) {
+      int n = 1 << l, k = 0, x = 0, y = 0, stop = 0;
+      while (!stop) { while (y >= 0) { if (x < n && y < n) sc[0][l][k++] = (uint8_t)(x | (y << 4)); y--; x++; } y = x; x = 0; if (k >= n * n) stop = 1; }
+      k = 0; for (y = 0; y < n; y++) for (x = 0; x < n; x++) sc[1][l][k++] = (uint8_t)(x | (y << 4));
+      k = 0; for (x = 0; x < n; x++) for (y = 0; y < n; y++) sc[2][l][k++] = (uint8_t)(x | (y << 4));
+    }
+    ready = 1;
+  }
+  int sb = i >> 4, p = i & 15;
+  int xs = sc[scan_idx][log2 - 2][sb] & 15, ys = sc[scan_idx][log2 - 2][sb] >> 4;
+  int x = (xs << 2) + (sc[scan_idx][2][p] & 15), y = (ys << 2) + (sc[scan_idx][2][p] >> 4);
+  return (y << log2) + x;
+}

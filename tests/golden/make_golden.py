@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures from the REFERENCE run in this container (never on the GPU box).
+
+  hevc_rom_tables.json   output of oracle/_ref/hevc_hls_ref tables  (reference ROM: PccHevcTComRom.cpp, PccHevcContextTables.h)
+  hls_<name>.annexb      parameter sets emitted by the oracle encoder for the product configurations
+  hls_<name>.json        the same NAL units parsed by the reference's TDecCavlc (oracle/_ref/hevc_hls_ref hls)
+
+Run:  oracle/ref_build.sh && python3 tests/golden/make_golden.py
+"""
+import json, os, subprocess, sys
+import numpy as np
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O
+
+REF = os.path.join(ROOT, "oracle", "_ref", "hevc_hls_ref")
+
+
+def main():
+    if not os.path.exists(REF):
+        sys.exit("oracle/_ref/hevc_hls_ref missing: run oracle/ref_build.sh (needs /root/reference)")
+    tables = subprocess.check_output([REF, "tables"]).decode()
+    json.loads(tables)
+    open(os.path.join(HERE, "hevc_rom_tables.json"), "w").write(tables)
+    cfgs = {"geo10_gop2": dict(w=64, h=64, bd=10, qp=24, gop=2, lossless=0, log2_ctb=5, rows=1),
+            "occ8_lossless": dict(w=64, h=32, bd=8, qp=8, gop=1, lossless=1, log2_ctb=5, rows=1),
+            "attr10_ctb64_oneslice": dict(w=128, h=64, bd=10, qp=22, gop=2, lossless=0, log2_ctb=6, rows=0)}
+    for name, c in cfgs.items():
+        fr = np.full((2, c["w"] * c["h"] * 3 // 2), 100, np.uint16)
+        bs, _ = O.encode(fr, c["w"], c["h"], c["bd"], c["qp"], gop=c["gop"], lossless=c["lossless"], log2_ctb=c["log2_ctb"], rows_per_slice=c["rows"])
+        p = os.path.join(HERE, f"hls_{name}.annexb")
+        open(p, "wb").write(bs)
+        out = subprocess.check_output([REF, "hls", p]).decode()
+        out = "".join(l + "\n" for l in out.splitlines() if l[:1] in "[],{")   # the reference parser also printf()s progress lines
+        json.loads(out)
+        open(os.path.join(HERE, f"hls_{name}.json"), "w").write(out)
+        print(name, len(bs), "bytes")
+
+
+if __name__ == "__main__":
+    main()

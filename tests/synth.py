@@ -1,0 +1,87 @@
+"""Synthetic V-PCC-like video maps: patch-packed geometry / attribute / occupancy frames.
+
+There is no 8i data and no HM here or on the GPU box, so the transcoder input is generated: an atlas of axis-aligned
+16-px aligned rectangular patches with smooth depth (geometry), textured colour (attribute) and a binary occupancy map.
+Frame pairs (D0,D1)/(T0,T1) mimic the two V-PCC maps: the far map differs from the near map by a small offset.
+"""
+import numpy as np
+
+
+def atlas_layout(w, h, seed, n_patches=None):
+    r = np.random.default_rng(seed)
+    occ = np.zeros((h, w), np.uint8)
+    patches = []
+    n = n_patches or max(3, (w * h) // (160 * 160))
+    for _ in range(n * 3):
+        pw = int(r.integers(2, max(3, w // 64))) * 16
+        ph = int(r.integers(2, max(3, h // 64))) * 16
+        if pw > w or ph > h:
+            continue
+        x = int(r.integers(0, (w - pw) // 16 + 1)) * 16
+        y = int(r.integers(0, (h - ph) // 16 + 1)) * 16
+        if occ[y:y + ph, x:x + pw].any():
+            continue
+        # blob-shaped occupancy inside the patch rectangle
+        yy, xx = np.mgrid[0:ph, 0:pw]
+        cx, cy = pw / 2, ph / 2
+        rad = ((xx - cx) / (pw / 2)) ** 2 + ((yy - cy) / (ph / 2)) ** 2
+        blob = rad < 0.95 + 0.1 * np.sin(xx / 7.0 + seed) * np.cos(yy / 5.0)
+        occ[y:y + ph, x:x + pw] = blob
+        patches.append((x, y, pw, ph))
+        if len(patches) >= n:
+            break
+    return occ, patches
+
+
+def make_maps(w, h, seed, bit_depth=10, jitter=0):
+    """-> dict with 'geo' [2, w*h*3/2], 'attr' [2, ...] uint16 (10-bit carried as 8-bit*4), 'occ' [1, (w/2*h/2)*3/2] (8-bit, precision 2)"""
+    occ, patches = atlas_layout(w, h, seed)
+    r = np.random.default_rng(seed + 7919 + jitter)
+    yy, xx = np.mgrid[0:h, 0:w]
+    d0 = np.zeros((h, w), np.float64)
+    col = np.zeros((3, h, w), np.float64)
+    for i, (x, y, pw, ph) in enumerate(patches):
+        py, px = np.mgrid[0:ph, 0:pw]
+        base = 40 + (i * 37) % 150
+        depth = base + 30 * np.sin(px / (pw / 3.0) + i) * np.cos(py / (ph / 2.5)) + 0.15 * px
+        d0[y:y + ph, x:x + pw] = depth
+        for c in range(3):
+            tex = 128 + 60 * np.sin(px / (3.0 + c) + i * 1.3) * np.cos(py / (4.0 + i % 3)) + 25 * np.sin((px + py) / (9.0 + c))
+            col[c, y:y + ph, x:x + pw] = tex + r.normal(0, 3, (ph, pw))
+    d0 = np.clip(d0 + r.integers(0, 2, (h, w)), 0, 255) * occ
+    d1 = np.clip(d0 + r.integers(0, 4, (h, w)) * (r.random((h, w)) < 0.3), 0, 255) * occ
+    # unoccupied pixels: smooth padding (the TMC2 encoder dilates patches); a flat mid value is enough here
+    pad_geo = 0
+    scale = 1 << (bit_depth - 8)
+
+    def pack(y_plane, u=None, v=None):
+        Y = (y_plane.astype(np.int64) * scale).clip(0, (1 << bit_depth) - 1).astype(np.uint16)
+        ch, cw = h // 2, w // 2
+        U = np.full((ch, cw), 1 << (bit_depth - 1), np.uint16) if u is None else (u.astype(np.int64) * scale).clip(0, (1 << bit_depth) - 1).astype(np.uint16)
+        V = np.full((ch, cw), 1 << (bit_depth - 1), np.uint16) if v is None else (v.astype(np.int64) * scale).clip(0, (1 << bit_depth) - 1).astype(np.uint16)
+        return np.concatenate([Y.ravel(), U.ravel(), V.ravel()])
+
+    geo = np.stack([pack(np.where(occ, d0, pad_geo)), pack(np.where(occ, d1, pad_geo))])
+    yv = 0.299 * col[0] + 0.587 * col[1] + 0.114 * col[2]
+    uv = (128 + 0.5 * (col[2] - yv) / 0.886)[::2, ::2]
+    vv = (128 + 0.5 * (col[0] - yv) / 0.701)[::2, ::2]
+    m = np.where(occ, 1.0, 0.0)
+    y0 = np.where(occ, yv, 128)
+    y1 = np.where(occ, yv + r.normal(0, 1.5, (h, w)), 128)
+    attr = np.stack([pack(np.clip(y0, 0, 255), np.clip(uv, 0, 255), np.clip(vv, 0, 255)),
+                     pack(np.clip(y1, 0, 255), np.clip(uv, 0, 255), np.clip(vv, 0, 255))])
+    del m
+    # occupancy video at precision 2: (w/2 x h/2), value 1 where any of the 2x2 block is occupied, 8-bit, chroma 128
+    o2 = occ.reshape(h // 2, 2, w // 2, 2).max(axis=(1, 3)).astype(np.uint16)
+    oc = np.full(((h // 4) * (w // 4),), 128, np.uint16)
+    occ_frame = np.concatenate([o2.ravel(), oc, oc])[None, :]
+    return {"geo": geo, "attr": attr, "occ": occ_frame, "occ_full": occ}
+
+
+def make_gof(w, h, n_pc_frames, seed0, bit_depth=10):
+    """One group of frames: geometry/attribute streams of 2*n frames, occupancy stream of n frames (precision 2)."""
+    geo, attr, occ = [], [], []
+    for i in range(n_pc_frames):
+        m = make_maps(w, h, seed0, bit_depth, jitter=i)
+        geo.append(m["geo"]); attr.append(m["attr"]); occ.append(m["occ"])
+    return np.concatenate(geo), np.concatenate(attr), np.concatenate(occ)

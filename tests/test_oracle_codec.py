@@ -1,0 +1,114 @@
+"""CPU tests of the oracle (the checker itself): MD5, stream conversions, OR-pool, codec round trips, HLS goldens."""
+import hashlib
+import json
+import os
+import numpy as np
+import pytest
+import oracle_lib as O
+import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_md5_against_hashlib():
+    r = np.random.default_rng(0)
+    for n in (0, 1, 55, 56, 63, 64, 65, 1000, 4097):
+        b = r.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert O.md5(b) == hashlib.md5(b).digest()
+
+
+def _mk_sample_stream(r, types):
+    out = b""
+    for t in types:
+        n = int(r.integers(3, 40))
+        payload = bytes([t << 1, 1]) + bytes(int(x) | 0x40 for x in r.integers(0, 64, n))   # no 00 00 01 inside
+        out += len(payload).to_bytes(4, "big") + payload
+    return out
+
+
+def test_sample_byte_stream_roundtrip_and_start_codes():
+    """PCCVideoBitstream.cpp:114-172: 4-byte start code for the first NAL and for types 32..40, else 3-byte."""
+    r = np.random.default_rng(3)
+    types = [32, 33, 34, 19, 40, 1, 39, 1, 0, 21]
+    ss = _mk_sample_stream(r, types)
+    bs = O.sample_to_byte_stream(ss)
+    pos, lens = 0, []
+    for i, t in enumerate(types):
+        long_sc = bs[pos:pos + 4] == b"\0\0\0\1"
+        assert long_sc == (i == 0 or 32 <= t <= 40), (i, t)
+        pos += 4 if long_sc else 3
+        assert (bs[pos] >> 1) & 63 == t
+        n = int.from_bytes(ss[sum(lens) + 4 * len(lens): sum(lens) + 4 * len(lens) + 4], "big")
+        lens.append(n); pos += n
+    assert pos == len(bs)
+    assert O.byte_to_sample_stream(bs) == ss
+
+
+def test_or_pool_matches_numpy():
+    r = np.random.default_rng(5)
+    for vals in ((0, 2), (0, 256)):
+        p = r.integers(vals[0], vals[1], (64, 96)).astype(np.uint16) * (r.random((64, 96)) < 0.3)
+        ref = (p.reshape(32, 2, 48, 2).max(axis=(1, 3)) > 0).astype(np.uint16)
+        assert np.array_equal(O.or_pool(p.astype(np.uint16), 2), ref)
+
+
+@pytest.mark.parametrize("log2_ctb,rows", [(5, 1), (6, 0), (4, 2)])
+def test_product_encoder_roundtrip(log2_ctb, rows):
+    m = synth.make_maps(128, 128, 11)
+    for key, qp in (("geo", 24), ("attr", 32)):
+        bs, rec = O.encode(m[key], 128, 128, 10, qp, gop=2, log2_ctb=log2_ctb, rows_per_slice=rows)
+        dec, w, h, bd, chk, fail = O.decode(bs)
+        assert (w, h, bd, chk, fail) == (128, 128, 10, 2, 0)
+        assert np.array_equal(dec, rec)
+        err = dec[:, :128 * 128].astype(np.int64) - m[key][:, :128 * 128]
+        assert 10 * np.log10(1023 ** 2 / max(1e-9, np.mean(err ** 2))) > 35
+
+
+def test_lossless_occupancy_roundtrip():
+    m = synth.make_maps(128, 128, 12)
+    bs, rec = O.encode(m["occ"], 64, 64, 8, 8, gop=1, lossless=1)
+    dec, w, h, bd, chk, fail = O.decode(bs)
+    assert fail == 0 and np.array_equal(dec, m["occ"]) and np.array_equal(rec, m["occ"])
+
+
+@pytest.mark.parametrize("seed", range(1, 25))
+def test_stress_streams_decode_to_encoder_recon(seed):
+    w = [64, 96, 128, 80][seed % 4]; h = [64, 80, 48, 128][(seed // 4) % 4]
+    bd = 10 if seed % 3 else 8
+    fr = np.zeros((5, w * h * 3 // 2), np.uint16)
+    bs, rec = O.encode(fr, w, h, bd, qp=30, gop=2, stress_seed=seed, log2_ctb=0)
+    dec, dw, dh, dbd, chk, fail = O.decode(bs)
+    assert (dw, dh, dbd, fail) == (w, h, bd, 0) and chk == 5
+    assert np.array_equal(dec, rec)
+
+
+def test_transcode_substream_pipeline():
+    """decode -> (pool) -> re-encode, PCCTranscoder.cpp:374-546: occupancy halves in size and stays binary + lossless."""
+    geo, attr, occ = synth.make_gof(128, 128, 2, 21)
+    src, _ = O.encode(occ, 64, 64, 8, 8, gop=1, lossless=1, log2_ctb=6, rows_per_slice=0)
+    out = O.transcode_substream(src, 0, 8, occupancy_precision=4)
+    dec, w, h, bd, chk, fail = O.decode(out)
+    assert (w, h, bd, fail) == (32, 32, 8, 0)
+    want = (occ[:, :64 * 64].reshape(2, 32, 2, 32, 2).max(axis=(2, 4)) > 0).astype(np.uint16)
+    assert np.array_equal(dec[:, :32 * 32].reshape(2, 32, 32), want)
+    src, _ = O.encode(geo, 128, 128, 10, 16, gop=2, log2_ctb=6, rows_per_slice=0)
+    out = O.transcode_substream(src, 1, 24)
+    dec, w, h, bd, chk, fail = O.decode(out)
+    assert (w, h, bd, chk, fail) == (128, 128, 10, 4, 0)
+    assert len(out) < len(src)
+
+
+@pytest.mark.parametrize("name,cfg", [("geo10_gop2", dict(w=64, h=64, bd=10, qp=24, gop=2, lossless=0, log2_ctb=5, rows=1)),
+                                      ("occ8_lossless", dict(w=64, h=32, bd=8, qp=8, gop=1, lossless=1, log2_ctb=5, rows=1)),
+                                      ("attr10_ctb64_oneslice", dict(w=128, h=64, bd=10, qp=22, gop=2, lossless=0, log2_ctb=6, rows=0))])
+def test_parameter_sets_match_reference_parser_golden(name, cfg):
+    """The committed hls_*.json is what the REFERENCE's TDecCavlc read from the oracle encoder's VPS/SPS/PPS."""
+    fr = np.full((2, cfg["w"] * cfg["h"] * 3 // 2), 100, np.uint16)
+    bs, _ = O.encode(fr, cfg["w"], cfg["h"], cfg["bd"], cfg["qp"], gop=cfg["gop"], lossless=cfg["lossless"], log2_ctb=cfg["log2_ctb"], rows_per_slice=cfg["rows"])
+    assert bs == open(os.path.join(GOLD, f"hls_{name}.annexb"), "rb").read()
+    parsed = json.load(open(os.path.join(GOLD, f"hls_{name}.json")))
+    sps = [p for p in parsed if p["nal"] == "SPS"][0]
+    pps = [p for p in parsed if p["nal"] == "PPS"][0]
+    assert (sps["width"], sps["height"], sps["bit_depth"], sps["bit_depth_c"], sps["chroma_format"]) == (cfg["w"], cfg["h"], cfg["bd"], cfg["bd"], 1)
+    assert pps["init_qp"] == cfg["qp"] and pps["tq_bypass"] == cfg["lossless"] and pps["deblock_disabled"] == cfg["lossless"]
+    assert pps["sign_hiding"] == 0 and pps["cu_qp_delta"] == 0 and pps["log2_par_mrg"] == 2 and pps["num_ref_idx_l0"] == 1
