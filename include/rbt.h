@@ -1,0 +1,90 @@
+/* rbt.h — C ABI of librbt.so, the MI355X-native replacement of the V-PCC transcoding hot path.
+ *
+ * Drop-in boundary: the reference's
+ *     void PCCTranscoder::transcodeVideo(PCCVideoBitstream& videoBitstream, PCCVideoType type)
+ *     (source/lib/PccLibTranscoder/include/PCCTranscoder.h:105, source/PCCTranscoder.cpp:374-546)
+ * which decodes one HEVC sub-bitstream of a GOF with libavcodec, OR-pools the occupancy luma plane when
+ * occupancyPrecision == 4 (resize_frame2, PCCTranscoder.cpp:594-646) and re-encodes it with libx265
+ * (setEncoderOptions :825-904, encodeVideo :548-592). rbt_transcode_substream() has the same contract on plain
+ * pointers: Annex-B in, Annex-B out, parameters from PCCTranscoderParameters (PCCTranscoderParameters.h:58-80).
+ * INTEGRATION.md shows the ten-line patch of transcodeVideo that calls it.
+ *
+ * Everything runs on the GPU selected at rbt_create(); there is no CPU fallback: every entry point returns
+ * RBT_ERR_NO_DEVICE if no HIP device is usable.
+ */
+#ifndef RBT_H
+#define RBT_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rbt_ctx rbt_ctx;
+
+enum {
+  RBT_OK = 0,
+  RBT_ERR_NO_DEVICE = -1,     /* no usable HIP device / HIP runtime error */
+  RBT_ERR_BITSTREAM = -2,     /* corrupt or truncated input */
+  RBT_ERR_UNSUPPORTED = -3,   /* stream uses a tool outside the V-PCC CTC toolset (B slices, tiles, PCM, ...) */
+  RBT_ERR_PARAM = -4,
+  RBT_ERR_NOMEM = -5,
+  RBT_ERR_MD5 = -6            /* decoded picture hash SEI mismatch on the input stream */
+};
+
+/* PCCVideoType values the reference passes (PCCBitstreamCommon.h:79-118) */
+enum { RBT_VIDEO_OCCUPANCY = 0, RBT_VIDEO_GEOMETRY = 1, RBT_VIDEO_ATTRIBUTE = 19 };
+
+typedef struct {
+  int video_type;            /* RBT_VIDEO_* (transcodeVideo's `type`) */
+  int qp;                    /* geometryQP_ / attributeQP_ / occupancyMapQP_ (PCCTranscoderParameters.h:58-80) */
+  int occupancy_precision;   /* occupancyPrecision_: 4 => 2x2 OR-pool of the occupancy map (PCCTranscoder.cpp:466) */
+  int log2_ctb;              /* encoder CTB size, 0 = default (5) */
+  int ctb_rows_per_slice;    /* encoder slice height in CTB rows, 0 = one slice per picture, default 1 */
+  int md5_sei;               /* emit decoded-picture-hash SEI in the output */
+  int verify_md5;            /* check the input stream's MD5 SEI (costs a device-to-host copy of every picture) */
+} rbt_stream_params;
+
+typedef struct {             /* decoded video returned by rbt_decode (host memory, rbt_free) */
+  int width, height, bit_depth, n_frames;
+  uint16_t* data;            /* n_frames x planar 4:2:0: Y (w*h), Cb, Cr */
+  int md5_checked, md5_failed;
+} rbt_video;
+
+typedef struct {             /* timings of the last call, milliseconds */
+  double host_parse_ms, h2d_ms, gpu_ms, d2h_ms, host_pack_ms, total_ms;
+  double k_parse_ms, k_recon_ms, k_filter_ms, k_analyse_ms, k_encode_ms, k_entropy_ms;
+  uint64_t algorithmic_bytes; /* SURVEY.md 8(d) accounting of the call */
+} rbt_stats;
+
+int rbt_create(rbt_ctx** ctx, int device, int world_rank, int world_size);
+void rbt_destroy(rbt_ctx* ctx);
+const char* rbt_strerror(int code);
+void rbt_free(void* p);
+const char* rbt_version(void);
+
+/* transcodeVideo: one Annex-B HEVC sub-bitstream of a GOF -> re-encoded Annex-B stream (malloc'd, rbt_free). */
+int rbt_transcode_substream(rbt_ctx* ctx, const uint8_t* annexb_in, size_t n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out);
+
+/* transcodeData (PCCTranscoder.cpp:145-168): the sub-bitstreams of one GOF in one call so that their pictures share
+ * kernel launches. n <= 8 streams. */
+int rbt_transcode_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out);
+
+/* The two halves exposed on their own (SURVEY.md 8(b) alternative seam; used by the parity tests). */
+int rbt_decode(rbt_ctx* ctx, const uint8_t* annexb, size_t n, int verify_md5, rbt_video* out);
+int rbt_encode(rbt_ctx* ctx, const uint16_t* yuv, int width, int height, int bit_depth, int n_frames, int qp, int gop, int lossless,
+               int log2_ctb, int ctb_rows_per_slice, int md5_sei, uint8_t** annexb_out, size_t* n_out);
+
+/* resize_frame2 (PCCTranscoder.cpp:594-646) on a host plane (tests): out[v][u] = any(in block > 0) */
+int rbt_or_pool(rbt_ctx* ctx, const uint16_t* plane, int width, int height, int factor, uint16_t* out);
+
+/* PCCVideoBitstream::sampleStreamToByteStream / byteStreamToSampleStream (PCCVideoBitstream.cpp:85-172), host side */
+int rbt_sample_to_byte_stream(const uint8_t* in, size_t n, uint8_t** out, size_t* n_out);
+int rbt_byte_to_sample_stream(const uint8_t* in, size_t n, uint8_t** out, size_t* n_out);
+
+int rbt_get_stats(rbt_ctx* ctx, rbt_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

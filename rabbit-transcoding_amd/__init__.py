@@ -1,0 +1,126 @@
+"""rabbit-transcoding_amd: ctypes binding of librbt.so (include/rbt.h), the MI355X-native V-PCC transcoding hot path.
+
+The package directory name contains a hyphen (mandated layout), so load it with
+    importlib.util.spec_from_file_location("rabbit_transcoding_amd", ".../rabbit-transcoding_amd/__init__.py")
+or through tests/rbt_lib.py. There is no CPU fallback: creating a Context without a HIP device raises RbtError.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "librbt.so")
+
+RBT_VIDEO_OCCUPANCY, RBT_VIDEO_GEOMETRY, RBT_VIDEO_ATTRIBUTE = 0, 1, 19
+
+
+class RbtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rbt error {code}: {msg}")
+        self.code = code
+
+
+class StreamParams(C.Structure):
+    _fields_ = [("video_type", C.c_int), ("qp", C.c_int), ("occupancy_precision", C.c_int), ("log2_ctb", C.c_int),
+                ("ctb_rows_per_slice", C.c_int), ("md5_sei", C.c_int), ("verify_md5", C.c_int)]
+
+
+class Video(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("n_frames", C.c_int),
+                ("data", C.POINTER(C.c_uint16)), ("md5_checked", C.c_int), ("md5_failed", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("host_parse_ms", "h2d_ms", "gpu_ms", "d2h_ms", "host_pack_ms", "total_ms", "k_parse_ms",
+                                          "k_recon_ms", "k_filter_ms", "k_analyse_ms", "k_encode_ms", "k_entropy_ms")] + [("algorithmic_bytes", C.c_uint64)]
+
+
+def load(path=None):
+    """Loads the shared library and declares the C ABI. Raises OSError if the HIP extension has not been built."""
+    L = C.CDLL(path or LIB_PATH)
+    L.rbt_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
+    L.rbt_destroy.argtypes = [C.c_void_p]
+    L.rbt_strerror.restype = C.c_char_p
+    L.rbt_strerror.argtypes = [C.c_int]
+    L.rbt_version.restype = C.c_char_p
+    L.rbt_free.argtypes = [C.c_void_p]
+    L.rbt_decode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(Video)]
+    L.rbt_encode.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.rbt_transcode_substream.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(StreamParams), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.rbt_transcode_gof.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(StreamParams), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.rbt_or_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.rbt_sample_to_byte_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.rbt_byte_to_sample_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.rbt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    return L
+
+
+class Context:
+    """One transcoder context (rbt_create). Mirrors how PCCTranscoder is used: construct, then transcode per GOF."""
+
+    def __init__(self, device=0, rank=0, world=1, lib_path=None):
+        self.L = load(lib_path)
+        self.h = C.c_void_p()
+        rc = self.L.rbt_create(C.byref(self.h), device, rank, world)
+        if rc != 0:
+            raise RbtError(rc, self.L.rbt_strerror(rc).decode())
+
+    def close(self):
+        if self.h:
+            self.L.rbt_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RbtError(rc, self.L.rbt_strerror(rc).decode())
+
+    def _take(self, ptr, n):
+        out = C.string_at(ptr, n.value) if ptr.value else b""
+        self.L.rbt_free(ptr)
+        return out
+
+    def decode(self, stream: bytes, verify_md5=True):
+        v = Video()
+        self._chk(self.L.rbt_decode(self.h, stream, len(stream), int(verify_md5), C.byref(v)))
+        fs = v.width * v.height * 3 // 2
+        arr = np.ctypeslib.as_array(v.data, shape=(v.n_frames, fs)).copy()
+        self.L.rbt_free(v.data)
+        return arr, v.width, v.height, v.bit_depth, v.md5_checked, v.md5_failed
+
+    def encode(self, frames, w, h, bit_depth, qp, gop=2, lossless=0, log2_ctb=5, rows_per_slice=1, md5_sei=1):
+        frames = np.ascontiguousarray(frames, dtype=np.uint16)
+        out, n = C.c_void_p(), C.c_size_t()
+        self._chk(self.L.rbt_encode(self.h, frames.ctypes.data, w, h, bit_depth, frames.shape[0], qp, gop, lossless, log2_ctb, rows_per_slice, md5_sei, C.byref(out), C.byref(n)))
+        return self._take(out, n)
+
+    def transcode_substream(self, stream: bytes, video_type, qp, occupancy_precision=4, log2_ctb=5, rows_per_slice=1, md5_sei=1, verify_md5=0):
+        p = StreamParams(video_type, qp, occupancy_precision, log2_ctb, rows_per_slice, md5_sei, verify_md5)
+        out, n = C.c_void_p(), C.c_size_t()
+        self._chk(self.L.rbt_transcode_substream(self.h, stream, len(stream), C.byref(p), C.byref(out), C.byref(n)))
+        return self._take(out, n)
+
+    def transcode_gof(self, streams, params):
+        k = len(streams)
+        ins = (C.c_char_p * k)(*streams)
+        sizes = (C.c_size_t * k)(*[len(s) for s in streams])
+        ps = (StreamParams * k)(*params)
+        outs = (C.c_void_p * k)()
+        ns = (C.c_size_t * k)()
+        self._chk(self.L.rbt_transcode_gof(self.h, k, ins, sizes, ps, outs, ns))
+        res = []
+        for i in range(k):
+            res.append(C.string_at(outs[i], ns[i]) if outs[i] else b"")
+            self.L.rbt_free(outs[i])
+        return res
+
+    def or_pool(self, plane, factor=2):
+        plane = np.ascontiguousarray(plane, dtype=np.uint16)
+        h, w = plane.shape
+        out = np.zeros((h // factor, w // factor), np.uint16)
+        self._chk(self.L.rbt_or_pool(self.h, plane.ctypes.data, w, h, factor, out.ctypes.data))
+        return out
+
+    def stats(self):
+        s = Stats()
+        self._chk(self.L.rbt_get_stats(self.h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in Stats._fields_}

@@ -1,0 +1,145 @@
+// In-loop filters: deblocking (H.265 8.7.2) and sample adaptive offset (8.7.3). HBM-bound streaming kernels:
+// one lane per 4-sample edge segment (deblocking, one launch per edge direction) / per sample (SAO).
+// Replaces the loop-filter stage of libavcodec's hevc decoder (PCCTranscoder.cpp:428-448); shared with the encoder.
+#pragma once
+#include "rbt_tables.h"
+#include "rbt_types.h"
+
+RBT_DEV int fl_slice_at(const RbtFrame* f, int x, int y) { return f->ctb_slice[(y >> f->cfg.log2_ctb) * f->cfg.w_ctb + (x >> f->cfg.log2_ctb)]; }
+
+// bS of the edge on the left (dir 0) / top (dir 1) boundary of the 4x4 unit at luma (x,y); 0 = not filtered
+RBT_DEV int fl_bs(const RbtFrame* f, const RbtSlice* slices, int x, int y, int dir) {
+  const RbtStreamCfg* g = &f->cfg;
+  int iq = (y >> 2) * g->w4 + (x >> 2);
+  int e = dir == 0 ? (f->edges[iq] & 3) : ((f->edges[iq] >> 2) & 3);
+  if (!e) return 0;
+  int xp = dir == 0 ? x - 1 : x, yp = dir == 0 ? y : y - 1;
+  if (xp < 0 || yp < 0) return 0;
+  int ip = (yp >> 2) * g->w4 + (xp >> 2);
+  int sq = fl_slice_at(f, x, y), sp = fl_slice_at(f, xp, yp);
+  if (slices[sq].deblocking_disabled) return 0;
+  if (sp != sq && !slices[sq].lf_across) return 0;
+  int mp = f->pm[ip], mq = f->pm[iq];
+  if ((mp & RBT_PM_MODE_MASK) == RBT_MODE_INTRA || (mq & RBT_PM_MODE_MASK) == RBT_MODE_INTRA) return 2;
+  if ((e & 1) && ((mp | mq) & RBT_PM_NZ)) return 1;
+  if (f->refpoc[ip] != f->refpoc[iq]) return 1;
+  if (rbt_abs(f->mv[2 * ip] - f->mv[2 * iq]) >= 4 || rbt_abs(f->mv[2 * ip + 1] - f->mv[2 * iq + 1]) >= 4) return 1;
+  return 0;
+}
+
+RBT_DEV void fl_luma_segment(RbtFrame* f, const RbtSlice* slices, int x, int y, int dir, int bs) {
+  const RbtStreamCfg* g = &f->cfg;
+  int bd = g->bit_depth, maxv = (1 << bd) - 1, st = g->w;
+  int sa = dir == 0 ? 1 : st, sl = dir == 0 ? st : 1;
+  int iq = (y >> 2) * g->w4 + (x >> 2), ip = dir == 0 ? iq - 1 : iq - g->w4;
+  const RbtSlice* s = &slices[fl_slice_at(f, x, y)];
+  int qpl = (f->qp[iq] + f->qp[ip] + 1) >> 1;
+  int beta = k_beta_table[rbt_clip3(0, 51, qpl + (s->beta_offset_div2 << 1))] * (1 << (bd - 8));
+  int tc = k_tc_table[rbt_clip3(0, 53, qpl + 2 * (bs - 1) + (s->tc_offset_div2 << 1))] * (1 << (bd - 8));
+  uint16_t* q = f->pix[0] + (size_t)y * st + x;
+#define FP(i, k) ((int)q[-((i) + 1) * sa + (k) * sl])
+#define FQ(i, k) ((int)q[(i) * sa + (k) * sl])
+  int dp0 = rbt_abs(FP(2, 0) - 2 * FP(1, 0) + FP(0, 0)), dp3 = rbt_abs(FP(2, 3) - 2 * FP(1, 3) + FP(0, 3));
+  int dq0 = rbt_abs(FQ(2, 0) - 2 * FQ(1, 0) + FQ(0, 0)), dq3 = rbt_abs(FQ(2, 3) - 2 * FQ(1, 3) + FQ(0, 3));
+  int dpq0 = dp0 + dq0, dpq3 = dp3 + dq3, dp = dp0 + dp3, dq = dq0 + dq3, d = dpq0 + dpq3;
+  if (d >= beta) return;
+  int ds0 = 2 * dpq0 < (beta >> 2) && rbt_abs(FP(3, 0) - FP(0, 0)) + rbt_abs(FQ(0, 0) - FQ(3, 0)) < (beta >> 3) && rbt_abs(FP(0, 0) - FQ(0, 0)) < ((5 * tc + 1) >> 1);
+  int ds3 = 2 * dpq3 < (beta >> 2) && rbt_abs(FP(3, 3) - FP(0, 3)) + rbt_abs(FQ(0, 3) - FQ(3, 3)) < (beta >> 3) && rbt_abs(FP(0, 3) - FQ(0, 3)) < ((5 * tc + 1) >> 1);
+  int strong = ds0 && ds3;
+  int dEp = dp < ((beta + (beta >> 1)) >> 3), dEq = dq < ((beta + (beta >> 1)) >> 3);
+  int no_p = f->pm[ip] & RBT_PM_TQ_BYPASS, no_q = f->pm[iq] & RBT_PM_TQ_BYPASS;
+  for (int k = 0; k < 4; k++) {
+    int p0 = FP(0, k), p1 = FP(1, k), p2 = FP(2, k), p3 = FP(3, k), q0 = FQ(0, k), q1 = FQ(1, k), q2 = FQ(2, k), q3 = FQ(3, k);
+    uint16_t* c = q + k * sl;
+    if (strong) {
+      if (!no_p) {
+        c[-1 * sa] = (uint16_t)rbt_clip3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+        c[-2 * sa] = (uint16_t)rbt_clip3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2);
+        c[-3 * sa] = (uint16_t)rbt_clip3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+      }
+      if (!no_q) {
+        c[0] = (uint16_t)rbt_clip3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+        c[sa] = (uint16_t)rbt_clip3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2);
+        c[2 * sa] = (uint16_t)rbt_clip3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3);
+      }
+    } else {
+      int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+      if (rbt_abs(delta) < tc * 10) {
+        delta = rbt_clip3(-tc, tc, delta);
+        if (!no_p) {
+          c[-sa] = (uint16_t)rbt_clip3(0, maxv, p0 + delta);
+          if (dEp) c[-2 * sa] = (uint16_t)rbt_clip3(0, maxv, p1 + rbt_clip3(-(tc >> 1), tc >> 1, (((p2 + p0 + 1) >> 1) - p1 + delta) >> 1));
+        }
+        if (!no_q) {
+          c[0] = (uint16_t)rbt_clip3(0, maxv, q0 - delta);
+          if (dEq) c[sa] = (uint16_t)rbt_clip3(0, maxv, q1 + rbt_clip3(-(tc >> 1), tc >> 1, (((q2 + q0 + 1) >> 1) - q1 - delta) >> 1));
+        }
+      }
+    }
+  }
+#undef FP
+#undef FQ
+}
+RBT_DEV void fl_chroma_segment(RbtFrame* f, const RbtSlice* slices, int c_idx, int xl, int yl, int dir) {
+  const RbtStreamCfg* g = &f->cfg;
+  int bd = g->bit_depth, maxv = (1 << bd) - 1, st = g->cw;
+  int sa = dir == 0 ? 1 : st, sl = dir == 0 ? st : 1;
+  int iq = (yl >> 2) * g->w4 + (xl >> 2), ip = dir == 0 ? iq - 1 : iq - g->w4;
+  const RbtSlice* s = &slices[fl_slice_at(f, xl, yl)];
+  int off = c_idx == 1 ? g->cb_qp_offset : g->cr_qp_offset;
+  int qpc = rbt_chroma_qp(((f->qp[iq] + f->qp[ip] + 1) >> 1) + off);
+  int tc = k_tc_table[rbt_clip3(0, 53, qpc + 2 + (s->tc_offset_div2 << 1))] * (1 << (bd - 8));
+  uint16_t* q = f->pix[c_idx] + (size_t)(yl >> 1) * st + (xl >> 1);
+  int no_p = f->pm[ip] & RBT_PM_TQ_BYPASS, no_q = f->pm[iq] & RBT_PM_TQ_BYPASS;
+  for (int k = 0; k < 2; k++) {
+    uint16_t* c = q + k * sl;
+    int p0 = c[-sa], p1 = c[-2 * sa], q0 = c[0], q1 = c[sa];
+    int delta = rbt_clip3(-tc, tc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
+    if (!no_p) c[-sa] = (uint16_t)rbt_clip3(0, maxv, p0 + delta);
+    if (!no_q) c[0] = (uint16_t)rbt_clip3(0, maxv, q0 - delta);
+  }
+}
+// one 4x4 unit of one picture for edge direction `dir`
+RBT_DEV void rbt_deblock_unit(RbtFrame* f, const RbtSlice* slices, int unit, int dir) {
+  const RbtStreamCfg* g = &f->cfg;
+  int x = (unit % g->w4) << 2, y = (unit / g->w4) << 2;
+  if (dir == 0 ? (x & 7) : (y & 7)) return;
+  int bs = fl_bs(f, slices, x, y, dir);
+  if (!bs) return;
+  fl_luma_segment(f, slices, x, y, dir, bs);
+  if (bs == 2 && !(dir == 0 ? (x & 15) : (y & 15))) { fl_chroma_segment(f, slices, 1, x, y, dir); fl_chroma_segment(f, slices, 2, x, y, dir); }
+}
+
+// SAO of one sample of component c: reads f->pix (deblocked), writes f->out
+RBT_DEV void rbt_sao_sample(RbtFrame* f, const RbtSlice* slices, int c, int x, int y) {
+  const RbtStreamCfg* g = &f->cfg;
+  int sh = c ? 1 : 0, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, bd = g->bit_depth, maxv = (1 << bd) - 1;
+  int xl = x << sh, yl = y << sh;
+  int ctb = (yl >> g->log2_ctb) * g->w_ctb + (xl >> g->log2_ctb);
+  const RbtSao* s = &f->sao[ctb];
+  const RbtSlice* sl = &slices[f->ctb_slice[ctb]];
+  const uint16_t* sp = f->pix[c];
+  int v = sp[(size_t)y * pw + x], outv = v;
+  int type = s->type[c];
+  if ((c ? sl->sao_chroma : sl->sao_luma) && type && !(f->pm[(yl >> 2) * g->w4 + (xl >> 2)] & RBT_PM_TQ_BYPASS)) {
+    if (type == 1) {
+      int band = v >> (bd - 5), k = (band - s->band_pos[c]) & 31;
+      if (k < 4) outv = rbt_clip3(0, maxv, v + s->offset[c][k]);
+    } else {
+      int cls = s->eo_class[c];
+      int dxa = cls == 1 ? 0 : (cls == 3 ? 1 : -1), dya = cls == 0 ? 0 : -1;
+      int xa = x + dxa, ya = y + dya, xb = x - dxa, yb = y - dya;
+      if (xa >= 0 && ya >= 0 && xb >= 0 && yb >= 0 && xa < pw && xb < pw && ya < ph && yb < ph) {
+        int sa_ = fl_slice_at(f, xa << sh, ya << sh), sb_ = fl_slice_at(f, xb << sh, yb << sh), sc_ = f->ctb_slice[ctb];
+        int ok = !((sa_ != sc_ && !slices[sa_ > sc_ ? sa_ : sc_].lf_across) || (sb_ != sc_ && !slices[sb_ > sc_ ? sb_ : sc_].lf_across));
+        if (ok) {
+          int va = sp[(size_t)ya * pw + xa], vb = sp[(size_t)yb * pw + xb];
+          int e = 2 + (v > va) - (v < va) + (v > vb) - (v < vb);
+          if (e == 0 || e == 1 || e == 2) e = (e == 2) ? 0 : e + 1;
+          if (e) outv = rbt_clip3(0, maxv, v + s->offset[c][e - 1]);
+        }
+      }
+    }
+  }
+  f->out[c][(size_t)y * pw + x] = (uint16_t)outv;
+}

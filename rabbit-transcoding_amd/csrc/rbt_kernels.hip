@@ -1,0 +1,93 @@
+// HIP kernels + launchers for gfx950 (MI355X). See rbt_kernels.h. One stream per context; kernels of a call are
+// enqueued back-to-back, the host synchronises once per phase that needs results.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include "rbt_kernels.h"
+#include "rbt_parse.h"
+#include "rbt_recon.h"
+#include "rbt_filter.h"
+
+namespace rbtk {
+static hipStream_t g_stream = nullptr;
+static char g_name[256] = "";
+static char g_err[256] = "";
+static hipEvent_t g_ev[32][2];
+static bool g_ev_init = false;
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(g_err, sizeof g_err, "%s: %s", #x, hipGetErrorString(e_)); return -1; } } while (0)
+
+int dev_init(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { snprintf(g_err, sizeof g_err, "no HIP device"); return -1; }
+  if (device < 0 || device >= n) { snprintf(g_err, sizeof g_err, "device %d out of range (%d devices)", device, n); return -1; }
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t p; HIPCHK(hipGetDeviceProperties(&p, device));
+  snprintf(g_name, sizeof g_name, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+  if (!g_stream) HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  if (!g_ev_init) { for (int i = 0; i < 32; i++) { HIPCHK(hipEventCreate(&g_ev[i][0])); HIPCHK(hipEventCreate(&g_ev[i][1])); } g_ev_init = true; }
+  return 0;
+}
+const char* dev_name() { return g_name; }
+void* dev_alloc(size_t n) { void* p = nullptr; if (hipMalloc(&p, n) != hipSuccess) return nullptr; return p; }
+void dev_free(void* p) { if (p) (void)hipFree(p); }
+int h2d(void* d, const void* h, size_t n) { HIPCHK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, g_stream)); return 0; }
+int d2h(void* h, const void* d, size_t n) { HIPCHK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, g_stream)); HIPCHK(hipStreamSynchronize(g_stream)); return 0; }
+int dev_memset(void* d, int v, size_t n) { HIPCHK(hipMemsetAsync(d, v, n, g_stream)); return 0; }
+int dev_sync() { HIPCHK(hipStreamSynchronize(g_stream)); HIPCHK(hipGetLastError()); return 0; }
+void timer_begin(int id) { (void)hipEventRecord(g_ev[id][0], g_stream); }
+void timer_end(int id) { (void)hipEventRecord(g_ev[id][1], g_stream); }
+double timer_ms(int id) { float ms = 0; if (hipEventElapsedTime(&ms, g_ev[id][0], g_ev[id][1]) != hipSuccess) return 0; return ms; }
+
+// ---------------------------------------------------------------------------------------------- decode kernels
+// one wave per slice segment: wave-uniform CABAC parse (rbt_parse.h)
+__global__ void __launch_bounds__(64) k_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list) {
+  __shared__ uint8_t ctx_states[RBT_CTX_COUNT + 3];
+  rbt_parse_slice(frames, slices, slice_list[blockIdx.x], rbsp, ctx_states);
+}
+// one wave per CTB on anti-diagonal d (x + 2y == d): left, above-left, above and above-right CTBs are complete
+__global__ void __launch_bounds__(64) k_recon_diag(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int d) {
+  __shared__ RbtReconLds lds;
+  int fi = frame_list[blockIdx.y];
+  const RbtStreamCfg* g = &frames[fi].cfg;
+  int y = blockIdx.x, x = d - 2 * y;
+  if (y >= g->h_ctb || x < 0 || x >= g->w_ctb) return;
+  int addr = y * g->w_ctb + x;
+  if (frames[fi].ctb_slice[addr] == 0xFFFF) return;     // CTB not covered by any decoded slice
+  rbt_recon_ctb(frames, slices, fi, addr, &lds);
+}
+__global__ void __launch_bounds__(256) k_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int dir) {
+  RbtFrame* f = &frames[frame_list[blockIdx.y]];
+  int unit = blockIdx.x * 256 + threadIdx.x;
+  if (unit >= f->cfg.w4 * f->cfg.h4) return;
+  rbt_deblock_unit(f, slices, unit, dir);
+}
+__global__ void __launch_bounds__(256) k_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
+  RbtFrame* f = &frames[frame_list[blockIdx.y]];
+  int c = blockIdx.z, pw = c ? f->cfg.cw : f->cfg.w, ph = c ? f->cfg.ch : f->cfg.h;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= pw * ph) return;
+  rbt_sao_sample(f, slices, c, i % pw, i / pw);
+}
+
+void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices) {
+  if (n_slices <= 0) return;
+  hipLaunchKernelGGL(k_parse, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, rbsp, slice_list);
+}
+void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb) {
+  if (n_frames <= 0) return;
+  int n_diag = max_w_ctb + 2 * (max_h_ctb - 1);
+  for (int d = 0; d < n_diag; d++) {
+    int rows = d / 2 + 1; if (rows > max_h_ctb) rows = max_h_ctb;
+    hipLaunchKernelGGL(k_recon_diag, dim3(rows, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list, d);
+  }
+}
+void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_units) {
+  if (n_frames <= 0) return;
+  for (int dir = 0; dir < 2; dir++)
+    hipLaunchKernelGGL(k_deblock, dim3((max_units + 255) / 256, n_frames), dim3(256), 0, g_stream, frames, slices, frame_list, dir);
+}
+void launch_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_luma_samples) {
+  if (n_frames <= 0) return;
+  hipLaunchKernelGGL(k_sao, dim3((max_luma_samples + 255) / 256, n_frames, 3), dim3(256), 0, g_stream, frames, slices, frame_list);
+}
+}  // namespace rbtk

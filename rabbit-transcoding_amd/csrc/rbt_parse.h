@@ -1,0 +1,593 @@
+// Slice-segment entropy decoding (H.265 7.3.8 / 9.3) as a WAVE-UNIFORM routine: one 64-lane wave per slice segment.
+// CABAC is a serial dependency chain, so every lane executes the same scalar sequence; what the 64 lanes buy is the
+// cooperative fill of the per-4x4 maps (RBT_PAR_FOR) and free redundancy instead of divergence. Parallelism comes
+// from the ~160 independent slice segments of a GOF (64 geometry + 64 attribute + 32 occupancy pictures).
+//
+// Replaces the entropy-decoding half of libavcodec's hevc decoder as driven by PCCTranscoder.cpp:428-448.
+// Output (HBM): per-CTB command lists (PU / TU records), coefficient levels in the dense coef planes, the per-4x4
+// maps (pm, edges, dm, qp, mv, ref, refpoc) and per-CTB SAO parameters. Reconstruction runs in later kernels.
+#pragma once
+#include "rbt_cabac.h"
+#include "rbt_types.h"
+
+#define RBT_NO_REFPOC ((int32_t)0x80000000)
+
+struct RbtParse {
+  RbtFrame* f; RbtSlice* sl; const RbtFrame* frames; int slice_idx;
+  RbtStreamCfg cfg;
+  RbtCabacDec c;
+  int qp_y, qp_pred, qp_y_prev, is_cu_qp_delta_coded, cu_qp_delta_val;
+  int ctb_addr; uint32_t n_cmds;
+  int cu_x, cu_y, cu_log2, cu_pred_mode, cu_part_mode, cu_tq_bypass;
+  int intra_luma[4], intra_chroma, max_trafo_depth, last_pu_merge;
+  int error;
+};
+struct RbtMv { int x, y, ref; };
+
+RBT_DEV int pz_idx(const RbtParse* s, int x, int y) { return (y >> 2) * s->cfg.w4 + (x >> 2); }
+RBT_DEV int pz_slice_at(const RbtParse* s, int x, int y) { return s->f->ctb_slice[(y >> s->cfg.log2_ctb) * s->cfg.w_ctb + (x >> s->cfg.log2_ctb)]; }
+RBT_DEV int pz_avail(const RbtParse* s, int xn, int yn) {
+  if (xn < 0 || yn < 0 || xn >= s->cfg.w || yn >= s->cfg.h) return 0;
+  if ((s->f->pm[pz_idx(s, xn, yn)] & RBT_PM_MODE_MASK) == RBT_MODE_NONE) return 0;
+  return pz_slice_at(s, xn, yn) == s->slice_idx;
+}
+RBT_DEV int pz_mode(const RbtParse* s, int x, int y) { return s->f->pm[pz_idx(s, x, y)] & RBT_PM_MODE_MASK; }
+RBT_DEV void pz_fill_u8(const RbtParse* s, uint8_t* a, int x, int y, int w, int h, int v) {
+  int w4 = w >> 2, n = w4 * (h >> 2), base = pz_idx(s, x, y), st = s->cfg.w4;
+  RBT_PAR_FOR(i, n) a[base + (i / w4) * st + (i % w4)] = (uint8_t)v;
+}
+RBT_DEV void pz_fill_pm(const RbtParse* s, int x, int y, int w, int h, int keep_mask, int v) {
+  int w4 = w >> 2, n = w4 * (h >> 2), base = pz_idx(s, x, y), st = s->cfg.w4;
+  RBT_PAR_FOR(i, n) { int k = base + (i / w4) * st + (i % w4); s->f->pm[k] = (uint8_t)((s->f->pm[k] & keep_mask) | v); }
+}
+RBT_DEV void pz_mark_edges(const RbtParse* s, int x, int y, int w, int h, int vbits, int hbits) {
+  int nv = h >> 2, nh = w >> 2;
+  RBT_PAR_FOR(i, nv + nh) {
+    if (i < nv) s->f->edges[pz_idx(s, x, y + 4 * i)] |= (uint8_t)vbits;
+    else s->f->edges[pz_idx(s, x + 4 * (i - nv), y)] |= (uint8_t)hbits;
+  }
+  RBT_SYNC();   // corner unit is touched by both halves in consecutive calls; keep read-modify-writes ordered
+}
+RBT_DEV void pz_emit(RbtParse* s, const RbtCmd& cmd) {
+  if ((int)s->n_cmds >= s->f->cmd_cap) { s->error = 3; return; }
+  if (RBT_LANE0) s->f->cmds[(size_t)s->ctb_addr * s->f->cmd_cap + s->n_cmds] = cmd;
+  s->n_cmds++;
+}
+
+// ------------------------------------------------------------------------------------------------ SAO (7.3.8.3)
+RBT_DEV void pz_sao(RbtParse* s, int rx, int ry) {
+  RbtCabacDec* c = &s->c; const RbtSlice* sl = s->sl;
+  RbtSao p; for (int i = 0; i < 3; i++) { p.type[i] = p.band_pos[i] = p.eo_class[i] = 0; for (int k = 0; k < 4; k++) p.offset[i][k] = 0; }
+  p.pad[0] = p.pad[1] = p.pad[2] = 0;
+  int wc = s->cfg.w_ctb;
+  if (sl->sao_luma || sl->sao_chroma) {
+    int merge_left = 0, merge_up = 0;
+    if (rx > 0 && s->f->ctb_slice[ry * wc + rx - 1] == s->slice_idx) merge_left = rbt_cd_bin(c, CTX_SAO_MERGE);
+    if (ry > 0 && !merge_left && s->f->ctb_slice[(ry - 1) * wc + rx] == s->slice_idx) merge_up = rbt_cd_bin(c, CTX_SAO_MERGE);
+    if (merge_left) p = s->f->sao[ry * wc + rx - 1];
+    else if (merge_up) p = s->f->sao[(ry - 1) * wc + rx];
+    else {
+      int bd = s->cfg.bit_depth, cmax = (1 << (rbt_min(bd, 10) - 5)) - 1;
+      for (int ci = 0; ci < 3; ci++) {
+        if ((ci == 0 && !sl->sao_luma) || (ci > 0 && !sl->sao_chroma)) continue;
+        if (ci == 2) p.type[2] = p.type[1];
+        else { int t = 0; if (rbt_cd_bin(c, CTX_SAO_TYPE)) t = rbt_cd_bypass(c) ? 2 : 1; p.type[ci] = (uint8_t)t; }
+        if (!p.type[ci]) continue;
+        int absv[4];
+        for (int i = 0; i < 4; i++) { int v = 0; while (v < cmax && rbt_cd_bypass(c)) v++; absv[i] = v; }
+        if (p.type[ci] == 1) {
+          for (int i = 0; i < 4; i++) if (absv[i] && rbt_cd_bypass(c)) absv[i] = -absv[i];
+          p.band_pos[ci] = (uint8_t)rbt_cd_bypass_n(c, 5);
+        } else {
+          absv[2] = -absv[2]; absv[3] = -absv[3];
+          if (ci == 0) p.eo_class[0] = (uint8_t)rbt_cd_bypass_n(c, 2);
+          else if (ci == 1) p.eo_class[1] = (uint8_t)rbt_cd_bypass_n(c, 2);
+          else p.eo_class[2] = p.eo_class[1];
+        }
+        for (int i = 0; i < 4; i++) p.offset[ci][i] = (int8_t)(absv[i] * (1 << (bd - rbt_min(bd, 10))));
+      }
+    }
+  }
+  if (RBT_LANE0) s->f->sao[ry * wc + rx] = p;
+}
+
+// ------------------------------------------------------------------------------------------------ residual_coding (7.3.8.11)
+// Levels go straight to the dense coefficient plane of component c_idx at TB origin (x0,y0) (component samples).
+RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int scan_idx) {
+  RbtCabacDec* c = &s->c;
+  int16_t* plane = s->f->coef[c_idx]; int pst = c_idx ? s->cfg.cw : s->cfg.w;
+  int ts_flag = 0;
+  if (s->cfg.transform_skip && !s->cu_tq_bypass && log2 <= 2) ts_flag = rbt_cd_bin(c, CTX_TRANSFORM_SKIP + (c_idx ? 1 : 0));
+  int ctx_off, ctx_shift;
+  if (c_idx == 0) { ctx_off = 3 * (log2 - 2) + ((log2 - 1) >> 2); ctx_shift = (log2 + 1) >> 2; }
+  else { ctx_off = 15; ctx_shift = log2 - 2; }
+  int maxp = (log2 << 1) - 1, px = 0, py = 0;
+  while (px < maxp && rbt_cd_bin(c, CTX_LAST_X + ctx_off + (px >> ctx_shift))) px++;
+  while (py < maxp && rbt_cd_bin(c, CTX_LAST_Y + ctx_off + (py >> ctx_shift))) py++;
+  int lx = px, ly = py;
+  if (px > 3) { int nb = (px >> 1) - 1; lx = (1 << nb) * (2 + (px & 1)) + (int)rbt_cd_bypass_n(c, nb); }
+  if (py > 3) { int nb = (py >> 1) - 1; ly = (1 << nb) * (2 + (py & 1)) + (int)rbt_cd_bypass_n(c, nb); }
+  if (scan_idx == 2) { int t = lx; lx = ly; ly = t; }
+  const uint8_t* sb_scan = k_scan[scan_idx][log2 - 2];
+  const uint8_t* pos_scan = k_scan[scan_idx][2];
+  int n_sb = 1 << (2 * (log2 - 2)), last_sb = 0, last_pos = 0;
+  { int sbx = lx >> 2, sby = ly >> 2, ix = lx & 3, iy = ly & 3;
+    for (int i = 0; i < n_sb; i++) if ((sb_scan[i] & 15) == sbx && (sb_scan[i] >> 4) == sby) { last_sb = i; break; }
+    for (int i = 0; i < 16; i++) if ((pos_scan[i] & 15) == ix && (pos_scan[i] >> 4) == iy) { last_pos = i; break; } }
+  uint64_t csbf = 0;   // bit (ys*8+xs)
+  int sbw = 1 << (log2 - 2);
+  int greater1_ctx = 1, first_sb_done = 0;
+  int sign_hiding = s->cfg.sign_hiding && !s->cu_tq_bypass;
+  for (int i = last_sb; i >= 0; i--) {
+    int xs = sb_scan[i] & 15, ys = sb_scan[i] >> 4;
+    int right = xs + 1 < sbw ? (int)((csbf >> (ys * 8 + xs + 1)) & 1) : 0, below = ys + 1 < sbw ? (int)((csbf >> ((ys + 1) * 8 + xs)) & 1) : 0;
+    int infer_dc = 0, coded;
+    if (i < last_sb && i > 0) { coded = rbt_cd_bin(c, CTX_CSBF + rbt_min(right + below, 1) + (c_idx ? 2 : 0)); infer_dc = 1; }
+    else coded = 1;
+    if (!coded) continue;
+    csbf |= 1ull << (ys * 8 + xs);
+    uint32_t sig_mask = 0; int nsig = 0;     // bit n = coefficient at scan position n significant
+    int start = i == last_sb ? last_pos - 1 : 15;
+    if (i == last_sb) { sig_mask |= 1u << last_pos; nsig++; }
+    int prev_csbf = right | (below << 1);
+    for (int n = start; n >= 0; n--) {
+      int xp = pos_scan[n] & 15, yp = pos_scan[n] >> 4, xc = (xs << 2) + xp, yc = (ys << 2) + yp, sig;
+      if (n > 0 || !infer_dc) {
+        int sc;
+        if (log2 == 2) sc = k_sig_ctx_4x4[(yc << 2) + xc];
+        else if (xc + yc == 0) sc = 0;
+        else {
+          if (prev_csbf == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
+          else if (prev_csbf == 1) sc = yp == 0 ? 2 : (yp == 1 ? 1 : 0);
+          else if (prev_csbf == 2) sc = xp == 0 ? 2 : (xp == 1 ? 1 : 0);
+          else sc = 2;
+          if (c_idx == 0) { if (xs || ys) sc += 3; sc += log2 == 3 ? (scan_idx == 0 ? 9 : 15) : 21; }
+          else sc += log2 == 3 ? 9 : 12;
+        }
+        sig = rbt_cd_bin(c, CTX_SIG + (c_idx == 0 ? sc : 27 + sc));
+        if (sig) infer_dc = 0;
+      } else sig = 1;
+      if (sig) { sig_mask |= 1u << n; nsig++; }
+    }
+    if (!nsig) continue;
+    int ctx_set = (i == 0 || c_idx > 0) ? 0 : 2;
+    if (first_sb_done && greater1_ctx == 0) ctx_set++;
+    first_sb_done = 1; greater1_ctx = 1;
+    // k-th significant coefficient in decode order = k-th set bit of sig_mask from the top
+    uint32_t g1_mask = 0; int first_g1 = -1, n8 = rbt_min(nsig, 8);
+    for (int k = 0; k < n8; k++) {
+      int g1 = rbt_cd_bin(c, CTX_GT1 + (ctx_set << 2) + greater1_ctx + (c_idx ? 16 : 0));
+      if (g1) { greater1_ctx = 0; g1_mask |= 1u << k; if (first_g1 < 0) first_g1 = k; }
+      else if (greater1_ctx > 0 && greater1_ctx < 3) greater1_ctx++;
+    }
+    int g2 = 0;
+    if (first_g1 >= 0) g2 = rbt_cd_bin(c, CTX_GT2 + ctx_set + (c_idx ? 4 : 0));
+    int hi = 31 - __builtin_clz(sig_mask), lo = __builtin_ctz(sig_mask);
+    int hidden = sign_hiding && (hi - lo > 3);
+    int nsign = nsig - (hidden ? 1 : 0);
+    uint32_t signs = rbt_cd_bypass_n(c, nsign) << (16 - nsign);
+    int rice = 0, sum = 0, k = 0;
+    uint32_t m = sig_mask;
+    while (m) {
+      int n = 31 - __builtin_clz(m); m &= ~(1u << n);
+      int a = 1 + (int)((g1_mask >> k) & 1) + ((k == first_g1) ? g2 : 0);
+      int base = k < 8 ? (k == first_g1 ? 3 : 2) : 1;
+      if (a == base) {
+        int pre = 0; while (pre < 32 && rbt_cd_bypass(c)) pre++;
+        int v;
+        if (pre <= 3) v = (pre << rice) + (int)rbt_cd_bypass_n(c, rice);
+        else { int sl = pre - 3 + rice; if (sl > 30) { s->error = 4; return 0; } v = (((1 << (pre - 3)) + 3 - 1) << rice) + (int)rbt_cd_bypass_n(c, sl); }
+        a += v;
+        if (a > 3 * (1 << rice)) rice = rbt_min(rice + 1, 4);
+      }
+      sum += a;
+      int neg = k < nsign ? (int)((signs >> (15 - k)) & 1) : (sum & 1);
+      int xc = (xs << 2) + (pos_scan[n] & 15), yc = (ys << 2) + (pos_scan[n] >> 4);
+      int v = rbt_clip3(-32768, 32767, neg ? -a : a);
+      if (RBT_LANE0) plane[(size_t)(y0 + yc) * pst + x0 + xc] = (int16_t)v;
+      k++;
+    }
+  }
+  return ts_flag;
+}
+
+// ------------------------------------------------------------------------------------------------ QP
+RBT_DEV int pz_wrap_qp(const RbtParse* s, int v) { int bdo = 6 * (s->cfg.bit_depth - 8); return ((v + 52 + 2 * bdo) % (52 + bdo)) - bdo; }
+RBT_DEV void pz_start_qg(RbtParse* s, int xqg, int yqg) {
+  int ctb_mask = ~((1 << s->cfg.log2_ctb) - 1);
+  s->qp_y_prev = s->qp_y; s->is_cu_qp_delta_coded = 0; s->cu_qp_delta_val = 0;
+  int qa = s->qp_y_prev, qb = s->qp_y_prev;
+  if (xqg > 0 && ((xqg - 1) & ctb_mask) == (xqg & ctb_mask) && pz_avail(s, xqg - 1, yqg)) qa = s->f->qp[pz_idx(s, xqg - 1, yqg)];
+  if (yqg > 0 && ((yqg - 1) & ctb_mask) == (yqg & ctb_mask) && pz_avail(s, xqg, yqg - 1)) qb = s->f->qp[pz_idx(s, xqg, yqg - 1)];
+  s->qp_pred = (qa + qb + 1) >> 1;
+}
+RBT_DEV int pz_chroma_qp(const RbtParse* s, int c_idx) {
+  int off = c_idx == 1 ? s->cfg.cb_qp_offset + s->sl->cb_qp_offset : s->cfg.cr_qp_offset + s->sl->cr_qp_offset;
+  int bdo = 6 * (s->cfg.bit_depth - 8);
+  int qpi = rbt_clip3(-bdo, 57, s->qp_y + off);
+  return (qpi < 0 ? qpi : rbt_chroma_qp(qpi)) + bdo;
+}
+RBT_DEV int pz_scan_idx(int pred_mode, int log2, int c_idx, int intra_mode) {
+  if (pred_mode == RBT_MODE_INTRA && (log2 == 2 || (log2 == 3 && c_idx == 0))) {
+    if (intra_mode >= 6 && intra_mode <= 14) return 2;
+    if (intra_mode >= 22 && intra_mode <= 30) return 1;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ transform tree (7.3.8.8-10)
+RBT_DEV void pz_transform_unit(RbtParse* s, int x0, int y0, int xb, int yb, int log2, int blk, int cbf_luma, int cbf_cb, int cbf_cr) {
+  RbtCabacDec* c = &s->c;
+  int N = 1 << log2;
+  if ((cbf_luma || cbf_cb || cbf_cr) && s->cfg.cu_qp_delta && !s->is_cu_qp_delta_coded) {
+    int v = 0; while (v < 5 && rbt_cd_bin(c, CTX_CU_QP_DELTA + (v ? 1 : 0))) v++;
+    if (v == 5) { int k = 0; while (k < 16 && rbt_cd_bypass(c)) { v += 1 << k; k++; } v += (int)rbt_cd_bypass_n(c, k); }
+    if (v && rbt_cd_bypass(c)) v = -v;
+    s->is_cu_qp_delta_coded = 1; s->cu_qp_delta_val = v;
+    s->qp_y = pz_wrap_qp(s, s->qp_pred + v);
+    pz_fill_u8(s, (uint8_t*)s->f->qp, s->cu_x, s->cu_y, 1 << s->cu_log2, 1 << s->cu_log2, (uint8_t)(int8_t)s->qp_y);
+  }
+  int intra = s->cu_pred_mode == RBT_MODE_INTRA;
+  int part = 0;
+  if (s->cu_part_mode == RBT_PART_NxN && intra) part = ((y0 - s->cu_y) >= (1 << (s->cu_log2 - 1)) ? 2 : 0) + ((x0 - s->cu_x) >= (1 << (s->cu_log2 - 1)) ? 1 : 0);
+  if (cbf_luma) pz_fill_pm(s, x0, y0, N, N, 0xFF, RBT_PM_NZ);
+  pz_mark_edges(s, x0, y0, N, N, RBT_EV_TU, RBT_EH_TU);
+  int chroma_here = log2 > 2 || blk == 3;
+  RbtCmd cmd; cmd.type = RBT_CMD_TU; cmd.x4 = (uint8_t)((x0 & ((1 << s->cfg.log2_ctb) - 1)) >> 2); cmd.y4 = (uint8_t)((y0 & ((1 << s->cfg.log2_ctb) - 1)) >> 2);
+  cmd.log2 = (uint8_t)log2; cmd.b = (uint8_t)s->intra_luma[part]; cmd.c = (uint8_t)s->intra_chroma; cmd.d = (uint8_t)s->cu_tq_bypass; cmd.mvx = cmd.mvy = 0; cmd.pad = 0;
+  int flags = (cbf_luma ? RBT_TU_CBF_Y : 0) | (intra ? RBT_TU_INTRA : 0) | (chroma_here ? RBT_TU_CHROMA : 0);
+  if (chroma_here) flags |= (cbf_cb ? RBT_TU_CBF_CB : 0) | (cbf_cr ? RBT_TU_CBF_CR : 0);
+  if (cbf_luma && pz_residual(s, 0, x0, y0, log2, pz_scan_idx(s->cu_pred_mode, log2, 0, s->intra_luma[part]))) flags |= RBT_TU_TS_Y;
+  if (chroma_here && !s->error) {
+    int xc = (log2 > 2 ? x0 : xb) >> 1, yc = (log2 > 2 ? y0 : yb) >> 1, l2c = log2 > 2 ? log2 - 1 : 2;
+    int sc = pz_scan_idx(s->cu_pred_mode, l2c, 1, s->intra_chroma);
+    if (cbf_cb && pz_residual(s, 1, xc, yc, l2c, sc)) flags |= RBT_TU_TS_CB;
+    if (cbf_cr && !s->error && pz_residual(s, 2, xc, yc, l2c, sc)) flags |= RBT_TU_TS_CR;
+  }
+  cmd.a = (uint8_t)flags;
+  cmd.qp[0] = (int8_t)(s->qp_y + 6 * (s->cfg.bit_depth - 8)); cmd.qp[1] = (int8_t)pz_chroma_qp(s, 1); cmd.qp[2] = (int8_t)pz_chroma_qp(s, 2);
+  pz_emit(s, cmd);
+}
+RBT_DEV void pz_transform_tree(RbtParse* s, int x0, int y0, int xb, int yb, int log2, int depth, int blk, int pcb, int pcr) {
+  // explicit stack instead of recursion (depth <= 4)
+  struct Node { int16_t x, y, xb, yb; int8_t log2, depth, blk, pcb, pcr, state, cb, cr; };
+  Node st[5]; int sp = 0;
+  st[0].x = (int16_t)x0; st[0].y = (int16_t)y0; st[0].xb = (int16_t)xb; st[0].yb = (int16_t)yb; st[0].log2 = (int8_t)log2; st[0].depth = (int8_t)depth;
+  st[0].blk = (int8_t)blk; st[0].pcb = (int8_t)pcb; st[0].pcr = (int8_t)pcr; st[0].state = -1;
+  RbtCabacDec* c = &s->c;
+  while (sp >= 0 && !s->error) {
+    Node* n = &st[sp];
+    if (n->state < 0) {
+      int intra_split = s->cu_pred_mode == RBT_MODE_INTRA && s->cu_part_mode == RBT_PART_NxN;
+      int inter_split = s->cfg.th_depth_inter == 0 && s->cu_pred_mode != RBT_MODE_INTRA && s->cu_part_mode != RBT_PART_2Nx2N && n->depth == 0;
+      int split;
+      if (n->log2 <= s->cfg.log2_max_tb && n->log2 > s->cfg.log2_min_tb && n->depth < s->max_trafo_depth && !(intra_split && n->depth == 0))
+        split = rbt_cd_bin(c, CTX_SPLIT_TRANSFORM + 5 - n->log2);
+      else split = (n->log2 > s->cfg.log2_max_tb || (intra_split && n->depth == 0) || inter_split) ? 1 : 0;
+      int cbf_cb = 0, cbf_cr = 0;
+      if (n->log2 > 2) {
+        if (n->depth == 0 || n->pcb) cbf_cb = rbt_cd_bin(c, CTX_CBF_CHROMA + n->depth);
+        if (n->depth == 0 || n->pcr) cbf_cr = rbt_cd_bin(c, CTX_CBF_CHROMA + n->depth);
+      } else { cbf_cb = n->pcb; cbf_cr = n->pcr; }
+      n->cb = (int8_t)cbf_cb; n->cr = (int8_t)cbf_cr;
+      if (!split) {
+        int cbf_luma = 1;
+        if (s->cu_pred_mode == RBT_MODE_INTRA || n->depth != 0 || cbf_cb || cbf_cr) cbf_luma = rbt_cd_bin(c, CTX_CBF_LUMA + (n->depth == 0 ? 1 : 0));
+        pz_transform_unit(s, n->x, n->y, n->xb, n->yb, n->log2, n->blk, cbf_luma, cbf_cb, cbf_cr);
+        sp--; continue;
+      }
+      n->state = 0;
+    }
+    if (n->state >= 4) { sp--; continue; }
+    int k = n->state++, h = 1 << (n->log2 - 1);
+    Node* ch = &st[sp + 1];
+    ch->x = (int16_t)(n->x + (k & 1) * h); ch->y = (int16_t)(n->y + (k >> 1) * h); ch->xb = n->x; ch->yb = n->y;
+    ch->log2 = (int8_t)(n->log2 - 1); ch->depth = (int8_t)(n->depth + 1); ch->blk = (int8_t)k; ch->pcb = n->cb; ch->pcr = n->cr; ch->state = -1;
+    sp++;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ motion (8.5.3.2)
+RBT_DEV int pz_pu_avail(const RbtParse* s, int xn, int yn) { return pz_avail(s, xn, yn) && pz_mode(s, xn, yn) != RBT_MODE_INTRA; }
+RBT_DEV RbtMv pz_mv_at(const RbtParse* s, int x, int y) { int i = pz_idx(s, x, y); RbtMv m; m.x = s->f->mv[2 * i]; m.y = s->f->mv[2 * i + 1]; m.ref = s->f->ref[i]; return m; }
+RBT_DEV int pz_mv_same(RbtMv a, RbtMv b) { return a.x == b.x && a.y == b.y && a.ref == b.ref; }
+RBT_DEV int pz_scale_mv(int mv, int tb, int td) {
+  td = rbt_clip3(-128, 127, td); tb = rbt_clip3(-128, 127, tb);
+  int tx = (16384 + (rbt_abs(td) >> 1)) / td;
+  int dsf = rbt_clip3(-4096, 4095, (tb * tx + 32) >> 6);
+  int p = dsf * mv;
+  return rbt_clip3(-32768, 32767, (p < 0 ? -1 : 1) * ((rbt_abs(p) + 127) >> 8));
+}
+RBT_DEV int pz_temporal(const RbtParse* s, int xpb, int ypb, int w, int h, int ref_idx, RbtMv* out) {
+  const RbtSlice* sl = s->sl;
+  if (!sl->temporal_mvp) return 0;
+  const RbtFrame* col = &s->frames[sl->ref_frame[sl->collocated_ref_idx]];
+  int cx[2] = {xpb + w, xpb + (w >> 1)}, cy[2] = {ypb + h, ypb + (h >> 1)};
+  for (int k = 0; k < 2; k++) {
+    int x = cx[k], y = cy[k];
+    if (k == 0 && ((ypb >> s->cfg.log2_ctb) != (y >> s->cfg.log2_ctb) || x >= s->cfg.w || y >= s->cfg.h)) continue;
+    x = (x >> 4) << 4; y = (y >> 4) << 4;
+    int i = (y >> 2) * s->cfg.w4 + (x >> 2);
+    int cm = col->pm[i] & RBT_PM_MODE_MASK;
+    if (cm == RBT_MODE_INTRA || cm == RBT_MODE_NONE) continue;
+    int td = col->poc - col->refpoc[i], tb = sl->poc - sl->ref_poc[ref_idx];
+    int mx = col->mv[2 * i], my = col->mv[2 * i + 1];
+    if (td != tb && td != 0) { mx = pz_scale_mv(mx, tb, td); my = pz_scale_mv(my, tb, td); }
+    out->x = mx; out->y = my; out->ref = ref_idx;
+    return 1;
+  }
+  return 0;
+}
+RBT_DEV RbtMv pz_merge(const RbtParse* s, int xpb, int ypb, int w, int h, int part_idx, int merge_idx) {
+  int pm = s->cu_part_mode, maxc = s->sl->max_merge_cand;
+  RbtMv list[6]; int n = 0;
+  RbtMv ca1 = {0, 0, 0}, cb1 = {0, 0, 0};
+  int a1 = pz_pu_avail(s, xpb - 1, ypb + h - 1) && !((pm == RBT_PART_Nx2N || pm == RBT_PART_nLx2N || pm == RBT_PART_nRx2N) && part_idx == 1);
+  if (a1) { ca1 = pz_mv_at(s, xpb - 1, ypb + h - 1); list[n++] = ca1; }
+  int b1 = pz_pu_avail(s, xpb + w - 1, ypb - 1) && !((pm == RBT_PART_2NxN || pm == RBT_PART_2NxnU || pm == RBT_PART_2NxnD) && part_idx == 1);
+  int b1_in = 0, b0_in = 0, a0_in = 0;
+  if (b1) { cb1 = pz_mv_at(s, xpb + w - 1, ypb - 1); if (!(a1 && pz_mv_same(ca1, cb1))) { list[n++] = cb1; b1_in = 1; } }
+  if (pz_pu_avail(s, xpb + w, ypb - 1)) { RbtMv q = pz_mv_at(s, xpb + w, ypb - 1); if (!(b1 && pz_mv_same(cb1, q))) { list[n++] = q; b0_in = 1; } }
+  if (pz_pu_avail(s, xpb - 1, ypb + h)) { RbtMv q = pz_mv_at(s, xpb - 1, ypb + h); if (!(a1 && pz_mv_same(ca1, q))) { list[n++] = q; a0_in = 1; } }
+  if (a1 + b1_in + b0_in + a0_in != 4 && pz_pu_avail(s, xpb - 1, ypb - 1)) {
+    RbtMv q = pz_mv_at(s, xpb - 1, ypb - 1);
+    if (!(a1 && pz_mv_same(ca1, q)) && !(b1 && pz_mv_same(cb1, q))) list[n++] = q;
+  }
+  if (n > maxc) n = maxc;
+  if (n < maxc) { RbtMv t; if (pz_temporal(s, xpb, ypb, w, h, 0, &t)) list[n++] = t; }
+  int zero_idx = 0;
+  while (n < maxc) { RbtMv z = {0, 0, zero_idx < s->sl->num_ref_idx ? zero_idx : 0}; list[n++] = z; zero_idx++; }
+  RbtMv r = list[0];
+  for (int i = 1; i < 5; i++) if (i == merge_idx) r = list[i];     // avoid dynamic private-array indexing
+  return r;
+}
+RBT_DEV RbtMv pz_amvp(const RbtParse* s, int xpb, int ypb, int w, int h, int ref_idx, int mvp_flag) {
+  const RbtSlice* sl = s->sl;
+  int tgt = sl->ref_poc[ref_idx], cur = sl->poc;
+  int xa[2] = {xpb - 1, xpb - 1}, ya[2] = {ypb + h, ypb + h - 1};
+  int xb[3] = {xpb + w, xpb + w - 1, xpb - 1}, yb[3] = {ypb - 1, ypb - 1, ypb - 1};
+  int ava[2], avb[3];
+  for (int k = 0; k < 2; k++) ava[k] = pz_pu_avail(s, xa[k], ya[k]);
+  for (int k = 0; k < 3; k++) avb[k] = pz_pu_avail(s, xb[k], yb[k]);
+  int fa = 0, fb = 0; RbtMv ma = {0, 0, 0}, mb = {0, 0, 0};
+  for (int k = 0; k < 2 && !fa; k++) if (ava[k]) { RbtMv q = pz_mv_at(s, xa[k], ya[k]); if (sl->ref_poc[q.ref] == tgt) { ma = q; fa = 1; } }
+  for (int k = 0; k < 2 && !fa; k++) if (ava[k]) {
+    RbtMv q = pz_mv_at(s, xa[k], ya[k]); int td = cur - sl->ref_poc[q.ref], tb = cur - tgt;
+    ma = q; fa = 1; if (td != tb && td != 0) { ma.x = pz_scale_mv(q.x, tb, td); ma.y = pz_scale_mv(q.y, tb, td); }
+  }
+  int is_scaled = ava[0] || ava[1];
+  for (int k = 0; k < 3 && !fb; k++) if (avb[k]) { RbtMv q = pz_mv_at(s, xb[k], yb[k]); if (sl->ref_poc[q.ref] == tgt) { mb = q; fb = 1; } }
+  if (!is_scaled && fb) { ma = mb; fa = 1; }
+  if (!is_scaled) {
+    fb = 0;
+    for (int k = 0; k < 3 && !fb; k++) if (avb[k]) {
+      RbtMv q = pz_mv_at(s, xb[k], yb[k]); int td = cur - sl->ref_poc[q.ref], tb = cur - tgt;
+      mb = q; fb = 1; if (td != tb && td != 0) { mb.x = pz_scale_mv(q.x, tb, td); mb.y = pz_scale_mv(q.y, tb, td); }
+    }
+  }
+  RbtMv l0 = {0, 0, ref_idx}, l1 = {0, 0, ref_idx}; int n = 0;
+  if (fa) { l0 = ma; n = 1; }
+  if (fb && !(fa && ma.x == mb.x && ma.y == mb.y)) { if (n == 0) l0 = mb; else l1 = mb; n++; }
+  if (n < 2) { RbtMv t; if (pz_temporal(s, xpb, ypb, w, h, ref_idx, &t)) { if (n == 0) l0 = t; else l1 = t; n++; } }
+  RbtMv r = mvp_flag ? l1 : l0; r.ref = ref_idx;
+  return r;
+}
+RBT_DEV int pz_mvd_comp(RbtCabacDec* c, int gt0, int gt1) {
+  if (!gt0) return 0;
+  int v = 1;
+  if (gt1) { int k = 1; v = 2; while (k < 24 && rbt_cd_bypass(c)) { v += 1 << k; k++; } v += (int)rbt_cd_bypass_n(c, k); }
+  return rbt_cd_bypass(c) ? -v : v;
+}
+RBT_DEV void pz_prediction_unit(RbtParse* s, int x0, int y0, int w, int h, int part_idx, int skip) {
+  RbtCabacDec* c = &s->c; const RbtSlice* sl = s->sl;
+  RbtMv mv;
+  int merge = skip ? 1 : rbt_cd_bin(c, CTX_MERGE_FLAG);
+  s->last_pu_merge = merge;
+  if (merge) {
+    int idx = 0;
+    if (sl->max_merge_cand > 1) { idx = rbt_cd_bin(c, CTX_MERGE_IDX); if (idx) while (idx < sl->max_merge_cand - 1 && rbt_cd_bypass(c)) idx++; }
+    mv = pz_merge(s, x0, y0, w, h, part_idx, idx);
+  } else {
+    int ref_idx = 0;
+    if (sl->num_ref_idx > 1) {
+      int mx = sl->num_ref_idx - 1;
+      while (ref_idx < mx) { int b = ref_idx < 2 ? rbt_cd_bin(c, CTX_REF_IDX + ref_idx) : rbt_cd_bypass(c); if (!b) break; ref_idx++; }
+    }
+    int gx0 = rbt_cd_bin(c, CTX_MVD_GT0), gy0 = rbt_cd_bin(c, CTX_MVD_GT0);
+    int gx1 = gx0 ? rbt_cd_bin(c, CTX_MVD_GT1) : 0, gy1 = gy0 ? rbt_cd_bin(c, CTX_MVD_GT1) : 0;
+    int dx = pz_mvd_comp(c, gx0, gx1), dy = pz_mvd_comp(c, gy0, gy1);
+    int mvp = rbt_cd_bin(c, CTX_MVP_FLAG);
+    mv = pz_amvp(s, x0, y0, w, h, ref_idx, mvp);
+    mv.x = (int16_t)(mv.x + dx); mv.y = (int16_t)(mv.y + dy);
+  }
+  if (mv.ref < 0 || mv.ref >= sl->num_ref_idx) { s->error = 5; return; }
+  int w4 = w >> 2, n = w4 * (h >> 2), base = pz_idx(s, x0, y0), st = s->cfg.w4, refpoc = sl->ref_poc[mv.ref];
+  int mode = skip ? RBT_MODE_SKIP : RBT_MODE_INTER;
+  RBT_PAR_FOR(i, n) {
+    int k = base + (i / w4) * st + (i % w4);
+    s->f->mv[2 * k] = (int16_t)mv.x; s->f->mv[2 * k + 1] = (int16_t)mv.y; s->f->ref[k] = (int8_t)mv.ref; s->f->refpoc[k] = refpoc;
+    s->f->pm[k] = (uint8_t)((s->f->pm[k] & ~RBT_PM_MODE_MASK) | mode);
+  }
+  RBT_SYNC();
+  pz_mark_edges(s, x0, y0, w, h, RBT_EV_PU, RBT_EH_PU);
+  RbtCmd cmd; cmd.type = RBT_CMD_PU; cmd.x4 = (uint8_t)((x0 & ((1 << s->cfg.log2_ctb) - 1)) >> 2); cmd.y4 = (uint8_t)((y0 & ((1 << s->cfg.log2_ctb) - 1)) >> 2);
+  cmd.log2 = 0; cmd.a = (uint8_t)(w >> 2); cmd.b = (uint8_t)(h >> 2); cmd.c = (uint8_t)mv.ref; cmd.d = 0; cmd.mvx = (int16_t)mv.x; cmd.mvy = (int16_t)mv.y;
+  cmd.qp[0] = cmd.qp[1] = cmd.qp[2] = 0; cmd.pad = 0;
+  pz_emit(s, cmd);
+}
+
+// ------------------------------------------------------------------------------------------------ coding unit (7.3.8.5)
+RBT_DEV void pz_intra_mpm(const RbtParse* s, int xp, int yp, int cand[3]) {
+  int ca = 1, cb = 1;
+  if (pz_avail(s, xp - 1, yp) && pz_mode(s, xp - 1, yp) == RBT_MODE_INTRA) ca = s->f->dm[pz_idx(s, xp - 1, yp)] & 63;
+  if (pz_avail(s, xp, yp - 1) && pz_mode(s, xp, yp - 1) == RBT_MODE_INTRA && ((yp - 1) >> s->cfg.log2_ctb) == (yp >> s->cfg.log2_ctb)) cb = s->f->dm[pz_idx(s, xp, yp - 1)] & 63;
+  if (ca == cb) {
+    if (ca < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
+    else { cand[0] = ca; cand[1] = 2 + ((ca + 29) % 32); cand[2] = 2 + ((ca - 2 + 1) % 32); }
+  } else { cand[0] = ca; cand[1] = cb; cand[2] = (ca != 0 && cb != 0) ? 0 : ((ca != 1 && cb != 1) ? 1 : 26); }
+}
+RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
+  RbtCabacDec* c = &s->c; const RbtStreamCfg* cfg = &s->cfg;
+  int N = 1 << log2;
+  s->cu_x = x0; s->cu_y = y0; s->cu_log2 = log2; s->cu_tq_bypass = 0; s->cu_part_mode = RBT_PART_2Nx2N; s->cu_pred_mode = RBT_MODE_INTRA;
+  if (cfg->cu_qp_delta) s->qp_y = pz_wrap_qp(s, s->qp_pred + s->cu_qp_delta_val);
+  if (cfg->tq_bypass_enabled) s->cu_tq_bypass = rbt_cd_bin(c, CTX_CU_TQ_BYPASS);
+  int skip = 0;
+  if (s->sl->slice_type != RBT_SLICE_I) {
+    int cl = pz_avail(s, x0 - 1, y0) && pz_mode(s, x0 - 1, y0) == RBT_MODE_SKIP;
+    int ca = pz_avail(s, x0, y0 - 1) && pz_mode(s, x0, y0 - 1) == RBT_MODE_SKIP;
+    skip = rbt_cd_bin(c, CTX_CU_SKIP + cl + ca);
+  }
+  pz_fill_u8(s, (uint8_t*)s->f->qp, x0, y0, N, N, (uint8_t)(int8_t)s->qp_y);
+  pz_mark_edges(s, x0, y0, N, N, RBT_EV_TU | RBT_EV_PU, RBT_EH_TU | RBT_EH_PU);
+  if (skip) {
+    s->cu_pred_mode = RBT_MODE_SKIP;
+    pz_fill_u8(s, s->f->dm, x0, y0, N, N, (depth << 6) | 1);
+    pz_fill_pm(s, x0, y0, N, N, 0, RBT_MODE_NONE | (s->cu_tq_bypass ? RBT_PM_TQ_BYPASS : 0));
+    RBT_SYNC();
+    pz_prediction_unit(s, x0, y0, N, N, 0, 1);
+    RBT_SYNC();
+    return;
+  }
+  if (s->sl->slice_type != RBT_SLICE_I) s->cu_pred_mode = rbt_cd_bin(c, CTX_PRED_MODE) ? RBT_MODE_INTRA : RBT_MODE_INTER;
+  if (s->cu_pred_mode == RBT_MODE_INTRA) {
+    if (log2 == cfg->log2_min_cb) s->cu_part_mode = rbt_cd_bin(c, CTX_PART_MODE) ? RBT_PART_2Nx2N : RBT_PART_NxN;
+    if (s->cu_part_mode == RBT_PART_NxN && log2 == 3 && cfg->log2_min_tb > 2) { s->error = 6; return; }
+  } else {
+    if (rbt_cd_bin(c, CTX_PART_MODE)) s->cu_part_mode = RBT_PART_2Nx2N;
+    else if (log2 == cfg->log2_min_cb) {
+      if (log2 == 3) s->cu_part_mode = rbt_cd_bin(c, CTX_PART_MODE + 1) ? RBT_PART_2NxN : RBT_PART_Nx2N;
+      else if (rbt_cd_bin(c, CTX_PART_MODE + 1)) s->cu_part_mode = RBT_PART_2NxN;
+      else s->cu_part_mode = rbt_cd_bin(c, CTX_PART_MODE + 2) ? RBT_PART_Nx2N : RBT_PART_NxN;
+    } else if (!cfg->amp) s->cu_part_mode = rbt_cd_bin(c, CTX_PART_MODE + 1) ? RBT_PART_2NxN : RBT_PART_Nx2N;
+    else {
+      int hor = rbt_cd_bin(c, CTX_PART_MODE + 1);
+      if (rbt_cd_bin(c, CTX_PART_MODE + 3)) s->cu_part_mode = hor ? RBT_PART_2NxN : RBT_PART_Nx2N;
+      else { int b = rbt_cd_bypass(c); s->cu_part_mode = hor ? (b ? RBT_PART_2NxnD : RBT_PART_2NxnU) : (b ? RBT_PART_nRx2N : RBT_PART_nLx2N); }
+    }
+  }
+  if (s->cu_pred_mode == RBT_MODE_INTRA) {
+    pz_fill_pm(s, x0, y0, N, N, 0, RBT_MODE_INTRA | (s->cu_tq_bypass ? RBT_PM_TQ_BYPASS : 0));
+    pz_fill_u8(s, s->f->dm, x0, y0, N, N, (depth << 6) | 1);
+    RBT_SYNC();
+    int np = s->cu_part_mode == RBT_PART_NxN ? 4 : 1, pb = N >> (np == 4);
+    int prev[4], mpm_idx[4], rem[4];
+    for (int i = 0; i < np; i++) prev[i] = rbt_cd_bin(c, CTX_PREV_INTRA_LUMA);
+    for (int i = 0; i < np; i++) {
+      mpm_idx[i] = 0; rem[i] = 0;
+      if (prev[i]) { mpm_idx[i] = rbt_cd_bypass(c); if (mpm_idx[i]) mpm_idx[i] += rbt_cd_bypass(c); }
+      else rem[i] = (int)rbt_cd_bypass_n(c, 5);
+    }
+    for (int i = 0; i < np; i++) {
+      int xp = x0 + (i & 1) * pb, yp = y0 + (i >> 1) * pb;
+      int cand[3]; pz_intra_mpm(s, xp, yp, cand);
+      int mode;
+      if (prev[i]) mode = mpm_idx[i] == 0 ? cand[0] : (mpm_idx[i] == 1 ? cand[1] : cand[2]);
+      else {
+        if (cand[0] > cand[1]) { int t = cand[0]; cand[0] = cand[1]; cand[1] = t; }
+        if (cand[0] > cand[2]) { int t = cand[0]; cand[0] = cand[2]; cand[2] = t; }
+        if (cand[1] > cand[2]) { int t = cand[1]; cand[1] = cand[2]; cand[2] = t; }
+        mode = rem[i];
+        for (int k = 0; k < 3; k++) if (mode >= cand[k]) mode++;
+      }
+      s->intra_luma[i] = mode;
+      pz_fill_u8(s, s->f->dm, xp, yp, pb, pb, (depth << 6) | mode);
+      RBT_SYNC();
+    }
+    int icp = 4;
+    if (rbt_cd_bin(c, CTX_INTRA_CHROMA)) icp = (int)rbt_cd_bypass_n(c, 2);
+    int cmode = icp == 0 ? 0 : (icp == 1 ? 26 : (icp == 2 ? 10 : 1));
+    if (icp == 4) s->intra_chroma = s->intra_luma[0];
+    else s->intra_chroma = cmode == s->intra_luma[0] ? 34 : cmode;
+  } else {
+    pz_fill_u8(s, s->f->dm, x0, y0, N, N, (depth << 6) | 1);
+    pz_fill_pm(s, x0, y0, N, N, 0, RBT_MODE_NONE | (s->cu_tq_bypass ? RBT_PM_TQ_BYPASS : 0));
+    RBT_SYNC();
+    int h2 = N >> 1, q = N >> 2, pmode = s->cu_part_mode;
+    int np = pmode == RBT_PART_2Nx2N ? 1 : (pmode == RBT_PART_NxN ? 4 : 2);
+    for (int i = 0; i < np && !s->error; i++) {
+      int px = 0, py = 0, pw = N, ph = N;
+      switch (pmode) {
+        case RBT_PART_2NxN: ph = h2; py = i * h2; break;
+        case RBT_PART_Nx2N: pw = h2; px = i * h2; break;
+        case RBT_PART_NxN: pw = ph = h2; px = (i & 1) * h2; py = (i >> 1) * h2; break;
+        case RBT_PART_2NxnU: ph = i ? N - q : q; py = i ? q : 0; break;
+        case RBT_PART_2NxnD: ph = i ? q : N - q; py = i ? N - q : 0; break;
+        case RBT_PART_nLx2N: pw = i ? N - q : q; px = i ? q : 0; break;
+        case RBT_PART_nRx2N: pw = i ? q : N - q; px = i ? N - q : 0; break;
+        default: break;
+      }
+      pz_prediction_unit(s, x0 + px, y0 + py, pw, ph, i, 0);
+      RBT_SYNC();
+    }
+    if (s->error) return;
+  }
+  int rqt_root_cbf = 1;
+  if (s->cu_pred_mode != RBT_MODE_INTRA && !(s->cu_part_mode == RBT_PART_2Nx2N && s->last_pu_merge)) rqt_root_cbf = rbt_cd_bin(c, CTX_RQT_ROOT_CBF);
+  if (rqt_root_cbf) {
+    s->max_trafo_depth = s->cu_pred_mode == RBT_MODE_INTRA ? cfg->th_depth_intra + (s->cu_part_mode == RBT_PART_NxN) : cfg->th_depth_inter;
+    pz_transform_tree(s, x0, y0, x0, y0, log2, 0, 0, 0, 0);
+  }
+  RBT_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------------ coding quadtree + slice data
+RBT_DEV void pz_coding_quadtree(RbtParse* s, int x0, int y0, int log2) {
+  struct Node { int16_t x, y; int8_t log2, depth, state; };
+  Node st[5]; int sp = 0;
+  st[0].x = (int16_t)x0; st[0].y = (int16_t)y0; st[0].log2 = (int8_t)log2; st[0].depth = 0; st[0].state = -1;
+  const RbtStreamCfg* cfg = &s->cfg;
+  while (sp >= 0 && !s->error) {
+    Node* n = &st[sp];
+    int N = 1 << n->log2, h = N >> 1;
+    if (n->state < 0) {
+      int split;
+      if (n->x + N <= cfg->w && n->y + N <= cfg->h && n->log2 > cfg->log2_min_cb) {
+        int cl = pz_avail(s, n->x - 1, n->y) && (s->f->dm[pz_idx(s, n->x - 1, n->y)] >> 6) > n->depth;
+        int ca = pz_avail(s, n->x, n->y - 1) && (s->f->dm[pz_idx(s, n->x, n->y - 1)] >> 6) > n->depth;
+        split = rbt_cd_bin(&s->c, CTX_SPLIT_CU + cl + ca);
+      } else split = n->log2 > cfg->log2_min_cb;
+      if (cfg->cu_qp_delta && n->log2 >= cfg->log2_ctb - cfg->diff_cu_qp_delta_depth) pz_start_qg(s, n->x, n->y);
+      if (!split) { pz_coding_unit(s, n->x, n->y, n->log2, n->depth); sp--; continue; }
+      n->state = 0;
+    }
+    if (n->state >= 4) { sp--; continue; }
+    int k = n->state++;
+    int cx = n->x + (k & 1) * h, cy = n->y + (k >> 1) * h;
+    if (cx >= cfg->w || cy >= cfg->h) continue;
+    Node* ch = &st[sp + 1];
+    ch->x = (int16_t)cx; ch->y = (int16_t)cy; ch->log2 = (int8_t)(n->log2 - 1); ch->depth = (int8_t)(n->depth + 1); ch->state = -1;
+    sp++;
+  }
+}
+
+// Entry: parses one slice segment. `ctx_states` is a RBT_CTX_COUNT byte scratch (LDS on the GPU).
+RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, const uint8_t* rbsp, uint8_t* ctx_states) {
+  RbtParse s;
+  s.sl = &slices[slice_idx]; s.frames = frames; s.f = &frames[s.sl->frame]; s.slice_idx = slice_idx; s.cfg = s.f->cfg; s.error = 0;
+  const RbtSlice* sl = s.sl;
+  int init_type = sl->slice_type == RBT_SLICE_I ? 0 : (sl->cabac_init_flag ? 2 : 1);
+  rbt_ctx_init(ctx_states, init_type, sl->qp);
+  RBT_SYNC();
+  rbt_cd_start(&s.c, rbsp + sl->data_off, sl->data_size, ctx_states);
+  s.qp_y = sl->qp; s.qp_pred = sl->qp; s.qp_y_prev = sl->qp; s.is_cu_qp_delta_coded = 0; s.cu_qp_delta_val = 0;
+  s.last_pu_merge = 0; s.max_trafo_depth = 0; s.intra_chroma = 1;
+  int n_ctb = s.cfg.w_ctb * s.cfg.h_ctb, end = 0, addr = sl->ctb_addr;
+  uint32_t count = 0;
+  while (!end) {
+    if (addr >= n_ctb) { s.error = 1; break; }
+    int rx = addr % s.cfg.w_ctb, ry = addr / s.cfg.w_ctb;
+    if (RBT_LANE0) s.f->ctb_slice[addr] = (uint16_t)slice_idx;
+    RBT_SYNC();
+    s.ctb_addr = addr; s.n_cmds = 0;
+    pz_sao(&s, rx, ry);
+    pz_coding_quadtree(&s, rx << s.cfg.log2_ctb, ry << s.cfg.log2_ctb, s.cfg.log2_ctb);
+    if (RBT_LANE0) s.f->cmd_count[addr] = s.n_cmds;
+    if (s.error) break;
+    end = rbt_cd_terminate(&s.c);
+    addr++; count++;
+    if (rbt_cd_bytes_consumed(&s.c) > sl->data_size + 8) { s.error = 2; break; }
+    RBT_SYNC();
+  }
+  if (RBT_LANE0) { slices[slice_idx].n_ctbs_decoded = count; if (s.error) s.f->error = s.error; }
+}

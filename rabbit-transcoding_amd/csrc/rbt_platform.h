@@ -1,0 +1,34 @@
+// rabbit-transcoding_amd — MI355X-native V-PCC video transcoding hot path.
+// Kernel-side platform glue. The product is built with hipcc for gfx950 only (RBT_HOSTEMU undefined).
+//
+// RBT_HOSTEMU is a TEST-ONLY build mode (tests/hostemu/, never shipped, never a fallback of the product library):
+// it compiles the same kernel bodies as serial host code so their logic can be debugged against the oracle in a
+// container that has no GPU. Kernel bodies are written in "phase" style: wave-/block-uniform scalar code plus
+// RBT_PAR_FOR loops separated by RBT_SYNC(); on the GPU a PAR_FOR is a thread-strided loop, in host emulation a
+// plain loop executed once per block.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef RBT_HOSTEMU
+#include <string.h>
+#define RBT_DEV static inline
+#define RBT_CONST static const
+#define RBT_PAR_FOR(i, n) for (int i = 0; i < (int)(n); i++)
+#define RBT_SYNC() do { } while (0)
+#define RBT_LANE0 1
+#define RBT_NTHREADS 1
+#else
+#include <hip/hip_runtime.h>
+#define RBT_DEV static __device__ __forceinline__
+#define RBT_CONST static __device__ const
+#define RBT_PAR_FOR(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += (int)blockDim.x)
+#define RBT_SYNC() __syncthreads()
+#define RBT_LANE0 (threadIdx.x == 0)
+#define RBT_NTHREADS ((int)blockDim.x)
+#endif
+
+RBT_DEV int rbt_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+RBT_DEV int rbt_min(int a, int b) { return a < b ? a : b; }
+RBT_DEV int rbt_max(int a, int b) { return a > b ? a : b; }
+RBT_DEV int rbt_abs(int a) { return a < 0 ? -a : a; }

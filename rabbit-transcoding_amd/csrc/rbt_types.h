@@ -1,0 +1,95 @@
+// Data layout in HBM shared by the host orchestrator and the kernels.
+//
+// One RbtFrame per coded picture of a batch (a batch = every picture of the sub-bitstreams handed to one call).
+// All per-picture state lives in HBM for the whole call (288 GB: a 32-frame GOF of the CTC streams needs ~2 GB):
+//   pix[3]    uint16 planes, stride = plane width: reconstruction, deblocked in place
+//   out[3]    uint16 planes: SAO output (== pix when SAO is off for the picture)
+//   coef[3]   int16 planes, same geometry as pix: transform coefficient LEVELS at their TB position
+//   per 4x4 luma unit maps (w4 x h4): pm, edges, dm, qp, mv, ref
+//   per CTB: sao parameters, slice index, command list (decode) / CU decisions (encode)
+#pragma once
+#include <stdint.h>
+
+enum { RBT_SLICE_B = 0, RBT_SLICE_P = 1, RBT_SLICE_I = 2 };
+enum { RBT_PART_2Nx2N = 0, RBT_PART_2NxN, RBT_PART_Nx2N, RBT_PART_NxN, RBT_PART_2NxnU, RBT_PART_2NxnD, RBT_PART_nLx2N, RBT_PART_nRx2N };
+enum { RBT_MODE_INTER = 0, RBT_MODE_INTRA = 1, RBT_MODE_SKIP = 2, RBT_MODE_NONE = 3 };
+
+// pm map bits
+#define RBT_PM_MODE_MASK 3
+#define RBT_PM_TQ_BYPASS 4
+#define RBT_PM_NZ 8
+// edges map bits: vertical edge on the unit's left boundary (TU 1, PU 2), horizontal edge on its top boundary (TU 4, PU 8)
+#define RBT_EV_TU 1
+#define RBT_EV_PU 2
+#define RBT_EH_TU 4
+#define RBT_EH_PU 8
+
+#define RBT_MAX_REFS 4
+// command list capacity of a CTB = 2 * (ctb/4)^2: every 4x4 TU plus every 8x4 PU (RbtFrame::cmd_cap)
+
+struct RbtStreamCfg {            // SPS + PPS fields the kernels need
+  int32_t w, h, cw, ch, w4, h4, w_ctb, h_ctb;
+  int8_t bit_depth, log2_ctb, log2_min_cb, log2_min_tb, log2_max_tb, th_depth_inter, th_depth_intra, diff_cu_qp_delta_depth;
+  uint8_t amp, sao, strong_intra, tmvp, sign_hiding, cabac_init_present, cip, transform_skip;
+  uint8_t cu_qp_delta, tq_bypass_enabled, pad0, pad1;
+  int8_t cb_qp_offset, cr_qp_offset, pad2, pad3;
+};
+
+struct RbtSao { uint8_t type[3], band_pos[3], eo_class[3]; int8_t offset[3][4]; uint8_t pad[3]; };   // 24 bytes
+
+struct RbtCmd {                  // 16 bytes, one per CU / PU / TU in decode order inside a CTB
+  uint8_t type;                  // 1 PU, 2 TU
+  uint8_t x4, y4;                // position inside the CTB in 4-luma-sample units
+  uint8_t log2;                  // TU: log2 luma TB size
+  uint8_t a, b, c, d;            // PU: w4, h4, ref_idx, -   TU: flags, intra_luma, intra_chroma, -
+  int16_t mvx, mvy;              // PU
+  int8_t qp[3];                  // TU: qP for Y, Cb, Cr (including QpBdOffset)
+  uint8_t pad;
+};
+#define RBT_CMD_PU 1
+#define RBT_CMD_TU 2
+#define RBT_TU_CBF_Y 1
+#define RBT_TU_CBF_CB 2
+#define RBT_TU_CBF_CR 4
+#define RBT_TU_TS_Y 8
+#define RBT_TU_TS_CB 16
+#define RBT_TU_TS_CR 32
+#define RBT_TU_CHROMA 64
+#define RBT_TU_INTRA 128
+
+struct RbtFrame {
+  RbtStreamCfg cfg;
+  uint16_t* pix[3];
+  uint16_t* out[3];
+  int16_t* coef[3];
+  uint8_t* pm;                   // per 4x4: mode | tq_bypass | nz
+  uint8_t* edges;                // per 4x4
+  uint8_t* dm;                   // per 4x4: cu depth (bits 6-7) | luma intra pred mode (bits 0-5)
+  int8_t* qp;                    // per 4x4: QpY
+  int16_t* mv;                   // per 4x4: x, y
+  int8_t* ref;                   // per 4x4: ref_idx (list 0), -1 none
+  int32_t* refpoc;               // per 4x4: POC of the reference (for TMVP / deblocking), filled after parsing
+  RbtSao* sao;                   // per CTB
+  uint16_t* ctb_slice;           // per CTB: index into the batch slice table
+  RbtCmd* cmds;                  // per CTB: cmd_cap records
+  int32_t cmd_cap;
+  uint32_t* cmd_count;           // per CTB
+  int32_t poc;
+  int32_t level;                 // dependency level inside the batch (0: no references inside the batch)
+  int32_t n_slices, first_slice;
+  int32_t error;                 // set by kernels (non-zero = corrupt / unsupported stream)
+};
+
+struct RbtSlice {                // one per slice segment, parsed on the host (7.3.6)
+  int32_t frame;                 // index into the batch frame table
+  uint32_t data_off, data_size;  // slice_segment_data() inside the batch RBSP buffer (emulation prevention removed)
+  int32_t ctb_addr;              // slice_segment_address
+  int8_t slice_type, qp, cb_qp_offset, cr_qp_offset;
+  uint8_t sao_luma, sao_chroma, deblocking_disabled, lf_across;
+  int8_t beta_offset_div2, tc_offset_div2;
+  uint8_t temporal_mvp, cabac_init_flag, max_merge_cand, num_ref_idx, collocated_ref_idx, pad[3];
+  int32_t ref_frame[RBT_MAX_REFS];   // batch frame index of RefPicList0[i]
+  int32_t ref_poc[RBT_MAX_REFS];
+  int32_t poc;
+  uint32_t n_ctbs_decoded;       // out: CTBs the slice covered
+};

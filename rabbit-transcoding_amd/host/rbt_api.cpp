@@ -1,0 +1,121 @@
+// C ABI of librbt.so (include/rbt.h). Drop-in for PCCTranscoder::transcodeVideo (PCCTranscoder.cpp:374-546).
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include "rbt_batch.h"
+#include "rbt_transcode.h"
+
+struct rbt_ctx { int device, rank, world; rbt_stats stats; std::string last_err; };
+
+static std::mutex g_mu;   // one HIP stream / timer set per process; calls on one context are serial (as the reference's are)
+
+extern "C" {
+
+const char* rbt_version(void) { return "rabbit-transcoding_amd 0.1 (RBT-E1 encoder, gfx950)"; }
+
+const char* rbt_strerror(int code) {
+  switch (code) {
+    case RBT_OK: return "ok";
+    case RBT_ERR_NO_DEVICE: return "no usable HIP device or HIP runtime failure (this library has no CPU fallback)";
+    case RBT_ERR_BITSTREAM: return "corrupt or truncated HEVC bitstream";
+    case RBT_ERR_UNSUPPORTED: return "bitstream uses a coding tool outside the supported V-PCC CTC toolset";
+    case RBT_ERR_PARAM: return "invalid parameter";
+    case RBT_ERR_NOMEM: return "out of memory";
+    case RBT_ERR_MD5: return "decoded picture hash mismatch on the input stream";
+    default: return "unknown error";
+  }
+}
+void rbt_free(void* p) { free(p); }
+
+int rbt_create(rbt_ctx** ctx, int device, int world_rank, int world_size) {
+  if (!ctx) return RBT_ERR_PARAM;
+  *ctx = nullptr;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (rbtk::dev_init(device)) return RBT_ERR_NO_DEVICE;
+  rbt_ctx* c = new rbt_ctx(); c->device = device; c->rank = world_rank; c->world = world_size; memset(&c->stats, 0, sizeof(c->stats));
+  *ctx = c;
+  return RBT_OK;
+}
+void rbt_destroy(rbt_ctx* ctx) { delete ctx; }
+int rbt_get_stats(rbt_ctx* ctx, rbt_stats* out) { if (!ctx || !out) return RBT_ERR_PARAM; *out = ctx->stats; return RBT_OK; }
+
+int rbt_decode(rbt_ctx* ctx, const uint8_t* annexb, size_t n, int verify_md5, rbt_video* out) {
+  if (!ctx || !annexb || !out) return RBT_ERR_PARAM;
+  std::lock_guard<std::mutex> lk(g_mu);
+  memset(out, 0, sizeof(*out));
+  rbt::DecodeBatch b; rbt::StreamIn in{annexb, n};
+  int rc = rbt::decode_build(b, &in, 1);
+  if (!rc) rc = rbt::decode_run(b);
+  if (!rc) rc = rbt::decode_fetch(b, 0, out, verify_md5 != 0);
+  if (rc) { ctx->last_err = b.err; free(out->data); memset(out, 0, sizeof(*out)); return rc; }
+  ctx->stats.k_parse_ms = rbtk::timer_ms(rbt::T_PARSE); ctx->stats.k_recon_ms = rbtk::timer_ms(rbt::T_RECON);
+  if (verify_md5 && out->md5_failed) return RBT_ERR_MD5;
+  return RBT_OK;
+}
+
+// PCCVideoBitstream.cpp:174-184
+static size_t end_of_nalu(const uint8_t* d, size_t size, size_t start) {
+  if (size < start + 4) return size;
+  for (size_t i = start; i < size - 4; i++)
+    if (d[i] == 0 && d[i + 1] == 0 && (d[i + 2] == 1 || (d[i + 2] == 0 && d[i + 3] == 1))) return i;
+  return size;
+}
+// PCCVideoBitstream::byteStreamToSampleStream (PCCVideoBitstream.cpp:85-112), precision 4, no emulation prevention handling
+int rbt_byte_to_sample_stream(const uint8_t* in, size_t n, uint8_t** out, size_t* n_out) {
+  if (!in || !out || !n_out || n < 4) return RBT_ERR_PARAM;
+  std::vector<uint8_t> v; v.reserve(n + 64);
+  size_t start = 0, end = 0;
+  do {
+    size_t sc = in[start + 2] == 0 ? 4 : 3;
+    end = end_of_nalu(in, n, start + sc);
+    size_t sz = end - (start + sc);
+    for (int i = 0; i < 4; i++) v.push_back((uint8_t)(sz >> (8 * (3 - i))));
+    v.insert(v.end(), in + start + sc, in + end);
+    start = end;
+  } while (end < n);
+  *out = (uint8_t*)malloc(v.size() ? v.size() : 1); if (!*out) return RBT_ERR_NOMEM;
+  memcpy(*out, v.data(), v.size()); *n_out = v.size();
+  return RBT_OK;
+}
+// PCCVideoBitstream::sampleStreamToByteStream (PCCVideoBitstream.cpp:114-172), HEVC, precision 4
+int rbt_sample_to_byte_stream(const uint8_t* in, size_t n, uint8_t** out, size_t* n_out) {
+  if (!in || !out || !n_out || n < 4) return RBT_ERR_PARAM;
+  std::vector<uint8_t> v; v.reserve(n + 64);
+  size_t sc = 4, start = 0, end = 0;
+  do {
+    uint32_t sz = 0; for (int i = 0; i < 4; i++) sz = (sz << 8) + in[start + i];
+    end = start + 4 + sz;
+    if (end > n) return RBT_ERR_BITSTREAM;
+    for (size_t i = 0; i + 1 < sc; i++) v.push_back(0);
+    v.push_back(1);
+    v.insert(v.end(), in + start + 4, in + end);
+    start = end;
+    if (start + 4 < n) { int type = (in[start + 4] & 126) >> 1; sc = (type >= 32 && type < 41) ? 4 : 3; }   // the reference resets newFrame before testing it (:146)
+  } while (end < n);
+  *out = (uint8_t*)malloc(v.size() ? v.size() : 1); if (!*out) return RBT_ERR_NOMEM;
+  memcpy(*out, v.data(), v.size()); *n_out = v.size();
+  return RBT_OK;
+}
+
+int rbt_transcode_substream(rbt_ctx* ctx, const uint8_t* annexb_in, size_t n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out) {
+  return rbt_transcode_gof(ctx, 1, &annexb_in, &n_in, p, annexb_out, n_out);
+}
+int rbt_transcode_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out) {
+  if (!ctx || n < 1 || n > 8 || !annexb_in || !n_in || !p || !annexb_out || !n_out) return RBT_ERR_PARAM;
+  std::lock_guard<std::mutex> lk(g_mu);
+  return rbt::transcode_gof(ctx->stats, ctx->last_err, n, annexb_in, n_in, p, annexb_out, n_out);
+}
+int rbt_encode(rbt_ctx* ctx, const uint16_t* yuv, int width, int height, int bit_depth, int n_frames, int qp, int gop, int lossless,
+               int log2_ctb, int ctb_rows_per_slice, int md5_sei, uint8_t** annexb_out, size_t* n_out) {
+  if (!ctx || !yuv || !annexb_out || !n_out || n_frames < 1) return RBT_ERR_PARAM;
+  std::lock_guard<std::mutex> lk(g_mu);
+  return rbt::encode_yuv(ctx->stats, ctx->last_err, yuv, width, height, bit_depth, n_frames, qp, gop, lossless, log2_ctb, ctb_rows_per_slice, md5_sei, annexb_out, n_out);
+}
+int rbt_or_pool(rbt_ctx* ctx, const uint16_t* plane, int width, int height, int factor, uint16_t* out) {
+  if (!ctx || !plane || !out || factor < 1 || width % factor || height % factor) return RBT_ERR_PARAM;
+  std::lock_guard<std::mutex> lk(g_mu);
+  return rbt::or_pool_host(plane, width, height, factor, out);
+}
+
+}  // extern "C"

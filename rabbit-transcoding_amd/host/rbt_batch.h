@@ -1,0 +1,43 @@
+// Host orchestration of one call: a "batch" is every picture of the sub-bitstreams handed over together (one GOF's
+// geometry + attribute + occupancy streams in rbt_transcode_gof, a single stream in rbt_transcode_substream).
+// The host parses NAL units, parameter sets and slice headers, lays the batch out in one HBM arena, uploads the
+// unescaped slice data once, and enqueues the kernels; pictures never leave HBM between decode and re-encode.
+#pragma once
+#include <string>
+#include <vector>
+#include "../../include/rbt.h"
+#include "../csrc/rbt_kernels.h"
+#include "rbt_hls.h"
+
+namespace rbt {
+
+struct StreamIn { const uint8_t* p; size_t n; };
+struct FrameInfo { int stream; int nal_type; bool has_md5; uint8_t md5[3][16]; bool sao; };
+
+enum { T_PARSE = 0, T_RECON = 1, T_FILTER = 2, T_ANALYSE = 3, T_ENCODE = 4, T_ENTROPY = 5, T_ALL = 6, T_POOL = 7, T_COUNT = 8 };
+
+struct Arena {           // bump allocator over one device allocation
+  uint8_t* base = nullptr; size_t size = 0, used = 0;
+  size_t reserve(size_t n) { size_t o = (used + 255) & ~(size_t)255; used = o + n; return o; }
+};
+
+struct DecodeBatch {
+  std::vector<uint8_t> rbsp;
+  std::vector<RbtFrame> frames; std::vector<RbtSlice> slices; std::vector<FrameInfo> info;
+  std::vector<int> stream_first, stream_count;
+  std::vector<Sps> stream_sps; std::vector<Pps> stream_pps;
+  std::vector<std::vector<int>> level_frames;
+  bool ordered_parse = false;
+  void* arena = nullptr; size_t arena_size = 0;
+  RbtFrame* d_frames = nullptr; RbtSlice* d_slices = nullptr; uint8_t* d_rbsp = nullptr; int32_t* d_lists = nullptr;
+  std::string err; int err_code = 0;
+  ~DecodeBatch() { rbtk::dev_free(arena); }
+};
+
+int decode_build(DecodeBatch& b, const StreamIn* streams, int n);
+int decode_run(DecodeBatch& b);
+int decode_fetch(DecodeBatch& b, int stream, rbt_video* out, bool verify_md5);
+
+size_t frame_samples(const RbtStreamCfg& c);
+
+}  // namespace rbt

@@ -1,0 +1,202 @@
+// Decode half of the hot path: replaces initDecoder + the av_read_frame / avcodec_send_packet / avcodec_receive_frame
+// loop of PCCTranscoder::transcodeVideo (PCCTranscoder.cpp:404, :428-448).
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include "rbt_batch.h"
+
+namespace rbt {
+
+size_t frame_samples(const RbtStreamCfg& c) { return (size_t)c.w * c.h + 2 * (size_t)c.cw * c.ch; }
+
+struct DpbEntry { int poc, frame; };
+
+int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
+  b.stream_first.assign(n_streams, 0); b.stream_count.assign(n_streams, 0);
+  b.stream_sps.resize(n_streams); b.stream_pps.resize(n_streams);
+  // ---- host parse ----
+  for (int si = 0; si < n_streams; si++) {
+    std::vector<Nal> nals; size_t rbsp_start = b.rbsp.size();
+    split_annexb(streams[si].p, streams[si].n, b.rbsp, nals);
+    (void)rbsp_start;
+    ParamSets* ps = new ParamSets();
+    std::vector<DpbEntry> dpb; int prev_tid0_poc = 0, cur = -1;
+    b.stream_first[si] = (int)b.frames.size();
+    for (const Nal& nal : nals) {
+      const uint8_t* r = b.rbsp.data() + nal.rbsp_off; int rc = 0;
+      if (nal.type == NAL_SPS) rc = parse_sps(*ps, r, nal.rbsp_size, b.err);
+      else if (nal.type == NAL_PPS) rc = parse_pps(*ps, r, nal.rbsp_size, b.err);
+      else if (nal.type == NAL_SEI_SUFFIX) { if (cur >= 0) { FrameInfo& fi = b.info[cur]; if (parse_md5_sei(r, nal.rbsp_size, fi.md5)) fi.has_md5 = true; } }
+      else if (nal.type <= NAL_TRAIL_R || (nal.type >= 16 && nal.type <= 21)) {
+        SliceHdr h; rc = parse_slice_header(*ps, r, nal.rbsp_size, nal.type, h, b.err);
+        if (rc) { delete ps; b.err_code = rc == -3 ? RBT_ERR_UNSUPPORTED : RBT_ERR_BITSTREAM; return b.err_code; }
+        const Pps& pps = ps->pps[h.pps_id]; const Sps& sps = ps->sps[pps.sps_id];
+        if (h.first_slice_in_pic) {
+          bool idr = nal.type == NAL_IDR_W_RADL || nal.type == NAL_IDR_N_LP;
+          if (idr) h.poc = 0;
+          else {
+            int max_lsb = 1 << sps.log2_max_poc_lsb, prev_lsb = prev_tid0_poc & (max_lsb - 1), prev_msb = prev_tid0_poc - prev_lsb, msb;
+            if (h.poc_lsb < prev_lsb && prev_lsb - h.poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb;
+            else if (h.poc_lsb > prev_lsb && h.poc_lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
+            else msb = prev_msb;
+            if (nal.type >= 16 && nal.type <= 23 && nal.type != NAL_CRA) msb = 0;
+            h.poc = msb + h.poc_lsb;
+          }
+          prev_tid0_poc = h.poc;
+          RbtFrame f; memset(&f, 0, sizeof(f));
+          fill_stream_cfg(sps, pps, f.cfg); f.poc = h.poc; f.first_slice = (int)b.slices.size();
+          int ctb = 1 << sps.log2_ctb; f.cmd_cap = 2 * (ctb / 4) * (ctb / 4);
+          if (b.stream_count[si] > 0 && memcmp(&b.frames[b.stream_first[si]].cfg, &f.cfg, sizeof(f.cfg)) != 0) {
+            // parameter sets may be repeated but must not change inside one sub-bitstream of a GOF
+            const RbtStreamCfg& c0 = b.frames[b.stream_first[si]].cfg;
+            if (c0.w != f.cfg.w || c0.h != f.cfg.h || c0.bit_depth != f.cfg.bit_depth) { delete ps; b.err = "picture size changes inside a stream"; return b.err_code = RBT_ERR_UNSUPPORTED; }
+          }
+          cur = (int)b.frames.size(); b.frames.push_back(f);
+          FrameInfo fi; memset(&fi, 0, sizeof(fi)); fi.stream = si; fi.nal_type = nal.type; b.info.push_back(fi);
+          b.stream_count[si]++; b.stream_sps[si] = sps; b.stream_pps[si] = pps;
+          dpb.insert(dpb.begin(), DpbEntry{h.poc, cur});
+        } else if (cur < 0) { delete ps; b.err = "slice segment before the first picture"; return b.err_code = RBT_ERR_BITSTREAM; }
+        else h.poc = b.frames[cur].poc;
+        RbtSlice s; memset(&s, 0, sizeof(s));
+        s.frame = cur; s.data_off = (uint32_t)(nal.rbsp_off + h.data_byte_offset);
+        if (h.data_byte_offset > nal.rbsp_size) { delete ps; b.err = "empty slice data"; return b.err_code = RBT_ERR_BITSTREAM; }
+        s.data_size = (uint32_t)(nal.rbsp_size - h.data_byte_offset); s.ctb_addr = h.segment_addr;
+        s.slice_type = (int8_t)h.slice_type; s.qp = (int8_t)h.qp; s.cb_qp_offset = (int8_t)h.cb_qp_offset; s.cr_qp_offset = (int8_t)h.cr_qp_offset;
+        s.sao_luma = (uint8_t)h.sao_luma; s.sao_chroma = (uint8_t)h.sao_chroma; s.deblocking_disabled = (uint8_t)h.deblocking_disabled; s.lf_across = (uint8_t)h.lf_across;
+        s.beta_offset_div2 = (int8_t)h.beta_offset_div2; s.tc_offset_div2 = (int8_t)h.tc_offset_div2; s.temporal_mvp = (uint8_t)h.temporal_mvp;
+        s.cabac_init_flag = (uint8_t)h.cabac_init_flag; s.max_merge_cand = (uint8_t)h.max_merge_cand; s.num_ref_idx = (uint8_t)h.num_ref_idx;
+        s.collocated_ref_idx = (uint8_t)h.collocated_ref_idx; s.poc = h.poc;
+        if (h.qp < -6 * (sps.bit_depth - 8) || h.qp > 51) { delete ps; b.err = "slice QP out of range"; return b.err_code = RBT_ERR_BITSTREAM; }
+        if (h.slice_type == RBT_SLICE_P) {
+          int cand[16], nc = 0;
+          for (int i = 0; i < h.rps.num; i++) if (h.rps.used[i]) cand[nc++] = h.poc + h.rps.delta_poc[i];
+          if (!nc) { delete ps; b.err = "P slice with an empty reference picture set"; return b.err_code = RBT_ERR_BITSTREAM; }
+          for (int i = 0; i < h.num_ref_idx; i++) {
+            int poc = cand[i % nc], found = -1;
+            for (size_t k = 1; k < dpb.size(); k++) if (dpb[k].poc == poc) { found = dpb[k].frame; break; }   // dpb[0] is the current picture
+            if (found < 0) { delete ps; b.err = "missing reference picture"; return b.err_code = RBT_ERR_BITSTREAM; }
+            s.ref_frame[i] = found; s.ref_poc[i] = poc;
+            b.frames[cur].level = std::max(b.frames[cur].level, b.frames[found].level + 1);
+            if (h.temporal_mvp && i == h.collocated_ref_idx && b.frames[found].level > 0) b.ordered_parse = true;
+          }
+        }
+        if (h.sao_luma || h.sao_chroma) b.info[cur].sao = true;
+        b.frames[cur].n_slices++;
+        b.slices.push_back(s);
+      } else if (nal.type >= 2 && nal.type <= 9) { rc = -3; b.err = "unsupported VCL NAL unit type"; }
+      if (rc) { delete ps; b.err_code = rc == -3 ? RBT_ERR_UNSUPPORTED : RBT_ERR_BITSTREAM; return b.err_code; }
+    }
+    delete ps;
+  }
+  if (b.frames.empty()) { b.err = "no pictures in the input"; return b.err_code = RBT_ERR_BITSTREAM; }
+  if (b.slices.size() >= 0xFFFF) { b.err = "too many slice segments"; return b.err_code = RBT_ERR_UNSUPPORTED; }
+  int n_levels = 0; for (auto& f : b.frames) n_levels = std::max(n_levels, f.level + 1);
+  b.level_frames.assign(n_levels, {});
+  for (size_t i = 0; i < b.frames.size(); i++) b.level_frames[b.frames[i].level].push_back((int)i);
+
+  // ---- HBM layout: [zero region | pm region (0x03) | ctb_slice region (0xFF) | rest] ----
+  Arena a;
+  size_t nf = b.frames.size();
+  std::vector<size_t> o_coef(nf), o_edges(nf), o_cnt(nf), o_pm(nf), o_cs(nf), o_pix(nf), o_out(nf), o_dm(nf), o_qp(nf), o_mv(nf), o_ref(nf), o_refpoc(nf), o_sao(nf), o_cmds(nf);
+  for (size_t i = 0; i < nf; i++) { const RbtStreamCfg& c = b.frames[i].cfg; size_t u = (size_t)c.w4 * c.h4, nc = (size_t)c.w_ctb * c.h_ctb;
+    o_coef[i] = a.reserve(frame_samples(c) * 2); o_edges[i] = a.reserve(u); o_cnt[i] = a.reserve(nc * 4); }
+  size_t zero_end = a.reserve(0);
+  for (size_t i = 0; i < nf; i++) { const RbtStreamCfg& c = b.frames[i].cfg; o_pm[i] = a.reserve((size_t)c.w4 * c.h4); }
+  size_t pm_begin = o_pm[0], pm_end = a.reserve(0);
+  for (size_t i = 0; i < nf; i++) { const RbtStreamCfg& c = b.frames[i].cfg; o_cs[i] = a.reserve((size_t)c.w_ctb * c.h_ctb * 2); }
+  size_t cs_begin = o_cs[0], cs_end = a.reserve(0);
+  for (size_t i = 0; i < nf; i++) {
+    const RbtStreamCfg& c = b.frames[i].cfg; size_t u = (size_t)c.w4 * c.h4, nc = (size_t)c.w_ctb * c.h_ctb;
+    o_pix[i] = a.reserve(frame_samples(c) * 2);
+    o_out[i] = b.info[i].sao ? a.reserve(frame_samples(c) * 2) : o_pix[i];
+    o_dm[i] = a.reserve(u); o_qp[i] = a.reserve(u); o_mv[i] = a.reserve(u * 4); o_ref[i] = a.reserve(u); o_refpoc[i] = a.reserve(u * 4);
+    o_sao[i] = a.reserve(nc * sizeof(RbtSao)); o_cmds[i] = a.reserve(nc * (size_t)b.frames[i].cmd_cap * sizeof(RbtCmd));
+  }
+  size_t o_frames = a.reserve(nf * sizeof(RbtFrame)), o_slices = a.reserve(b.slices.size() * sizeof(RbtSlice));
+  size_t o_rbsp = a.reserve(b.rbsp.size() + 16), o_lists = a.reserve((nf + b.slices.size()) * 2 * sizeof(int32_t));
+  b.arena_size = a.reserve(0);
+  b.arena = rbtk::dev_alloc(b.arena_size);
+  if (!b.arena) { b.err = "device allocation failed"; return b.err_code = RBT_ERR_NOMEM; }
+  uint8_t* base = (uint8_t*)b.arena;
+  for (size_t i = 0; i < nf; i++) {
+    RbtFrame& f = b.frames[i]; const RbtStreamCfg& c = f.cfg; size_t ys = (size_t)c.w * c.h, cs = (size_t)c.cw * c.ch;
+    auto planes = [&](size_t off, uint16_t** p) { p[0] = (uint16_t*)(base + off); p[1] = p[0] + ys; p[2] = p[1] + cs; };
+    planes(o_pix[i], f.pix); planes(o_out[i], f.out);
+    f.coef[0] = (int16_t*)(base + o_coef[i]); f.coef[1] = f.coef[0] + ys; f.coef[2] = f.coef[1] + cs;
+    f.pm = base + o_pm[i]; f.edges = base + o_edges[i]; f.dm = base + o_dm[i]; f.qp = (int8_t*)(base + o_qp[i]); f.mv = (int16_t*)(base + o_mv[i]);
+    f.ref = (int8_t*)(base + o_ref[i]); f.refpoc = (int32_t*)(base + o_refpoc[i]); f.sao = (RbtSao*)(base + o_sao[i]); f.ctb_slice = (uint16_t*)(base + o_cs[i]);
+    f.cmds = (RbtCmd*)(base + o_cmds[i]); f.cmd_count = (uint32_t*)(base + o_cnt[i]);
+  }
+  b.d_frames = (RbtFrame*)(base + o_frames); b.d_slices = (RbtSlice*)(base + o_slices); b.d_rbsp = base + o_rbsp; b.d_lists = (int32_t*)(base + o_lists);
+  if (rbtk::dev_memset(base, 0, zero_end) || rbtk::dev_memset(base + pm_begin, RBT_MODE_NONE, pm_end - pm_begin) || rbtk::dev_memset(base + cs_begin, 0xFF, cs_end - cs_begin) ||
+      rbtk::h2d(b.d_frames, b.frames.data(), nf * sizeof(RbtFrame)) || rbtk::h2d(b.d_slices, b.slices.data(), b.slices.size() * sizeof(RbtSlice)) ||
+      rbtk::h2d(b.d_rbsp, b.rbsp.data(), b.rbsp.size())) { b.err = "device transfer failed"; return b.err_code = RBT_ERR_NO_DEVICE; }
+  return 0;
+}
+
+int decode_run(DecodeBatch& b) {
+  size_t nf = b.frames.size(), ns = b.slices.size();
+  // index lists: slices grouped by level, frames grouped by level
+  std::vector<int32_t> lists; std::vector<size_t> sl_off, sl_cnt, fr_off;
+  for (auto& lf : b.level_frames) {
+    sl_off.push_back(lists.size());
+    for (int fi : lf) for (int k = 0; k < b.frames[fi].n_slices; k++) lists.push_back(b.frames[fi].first_slice + k);
+    sl_cnt.push_back(lists.size() - sl_off.back());
+  }
+  for (auto& lf : b.level_frames) { fr_off.push_back(lists.size()); for (int fi : lf) lists.push_back(fi); }
+  if (lists.size() > (nf + ns) * 2) { b.err = "internal: list overflow"; return b.err_code = RBT_ERR_PARAM; }
+  if (rbtk::h2d(b.d_lists, lists.data(), lists.size() * sizeof(int32_t))) { b.err = "device transfer failed"; return b.err_code = RBT_ERR_NO_DEVICE; }
+  rbtk::timer_begin(T_PARSE);
+  if (b.ordered_parse) { for (size_t l = 0; l < b.level_frames.size(); l++) rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists + sl_off[l], (int)sl_cnt[l]); }
+  else rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists, (int)ns);
+  rbtk::timer_end(T_PARSE);
+  rbtk::timer_begin(T_RECON);
+  for (size_t l = 0; l < b.level_frames.size(); l++) {
+    const std::vector<int>& lf = b.level_frames[l];
+    int mw = 0, mh = 0, mu = 0, ml = 0; std::vector<int> sao_frames;
+    for (int fi : lf) { const RbtStreamCfg& c = b.frames[fi].cfg; mw = std::max(mw, c.w_ctb); mh = std::max(mh, c.h_ctb); mu = std::max(mu, c.w4 * c.h4); ml = std::max(ml, c.w * c.h); }
+    rbtk::launch_recon(b.d_frames, b.d_slices, b.d_lists + fr_off[l], (int)lf.size(), mw, mh);
+    rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + fr_off[l], (int)lf.size(), mu);
+    // SAO frames of this level are a contiguous sub-list only if all (or none) use SAO; otherwise launch per frame run
+    size_t k = 0;
+    while (k < lf.size()) {
+      if (!b.info[lf[k]].sao) { k++; continue; }
+      size_t e = k; while (e < lf.size() && b.info[lf[e]].sao) e++;
+      rbtk::launch_sao(b.d_frames, b.d_slices, b.d_lists + fr_off[l] + k, (int)(e - k), ml);
+      k = e;
+    }
+  }
+  rbtk::timer_end(T_RECON);
+  if (rbtk::dev_sync()) { b.err = "kernel execution failed"; return b.err_code = RBT_ERR_NO_DEVICE; }
+  // per-picture error words and slice coverage
+  std::vector<RbtFrame> fr(nf);
+  if (rbtk::d2h(fr.data(), b.d_frames, nf * sizeof(RbtFrame))) { b.err = "device transfer failed"; return b.err_code = RBT_ERR_NO_DEVICE; }
+  for (size_t i = 0; i < nf; i++) if (fr[i].error) { b.err = "slice data decoding failed (code " + std::to_string(fr[i].error) + ")"; return b.err_code = RBT_ERR_BITSTREAM; }
+  return 0;
+}
+
+int decode_fetch(DecodeBatch& b, int stream, rbt_video* out, bool verify_md5) {
+  memset(out, 0, sizeof(*out));
+  int first = b.stream_first[stream], n = b.stream_count[stream];
+  if (n <= 0) return RBT_ERR_BITSTREAM;
+  const RbtStreamCfg& c = b.frames[first].cfg;
+  size_t fs = frame_samples(c);
+  out->width = c.w; out->height = c.h; out->bit_depth = c.bit_depth; out->n_frames = n;
+  out->data = (uint16_t*)malloc(fs * 2 * (size_t)n);
+  if (!out->data) return RBT_ERR_NOMEM;
+  for (int i = 0; i < n; i++) {
+    const RbtFrame& f = b.frames[first + i];
+    if (rbtk::d2h(out->data + fs * (size_t)i, f.out[0], fs * 2)) return RBT_ERR_NO_DEVICE;
+    if (verify_md5 && b.info[first + i].has_md5) {
+      out->md5_checked++;
+      const uint16_t* p = out->data + fs * (size_t)i; uint8_t h[16]; bool bad = false;
+      md5_plane_u16(p, c.w, c.h, c.bit_depth, h); bad |= memcmp(h, b.info[first + i].md5[0], 16) != 0;
+      md5_plane_u16(p + (size_t)c.w * c.h, c.cw, c.ch, c.bit_depth, h); bad |= memcmp(h, b.info[first + i].md5[1], 16) != 0;
+      md5_plane_u16(p + (size_t)c.w * c.h + (size_t)c.cw * c.ch, c.cw, c.ch, c.bit_depth, h); bad |= memcmp(h, b.info[first + i].md5[2], 16) != 0;
+      if (bad) out->md5_failed++;
+    }
+  }
+  return 0;
+}
+
+}  // namespace rbt

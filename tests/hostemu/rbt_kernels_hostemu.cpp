@@ -1,0 +1,60 @@
+// TEST-ONLY serial stand-in of csrc/rbt_kernels.h: runs the kernel bodies (rbt_parse.h, rbt_recon.h, rbt_filter.h,
+// rbt_encode.h) as plain host code so their logic can be debugged against the oracle in a container without a GPU.
+// Built into tests/hostemu/librbt_hostemu.so by tests/hostemu/Makefile. It is NOT part of the product: librbt.so is
+// linked against csrc/rbt_kernels.hip only and has no CPU path.
+#ifndef RBT_HOSTEMU
+#error "build with -DRBT_HOSTEMU"
+#endif
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include "../../rabbit-transcoding_amd/csrc/rbt_kernels.h"
+#include "../../rabbit-transcoding_amd/csrc/rbt_parse.h"
+#include "../../rabbit-transcoding_amd/csrc/rbt_recon.h"
+#include "../../rabbit-transcoding_amd/csrc/rbt_filter.h"
+#include "../../rabbit-transcoding_amd/csrc/rbt_encode.h"
+
+namespace rbtk {
+static double g_t[32][2];
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+int dev_init(int) { return 0; }
+const char* dev_name() { return "host emulation (test only)"; }
+void* dev_alloc(size_t n) { return malloc(n ? n : 1); }
+void dev_free(void* p) { free(p); }
+int h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); return 0; }
+int d2h(void* h, const void* d, size_t n) { memcpy(h, d, n); return 0; }
+int dev_memset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
+int dev_sync() { return 0; }
+void timer_begin(int id) { g_t[id][0] = now_ms(); }
+void timer_end(int id) { g_t[id][1] = now_ms(); }
+double timer_ms(int id) { return g_t[id][1] - g_t[id][0]; }
+
+void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices) {
+  for (int i = 0; i < n_slices; i++) { uint8_t st[RBT_CTX_COUNT + 3]; rbt_parse_slice(frames, slices, slice_list[i], rbsp, st); }
+}
+void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb) {
+  static RbtReconLds lds;
+  int n_diag = max_w_ctb + 2 * (max_h_ctb - 1);
+  for (int d = 0; d < n_diag; d++)
+    for (int k = 0; k < n_frames; k++) {
+      int fi = frame_list[k]; const RbtStreamCfg* g = &frames[fi].cfg;
+      for (int y = 0; y < g->h_ctb; y++) {
+        int x = d - 2 * y; if (x < 0 || x >= g->w_ctb) continue;
+        int addr = y * g->w_ctb + x;
+        if (frames[fi].ctb_slice[addr] == 0xFFFF) continue;
+        rbt_recon_ctb(frames, slices, fi, addr, &lds);
+      }
+    }
+}
+void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int) {
+  for (int dir = 0; dir < 2; dir++)
+    for (int k = 0; k < n_frames; k++) { RbtFrame* f = &frames[frame_list[k]]; for (int u = 0; u < f->cfg.w4 * f->cfg.h4; u++) rbt_deblock_unit(f, slices, u, dir); }
+}
+void launch_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int) {
+  for (int k = 0; k < n_frames; k++) {
+    RbtFrame* f = &frames[frame_list[k]];
+    for (int c = 0; c < 3; c++) { int pw = c ? f->cfg.cw : f->cfg.w, ph = c ? f->cfg.ch : f->cfg.h; for (int i = 0; i < pw * ph; i++) rbt_sao_sample(f, slices, c, i % pw, i / pw); }
+  }
+}
+#include "rbt_kernels_hostemu_enc.inc"
+}  // namespace rbtk

@@ -1,0 +1,57 @@
+"""GPU parity: HIP decode path (through the C ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+import oracle_lib as O
+import rbt_lib
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    R = rbt_lib.module()
+    c = R.Context(device=0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("seed", range(1, 41))
+def test_stress_streams(ctx, seed):
+    """random-syntax streams: all intra modes, NxN, TU trees, TS, bypass, AMP, AMVP/merge, TMVP, SAO, dQP, SDH, slices"""
+    w = [64, 96, 128, 80][seed % 4]; h = [64, 80, 48, 128][(seed // 4) % 4]
+    bd = 10 if seed % 3 else 8
+    fr = np.zeros((5, w * h * 3 // 2), np.uint16)
+    bs, rec = O.encode(fr, w, h, bd, qp=30, gop=2, stress_seed=seed, log2_ctb=0)
+    dec, dw, dh, dbd, chk, fail = ctx.decode(bs)
+    assert (dw, dh, dbd) == (w, h, bd) and chk == 5 and fail == 0
+    assert np.array_equal(dec, rec)
+
+
+@pytest.mark.parametrize("log2_ctb,rows", [(5, 1), (6, 0), (4, 2)])
+def test_product_streams(ctx, log2_ctb, rows):
+    m = synth.make_maps(256, 192, 31)
+    for key, qp in (("geo", 16), ("attr", 22)):
+        bs, rec = O.encode(m[key], 256, 192, 10, qp, gop=2, log2_ctb=log2_ctb, rows_per_slice=rows)
+        dec, w, h, bd, chk, fail = ctx.decode(bs)
+        assert fail == 0 and chk == 2 and np.array_equal(dec, rec)
+    bs, rec = O.encode(m["occ"], 128, 96, 8, 8, gop=1, lossless=1, log2_ctb=log2_ctb, rows_per_slice=rows)
+    dec, *_ = ctx.decode(bs)
+    assert np.array_equal(dec, m["occ"])
+
+
+def test_full_size_frame_pair(ctx):
+    """BASELINE.json size: 1280x1280 10-bit I/P pair, HM-like structure (CTB 64, one slice per picture); MD5 SEI self-check"""
+    m = synth.make_maps(1280, 1280, 1051)
+    bs, rec = O.encode(m["attr"], 1280, 1280, 10, 22, gop=2, log2_ctb=6, rows_per_slice=0)
+    dec, w, h, bd, chk, fail = ctx.decode(bs)
+    assert (w, h, bd, chk, fail) == (1280, 1280, 10, 2, 0)
+    assert np.array_equal(dec, rec)
+
+
+def test_corrupt_stream_is_rejected(ctx):
+    R = rbt_lib.module()
+    m = synth.make_maps(64, 64, 5)
+    bs, _ = O.encode(m["geo"], 64, 64, 10, 24, gop=2)
+    with pytest.raises(R.RbtError):
+        ctx.decode(bs[:40])
