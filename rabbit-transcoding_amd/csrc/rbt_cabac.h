@@ -11,7 +11,7 @@ enum {
   CTX_TRANSFORM_SKIP = 41, CTX_LAST_X = 43, CTX_LAST_Y = 61, CTX_CSBF = 79, CTX_SIG = 83, CTX_GT1 = 127, CTX_GT2 = 151
 };
 
-RBT_DEV void rbt_ctx_init(uint8_t* st, int init_type, int qp) {
+RBT_DEV void rbt_ctx_init(RBT_LDS_AS uint8_t* st, int init_type, int qp) {
   qp = rbt_clip3(0, 51, qp);
   RBT_PAR_FOR(i, RBT_CTX_COUNT) {
     int iv = k_ctx_init[init_type][i];
@@ -27,7 +27,7 @@ struct RbtCabacDec {
   const uint8_t* p; uint32_t size, pos;   // byte cursor of the next refill
   uint64_t buf; int nbuf;                 // bit reservoir (MSB first)
   uint32_t range, offset;
-  uint8_t* st;
+  RBT_LDS_AS uint8_t* st;
 };
 RBT_DEV uint32_t rbt_cd_bits(RbtCabacDec* c, int n) {
   if (n == 0) return 0;
@@ -40,7 +40,7 @@ RBT_DEV uint32_t rbt_cd_bits(RbtCabacDec* c, int n) {
   c->nbuf -= n;
   return r;
 }
-RBT_DEV void rbt_cd_start(RbtCabacDec* c, const uint8_t* p, uint32_t size, uint8_t* st) {
+RBT_DEV void rbt_cd_start(RbtCabacDec* c, const uint8_t* p, uint32_t size, RBT_LDS_AS uint8_t* st) {
   c->p = p; c->size = size; c->pos = 0; c->buf = 0; c->nbuf = 0; c->st = st; c->range = 510; c->offset = rbt_cd_bits(c, 9);
 }
 RBT_DEV int rbt_cd_bin(RbtCabacDec* c, int ctx) {
@@ -78,7 +78,7 @@ struct RbtCabacEnc {
   uint8_t* out; uint32_t cap, n;          // byte output (lane 0 stores)
   uint32_t acc; int nacc;                 // bit accumulator
   uint32_t low, range; int outstanding, first;
-  uint8_t* st;
+  RBT_LDS_AS uint8_t* st;
   int overflow;
 };
 RBT_DEV void rbt_ce_write_bit(RbtCabacEnc* c, int b) {
@@ -101,7 +101,7 @@ RBT_DEV void rbt_ce_renorm(RbtCabacEnc* c) {
     c->range <<= 1; c->low <<= 1;
   }
 }
-RBT_DEV void rbt_ce_start(RbtCabacEnc* c, uint8_t* st) { c->low = 0; c->range = 510; c->first = 1; c->outstanding = 0; c->st = st; }
+RBT_DEV void rbt_ce_start(RbtCabacEnc* c, RBT_LDS_AS uint8_t* st) { c->low = 0; c->range = 510; c->first = 1; c->outstanding = 0; c->st = st; }
 RBT_DEV void rbt_ce_bin(RbtCabacEnc* c, int ctx, int bin) {
   int s = c->st[ctx] >> 1, mps = c->st[ctx] & 1;
   uint32_t lps = k_range_lps[s][(c->range >> 6) & 3];

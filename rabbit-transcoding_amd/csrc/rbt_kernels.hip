@@ -42,7 +42,7 @@ double timer_ms(int id) { float ms = 0; if (hipEventElapsedTime(&ms, g_ev[id][0]
 // one wave per slice segment: wave-uniform CABAC parse (rbt_parse.h)
 __global__ void __launch_bounds__(64) k_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list) {
   __shared__ uint8_t ctx_states[RBT_CTX_COUNT + 3];
-  rbt_parse_slice(frames, slices, slice_list[blockIdx.x], rbsp, ctx_states);
+  rbt_parse_slice(frames, slices, slice_list[blockIdx.x], rbsp, RBT_LDS_CAST(uint8_t, ctx_states));
 }
 // one wave per CTB on anti-diagonal d (x + 2y == d): left, above-left, above and above-right CTBs are complete
 __global__ void __launch_bounds__(64) k_recon_diag(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int d) {
@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(64) k_recon_diag(RbtFrame* frames, const RbtSl
   if (y >= g->h_ctb || x < 0 || x >= g->w_ctb) return;
   int addr = y * g->w_ctb + x;
   if (frames[fi].ctb_slice[addr] == 0xFFFF) return;     // CTB not covered by any decoded slice
-  rbt_recon_ctb(frames, slices, fi, addr, &lds);
+  rbt_recon_ctb(frames, slices, fi, addr, RBT_LDS_CAST(RbtReconLds, &lds));
 }
 __global__ void __launch_bounds__(256) k_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int dir) {
   RbtFrame* f = &frames[frame_list[blockIdx.y]];

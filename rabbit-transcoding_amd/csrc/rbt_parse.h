@@ -11,6 +11,11 @@
 #include "rbt_types.h"
 
 #define RBT_NO_REFPOC ((int32_t)0x80000000)
+#if defined(RBT_TRACE) && !defined(RBT_HOSTEMU)
+#define RBT_TR(...) do { if (RBT_LANE0) printf(__VA_ARGS__); } while (0)
+#else
+#define RBT_TR(...) do { } while (0)
+#endif
 
 struct RbtParse {
   RbtFrame* f; RbtSlice* sl; const RbtFrame* frames; int slice_idx;
@@ -41,12 +46,13 @@ RBT_DEV void pz_fill_pm(const RbtParse* s, int x, int y, int w, int h, int keep_
   RBT_PAR_FOR(i, n) { int k = base + (i / w4) * st + (i % w4); s->f->pm[k] = (uint8_t)((s->f->pm[k] & keep_mask) | v); }
 }
 RBT_DEV void pz_mark_edges(const RbtParse* s, int x, int y, int w, int h, int vbits, int hbits) {
+  // two passes: the corner unit belongs to both the left column and the top row, and a read-modify-write of the same
+  // byte by two lanes of one instruction would lose one of the updates
   int nv = h >> 2, nh = w >> 2;
-  RBT_PAR_FOR(i, nv + nh) {
-    if (i < nv) s->f->edges[pz_idx(s, x, y + 4 * i)] |= (uint8_t)vbits;
-    else s->f->edges[pz_idx(s, x + 4 * (i - nv), y)] |= (uint8_t)hbits;
-  }
-  RBT_SYNC();   // corner unit is touched by both halves in consecutive calls; keep read-modify-writes ordered
+  RBT_PAR_FOR(i, nv) s->f->edges[pz_idx(s, x, y + 4 * i)] |= (uint8_t)vbits;
+  RBT_SYNC();
+  RBT_PAR_FOR(i, nh) s->f->edges[pz_idx(s, x + 4 * i, y)] |= (uint8_t)hbits;
+  RBT_SYNC();
 }
 RBT_DEV void pz_emit(RbtParse* s, const RbtCmd& cmd) {
   if ((int)s->n_cmds >= s->f->cmd_cap) { s->error = 3; return; }
@@ -562,7 +568,7 @@ RBT_DEV void pz_coding_quadtree(RbtParse* s, int x0, int y0, int log2) {
 }
 
 // Entry: parses one slice segment. `ctx_states` is a RBT_CTX_COUNT byte scratch (LDS on the GPU).
-RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, const uint8_t* rbsp, uint8_t* ctx_states) {
+RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, const uint8_t* rbsp, RBT_LDS_AS uint8_t* ctx_states) {
   RbtParse s;
   s.sl = &slices[slice_idx]; s.frames = frames; s.f = &frames[s.sl->frame]; s.slice_idx = slice_idx; s.cfg = s.f->cfg; s.error = 0;
   const RbtSlice* sl = s.sl;

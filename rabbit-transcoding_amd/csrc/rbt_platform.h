@@ -18,6 +18,8 @@
 #define RBT_SYNC() do { } while (0)
 #define RBT_LANE0 1
 #define RBT_NTHREADS 1
+#define RBT_LDS_AS
+#define RBT_LDS_CAST(T, p) (p)
 #else
 #include <hip/hip_runtime.h>
 #define RBT_DEV static __device__ __forceinline__
@@ -26,6 +28,12 @@
 #define RBT_SYNC() __syncthreads()
 #define RBT_LANE0 (threadIdx.x == 0)
 #define RBT_NTHREADS ((int)blockDim.x)
+// LDS objects are always reached through address_space(3) pointers (ds_* instructions). A generic (flat) pointer into
+// LDS is unsafe on gfx950: the compiler may fold part of an index into the instruction's immediate offset, and a base
+// register that underflows the LDS aperture (object at LDS offset 0, negative partial index) is treated as a global
+// address and faults with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.
+#define RBT_LDS_AS __attribute__((address_space(3)))
+#define RBT_LDS_CAST(T, p) ((RBT_LDS_AS T*)(uintptr_t)(p))
 #endif
 
 RBT_DEV int rbt_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }

@@ -38,7 +38,7 @@ RBT_DEV int rc_avail(const RbtFrame* f, int xc, int yc, int xn, int yn) {
 RBT_DEV int rc_tcoef(int N, int is_dst, int k, int n) { return is_dst ? k_dst4[k][n] : k_dct32[k * (32 / N)][n]; }
 
 // ---- intra prediction of one TB into lds->pred (8.4.4.2). `src` is the plane neighbours are read from. ----
-RBT_DEV void rc_intra_pred(const RbtFrame* f, const uint16_t* src, int c_idx, int x0, int y0, int log2, int mode, RbtReconLds* l) {
+RBT_DEV void rc_intra_pred(const RbtFrame* f, const uint16_t* src, int c_idx, int x0, int y0, int log2, int mode, RBT_LDS_AS RbtReconLds* l) {
   const RbtStreamCfg* g = &f->cfg;
   int N = 1 << log2, sh = c_idx ? 1 : 0, pw = c_idx ? g->cw : g->w, bd = g->bit_depth, maxv = (1 << bd) - 1;
   int xcL = x0 << sh, ycL = y0 << sh, tot = 4 * N + 1;
@@ -147,7 +147,7 @@ RBT_DEV void rc_intra_pred(const RbtFrame* f, const uint16_t* src, int c_idx, in
 }
 
 // ---- scaling (8.6.3, flat lists) of the TB's levels from the coefficient plane into lds->res ----
-RBT_DEV void rc_dequant(const int16_t* plane, int pst, int x0, int y0, int log2, int qp, int bd, RbtReconLds* l) {
+RBT_DEV void rc_dequant(const int16_t* plane, int pst, int x0, int y0, int log2, int qp, int bd, RBT_LDS_AS RbtReconLds* l) {
   int N = 1 << log2, bd_shift = bd + log2 - 5;
   int scale = (16 * k_dequant_scale[qp % 6]) << (qp / 6);
   long long add = 1ll << (bd_shift - 1);
@@ -159,7 +159,7 @@ RBT_DEV void rc_dequant(const int16_t* plane, int pst, int x0, int y0, int log2,
   RBT_SYNC();
 }
 // ---- inverse transform of lds->res in place (8.6.4.2) ----
-RBT_DEV void rc_inv_transform(int log2, int is_dst, int ts, int bd, RbtReconLds* l) {
+RBT_DEV void rc_inv_transform(int log2, int is_dst, int ts, int bd, RBT_LDS_AS RbtReconLds* l) {
   int N = 1 << log2, sh = 20 - bd;
   if (ts) {
     RBT_PAR_FOR(i, N * N) l->res[i] = (int16_t)((((int)l->res[i] << 7) + (1 << (sh - 1))) >> sh);
@@ -181,7 +181,7 @@ RBT_DEV void rc_inv_transform(int log2, int is_dst, int ts, int bd, RbtReconLds*
 }
 
 // ---- one TB of the decoder: prediction (intra) + residual, written to f->pix ----
-RBT_DEV void rc_decode_tb(RbtFrame* f, int c_idx, int x0, int y0, int log2, int intra, int mode, int cbf, int ts, int tq_bypass, int qp, RbtReconLds* l) {
+RBT_DEV void rc_decode_tb(RbtFrame* f, int c_idx, int x0, int y0, int log2, int intra, int mode, int cbf, int ts, int tq_bypass, int qp, RBT_LDS_AS RbtReconLds* l) {
   const RbtStreamCfg* g = &f->cfg;
   int N = 1 << log2, pw = c_idx ? g->cw : g->w, bd = g->bit_depth, maxv = (1 << bd) - 1;
   uint16_t* p = f->pix[c_idx];
@@ -237,7 +237,7 @@ RBT_DEV void rc_inter_pu(RbtFrame* f, const RbtFrame* ref, int x0, int y0, int w
 }
 
 // ---- reconstruct one CTB of the decoder from its command list ----
-RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_idx, int ctb_addr, RbtReconLds* l) {
+RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_idx, int ctb_addr, RBT_LDS_AS RbtReconLds* l) {
   RbtFrame* f = &frames[frame_idx];
   const RbtStreamCfg* g = &f->cfg;
   int cx = (ctb_addr % g->w_ctb) << g->log2_ctb, cy = (ctb_addr / g->w_ctb) << g->log2_ctb;
