@@ -732,7 +732,8 @@ static void analyse_ctb_intra(enc* e, int cx, int cy) {
       int bi = by * nb + bx;
       e->an_cost[si][bi] = 0x7FFFFFFF; e->an_mode[si][bi] = 0;
       if (x0 >= sps->width || y0 >= sps->height) { e->an_cost[si][bi] = 0; continue; }
-      if (x0 + S > sps->width || y0 + S > sps->height) { e->an_cost[si][bi] = 0x3FFFFFFF; continue; }
+      if (x0 + S > sps->width || y0 + S > sps->height) {   /* block straddles the picture edge: never a CU, but its inside part counts as coded */
+        e->an_cost[si][bi] = 0x0FFFFFFF; set_rect8(m->done, m->w4, x0, y0, imin(S, sps->width - x0), imin(S, sps->height - y0), 1); continue; }
       for (int k = 0; k < 11; k++) {
         int mode = k_intra_cand[k];
         hevc_intra_pred_buf(&srcview, m, 0, x0, y0, 3 + si, mode, pred);

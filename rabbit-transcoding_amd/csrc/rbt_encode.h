@@ -1,2 +1,502 @@
-// placeholder, replaced below
+// RBT-E1 encoder kernels: the MI355X replacement of the libx265 encode the reference drives through libavcodec
+// (PCCTranscoder.cpp:548-592 encodeVideo, :825-904 setEncoderOptions) and of resize_frame2 (:594-646).
+// Bit-exact counterpart of oracle/hevc_enc.c (product mode). Stages, all one 64-lane wave per work item:
+//   en_analyse_ctb     open-loop intra analysis of one CTB: 11 candidate modes x {8,16,32}, bottom-up quadtree (parallel
+//                      over every CTB of every I picture)
+//   en_intra_ctb       closed-loop intra coding of one CTB: predict, forward DCT, dead-zone quantiser, reconstruction
+//                      (serial along a slice, parallel over slices = CTB rows and pictures)
+//   en_inter_ctb       P pictures: zero-motion merge from the reconstructed IDR, 16x16 CUs, skip merging (fully parallel)
+//   en_entropy_slice   wave-uniform CABAC encoding of one slice segment (parallel over slices)
+//   en_pool_sample     2x2 OR-pool of the occupancy map
 #pragma once
+#include "rbt_cabac.h"
+#include "rbt_recon.h"
+
+RBT_CONST uint16_t k_lambda16[76] = {3,    3,    4,    4,    5,    5,    6,    7,    8,    9,    10,   11,   12,   14,   15,   17,   19,   22,   24,
+                                     27,   30,   34,   38,   43,   48,   54,   61,   68,   77,   86,   97,   108,  122,  137,  153,  172,  193,  217,
+                                     244,  273,  307,  344,  387,  434,  487,  547,  614,  689,  773,  868,  974,  1093, 1227, 1378, 1546, 1736, 1948,
+                                     2187, 2454, 2755, 3092, 3471, 3896, 4373, 4909, 5510, 6185, 6942, 7792, 8747, 9818, 11020, 12370, 13884, 15585, 17493};
+RBT_CONST uint8_t k_intra_cand[11] = {0, 1, 26, 10, 2, 6, 14, 18, 22, 30, 34};
+#define RBT_SPLIT_BITS 24
+#define RBT_PARTIAL_COST 0x0FFFFFFF
+
+struct RbtEncLds {
+  RbtReconLds rc;
+  int16_t lvl[32 * 32];      // quantised levels of the current TB
+  int32_t red[64];           // wave reduction scratch
+  int32_t cost[3][16];       // analysis: best SAD per block [size][block]
+  uint8_t mode[3][16];
+  uint8_t split[3][16];
+  uint16_t cg_mask[64];      // entropy: significance mask of each 4x4 coefficient group (bit n = scan position n)
+  uint8_t ctx[RBT_CTX_COUNT + 3];
+};
+
+// sum of v over the lanes of the wave (host emulation: the PAR_FOR already accumulated everything)
+RBT_DEV int en_wave_sum(int v, RBT_LDS_AS RbtEncLds* l) {
+#ifdef RBT_HOSTEMU
+  (void)l; return v;
+#else
+  l->red[threadIdx.x] = v;
+  RBT_SYNC();
+  int s = 0;
+  for (int i = 0; i < 64; i++) s += l->red[i];
+  RBT_SYNC();
+  return s;
+#endif
+}
+RBT_DEV int en_chroma_qp(const RbtFrame* f, const RbtSlice* sl, int c_idx, int qp_y) {
+  int off = c_idx == 1 ? f->cfg.cb_qp_offset + sl->cb_qp_offset : f->cfg.cr_qp_offset + sl->cr_qp_offset;
+  int bdo = 6 * (f->cfg.bit_depth - 8);
+  int qpi = rbt_clip3(-bdo, 57, qp_y + off);
+  return (qpi < 0 ? qpi : rbt_chroma_qp(qpi)) + bdo;
+}
+
+// ------------------------------------------------------------------------------------------------ analysis (I pictures)
+RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtEncLds* l) {
+  const RbtStreamCfg* g = &f->cfg;
+  int ctb = 1 << g->log2_ctb, cx = (ctb_addr % g->w_ctb) << g->log2_ctb, cy = (ctb_addr / g->w_ctb) << g->log2_ctb;
+  const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
+  RBT_LDS_AS RbtReconLds* rl = &l->rc;
+  // CTBs larger than 32 are analysed as independent 32x32 quadrants (a 64x64 intra CU is always split)
+  int nq = ctb > 32 ? 2 : 1, qs = ctb > 32 ? 32 : ctb;
+  for (int q = 0; q < nq * nq; q++) {
+    int qx = cx + (q % nq) * 32, qy = cy + (q / nq) * 32;
+    if (nq > 1 && (qx >= g->w || qy >= g->h)) continue;
+    for (int si = 0; si < 3; si++) {
+      int S = 8 << si; if (S > qs) break;
+      int nb = qs / S;
+      for (int b = 0; b < nb * nb; b++) {
+        int x0 = qx + (b % nb) * S, y0 = qy + (b / nb) * S, best = 0x7FFFFFFF, bmode = 0;
+        if (x0 >= g->w || y0 >= g->h) best = 0;
+        else if (x0 + S > g->w || y0 + S > g->h) best = RBT_PARTIAL_COST;
+        else {
+          for (int k = 0; k < 11; k++) {
+            int mode = k_intra_cand[k];
+            rc_intra_pred(f, f->src[0], 0, x0, y0, 3 + si, mode, rl);
+            int part = 0;
+            RBT_PAR_FOR(i, S * S) { int x = i & (S - 1), y = i >> (3 + si); part += rbt_abs((int)f->src[0][(size_t)(y0 + y) * g->w + x0 + x] - (int)rl->pred[i]); }
+            int sad = en_wave_sum(part, l);
+            if (sad < best) { best = sad; bmode = mode; }
+          }
+        }
+        if (RBT_LANE0) { l->cost[si][b] = best; l->mode[si][b] = (uint8_t)bmode; }
+      }
+    }
+    RBT_SYNC();
+    int lam = k_lambda16[rbt_clip3(0, 75, sl->qp + 6 * (g->bit_depth - 8))], pen = (lam * RBT_SPLIT_BITS) >> 4;
+    for (int si = 1; si < 3; si++) {
+      int S = 8 << si; if (S > qs) break;
+      int nb = qs / S, nbc = nb * 2;
+      RBT_PAR_FOR(b, nb * nb) {
+        int bx = b % nb, by = b / nb;
+        int child = l->cost[si - 1][(2 * by) * nbc + 2 * bx] + l->cost[si - 1][(2 * by) * nbc + 2 * bx + 1] + l->cost[si - 1][(2 * by + 1) * nbc + 2 * bx] +
+                    l->cost[si - 1][(2 * by + 1) * nbc + 2 * bx + 1] + pen;
+        int split = child < l->cost[si][b];
+        l->split[si][b] = (uint8_t)split;
+        if (split) l->cost[si][b] = child;
+      }
+      RBT_SYNC();
+    }
+    // leaf CU size / mode per 8x8 unit of the quadrant
+    int n8 = qs / 8;
+    RBT_PAR_FOR(u, n8 * n8) {
+      int ux = u % n8, uy = u / n8, x = qx + ux * 8, y = qy + uy * 8;
+      if (x < g->w && y < g->h) {
+        int lg = 3, mode = l->mode[0][uy * n8 + ux];
+        int inside32 = qx + 32 <= g->w && qy + 32 <= g->h, inside16 = (x & ~15) + 16 <= g->w && (y & ~15) + 16 <= g->h;
+        int b16 = (uy / 2) * (n8 / 2) + ux / 2;
+        int split32 = qs >= 32 ? (inside32 ? l->split[2][0] : 1) : 1;
+        int split16 = qs >= 16 ? (inside16 ? l->split[1][b16] : 1) : 1;
+        if (qs >= 32 && !split32) { lg = 5; mode = l->mode[2][0]; }
+        else if (qs >= 16 && !split16) { lg = 4; mode = l->mode[1][b16]; }
+        int k = (y >> 3) * f->w8 + (x >> 3);
+        f->cu_log2[k] = (uint8_t)lg; f->cu_mode[k] = (uint8_t)mode;
+      }
+    }
+    RBT_SYNC();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ transform / quantiser
+// forward transform of l->rc.res (residual, N x N) into l->rc.res (coefficients); HM shift convention
+RBT_DEV void en_fwd_transform(int log2, int is_dst, int bd, RBT_LDS_AS RbtReconLds* r) {
+  int N = 1 << log2, s1 = log2 + bd - 9, s2 = log2 + 6;
+  RBT_PAR_FOR(i, N * N) {
+    int k = i & (N - 1), y = i >> log2, s = 0;
+    for (int x = 0; x < N; x++) s += rc_tcoef(N, is_dst, k, x) * r->res[y * N + x];
+    r->tmp[i] = s1 > 0 ? (s + (1 << (s1 - 1))) >> s1 : s;
+  }
+  RBT_SYNC();
+  RBT_PAR_FOR(i, N * N) {
+    int kh = i & (N - 1), kv = i >> log2, s = 0;
+    for (int y = 0; y < N; y++) s += rc_tcoef(N, is_dst, kv, y) * r->tmp[y * N + kh];
+    r->res[i] = (int16_t)rbt_clip3(-32768, 32767, (s + (1 << (s2 - 1))) >> s2);
+  }
+  RBT_SYNC();
+}
+// dead-zone quantiser of l->rc.res into l->lvl; returns the number of non-zero levels
+RBT_DEV int en_quant(int log2, int qp, int bd, int is_intra, RBT_LDS_AS RbtEncLds* l) {
+  int N = 1 << log2, qbits = 14 + qp / 6 + (15 - bd - log2), sc = k_quant_scale[qp % 6], part = 0;
+  long long add = (long long)(is_intra ? 171 : 85) << (qbits - 9);
+  RBT_PAR_FOR(i, N * N) {
+    int c = l->rc.res[i], a = rbt_abs(c);
+    long long q = ((long long)a * sc + add) >> qbits;
+    if (q > 32767) q = 32767;
+    l->lvl[i] = (int16_t)(c < 0 ? -q : q);
+    part += q != 0;
+  }
+  int nz = en_wave_sum(part, l);
+  return nz;
+}
+// codes one TB: residual = src - prediction (prediction in l->rc.pred), levels -> coef plane, reconstruction -> pix. Returns cbf.
+RBT_DEV int en_code_tb(RbtFrame* f, int c_idx, int x0, int y0, int log2, int qp, int is_intra, RBT_LDS_AS RbtEncLds* l) {
+  const RbtStreamCfg* g = &f->cfg;
+  int N = 1 << log2, pw = c_idx ? g->cw : g->w, bd = g->bit_depth, maxv = (1 << bd) - 1;
+  const uint16_t* sp = f->src[c_idx]; uint16_t* rp = f->pix[c_idx]; int16_t* cp = f->coef[c_idx];
+  RBT_PAR_FOR(i, N * N) { int x = i & (N - 1), y = i >> log2; l->rc.res[i] = (int16_t)((int)sp[(size_t)(y0 + y) * pw + x0 + x] - (int)l->rc.pred[i]); }
+  RBT_SYNC();
+  int nz;
+  if (f->lossless) {
+    int part = 0;
+    RBT_PAR_FOR(i, N * N) { l->lvl[i] = l->rc.res[i]; part += l->rc.res[i] != 0; }
+    nz = en_wave_sum(part, l);
+  } else {
+    en_fwd_transform(log2, c_idx == 0 && log2 == 2 && is_intra, bd, &l->rc);
+    nz = en_quant(log2, qp, bd, is_intra, l);
+  }
+  RBT_SYNC();
+  RBT_PAR_FOR(i, N * N) { int x = i & (N - 1), y = i >> log2; cp[(size_t)(y0 + y) * pw + x0 + x] = l->lvl[i]; }
+  if (nz && !f->lossless) {
+    int bd_shift = bd + log2 - 5, scale = (16 * k_dequant_scale[qp % 6]) << (qp / 6);
+    long long add = 1ll << (bd_shift - 1);
+    RBT_PAR_FOR(i, N * N) { long long v = ((long long)l->lvl[i] * scale + add) >> bd_shift; l->rc.res[i] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+    RBT_SYNC();
+    rc_inv_transform(log2, c_idx == 0 && log2 == 2 && is_intra, 0, bd, &l->rc);
+  } else if (nz) {
+    RBT_PAR_FOR(i, N * N) l->rc.res[i] = l->lvl[i];
+    RBT_SYNC();
+  }
+  RBT_PAR_FOR(i, N * N) {
+    int x = i & (N - 1), y = i >> log2;
+    rp[(size_t)(y0 + y) * pw + x0 + x] = (uint16_t)(nz ? rbt_clip3(0, maxv, (int)l->rc.pred[i] + l->rc.res[i]) : l->rc.pred[i]);
+  }
+  RBT_SYNC();
+  return nz != 0;
+}
+RBT_DEV void en_fill_cu_maps(RbtFrame* f, int x0, int y0, int N, int pm_val, int qp_y, int cbf_bits_or_flags, int set_flags) {
+  const RbtStreamCfg* g = &f->cfg;
+  int n4 = N >> 2, n8 = N >> 3;
+  RBT_PAR_FOR(i, n4 * n4) {
+    int k = ((y0 >> 2) + i / n4) * g->w4 + (x0 >> 2) + i % n4;
+    f->pm[k] = (uint8_t)pm_val; f->qp[k] = (int8_t)qp_y;
+    int e = 0;
+    if (i % n4 == 0) e |= RBT_EV_TU | RBT_EV_PU;
+    if (i / n4 == 0) e |= RBT_EH_TU | RBT_EH_PU;
+    f->edges[k] = (uint8_t)e;
+  }
+  if (set_flags) RBT_PAR_FOR(i, n8 * n8) { int k = ((y0 >> 3) + i / n8) * f->w8 + (x0 >> 3) + i % n8; f->cu_flags[k] = (uint8_t)cbf_bits_or_flags; }
+  RBT_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------------ I pictures: one CTB
+RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtEncLds* l) {
+  const RbtStreamCfg* g = &f->cfg;
+  int ctb = 1 << g->log2_ctb, cx = (ctb_addr % g->w_ctb) << g->log2_ctb, cy = (ctb_addr / g->w_ctb) << g->log2_ctb;
+  const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
+  int qp_y = sl->qp, bd = g->bit_depth;
+  int qp_l = qp_y + 6 * (bd - 8), qp_cb = en_chroma_qp(f, sl, 1, qp_y), qp_cr = en_chroma_qp(f, sl, 2, qp_y);
+  int n8 = ctb / 8;
+  // leaf CUs in z-order: walk 8x8 units in Morton order, a CU is coded when its first unit is reached
+  for (int z = 0; z < n8 * n8; z++) {
+    int ux = 0, uy = 0;
+    for (int b = 0; b < 3; b++) { ux |= ((z >> (2 * b)) & 1) << b; uy |= ((z >> (2 * b + 1)) & 1) << b; }
+    int x0 = cx + ux * 8, y0 = cy + uy * 8;
+    if (x0 >= g->w || y0 >= g->h) continue;
+    int k8 = (y0 >> 3) * f->w8 + (x0 >> 3);
+    int lg = f->cu_log2[k8], N = 1 << lg;
+    if ((x0 & (N - 1)) || (y0 & (N - 1))) continue;
+    int mode = f->cu_mode[k8];
+    rc_intra_pred(f, f->pix[0], 0, x0, y0, lg, mode, &l->rc);
+    int cbf = en_code_tb(f, 0, x0, y0, lg, qp_l, 1, l) ? RBT_CU_CBF_Y : 0;
+    rc_intra_pred(f, f->pix[1], 1, x0 >> 1, y0 >> 1, lg - 1, mode, &l->rc);
+    if (en_code_tb(f, 1, x0 >> 1, y0 >> 1, lg - 1, qp_cb, 1, l)) cbf |= RBT_CU_CBF_CB;
+    rc_intra_pred(f, f->pix[2], 2, x0 >> 1, y0 >> 1, lg - 1, mode, &l->rc);
+    if (en_code_tb(f, 2, x0 >> 1, y0 >> 1, lg - 1, qp_cr, 1, l)) cbf |= RBT_CU_CBF_CR;
+    en_fill_cu_maps(f, x0, y0, N, RBT_MODE_INTRA | (f->lossless ? RBT_PM_TQ_BYPASS : 0) | ((cbf & RBT_CU_CBF_Y) ? RBT_PM_NZ : 0), qp_y, cbf, 1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ P pictures: one CTB
+RBT_DEV void en_inter_ctb(RbtFrame* frames, RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtEncLds* l) {
+  const RbtStreamCfg* g = &f->cfg;
+  const RbtFrame* ref = &frames[f->ref_frame];
+  int ctb = 1 << g->log2_ctb, cx = (ctb_addr % g->w_ctb) << g->log2_ctb, cy = (ctb_addr / g->w_ctb) << g->log2_ctb;
+  const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
+  int qp_y = sl->qp, bd = g->bit_depth;
+  int qp[3] = {qp_y + 6 * (bd - 8), en_chroma_qp(f, sl, 1, qp_y), en_chroma_qp(f, sl, 2, qp_y)};
+  int n16 = ctb / 16;
+  for (int b = 0; b < n16 * n16; b++) {
+    int x0 = cx + (b % n16) * 16, y0 = cy + (b / n16) * 16;
+    if (x0 >= g->w || y0 >= g->h) continue;
+    int cbf = 0;
+    for (int c = 0; c < 3; c++) {
+      int sh = c ? 1 : 0, S = 16 >> sh, pw = c ? g->cw : g->w;
+      const uint16_t* rp = ref->out[c];
+      RBT_PAR_FOR(i, S * S) { int x = i & (S - 1), y = i / S; l->rc.pred[i] = rp[(size_t)((y0 >> sh) + y) * pw + (x0 >> sh) + x]; }
+      RBT_SYNC();
+      if (en_code_tb(f, c, x0 >> sh, y0 >> sh, 4 - sh, qp[c], 0, l)) cbf |= 1 << c;
+    }
+    int flags = cbf | (cbf ? 0 : RBT_CU_SKIP);
+    // 16x16 CU maps; merged skips are rewritten below
+    int n4 = 4;
+    RBT_PAR_FOR(i, n4 * n4) {
+      int k = ((y0 >> 2) + i / n4) * g->w4 + (x0 >> 2) + i % n4;
+      f->pm[k] = (uint8_t)((cbf ? RBT_MODE_INTER : RBT_MODE_SKIP) | ((cbf & 1) ? RBT_PM_NZ : 0));
+      f->qp[k] = (int8_t)qp_y; f->mv[2 * k] = 0; f->mv[2 * k + 1] = 0; f->ref[k] = 0; f->refpoc[k] = f->ref_poc;
+      int e = 0; if (i % n4 == 0) e |= RBT_EV_TU | RBT_EV_PU; if (i / n4 == 0) e |= RBT_EH_TU | RBT_EH_PU;
+      f->edges[k] = (uint8_t)e;
+    }
+    RBT_PAR_FOR(i, 4) { int k = ((y0 >> 3) + i / 2) * f->w8 + (x0 >> 3) + i % 2; f->cu_flags[k] = (uint8_t)flags; f->cu_log2[k] = 4; f->cu_mode[k] = 1; }
+    RBT_SYNC();
+  }
+  // merge skips up the tree: a node whose four children are skip CUs becomes one skip CU
+  for (int lg = 5; lg <= g->log2_ctb; lg++) {
+    int S = 1 << lg, nb = ctb / S;
+    for (int b = 0; b < nb * nb; b++) {
+      int x0 = cx + (b % nb) * S, y0 = cy + (b / nb) * S, h = S >> 1;
+      if (x0 + S > g->w || y0 + S > g->h) continue;
+      int all = 1;
+      for (int c = 0; c < 4; c++) {
+        int k = ((y0 + (c >> 1) * h) >> 3) * f->w8 + ((x0 + (c & 1) * h) >> 3);
+        if (!(f->cu_flags[k] & RBT_CU_SKIP) || f->cu_log2[k] != lg - 1) all = 0;
+      }
+      if (!all) continue;
+      int n8 = S >> 3, n4 = S >> 2;
+      RBT_PAR_FOR(i, n8 * n8) { int k = ((y0 >> 3) + i / n8) * f->w8 + (x0 >> 3) + i % n8; f->cu_log2[k] = (uint8_t)lg; }
+      RBT_PAR_FOR(i, n4 * n4) {
+        int k = ((y0 >> 2) + i / n4) * g->w4 + (x0 >> 2) + i % n4;
+        int e = 0; if (i % n4 == 0) e |= RBT_EV_TU | RBT_EV_PU; if (i / n4 == 0) e |= RBT_EH_TU | RBT_EH_PU;
+        f->edges[k] = (uint8_t)e;
+      }
+      RBT_SYNC();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ entropy coding
+struct RbtEnt { RbtFrame* f; const RbtSlice* sl; int slice_idx; RbtCabacEnc c; RBT_LDS_AS RbtEncLds* l; };
+
+// residual_coding (7.3.8.11) of the TB whose levels sit in the coefficient plane
+RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, int x0, int y0, int log2, int scan_idx) {
+  RbtCabacEnc* c = &s->c; RBT_LDS_AS RbtEncLds* l = s->l; const RbtFrame* f = s->f;
+  int N = 1 << log2, pw = c_idx ? f->cfg.cw : f->cfg.w;
+  const int16_t* cp = f->coef[c_idx];
+  RBT_PAR_FOR(i, N * N) { int x = i & (N - 1), y = i >> log2; l->lvl[i] = cp[(size_t)(y0 + y) * pw + x0 + x]; }
+  RBT_SYNC();
+  const uint8_t* sb_scan = k_scan[scan_idx][log2 - 2];
+  const uint8_t* pos_scan = k_scan[scan_idx][2];
+  int n_sb = 1 << (2 * (log2 - 2));
+  RBT_PAR_FOR(i, n_sb) {
+    int xs = sb_scan[i] & 15, ys = sb_scan[i] >> 4, m = 0;
+    for (int n = 0; n < 16; n++) if (l->lvl[((ys << 2) + (pos_scan[n] >> 4)) * N + (xs << 2) + (pos_scan[n] & 15)]) m |= 1 << n;
+    l->cg_mask[i] = (uint16_t)m;
+  }
+  RBT_SYNC();
+  int last_sb = 0;
+  for (int i = n_sb - 1; i >= 0; i--) if (l->cg_mask[i]) { last_sb = i; break; }
+  int last_pos = 31 - __builtin_clz((unsigned)l->cg_mask[last_sb]);
+  int lx = ((sb_scan[last_sb] & 15) << 2) + (pos_scan[last_pos] & 15), ly = ((sb_scan[last_sb] >> 4) << 2) + (pos_scan[last_pos] >> 4);
+  int cx = lx, cy = ly;
+  if (scan_idx == 2) { cx = ly; cy = lx; }
+  int ctx_off, ctx_shift;
+  if (c_idx == 0) { ctx_off = 3 * (log2 - 2) + ((log2 - 1) >> 2); ctx_shift = (log2 + 1) >> 2; }
+  else { ctx_off = 15; ctx_shift = log2 - 2; }
+  int maxp = (log2 << 1) - 1, px = k_group_idx[cx], py = k_group_idx[cy];
+  for (int i = 0; i < px; i++) rbt_ce_bin(c, CTX_LAST_X + ctx_off + (i >> ctx_shift), 1);
+  if (px < maxp) rbt_ce_bin(c, CTX_LAST_X + ctx_off + (px >> ctx_shift), 0);
+  for (int i = 0; i < py; i++) rbt_ce_bin(c, CTX_LAST_Y + ctx_off + (i >> ctx_shift), 1);
+  if (py < maxp) rbt_ce_bin(c, CTX_LAST_Y + ctx_off + (py >> ctx_shift), 0);
+  if (px > 3) rbt_ce_bypass_n(c, (uint32_t)(cx - k_min_in_group[px]), (px >> 1) - 1);
+  if (py > 3) rbt_ce_bypass_n(c, (uint32_t)(cy - k_min_in_group[py]), (py >> 1) - 1);
+  uint64_t csbf = 0;
+  int sbw = 1 << (log2 - 2), greater1_ctx = 1, first_sb_done = 0;
+  for (int i = last_sb; i >= 0; i--) {
+    int xs = sb_scan[i] & 15, ys = sb_scan[i] >> 4;
+    int right = xs + 1 < sbw ? (int)((csbf >> (ys * 8 + xs + 1)) & 1) : 0, below = ys + 1 < sbw ? (int)((csbf >> ((ys + 1) * 8 + xs)) & 1) : 0;
+    uint32_t mask = l->cg_mask[i];
+    int infer_dc = 0, coded;
+    if (i < last_sb && i > 0) { coded = mask != 0; rbt_ce_bin(c, CTX_CSBF + rbt_min(right + below, 1) + (c_idx ? 2 : 0), coded); infer_dc = 1; }
+    else coded = 1;
+    if (!coded) continue;
+    csbf |= 1ull << (ys * 8 + xs);
+    int start = i == last_sb ? last_pos - 1 : 15, prev_csbf = right | (below << 1);
+    for (int n = start; n >= 0; n--) {
+      int xp = pos_scan[n] & 15, yp = pos_scan[n] >> 4, xc = (xs << 2) + xp, yc = (ys << 2) + yp;
+      int sig = (int)((mask >> n) & 1);
+      if (n > 0 || !infer_dc) {
+        int sc;
+        if (log2 == 2) sc = k_sig_ctx_4x4[(yc << 2) + xc];
+        else if (xc + yc == 0) sc = 0;
+        else {
+          if (prev_csbf == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
+          else if (prev_csbf == 1) sc = yp == 0 ? 2 : (yp == 1 ? 1 : 0);
+          else if (prev_csbf == 2) sc = xp == 0 ? 2 : (xp == 1 ? 1 : 0);
+          else sc = 2;
+          if (c_idx == 0) { if (xs || ys) sc += 3; sc += log2 == 3 ? (scan_idx == 0 ? 9 : 15) : 21; }
+          else sc += log2 == 3 ? 9 : 12;
+        }
+        rbt_ce_bin(c, CTX_SIG + (c_idx == 0 ? sc : 27 + sc), sig);
+        if (sig) infer_dc = 0;
+      }
+    }
+    int ctx_set = (i == 0 || c_idx > 0) ? 0 : 2;
+    if (first_sb_done && greater1_ctx == 0) ctx_set++;
+    first_sb_done = 1; greater1_ctx = 1;
+    int first_g1 = -1, first_g1_abs = 0, k = 0;
+    uint32_t m = mask, signs = 0; int nsig = 0;
+    while (m && k < 8) {
+      int n = 31 - __builtin_clz(m); m &= ~(1u << n);
+      int v = l->lvl[((ys << 2) + (pos_scan[n] >> 4)) * N + (xs << 2) + (pos_scan[n] & 15)], a = rbt_abs(v), g1 = a > 1;
+      rbt_ce_bin(c, CTX_GT1 + (ctx_set << 2) + greater1_ctx + (c_idx ? 16 : 0), g1);
+      if (g1) { greater1_ctx = 0; if (first_g1 < 0) { first_g1 = k; first_g1_abs = a; } }
+      else if (greater1_ctx > 0 && greater1_ctx < 3) greater1_ctx++;
+      k++;
+    }
+    if (first_g1 >= 0) rbt_ce_bin(c, CTX_GT2 + ctx_set + (c_idx ? 4 : 0), first_g1_abs > 2);
+    m = mask;
+    while (m) { int n = 31 - __builtin_clz(m); m &= ~(1u << n); int v = l->lvl[((ys << 2) + (pos_scan[n] >> 4)) * N + (xs << 2) + (pos_scan[n] & 15)]; signs = (signs << 1) | (uint32_t)(v < 0); nsig++; }
+    rbt_ce_bypass_n(c, signs, nsig);      // sign_data_hiding is off in RBT-E1 streams
+    int rice = 0; k = 0; m = mask;
+    while (m) {
+      int n = 31 - __builtin_clz(m); m &= ~(1u << n);
+      int a = rbt_abs((int)l->lvl[((ys << 2) + (pos_scan[n] >> 4)) * N + (xs << 2) + (pos_scan[n] & 15)]);
+      int base = k < 8 ? (k == first_g1 ? 3 : 2) : 1;
+      if (a >= base) {
+        int v = a - base;
+        if (v < (4 << rice)) { int pre = v >> rice; for (int t = 0; t < pre; t++) rbt_ce_bypass(c, 1); rbt_ce_bypass(c, 0); rbt_ce_bypass_n(c, (uint32_t)(v & ((1 << rice) - 1)), rice); }
+        else {
+          int p = 4; while (v >= (((1 << (p - 2)) + 2) << rice)) p++;
+          for (int t = 0; t < p; t++) rbt_ce_bypass(c, 1);
+          rbt_ce_bypass(c, 0);
+          rbt_ce_bypass_n(c, (uint32_t)(v - (((1 << (p - 3)) + 2) << rice)), p - 3 + rice);
+        }
+        if (a > 3 * (1 << rice)) rice = rbt_min(rice + 1, 4);
+      }
+      k++;
+    }
+  }
+  RBT_SYNC();
+}
+RBT_DEV int en_cu_coded(const RbtEnt* s, int xc, int yc, int xn, int yn) {
+  // neighbour CU available for context derivation: inside the picture, same slice, earlier in decoding order
+  const RbtFrame* f = s->f; const RbtStreamCfg* g = &f->cfg;
+  if (xn < 0 || yn < 0 || xn >= g->w || yn >= g->h) return 0;
+  int L = g->log2_ctb, an = (yn >> L) * g->w_ctb + (xn >> L), ac = (yc >> L) * g->w_ctb + (xc >> L);
+  if (an > ac || f->ctb_slice[an] != f->ctb_slice[ac]) return 0;
+  return 1;   // left / above neighbours inside the same CTB always precede in z-order
+}
+RBT_DEV int en_scan_idx(int is_intra, int log2, int c_idx, int mode) {
+  if (is_intra && (log2 == 2 || (log2 == 3 && c_idx == 0))) { if (mode >= 6 && mode <= 14) return 2; if (mode >= 22 && mode <= 30) return 1; }
+  return 0;
+}
+RBT_DEV void en_write_cu(RbtEnt* s, int x0, int y0, int log2, int depth) {
+  RbtCabacEnc* c = &s->c; const RbtFrame* f = s->f; const RbtStreamCfg* g = &f->cfg;
+  int k8 = (y0 >> 3) * f->w8 + (x0 >> 3), flags = f->cu_flags[k8], mode = f->cu_mode[k8];
+  int is_p = s->sl->slice_type == RBT_SLICE_P;
+  if (g->tq_bypass_enabled) rbt_ce_bin(c, CTX_CU_TQ_BYPASS, f->lossless ? 1 : 0);
+  if (is_p) {
+    int cl = en_cu_coded(s, x0, y0, x0 - 1, y0) && (f->cu_flags[(y0 >> 3) * f->w8 + ((x0 - 1) >> 3)] & RBT_CU_SKIP);
+    int ca = en_cu_coded(s, x0, y0, x0, y0 - 1) && (f->cu_flags[((y0 - 1) >> 3) * f->w8 + (x0 >> 3)] & RBT_CU_SKIP);
+    rbt_ce_bin(c, CTX_CU_SKIP + (cl ? 1 : 0) + (ca ? 1 : 0), (flags & RBT_CU_SKIP) ? 1 : 0);
+    if (flags & RBT_CU_SKIP) return;                 // merge_idx absent: MaxNumMergeCand == 1
+    rbt_ce_bin(c, CTX_PRED_MODE, 0);
+    rbt_ce_bin(c, CTX_PART_MODE, 1);
+    rbt_ce_bin(c, CTX_MERGE_FLAG, 1);
+  } else {
+    if (log2 == g->log2_min_cb) rbt_ce_bin(c, CTX_PART_MODE, 1);
+    int ca = 1, cb = 1;
+    if (en_cu_coded(s, x0, y0, x0 - 1, y0)) ca = f->cu_mode[(y0 >> 3) * f->w8 + ((x0 - 1) >> 3)];
+    if (en_cu_coded(s, x0, y0, x0, y0 - 1) && ((y0 - 1) >> g->log2_ctb) == (y0 >> g->log2_ctb)) cb = f->cu_mode[((y0 - 1) >> 3) * f->w8 + (x0 >> 3)];
+    int c0, c1, c2;
+    if (ca == cb) { if (ca < 2) { c0 = 0; c1 = 1; c2 = 26; } else { c0 = ca; c1 = 2 + ((ca + 29) % 32); c2 = 2 + ((ca - 2 + 1) % 32); } }
+    else { c0 = ca; c1 = cb; c2 = (ca != 0 && cb != 0) ? 0 : ((ca != 1 && cb != 1) ? 1 : 26); }
+    int idx = mode == c0 ? 0 : (mode == c1 ? 1 : (mode == c2 ? 2 : -1));
+    // the oracle keeps the LAST matching candidate; candidates are distinct, so first == last
+    rbt_ce_bin(c, CTX_PREV_INTRA_LUMA, idx >= 0);
+    if (idx >= 0) { rbt_ce_bypass(c, idx > 0); if (idx > 0) rbt_ce_bypass(c, idx > 1); }
+    else {
+      int t;
+      if (c0 > c1) { t = c0; c0 = c1; c1 = t; }
+      if (c0 > c2) { t = c0; c0 = c2; c2 = t; }
+      if (c1 > c2) { t = c1; c1 = c2; c2 = t; }
+      int rem = mode;
+      if (rem > c2) rem--;
+      if (rem > c1) rem--;
+      if (rem > c0) rem--;
+      rbt_ce_bypass_n(c, (uint32_t)rem, 5);
+    }
+    rbt_ce_bin(c, CTX_INTRA_CHROMA, 0);              // intra_chroma_pred_mode = 4 (DM)
+  }
+  // transform tree: one TU per CU (max_transform_hierarchy_depth = 0, no split flag)
+  int cbf_cb = (flags & RBT_CU_CBF_CB) != 0, cbf_cr = (flags & RBT_CU_CBF_CR) != 0, cbf_y = (flags & RBT_CU_CBF_Y) != 0;
+  rbt_ce_bin(c, CTX_CBF_CHROMA + 0, cbf_cb);
+  rbt_ce_bin(c, CTX_CBF_CHROMA + 0, cbf_cr);
+  if (!is_p || cbf_cb || cbf_cr) rbt_ce_bin(c, CTX_CBF_LUMA + 1, cbf_y);
+  int intra = !is_p;
+  if (cbf_y) en_write_residual(s, 0, x0, y0, log2, en_scan_idx(intra, log2, 0, mode));
+  if (cbf_cb) en_write_residual(s, 1, x0 >> 1, y0 >> 1, log2 - 1, en_scan_idx(intra, log2 - 1, 1, mode));
+  if (cbf_cr) en_write_residual(s, 2, x0 >> 1, y0 >> 1, log2 - 1, en_scan_idx(intra, log2 - 1, 2, mode));
+  (void)depth;
+}
+RBT_DEV void en_write_quadtree(RbtEnt* s, int x0, int y0, int log2) {
+  struct Node { int16_t x, y; int8_t log2, depth, state; };
+  Node st[5]; int sp = 0;
+  st[0].x = (int16_t)x0; st[0].y = (int16_t)y0; st[0].log2 = (int8_t)log2; st[0].depth = 0; st[0].state = -1;
+  const RbtFrame* f = s->f; const RbtStreamCfg* g = &f->cfg;
+  while (sp >= 0) {
+    Node* n = &st[sp];
+    int N = 1 << n->log2, h = N >> 1;
+    if (n->state < 0) {
+      int can_flag = n->x + N <= g->w && n->y + N <= g->h && n->log2 > g->log2_min_cb;
+      int split = f->cu_log2[(n->y >> 3) * f->w8 + (n->x >> 3)] < n->log2;
+      if (!can_flag) split = n->log2 > g->log2_min_cb;
+      if (can_flag) {
+        int cl = en_cu_coded(s, n->x, n->y, n->x - 1, n->y) && (g->log2_ctb - f->cu_log2[(n->y >> 3) * f->w8 + ((n->x - 1) >> 3)]) > n->depth;
+        int ca = en_cu_coded(s, n->x, n->y, n->x, n->y - 1) && (g->log2_ctb - f->cu_log2[((n->y - 1) >> 3) * f->w8 + (n->x >> 3)]) > n->depth;
+        rbt_ce_bin(&s->c, CTX_SPLIT_CU + (cl ? 1 : 0) + (ca ? 1 : 0), split);
+      }
+      if (!split) { en_write_cu(s, n->x, n->y, n->log2, n->depth); sp--; continue; }
+      n->state = 0;
+    }
+    if (n->state >= 4) { sp--; continue; }
+    int k = n->state++;
+    int cx = n->x + (k & 1) * h, cy = n->y + (k >> 1) * h;
+    if (cx >= g->w || cy >= g->h) continue;
+    Node* ch = &st[sp + 1];
+    ch->x = (int16_t)cx; ch->y = (int16_t)cy; ch->log2 = (int8_t)(n->log2 - 1); ch->depth = (int8_t)(n->depth + 1); ch->state = -1;
+    sp++;
+  }
+}
+RBT_DEV void en_entropy_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, uint8_t* out, RBT_LDS_AS RbtEncLds* l) {
+  RbtEnt s; s.sl = &slices[slice_idx]; s.f = &frames[s.sl->frame]; s.slice_idx = slice_idx; s.l = l;
+  const RbtSlice* sl = s.sl; const RbtStreamCfg* g = &s.f->cfg;
+  rbt_ctx_init(l->ctx, sl->slice_type == RBT_SLICE_I ? 0 : 1, sl->qp);
+  RBT_SYNC();
+  s.c.out = out + sl->out_off; s.c.cap = sl->out_cap; s.c.n = 0; s.c.acc = 0; s.c.nacc = 0; s.c.overflow = 0;
+  rbt_ce_start(&s.c, l->ctx);
+  for (int a = 0; a < sl->n_ctbs; a++) {
+    int addr = sl->ctb_addr + a, rx = addr % g->w_ctb, ry = addr / g->w_ctb;
+    en_write_quadtree(&s, rx << g->log2_ctb, ry << g->log2_ctb, g->log2_ctb);
+    rbt_ce_terminate(&s.c, a == sl->n_ctbs - 1);
+  }
+  rbt_ce_align_zero(&s.c);
+  if (RBT_LANE0) slices[slice_idx].out_size = s.c.overflow ? 0xFFFFFFFFu : s.c.n;
+}
+
+// ------------------------------------------------------------------------------------------------ occupancy OR-pool
+// resize_frame2 (PCCTranscoder.cpp:615-637): out[v][u] = any(in[v*f+v1][u*f+u1] > 0) ? 1 : 0
+RBT_DEV void en_pool_sample(const uint16_t* in, int w, int factor, uint16_t* out, int ow, int u, int v) {
+  int any = 0;
+  for (int v1 = 0; v1 < factor; v1++) for (int u1 = 0; u1 < factor; u1++) any |= in[(size_t)(v * factor + v1) * w + u * factor + u1] > 0;
+  out[(size_t)v * ow + u] = (uint16_t)(any ? 1 : 0);
+}

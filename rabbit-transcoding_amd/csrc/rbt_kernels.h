@@ -24,4 +24,15 @@ void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const
 void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb);
 void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_units);
 void launch_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_luma_samples);
+
+// encode (RBT-E1)
+void launch_pool(const uint16_t* in, int w, int h, int factor, uint16_t* out, uint16_t* out_cb, uint16_t* out_cr, int chroma_value);
+void launch_enc_analyse(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs);
+// row_mode != 0: every slice is one CTB row, rows are independent and each wave walks its row;
+// otherwise CTBs are scheduled on anti-diagonals like the decoder's reconstruction
+void launch_enc_intra(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int row_mode);
+void launch_enc_inter(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs);
+void launch_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list, int n_slices);
+// gathers the slice data of every slice segment into one contiguous buffer (dst_off = exclusive prefix sum of out_size)
+void launch_pack(const uint8_t* out, const RbtSlice* slices, const uint32_t* dst_off, uint8_t* packed, int n_slices);
 }  // namespace rbtk

@@ -6,6 +6,7 @@
 #include "rbt_parse.h"
 #include "rbt_recon.h"
 #include "rbt_filter.h"
+#include "rbt_encode.h"
 
 namespace rbtk {
 static hipStream_t g_stream = nullptr;
@@ -89,5 +90,77 @@ void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* fra
 void launch_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_luma_samples) {
   if (n_frames <= 0) return;
   hipLaunchKernelGGL(k_sao, dim3((max_luma_samples + 255) / 256, n_frames, 3), dim3(256), 0, g_stream, frames, slices, frame_list);
+}
+
+// ---------------------------------------------------------------------------------------------- encode kernels
+__global__ void __launch_bounds__(256) k_pool(const uint16_t* in, int w, int factor, uint16_t* out, int ow, int oh, uint16_t* out_cb, uint16_t* out_cr, int chroma_value) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < ow * oh) en_pool_sample(in, w, factor, out, ow, i % ow, i / ow);
+  if (i < (ow / 2) * (oh / 2)) { out_cb[i] = (uint16_t)chroma_value; out_cr[i] = (uint16_t)chroma_value; }
+}
+__global__ void __launch_bounds__(64) k_enc_analyse(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
+  __shared__ RbtEncLds lds;
+  RbtFrame* f = &frames[frame_list[blockIdx.y]];
+  if ((int)blockIdx.x >= f->cfg.w_ctb * f->cfg.h_ctb) return;
+  en_analyse_ctb(f, slices, blockIdx.x, RBT_LDS_CAST(RbtEncLds, &lds));
+}
+__global__ void __launch_bounds__(64) k_enc_intra_rows(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
+  __shared__ RbtEncLds lds;
+  RbtFrame* f = &frames[frame_list[blockIdx.y]];
+  int row = blockIdx.x;
+  if (row >= f->cfg.h_ctb) return;
+  for (int x = 0; x < f->cfg.w_ctb; x++) en_intra_ctb(f, slices, row * f->cfg.w_ctb + x, RBT_LDS_CAST(RbtEncLds, &lds));
+}
+__global__ void __launch_bounds__(64) k_enc_intra_diag(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int d) {
+  __shared__ RbtEncLds lds;
+  RbtFrame* f = &frames[frame_list[blockIdx.y]];
+  int y = blockIdx.x, x = d - 2 * y;
+  if (y >= f->cfg.h_ctb || x < 0 || x >= f->cfg.w_ctb) return;
+  en_intra_ctb(f, slices, y * f->cfg.w_ctb + x, RBT_LDS_CAST(RbtEncLds, &lds));
+}
+__global__ void __launch_bounds__(64) k_enc_inter(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
+  __shared__ RbtEncLds lds;
+  RbtFrame* f = &frames[frame_list[blockIdx.y]];
+  if ((int)blockIdx.x >= f->cfg.w_ctb * f->cfg.h_ctb) return;
+  en_inter_ctb(frames, f, slices, blockIdx.x, RBT_LDS_CAST(RbtEncLds, &lds));
+}
+__global__ void __launch_bounds__(64) k_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list) {
+  __shared__ RbtEncLds lds;
+  en_entropy_slice(frames, slices, slice_list[blockIdx.x], out, RBT_LDS_CAST(RbtEncLds, &lds));
+}
+
+__global__ void __launch_bounds__(256) k_pack(const uint8_t* out, const RbtSlice* slices, const uint32_t* dst_off, uint8_t* packed) {
+  const RbtSlice* sl = &slices[blockIdx.x];
+  const uint8_t* src = out + sl->out_off; uint8_t* dst = packed + dst_off[blockIdx.x];
+  for (uint32_t i = threadIdx.x; i < sl->out_size; i += 256) dst[i] = src[i];
+}
+void launch_pack(const uint8_t* out, const RbtSlice* slices, const uint32_t* dst_off, uint8_t* packed, int n_slices) {
+  if (n_slices <= 0) return;
+  hipLaunchKernelGGL(k_pack, dim3(n_slices), dim3(256), 0, g_stream, out, slices, dst_off, packed);
+}
+void launch_pool(const uint16_t* in, int w, int h, int factor, uint16_t* out, uint16_t* out_cb, uint16_t* out_cr, int chroma_value) {
+  int ow = w / factor, oh = h / factor;
+  hipLaunchKernelGGL(k_pool, dim3((ow * oh + 255) / 256), dim3(256), 0, g_stream, in, w, factor, out, ow, oh, out_cb, out_cr, chroma_value);
+}
+void launch_enc_analyse(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs) {
+  if (n_frames <= 0) return;
+  hipLaunchKernelGGL(k_enc_analyse, dim3(max_ctbs, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
+}
+void launch_enc_intra(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int row_mode) {
+  if (n_frames <= 0) return;
+  if (row_mode) { hipLaunchKernelGGL(k_enc_intra_rows, dim3(max_h_ctb, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list); return; }
+  int n_diag = max_w_ctb + 2 * (max_h_ctb - 1);
+  for (int d = 0; d < n_diag; d++) {
+    int rows = d / 2 + 1; if (rows > max_h_ctb) rows = max_h_ctb;
+    hipLaunchKernelGGL(k_enc_intra_diag, dim3(rows, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list, d);
+  }
+}
+void launch_enc_inter(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs) {
+  if (n_frames <= 0) return;
+  hipLaunchKernelGGL(k_enc_inter, dim3(max_ctbs, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
+}
+void launch_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list, int n_slices) {
+  if (n_slices <= 0) return;
+  hipLaunchKernelGGL(k_entropy, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, out, slice_list);
 }
 }  // namespace rbtk

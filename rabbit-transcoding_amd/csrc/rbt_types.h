@@ -78,7 +78,20 @@ struct RbtFrame {
   int32_t level;                 // dependency level inside the batch (0: no references inside the batch)
   int32_t n_slices, first_slice;
   int32_t error;                 // set by kernels (non-zero = corrupt / unsupported stream)
+  // ---- encoder side (RBT-E1) ----
+  const uint16_t* src[3];        // source planes (the decoder's `out` planes or the pooled occupancy map)
+  uint8_t* cu_log2;              // per 8x8 unit: log2 size of the coding unit covering it
+  uint8_t* cu_mode;              // per 8x8 unit: luma intra prediction mode of that CU
+  uint8_t* cu_flags;             // per 8x8 unit: RBT_CU_* bits of that CU
+  int32_t w8, h8;
+  int32_t lossless;              // every CU cu_transquant_bypass (x265 lossless=1, PCCTranscoder.cpp:841)
+  int32_t ref_frame;             // P pictures: batch index of the reference picture (zero-motion merge), else -1
+  int32_t ref_poc;
 };
+#define RBT_CU_CBF_Y 1
+#define RBT_CU_CBF_CB 2
+#define RBT_CU_CBF_CR 4
+#define RBT_CU_SKIP 8
 
 struct RbtSlice {                // one per slice segment, parsed on the host (7.3.6)
   int32_t frame;                 // index into the batch frame table
@@ -92,4 +105,8 @@ struct RbtSlice {                // one per slice segment, parsed on the host (7
   int32_t ref_poc[RBT_MAX_REFS];
   int32_t poc;
   uint32_t n_ctbs_decoded;       // out: CTBs the slice covered
+  // ---- encoder side ----
+  int32_t n_ctbs;                // CTBs of this slice segment (encoder input)
+  uint32_t out_off, out_cap;     // slice_segment_data() bytes inside the batch output buffer
+  uint32_t out_size;             // out: bytes written (out_size > out_cap = overflow)
 };

@@ -1,6 +1,301 @@
+// Encode half of the hot path and the transcode pipeline.
+// Replaces initEncoder / setEncoderOptions / encodeVideo / resize_frame2 of PCCTranscoder (PCCTranscoder.cpp:683-753,
+// :825-904, :548-592, :594-646) and the decode -> pool -> encode loop of transcodeVideo (:428-510).
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include "rbt_batch.h"
 #include "rbt_transcode.h"
+
 namespace rbt {
-int transcode_gof(rbt_stats&, std::string& err, int, const uint8_t* const*, const size_t*, const rbt_stream_params*, uint8_t**, size_t*) { err = "not built yet"; return RBT_ERR_PARAM; }
-int encode_yuv(rbt_stats&, std::string& err, const uint16_t*, int, int, int, int, int, int, int, int, int, int, uint8_t**, size_t*) { err = "not built yet"; return RBT_ERR_PARAM; }
-int or_pool_host(const uint16_t*, int, int, int, uint16_t*) { return RBT_ERR_PARAM; }
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct EncStreamDesc {
+  int w, h, bd, n_frames, qp, i_qp_offset, gop, lossless, log2_ctb, rows, md5;
+  std::vector<const uint16_t*> src[3];   // device planes per frame
+};
+struct EncodeBatch {
+  std::vector<EncStreamDesc> desc;
+  std::vector<Sps> sps; std::vector<Pps> pps;
+  std::vector<RbtFrame> frames; std::vector<RbtSlice> slices; std::vector<int> frame_stream, frame_is_idr;
+  std::vector<int> stream_first;
+  void* arena = nullptr; size_t arena_size = 0;
+  RbtFrame* d_frames = nullptr; RbtSlice* d_slices = nullptr; int32_t* d_lists = nullptr; uint8_t* d_out = nullptr; uint8_t* d_packed = nullptr; uint32_t* d_dst = nullptr;
+  size_t out_total = 0;
+  std::vector<std::vector<uint16_t>> cs_keep;   // host staging of the ctb->slice maps, alive until the copies have completed
+  std::string err;
+  ~EncodeBatch() { rbtk::dev_free(arena); }
+};
+
+static void make_param_sets(const EncStreamDesc& d, Sps& s, Pps& p) {
+  s = Sps(); p = Pps();
+  s.valid = true; s.width = d.w; s.height = d.h; s.bit_depth = d.bd; s.log2_max_poc_lsb = 8; s.max_dec_pic_buffering = 3;
+  s.log2_ctb = d.log2_ctb ? d.log2_ctb : 5; s.log2_min_cb = 3; s.log2_diff_max_min_cb = s.log2_ctb - 3;
+  s.log2_min_tb = 2; s.log2_max_tb = std::min(5, s.log2_ctb); s.log2_diff_max_min_tb = s.log2_max_tb - 2;
+  s.num_st_rps = 1;
+  s.w_ctb = (d.w + (1 << s.log2_ctb) - 1) >> s.log2_ctb; s.h_ctb = (d.h + (1 << s.log2_ctb) - 1) >> s.log2_ctb;
+  p.valid = true; p.num_ref_idx_default = 1; p.init_qp = std::min(51, std::max(0, d.qp)); p.loop_filter_across_slices = 1;
+  if (d.lossless) { p.transquant_bypass = 1; p.deblocking_control_present = 1; p.pps_deblocking_disabled = 1; p.loop_filter_across_slices = 0; }
 }
+
+static int encode_build(EncodeBatch& b) {
+  size_t ns = b.desc.size();
+  b.sps.resize(ns); b.pps.resize(ns); b.stream_first.resize(ns);
+  for (size_t si = 0; si < ns; si++) {
+    const EncStreamDesc& d = b.desc[si];
+    if (d.w % 8 || d.h % 8 || d.w <= 0 || d.h <= 0 || d.w > 8192 || d.h > 8192) { b.err = "picture size must be a multiple of 8"; return RBT_ERR_UNSUPPORTED; }
+    if (d.gop > 1 && (d.w % 16 || d.h % 16)) { b.err = "gop=2 needs a picture size that is a multiple of 16"; return RBT_ERR_UNSUPPORTED; }
+    if (d.log2_ctb && (d.log2_ctb < 4 || d.log2_ctb > 6)) { b.err = "log2_ctb must be 4..6"; return RBT_ERR_PARAM; }
+    make_param_sets(d, b.sps[si], b.pps[si]);
+    const Sps& s = b.sps[si]; const Pps& p = b.pps[si];
+    b.stream_first[si] = (int)b.frames.size();
+    for (int i = 0; i < d.n_frames; i++) {
+      bool is_i = d.gop <= 1 || (i % d.gop) == 0;
+      RbtFrame f; memset(&f, 0, sizeof(f));
+      fill_stream_cfg(s, p, f.cfg);
+      f.poc = is_i ? 0 : (i % d.gop); f.level = is_i ? 0 : 1; f.first_slice = (int)b.slices.size();
+      f.w8 = d.w / 8; f.h8 = d.h / 8; f.lossless = d.lossless; f.ref_frame = is_i ? -1 : (int)b.frames.size() - 1; f.ref_poc = is_i ? 0 : f.poc - 1;
+      for (int c = 0; c < 3; c++) f.src[c] = d.src[c][i];
+      int n_ctb = s.w_ctb * s.h_ctb, step = d.rows > 0 ? d.rows * s.w_ctb : n_ctb;
+      for (int addr = 0; addr < n_ctb; addr += step) {
+        RbtSlice sl; memset(&sl, 0, sizeof(sl));
+        sl.frame = (int)b.frames.size(); sl.ctb_addr = addr; sl.n_ctbs = std::min(step, n_ctb - addr);
+        sl.slice_type = (int8_t)(is_i ? RBT_SLICE_I : RBT_SLICE_P);
+        sl.qp = (int8_t)std::min(51, std::max(0, is_i ? d.qp + d.i_qp_offset : d.qp));
+        sl.deblocking_disabled = (uint8_t)p.pps_deblocking_disabled; sl.lf_across = (uint8_t)p.loop_filter_across_slices;
+        sl.max_merge_cand = 1; sl.num_ref_idx = 1; sl.poc = f.poc;
+        if (!is_i) { sl.ref_frame[0] = f.ref_frame; sl.ref_poc[0] = f.ref_poc; }
+        // worst-case slice data: raw samples of the slice at 2 bytes each plus slack
+        size_t rows = (size_t)(sl.n_ctbs + s.w_ctb - 1) / s.w_ctb;
+        sl.out_cap = (uint32_t)(rows * ((size_t)d.w << s.log2_ctb) * 3 + 4096);
+        f.n_slices++;
+        b.slices.push_back(sl);
+      }
+      b.frames.push_back(f); b.frame_stream.push_back((int)si); b.frame_is_idr.push_back(is_i);
+    }
+  }
+  if (b.slices.size() >= 0xFFFF) { b.err = "too many slice segments in one call"; return RBT_ERR_UNSUPPORTED; }
+  // ---- HBM layout ----
+  Arena a; size_t nf = b.frames.size();
+  std::vector<size_t> o_pix(nf), o_coef(nf), o_pm(nf), o_edges(nf), o_qp(nf), o_mv(nf), o_ref(nf), o_refpoc(nf), o_cs(nf), o_cul(nf), o_cum(nf), o_cuf(nf);
+  for (size_t i = 0; i < nf; i++) {
+    const RbtStreamCfg& c = b.frames[i].cfg; size_t u = (size_t)c.w4 * c.h4, nc = (size_t)c.w_ctb * c.h_ctb, u8 = (size_t)b.frames[i].w8 * b.frames[i].h8;
+    o_pix[i] = a.reserve(frame_samples(c) * 2); o_coef[i] = a.reserve(frame_samples(c) * 2);
+    o_pm[i] = a.reserve(u); o_edges[i] = a.reserve(u); o_qp[i] = a.reserve(u); o_mv[i] = a.reserve(u * 4); o_ref[i] = a.reserve(u); o_refpoc[i] = a.reserve(u * 4);
+    o_cs[i] = a.reserve(nc * 2); o_cul[i] = a.reserve(u8); o_cum[i] = a.reserve(u8); o_cuf[i] = a.reserve(u8);
+  }
+  size_t o_frames = a.reserve(nf * sizeof(RbtFrame)), o_slices = a.reserve(b.slices.size() * sizeof(RbtSlice));
+  size_t o_lists = a.reserve((nf + b.slices.size()) * 2 * sizeof(int32_t)), o_dst = a.reserve(b.slices.size() * sizeof(uint32_t));
+  size_t out_cap_total = 0; for (auto& sl : b.slices) { sl.out_off = (uint32_t)out_cap_total; out_cap_total += sl.out_cap; }
+  if (out_cap_total >= 0xFFFFFFFFull) { b.err = "output buffer too large for one call"; return RBT_ERR_UNSUPPORTED; }
+  size_t o_out = a.reserve(out_cap_total), o_packed = a.reserve(out_cap_total / 2 + 65536);
+  b.arena_size = a.reserve(0);
+  b.arena = rbtk::dev_alloc(b.arena_size);
+  if (!b.arena) { b.err = "device allocation failed"; return RBT_ERR_NOMEM; }
+  uint8_t* base = (uint8_t*)b.arena;
+  b.cs_keep.resize(nf);
+  for (size_t i = 0; i < nf; i++) {
+    std::vector<uint16_t>& cs_host = b.cs_keep[i];
+    RbtFrame& f = b.frames[i]; const RbtStreamCfg& c = f.cfg; size_t ys = (size_t)c.w * c.h, cs = (size_t)c.cw * c.ch;
+    f.pix[0] = (uint16_t*)(base + o_pix[i]); f.pix[1] = f.pix[0] + ys; f.pix[2] = f.pix[1] + cs;
+    for (int k = 0; k < 3; k++) f.out[k] = f.pix[k];
+    f.coef[0] = (int16_t*)(base + o_coef[i]); f.coef[1] = f.coef[0] + ys; f.coef[2] = f.coef[1] + cs;
+    f.pm = base + o_pm[i]; f.edges = base + o_edges[i]; f.qp = (int8_t*)(base + o_qp[i]); f.mv = (int16_t*)(base + o_mv[i]); f.ref = (int8_t*)(base + o_ref[i]);
+    f.refpoc = (int32_t*)(base + o_refpoc[i]); f.ctb_slice = (uint16_t*)(base + o_cs[i]);
+    f.cu_log2 = base + o_cul[i]; f.cu_mode = base + o_cum[i]; f.cu_flags = base + o_cuf[i];
+    cs_host.assign((size_t)c.w_ctb * c.h_ctb, 0);
+    for (int k = 0; k < f.n_slices; k++) { const RbtSlice& sl = b.slices[f.first_slice + k]; for (int q = 0; q < sl.n_ctbs; q++) cs_host[sl.ctb_addr + q] = (uint16_t)(f.first_slice + k); }
+    if (rbtk::h2d(f.ctb_slice, cs_host.data(), cs_host.size() * 2)) { b.err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
+  }
+  b.d_frames = (RbtFrame*)(base + o_frames); b.d_slices = (RbtSlice*)(base + o_slices); b.d_lists = (int32_t*)(base + o_lists); b.d_dst = (uint32_t*)(base + o_dst);
+  b.d_out = base + o_out; b.d_packed = base + o_packed; b.out_total = out_cap_total;
+  if (rbtk::h2d(b.d_frames, b.frames.data(), nf * sizeof(RbtFrame)) || rbtk::h2d(b.d_slices, b.slices.data(), b.slices.size() * sizeof(RbtSlice))) { b.err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
+  return 0;
+}
+
+// runs the kernels and packs one Annex-B stream per input stream
+static int encode_run(EncodeBatch& b, std::vector<std::vector<uint8_t>>& outs, rbt_stats& st) {
+  size_t nf = b.frames.size(), ns = b.slices.size();
+  std::vector<int32_t> lists; size_t off_i, off_ideb, off_p, off_sl; int n_i = 0, n_ideb = 0, n_p = 0;
+  off_i = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i]) { lists.push_back((int)i); n_i++; }
+  off_ideb = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i] && !b.frames[i].lossless) { lists.push_back((int)i); n_ideb++; }
+  off_p = lists.size(); for (size_t i = 0; i < nf; i++) if (!b.frame_is_idr[i]) { lists.push_back((int)i); n_p++; }
+  off_sl = lists.size(); for (size_t i = 0; i < ns; i++) lists.push_back((int)i);
+  if (rbtk::h2d(b.d_lists, lists.data(), lists.size() * sizeof(int32_t))) { b.err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
+  int mw = 0, mh = 0, mu = 0, mc = 0, row_mode = 1;
+  for (size_t i = 0; i < nf; i++) {
+    const RbtStreamCfg& c = b.frames[i].cfg; mw = std::max(mw, c.w_ctb); mh = std::max(mh, c.h_ctb); mu = std::max(mu, c.w4 * c.h4); mc = std::max(mc, c.w_ctb * c.h_ctb);
+    if (b.desc[b.frame_stream[i]].rows != 1) row_mode = 0;
+  }
+  rbtk::timer_begin(T_ANALYSE);
+  rbtk::launch_enc_analyse(b.d_frames, b.d_slices, b.d_lists + off_i, n_i, mc);
+  rbtk::timer_end(T_ANALYSE);
+  rbtk::timer_begin(T_ENCODE);
+  rbtk::launch_enc_intra(b.d_frames, b.d_slices, b.d_lists + off_i, n_i, mw, mh, row_mode);
+  rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + off_ideb, n_ideb, mu);
+  rbtk::launch_enc_inter(b.d_frames, b.d_slices, b.d_lists + off_p, n_p, mc);
+  rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + off_p, n_p, mu);
+  rbtk::timer_end(T_ENCODE);
+  rbtk::timer_begin(T_ENTROPY);
+  rbtk::launch_entropy(b.d_frames, b.d_slices, b.d_out, b.d_lists + off_sl, (int)ns);
+  rbtk::timer_end(T_ENTROPY);
+  if (rbtk::d2h(b.slices.data(), b.d_slices, ns * sizeof(RbtSlice))) { b.err = "kernel execution failed"; return RBT_ERR_NO_DEVICE; }
+  std::vector<uint32_t> dst(ns); size_t total = 0;
+  for (size_t i = 0; i < ns; i++) { if (b.slices[i].out_size > b.slices[i].out_cap) { b.err = "slice data exceeds its buffer"; return RBT_ERR_NOMEM; } dst[i] = (uint32_t)total; total += b.slices[i].out_size; }
+  if (total > b.out_total / 2 + 65536) { b.err = "packed output exceeds its buffer"; return RBT_ERR_NOMEM; }
+  std::vector<uint8_t> packed(total);
+  if (rbtk::h2d(b.d_dst, dst.data(), ns * sizeof(uint32_t))) { b.err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
+  rbtk::launch_pack(b.d_out, b.d_slices, b.d_dst, b.d_packed, (int)ns);
+  double t0 = now_ms();
+  if (total && rbtk::d2h(packed.data(), b.d_packed, total)) { b.err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
+  if (rbtk::dev_sync()) { b.err = "kernel execution failed"; return RBT_ERR_NO_DEVICE; }
+  st.d2h_ms += now_ms() - t0;
+  // ---- NAL packing (parameter sets, slice headers, emulation prevention) ----
+  double t1 = now_ms();
+  outs.assign(b.desc.size(), {});
+  std::vector<uint16_t> rec;
+  for (size_t i = 0; i < nf; i++) {
+    int si = b.frame_stream[i]; const Sps& s = b.sps[si]; const Pps& p = b.pps[si]; std::vector<uint8_t>& out = outs[si]; const RbtFrame& f = b.frames[i];
+    bool idr = b.frame_is_idr[i] != 0;
+    if (idr) write_param_sets(out, s, p);
+    for (int k = 0; k < f.n_slices; k++) {
+      const RbtSlice& sl = b.slices[f.first_slice + k];
+      SliceHdr h; h.first_slice_in_pic = k == 0; h.segment_addr = sl.ctb_addr; h.slice_type = sl.slice_type; h.poc = sl.poc; h.num_ref_idx = 1; h.max_merge_cand = 1; h.qp = sl.qp;
+      h.deblocking_disabled = sl.deblocking_disabled; h.beta_offset_div2 = p.beta_offset_div2; h.tc_offset_div2 = p.tc_offset_div2; h.lf_across = sl.lf_across;
+      BitWriter w; write_slice_header(w, s, p, h, idr, 0);
+      w.b.insert(w.b.end(), packed.begin() + dst[f.first_slice + k], packed.begin() + dst[f.first_slice + k] + sl.out_size);
+      append_nal(out, idr ? NAL_IDR_W_RADL : NAL_TRAIL_R, w.b.data(), w.b.size(), k == 0);
+    }
+    if (b.desc[si].md5) {
+      // decoded picture hash SEI: needs the reconstructed picture on the host (diagnostic option, off in the benchmark)
+      const RbtStreamCfg& c = f.cfg; size_t fs = frame_samples(c); rec.resize(fs);
+      if (rbtk::d2h(rec.data(), f.pix[0], fs * 2)) { b.err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
+      uint8_t sei[52]; sei[0] = 132; sei[1] = 49; sei[2] = 0;
+      md5_plane_u16(rec.data(), c.w, c.h, c.bit_depth, sei + 3);
+      md5_plane_u16(rec.data() + (size_t)c.w * c.h, c.cw, c.ch, c.bit_depth, sei + 19);
+      md5_plane_u16(rec.data() + (size_t)c.w * c.h + (size_t)c.cw * c.ch, c.cw, c.ch, c.bit_depth, sei + 35);
+      sei[51] = 0x80;
+      append_nal(out, NAL_SEI_SUFFIX, sei, 52, false);
+    }
+  }
+  st.host_pack_ms += now_ms() - t1;
+  st.k_analyse_ms = rbtk::timer_ms(T_ANALYSE); st.k_encode_ms = rbtk::timer_ms(T_ENCODE); st.k_entropy_ms = rbtk::timer_ms(T_ENTROPY);
+  return 0;
+}
+
+static int hand_out(const std::vector<std::vector<uint8_t>>& outs, uint8_t** out, size_t* n_out) {
+  for (size_t i = 0; i < outs.size(); i++) {
+    out[i] = (uint8_t*)malloc(outs[i].size() ? outs[i].size() : 1);
+    if (!out[i]) { for (size_t k = 0; k < i; k++) { free(out[k]); out[k] = nullptr; } return RBT_ERR_NOMEM; }
+    memcpy(out[i], outs[i].data(), outs[i].size()); n_out[i] = outs[i].size();
+  }
+  return 0;
+}
+
+int transcode_gof(rbt_stats& st, std::string& err, int n, const uint8_t* const* in, const size_t* n_in, const rbt_stream_params* p, uint8_t** out, size_t* n_out) {
+  double t_all = now_ms();
+  memset(&st, 0, sizeof(st));
+  for (int i = 0; i < n; i++) { out[i] = nullptr; n_out[i] = 0; }
+  // ---- decode (PCCTranscoder.cpp:428-448) ----
+  DecodeBatch db; std::vector<StreamIn> sin(n);
+  for (int i = 0; i < n; i++) { sin[i].p = in[i]; sin[i].n = n_in[i]; }
+  double t0 = now_ms();
+  int rc = decode_build(db, sin.data(), n);
+  st.host_parse_ms = now_ms() - t0;
+  rbtk::timer_begin(T_ALL);
+  if (!rc) rc = decode_run(db);
+  if (rc) { err = db.err; return rc; }
+  st.k_parse_ms = rbtk::timer_ms(T_PARSE); st.k_recon_ms = rbtk::timer_ms(T_RECON);
+  for (int i = 0; i < n; i++) if (p[i].verify_md5) {
+    rbt_video v; rc = decode_fetch(db, i, &v, true); free(v.data);
+    if (rc) { err = "fetch failed"; return rc; }
+    if (v.md5_failed) { err = "input MD5 mismatch"; return RBT_ERR_MD5; }
+  }
+  // ---- pool + encoder setup (PCCTranscoder.cpp:466, :825-904) ----
+  EncodeBatch eb; eb.desc.resize(n);
+  std::vector<void*> pooled;
+  struct Guard { std::vector<void*>& v; ~Guard() { for (void* q : v) rbtk::dev_free(q); } } guard{pooled};
+  for (int i = 0; i < n; i++) {
+    EncStreamDesc& d = eb.desc[i]; int first = db.stream_first[i], cnt = db.stream_count[i];
+    const RbtStreamCfg& c = db.frames[first].cfg;
+    d.bd = c.bit_depth; d.n_frames = cnt; d.qp = p[i].qp; d.log2_ctb = p[i].log2_ctb; d.rows = p[i].ctb_rows_per_slice; d.md5 = p[i].md5_sei;
+    for (int k = 0; k < 3; k++) d.src[k].resize(cnt);
+    if (p[i].video_type == RBT_VIDEO_OCCUPANCY) {
+      int factor = p[i].occupancy_precision / 2; if (factor < 1) factor = 1;
+      d.gop = 1; d.lossless = 1; d.i_qp_offset = 0; d.w = c.w / factor; d.h = c.h / factor;
+      if (p[i].occupancy_precision == 4) {
+        if (c.w % 4 || c.h % 4) { err = "occupancy map size must be a multiple of 4 to pool"; return RBT_ERR_UNSUPPORTED; }
+        size_t ys = (size_t)d.w * d.h, cs = (size_t)(d.w / 2) * (d.h / 2);
+        uint16_t* buf = (uint16_t*)rbtk::dev_alloc((ys + 2 * cs) * 2 * (size_t)cnt);
+        if (!buf) { err = "device allocation failed"; return RBT_ERR_NOMEM; }
+        pooled.push_back(buf);
+        rbtk::timer_begin(T_POOL);
+        for (int k = 0; k < cnt; k++) {
+          uint16_t* y = buf + (ys + 2 * cs) * (size_t)k;
+          // the reference leaves the pooled chroma planes unwritten (PCCTranscoder.cpp:638-641); mid-grey here
+          rbtk::launch_pool(db.frames[first + k].out[0], c.w, c.h, 2, y, y + ys, y + ys + cs, 1 << (c.bit_depth - 1));
+          d.src[0][k] = y; d.src[1][k] = y + ys; d.src[2][k] = y + ys + cs;
+        }
+        rbtk::timer_end(T_POOL);
+      } else for (int k = 0; k < cnt; k++) for (int q = 0; q < 3; q++) d.src[q][k] = db.frames[first + k].out[q];
+    } else {
+      d.gop = 2; d.lossless = 0; d.i_qp_offset = -3; d.w = c.w; d.h = c.h;
+      for (int k = 0; k < cnt; k++) for (int q = 0; q < 3; q++) d.src[q][k] = db.frames[first + k].out[q];
+    }
+  }
+  rc = encode_build(eb);
+  std::vector<std::vector<uint8_t>> outs;
+  if (!rc) rc = encode_run(eb, outs, st);
+  rbtk::timer_end(T_ALL);
+  if (rc) { err = eb.err; return rc; }
+  rbtk::dev_sync();
+  st.gpu_ms = rbtk::timer_ms(T_ALL);
+  rc = hand_out(outs, out, n_out);
+  // SURVEY.md 8(d) algorithmic traffic: per coded picture of S samples (2 bytes each): decode writes S, P pictures read
+  // their reference once; encode reads the source S, writes the reconstruction S (I) and reads the reference (P)
+  uint64_t bytes = 0;
+  for (size_t i = 0; i < db.frames.size(); i++) { uint64_t s2 = frame_samples(db.frames[i].cfg) * 2; bytes += s2 + (db.frames[i].level ? s2 : 0); }
+  for (size_t i = 0; i < eb.frames.size(); i++) { uint64_t s2 = frame_samples(eb.frames[i].cfg) * 2; bytes += s2 + s2; }
+  for (int i = 0; i < n; i++) bytes += n_in[i] + n_out[i];
+  st.algorithmic_bytes = bytes;
+  st.total_ms = now_ms() - t_all;
+  return rc;
+}
+
+int encode_yuv(rbt_stats& st, std::string& err, const uint16_t* yuv, int w, int h, int bd, int n_frames, int qp, int gop, int lossless, int log2_ctb, int rows, int md5,
+               uint8_t** out, size_t* n_out) {
+  memset(&st, 0, sizeof(st));
+  *out = nullptr; *n_out = 0;
+  if (w <= 0 || h <= 0 || w % 8 || h % 8 || bd < 8 || bd > 12) { err = "bad picture format"; return RBT_ERR_PARAM; }
+  size_t ys = (size_t)w * h, cs = (size_t)(w / 2) * (h / 2), fs = ys + 2 * cs;
+  uint16_t* buf = (uint16_t*)rbtk::dev_alloc(fs * 2 * (size_t)n_frames);
+  if (!buf) { err = "device allocation failed"; return RBT_ERR_NOMEM; }
+  struct G { void* p; ~G() { rbtk::dev_free(p); } } g{buf};
+  if (rbtk::h2d(buf, yuv, fs * 2 * (size_t)n_frames)) { err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
+  EncodeBatch eb; eb.desc.resize(1);
+  EncStreamDesc& d = eb.desc[0];
+  d.w = w; d.h = h; d.bd = bd; d.n_frames = n_frames; d.qp = qp; d.i_qp_offset = lossless ? 0 : -3; d.gop = gop; d.lossless = lossless; d.log2_ctb = log2_ctb; d.rows = rows; d.md5 = md5;
+  for (int k = 0; k < 3; k++) d.src[k].resize(n_frames);
+  for (int i = 0; i < n_frames; i++) { uint16_t* y = buf + fs * (size_t)i; d.src[0][i] = y; d.src[1][i] = y + ys; d.src[2][i] = y + ys + cs; }
+  int rc = encode_build(eb);
+  std::vector<std::vector<uint8_t>> outs;
+  if (!rc) rc = encode_run(eb, outs, st);
+  if (rc) { err = eb.err; return rc; }
+  return hand_out(outs, out, n_out);
+}
+
+int or_pool_host(const uint16_t* plane, int w, int h, int factor, uint16_t* out) {
+  int ow = w / factor, oh = h / factor;
+  size_t in_n = (size_t)w * h, out_n = (size_t)ow * oh;
+  uint16_t* buf = (uint16_t*)rbtk::dev_alloc((in_n + out_n * 2) * 2);
+  if (!buf) return RBT_ERR_NOMEM;
+  struct G { void* p; ~G() { rbtk::dev_free(p); } } g{buf};
+  if (rbtk::h2d(buf, plane, in_n * 2)) return RBT_ERR_NO_DEVICE;
+  rbtk::launch_pool(buf, w, h, factor, buf + in_n, buf + in_n + out_n, buf + in_n + out_n + out_n / 4, 0);
+  if (rbtk::d2h(out, buf + in_n, out_n * 2)) return RBT_ERR_NO_DEVICE;
+  return 0;
+}
+
+}  // namespace rbt

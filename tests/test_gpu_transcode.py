@@ -1,0 +1,107 @@
+"""GPU parity of the encode half and of the whole transcode path (through the C ABI) vs the CPU oracle: bit-exact
+bitstreams, plus size-independent properties at BASELINE.json frame size."""
+import numpy as np
+import pytest
+import oracle_lib as O
+import rbt_lib
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    R = rbt_lib.module()
+    c = R.Context(device=0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("log2_ctb,rows", [(5, 1), (6, 0), (4, 2), (5, 0), (6, 1)])
+def test_encoder_bitstream_identical(ctx, log2_ctb, rows):
+    m = synth.make_maps(256, 192, 41)
+    for key, qp in (("geo", 24), ("attr", 32), ("geo", 40), ("attr", 12)):
+        a = ctx.encode(m[key], 256, 192, 10, qp, gop=2, log2_ctb=log2_ctb, rows_per_slice=rows)
+        b, _ = O.encode(m[key], 256, 192, 10, qp, gop=2, log2_ctb=log2_ctb, rows_per_slice=rows)
+        assert a == b
+    a = ctx.encode(m["occ"], 128, 96, 8, 8, gop=1, lossless=1, log2_ctb=log2_ctb, rows_per_slice=rows)
+    b, _ = O.encode(m["occ"], 128, 96, 8, 8, gop=1, lossless=1, i_qp_offset=0, log2_ctb=log2_ctb, rows_per_slice=rows)
+    assert a == b
+
+
+def test_encoder_edge_sizes(ctx):
+    """picture sizes that are not multiples of the CTB: implicit quadtree splits at the right / bottom edge"""
+    for (w, h) in ((80, 48), (144, 112), (48, 208)):
+        r = np.random.default_rng(w * h)
+        fr = r.integers(0, 1024, (4, w * h * 3 // 2)).astype(np.uint16)
+        fr[1] = np.clip(fr[0].astype(int) + r.integers(-3, 4, fr[0].shape), 0, 1023)
+        fr[3] = fr[2]
+        for log2_ctb in (4, 5, 6):
+            a = ctx.encode(fr, w, h, 10, 30, gop=2, log2_ctb=log2_ctb, rows_per_slice=1)
+            b, _ = O.encode(fr, w, h, 10, 30, gop=2, log2_ctb=log2_ctb, rows_per_slice=1)
+            assert a == b
+
+
+def test_or_pool(ctx):
+    r = np.random.default_rng(9)
+    p = (r.integers(0, 256, (128, 192)) * (r.random((128, 192)) < 0.2)).astype(np.uint16)
+    assert np.array_equal(ctx.or_pool(p, 2), O.or_pool(p, 2))
+    assert np.array_equal(ctx.or_pool(np.zeros((64, 64), np.uint16), 2), np.zeros((32, 32), np.uint16))
+
+
+def _r5_streams(w, h, n_pc, seed):
+    geo, attr, occ = synth.make_gof(w, h, n_pc, seed)
+    sg, _ = O.encode(geo, w, h, 10, 16, gop=2, log2_ctb=6, rows_per_slice=0)
+    sa, _ = O.encode(attr, w, h, 10, 22, gop=2, log2_ctb=6, rows_per_slice=0)
+    so, _ = O.encode(occ, w // 2, h // 2, 8, 8, gop=1, lossless=1, i_qp_offset=0, log2_ctb=6, rows_per_slice=0)
+    return so, sg, sa, occ
+
+
+@pytest.mark.parametrize("target", [(24, 32), (32, 42)])   # R3 and R1 QPs (cfg/rate/ctc-r3.cfg, ctc-r1.cfg)
+def test_transcode_substreams_identical_to_oracle(ctx, target):
+    R = rbt_lib.module()
+    so, sg, sa, _ = _r5_streams(192, 128, 2, 77)
+    for s, vt, qp in ((sg, R.RBT_VIDEO_GEOMETRY, target[0]), (sa, R.RBT_VIDEO_ATTRIBUTE, target[1]), (so, R.RBT_VIDEO_OCCUPANCY, 8)):
+        assert ctx.transcode_substream(s, vt, qp, verify_md5=1) == O.transcode_substream(s, vt, qp)
+    # occupancy precision 2: no pooling, lossless re-encode at the same size
+    assert ctx.transcode_substream(so, R.RBT_VIDEO_OCCUPANCY, 8, occupancy_precision=2) == O.transcode_substream(so, 0, 8, occupancy_precision=2)
+
+
+def test_transcode_gof_equals_per_stream_calls(ctx):
+    R = rbt_lib.module()
+    so, sg, sa, _ = _r5_streams(192, 128, 3, 5)
+    P = R.StreamParams
+    outs = ctx.transcode_gof([so, sg, sa], [P(0, 8, 4, 5, 1, 1, 0), P(1, 24, 4, 5, 1, 1, 0), P(19, 32, 4, 5, 1, 1, 0)])
+    assert outs[0] == ctx.transcode_substream(so, 0, 8)
+    assert outs[1] == ctx.transcode_substream(sg, 1, 24)
+    assert outs[2] == ctx.transcode_substream(sa, 19, 32)
+
+
+def test_full_size_point_cloud_frame(ctx):
+    """BASELINE.json frame size (1280x1280 maps, 640x640 occupancy), one point-cloud frame, R5 -> R3, bit-exact vs oracle;
+    then the size-independent properties: output decodes with every MD5 SEI matching, occupancy == OR-pool of the input."""
+    R = rbt_lib.module()
+    so, sg, sa, occ = _r5_streams(1280, 1280, 1, 1051)
+    P = R.StreamParams
+    outs = ctx.transcode_gof([so, sg, sa], [P(0, 8, 4, 5, 1, 1, 1), P(1, 24, 4, 5, 1, 1, 1), P(19, 32, 4, 5, 1, 1, 1)])
+    assert outs[1] == O.transcode_substream(sg, 1, 24)
+    assert outs[2] == O.transcode_substream(sa, 19, 32)
+    assert outs[0] == O.transcode_substream(so, 0, 8)
+    dec, w, h, bd, chk, fail = ctx.decode(outs[0])
+    assert (w, h, bd, fail) == (320, 320, 8, 0) and chk == 1
+    want = (occ[:, :640 * 640].reshape(1, 320, 2, 320, 2).max(axis=(2, 4)) > 0).astype(np.uint16)
+    assert np.array_equal(dec[:, :320 * 320].reshape(1, 320, 320), want)
+    for o in outs[1:]:
+        dec, w, h, bd, chk, fail = ctx.decode(o)
+        assert (w, h, bd, chk, fail) == (1280, 1280, 10, 2, 0)
+
+
+def test_transcode_is_idempotent_in_structure(ctx):
+    """transcoding the transcoder's own output (per-row slices, CTB 32) works and keeps sizes / frame counts"""
+    R = rbt_lib.module()
+    so, sg, sa, _ = _r5_streams(128, 128, 2, 3)
+    once = ctx.transcode_substream(sg, R.RBT_VIDEO_GEOMETRY, 24)
+    twice = ctx.transcode_substream(once, R.RBT_VIDEO_GEOMETRY, 32, verify_md5=1)
+    assert twice == O.transcode_substream(once, 1, 32)
+    dec, w, h, bd, chk, fail = ctx.decode(twice)
+    assert (w, h, dec.shape[0], fail) == (128, 128, 4, 0)
