@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Benchmark of the V-PCC transcoding hot path on MI355X (BASELINE.json metric: transcoded point-cloud frames/s).
+
+Workload (config.workload): one 32-frame GOF of 1280x1280 V-PCC maps — 64 geometry + 64 attribute pictures
+(yuv420p10, I/P pairs) and 32 occupancy pictures (640x640, 8 bit, lossless) — at "R5" (QP 16 / 22, occupancy
+precision 2), transcoded to R3 (geometryQP 24, attributeQP 32, occupancyPrecision 4). There is no 8i data and no HM
+here, so the maps are synthetic (tests/synth.py) and the R5 input is produced by this repository's own GPU encoder in
+HM-like structure (CTB 64, one slice per picture). One "step" = one rbt_transcode_gof call over the whole GOF.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--pc-frames F]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+N > 1: weak scaling — every rank transcodes its own GOF, then the re-encoded NAL units are gathered on rank 0 with RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def make_gof_maps(w, h, n_pc, seed):
+    """n_pc point-cloud frames: 4 base atlases jittered by a few pixels per frame."""
+    import synth
+    bases = [synth.make_maps(w, h, seed + k) for k in range(min(4, n_pc))]
+    geo, attr, occ = [], [], []
+    ys, cs = w * h, (w // 2) * (h // 2)
+
+    def roll(frame, ww, hh, d):
+        y = np.roll(frame[: ww * hh].reshape(hh, ww), d, axis=1).ravel()
+        c = (ww // 2) * (hh // 2)
+        u = np.roll(frame[ww * hh: ww * hh + c].reshape(hh // 2, ww // 2), d // 2, axis=1).ravel()
+        v = np.roll(frame[ww * hh + c:].reshape(hh // 2, ww // 2), d // 2, axis=1).ravel()
+        return np.concatenate([y, u, v])
+    for i in range(n_pc):
+        b = bases[i % len(bases)]
+        d = 2 * (i // len(bases))
+        geo += [roll(b["geo"][0], w, h, d), roll(b["geo"][1], w, h, d)]
+        attr += [roll(b["attr"][0], w, h, d), roll(b["attr"][1], w, h, d)]
+        occ += [roll(b["occ"][0], w // 2, h // 2, d // 2)]
+    del ys, cs
+    return np.stack(geo), np.stack(attr), np.stack(occ)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pc-frames", type=int, default=32)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=1280)
+    ap.add_argument("--cpu-sample", type=int, default=6, help="point-cloud frames of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    import rbt_lib
+    R = rbt_lib.module()
+    ctx = R.Context(device=local_rank, rank=rank, world=world)   # raises without a GPU: no CPU fallback
+
+    w, h, n_pc = args.width, args.height, args.pc_frames
+    geo, attr, occ = make_gof_maps(w, h, n_pc, 1051 + 1000 * rank)
+    # R5 input in HM-like structure, produced by the GPU encoder (outside the timed region)
+    sg = ctx.encode(geo, w, h, 10, 16, gop=2, log2_ctb=6, rows_per_slice=0, md5_sei=0)
+    sa = ctx.encode(attr, w, h, 10, 22, gop=2, log2_ctb=6, rows_per_slice=0, md5_sei=0)
+    so = ctx.encode(occ, w // 2, h // 2, 8, 8, gop=1, lossless=1, log2_ctb=6, rows_per_slice=0, md5_sei=0)
+    P = R.StreamParams
+    params = [P(R.RBT_VIDEO_OCCUPANCY, 8, 4, 5, 1, 0, 0), P(R.RBT_VIDEO_GEOMETRY, 24, 4, 5, 1, 0, 0), P(R.RBT_VIDEO_ATTRIBUTE, 32, 4, 5, 1, 0, 0)]
+    streams = [so, sg, sa]
+
+    def step():
+        outs = ctx.transcode_gof(streams, params)
+        if world > 1:
+            from importlib import import_module  # noqa: F401
+            gs = rbt_lib.module_file("gof_shard")
+            gs.gather_streams(outs, device=f"cuda:{local_rank}")
+        return outs
+
+    def sync():
+        if world > 1:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    stats_acc = {}
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outs = step()
+        s = ctx.stats()
+        for k, v in s.items():
+            stats_acc[k] = stats_acc.get(k, 0.0) + v
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    steps = args.steps
+    fps = world * n_pc * steps / elapsed
+    st = {k: v / steps for k, v in stats_acc.items()}
+
+    # dominant kernel group of the path (GPU-side hipEvent timings taken on the launch stream inside librbt)
+    groups = {"cabac_parse": st["k_parse_ms"], "reconstruct+loopfilter": st["k_recon_ms"], "intra_analysis": st["k_analyse_ms"],
+              "encode_recon": st["k_encode_ms"], "cabac_encode": st["k_entropy_ms"]}
+    dom = max(groups, key=groups.get)
+    in_bytes = sum(len(s_) for s_ in streams)
+    out_bytes = sum(len(o) for o in outs)
+    fsz = lambda ww, hh: ww * hh * 3  # noqa: E731  (4:2:0, 2 bytes per sample)
+    pics = {"geo": (2 * n_pc, fsz(w, h)), "attr": (2 * n_pc, fsz(w, h)), "occ_in": (n_pc, fsz(w // 2, h // 2)), "occ_out": (n_pc, fsz(w // 4, h // 4))}
+    dec_pix = pics["geo"][0] * pics["geo"][1] + pics["attr"][0] * pics["attr"][1] + pics["occ_in"][0] * pics["occ_in"][1]
+    enc_pix = pics["geo"][0] * pics["geo"][1] + pics["attr"][0] * pics["attr"][1] + pics["occ_out"][0] * pics["occ_out"][1]
+    # algorithmic bytes per launch group (DESIGN.md "Measurement"): what each stage must move at minimum
+    alg = {"cabac_parse": in_bytes + dec_pix,                 # slice data in, one coefficient level per sample out
+           "reconstruct+loopfilter": 2 * dec_pix + dec_pix // 2,   # levels in, samples out, P pictures read their reference
+           "intra_analysis": enc_pix // 2,                     # I-picture source samples
+           "encode_recon": 3 * enc_pix + enc_pix // 2,         # source in, levels + reconstruction out, P reference in
+           "cabac_encode": enc_pix + out_bytes}                # levels in, slice data out
+    achieved = alg[dom] / (groups[dom] * 1e-3) / 1e9 if groups[dom] > 0 else 0.0
+    path_achieved = st["algorithmic_bytes"] / (st["gpu_ms"] * 1e-3) / 1e9 if st.get("gpu_ms", 0) > 0 else 0.0
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        import oracle_lib as O   # CPU checker, used here only as the timed CPU baseline ("port")
+        k = min(args.cpu_sample, n_pc)
+        # bounded sample of the same workload: the first k point-cloud frames of the same GOF
+        sub = [ctx.encode(occ[:k], w // 2, h // 2, 8, 8, gop=1, lossless=1, log2_ctb=6, rows_per_slice=0, md5_sei=0),
+               ctx.encode(geo[:2 * k], w, h, 10, 16, gop=2, log2_ctb=6, rows_per_slice=0, md5_sei=0),
+               ctx.encode(attr[:2 * k], w, h, 10, 22, gop=2, log2_ctb=6, rows_per_slice=0, md5_sei=0)]
+        c0 = time.perf_counter()
+        O.transcode_substream(sub[0], 0, 8, md5_sei=0)
+        O.transcode_substream(sub[1], 1, 24, md5_sei=0)
+        O.transcode_substream(sub[2], 19, 32, md5_sei=0)
+        ct = time.perf_counter() - c0
+        cpu = {"value": round(k / ct, 4), "unit": "point-cloud frames/s", "cores": 1, "kind": "port",
+               "sample": f"first {k} point-cloud frames of the same GOF, oracle/liboracle.so (scalar C restatement), {ct:.1f} s"}
+
+    if rank == 0:
+        line = {"metric": "transcoded point-cloud frames/sec, R5->R3", "value": round(fps, 3), "unit": "point-cloud frames/s", "n_gpus": world,
+                "steps": steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "u16/i32", "data": "synthetic",
+                "config": {"workload": f"{n_pc}-frame GOF, {w}x{h} V-PCC maps (2x{n_pc} geometry + 2x{n_pc} attribute yuv420p10 I/P pairs, {n_pc} occupancy {w // 2}x{h // 2} lossless), "
+                                       f"R5 (QP16/22, prec 2) -> R3 (QP24/32, prec 4), synthetic longdress-like atlas",
+                           "gof_per_gpu": 1, "in_bytes": in_bytes, "out_bytes": out_bytes, "parallelism": f"gof-shard x{world}"},
+                "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                             "traffic": None, "kernel_ms": {k_: round(v, 3) for k_, v in groups.items()},
+                             "path_achieved_GBs": round(path_achieved, 3), "path_frac": round(path_achieved / HBM_PEAK_GBS, 6)},
+                "cpu_baseline": cpu,
+                "host_ms": {"parse": round(st["host_parse_ms"], 3), "pack": round(st["host_pack_ms"], 3), "gpu": round(st["gpu_ms"], 3), "total": round(st["total_ms"], 3)}}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,5 +1,11 @@
 // CABAC engines (H.265 9.3.4.3 decode, 9.3.4.x encode) for wave-uniform execution: one wave runs one slice segment,
 // every lane executes the same scalar sequence, lane 0 owns the global stores.
+//
+// The engine state lives in registers, not memory: the 157 context variables are spread over the 64 lanes of three
+// VGPRs (context i = lane i & 63 of register i >> 6) and are read / updated with v_readlane / a lane-select; rangeTabLPS
+// and the LPS state transition table sit in two more VGPRs (lane = pStateIdx). Everything derived from them is
+// wave-uniform, so range / offset arithmetic runs on the scalar unit and a bin costs no LDS or global-memory access.
+// The bitstream is consumed through aligned 32-bit words (scalar loads).
 #pragma once
 #include "rbt_tables.h"
 
@@ -11,55 +17,129 @@ enum {
   CTX_TRANSFORM_SKIP = 41, CTX_LAST_X = 43, CTX_LAST_Y = 61, CTX_CSBF = 79, CTX_SIG = 83, CTX_GT1 = 127, CTX_GT2 = 151
 };
 
-RBT_DEV void rbt_ctx_init(RBT_LDS_AS uint8_t* st, int init_type, int qp) {
+// ------------------------------------------------------------------------------------------------ context store
+struct RbtCtxStore {
+#ifdef RBT_HOSTEMU
+  uint8_t st[RBT_CTX_COUNT + 3];
+#else
+  int st0, st1, st2;     // lane-distributed context variables: pStateIdx << 1 | valMps
+  int lps_tab;           // lane s: rangeTabLPS[s][0..3] packed little-endian
+  int nxt_tab;           // lane s: transIdxLps[s]
+#endif
+};
+RBT_DEV int rbt_ctx_initval(int init_type, int qp, int i) {
+  int iv = k_ctx_init[init_type][i];
+  int m = (iv >> 4) * 5 - 45, n = ((iv & 15) << 3) - 16;
+  int pre = rbt_clip3(1, 126, ((m * qp) >> 4) + n);
+  int mps = pre <= 63 ? 0 : 1;
+  return ((mps ? pre - 64 : 63 - pre) << 1) | mps;
+}
+RBT_DEV void rbt_ctx_init(RbtCtxStore* s, int init_type, int qp) {
   qp = rbt_clip3(0, 51, qp);
-  RBT_PAR_FOR(i, RBT_CTX_COUNT) {
-    int iv = k_ctx_init[init_type][i];
-    int m = (iv >> 4) * 5 - 45, n = ((iv & 15) << 3) - 16;
-    int pre = rbt_clip3(1, 126, ((m * qp) >> 4) + n);
-    int mps = pre <= 63 ? 0 : 1;
-    st[i] = (uint8_t)(((mps ? pre - 64 : 63 - pre) << 1) | mps);
-  }
+#ifdef RBT_HOSTEMU
+  for (int i = 0; i < RBT_CTX_COUNT; i++) s->st[i] = (uint8_t)rbt_ctx_initval(init_type, qp, i);
+#else
+  int lane = (int)threadIdx.x & 63;
+  s->st0 = rbt_ctx_initval(init_type, qp, lane);
+  s->st1 = rbt_ctx_initval(init_type, qp, lane + 64);
+  s->st2 = lane + 128 < RBT_CTX_COUNT ? rbt_ctx_initval(init_type, qp, lane + 128) : 0;
+  s->lps_tab = (int)(k_range_lps[lane][0] | (k_range_lps[lane][1] << 8) | (k_range_lps[lane][2] << 16) | ((uint32_t)k_range_lps[lane][3] << 24));
+  s->nxt_tab = k_next_lps[lane];
+#endif
+}
+RBT_DEV int rbt_ctx_get(const RbtCtxStore* s, int ctx) {
+#ifdef RBT_HOSTEMU
+  return s->st[ctx];
+#else
+  int lane = ctx & 63, r = ctx >> 6;
+  if (r == 0) return __builtin_amdgcn_readlane(s->st0, lane);
+  if (r == 1) return __builtin_amdgcn_readlane(s->st1, lane);
+  return __builtin_amdgcn_readlane(s->st2, lane);
+#endif
+}
+RBT_DEV void rbt_ctx_set(RbtCtxStore* s, int ctx, int v) {
+#ifdef RBT_HOSTEMU
+  s->st[ctx] = (uint8_t)v;
+#else
+  // v_writelane has no builtin in this toolchain: a per-lane select (v_cmp + v_cndmask) does the same job
+  int me = (int)threadIdx.x & 63, lane = ctx & 63, r = ctx >> 6;
+  if (r == 0) s->st0 = me == lane ? v : s->st0;
+  else if (r == 1) s->st1 = me == lane ? v : s->st1;
+  else s->st2 = me == lane ? v : s->st2;
+#endif
+}
+RBT_DEV int rbt_lps(const RbtCtxStore* s, int state, int q) {
+#ifdef RBT_HOSTEMU
+  (void)s; return k_range_lps[state][q];
+#else
+  return (int)(((uint32_t)__builtin_amdgcn_readlane(s->lps_tab, state) >> (8 * q)) & 255u);
+#endif
+}
+RBT_DEV int rbt_next_lps(const RbtCtxStore* s, int state) {
+#ifdef RBT_HOSTEMU
+  (void)s; return k_next_lps[state];
+#else
+  return __builtin_amdgcn_readlane(s->nxt_tab, state);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ decoder
 struct RbtCabacDec {
-  const uint8_t* p; uint32_t size, pos;   // byte cursor of the next refill
-  uint64_t buf; int nbuf;                 // bit reservoir (MSB first)
+  const uint32_t* w; uint32_t n_words, widx;   // aligned word cursor over the slice data
+  uint32_t next_raw;                           // word widx, loaded one refill ahead so its latency is hidden (raw, per-lane copy)
+  uint64_t buf; int nbuf;                      // bit reservoir (MSB first)
   uint32_t range, offset;
-  RBT_LDS_AS uint8_t* st;
+  uint32_t bits_total, bits_read;
+#ifdef RBT_PROFILE
+  uint32_t n_bins, n_byp;
+#endif
+  RbtCtxStore cs;
 };
 RBT_DEV uint32_t rbt_cd_bits(RbtCabacDec* c, int n) {
   if (n == 0) return 0;
   if (c->nbuf < n) {
-    uint32_t v = 0;
-    for (int i = 0; i < 4; i++) { uint32_t b = c->pos < c->size ? c->p[c->pos] : 0; c->pos++; v = (v << 8) | b; }
+    uint32_t v = (uint32_t)RBT_UNI(__builtin_bswap32(c->next_raw));
+    c->widx++;
+    c->next_raw = c->widx < c->n_words ? c->w[c->widx] : 0;
     c->buf = (c->buf << 32) | v; c->nbuf += 32;
   }
   uint32_t r = (uint32_t)(c->buf >> (c->nbuf - n)) & ((1u << n) - 1u);
-  c->nbuf -= n;
+  c->nbuf -= n; c->bits_read += (uint32_t)n;
   return r;
 }
-RBT_DEV void rbt_cd_start(RbtCabacDec* c, const uint8_t* p, uint32_t size, RBT_LDS_AS uint8_t* st) {
-  c->p = p; c->size = size; c->pos = 0; c->buf = 0; c->nbuf = 0; c->st = st; c->range = 510; c->offset = rbt_cd_bits(c, 9);
+// p .. p+size is the slice data; the allocation is padded so that the aligned words covering it can be read
+RBT_DEV void rbt_cd_start(RbtCabacDec* c, const uint8_t* p, uint32_t size) {
+  uintptr_t a = (uintptr_t)p; int mis = (int)(a & 3);
+  c->w = (const uint32_t*)(a - (uintptr_t)mis); c->n_words = (size + (uint32_t)mis + 3) >> 2; c->widx = 0;
+  c->buf = 0; c->nbuf = 0; c->bits_total = size * 8; c->bits_read = 0;
+  c->next_raw = c->n_words ? c->w[0] : 0;
+  if (mis) { (void)rbt_cd_bits(c, 8 * mis); c->bits_read = 0; }
+  c->range = 510; c->offset = rbt_cd_bits(c, 9);
 }
 RBT_DEV int rbt_cd_bin(RbtCabacDec* c, int ctx) {
-  int s = c->st[ctx] >> 1, mps = c->st[ctx] & 1, bin;
-  uint32_t lps = k_range_lps[s][(c->range >> 6) & 3];
+#ifdef RBT_PROFILE
+  c->n_bins++;
+#endif
+  int st = rbt_ctx_get(&c->cs, ctx);
+  int s = st >> 1, mps = st & 1, bin;
+  uint32_t lps = (uint32_t)rbt_lps(&c->cs, s, (int)((c->range >> 6) & 3));
   c->range -= lps;
   if (c->offset >= c->range) {
     bin = !mps; c->offset -= c->range; c->range = lps;
     if (s == 0) mps = 1 - mps;
-    s = k_next_lps[s];
+    s = rbt_next_lps(&c->cs, s);
   } else { bin = mps; s = s >= 62 ? s : s + 1; }
-  c->st[ctx] = (uint8_t)((s << 1) | mps);
+  rbt_ctx_set(&c->cs, ctx, (s << 1) | mps);
   if (c->range < 256) {
-    int sh = 0; uint32_t r = c->range; while (r < 256) { r <<= 1; sh++; }
-    c->range = r; c->offset = (c->offset << sh) | rbt_cd_bits(c, sh);
+    int sh = __builtin_clz(c->range) - 23;
+    c->range <<= sh; c->offset = (c->offset << sh) | rbt_cd_bits(c, sh);
   }
   return bin;
 }
 RBT_DEV int rbt_cd_bypass(RbtCabacDec* c) {
+#ifdef RBT_PROFILE
+  c->n_byp++;
+#endif
   c->offset = (c->offset << 1) | rbt_cd_bits(c, 1);
   if (c->offset >= c->range) { c->offset -= c->range; return 1; }
   return 0;
@@ -71,14 +151,27 @@ RBT_DEV int rbt_cd_terminate(RbtCabacDec* c) {
   if (c->range < 256) { c->range <<= 1; c->offset = (c->offset << 1) | rbt_cd_bits(c, 1); }
   return 0;
 }
-RBT_DEV uint32_t rbt_cd_bytes_consumed(const RbtCabacDec* c) { return c->pos - (uint32_t)(c->nbuf >> 3); }
+// Copies the engine into a function-local object whose scalar fields are marked wave-uniform: the local lives in SGPRs
+// (scalar ALU, scalar branches) for the duration of a hot loop, independent of where the enclosing parser state sits.
+RBT_DEV void rbt_cd_localise(RbtCabacDec* d, const RbtCabacDec* c) {
+  d->next_raw = c->next_raw;
+  d->w = rbt_uni_ptr(c->w); d->n_words = (uint32_t)RBT_UNI(c->n_words); d->widx = (uint32_t)RBT_UNI(c->widx);
+  d->buf = ((uint64_t)(uint32_t)RBT_UNI((uint32_t)(c->buf >> 32)) << 32) | (uint32_t)RBT_UNI((uint32_t)c->buf);
+  d->nbuf = RBT_UNI(c->nbuf); d->range = (uint32_t)RBT_UNI(c->range); d->offset = (uint32_t)RBT_UNI(c->offset);
+  d->bits_total = (uint32_t)RBT_UNI(c->bits_total); d->bits_read = (uint32_t)RBT_UNI(c->bits_read);
+  d->cs = c->cs;
+#ifdef RBT_PROFILE
+  d->n_bins = c->n_bins; d->n_byp = c->n_byp;
+#endif
+}
+RBT_DEV int rbt_cd_overrun(const RbtCabacDec* c) { return c->bits_read > c->bits_total + 64; }
 
 // ------------------------------------------------------------------------------------------------ encoder
 struct RbtCabacEnc {
   uint8_t* out; uint32_t cap, n;          // byte output (lane 0 stores)
   uint32_t acc; int nacc;                 // bit accumulator
   uint32_t low, range; int outstanding, first;
-  RBT_LDS_AS uint8_t* st;
+  RbtCtxStore cs;
   int overflow;
 };
 RBT_DEV void rbt_ce_write_bit(RbtCabacEnc* c, int b) {
@@ -101,14 +194,15 @@ RBT_DEV void rbt_ce_renorm(RbtCabacEnc* c) {
     c->range <<= 1; c->low <<= 1;
   }
 }
-RBT_DEV void rbt_ce_start(RbtCabacEnc* c, RBT_LDS_AS uint8_t* st) { c->low = 0; c->range = 510; c->first = 1; c->outstanding = 0; c->st = st; }
+RBT_DEV void rbt_ce_start(RbtCabacEnc* c) { c->low = 0; c->range = 510; c->first = 1; c->outstanding = 0; }
 RBT_DEV void rbt_ce_bin(RbtCabacEnc* c, int ctx, int bin) {
-  int s = c->st[ctx] >> 1, mps = c->st[ctx] & 1;
-  uint32_t lps = k_range_lps[s][(c->range >> 6) & 3];
+  int st = rbt_ctx_get(&c->cs, ctx);
+  int s = st >> 1, mps = st & 1;
+  uint32_t lps = (uint32_t)rbt_lps(&c->cs, s, (int)((c->range >> 6) & 3));
   c->range -= lps;
-  if (bin != mps) { c->low += c->range; c->range = lps; if (s == 0) mps = 1 - mps; s = k_next_lps[s]; }
+  if (bin != mps) { c->low += c->range; c->range = lps; if (s == 0) mps = 1 - mps; s = rbt_next_lps(&c->cs, s); }
   else s = s >= 62 ? s : s + 1;
-  c->st[ctx] = (uint8_t)((s << 1) | mps);
+  rbt_ctx_set(&c->cs, ctx, (s << 1) | mps);
   rbt_ce_renorm(c);
 }
 RBT_DEV void rbt_ce_bypass(RbtCabacEnc* c, int bin) {

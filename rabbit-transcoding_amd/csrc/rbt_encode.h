@@ -28,7 +28,6 @@ struct RbtEncLds {
   uint8_t mode[3][16];
   uint8_t split[3][16];
   uint16_t cg_mask[64];      // entropy: significance mask of each 4x4 coefficient group (bit n = scan position n)
-  uint8_t ctx[RBT_CTX_COUNT + 3];
 };
 
 // sum of v over the lanes of the wave (host emulation: the PAR_FOR already accumulated everything)
@@ -480,10 +479,9 @@ RBT_DEV void en_write_quadtree(RbtEnt* s, int x0, int y0, int log2) {
 RBT_DEV void en_entropy_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, uint8_t* out, RBT_LDS_AS RbtEncLds* l) {
   RbtEnt s; s.sl = &slices[slice_idx]; s.f = &frames[s.sl->frame]; s.slice_idx = slice_idx; s.l = l;
   const RbtSlice* sl = s.sl; const RbtStreamCfg* g = &s.f->cfg;
-  rbt_ctx_init(l->ctx, sl->slice_type == RBT_SLICE_I ? 0 : 1, sl->qp);
-  RBT_SYNC();
+  rbt_ctx_init(&s.c.cs, sl->slice_type == RBT_SLICE_I ? 0 : 1, sl->qp);
   s.c.out = out + sl->out_off; s.c.cap = sl->out_cap; s.c.n = 0; s.c.acc = 0; s.c.nacc = 0; s.c.overflow = 0;
-  rbt_ce_start(&s.c, l->ctx);
+  rbt_ce_start(&s.c);
   for (int a = 0; a < sl->n_ctbs; a++) {
     int addr = sl->ctb_addr + a, rx = addr % g->w_ctb, ry = addr / g->w_ctb;
     en_write_quadtree(&s, rx << g->log2_ctb, ry << g->log2_ctb, g->log2_ctb);

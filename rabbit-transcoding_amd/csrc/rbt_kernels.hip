@@ -42,8 +42,8 @@ double timer_ms(int id) { float ms = 0; if (hipEventElapsedTime(&ms, g_ev[id][0]
 // ---------------------------------------------------------------------------------------------- decode kernels
 // one wave per slice segment: wave-uniform CABAC parse (rbt_parse.h)
 __global__ void __launch_bounds__(64) k_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list) {
-  __shared__ uint8_t ctx_states[RBT_CTX_COUNT + 3];
-  rbt_parse_slice(frames, slices, slice_list[blockIdx.x], rbsp, RBT_LDS_CAST(uint8_t, ctx_states));
+  __shared__ RbtParseLds lds;
+  rbt_parse_slice(frames, slices, slice_list[blockIdx.x], rbsp, RBT_LDS_CAST(RbtParseLds, &lds));
 }
 // one wave per CTB on anti-diagonal d (x + 2y == d): left, above-left, above and above-right CTBs are complete
 __global__ void __launch_bounds__(64) k_recon_diag(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int d) {

@@ -17,61 +17,155 @@
 #define RBT_TR(...) do { } while (0)
 #endif
 
+// wave-uniform copy of the slice header fields the parser needs (scalar members only)
+struct RbtSliceU {
+  int slice_type, qp, cb_qp_offset, cr_qp_offset, sao_luma, sao_chroma, temporal_mvp, cabac_init_flag, max_merge_cand, num_ref_idx, collocated_ref_idx, poc;
+};
+
+struct RbtParseLds {
+  uint8_t cur_pm[256], cur_dm[256], cur_edges[256]; int8_t cur_qp[256], cur_ref[256]; int32_t cur_mv[256];   // current CTB, row stride 16 units
+  uint8_t left_pm[16], left_dm[16]; int8_t left_ref[16]; int32_t left_mv[16];                                 // right column of the left CTB
+  uint8_t above_pm[2048], above_dm[2048]; int8_t above_ref[2048]; int32_t above_mv[2048];                     // bottom row of the CTB row above
+  uint16_t above_slice[512];                                                                                   // slice that decoded the CTB above (0xFFFF none)
+  RbtSao sao_above[512]; RbtSao sao_left;
+  uint8_t scan[3][4][64];                                                                                      // k_scan copied once per slice
+  int32_t ref_poc[RBT_MAX_REFS], ref_frame[RBT_MAX_REFS];   // RefPicList0 of the slice (indexed at run time: kept out of the register-resident parser state)
+};
 struct RbtParse {
-  RbtFrame* f; RbtSlice* sl; const RbtFrame* frames; int slice_idx;
+  RBT_LDS_AS RbtParseLds* L; int ctb_x, ctb_y, left_ok, corner_ok, corner_pm, corner_dm, corner_ref, corner_mv;
+  RbtFrame* f; RbtSliceU sl; const RbtFrame* frames; int slice_idx;
+  // wave-uniform copies of the picture's map pointers (SGPR pairs instead of a pointer load per access)
+  uint8_t *m_pm, *m_edges, *m_dm; int8_t *m_qp, *m_ref; int16_t* m_mv; int32_t* m_refpoc; uint16_t* m_cs; RbtSao* m_sao; RbtCmd* m_cmds; uint32_t* m_cnt;
+  int16_t *m_coef0, *m_coef1, *m_coef2; int m_cap;
   RbtStreamCfg cfg;
   RbtCabacDec c;
   int qp_y, qp_pred, qp_y_prev, is_cu_qp_delta_coded, cu_qp_delta_val;
   int ctb_addr; uint32_t n_cmds;
   int cu_x, cu_y, cu_log2, cu_pred_mode, cu_part_mode, cu_tq_bypass;
-  int intra_luma[4], intra_chroma, max_trafo_depth, last_pu_merge;
+  int il_packed, intra_chroma, max_trafo_depth, last_pu_merge;   // no arrays / index-selected fields here: they would pin the whole struct in scratch
   int error;
+#ifdef RBT_PROFILE
+  unsigned long long t_res, t_ctb, t_cu; uint32_t n_res, n_cu;
+#endif
 };
 struct RbtMv { int x, y, ref; };
+RBT_DEV int pz_il(const RbtParse* s, int i) { return (s->il_packed >> (8 * i)) & 255; }   // luma intra modes of the (up to four) PUs, 8 bits each
+RBT_DEV void pz_set_il(RbtParse* s, int i, int v) { s->il_packed = (s->il_packed & ~(255 << (8 * i))) | (v << (8 * i)); }
 
+// ---- neighbour context in LDS -------------------------------------------------------------------------------------
+// The parser never reads the HBM maps of its own picture back: everything later syntax depends on (prediction mode,
+// skip, depth, intra mode, QP, motion) is kept per 4x4 unit in LDS for the current CTB, the right column of the left
+// CTB, the bottom row of the CTB row above (line buffer over the picture width) and the above-left corner unit. The
+// HBM maps are written once per CTB (pz_flush_ctb) with plain stores that nobody waits for.
 RBT_DEV int pz_idx(const RbtParse* s, int x, int y) { return (y >> 2) * s->cfg.w4 + (x >> 2); }
-RBT_DEV int pz_slice_at(const RbtParse* s, int x, int y) { return s->f->ctb_slice[(y >> s->cfg.log2_ctb) * s->cfg.w_ctb + (x >> s->cfg.log2_ctb)]; }
-RBT_DEV int pz_avail(const RbtParse* s, int xn, int yn) {
-  if (xn < 0 || yn < 0 || xn >= s->cfg.w || yn >= s->cfg.h) return 0;
-  if ((s->f->pm[pz_idx(s, xn, yn)] & RBT_PM_MODE_MASK) == RBT_MODE_NONE) return 0;
-  return pz_slice_at(s, xn, yn) == s->slice_idx;
+// handle of luma position (xn,yn): -1 = not available (outside the picture, other slice, not decoded yet);
+// else region << 12 | index with region 0 current CTB, 1 left column, 2 above row, 3 above-left corner
+RBT_DEV int pz_loc(const RbtParse* s, int xn, int yn) {
+  if (xn < 0 || yn < 0 || xn >= s->cfg.w || yn >= s->cfg.h) return -1;
+  int cx = s->ctb_x, cy = s->ctb_y, L = s->cfg.log2_ctb, ctb = 1 << L;
+  if (yn >= cy + ctb) return -1;
+  if (yn < cy) {
+    if (yn < cy - 1) return -1;
+    if (xn < cx) return s->corner_ok ? (3 << 12) : -1;
+    if (s->L->above_slice[xn >> L] != s->slice_idx) return -1;
+    return (2 << 12) | (xn >> 2);
+  }
+  if (xn < cx) return s->left_ok ? ((1 << 12) | ((yn - cy) >> 2)) : -1;
+  if (xn >= cx + ctb) return -1;
+  int k = ((yn - cy) >> 2) * 16 + ((xn - cx) >> 2);
+  return (s->L->cur_pm[k] & RBT_PM_MODE_MASK) == RBT_MODE_NONE ? -1 : k;
 }
-RBT_DEV int pz_mode(const RbtParse* s, int x, int y) { return s->f->pm[pz_idx(s, x, y)] & RBT_PM_MODE_MASK; }
-RBT_DEV void pz_fill_u8(const RbtParse* s, uint8_t* a, int x, int y, int w, int h, int v) {
-  int w4 = w >> 2, n = w4 * (h >> 2), base = pz_idx(s, x, y), st = s->cfg.w4;
-  RBT_PAR_FOR(i, n) a[base + (i / w4) * st + (i % w4)] = (uint8_t)v;
+RBT_DEV int pz_ld_pm(const RbtParse* s, int loc) { int r = loc >> 12, i = loc & 4095; return r == 0 ? s->L->cur_pm[i] : (r == 1 ? s->L->left_pm[i] : (r == 2 ? s->L->above_pm[i] : s->corner_pm)); }
+RBT_DEV int pz_ld_dm(const RbtParse* s, int loc) { int r = loc >> 12, i = loc & 4095; return r == 0 ? s->L->cur_dm[i] : (r == 1 ? s->L->left_dm[i] : (r == 2 ? s->L->above_dm[i] : s->corner_dm)); }
+RBT_DEV int pz_ld_ref(const RbtParse* s, int loc) { int r = loc >> 12, i = loc & 4095; return r == 0 ? s->L->cur_ref[i] : (r == 1 ? s->L->left_ref[i] : (r == 2 ? s->L->above_ref[i] : s->corner_ref)); }
+RBT_DEV int pz_ld_mv(const RbtParse* s, int loc) { int r = loc >> 12, i = loc & 4095; return r == 0 ? s->L->cur_mv[i] : (r == 1 ? s->L->left_mv[i] : (r == 2 ? s->L->above_mv[i] : s->corner_mv)); }
+RBT_DEV int pz_avail(const RbtParse* s, int xn, int yn) { return pz_loc(s, xn, yn) >= 0; }
+RBT_DEV int pz_mode(const RbtParse* s, int x, int y) { return pz_ld_pm(s, pz_loc(s, x, y)) & RBT_PM_MODE_MASK; }   // caller checked pz_avail
+RBT_DEV int pz_dm(const RbtParse* s, int x, int y) { return pz_ld_dm(s, pz_loc(s, x, y)); }
+RBT_DEV int pz_cur(const RbtParse* s, int x, int y) { return ((y - s->ctb_y) >> 2) * 16 + ((x - s->ctb_x) >> 2); }
+RBT_DEV void pz_fill_dm(const RbtParse* s, int x, int y, int w, int h, int v) {
+  int w4 = w >> 2, n = w4 * (h >> 2), base = pz_cur(s, x, y);
+  RBT_PAR_FOR(i, n) s->L->cur_dm[base + (i / w4) * 16 + (i % w4)] = (uint8_t)v;
+}
+RBT_DEV void pz_fill_qp(const RbtParse* s, int x, int y, int w, int h, int v) {
+  int w4 = w >> 2, n = w4 * (h >> 2), base = pz_cur(s, x, y);
+  RBT_PAR_FOR(i, n) s->L->cur_qp[base + (i / w4) * 16 + (i % w4)] = (int8_t)v;
 }
 RBT_DEV void pz_fill_pm(const RbtParse* s, int x, int y, int w, int h, int keep_mask, int v) {
-  int w4 = w >> 2, n = w4 * (h >> 2), base = pz_idx(s, x, y), st = s->cfg.w4;
-  RBT_PAR_FOR(i, n) { int k = base + (i / w4) * st + (i % w4); s->f->pm[k] = (uint8_t)((s->f->pm[k] & keep_mask) | v); }
+  int w4 = w >> 2, n = w4 * (h >> 2), base = pz_cur(s, x, y);
+  RBT_PAR_FOR(i, n) { int k = base + (i / w4) * 16 + (i % w4); s->L->cur_pm[k] = (uint8_t)((s->L->cur_pm[k] & keep_mask) | v); }
 }
 RBT_DEV void pz_mark_edges(const RbtParse* s, int x, int y, int w, int h, int vbits, int hbits) {
   // two passes: the corner unit belongs to both the left column and the top row, and a read-modify-write of the same
   // byte by two lanes of one instruction would lose one of the updates
-  int nv = h >> 2, nh = w >> 2;
-  RBT_PAR_FOR(i, nv) s->f->edges[pz_idx(s, x, y + 4 * i)] |= (uint8_t)vbits;
-  RBT_SYNC();
-  RBT_PAR_FOR(i, nh) s->f->edges[pz_idx(s, x + 4 * i, y)] |= (uint8_t)hbits;
-  RBT_SYNC();
+  int nv = h >> 2, nh = w >> 2, base = pz_cur(s, x, y);
+  RBT_SYNC_LDS();
+  RBT_PAR_FOR(i, nv) s->L->cur_edges[base + i * 16] |= (uint8_t)vbits;
+  RBT_SYNC_LDS();
+  RBT_PAR_FOR(i, nh) s->L->cur_edges[base + i] |= (uint8_t)hbits;
+  RBT_SYNC_LDS();
+}
+// start of a CTB: nothing of it is decoded yet
+RBT_DEV void pz_begin_ctb(RbtParse* s, int rx, int ry) {
+  s->ctb_x = rx << s->cfg.log2_ctb; s->ctb_y = ry << s->cfg.log2_ctb;
+  RBT_PAR_FOR(i, 256) { s->L->cur_pm[i] = RBT_MODE_NONE; s->L->cur_edges[i] = 0; s->L->cur_dm[i] = 1; s->L->cur_qp[i] = 0; s->L->cur_ref[i] = -1; s->L->cur_mv[i] = 0; }
+  RBT_SYNC_LDS();
+}
+// end of a CTB: write its units to the HBM maps, then roll the line buffers
+RBT_DEV void pz_end_ctb(RbtParse* s, int rx, int ry) {
+  const RbtStreamCfg* g = &s->cfg; RBT_LDS_AS RbtParseLds* L = s->L;
+  int cx = s->ctb_x, cy = s->ctb_y, ctb = 1 << g->log2_ctb, n4 = ctb >> 2;
+  RBT_SYNC_LDS();
+  RBT_PAR_FOR(u, n4 * n4) {
+    int ux = u % n4, uy = u / n4, x = cx + ux * 4, y = cy + uy * 4;
+    if (x < g->w && y < g->h) {
+      int k = uy * 16 + ux, gk = (y >> 2) * g->w4 + (x >> 2), pm = L->cur_pm[k], ref = L->cur_ref[k], mv = L->cur_mv[k];
+      s->m_pm[gk] = (uint8_t)pm; s->m_dm[gk] = L->cur_dm[k]; s->m_edges[gk] = L->cur_edges[k]; s->m_qp[gk] = L->cur_qp[k]; s->m_ref[gk] = (int8_t)ref;
+      s->m_mv[2 * gk] = (int16_t)(mv & 0xFFFF); s->m_mv[2 * gk + 1] = (int16_t)(mv >> 16);
+      int mode = pm & RBT_PM_MODE_MASK;
+      s->m_refpoc[gk] = (mode == RBT_MODE_INTER || mode == RBT_MODE_SKIP) ? s->L->ref_poc[ref < 0 ? 0 : ref] : RBT_NO_REFPOC;
+    }
+  }
+  // above-left corner of the NEXT CTB = last unit of the old above row under this CTB
+  int last = rbt_min(cx + ctb, g->w) / 4 - 1;
+  int c_ok = ry > 0 && L->above_slice[rx] == s->slice_idx;
+  int c_pm = L->above_pm[last], c_dm = L->above_dm[last], c_ref = L->above_ref[last], c_mv = L->above_mv[last];
+  RBT_SYNC_LDS();
+  s->corner_ok = c_ok; s->corner_pm = c_pm; s->corner_dm = c_dm; s->corner_ref = c_ref; s->corner_mv = c_mv;
+  int rows = rbt_min(ctb, g->h - cy) >> 2, cols = rbt_min(ctb, g->w - cx) >> 2;
+  RBT_PAR_FOR(i, cols) { int k = (rows - 1) * 16 + i, a = (cx >> 2) + i; L->above_pm[a] = L->cur_pm[k]; L->above_dm[a] = L->cur_dm[k]; L->above_ref[a] = L->cur_ref[k]; L->above_mv[a] = L->cur_mv[k]; }
+  RBT_PAR_FOR(i, 16) { int k = i * 16 + cols - 1; L->left_pm[i] = i < rows ? L->cur_pm[k] : RBT_MODE_NONE; L->left_dm[i] = L->cur_dm[k]; L->left_ref[i] = L->cur_ref[k]; L->left_mv[i] = L->cur_mv[k]; }
+  if (RBT_LANE0) L->above_slice[rx] = (uint16_t)s->slice_idx;
+  s->left_ok = rx + 1 < g->w_ctb;
+  if (rx + 1 >= g->w_ctb) s->corner_ok = 0;
+  RBT_SYNC_LDS();
 }
 RBT_DEV void pz_emit(RbtParse* s, const RbtCmd& cmd) {
-  if ((int)s->n_cmds >= s->f->cmd_cap) { s->error = 3; return; }
-  if (RBT_LANE0) s->f->cmds[(size_t)s->ctb_addr * s->f->cmd_cap + s->n_cmds] = cmd;
+  if ((int)s->n_cmds >= s->m_cap) { s->error = 3; return; }
+  if (RBT_LANE0) s->m_cmds[(size_t)s->ctb_addr * s->m_cap + s->n_cmds] = cmd;
   s->n_cmds++;
 }
 
+// RbtSao <-> LDS copies (struct assignment across address spaces is not defined; RbtSao is 24 plain bytes)
+RBT_DEV void pz_sao_from_lds(RbtSao* d, const RBT_LDS_AS RbtSao* l) {
+  for (int i = 0; i < 3; i++) { d->type[i] = l->type[i]; d->band_pos[i] = l->band_pos[i]; d->eo_class[i] = l->eo_class[i]; for (int k = 0; k < 4; k++) d->offset[i][k] = l->offset[i][k]; }
+  d->pad[0] = d->pad[1] = d->pad[2] = 0;
+}
+RBT_DEV void pz_sao_to_lds(RBT_LDS_AS RbtSao* l, const RbtSao* d) {
+  for (int i = 0; i < 3; i++) { l->type[i] = d->type[i]; l->band_pos[i] = d->band_pos[i]; l->eo_class[i] = d->eo_class[i]; for (int k = 0; k < 4; k++) l->offset[i][k] = d->offset[i][k]; }
+}
 // ------------------------------------------------------------------------------------------------ SAO (7.3.8.3)
 RBT_DEV void pz_sao(RbtParse* s, int rx, int ry) {
-  RbtCabacDec* c = &s->c; const RbtSlice* sl = s->sl;
+  RbtCabacDec* c = &s->c; const RbtSliceU* sl = &s->sl;
   RbtSao p; for (int i = 0; i < 3; i++) { p.type[i] = p.band_pos[i] = p.eo_class[i] = 0; for (int k = 0; k < 4; k++) p.offset[i][k] = 0; }
   p.pad[0] = p.pad[1] = p.pad[2] = 0;
   int wc = s->cfg.w_ctb;
   if (sl->sao_luma || sl->sao_chroma) {
     int merge_left = 0, merge_up = 0;
-    if (rx > 0 && s->f->ctb_slice[ry * wc + rx - 1] == s->slice_idx) merge_left = rbt_cd_bin(c, CTX_SAO_MERGE);
-    if (ry > 0 && !merge_left && s->f->ctb_slice[(ry - 1) * wc + rx] == s->slice_idx) merge_up = rbt_cd_bin(c, CTX_SAO_MERGE);
-    if (merge_left) p = s->f->sao[ry * wc + rx - 1];
-    else if (merge_up) p = s->f->sao[(ry - 1) * wc + rx];
+    if (rx > 0 && s->left_ok) merge_left = rbt_cd_bin(c, CTX_SAO_MERGE);
+    if (ry > 0 && !merge_left && s->L->above_slice[rx] == s->slice_idx) merge_up = rbt_cd_bin(c, CTX_SAO_MERGE);
+    if (merge_left) pz_sao_from_lds(&p, &s->L->sao_left);
+    else if (merge_up) pz_sao_from_lds(&p, &s->L->sao_above[rx]);
     else {
       int bd = s->cfg.bit_depth, cmax = (1 << (rbt_min(bd, 10) - 5)) - 1;
       for (int ci = 0; ci < 3; ci++) {
@@ -94,16 +188,27 @@ RBT_DEV void pz_sao(RbtParse* s, int rx, int ry) {
       }
     }
   }
-  if (RBT_LANE0) s->f->sao[ry * wc + rx] = p;
+  if (RBT_LANE0) { s->m_sao[ry * wc + rx] = p; pz_sao_to_lds(&s->L->sao_left, &p); pz_sao_to_lds(&s->L->sao_above[rx], &p); }
+  RBT_SYNC_LDS();
 }
 
+// 4x4 scan positions packed 4 bits per entry (x | y << 2): diagonal, horizontal, vertical; and ctxIdxMap of 4x4 TBs
+RBT_DEV uint64_t pz_scan4_const(int scan_idx) { return scan_idx == 0 ? 0xFBE7AD369C258140ull : (scan_idx == 1 ? 0xFEDCBA9876543210ull : 0xFB73EA62D951C840ull); }
+#define PZ_SIGCTX4 0x8877886654325410ull
 // ------------------------------------------------------------------------------------------------ residual_coding (7.3.8.11)
 // Levels go straight to the dense coefficient plane of component c_idx at TB origin (x0,y0) (component samples).
 RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int scan_idx) {
-  RbtCabacDec* c = &s->c;
-  int16_t* plane = s->f->coef[c_idx]; int pst = c_idx ? s->cfg.cw : s->cfg.w;
+#ifdef RBT_PROFILE
+  unsigned long long t0_ = __builtin_readcyclecounter(); s->n_res++;
+#endif
+  RbtCabacDec cl; rbt_cd_localise(&cl, &s->c); RbtCabacDec* c = &cl;
+  x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); log2 = RBT_UNI(log2); scan_idx = RBT_UNI(scan_idx);
+  const uint64_t ps = pz_scan4_const(scan_idx);
+#define PZ_POS(n) ((int)((ps >> (4 * (n))) & 15))
+  int16_t* plane = rbt_uni_ptr(c_idx == 0 ? s->m_coef0 : (c_idx == 1 ? s->m_coef1 : s->m_coef2)); int pst = RBT_UNI(c_idx ? s->cfg.cw : s->cfg.w);
+  const int tq_bypass = RBT_UNI(s->cu_tq_bypass), sdh_on = RBT_UNI(s->cfg.sign_hiding), ts_on = RBT_UNI(s->cfg.transform_skip);
   int ts_flag = 0;
-  if (s->cfg.transform_skip && !s->cu_tq_bypass && log2 <= 2) ts_flag = rbt_cd_bin(c, CTX_TRANSFORM_SKIP + (c_idx ? 1 : 0));
+  if (ts_on && !tq_bypass && log2 <= 2) ts_flag = rbt_cd_bin(c, CTX_TRANSFORM_SKIP + (c_idx ? 1 : 0));
   int ctx_off, ctx_shift;
   if (c_idx == 0) { ctx_off = 3 * (log2 - 2) + ((log2 - 1) >> 2); ctx_shift = (log2 + 1) >> 2; }
   else { ctx_off = 15; ctx_shift = log2 - 2; }
@@ -114,18 +219,17 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
   if (px > 3) { int nb = (px >> 1) - 1; lx = (1 << nb) * (2 + (px & 1)) + (int)rbt_cd_bypass_n(c, nb); }
   if (py > 3) { int nb = (py >> 1) - 1; ly = (1 << nb) * (2 + (py & 1)) + (int)rbt_cd_bypass_n(c, nb); }
   if (scan_idx == 2) { int t = lx; lx = ly; ly = t; }
-  const uint8_t* sb_scan = k_scan[scan_idx][log2 - 2];
-  const uint8_t* pos_scan = k_scan[scan_idx][2];
+  const RBT_LDS_AS uint8_t* sb_scan = s->L->scan[scan_idx][log2 - 2];
   int n_sb = 1 << (2 * (log2 - 2)), last_sb = 0, last_pos = 0;
   { int sbx = lx >> 2, sby = ly >> 2, ix = lx & 3, iy = ly & 3;
-    for (int i = 0; i < n_sb; i++) if ((sb_scan[i] & 15) == sbx && (sb_scan[i] >> 4) == sby) { last_sb = i; break; }
-    for (int i = 0; i < 16; i++) if ((pos_scan[i] & 15) == ix && (pos_scan[i] >> 4) == iy) { last_pos = i; break; } }
+    for (int i = 0; i < n_sb; i++) if (RBT_UNI(sb_scan[i]) == (sbx | (sby << 4))) { last_sb = i; break; }
+    for (int i = 0; i < 16; i++) if (PZ_POS(i) == (ix | (iy << 2))) { last_pos = i; break; } }
   uint64_t csbf = 0;   // bit (ys*8+xs)
   int sbw = 1 << (log2 - 2);
   int greater1_ctx = 1, first_sb_done = 0;
-  int sign_hiding = s->cfg.sign_hiding && !s->cu_tq_bypass;
+  int sign_hiding = sdh_on && !tq_bypass;
   for (int i = last_sb; i >= 0; i--) {
-    int xs = sb_scan[i] & 15, ys = sb_scan[i] >> 4;
+    int sbv = RBT_UNI(sb_scan[i]); int xs = sbv & 15, ys = sbv >> 4;
     int right = xs + 1 < sbw ? (int)((csbf >> (ys * 8 + xs + 1)) & 1) : 0, below = ys + 1 < sbw ? (int)((csbf >> ((ys + 1) * 8 + xs)) & 1) : 0;
     int infer_dc = 0, coded;
     if (i < last_sb && i > 0) { coded = rbt_cd_bin(c, CTX_CSBF + rbt_min(right + below, 1) + (c_idx ? 2 : 0)); infer_dc = 1; }
@@ -137,10 +241,10 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
     if (i == last_sb) { sig_mask |= 1u << last_pos; nsig++; }
     int prev_csbf = right | (below << 1);
     for (int n = start; n >= 0; n--) {
-      int xp = pos_scan[n] & 15, yp = pos_scan[n] >> 4, xc = (xs << 2) + xp, yc = (ys << 2) + yp, sig;
+      int xp = PZ_POS(n) & 3, yp = PZ_POS(n) >> 2, xc = (xs << 2) + xp, yc = (ys << 2) + yp, sig;
       if (n > 0 || !infer_dc) {
         int sc;
-        if (log2 == 2) sc = k_sig_ctx_4x4[(yc << 2) + xc];
+        if (log2 == 2) sc = (int)((PZ_SIGCTX4 >> (4 * ((yc << 2) + xc))) & 15);
         else if (xc + yc == 0) sc = 0;
         else {
           if (prev_csbf == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
@@ -182,19 +286,24 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
         int pre = 0; while (pre < 32 && rbt_cd_bypass(c)) pre++;
         int v;
         if (pre <= 3) v = (pre << rice) + (int)rbt_cd_bypass_n(c, rice);
-        else { int sl = pre - 3 + rice; if (sl > 30) { s->error = 4; return 0; } v = (((1 << (pre - 3)) + 3 - 1) << rice) + (int)rbt_cd_bypass_n(c, sl); }
+        else { int sl = pre - 3 + rice; if (sl > 30) { s->error = 4; s->c = cl; return 0; } v = (((1 << (pre - 3)) + 3 - 1) << rice) + (int)rbt_cd_bypass_n(c, sl); }
         a += v;
         if (a > 3 * (1 << rice)) rice = rbt_min(rice + 1, 4);
       }
       sum += a;
       int neg = k < nsign ? (int)((signs >> (15 - k)) & 1) : (sum & 1);
-      int xc = (xs << 2) + (pos_scan[n] & 15), yc = (ys << 2) + (pos_scan[n] >> 4);
+      int xc = (xs << 2) + (PZ_POS(n) & 3), yc = (ys << 2) + (PZ_POS(n) >> 2);
       int v = rbt_clip3(-32768, 32767, neg ? -a : a);
       if (RBT_LANE0) plane[(size_t)(y0 + yc) * pst + x0 + xc] = (int16_t)v;
       k++;
     }
   }
+  s->c = cl;
+#ifdef RBT_PROFILE
+  s->t_res += __builtin_readcyclecounter() - t0_;
+#endif
   return ts_flag;
+#undef PZ_POS
 }
 
 // ------------------------------------------------------------------------------------------------ QP
@@ -203,12 +312,12 @@ RBT_DEV void pz_start_qg(RbtParse* s, int xqg, int yqg) {
   int ctb_mask = ~((1 << s->cfg.log2_ctb) - 1);
   s->qp_y_prev = s->qp_y; s->is_cu_qp_delta_coded = 0; s->cu_qp_delta_val = 0;
   int qa = s->qp_y_prev, qb = s->qp_y_prev;
-  if (xqg > 0 && ((xqg - 1) & ctb_mask) == (xqg & ctb_mask) && pz_avail(s, xqg - 1, yqg)) qa = s->f->qp[pz_idx(s, xqg - 1, yqg)];
-  if (yqg > 0 && ((yqg - 1) & ctb_mask) == (yqg & ctb_mask) && pz_avail(s, xqg, yqg - 1)) qb = s->f->qp[pz_idx(s, xqg, yqg - 1)];
+  if (xqg > 0 && ((xqg - 1) & ctb_mask) == (xqg & ctb_mask) && pz_avail(s, xqg - 1, yqg)) qa = s->L->cur_qp[pz_cur(s, xqg - 1, yqg)];
+  if (yqg > 0 && ((yqg - 1) & ctb_mask) == (yqg & ctb_mask) && pz_avail(s, xqg, yqg - 1)) qb = s->L->cur_qp[pz_cur(s, xqg, yqg - 1)];
   s->qp_pred = (qa + qb + 1) >> 1;
 }
 RBT_DEV int pz_chroma_qp(const RbtParse* s, int c_idx) {
-  int off = c_idx == 1 ? s->cfg.cb_qp_offset + s->sl->cb_qp_offset : s->cfg.cr_qp_offset + s->sl->cr_qp_offset;
+  int off = c_idx == 1 ? s->cfg.cb_qp_offset + s->sl.cb_qp_offset : s->cfg.cr_qp_offset + s->sl.cr_qp_offset;
   int bdo = 6 * (s->cfg.bit_depth - 8);
   int qpi = rbt_clip3(-bdo, 57, s->qp_y + off);
   return (qpi < 0 ? qpi : rbt_chroma_qp(qpi)) + bdo;
@@ -231,7 +340,7 @@ RBT_DEV void pz_transform_unit(RbtParse* s, int x0, int y0, int xb, int yb, int 
     if (v && rbt_cd_bypass(c)) v = -v;
     s->is_cu_qp_delta_coded = 1; s->cu_qp_delta_val = v;
     s->qp_y = pz_wrap_qp(s, s->qp_pred + v);
-    pz_fill_u8(s, (uint8_t*)s->f->qp, s->cu_x, s->cu_y, 1 << s->cu_log2, 1 << s->cu_log2, (uint8_t)(int8_t)s->qp_y);
+    pz_fill_qp(s, s->cu_x, s->cu_y, 1 << s->cu_log2, 1 << s->cu_log2, s->qp_y);
   }
   int intra = s->cu_pred_mode == RBT_MODE_INTRA;
   int part = 0;
@@ -240,10 +349,10 @@ RBT_DEV void pz_transform_unit(RbtParse* s, int x0, int y0, int xb, int yb, int 
   pz_mark_edges(s, x0, y0, N, N, RBT_EV_TU, RBT_EH_TU);
   int chroma_here = log2 > 2 || blk == 3;
   RbtCmd cmd; cmd.type = RBT_CMD_TU; cmd.x4 = (uint8_t)((x0 & ((1 << s->cfg.log2_ctb) - 1)) >> 2); cmd.y4 = (uint8_t)((y0 & ((1 << s->cfg.log2_ctb) - 1)) >> 2);
-  cmd.log2 = (uint8_t)log2; cmd.b = (uint8_t)s->intra_luma[part]; cmd.c = (uint8_t)s->intra_chroma; cmd.d = (uint8_t)s->cu_tq_bypass; cmd.mvx = cmd.mvy = 0; cmd.pad = 0;
+  cmd.log2 = (uint8_t)log2; cmd.b = (uint8_t)pz_il(s, part); cmd.c = (uint8_t)s->intra_chroma; cmd.d = (uint8_t)s->cu_tq_bypass; cmd.mvx = cmd.mvy = 0; cmd.pad = 0;
   int flags = (cbf_luma ? RBT_TU_CBF_Y : 0) | (intra ? RBT_TU_INTRA : 0) | (chroma_here ? RBT_TU_CHROMA : 0);
   if (chroma_here) flags |= (cbf_cb ? RBT_TU_CBF_CB : 0) | (cbf_cr ? RBT_TU_CBF_CR : 0);
-  if (cbf_luma && pz_residual(s, 0, x0, y0, log2, pz_scan_idx(s->cu_pred_mode, log2, 0, s->intra_luma[part]))) flags |= RBT_TU_TS_Y;
+  if (cbf_luma && pz_residual(s, 0, x0, y0, log2, pz_scan_idx(s->cu_pred_mode, log2, 0, pz_il(s, part)))) flags |= RBT_TU_TS_Y;
   if (chroma_here && !s->error) {
     int xc = (log2 > 2 ? x0 : xb) >> 1, yc = (log2 > 2 ? y0 : yb) >> 1, l2c = log2 > 2 ? log2 - 1 : 2;
     int sc = pz_scan_idx(s->cu_pred_mode, l2c, 1, s->intra_chroma);
@@ -295,7 +404,7 @@ RBT_DEV void pz_transform_tree(RbtParse* s, int x0, int y0, int xb, int yb, int 
 
 // ------------------------------------------------------------------------------------------------ motion (8.5.3.2)
 RBT_DEV int pz_pu_avail(const RbtParse* s, int xn, int yn) { return pz_avail(s, xn, yn) && pz_mode(s, xn, yn) != RBT_MODE_INTRA; }
-RBT_DEV RbtMv pz_mv_at(const RbtParse* s, int x, int y) { int i = pz_idx(s, x, y); RbtMv m; m.x = s->f->mv[2 * i]; m.y = s->f->mv[2 * i + 1]; m.ref = s->f->ref[i]; return m; }
+RBT_DEV RbtMv pz_mv_at(const RbtParse* s, int x, int y) { int loc = pz_loc(s, x, y), v = pz_ld_mv(s, loc); RbtMv m; m.x = (int16_t)(v & 0xFFFF); m.y = (int16_t)(v >> 16); m.ref = pz_ld_ref(s, loc); return m; }
 RBT_DEV int pz_mv_same(RbtMv a, RbtMv b) { return a.x == b.x && a.y == b.y && a.ref == b.ref; }
 RBT_DEV int pz_scale_mv(int mv, int tb, int td) {
   td = rbt_clip3(-128, 127, td); tb = rbt_clip3(-128, 127, tb);
@@ -305,9 +414,9 @@ RBT_DEV int pz_scale_mv(int mv, int tb, int td) {
   return rbt_clip3(-32768, 32767, (p < 0 ? -1 : 1) * ((rbt_abs(p) + 127) >> 8));
 }
 RBT_DEV int pz_temporal(const RbtParse* s, int xpb, int ypb, int w, int h, int ref_idx, RbtMv* out) {
-  const RbtSlice* sl = s->sl;
+  const RbtSliceU* sl = &s->sl;
   if (!sl->temporal_mvp) return 0;
-  const RbtFrame* col = &s->frames[sl->ref_frame[sl->collocated_ref_idx]];
+  const RbtFrame* col = &s->frames[s->L->ref_frame[sl->collocated_ref_idx]];
   int cx[2] = {xpb + w, xpb + (w >> 1)}, cy[2] = {ypb + h, ypb + (h >> 1)};
   for (int k = 0; k < 2; k++) {
     int x = cx[k], y = cy[k];
@@ -316,7 +425,7 @@ RBT_DEV int pz_temporal(const RbtParse* s, int xpb, int ypb, int w, int h, int r
     int i = (y >> 2) * s->cfg.w4 + (x >> 2);
     int cm = col->pm[i] & RBT_PM_MODE_MASK;
     if (cm == RBT_MODE_INTRA || cm == RBT_MODE_NONE) continue;
-    int td = col->poc - col->refpoc[i], tb = sl->poc - sl->ref_poc[ref_idx];
+    int td = col->poc - col->refpoc[i], tb = sl->poc - s->L->ref_poc[ref_idx];
     int mx = col->mv[2 * i], my = col->mv[2 * i + 1];
     if (td != tb && td != 0) { mx = pz_scale_mv(mx, tb, td); my = pz_scale_mv(my, tb, td); }
     out->x = mx; out->y = my; out->ref = ref_idx;
@@ -325,7 +434,7 @@ RBT_DEV int pz_temporal(const RbtParse* s, int xpb, int ypb, int w, int h, int r
   return 0;
 }
 RBT_DEV RbtMv pz_merge(const RbtParse* s, int xpb, int ypb, int w, int h, int part_idx, int merge_idx) {
-  int pm = s->cu_part_mode, maxc = s->sl->max_merge_cand;
+  int pm = s->cu_part_mode, maxc = s->sl.max_merge_cand;
   RbtMv list[6]; int n = 0;
   RbtMv ca1 = {0, 0, 0}, cb1 = {0, 0, 0};
   int a1 = pz_pu_avail(s, xpb - 1, ypb + h - 1) && !((pm == RBT_PART_Nx2N || pm == RBT_PART_nLx2N || pm == RBT_PART_nRx2N) && part_idx == 1);
@@ -342,32 +451,32 @@ RBT_DEV RbtMv pz_merge(const RbtParse* s, int xpb, int ypb, int w, int h, int pa
   if (n > maxc) n = maxc;
   if (n < maxc) { RbtMv t; if (pz_temporal(s, xpb, ypb, w, h, 0, &t)) list[n++] = t; }
   int zero_idx = 0;
-  while (n < maxc) { RbtMv z = {0, 0, zero_idx < s->sl->num_ref_idx ? zero_idx : 0}; list[n++] = z; zero_idx++; }
+  while (n < maxc) { RbtMv z = {0, 0, zero_idx < s->sl.num_ref_idx ? zero_idx : 0}; list[n++] = z; zero_idx++; }
   RbtMv r = list[0];
   for (int i = 1; i < 5; i++) if (i == merge_idx) r = list[i];     // avoid dynamic private-array indexing
   return r;
 }
 RBT_DEV RbtMv pz_amvp(const RbtParse* s, int xpb, int ypb, int w, int h, int ref_idx, int mvp_flag) {
-  const RbtSlice* sl = s->sl;
-  int tgt = sl->ref_poc[ref_idx], cur = sl->poc;
+  const RbtSliceU* sl = &s->sl;
+  int tgt = s->L->ref_poc[ref_idx], cur = sl->poc;
   int xa[2] = {xpb - 1, xpb - 1}, ya[2] = {ypb + h, ypb + h - 1};
   int xb[3] = {xpb + w, xpb + w - 1, xpb - 1}, yb[3] = {ypb - 1, ypb - 1, ypb - 1};
   int ava[2], avb[3];
   for (int k = 0; k < 2; k++) ava[k] = pz_pu_avail(s, xa[k], ya[k]);
   for (int k = 0; k < 3; k++) avb[k] = pz_pu_avail(s, xb[k], yb[k]);
   int fa = 0, fb = 0; RbtMv ma = {0, 0, 0}, mb = {0, 0, 0};
-  for (int k = 0; k < 2 && !fa; k++) if (ava[k]) { RbtMv q = pz_mv_at(s, xa[k], ya[k]); if (sl->ref_poc[q.ref] == tgt) { ma = q; fa = 1; } }
+  for (int k = 0; k < 2 && !fa; k++) if (ava[k]) { RbtMv q = pz_mv_at(s, xa[k], ya[k]); if (s->L->ref_poc[q.ref] == tgt) { ma = q; fa = 1; } }
   for (int k = 0; k < 2 && !fa; k++) if (ava[k]) {
-    RbtMv q = pz_mv_at(s, xa[k], ya[k]); int td = cur - sl->ref_poc[q.ref], tb = cur - tgt;
+    RbtMv q = pz_mv_at(s, xa[k], ya[k]); int td = cur - s->L->ref_poc[q.ref], tb = cur - tgt;
     ma = q; fa = 1; if (td != tb && td != 0) { ma.x = pz_scale_mv(q.x, tb, td); ma.y = pz_scale_mv(q.y, tb, td); }
   }
   int is_scaled = ava[0] || ava[1];
-  for (int k = 0; k < 3 && !fb; k++) if (avb[k]) { RbtMv q = pz_mv_at(s, xb[k], yb[k]); if (sl->ref_poc[q.ref] == tgt) { mb = q; fb = 1; } }
+  for (int k = 0; k < 3 && !fb; k++) if (avb[k]) { RbtMv q = pz_mv_at(s, xb[k], yb[k]); if (s->L->ref_poc[q.ref] == tgt) { mb = q; fb = 1; } }
   if (!is_scaled && fb) { ma = mb; fa = 1; }
   if (!is_scaled) {
     fb = 0;
     for (int k = 0; k < 3 && !fb; k++) if (avb[k]) {
-      RbtMv q = pz_mv_at(s, xb[k], yb[k]); int td = cur - sl->ref_poc[q.ref], tb = cur - tgt;
+      RbtMv q = pz_mv_at(s, xb[k], yb[k]); int td = cur - s->L->ref_poc[q.ref], tb = cur - tgt;
       mb = q; fb = 1; if (td != tb && td != 0) { mb.x = pz_scale_mv(q.x, tb, td); mb.y = pz_scale_mv(q.y, tb, td); }
     }
   }
@@ -385,7 +494,7 @@ RBT_DEV int pz_mvd_comp(RbtCabacDec* c, int gt0, int gt1) {
   return rbt_cd_bypass(c) ? -v : v;
 }
 RBT_DEV void pz_prediction_unit(RbtParse* s, int x0, int y0, int w, int h, int part_idx, int skip) {
-  RbtCabacDec* c = &s->c; const RbtSlice* sl = s->sl;
+  RbtCabacDec* c = &s->c; const RbtSliceU* sl = &s->sl;
   RbtMv mv;
   int merge = skip ? 1 : rbt_cd_bin(c, CTX_MERGE_FLAG);
   s->last_pu_merge = merge;
@@ -407,14 +516,13 @@ RBT_DEV void pz_prediction_unit(RbtParse* s, int x0, int y0, int w, int h, int p
     mv.x = (int16_t)(mv.x + dx); mv.y = (int16_t)(mv.y + dy);
   }
   if (mv.ref < 0 || mv.ref >= sl->num_ref_idx) { s->error = 5; return; }
-  int w4 = w >> 2, n = w4 * (h >> 2), base = pz_idx(s, x0, y0), st = s->cfg.w4, refpoc = sl->ref_poc[mv.ref];
-  int mode = skip ? RBT_MODE_SKIP : RBT_MODE_INTER;
+  int w4 = w >> 2, n = w4 * (h >> 2), base = pz_cur(s, x0, y0);
+  int mode = skip ? RBT_MODE_SKIP : RBT_MODE_INTER, packed = (int)(((uint32_t)(uint16_t)mv.y << 16) | (uint16_t)mv.x);
   RBT_PAR_FOR(i, n) {
-    int k = base + (i / w4) * st + (i % w4);
-    s->f->mv[2 * k] = (int16_t)mv.x; s->f->mv[2 * k + 1] = (int16_t)mv.y; s->f->ref[k] = (int8_t)mv.ref; s->f->refpoc[k] = refpoc;
-    s->f->pm[k] = (uint8_t)((s->f->pm[k] & ~RBT_PM_MODE_MASK) | mode);
+    int k = base + (i / w4) * 16 + (i % w4);
+    s->L->cur_mv[k] = packed; s->L->cur_ref[k] = (int8_t)mv.ref;
+    s->L->cur_pm[k] = (uint8_t)((s->L->cur_pm[k] & ~RBT_PM_MODE_MASK) | mode);
   }
-  RBT_SYNC();
   pz_mark_edges(s, x0, y0, w, h, RBT_EV_PU, RBT_EH_PU);
   RbtCmd cmd; cmd.type = RBT_CMD_PU; cmd.x4 = (uint8_t)((x0 & ((1 << s->cfg.log2_ctb) - 1)) >> 2); cmd.y4 = (uint8_t)((y0 & ((1 << s->cfg.log2_ctb) - 1)) >> 2);
   cmd.log2 = 0; cmd.a = (uint8_t)(w >> 2); cmd.b = (uint8_t)(h >> 2); cmd.c = (uint8_t)mv.ref; cmd.d = 0; cmd.mvx = (int16_t)mv.x; cmd.mvy = (int16_t)mv.y;
@@ -425,8 +533,8 @@ RBT_DEV void pz_prediction_unit(RbtParse* s, int x0, int y0, int w, int h, int p
 // ------------------------------------------------------------------------------------------------ coding unit (7.3.8.5)
 RBT_DEV void pz_intra_mpm(const RbtParse* s, int xp, int yp, int cand[3]) {
   int ca = 1, cb = 1;
-  if (pz_avail(s, xp - 1, yp) && pz_mode(s, xp - 1, yp) == RBT_MODE_INTRA) ca = s->f->dm[pz_idx(s, xp - 1, yp)] & 63;
-  if (pz_avail(s, xp, yp - 1) && pz_mode(s, xp, yp - 1) == RBT_MODE_INTRA && ((yp - 1) >> s->cfg.log2_ctb) == (yp >> s->cfg.log2_ctb)) cb = s->f->dm[pz_idx(s, xp, yp - 1)] & 63;
+  if (pz_avail(s, xp - 1, yp) && pz_mode(s, xp - 1, yp) == RBT_MODE_INTRA) ca = pz_dm(s, xp - 1, yp) & 63;
+  if (pz_avail(s, xp, yp - 1) && pz_mode(s, xp, yp - 1) == RBT_MODE_INTRA && ((yp - 1) >> s->cfg.log2_ctb) == (yp >> s->cfg.log2_ctb)) cb = pz_dm(s, xp, yp - 1) & 63;
   if (ca == cb) {
     if (ca < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
     else { cand[0] = ca; cand[1] = 2 + ((ca + 29) % 32); cand[2] = 2 + ((ca - 2 + 1) % 32); }
@@ -439,23 +547,23 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
   if (cfg->cu_qp_delta) s->qp_y = pz_wrap_qp(s, s->qp_pred + s->cu_qp_delta_val);
   if (cfg->tq_bypass_enabled) s->cu_tq_bypass = rbt_cd_bin(c, CTX_CU_TQ_BYPASS);
   int skip = 0;
-  if (s->sl->slice_type != RBT_SLICE_I) {
+  if (s->sl.slice_type != RBT_SLICE_I) {
     int cl = pz_avail(s, x0 - 1, y0) && pz_mode(s, x0 - 1, y0) == RBT_MODE_SKIP;
     int ca = pz_avail(s, x0, y0 - 1) && pz_mode(s, x0, y0 - 1) == RBT_MODE_SKIP;
     skip = rbt_cd_bin(c, CTX_CU_SKIP + cl + ca);
   }
-  pz_fill_u8(s, (uint8_t*)s->f->qp, x0, y0, N, N, (uint8_t)(int8_t)s->qp_y);
+  pz_fill_qp(s, x0, y0, N, N, s->qp_y);
   pz_mark_edges(s, x0, y0, N, N, RBT_EV_TU | RBT_EV_PU, RBT_EH_TU | RBT_EH_PU);
   if (skip) {
     s->cu_pred_mode = RBT_MODE_SKIP;
-    pz_fill_u8(s, s->f->dm, x0, y0, N, N, (depth << 6) | 1);
+    pz_fill_dm(s, x0, y0, N, N, (depth << 6) | 1);
     pz_fill_pm(s, x0, y0, N, N, 0, RBT_MODE_NONE | (s->cu_tq_bypass ? RBT_PM_TQ_BYPASS : 0));
-    RBT_SYNC();
+    RBT_SYNC_LDS();
     pz_prediction_unit(s, x0, y0, N, N, 0, 1);
-    RBT_SYNC();
+    RBT_SYNC_LDS();
     return;
   }
-  if (s->sl->slice_type != RBT_SLICE_I) s->cu_pred_mode = rbt_cd_bin(c, CTX_PRED_MODE) ? RBT_MODE_INTRA : RBT_MODE_INTER;
+  if (s->sl.slice_type != RBT_SLICE_I) s->cu_pred_mode = rbt_cd_bin(c, CTX_PRED_MODE) ? RBT_MODE_INTRA : RBT_MODE_INTER;
   if (s->cu_pred_mode == RBT_MODE_INTRA) {
     if (log2 == cfg->log2_min_cb) s->cu_part_mode = rbt_cd_bin(c, CTX_PART_MODE) ? RBT_PART_2Nx2N : RBT_PART_NxN;
     if (s->cu_part_mode == RBT_PART_NxN && log2 == 3 && cfg->log2_min_tb > 2) { s->error = 6; return; }
@@ -474,8 +582,8 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
   }
   if (s->cu_pred_mode == RBT_MODE_INTRA) {
     pz_fill_pm(s, x0, y0, N, N, 0, RBT_MODE_INTRA | (s->cu_tq_bypass ? RBT_PM_TQ_BYPASS : 0));
-    pz_fill_u8(s, s->f->dm, x0, y0, N, N, (depth << 6) | 1);
-    RBT_SYNC();
+    pz_fill_dm(s, x0, y0, N, N, (depth << 6) | 1);
+    RBT_SYNC_LDS();
     int np = s->cu_part_mode == RBT_PART_NxN ? 4 : 1, pb = N >> (np == 4);
     int prev[4], mpm_idx[4], rem[4];
     for (int i = 0; i < np; i++) prev[i] = rbt_cd_bin(c, CTX_PREV_INTRA_LUMA);
@@ -496,19 +604,19 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
         mode = rem[i];
         for (int k = 0; k < 3; k++) if (mode >= cand[k]) mode++;
       }
-      s->intra_luma[i] = mode;
-      pz_fill_u8(s, s->f->dm, xp, yp, pb, pb, (depth << 6) | mode);
-      RBT_SYNC();
+      pz_set_il(s, i, mode);
+      pz_fill_dm(s, xp, yp, pb, pb, (depth << 6) | mode);
+      RBT_SYNC_LDS();
     }
     int icp = 4;
     if (rbt_cd_bin(c, CTX_INTRA_CHROMA)) icp = (int)rbt_cd_bypass_n(c, 2);
     int cmode = icp == 0 ? 0 : (icp == 1 ? 26 : (icp == 2 ? 10 : 1));
-    if (icp == 4) s->intra_chroma = s->intra_luma[0];
-    else s->intra_chroma = cmode == s->intra_luma[0] ? 34 : cmode;
+    if (icp == 4) s->intra_chroma = pz_il(s, 0);
+    else s->intra_chroma = cmode == pz_il(s, 0) ? 34 : cmode;
   } else {
-    pz_fill_u8(s, s->f->dm, x0, y0, N, N, (depth << 6) | 1);
+    pz_fill_dm(s, x0, y0, N, N, (depth << 6) | 1);
     pz_fill_pm(s, x0, y0, N, N, 0, RBT_MODE_NONE | (s->cu_tq_bypass ? RBT_PM_TQ_BYPASS : 0));
-    RBT_SYNC();
+    RBT_SYNC_LDS();
     int h2 = N >> 1, q = N >> 2, pmode = s->cu_part_mode;
     int np = pmode == RBT_PART_2Nx2N ? 1 : (pmode == RBT_PART_NxN ? 4 : 2);
     for (int i = 0; i < np && !s->error; i++) {
@@ -524,7 +632,7 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
         default: break;
       }
       pz_prediction_unit(s, x0 + px, y0 + py, pw, ph, i, 0);
-      RBT_SYNC();
+      RBT_SYNC_LDS();
     }
     if (s->error) return;
   }
@@ -534,7 +642,7 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
     s->max_trafo_depth = s->cu_pred_mode == RBT_MODE_INTRA ? cfg->th_depth_intra + (s->cu_part_mode == RBT_PART_NxN) : cfg->th_depth_inter;
     pz_transform_tree(s, x0, y0, x0, y0, log2, 0, 0, 0, 0);
   }
-  RBT_SYNC();
+  RBT_SYNC_LDS();
 }
 
 // ------------------------------------------------------------------------------------------------ coding quadtree + slice data
@@ -549,8 +657,8 @@ RBT_DEV void pz_coding_quadtree(RbtParse* s, int x0, int y0, int log2) {
     if (n->state < 0) {
       int split;
       if (n->x + N <= cfg->w && n->y + N <= cfg->h && n->log2 > cfg->log2_min_cb) {
-        int cl = pz_avail(s, n->x - 1, n->y) && (s->f->dm[pz_idx(s, n->x - 1, n->y)] >> 6) > n->depth;
-        int ca = pz_avail(s, n->x, n->y - 1) && (s->f->dm[pz_idx(s, n->x, n->y - 1)] >> 6) > n->depth;
+        int cl = pz_avail(s, n->x - 1, n->y) && (pz_dm(s, n->x - 1, n->y) >> 6) > n->depth;
+        int ca = pz_avail(s, n->x, n->y - 1) && (pz_dm(s, n->x, n->y - 1) >> 6) > n->depth;
         split = rbt_cd_bin(&s->c, CTX_SPLIT_CU + cl + ca);
       } else split = n->log2 > cfg->log2_min_cb;
       if (cfg->cu_qp_delta && n->log2 >= cfg->log2_ctb - cfg->diff_cu_qp_delta_depth) pz_start_qg(s, n->x, n->y);
@@ -567,33 +675,75 @@ RBT_DEV void pz_coding_quadtree(RbtParse* s, int x0, int y0, int log2) {
   }
 }
 
-// Entry: parses one slice segment. `ctx_states` is a RBT_CTX_COUNT byte scratch (LDS on the GPU).
-RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, const uint8_t* rbsp, RBT_LDS_AS uint8_t* ctx_states) {
+// Entry: parses one slice segment.
+RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, const uint8_t* rbsp, RBT_LDS_AS RbtParseLds* lds) {
   RbtParse s;
-  s.sl = &slices[slice_idx]; s.frames = frames; s.f = &frames[s.sl->frame]; s.slice_idx = slice_idx; s.cfg = s.f->cfg; s.error = 0;
-  const RbtSlice* sl = s.sl;
+  s.L = lds; s.left_ok = 0; s.corner_ok = 0; s.corner_pm = s.corner_dm = s.corner_ref = s.corner_mv = 0; s.ctb_x = s.ctb_y = 0;
+  RBT_PAR_FOR(i, 512) lds->above_slice[i] = 0xFFFF;
+  RBT_SYNC_LDS();
+  const RbtSlice* gs = &slices[slice_idx];
+  s.frames = frames; s.f = &frames[RBT_UNI(gs->frame)]; s.slice_idx = slice_idx; s.error = 0;
+  { RbtSliceU* u = &s.sl;
+    u->slice_type = RBT_UNI(gs->slice_type); u->qp = RBT_UNI(gs->qp); u->cb_qp_offset = RBT_UNI(gs->cb_qp_offset); u->cr_qp_offset = RBT_UNI(gs->cr_qp_offset);
+    u->sao_luma = RBT_UNI(gs->sao_luma); u->sao_chroma = RBT_UNI(gs->sao_chroma); u->temporal_mvp = RBT_UNI(gs->temporal_mvp); u->cabac_init_flag = RBT_UNI(gs->cabac_init_flag);
+    u->max_merge_cand = RBT_UNI(gs->max_merge_cand); u->num_ref_idx = RBT_UNI(gs->num_ref_idx); u->collocated_ref_idx = RBT_UNI(gs->collocated_ref_idx); u->poc = RBT_UNI(gs->poc);
+  }
+  RBT_PAR_FOR(i, RBT_MAX_REFS) { lds->ref_poc[i] = gs->ref_poc[i]; lds->ref_frame[i] = gs->ref_frame[i]; }
+  RBT_PAR_FOR(i, 3 * 4 * 64) lds->scan[i / 256][(i / 64) & 3][i & 63] = k_scan[i / 256][(i / 64) & 3][i & 63];
+  { const RbtFrame* f = s.f;
+    s.m_pm = rbt_uni_ptr(f->pm); s.m_edges = rbt_uni_ptr(f->edges); s.m_dm = rbt_uni_ptr(f->dm); s.m_qp = rbt_uni_ptr(f->qp); s.m_ref = rbt_uni_ptr(f->ref); s.m_mv = rbt_uni_ptr(f->mv);
+    s.m_refpoc = rbt_uni_ptr(f->refpoc); s.m_cs = rbt_uni_ptr(f->ctb_slice); s.m_sao = rbt_uni_ptr(f->sao); s.m_cmds = rbt_uni_ptr(f->cmds); s.m_cnt = rbt_uni_ptr(f->cmd_count);
+    s.m_coef0 = rbt_uni_ptr(f->coef[0]); s.m_coef1 = rbt_uni_ptr(f->coef[1]); s.m_coef2 = rbt_uni_ptr(f->coef[2]); s.m_cap = RBT_UNI(f->cmd_cap); }
+  { const RbtStreamCfg* g = &s.f->cfg; RbtStreamCfg* d = &s.cfg;
+#define PZ_U(fld) d->fld = (decltype(d->fld))RBT_UNI(g->fld)
+    PZ_U(w); PZ_U(h); PZ_U(cw); PZ_U(ch); PZ_U(w4); PZ_U(h4); PZ_U(w_ctb); PZ_U(h_ctb); PZ_U(bit_depth); PZ_U(log2_ctb); PZ_U(log2_min_cb); PZ_U(log2_min_tb);
+    PZ_U(log2_max_tb); PZ_U(th_depth_inter); PZ_U(th_depth_intra); PZ_U(diff_cu_qp_delta_depth); PZ_U(amp); PZ_U(sao); PZ_U(strong_intra); PZ_U(tmvp);
+    PZ_U(sign_hiding); PZ_U(cabac_init_present); PZ_U(cip); PZ_U(transform_skip); PZ_U(cu_qp_delta); PZ_U(tq_bypass_enabled); PZ_U(cb_qp_offset); PZ_U(cr_qp_offset);
+    d->pad0 = d->pad1 = 0; d->pad2 = d->pad3 = 0;
+#undef PZ_U
+  }
+  const RbtSliceU* sl = &s.sl;
   int init_type = sl->slice_type == RBT_SLICE_I ? 0 : (sl->cabac_init_flag ? 2 : 1);
-  rbt_ctx_init(ctx_states, init_type, sl->qp);
-  RBT_SYNC();
-  rbt_cd_start(&s.c, rbsp + sl->data_off, sl->data_size, ctx_states);
+#ifdef RBT_PROFILE
+  unsigned long long t_all_ = __builtin_readcyclecounter(); s.t_res = s.t_ctb = s.t_cu = 0; s.n_res = s.n_cu = 0; s.c.n_bins = s.c.n_byp = 0;
+#endif
+  rbt_ctx_init(&s.c.cs, init_type, sl->qp);
+  rbt_cd_start(&s.c, rbsp + (uint32_t)RBT_UNI(gs->data_off), (uint32_t)RBT_UNI(gs->data_size));
   s.qp_y = sl->qp; s.qp_pred = sl->qp; s.qp_y_prev = sl->qp; s.is_cu_qp_delta_coded = 0; s.cu_qp_delta_val = 0;
-  s.last_pu_merge = 0; s.max_trafo_depth = 0; s.intra_chroma = 1;
-  int n_ctb = s.cfg.w_ctb * s.cfg.h_ctb, end = 0, addr = sl->ctb_addr;
+  s.last_pu_merge = 0; s.max_trafo_depth = 0; s.intra_chroma = 1; s.il_packed = 0x01010101;
+  int n_ctb = s.cfg.w_ctb * s.cfg.h_ctb, end = 0, addr = RBT_UNI(gs->ctb_addr);
   uint32_t count = 0;
   while (!end) {
     if (addr >= n_ctb) { s.error = 1; break; }
     int rx = addr % s.cfg.w_ctb, ry = addr / s.cfg.w_ctb;
-    if (RBT_LANE0) s.f->ctb_slice[addr] = (uint16_t)slice_idx;
-    RBT_SYNC();
+    if (RBT_LANE0) s.m_cs[addr] = (uint16_t)slice_idx;
     s.ctb_addr = addr; s.n_cmds = 0;
+    if (rx == 0) { s.left_ok = 0; s.corner_ok = 0; }
+#ifdef RBT_PROFILE
+    unsigned long long tb_ = __builtin_readcyclecounter();
+#endif
+    pz_begin_ctb(&s, rx, ry);
+#ifdef RBT_PROFILE
+    s.t_ctb += __builtin_readcyclecounter() - tb_;
+#endif
     pz_sao(&s, rx, ry);
     pz_coding_quadtree(&s, rx << s.cfg.log2_ctb, ry << s.cfg.log2_ctb, s.cfg.log2_ctb);
-    if (RBT_LANE0) s.f->cmd_count[addr] = s.n_cmds;
+    if (RBT_LANE0) s.m_cnt[addr] = s.n_cmds;
     if (s.error) break;
+#ifdef RBT_PROFILE
+    unsigned long long te_ = __builtin_readcyclecounter();
+#endif
+    pz_end_ctb(&s, rx, ry);
+#ifdef RBT_PROFILE
+    s.t_ctb += __builtin_readcyclecounter() - te_;
+#endif
     end = rbt_cd_terminate(&s.c);
     addr++; count++;
-    if (rbt_cd_bytes_consumed(&s.c) > sl->data_size + 8) { s.error = 2; break; }
-    RBT_SYNC();
+    if (rbt_cd_overrun(&s.c)) { s.error = 2; break; }
+    RBT_SYNC_LDS();
   }
+#ifdef RBT_PROFILE
+  if (RBT_LANE0) printf("slice %d: total %llu cyc, residual %llu (%u TBs), ctb begin/end %llu, bins ctx %u bypass %u, bits %u\n", slice_idx, __builtin_readcyclecounter() - t_all_, s.t_res, s.n_res, s.t_ctb, s.c.n_bins, s.c.n_byp, s.c.bits_read);
+#endif
   if (RBT_LANE0) { slices[slice_idx].n_ctbs_decoded = count; if (s.error) s.f->error = s.error; }
 }

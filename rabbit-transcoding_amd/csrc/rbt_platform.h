@@ -16,16 +16,21 @@
 #define RBT_CONST static const
 #define RBT_PAR_FOR(i, n) for (int i = 0; i < (int)(n); i++)
 #define RBT_SYNC() do { } while (0)
+#define RBT_SYNC_LDS() do { } while (0)
 #define RBT_LANE0 1
 #define RBT_NTHREADS 1
 #define RBT_LDS_AS
 #define RBT_LDS_CAST(T, p) (p)
+#define RBT_UNI(x) (x)
 #else
 #include <hip/hip_runtime.h>
 #define RBT_DEV static __device__ __forceinline__
 #define RBT_CONST static __device__ const
 #define RBT_PAR_FOR(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += (int)blockDim.x)
 #define RBT_SYNC() __syncthreads()
+// single-wave workgroups only: orders LDS traffic between the lanes of the wave without waiting for outstanding global
+// stores (a __syncthreads() would wait for every store round trip to HBM)
+#define RBT_SYNC_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define RBT_LANE0 (threadIdx.x == 0)
 #define RBT_NTHREADS ((int)blockDim.x)
 // LDS objects are always reached through address_space(3) pointers (ds_* instructions). A generic (flat) pointer into
@@ -34,8 +39,20 @@
 // address and faults with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.
 #define RBT_LDS_AS __attribute__((address_space(3)))
 #define RBT_LDS_CAST(T, p) ((RBT_LDS_AS T*)(uintptr_t)(p))
+// Marks a value as wave-uniform so the compiler keeps it in SGPRs / issues it on the scalar unit. Only for values that
+// ARE uniform by construction (the entropy kernels run every lane of the wave on identical data).
+#define RBT_UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
 #endif
 
+template <class T> RBT_DEV T* rbt_uni_ptr(T* p) {
+#ifdef RBT_HOSTEMU
+  return p;
+#else
+  uintptr_t a = (uintptr_t)p;
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+  return (T*)(((uintptr_t)hi << 32) | lo);
+#endif
+}
 RBT_DEV int rbt_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 RBT_DEV int rbt_min(int a, int b) { return a < b ? a : b; }
 RBT_DEV int rbt_max(int a, int b) { return a > b ? a : b; }

@@ -30,7 +30,8 @@ void timer_end(int id) { g_t[id][1] = now_ms(); }
 double timer_ms(int id) { return g_t[id][1] - g_t[id][0]; }
 
 void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices) {
-  for (int i = 0; i < n_slices; i++) { uint8_t st[RBT_CTX_COUNT + 3]; rbt_parse_slice(frames, slices, slice_list[i], rbsp, st); }
+  static RbtParseLds plds;
+  for (int i = 0; i < n_slices; i++) rbt_parse_slice(frames, slices, slice_list[i], rbsp, &plds);
 }
 void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb) {
   static RbtReconLds lds;

@@ -15,3 +15,14 @@ def module():
         sys.modules["rabbit_transcoding_amd"] = m
         spec.loader.exec_module(m)
     return sys.modules["rabbit_transcoding_amd"]
+
+
+def module_file(name):
+    """Loads rabbit-transcoding_amd/<name>.py as rabbit_transcoding_amd_<name>."""
+    key = "rabbit_transcoding_amd_" + name
+    if key not in sys.modules:
+        spec = importlib.util.spec_from_file_location(key, os.path.join(_ROOT, "rabbit-transcoding_amd", name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[key] = m
+        spec.loader.exec_module(m)
+    return sys.modules[key]

@@ -33,6 +33,18 @@ def atlas_layout(w, h, seed, n_patches=None):
     return occ, patches
 
 
+def _smooth_fill(v, mask):
+    """TMC2 pads unoccupied map pixels smoothly (push-pull); this is a light version: normalised box blurs, coarse to fine."""
+    from scipy.ndimage import uniform_filter
+    m = mask.astype(np.float64)
+    out = np.full(v.shape, float((v * m).sum() / max(1.0, m.sum())))
+    for k in (129, 33, 9, 3):
+        num = uniform_filter(v * m, k, mode="nearest")
+        den = uniform_filter(m, k, mode="nearest")
+        out = np.where(den > 1e-3, num / np.maximum(den, 1e-3), out)
+    return np.where(mask > 0, v, out)
+
+
 def make_maps(w, h, seed, bit_depth=10, jitter=0):
     """-> dict with 'geo' [2, w*h*3/2], 'attr' [2, ...] uint16 (10-bit carried as 8-bit*4), 'occ' [1, (w/2*h/2)*3/2] (8-bit, precision 2)"""
     occ, patches = atlas_layout(w, h, seed)
@@ -43,13 +55,15 @@ def make_maps(w, h, seed, bit_depth=10, jitter=0):
     for i, (x, y, pw, ph) in enumerate(patches):
         py, px = np.mgrid[0:ph, 0:pw]
         base = 40 + (i * 37) % 150
-        depth = base + 30 * np.sin(px / (pw / 3.0) + i) * np.cos(py / (ph / 2.5)) + 0.15 * px
+        depth = base + 10 * np.sin(px / (pw / 2.0) + i) * np.cos(py / (ph / 1.8)) + 0.04 * px
         d0[y:y + ph, x:x + pw] = depth
         for c in range(3):
-            tex = 128 + 60 * np.sin(px / (3.0 + c) + i * 1.3) * np.cos(py / (4.0 + i % 3)) + 25 * np.sin((px + py) / (9.0 + c))
-            col[c, y:y + ph, x:x + pw] = tex + r.normal(0, 3, (ph, pw))
-    d0 = np.clip(d0 + r.integers(0, 2, (h, w)), 0, 255) * occ
-    d1 = np.clip(d0 + r.integers(0, 4, (h, w)) * (r.random((h, w)) < 0.3), 0, 255) * occ
+            tex = 128 + 38 * np.sin(px / (5.0 + c) + i * 1.3) * np.cos(py / (6.0 + i % 3)) + 20 * np.sin((px + py) / (11.0 + c))
+            col[c, y:y + ph, x:x + pw] = tex + r.normal(0, 1.6, (ph, pw))
+    # integer depth surfaces; the far map D1 exceeds the near map D0 by 0..3 on a smooth sub-region (surface thickness)
+    d0 = np.clip(np.round(d0), 0, 255) * occ
+    thick = (np.sin(xx / 23.0 + seed) * np.cos(yy / 31.0) > 0.55) * (1 + (np.sin(xx / 5.0) > 0.3))
+    d1 = np.clip(d0 + thick, 0, 255) * occ
     # unoccupied pixels: smooth padding (the TMC2 encoder dilates patches); a flat mid value is enough here
     pad_geo = 0
     scale = 1 << (bit_depth - 8)
@@ -61,13 +75,18 @@ def make_maps(w, h, seed, bit_depth=10, jitter=0):
         V = np.full((ch, cw), 1 << (bit_depth - 1), np.uint16) if v is None else (v.astype(np.int64) * scale).clip(0, (1 << bit_depth) - 1).astype(np.uint16)
         return np.concatenate([Y.ravel(), U.ravel(), V.ravel()])
 
-    geo = np.stack([pack(np.where(occ, d0, pad_geo)), pack(np.where(occ, d1, pad_geo))])
+    del pad_geo
+    f0 = _smooth_fill(d0, occ)
+    geo = np.stack([pack(np.round(f0)), pack(np.round(np.where(occ, d1, f0)))])
     yv = 0.299 * col[0] + 0.587 * col[1] + 0.114 * col[2]
     uv = (128 + 0.5 * (col[2] - yv) / 0.886)[::2, ::2]
     vv = (128 + 0.5 * (col[0] - yv) / 0.701)[::2, ::2]
     m = np.where(occ, 1.0, 0.0)
-    y0 = np.where(occ, yv, 128)
-    y1 = np.where(occ, yv + r.normal(0, 1.5, (h, w)), 128)
+    yf = _smooth_fill(yv, occ)
+    y0 = yf
+    y1 = np.where(occ, yv + r.normal(0, 0.7, (h, w)), yf)
+    occ_c = occ[::2, ::2]
+    uv = _smooth_fill(uv, occ_c); vv = _smooth_fill(vv, occ_c)
     attr = np.stack([pack(np.clip(y0, 0, 255), np.clip(uv, 0, 255), np.clip(vv, 0, 255)),
                      pack(np.clip(y1, 0, 255), np.clip(uv, 0, 255), np.clip(vv, 0, 255))])
     del m

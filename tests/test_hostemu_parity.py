@@ -1,0 +1,41 @@
+"""Runs the kernel BODIES (rabbit-transcoding_amd/csrc/*.h) as serial host code (tests/hostemu, a test-only build) and
+checks them bit-exactly against the oracle. This catches logic regressions in this GPU-less container; the real parity
+tests of the HIP build are tests/test_gpu_*.py (-m gpu)."""
+import os
+import subprocess
+import numpy as np
+import pytest
+import oracle_lib as O
+import rbt_lib
+import synth
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(__file__), "hostemu")])
+    R = rbt_lib.module()
+    c = R.Context(lib_path=rbt_lib.HOSTEMU_LIB)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("seed", range(1, 31))
+def test_decode_stress_streams(ctx, seed):
+    w = [64, 96, 128, 80][seed % 4]; h = [64, 80, 48, 128][(seed // 4) % 4]
+    bd = 10 if seed % 3 else 8
+    fr = np.zeros((5, w * h * 3 // 2), np.uint16)
+    bs, rec = O.encode(fr, w, h, bd, qp=30, gop=2, stress_seed=seed, log2_ctb=0)
+    dec, dw, dh, dbd, chk, fail = ctx.decode(bs)
+    assert (dw, dh, dbd, chk, fail) == (w, h, bd, 5, 0) and np.array_equal(dec, rec)
+
+
+@pytest.mark.parametrize("log2_ctb,rows", [(5, 1), (6, 0), (4, 2)])
+def test_encoder_and_transcode_bitstreams(ctx, log2_ctb, rows):
+    R = rbt_lib.module()
+    geo, attr, occ = synth.make_gof(128, 128, 2, 21)
+    for fr, qp in ((geo, 24), (attr, 32)):
+        assert ctx.encode(fr, 128, 128, 10, qp, gop=2, log2_ctb=log2_ctb, rows_per_slice=rows) == O.encode(fr, 128, 128, 10, qp, gop=2, log2_ctb=log2_ctb, rows_per_slice=rows)[0]
+    sg, _ = O.encode(geo, 128, 128, 10, 16, gop=2, log2_ctb=6, rows_per_slice=0)
+    so, _ = O.encode(occ, 64, 64, 8, 8, gop=1, lossless=1, i_qp_offset=0, log2_ctb=6, rows_per_slice=0)
+    assert ctx.transcode_substream(sg, R.RBT_VIDEO_GEOMETRY, 24, log2_ctb=log2_ctb, rows_per_slice=rows) == O.transcode_substream(sg, 1, 24, log2_ctb=log2_ctb, rows_per_slice=rows)
+    assert ctx.transcode_substream(so, R.RBT_VIDEO_OCCUPANCY, 8, log2_ctb=log2_ctb, rows_per_slice=rows) == O.transcode_substream(so, 0, 8, log2_ctb=log2_ctb, rows_per_slice=rows)
