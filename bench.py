@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--pc-frames", type=int, default=32)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=1280)
-    ap.add_argument("--cpu-sample", type=int, default=6, help="point-cloud frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="point-cloud frames of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
