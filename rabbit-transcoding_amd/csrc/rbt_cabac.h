@@ -18,15 +18,23 @@ enum {
 };
 
 // ------------------------------------------------------------------------------------------------ context store
+// Register file layout of the 157 context variables (value = pStateIdx << 1 | valMps), one VGPR per syntax class so that
+// a call site addresses its register statically:
+//   reg 0  lanes 0..42   everything outside residual_coding (ctx 0..42)
+//   reg 1  lanes 0..43   sig_coeff_flag                      (CTX_SIG + i)
+//   reg 2  lanes 0..3    coded_sub_block_flag, 4..27 greater1, 28..33 greater2
+//   reg 3  lanes 0..17   last_sig_coeff_x_prefix, 18..35 last_sig_coeff_y_prefix
 struct RbtCtxStore {
 #ifdef RBT_HOSTEMU
   uint8_t st[RBT_CTX_COUNT + 3];
 #else
-  int st0, st1, st2;     // lane-distributed context variables: pStateIdx << 1 | valMps
+  int st0, st1, st2, st3;
   int lps_tab;           // lane s: rangeTabLPS[s][0..3] packed little-endian
   int nxt_tab;           // lane s: transIdxLps[s]
 #endif
 };
+RBT_DEV int rbt_ctx_reg(int ctx) { return ctx < CTX_LAST_X ? 0 : (ctx < CTX_CSBF ? 3 : (ctx < CTX_SIG ? 2 : (ctx < CTX_GT1 ? 1 : 2))); }
+RBT_DEV int rbt_ctx_lane(int ctx) { return ctx < CTX_LAST_X ? ctx : (ctx < CTX_CSBF ? ctx - CTX_LAST_X : (ctx < CTX_SIG ? ctx - CTX_CSBF : (ctx < CTX_GT1 ? ctx - CTX_SIG : ctx - CTX_GT1 + 4))); }
 RBT_DEV int rbt_ctx_initval(int init_type, int qp, int i) {
   int iv = k_ctx_init[init_type][i];
   int m = (iv >> 4) * 5 - 45, n = ((iv & 15) << 3) - 16;
@@ -39,22 +47,23 @@ RBT_DEV void rbt_ctx_init(RbtCtxStore* s, int init_type, int qp) {
 #ifdef RBT_HOSTEMU
   for (int i = 0; i < RBT_CTX_COUNT; i++) s->st[i] = (uint8_t)rbt_ctx_initval(init_type, qp, i);
 #else
-  int lane = (int)threadIdx.x & 63;
-  s->st0 = rbt_ctx_initval(init_type, qp, lane);
-  s->st1 = rbt_ctx_initval(init_type, qp, lane + 64);
-  s->st2 = lane + 128 < RBT_CTX_COUNT ? rbt_ctx_initval(init_type, qp, lane + 128) : 0;
-  s->lps_tab = (int)(k_range_lps[lane][0] | (k_range_lps[lane][1] << 8) | (k_range_lps[lane][2] << 16) | ((uint32_t)k_range_lps[lane][3] << 24));
-  s->nxt_tab = k_next_lps[lane];
+  int l = (int)threadIdx.x & 63;
+  s->st0 = l < CTX_LAST_X ? rbt_ctx_initval(init_type, qp, l) : 0;
+  s->st1 = l < 44 ? rbt_ctx_initval(init_type, qp, CTX_SIG + l) : 0;
+  s->st2 = l < 4 ? rbt_ctx_initval(init_type, qp, CTX_CSBF + l) : (l < 34 ? rbt_ctx_initval(init_type, qp, CTX_GT1 + l - 4) : 0);
+  s->st3 = l < 36 ? rbt_ctx_initval(init_type, qp, CTX_LAST_X + l) : 0;
+  s->lps_tab = (int)(k_range_lps[l][0] | (k_range_lps[l][1] << 8) | (k_range_lps[l][2] << 16) | ((uint32_t)k_range_lps[l][3] << 24));
+  s->nxt_tab = k_next_lps[l];
 #endif
 }
+// generic access by context index (any syntax class)
 RBT_DEV int rbt_ctx_get(const RbtCtxStore* s, int ctx) {
 #ifdef RBT_HOSTEMU
   return s->st[ctx];
 #else
-  int lane = ctx & 63, r = ctx >> 6;
-  if (r == 0) return __builtin_amdgcn_readlane(s->st0, lane);
-  if (r == 1) return __builtin_amdgcn_readlane(s->st1, lane);
-  return __builtin_amdgcn_readlane(s->st2, lane);
+  int r = rbt_ctx_reg(ctx), lane = rbt_ctx_lane(ctx);
+  int v0 = __builtin_amdgcn_readlane(s->st0, lane), v1 = __builtin_amdgcn_readlane(s->st1, lane), v2 = __builtin_amdgcn_readlane(s->st2, lane), v3 = __builtin_amdgcn_readlane(s->st3, lane);
+  return r == 0 ? v0 : (r == 1 ? v1 : (r == 2 ? v2 : v3));
 #endif
 }
 RBT_DEV void rbt_ctx_set(RbtCtxStore* s, int ctx, int v) {
@@ -62,10 +71,9 @@ RBT_DEV void rbt_ctx_set(RbtCtxStore* s, int ctx, int v) {
   s->st[ctx] = (uint8_t)v;
 #else
   // v_writelane has no builtin in this toolchain: a per-lane select (v_cmp + v_cndmask) does the same job
-  int me = (int)threadIdx.x & 63, lane = ctx & 63, r = ctx >> 6;
-  if (r == 0) s->st0 = me == lane ? v : s->st0;
-  else if (r == 1) s->st1 = me == lane ? v : s->st1;
-  else s->st2 = me == lane ? v : s->st2;
+  int me = (int)threadIdx.x & 63, r = rbt_ctx_reg(ctx), lane = rbt_ctx_lane(ctx);
+  s->st0 = (r == 0 && me == lane) ? v : s->st0; s->st1 = (r == 1 && me == lane) ? v : s->st1;
+  s->st2 = (r == 2 && me == lane) ? v : s->st2; s->st3 = (r == 3 && me == lane) ? v : s->st3;
 #endif
 }
 RBT_DEV int rbt_lps(const RbtCtxStore* s, int state, int q) {
@@ -89,60 +97,83 @@ struct RbtCabacDec {
   uint32_t next_raw;                           // word widx, loaded one refill ahead so its latency is hidden (raw, per-lane copy)
   uint64_t buf; int nbuf;                      // bit reservoir (MSB first)
   uint32_t range, offset;
-  uint32_t bits_total, bits_read;
+  uint32_t bits_total;                         // bits of the aligned words that belong to the slice data
 #ifdef RBT_PROFILE
   uint32_t n_bins, n_byp;
 #endif
   RbtCtxStore cs;
 };
 RBT_DEV uint32_t rbt_cd_bits(RbtCabacDec* c, int n) {
-  if (n == 0) return 0;
-  if (c->nbuf < n) {
+  if (c->nbuf < n) {                                   // rare: once per 32 bits
     uint32_t v = (uint32_t)RBT_UNI(__builtin_bswap32(c->next_raw));
     c->widx++;
     c->next_raw = c->widx < c->n_words ? c->w[c->widx] : 0;
     c->buf = (c->buf << 32) | v; c->nbuf += 32;
   }
-  uint32_t r = (uint32_t)(c->buf >> (c->nbuf - n)) & ((1u << n) - 1u);
-  c->nbuf -= n; c->bits_read += (uint32_t)n;
-  return r;
+  c->nbuf -= n;
+  return (uint32_t)(c->buf >> c->nbuf) & ((1u << n) - 1u);   // n == 0 yields 0
 }
 // p .. p+size is the slice data; the allocation is padded so that the aligned words covering it can be read
 RBT_DEV void rbt_cd_start(RbtCabacDec* c, const uint8_t* p, uint32_t size) {
   uintptr_t a = (uintptr_t)p; int mis = (int)(a & 3);
   c->w = (const uint32_t*)(a - (uintptr_t)mis); c->n_words = (size + (uint32_t)mis + 3) >> 2; c->widx = 0;
-  c->buf = 0; c->nbuf = 0; c->bits_total = size * 8; c->bits_read = 0;
+  c->buf = 0; c->nbuf = 0; c->bits_total = (size + (uint32_t)mis) * 8;
   c->next_raw = c->n_words ? c->w[0] : 0;
-  if (mis) { (void)rbt_cd_bits(c, 8 * mis); c->bits_read = 0; }
+  if (mis) (void)rbt_cd_bits(c, 8 * mis);
   c->range = 510; c->offset = rbt_cd_bits(c, 9);
 }
-RBT_DEV int rbt_cd_bin(RbtCabacDec* c, int ctx) {
+// Decodes one bin given the context variable value; returns bin | new context value << 1. Branch-free on purpose: a lone
+// wave pays ~4 cycles per instruction but ~20 per taken branch.
+RBT_DEV int rbt_cd_core(RbtCabacDec* c, int st) {
 #ifdef RBT_PROFILE
   c->n_bins++;
 #endif
-  int st = rbt_ctx_get(&c->cs, ctx);
-  int s = st >> 1, mps = st & 1, bin;
-  uint32_t lps = (uint32_t)rbt_lps(&c->cs, s, (int)((c->range >> 6) & 3));
-  c->range -= lps;
-  if (c->offset >= c->range) {
-    bin = !mps; c->offset -= c->range; c->range = lps;
-    if (s == 0) mps = 1 - mps;
-    s = rbt_next_lps(&c->cs, s);
-  } else { bin = mps; s = s >= 62 ? s : s + 1; }
-  rbt_ctx_set(&c->cs, ctx, (s << 1) | mps);
-  if (c->range < 256) {
-    int sh = __builtin_clz(c->range) - 23;
-    c->range <<= sh; c->offset = (c->offset << sh) | rbt_cd_bits(c, sh);
-  }
-  return bin;
+  // mask arithmetic instead of selects: the compiler turns scalar ?: into SCC / exec-mask gymnastics that cost 3-4
+  // instructions each
+  uint32_t s = (uint32_t)st >> 1, mps = (uint32_t)st & 1u;
+  uint32_t lps = (uint32_t)rbt_lps(&c->cs, (int)s, (int)((c->range >> 6) & 3));
+  uint32_t nl = (uint32_t)rbt_next_lps(&c->cs, (int)s);
+  uint32_t rm = c->range - lps;
+  uint32_t m = 0u - (uint32_t)(c->offset >= rm);       // all ones on the LPS path
+  uint32_t offset = c->offset - (rm & m);
+  uint32_t range = rm ^ ((rm ^ lps) & m);
+  uint32_t bin = mps ^ (m & 1u);
+  uint32_t nm = s + (uint32_t)(s < 62u);
+  uint32_t ns = nm ^ ((nm ^ nl) & m);
+  uint32_t nmps = mps ^ (m & (uint32_t)(s == 0u));
+  int sh = __builtin_clz(range) - 23;                  // 0 when range >= 256
+  c->range = range << sh;
+  c->offset = (offset << sh) | rbt_cd_bits(c, sh);
+  return (int)(bin | (((ns << 1) | nmps) << 1));
 }
+RBT_DEV int rbt_cd_bin(RbtCabacDec* c, int ctx) {
+  int r = rbt_cd_core(c, rbt_ctx_get(&c->cs, ctx));
+  rbt_ctx_set(&c->cs, ctx, r >> 1);
+  return r & 1;
+}
+// class-specific entry points: the register holding the context is known at the call site
+#ifdef RBT_HOSTEMU
+#define RBT_CD_BIN_REG(NAME, REG, BASE) RBT_DEV int NAME(RbtCabacDec* c, int lane) { return rbt_cd_bin(c, (BASE) + lane); }
+#else
+#define RBT_CD_BIN_REG(NAME, REG, BASE) RBT_DEV int NAME(RbtCabacDec* c, int lane) { \
+  int r = rbt_cd_core(c, __builtin_amdgcn_readlane(c->cs.REG, lane)); \
+  c->cs.REG = ((int)threadIdx.x & 63) == lane ? (r >> 1) : c->cs.REG; \
+  return r & 1; }
+#endif
+RBT_CD_BIN_REG(rbt_cd_bin_sig, st1, CTX_SIG)          // lane = sigCtx (0..43)
+RBT_CD_BIN_REG(rbt_cd_bin_res2, st2, (lane < 4 ? CTX_CSBF : CTX_GT1 - 4))   // lane = 0..3 csbf, 4..27 greater1, 28..33 greater2
+RBT_DEV int rbt_cd_bin_csbf(RbtCabacDec* c, int i) { return rbt_cd_bin_res2(c, i); }
+RBT_DEV int rbt_cd_bin_gt1(RbtCabacDec* c, int i) { return rbt_cd_bin_res2(c, 4 + i); }
+RBT_DEV int rbt_cd_bin_gt2(RbtCabacDec* c, int i) { return rbt_cd_bin_res2(c, 28 + i); }
+RBT_CD_BIN_REG(rbt_cd_bin_last, st3, CTX_LAST_X)      // lane = 0..17 x prefix, 18..35 y prefix
 RBT_DEV int rbt_cd_bypass(RbtCabacDec* c) {
 #ifdef RBT_PROFILE
   c->n_byp++;
 #endif
-  c->offset = (c->offset << 1) | rbt_cd_bits(c, 1);
-  if (c->offset >= c->range) { c->offset -= c->range; return 1; }
-  return 0;
+  uint32_t o = (c->offset << 1) | rbt_cd_bits(c, 1);
+  int b = o >= c->range;
+  c->offset = b ? o - c->range : o;
+  return b;
 }
 RBT_DEV uint32_t rbt_cd_bypass_n(RbtCabacDec* c, int n) { uint32_t v = 0; while (n--) v = (v << 1) | (uint32_t)rbt_cd_bypass(c); return v; }
 RBT_DEV int rbt_cd_terminate(RbtCabacDec* c) {
@@ -158,13 +189,13 @@ RBT_DEV void rbt_cd_localise(RbtCabacDec* d, const RbtCabacDec* c) {
   d->w = rbt_uni_ptr(c->w); d->n_words = (uint32_t)RBT_UNI(c->n_words); d->widx = (uint32_t)RBT_UNI(c->widx);
   d->buf = ((uint64_t)(uint32_t)RBT_UNI((uint32_t)(c->buf >> 32)) << 32) | (uint32_t)RBT_UNI((uint32_t)c->buf);
   d->nbuf = RBT_UNI(c->nbuf); d->range = (uint32_t)RBT_UNI(c->range); d->offset = (uint32_t)RBT_UNI(c->offset);
-  d->bits_total = (uint32_t)RBT_UNI(c->bits_total); d->bits_read = (uint32_t)RBT_UNI(c->bits_read);
+  d->bits_total = (uint32_t)RBT_UNI(c->bits_total);
   d->cs = c->cs;
 #ifdef RBT_PROFILE
   d->n_bins = c->n_bins; d->n_byp = c->n_byp;
 #endif
 }
-RBT_DEV int rbt_cd_overrun(const RbtCabacDec* c) { return c->bits_read > c->bits_total + 64; }
+RBT_DEV int rbt_cd_overrun(const RbtCabacDec* c) { return c->widx * 32u - (uint32_t)c->nbuf > c->bits_total + 96u; }
 
 // ------------------------------------------------------------------------------------------------ encoder
 struct RbtCabacEnc {

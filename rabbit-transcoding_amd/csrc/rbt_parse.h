@@ -45,7 +45,7 @@ struct RbtParse {
   int il_packed, intra_chroma, max_trafo_depth, last_pu_merge;   // no arrays / index-selected fields here: they would pin the whole struct in scratch
   int error;
 #ifdef RBT_PROFILE
-  unsigned long long t_res, t_ctb, t_cu; uint32_t n_res, n_cu;
+  unsigned long long t_res, t_ctb, t_cu, t_a, t_b, t_c, t_d; uint32_t n_res, n_cu;
 #endif
 };
 struct RbtMv { int x, y, ref; };
@@ -209,16 +209,20 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
   const int tq_bypass = RBT_UNI(s->cu_tq_bypass), sdh_on = RBT_UNI(s->cfg.sign_hiding), ts_on = RBT_UNI(s->cfg.transform_skip);
   int ts_flag = 0;
   if (ts_on && !tq_bypass && log2 <= 2) ts_flag = rbt_cd_bin(c, CTX_TRANSFORM_SKIP + (c_idx ? 1 : 0));
+  const int chroma = c_idx != 0;
   int ctx_off, ctx_shift;
   if (c_idx == 0) { ctx_off = 3 * (log2 - 2) + ((log2 - 1) >> 2); ctx_shift = (log2 + 1) >> 2; }
   else { ctx_off = 15; ctx_shift = log2 - 2; }
   int maxp = (log2 << 1) - 1, px = 0, py = 0;
-  while (px < maxp && rbt_cd_bin(c, CTX_LAST_X + ctx_off + (px >> ctx_shift))) px++;
-  while (py < maxp && rbt_cd_bin(c, CTX_LAST_Y + ctx_off + (py >> ctx_shift))) py++;
+  while (px < maxp && rbt_cd_bin_last(c, ctx_off + (px >> ctx_shift))) px++;
+  while (py < maxp && rbt_cd_bin_last(c, 18 + ctx_off + (py >> ctx_shift))) py++;
   int lx = px, ly = py;
   if (px > 3) { int nb = (px >> 1) - 1; lx = (1 << nb) * (2 + (px & 1)) + (int)rbt_cd_bypass_n(c, nb); }
   if (py > 3) { int nb = (py >> 1) - 1; ly = (1 << nb) * (2 + (py & 1)) + (int)rbt_cd_bypass_n(c, nb); }
   if (scan_idx == 2) { int t = lx; lx = ly; ly = t; }
+#ifdef RBT_PROFILE
+  unsigned long long ta_ = __builtin_readcyclecounter(); s->t_a += ta_ - t0_;
+#endif
   const RBT_LDS_AS uint8_t* sb_scan = s->L->scan[scan_idx][log2 - 2];
   int n_sb = 1 << (2 * (log2 - 2)), last_sb = 0, last_pos = 0;
   { int sbx = lx >> 2, sby = ly >> 2, ix = lx & 3, iy = ly & 3;
@@ -231,8 +235,11 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
   for (int i = last_sb; i >= 0; i--) {
     int sbv = RBT_UNI(sb_scan[i]); int xs = sbv & 15, ys = sbv >> 4;
     int right = xs + 1 < sbw ? (int)((csbf >> (ys * 8 + xs + 1)) & 1) : 0, below = ys + 1 < sbw ? (int)((csbf >> ((ys + 1) * 8 + xs)) & 1) : 0;
+#ifdef RBT_PROFILE
+    unsigned long long tb0_ = __builtin_readcyclecounter();
+#endif
     int infer_dc = 0, coded;
-    if (i < last_sb && i > 0) { coded = rbt_cd_bin(c, CTX_CSBF + rbt_min(right + below, 1) + (c_idx ? 2 : 0)); infer_dc = 1; }
+    if (i < last_sb && i > 0) { coded = rbt_cd_bin_csbf(c, rbt_min(right + below, 1) + (chroma ? 2 : 0)); infer_dc = 1; }
     else coded = 1;
     if (!coded) continue;
     csbf |= 1ull << (ys * 8 + xs);
@@ -240,25 +247,26 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
     int start = i == last_sb ? last_pos - 1 : 15;
     if (i == last_sb) { sig_mask |= 1u << last_pos; nsig++; }
     int prev_csbf = right | (below << 1);
+    // sigCtx (9.3.4.2.5) = per-CG base + a 2-bit pattern value looked up by the position inside the CG
+    const uint32_t pat = prev_csbf == 0 ? 0x00010516u : (prev_csbf == 1 ? 0x000055AAu : (prev_csbf == 2 ? 0x06060606u : 0xAAAAAAAAu));
+    int cg_base;
+    if (!chroma) cg_base = ((xs | ys) ? 3 : 0) + (log2 == 3 ? (scan_idx == 0 ? 9 : 15) : 21);
+    else cg_base = 27 + (log2 == 3 ? 9 : 12);
+    const int dc_cg = (xs | ys) == 0;
     for (int n = start; n >= 0; n--) {
-      int xp = PZ_POS(n) & 3, yp = PZ_POS(n) >> 2, xc = (xs << 2) + xp, yc = (ys << 2) + yp, sig;
+      int sig = 1;
       if (n > 0 || !infer_dc) {
-        int sc;
-        if (log2 == 2) sc = (int)((PZ_SIGCTX4 >> (4 * ((yc << 2) + xc))) & 15);
-        else if (xc + yc == 0) sc = 0;
-        else {
-          if (prev_csbf == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
-          else if (prev_csbf == 1) sc = yp == 0 ? 2 : (yp == 1 ? 1 : 0);
-          else if (prev_csbf == 2) sc = xp == 0 ? 2 : (xp == 1 ? 1 : 0);
-          else sc = 2;
-          if (c_idx == 0) { if (xs || ys) sc += 3; sc += log2 == 3 ? (scan_idx == 0 ? 9 : 15) : 21; }
-          else sc += log2 == 3 ? 9 : 12;
-        }
-        sig = rbt_cd_bin(c, CTX_SIG + (c_idx == 0 ? sc : 27 + sc));
-        if (sig) infer_dc = 0;
-      } else sig = 1;
-      if (sig) { sig_mask |= 1u << n; nsig++; }
+        int p4 = PZ_POS(n), sc;
+        if (log2 == 2) sc = (int)((PZ_SIGCTX4 >> (4 * p4)) & 15) + (chroma ? 27 : 0);     // p4 = x | y << 2 = raster index of a 4x4 TB
+        else sc = (dc_cg && p4 == 0) ? (chroma ? 27 : 0) : cg_base + (int)((pat >> (2 * p4)) & 3);
+        sig = rbt_cd_bin_sig(c, sc);
+        infer_dc &= sig ^ 1;
+      }
+      sig_mask |= (uint32_t)sig << n; nsig += sig;
     }
+#ifdef RBT_PROFILE
+    unsigned long long tb1_ = __builtin_readcyclecounter(); s->t_b += tb1_ - tb0_;
+#endif
     if (!nsig) continue;
     int ctx_set = (i == 0 || c_idx > 0) ? 0 : 2;
     if (first_sb_done && greater1_ctx == 0) ctx_set++;
@@ -266,12 +274,15 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
     // k-th significant coefficient in decode order = k-th set bit of sig_mask from the top
     uint32_t g1_mask = 0; int first_g1 = -1, n8 = rbt_min(nsig, 8);
     for (int k = 0; k < n8; k++) {
-      int g1 = rbt_cd_bin(c, CTX_GT1 + (ctx_set << 2) + greater1_ctx + (c_idx ? 16 : 0));
+      int g1 = rbt_cd_bin_gt1(c, (ctx_set << 2) + greater1_ctx + (chroma ? 16 : 0));
       if (g1) { greater1_ctx = 0; g1_mask |= 1u << k; if (first_g1 < 0) first_g1 = k; }
       else if (greater1_ctx > 0 && greater1_ctx < 3) greater1_ctx++;
     }
     int g2 = 0;
-    if (first_g1 >= 0) g2 = rbt_cd_bin(c, CTX_GT2 + ctx_set + (c_idx ? 4 : 0));
+    if (first_g1 >= 0) g2 = rbt_cd_bin_gt2(c, ctx_set + (chroma ? 4 : 0));
+#ifdef RBT_PROFILE
+    unsigned long long tc1_ = __builtin_readcyclecounter(); s->t_c += tc1_ - tb1_;
+#endif
     int hi = 31 - __builtin_clz(sig_mask), lo = __builtin_ctz(sig_mask);
     int hidden = sign_hiding && (hi - lo > 3);
     int nsign = nsig - (hidden ? 1 : 0);
@@ -297,6 +308,9 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
       if (RBT_LANE0) plane[(size_t)(y0 + yc) * pst + x0 + xc] = (int16_t)v;
       k++;
     }
+#ifdef RBT_PROFILE
+    s->t_d += __builtin_readcyclecounter() - tc1_;
+#endif
   }
   s->c = cl;
 #ifdef RBT_PROFILE
@@ -363,42 +377,54 @@ RBT_DEV void pz_transform_unit(RbtParse* s, int x0, int y0, int xb, int yb, int 
   cmd.qp[0] = (int8_t)(s->qp_y + 6 * (s->cfg.bit_depth - 8)); cmd.qp[1] = (int8_t)pz_chroma_qp(s, 1); cmd.qp[2] = (int8_t)pz_chroma_qp(s, 2);
   pz_emit(s, cmd);
 }
-RBT_DEV void pz_transform_tree(RbtParse* s, int x0, int y0, int xb, int yb, int log2, int depth, int blk, int pcb, int pcr) {
-  // explicit stack instead of recursion (depth <= 4)
-  struct Node { int16_t x, y, xb, yb; int8_t log2, depth, blk, pcb, pcr, state, cb, cr; };
-  Node st[5]; int sp = 0;
-  st[0].x = (int16_t)x0; st[0].y = (int16_t)y0; st[0].xb = (int16_t)xb; st[0].yb = (int16_t)yb; st[0].log2 = (int8_t)log2; st[0].depth = (int8_t)depth;
-  st[0].blk = (int8_t)blk; st[0].pcb = (int8_t)pcb; st[0].pcr = (int8_t)pcr; st[0].state = -1;
+RBT_DEV void pz_transform_tree(RbtParse* s, int x0, int y0, int xb0, int yb0, int log2, int depth0, int blk0, int pcb, int pcr) {
+  // Depth-first walk without recursion and without a stack in memory (a private array would live in scratch, and every
+  // scratch access is an HBM-latency round trip for this lone wave): the per-level child counter (4 bits) and cbf_cb /
+  // cbf_cr flags (2 bits) are packed into two registers, node coordinates are updated incrementally.
   RbtCabacDec* c = &s->c;
-  while (sp >= 0 && !s->error) {
-    Node* n = &st[sp];
-    if (n->state < 0) {
-      int intra_split = s->cu_pred_mode == RBT_MODE_INTRA && s->cu_part_mode == RBT_PART_NxN;
-      int inter_split = s->cfg.th_depth_inter == 0 && s->cu_pred_mode != RBT_MODE_INTRA && s->cu_part_mode != RBT_PART_2Nx2N && n->depth == 0;
+  (void)xb0; (void)yb0; (void)depth0; (void)blk0;
+  int lvl = 0, x = x0, y = y0, lg = log2;
+  uint32_t states = 15u;                               // nibble lvl: 15 = not parsed yet, 0..3 = next child, 4 = done
+  uint32_t flags = (uint32_t)((pcb ? 1 : 0) | (pcr ? 2 : 0));   // 2 bits per level: flags of the PARENT of the nodes at that level
+  const int intra = s->cu_pred_mode == RBT_MODE_INTRA;
+  const int intra_split = intra && s->cu_part_mode == RBT_PART_NxN;
+  while (!s->error) {
+    int st = (int)((states >> (4 * lvl)) & 15u);
+    if (st == 15) {
+      int inter_split = s->cfg.th_depth_inter == 0 && !intra && s->cu_part_mode != RBT_PART_2Nx2N && lvl == 0;
       int split;
-      if (n->log2 <= s->cfg.log2_max_tb && n->log2 > s->cfg.log2_min_tb && n->depth < s->max_trafo_depth && !(intra_split && n->depth == 0))
-        split = rbt_cd_bin(c, CTX_SPLIT_TRANSFORM + 5 - n->log2);
-      else split = (n->log2 > s->cfg.log2_max_tb || (intra_split && n->depth == 0) || inter_split) ? 1 : 0;
+      if (lg <= s->cfg.log2_max_tb && lg > s->cfg.log2_min_tb && lvl < s->max_trafo_depth && !(intra_split && lvl == 0))
+        split = rbt_cd_bin(c, CTX_SPLIT_TRANSFORM + 5 - lg);
+      else split = (lg > s->cfg.log2_max_tb || (intra_split && lvl == 0) || inter_split) ? 1 : 0;
+      int ppcb = (int)((flags >> (2 * lvl)) & 1u), ppcr = (int)((flags >> (2 * lvl + 1)) & 1u);
       int cbf_cb = 0, cbf_cr = 0;
-      if (n->log2 > 2) {
-        if (n->depth == 0 || n->pcb) cbf_cb = rbt_cd_bin(c, CTX_CBF_CHROMA + n->depth);
-        if (n->depth == 0 || n->pcr) cbf_cr = rbt_cd_bin(c, CTX_CBF_CHROMA + n->depth);
-      } else { cbf_cb = n->pcb; cbf_cr = n->pcr; }
-      n->cb = (int8_t)cbf_cb; n->cr = (int8_t)cbf_cr;
+      if (lg > 2) {
+        if (lvl == 0 || ppcb) cbf_cb = rbt_cd_bin(c, CTX_CBF_CHROMA + lvl);
+        if (lvl == 0 || ppcr) cbf_cr = rbt_cd_bin(c, CTX_CBF_CHROMA + lvl);
+      } else { cbf_cb = ppcb; cbf_cr = ppcr; }
       if (!split) {
         int cbf_luma = 1;
-        if (s->cu_pred_mode == RBT_MODE_INTRA || n->depth != 0 || cbf_cb || cbf_cr) cbf_luma = rbt_cd_bin(c, CTX_CBF_LUMA + (n->depth == 0 ? 1 : 0));
-        pz_transform_unit(s, n->x, n->y, n->xb, n->yb, n->log2, n->blk, cbf_luma, cbf_cb, cbf_cr);
-        sp--; continue;
+        if (intra || lvl != 0 || cbf_cb || cbf_cr) cbf_luma = rbt_cd_bin(c, CTX_CBF_LUMA + (lvl == 0 ? 1 : 0));
+        int k = lvl ? (int)((states >> (4 * (lvl - 1))) & 15u) - 1 : 0, h = 1 << lg;
+        int xb = lvl ? x - (k & 1) * h : x, yb = lvl ? y - (k >> 1) * h : y;
+        pz_transform_unit(s, x, y, xb, yb, lg, k, cbf_luma, cbf_cb, cbf_cr);
+        st = 4;
+      } else {
+        flags = (flags & ~(3u << (2 * (lvl + 1)))) | ((uint32_t)(cbf_cb | (cbf_cr << 1)) << (2 * (lvl + 1)));
+        st = 0;
       }
-      n->state = 0;
     }
-    if (n->state >= 4) { sp--; continue; }
-    int k = n->state++, h = 1 << (n->log2 - 1);
-    Node* ch = &st[sp + 1];
-    ch->x = (int16_t)(n->x + (k & 1) * h); ch->y = (int16_t)(n->y + (k >> 1) * h); ch->xb = n->x; ch->yb = n->y;
-    ch->log2 = (int8_t)(n->log2 - 1); ch->depth = (int8_t)(n->depth + 1); ch->blk = (int8_t)k; ch->pcb = n->cb; ch->pcr = n->cr; ch->state = -1;
-    sp++;
+    if (st < 4) {                                      // descend into child st
+      states = (states & ~(15u << (4 * lvl))) | ((uint32_t)(st + 1) << (4 * lvl));
+      int h = 1 << (lg - 1);
+      x += (st & 1) * h; y += (st >> 1) * h; lg--; lvl++;
+      states = (states & ~(15u << (4 * lvl))) | (15u << (4 * lvl));
+    } else {                                           // node complete: ascend
+      if (lvl == 0) break;
+      lvl--;
+      int k = (int)((states >> (4 * lvl)) & 15u) - 1, h = 1 << lg;
+      x -= (k & 1) * h; y -= (k >> 1) * h; lg++;
+    }
   }
 }
 
@@ -647,31 +673,36 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
 
 // ------------------------------------------------------------------------------------------------ coding quadtree + slice data
 RBT_DEV void pz_coding_quadtree(RbtParse* s, int x0, int y0, int log2) {
-  struct Node { int16_t x, y; int8_t log2, depth, state; };
-  Node st[5]; int sp = 0;
-  st[0].x = (int16_t)x0; st[0].y = (int16_t)y0; st[0].log2 = (int8_t)log2; st[0].depth = 0; st[0].state = -1;
+  // same stack-free walk as pz_transform_tree; children outside the picture are skipped (7.3.8.4)
   const RbtStreamCfg* cfg = &s->cfg;
-  while (sp >= 0 && !s->error) {
-    Node* n = &st[sp];
-    int N = 1 << n->log2, h = N >> 1;
-    if (n->state < 0) {
+  int lvl = 0, x = x0, y = y0, lg = log2;
+  uint32_t states = 15u;
+  while (!s->error) {
+    int st = (int)((states >> (4 * lvl)) & 15u);
+    int N = 1 << lg;
+    if (st == 15) {
       int split;
-      if (n->x + N <= cfg->w && n->y + N <= cfg->h && n->log2 > cfg->log2_min_cb) {
-        int cl = pz_avail(s, n->x - 1, n->y) && (pz_dm(s, n->x - 1, n->y) >> 6) > n->depth;
-        int ca = pz_avail(s, n->x, n->y - 1) && (pz_dm(s, n->x, n->y - 1) >> 6) > n->depth;
+      if (x + N <= cfg->w && y + N <= cfg->h && lg > cfg->log2_min_cb) {
+        int cl = pz_avail(s, x - 1, y) && (pz_dm(s, x - 1, y) >> 6) > lvl;
+        int ca = pz_avail(s, x, y - 1) && (pz_dm(s, x, y - 1) >> 6) > lvl;
         split = rbt_cd_bin(&s->c, CTX_SPLIT_CU + cl + ca);
-      } else split = n->log2 > cfg->log2_min_cb;
-      if (cfg->cu_qp_delta && n->log2 >= cfg->log2_ctb - cfg->diff_cu_qp_delta_depth) pz_start_qg(s, n->x, n->y);
-      if (!split) { pz_coding_unit(s, n->x, n->y, n->log2, n->depth); sp--; continue; }
-      n->state = 0;
+      } else split = lg > cfg->log2_min_cb;
+      if (cfg->cu_qp_delta && lg >= cfg->log2_ctb - cfg->diff_cu_qp_delta_depth) pz_start_qg(s, x, y);
+      if (!split) { pz_coding_unit(s, x, y, lg, lvl); st = 4; } else st = 0;
     }
-    if (n->state >= 4) { sp--; continue; }
-    int k = n->state++;
-    int cx = n->x + (k & 1) * h, cy = n->y + (k >> 1) * h;
-    if (cx >= cfg->w || cy >= cfg->h) continue;
-    Node* ch = &st[sp + 1];
-    ch->x = (int16_t)cx; ch->y = (int16_t)cy; ch->log2 = (int8_t)(n->log2 - 1); ch->depth = (int8_t)(n->depth + 1); ch->state = -1;
-    sp++;
+    // next child that lies inside the picture
+    int h = N >> 1;
+    while (st < 4 && (x + (st & 1) * h >= cfg->w || y + (st >> 1) * h >= cfg->h)) st++;
+    if (st < 4) {
+      states = (states & ~(15u << (4 * lvl))) | ((uint32_t)(st + 1) << (4 * lvl));
+      x += (st & 1) * h; y += (st >> 1) * h; lg--; lvl++;
+      states = (states & ~(15u << (4 * lvl))) | (15u << (4 * lvl));
+    } else {
+      if (lvl == 0) break;
+      lvl--;
+      int k = (int)((states >> (4 * lvl)) & 15u) - 1, hh = 1 << lg;
+      x -= (k & 1) * hh; y -= (k >> 1) * hh; lg++;
+    }
   }
 }
 
@@ -705,7 +736,7 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
   const RbtSliceU* sl = &s.sl;
   int init_type = sl->slice_type == RBT_SLICE_I ? 0 : (sl->cabac_init_flag ? 2 : 1);
 #ifdef RBT_PROFILE
-  unsigned long long t_all_ = __builtin_readcyclecounter(); s.t_res = s.t_ctb = s.t_cu = 0; s.n_res = s.n_cu = 0; s.c.n_bins = s.c.n_byp = 0;
+  unsigned long long t_all_ = __builtin_readcyclecounter(); s.t_res = s.t_ctb = s.t_cu = s.t_a = s.t_b = s.t_c = s.t_d = 0; s.n_res = s.n_cu = 0; s.c.n_bins = s.c.n_byp = 0;
 #endif
   rbt_ctx_init(&s.c.cs, init_type, sl->qp);
   rbt_cd_start(&s.c, rbsp + (uint32_t)RBT_UNI(gs->data_off), (uint32_t)RBT_UNI(gs->data_size));
@@ -743,7 +774,7 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
     RBT_SYNC_LDS();
   }
 #ifdef RBT_PROFILE
-  if (RBT_LANE0) printf("slice %d: total %llu cyc, residual %llu (%u TBs), ctb begin/end %llu, bins ctx %u bypass %u, bits %u\n", slice_idx, __builtin_readcyclecounter() - t_all_, s.t_res, s.n_res, s.t_ctb, s.c.n_bins, s.c.n_byp, s.c.bits_read);
+  if (RBT_LANE0) printf("slice %d: total %llu cyc, residual %llu (%u TBs) [setup+last %llu, csbf+sig %llu, gt1/2 %llu, levels %llu], ctb begin/end %llu, bins ctx %u bypass %u, bits %u\n", slice_idx, __builtin_readcyclecounter() - t_all_, s.t_res, s.n_res, s.t_a, s.t_b, s.t_c, s.t_d, s.t_ctb, s.c.n_bins, s.c.n_byp, s.c.widx * 32u - (uint32_t)s.c.nbuf);
 #endif
   if (RBT_LANE0) { slices[slice_idx].n_ctbs_decoded = count; if (s.error) s.f->error = s.error; }
 }

@@ -41,7 +41,11 @@
 #define RBT_LDS_CAST(T, p) ((RBT_LDS_AS T*)(uintptr_t)(p))
 // Marks a value as wave-uniform so the compiler keeps it in SGPRs / issues it on the scalar unit. Only for values that
 // ARE uniform by construction (the entropy kernels run every lane of the wave on identical data).
+#ifdef RBT_NO_UNI
+#define RBT_UNI(x) (x)
+#else
 #define RBT_UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
+#endif
 #endif
 
 template <class T> RBT_DEV T* rbt_uni_ptr(T* p) {
