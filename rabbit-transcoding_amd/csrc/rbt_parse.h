@@ -45,7 +45,7 @@ struct RbtParse {
   int il_packed, intra_chroma, max_trafo_depth, last_pu_merge;   // no arrays / index-selected fields here: they would pin the whole struct in scratch
   int error;
 #ifdef RBT_PROFILE
-  unsigned long long t_res, t_ctb, t_cu, t_a, t_b, t_c, t_d; uint32_t n_res, n_cu;
+  unsigned long long t_res, t_ctb, t_cu, t_a, t_b, t_c, t_d, t_tu, t_hdr, t_fill; uint32_t n_res, n_cu;
 #endif
 };
 struct RbtMv { int x, y, ref; };
@@ -82,27 +82,41 @@ RBT_DEV int pz_ld_mv(const RbtParse* s, int loc) { int r = loc >> 12, i = loc & 
 RBT_DEV int pz_avail(const RbtParse* s, int xn, int yn) { return pz_loc(s, xn, yn) >= 0; }
 RBT_DEV int pz_mode(const RbtParse* s, int x, int y) { return pz_ld_pm(s, pz_loc(s, x, y)) & RBT_PM_MODE_MASK; }   // caller checked pz_avail
 RBT_DEV int pz_dm(const RbtParse* s, int x, int y) { return pz_ld_dm(s, pz_loc(s, x, y)); }
+// neighbour summary in one lookup: -1 = unavailable, else pm | dm << 8
+RBT_DEV int pz_nb(const RbtParse* s, int x, int y) { int loc = pz_loc(s, x, y); return loc < 0 ? -1 : (pz_ld_pm(s, loc) | (pz_ld_dm(s, loc) << 8)); }
 RBT_DEV int pz_cur(const RbtParse* s, int x, int y) { return ((y - s->ctb_y) >> 2) * 16 + ((x - s->ctb_x) >> 2); }
-RBT_DEV void pz_fill_dm(const RbtParse* s, int x, int y, int w, int h, int v) {
-  int w4 = w >> 2, n = w4 * (h >> 2), base = pz_cur(s, x, y);
-  RBT_PAR_FOR(i, n) s->L->cur_dm[base + (i / w4) * 16 + (i % w4)] = (uint8_t)v;
-}
-RBT_DEV void pz_fill_qp(const RbtParse* s, int x, int y, int w, int h, int v) {
-  int w4 = w >> 2, n = w4 * (h >> 2), base = pz_cur(s, x, y);
-  RBT_PAR_FOR(i, n) s->L->cur_qp[base + (i / w4) * 16 + (i % w4)] = (int8_t)v;
-}
-RBT_DEV void pz_fill_pm(const RbtParse* s, int x, int y, int w, int h, int keep_mask, int v) {
-  int w4 = w >> 2, n = w4 * (h >> 2), base = pz_cur(s, x, y);
-  RBT_PAR_FOR(i, n) { int k = base + (i / w4) * 16 + (i % w4); s->L->cur_pm[k] = (uint8_t)((s->L->cur_pm[k] & keep_mask) | v); }
-}
-RBT_DEV void pz_mark_edges(const RbtParse* s, int x, int y, int w, int h, int vbits, int hbits) {
-  // two passes: the corner unit belongs to both the left column and the top row, and a read-modify-write of the same
-  // byte by two lanes of one instruction would lose one of the updates
-  int nv = h >> 2, nh = w >> 2, base = pz_cur(s, x, y);
+// ---- cooperative fills of square power-of-two blocks (shifts, no division); one pass per event ----
+RBT_DEV int pz_log2u(int n4) { return 31 - __builtin_clz((unsigned)n4); }     // n4 = units per side (1,2,4,8,16)
+// coding unit: every unit gets its mode / depth|mode / QP, and the CU boundary becomes a TU+PU edge. Each unit belongs to
+// exactly one CU, so edges are assigned, not OR-ed.
+RBT_DEV void pz_fill_cu(const RbtParse* s, int x, int y, int N, int pm, int dm, int qp) {
+  int n4 = N >> 2, l4 = pz_log2u(n4), base = pz_cur(s, x, y);
+  RBT_PAR_FOR(i, n4 * n4) {
+    int ux = i & (n4 - 1), uy = i >> l4, k = base + uy * 16 + ux;
+    s->L->cur_pm[k] = (uint8_t)pm; s->L->cur_dm[k] = (uint8_t)dm; s->L->cur_qp[k] = (int8_t)qp;
+    s->L->cur_edges[k] = (uint8_t)((ux == 0 ? (RBT_EV_TU | RBT_EV_PU) : 0) | (uy == 0 ? (RBT_EH_TU | RBT_EH_PU) : 0));
+  }
   RBT_SYNC_LDS();
-  RBT_PAR_FOR(i, nv) s->L->cur_edges[base + i * 16] |= (uint8_t)vbits;
+}
+RBT_DEV void pz_fill_dm(const RbtParse* s, int x, int y, int N, int v) {
+  int n4 = N >> 2, l4 = pz_log2u(n4), base = pz_cur(s, x, y);
+  RBT_PAR_FOR(i, n4 * n4) s->L->cur_dm[base + (i >> l4) * 16 + (i & (n4 - 1))] = (uint8_t)v;
   RBT_SYNC_LDS();
-  RBT_PAR_FOR(i, nh) s->L->cur_edges[base + i] |= (uint8_t)hbits;
+}
+RBT_DEV void pz_fill_qp(const RbtParse* s, int x, int y, int N, int v) {
+  int n4 = N >> 2, l4 = pz_log2u(n4), base = pz_cur(s, x, y);
+  RBT_PAR_FOR(i, n4 * n4) s->L->cur_qp[base + (i >> l4) * 16 + (i & (n4 - 1))] = (int8_t)v;
+  RBT_SYNC_LDS();
+}
+// transform unit: non-zero flag of the luma TB and its TU edges in one pass
+RBT_DEV void pz_fill_tu(const RbtParse* s, int x, int y, int N, int nz) {
+  int n4 = N >> 2, l4 = pz_log2u(n4), base = pz_cur(s, x, y);
+  RBT_PAR_FOR(i, n4 * n4) {
+    int ux = i & (n4 - 1), uy = i >> l4, k = base + uy * 16 + ux;
+    if (nz) s->L->cur_pm[k] |= RBT_PM_NZ;
+    int e = (ux == 0 ? RBT_EV_TU : 0) | (uy == 0 ? RBT_EH_TU : 0);
+    if (e) s->L->cur_edges[k] |= (uint8_t)e;
+  }
   RBT_SYNC_LDS();
 }
 // start of a CTB: nothing of it is decoded yet
@@ -347,6 +361,9 @@ RBT_DEV int pz_scan_idx(int pred_mode, int log2, int c_idx, int intra_mode) {
 // ------------------------------------------------------------------------------------------------ transform tree (7.3.8.8-10)
 RBT_DEV void pz_transform_unit(RbtParse* s, int x0, int y0, int xb, int yb, int log2, int blk, int cbf_luma, int cbf_cb, int cbf_cr) {
   RbtCabacDec* c = &s->c;
+#ifdef RBT_PROFILE
+  unsigned long long ttu_ = __builtin_readcyclecounter();
+#endif
   int N = 1 << log2;
   if ((cbf_luma || cbf_cb || cbf_cr) && s->cfg.cu_qp_delta && !s->is_cu_qp_delta_coded) {
     int v = 0; while (v < 5 && rbt_cd_bin(c, CTX_CU_QP_DELTA + (v ? 1 : 0))) v++;
@@ -354,13 +371,12 @@ RBT_DEV void pz_transform_unit(RbtParse* s, int x0, int y0, int xb, int yb, int 
     if (v && rbt_cd_bypass(c)) v = -v;
     s->is_cu_qp_delta_coded = 1; s->cu_qp_delta_val = v;
     s->qp_y = pz_wrap_qp(s, s->qp_pred + v);
-    pz_fill_qp(s, s->cu_x, s->cu_y, 1 << s->cu_log2, 1 << s->cu_log2, s->qp_y);
+    pz_fill_qp(s, s->cu_x, s->cu_y, 1 << s->cu_log2, s->qp_y);
   }
   int intra = s->cu_pred_mode == RBT_MODE_INTRA;
   int part = 0;
   if (s->cu_part_mode == RBT_PART_NxN && intra) part = ((y0 - s->cu_y) >= (1 << (s->cu_log2 - 1)) ? 2 : 0) + ((x0 - s->cu_x) >= (1 << (s->cu_log2 - 1)) ? 1 : 0);
-  if (cbf_luma) pz_fill_pm(s, x0, y0, N, N, 0xFF, RBT_PM_NZ);
-  pz_mark_edges(s, x0, y0, N, N, RBT_EV_TU, RBT_EH_TU);
+  pz_fill_tu(s, x0, y0, N, cbf_luma);
   int chroma_here = log2 > 2 || blk == 3;
   RbtCmd cmd; cmd.type = RBT_CMD_TU; cmd.x4 = (uint8_t)((x0 & ((1 << s->cfg.log2_ctb) - 1)) >> 2); cmd.y4 = (uint8_t)((y0 & ((1 << s->cfg.log2_ctb) - 1)) >> 2);
   cmd.log2 = (uint8_t)log2; cmd.b = (uint8_t)pz_il(s, part); cmd.c = (uint8_t)s->intra_chroma; cmd.d = (uint8_t)s->cu_tq_bypass; cmd.mvx = cmd.mvy = 0; cmd.pad = 0;
@@ -376,6 +392,9 @@ RBT_DEV void pz_transform_unit(RbtParse* s, int x0, int y0, int xb, int yb, int 
   cmd.a = (uint8_t)flags;
   cmd.qp[0] = (int8_t)(s->qp_y + 6 * (s->cfg.bit_depth - 8)); cmd.qp[1] = (int8_t)pz_chroma_qp(s, 1); cmd.qp[2] = (int8_t)pz_chroma_qp(s, 2);
   pz_emit(s, cmd);
+#ifdef RBT_PROFILE
+  s->t_tu += __builtin_readcyclecounter() - ttu_;
+#endif
 }
 RBT_DEV void pz_transform_tree(RbtParse* s, int x0, int y0, int xb0, int yb0, int log2, int depth0, int blk0, int pcb, int pcr) {
   // Depth-first walk without recursion and without a stack in memory (a private array would live in scratch, and every
@@ -429,7 +448,7 @@ RBT_DEV void pz_transform_tree(RbtParse* s, int x0, int y0, int xb0, int yb0, in
 }
 
 // ------------------------------------------------------------------------------------------------ motion (8.5.3.2)
-RBT_DEV int pz_pu_avail(const RbtParse* s, int xn, int yn) { return pz_avail(s, xn, yn) && pz_mode(s, xn, yn) != RBT_MODE_INTRA; }
+RBT_DEV int pz_pu_avail(const RbtParse* s, int xn, int yn) { int loc = pz_loc(s, xn, yn); return loc >= 0 && (pz_ld_pm(s, loc) & RBT_PM_MODE_MASK) != RBT_MODE_INTRA; }
 RBT_DEV RbtMv pz_mv_at(const RbtParse* s, int x, int y) { int loc = pz_loc(s, x, y), v = pz_ld_mv(s, loc); RbtMv m; m.x = (int16_t)(v & 0xFFFF); m.y = (int16_t)(v >> 16); m.ref = pz_ld_ref(s, loc); return m; }
 RBT_DEV int pz_mv_same(RbtMv a, RbtMv b) { return a.x == b.x && a.y == b.y && a.ref == b.ref; }
 RBT_DEV int pz_scale_mv(int mv, int tb, int td) {
@@ -545,11 +564,13 @@ RBT_DEV void pz_prediction_unit(RbtParse* s, int x0, int y0, int w, int h, int p
   int w4 = w >> 2, n = w4 * (h >> 2), base = pz_cur(s, x0, y0);
   int mode = skip ? RBT_MODE_SKIP : RBT_MODE_INTER, packed = (int)(((uint32_t)(uint16_t)mv.y << 16) | (uint16_t)mv.x);
   RBT_PAR_FOR(i, n) {
-    int k = base + (i / w4) * 16 + (i % w4);
+    int ux = i % w4, uy = i / w4, k = base + uy * 16 + ux;   // PU widths may be 3 or 12 units (AMP): general division, once per PU
     s->L->cur_mv[k] = packed; s->L->cur_ref[k] = (int8_t)mv.ref;
     s->L->cur_pm[k] = (uint8_t)((s->L->cur_pm[k] & ~RBT_PM_MODE_MASK) | mode);
+    int e = (ux == 0 ? RBT_EV_PU : 0) | (uy == 0 ? RBT_EH_PU : 0);
+    if (e) s->L->cur_edges[k] |= (uint8_t)e;
   }
-  pz_mark_edges(s, x0, y0, w, h, RBT_EV_PU, RBT_EH_PU);
+  RBT_SYNC_LDS();
   RbtCmd cmd; cmd.type = RBT_CMD_PU; cmd.x4 = (uint8_t)((x0 & ((1 << s->cfg.log2_ctb) - 1)) >> 2); cmd.y4 = (uint8_t)((y0 & ((1 << s->cfg.log2_ctb) - 1)) >> 2);
   cmd.log2 = 0; cmd.a = (uint8_t)(w >> 2); cmd.b = (uint8_t)(h >> 2); cmd.c = (uint8_t)mv.ref; cmd.d = 0; cmd.mvx = (int16_t)mv.x; cmd.mvy = (int16_t)mv.y;
   cmd.qp[0] = cmd.qp[1] = cmd.qp[2] = 0; cmd.pad = 0;
@@ -559,8 +580,9 @@ RBT_DEV void pz_prediction_unit(RbtParse* s, int x0, int y0, int w, int h, int p
 // ------------------------------------------------------------------------------------------------ coding unit (7.3.8.5)
 RBT_DEV void pz_intra_mpm(const RbtParse* s, int xp, int yp, int cand[3]) {
   int ca = 1, cb = 1;
-  if (pz_avail(s, xp - 1, yp) && pz_mode(s, xp - 1, yp) == RBT_MODE_INTRA) ca = pz_dm(s, xp - 1, yp) & 63;
-  if (pz_avail(s, xp, yp - 1) && pz_mode(s, xp, yp - 1) == RBT_MODE_INTRA && ((yp - 1) >> s->cfg.log2_ctb) == (yp >> s->cfg.log2_ctb)) cb = pz_dm(s, xp, yp - 1) & 63;
+  int nl = pz_nb(s, xp - 1, yp);
+  if (nl >= 0 && (nl & RBT_PM_MODE_MASK) == RBT_MODE_INTRA) ca = (nl >> 8) & 63;
+  if (((yp - 1) >> s->cfg.log2_ctb) == (yp >> s->cfg.log2_ctb)) { int na = pz_nb(s, xp, yp - 1); if (na >= 0 && (na & RBT_PM_MODE_MASK) == RBT_MODE_INTRA) cb = (na >> 8) & 63; }
   if (ca == cb) {
     if (ca < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
     else { cand[0] = ca; cand[1] = 2 + ((ca + 29) % 32); cand[2] = 2 + ((ca - 2 + 1) % 32); }
@@ -568,22 +590,22 @@ RBT_DEV void pz_intra_mpm(const RbtParse* s, int xp, int yp, int cand[3]) {
 }
 RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
   RbtCabacDec* c = &s->c; const RbtStreamCfg* cfg = &s->cfg;
+#ifdef RBT_PROFILE
+  unsigned long long tcu_ = __builtin_readcyclecounter(); s->n_cu++;
+#endif
   int N = 1 << log2;
   s->cu_x = x0; s->cu_y = y0; s->cu_log2 = log2; s->cu_tq_bypass = 0; s->cu_part_mode = RBT_PART_2Nx2N; s->cu_pred_mode = RBT_MODE_INTRA;
   if (cfg->cu_qp_delta) s->qp_y = pz_wrap_qp(s, s->qp_pred + s->cu_qp_delta_val);
   if (cfg->tq_bypass_enabled) s->cu_tq_bypass = rbt_cd_bin(c, CTX_CU_TQ_BYPASS);
   int skip = 0;
   if (s->sl.slice_type != RBT_SLICE_I) {
-    int cl = pz_avail(s, x0 - 1, y0) && pz_mode(s, x0 - 1, y0) == RBT_MODE_SKIP;
-    int ca = pz_avail(s, x0, y0 - 1) && pz_mode(s, x0, y0 - 1) == RBT_MODE_SKIP;
+    int nl = pz_nb(s, x0 - 1, y0), na = pz_nb(s, x0, y0 - 1);
+    int cl = nl >= 0 && (nl & RBT_PM_MODE_MASK) == RBT_MODE_SKIP, ca = na >= 0 && (na & RBT_PM_MODE_MASK) == RBT_MODE_SKIP;
     skip = rbt_cd_bin(c, CTX_CU_SKIP + cl + ca);
   }
-  pz_fill_qp(s, x0, y0, N, N, s->qp_y);
-  pz_mark_edges(s, x0, y0, N, N, RBT_EV_TU | RBT_EV_PU, RBT_EH_TU | RBT_EH_PU);
   if (skip) {
     s->cu_pred_mode = RBT_MODE_SKIP;
-    pz_fill_dm(s, x0, y0, N, N, (depth << 6) | 1);
-    pz_fill_pm(s, x0, y0, N, N, 0, RBT_MODE_NONE | (s->cu_tq_bypass ? RBT_PM_TQ_BYPASS : 0));
+    pz_fill_cu(s, x0, y0, N, RBT_MODE_NONE | (s->cu_tq_bypass ? RBT_PM_TQ_BYPASS : 0), (depth << 6) | 1, s->qp_y);
     RBT_SYNC_LDS();
     pz_prediction_unit(s, x0, y0, N, N, 0, 1);
     RBT_SYNC_LDS();
@@ -607,8 +629,7 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
     }
   }
   if (s->cu_pred_mode == RBT_MODE_INTRA) {
-    pz_fill_pm(s, x0, y0, N, N, 0, RBT_MODE_INTRA | (s->cu_tq_bypass ? RBT_PM_TQ_BYPASS : 0));
-    pz_fill_dm(s, x0, y0, N, N, (depth << 6) | 1);
+    pz_fill_cu(s, x0, y0, N, RBT_MODE_INTRA | (s->cu_tq_bypass ? RBT_PM_TQ_BYPASS : 0), (depth << 6) | 1, s->qp_y);
     RBT_SYNC_LDS();
     int np = s->cu_part_mode == RBT_PART_NxN ? 4 : 1, pb = N >> (np == 4);
     int prev[4], mpm_idx[4], rem[4];
@@ -631,7 +652,7 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
         for (int k = 0; k < 3; k++) if (mode >= cand[k]) mode++;
       }
       pz_set_il(s, i, mode);
-      pz_fill_dm(s, xp, yp, pb, pb, (depth << 6) | mode);
+      pz_fill_dm(s, xp, yp, pb, (depth << 6) | mode);
       RBT_SYNC_LDS();
     }
     int icp = 4;
@@ -640,8 +661,7 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
     if (icp == 4) s->intra_chroma = pz_il(s, 0);
     else s->intra_chroma = cmode == pz_il(s, 0) ? 34 : cmode;
   } else {
-    pz_fill_dm(s, x0, y0, N, N, (depth << 6) | 1);
-    pz_fill_pm(s, x0, y0, N, N, 0, RBT_MODE_NONE | (s->cu_tq_bypass ? RBT_PM_TQ_BYPASS : 0));
+    pz_fill_cu(s, x0, y0, N, RBT_MODE_NONE | (s->cu_tq_bypass ? RBT_PM_TQ_BYPASS : 0), (depth << 6) | 1, s->qp_y);
     RBT_SYNC_LDS();
     int h2 = N >> 1, q = N >> 2, pmode = s->cu_part_mode;
     int np = pmode == RBT_PART_2Nx2N ? 1 : (pmode == RBT_PART_NxN ? 4 : 2);
@@ -662,6 +682,9 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
     }
     if (s->error) return;
   }
+#ifdef RBT_PROFILE
+  s->t_hdr += __builtin_readcyclecounter() - tcu_;
+#endif
   int rqt_root_cbf = 1;
   if (s->cu_pred_mode != RBT_MODE_INTRA && !(s->cu_part_mode == RBT_PART_2Nx2N && s->last_pu_merge)) rqt_root_cbf = rbt_cd_bin(c, CTX_RQT_ROOT_CBF);
   if (rqt_root_cbf) {
@@ -683,8 +706,8 @@ RBT_DEV void pz_coding_quadtree(RbtParse* s, int x0, int y0, int log2) {
     if (st == 15) {
       int split;
       if (x + N <= cfg->w && y + N <= cfg->h && lg > cfg->log2_min_cb) {
-        int cl = pz_avail(s, x - 1, y) && (pz_dm(s, x - 1, y) >> 6) > lvl;
-        int ca = pz_avail(s, x, y - 1) && (pz_dm(s, x, y - 1) >> 6) > lvl;
+        int nl = pz_nb(s, x - 1, y), na = pz_nb(s, x, y - 1);
+        int cl = nl >= 0 && (nl >> 14) > lvl, ca = na >= 0 && (na >> 14) > lvl;
         split = rbt_cd_bin(&s->c, CTX_SPLIT_CU + cl + ca);
       } else split = lg > cfg->log2_min_cb;
       if (cfg->cu_qp_delta && lg >= cfg->log2_ctb - cfg->diff_cu_qp_delta_depth) pz_start_qg(s, x, y);
@@ -736,7 +759,7 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
   const RbtSliceU* sl = &s.sl;
   int init_type = sl->slice_type == RBT_SLICE_I ? 0 : (sl->cabac_init_flag ? 2 : 1);
 #ifdef RBT_PROFILE
-  unsigned long long t_all_ = __builtin_readcyclecounter(); s.t_res = s.t_ctb = s.t_cu = s.t_a = s.t_b = s.t_c = s.t_d = 0; s.n_res = s.n_cu = 0; s.c.n_bins = s.c.n_byp = 0;
+  unsigned long long t_all_ = __builtin_readcyclecounter(); s.t_res = s.t_ctb = s.t_cu = s.t_a = s.t_b = s.t_c = s.t_d = s.t_tu = s.t_hdr = s.t_fill = 0; s.n_res = s.n_cu = 0; s.c.n_bins = s.c.n_byp = 0;
 #endif
   rbt_ctx_init(&s.c.cs, init_type, sl->qp);
   rbt_cd_start(&s.c, rbsp + (uint32_t)RBT_UNI(gs->data_off), (uint32_t)RBT_UNI(gs->data_size));
@@ -774,7 +797,7 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
     RBT_SYNC_LDS();
   }
 #ifdef RBT_PROFILE
-  if (RBT_LANE0) printf("slice %d: total %llu cyc, residual %llu (%u TBs) [setup+last %llu, csbf+sig %llu, gt1/2 %llu, levels %llu], ctb begin/end %llu, bins ctx %u bypass %u, bits %u\n", slice_idx, __builtin_readcyclecounter() - t_all_, s.t_res, s.n_res, s.t_a, s.t_b, s.t_c, s.t_d, s.t_ctb, s.c.n_bins, s.c.n_byp, s.c.widx * 32u - (uint32_t)s.c.nbuf);
+  if (RBT_LANE0) printf("slice %d: total %llu cyc, residual %llu (%u TBs) [setup+last %llu, csbf+sig %llu, gt1/2 %llu, levels %llu], TU total (incl. residual) %llu, CU header %llu (%u CUs), ctb begin/end %llu, bins ctx %u bypass %u, bits %u\n", slice_idx, __builtin_readcyclecounter() - t_all_, s.t_res, s.n_res, s.t_a, s.t_b, s.t_c, s.t_d, s.t_tu, s.t_hdr, s.n_cu, s.t_ctb, s.c.n_bins, s.c.n_byp, s.c.widx * 32u - (uint32_t)s.c.nbuf);
 #endif
   if (RBT_LANE0) { slices[slice_idx].n_ctbs_decoded = count; if (s.error) s.f->error = s.error; }
 }
