@@ -36,10 +36,10 @@ RBT_DEV int en_wave_sum(int v, RBT_LDS_AS RbtEncLds* l) {
   (void)l; return v;
 #else
   l->red[threadIdx.x] = v;
-  RBT_SYNC();
+  RBT_SYNC_LDS();
   int s = 0;
   for (int i = 0; i < 64; i++) s += l->red[i];
-  RBT_SYNC();
+  RBT_SYNC_LDS();
   return s;
 #endif
 }
@@ -81,7 +81,7 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
         if (RBT_LANE0) { l->cost[si][b] = best; l->mode[si][b] = (uint8_t)bmode; }
       }
     }
-    RBT_SYNC();
+    RBT_SYNC_LDS();
     int lam = k_lambda16[rbt_clip3(0, 75, sl->qp + 6 * (g->bit_depth - 8))], pen = (lam * RBT_SPLIT_BITS) >> 4;
     for (int si = 1; si < 3; si++) {
       int S = 8 << si; if (S > qs) break;
@@ -94,7 +94,7 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
         l->split[si][b] = (uint8_t)split;
         if (split) l->cost[si][b] = child;
       }
-      RBT_SYNC();
+      RBT_SYNC_LDS();
     }
     // leaf CU size / mode per 8x8 unit of the quadrant
     int n8 = qs / 8;
@@ -112,7 +112,7 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
         f->cu_log2[k] = (uint8_t)lg; f->cu_mode[k] = (uint8_t)mode;
       }
     }
-    RBT_SYNC();
+    RBT_SYNC_LDS();
   }
 }
 
@@ -125,13 +125,13 @@ RBT_DEV void en_fwd_transform(int log2, int is_dst, int bd, RBT_LDS_AS RbtReconL
     for (int x = 0; x < N; x++) s += rc_tcoef(N, is_dst, k, x) * r->res[y * N + x];
     r->tmp[i] = s1 > 0 ? (s + (1 << (s1 - 1))) >> s1 : s;
   }
-  RBT_SYNC();
+  RBT_SYNC_LDS();
   RBT_PAR_FOR(i, N * N) {
     int kh = i & (N - 1), kv = i >> log2, s = 0;
     for (int y = 0; y < N; y++) s += rc_tcoef(N, is_dst, kv, y) * r->tmp[y * N + kh];
     r->res[i] = (int16_t)rbt_clip3(-32768, 32767, (s + (1 << (s2 - 1))) >> s2);
   }
-  RBT_SYNC();
+  RBT_SYNC_LDS();
 }
 // dead-zone quantiser of l->rc.res into l->lvl; returns the number of non-zero levels
 RBT_DEV int en_quant(int log2, int qp, int bd, int is_intra, RBT_LDS_AS RbtEncLds* l) {
@@ -153,7 +153,7 @@ RBT_DEV int en_code_tb(RbtFrame* f, int c_idx, int x0, int y0, int log2, int qp,
   int N = 1 << log2, pw = c_idx ? g->cw : g->w, bd = g->bit_depth, maxv = (1 << bd) - 1;
   const uint16_t* sp = f->src[c_idx]; uint16_t* rp = f->pix[c_idx]; int16_t* cp = f->coef[c_idx];
   RBT_PAR_FOR(i, N * N) { int x = i & (N - 1), y = i >> log2; l->rc.res[i] = (int16_t)((int)sp[(size_t)(y0 + y) * pw + x0 + x] - (int)l->rc.pred[i]); }
-  RBT_SYNC();
+  RBT_SYNC_LDS();
   int nz;
   if (f->lossless) {
     int part = 0;
@@ -163,17 +163,17 @@ RBT_DEV int en_code_tb(RbtFrame* f, int c_idx, int x0, int y0, int log2, int qp,
     en_fwd_transform(log2, c_idx == 0 && log2 == 2 && is_intra, bd, &l->rc);
     nz = en_quant(log2, qp, bd, is_intra, l);
   }
-  RBT_SYNC();
+  RBT_SYNC_LDS();
   RBT_PAR_FOR(i, N * N) { int x = i & (N - 1), y = i >> log2; cp[(size_t)(y0 + y) * pw + x0 + x] = l->lvl[i]; }
   if (nz && !f->lossless) {
     int bd_shift = bd + log2 - 5, scale = (16 * k_dequant_scale[qp % 6]) << (qp / 6);
     long long add = 1ll << (bd_shift - 1);
     RBT_PAR_FOR(i, N * N) { long long v = ((long long)l->lvl[i] * scale + add) >> bd_shift; l->rc.res[i] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
-    RBT_SYNC();
+    RBT_SYNC_LDS();
     rc_inv_transform(log2, c_idx == 0 && log2 == 2 && is_intra, 0, bd, &l->rc);
   } else if (nz) {
     RBT_PAR_FOR(i, N * N) l->rc.res[i] = l->lvl[i];
-    RBT_SYNC();
+    RBT_SYNC_LDS();
   }
   RBT_PAR_FOR(i, N * N) {
     int x = i & (N - 1), y = i >> log2;
@@ -242,7 +242,7 @@ RBT_DEV void en_inter_ctb(RbtFrame* frames, RbtFrame* f, const RbtSlice* slices,
       int sh = c ? 1 : 0, S = 16 >> sh, pw = c ? g->cw : g->w;
       const uint16_t* rp = ref->out[c];
       RBT_PAR_FOR(i, S * S) { int x = i & (S - 1), y = i / S; l->rc.pred[i] = rp[(size_t)((y0 >> sh) + y) * pw + (x0 >> sh) + x]; }
-      RBT_SYNC();
+      RBT_SYNC_LDS();
       if (en_code_tb(f, c, x0 >> sh, y0 >> sh, 4 - sh, qp[c], 0, l)) cbf |= 1 << c;
     }
     int flags = cbf | (cbf ? 0 : RBT_CU_SKIP);
@@ -291,7 +291,7 @@ RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, int x0, int y0, int log2, i
   int N = 1 << log2, pw = c_idx ? f->cfg.cw : f->cfg.w;
   const int16_t* cp = f->coef[c_idx];
   RBT_PAR_FOR(i, N * N) { int x = i & (N - 1), y = i >> log2; l->lvl[i] = cp[(size_t)(y0 + y) * pw + x0 + x]; }
-  RBT_SYNC();
+  RBT_SYNC_LDS();
   const uint8_t* sb_scan = k_scan[scan_idx][log2 - 2];
   const uint8_t* pos_scan = k_scan[scan_idx][2];
   int n_sb = 1 << (2 * (log2 - 2));
@@ -300,7 +300,7 @@ RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, int x0, int y0, int log2, i
     for (int n = 0; n < 16; n++) if (l->lvl[((ys << 2) + (pos_scan[n] >> 4)) * N + (xs << 2) + (pos_scan[n] & 15)]) m |= 1 << n;
     l->cg_mask[i] = (uint16_t)m;
   }
-  RBT_SYNC();
+  RBT_SYNC_LDS();
   int last_sb = 0;
   for (int i = n_sb - 1; i >= 0; i--) if (l->cg_mask[i]) { last_sb = i; break; }
   int last_pos = 31 - __builtin_clz((unsigned)l->cg_mask[last_sb]);
@@ -384,7 +384,7 @@ RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, int x0, int y0, int log2, i
       k++;
     }
   }
-  RBT_SYNC();
+  RBT_SYNC_LDS();
 }
 RBT_DEV int en_cu_coded(const RbtEnt* s, int xc, int yc, int xn, int yn) {
   // neighbour CU available for context derivation: inside the picture, same slice, earlier in decoding order

@@ -51,7 +51,7 @@ RBT_DEV void rc_intra_pred(const RbtFrame* f, const uint16_t* src, int c_idx, in
     l->av[i] = (uint8_t)a;
     l->nb[i] = a ? src[(size_t)yn * pw + xn] : 0;
   }
-  RBT_SYNC();
+  RBT_SYNC_LDS();
   // substitution (8.4.4.2.2): uniform serial scan
   {
     int first = -1;
@@ -65,11 +65,11 @@ RBT_DEV void rc_intra_pred(const RbtFrame* f, const uint16_t* src, int c_idx, in
           l->nbf[i] = j >= 0 ? l->nb[j] : l->nb[first];
         } else l->nbf[i] = l->nb[i];
       }
-      RBT_SYNC();
+      RBT_SYNC_LDS();
       RBT_PAR_FOR(i, tot) l->nb[i] = l->nbf[i];
     }
   }
-  RBT_SYNC();
+  RBT_SYNC_LDS();
   int filt = 0;
   if (c_idx == 0 && mode != 1 && N != 4) {
     int md = rbt_min(rbt_abs(mode - 26), rbt_abs(mode - 10));
@@ -90,9 +90,9 @@ RBT_DEV void rc_intra_pred(const RbtFrame* f, const uint16_t* src, int c_idx, in
       } else v = (l->nb[i - 1] + 2 * l->nb[i] + l->nb[i + 1] + 2) >> 2;
       l->nbf[i] = v;
     }
-    RBT_SYNC();
+    RBT_SYNC_LDS();
     RBT_PAR_FOR(i, tot) l->nb[i] = l->nbf[i];
-    RBT_SYNC();
+    RBT_SYNC_LDS();
   }
 #define RC_LEFT(y) l->nb[2 * N - 1 - (y)]
 #define RC_TOP(x) l->nb[2 * N + 1 + (x)]
@@ -127,7 +127,7 @@ RBT_DEV void rc_intra_pred(const RbtFrame* f, const uint16_t* src, int c_idx, in
       else if (ang >= 0) v = ver ? RC_TOP(x - 1) : RC_LEFT(x - 1);
       l->ref[x + 32] = v;
     }
-    RBT_SYNC();
+    RBT_SYNC_LDS();
     int edge = c_idx == 0 && N < 32 && (mode == 26 || mode == 10);
     RBT_PAR_FOR(i, N * N) {
       int x = i & (N - 1), y = i >> log2;
@@ -143,7 +143,7 @@ RBT_DEV void rc_intra_pred(const RbtFrame* f, const uint16_t* src, int c_idx, in
   }
 #undef RC_LEFT
 #undef RC_TOP
-  RBT_SYNC();
+  RBT_SYNC_LDS();
 }
 
 // ---- scaling (8.6.3, flat lists) of the TB's levels from the coefficient plane into lds->res ----
@@ -156,14 +156,14 @@ RBT_DEV void rc_dequant(const int16_t* plane, int pst, int x0, int y0, int log2,
     long long v = ((long long)plane[(size_t)(y0 + y) * pst + x0 + x] * scale + add) >> bd_shift;
     l->res[i] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
   }
-  RBT_SYNC();
+  RBT_SYNC_LDS();
 }
 // ---- inverse transform of lds->res in place (8.6.4.2) ----
 RBT_DEV void rc_inv_transform(int log2, int is_dst, int ts, int bd, RBT_LDS_AS RbtReconLds* l) {
   int N = 1 << log2, sh = 20 - bd;
   if (ts) {
     RBT_PAR_FOR(i, N * N) l->res[i] = (int16_t)((((int)l->res[i] << 7) + (1 << (sh - 1))) >> sh);
-    RBT_SYNC();
+    RBT_SYNC_LDS();
     return;
   }
   RBT_PAR_FOR(i, N * N) {
@@ -171,13 +171,13 @@ RBT_DEV void rc_inv_transform(int log2, int is_dst, int ts, int bd, RBT_LDS_AS R
     for (int k = 0; k < N; k++) s += rc_tcoef(N, is_dst, k, y) * l->res[k * N + x];
     l->tmp[i] = rbt_clip3(-32768, 32767, (s + 64) >> 7);
   }
-  RBT_SYNC();
+  RBT_SYNC_LDS();
   RBT_PAR_FOR(i, N * N) {
     int x = i & (N - 1), y = i >> log2, s = 0;
     for (int k = 0; k < N; k++) s += rc_tcoef(N, is_dst, k, x) * l->tmp[y * N + k];
     l->res[i] = (int16_t)((s + (1 << (sh - 1))) >> sh);
   }
-  RBT_SYNC();
+  RBT_SYNC_LDS();
 }
 
 // ---- one TB of the decoder: prediction (intra) + residual, written to f->pix ----
@@ -189,7 +189,7 @@ RBT_DEV void rc_decode_tb(RbtFrame* f, int c_idx, int x0, int y0, int log2, int 
   if (cbf) {
     if (tq_bypass) {
       RBT_PAR_FOR(i, N * N) { int x = i & (N - 1), y = i >> log2; l->res[i] = f->coef[c_idx][(size_t)(y0 + y) * pw + x0 + x]; }
-      RBT_SYNC();
+      RBT_SYNC_LDS();
     } else {
       rc_dequant(f->coef[c_idx], pw, x0, y0, log2, qp, bd, l);
       rc_inv_transform(log2, c_idx == 0 && log2 == 2 && intra, ts, bd, l);
@@ -202,7 +202,7 @@ RBT_DEV void rc_decode_tb(RbtFrame* f, int c_idx, int x0, int y0, int log2, int 
     int base = intra ? l->pred[i] : p[o];
     p[o] = (uint16_t)(cbf ? rbt_clip3(0, maxv, base + l->res[i]) : base);
   }
-  RBT_SYNC();
+  RBT_SYNC();   // the next TB reads these samples from HBM/L2 as neighbours
 }
 
 // ---- uni-directional motion compensation of one PU (8.5.3.3) from ref->out into f->pix ----
