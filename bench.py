@@ -135,6 +135,16 @@ def main():
            "encode_recon": 3 * enc_pix + enc_pix // 2,         # source in, levels + reconstruction out, P reference in
            "cabac_encode": enc_pix + out_bytes}                # levels in, slice data out
     achieved = alg[dom] / (groups[dom] * 1e-3) / 1e9 if groups[dom] > 0 else 0.0
+    # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+    # runs of this same command: profiles/r01_pmc_traffic.json); counters cannot be read live from inside the benchmark
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        kmap = {"cabac_parse": ["k_parse"], "intra_analysis": ["k_enc_analyse"], "cabac_encode": ["k_entropy"]}
+        if dom in kmap and n_pc == 32 and (w, h) == (1280, 1280):
+            traffic = int(sum((pmc[k]["FETCH_SIZE_KB"] + pmc[k]["WRITE_SIZE_KB"]) * 1024 for k in kmap[dom]))
+    except Exception:
+        traffic = None
     path_achieved = st["algorithmic_bytes"] / (st["gpu_ms"] * 1e-3) / 1e9 if st.get("gpu_ms", 0) > 0 else 0.0
 
     cpu = None
@@ -161,7 +171,7 @@ def main():
                                        f"R5 (QP16/22, prec 2) -> R3 (QP24/32, prec 4), synthetic longdress-like atlas",
                            "gof_per_gpu": 1, "in_bytes": in_bytes, "out_bytes": out_bytes, "parallelism": f"gof-shard x{world}"},
                 "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                             "traffic": None, "kernel_ms": {k_: round(v, 3) for k_, v in groups.items()},
+                             "traffic": traffic, "kernel_ms": {k_: round(v, 3) for k_, v in groups.items()},
                              "path_achieved_GBs": round(path_achieved, 3), "path_frac": round(path_achieved / HBM_PEAK_GBS, 6)},
                 "cpu_baseline": cpu,
                 "host_ms": {"parse": round(st["host_parse_ms"], 3), "pack": round(st["host_pack_ms"], 3), "gpu": round(st["gpu_ms"], 3), "total": round(st["total_ms"], 3)}}
