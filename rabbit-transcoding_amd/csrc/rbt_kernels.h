@@ -8,6 +8,10 @@
 
 namespace rbtk {
 int dev_init(int device);                 // 0 = ok
+// Independent sub-bitstreams run on separate HIP streams so that the short pipelines (occupancy, geometry) overlap the
+// long entropy-decoding chain of the attribute stream. All calls below act on the currently selected stream.
+enum { RBT_N_STREAMS = 4 };
+void set_stream(int i);
 const char* dev_name();
 void* dev_alloc(size_t n);                // nullptr on failure
 void dev_free(void* p);

@@ -9,10 +9,12 @@
 #include "rbt_encode.h"
 
 namespace rbtk {
-static hipStream_t g_stream = nullptr;
+static hipStream_t g_streams[RBT_N_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+static int g_cur = 0;
+#define g_stream (g_streams[g_cur])
 static char g_name[256] = "";
 static char g_err[256] = "";
-static hipEvent_t g_ev[32][2];
+static hipEvent_t g_ev[RBT_N_STREAMS][32][2];
 static bool g_ev_init = false;
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(g_err, sizeof g_err, "%s: %s", #x, hipGetErrorString(e_)); return -1; } } while (0)
@@ -24,20 +26,21 @@ int dev_init(int device) {
   HIPCHK(hipSetDevice(device));
   hipDeviceProp_t p; HIPCHK(hipGetDeviceProperties(&p, device));
   snprintf(g_name, sizeof g_name, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
-  if (!g_stream) HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-  if (!g_ev_init) { for (int i = 0; i < 32; i++) { HIPCHK(hipEventCreate(&g_ev[i][0])); HIPCHK(hipEventCreate(&g_ev[i][1])); } g_ev_init = true; }
+  for (int k = 0; k < RBT_N_STREAMS; k++) if (!g_streams[k]) HIPCHK(hipStreamCreateWithFlags(&g_streams[k], hipStreamNonBlocking));
+  if (!g_ev_init) { for (int k = 0; k < RBT_N_STREAMS; k++) for (int i = 0; i < 32; i++) { HIPCHK(hipEventCreate(&g_ev[k][i][0])); HIPCHK(hipEventCreate(&g_ev[k][i][1])); } g_ev_init = true; }
   return 0;
 }
 const char* dev_name() { return g_name; }
+void set_stream(int i) { g_cur = ((i % RBT_N_STREAMS) + RBT_N_STREAMS) % RBT_N_STREAMS; }
 void* dev_alloc(size_t n) { void* p = nullptr; if (hipMalloc(&p, n) != hipSuccess) return nullptr; return p; }
 void dev_free(void* p) { if (p) (void)hipFree(p); }
 int h2d(void* d, const void* h, size_t n) { HIPCHK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, g_stream)); return 0; }
 int d2h(void* h, const void* d, size_t n) { HIPCHK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, g_stream)); HIPCHK(hipStreamSynchronize(g_stream)); return 0; }
 int dev_memset(void* d, int v, size_t n) { HIPCHK(hipMemsetAsync(d, v, n, g_stream)); return 0; }
 int dev_sync() { HIPCHK(hipStreamSynchronize(g_stream)); HIPCHK(hipGetLastError()); return 0; }
-void timer_begin(int id) { (void)hipEventRecord(g_ev[id][0], g_stream); }
-void timer_end(int id) { (void)hipEventRecord(g_ev[id][1], g_stream); }
-double timer_ms(int id) { float ms = 0; if (hipEventElapsedTime(&ms, g_ev[id][0], g_ev[id][1]) != hipSuccess) return 0; return ms; }
+void timer_begin(int id) { (void)hipEventRecord(g_ev[g_cur][id][0], g_stream); }
+void timer_end(int id) { (void)hipEventRecord(g_ev[g_cur][id][1], g_stream); }
+double timer_ms(int id) { float ms = 0; if (hipEventElapsedTime(&ms, g_ev[g_cur][id][0], g_ev[g_cur][id][1]) != hipSuccess) return 0; return ms; }
 
 // ---------------------------------------------------------------------------------------------- decode kernels
 // one wave per slice segment: wave-uniform CABAC parse (rbt_parse.h)

@@ -28,6 +28,7 @@ struct DecodeBatch {
   std::vector<Sps> stream_sps; std::vector<Pps> stream_pps;
   std::vector<std::vector<int>> level_frames;
   bool ordered_parse = false;
+  std::vector<int32_t> lists_keep;     // host staging of the index lists, alive until the copy has completed
   void* arena = nullptr; size_t arena_size = 0;
   RbtFrame* d_frames = nullptr; RbtSlice* d_slices = nullptr; uint8_t* d_rbsp = nullptr; int32_t* d_lists = nullptr;
   std::string err; int err_code = 0;
@@ -35,7 +36,9 @@ struct DecodeBatch {
 };
 
 int decode_build(DecodeBatch& b, const StreamIn* streams, int n);
-int decode_run(DecodeBatch& b);
+int decode_launch(DecodeBatch& b);   // enqueue every decode kernel of the batch on the current stream (no wait)
+int decode_finish(DecodeBatch& b);   // wait for the batch's stream and check the per-picture error words
+int decode_run(DecodeBatch& b);      // launch + finish
 int decode_fetch(DecodeBatch& b, int stream, rbt_video* out, bool verify_md5);
 
 size_t frame_samples(const RbtStreamCfg& c);

@@ -134,10 +134,12 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
   return 0;
 }
 
-int decode_run(DecodeBatch& b) {
+int decode_run(DecodeBatch& b) { int rc = decode_launch(b); return rc ? rc : decode_finish(b); }
+
+int decode_launch(DecodeBatch& b) {
   size_t nf = b.frames.size(), ns = b.slices.size();
   // index lists: slices grouped by level, frames grouped by level
-  std::vector<int32_t> lists; std::vector<size_t> sl_off, sl_cnt, fr_off;
+  std::vector<int32_t>& lists = b.lists_keep; lists.clear(); std::vector<size_t> sl_off, sl_cnt, fr_off;
   for (auto& lf : b.level_frames) {
     sl_off.push_back(lists.size());
     for (int fi : lf) for (int k = 0; k < b.frames[fi].n_slices; k++) lists.push_back(b.frames[fi].first_slice + k);
@@ -167,6 +169,11 @@ int decode_run(DecodeBatch& b) {
     }
   }
   rbtk::timer_end(T_RECON);
+  return 0;
+}
+
+int decode_finish(DecodeBatch& b) {
+  size_t nf = b.frames.size();
   if (rbtk::dev_sync()) { b.err = "kernel execution failed"; return b.err_code = RBT_ERR_NO_DEVICE; }
   // per-picture error words and slice coverage
   std::vector<RbtFrame> fr(nf);

@@ -181,7 +181,7 @@ static int encode_run(EncodeBatch& b, std::vector<std::vector<uint8_t>>& outs, r
     }
   }
   st.host_pack_ms += now_ms() - t1;
-  st.k_analyse_ms = rbtk::timer_ms(T_ANALYSE); st.k_encode_ms = rbtk::timer_ms(T_ENCODE); st.k_entropy_ms = rbtk::timer_ms(T_ENTROPY);
+  st.k_analyse_ms += rbtk::timer_ms(T_ANALYSE); st.k_encode_ms += rbtk::timer_ms(T_ENCODE); st.k_entropy_ms += rbtk::timer_ms(T_ENTROPY);
   return 0;
 }
 
@@ -194,71 +194,96 @@ static int hand_out(const std::vector<std::vector<uint8_t>>& outs, uint8_t** out
   return 0;
 }
 
+// Pool + encoder setup for the one stream of `db` (PCCTranscoder.cpp:466, :825-904).
+static int setup_encode(DecodeBatch& db, const rbt_stream_params& p, EncodeBatch& eb, std::vector<void*>& pooled, std::string& err) {
+  eb.desc.resize(1);
+  EncStreamDesc& d = eb.desc[0]; int first = db.stream_first[0], cnt = db.stream_count[0];
+  const RbtStreamCfg& c = db.frames[first].cfg;
+  d.bd = c.bit_depth; d.n_frames = cnt; d.qp = p.qp; d.log2_ctb = p.log2_ctb; d.rows = p.ctb_rows_per_slice; d.md5 = p.md5_sei;
+  for (int k = 0; k < 3; k++) d.src[k].resize(cnt);
+  if (p.video_type == RBT_VIDEO_OCCUPANCY) {
+    int factor = p.occupancy_precision / 2; if (factor < 1) factor = 1;
+    d.gop = 1; d.lossless = 1; d.i_qp_offset = 0; d.w = c.w / factor; d.h = c.h / factor;
+    if (p.occupancy_precision == 4) {
+      if (c.w % 4 || c.h % 4) { err = "occupancy map size must be a multiple of 4 to pool"; return RBT_ERR_UNSUPPORTED; }
+      size_t ys = (size_t)d.w * d.h, cs = (size_t)(d.w / 2) * (d.h / 2);
+      uint16_t* buf = (uint16_t*)rbtk::dev_alloc((ys + 2 * cs) * 2 * (size_t)cnt);
+      if (!buf) { err = "device allocation failed"; return RBT_ERR_NOMEM; }
+      pooled.push_back(buf);
+      rbtk::timer_begin(T_POOL);
+      for (int k = 0; k < cnt; k++) {
+        uint16_t* y = buf + (ys + 2 * cs) * (size_t)k;
+        // the reference leaves the pooled chroma planes unwritten (PCCTranscoder.cpp:638-641); mid-grey here
+        rbtk::launch_pool(db.frames[first + k].out[0], c.w, c.h, 2, y, y + ys, y + ys + cs, 1 << (c.bit_depth - 1));
+        d.src[0][k] = y; d.src[1][k] = y + ys; d.src[2][k] = y + ys + cs;
+      }
+      rbtk::timer_end(T_POOL);
+    } else for (int k = 0; k < cnt; k++) for (int q = 0; q < 3; q++) d.src[q][k] = db.frames[first + k].out[q];
+  } else {
+    d.gop = 2; d.lossless = 0; d.i_qp_offset = -3; d.w = c.w; d.h = c.h;
+    for (int k = 0; k < cnt; k++) for (int q = 0; q < 3; q++) d.src[q][k] = db.frames[first + k].out[q];
+  }
+  return 0;
+}
+
+// The sub-bitstreams of a GOF are independent (PCCTranscoder.cpp:122-165 transcodes them one after the other), so each
+// gets its own decode/encode batch on its own HIP stream: every decode chain is enqueued up front, longest first, and
+// the host then walks the streams shortest first, so the pool / re-encode of the short streams (occupancy, geometry)
+// runs underneath the entropy-decoding chain of the longest one (attribute) instead of behind it.
 int transcode_gof(rbt_stats& st, std::string& err, int n, const uint8_t* const* in, const size_t* n_in, const rbt_stream_params* p, uint8_t** out, size_t* n_out) {
   double t_all = now_ms();
   memset(&st, 0, sizeof(st));
   for (int i = 0; i < n; i++) { out[i] = nullptr; n_out[i] = 0; }
-  // ---- decode (PCCTranscoder.cpp:428-448) ----
-  DecodeBatch db; std::vector<StreamIn> sin(n);
-  for (int i = 0; i < n; i++) { sin[i].p = in[i]; sin[i].n = n_in[i]; }
-  double t0 = now_ms();
-  int rc = decode_build(db, sin.data(), n);
-  st.host_parse_ms = now_ms() - t0;
-  rbtk::timer_begin(T_ALL);
-  if (!rc) rc = decode_run(db);
-  if (rc) { err = db.err; return rc; }
-  st.k_parse_ms = rbtk::timer_ms(T_PARSE); st.k_recon_ms = rbtk::timer_ms(T_RECON);
-  for (int i = 0; i < n; i++) if (p[i].verify_md5) {
-    rbt_video v; rc = decode_fetch(db, i, &v, true); free(v.data);
-    if (rc) { err = "fetch failed"; return rc; }
-    if (v.md5_failed) { err = "input MD5 mismatch"; return RBT_ERR_MD5; }
-  }
-  // ---- pool + encoder setup (PCCTranscoder.cpp:466, :825-904) ----
-  EncodeBatch eb; eb.desc.resize(n);
+  std::vector<DecodeBatch> db(n); std::vector<EncodeBatch> eb(n);
   std::vector<void*> pooled;
-  struct Guard { std::vector<void*>& v; ~Guard() { for (void* q : v) rbtk::dev_free(q); } } guard{pooled};
-  for (int i = 0; i < n; i++) {
-    EncStreamDesc& d = eb.desc[i]; int first = db.stream_first[i], cnt = db.stream_count[i];
-    const RbtStreamCfg& c = db.frames[first].cfg;
-    d.bd = c.bit_depth; d.n_frames = cnt; d.qp = p[i].qp; d.log2_ctb = p[i].log2_ctb; d.rows = p[i].ctb_rows_per_slice; d.md5 = p[i].md5_sei;
-    for (int k = 0; k < 3; k++) d.src[k].resize(cnt);
-    if (p[i].video_type == RBT_VIDEO_OCCUPANCY) {
-      int factor = p[i].occupancy_precision / 2; if (factor < 1) factor = 1;
-      d.gop = 1; d.lossless = 1; d.i_qp_offset = 0; d.w = c.w / factor; d.h = c.h / factor;
-      if (p[i].occupancy_precision == 4) {
-        if (c.w % 4 || c.h % 4) { err = "occupancy map size must be a multiple of 4 to pool"; return RBT_ERR_UNSUPPORTED; }
-        size_t ys = (size_t)d.w * d.h, cs = (size_t)(d.w / 2) * (d.h / 2);
-        uint16_t* buf = (uint16_t*)rbtk::dev_alloc((ys + 2 * cs) * 2 * (size_t)cnt);
-        if (!buf) { err = "device allocation failed"; return RBT_ERR_NOMEM; }
-        pooled.push_back(buf);
-        rbtk::timer_begin(T_POOL);
-        for (int k = 0; k < cnt; k++) {
-          uint16_t* y = buf + (ys + 2 * cs) * (size_t)k;
-          // the reference leaves the pooled chroma planes unwritten (PCCTranscoder.cpp:638-641); mid-grey here
-          rbtk::launch_pool(db.frames[first + k].out[0], c.w, c.h, 2, y, y + ys, y + ys + cs, 1 << (c.bit_depth - 1));
-          d.src[0][k] = y; d.src[1][k] = y + ys; d.src[2][k] = y + ys + cs;
-        }
-        rbtk::timer_end(T_POOL);
-      } else for (int k = 0; k < cnt; k++) for (int q = 0; q < 3; q++) d.src[q][k] = db.frames[first + k].out[q];
-    } else {
-      d.gop = 2; d.lossless = 0; d.i_qp_offset = -3; d.w = c.w; d.h = c.h;
-      for (int k = 0; k < cnt; k++) for (int q = 0; q < 3; q++) d.src[q][k] = db.frames[first + k].out[q];
-    }
+  struct Guard { std::vector<void*>& v; ~Guard() { rbtk::set_stream(0); for (void* q : v) rbtk::dev_free(q); } } guard{pooled};
+  std::vector<int> order(n); for (int i = 0; i < n; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n_in[a] > n_in[b]; });
+  // ---- decode (PCCTranscoder.cpp:428-448): build and enqueue every stream, longest first ----
+  double t_gpu = now_ms();
+  for (int k = 0; k < n; k++) {
+    int i = order[k]; rbtk::set_stream(i);
+    StreamIn sin{in[i], n_in[i]};
+    double t0 = now_ms();
+    int rc = decode_build(db[i], &sin, 1);
+    st.host_parse_ms += now_ms() - t0;
+    if (!rc) rc = decode_launch(db[i]);
+    if (rc) { err = db[i].err; for (int q = 0; q < k; q++) { rbtk::set_stream(order[q]); rbtk::dev_sync(); } rbtk::set_stream(0); return rc; }
   }
-  rc = encode_build(eb);
-  std::vector<std::vector<uint8_t>> outs;
-  if (!rc) rc = encode_run(eb, outs, st);
-  rbtk::timer_end(T_ALL);
-  if (rc) { err = eb.err; return rc; }
-  rbtk::dev_sync();
-  st.gpu_ms = rbtk::timer_ms(T_ALL);
+  // ---- finish, pool, re-encode: shortest first ----
+  std::vector<std::vector<uint8_t>> outs(n);
+  int rc = 0;
+  for (int k = n - 1; k >= 0; k--) {
+    int i = order[k]; rbtk::set_stream(i);
+    if (rc) { rbtk::dev_sync(); continue; }              // drain the remaining streams before their arenas are released
+    rc = decode_finish(db[i]);
+    if (rc) { err = db[i].err; continue; }
+    st.k_parse_ms += rbtk::timer_ms(T_PARSE); st.k_recon_ms += rbtk::timer_ms(T_RECON);
+    if (p[i].verify_md5) {
+      rbt_video v; rc = decode_fetch(db[i], 0, &v, true); free(v.data);
+      if (rc) { err = "fetch failed"; continue; }
+      if (v.md5_failed) { err = "input MD5 mismatch"; rc = RBT_ERR_MD5; continue; }
+    }
+    rc = setup_encode(db[i], p[i], eb[i], pooled, err);
+    if (rc) continue;
+    rc = encode_build(eb[i]);
+    std::vector<std::vector<uint8_t>> o1;
+    if (!rc) rc = encode_run(eb[i], o1, st);
+    if (rc) { err = eb[i].err; continue; }
+    outs[i].swap(o1[0]);
+  }
+  rbtk::set_stream(0);
+  if (rc) return rc;
+  st.gpu_ms = now_ms() - t_gpu;
   rc = hand_out(outs, out, n_out);
   // SURVEY.md 8(d) algorithmic traffic: per coded picture of S samples (2 bytes each): decode writes S, P pictures read
   // their reference once; encode reads the source S, writes the reconstruction S (I) and reads the reference (P)
   uint64_t bytes = 0;
-  for (size_t i = 0; i < db.frames.size(); i++) { uint64_t s2 = frame_samples(db.frames[i].cfg) * 2; bytes += s2 + (db.frames[i].level ? s2 : 0); }
-  for (size_t i = 0; i < eb.frames.size(); i++) { uint64_t s2 = frame_samples(eb.frames[i].cfg) * 2; bytes += s2 + s2; }
-  for (int i = 0; i < n; i++) bytes += n_in[i] + n_out[i];
+  for (int i = 0; i < n; i++) {
+    for (size_t k = 0; k < db[i].frames.size(); k++) { uint64_t s2 = frame_samples(db[i].frames[k].cfg) * 2; bytes += s2 + (db[i].frames[k].level ? s2 : 0); }
+    for (size_t k = 0; k < eb[i].frames.size(); k++) { uint64_t s2 = frame_samples(eb[i].frames[k].cfg) * 2; bytes += s2 + s2; }
+    bytes += n_in[i] + n_out[i];
+  }
   st.algorithmic_bytes = bytes;
   st.total_ms = now_ms() - t_all;
   return rc;
