@@ -31,6 +31,7 @@ struct RbtCtxStore {
   int st0, st1, st2, st3;
   int lps_tab;           // lane s: rangeTabLPS[s][0..3] packed little-endian
   int nxt_tab;           // lane s: transIdxLps[s]
+  int trans_tab;         // lane s: next context variable on the MPS path (bits 0..7) / LPS path (bits 8..15), to be XORed with valMps
 #endif
 };
 RBT_DEV int rbt_ctx_reg(int ctx) { return ctx < CTX_LAST_X ? 0 : (ctx < CTX_CSBF ? 3 : (ctx < CTX_SIG ? 2 : (ctx < CTX_GT1 ? 1 : 2))); }
@@ -42,6 +43,8 @@ RBT_DEV int rbt_ctx_initval(int init_type, int qp, int i) {
   int mps = pre <= 63 ? 0 : 1;
   return ((mps ? pre - 64 : 63 - pre) << 1) | mps;
 }
+// transition word of pStateIdx s: (transIdxMps << 1) | ((transIdxLps << 1 | (s == 0)) << 8); XOR valMps onto the selected byte
+RBT_DEV int rbt_trans_word(int s) { s &= 63; int nm = s < 62 ? s + 1 : s; return (nm << 1) | (((k_next_lps[s] << 1) | (s == 0)) << 8); }
 RBT_DEV void rbt_ctx_init(RbtCtxStore* s, int init_type, int qp) {
   qp = rbt_clip3(0, 51, qp);
 #ifdef RBT_HOSTEMU
@@ -54,6 +57,7 @@ RBT_DEV void rbt_ctx_init(RbtCtxStore* s, int init_type, int qp) {
   s->st3 = l < 36 ? rbt_ctx_initval(init_type, qp, CTX_LAST_X + l) : 0;
   s->lps_tab = (int)(k_range_lps[l][0] | (k_range_lps[l][1] << 8) | (k_range_lps[l][2] << 16) | ((uint32_t)k_range_lps[l][3] << 24));
   s->nxt_tab = k_next_lps[l];
+  s->trans_tab = rbt_trans_word(l);
 #endif
 }
 // generic access by context index (any syntax class)
@@ -83,6 +87,13 @@ RBT_DEV int rbt_lps(const RbtCtxStore* s, int state, int q) {
   return (int)(((uint32_t)__builtin_amdgcn_readlane(s->lps_tab, state) >> (8 * q)) & 255u);
 #endif
 }
+RBT_DEV int rbt_trans(const RbtCtxStore* s, int state) {
+#ifdef RBT_HOSTEMU
+  (void)s; return rbt_trans_word(state);
+#else
+  return __builtin_amdgcn_readlane(s->trans_tab, state);
+#endif
+}
 RBT_DEV int rbt_next_lps(const RbtCtxStore* s, int state) {
 #ifdef RBT_HOSTEMU
   (void)s; return k_next_lps[state];
@@ -92,19 +103,23 @@ RBT_DEV int rbt_next_lps(const RbtCtxStore* s, int state) {
 }
 
 // ------------------------------------------------------------------------------------------------ decoder
+// The arithmetic decoder keeps ivlOffset pre-scaled: `value` = ivlOffset << 22 with the next `avail` (>= 7 between bins)
+// bits of the slice data already sitting below it, so renormalisation is a plain left shift and the bitstream is touched
+// once per 16 bits instead of once per bin. Bit 31 is head-room for the doubling in a bypass bin.
 struct RbtCabacDec {
   const uint32_t* w; uint32_t n_words, widx;   // aligned word cursor over the slice data
   uint32_t next_raw;                           // word widx, loaded one refill ahead so its latency is hidden (raw, per-lane copy)
   uint64_t buf; int nbuf;                      // bit reservoir (MSB first)
-  uint32_t range, offset;
+  uint32_t range, value; int avail;
   uint32_t bits_total;                         // bits of the aligned words that belong to the slice data
 #ifdef RBT_PROFILE
   uint32_t n_bins, n_byp;
 #endif
   RbtCtxStore cs;
 };
+enum { RBT_CD_SCALE = 22 };
 RBT_DEV uint32_t rbt_cd_bits(RbtCabacDec* c, int n) {
-  if (c->nbuf < n) {                                   // rare: once per 32 bits
+  if (c->nbuf < n) {                                   // once per 32 bits
     uint32_t v = (uint32_t)RBT_UNI(__builtin_bswap32(c->next_raw));
     c->widx++;
     c->next_raw = c->widx < c->n_words ? c->w[c->widx] : 0;
@@ -113,6 +128,10 @@ RBT_DEV uint32_t rbt_cd_bits(RbtCabacDec* c, int n) {
   c->nbuf -= n;
   return (uint32_t)(c->buf >> c->nbuf) & ((1u << n) - 1u);   // n == 0 yields 0
 }
+RBT_DEV void rbt_cd_refill(RbtCabacDec* c) {          // avail in 0..6 -> 16..22
+  c->value |= rbt_cd_bits(c, 16) << (6 - c->avail);
+  c->avail += 16;
+}
 // p .. p+size is the slice data; the allocation is padded so that the aligned words covering it can be read
 RBT_DEV void rbt_cd_start(RbtCabacDec* c, const uint8_t* p, uint32_t size) {
   uintptr_t a = (uintptr_t)p; int mis = (int)(a & 3);
@@ -120,45 +139,43 @@ RBT_DEV void rbt_cd_start(RbtCabacDec* c, const uint8_t* p, uint32_t size) {
   c->buf = 0; c->nbuf = 0; c->bits_total = (size + (uint32_t)mis) * 8;
   c->next_raw = c->n_words ? c->w[0] : 0;
   if (mis) (void)rbt_cd_bits(c, 8 * mis);
-  c->range = 510; c->offset = rbt_cd_bits(c, 9);
+  c->range = 510;
+  c->value = rbt_cd_bits(c, 9) << RBT_CD_SCALE; c->avail = 0;
+  rbt_cd_refill(c);
 }
-// Decodes one bin given the context variable value; returns bin | new context value << 1. Branch-free on purpose: a lone
-// wave pays ~4 cycles per instruction but ~20 per taken branch.
-RBT_DEV int rbt_cd_core(RbtCabacDec* c, int st) {
+// Decodes one bin given the context variable value `st` (pStateIdx << 1 | valMps); stores the updated variable to *nst.
+RBT_DEV int rbt_cd_core(RbtCabacDec* c, int st, int* nst) {
 #ifdef RBT_PROFILE
   c->n_bins++;
 #endif
-  // mask arithmetic instead of selects: the compiler turns scalar ?: into SCC / exec-mask gymnastics that cost 3-4
-  // instructions each
   uint32_t s = (uint32_t)st >> 1, mps = (uint32_t)st & 1u;
   uint32_t lps = (uint32_t)rbt_lps(&c->cs, (int)s, (int)((c->range >> 6) & 3));
-  uint32_t nl = (uint32_t)rbt_next_lps(&c->cs, (int)s);
-  uint32_t rm = c->range - lps;
-  uint32_t m = 0u - (uint32_t)(c->offset >= rm);       // all ones on the LPS path
-  uint32_t offset = c->offset - (rm & m);
-  uint32_t range = rm ^ ((rm ^ lps) & m);
-  uint32_t bin = mps ^ (m & 1u);
-  uint32_t nm = s + (uint32_t)(s < 62u);
-  uint32_t ns = nm ^ ((nm ^ nl) & m);
-  uint32_t nmps = mps ^ (m & (uint32_t)(s == 0u));
-  int sh = __builtin_clz(range) - 23;                  // 0 when range >= 256
+  uint32_t tr = (uint32_t)rbt_trans(&c->cs, (int)s);
+  uint32_t rm = c->range - lps, rms = rm << RBT_CD_SCALE;
+  bool l = c->value >= rms;                            // LPS path
+  uint32_t value = c->value - (l ? rms : 0u);
+  uint32_t range = l ? lps : rm;
+  *nst = (int)(((tr >> (l ? 8 : 0)) & 255u) ^ mps);
+  int sh = __builtin_clz(range) - 23;                  // 0 when range >= 256, at most 6
   c->range = range << sh;
-  c->offset = (offset << sh) | rbt_cd_bits(c, sh);
-  return (int)(bin | (((ns << 1) | nmps) << 1));
+  c->value = value << sh;
+  c->avail -= sh;
+  if (c->avail < 7) rbt_cd_refill(c);
+  return (int)(mps ^ (uint32_t)l);
 }
 RBT_DEV int rbt_cd_bin(RbtCabacDec* c, int ctx) {
-  int r = rbt_cd_core(c, rbt_ctx_get(&c->cs, ctx));
-  rbt_ctx_set(&c->cs, ctx, r >> 1);
-  return r & 1;
+  int nst, b = rbt_cd_core(c, rbt_ctx_get(&c->cs, ctx), &nst);
+  rbt_ctx_set(&c->cs, ctx, nst);
+  return b;
 }
 // class-specific entry points: the register holding the context is known at the call site
 #ifdef RBT_HOSTEMU
 #define RBT_CD_BIN_REG(NAME, REG, BASE) RBT_DEV int NAME(RbtCabacDec* c, int lane) { return rbt_cd_bin(c, (BASE) + lane); }
 #else
 #define RBT_CD_BIN_REG(NAME, REG, BASE) RBT_DEV int NAME(RbtCabacDec* c, int lane) { \
-  int r = rbt_cd_core(c, __builtin_amdgcn_readlane(c->cs.REG, lane)); \
-  c->cs.REG = ((int)threadIdx.x & 63) == lane ? (r >> 1) : c->cs.REG; \
-  return r & 1; }
+  int nst, b = rbt_cd_core(c, __builtin_amdgcn_readlane(c->cs.REG, lane), &nst); \
+  c->cs.REG = rbt_writelane(c->cs.REG, nst, lane); \
+  return b; }
 #endif
 RBT_CD_BIN_REG(rbt_cd_bin_sig, st1, CTX_SIG)          // lane = sigCtx (0..43)
 RBT_CD_BIN_REG(rbt_cd_bin_res2, st2, (lane < 4 ? CTX_CSBF : CTX_GT1 - 4))   // lane = 0..3 csbf, 4..27 greater1, 28..33 greater2
@@ -170,16 +187,29 @@ RBT_DEV int rbt_cd_bypass(RbtCabacDec* c) {
 #ifdef RBT_PROFILE
   c->n_byp++;
 #endif
-  uint32_t o = (c->offset << 1) | rbt_cd_bits(c, 1);
-  int b = o >= c->range;
-  c->offset = b ? o - c->range : o;
-  return b;
+  uint32_t v = c->value << 1, rs = c->range << RBT_CD_SCALE;
+  bool b = v >= rs;
+  c->value = v - (b ? rs : 0u);
+  if (--c->avail < 7) rbt_cd_refill(c);
+  return (int)b;
 }
-RBT_DEV uint32_t rbt_cd_bypass_n(RbtCabacDec* c, int n) { uint32_t v = 0; while (n--) v = (v << 1) | (uint32_t)rbt_cd_bypass(c); return v; }
+RBT_DEV uint32_t rbt_cd_bypass_n(RbtCabacDec* c, int n) {
+  uint32_t r = 0, rs = c->range << RBT_CD_SCALE;
+  while (n > 0) {                                      // up to 7 bins between refill checks
+    int k = n < 7 ? n : 7;
+    for (int i = 0; i < k; i++) { uint32_t v = c->value << 1; bool b = v >= rs; c->value = v - (b ? rs : 0u); r = (r << 1) | (uint32_t)b; }
+#ifdef RBT_PROFILE
+    c->n_byp += (uint32_t)k;
+#endif
+    c->avail -= k; n -= k;
+    if (c->avail < 7) rbt_cd_refill(c);
+  }
+  return r;
+}
 RBT_DEV int rbt_cd_terminate(RbtCabacDec* c) {
   c->range -= 2;
-  if (c->offset >= c->range) return 1;
-  if (c->range < 256) { c->range <<= 1; c->offset = (c->offset << 1) | rbt_cd_bits(c, 1); }
+  if (c->value >= (c->range << RBT_CD_SCALE)) return 1;
+  if (c->range < 256) { c->range <<= 1; c->value <<= 1; if (--c->avail < 7) rbt_cd_refill(c); }
   return 0;
 }
 // Copies the engine into a function-local object whose scalar fields are marked wave-uniform: the local lives in SGPRs
@@ -188,14 +218,14 @@ RBT_DEV void rbt_cd_localise(RbtCabacDec* d, const RbtCabacDec* c) {
   d->next_raw = c->next_raw;
   d->w = rbt_uni_ptr(c->w); d->n_words = (uint32_t)RBT_UNI(c->n_words); d->widx = (uint32_t)RBT_UNI(c->widx);
   d->buf = ((uint64_t)(uint32_t)RBT_UNI((uint32_t)(c->buf >> 32)) << 32) | (uint32_t)RBT_UNI((uint32_t)c->buf);
-  d->nbuf = RBT_UNI(c->nbuf); d->range = (uint32_t)RBT_UNI(c->range); d->offset = (uint32_t)RBT_UNI(c->offset);
+  d->nbuf = RBT_UNI(c->nbuf); d->range = (uint32_t)RBT_UNI(c->range); d->value = (uint32_t)RBT_UNI(c->value); d->avail = RBT_UNI(c->avail);
   d->bits_total = (uint32_t)RBT_UNI(c->bits_total);
   d->cs = c->cs;
 #ifdef RBT_PROFILE
   d->n_bins = c->n_bins; d->n_byp = c->n_byp;
 #endif
 }
-RBT_DEV int rbt_cd_overrun(const RbtCabacDec* c) { return c->widx * 32u - (uint32_t)c->nbuf > c->bits_total + 96u; }
+RBT_DEV int rbt_cd_overrun(const RbtCabacDec* c) { return c->widx * 32u - (uint32_t)c->nbuf > c->bits_total + 96u + (uint32_t)c->avail; }
 
 // ------------------------------------------------------------------------------------------------ encoder
 struct RbtCabacEnc {

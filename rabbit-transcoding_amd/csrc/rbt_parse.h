@@ -237,90 +237,102 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
 #ifdef RBT_PROFILE
   unsigned long long ta_ = __builtin_readcyclecounter(); s->t_a += ta_ - t0_;
 #endif
+  // Everything that is not the serial arithmetic decode runs on the lanes: lane i holds sub-block scan entry i, lane p
+  // (p < 16) the position of scan index p inside a 4x4 sub-block, its sig_coeff_flag context and, after the bins of a
+  // sub-block are known, the level / sign / address of the coefficient at that scan index.
   const RBT_LDS_AS uint8_t* sb_scan = s->L->scan[scan_idx][log2 - 2];
-  int n_sb = 1 << (2 * (log2 - 2)), last_sb = 0, last_pos = 0;
-  { int sbx = lx >> 2, sby = ly >> 2, ix = lx & 3, iy = ly & 3;
-    for (int i = 0; i < n_sb; i++) if (RBT_UNI(sb_scan[i]) == (sbx | (sby << 4))) { last_sb = i; break; }
-    for (int i = 0; i < 16; i++) if (PZ_POS(i) == (ix | (iy << 2))) { last_pos = i; break; } }
+  const int n_sb = 1 << (2 * (log2 - 2));
+  RBT_VEC(int, v_sbscan); RBT_VEC(int, v_pos);
+  RBT_VFOR(p, 64) { RBT_V(v_sbscan, p) = p < n_sb ? (int)sb_scan[p] : 0xFFFF; RBT_V(v_pos, p) = PZ_POS(p & 15); }
+  int last_sb, last_pos;
+  { uint64_t mb; const int key = (lx >> 2) | ((ly >> 2) << 4), ikey = (lx & 3) | ((ly & 3) << 2);
+    RBT_VBALLOT(mb, p, 64, RBT_V(v_sbscan, p) == key); last_sb = mb ? __builtin_ctzll(mb) : 0;
+    RBT_VBALLOT(mb, p, 16, RBT_V(v_pos, p) == ikey); last_pos = mb ? __builtin_ctzll(mb) : 0; }
   uint64_t csbf = 0;   // bit (ys*8+xs)
-  int sbw = 1 << (log2 - 2);
+  const int sbw = 1 << (log2 - 2);
   int greater1_ctx = 1, first_sb_done = 0;
-  int sign_hiding = sdh_on && !tq_bypass;
+  const int sign_hiding = sdh_on && !tq_bypass;
+  const int sig_c0 = chroma ? 27 : 0, g1_c0 = chroma ? 16 : 0, g2_c0 = chroma ? 4 : 0;
   for (int i = last_sb; i >= 0; i--) {
-    int sbv = RBT_UNI(sb_scan[i]); int xs = sbv & 15, ys = sbv >> 4;
-    int right = xs + 1 < sbw ? (int)((csbf >> (ys * 8 + xs + 1)) & 1) : 0, below = ys + 1 < sbw ? (int)((csbf >> ((ys + 1) * 8 + xs)) & 1) : 0;
+    const int sbv = RBT_VGET(v_sbscan, i), xs = sbv & 15, ys = sbv >> 4;
+    const int right = xs + 1 < sbw ? (int)((csbf >> (ys * 8 + xs + 1)) & 1) : 0, below = ys + 1 < sbw ? (int)((csbf >> ((ys + 1) * 8 + xs)) & 1) : 0;
 #ifdef RBT_PROFILE
     unsigned long long tb0_ = __builtin_readcyclecounter();
 #endif
-    int infer_dc = 0, coded;
-    if (i < last_sb && i > 0) { coded = rbt_cd_bin_csbf(c, rbt_min(right + below, 1) + (chroma ? 2 : 0)); infer_dc = 1; }
-    else coded = 1;
-    if (!coded) continue;
+    int infer_dc = 0;
+    if (i < last_sb && i > 0) { if (!rbt_cd_bin_csbf(c, rbt_min(right + below, 1) + (chroma ? 2 : 0))) continue; infer_dc = 1; }
     csbf |= 1ull << (ys * 8 + xs);
-    uint32_t sig_mask = 0; int nsig = 0;     // bit n = coefficient at scan position n significant
-    int start = i == last_sb ? last_pos - 1 : 15;
-    if (i == last_sb) { sig_mask |= 1u << last_pos; nsig++; }
-    int prev_csbf = right | (below << 1);
     // sigCtx (9.3.4.2.5) = per-CG base + a 2-bit pattern value looked up by the position inside the CG
+    const int prev_csbf = right | (below << 1);
     const uint32_t pat = prev_csbf == 0 ? 0x00010516u : (prev_csbf == 1 ? 0x000055AAu : (prev_csbf == 2 ? 0x06060606u : 0xAAAAAAAAu));
-    int cg_base;
-    if (!chroma) cg_base = ((xs | ys) ? 3 : 0) + (log2 == 3 ? (scan_idx == 0 ? 9 : 15) : 21);
-    else cg_base = 27 + (log2 == 3 ? 9 : 12);
+    const int cg_base = !chroma ? ((xs | ys) ? 3 : 0) + (log2 == 3 ? (scan_idx == 0 ? 9 : 15) : 21) : 27 + (log2 == 3 ? 9 : 12);
     const int dc_cg = (xs | ys) == 0;
-    for (int n = start; n >= 0; n--) {
-      int sig = 1;
-      if (n > 0 || !infer_dc) {
-        int p4 = PZ_POS(n), sc;
-        if (log2 == 2) sc = (int)((PZ_SIGCTX4 >> (4 * p4)) & 15) + (chroma ? 27 : 0);     // p4 = x | y << 2 = raster index of a 4x4 TB
-        else sc = (dc_cg && p4 == 0) ? (chroma ? 27 : 0) : cg_base + (int)((pat >> (2 * p4)) & 3);
-        sig = rbt_cd_bin_sig(c, sc);
-        infer_dc &= sig ^ 1;
-      }
-      sig_mask |= (uint32_t)sig << n; nsig += sig;
+    RBT_VEC(int, v_sc);
+    RBT_VFOR(p, 16) {
+      const int p4 = RBT_V(v_pos, p);                  // x | y << 2 = raster index inside the sub-block
+      RBT_V(v_sc, p) = log2 == 2 ? (int)((PZ_SIGCTX4 >> (4 * p4)) & 15) + sig_c0 : ((dc_cg && p4 == 0) ? sig_c0 : cg_base + (int)((pat >> (2 * p4)) & 3));
+    }
+    uint32_t sig_mask = i == last_sb ? 1u << last_pos : 0u;   // bit n = coefficient at scan index n significant
+    const int start = i == last_sb ? last_pos - 1 : 15;
+    for (int n = start; n >= 1; n--) sig_mask |= (uint32_t)rbt_cd_bin_sig(c, RBT_VGET(v_sc, n)) << n;
+    if (start >= 0) {
+      if (infer_dc && sig_mask == 0) sig_mask = 1u;
+      else sig_mask |= (uint32_t)rbt_cd_bin_sig(c, RBT_VGET(v_sc, 0));
     }
 #ifdef RBT_PROFILE
     unsigned long long tb1_ = __builtin_readcyclecounter(); s->t_b += tb1_ - tb0_;
 #endif
-    if (!nsig) continue;
+    if (!sig_mask) continue;
+    const int nsig = __builtin_popcount(sig_mask);
     int ctx_set = (i == 0 || c_idx > 0) ? 0 : 2;
     if (first_sb_done && greater1_ctx == 0) ctx_set++;
     first_sb_done = 1; greater1_ctx = 1;
-    // k-th significant coefficient in decode order = k-th set bit of sig_mask from the top
-    uint32_t g1_mask = 0; int first_g1 = -1, n8 = rbt_min(nsig, 8);
+    // the k-th significant coefficient in decode order is the k-th set bit of sig_mask from the top
+    uint32_t g1_mask = 0; const int n8 = rbt_min(nsig, 8), g1_base = (ctx_set << 2) + g1_c0;
     for (int k = 0; k < n8; k++) {
-      int g1 = rbt_cd_bin_gt1(c, (ctx_set << 2) + greater1_ctx + (chroma ? 16 : 0));
-      if (g1) { greater1_ctx = 0; g1_mask |= 1u << k; if (first_g1 < 0) first_g1 = k; }
-      else if (greater1_ctx > 0 && greater1_ctx < 3) greater1_ctx++;
+      const int g1 = rbt_cd_bin_gt1(c, g1_base + greater1_ctx);
+      g1_mask |= (uint32_t)g1 << k;
+      greater1_ctx = g1 ? 0 : (greater1_ctx ? rbt_min(greater1_ctx + 1, 3) : 0);
     }
+    const int first_g1 = g1_mask ? __builtin_ctz(g1_mask) : -1;
     int g2 = 0;
-    if (first_g1 >= 0) g2 = rbt_cd_bin_gt2(c, ctx_set + (chroma ? 4 : 0));
+    if (g1_mask) g2 = rbt_cd_bin_gt2(c, ctx_set + g2_c0);
 #ifdef RBT_PROFILE
     unsigned long long tc1_ = __builtin_readcyclecounter(); s->t_c += tc1_ - tb1_;
 #endif
-    int hi = 31 - __builtin_clz(sig_mask), lo = __builtin_ctz(sig_mask);
-    int hidden = sign_hiding && (hi - lo > 3);
-    int nsign = nsig - (hidden ? 1 : 0);
-    uint32_t signs = rbt_cd_bypass_n(c, nsign) << (16 - nsign);
-    int rice = 0, sum = 0, k = 0;
-    uint32_t m = sig_mask;
-    while (m) {
-      int n = 31 - __builtin_clz(m); m &= ~(1u << n);
-      int a = 1 + (int)((g1_mask >> k) & 1) + ((k == first_g1) ? g2 : 0);
-      int base = k < 8 ? (k == first_g1 ? 3 : 2) : 1;
-      if (a == base) {
+    const int hi = 31 - __builtin_clz(sig_mask), lo = __builtin_ctz(sig_mask);
+    const int hidden = sign_hiding && (hi - lo > 3);
+    const int nsign = nsig - (hidden ? 1 : 0);
+    // lanes: decode-order index, base level and "needs coeff_abs_level_remaining" of every scan index
+    RBT_VEC(int, v_k); RBT_VEC(int, v_a); RBT_VEC(int, v_rem); uint64_t need64;
+    RBT_VFOR(p, 16) {
+      const int k = __builtin_popcount(sig_mask >> (p + 1)), isf = k == first_g1;
+      const int a = 1 + (k < 8 ? (int)((g1_mask >> k) & 1) : 0) + (isf ? g2 : 0);
+      RBT_V(v_k, p) = k; RBT_V(v_a, p) = a; RBT_V(v_rem, p) = 0;
+    }
+    RBT_VBALLOT(need64, p, 16, ((sig_mask >> p) & 1) && RBT_V(v_a, p) == (RBT_V(v_k, p) < 8 ? (RBT_V(v_k, p) == first_g1 ? 3 : 2) : 1));
+    const uint32_t signs = rbt_cd_bypass_n(c, nsign);     // sign of decode-order index k = bit nsign-1-k
+    { uint32_t m = (uint32_t)need64; int rice = 0;
+      while (m) {
+        const int n = 31 - __builtin_clz(m); m &= ~(1u << n);
         int pre = 0; while (pre < 32 && rbt_cd_bypass(c)) pre++;
         int v;
         if (pre <= 3) v = (pre << rice) + (int)rbt_cd_bypass_n(c, rice);
         else { int sl = pre - 3 + rice; if (sl > 30) { s->error = 4; s->c = cl; return 0; } v = (((1 << (pre - 3)) + 3 - 1) << rice) + (int)rbt_cd_bypass_n(c, sl); }
-        a += v;
+        const int k = __builtin_popcount(sig_mask >> (n + 1)), a = (k < 8 ? (k == first_g1 ? 3 : 2) : 1) + v;
         if (a > 3 * (1 << rice)) rice = rbt_min(rice + 1, 4);
+        RBT_VSET(v_rem, n, v);
+      } }
+    uint64_t odd64 = 0;
+    if (hidden) RBT_VBALLOT(odd64, p, 16, ((sig_mask >> p) & 1) && ((RBT_V(v_a, p) + RBT_V(v_rem, p)) & 1));
+    const int parity = __builtin_popcountll(odd64) & 1;
+    RBT_VFOR(p, 16) {
+      if ((sig_mask >> p) & 1) {
+        const int k = RBT_V(v_k, p), a = RBT_V(v_a, p) + RBT_V(v_rem, p), p4 = RBT_V(v_pos, p);
+        const int neg = k < nsign ? (int)((signs >> (nsign - 1 - k)) & 1) : parity;
+        const int xc = (xs << 2) + (p4 & 3), yc = (ys << 2) + (p4 >> 2);
+        plane[(size_t)(y0 + yc) * pst + x0 + xc] = (int16_t)rbt_clip3(-32768, 32767, neg ? -a : a);
       }
-      sum += a;
-      int neg = k < nsign ? (int)((signs >> (15 - k)) & 1) : (sum & 1);
-      int xc = (xs << 2) + (PZ_POS(n) & 3), yc = (ys << 2) + (PZ_POS(n) >> 2);
-      int v = rbt_clip3(-32768, 32767, neg ? -a : a);
-      if (RBT_LANE0) plane[(size_t)(y0 + yc) * pst + x0 + xc] = (int16_t)v;
-      k++;
     }
 #ifdef RBT_PROFILE
     s->t_d += __builtin_readcyclecounter() - tc1_;

@@ -22,8 +22,25 @@
 #define RBT_LDS_AS
 #define RBT_LDS_CAST(T, p) (p)
 #define RBT_UNI(x) (x)
+// Per-lane ("vector") values inside wave-uniform code: on the GPU one register whose lane p holds element p; in host
+// emulation an array. RBT_VFOR(p, n) runs its body for p = 0..n-1 (n <= 64): lane p on the GPU, a loop on the host.
+#define RBT_VEC(T, name) T name[64]
+#define RBT_V(name, p) name[p]
+#define RBT_VFOR(p, n) for (int p = 0; p < (int)(n); p++)
+#define RBT_VBALLOT(out, p, n, expr) do { uint64_t b_ = 0; for (int p = 0; p < (int)(n); p++) if (expr) b_ |= 1ull << p; (out) = b_; } while (0)
+#define RBT_VGET(name, lane) name[lane]
+#define RBT_VSET(name, lane, v) name[lane] = (v)
 #else
 #include <hip/hip_runtime.h>
+#define RBT_VEC(T, name) T name
+#define RBT_V(name, p) name
+#define RBT_VFOR(p, n) for (int p = (int)threadIdx.x & 63, once_ = 1; once_ && p < (int)(n); once_ = 0)
+#define RBT_VBALLOT(out, p, n, expr) do { int p = (int)threadIdx.x & 63; (out) = __ballot(p < (int)(n) && (expr)); } while (0)
+#define RBT_VGET(name, lane) __builtin_amdgcn_readlane(name, lane)
+#define RBT_VSET(name, lane, v) name = rbt_writelane(name, v, lane)
+// v_writelane_b32 through the LLVM intrinsic (this clang has no builtin for it)
+__device__ int rbt_llvm_writelane(int v, int lane, int old) __asm("llvm.amdgcn.writelane");
+static __device__ __forceinline__ int rbt_writelane(int old, int v, int lane) { return rbt_llvm_writelane(v, lane, old); }
 #define RBT_DEV static __device__ __forceinline__
 #define RBT_CONST static __device__ const
 #define RBT_PAR_FOR(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += (int)blockDim.x)
