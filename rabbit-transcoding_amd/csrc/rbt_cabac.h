@@ -31,7 +31,7 @@ struct RbtCtxStore {
   int st0, st1, st2, st3;
   int lps_tab;           // lane s: rangeTabLPS[s][0..3] packed little-endian
   int nxt_tab;           // lane s: transIdxLps[s]
-  int trans_tab;         // lane s: next context variable on the MPS path (bits 0..7) / LPS path (bits 8..15), to be XORed with valMps
+  int trans_tab;         // lane s: rbt_trans_word(s)
 #endif
 };
 RBT_DEV int rbt_ctx_reg(int ctx) { return ctx < CTX_LAST_X ? 0 : (ctx < CTX_CSBF ? 3 : (ctx < CTX_SIG ? 2 : (ctx < CTX_GT1 ? 1 : 2))); }
@@ -43,8 +43,9 @@ RBT_DEV int rbt_ctx_initval(int init_type, int qp, int i) {
   int mps = pre <= 63 ? 0 : 1;
   return ((mps ? pre - 64 : 63 - pre) << 1) | mps;
 }
-// transition word of pStateIdx s: (transIdxMps << 1) | ((transIdxLps << 1 | (s == 0)) << 8); XOR valMps onto the selected byte
-RBT_DEV int rbt_trans_word(int s) { s &= 63; int nm = s < 62 ? s + 1 : s; return (nm << 1) | (((k_next_lps[s] << 1) | (s == 0)) << 8); }
+// transition word of pStateIdx s: bits 0..7 = (transIdxLps << 1 | (s == 0)) ^ 1, bits 8..15 = (transIdxMps << 1) ^ 1; the
+// selected byte XOR !valMps is the updated context variable
+RBT_DEV int rbt_trans_word(int s) { s &= 63; int nm = s < 62 ? s + 1 : s; return (((k_next_lps[s] << 1) | (s == 0)) ^ 1) | (((nm << 1) ^ 1) << 8); }
 RBT_DEV void rbt_ctx_init(RbtCtxStore* s, int init_type, int qp) {
   qp = rbt_clip3(0, 51, qp);
 #ifdef RBT_HOSTEMU
@@ -148,20 +149,23 @@ RBT_DEV int rbt_cd_core(RbtCabacDec* c, int st, int* nst) {
 #ifdef RBT_PROFILE
   c->n_bins++;
 #endif
-  uint32_t s = (uint32_t)st >> 1, mps = (uint32_t)st & 1u;
-  uint32_t lps = (uint32_t)rbt_lps(&c->cs, (int)s, (int)((c->range >> 6) & 3));
-  uint32_t tr = (uint32_t)rbt_trans(&c->cs, (int)s);
-  uint32_t rm = c->range - lps, rms = rm << RBT_CD_SCALE;
-  bool l = c->value >= rms;                            // LPS path
-  uint32_t value = c->value - (l ? rms : 0u);
-  uint32_t range = l ? lps : rm;
-  *nst = (int)(((tr >> (l ? 8 : 0)) & 255u) ^ mps);
-  int sh = __builtin_clz(range) - 23;                  // 0 when range >= 256, at most 6
+  // Pure integer arithmetic, no boolean temporaries: the compiler materialises a wave-uniform bool through the vector unit
+  // (v_cndmask + v_readfirstlane), which costs more than the decision itself. value and rms are below 2^31, so the sign
+  // bit of their difference is the MPS/LPS decision.
+  const uint32_t s = (uint32_t)st >> 1, nmps = ~(uint32_t)st & 1u;
+  const uint32_t lps = (uint32_t)rbt_lps(&c->cs, (int)s, (int)((c->range >> 6) & 3));
+  const uint32_t tr = (uint32_t)rbt_trans(&c->cs, (int)s);
+  const uint32_t rm = c->range - lps, rms = rm << RBT_CD_SCALE;
+  const uint32_t d = c->value - rms, mf = d >> 31;     // mf = 1 on the MPS path
+  const uint32_t value = d < c->value ? d : c->value;
+  const uint32_t range = mf ? rm : lps;
+  *nst = (int)(((tr >> (mf << 3)) & 255u) ^ nmps);
+  const int sh = __builtin_clz(range) - 23;            // 0 when range >= 256, at most 6
   c->range = range << sh;
   c->value = value << sh;
   c->avail -= sh;
   if (c->avail < 7) rbt_cd_refill(c);
-  return (int)(mps ^ (uint32_t)l);
+  return (int)(nmps ^ mf);
 }
 RBT_DEV int rbt_cd_bin(RbtCabacDec* c, int ctx) {
   int nst, b = rbt_cd_core(c, rbt_ctx_get(&c->cs, ctx), &nst);
@@ -187,24 +191,23 @@ RBT_DEV int rbt_cd_bypass(RbtCabacDec* c) {
 #ifdef RBT_PROFILE
   c->n_byp++;
 #endif
-  uint32_t v = c->value << 1, rs = c->range << RBT_CD_SCALE;
-  bool b = v >= rs;
-  c->value = v - (b ? rs : 0u);
+  const uint32_t v = c->value << 1, d = v - (c->range << RBT_CD_SCALE);   // v < 2 * rs and rs < 2^31: bit 31 of d = (v < rs)
+  c->value = d < v ? d : v;
   if (--c->avail < 7) rbt_cd_refill(c);
-  return (int)b;
+  return (int)((d >> 31) ^ 1u);
 }
 RBT_DEV uint32_t rbt_cd_bypass_n(RbtCabacDec* c, int n) {
-  uint32_t r = 0, rs = c->range << RBT_CD_SCALE;
+  uint32_t r = 0; const uint32_t rs = c->range << RBT_CD_SCALE, inv = n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u;
   while (n > 0) {                                      // up to 7 bins between refill checks
-    int k = n < 7 ? n : 7;
-    for (int i = 0; i < k; i++) { uint32_t v = c->value << 1; bool b = v >= rs; c->value = v - (b ? rs : 0u); r = (r << 1) | (uint32_t)b; }
+    const int k = n < 7 ? n : 7;
+    for (int i = 0; i < k; i++) { const uint32_t v = c->value << 1, d = v - rs; c->value = d < v ? d : v; r = (r << 1) | (d >> 31); }
 #ifdef RBT_PROFILE
     c->n_byp += (uint32_t)k;
 #endif
     c->avail -= k; n -= k;
     if (c->avail < 7) rbt_cd_refill(c);
   }
-  return r;
+  return r ^ inv;                                      // the loop collected the complemented bins
 }
 RBT_DEV int rbt_cd_terminate(RbtCabacDec* c) {
   c->range -= 2;

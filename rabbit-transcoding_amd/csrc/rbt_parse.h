@@ -250,7 +250,7 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
     RBT_VBALLOT(mb, p, 16, RBT_V(v_pos, p) == ikey); last_pos = mb ? __builtin_ctzll(mb) : 0; }
   uint64_t csbf = 0;   // bit (ys*8+xs)
   const int sbw = 1 << (log2 - 2);
-  int greater1_ctx = 1, first_sb_done = 0;
+  int greater1_ctx = 1, first_sb_done = 0, err = 0;
   const int sign_hiding = sdh_on && !tq_bypass;
   const int sig_c0 = chroma ? 27 : 0, g1_c0 = chroma ? 16 : 0, g2_c0 = chroma ? 4 : 0;
   for (int i = last_sb; i >= 0; i--) {
@@ -285,14 +285,15 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
     if (!sig_mask) continue;
     const int nsig = __builtin_popcount(sig_mask);
     int ctx_set = (i == 0 || c_idx > 0) ? 0 : 2;
-    if (first_sb_done && greater1_ctx == 0) ctx_set++;
+    ctx_set += first_sb_done & (int)((uint32_t)(greater1_ctx - 1) >> 31);   // previous sub-block ended with greater1Ctx == 0
     first_sb_done = 1; greater1_ctx = 1;
     // the k-th significant coefficient in decode order is the k-th set bit of sig_mask from the top
     uint32_t g1_mask = 0; const int n8 = rbt_min(nsig, 8), g1_base = (ctx_set << 2) + g1_c0;
     for (int k = 0; k < n8; k++) {
       const int g1 = rbt_cd_bin_gt1(c, g1_base + greater1_ctx);
       g1_mask |= (uint32_t)g1 << k;
-      greater1_ctx = g1 ? 0 : (greater1_ctx ? rbt_min(greater1_ctx + 1, 3) : 0);
+      // 0 stays 0, a 1 bin resets to 0, otherwise count up to 3 (integer arithmetic, see rbt_cd_core)
+      greater1_ctx = (int)((0x3320u >> (4 * greater1_ctx)) & 15u) & (g1 - 1);
     }
     const int first_g1 = g1_mask ? __builtin_ctz(g1_mask) : -1;
     int g2 = 0;
@@ -318,7 +319,7 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
         int pre = 0; while (pre < 32 && rbt_cd_bypass(c)) pre++;
         int v;
         if (pre <= 3) v = (pre << rice) + (int)rbt_cd_bypass_n(c, rice);
-        else { int sl = pre - 3 + rice; if (sl > 30) { s->error = 4; s->c = cl; return 0; } v = (((1 << (pre - 3)) + 3 - 1) << rice) + (int)rbt_cd_bypass_n(c, sl); }
+        else { int sl = pre - 3 + rice; if (sl > 30) { err = 4; sl = 30; } v = (int)((((1u << (pre - 3)) + 3u - 1u) << rice) + rbt_cd_bypass_n(c, sl)); }   // no early exit: keeps the loop single-exit
         const int k = __builtin_popcount(sig_mask >> (n + 1)), a = (k < 8 ? (k == first_g1 ? 3 : 2) : 1) + v;
         if (a > 3 * (1 << rice)) rice = rbt_min(rice + 1, 4);
         RBT_VSET(v_rem, n, v);
@@ -339,6 +340,7 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
 #endif
   }
   s->c = cl;
+  if (err) s->error = err;
 #ifdef RBT_PROFILE
   s->t_res += __builtin_readcyclecounter() - t0_;
 #endif
