@@ -108,8 +108,8 @@ RBT_DEV int rbt_next_lps(const RbtCtxStore* s, int state) {
 // bits of the slice data already sitting below it, so renormalisation is a plain left shift and the bitstream is touched
 // once per 16 bits instead of once per bin. Bit 31 is head-room for the doubling in a bypass bin.
 struct RbtCabacDec {
-  const uint32_t* w; uint32_t n_words, widx;   // aligned word cursor over the slice data
-  uint32_t next_raw;                           // word widx, loaded one refill ahead so its latency is hidden (raw, per-lane copy)
+  const RBT_CONST_AS uint32_t* w; uint32_t n_words, widx;   // aligned word cursor over the slice data (scalar loads)
+  uint32_t next_raw;                           // word widx, loaded one refill ahead so its latency is hidden
   uint64_t buf; int nbuf;                      // bit reservoir (MSB first)
   uint32_t range, value; int avail;
   uint32_t bits_total;                         // bits of the aligned words that belong to the slice data
@@ -119,11 +119,19 @@ struct RbtCabacDec {
   RbtCtxStore cs;
 };
 enum { RBT_CD_SCALE = 22 };
+// The engine state is wave-uniform by construction. Outside the hot loops the compiler cannot always prove it (the state
+// passes through joins it considers divergent), and one unproven value turns the whole syntax parser into exec-masked
+// vector code; re-asserting uniformity here is free where it is already known (the readfirstlane folds away).
+RBT_DEV void rbt_cd_assert_uniform(RbtCabacDec* c) {
+  c->range = (uint32_t)RBT_UNI(c->range); c->value = (uint32_t)RBT_UNI(c->value); c->avail = RBT_UNI(c->avail); c->nbuf = RBT_UNI(c->nbuf);
+}
 RBT_DEV uint32_t rbt_cd_bits(RbtCabacDec* c, int n) {
   if (c->nbuf < n) {                                   // once per 32 bits
     uint32_t v = (uint32_t)RBT_UNI(__builtin_bswap32(c->next_raw));
-    c->widx++;
-    c->next_raw = c->widx < c->n_words ? c->w[c->widx] : 0;
+    c->widx = (uint32_t)RBT_UNI(c->widx) + 1;
+    c->buf = ((uint64_t)(uint32_t)RBT_UNI((uint32_t)(c->buf >> 32)) << 32) | (uint32_t)RBT_UNI((uint32_t)c->buf);
+    { const RBT_CONST_AS uint32_t* w = (const RBT_CONST_AS uint32_t*)rbt_uni_ptr((const uint32_t*)(uintptr_t)c->w);   // uniform base: scalar load
+      c->next_raw = c->widx < (uint32_t)RBT_UNI(c->n_words) ? w[c->widx] : 0; }
     c->buf = (c->buf << 32) | v; c->nbuf += 32;
   }
   c->nbuf -= n;
@@ -136,7 +144,7 @@ RBT_DEV void rbt_cd_refill(RbtCabacDec* c) {          // avail in 0..6 -> 16..22
 // p .. p+size is the slice data; the allocation is padded so that the aligned words covering it can be read
 RBT_DEV void rbt_cd_start(RbtCabacDec* c, const uint8_t* p, uint32_t size) {
   uintptr_t a = (uintptr_t)p; int mis = (int)(a & 3);
-  c->w = (const uint32_t*)(a - (uintptr_t)mis); c->n_words = (size + (uint32_t)mis + 3) >> 2; c->widx = 0;
+  c->w = (const RBT_CONST_AS uint32_t*)(a - (uintptr_t)mis); c->n_words = (size + (uint32_t)mis + 3) >> 2; c->widx = 0;
   c->buf = 0; c->nbuf = 0; c->bits_total = (size + (uint32_t)mis) * 8;
   c->next_raw = c->n_words ? c->w[0] : 0;
   if (mis) (void)rbt_cd_bits(c, 8 * mis);
@@ -145,10 +153,11 @@ RBT_DEV void rbt_cd_start(RbtCabacDec* c, const uint8_t* p, uint32_t size) {
   rbt_cd_refill(c);
 }
 // Decodes one bin given the context variable value `st` (pStateIdx << 1 | valMps); stores the updated variable to *nst.
-RBT_DEV int rbt_cd_core(RbtCabacDec* c, int st, int* nst) {
+template <bool AU> RBT_DEV int rbt_cd_core(RbtCabacDec* c, int st, int* nst) {
 #ifdef RBT_PROFILE
   c->n_bins++;
 #endif
+  if (AU) rbt_cd_assert_uniform(c);
   // Pure integer arithmetic, no boolean temporaries: the compiler materialises a wave-uniform bool through the vector unit
   // (v_cndmask + v_readfirstlane), which costs more than the decision itself. value and rms are below 2^31, so the sign
   // bit of their difference is the MPS/LPS decision.
@@ -164,11 +173,11 @@ RBT_DEV int rbt_cd_core(RbtCabacDec* c, int st, int* nst) {
   c->range = range << sh;
   c->value = value << sh;
   c->avail -= sh;
-  if (c->avail < 7) rbt_cd_refill(c);
+  if (__builtin_expect(c->avail < 7, 0)) rbt_cd_refill(c);
   return (int)(nmps ^ mf);
 }
 RBT_DEV int rbt_cd_bin(RbtCabacDec* c, int ctx) {
-  int nst, b = rbt_cd_core(c, rbt_ctx_get(&c->cs, ctx), &nst);
+  int nst, b = rbt_cd_core<true>(c, rbt_ctx_get(&c->cs, ctx), &nst);
   rbt_ctx_set(&c->cs, ctx, nst);
   return b;
 }
@@ -177,7 +186,7 @@ RBT_DEV int rbt_cd_bin(RbtCabacDec* c, int ctx) {
 #define RBT_CD_BIN_REG(NAME, REG, BASE) RBT_DEV int NAME(RbtCabacDec* c, int lane) { return rbt_cd_bin(c, (BASE) + lane); }
 #else
 #define RBT_CD_BIN_REG(NAME, REG, BASE) RBT_DEV int NAME(RbtCabacDec* c, int lane) { \
-  int nst, b = rbt_cd_core(c, __builtin_amdgcn_readlane(c->cs.REG, lane), &nst); \
+  int nst, b = rbt_cd_core<false>(c, __builtin_amdgcn_readlane(c->cs.REG, lane), &nst); \
   c->cs.REG = rbt_writelane(c->cs.REG, nst, lane); \
   return b; }
 #endif
@@ -187,16 +196,18 @@ RBT_DEV int rbt_cd_bin_csbf(RbtCabacDec* c, int i) { return rbt_cd_bin_res2(c, i
 RBT_DEV int rbt_cd_bin_gt1(RbtCabacDec* c, int i) { return rbt_cd_bin_res2(c, 4 + i); }
 RBT_DEV int rbt_cd_bin_gt2(RbtCabacDec* c, int i) { return rbt_cd_bin_res2(c, 28 + i); }
 RBT_CD_BIN_REG(rbt_cd_bin_last, st3, CTX_LAST_X)      // lane = 0..17 x prefix, 18..35 y prefix
-RBT_DEV int rbt_cd_bypass(RbtCabacDec* c) {
+template <bool AU = true> RBT_DEV int rbt_cd_bypass(RbtCabacDec* c) {
 #ifdef RBT_PROFILE
   c->n_byp++;
 #endif
+  if (AU) rbt_cd_assert_uniform(c);
   const uint32_t v = c->value << 1, d = v - (c->range << RBT_CD_SCALE);   // v < 2 * rs and rs < 2^31: bit 31 of d = (v < rs)
   c->value = d < v ? d : v;
-  if (--c->avail < 7) rbt_cd_refill(c);
+  if (__builtin_expect(--c->avail < 7, 0)) rbt_cd_refill(c);
   return (int)((d >> 31) ^ 1u);
 }
-RBT_DEV uint32_t rbt_cd_bypass_n(RbtCabacDec* c, int n) {
+template <bool AU = true> RBT_DEV uint32_t rbt_cd_bypass_n(RbtCabacDec* c, int n) {
+  if (AU) { rbt_cd_assert_uniform(c); n = RBT_UNI(n); }
   uint32_t r = 0; const uint32_t rs = c->range << RBT_CD_SCALE, inv = n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u;
   while (n > 0) {                                      // up to 7 bins between refill checks
     const int k = n < 7 ? n : 7;
@@ -205,21 +216,22 @@ RBT_DEV uint32_t rbt_cd_bypass_n(RbtCabacDec* c, int n) {
     c->n_byp += (uint32_t)k;
 #endif
     c->avail -= k; n -= k;
-    if (c->avail < 7) rbt_cd_refill(c);
+    if (__builtin_expect(c->avail < 7, 0)) rbt_cd_refill(c);
   }
   return r ^ inv;                                      // the loop collected the complemented bins
 }
 RBT_DEV int rbt_cd_terminate(RbtCabacDec* c) {
+  rbt_cd_assert_uniform(c);
   c->range -= 2;
   if (c->value >= (c->range << RBT_CD_SCALE)) return 1;
-  if (c->range < 256) { c->range <<= 1; c->value <<= 1; if (--c->avail < 7) rbt_cd_refill(c); }
+  if (c->range < 256) { c->range <<= 1; c->value <<= 1; if (__builtin_expect(--c->avail < 7, 0)) rbt_cd_refill(c); }
   return 0;
 }
 // Copies the engine into a function-local object whose scalar fields are marked wave-uniform: the local lives in SGPRs
 // (scalar ALU, scalar branches) for the duration of a hot loop, independent of where the enclosing parser state sits.
 RBT_DEV void rbt_cd_localise(RbtCabacDec* d, const RbtCabacDec* c) {
   d->next_raw = c->next_raw;
-  d->w = rbt_uni_ptr(c->w); d->n_words = (uint32_t)RBT_UNI(c->n_words); d->widx = (uint32_t)RBT_UNI(c->widx);
+  d->w = (const RBT_CONST_AS uint32_t*)rbt_uni_ptr((const uint32_t*)(uintptr_t)c->w); d->n_words = (uint32_t)RBT_UNI(c->n_words); d->widx = (uint32_t)RBT_UNI(c->widx);
   d->buf = ((uint64_t)(uint32_t)RBT_UNI((uint32_t)(c->buf >> 32)) << 32) | (uint32_t)RBT_UNI((uint32_t)c->buf);
   d->nbuf = RBT_UNI(c->nbuf); d->range = (uint32_t)RBT_UNI(c->range); d->value = (uint32_t)RBT_UNI(c->value); d->avail = RBT_UNI(c->avail);
   d->bits_total = (uint32_t)RBT_UNI(c->bits_total);

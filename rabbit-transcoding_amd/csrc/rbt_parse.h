@@ -44,91 +44,177 @@ struct RbtParse {
   int cu_x, cu_y, cu_log2, cu_pred_mode, cu_part_mode, cu_tq_bypass;
   int il_packed, intra_chroma, max_trafo_depth, last_pu_merge;   // no arrays / index-selected fields here: they would pin the whole struct in scratch
   int error;
+  // Register-resident neighbour context (one value per lane). Current CTB, four horizontally adjacent 4x4 units per lane:
+  // unit (ux,uy) lives in lane uy * 4 + (ux >> 2), byte ux & 3 (mv: register r_mv<ux & 3>).
+  RBT_VEC(uint32_t, r_pm); RBT_VEC(uint32_t, r_dm); RBT_VEC(uint32_t, r_ed); RBT_VEC(uint32_t, r_qp); RBT_VEC(uint32_t, r_ref);
+  RBT_VEC(uint32_t, r_mv0); RBT_VEC(uint32_t, r_mv1); RBT_VEC(uint32_t, r_mv2); RBT_VEC(uint32_t, r_mv3);
+  // Units around the CTB: lane 0 above-left corner, lanes 1..17 the row above (16 units + the first above-right one),
+  // lanes 32..47 the column to the left. Availability is folded in: an unavailable unit reads pm = RBT_MODE_NONE.
+  RBT_VEC(uint32_t, n_pm); RBT_VEC(uint32_t, n_dm); RBT_VEC(uint32_t, n_ref); RBT_VEC(uint32_t, n_mv);
 #ifdef RBT_PROFILE
-  unsigned long long t_res, t_ctb, t_cu, t_a, t_b, t_c, t_d, t_tu, t_hdr, t_fill; uint32_t n_res, n_cu;
+  unsigned long long t_res, t_ctb, t_cu, t_a, t_b, t_c, t_d, t_tu, t_hdr, t_fill, t_mpm; uint32_t n_res, n_cu;
 #endif
 };
 struct RbtMv { int x, y, ref; };
 RBT_DEV int pz_il(const RbtParse* s, int i) { return (s->il_packed >> (8 * i)) & 255; }   // luma intra modes of the (up to four) PUs, 8 bits each
 RBT_DEV void pz_set_il(RbtParse* s, int i, int v) { s->il_packed = (s->il_packed & ~(255 << (8 * i))) | (v << (8 * i)); }
-
-// ---- neighbour context in LDS -------------------------------------------------------------------------------------
-// The parser never reads the HBM maps of its own picture back: everything later syntax depends on (prediction mode,
-// skip, depth, intra mode, QP, motion) is kept per 4x4 unit in LDS for the current CTB, the right column of the left
-// CTB, the bottom row of the CTB row above (line buffer over the picture width) and the above-left corner unit. The
-// HBM maps are written once per CTB (pz_flush_ctb) with plain stores that nobody waits for.
-RBT_DEV int pz_idx(const RbtParse* s, int x, int y) { return (y >> 2) * s->cfg.w4 + (x >> 2); }
-// handle of luma position (xn,yn): -1 = not available (outside the picture, other slice, not decoded yet);
-// else region << 12 | index with region 0 current CTB, 1 left column, 2 above row, 3 above-left corner
-RBT_DEV int pz_loc(const RbtParse* s, int xn, int yn) {
-  if (xn < 0 || yn < 0 || xn >= s->cfg.w || yn >= s->cfg.h) return -1;
-  int cx = s->ctb_x, cy = s->ctb_y, L = s->cfg.log2_ctb, ctb = 1 << L;
-  if (yn >= cy + ctb) return -1;
-  if (yn < cy) {
-    if (yn < cy - 1) return -1;
-    if (xn < cx) return s->corner_ok ? (3 << 12) : -1;
-    if (s->L->above_slice[xn >> L] != s->slice_idx) return -1;
-    return (2 << 12) | (xn >> 2);
-  }
-  if (xn < cx) return s->left_ok ? ((1 << 12) | ((yn - cy) >> 2)) : -1;
-  if (xn >= cx + ctb) return -1;
-  int k = ((yn - cy) >> 2) * 16 + ((xn - cx) >> 2);
-  return (s->L->cur_pm[k] & RBT_PM_MODE_MASK) == RBT_MODE_NONE ? -1 : k;
+// Re-asserts that the scalar parser state is wave-uniform (see rbt_cd_assert_uniform): called where the syntax walkers
+// re-enter, so that one value the compiler could not prove uniform does not drag the control flow onto the vector unit.
+RBT_DEV void pz_assert_uniform(RbtParse* s) {
+#define PZ_AU(f) s->f = (decltype(s->f))RBT_UNI(s->f)
+  PZ_AU(ctb_x); PZ_AU(ctb_y); PZ_AU(left_ok); PZ_AU(corner_ok); PZ_AU(corner_pm); PZ_AU(corner_dm); PZ_AU(corner_ref); PZ_AU(corner_mv);
+  PZ_AU(qp_y); PZ_AU(qp_pred); PZ_AU(qp_y_prev); PZ_AU(is_cu_qp_delta_coded); PZ_AU(cu_qp_delta_val); PZ_AU(ctb_addr); PZ_AU(n_cmds);
+  PZ_AU(cu_x); PZ_AU(cu_y); PZ_AU(cu_log2); PZ_AU(cu_pred_mode); PZ_AU(cu_part_mode); PZ_AU(cu_tq_bypass);
+  PZ_AU(il_packed); PZ_AU(intra_chroma); PZ_AU(max_trafo_depth); PZ_AU(last_pu_merge); PZ_AU(error);
+#undef PZ_AU
+  rbt_cd_assert_uniform(&s->c);
+  s->c.widx = (uint32_t)RBT_UNI(s->c.widx); s->c.n_words = (uint32_t)RBT_UNI(s->c.n_words);
 }
-RBT_DEV int pz_ld_pm(const RbtParse* s, int loc) { int r = loc >> 12, i = loc & 4095; return r == 0 ? s->L->cur_pm[i] : (r == 1 ? s->L->left_pm[i] : (r == 2 ? s->L->above_pm[i] : s->corner_pm)); }
-RBT_DEV int pz_ld_dm(const RbtParse* s, int loc) { int r = loc >> 12, i = loc & 4095; return r == 0 ? s->L->cur_dm[i] : (r == 1 ? s->L->left_dm[i] : (r == 2 ? s->L->above_dm[i] : s->corner_dm)); }
-RBT_DEV int pz_ld_ref(const RbtParse* s, int loc) { int r = loc >> 12, i = loc & 4095; return r == 0 ? s->L->cur_ref[i] : (r == 1 ? s->L->left_ref[i] : (r == 2 ? s->L->above_ref[i] : s->corner_ref)); }
-RBT_DEV int pz_ld_mv(const RbtParse* s, int loc) { int r = loc >> 12, i = loc & 4095; return r == 0 ? s->L->cur_mv[i] : (r == 1 ? s->L->left_mv[i] : (r == 2 ? s->L->above_mv[i] : s->corner_mv)); }
+#define PZ_UNI_VARS2(a, b) do { a = RBT_UNI(a); b = RBT_UNI(b); } while (0)
+
+// ---- neighbour context -------------------------------------------------------------------------------------------
+// The parser never reads the HBM maps of its own picture back. What later syntax depends on (prediction mode, skip,
+// depth, intra mode, QP, motion) is kept per 4x4 unit in REGISTERS for the current CTB and the units around it, read with
+// v_readlane and updated with a handful of lane-parallel VALU instructions per block (no LDS round trip, no sync).
+// LDS only carries the context from one CTB to the next (right column, bottom row over the picture width, corner); the
+// HBM maps are written once per CTB (pz_end_ctb) with plain stores that nobody waits for.
+RBT_DEV int pz_idx(const RbtParse* s, int x, int y) { return (y >> 2) * s->cfg.w4 + (x >> 2); }
+#define PZ_RD8(reg, k) ((int)((RBT_VGET(reg, (k) >> 2) >> (((k) & 3) * 8)) & 255u))
+#define PZ_NB_BASE 256
+// handle of luma position (xn,yn): -1 = not available (outside the picture, other slice, not decoded yet);
+// else 0..255 = unit of the current CTB, PZ_NB_BASE + lane = surrounding unit
+RBT_DEV int pz_ld_pm(const RbtParse* s, int loc) { return loc < PZ_NB_BASE ? PZ_RD8(s->r_pm, loc) : (int)RBT_VGET(s->n_pm, loc - PZ_NB_BASE); }
+RBT_DEV int pz_ld_dm(const RbtParse* s, int loc) { return loc < PZ_NB_BASE ? PZ_RD8(s->r_dm, loc) : (int)RBT_VGET(s->n_dm, loc - PZ_NB_BASE); }
+RBT_DEV int pz_ld_ref(const RbtParse* s, int loc) { return (int8_t)(loc < PZ_NB_BASE ? PZ_RD8(s->r_ref, loc) : (int)RBT_VGET(s->n_ref, loc - PZ_NB_BASE)); }
+RBT_DEV int pz_ld_mv(const RbtParse* s, int loc) {
+  if (loc >= PZ_NB_BASE) return (int)RBT_VGET(s->n_mv, loc - PZ_NB_BASE);
+  int l = loc >> 2, j = loc & 3;
+  uint32_t a = RBT_VGET(s->r_mv0, l), b = RBT_VGET(s->r_mv1, l), c = RBT_VGET(s->r_mv2, l), d = RBT_VGET(s->r_mv3, l);
+  return (int)(j == 0 ? a : (j == 1 ? b : (j == 2 ? c : d)));
+}
+RBT_DEV int pz_loc(const RbtParse* s, int xn, int yn) {
+  const int dx = xn - s->ctb_x, dy = yn - s->ctb_y, ctb = 1 << s->cfg.log2_ctb;
+  int loc;
+  if (dx < -1 || dy < -1) return -1;
+  if (dy < 0) { loc = (dx + 4) >> 2; if (loc > (ctb >> 2) + 1) return -1; loc += PZ_NB_BASE; }
+  else if (dy >= ctb) return -1;
+  else if (dx < 0) loc = PZ_NB_BASE + 32 + (dy >> 2);
+  else if (dx >= ctb) return -1;
+  else loc = (dy >> 2) * 16 + (dx >> 2);
+  return (pz_ld_pm(s, loc) & RBT_PM_MODE_MASK) == RBT_MODE_NONE ? -1 : loc;
+}
 RBT_DEV int pz_avail(const RbtParse* s, int xn, int yn) { return pz_loc(s, xn, yn) >= 0; }
 RBT_DEV int pz_mode(const RbtParse* s, int x, int y) { return pz_ld_pm(s, pz_loc(s, x, y)) & RBT_PM_MODE_MASK; }   // caller checked pz_avail
 RBT_DEV int pz_dm(const RbtParse* s, int x, int y) { return pz_ld_dm(s, pz_loc(s, x, y)); }
 // neighbour summary in one lookup: -1 = unavailable, else pm | dm << 8
 RBT_DEV int pz_nb(const RbtParse* s, int x, int y) { int loc = pz_loc(s, x, y); return loc < 0 ? -1 : (pz_ld_pm(s, loc) | (pz_ld_dm(s, loc) << 8)); }
 RBT_DEV int pz_cur(const RbtParse* s, int x, int y) { return ((y - s->ctb_y) >> 2) * 16 + ((x - s->ctb_x) >> 2); }
-// ---- cooperative fills of square power-of-two blocks (shifts, no division); one pass per event ----
-RBT_DEV int pz_log2u(int n4) { return 31 - __builtin_clz((unsigned)n4); }     // n4 = units per side (1,2,4,8,16)
+// ---- lane-parallel block updates: byte mask of the units of lane p that lie inside a block (unit coordinates in the CTB)
+RBT_DEV uint32_t pz_sq_mask(int p, int bx, int by, int n4) {            // aligned square, n4 = 1, 2, 4, 8 or 16 units
+  const int uy = p >> 2, ux0 = (p & 3) << 2;
+  const uint32_t m = n4 >= 4 ? ((unsigned)(ux0 - bx) < (unsigned)n4 ? 0xFFFFFFFFu : 0u) : (ux0 == (bx & ~3) ? (((1u << (8 * n4)) - 1u) << (8 * (bx & 3))) : 0u);
+  return (unsigned)(uy - by) < (unsigned)n4 ? m : 0u;
+}
+RBT_DEV uint32_t pz_rect_mask(int p, int bx, int by, int w4, int h4) {  // any rectangle (AMP prediction units)
+  const int uy = p >> 2, ux0 = (p & 3) << 2; uint32_t m = 0;
+  for (int j = 0; j < 4; j++) if ((unsigned)(ux0 + j - bx) < (unsigned)w4) m |= 0xFFu << (8 * j);
+  return (unsigned)(uy - by) < (unsigned)h4 ? m : 0u;
+}
+RBT_DEV uint32_t pz_left_mask(int p, int bx, uint32_t m) { return ((p & 3) << 2) == (bx & ~3) ? (m & (0xFFu << (8 * (bx & 3)))) : 0u; }   // units in column bx
+RBT_DEV uint32_t pz_top_mask(int p, int by, uint32_t m) { return (p >> 2) == by ? m : 0u; }                                                // units in row by
+#define PZ_REP4(v) ((uint32_t)((v) & 255) * 0x01010101u)
+#ifdef RBT_PROFILE
+#define PZ_TF0() unsigned long long tf_ = __builtin_readcyclecounter()
+#define PZ_TF1() (s->t_fill += __builtin_readcyclecounter() - tf_)
+#else
+#define PZ_TF0() ((void)0)
+#define PZ_TF1() ((void)0)
+#endif
 // coding unit: every unit gets its mode / depth|mode / QP, and the CU boundary becomes a TU+PU edge. Each unit belongs to
 // exactly one CU, so edges are assigned, not OR-ed.
-RBT_DEV void pz_fill_cu(const RbtParse* s, int x, int y, int N, int pm, int dm, int qp) {
-  int n4 = N >> 2, l4 = pz_log2u(n4), base = pz_cur(s, x, y);
-  RBT_PAR_FOR(i, n4 * n4) {
-    int ux = i & (n4 - 1), uy = i >> l4, k = base + uy * 16 + ux;
-    s->L->cur_pm[k] = (uint8_t)pm; s->L->cur_dm[k] = (uint8_t)dm; s->L->cur_qp[k] = (int8_t)qp;
-    s->L->cur_edges[k] = (uint8_t)((ux == 0 ? (RBT_EV_TU | RBT_EV_PU) : 0) | (uy == 0 ? (RBT_EH_TU | RBT_EH_PU) : 0));
+RBT_DEV void pz_fill_cu(RbtParse* s, int x, int y, int N, int pm, int dm, int qp) {
+  PZ_TF0();
+  const int n4 = N >> 2, bx = (x - s->ctb_x) >> 2, by = (y - s->ctb_y) >> 2;
+  RBT_VFOR(p, 64) {
+    const uint32_t m = pz_sq_mask(p, bx, by, n4), ml = pz_left_mask(p, bx, m), mt = pz_top_mask(p, by, m);
+    RBT_V(s->r_pm, p) = (RBT_V(s->r_pm, p) & ~m) | (PZ_REP4(pm) & m);
+    RBT_V(s->r_dm, p) = (RBT_V(s->r_dm, p) & ~m) | (PZ_REP4(dm) & m);
+    RBT_V(s->r_qp, p) = (RBT_V(s->r_qp, p) & ~m) | (PZ_REP4(qp) & m);
+    RBT_V(s->r_ed, p) = (RBT_V(s->r_ed, p) & ~m) | (PZ_REP4(RBT_EV_TU | RBT_EV_PU) & ml) | (PZ_REP4(RBT_EH_TU | RBT_EH_PU) & mt);
   }
-  RBT_SYNC_LDS();
+  PZ_TF1();
 }
-RBT_DEV void pz_fill_dm(const RbtParse* s, int x, int y, int N, int v) {
-  int n4 = N >> 2, l4 = pz_log2u(n4), base = pz_cur(s, x, y);
-  RBT_PAR_FOR(i, n4 * n4) s->L->cur_dm[base + (i >> l4) * 16 + (i & (n4 - 1))] = (uint8_t)v;
-  RBT_SYNC_LDS();
+RBT_DEV void pz_fill_dm(RbtParse* s, int x, int y, int N, int v) {
+  PZ_TF0();
+  const int n4 = N >> 2, bx = (x - s->ctb_x) >> 2, by = (y - s->ctb_y) >> 2;
+  RBT_VFOR(p, 64) { const uint32_t m = pz_sq_mask(p, bx, by, n4); RBT_V(s->r_dm, p) = (RBT_V(s->r_dm, p) & ~m) | (PZ_REP4(v) & m); }
+  PZ_TF1();
 }
-RBT_DEV void pz_fill_qp(const RbtParse* s, int x, int y, int N, int v) {
-  int n4 = N >> 2, l4 = pz_log2u(n4), base = pz_cur(s, x, y);
-  RBT_PAR_FOR(i, n4 * n4) s->L->cur_qp[base + (i >> l4) * 16 + (i & (n4 - 1))] = (int8_t)v;
-  RBT_SYNC_LDS();
+RBT_DEV void pz_fill_qp(RbtParse* s, int x, int y, int N, int v) {
+  PZ_TF0();
+  const int n4 = N >> 2, bx = (x - s->ctb_x) >> 2, by = (y - s->ctb_y) >> 2;
+  RBT_VFOR(p, 64) { const uint32_t m = pz_sq_mask(p, bx, by, n4); RBT_V(s->r_qp, p) = (RBT_V(s->r_qp, p) & ~m) | (PZ_REP4(v) & m); }
+  PZ_TF1();
 }
 // transform unit: non-zero flag of the luma TB and its TU edges in one pass
-RBT_DEV void pz_fill_tu(const RbtParse* s, int x, int y, int N, int nz) {
-  int n4 = N >> 2, l4 = pz_log2u(n4), base = pz_cur(s, x, y);
-  RBT_PAR_FOR(i, n4 * n4) {
-    int ux = i & (n4 - 1), uy = i >> l4, k = base + uy * 16 + ux;
-    if (nz) s->L->cur_pm[k] |= RBT_PM_NZ;
-    int e = (ux == 0 ? RBT_EV_TU : 0) | (uy == 0 ? RBT_EH_TU : 0);
-    if (e) s->L->cur_edges[k] |= (uint8_t)e;
+RBT_DEV void pz_fill_tu(RbtParse* s, int x, int y, int N, int nz) {
+  PZ_TF0();
+  const int n4 = N >> 2, bx = (x - s->ctb_x) >> 2, by = (y - s->ctb_y) >> 2;
+  RBT_VFOR(p, 64) {
+    const uint32_t m = pz_sq_mask(p, bx, by, n4), ml = pz_left_mask(p, bx, m), mt = pz_top_mask(p, by, m);
+    if (nz) RBT_V(s->r_pm, p) |= PZ_REP4(RBT_PM_NZ) & m;
+    RBT_V(s->r_ed, p) |= (PZ_REP4(RBT_EV_TU) & ml) | (PZ_REP4(RBT_EH_TU) & mt);
   }
-  RBT_SYNC_LDS();
+  PZ_TF1();
 }
-// start of a CTB: nothing of it is decoded yet
+// prediction unit: motion, mode and PU edges of an arbitrary rectangle
+RBT_DEV void pz_fill_pu(RbtParse* s, int x, int y, int w, int h, int mode, int ref, uint32_t packed_mv) {
+  PZ_TF0();
+  const int bx = (x - s->ctb_x) >> 2, by = (y - s->ctb_y) >> 2, w4 = w >> 2, h4 = h >> 2;
+  RBT_VFOR(p, 64) {
+    const uint32_t m = pz_rect_mask(p, bx, by, w4, h4), ml = pz_left_mask(p, bx, m), mt = pz_top_mask(p, by, m);
+    RBT_V(s->r_pm, p) = (RBT_V(s->r_pm, p) & ~(PZ_REP4(RBT_PM_MODE_MASK) & m)) | (PZ_REP4(mode) & m);
+    RBT_V(s->r_ref, p) = (RBT_V(s->r_ref, p) & ~m) | (PZ_REP4(ref) & m);
+    if (m & 0x000000FFu) RBT_V(s->r_mv0, p) = packed_mv;
+    if (m & 0x0000FF00u) RBT_V(s->r_mv1, p) = packed_mv;
+    if (m & 0x00FF0000u) RBT_V(s->r_mv2, p) = packed_mv;
+    if (m & 0xFF000000u) RBT_V(s->r_mv3, p) = packed_mv;
+    RBT_V(s->r_ed, p) |= (PZ_REP4(RBT_EV_PU) & ml) | (PZ_REP4(RBT_EH_PU) & mt);
+  }
+  PZ_TF1();
+}
+// start of a CTB: nothing of it is decoded yet; fetch the surrounding units from the LDS line buffers
 RBT_DEV void pz_begin_ctb(RbtParse* s, int rx, int ry) {
-  s->ctb_x = rx << s->cfg.log2_ctb; s->ctb_y = ry << s->cfg.log2_ctb;
-  RBT_PAR_FOR(i, 256) { s->L->cur_pm[i] = RBT_MODE_NONE; s->L->cur_edges[i] = 0; s->L->cur_dm[i] = 1; s->L->cur_qp[i] = 0; s->L->cur_ref[i] = -1; s->L->cur_mv[i] = 0; }
-  RBT_SYNC_LDS();
+  const RbtStreamCfg* g = &s->cfg; RBT_LDS_AS RbtParseLds* L = s->L;
+  s->ctb_x = rx << g->log2_ctb; s->ctb_y = ry << g->log2_ctb;
+  const int cx4 = s->ctb_x >> 2;
+  RBT_VFOR(p, 64) {
+    RBT_V(s->r_pm, p) = PZ_REP4(RBT_MODE_NONE); RBT_V(s->r_dm, p) = PZ_REP4(1); RBT_V(s->r_ed, p) = 0; RBT_V(s->r_qp, p) = 0; RBT_V(s->r_ref, p) = 0xFFFFFFFFu;
+    RBT_V(s->r_mv0, p) = 0; RBT_V(s->r_mv1, p) = 0; RBT_V(s->r_mv2, p) = 0; RBT_V(s->r_mv3, p) = 0;
+    uint32_t pm = RBT_MODE_NONE, dm = 1, ref = 0xFF, mv = 0;
+    if (p == 0) { if (s->corner_ok) { pm = (uint32_t)s->corner_pm; dm = (uint32_t)s->corner_dm; ref = (uint32_t)s->corner_ref & 255u; mv = (uint32_t)s->corner_mv; } }
+    else if (p <= 17) {
+      const int xa4 = cx4 - 1 + p;
+      if (ry > 0 && xa4 < g->w4 && L->above_slice[(xa4 << 2) >> g->log2_ctb] == s->slice_idx) { pm = L->above_pm[xa4]; dm = L->above_dm[xa4]; ref = (uint8_t)L->above_ref[xa4]; mv = (uint32_t)L->above_mv[xa4]; }
+    } else if (p >= 32 && p < 48) {
+      if (s->left_ok) { pm = L->left_pm[p - 32]; dm = L->left_dm[p - 32]; ref = (uint8_t)L->left_ref[p - 32]; mv = (uint32_t)L->left_mv[p - 32]; }
+    }
+    RBT_V(s->n_pm, p) = pm; RBT_V(s->n_dm, p) = dm; RBT_V(s->n_ref, p) = ref; RBT_V(s->n_mv, p) = mv;
+  }
 }
-// end of a CTB: write its units to the HBM maps, then roll the line buffers
+// end of a CTB: spill its units to LDS, write them to the HBM maps, then roll the line buffers
 RBT_DEV void pz_end_ctb(RbtParse* s, int rx, int ry) {
   const RbtStreamCfg* g = &s->cfg; RBT_LDS_AS RbtParseLds* L = s->L;
   int cx = s->ctb_x, cy = s->ctb_y, ctb = 1 << g->log2_ctb, n4 = ctb >> 2;
+  RBT_VFOR(p, 64) {
+    const uint32_t pm = RBT_V(s->r_pm, p), dm = RBT_V(s->r_dm, p), ed = RBT_V(s->r_ed, p), qp = RBT_V(s->r_qp, p), rf = RBT_V(s->r_ref, p);
+    for (int j = 0; j < 4; j++) {
+      const int k = 4 * p + j;
+      L->cur_pm[k] = (uint8_t)(pm >> (8 * j)); L->cur_dm[k] = (uint8_t)(dm >> (8 * j)); L->cur_edges[k] = (uint8_t)(ed >> (8 * j));
+      L->cur_qp[k] = (int8_t)(qp >> (8 * j)); L->cur_ref[k] = (int8_t)(rf >> (8 * j));
+    }
+    L->cur_mv[4 * p] = (int32_t)RBT_V(s->r_mv0, p); L->cur_mv[4 * p + 1] = (int32_t)RBT_V(s->r_mv1, p); L->cur_mv[4 * p + 2] = (int32_t)RBT_V(s->r_mv2, p); L->cur_mv[4 * p + 3] = (int32_t)RBT_V(s->r_mv3, p);
+  }
   RBT_SYNC_LDS();
   RBT_PAR_FOR(u, n4 * n4) {
     int ux = u % n4, uy = u / n4, x = cx + ux * 4, y = cy + uy * 4;
@@ -171,6 +257,7 @@ RBT_DEV void pz_sao_to_lds(RBT_LDS_AS RbtSao* l, const RbtSao* d) {
 // ------------------------------------------------------------------------------------------------ SAO (7.3.8.3)
 RBT_DEV void pz_sao(RbtParse* s, int rx, int ry) {
   RbtCabacDec* c = &s->c; const RbtSliceU* sl = &s->sl;
+  pz_assert_uniform(s); rx = RBT_UNI(rx); ry = RBT_UNI(ry);
   RbtSao p; for (int i = 0; i < 3; i++) { p.type[i] = p.band_pos[i] = p.eo_class[i] = 0; for (int k = 0; k < 4; k++) p.offset[i][k] = 0; }
   p.pad[0] = p.pad[1] = p.pad[2] = 0;
   int wc = s->cfg.w_ctb;
@@ -231,8 +318,8 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
   while (px < maxp && rbt_cd_bin_last(c, ctx_off + (px >> ctx_shift))) px++;
   while (py < maxp && rbt_cd_bin_last(c, 18 + ctx_off + (py >> ctx_shift))) py++;
   int lx = px, ly = py;
-  if (px > 3) { int nb = (px >> 1) - 1; lx = (1 << nb) * (2 + (px & 1)) + (int)rbt_cd_bypass_n(c, nb); }
-  if (py > 3) { int nb = (py >> 1) - 1; ly = (1 << nb) * (2 + (py & 1)) + (int)rbt_cd_bypass_n(c, nb); }
+  if (px > 3) { int nb = (px >> 1) - 1; lx = (1 << nb) * (2 + (px & 1)) + (int)rbt_cd_bypass_n<false>(c, nb); }
+  if (py > 3) { int nb = (py >> 1) - 1; ly = (1 << nb) * (2 + (py & 1)) + (int)rbt_cd_bypass_n<false>(c, nb); }
   if (scan_idx == 2) { int t = lx; lx = ly; ly = t; }
 #ifdef RBT_PROFILE
   unsigned long long ta_ = __builtin_readcyclecounter(); s->t_a += ta_ - t0_;
@@ -312,14 +399,14 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
       RBT_V(v_k, p) = k; RBT_V(v_a, p) = a; RBT_V(v_rem, p) = 0;
     }
     RBT_VBALLOT(need64, p, 16, ((sig_mask >> p) & 1) && RBT_V(v_a, p) == (RBT_V(v_k, p) < 8 ? (RBT_V(v_k, p) == first_g1 ? 3 : 2) : 1));
-    const uint32_t signs = rbt_cd_bypass_n(c, nsign);     // sign of decode-order index k = bit nsign-1-k
+    const uint32_t signs = rbt_cd_bypass_n<false>(c, nsign);     // sign of decode-order index k = bit nsign-1-k
     { uint32_t m = (uint32_t)need64; int rice = 0;
       while (m) {
         const int n = 31 - __builtin_clz(m); m &= ~(1u << n);
-        int pre = 0; while (pre < 32 && rbt_cd_bypass(c)) pre++;
+        int pre = 0; while (pre < 32 && rbt_cd_bypass<false>(c)) pre++;
         int v;
-        if (pre <= 3) v = (pre << rice) + (int)rbt_cd_bypass_n(c, rice);
-        else { int sl = pre - 3 + rice; if (sl > 30) { err = 4; sl = 30; } v = (int)((((1u << (pre - 3)) + 3u - 1u) << rice) + rbt_cd_bypass_n(c, sl)); }   // no early exit: keeps the loop single-exit
+        if (pre <= 3) v = (pre << rice) + (int)rbt_cd_bypass_n<false>(c, rice);
+        else { int sl = pre - 3 + rice; if (sl > 30) { err = 4; sl = 30; } v = (int)((((1u << (pre - 3)) + 3u - 1u) << rice) + rbt_cd_bypass_n<false>(c, sl)); }   // no early exit: keeps the loop single-exit
         const int k = __builtin_popcount(sig_mask >> (n + 1)), a = (k < 8 ? (k == first_g1 ? 3 : 2) : 1) + v;
         if (a > 3 * (1 << rice)) rice = rbt_min(rice + 1, 4);
         RBT_VSET(v_rem, n, v);
@@ -354,8 +441,8 @@ RBT_DEV void pz_start_qg(RbtParse* s, int xqg, int yqg) {
   int ctb_mask = ~((1 << s->cfg.log2_ctb) - 1);
   s->qp_y_prev = s->qp_y; s->is_cu_qp_delta_coded = 0; s->cu_qp_delta_val = 0;
   int qa = s->qp_y_prev, qb = s->qp_y_prev;
-  if (xqg > 0 && ((xqg - 1) & ctb_mask) == (xqg & ctb_mask) && pz_avail(s, xqg - 1, yqg)) qa = s->L->cur_qp[pz_cur(s, xqg - 1, yqg)];
-  if (yqg > 0 && ((yqg - 1) & ctb_mask) == (yqg & ctb_mask) && pz_avail(s, xqg, yqg - 1)) qb = s->L->cur_qp[pz_cur(s, xqg, yqg - 1)];
+  if (xqg > 0 && ((xqg - 1) & ctb_mask) == (xqg & ctb_mask) && pz_avail(s, xqg - 1, yqg)) qa = (int8_t)PZ_RD8(s->r_qp, pz_cur(s, xqg - 1, yqg));
+  if (yqg > 0 && ((yqg - 1) & ctb_mask) == (yqg & ctb_mask) && pz_avail(s, xqg, yqg - 1)) qb = (int8_t)PZ_RD8(s->r_qp, pz_cur(s, xqg, yqg - 1));
   s->qp_pred = (qa + qb + 1) >> 1;
 }
 RBT_DEV int pz_chroma_qp(const RbtParse* s, int c_idx) {
@@ -378,6 +465,8 @@ RBT_DEV void pz_transform_unit(RbtParse* s, int x0, int y0, int xb, int yb, int 
 #ifdef RBT_PROFILE
   unsigned long long ttu_ = __builtin_readcyclecounter();
 #endif
+  pz_assert_uniform(s);
+  x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); xb = RBT_UNI(xb); yb = RBT_UNI(yb); log2 = RBT_UNI(log2); blk = RBT_UNI(blk); cbf_luma = RBT_UNI(cbf_luma); cbf_cb = RBT_UNI(cbf_cb); cbf_cr = RBT_UNI(cbf_cr);
   int N = 1 << log2;
   if ((cbf_luma || cbf_cb || cbf_cr) && s->cfg.cu_qp_delta && !s->is_cu_qp_delta_coded) {
     int v = 0; while (v < 5 && rbt_cd_bin(c, CTX_CU_QP_DELTA + (v ? 1 : 0))) v++;
@@ -422,6 +511,8 @@ RBT_DEV void pz_transform_tree(RbtParse* s, int x0, int y0, int xb0, int yb0, in
   const int intra = s->cu_pred_mode == RBT_MODE_INTRA;
   const int intra_split = intra && s->cu_part_mode == RBT_PART_NxN;
   while (!s->error) {
+    pz_assert_uniform(s);
+    lvl = RBT_UNI(lvl); x = RBT_UNI(x); y = RBT_UNI(y); lg = RBT_UNI(lg); states = (uint32_t)RBT_UNI(states); flags = (uint32_t)RBT_UNI(flags);
     int st = (int)((states >> (4 * lvl)) & 15u);
     if (st == 15) {
       int inter_split = s->cfg.th_depth_inter == 0 && !intra && s->cu_part_mode != RBT_PART_2Nx2N && lvl == 0;
@@ -554,6 +645,8 @@ RBT_DEV int pz_mvd_comp(RbtCabacDec* c, int gt0, int gt1) {
 }
 RBT_DEV void pz_prediction_unit(RbtParse* s, int x0, int y0, int w, int h, int part_idx, int skip) {
   RbtCabacDec* c = &s->c; const RbtSliceU* sl = &s->sl;
+  pz_assert_uniform(s);
+  x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); w = RBT_UNI(w); h = RBT_UNI(h); part_idx = RBT_UNI(part_idx); skip = RBT_UNI(skip);
   RbtMv mv;
   int merge = skip ? 1 : rbt_cd_bin(c, CTX_MERGE_FLAG);
   s->last_pu_merge = merge;
@@ -575,16 +668,7 @@ RBT_DEV void pz_prediction_unit(RbtParse* s, int x0, int y0, int w, int h, int p
     mv.x = (int16_t)(mv.x + dx); mv.y = (int16_t)(mv.y + dy);
   }
   if (mv.ref < 0 || mv.ref >= sl->num_ref_idx) { s->error = 5; return; }
-  int w4 = w >> 2, n = w4 * (h >> 2), base = pz_cur(s, x0, y0);
-  int mode = skip ? RBT_MODE_SKIP : RBT_MODE_INTER, packed = (int)(((uint32_t)(uint16_t)mv.y << 16) | (uint16_t)mv.x);
-  RBT_PAR_FOR(i, n) {
-    int ux = i % w4, uy = i / w4, k = base + uy * 16 + ux;   // PU widths may be 3 or 12 units (AMP): general division, once per PU
-    s->L->cur_mv[k] = packed; s->L->cur_ref[k] = (int8_t)mv.ref;
-    s->L->cur_pm[k] = (uint8_t)((s->L->cur_pm[k] & ~RBT_PM_MODE_MASK) | mode);
-    int e = (ux == 0 ? RBT_EV_PU : 0) | (uy == 0 ? RBT_EH_PU : 0);
-    if (e) s->L->cur_edges[k] |= (uint8_t)e;
-  }
-  RBT_SYNC_LDS();
+  pz_fill_pu(s, x0, y0, w, h, skip ? RBT_MODE_SKIP : RBT_MODE_INTER, mv.ref, ((uint32_t)(uint16_t)mv.y << 16) | (uint16_t)mv.x);
   RbtCmd cmd; cmd.type = RBT_CMD_PU; cmd.x4 = (uint8_t)((x0 & ((1 << s->cfg.log2_ctb) - 1)) >> 2); cmd.y4 = (uint8_t)((y0 & ((1 << s->cfg.log2_ctb) - 1)) >> 2);
   cmd.log2 = 0; cmd.a = (uint8_t)(w >> 2); cmd.b = (uint8_t)(h >> 2); cmd.c = (uint8_t)mv.ref; cmd.d = 0; cmd.mvx = (int16_t)mv.x; cmd.mvy = (int16_t)mv.y;
   cmd.qp[0] = cmd.qp[1] = cmd.qp[2] = 0; cmd.pad = 0;
@@ -607,6 +691,8 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
 #ifdef RBT_PROFILE
   unsigned long long tcu_ = __builtin_readcyclecounter(); s->n_cu++;
 #endif
+  pz_assert_uniform(s);
+  x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); log2 = RBT_UNI(log2); depth = RBT_UNI(depth);
   int N = 1 << log2;
   s->cu_x = x0; s->cu_y = y0; s->cu_log2 = log2; s->cu_tq_bypass = 0; s->cu_part_mode = RBT_PART_2Nx2N; s->cu_pred_mode = RBT_MODE_INTRA;
   if (cfg->cu_qp_delta) s->qp_y = pz_wrap_qp(s, s->qp_pred + s->cu_qp_delta_val);
@@ -655,7 +741,13 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
     }
     for (int i = 0; i < np; i++) {
       int xp = x0 + (i & 1) * pb, yp = y0 + (i >> 1) * pb;
+#ifdef RBT_PROFILE
+      unsigned long long tm_ = __builtin_readcyclecounter();
+#endif
       int cand[3]; pz_intra_mpm(s, xp, yp, cand);
+#ifdef RBT_PROFILE
+      s->t_mpm += __builtin_readcyclecounter() - tm_;
+#endif
       int mode;
       if (prev[i]) mode = mpm_idx[i] == 0 ? cand[0] : (mpm_idx[i] == 1 ? cand[1] : cand[2]);
       else {
@@ -699,6 +791,11 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
 #ifdef RBT_PROFILE
   s->t_hdr += __builtin_readcyclecounter() - tcu_;
 #endif
+#ifdef RBT_PROFILE
+#define PZ_CU_END() (s->t_cu += __builtin_readcyclecounter() - tcu_)
+#else
+#define PZ_CU_END() ((void)0)
+#endif
   int rqt_root_cbf = 1;
   if (s->cu_pred_mode != RBT_MODE_INTRA && !(s->cu_part_mode == RBT_PART_2Nx2N && s->last_pu_merge)) rqt_root_cbf = rbt_cd_bin(c, CTX_RQT_ROOT_CBF);
   if (rqt_root_cbf) {
@@ -706,6 +803,7 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
     pz_transform_tree(s, x0, y0, x0, y0, log2, 0, 0, 0, 0);
   }
   RBT_SYNC_LDS();
+  PZ_CU_END();
 }
 
 // ------------------------------------------------------------------------------------------------ coding quadtree + slice data
@@ -715,6 +813,8 @@ RBT_DEV void pz_coding_quadtree(RbtParse* s, int x0, int y0, int log2) {
   int lvl = 0, x = x0, y = y0, lg = log2;
   uint32_t states = 15u;
   while (!s->error) {
+    pz_assert_uniform(s);
+    lvl = RBT_UNI(lvl); x = RBT_UNI(x); y = RBT_UNI(y); lg = RBT_UNI(lg); states = (uint32_t)RBT_UNI(states);
     int st = (int)((states >> (4 * lvl)) & 15u);
     int N = 1 << lg;
     if (st == 15) {
@@ -773,7 +873,7 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
   const RbtSliceU* sl = &s.sl;
   int init_type = sl->slice_type == RBT_SLICE_I ? 0 : (sl->cabac_init_flag ? 2 : 1);
 #ifdef RBT_PROFILE
-  unsigned long long t_all_ = __builtin_readcyclecounter(); s.t_res = s.t_ctb = s.t_cu = s.t_a = s.t_b = s.t_c = s.t_d = s.t_tu = s.t_hdr = s.t_fill = 0; s.n_res = s.n_cu = 0; s.c.n_bins = s.c.n_byp = 0;
+  unsigned long long t_all_ = __builtin_readcyclecounter(); s.t_res = s.t_ctb = s.t_cu = s.t_a = s.t_b = s.t_c = s.t_d = s.t_tu = s.t_hdr = s.t_fill = s.t_mpm = 0; s.n_res = s.n_cu = 0; s.c.n_bins = s.c.n_byp = 0;
 #endif
   rbt_ctx_init(&s.c.cs, init_type, sl->qp);
   rbt_cd_start(&s.c, rbsp + (uint32_t)RBT_UNI(gs->data_off), (uint32_t)RBT_UNI(gs->data_size));
@@ -783,7 +883,8 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
   uint32_t count = 0;
   while (!end) {
     if (addr >= n_ctb) { s.error = 1; break; }
-    int rx = addr % s.cfg.w_ctb, ry = addr / s.cfg.w_ctb;
+    pz_assert_uniform(&s); addr = RBT_UNI(addr);
+    int rx = RBT_UNI(addr % s.cfg.w_ctb), ry = RBT_UNI(addr / s.cfg.w_ctb);
     if (RBT_LANE0) s.m_cs[addr] = (uint16_t)slice_idx;
     s.ctb_addr = addr; s.n_cmds = 0;
     if (rx == 0) { s.left_ok = 0; s.corner_ok = 0; }
@@ -811,7 +912,7 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
     RBT_SYNC_LDS();
   }
 #ifdef RBT_PROFILE
-  if (RBT_LANE0) printf("slice %d: total %llu cyc, residual %llu (%u TBs) [setup+last %llu, csbf+sig %llu, gt1/2 %llu, levels %llu], TU total (incl. residual) %llu, CU header %llu (%u CUs), ctb begin/end %llu, bins ctx %u bypass %u, bits %u\n", slice_idx, __builtin_readcyclecounter() - t_all_, s.t_res, s.n_res, s.t_a, s.t_b, s.t_c, s.t_d, s.t_tu, s.t_hdr, s.n_cu, s.t_ctb, s.c.n_bins, s.c.n_byp, s.c.widx * 32u - (uint32_t)s.c.nbuf);
+  if (RBT_LANE0) printf("slice %d: total %llu cyc, residual %llu (%u TBs) [setup+last %llu, csbf+sig %llu, gt1/2 %llu, levels %llu], TU total (incl. residual) %llu, CU header %llu (%u CUs), ctb begin/end %llu, CU total %llu, fills %llu, mpm %llu, bins ctx %u bypass %u, bits %u\n", slice_idx, __builtin_readcyclecounter() - t_all_, s.t_res, s.n_res, s.t_a, s.t_b, s.t_c, s.t_d, s.t_tu, s.t_hdr, s.n_cu, s.t_ctb, s.t_cu, s.t_fill, s.t_mpm, s.c.n_bins, s.c.n_byp, s.c.widx * 32u - (uint32_t)s.c.nbuf);
 #endif
   if (RBT_LANE0) { slices[slice_idx].n_ctbs_decoded = count; if (s.error) s.f->error = s.error; }
 }

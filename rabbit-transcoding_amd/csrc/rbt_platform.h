@@ -20,6 +20,7 @@
 #define RBT_LANE0 1
 #define RBT_NTHREADS 1
 #define RBT_LDS_AS
+#define RBT_CONST_AS
 #define RBT_LDS_CAST(T, p) (p)
 #define RBT_UNI(x) (x)
 // Per-lane ("vector") values inside wave-uniform code: on the GPU one register whose lane p holds element p; in host
@@ -55,6 +56,11 @@ static __device__ __forceinline__ int rbt_writelane(int old, int v, int lane) { 
 // register that underflows the LDS aperture (object at LDS offset 0, negative partial index) is treated as a global
 // address and faults with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.
 #define RBT_LDS_AS __attribute__((address_space(3)))
+// Read-only kernel inputs that are addressed wave-uniformly (the slice data) are read through the constant address space:
+// the loads become scalar (s_load_dword, counted by lgkmcnt) instead of flat vector loads. Vector loads share vmcnt with
+// the stores on gfx9-family parts, so waiting for one loaded word also waits for every store still in flight - each wait
+// then costs a full store round trip to HBM.
+#define RBT_CONST_AS __attribute__((address_space(4)))
 #define RBT_LDS_CAST(T, p) ((RBT_LDS_AS T*)(uintptr_t)(p))
 // Marks a value as wave-uniform so the compiler keeps it in SGPRs / issues it on the scalar unit. Only for values that
 // ARE uniform by construction (the entropy kernels run every lane of the wave on identical data).
