@@ -122,13 +122,13 @@ RBT_DEV void en_fwd_transform(int log2, int is_dst, int bd, RBT_LDS_AS RbtReconL
   int N = 1 << log2, s1 = log2 + bd - 9, s2 = log2 + 6;
   RBT_PAR_FOR(i, N * N) {
     int k = i & (N - 1), y = i >> log2, s = 0;
-    for (int x = 0; x < N; x++) s += rc_tcoef(N, is_dst, k, x) * r->res[y * N + x];
+    for (int x = 0; x < N; x++) s += rc_tcoef(r, N, is_dst, k, x) * r->res[y * N + x];
     r->tmp[i] = s1 > 0 ? (s + (1 << (s1 - 1))) >> s1 : s;
   }
   RBT_SYNC_LDS();
   RBT_PAR_FOR(i, N * N) {
     int kh = i & (N - 1), kv = i >> log2, s = 0;
-    for (int y = 0; y < N; y++) s += rc_tcoef(N, is_dst, kv, y) * r->tmp[y * N + kh];
+    for (int y = 0; y < N; y++) s += rc_tcoef(r, N, is_dst, kv, y) * r->tmp[y * N + kh];
     r->res[i] = (int16_t)rbt_clip3(-32768, 32767, (s + (1 << (s2 - 1))) >> s2);
   }
   RBT_SYNC_LDS();

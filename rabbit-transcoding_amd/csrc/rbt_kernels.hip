@@ -50,14 +50,14 @@ __global__ void __launch_bounds__(64) k_parse(RbtFrame* frames, RbtSlice* slices
 }
 // one wave per CTB on anti-diagonal d (x + 2y == d): left, above-left, above and above-right CTBs are complete
 __global__ void __launch_bounds__(64) k_recon_diag(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int d) {
-  __shared__ RbtReconLds lds;
+  __shared__ RbtReconCtbLds lds;
   int fi = frame_list[blockIdx.y];
   const RbtStreamCfg* g = &frames[fi].cfg;
   int y = blockIdx.x, x = d - 2 * y;
   if (y >= g->h_ctb || x < 0 || x >= g->w_ctb) return;
   int addr = y * g->w_ctb + x;
   if (frames[fi].ctb_slice[addr] == 0xFFFF) return;     // CTB not covered by any decoded slice
-  rbt_recon_ctb(frames, slices, fi, addr, RBT_LDS_CAST(RbtReconLds, &lds));
+  rbt_recon_ctb(frames, slices, fi, addr, RBT_LDS_CAST(RbtReconCtbLds, &lds));
 }
 __global__ void __launch_bounds__(256) k_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int dir) {
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
@@ -112,6 +112,7 @@ __global__ void __launch_bounds__(64) k_enc_intra_rows(RbtFrame* frames, const R
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   int row = blockIdx.x;
   if (row >= f->cfg.h_ctb) return;
+  rc_stage_tables(&RBT_LDS_CAST(RbtEncLds, &lds)->rc);
   for (int x = 0; x < f->cfg.w_ctb; x++) en_intra_ctb(f, slices, row * f->cfg.w_ctb + x, RBT_LDS_CAST(RbtEncLds, &lds));
 }
 __global__ void __launch_bounds__(64) k_enc_intra_diag(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int d) {
@@ -119,12 +120,14 @@ __global__ void __launch_bounds__(64) k_enc_intra_diag(RbtFrame* frames, const R
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   int y = blockIdx.x, x = d - 2 * y;
   if (y >= f->cfg.h_ctb || x < 0 || x >= f->cfg.w_ctb) return;
+  rc_stage_tables(&RBT_LDS_CAST(RbtEncLds, &lds)->rc);
   en_intra_ctb(f, slices, y * f->cfg.w_ctb + x, RBT_LDS_CAST(RbtEncLds, &lds));
 }
 __global__ void __launch_bounds__(64) k_enc_inter(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
   __shared__ RbtEncLds lds;
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   if ((int)blockIdx.x >= f->cfg.w_ctb * f->cfg.h_ctb) return;
+  rc_stage_tables(&RBT_LDS_CAST(RbtEncLds, &lds)->rc);
   en_inter_ctb(frames, f, slices, blockIdx.x, RBT_LDS_CAST(RbtEncLds, &lds));
 }
 __global__ void __launch_bounds__(64) k_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list) {

@@ -15,7 +15,13 @@ struct RbtReconLds {
   int16_t res[32 * 32];   // dequantised coefficients, then residual
   int32_t tmp[32 * 32];   // first transform stage
   uint16_t pred[32 * 32];
+  int8_t dct[32 * 32]; int8_t dst[16];   // transform matrices, staged once per workgroup (rc_stage_tables)
 };
+RBT_DEV void rc_stage_tables(RBT_LDS_AS RbtReconLds* l) {
+  RBT_PAR_FOR(i, 1024) l->dct[i] = k_dct32[i >> 5][i & 31];
+  RBT_PAR_FOR(i, 16) l->dst[i] = k_dst4[i >> 2][i & 3];
+  RBT_SYNC_LDS();
+}
 
 RBT_DEV int rc_morton(int x4, int y4) {
   int z = 0;
@@ -35,12 +41,16 @@ RBT_DEV int rc_avail(const RbtFrame* f, int xc, int yc, int xn, int yn) {
   if (g->cip && (f->pm[(yn >> 2) * g->w4 + (xn >> 2)] & RBT_PM_MODE_MASK) != RBT_MODE_INTRA) return 0;
   return 1;
 }
-RBT_DEV int rc_tcoef(int N, int is_dst, int k, int n) { return is_dst ? k_dst4[k][n] : k_dct32[k * (32 / N)][n]; }
+RBT_DEV int rc_tcoef(const RBT_LDS_AS RbtReconLds* l, int N, int is_dst, int k, int n) { return is_dst ? l->dst[k * 4 + n] : l->dct[k * (32 / N) * 32 + n]; }
 
-// ---- intra prediction of one TB into lds->pred (8.4.4.2). `src` is the plane neighbours are read from. ----
+// ---- intra prediction of one TB into lds->pred (8.4.4.2) ----
+// Step 1 (two variants): gather the 4N+1 neighbour samples and their availability into l->nb / l->av.
+// Step 2 (rc_intra_finish): substitution, smoothing filter and the prediction itself, all in LDS.
+RBT_DEV void rc_intra_finish(const RbtStreamCfg* g, int c_idx, int log2, int mode, RBT_LDS_AS RbtReconLds* l);
+// variant A: neighbours from a picture plane in HBM (`src`), availability from the picture's maps
 RBT_DEV void rc_intra_pred(const RbtFrame* f, const uint16_t* src, int c_idx, int x0, int y0, int log2, int mode, RBT_LDS_AS RbtReconLds* l) {
   const RbtStreamCfg* g = &f->cfg;
-  int N = 1 << log2, sh = c_idx ? 1 : 0, pw = c_idx ? g->cw : g->w, bd = g->bit_depth, maxv = (1 << bd) - 1;
+  int N = 1 << log2, sh = c_idx ? 1 : 0, pw = c_idx ? g->cw : g->w;
   int xcL = x0 << sh, ycL = y0 << sh, tot = 4 * N + 1;
   RBT_PAR_FOR(i, tot) {
     int xn, yn;
@@ -52,24 +62,34 @@ RBT_DEV void rc_intra_pred(const RbtFrame* f, const uint16_t* src, int c_idx, in
     l->nb[i] = a ? src[(size_t)yn * pw + xn] : 0;
   }
   RBT_SYNC_LDS();
-  // substitution (8.4.4.2.2): uniform serial scan
+  rc_intra_finish(g, c_idx, log2, mode, l);
+}
+// index of the nearest available neighbour at or below i (-1: none), from the availability masks of indices 0..63, 64..127, 128
+RBT_DEV int rc_last_avail(int i, uint64_t m0, uint64_t m1, int m2) {
+  if (i >= 128) { if (m2) return 128; i = 127; }
+  if (i >= 64) { uint64_t t = m1 & (~0ull >> (127 - i)); if (t) return 127 - __builtin_clzll(t); i = 63; }
+  uint64_t t = m0 & (~0ull >> (63 - i));
+  return t ? 63 - __builtin_clzll(t) : -1;
+}
+RBT_DEV void rc_intra_finish(const RbtStreamCfg* g, int c_idx, int log2, int mode, RBT_LDS_AS RbtReconLds* l) {
+  int N = 1 << log2, bd = g->bit_depth, maxv = (1 << bd) - 1, tot = 4 * N + 1;
+  RBT_LDS_AS int32_t* nb = l->nb; RBT_LDS_AS int32_t* alt = l->nbf;      // current / scratch neighbour arrays (swapped, not copied)
+  // substitution (8.4.4.2.2): availability as bit masks, every lane finds its source with bit operations
   {
-    int first = -1;
-    for (int i = 0; i < tot; i++) if (l->av[i]) { first = i; break; }
-    if (first < 0) { RBT_PAR_FOR(i, tot) l->nb[i] = 1 << (bd - 1); }
-    else {
-      RBT_PAR_FOR(i, tot) {
-        if (!l->av[i]) {
-          int j = i; while (j >= 0 && !l->av[j]) j--;
-          // unavailable samples before the first available one take its value; later ones copy the nearest below
-          l->nbf[i] = j >= 0 ? l->nb[j] : l->nb[first];
-        } else l->nbf[i] = l->nb[i];
-      }
+    uint64_t m0, m1 = 0; int m2 = 0;
+    RBT_VBALLOT(m0, p, rbt_min(tot, 64), l->av[p]);
+    if (tot > 64) { RBT_VBALLOT(m1, p, rbt_min(tot - 64, 64), l->av[64 + p]); }
+    if (tot > 128) m2 = l->av[128];
+    const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : (m2 ? 128 : -1));
+    const int all = __builtin_popcountll(m0) + __builtin_popcountll(m1) + m2 == tot;
+    if (first < 0) { RBT_PAR_FOR(i, tot) nb[i] = 1 << (bd - 1); RBT_SYNC_LDS(); }
+    else if (!all) {
+      // unavailable samples before the first available one take its value; later ones copy the nearest below
+      RBT_PAR_FOR(i, tot) { int j = rc_last_avail(i, m0, m1, m2); alt[i] = nb[j >= 0 ? j : first]; }
       RBT_SYNC_LDS();
-      RBT_PAR_FOR(i, tot) l->nb[i] = l->nbf[i];
+      RBT_LDS_AS int32_t* t = nb; nb = alt; alt = t;
     }
   }
-  RBT_SYNC_LDS();
   int filt = 0;
   if (c_idx == 0 && mode != 1 && N != 4) {
     int md = rbt_min(rbt_abs(mode - 26), rbt_abs(mode - 10));
@@ -77,33 +97,33 @@ RBT_DEV void rc_intra_pred(const RbtFrame* f, const uint16_t* src, int c_idx, in
     filt = md > thr;
   }
   if (filt) {
-    int corner = l->nb[2 * N], bl = l->nb[0], tr = l->nb[4 * N];
-    int strong = g->strong_intra && N == 32 && rbt_abs(corner + tr - 2 * l->nb[2 * N + 32]) < (1 << (bd - 5)) &&
-                 rbt_abs(corner + bl - 2 * l->nb[2 * N - 32]) < (1 << (bd - 5));
+    int corner = nb[2 * N], bl = nb[0], tr = nb[4 * N];
+    int strong = g->strong_intra && N == 32 && rbt_abs(corner + tr - 2 * nb[2 * N + 32]) < (1 << (bd - 5)) &&
+                 rbt_abs(corner + bl - 2 * nb[2 * N - 32]) < (1 << (bd - 5));
     RBT_PAR_FOR(i, tot) {
       int v;
-      if (i == 0 || i == 4 * N) v = l->nb[i];
+      if (i == 0 || i == 4 * N) v = nb[i];
       else if (strong) {
         if (i == 2 * N) v = corner;
         else if (i < 2 * N) { int k = 2 * N - 1 - i; v = ((63 - k) * corner + (k + 1) * bl + 32) >> 6; }
         else { int k = i - 2 * N - 1; v = ((63 - k) * corner + (k + 1) * tr + 32) >> 6; }
-      } else v = (l->nb[i - 1] + 2 * l->nb[i] + l->nb[i + 1] + 2) >> 2;
-      l->nbf[i] = v;
+      } else v = (nb[i - 1] + 2 * nb[i] + nb[i + 1] + 2) >> 2;
+      alt[i] = v;
     }
     RBT_SYNC_LDS();
-    RBT_PAR_FOR(i, tot) l->nb[i] = l->nbf[i];
-    RBT_SYNC_LDS();
+    RBT_LDS_AS int32_t* t = nb; nb = alt; alt = t;
   }
-#define RC_LEFT(y) l->nb[2 * N - 1 - (y)]
-#define RC_TOP(x) l->nb[2 * N + 1 + (x)]
+#define RC_LEFT(y) nb[2 * N - 1 - (y)]
+#define RC_TOP(x) nb[2 * N + 1 + (x)]
   if (mode == 0) {
     RBT_PAR_FOR(i, N * N) {
       int x = i & (N - 1), y = i >> log2;
       l->pred[i] = (uint16_t)(((N - 1 - x) * RC_LEFT(y) + (x + 1) * RC_TOP(N) + (N - 1 - y) * RC_TOP(x) + (y + 1) * RC_LEFT(N) + N) >> (log2 + 1));
     }
   } else if (mode == 1) {
+    // sum of the 2N neighbours (lanes 0..N-1 hold the top row, N..2N-1 the left column), one ballot per bit plane
     int sum = N;
-    for (int i = 0; i < N; i++) sum += RC_TOP(i) + RC_LEFT(i);
+    for (int b = 0; b < bd; b++) { uint64_t m; RBT_VBALLOT(m, p, 2 * N, ((p < N ? RC_TOP(p) : RC_LEFT(p - N)) >> b) & 1); sum += __builtin_popcountll(m) << b; }
     int dc = sum >> (log2 + 1);
     int edge = c_idx == 0 && N < 32;
     RBT_PAR_FOR(i, N * N) {
@@ -147,7 +167,7 @@ RBT_DEV void rc_intra_pred(const RbtFrame* f, const uint16_t* src, int c_idx, in
 }
 
 // ---- scaling (8.6.3, flat lists) of the TB's levels from the coefficient plane into lds->res ----
-RBT_DEV void rc_dequant(const int16_t* plane, int pst, int x0, int y0, int log2, int qp, int bd, RBT_LDS_AS RbtReconLds* l) {
+template <class CP> RBT_DEV void rc_dequant(CP plane, int pst, int x0, int y0, int log2, int qp, int bd, RBT_LDS_AS RbtReconLds* l) {
   int N = 1 << log2, bd_shift = bd + log2 - 5;
   int scale = (16 * k_dequant_scale[qp % 6]) << (qp / 6);
   long long add = 1ll << (bd_shift - 1);
@@ -168,46 +188,22 @@ RBT_DEV void rc_inv_transform(int log2, int is_dst, int ts, int bd, RBT_LDS_AS R
   }
   RBT_PAR_FOR(i, N * N) {
     int x = i & (N - 1), y = i >> log2, s = 0;
-    for (int k = 0; k < N; k++) s += rc_tcoef(N, is_dst, k, y) * l->res[k * N + x];
+    for (int k = 0; k < N; k++) s += rc_tcoef(l, N, is_dst, k, y) * l->res[k * N + x];
     l->tmp[i] = rbt_clip3(-32768, 32767, (s + 64) >> 7);
   }
   RBT_SYNC_LDS();
   RBT_PAR_FOR(i, N * N) {
     int x = i & (N - 1), y = i >> log2, s = 0;
-    for (int k = 0; k < N; k++) s += rc_tcoef(N, is_dst, k, x) * l->tmp[y * N + k];
+    for (int k = 0; k < N; k++) s += rc_tcoef(l, N, is_dst, k, x) * l->tmp[y * N + k];
     l->res[i] = (int16_t)((s + (1 << (sh - 1))) >> sh);
   }
   RBT_SYNC_LDS();
 }
 
-// ---- one TB of the decoder: prediction (intra) + residual, written to f->pix ----
-RBT_DEV void rc_decode_tb(RbtFrame* f, int c_idx, int x0, int y0, int log2, int intra, int mode, int cbf, int ts, int tq_bypass, int qp, RBT_LDS_AS RbtReconLds* l) {
-  const RbtStreamCfg* g = &f->cfg;
-  int N = 1 << log2, pw = c_idx ? g->cw : g->w, bd = g->bit_depth, maxv = (1 << bd) - 1;
-  uint16_t* p = f->pix[c_idx];
-  if (intra) rc_intra_pred(f, p, c_idx, x0, y0, log2, mode, l);
-  if (cbf) {
-    if (tq_bypass) {
-      RBT_PAR_FOR(i, N * N) { int x = i & (N - 1), y = i >> log2; l->res[i] = f->coef[c_idx][(size_t)(y0 + y) * pw + x0 + x]; }
-      RBT_SYNC_LDS();
-    } else {
-      rc_dequant(f->coef[c_idx], pw, x0, y0, log2, qp, bd, l);
-      rc_inv_transform(log2, c_idx == 0 && log2 == 2 && intra, ts, bd, l);
-    }
-  }
-  if (!intra && !cbf) return;
-  RBT_PAR_FOR(i, N * N) {
-    int x = i & (N - 1), y = i >> log2;
-    size_t o = (size_t)(y0 + y) * pw + x0 + x;
-    int base = intra ? l->pred[i] : p[o];
-    p[o] = (uint16_t)(cbf ? rbt_clip3(0, maxv, base + l->res[i]) : base);
-  }
-  RBT_SYNC();   // the next TB reads these samples from HBM/L2 as neighbours
-}
-
 // ---- uni-directional motion compensation of one PU (8.5.3.3) from ref->out into f->pix ----
 RBT_DEV int rc_refpix(const uint16_t* p, int w, int h, int x, int y) { return p[(size_t)rbt_clip3(0, h - 1, y) * w + rbt_clip3(0, w - 1, x)]; }
-RBT_DEV void rc_mc_plane(uint16_t* dst, const uint16_t* ref, int pw, int ph, int x0, int y0, int bw, int bh, int xint, int yint, int xf, int yf, int taps,
+// dst(x,y) = dst[(dy0 + y) * dstride + dx0 + x]: a picture plane in HBM or the CTB tile in LDS
+template <class DP> RBT_DEV void rc_mc_plane(DP dst, int dstride, int dx0, int dy0, const uint16_t* ref, int pw, int ph, int x0, int y0, int bw, int bh, int xint, int yint, int xf, int yf, int taps,
                          const int8_t* fx, const int8_t* fy, int bd) {
   int sh1 = rbt_min(4, bd - 8), sh3 = 14 - bd, half = taps / 2 - 1, maxv = (1 << bd) - 1;
   int fsh = 14 - bd, fadd = fsh ? 1 << (fsh - 1) : 0;
@@ -225,39 +221,126 @@ RBT_DEV void rc_mc_plane(uint16_t* dst, const uint16_t* ref, int pw, int ph, int
       }
       v = s >> 6;
     }
-    dst[(size_t)(y0 + y) * pw + x0 + x] = (uint16_t)rbt_clip3(0, maxv, (v + fadd) >> fsh);
+    dst[(dy0 + y) * dstride + dx0 + x] = (uint16_t)rbt_clip3(0, maxv, (v + fadd) >> fsh);
   }
 }
-RBT_DEV void rc_inter_pu(RbtFrame* f, const RbtFrame* ref, int x0, int y0, int w, int h, int mvx, int mvy) {
-  const RbtStreamCfg* g = &f->cfg;
-  rc_mc_plane(f->pix[0], ref->out[0], g->w, g->h, x0, y0, w, h, mvx >> 2, mvy >> 2, mvx & 3, mvy & 3, 8, k_luma_filter[mvx & 3], k_luma_filter[mvy & 3], g->bit_depth);
-  for (int c = 1; c < 3; c++)
-    rc_mc_plane(f->pix[c], ref->out[c], g->cw, g->ch, x0 >> 1, y0 >> 1, w >> 1, h >> 1, mvx >> 3, mvy >> 3, mvx & 7, mvy & 7, 4, k_chroma_filter[mvx & 7], k_chroma_filter[mvy & 7], g->bit_depth);
-  RBT_SYNC();
-}
+// ---- decoder: one CTB reconstructed inside LDS ----------------------------------------------------------------------
+// The TBs of a CTB form a serial chain (intra prediction reads the samples the previous TB wrote). Through HBM every link
+// of that chain costs a store round trip plus a load round trip (~3-5 us per TB); here the CTB's samples, its border, the
+// availability of every 4x4 unit around it and its coefficient levels are fetched into LDS once, every TB works in LDS,
+// and the finished CTB is written back with coalesced row stores.
+#define RC_TS_Y 130      // tile strides: column -1 .. 2n (left border, the CTB, the above-right CTB for row -1)
+#define RC_TS_C 66
+#define RC_US 34         // unit availability stride: ux = -1 .. 32
+struct RbtCtbTile {
+  uint16_t y[65 * RC_TS_Y]; uint16_t c[2][33 * RC_TS_C];   // sample (xx,yy) relative to the CTB at (yy + 1) * stride + xx + 1
+  int16_t coef_y[64 * 64]; int16_t coef_c[2][32 * 32];     // coefficient levels of the CTB (row stride = CTB size)
+  uint8_t uav[17 * RC_US];                                  // 4x4 luma unit (ux,uy) usable as intra reference: (uy + 1) * RC_US + ux + 1
+};
+struct RbtReconCtbLds { RbtReconLds rc; RbtCtbTile t; };
 
-// ---- reconstruct one CTB of the decoder from its command list ----
-RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_idx, int ctb_addr, RBT_LDS_AS RbtReconLds* l) {
-  RbtFrame* f = &frames[frame_idx];
+RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int c_idx, int x0, int y0, int log2, int intra, int mode, int cbf, int ts, int tq_bypass, int qp) {
+  // (x0,y0): TB origin relative to the CTB, in samples of component c_idx
+  RBT_LDS_AS RbtReconLds* l = &L->rc; RBT_LDS_AS RbtCtbTile* t = &L->t;
+  const int N = 1 << log2, sh = c_idx ? 1 : 0, bd = g->bit_depth, maxv = (1 << bd) - 1, n = (1 << g->log2_ctb) >> sh, n4 = (1 << g->log2_ctb) >> 2;
+  RBT_LDS_AS uint16_t* tile = c_idx == 0 ? t->y : t->c[c_idx - 1]; const int S = c_idx == 0 ? RC_TS_Y : RC_TS_C;
+  RBT_LDS_AS int16_t* coef = c_idx == 0 ? t->coef_y : t->coef_c[c_idx - 1];
+  if (intra) {
+    const int tot = 4 * N + 1;
+    RBT_PAR_FOR(i, tot) {
+      int xn, yn;
+      if (i < 2 * N) { xn = x0 - 1; yn = y0 + (2 * N - 1 - i); }
+      else if (i == 2 * N) { xn = x0 - 1; yn = y0 - 1; }
+      else { xn = x0 + (i - 2 * N - 1); yn = y0 - 1; }
+      const int ux = (xn << sh) >> 2, uy = (yn << sh) >> 2;            // -1 for the border column / row
+      const int a = uy < n4 && t->uav[(uy + 1) * RC_US + ux + 1];
+      l->av[i] = (uint8_t)a;
+      l->nb[i] = a ? tile[(yn + 1) * S + xn + 1] : 0;
+    }
+    RBT_SYNC_LDS();
+    rc_intra_finish(g, c_idx, log2, mode, l);
+  }
+  if (cbf) {
+    if (tq_bypass) {
+      RBT_PAR_FOR(i, N * N) { int x = i & (N - 1), y = i >> log2; l->res[i] = coef[(y0 + y) * n + x0 + x]; }
+      RBT_SYNC_LDS();
+    } else {
+      rc_dequant(coef, n, x0, y0, log2, qp, bd, l);
+      rc_inv_transform(log2, c_idx == 0 && log2 == 2 && intra, ts, bd, l);
+    }
+  }
+  if (!intra && !cbf) return;
+  RBT_PAR_FOR(i, N * N) {
+    int x = i & (N - 1), y = i >> log2, o = (y0 + y + 1) * S + x0 + x + 1;
+    int base = intra ? l->pred[i] : tile[o];
+    tile[o] = (uint16_t)(cbf ? rbt_clip3(0, maxv, base + l->res[i]) : base);
+  }
+  RBT_SYNC_LDS();
+}
+RBT_DEV void rc_tile_mark(RBT_LDS_AS RbtCtbTile* t, int ux, int uy, int w4, int h4, int flag) {
+  RBT_PAR_FOR(i, w4 * h4) t->uav[(uy + i / w4 + 1) * RC_US + ux + i % w4 + 1] = (uint8_t)flag;
+  RBT_SYNC_LDS();
+}
+// usable-as-intra-reference flag of the 4x4 unit (gxu,gyu) of the picture for CTB ac (a unit outside the current CTB)
+RBT_DEV int rc_unit_avail(const RbtFrame* f, int ac, int gxu, int gyu) {
   const RbtStreamCfg* g = &f->cfg;
-  int cx = (ctb_addr % g->w_ctb) << g->log2_ctb, cy = (ctb_addr / g->w_ctb) << g->log2_ctb;
+  if (gxu < 0 || gyu < 0 || gxu >= g->w4 || gyu >= g->h4) return 0;
+  int L = g->log2_ctb, an = ((gyu << 2) >> L) * g->w_ctb + ((gxu << 2) >> L);
+  if (an >= ac || f->ctb_slice[an] != f->ctb_slice[ac]) return 0;
+  if (g->cip && (f->pm[gyu * g->w4 + gxu] & RBT_PM_MODE_MASK) != RBT_MODE_INTRA) return 0;
+  return 1;
+}
+RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_idx, int ctb_addr, RBT_LDS_AS RbtReconCtbLds* L) {
+  RbtFrame* f = &frames[frame_idx];
+  const RbtStreamCfg* g = &f->cfg; RBT_LDS_AS RbtCtbTile* t = &L->t;
+  const int ctb = 1 << g->log2_ctb, n4 = ctb >> 2, cx = (ctb_addr % g->w_ctb) << g->log2_ctb, cy = (ctb_addr / g->w_ctb) << g->log2_ctb;
   uint32_t n = f->cmd_count[ctb_addr];
   if ((int)n > f->cmd_cap) n = (uint32_t)f->cmd_cap;
   const RbtCmd* cmds = f->cmds + (size_t)ctb_addr * f->cmd_cap;
   const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
+  rc_stage_tables(&L->rc);
+  // ---- fetch: borders, unit availability, coefficient levels (one HBM round trip for everything) ----
+  for (int c = 0; c < 3; c++) {
+    const int sh = c ? 1 : 0, nn = ctb >> sh, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, ox = cx >> sh, oy = cy >> sh, S = c ? RC_TS_C : RC_TS_Y;
+    const uint16_t* p = f->pix[c]; RBT_LDS_AS uint16_t* tile = c == 0 ? t->y : t->c[c - 1];
+    RBT_PAR_FOR(i, 2 * nn + 1) { int x = ox + i - 1, y = oy - 1; tile[i] = (x >= 0 && y >= 0 && x < pw) ? p[(size_t)y * pw + x] : 0; }
+    RBT_PAR_FOR(i, nn) { int x = ox - 1, y = oy + i; tile[(i + 1) * S] = (x >= 0 && y < ph) ? p[(size_t)y * pw + x] : 0; }
+    const int16_t* cp = f->coef[c]; RBT_LDS_AS int16_t* cd = c == 0 ? t->coef_y : t->coef_c[c - 1];
+    RBT_PAR_FOR(i, nn * nn) { int x = i & (nn - 1), y = i / nn; cd[i] = (ox + x < pw && oy + y < ph) ? cp[(size_t)(oy + y) * pw + ox + x] : 0; }
+  }
+  RBT_PAR_FOR(i, 17 * RC_US) {
+    int ux = i % RC_US - 1, uy = i / RC_US - 1, a = 0;
+    if ((uy < 0 && ux < 2 * n4) || (ux < 0 && uy < n4)) a = rc_unit_avail(f, ctb_addr, (cx >> 2) + ux, (cy >> 2) + uy);
+    t->uav[i] = (uint8_t)a;
+  }
+  RBT_SYNC();
+  // ---- the CTB's commands, in decoding order ----
   for (uint32_t k = 0; k < n; k++) {
     RbtCmd c = cmds[k];
-    int x0 = cx + c.x4 * 4, y0 = cy + c.y4 * 4;
+    const int x0 = c.x4 * 4, y0 = c.y4 * 4;                               // relative to the CTB
     if (c.type == RBT_CMD_PU) {
-      rc_inter_pu(f, &frames[sl->ref_frame[c.c]], x0, y0, c.a * 4, c.b * 4, c.mvx, c.mvy);
+      const RbtFrame* ref = &frames[sl->ref_frame[c.c]];
+      const int w = c.a * 4, h = c.b * 4, mvx = c.mvx, mvy = c.mvy;
+      rc_mc_plane(t->y, RC_TS_Y, x0 + 1, y0 + 1, ref->out[0], g->w, g->h, cx + x0, cy + y0, w, h, mvx >> 2, mvy >> 2, mvx & 3, mvy & 3, 8, k_luma_filter[mvx & 3], k_luma_filter[mvy & 3], g->bit_depth);
+      for (int cc = 1; cc < 3; cc++)
+        rc_mc_plane(t->c[cc - 1], RC_TS_C, (x0 >> 1) + 1, (y0 >> 1) + 1, ref->out[cc], g->cw, g->ch, (cx + x0) >> 1, (cy + y0) >> 1, w >> 1, h >> 1, mvx >> 3, mvy >> 3, mvx & 7, mvy & 7, 4,
+                    k_chroma_filter[mvx & 7], k_chroma_filter[mvy & 7], g->bit_depth);
+      rc_tile_mark(t, c.x4, c.y4, c.a, c.b, !g->cip);
     } else if (c.type == RBT_CMD_TU) {
-      int fl = c.a, log2 = c.log2, intra = (fl & RBT_TU_INTRA) != 0;
-      rc_decode_tb(f, 0, x0, y0, log2, intra, c.b, fl & RBT_TU_CBF_Y, (fl & RBT_TU_TS_Y) != 0, c.d, c.qp[0], l);
+      const int fl = c.a, log2 = c.log2, intra = (fl & RBT_TU_INTRA) != 0;
+      rc_tile_tb(g, L, 0, x0, y0, log2, intra, c.b, fl & RBT_TU_CBF_Y, (fl & RBT_TU_TS_Y) != 0, c.d, c.qp[0]);
+      rc_tile_mark(t, c.x4, c.y4, 1 << (log2 - 2), 1 << (log2 - 2), intra || !g->cip);
       if (fl & RBT_TU_CHROMA) {
-        int xc = (log2 > 2 ? x0 : x0 - 4) >> 1, yc = (log2 > 2 ? y0 : y0 - 4) >> 1, l2c = log2 > 2 ? log2 - 1 : 2;
-        rc_decode_tb(f, 1, xc, yc, l2c, intra, c.c, fl & RBT_TU_CBF_CB, (fl & RBT_TU_TS_CB) != 0, c.d, c.qp[1], l);
-        rc_decode_tb(f, 2, xc, yc, l2c, intra, c.c, fl & RBT_TU_CBF_CR, (fl & RBT_TU_TS_CR) != 0, c.d, c.qp[2], l);
+        const int xc = (log2 > 2 ? x0 : x0 - 4) >> 1, yc = (log2 > 2 ? y0 : y0 - 4) >> 1, l2c = log2 > 2 ? log2 - 1 : 2;
+        rc_tile_tb(g, L, 1, xc, yc, l2c, intra, c.c, fl & RBT_TU_CBF_CB, (fl & RBT_TU_TS_CB) != 0, c.d, c.qp[1]);
+        rc_tile_tb(g, L, 2, xc, yc, l2c, intra, c.c, fl & RBT_TU_CBF_CR, (fl & RBT_TU_TS_CR) != 0, c.d, c.qp[2]);
       }
     }
+  }
+  // ---- write the CTB back (clipped to the picture) ----
+  for (int c = 0; c < 3; c++) {
+    const int sh = c ? 1 : 0, nn = ctb >> sh, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, ox = cx >> sh, oy = cy >> sh, S = c ? RC_TS_C : RC_TS_Y;
+    uint16_t* p = f->pix[c]; RBT_LDS_AS uint16_t* tile = c == 0 ? t->y : t->c[c - 1];
+    RBT_PAR_FOR(i, nn * nn) { int x = i & (nn - 1), y = i / nn; if (ox + x < pw && oy + y < ph) p[(size_t)(oy + y) * pw + ox + x] = tile[(y + 1) * S + x + 1]; }
   }
 }

@@ -35,7 +35,7 @@ void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const
   for (int i = 0; i < n_slices; i++) rbt_parse_slice(frames, slices, slice_list[i], rbsp, &plds);
 }
 void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb) {
-  static RbtReconLds lds;
+  static RbtReconCtbLds lds;
   int n_diag = max_w_ctb + 2 * (max_h_ctb - 1);
   for (int d = 0; d < n_diag; d++)
     for (int k = 0; k < n_frames; k++) {
