@@ -118,20 +118,28 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
 
 // ------------------------------------------------------------------------------------------------ transform / quantiser
 // forward transform of l->rc.res (residual, N x N) into l->rc.res (coefficients); HM shift convention
-RBT_DEV void en_fwd_transform(int log2, int is_dst, int bd, RBT_LDS_AS RbtReconLds* r) {
-  int N = 1 << log2, s1 = log2 + bd - 9, s2 = log2 + 6;
+template <int LOG2> RBT_DEV void en_fwd_transform_n(int is_dst, int bd, RBT_LDS_AS RbtReconLds* r) {   // fully unrolled per size (see rc_inv_transform_n)
+  constexpr int N = 1 << LOG2; const int s1 = LOG2 + bd - 9, s2 = LOG2 + 6;
   RBT_PAR_FOR(i, N * N) {
-    int k = i & (N - 1), y = i >> log2, s = 0;
+    int k = i & (N - 1), y = i >> LOG2, s = 0;
+#pragma unroll
     for (int x = 0; x < N; x++) s += rc_tcoef(r, N, is_dst, k, x) * r->res[y * N + x];
     r->tmp[i] = s1 > 0 ? (s + (1 << (s1 - 1))) >> s1 : s;
   }
   RBT_SYNC_LDS();
   RBT_PAR_FOR(i, N * N) {
-    int kh = i & (N - 1), kv = i >> log2, s = 0;
+    int kh = i & (N - 1), kv = i >> LOG2, s = 0;
+#pragma unroll
     for (int y = 0; y < N; y++) s += rc_tcoef(r, N, is_dst, kv, y) * r->tmp[y * N + kh];
     r->res[i] = (int16_t)rbt_clip3(-32768, 32767, (s + (1 << (s2 - 1))) >> s2);
   }
   RBT_SYNC_LDS();
+}
+RBT_DEV void en_fwd_transform(int log2, int is_dst, int bd, RBT_LDS_AS RbtReconLds* r) {
+  if (log2 == 2) en_fwd_transform_n<2>(is_dst, bd, r);
+  else if (log2 == 3) en_fwd_transform_n<3>(0, bd, r);
+  else if (log2 == 4) en_fwd_transform_n<4>(0, bd, r);
+  else en_fwd_transform_n<5>(0, bd, r);
 }
 // dead-zone quantiser of l->rc.res into l->lvl; returns the number of non-zero levels
 RBT_DEV int en_quant(int log2, int qp, int bd, int is_intra, RBT_LDS_AS RbtEncLds* l) {

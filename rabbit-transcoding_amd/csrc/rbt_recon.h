@@ -179,6 +179,25 @@ template <class CP> RBT_DEV void rc_dequant(CP plane, int pst, int x0, int y0, i
   RBT_SYNC_LDS();
 }
 // ---- inverse transform of lds->res in place (8.6.4.2) ----
+// Specialised per size so that the dot products unroll fully: with a run-time trip count every iteration would wait for
+// its own LDS reads (~130 cycles each) instead of having all of them in flight.
+template <int LOG2> RBT_DEV void rc_inv_transform_n(int is_dst, int sh, RBT_LDS_AS RbtReconLds* l) {
+  constexpr int N = 1 << LOG2;
+  RBT_PAR_FOR(i, N * N) {
+    int x = i & (N - 1), y = i >> LOG2, s = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) s += rc_tcoef(l, N, is_dst, k, y) * l->res[k * N + x];
+    l->tmp[i] = rbt_clip3(-32768, 32767, (s + 64) >> 7);
+  }
+  RBT_SYNC_LDS();
+  RBT_PAR_FOR(i, N * N) {
+    int x = i & (N - 1), y = i >> LOG2, s = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) s += rc_tcoef(l, N, is_dst, k, x) * l->tmp[y * N + k];
+    l->res[i] = (int16_t)((s + (1 << (sh - 1))) >> sh);
+  }
+  RBT_SYNC_LDS();
+}
 RBT_DEV void rc_inv_transform(int log2, int is_dst, int ts, int bd, RBT_LDS_AS RbtReconLds* l) {
   int N = 1 << log2, sh = 20 - bd;
   if (ts) {
@@ -186,18 +205,10 @@ RBT_DEV void rc_inv_transform(int log2, int is_dst, int ts, int bd, RBT_LDS_AS R
     RBT_SYNC_LDS();
     return;
   }
-  RBT_PAR_FOR(i, N * N) {
-    int x = i & (N - 1), y = i >> log2, s = 0;
-    for (int k = 0; k < N; k++) s += rc_tcoef(l, N, is_dst, k, y) * l->res[k * N + x];
-    l->tmp[i] = rbt_clip3(-32768, 32767, (s + 64) >> 7);
-  }
-  RBT_SYNC_LDS();
-  RBT_PAR_FOR(i, N * N) {
-    int x = i & (N - 1), y = i >> log2, s = 0;
-    for (int k = 0; k < N; k++) s += rc_tcoef(l, N, is_dst, k, x) * l->tmp[y * N + k];
-    l->res[i] = (int16_t)((s + (1 << (sh - 1))) >> sh);
-  }
-  RBT_SYNC_LDS();
+  if (log2 == 2) rc_inv_transform_n<2>(is_dst, sh, l);
+  else if (log2 == 3) rc_inv_transform_n<3>(0, sh, l);
+  else if (log2 == 4) rc_inv_transform_n<4>(0, sh, l);
+  else rc_inv_transform_n<5>(0, sh, l);
 }
 
 // ---- uni-directional motion compensation of one PU (8.5.3.3) from ref->out into f->pix ----
@@ -277,8 +288,12 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int
   }
   RBT_SYNC_LDS();
 }
-RBT_DEV void rc_tile_mark(RBT_LDS_AS RbtCtbTile* t, int ux, int uy, int w4, int h4, int flag) {
+RBT_DEV void rc_tile_mark(RBT_LDS_AS RbtCtbTile* t, int ux, int uy, int w4, int h4, int flag) {   // any rectangle (prediction units)
   RBT_PAR_FOR(i, w4 * h4) t->uav[(uy + i / w4 + 1) * RC_US + ux + i % w4 + 1] = (uint8_t)flag;
+  RBT_SYNC_LDS();
+}
+RBT_DEV void rc_tile_mark_sq(RBT_LDS_AS RbtCtbTile* t, int ux, int uy, int l4, int flag) {           // square of 1 << l4 units (transform units)
+  RBT_PAR_FOR(i, 1 << (2 * l4)) t->uav[(uy + (i >> l4) + 1) * RC_US + ux + (i & ((1 << l4) - 1)) + 1] = (uint8_t)flag;
   RBT_SYNC_LDS();
 }
 // usable-as-intra-reference flag of the 4x4 unit (gxu,gyu) of the picture for CTB ac (a unit outside the current CTB)
@@ -292,7 +307,8 @@ RBT_DEV int rc_unit_avail(const RbtFrame* f, int ac, int gxu, int gyu) {
 }
 RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_idx, int ctb_addr, RBT_LDS_AS RbtReconCtbLds* L) {
   RbtFrame* f = &frames[frame_idx];
-  const RbtStreamCfg* g = &f->cfg; RBT_LDS_AS RbtCtbTile* t = &L->t;
+  const RbtStreamCfg gcopy = f->cfg;                                     // private copy: not reloaded after every store
+  const RbtStreamCfg* g = &gcopy; RBT_LDS_AS RbtCtbTile* t = &L->t;
   const int ctb = 1 << g->log2_ctb, n4 = ctb >> 2, cx = (ctb_addr % g->w_ctb) << g->log2_ctb, cy = (ctb_addr / g->w_ctb) << g->log2_ctb;
   uint32_t n = f->cmd_count[ctb_addr];
   if ((int)n > f->cmd_cap) n = (uint32_t)f->cmd_cap;
@@ -306,7 +322,8 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
     RBT_PAR_FOR(i, 2 * nn + 1) { int x = ox + i - 1, y = oy - 1; tile[i] = (x >= 0 && y >= 0 && x < pw) ? p[(size_t)y * pw + x] : 0; }
     RBT_PAR_FOR(i, nn) { int x = ox - 1, y = oy + i; tile[(i + 1) * S] = (x >= 0 && y < ph) ? p[(size_t)y * pw + x] : 0; }
     const int16_t* cp = f->coef[c]; RBT_LDS_AS int16_t* cd = c == 0 ? t->coef_y : t->coef_c[c - 1];
-    RBT_PAR_FOR(i, nn * nn) { int x = i & (nn - 1), y = i / nn; cd[i] = (ox + x < pw && oy + y < ph) ? cp[(size_t)(oy + y) * pw + ox + x] : 0; }
+    const int lnn = g->log2_ctb - sh;
+    RBT_PAR_FOR(i, nn * nn) { int x = i & (nn - 1), y = i >> lnn; cd[i] = (ox + x < pw && oy + y < ph) ? cp[(size_t)(oy + y) * pw + ox + x] : 0; }
   }
   RBT_PAR_FOR(i, 17 * RC_US) {
     int ux = i % RC_US - 1, uy = i / RC_US - 1, a = 0;
@@ -315,8 +332,10 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
   }
   RBT_SYNC();
   // ---- the CTB's commands, in decoding order ----
+  RbtCmd nxt; if (n) nxt = cmds[0];
   for (uint32_t k = 0; k < n; k++) {
-    RbtCmd c = cmds[k];
+    const RbtCmd c = nxt;
+    if (k + 1 < n) nxt = cmds[k + 1];                                     // fetched while command k is processed
     const int x0 = c.x4 * 4, y0 = c.y4 * 4;                               // relative to the CTB
     if (c.type == RBT_CMD_PU) {
       const RbtFrame* ref = &frames[sl->ref_frame[c.c]];
@@ -329,7 +348,7 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
     } else if (c.type == RBT_CMD_TU) {
       const int fl = c.a, log2 = c.log2, intra = (fl & RBT_TU_INTRA) != 0;
       rc_tile_tb(g, L, 0, x0, y0, log2, intra, c.b, fl & RBT_TU_CBF_Y, (fl & RBT_TU_TS_Y) != 0, c.d, c.qp[0]);
-      rc_tile_mark(t, c.x4, c.y4, 1 << (log2 - 2), 1 << (log2 - 2), intra || !g->cip);
+      rc_tile_mark_sq(t, c.x4, c.y4, log2 - 2, intra || !g->cip);
       if (fl & RBT_TU_CHROMA) {
         const int xc = (log2 > 2 ? x0 : x0 - 4) >> 1, yc = (log2 > 2 ? y0 : y0 - 4) >> 1, l2c = log2 > 2 ? log2 - 1 : 2;
         rc_tile_tb(g, L, 1, xc, yc, l2c, intra, c.c, fl & RBT_TU_CBF_CB, (fl & RBT_TU_TS_CB) != 0, c.d, c.qp[1]);
@@ -341,6 +360,7 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
   for (int c = 0; c < 3; c++) {
     const int sh = c ? 1 : 0, nn = ctb >> sh, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, ox = cx >> sh, oy = cy >> sh, S = c ? RC_TS_C : RC_TS_Y;
     uint16_t* p = f->pix[c]; RBT_LDS_AS uint16_t* tile = c == 0 ? t->y : t->c[c - 1];
-    RBT_PAR_FOR(i, nn * nn) { int x = i & (nn - 1), y = i / nn; if (ox + x < pw && oy + y < ph) p[(size_t)(oy + y) * pw + ox + x] = tile[(y + 1) * S + x + 1]; }
+    const int lnn = g->log2_ctb - sh;
+    RBT_PAR_FOR(i, nn * nn) { int x = i & (nn - 1), y = i >> lnn; if (ox + x < pw && oy + y < ph) p[(size_t)(oy + y) * pw + ox + x] = tile[(y + 1) * S + x + 1]; }
   }
 }
