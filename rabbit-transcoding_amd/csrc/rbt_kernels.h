@@ -14,7 +14,8 @@ enum { RBT_N_STREAMS = 4 };
 void set_stream(int i);
 const char* dev_name();
 void* dev_alloc(size_t n);                // nullptr on failure
-void dev_free(void* p);
+void dev_free(void* p);                   // returns the block to a recycling pool
+void dev_release_pool();                  // hands pooled blocks back to the driver (rbt_destroy)
 int h2d(void* d, const void* h, size_t n);
 int d2h(void* h, const void* d, size_t n);
 int dev_memset(void* d, int v, size_t n);

@@ -1,6 +1,8 @@
 // HIP kernels + launchers for gfx950 (MI355X). See rbt_kernels.h. One stream per context; kernels of a call are
 // enqueued back-to-back, the host synchronises once per phase that needs results.
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <vector>
 #include <cstdio>
 #include "rbt_kernels.h"
 #include "rbt_parse.h"
@@ -32,8 +34,50 @@ int dev_init(int device) {
 }
 const char* dev_name() { return g_name; }
 void set_stream(int i) { g_cur = ((i % RBT_N_STREAMS) + RBT_N_STREAMS) % RBT_N_STREAMS; }
-void* dev_alloc(size_t n) { void* p = nullptr; if (hipMalloc(&p, n) != hipSuccess) return nullptr; return p; }
-void dev_free(void* p) { if (p) (void)hipFree(p); }
+// Device allocations are recycled: hipMalloc / hipFree of GOF-sized arenas cost milliseconds each (hipFree also drains the
+// device), and a transcoder calls with the same sizes over and over. Freed blocks go to a small best-fit pool; at most
+// RBT_POOL_KEEP blocks are kept, the rest is returned to the driver.
+enum { RBT_POOL_KEEP = 16 };
+struct PoolBlock { void* p; size_t n; };
+static std::vector<PoolBlock> g_pool_free, g_pool_live;
+static std::mutex g_pool_mu;
+void* dev_alloc(size_t n) {
+  if (!n) n = 1;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  int best = -1;
+  for (size_t i = 0; i < g_pool_free.size(); i++)
+    if (g_pool_free[i].n >= n && g_pool_free[i].n <= n + n / 4 + (1u << 20) && (best < 0 || g_pool_free[i].n < g_pool_free[(size_t)best].n)) best = (int)i;
+  PoolBlock b;
+  if (best >= 0) { b = g_pool_free[(size_t)best]; g_pool_free.erase(g_pool_free.begin() + best); }
+  else {
+    b.p = nullptr; b.n = n;
+    if (hipMalloc(&b.p, n) != hipSuccess) {
+      for (auto& f : g_pool_free) (void)hipFree(f.p);                 // give everything back and try once more
+      g_pool_free.clear();
+      if (hipMalloc(&b.p, n) != hipSuccess) return nullptr;
+    }
+  }
+  g_pool_live.push_back(b);
+  return b.p;
+}
+void dev_free(void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (size_t i = 0; i < g_pool_live.size(); i++) if (g_pool_live[i].p == p) {
+    g_pool_free.push_back(g_pool_live[i]); g_pool_live.erase(g_pool_live.begin() + (long)i);
+    while (g_pool_free.size() > RBT_POOL_KEEP) {                      // drop the smallest block
+      size_t k = 0; for (size_t j = 1; j < g_pool_free.size(); j++) if (g_pool_free[j].n < g_pool_free[k].n) k = j;
+      (void)hipFree(g_pool_free[k].p); g_pool_free.erase(g_pool_free.begin() + (long)k);
+    }
+    return;
+  }
+  (void)hipFree(p);
+}
+void dev_release_pool() {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (auto& f : g_pool_free) (void)hipFree(f.p);
+  g_pool_free.clear();
+}
 int h2d(void* d, const void* h, size_t n) { HIPCHK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, g_stream)); return 0; }
 int d2h(void* h, const void* d, size_t n) { HIPCHK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, g_stream)); HIPCHK(hipStreamSynchronize(g_stream)); return 0; }
 int dev_memset(void* d, int v, size_t n) { HIPCHK(hipMemsetAsync(d, v, n, g_stream)); return 0; }

@@ -64,6 +64,20 @@ RBT_DEV void rc_intra_pred(const RbtFrame* f, const uint16_t* src, int c_idx, in
   RBT_SYNC_LDS();
   rc_intra_finish(g, c_idx, log2, mode, l);
 }
+// Small normative tables as packed immediates (no memory access on the dependent path of a TB):
+// intraPredAngle (Table 8-5), invAngle (Table 8-6) and levelScale (8.6.3)
+RBT_DEV int rc_intra_angle(int mode) {           // modes 2..34
+  const int k = mode <= 18 ? mode - 2 : 34 - mode, d = k < 8 ? 8 - k : k - 8;                 // |angle| = M[d], M = {0,2,5,9,13,17,21,26,32}
+  const uint64_t M = 0ull | (2ull << 6) | (5ull << 12) | (9ull << 18) | (13ull << 24) | (17ull << 30) | (21ull << 36) | (26ull << 42) | (32ull << 48);
+  const int a = (int)((M >> (6 * d)) & 63);
+  return k <= 8 ? a : -a;
+}
+RBT_DEV int rc_intra_inv_angle(int mode) {       // modes 11..25
+  const int d = mode < 18 ? 18 - mode : mode - 18;                                             // invAngle = -IA[d]
+  const uint64_t lo = 256ull | (315ull << 16) | (390ull << 32) | (482ull << 48), hi = 630ull | (910ull << 16) | (1638ull << 32) | (4096ull << 48);
+  return -(int)(((d < 4 ? lo : hi) >> (16 * (d & 3))) & 0xFFFF);
+}
+RBT_DEV int rc_level_scale(int r) { return (int)((0x484039332D28ull >> (8 * r)) & 255); }      // {40,45,51,57,64,72}[r]
 // index of the nearest available neighbour at or below i (-1: none), from the availability masks of indices 0..63, 64..127, 128
 RBT_DEV int rc_last_avail(int i, uint64_t m0, uint64_t m1, int m2) {
   if (i >= 128) { if (m2) return 128; i = 127; }
@@ -71,15 +85,100 @@ RBT_DEV int rc_last_avail(int i, uint64_t m0, uint64_t m1, int m2) {
   uint64_t t = m0 & (~0ull >> (63 - i));
   return t ? 63 - __builtin_clzll(t) : -1;
 }
+// Substitution (8.4.4.2.2) + smoothing (8.4.4.2.3) of the gathered neighbours; `have_nb` = 0 when the caller wants the
+// substituted samples fetched through `fetch(j)` semantics instead (tile variant fills l->nb itself). Returns the array that
+// holds the final reference samples (l->nb or l->nbf: the two are swapped, never copied).
+RBT_DEV RBT_LDS_AS int32_t* rc_intra_filter(const RbtStreamCfg* g, int c_idx, int log2, int mode, RBT_LDS_AS int32_t* nb, RBT_LDS_AS int32_t* alt) {
+  const int N = 1 << log2, bd = g->bit_depth, tot = 4 * N + 1;
+  int filt = 0;
+  if (c_idx == 0 && mode != 1 && N != 4) {
+    int md = rbt_min(rbt_abs(mode - 26), rbt_abs(mode - 10));
+    int thr = N == 8 ? 7 : (N == 16 ? 1 : 0);
+    filt = md > thr;
+  }
+  if (!filt) return nb;
+  int corner = nb[2 * N], bl = nb[0], tr = nb[4 * N];
+  int strong = g->strong_intra && N == 32 && rbt_abs(corner + tr - 2 * nb[2 * N + 32]) < (1 << (bd - 5)) &&
+               rbt_abs(corner + bl - 2 * nb[2 * N - 32]) < (1 << (bd - 5));
+  RBT_PAR_FOR(i, tot) {
+    int v;
+    if (i == 0 || i == 4 * N) v = nb[i];
+    else if (strong) {
+      if (i == 2 * N) v = corner;
+      else if (i < 2 * N) { int k = 2 * N - 1 - i; v = ((63 - k) * corner + (k + 1) * bl + 32) >> 6; }
+      else { int k = i - 2 * N - 1; v = ((63 - k) * corner + (k + 1) * tr + 32) >> 6; }
+    } else v = (nb[i - 1] + 2 * nb[i] + nb[i + 1] + 2) >> 2;
+    alt[i] = v;
+  }
+  RBT_SYNC_LDS();
+  return alt;
+}
+// availability masks of the 4N+1 gathered neighbours (l->av) -> m[0] (indices 0..63), m[1] (64..127), *m2 (128)
+RBT_DEV void rc_avail_masks(int tot, RBT_LDS_AS RbtReconLds* l, uint64_t* m0, uint64_t* m1, int* m2) {
+  uint64_t a, b = 0; int c = 0;
+  RBT_VBALLOT(a, p, rbt_min(tot, 64), l->av[p]);
+  if (tot > 64) { RBT_VBALLOT(b, p, rbt_min(tot - 64, 64), l->av[64 + p]); }
+  if (tot > 128) c = l->av[128];
+  *m0 = a; *m1 = b; *m2 = c;
+}
+// Prediction value of sample (x,y) of the TB from the final reference samples `nb` (planar / DC / angular incl. edge
+// filters). Angular modes read l->ref, DC reads `dc`; both are prepared by rc_intra_setup.
+struct RcIntraCtx { int N, log2, mode, c_idx, maxv, ang, ver, dc, edge; };
+RBT_DEV void rc_intra_setup(const RbtStreamCfg* g, int c_idx, int log2, int mode, RBT_LDS_AS int32_t* nb, RBT_LDS_AS RbtReconLds* l, RcIntraCtx* q) {
+  const int N = 1 << log2, bd = g->bit_depth;
+  q->N = N; q->log2 = log2; q->mode = mode; q->c_idx = c_idx; q->maxv = (1 << bd) - 1; q->ang = 0; q->ver = mode >= 18; q->dc = 0; q->edge = 0;
+#define RC_LEFT(y) nb[2 * N - 1 - (y)]
+#define RC_TOP(x) nb[2 * N + 1 + (x)]
+  if (mode == 1) {
+    // sum of the 2N neighbours (lanes 0..N-1 hold the top row, N..2N-1 the left column), one ballot per bit plane
+    int sum = N;
+    for (int b = 0; b < bd; b++) { uint64_t m; RBT_VBALLOT(m, p, 2 * N, ((p < N ? RC_TOP(p) : RC_LEFT(p - N)) >> b) & 1); sum += __builtin_popcountll(m) << b; }
+    q->dc = sum >> (log2 + 1); q->edge = c_idx == 0 && N < 32;
+  } else if (mode >= 2) {
+    const int ang = rc_intra_angle(mode), ver = mode >= 18, last = (N * ang) >> 5;
+    const int inv = (mode >= 11 && mode <= 25) ? rc_intra_inv_angle(mode) : 0;
+    q->ang = ang; q->edge = c_idx == 0 && N < 32 && (mode == 26 || mode == 10);
+    // ref[x], x = -N .. 2N  (stored at index x + 32)
+    RBT_PAR_FOR(i, 3 * N + 1) {
+      int x = i - N, v = 0;
+      if (x >= 0 && x <= N) v = ver ? RC_TOP(x - 1) : RC_LEFT(x - 1);
+      else if (x < 0) { if (ang < 0 && last < -1 && x >= last) { int k = -1 + ((x * inv + 128) >> 8); v = ver ? RC_LEFT(k) : RC_TOP(k); } }
+      else if (ang >= 0) v = ver ? RC_TOP(x - 1) : RC_LEFT(x - 1);
+      l->ref[x + 32] = v;
+    }
+    RBT_SYNC_LDS();
+  }
+}
+RBT_DEV int rc_intra_sample(const RcIntraCtx* q, RBT_LDS_AS int32_t* nb, const RBT_LDS_AS RbtReconLds* l, int x, int y) {
+  const int N = q->N, mode = q->mode;
+  if (mode == 0) return ((N - 1 - x) * RC_LEFT(y) + (x + 1) * RC_TOP(N) + (N - 1 - y) * RC_TOP(x) + (y + 1) * RC_LEFT(N) + N) >> (q->log2 + 1);
+  if (mode == 1) {
+    int v = q->dc;
+    if (q->edge) {
+      if (x == 0 && y == 0) v = (RC_LEFT(0) + 2 * q->dc + RC_TOP(0) + 2) >> 2;
+      else if (y == 0) v = (RC_TOP(x) + 3 * q->dc + 2) >> 2;
+      else if (x == 0) v = (RC_LEFT(y) + 3 * q->dc + 2) >> 2;
+    }
+    return v;
+  }
+  const int a = q->ver ? y : x, b = q->ver ? x : y;
+  const int idx = ((a + 1) * q->ang) >> 5, fr = ((a + 1) * q->ang) & 31;
+  int v = fr ? ((32 - fr) * l->ref[32 + b + idx + 1] + fr * l->ref[32 + b + idx + 2] + 16) >> 5 : l->ref[32 + b + idx + 1];
+  if (q->edge) {
+    if (mode == 26 && x == 0) v = rbt_clip3(0, q->maxv, RC_TOP(0) + ((RC_LEFT(y) - RC_LEFT(-1)) >> 1));
+    if (mode == 10 && y == 0) v = rbt_clip3(0, q->maxv, RC_LEFT(0) + ((RC_TOP(x) - RC_TOP(-1)) >> 1));
+  }
+  return v;
+}
+#undef RC_LEFT
+#undef RC_TOP
+// variant-A tail: l->nb / l->av gathered by the caller -> l->pred
 RBT_DEV void rc_intra_finish(const RbtStreamCfg* g, int c_idx, int log2, int mode, RBT_LDS_AS RbtReconLds* l) {
-  int N = 1 << log2, bd = g->bit_depth, maxv = (1 << bd) - 1, tot = 4 * N + 1;
+  const int N = 1 << log2, bd = g->bit_depth, tot = 4 * N + 1;
   RBT_LDS_AS int32_t* nb = l->nb; RBT_LDS_AS int32_t* alt = l->nbf;      // current / scratch neighbour arrays (swapped, not copied)
-  // substitution (8.4.4.2.2): availability as bit masks, every lane finds its source with bit operations
   {
-    uint64_t m0, m1 = 0; int m2 = 0;
-    RBT_VBALLOT(m0, p, rbt_min(tot, 64), l->av[p]);
-    if (tot > 64) { RBT_VBALLOT(m1, p, rbt_min(tot - 64, 64), l->av[64 + p]); }
-    if (tot > 128) m2 = l->av[128];
+    uint64_t m0, m1; int m2;
+    rc_avail_masks(tot, l, &m0, &m1, &m2);
     const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : (m2 ? 128 : -1));
     const int all = __builtin_popcountll(m0) + __builtin_popcountll(m1) + m2 == tot;
     if (first < 0) { RBT_PAR_FOR(i, tot) nb[i] = 1 << (bd - 1); RBT_SYNC_LDS(); }
@@ -90,86 +189,16 @@ RBT_DEV void rc_intra_finish(const RbtStreamCfg* g, int c_idx, int log2, int mod
       RBT_LDS_AS int32_t* t = nb; nb = alt; alt = t;
     }
   }
-  int filt = 0;
-  if (c_idx == 0 && mode != 1 && N != 4) {
-    int md = rbt_min(rbt_abs(mode - 26), rbt_abs(mode - 10));
-    int thr = N == 8 ? 7 : (N == 16 ? 1 : 0);
-    filt = md > thr;
-  }
-  if (filt) {
-    int corner = nb[2 * N], bl = nb[0], tr = nb[4 * N];
-    int strong = g->strong_intra && N == 32 && rbt_abs(corner + tr - 2 * nb[2 * N + 32]) < (1 << (bd - 5)) &&
-                 rbt_abs(corner + bl - 2 * nb[2 * N - 32]) < (1 << (bd - 5));
-    RBT_PAR_FOR(i, tot) {
-      int v;
-      if (i == 0 || i == 4 * N) v = nb[i];
-      else if (strong) {
-        if (i == 2 * N) v = corner;
-        else if (i < 2 * N) { int k = 2 * N - 1 - i; v = ((63 - k) * corner + (k + 1) * bl + 32) >> 6; }
-        else { int k = i - 2 * N - 1; v = ((63 - k) * corner + (k + 1) * tr + 32) >> 6; }
-      } else v = (nb[i - 1] + 2 * nb[i] + nb[i + 1] + 2) >> 2;
-      alt[i] = v;
-    }
-    RBT_SYNC_LDS();
-    RBT_LDS_AS int32_t* t = nb; nb = alt; alt = t;
-  }
-#define RC_LEFT(y) nb[2 * N - 1 - (y)]
-#define RC_TOP(x) nb[2 * N + 1 + (x)]
-  if (mode == 0) {
-    RBT_PAR_FOR(i, N * N) {
-      int x = i & (N - 1), y = i >> log2;
-      l->pred[i] = (uint16_t)(((N - 1 - x) * RC_LEFT(y) + (x + 1) * RC_TOP(N) + (N - 1 - y) * RC_TOP(x) + (y + 1) * RC_LEFT(N) + N) >> (log2 + 1));
-    }
-  } else if (mode == 1) {
-    // sum of the 2N neighbours (lanes 0..N-1 hold the top row, N..2N-1 the left column), one ballot per bit plane
-    int sum = N;
-    for (int b = 0; b < bd; b++) { uint64_t m; RBT_VBALLOT(m, p, 2 * N, ((p < N ? RC_TOP(p) : RC_LEFT(p - N)) >> b) & 1); sum += __builtin_popcountll(m) << b; }
-    int dc = sum >> (log2 + 1);
-    int edge = c_idx == 0 && N < 32;
-    RBT_PAR_FOR(i, N * N) {
-      int x = i & (N - 1), y = i >> log2, v = dc;
-      if (edge) {
-        if (x == 0 && y == 0) v = (RC_LEFT(0) + 2 * dc + RC_TOP(0) + 2) >> 2;
-        else if (y == 0) v = (RC_TOP(x) + 3 * dc + 2) >> 2;
-        else if (x == 0) v = (RC_LEFT(y) + 3 * dc + 2) >> 2;
-      }
-      l->pred[i] = (uint16_t)v;
-    }
-  } else {
-    int ang = k_intra_angle[mode], ver = mode >= 18;
-    int last = (N * ang) >> 5;
-    int inv = (mode >= 11 && mode <= 25) ? k_intra_inv_angle[mode - 11] : 0;
-    // ref[x], x = -N .. 2N  (stored at index x + 32)
-    RBT_PAR_FOR(i, 3 * N + 1) {
-      int x = i - N, v = 0;
-      if (x >= 0 && x <= N) v = ver ? RC_TOP(x - 1) : RC_LEFT(x - 1);
-      else if (x < 0) { if (ang < 0 && last < -1 && x >= last) { int k = -1 + ((x * inv + 128) >> 8); v = ver ? RC_LEFT(k) : RC_TOP(k); } }
-      else if (ang >= 0) v = ver ? RC_TOP(x - 1) : RC_LEFT(x - 1);
-      l->ref[x + 32] = v;
-    }
-    RBT_SYNC_LDS();
-    int edge = c_idx == 0 && N < 32 && (mode == 26 || mode == 10);
-    RBT_PAR_FOR(i, N * N) {
-      int x = i & (N - 1), y = i >> log2;
-      int a = ver ? y : x, b = ver ? x : y;
-      int idx = ((a + 1) * ang) >> 5, fr = ((a + 1) * ang) & 31;
-      int v = fr ? ((32 - fr) * l->ref[32 + b + idx + 1] + fr * l->ref[32 + b + idx + 2] + 16) >> 5 : l->ref[32 + b + idx + 1];
-      if (edge) {
-        if (mode == 26 && x == 0) v = rbt_clip3(0, maxv, RC_TOP(0) + ((RC_LEFT(y) - RC_LEFT(-1)) >> 1));
-        if (mode == 10 && y == 0) v = rbt_clip3(0, maxv, RC_LEFT(0) + ((RC_TOP(x) - RC_TOP(-1)) >> 1));
-      }
-      l->pred[i] = (uint16_t)v;
-    }
-  }
-#undef RC_LEFT
-#undef RC_TOP
+  RBT_LDS_AS int32_t* fin = rc_intra_filter(g, c_idx, log2, mode, nb, alt);
+  RcIntraCtx q; rc_intra_setup(g, c_idx, log2, mode, fin, l, &q);
+  RBT_PAR_FOR(i, N * N) l->pred[i] = (uint16_t)rc_intra_sample(&q, fin, l, i & (N - 1), i >> log2);
   RBT_SYNC_LDS();
 }
 
 // ---- scaling (8.6.3, flat lists) of the TB's levels from the coefficient plane into lds->res ----
 template <class CP> RBT_DEV void rc_dequant(CP plane, int pst, int x0, int y0, int log2, int qp, int bd, RBT_LDS_AS RbtReconLds* l) {
   int N = 1 << log2, bd_shift = bd + log2 - 5;
-  int scale = (16 * k_dequant_scale[qp % 6]) << (qp / 6);
+  int scale = (16 * rc_level_scale(qp % 6)) << (qp / 6);
   long long add = 1ll << (bd_shift - 1);
   RBT_PAR_FOR(i, N * N) {
     int x = i & (N - 1), y = i >> log2;
@@ -243,34 +272,41 @@ template <class DP> RBT_DEV void rc_mc_plane(DP dst, int dstride, int dx0, int d
 #define RC_TS_Y 130      // tile strides: column -1 .. 2n (left border, the CTB, the above-right CTB for row -1)
 #define RC_TS_C 66
 #define RC_US 34         // unit availability stride: ux = -1 .. 32
+struct alignas(8) RbtU2 { uint32_t x, y; };
 struct RbtCtbTile {
+  alignas(16) int16_t coef_y[64 * 64]; alignas(16) int16_t coef_c[2][32 * 32];   // coefficient levels of the CTB (row stride = CTB size)
   uint16_t y[65 * RC_TS_Y]; uint16_t c[2][33 * RC_TS_C];   // sample (xx,yy) relative to the CTB at (yy + 1) * stride + xx + 1
-  int16_t coef_y[64 * 64]; int16_t coef_c[2][32 * 32];     // coefficient levels of the CTB (row stride = CTB size)
   uint8_t uav[17 * RC_US];                                  // 4x4 luma unit (ux,uy) usable as intra reference: (uy + 1) * RC_US + ux + 1
 };
-struct RbtReconCtbLds { RbtReconLds rc; RbtCtbTile t; };
+struct RbtReconCtbLds { RbtCtbTile t; RbtReconLds rc;
+#ifdef RBT_PROFILE
+  unsigned long long prof[8];
+#endif
+};
 
-RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int c_idx, int x0, int y0, int log2, int intra, int mode, int cbf, int ts, int tq_bypass, int qp) {
+// neighbour index i of a TB at (x0,y0): 0 .. 2N-1 left column bottom-up, 2N corner, 2N+1 .. 4N top row left to right
+RBT_DEV void rc_nb_xy(int i, int x0, int y0, int N, int* xn, int* yn) {
+  if (i < 2 * N) { *xn = x0 - 1; *yn = y0 + (2 * N - 1 - i); }
+  else if (i == 2 * N) { *xn = x0 - 1; *yn = y0 - 1; }
+  else { *xn = x0 + (i - 2 * N - 1); *yn = y0 - 1; }
+}
+RBT_DEV int rc_nb_av(const RBT_LDS_AS RbtCtbTile* t, int i, int x0, int y0, int N, int sh, int n4) {
+  int xn, yn; rc_nb_xy(i, x0, y0, N, &xn, &yn);
+  const int ux = (xn << sh) >> 2, uy = (yn << sh) >> 2;                  // -1 for the border column / row
+  return uy < n4 && t->uav[(uy + 1) * RC_US + ux + 1];
+}
+// mark_l4 >= 0: also flags the TB's (1 << mark_l4)^2 luma units at (mux,muy) as decoded in the same pass
+RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int c_idx, int x0, int y0, int log2, int intra, int mode, int cbf, int ts, int tq_bypass, int qp,
+                        int mark_l4, int mux, int muy, int mark_flag) {
   // (x0,y0): TB origin relative to the CTB, in samples of component c_idx
   RBT_LDS_AS RbtReconLds* l = &L->rc; RBT_LDS_AS RbtCtbTile* t = &L->t;
   const int N = 1 << log2, sh = c_idx ? 1 : 0, bd = g->bit_depth, maxv = (1 << bd) - 1, n = (1 << g->log2_ctb) >> sh, n4 = (1 << g->log2_ctb) >> 2;
   RBT_LDS_AS uint16_t* tile = c_idx == 0 ? t->y : t->c[c_idx - 1]; const int S = c_idx == 0 ? RC_TS_Y : RC_TS_C;
   RBT_LDS_AS int16_t* coef = c_idx == 0 ? t->coef_y : t->coef_c[c_idx - 1];
-  if (intra) {
-    const int tot = 4 * N + 1;
-    RBT_PAR_FOR(i, tot) {
-      int xn, yn;
-      if (i < 2 * N) { xn = x0 - 1; yn = y0 + (2 * N - 1 - i); }
-      else if (i == 2 * N) { xn = x0 - 1; yn = y0 - 1; }
-      else { xn = x0 + (i - 2 * N - 1); yn = y0 - 1; }
-      const int ux = (xn << sh) >> 2, uy = (yn << sh) >> 2;            // -1 for the border column / row
-      const int a = uy < n4 && t->uav[(uy + 1) * RC_US + ux + 1];
-      l->av[i] = (uint8_t)a;
-      l->nb[i] = a ? tile[(yn + 1) * S + xn + 1] : 0;
-    }
-    RBT_SYNC_LDS();
-    rc_intra_finish(g, c_idx, log2, mode, l);
-  }
+#ifdef RBT_PROFILE
+  unsigned long long p0_ = __builtin_readcyclecounter(), p1_ = p0_, p2_ = p0_, p3_ = p0_;
+#endif
+  // residual first: it does not depend on the prediction, and the prediction pass can then add it on the fly
   if (cbf) {
     if (tq_bypass) {
       RBT_PAR_FOR(i, N * N) { int x = i & (N - 1), y = i >> log2; l->res[i] = coef[(y0 + y) * n + x0 + x]; }
@@ -280,13 +316,43 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int
       rc_inv_transform(log2, c_idx == 0 && log2 == 2 && intra, ts, bd, l);
     }
   }
-  if (!intra && !cbf) return;
-  RBT_PAR_FOR(i, N * N) {
-    int x = i & (N - 1), y = i >> log2, o = (y0 + y + 1) * S + x0 + x + 1;
-    int base = intra ? l->pred[i] : tile[o];
-    tile[o] = (uint16_t)(cbf ? rbt_clip3(0, maxv, base + l->res[i]) : base);
+#ifdef RBT_PROFILE
+  p1_ = __builtin_readcyclecounter();
+#endif
+  RBT_LDS_AS int32_t* fin = l->nb; RcIntraCtx q;
+  if (intra) {
+    // availability of the 4N+1 neighbours straight from the unit flags (no LDS round trip), then every lane fetches the
+    // sample its index is substituted from (8.4.4.2.2) - gather and substitution in one pass
+    const int tot = 4 * N + 1;
+    uint64_t m0 = 0, m1 = 0; int m2 = 0;
+    RBT_VBALLOT(m0, p, rbt_min(tot, 64), rc_nb_av(t, p, x0, y0, N, sh, n4));
+    if (tot > 64) { RBT_VBALLOT(m1, p, rbt_min(tot - 64, 64), rc_nb_av(t, 64 + p, x0, y0, N, sh, n4)); }
+    if (tot > 128) m2 = rc_nb_av(t, 128, x0, y0, N, sh, n4);
+    const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : (m2 ? 128 : -1));
+    RBT_PAR_FOR(i, tot) {
+      int v = 1 << (bd - 1);
+      if (first >= 0) { int j = rc_last_avail(i, m0, m1, m2); if (j < 0) j = first; int xn, yn; rc_nb_xy(j, x0, y0, N, &xn, &yn); v = tile[(yn + 1) * S + xn + 1]; }
+      l->nb[i] = v;
+    }
+    RBT_SYNC_LDS();
+    fin = rc_intra_filter(g, c_idx, log2, mode, l->nb, l->nbf);
+    rc_intra_setup(g, c_idx, log2, mode, fin, l, &q);
   }
+#ifdef RBT_PROFILE
+  p2_ = p3_ = __builtin_readcyclecounter();
+#endif
+  if (intra || cbf) {
+    RBT_PAR_FOR(i, N * N) {
+      int x = i & (N - 1), y = i >> log2, o = (y0 + y + 1) * S + x0 + x + 1;
+      int base = intra ? rc_intra_sample(&q, fin, l, x, y) : tile[o];
+      tile[o] = (uint16_t)(cbf ? rbt_clip3(0, maxv, base + l->res[i]) : base);
+    }
+  }
+  if (mark_l4 >= 0) { RBT_PAR_FOR(i, 1 << (2 * mark_l4)) t->uav[(muy + (i >> mark_l4) + 1) * RC_US + mux + (i & ((1 << mark_l4) - 1)) + 1] = (uint8_t)mark_flag; }
   RBT_SYNC_LDS();
+#ifdef RBT_PROFILE
+  { unsigned long long p4_ = __builtin_readcyclecounter(); L->prof[0] += p1_ - p0_; L->prof[1] += p2_ - p1_; L->prof[2] += p3_ - p2_; L->prof[3] += p4_ - p3_; L->prof[4] += 1; }
+#endif
 }
 RBT_DEV void rc_tile_mark(RBT_LDS_AS RbtCtbTile* t, int ux, int uy, int w4, int h4, int flag) {   // any rectangle (prediction units)
   RBT_PAR_FOR(i, w4 * h4) t->uav[(uy + i / w4 + 1) * RC_US + ux + i % w4 + 1] = (uint8_t)flag;
@@ -314,6 +380,10 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
   if ((int)n > f->cmd_cap) n = (uint32_t)f->cmd_cap;
   const RbtCmd* cmds = f->cmds + (size_t)ctb_addr * f->cmd_cap;
   const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
+#ifdef RBT_PROFILE
+  unsigned long long q0_ = __builtin_readcyclecounter();
+  for (int i = 0; i < 8; i++) L->prof[i] = 0;
+#endif
   rc_stage_tables(&L->rc);
   // ---- fetch: borders, unit availability, coefficient levels (one HBM round trip for everything) ----
   for (int c = 0; c < 3; c++) {
@@ -321,9 +391,16 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
     const uint16_t* p = f->pix[c]; RBT_LDS_AS uint16_t* tile = c == 0 ? t->y : t->c[c - 1];
     RBT_PAR_FOR(i, 2 * nn + 1) { int x = ox + i - 1, y = oy - 1; tile[i] = (x >= 0 && y >= 0 && x < pw) ? p[(size_t)y * pw + x] : 0; }
     RBT_PAR_FOR(i, nn) { int x = ox - 1, y = oy + i; tile[(i + 1) * S] = (x >= 0 && y < ph) ? p[(size_t)y * pw + x] : 0; }
-    const int16_t* cp = f->coef[c]; RBT_LDS_AS int16_t* cd = c == 0 ? t->coef_y : t->coef_c[c - 1];
-    const int lnn = g->log2_ctb - sh;
-    RBT_PAR_FOR(i, nn * nn) { int x = i & (nn - 1), y = i >> lnn; cd[i] = (ox + x < pw && oy + y < ph) ? cp[(size_t)(oy + y) * pw + ox + x] : 0; }
+    // coefficient levels: 4 per lane and load (8-byte aligned: widths are multiples of 8, chroma of 4), several loads in flight
+    const RbtU2* cp = (const RbtU2*)(f->coef[c] + (size_t)oy * pw + ox); RBT_LDS_AS RbtU2* cd = (RBT_LDS_AS RbtU2*)(c == 0 ? t->coef_y : t->coef_c[c - 1]);
+    const int q4 = nn >> 2, lq4 = g->log2_ctb - sh - 2, rows = rbt_min(nn, ph - oy), cols4 = rbt_min(nn, pw - ox) >> 2;
+#pragma unroll 4
+    RBT_PAR_FOR(i, nn * q4) {
+      const int x4 = i & (q4 - 1), y = i >> lq4;
+      RbtU2 v; v.x = 0; v.y = 0;
+      if (x4 < cols4 && y < rows) v = cp[((size_t)y * pw >> 2) + x4];
+      cd[i].x = v.x; cd[i].y = v.y;
+    }
   }
   RBT_PAR_FOR(i, 17 * RC_US) {
     int ux = i % RC_US - 1, uy = i / RC_US - 1, a = 0;
@@ -331,6 +408,9 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
     t->uav[i] = (uint8_t)a;
   }
   RBT_SYNC();
+#ifdef RBT_PROFILE
+  unsigned long long q1_ = __builtin_readcyclecounter();
+#endif
   // ---- the CTB's commands, in decoding order ----
   RbtCmd nxt; if (n) nxt = cmds[0];
   for (uint32_t k = 0; k < n; k++) {
@@ -347,15 +427,17 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
       rc_tile_mark(t, c.x4, c.y4, c.a, c.b, !g->cip);
     } else if (c.type == RBT_CMD_TU) {
       const int fl = c.a, log2 = c.log2, intra = (fl & RBT_TU_INTRA) != 0;
-      rc_tile_tb(g, L, 0, x0, y0, log2, intra, c.b, fl & RBT_TU_CBF_Y, (fl & RBT_TU_TS_Y) != 0, c.d, c.qp[0]);
-      rc_tile_mark_sq(t, c.x4, c.y4, log2 - 2, intra || !g->cip);
+      rc_tile_tb(g, L, 0, x0, y0, log2, intra, c.b, fl & RBT_TU_CBF_Y, (fl & RBT_TU_TS_Y) != 0, c.d, c.qp[0], log2 - 2, c.x4, c.y4, intra || !g->cip);
       if (fl & RBT_TU_CHROMA) {
         const int xc = (log2 > 2 ? x0 : x0 - 4) >> 1, yc = (log2 > 2 ? y0 : y0 - 4) >> 1, l2c = log2 > 2 ? log2 - 1 : 2;
-        rc_tile_tb(g, L, 1, xc, yc, l2c, intra, c.c, fl & RBT_TU_CBF_CB, (fl & RBT_TU_TS_CB) != 0, c.d, c.qp[1]);
-        rc_tile_tb(g, L, 2, xc, yc, l2c, intra, c.c, fl & RBT_TU_CBF_CR, (fl & RBT_TU_TS_CR) != 0, c.d, c.qp[2]);
+        rc_tile_tb(g, L, 1, xc, yc, l2c, intra, c.c, fl & RBT_TU_CBF_CB, (fl & RBT_TU_TS_CB) != 0, c.d, c.qp[1], -1, 0, 0, 0);
+        rc_tile_tb(g, L, 2, xc, yc, l2c, intra, c.c, fl & RBT_TU_CBF_CR, (fl & RBT_TU_TS_CR) != 0, c.d, c.qp[2], -1, 0, 0, 0);
       }
     }
   }
+#ifdef RBT_PROFILE
+  unsigned long long q2_ = __builtin_readcyclecounter();
+#endif
   // ---- write the CTB back (clipped to the picture) ----
   for (int c = 0; c < 3; c++) {
     const int sh = c ? 1 : 0, nn = ctb >> sh, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, ox = cx >> sh, oy = cy >> sh, S = c ? RC_TS_C : RC_TS_Y;
@@ -363,4 +445,8 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
     const int lnn = g->log2_ctb - sh;
     RBT_PAR_FOR(i, nn * nn) { int x = i & (nn - 1), y = i >> lnn; if (ox + x < pw && oy + y < ph) p[(size_t)(oy + y) * pw + ox + x] = tile[(y + 1) * S + x + 1]; }
   }
+#ifdef RBT_PROFILE
+  if (RBT_LANE0 && frame_idx == 0 && ctb_addr == 190) printf("ctb %d: fetch %llu, cmds %llu (n %u), writeback %llu; TBs %llu: residual %llu, intra prep %llu, - %llu, predict+add %llu\n", ctb_addr, q1_ - q0_, q2_ - q1_, n,
+      __builtin_readcyclecounter() - q2_, L->prof[4], L->prof[0], L->prof[1], L->prof[2], L->prof[3]);
+#endif
 }

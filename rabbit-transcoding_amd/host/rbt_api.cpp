@@ -37,7 +37,7 @@ int rbt_create(rbt_ctx** ctx, int device, int world_rank, int world_size) {
   *ctx = c;
   return RBT_OK;
 }
-void rbt_destroy(rbt_ctx* ctx) { delete ctx; }
+void rbt_destroy(rbt_ctx* ctx) { if (ctx) { std::lock_guard<std::mutex> lk(g_mu); rbtk::dev_release_pool(); } delete ctx; }
 int rbt_get_stats(rbt_ctx* ctx, rbt_stats* out) { if (!ctx || !out) return RBT_ERR_PARAM; *out = ctx->stats; return RBT_OK; }
 
 int rbt_decode(rbt_ctx* ctx, const uint8_t* annexb, size_t n, int verify_md5, rbt_video* out) {

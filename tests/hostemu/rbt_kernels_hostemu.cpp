@@ -22,6 +22,7 @@ void set_stream(int) {}
 const char* dev_name() { return "host emulation (test only)"; }
 void* dev_alloc(size_t n) { return malloc(n ? n : 1); }
 void dev_free(void* p) { free(p); }
+void dev_release_pool() {}
 int h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); return 0; }
 int d2h(void* h, const void* d, size_t n) { memcpy(h, d, n); return 0; }
 int dev_memset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
