@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=1280)
     ap.add_argument("--cpu-sample", type=int, default=16, help="point-cloud frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--save-input", default=None, help="write the generated R5 input streams to this .npz file and exit")
+    ap.add_argument("--load-input", default=None, help="read the R5 input streams from a file written by --save-input (keeps the input "
+                    "encoder's kernels out of a profile of the transcode step); the file must come from the same size / seed")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -76,9 +79,16 @@ def main():
     w, h, n_pc = args.width, args.height, args.pc_frames
     geo, attr, occ = make_gof_maps(w, h, n_pc, 1051 + 1000 * rank)
     # R5 input in HM-like structure, produced by the GPU encoder (outside the timed region)
-    sg = ctx.encode(geo, w, h, 10, 16, gop=2, log2_ctb=6, rows_per_slice=0, md5_sei=0)
-    sa = ctx.encode(attr, w, h, 10, 22, gop=2, log2_ctb=6, rows_per_slice=0, md5_sei=0)
-    so = ctx.encode(occ, w // 2, h // 2, 8, 8, gop=1, lossless=1, log2_ctb=6, rows_per_slice=0, md5_sei=0)
+    if args.load_input:
+        z = np.load(args.load_input)
+        sg, sa, so = z["sg"].tobytes(), z["sa"].tobytes(), z["so"].tobytes()
+    else:
+        sg = ctx.encode(geo, w, h, 10, 16, gop=2, log2_ctb=6, rows_per_slice=0, md5_sei=0)
+        sa = ctx.encode(attr, w, h, 10, 22, gop=2, log2_ctb=6, rows_per_slice=0, md5_sei=0)
+        so = ctx.encode(occ, w // 2, h // 2, 8, 8, gop=1, lossless=1, log2_ctb=6, rows_per_slice=0, md5_sei=0)
+    if args.save_input:
+        np.savez(args.save_input, sg=np.frombuffer(sg, np.uint8), sa=np.frombuffer(sa, np.uint8), so=np.frombuffer(so, np.uint8))
+        return
     P = R.StreamParams
     params = [P(R.RBT_VIDEO_OCCUPANCY, 8, 4, 5, 1, 0, 0), P(R.RBT_VIDEO_GEOMETRY, 24, 4, 5, 1, 0, 0), P(R.RBT_VIDEO_ATTRIBUTE, 32, 4, 5, 1, 0, 0)]
     streams = [so, sg, sa]
