@@ -17,11 +17,6 @@
 #define RBT_TR(...) do { } while (0)
 #endif
 
-// wave-uniform copy of the slice header fields the parser needs (scalar members only)
-struct RbtSliceU {
-  int slice_type, qp, cb_qp_offset, cr_qp_offset, sao_luma, sao_chroma, temporal_mvp, cabac_init_flag, max_merge_cand, num_ref_idx, collocated_ref_idx, poc;
-};
-
 struct RbtParseLds {
   uint8_t cur_pm[256], cur_dm[256], cur_edges[256]; int8_t cur_qp[256], cur_ref[256]; int32_t cur_mv[256];   // current CTB, row stride 16 units
   uint8_t left_pm[16], left_dm[16]; int8_t left_ref[16]; int32_t left_mv[16];                                 // right column of the left CTB
@@ -33,11 +28,12 @@ struct RbtParseLds {
 };
 struct RbtParse {
   RBT_LDS_AS RbtParseLds* L; int ctb_x, ctb_y, left_ok, corner_ok, corner_pm, corner_dm, corner_ref, corner_mv;
-  RbtFrame* f; RbtSliceU sl; const RbtFrame* frames; int slice_idx;
+  RbtFrame* f; const RbtFrame* frames; int slice_idx;
+  // picture / slice parameters packed into a few wave-uniform words (read with pzc_* / pzs_*: one s_bfe each)
+  uint32_t c_dim, c_logs, c_flags, s_bits, s_qp; int s_poc;
   // wave-uniform copies of the picture's map pointers (SGPR pairs instead of a pointer load per access)
-  uint8_t *m_pm, *m_edges, *m_dm; int8_t *m_qp, *m_ref; int16_t* m_mv; int32_t* m_refpoc; uint16_t* m_cs; RbtSao* m_sao; RbtCmd* m_cmds; uint32_t* m_cnt;
+  RbtCmd* m_cmds;                       // the per-CTB map pointers are fetched from the RbtFrame where they are used (once per CTB)
   int16_t *m_coef0, *m_coef1, *m_coef2; int m_cap;
-  RbtStreamCfg cfg;
   RbtCabacDec c;
   int qp_y, qp_pred, qp_y_prev, is_cu_qp_delta_coded, cu_qp_delta_val;
   int ctb_addr; uint32_t n_cmds;
@@ -56,6 +52,47 @@ struct RbtParse {
 #endif
 };
 struct RbtMv { int x, y, ref; };
+// ---- packed parameter words ----
+// c_dim: w | h << 16.  c_logs: bit_depth 0..3, log2_ctb 4..6, log2_min_cb 7..9, log2_min_tb 10..12, log2_max_tb 13..15, th_depth_inter 16..18,
+// th_depth_intra 19..21, diff_cu_qp_delta_depth 22..23.  c_flags: amp 0, sao 1, strong_intra 2, tmvp 3, sign_hiding 4, cabac_init_present 5, cip 6,
+// transform_skip 7, cu_qp_delta 8, tq_bypass_enabled 9, cb_qp_offset 16..23 (signed), cr_qp_offset 24..31 (signed).
+// s_bits: slice_type 0..1, sao_luma 2, sao_chroma 3, temporal_mvp 4, cabac_init_flag 5, max_merge_cand 6..8, num_ref_idx 9..13, collocated_ref_idx 14..17.
+// s_qp: qp 0..7, cb_qp_offset 8..15, cr_qp_offset 16..23 (all signed).
+RBT_DEV int pzc_w(const RbtParse* s) { return (int)rbt_bfe<0, 16>(s->c_dim); }
+RBT_DEV int pzc_h(const RbtParse* s) { return (int)rbt_bfe<16, 16>(s->c_dim); }
+RBT_DEV int pzc_cw(const RbtParse* s) { return pzc_w(s) >> 1; }
+RBT_DEV int pzc_ch(const RbtParse* s) { return pzc_h(s) >> 1; }
+RBT_DEV int pzc_w4(const RbtParse* s) { return pzc_w(s) >> 2; }
+RBT_DEV int pzc_h4(const RbtParse* s) { return pzc_h(s) >> 2; }
+RBT_DEV int pzc_bit_depth(const RbtParse* s) { return (int)rbt_bfe<0, 4>(s->c_logs); }
+RBT_DEV int pzc_log2_ctb(const RbtParse* s) { return (int)rbt_bfe<4, 3>(s->c_logs); }
+RBT_DEV int pzc_log2_min_cb(const RbtParse* s) { return (int)rbt_bfe<7, 3>(s->c_logs); }
+RBT_DEV int pzc_log2_min_tb(const RbtParse* s) { return (int)rbt_bfe<10, 3>(s->c_logs); }
+RBT_DEV int pzc_log2_max_tb(const RbtParse* s) { return (int)rbt_bfe<13, 3>(s->c_logs); }
+RBT_DEV int pzc_th_depth_inter(const RbtParse* s) { return (int)rbt_bfe<16, 3>(s->c_logs); }
+RBT_DEV int pzc_th_depth_intra(const RbtParse* s) { return (int)rbt_bfe<19, 3>(s->c_logs); }
+RBT_DEV int pzc_diff_cu_qp_delta_depth(const RbtParse* s) { return (int)rbt_bfe<22, 2>(s->c_logs); }
+RBT_DEV int pzc_w_ctb(const RbtParse* s) { int L = pzc_log2_ctb(s); return (pzc_w(s) + (1 << L) - 1) >> L; }
+RBT_DEV int pzc_h_ctb(const RbtParse* s) { int L = pzc_log2_ctb(s); return (pzc_h(s) + (1 << L) - 1) >> L; }
+RBT_DEV int pzc_amp(const RbtParse* s) { return (int)rbt_bfe<0, 1>(s->c_flags); }
+RBT_DEV int pzc_sign_hiding(const RbtParse* s) { return (int)rbt_bfe<4, 1>(s->c_flags); }
+RBT_DEV int pzc_transform_skip(const RbtParse* s) { return (int)rbt_bfe<7, 1>(s->c_flags); }
+RBT_DEV int pzc_cu_qp_delta(const RbtParse* s) { return (int)rbt_bfe<8, 1>(s->c_flags); }
+RBT_DEV int pzc_tq_bypass_enabled(const RbtParse* s) { return (int)rbt_bfe<9, 1>(s->c_flags); }
+RBT_DEV int pzc_cb_qp_offset(const RbtParse* s) { return rbt_bfe_i<16, 8>(s->c_flags); }
+RBT_DEV int pzc_cr_qp_offset(const RbtParse* s) { return rbt_bfe_i<24, 8>(s->c_flags); }
+RBT_DEV int pzs_slice_type(const RbtParse* s) { return (int)rbt_bfe<0, 2>(s->s_bits); }
+RBT_DEV int pzs_sao_luma(const RbtParse* s) { return (int)rbt_bfe<2, 1>(s->s_bits); }
+RBT_DEV int pzs_sao_chroma(const RbtParse* s) { return (int)rbt_bfe<3, 1>(s->s_bits); }
+RBT_DEV int pzs_temporal_mvp(const RbtParse* s) { return (int)rbt_bfe<4, 1>(s->s_bits); }
+RBT_DEV int pzs_cabac_init_flag(const RbtParse* s) { return (int)rbt_bfe<5, 1>(s->s_bits); }
+RBT_DEV int pzs_max_merge_cand(const RbtParse* s) { return (int)rbt_bfe<6, 3>(s->s_bits); }
+RBT_DEV int pzs_num_ref_idx(const RbtParse* s) { return (int)rbt_bfe<9, 5>(s->s_bits); }
+RBT_DEV int pzs_collocated_ref_idx(const RbtParse* s) { return (int)rbt_bfe<14, 4>(s->s_bits); }
+RBT_DEV int pzs_qp(const RbtParse* s) { return rbt_bfe_i<0, 8>(s->s_qp); }
+RBT_DEV int pzs_cb_qp_offset(const RbtParse* s) { return rbt_bfe_i<8, 8>(s->s_qp); }
+RBT_DEV int pzs_cr_qp_offset(const RbtParse* s) { return rbt_bfe_i<16, 8>(s->s_qp); }
+RBT_DEV int pzs_poc(const RbtParse* s) { return s->s_poc; }
 RBT_DEV int pz_il(const RbtParse* s, int i) { return (s->il_packed >> (8 * i)) & 255; }   // luma intra modes of the (up to four) PUs, 8 bits each
 RBT_DEV void pz_set_il(RbtParse* s, int i, int v) { s->il_packed = (s->il_packed & ~(255 << (8 * i))) | (v << (8 * i)); }
 // Re-asserts that the scalar parser state is wave-uniform (see rbt_cd_assert_uniform): called where the syntax walkers
@@ -78,7 +115,7 @@ RBT_DEV void pz_assert_uniform(RbtParse* s) {
 // v_readlane and updated with a handful of lane-parallel VALU instructions per block (no LDS round trip, no sync).
 // LDS only carries the context from one CTB to the next (right column, bottom row over the picture width, corner); the
 // HBM maps are written once per CTB (pz_end_ctb) with plain stores that nobody waits for.
-RBT_DEV int pz_idx(const RbtParse* s, int x, int y) { return (y >> 2) * s->cfg.w4 + (x >> 2); }
+RBT_DEV int pz_idx(const RbtParse* s, int x, int y) { return (y >> 2) * pzc_w4(s) + (x >> 2); }
 #define PZ_RD8(reg, k) ((int)((RBT_VGET(reg, (k) >> 2) >> (((k) & 3) * 8)) & 255u))
 #define PZ_NB_BASE 256
 // handle of luma position (xn,yn): -1 = not available (outside the picture, other slice, not decoded yet);
@@ -93,7 +130,7 @@ RBT_DEV int pz_ld_mv(const RbtParse* s, int loc) {
   return (int)(j == 0 ? a : (j == 1 ? b : (j == 2 ? c : d)));
 }
 RBT_DEV int pz_loc(const RbtParse* s, int xn, int yn) {
-  const int dx = xn - s->ctb_x, dy = yn - s->ctb_y, ctb = 1 << s->cfg.log2_ctb;
+  const int dx = xn - s->ctb_x, dy = yn - s->ctb_y, ctb = 1 << pzc_log2_ctb(s);
   int loc;
   if (dx < -1 || dy < -1) return -1;
   if (dy < 0) { loc = (dx + 4) >> 2; if (loc > (ctb >> 2) + 1) return -1; loc += PZ_NB_BASE; }
@@ -185,8 +222,8 @@ RBT_DEV void pz_fill_pu(RbtParse* s, int x, int y, int w, int h, int mode, int r
 }
 // start of a CTB: nothing of it is decoded yet; fetch the surrounding units from the LDS line buffers
 RBT_DEV void pz_begin_ctb(RbtParse* s, int rx, int ry) {
-  const RbtStreamCfg* g = &s->cfg; RBT_LDS_AS RbtParseLds* L = s->L;
-  s->ctb_x = rx << g->log2_ctb; s->ctb_y = ry << g->log2_ctb;
+  RBT_LDS_AS RbtParseLds* L = s->L;
+  s->ctb_x = rx << pzc_log2_ctb(s); s->ctb_y = ry << pzc_log2_ctb(s);
   const int cx4 = s->ctb_x >> 2;
   RBT_VFOR(p, 64) {
     RBT_V(s->r_pm, p) = PZ_REP4(RBT_MODE_NONE); RBT_V(s->r_dm, p) = PZ_REP4(1); RBT_V(s->r_ed, p) = 0; RBT_V(s->r_qp, p) = 0; RBT_V(s->r_ref, p) = 0xFFFFFFFFu;
@@ -195,7 +232,7 @@ RBT_DEV void pz_begin_ctb(RbtParse* s, int rx, int ry) {
     if (p == 0) { if (s->corner_ok) { pm = (uint32_t)s->corner_pm; dm = (uint32_t)s->corner_dm; ref = (uint32_t)s->corner_ref & 255u; mv = (uint32_t)s->corner_mv; } }
     else if (p <= 17) {
       const int xa4 = cx4 - 1 + p;
-      if (ry > 0 && xa4 < g->w4 && L->above_slice[(xa4 << 2) >> g->log2_ctb] == s->slice_idx) { pm = L->above_pm[xa4]; dm = L->above_dm[xa4]; ref = (uint8_t)L->above_ref[xa4]; mv = (uint32_t)L->above_mv[xa4]; }
+      if (ry > 0 && xa4 < pzc_w4(s) && L->above_slice[(xa4 << 2) >> pzc_log2_ctb(s)] == s->slice_idx) { pm = L->above_pm[xa4]; dm = L->above_dm[xa4]; ref = (uint8_t)L->above_ref[xa4]; mv = (uint32_t)L->above_mv[xa4]; }
     } else if (p >= 32 && p < 48) {
       if (s->left_ok) { pm = L->left_pm[p - 32]; dm = L->left_dm[p - 32]; ref = (uint8_t)L->left_ref[p - 32]; mv = (uint32_t)L->left_mv[p - 32]; }
     }
@@ -204,8 +241,8 @@ RBT_DEV void pz_begin_ctb(RbtParse* s, int rx, int ry) {
 }
 // end of a CTB: spill its units to LDS, write them to the HBM maps, then roll the line buffers
 RBT_DEV void pz_end_ctb(RbtParse* s, int rx, int ry) {
-  const RbtStreamCfg* g = &s->cfg; RBT_LDS_AS RbtParseLds* L = s->L;
-  int cx = s->ctb_x, cy = s->ctb_y, ctb = 1 << g->log2_ctb, n4 = ctb >> 2;
+  RBT_LDS_AS RbtParseLds* L = s->L;
+  int cx = s->ctb_x, cy = s->ctb_y, ctb = 1 << pzc_log2_ctb(s), n4 = ctb >> 2;
   RBT_VFOR(p, 64) {
     const uint32_t pm = RBT_V(s->r_pm, p), dm = RBT_V(s->r_dm, p), ed = RBT_V(s->r_ed, p), qp = RBT_V(s->r_qp, p), rf = RBT_V(s->r_ref, p);
     for (int j = 0; j < 4; j++) {
@@ -216,28 +253,30 @@ RBT_DEV void pz_end_ctb(RbtParse* s, int rx, int ry) {
     L->cur_mv[4 * p] = (int32_t)RBT_V(s->r_mv0, p); L->cur_mv[4 * p + 1] = (int32_t)RBT_V(s->r_mv1, p); L->cur_mv[4 * p + 2] = (int32_t)RBT_V(s->r_mv2, p); L->cur_mv[4 * p + 3] = (int32_t)RBT_V(s->r_mv3, p);
   }
   RBT_SYNC_LDS();
+  // map pointers are read from the picture record here, once per CTB, instead of living in registers for the whole slice
+  uint8_t *m_pm = s->f->pm, *m_dm = s->f->dm, *m_edges = s->f->edges; int8_t *m_qp = s->f->qp, *m_ref = s->f->ref; int16_t* m_mv = s->f->mv; int32_t* m_refpoc = s->f->refpoc;
   RBT_PAR_FOR(u, n4 * n4) {
     int ux = u % n4, uy = u / n4, x = cx + ux * 4, y = cy + uy * 4;
-    if (x < g->w && y < g->h) {
-      int k = uy * 16 + ux, gk = (y >> 2) * g->w4 + (x >> 2), pm = L->cur_pm[k], ref = L->cur_ref[k], mv = L->cur_mv[k];
-      s->m_pm[gk] = (uint8_t)pm; s->m_dm[gk] = L->cur_dm[k]; s->m_edges[gk] = L->cur_edges[k]; s->m_qp[gk] = L->cur_qp[k]; s->m_ref[gk] = (int8_t)ref;
-      s->m_mv[2 * gk] = (int16_t)(mv & 0xFFFF); s->m_mv[2 * gk + 1] = (int16_t)(mv >> 16);
+    if (x < pzc_w(s) && y < pzc_h(s)) {
+      int k = uy * 16 + ux, gk = (y >> 2) * pzc_w4(s) + (x >> 2), pm = L->cur_pm[k], ref = L->cur_ref[k], mv = L->cur_mv[k];
+      m_pm[gk] = (uint8_t)pm; m_dm[gk] = L->cur_dm[k]; m_edges[gk] = L->cur_edges[k]; m_qp[gk] = L->cur_qp[k]; m_ref[gk] = (int8_t)ref;
+      m_mv[2 * gk] = (int16_t)(mv & 0xFFFF); m_mv[2 * gk + 1] = (int16_t)(mv >> 16);
       int mode = pm & RBT_PM_MODE_MASK;
-      s->m_refpoc[gk] = (mode == RBT_MODE_INTER || mode == RBT_MODE_SKIP) ? s->L->ref_poc[ref < 0 ? 0 : ref] : RBT_NO_REFPOC;
+      m_refpoc[gk] = (mode == RBT_MODE_INTER || mode == RBT_MODE_SKIP) ? s->L->ref_poc[ref < 0 ? 0 : ref] : RBT_NO_REFPOC;
     }
   }
   // above-left corner of the NEXT CTB = last unit of the old above row under this CTB
-  int last = rbt_min(cx + ctb, g->w) / 4 - 1;
+  int last = rbt_min(cx + ctb, pzc_w(s)) / 4 - 1;
   int c_ok = ry > 0 && L->above_slice[rx] == s->slice_idx;
   int c_pm = L->above_pm[last], c_dm = L->above_dm[last], c_ref = L->above_ref[last], c_mv = L->above_mv[last];
   RBT_SYNC_LDS();
   s->corner_ok = c_ok; s->corner_pm = c_pm; s->corner_dm = c_dm; s->corner_ref = c_ref; s->corner_mv = c_mv;
-  int rows = rbt_min(ctb, g->h - cy) >> 2, cols = rbt_min(ctb, g->w - cx) >> 2;
+  int rows = rbt_min(ctb, pzc_h(s) - cy) >> 2, cols = rbt_min(ctb, pzc_w(s) - cx) >> 2;
   RBT_PAR_FOR(i, cols) { int k = (rows - 1) * 16 + i, a = (cx >> 2) + i; L->above_pm[a] = L->cur_pm[k]; L->above_dm[a] = L->cur_dm[k]; L->above_ref[a] = L->cur_ref[k]; L->above_mv[a] = L->cur_mv[k]; }
   RBT_PAR_FOR(i, 16) { int k = i * 16 + cols - 1; L->left_pm[i] = i < rows ? L->cur_pm[k] : RBT_MODE_NONE; L->left_dm[i] = L->cur_dm[k]; L->left_ref[i] = L->cur_ref[k]; L->left_mv[i] = L->cur_mv[k]; }
   if (RBT_LANE0) L->above_slice[rx] = (uint16_t)s->slice_idx;
-  s->left_ok = rx + 1 < g->w_ctb;
-  if (rx + 1 >= g->w_ctb) s->corner_ok = 0;
+  s->left_ok = rx + 1 < pzc_w_ctb(s);
+  if (rx + 1 >= pzc_w_ctb(s)) s->corner_ok = 0;
   RBT_SYNC_LDS();
 }
 RBT_DEV void pz_emit(RbtParse* s, const RbtCmd& cmd) {
@@ -256,21 +295,21 @@ RBT_DEV void pz_sao_to_lds(RBT_LDS_AS RbtSao* l, const RbtSao* d) {
 }
 // ------------------------------------------------------------------------------------------------ SAO (7.3.8.3)
 RBT_DEV void pz_sao(RbtParse* s, int rx, int ry) {
-  RbtCabacDec* c = &s->c; const RbtSliceU* sl = &s->sl;
+  RbtCabacDec* c = &s->c;
   pz_assert_uniform(s); rx = RBT_UNI(rx); ry = RBT_UNI(ry);
   RbtSao p; for (int i = 0; i < 3; i++) { p.type[i] = p.band_pos[i] = p.eo_class[i] = 0; for (int k = 0; k < 4; k++) p.offset[i][k] = 0; }
   p.pad[0] = p.pad[1] = p.pad[2] = 0;
-  int wc = s->cfg.w_ctb;
-  if (sl->sao_luma || sl->sao_chroma) {
+  int wc = pzc_w_ctb(s);
+  if (pzs_sao_luma(s) || pzs_sao_chroma(s)) {
     int merge_left = 0, merge_up = 0;
     if (rx > 0 && s->left_ok) merge_left = rbt_cd_bin(c, CTX_SAO_MERGE);
     if (ry > 0 && !merge_left && s->L->above_slice[rx] == s->slice_idx) merge_up = rbt_cd_bin(c, CTX_SAO_MERGE);
     if (merge_left) pz_sao_from_lds(&p, &s->L->sao_left);
     else if (merge_up) pz_sao_from_lds(&p, &s->L->sao_above[rx]);
     else {
-      int bd = s->cfg.bit_depth, cmax = (1 << (rbt_min(bd, 10) - 5)) - 1;
+      int bd = pzc_bit_depth(s), cmax = (1 << (rbt_min(bd, 10) - 5)) - 1;
       for (int ci = 0; ci < 3; ci++) {
-        if ((ci == 0 && !sl->sao_luma) || (ci > 0 && !sl->sao_chroma)) continue;
+        if ((ci == 0 && !pzs_sao_luma(s)) || (ci > 0 && !pzs_sao_chroma(s))) continue;
         if (ci == 2) p.type[2] = p.type[1];
         else { int t = 0; if (rbt_cd_bin(c, CTX_SAO_TYPE)) t = rbt_cd_bypass(c) ? 2 : 1; p.type[ci] = (uint8_t)t; }
         if (!p.type[ci]) continue;
@@ -289,7 +328,7 @@ RBT_DEV void pz_sao(RbtParse* s, int rx, int ry) {
       }
     }
   }
-  if (RBT_LANE0) { s->m_sao[ry * wc + rx] = p; pz_sao_to_lds(&s->L->sao_left, &p); pz_sao_to_lds(&s->L->sao_above[rx], &p); }
+  if (RBT_LANE0) { s->f->sao[ry * wc + rx] = p; pz_sao_to_lds(&s->L->sao_left, &p); pz_sao_to_lds(&s->L->sao_above[rx], &p); }
   RBT_SYNC_LDS();
 }
 
@@ -306,8 +345,8 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
   x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); log2 = RBT_UNI(log2); scan_idx = RBT_UNI(scan_idx);
   const uint64_t ps = pz_scan4_const(scan_idx);
 #define PZ_POS(n) ((int)((ps >> (4 * (n))) & 15))
-  int16_t* plane = rbt_uni_ptr(c_idx == 0 ? s->m_coef0 : (c_idx == 1 ? s->m_coef1 : s->m_coef2)); int pst = RBT_UNI(c_idx ? s->cfg.cw : s->cfg.w);
-  const int tq_bypass = RBT_UNI(s->cu_tq_bypass), sdh_on = RBT_UNI(s->cfg.sign_hiding), ts_on = RBT_UNI(s->cfg.transform_skip);
+  int16_t* plane = rbt_uni_ptr(c_idx == 0 ? s->m_coef0 : (c_idx == 1 ? s->m_coef1 : s->m_coef2)); int pst = RBT_UNI(c_idx ? pzc_cw(s) : pzc_w(s));
+  const int tq_bypass = RBT_UNI(s->cu_tq_bypass), sdh_on = RBT_UNI(pzc_sign_hiding(s)), ts_on = RBT_UNI(pzc_transform_skip(s));
   int ts_flag = 0;
   if (ts_on && !tq_bypass && log2 <= 2) ts_flag = rbt_cd_bin(c, CTX_TRANSFORM_SKIP + (c_idx ? 1 : 0));
   const int chroma = c_idx != 0;
@@ -436,9 +475,9 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
 }
 
 // ------------------------------------------------------------------------------------------------ QP
-RBT_DEV int pz_wrap_qp(const RbtParse* s, int v) { int bdo = 6 * (s->cfg.bit_depth - 8); return ((v + 52 + 2 * bdo) % (52 + bdo)) - bdo; }
+RBT_DEV int pz_wrap_qp(const RbtParse* s, int v) { int bdo = 6 * (pzc_bit_depth(s) - 8); return ((v + 52 + 2 * bdo) % (52 + bdo)) - bdo; }
 RBT_DEV void pz_start_qg(RbtParse* s, int xqg, int yqg) {
-  int ctb_mask = ~((1 << s->cfg.log2_ctb) - 1);
+  int ctb_mask = ~((1 << pzc_log2_ctb(s)) - 1);
   s->qp_y_prev = s->qp_y; s->is_cu_qp_delta_coded = 0; s->cu_qp_delta_val = 0;
   int qa = s->qp_y_prev, qb = s->qp_y_prev;
   if (xqg > 0 && ((xqg - 1) & ctb_mask) == (xqg & ctb_mask) && pz_avail(s, xqg - 1, yqg)) qa = (int8_t)PZ_RD8(s->r_qp, pz_cur(s, xqg - 1, yqg));
@@ -446,8 +485,8 @@ RBT_DEV void pz_start_qg(RbtParse* s, int xqg, int yqg) {
   s->qp_pred = (qa + qb + 1) >> 1;
 }
 RBT_DEV int pz_chroma_qp(const RbtParse* s, int c_idx) {
-  int off = c_idx == 1 ? s->cfg.cb_qp_offset + s->sl.cb_qp_offset : s->cfg.cr_qp_offset + s->sl.cr_qp_offset;
-  int bdo = 6 * (s->cfg.bit_depth - 8);
+  int off = c_idx == 1 ? pzc_cb_qp_offset(s) + pzs_cb_qp_offset(s) : pzc_cr_qp_offset(s) + pzs_cr_qp_offset(s);
+  int bdo = 6 * (pzc_bit_depth(s) - 8);
   int qpi = rbt_clip3(-bdo, 57, s->qp_y + off);
   return (qpi < 0 ? qpi : rbt_chroma_qp(qpi)) + bdo;
 }
@@ -468,7 +507,7 @@ RBT_DEV void pz_transform_unit(RbtParse* s, int x0, int y0, int xb, int yb, int 
   pz_assert_uniform(s);
   x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); xb = RBT_UNI(xb); yb = RBT_UNI(yb); log2 = RBT_UNI(log2); blk = RBT_UNI(blk); cbf_luma = RBT_UNI(cbf_luma); cbf_cb = RBT_UNI(cbf_cb); cbf_cr = RBT_UNI(cbf_cr);
   int N = 1 << log2;
-  if ((cbf_luma || cbf_cb || cbf_cr) && s->cfg.cu_qp_delta && !s->is_cu_qp_delta_coded) {
+  if ((cbf_luma || cbf_cb || cbf_cr) && pzc_cu_qp_delta(s) && !s->is_cu_qp_delta_coded) {
     int v = 0; while (v < 5 && rbt_cd_bin(c, CTX_CU_QP_DELTA + (v ? 1 : 0))) v++;
     if (v == 5) { int k = 0; while (k < 16 && rbt_cd_bypass(c)) { v += 1 << k; k++; } v += (int)rbt_cd_bypass_n(c, k); }
     if (v && rbt_cd_bypass(c)) v = -v;
@@ -481,7 +520,7 @@ RBT_DEV void pz_transform_unit(RbtParse* s, int x0, int y0, int xb, int yb, int 
   if (s->cu_part_mode == RBT_PART_NxN && intra) part = ((y0 - s->cu_y) >= (1 << (s->cu_log2 - 1)) ? 2 : 0) + ((x0 - s->cu_x) >= (1 << (s->cu_log2 - 1)) ? 1 : 0);
   pz_fill_tu(s, x0, y0, N, cbf_luma);
   int chroma_here = log2 > 2 || blk == 3;
-  RbtCmd cmd; cmd.type = RBT_CMD_TU; cmd.x4 = (uint8_t)((x0 & ((1 << s->cfg.log2_ctb) - 1)) >> 2); cmd.y4 = (uint8_t)((y0 & ((1 << s->cfg.log2_ctb) - 1)) >> 2);
+  RbtCmd cmd; cmd.type = RBT_CMD_TU; cmd.x4 = (uint8_t)((x0 & ((1 << pzc_log2_ctb(s)) - 1)) >> 2); cmd.y4 = (uint8_t)((y0 & ((1 << pzc_log2_ctb(s)) - 1)) >> 2);
   cmd.log2 = (uint8_t)log2; cmd.b = (uint8_t)pz_il(s, part); cmd.c = (uint8_t)s->intra_chroma; cmd.d = (uint8_t)s->cu_tq_bypass; cmd.mvx = cmd.mvy = 0; cmd.pad = 0;
   int flags = (cbf_luma ? RBT_TU_CBF_Y : 0) | (intra ? RBT_TU_INTRA : 0) | (chroma_here ? RBT_TU_CHROMA : 0);
   if (chroma_here) flags |= (cbf_cb ? RBT_TU_CBF_CB : 0) | (cbf_cr ? RBT_TU_CBF_CR : 0);
@@ -493,7 +532,7 @@ RBT_DEV void pz_transform_unit(RbtParse* s, int x0, int y0, int xb, int yb, int 
     if (cbf_cr && !s->error && pz_residual(s, 2, xc, yc, l2c, sc)) flags |= RBT_TU_TS_CR;
   }
   cmd.a = (uint8_t)flags;
-  cmd.qp[0] = (int8_t)(s->qp_y + 6 * (s->cfg.bit_depth - 8)); cmd.qp[1] = (int8_t)pz_chroma_qp(s, 1); cmd.qp[2] = (int8_t)pz_chroma_qp(s, 2);
+  cmd.qp[0] = (int8_t)(s->qp_y + 6 * (pzc_bit_depth(s) - 8)); cmd.qp[1] = (int8_t)pz_chroma_qp(s, 1); cmd.qp[2] = (int8_t)pz_chroma_qp(s, 2);
   pz_emit(s, cmd);
 #ifdef RBT_PROFILE
   s->t_tu += __builtin_readcyclecounter() - ttu_;
@@ -515,11 +554,11 @@ RBT_DEV void pz_transform_tree(RbtParse* s, int x0, int y0, int xb0, int yb0, in
     lvl = RBT_UNI(lvl); x = RBT_UNI(x); y = RBT_UNI(y); lg = RBT_UNI(lg); states = (uint32_t)RBT_UNI(states); flags = (uint32_t)RBT_UNI(flags);
     int st = (int)((states >> (4 * lvl)) & 15u);
     if (st == 15) {
-      int inter_split = s->cfg.th_depth_inter == 0 && !intra && s->cu_part_mode != RBT_PART_2Nx2N && lvl == 0;
+      int inter_split = pzc_th_depth_inter(s) == 0 && !intra && s->cu_part_mode != RBT_PART_2Nx2N && lvl == 0;
       int split;
-      if (lg <= s->cfg.log2_max_tb && lg > s->cfg.log2_min_tb && lvl < s->max_trafo_depth && !(intra_split && lvl == 0))
+      if (lg <= pzc_log2_max_tb(s) && lg > pzc_log2_min_tb(s) && lvl < s->max_trafo_depth && !(intra_split && lvl == 0))
         split = rbt_cd_bin(c, CTX_SPLIT_TRANSFORM + 5 - lg);
-      else split = (lg > s->cfg.log2_max_tb || (intra_split && lvl == 0) || inter_split) ? 1 : 0;
+      else split = (lg > pzc_log2_max_tb(s) || (intra_split && lvl == 0) || inter_split) ? 1 : 0;
       int ppcb = (int)((flags >> (2 * lvl)) & 1u), ppcr = (int)((flags >> (2 * lvl + 1)) & 1u);
       int cbf_cb = 0, cbf_cr = 0;
       if (lg > 2) {
@@ -564,18 +603,17 @@ RBT_DEV int pz_scale_mv(int mv, int tb, int td) {
   return rbt_clip3(-32768, 32767, (p < 0 ? -1 : 1) * ((rbt_abs(p) + 127) >> 8));
 }
 RBT_DEV int pz_temporal(const RbtParse* s, int xpb, int ypb, int w, int h, int ref_idx, RbtMv* out) {
-  const RbtSliceU* sl = &s->sl;
-  if (!sl->temporal_mvp) return 0;
-  const RbtFrame* col = &s->frames[s->L->ref_frame[sl->collocated_ref_idx]];
+  if (!pzs_temporal_mvp(s)) return 0;
+  const RbtFrame* col = &s->frames[s->L->ref_frame[pzs_collocated_ref_idx(s)]];
   int cx[2] = {xpb + w, xpb + (w >> 1)}, cy[2] = {ypb + h, ypb + (h >> 1)};
   for (int k = 0; k < 2; k++) {
     int x = cx[k], y = cy[k];
-    if (k == 0 && ((ypb >> s->cfg.log2_ctb) != (y >> s->cfg.log2_ctb) || x >= s->cfg.w || y >= s->cfg.h)) continue;
+    if (k == 0 && ((ypb >> pzc_log2_ctb(s)) != (y >> pzc_log2_ctb(s)) || x >= pzc_w(s) || y >= pzc_h(s))) continue;
     x = (x >> 4) << 4; y = (y >> 4) << 4;
-    int i = (y >> 2) * s->cfg.w4 + (x >> 2);
+    int i = (y >> 2) * pzc_w4(s) + (x >> 2);
     int cm = col->pm[i] & RBT_PM_MODE_MASK;
     if (cm == RBT_MODE_INTRA || cm == RBT_MODE_NONE) continue;
-    int td = col->poc - col->refpoc[i], tb = sl->poc - s->L->ref_poc[ref_idx];
+    int td = col->poc - col->refpoc[i], tb = pzs_poc(s) - s->L->ref_poc[ref_idx];
     int mx = col->mv[2 * i], my = col->mv[2 * i + 1];
     if (td != tb && td != 0) { mx = pz_scale_mv(mx, tb, td); my = pz_scale_mv(my, tb, td); }
     out->x = mx; out->y = my; out->ref = ref_idx;
@@ -584,7 +622,7 @@ RBT_DEV int pz_temporal(const RbtParse* s, int xpb, int ypb, int w, int h, int r
   return 0;
 }
 RBT_DEV RbtMv pz_merge(const RbtParse* s, int xpb, int ypb, int w, int h, int part_idx, int merge_idx) {
-  int pm = s->cu_part_mode, maxc = s->sl.max_merge_cand;
+  int pm = s->cu_part_mode, maxc = pzs_max_merge_cand(s);
   RbtMv list[6]; int n = 0;
   RbtMv ca1 = {0, 0, 0}, cb1 = {0, 0, 0};
   int a1 = pz_pu_avail(s, xpb - 1, ypb + h - 1) && !((pm == RBT_PART_Nx2N || pm == RBT_PART_nLx2N || pm == RBT_PART_nRx2N) && part_idx == 1);
@@ -601,14 +639,13 @@ RBT_DEV RbtMv pz_merge(const RbtParse* s, int xpb, int ypb, int w, int h, int pa
   if (n > maxc) n = maxc;
   if (n < maxc) { RbtMv t; if (pz_temporal(s, xpb, ypb, w, h, 0, &t)) list[n++] = t; }
   int zero_idx = 0;
-  while (n < maxc) { RbtMv z = {0, 0, zero_idx < s->sl.num_ref_idx ? zero_idx : 0}; list[n++] = z; zero_idx++; }
+  while (n < maxc) { RbtMv z = {0, 0, zero_idx < pzs_num_ref_idx(s) ? zero_idx : 0}; list[n++] = z; zero_idx++; }
   RbtMv r = list[0];
   for (int i = 1; i < 5; i++) if (i == merge_idx) r = list[i];     // avoid dynamic private-array indexing
   return r;
 }
 RBT_DEV RbtMv pz_amvp(const RbtParse* s, int xpb, int ypb, int w, int h, int ref_idx, int mvp_flag) {
-  const RbtSliceU* sl = &s->sl;
-  int tgt = s->L->ref_poc[ref_idx], cur = sl->poc;
+  int tgt = s->L->ref_poc[ref_idx], cur = pzs_poc(s);
   int xa[2] = {xpb - 1, xpb - 1}, ya[2] = {ypb + h, ypb + h - 1};
   int xb[3] = {xpb + w, xpb + w - 1, xpb - 1}, yb[3] = {ypb - 1, ypb - 1, ypb - 1};
   int ava[2], avb[3];
@@ -644,7 +681,7 @@ RBT_DEV int pz_mvd_comp(RbtCabacDec* c, int gt0, int gt1) {
   return rbt_cd_bypass(c) ? -v : v;
 }
 RBT_DEV void pz_prediction_unit(RbtParse* s, int x0, int y0, int w, int h, int part_idx, int skip) {
-  RbtCabacDec* c = &s->c; const RbtSliceU* sl = &s->sl;
+  RbtCabacDec* c = &s->c;
   pz_assert_uniform(s);
   x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); w = RBT_UNI(w); h = RBT_UNI(h); part_idx = RBT_UNI(part_idx); skip = RBT_UNI(skip);
   RbtMv mv;
@@ -652,12 +689,12 @@ RBT_DEV void pz_prediction_unit(RbtParse* s, int x0, int y0, int w, int h, int p
   s->last_pu_merge = merge;
   if (merge) {
     int idx = 0;
-    if (sl->max_merge_cand > 1) { idx = rbt_cd_bin(c, CTX_MERGE_IDX); if (idx) while (idx < sl->max_merge_cand - 1 && rbt_cd_bypass(c)) idx++; }
+    if (pzs_max_merge_cand(s) > 1) { idx = rbt_cd_bin(c, CTX_MERGE_IDX); if (idx) while (idx < pzs_max_merge_cand(s) - 1 && rbt_cd_bypass(c)) idx++; }
     mv = pz_merge(s, x0, y0, w, h, part_idx, idx);
   } else {
     int ref_idx = 0;
-    if (sl->num_ref_idx > 1) {
-      int mx = sl->num_ref_idx - 1;
+    if (pzs_num_ref_idx(s) > 1) {
+      int mx = pzs_num_ref_idx(s) - 1;
       while (ref_idx < mx) { int b = ref_idx < 2 ? rbt_cd_bin(c, CTX_REF_IDX + ref_idx) : rbt_cd_bypass(c); if (!b) break; ref_idx++; }
     }
     int gx0 = rbt_cd_bin(c, CTX_MVD_GT0), gy0 = rbt_cd_bin(c, CTX_MVD_GT0);
@@ -667,9 +704,9 @@ RBT_DEV void pz_prediction_unit(RbtParse* s, int x0, int y0, int w, int h, int p
     mv = pz_amvp(s, x0, y0, w, h, ref_idx, mvp);
     mv.x = (int16_t)(mv.x + dx); mv.y = (int16_t)(mv.y + dy);
   }
-  if (mv.ref < 0 || mv.ref >= sl->num_ref_idx) { s->error = 5; return; }
+  if (mv.ref < 0 || mv.ref >= pzs_num_ref_idx(s)) { s->error = 5; return; }
   pz_fill_pu(s, x0, y0, w, h, skip ? RBT_MODE_SKIP : RBT_MODE_INTER, mv.ref, ((uint32_t)(uint16_t)mv.y << 16) | (uint16_t)mv.x);
-  RbtCmd cmd; cmd.type = RBT_CMD_PU; cmd.x4 = (uint8_t)((x0 & ((1 << s->cfg.log2_ctb) - 1)) >> 2); cmd.y4 = (uint8_t)((y0 & ((1 << s->cfg.log2_ctb) - 1)) >> 2);
+  RbtCmd cmd; cmd.type = RBT_CMD_PU; cmd.x4 = (uint8_t)((x0 & ((1 << pzc_log2_ctb(s)) - 1)) >> 2); cmd.y4 = (uint8_t)((y0 & ((1 << pzc_log2_ctb(s)) - 1)) >> 2);
   cmd.log2 = 0; cmd.a = (uint8_t)(w >> 2); cmd.b = (uint8_t)(h >> 2); cmd.c = (uint8_t)mv.ref; cmd.d = 0; cmd.mvx = (int16_t)mv.x; cmd.mvy = (int16_t)mv.y;
   cmd.qp[0] = cmd.qp[1] = cmd.qp[2] = 0; cmd.pad = 0;
   pz_emit(s, cmd);
@@ -680,14 +717,14 @@ RBT_DEV void pz_intra_mpm(const RbtParse* s, int xp, int yp, int cand[3]) {
   int ca = 1, cb = 1;
   int nl = pz_nb(s, xp - 1, yp);
   if (nl >= 0 && (nl & RBT_PM_MODE_MASK) == RBT_MODE_INTRA) ca = (nl >> 8) & 63;
-  if (((yp - 1) >> s->cfg.log2_ctb) == (yp >> s->cfg.log2_ctb)) { int na = pz_nb(s, xp, yp - 1); if (na >= 0 && (na & RBT_PM_MODE_MASK) == RBT_MODE_INTRA) cb = (na >> 8) & 63; }
+  if (((yp - 1) >> pzc_log2_ctb(s)) == (yp >> pzc_log2_ctb(s))) { int na = pz_nb(s, xp, yp - 1); if (na >= 0 && (na & RBT_PM_MODE_MASK) == RBT_MODE_INTRA) cb = (na >> 8) & 63; }
   if (ca == cb) {
     if (ca < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
     else { cand[0] = ca; cand[1] = 2 + ((ca + 29) % 32); cand[2] = 2 + ((ca - 2 + 1) % 32); }
   } else { cand[0] = ca; cand[1] = cb; cand[2] = (ca != 0 && cb != 0) ? 0 : ((ca != 1 && cb != 1) ? 1 : 26); }
 }
 RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
-  RbtCabacDec* c = &s->c; const RbtStreamCfg* cfg = &s->cfg;
+  RbtCabacDec* c = &s->c;
 #ifdef RBT_PROFILE
   unsigned long long tcu_ = __builtin_readcyclecounter(); s->n_cu++;
 #endif
@@ -695,10 +732,10 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
   x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); log2 = RBT_UNI(log2); depth = RBT_UNI(depth);
   int N = 1 << log2;
   s->cu_x = x0; s->cu_y = y0; s->cu_log2 = log2; s->cu_tq_bypass = 0; s->cu_part_mode = RBT_PART_2Nx2N; s->cu_pred_mode = RBT_MODE_INTRA;
-  if (cfg->cu_qp_delta) s->qp_y = pz_wrap_qp(s, s->qp_pred + s->cu_qp_delta_val);
-  if (cfg->tq_bypass_enabled) s->cu_tq_bypass = rbt_cd_bin(c, CTX_CU_TQ_BYPASS);
+  if (pzc_cu_qp_delta(s)) s->qp_y = pz_wrap_qp(s, s->qp_pred + s->cu_qp_delta_val);
+  if (pzc_tq_bypass_enabled(s)) s->cu_tq_bypass = rbt_cd_bin(c, CTX_CU_TQ_BYPASS);
   int skip = 0;
-  if (s->sl.slice_type != RBT_SLICE_I) {
+  if (pzs_slice_type(s) != RBT_SLICE_I) {
     int nl = pz_nb(s, x0 - 1, y0), na = pz_nb(s, x0, y0 - 1);
     int cl = nl >= 0 && (nl & RBT_PM_MODE_MASK) == RBT_MODE_SKIP, ca = na >= 0 && (na & RBT_PM_MODE_MASK) == RBT_MODE_SKIP;
     skip = rbt_cd_bin(c, CTX_CU_SKIP + cl + ca);
@@ -711,17 +748,17 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
     RBT_SYNC_LDS();
     return;
   }
-  if (s->sl.slice_type != RBT_SLICE_I) s->cu_pred_mode = rbt_cd_bin(c, CTX_PRED_MODE) ? RBT_MODE_INTRA : RBT_MODE_INTER;
+  if (pzs_slice_type(s) != RBT_SLICE_I) s->cu_pred_mode = rbt_cd_bin(c, CTX_PRED_MODE) ? RBT_MODE_INTRA : RBT_MODE_INTER;
   if (s->cu_pred_mode == RBT_MODE_INTRA) {
-    if (log2 == cfg->log2_min_cb) s->cu_part_mode = rbt_cd_bin(c, CTX_PART_MODE) ? RBT_PART_2Nx2N : RBT_PART_NxN;
-    if (s->cu_part_mode == RBT_PART_NxN && log2 == 3 && cfg->log2_min_tb > 2) { s->error = 6; return; }
+    if (log2 == pzc_log2_min_cb(s)) s->cu_part_mode = rbt_cd_bin(c, CTX_PART_MODE) ? RBT_PART_2Nx2N : RBT_PART_NxN;
+    if (s->cu_part_mode == RBT_PART_NxN && log2 == 3 && pzc_log2_min_tb(s) > 2) { s->error = 6; return; }
   } else {
     if (rbt_cd_bin(c, CTX_PART_MODE)) s->cu_part_mode = RBT_PART_2Nx2N;
-    else if (log2 == cfg->log2_min_cb) {
+    else if (log2 == pzc_log2_min_cb(s)) {
       if (log2 == 3) s->cu_part_mode = rbt_cd_bin(c, CTX_PART_MODE + 1) ? RBT_PART_2NxN : RBT_PART_Nx2N;
       else if (rbt_cd_bin(c, CTX_PART_MODE + 1)) s->cu_part_mode = RBT_PART_2NxN;
       else s->cu_part_mode = rbt_cd_bin(c, CTX_PART_MODE + 2) ? RBT_PART_Nx2N : RBT_PART_NxN;
-    } else if (!cfg->amp) s->cu_part_mode = rbt_cd_bin(c, CTX_PART_MODE + 1) ? RBT_PART_2NxN : RBT_PART_Nx2N;
+    } else if (!pzc_amp(s)) s->cu_part_mode = rbt_cd_bin(c, CTX_PART_MODE + 1) ? RBT_PART_2NxN : RBT_PART_Nx2N;
     else {
       int hor = rbt_cd_bin(c, CTX_PART_MODE + 1);
       if (rbt_cd_bin(c, CTX_PART_MODE + 3)) s->cu_part_mode = hor ? RBT_PART_2NxN : RBT_PART_Nx2N;
@@ -799,7 +836,7 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
   int rqt_root_cbf = 1;
   if (s->cu_pred_mode != RBT_MODE_INTRA && !(s->cu_part_mode == RBT_PART_2Nx2N && s->last_pu_merge)) rqt_root_cbf = rbt_cd_bin(c, CTX_RQT_ROOT_CBF);
   if (rqt_root_cbf) {
-    s->max_trafo_depth = s->cu_pred_mode == RBT_MODE_INTRA ? cfg->th_depth_intra + (s->cu_part_mode == RBT_PART_NxN) : cfg->th_depth_inter;
+    s->max_trafo_depth = s->cu_pred_mode == RBT_MODE_INTRA ? pzc_th_depth_intra(s) + (s->cu_part_mode == RBT_PART_NxN) : pzc_th_depth_inter(s);
     pz_transform_tree(s, x0, y0, x0, y0, log2, 0, 0, 0, 0);
   }
   RBT_SYNC_LDS();
@@ -809,7 +846,6 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
 // ------------------------------------------------------------------------------------------------ coding quadtree + slice data
 RBT_DEV void pz_coding_quadtree(RbtParse* s, int x0, int y0, int log2) {
   // same stack-free walk as pz_transform_tree; children outside the picture are skipped (7.3.8.4)
-  const RbtStreamCfg* cfg = &s->cfg;
   int lvl = 0, x = x0, y = y0, lg = log2;
   uint32_t states = 15u;
   while (!s->error) {
@@ -819,17 +855,17 @@ RBT_DEV void pz_coding_quadtree(RbtParse* s, int x0, int y0, int log2) {
     int N = 1 << lg;
     if (st == 15) {
       int split;
-      if (x + N <= cfg->w && y + N <= cfg->h && lg > cfg->log2_min_cb) {
+      if (x + N <= pzc_w(s) && y + N <= pzc_h(s) && lg > pzc_log2_min_cb(s)) {
         int nl = pz_nb(s, x - 1, y), na = pz_nb(s, x, y - 1);
         int cl = nl >= 0 && (nl >> 14) > lvl, ca = na >= 0 && (na >> 14) > lvl;
         split = rbt_cd_bin(&s->c, CTX_SPLIT_CU + cl + ca);
-      } else split = lg > cfg->log2_min_cb;
-      if (cfg->cu_qp_delta && lg >= cfg->log2_ctb - cfg->diff_cu_qp_delta_depth) pz_start_qg(s, x, y);
+      } else split = lg > pzc_log2_min_cb(s);
+      if (pzc_cu_qp_delta(s) && lg >= pzc_log2_ctb(s) - pzc_diff_cu_qp_delta_depth(s)) pz_start_qg(s, x, y);
       if (!split) { pz_coding_unit(s, x, y, lg, lvl); st = 4; } else st = 0;
     }
     // next child that lies inside the picture
     int h = N >> 1;
-    while (st < 4 && (x + (st & 1) * h >= cfg->w || y + (st >> 1) * h >= cfg->h)) st++;
+    while (st < 4 && (x + (st & 1) * h >= pzc_w(s) || y + (st >> 1) * h >= pzc_h(s))) st++;
     if (st < 4) {
       states = (states & ~(15u << (4 * lvl))) | ((uint32_t)(st + 1) << (4 * lvl));
       x += (st & 1) * h; y += (st >> 1) * h; lg--; lvl++;
@@ -851,41 +887,35 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
   RBT_SYNC_LDS();
   const RbtSlice* gs = &slices[slice_idx];
   s.frames = frames; s.f = &frames[RBT_UNI(gs->frame)]; s.slice_idx = slice_idx; s.error = 0;
-  { RbtSliceU* u = &s.sl;
-    u->slice_type = RBT_UNI(gs->slice_type); u->qp = RBT_UNI(gs->qp); u->cb_qp_offset = RBT_UNI(gs->cb_qp_offset); u->cr_qp_offset = RBT_UNI(gs->cr_qp_offset);
-    u->sao_luma = RBT_UNI(gs->sao_luma); u->sao_chroma = RBT_UNI(gs->sao_chroma); u->temporal_mvp = RBT_UNI(gs->temporal_mvp); u->cabac_init_flag = RBT_UNI(gs->cabac_init_flag);
-    u->max_merge_cand = RBT_UNI(gs->max_merge_cand); u->num_ref_idx = RBT_UNI(gs->num_ref_idx); u->collocated_ref_idx = RBT_UNI(gs->collocated_ref_idx); u->poc = RBT_UNI(gs->poc);
-  }
+  s.s_bits = (uint32_t)RBT_UNI((gs->slice_type & 3) | ((gs->sao_luma & 1) << 2) | ((gs->sao_chroma & 1) << 3) | ((gs->temporal_mvp & 1) << 4) | ((gs->cabac_init_flag & 1) << 5) |
+                               ((gs->max_merge_cand & 7) << 6) | ((gs->num_ref_idx & 31) << 9) | ((gs->collocated_ref_idx & 15) << 14));
+  s.s_qp = (uint32_t)RBT_UNI((uint32_t)(uint8_t)gs->qp | ((uint32_t)(uint8_t)gs->cb_qp_offset << 8) | ((uint32_t)(uint8_t)gs->cr_qp_offset << 16));
+  s.s_poc = RBT_UNI(gs->poc);
   RBT_PAR_FOR(i, RBT_MAX_REFS) { lds->ref_poc[i] = gs->ref_poc[i]; lds->ref_frame[i] = gs->ref_frame[i]; }
   RBT_PAR_FOR(i, 3 * 4 * 64) lds->scan[i / 256][(i / 64) & 3][i & 63] = k_scan[i / 256][(i / 64) & 3][i & 63];
-  { const RbtFrame* f = s.f;
-    s.m_pm = rbt_uni_ptr(f->pm); s.m_edges = rbt_uni_ptr(f->edges); s.m_dm = rbt_uni_ptr(f->dm); s.m_qp = rbt_uni_ptr(f->qp); s.m_ref = rbt_uni_ptr(f->ref); s.m_mv = rbt_uni_ptr(f->mv);
-    s.m_refpoc = rbt_uni_ptr(f->refpoc); s.m_cs = rbt_uni_ptr(f->ctb_slice); s.m_sao = rbt_uni_ptr(f->sao); s.m_cmds = rbt_uni_ptr(f->cmds); s.m_cnt = rbt_uni_ptr(f->cmd_count);
-    s.m_coef0 = rbt_uni_ptr(f->coef[0]); s.m_coef1 = rbt_uni_ptr(f->coef[1]); s.m_coef2 = rbt_uni_ptr(f->coef[2]); s.m_cap = RBT_UNI(f->cmd_cap); }
-  { const RbtStreamCfg* g = &s.f->cfg; RbtStreamCfg* d = &s.cfg;
-#define PZ_U(fld) d->fld = (decltype(d->fld))RBT_UNI(g->fld)
-    PZ_U(w); PZ_U(h); PZ_U(cw); PZ_U(ch); PZ_U(w4); PZ_U(h4); PZ_U(w_ctb); PZ_U(h_ctb); PZ_U(bit_depth); PZ_U(log2_ctb); PZ_U(log2_min_cb); PZ_U(log2_min_tb);
-    PZ_U(log2_max_tb); PZ_U(th_depth_inter); PZ_U(th_depth_intra); PZ_U(diff_cu_qp_delta_depth); PZ_U(amp); PZ_U(sao); PZ_U(strong_intra); PZ_U(tmvp);
-    PZ_U(sign_hiding); PZ_U(cabac_init_present); PZ_U(cip); PZ_U(transform_skip); PZ_U(cu_qp_delta); PZ_U(tq_bypass_enabled); PZ_U(cb_qp_offset); PZ_U(cr_qp_offset);
-    d->pad0 = d->pad1 = 0; d->pad2 = d->pad3 = 0;
-#undef PZ_U
-  }
-  const RbtSliceU* sl = &s.sl;
-  int init_type = sl->slice_type == RBT_SLICE_I ? 0 : (sl->cabac_init_flag ? 2 : 1);
+  { const RbtFrame* f = s.f; const RbtStreamCfg* g = &f->cfg;
+    s.m_cmds = rbt_uni_ptr(f->cmds); s.m_coef0 = rbt_uni_ptr(f->coef[0]); s.m_coef1 = rbt_uni_ptr(f->coef[1]); s.m_coef2 = rbt_uni_ptr(f->coef[2]); s.m_cap = RBT_UNI(f->cmd_cap);
+    s.c_dim = (uint32_t)RBT_UNI((uint32_t)g->w | ((uint32_t)g->h << 16));
+    s.c_logs = (uint32_t)RBT_UNI((g->bit_depth & 15) | ((g->log2_ctb & 7) << 4) | ((g->log2_min_cb & 7) << 7) | ((g->log2_min_tb & 7) << 10) | ((g->log2_max_tb & 7) << 13) |
+                                 ((g->th_depth_inter & 7) << 16) | ((g->th_depth_intra & 7) << 19) | ((g->diff_cu_qp_delta_depth & 3) << 22));
+    s.c_flags = (uint32_t)RBT_UNI((uint32_t)(g->amp & 1) | ((uint32_t)(g->sao & 1) << 1) | ((uint32_t)(g->strong_intra & 1) << 2) | ((uint32_t)(g->tmvp & 1) << 3) | ((uint32_t)(g->sign_hiding & 1) << 4) |
+                                  ((uint32_t)(g->cabac_init_present & 1) << 5) | ((uint32_t)(g->cip & 1) << 6) | ((uint32_t)(g->transform_skip & 1) << 7) | ((uint32_t)(g->cu_qp_delta & 1) << 8) |
+                                  ((uint32_t)(g->tq_bypass_enabled & 1) << 9) | ((uint32_t)(uint8_t)g->cb_qp_offset << 16) | ((uint32_t)(uint8_t)g->cr_qp_offset << 24)); }
+  int init_type = pzs_slice_type(&s) == RBT_SLICE_I ? 0 : (pzs_cabac_init_flag(&s) ? 2 : 1);
 #ifdef RBT_PROFILE
   unsigned long long t_all_ = __builtin_readcyclecounter(); s.t_res = s.t_ctb = s.t_cu = s.t_a = s.t_b = s.t_c = s.t_d = s.t_tu = s.t_hdr = s.t_fill = s.t_mpm = 0; s.n_res = s.n_cu = 0; s.c.n_bins = s.c.n_byp = 0;
 #endif
-  rbt_ctx_init(&s.c.cs, init_type, sl->qp);
+  rbt_ctx_init(&s.c.cs, init_type, pzs_qp(&s));
   rbt_cd_start(&s.c, rbsp + (uint32_t)RBT_UNI(gs->data_off), (uint32_t)RBT_UNI(gs->data_size));
-  s.qp_y = sl->qp; s.qp_pred = sl->qp; s.qp_y_prev = sl->qp; s.is_cu_qp_delta_coded = 0; s.cu_qp_delta_val = 0;
+  s.qp_y = pzs_qp(&s); s.qp_pred = pzs_qp(&s); s.qp_y_prev = pzs_qp(&s); s.is_cu_qp_delta_coded = 0; s.cu_qp_delta_val = 0;
   s.last_pu_merge = 0; s.max_trafo_depth = 0; s.intra_chroma = 1; s.il_packed = 0x01010101;
-  int n_ctb = s.cfg.w_ctb * s.cfg.h_ctb, end = 0, addr = RBT_UNI(gs->ctb_addr);
+  int n_ctb = pzc_w_ctb(&s) * pzc_h_ctb(&s), end = 0, addr = RBT_UNI(gs->ctb_addr);
   uint32_t count = 0;
   while (!end) {
     if (addr >= n_ctb) { s.error = 1; break; }
     pz_assert_uniform(&s); addr = RBT_UNI(addr);
-    int rx = RBT_UNI(addr % s.cfg.w_ctb), ry = RBT_UNI(addr / s.cfg.w_ctb);
-    if (RBT_LANE0) s.m_cs[addr] = (uint16_t)slice_idx;
+    int rx = RBT_UNI(addr % pzc_w_ctb(&s)), ry = RBT_UNI(addr / pzc_w_ctb(&s));
+    if (RBT_LANE0) s.f->ctb_slice[addr] = (uint16_t)slice_idx;
     s.ctb_addr = addr; s.n_cmds = 0;
     if (rx == 0) { s.left_ok = 0; s.corner_ok = 0; }
 #ifdef RBT_PROFILE
@@ -896,8 +926,8 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
     s.t_ctb += __builtin_readcyclecounter() - tb_;
 #endif
     pz_sao(&s, rx, ry);
-    pz_coding_quadtree(&s, rx << s.cfg.log2_ctb, ry << s.cfg.log2_ctb, s.cfg.log2_ctb);
-    if (RBT_LANE0) s.m_cnt[addr] = s.n_cmds;
+    pz_coding_quadtree(&s, rx << pzc_log2_ctb(&s), ry << pzc_log2_ctb(&s), pzc_log2_ctb(&s));
+    if (RBT_LANE0) s.f->cmd_count[addr] = s.n_cmds;
     if (s.error) break;
 #ifdef RBT_PROFILE
     unsigned long long te_ = __builtin_readcyclecounter();

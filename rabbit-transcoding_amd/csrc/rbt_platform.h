@@ -71,6 +71,22 @@ static __device__ __forceinline__ int rbt_writelane(int old, int v, int lane) { 
 #endif
 #endif
 
+// Bit-field read of a packed wave-uniform word. On the GPU it is one scalar instruction the compiler may neither hoist nor
+// keep alive: rarely used parameters then cost one SGPR per word instead of one (spilled) SGPR per field.
+template <int SH, int N> RBT_DEV uint32_t rbt_bfe(uint32_t w) {
+#ifdef RBT_HOSTEMU
+  return (w >> SH) & ((1u << N) - 1u);
+#else
+  uint32_t v; asm volatile("s_bfe_u32 %0, %1, %2" : "=s"(v) : "s"(w), "n"(SH | (N << 16)) : "scc"); return v;
+#endif
+}
+template <int SH, int N> RBT_DEV int rbt_bfe_i(uint32_t w) {
+#ifdef RBT_HOSTEMU
+  return (int)(w << (32 - SH - N)) >> (32 - N);
+#else
+  int v; asm volatile("s_bfe_i32 %0, %1, %2" : "=s"(v) : "s"(w), "n"(SH | (N << 16)) : "scc"); return v;
+#endif
+}
 template <class T> RBT_DEV T* rbt_uni_ptr(T* p) {
 #ifdef RBT_HOSTEMU
   return p;
