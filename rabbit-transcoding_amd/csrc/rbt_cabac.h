@@ -176,9 +176,16 @@ template <bool AU> RBT_DEV int rbt_cd_core(RbtCabacDec* c, int st, int* nst) {
   if (__builtin_expect(c->avail < 7, 0)) rbt_cd_refill(c);
   return (int)(nmps ^ mf);
 }
+// contexts outside residual_coding (ctx < CTX_LAST_X): all of them live in context register 0
 RBT_DEV int rbt_cd_bin(RbtCabacDec* c, int ctx) {
+#ifdef RBT_HOSTEMU
   int nst, b = rbt_cd_core<true>(c, rbt_ctx_get(&c->cs, ctx), &nst);
   rbt_ctx_set(&c->cs, ctx, nst);
+#else
+  ctx = RBT_UNI(ctx);
+  int nst, b = rbt_cd_core<true>(c, __builtin_amdgcn_readlane(c->cs.st0, ctx), &nst);
+  c->cs.st0 = rbt_writelane(c->cs.st0, nst, ctx);
+#endif
   return b;
 }
 // class-specific entry points: the register holding the context is known at the call site

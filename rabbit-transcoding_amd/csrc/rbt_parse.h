@@ -11,6 +11,11 @@
 #include "rbt_types.h"
 
 #define RBT_NO_REFPOC ((int32_t)0x80000000)
+#ifdef RBT_PROFILE
+#define PZ_STAMP(s, id) do { unsigned long long n_ = __builtin_readcyclecounter(); if (RBT_LANE0) { (s)->L->prof[id] += n_ - (s)->t_last; (s)->L->profn[id]++; } (s)->t_last = __builtin_readcyclecounter(); } while (0)
+#else
+#define PZ_STAMP(s, label) do { } while (0)
+#endif
 #if defined(RBT_TRACE) && !defined(RBT_HOSTEMU)
 #define RBT_TR(...) do { if (RBT_LANE0) printf(__VA_ARGS__); } while (0)
 #else
@@ -24,6 +29,9 @@ struct RbtParseLds {
   uint16_t above_slice[512];                                                                                   // slice that decoded the CTB above (0xFFFF none)
   RbtSao sao_above[512]; RbtSao sao_left;
   uint8_t scan[3][4][64];                                                                                      // k_scan copied once per slice
+#ifdef RBT_PROFILE
+  unsigned long long prof[32]; unsigned int profn[32];
+#endif
   int32_t ref_poc[RBT_MAX_REFS], ref_frame[RBT_MAX_REFS];   // RefPicList0 of the slice (indexed at run time: kept out of the register-resident parser state)
 };
 struct RbtParse {
@@ -48,7 +56,7 @@ struct RbtParse {
   // lanes 32..47 the column to the left. Availability is folded in: an unavailable unit reads pm = RBT_MODE_NONE.
   RBT_VEC(uint32_t, n_pm); RBT_VEC(uint32_t, n_dm); RBT_VEC(uint32_t, n_ref); RBT_VEC(uint32_t, n_mv);
 #ifdef RBT_PROFILE
-  unsigned long long t_res, t_ctb, t_cu, t_a, t_b, t_c, t_d, t_tu, t_hdr, t_fill, t_mpm; uint32_t n_res, n_cu;
+  unsigned long long t_res, t_ctb, t_cu, t_a, t_b, t_c, t_d, t_tu, t_hdr, t_fill, t_mpm, t_last; uint32_t n_res, n_cu;
 #endif
 };
 struct RbtMv { int x, y, ref; };
@@ -341,6 +349,7 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
 #ifdef RBT_PROFILE
   unsigned long long t0_ = __builtin_readcyclecounter(); s->n_res++;
 #endif
+  PZ_STAMP(s, 0);
   RbtCabacDec cl; rbt_cd_localise(&cl, &s->c); RbtCabacDec* c = &cl;
   x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); log2 = RBT_UNI(log2); scan_idx = RBT_UNI(scan_idx);
   const uint64_t ps = pz_scan4_const(scan_idx);
@@ -353,6 +362,7 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
   int ctx_off, ctx_shift;
   if (c_idx == 0) { ctx_off = 3 * (log2 - 2) + ((log2 - 1) >> 2); ctx_shift = (log2 + 1) >> 2; }
   else { ctx_off = 15; ctx_shift = log2 - 2; }
+  PZ_STAMP(s, 1);
   int maxp = (log2 << 1) - 1, px = 0, py = 0;
   while (px < maxp && rbt_cd_bin_last(c, ctx_off + (px >> ctx_shift))) px++;
   while (py < maxp && rbt_cd_bin_last(c, 18 + ctx_off + (py >> ctx_shift))) py++;
@@ -366,6 +376,7 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
   // Everything that is not the serial arithmetic decode runs on the lanes: lane i holds sub-block scan entry i, lane p
   // (p < 16) the position of scan index p inside a 4x4 sub-block, its sig_coeff_flag context and, after the bins of a
   // sub-block are known, the level / sign / address of the coefficient at that scan index.
+  PZ_STAMP(s, 2);
   const RBT_LDS_AS uint8_t* sb_scan = s->L->scan[scan_idx][log2 - 2];
   const int n_sb = 1 << (2 * (log2 - 2));
   RBT_VEC(int, v_sbscan); RBT_VEC(int, v_pos);
@@ -374,6 +385,7 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
   { uint64_t mb; const int key = (lx >> 2) | ((ly >> 2) << 4), ikey = (lx & 3) | ((ly & 3) << 2);
     RBT_VBALLOT(mb, p, 64, RBT_V(v_sbscan, p) == key); last_sb = mb ? __builtin_ctzll(mb) : 0;
     RBT_VBALLOT(mb, p, 16, RBT_V(v_pos, p) == ikey); last_pos = mb ? __builtin_ctzll(mb) : 0; }
+  PZ_STAMP(s, 3);
   uint64_t csbf = 0;   // bit (ys*8+xs)
   const int sbw = 1 << (log2 - 2);
   int greater1_ctx = 1, first_sb_done = 0, err = 0;
@@ -465,8 +477,10 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
     s->t_d += __builtin_readcyclecounter() - tc1_;
 #endif
   }
+  PZ_STAMP(s, 4);
   s->c = cl;
   if (err) s->error = err;
+  PZ_STAMP(s, 5);
 #ifdef RBT_PROFILE
   s->t_res += __builtin_readcyclecounter() - t0_;
 #endif
@@ -515,25 +529,31 @@ RBT_DEV void pz_transform_unit(RbtParse* s, int x0, int y0, int xb, int yb, int 
     s->qp_y = pz_wrap_qp(s, s->qp_pred + v);
     pz_fill_qp(s, s->cu_x, s->cu_y, 1 << s->cu_log2, s->qp_y);
   }
+  PZ_STAMP(s, 6);
   int intra = s->cu_pred_mode == RBT_MODE_INTRA;
   int part = 0;
   if (s->cu_part_mode == RBT_PART_NxN && intra) part = ((y0 - s->cu_y) >= (1 << (s->cu_log2 - 1)) ? 2 : 0) + ((x0 - s->cu_x) >= (1 << (s->cu_log2 - 1)) ? 1 : 0);
   pz_fill_tu(s, x0, y0, N, cbf_luma);
+  PZ_STAMP(s, 7);
   int chroma_here = log2 > 2 || blk == 3;
   RbtCmd cmd; cmd.type = RBT_CMD_TU; cmd.x4 = (uint8_t)((x0 & ((1 << pzc_log2_ctb(s)) - 1)) >> 2); cmd.y4 = (uint8_t)((y0 & ((1 << pzc_log2_ctb(s)) - 1)) >> 2);
   cmd.log2 = (uint8_t)log2; cmd.b = (uint8_t)pz_il(s, part); cmd.c = (uint8_t)s->intra_chroma; cmd.d = (uint8_t)s->cu_tq_bypass; cmd.mvx = cmd.mvy = 0; cmd.pad = 0;
   int flags = (cbf_luma ? RBT_TU_CBF_Y : 0) | (intra ? RBT_TU_INTRA : 0) | (chroma_here ? RBT_TU_CHROMA : 0);
   if (chroma_here) flags |= (cbf_cb ? RBT_TU_CBF_CB : 0) | (cbf_cr ? RBT_TU_CBF_CR : 0);
+  PZ_STAMP(s, 8);
   if (cbf_luma && pz_residual(s, 0, x0, y0, log2, pz_scan_idx(s->cu_pred_mode, log2, 0, pz_il(s, part)))) flags |= RBT_TU_TS_Y;
+  PZ_STAMP(s, 9);
   if (chroma_here && !s->error) {
     int xc = (log2 > 2 ? x0 : xb) >> 1, yc = (log2 > 2 ? y0 : yb) >> 1, l2c = log2 > 2 ? log2 - 1 : 2;
     int sc = pz_scan_idx(s->cu_pred_mode, l2c, 1, s->intra_chroma);
     if (cbf_cb && pz_residual(s, 1, xc, yc, l2c, sc)) flags |= RBT_TU_TS_CB;
     if (cbf_cr && !s->error && pz_residual(s, 2, xc, yc, l2c, sc)) flags |= RBT_TU_TS_CR;
   }
+  PZ_STAMP(s, 10);
   cmd.a = (uint8_t)flags;
   cmd.qp[0] = (int8_t)(s->qp_y + 6 * (pzc_bit_depth(s) - 8)); cmd.qp[1] = (int8_t)pz_chroma_qp(s, 1); cmd.qp[2] = (int8_t)pz_chroma_qp(s, 2);
   pz_emit(s, cmd);
+  PZ_STAMP(s, 11);
 #ifdef RBT_PROFILE
   s->t_tu += __builtin_readcyclecounter() - ttu_;
 #endif
@@ -559,6 +579,7 @@ RBT_DEV void pz_transform_tree(RbtParse* s, int x0, int y0, int xb0, int yb0, in
       if (lg <= pzc_log2_max_tb(s) && lg > pzc_log2_min_tb(s) && lvl < s->max_trafo_depth && !(intra_split && lvl == 0))
         split = rbt_cd_bin(c, CTX_SPLIT_TRANSFORM + 5 - lg);
       else split = (lg > pzc_log2_max_tb(s) || (intra_split && lvl == 0) || inter_split) ? 1 : 0;
+      PZ_STAMP(s, 12);
       int ppcb = (int)((flags >> (2 * lvl)) & 1u), ppcr = (int)((flags >> (2 * lvl + 1)) & 1u);
       int cbf_cb = 0, cbf_cr = 0;
       if (lg > 2) {
@@ -568,9 +589,11 @@ RBT_DEV void pz_transform_tree(RbtParse* s, int x0, int y0, int xb0, int yb0, in
       if (!split) {
         int cbf_luma = 1;
         if (intra || lvl != 0 || cbf_cb || cbf_cr) cbf_luma = rbt_cd_bin(c, CTX_CBF_LUMA + (lvl == 0 ? 1 : 0));
+        PZ_STAMP(s, 13);
         int k = lvl ? (int)((states >> (4 * (lvl - 1))) & 15u) - 1 : 0, h = 1 << lg;
         int xb = lvl ? x - (k & 1) * h : x, yb = lvl ? y - (k >> 1) * h : y;
         pz_transform_unit(s, x, y, xb, yb, lg, k, cbf_luma, cbf_cb, cbf_cr);
+        PZ_STAMP(s, 14);
         st = 4;
       } else {
         flags = (flags & ~(3u << (2 * (lvl + 1)))) | ((uint32_t)(cbf_cb | (cbf_cr << 1)) << (2 * (lvl + 1)));
@@ -730,6 +753,10 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
 #endif
   pz_assert_uniform(s);
   x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); log2 = RBT_UNI(log2); depth = RBT_UNI(depth);
+#ifdef RBT_PROFILE
+  s->t_last = __builtin_readcyclecounter();
+#endif
+  PZ_STAMP(s, 15);
   int N = 1 << log2;
   s->cu_x = x0; s->cu_y = y0; s->cu_log2 = log2; s->cu_tq_bypass = 0; s->cu_part_mode = RBT_PART_2Nx2N; s->cu_pred_mode = RBT_MODE_INTRA;
   if (pzc_cu_qp_delta(s)) s->qp_y = pz_wrap_qp(s, s->qp_pred + s->cu_qp_delta_val);
@@ -765,9 +792,11 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
       else { int b = rbt_cd_bypass(c); s->cu_part_mode = hor ? (b ? RBT_PART_2NxnD : RBT_PART_2NxnU) : (b ? RBT_PART_nRx2N : RBT_PART_nLx2N); }
     }
   }
+  PZ_STAMP(s, 16);
   if (s->cu_pred_mode == RBT_MODE_INTRA) {
     pz_fill_cu(s, x0, y0, N, RBT_MODE_INTRA | (s->cu_tq_bypass ? RBT_PM_TQ_BYPASS : 0), (depth << 6) | 1, s->qp_y);
     RBT_SYNC_LDS();
+    PZ_STAMP(s, 17);
     int np = s->cu_part_mode == RBT_PART_NxN ? 4 : 1, pb = N >> (np == 4);
     int prev[4], mpm_idx[4], rem[4];
     for (int i = 0; i < np; i++) prev[i] = rbt_cd_bin(c, CTX_PREV_INTRA_LUMA);
@@ -776,6 +805,7 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
       if (prev[i]) { mpm_idx[i] = rbt_cd_bypass(c); if (mpm_idx[i]) mpm_idx[i] += rbt_cd_bypass(c); }
       else rem[i] = (int)rbt_cd_bypass_n(c, 5);
     }
+    PZ_STAMP(s, 18);
     for (int i = 0; i < np; i++) {
       int xp = x0 + (i & 1) * pb, yp = y0 + (i >> 1) * pb;
 #ifdef RBT_PROFILE
@@ -798,6 +828,7 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
       pz_fill_dm(s, xp, yp, pb, (depth << 6) | mode);
       RBT_SYNC_LDS();
     }
+    PZ_STAMP(s, 19);
     int icp = 4;
     if (rbt_cd_bin(c, CTX_INTRA_CHROMA)) icp = (int)rbt_cd_bypass_n(c, 2);
     int cmode = icp == 0 ? 0 : (icp == 1 ? 26 : (icp == 2 ? 10 : 1));
@@ -833,6 +864,7 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
 #else
 #define PZ_CU_END() ((void)0)
 #endif
+  PZ_STAMP(s, 20);
   int rqt_root_cbf = 1;
   if (s->cu_pred_mode != RBT_MODE_INTRA && !(s->cu_part_mode == RBT_PART_2Nx2N && s->last_pu_merge)) rqt_root_cbf = rbt_cd_bin(c, CTX_RQT_ROOT_CBF);
   if (rqt_root_cbf) {
@@ -840,6 +872,7 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
     pz_transform_tree(s, x0, y0, x0, y0, log2, 0, 0, 0, 0);
   }
   RBT_SYNC_LDS();
+  PZ_STAMP(s, 21);
   PZ_CU_END();
 }
 
@@ -905,6 +938,10 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
 #ifdef RBT_PROFILE
   unsigned long long t_all_ = __builtin_readcyclecounter(); s.t_res = s.t_ctb = s.t_cu = s.t_a = s.t_b = s.t_c = s.t_d = s.t_tu = s.t_hdr = s.t_fill = s.t_mpm = 0; s.n_res = s.n_cu = 0; s.c.n_bins = s.c.n_byp = 0;
 #endif
+#ifdef RBT_PROFILE
+  RBT_PAR_FOR(i, 32) { lds->prof[i] = 0; lds->profn[i] = 0; }
+  s.t_last = __builtin_readcyclecounter();
+#endif
   rbt_ctx_init(&s.c.cs, init_type, pzs_qp(&s));
   rbt_cd_start(&s.c, rbsp + (uint32_t)RBT_UNI(gs->data_off), (uint32_t)RBT_UNI(gs->data_size));
   s.qp_y = pzs_qp(&s); s.qp_pred = pzs_qp(&s); s.qp_y_prev = pzs_qp(&s); s.is_cu_qp_delta_coded = 0; s.cu_qp_delta_val = 0;
@@ -942,6 +979,7 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
     RBT_SYNC_LDS();
   }
 #ifdef RBT_PROFILE
+  if (RBT_LANE0) for (int i = 0; i < 22; i++) printf("stamp %d: %llu cycles, %u hits\n", i, lds->prof[i], lds->profn[i]);
   if (RBT_LANE0) printf("slice %d: total %llu cyc, residual %llu (%u TBs) [setup+last %llu, csbf+sig %llu, gt1/2 %llu, levels %llu], TU total (incl. residual) %llu, CU header %llu (%u CUs), ctb begin/end %llu, CU total %llu, fills %llu, mpm %llu, bins ctx %u bypass %u, bits %u\n", slice_idx, __builtin_readcyclecounter() - t_all_, s.t_res, s.n_res, s.t_a, s.t_b, s.t_c, s.t_d, s.t_tu, s.t_hdr, s.n_cu, s.t_ctb, s.t_cu, s.t_fill, s.t_mpm, s.c.n_bins, s.c.n_byp, s.c.widx * 32u - (uint32_t)s.c.nbuf);
 #endif
   if (RBT_LANE0) { slices[slice_idx].n_ctbs_decoded = count; if (s.error) s.f->error = s.error; }
