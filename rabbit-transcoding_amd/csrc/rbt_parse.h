@@ -103,18 +103,6 @@ RBT_DEV int pzs_cr_qp_offset(const RbtParse* s) { return rbt_bfe_i<16, 8>(s->s_q
 RBT_DEV int pzs_poc(const RbtParse* s) { return s->s_poc; }
 RBT_DEV int pz_il(const RbtParse* s, int i) { return (s->il_packed >> (8 * i)) & 255; }   // luma intra modes of the (up to four) PUs, 8 bits each
 RBT_DEV void pz_set_il(RbtParse* s, int i, int v) { s->il_packed = (s->il_packed & ~(255 << (8 * i))) | (v << (8 * i)); }
-// Re-asserts that the scalar parser state is wave-uniform (see rbt_cd_assert_uniform): called where the syntax walkers
-// re-enter, so that one value the compiler could not prove uniform does not drag the control flow onto the vector unit.
-RBT_DEV void pz_assert_uniform(RbtParse* s) {
-#define PZ_AU(f) s->f = (decltype(s->f))RBT_UNI(s->f)
-  PZ_AU(ctb_x); PZ_AU(ctb_y); PZ_AU(left_ok); PZ_AU(corner_ok); PZ_AU(corner_pm); PZ_AU(corner_dm); PZ_AU(corner_ref); PZ_AU(corner_mv);
-  PZ_AU(qp_y); PZ_AU(qp_pred); PZ_AU(qp_y_prev); PZ_AU(is_cu_qp_delta_coded); PZ_AU(cu_qp_delta_val); PZ_AU(ctb_addr); PZ_AU(n_cmds);
-  PZ_AU(cu_x); PZ_AU(cu_y); PZ_AU(cu_log2); PZ_AU(cu_pred_mode); PZ_AU(cu_part_mode); PZ_AU(cu_tq_bypass);
-  PZ_AU(il_packed); PZ_AU(intra_chroma); PZ_AU(max_trafo_depth); PZ_AU(last_pu_merge); PZ_AU(error);
-#undef PZ_AU
-  rbt_cd_assert_uniform(&s->c);
-  s->c.widx = (uint32_t)RBT_UNI(s->c.widx); s->c.n_words = (uint32_t)RBT_UNI(s->c.n_words);
-}
 #define PZ_UNI_VARS2(a, b) do { a = RBT_UNI(a); b = RBT_UNI(b); } while (0)
 
 // ---- neighbour context -------------------------------------------------------------------------------------------
@@ -304,7 +292,7 @@ RBT_DEV void pz_sao_to_lds(RBT_LDS_AS RbtSao* l, const RbtSao* d) {
 // ------------------------------------------------------------------------------------------------ SAO (7.3.8.3)
 RBT_DEV void pz_sao(RbtParse* s, int rx, int ry) {
   RbtCabacDec* c = &s->c;
-  pz_assert_uniform(s); rx = RBT_UNI(rx); ry = RBT_UNI(ry);
+  rx = RBT_UNI(rx); ry = RBT_UNI(ry);
   RbtSao p; for (int i = 0; i < 3; i++) { p.type[i] = p.band_pos[i] = p.eo_class[i] = 0; for (int k = 0; k < 4; k++) p.offset[i][k] = 0; }
   p.pad[0] = p.pad[1] = p.pad[2] = 0;
   int wc = pzc_w_ctb(s);
@@ -518,7 +506,6 @@ RBT_DEV void pz_transform_unit(RbtParse* s, int x0, int y0, int xb, int yb, int 
 #ifdef RBT_PROFILE
   unsigned long long ttu_ = __builtin_readcyclecounter();
 #endif
-  pz_assert_uniform(s);
   x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); xb = RBT_UNI(xb); yb = RBT_UNI(yb); log2 = RBT_UNI(log2); blk = RBT_UNI(blk); cbf_luma = RBT_UNI(cbf_luma); cbf_cb = RBT_UNI(cbf_cb); cbf_cr = RBT_UNI(cbf_cr);
   int N = 1 << log2;
   if ((cbf_luma || cbf_cb || cbf_cr) && pzc_cu_qp_delta(s) && !s->is_cu_qp_delta_coded) {
@@ -570,7 +557,6 @@ RBT_DEV void pz_transform_tree(RbtParse* s, int x0, int y0, int xb0, int yb0, in
   const int intra = s->cu_pred_mode == RBT_MODE_INTRA;
   const int intra_split = intra && s->cu_part_mode == RBT_PART_NxN;
   while (!s->error) {
-    pz_assert_uniform(s);
     lvl = RBT_UNI(lvl); x = RBT_UNI(x); y = RBT_UNI(y); lg = RBT_UNI(lg); states = (uint32_t)RBT_UNI(states); flags = (uint32_t)RBT_UNI(flags);
     int st = (int)((states >> (4 * lvl)) & 15u);
     if (st == 15) {
@@ -705,7 +691,6 @@ RBT_DEV int pz_mvd_comp(RbtCabacDec* c, int gt0, int gt1) {
 }
 RBT_DEV void pz_prediction_unit(RbtParse* s, int x0, int y0, int w, int h, int part_idx, int skip) {
   RbtCabacDec* c = &s->c;
-  pz_assert_uniform(s);
   x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); w = RBT_UNI(w); h = RBT_UNI(h); part_idx = RBT_UNI(part_idx); skip = RBT_UNI(skip);
   RbtMv mv;
   int merge = skip ? 1 : rbt_cd_bin(c, CTX_MERGE_FLAG);
@@ -751,7 +736,6 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
 #ifdef RBT_PROFILE
   unsigned long long tcu_ = __builtin_readcyclecounter(); s->n_cu++;
 #endif
-  pz_assert_uniform(s);
   x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); log2 = RBT_UNI(log2); depth = RBT_UNI(depth);
 #ifdef RBT_PROFILE
   s->t_last = __builtin_readcyclecounter();
@@ -882,7 +866,6 @@ RBT_DEV void pz_coding_quadtree(RbtParse* s, int x0, int y0, int log2) {
   int lvl = 0, x = x0, y = y0, lg = log2;
   uint32_t states = 15u;
   while (!s->error) {
-    pz_assert_uniform(s);
     lvl = RBT_UNI(lvl); x = RBT_UNI(x); y = RBT_UNI(y); lg = RBT_UNI(lg); states = (uint32_t)RBT_UNI(states);
     int st = (int)((states >> (4 * lvl)) & 15u);
     int N = 1 << lg;
@@ -950,7 +933,7 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
   uint32_t count = 0;
   while (!end) {
     if (addr >= n_ctb) { s.error = 1; break; }
-    pz_assert_uniform(&s); addr = RBT_UNI(addr);
+    addr = RBT_UNI(addr);
     int rx = RBT_UNI(addr % pzc_w_ctb(&s)), ry = RBT_UNI(addr / pzc_w_ctb(&s));
     if (RBT_LANE0) s.f->ctb_slice[addr] = (uint16_t)slice_idx;
     s.ctb_addr = addr; s.n_cmds = 0;
