@@ -103,7 +103,11 @@ RBT_DEV int pzs_cr_qp_offset(const RbtParse* s) { return rbt_bfe_i<16, 8>(s->s_q
 RBT_DEV int pzs_poc(const RbtParse* s) { return s->s_poc; }
 RBT_DEV int pz_il(const RbtParse* s, int i) { return (s->il_packed >> (8 * i)) & 255; }   // luma intra modes of the (up to four) PUs, 8 bits each
 RBT_DEV void pz_set_il(RbtParse* s, int i, int v) { s->il_packed = (s->il_packed & ~(255 << (8 * i))) | (v << (8 * i)); }
-#define PZ_UNI_VARS2(a, b) do { a = RBT_UNI(a); b = RBT_UNI(b); } while (0)
+#ifdef RBT_NO_WALKER_UNI
+#define PZ_WU(x) (x)
+#else
+#define PZ_WU(x) RBT_UNI(x)
+#endif
 
 // ---- neighbour context -------------------------------------------------------------------------------------------
 // The parser never reads the HBM maps of its own picture back. What later syntax depends on (prediction mode, skip,
@@ -292,7 +296,7 @@ RBT_DEV void pz_sao_to_lds(RBT_LDS_AS RbtSao* l, const RbtSao* d) {
 // ------------------------------------------------------------------------------------------------ SAO (7.3.8.3)
 RBT_DEV void pz_sao(RbtParse* s, int rx, int ry) {
   RbtCabacDec* c = &s->c;
-  rx = RBT_UNI(rx); ry = RBT_UNI(ry);
+  rx = PZ_WU(rx); ry = PZ_WU(ry);
   RbtSao p; for (int i = 0; i < 3; i++) { p.type[i] = p.band_pos[i] = p.eo_class[i] = 0; for (int k = 0; k < 4; k++) p.offset[i][k] = 0; }
   p.pad[0] = p.pad[1] = p.pad[2] = 0;
   int wc = pzc_w_ctb(s);
@@ -506,7 +510,7 @@ RBT_DEV void pz_transform_unit(RbtParse* s, int x0, int y0, int xb, int yb, int 
 #ifdef RBT_PROFILE
   unsigned long long ttu_ = __builtin_readcyclecounter();
 #endif
-  x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); xb = RBT_UNI(xb); yb = RBT_UNI(yb); log2 = RBT_UNI(log2); blk = RBT_UNI(blk); cbf_luma = RBT_UNI(cbf_luma); cbf_cb = RBT_UNI(cbf_cb); cbf_cr = RBT_UNI(cbf_cr);
+  x0 = PZ_WU(x0); y0 = PZ_WU(y0); xb = PZ_WU(xb); yb = PZ_WU(yb); log2 = PZ_WU(log2); blk = PZ_WU(blk); cbf_luma = PZ_WU(cbf_luma); cbf_cb = PZ_WU(cbf_cb); cbf_cr = PZ_WU(cbf_cr);
   int N = 1 << log2;
   if ((cbf_luma || cbf_cb || cbf_cr) && pzc_cu_qp_delta(s) && !s->is_cu_qp_delta_coded) {
     int v = 0; while (v < 5 && rbt_cd_bin(c, CTX_CU_QP_DELTA + (v ? 1 : 0))) v++;
@@ -557,7 +561,7 @@ RBT_DEV void pz_transform_tree(RbtParse* s, int x0, int y0, int xb0, int yb0, in
   const int intra = s->cu_pred_mode == RBT_MODE_INTRA;
   const int intra_split = intra && s->cu_part_mode == RBT_PART_NxN;
   while (!s->error) {
-    lvl = RBT_UNI(lvl); x = RBT_UNI(x); y = RBT_UNI(y); lg = RBT_UNI(lg); states = (uint32_t)RBT_UNI(states); flags = (uint32_t)RBT_UNI(flags);
+    lvl = PZ_WU(lvl); x = PZ_WU(x); y = PZ_WU(y); lg = PZ_WU(lg); states = (uint32_t)PZ_WU(states); flags = (uint32_t)PZ_WU(flags);
     int st = (int)((states >> (4 * lvl)) & 15u);
     if (st == 15) {
       int inter_split = pzc_th_depth_inter(s) == 0 && !intra && s->cu_part_mode != RBT_PART_2Nx2N && lvl == 0;
@@ -691,7 +695,7 @@ RBT_DEV int pz_mvd_comp(RbtCabacDec* c, int gt0, int gt1) {
 }
 RBT_DEV void pz_prediction_unit(RbtParse* s, int x0, int y0, int w, int h, int part_idx, int skip) {
   RbtCabacDec* c = &s->c;
-  x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); w = RBT_UNI(w); h = RBT_UNI(h); part_idx = RBT_UNI(part_idx); skip = RBT_UNI(skip);
+  x0 = PZ_WU(x0); y0 = PZ_WU(y0); w = PZ_WU(w); h = PZ_WU(h); part_idx = PZ_WU(part_idx); skip = PZ_WU(skip);
   RbtMv mv;
   int merge = skip ? 1 : rbt_cd_bin(c, CTX_MERGE_FLAG);
   s->last_pu_merge = merge;
@@ -736,7 +740,7 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
 #ifdef RBT_PROFILE
   unsigned long long tcu_ = __builtin_readcyclecounter(); s->n_cu++;
 #endif
-  x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); log2 = RBT_UNI(log2); depth = RBT_UNI(depth);
+  x0 = PZ_WU(x0); y0 = PZ_WU(y0); log2 = PZ_WU(log2); depth = PZ_WU(depth);
 #ifdef RBT_PROFILE
   s->t_last = __builtin_readcyclecounter();
 #endif
@@ -866,7 +870,7 @@ RBT_DEV void pz_coding_quadtree(RbtParse* s, int x0, int y0, int log2) {
   int lvl = 0, x = x0, y = y0, lg = log2;
   uint32_t states = 15u;
   while (!s->error) {
-    lvl = RBT_UNI(lvl); x = RBT_UNI(x); y = RBT_UNI(y); lg = RBT_UNI(lg); states = (uint32_t)RBT_UNI(states);
+    lvl = PZ_WU(lvl); x = PZ_WU(x); y = PZ_WU(y); lg = PZ_WU(lg); states = (uint32_t)PZ_WU(states);
     int st = (int)((states >> (4 * lvl)) & 15u);
     int N = 1 << lg;
     if (st == 15) {
