@@ -28,6 +28,7 @@ struct RbtEncLds {
   uint8_t mode[3][16];
   uint8_t split[3][16];
   uint16_t cg_mask[64];      // entropy: significance mask of each 4x4 coefficient group (bit n = scan position n)
+  uint16_t src[65 * 66];     // analysis: source samples of a 32x32 quadrant and what its blocks reference around it: (yy + 1) * 66 + xx + 1, xx,yy = -1..63
 };
 
 // sum of v over the lanes of the wave (host emulation: the PAR_FOR already accumulated everything)
@@ -35,12 +36,14 @@ RBT_DEV int en_wave_sum(int v, RBT_LDS_AS RbtEncLds* l) {
 #ifdef RBT_HOSTEMU
   (void)l; return v;
 #else
-  l->red[threadIdx.x] = v;
-  RBT_SYNC_LDS();
-  int s = 0;
-  for (int i = 0; i < 64; i++) s += l->red[i];
-  RBT_SYNC_LDS();
-  return s;
+  (void)l;
+  // DPP butterflies inside each row of 16 lanes (quad swaps, half-row mirror, row mirror), then the four row sums
+  int x = v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);    // quad_perm:[1,0,3,2]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);    // quad_perm:[2,3,0,1]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false);   // row_half_mirror
+  x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false);   // row_mirror
+  return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
 #endif
 }
 RBT_DEV int en_chroma_qp(const RbtFrame* f, const RbtSlice* sl, int c_idx, int qp_y) {
@@ -51,34 +54,76 @@ RBT_DEV int en_chroma_qp(const RbtFrame* f, const RbtSlice* sl, int c_idx, int q
 }
 
 // ------------------------------------------------------------------------------------------------ analysis (I pictures)
+// availability (6.4.1) of luma position (xn,yn) as intra reference of the block at (xc,yc), both inside or next to CTB
+// (cx,cy): same result as rc_avail, from flags of the four neighbouring CTBs fetched once instead of map reads per sample
+struct EnCtbNb { int cx, cy, ctb, w, h, left, above_left, above, above_right; };
+RBT_DEV int en_avail(const EnCtbNb* q, int xc, int yc, int xn, int yn) {
+  if (xn < 0 || yn < 0 || xn >= q->w || yn >= q->h) return 0;
+  const int dx = xn - q->cx, dy = yn - q->cy;
+  if (dy >= q->ctb) return 0;
+  if (dy < 0) return dx < 0 ? q->above_left : (dx < q->ctb ? q->above : q->above_right);
+  if (dx < 0) return q->left;
+  if (dx >= q->ctb) return 0;
+  return rc_morton(dx >> 2, dy >> 2) < rc_morton((xc - q->cx) >> 2, (yc - q->cy) >> 2);
+}
+RBT_DEV int en_nb_av(const EnCtbNb* q, int i, int x0, int y0, int S) { int xn, yn; rc_nb_xy(i, x0, y0, S, &xn, &yn); return en_avail(q, x0, y0, xn, yn); }
 RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtEncLds* l) {
-  const RbtStreamCfg* g = &f->cfg;
-  int ctb = 1 << g->log2_ctb, cx = (ctb_addr % g->w_ctb) << g->log2_ctb, cy = (ctb_addr / g->w_ctb) << g->log2_ctb;
-  const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
+  const RbtStreamCfg gcopy = f->cfg; const RbtStreamCfg* g = &gcopy;
+  int ctb = 1 << g->log2_ctb, rx = ctb_addr % g->w_ctb, ry = ctb_addr / g->w_ctb, cx = rx << g->log2_ctb, cy = ry << g->log2_ctb;
+  const int my_slice = f->ctb_slice[ctb_addr];
+  const RbtSlice* sl = &slices[my_slice];
   RBT_LDS_AS RbtReconLds* rl = &l->rc;
+  EnCtbNb nbq; nbq.cx = cx; nbq.cy = cy; nbq.ctb = ctb; nbq.w = g->w; nbq.h = g->h;
+  nbq.left = rx > 0 && f->ctb_slice[ctb_addr - 1] == my_slice;
+  nbq.above = ry > 0 && f->ctb_slice[ctb_addr - g->w_ctb] == my_slice;
+  nbq.above_left = rx > 0 && ry > 0 && f->ctb_slice[ctb_addr - g->w_ctb - 1] == my_slice;
+  nbq.above_right = ry > 0 && rx + 1 < g->w_ctb && f->ctb_slice[ctb_addr - g->w_ctb + 1] == my_slice;
+  const uint16_t* srcp = f->src[0];
   // CTBs larger than 32 are analysed as independent 32x32 quadrants (a 64x64 intra CU is always split)
   int nq = ctb > 32 ? 2 : 1, qs = ctb > 32 ? 32 : ctb;
   for (int q = 0; q < nq * nq; q++) {
     int qx = cx + (q % nq) * 32, qy = cy + (q / nq) * 32;
     if (nq > 1 && (qx >= g->w || qy >= g->h)) continue;
+    // source samples of the quadrant and of everything its blocks can reference (one row / column before it, 2 * 32 beyond)
+    RBT_PAR_FOR(i, 65 * 65) {
+      int xx = i % 65 - 1, yy = i / 65 - 1, x = qx + xx, y = qy + yy;
+      l->src[(yy + 1) * 66 + xx + 1] = (x >= 0 && y >= 0 && x < g->w && y < g->h) ? srcp[(size_t)y * g->w + x] : 0;
+    }
+    RBT_SYNC_LDS();
     for (int si = 0; si < 3; si++) {
       int S = 8 << si; if (S > qs) break;
-      int nb = qs / S;
+      int nb = qs / S, lg = 3 + si;
       for (int b = 0; b < nb * nb; b++) {
         int x0 = qx + (b % nb) * S, y0 = qy + (b / nb) * S, best = 0x7FFFFFFF, bmode = 0;
         if (x0 >= g->w || y0 >= g->h) best = 0;
         else if (x0 + S > g->w || y0 + S > g->h) best = RBT_PARTIAL_COST;
         else {
+          // reference samples once per block: availability masks, substitution (8.4.4.2.2) while gathering, and the smoothed copy
+          const int tot = 4 * S + 1, bx0 = x0 - qx, by0 = y0 - qy;
+          uint64_t m0, m1 = 0; int m2 = 0;
+          { RBT_VBALLOT(m0, p, rbt_min(tot, 64), en_nb_av(&nbq, p, x0, y0, S)); }
+          if (tot > 64) { RBT_VBALLOT(m1, p, rbt_min(tot - 64, 64), en_nb_av(&nbq, 64 + p, x0, y0, S)); }
+          if (tot > 128) m2 = en_nb_av(&nbq, 128, x0, y0, S);
+          const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : (m2 ? 128 : -1));
+          RBT_PAR_FOR(i, tot) {
+            int v = 1 << (g->bit_depth - 1);
+            if (first >= 0) { int j = rc_last_avail(i, m0, m1, m2); if (j < 0) j = first; int xn, yn; rc_nb_xy(j, bx0, by0, S, &xn, &yn); v = l->src[(yn + 1) * 66 + xn + 1]; }
+            rl->nb[i] = v;
+          }
+          RBT_SYNC_LDS();
+          rc_intra_filter_apply(g, lg, rl->nb, rl->nbf);
           for (int k = 0; k < 11; k++) {
             int mode = k_intra_cand[k];
-            rc_intra_pred(f, f->src[0], 0, x0, y0, 3 + si, mode, rl);
+            RBT_LDS_AS int32_t* fin = rc_intra_filter_needed(0, lg, mode) ? rl->nbf : rl->nb;
+            RcIntraCtx qc; rc_intra_setup(g, 0, lg, mode, fin, rl, &qc);
             int part = 0;
-            RBT_PAR_FOR(i, S * S) { int x = i & (S - 1), y = i >> (3 + si); part += rbt_abs((int)f->src[0][(size_t)(y0 + y) * g->w + x0 + x] - (int)rl->pred[i]); }
+            RBT_PAR_FOR(i, S * S) { int x = i & (S - 1), y = i >> lg; part += rbt_abs((int)l->src[(by0 + y + 1) * 66 + bx0 + x + 1] - rc_intra_sample(&qc, fin, rl, x, y)); }
             int sad = en_wave_sum(part, l);
             if (sad < best) { best = sad; bmode = mode; }
+            RBT_SYNC_LDS();                                     // rl->ref is rebuilt by the next mode
           }
         }
-        if (RBT_LANE0) { l->cost[si][b] = best; l->mode[si][b] = (uint8_t)bmode; }
+    if (RBT_LANE0) { l->cost[si][b] = best; l->mode[si][b] = (uint8_t)bmode; }
       }
     }
     RBT_SYNC_LDS();

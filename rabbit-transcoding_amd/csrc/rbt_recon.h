@@ -88,15 +88,14 @@ RBT_DEV int rc_last_avail(int i, uint64_t m0, uint64_t m1, int m2) {
 // Substitution (8.4.4.2.2) + smoothing (8.4.4.2.3) of the gathered neighbours; `have_nb` = 0 when the caller wants the
 // substituted samples fetched through `fetch(j)` semantics instead (tile variant fills l->nb itself). Returns the array that
 // holds the final reference samples (l->nb or l->nbf: the two are swapped, never copied).
-RBT_DEV RBT_LDS_AS int32_t* rc_intra_filter(const RbtStreamCfg* g, int c_idx, int log2, int mode, RBT_LDS_AS int32_t* nb, RBT_LDS_AS int32_t* alt) {
+RBT_DEV int rc_intra_filter_needed(int c_idx, int log2, int mode) {       // filterFlag of 8.4.4.2.3
+  const int N = 1 << log2;
+  if (c_idx != 0 || mode == 1 || N == 4) return 0;
+  const int md = rbt_min(rbt_abs(mode - 26), rbt_abs(mode - 10)), thr = N == 8 ? 7 : (N == 16 ? 1 : 0);
+  return md > thr;
+}
+RBT_DEV void rc_intra_filter_apply(const RbtStreamCfg* g, int log2, RBT_LDS_AS int32_t* nb, RBT_LDS_AS int32_t* alt) {   // nb -> alt
   const int N = 1 << log2, bd = g->bit_depth, tot = 4 * N + 1;
-  int filt = 0;
-  if (c_idx == 0 && mode != 1 && N != 4) {
-    int md = rbt_min(rbt_abs(mode - 26), rbt_abs(mode - 10));
-    int thr = N == 8 ? 7 : (N == 16 ? 1 : 0);
-    filt = md > thr;
-  }
-  if (!filt) return nb;
   int corner = nb[2 * N], bl = nb[0], tr = nb[4 * N];
   int strong = g->strong_intra && N == 32 && rbt_abs(corner + tr - 2 * nb[2 * N + 32]) < (1 << (bd - 5)) &&
                rbt_abs(corner + bl - 2 * nb[2 * N - 32]) < (1 << (bd - 5));
@@ -111,6 +110,10 @@ RBT_DEV RBT_LDS_AS int32_t* rc_intra_filter(const RbtStreamCfg* g, int c_idx, in
     alt[i] = v;
   }
   RBT_SYNC_LDS();
+}
+RBT_DEV RBT_LDS_AS int32_t* rc_intra_filter(const RbtStreamCfg* g, int c_idx, int log2, int mode, RBT_LDS_AS int32_t* nb, RBT_LDS_AS int32_t* alt) {
+  if (!rc_intra_filter_needed(c_idx, log2, mode)) return nb;
+  rc_intra_filter_apply(g, log2, nb, alt);
   return alt;
 }
 // availability masks of the 4N+1 gathered neighbours (l->av) -> m[0] (indices 0..63), m[1] (64..127), *m2 (128)
