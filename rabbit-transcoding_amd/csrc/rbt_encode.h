@@ -85,10 +85,16 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
     int qx = cx + (q % nq) * 32, qy = cy + (q / nq) * 32;
     if (nq > 1 && (qx >= g->w || qy >= g->h)) continue;
     // source samples of the quadrant and of everything its blocks can reference (one row / column before it, 2 * 32 beyond)
-    RBT_PAR_FOR(i, 65 * 65) {
-      int xx = i % 65 - 1, yy = i / 65 - 1, x = qx + xx, y = qy + yy;
-      l->src[(yy + 1) * 66 + xx + 1] = (x >= 0 && y >= 0 && x < g->w && y < g->h) ? srcp[(size_t)y * g->w + x] : 0;
+    // rows yy = -1..63, columns 0..63 as 8-byte groups of four samples (qx is a multiple of 32, the width a multiple of 8), several loads in flight
+#pragma unroll 4
+    RBT_PAR_FOR(i, 65 * 16) {
+      const int x4 = i & 15, yy = (i >> 4) - 1, x = qx + 4 * x4, y = qy + yy;
+      RbtU2 v; v.x = 0; v.y = 0;
+      if (y >= 0 && y < g->h && x < g->w) v = *(const RbtU2*)(srcp + (size_t)y * g->w + x);
+      RBT_LDS_AS uint16_t* d = &l->src[(yy + 1) * 66 + 4 * x4 + 1];
+      d[0] = (uint16_t)v.x; d[1] = (uint16_t)(v.x >> 16); d[2] = (uint16_t)v.y; d[3] = (uint16_t)(v.y >> 16);
     }
+    RBT_PAR_FOR(i, 65) { const int x = qx - 1, y = qy + i - 1; l->src[i * 66] = (x >= 0 && y >= 0 && y < g->h) ? srcp[(size_t)y * g->w + x] : 0; }
     RBT_SYNC_LDS();
     for (int si = 0; si < 3; si++) {
       int S = 8 << si; if (S > qs) break;
