@@ -1,22 +1,43 @@
 // See rbt_hls.h. H.265 7.3.1.1 (NAL), 7.3.2.x (parameter sets), 7.3.6 (slice segment header), D.2.19 (picture hash).
+#include <cstring>
 #include "rbt_hls.h"
 #include <cmath>
 
 namespace rbt {
 
+// Start codes and emulation-prevention bytes both begin with 00 00, so the scan jumps from one zero byte to the next
+// with memchr and copies the spans in between with one insert each (the byte loop cost ~1.3 ms per MB on the critical path).
 void split_annexb(const uint8_t* p, size_t n, std::vector<uint8_t>& rbsp, std::vector<Nal>& nals) {
-  auto find = [&](size_t from) { for (size_t i = from; i + 3 <= n; i++) if (p[i] == 0 && p[i + 1] == 0 && p[i + 2] == 1) return i; return n; };
+  auto find = [&](size_t from) {
+    while (from + 3 <= n) {
+      const uint8_t* z = (const uint8_t*)memchr(p + from, 0, n - from - 2);
+      if (!z) return n;
+      size_t i = (size_t)(z - p);
+      if (p[i + 1] == 0 && p[i + 2] == 1) return i;
+      from = i + 1;
+    }
+    return n;
+  };
+  rbsp.reserve(rbsp.size() + n);
   size_t pos = find(0);
   while (pos < n) {
     size_t ns = pos + 3, next = find(ns), ne = next;
     while (ne > ns && p[ne - 1] == 0) ne--;
     if (ne - ns >= 2) {
       Nal nal; nal.type = (p[ns] >> 1) & 0x3F; nal.rbsp_off = rbsp.size();
-      int z = 0;
-      for (size_t i = ns; i < ne; i++) {
-        if (z >= 2 && p[i] == 3) { z = 0; continue; }
-        z = p[i] == 0 ? z + 1 : 0;
-        rbsp.push_back(p[i]);
+      size_t i = ns;
+      while (i < ne) {
+        // next 00 00 03 inside [i, ne): everything before its 03 is payload
+        size_t j = i, cut = ne;
+        while (j + 2 < ne) {
+          const uint8_t* z = (const uint8_t*)memchr(p + j, 0, ne - j - 2);
+          if (!z) break;
+          size_t k = (size_t)(z - p);
+          if (p[k + 1] == 0 && p[k + 2] == 3) { cut = k + 2; break; }
+          j = k + 1;
+        }
+        rbsp.insert(rbsp.end(), p + i, p + cut);
+        i = cut < ne ? cut + 1 : ne;                  // skip the emulation prevention byte
       }
       nal.rbsp_size = rbsp.size() - nal.rbsp_off;
       nals.push_back(nal);

@@ -25,6 +25,7 @@ struct EncodeBatch {
   RbtFrame* d_frames = nullptr; RbtSlice* d_slices = nullptr; int32_t* d_lists = nullptr; uint8_t* d_out = nullptr; uint8_t* d_packed = nullptr; uint32_t* d_dst = nullptr;
   size_t out_total = 0;
   std::vector<std::vector<uint16_t>> cs_keep;   // host staging of the ctb->slice maps, alive until the copies have completed
+  std::vector<int32_t> lists_keep; size_t off_i = 0, off_ideb = 0, off_p = 0, off_sl = 0; int n_i = 0, n_ideb = 0, n_p = 0;   // index lists (encode_upload_lists)
   std::string err;
   ~EncodeBatch() { rbtk::dev_free(arena); }
 };
@@ -116,31 +117,42 @@ static int encode_build(EncodeBatch& b) {
 }
 
 // runs the kernels and packs one Annex-B stream per input stream
-static int encode_run(EncodeBatch& b, std::vector<std::vector<uint8_t>>& outs, rbt_stats& st) {
+// The encoder of one stream is enqueued in three steps so that nothing on the host waits for the GPU in between:
+// encode_upload_lists (host -> device copies, issued while the stream is still empty), encode_launch (kernels up to the
+// entropy coder, may be enqueued behind the decoder's kernels on the same stream), encode_finish (one sync, packing, NALs).
+static int encode_upload_lists(EncodeBatch& b) {
   size_t nf = b.frames.size(), ns = b.slices.size();
-  std::vector<int32_t> lists; size_t off_i, off_ideb, off_p, off_sl; int n_i = 0, n_ideb = 0, n_p = 0;
-  off_i = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i]) { lists.push_back((int)i); n_i++; }
-  off_ideb = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i] && !b.frames[i].lossless) { lists.push_back((int)i); n_ideb++; }
-  off_p = lists.size(); for (size_t i = 0; i < nf; i++) if (!b.frame_is_idr[i]) { lists.push_back((int)i); n_p++; }
-  off_sl = lists.size(); for (size_t i = 0; i < ns; i++) lists.push_back((int)i);
+  std::vector<int32_t>& lists = b.lists_keep; lists.clear(); b.n_i = b.n_ideb = b.n_p = 0;
+  b.off_i = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i]) { lists.push_back((int)i); b.n_i++; }
+  b.off_ideb = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i] && !b.frames[i].lossless) { lists.push_back((int)i); b.n_ideb++; }
+  b.off_p = lists.size(); for (size_t i = 0; i < nf; i++) if (!b.frame_is_idr[i]) { lists.push_back((int)i); b.n_p++; }
+  b.off_sl = lists.size(); for (size_t i = 0; i < ns; i++) lists.push_back((int)i);
   if (rbtk::h2d(b.d_lists, lists.data(), lists.size() * sizeof(int32_t))) { b.err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
+  return 0;
+}
+static int encode_launch(EncodeBatch& b) {
+  size_t nf = b.frames.size(), ns = b.slices.size();
   int mw = 0, mh = 0, mu = 0, mc = 0, row_mode = 1;
   for (size_t i = 0; i < nf; i++) {
     const RbtStreamCfg& c = b.frames[i].cfg; mw = std::max(mw, c.w_ctb); mh = std::max(mh, c.h_ctb); mu = std::max(mu, c.w4 * c.h4); mc = std::max(mc, c.w_ctb * c.h_ctb);
     if (b.desc[b.frame_stream[i]].rows != 1) row_mode = 0;
   }
   rbtk::timer_begin(T_ANALYSE);
-  rbtk::launch_enc_analyse(b.d_frames, b.d_slices, b.d_lists + off_i, n_i, mc);
+  rbtk::launch_enc_analyse(b.d_frames, b.d_slices, b.d_lists + b.off_i, b.n_i, mc);
   rbtk::timer_end(T_ANALYSE);
   rbtk::timer_begin(T_ENCODE);
-  rbtk::launch_enc_intra(b.d_frames, b.d_slices, b.d_lists + off_i, n_i, mw, mh, row_mode);
-  rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + off_ideb, n_ideb, mu);
-  rbtk::launch_enc_inter(b.d_frames, b.d_slices, b.d_lists + off_p, n_p, mc);
-  rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + off_p, n_p, mu);
+  rbtk::launch_enc_intra(b.d_frames, b.d_slices, b.d_lists + b.off_i, b.n_i, mw, mh, row_mode);
+  rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_ideb, b.n_ideb, mu);
+  rbtk::launch_enc_inter(b.d_frames, b.d_slices, b.d_lists + b.off_p, b.n_p, mc);
+  rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_p, b.n_p, mu);
   rbtk::timer_end(T_ENCODE);
   rbtk::timer_begin(T_ENTROPY);
-  rbtk::launch_entropy(b.d_frames, b.d_slices, b.d_out, b.d_lists + off_sl, (int)ns);
+  rbtk::launch_entropy(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_sl, (int)ns);
   rbtk::timer_end(T_ENTROPY);
+  return 0;
+}
+static int encode_finish(EncodeBatch& b, std::vector<std::vector<uint8_t>>& outs, rbt_stats& st) {
+  size_t nf = b.frames.size(), ns = b.slices.size();
   if (rbtk::d2h(b.slices.data(), b.d_slices, ns * sizeof(RbtSlice))) { b.err = "kernel execution failed"; return RBT_ERR_NO_DEVICE; }
   std::vector<uint32_t> dst(ns); size_t total = 0;
   for (size_t i = 0; i < ns; i++) { if (b.slices[i].out_size > b.slices[i].out_cap) { b.err = "slice data exceeds its buffer"; return RBT_ERR_NOMEM; } dst[i] = (uint32_t)total; total += b.slices[i].out_size; }
@@ -185,6 +197,12 @@ static int encode_run(EncodeBatch& b, std::vector<std::vector<uint8_t>>& outs, r
   return 0;
 }
 
+static int encode_run(EncodeBatch& b, std::vector<std::vector<uint8_t>>& outs, rbt_stats& st) {
+  int rc = encode_upload_lists(b);
+  if (!rc) rc = encode_launch(b);
+  return rc ? rc : encode_finish(b, outs, st);
+}
+
 static int hand_out(const std::vector<std::vector<uint8_t>>& outs, uint8_t** out, size_t* n_out) {
   for (size_t i = 0; i < outs.size(); i++) {
     out[i] = (uint8_t*)malloc(outs[i].size() ? outs[i].size() : 1);
@@ -195,7 +213,9 @@ static int hand_out(const std::vector<std::vector<uint8_t>>& outs, uint8_t** out
 }
 
 // Pool + encoder setup for the one stream of `db` (PCCTranscoder.cpp:466, :825-904).
-static int setup_encode(DecodeBatch& db, const rbt_stream_params& p, EncodeBatch& eb, std::vector<void*>& pooled, std::string& err) {
+struct PoolJob { const uint16_t* in; int w, h; uint16_t *y, *cb, *cr; int grey; };
+// pool_jobs != nullptr: the OR-pool launches are recorded instead of issued (the decoder's kernels are not enqueued yet)
+static int setup_encode(DecodeBatch& db, const rbt_stream_params& p, EncodeBatch& eb, std::vector<void*>& pooled, std::string& err, std::vector<PoolJob>* pool_jobs = nullptr) {
   eb.desc.resize(1);
   EncStreamDesc& d = eb.desc[0]; int first = db.stream_first[0], cnt = db.stream_count[0];
   const RbtStreamCfg& c = db.frames[first].cfg;
@@ -210,14 +230,15 @@ static int setup_encode(DecodeBatch& db, const rbt_stream_params& p, EncodeBatch
       uint16_t* buf = (uint16_t*)rbtk::dev_alloc((ys + 2 * cs) * 2 * (size_t)cnt);
       if (!buf) { err = "device allocation failed"; return RBT_ERR_NOMEM; }
       pooled.push_back(buf);
-      rbtk::timer_begin(T_POOL);
+      if (!pool_jobs) rbtk::timer_begin(T_POOL);
       for (int k = 0; k < cnt; k++) {
         uint16_t* y = buf + (ys + 2 * cs) * (size_t)k;
         // the reference leaves the pooled chroma planes unwritten (PCCTranscoder.cpp:638-641); mid-grey here
-        rbtk::launch_pool(db.frames[first + k].out[0], c.w, c.h, 2, y, y + ys, y + ys + cs, 1 << (c.bit_depth - 1));
+        if (pool_jobs) pool_jobs->push_back(PoolJob{db.frames[first + k].out[0], c.w, c.h, y, y + ys, y + ys + cs, 1 << (c.bit_depth - 1)});
+        else rbtk::launch_pool(db.frames[first + k].out[0], c.w, c.h, 2, y, y + ys, y + ys + cs, 1 << (c.bit_depth - 1));
         d.src[0][k] = y; d.src[1][k] = y + ys; d.src[2][k] = y + ys + cs;
       }
-      rbtk::timer_end(T_POOL);
+      if (!pool_jobs) rbtk::timer_end(T_POOL);
     } else for (int k = 0; k < cnt; k++) for (int q = 0; q < 3; q++) d.src[q][k] = db.frames[first + k].out[q];
   } else {
     d.gop = 2; d.lossless = 0; d.i_qp_offset = -3; d.w = c.w; d.h = c.h;
@@ -239,37 +260,55 @@ int transcode_gof(rbt_stats& st, std::string& err, int n, const uint8_t* const* 
   struct Guard { std::vector<void*>& v; ~Guard() { rbtk::set_stream(0); for (void* q : v) rbtk::dev_free(q); } } guard{pooled};
   std::vector<int> order(n); for (int i = 0; i < n; i++) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n_in[a] > n_in[b]; });
-  // ---- decode (PCCTranscoder.cpp:428-448): build and enqueue every stream, longest first ----
+  // ---- phase A, longest stream first: build decoder and encoder batches, upload, then enqueue decode -> pool -> encode on
+  // the stream without a host round trip in between (PCCTranscoder.cpp:428-448, :466, :825-904). Streams that ask for the
+  // input MD5 check keep the decoder / encoder split, because the check needs the decoded pictures on the host first.
   double t_gpu = now_ms();
-  for (int k = 0; k < n; k++) {
+  std::vector<char> chained(n, 0);
+  int rc = 0;
+  for (int k = 0; k < n && !rc; k++) {
     int i = order[k]; rbtk::set_stream(i);
     StreamIn sin{in[i], n_in[i]};
     double t0 = now_ms();
-    int rc = decode_build(db[i], &sin, 1);
+    rc = decode_build(db[i], &sin, 1);
     st.host_parse_ms += now_ms() - t0;
-    if (!rc) rc = decode_launch(db[i]);
-    if (rc) { err = db[i].err; for (int q = 0; q < k; q++) { rbtk::set_stream(order[q]); rbtk::dev_sync(); } rbtk::set_stream(0); return rc; }
+    if (rc) { err = db[i].err; break; }
+    std::vector<PoolJob> jobs;
+    if (!p[i].verify_md5) {
+      rc = setup_encode(db[i], p[i], eb[i], pooled, err, &jobs);
+      if (!rc) { rc = encode_build(eb[i]); if (!rc) rc = encode_upload_lists(eb[i]); if (rc) err = eb[i].err; }
+      if (rc) break;
+      chained[i] = 1;
+    }
+    rc = decode_launch(db[i]);
+    if (rc) { err = db[i].err; break; }
+    if (chained[i]) {
+      if (!jobs.empty()) { rbtk::timer_begin(T_POOL); for (const PoolJob& j : jobs) rbtk::launch_pool(j.in, j.w, j.h, 2, j.y, j.cb, j.cr, j.grey); rbtk::timer_end(T_POOL); }
+      rc = encode_launch(eb[i]);
+      if (rc) err = eb[i].err;
+    }
   }
-  // ---- finish, pool, re-encode: shortest first ----
+  // ---- phase B, shortest stream first: one sync per stream, then slice sizes -> pack -> NAL assembly ----
   std::vector<std::vector<uint8_t>> outs(n);
-  int rc = 0;
   for (int k = n - 1; k >= 0; k--) {
     int i = order[k]; rbtk::set_stream(i);
     if (rc) { rbtk::dev_sync(); continue; }              // drain the remaining streams before their arenas are released
+    if (db[i].frames.empty()) continue;
     rc = decode_finish(db[i]);
     if (rc) { err = db[i].err; continue; }
     st.k_parse_ms += rbtk::timer_ms(T_PARSE); st.k_recon_ms += rbtk::timer_ms(T_RECON);
-    if (p[i].verify_md5) {
+    std::vector<std::vector<uint8_t>> o1;
+    if (chained[i]) rc = encode_finish(eb[i], o1, st);
+    else {
       rbt_video v; rc = decode_fetch(db[i], 0, &v, true); free(v.data);
       if (rc) { err = "fetch failed"; continue; }
       if (v.md5_failed) { err = "input MD5 mismatch"; rc = RBT_ERR_MD5; continue; }
+      rc = setup_encode(db[i], p[i], eb[i], pooled, err);
+      if (rc) continue;
+      rc = encode_build(eb[i]);
+      if (!rc) rc = encode_run(eb[i], o1, st);
     }
-    rc = setup_encode(db[i], p[i], eb[i], pooled, err);
-    if (rc) continue;
-    rc = encode_build(eb[i]);
-    std::vector<std::vector<uint8_t>> o1;
-    if (!rc) rc = encode_run(eb[i], o1, st);
-    if (rc) { err = eb[i].err; continue; }
+    if (rc) { if (err.empty()) err = eb[i].err; continue; }
     outs[i].swap(o1[0]);
   }
   rbtk::set_stream(0);
