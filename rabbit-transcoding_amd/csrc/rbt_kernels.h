@@ -10,8 +10,12 @@ namespace rbtk {
 int dev_init(int device);                 // 0 = ok
 // Independent sub-bitstreams run on separate HIP streams so that the short pipelines (occupancy, geometry) overlap the
 // long entropy-decoding chain of the attribute stream. All calls below act on the currently selected stream.
-enum { RBT_N_STREAMS = 4 };
+// The HIP runtime multiplexes streams onto 4 hardware queues by default; two streams sharing a queue serialise (measured:
+// with 8 streams the geometry upload queued behind the attribute kernels and blocked the host for 285 ms). So: 4 streams,
+// one per sub-bitstream pipeline, and the last one doubles as the auxiliary stream of the longest pipeline when free.
+enum { RBT_N_STREAMS = 4, RBT_AUX_STREAM = 3 };
 void set_stream(int i);
+void stream_wait(int waiter, int signaller);   // work enqueued on `waiter` from now on starts after everything enqueued on `signaller` so far
 const char* dev_name();
 void* dev_alloc(size_t n);                // nullptr on failure
 void dev_free(void* p);                   // returns the block to a recycling pool

@@ -11,7 +11,8 @@
 #include "rbt_encode.h"
 
 namespace rbtk {
-static hipStream_t g_streams[RBT_N_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+static hipStream_t g_streams[RBT_N_STREAMS] = {};
+static hipEvent_t g_dep_ev[64]; static int g_dep_next = 0;
 static int g_cur = 0;
 #define g_stream (g_streams[g_cur])
 static char g_name[256] = "";
@@ -29,11 +30,17 @@ int dev_init(int device) {
   hipDeviceProp_t p; HIPCHK(hipGetDeviceProperties(&p, device));
   snprintf(g_name, sizeof g_name, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
   for (int k = 0; k < RBT_N_STREAMS; k++) if (!g_streams[k]) HIPCHK(hipStreamCreateWithFlags(&g_streams[k], hipStreamNonBlocking));
-  if (!g_ev_init) { for (int k = 0; k < RBT_N_STREAMS; k++) for (int i = 0; i < 32; i++) { HIPCHK(hipEventCreate(&g_ev[k][i][0])); HIPCHK(hipEventCreate(&g_ev[k][i][1])); } g_ev_init = true; }
+  if (!g_ev_init) { for (int i = 0; i < 64; i++) HIPCHK(hipEventCreateWithFlags(&g_dep_ev[i], hipEventDisableTiming));
+    for (int k = 0; k < RBT_N_STREAMS; k++) for (int i = 0; i < 32; i++) { HIPCHK(hipEventCreate(&g_ev[k][i][0])); HIPCHK(hipEventCreate(&g_ev[k][i][1])); } g_ev_init = true; }
   return 0;
 }
 const char* dev_name() { return g_name; }
 void set_stream(int i) { g_cur = ((i % RBT_N_STREAMS) + RBT_N_STREAMS) % RBT_N_STREAMS; }
+void stream_wait(int waiter, int signaller) {
+  hipEvent_t e = g_dep_ev[g_dep_next]; g_dep_next = (g_dep_next + 1) % 64;
+  (void)hipEventRecord(e, g_streams[((signaller % RBT_N_STREAMS) + RBT_N_STREAMS) % RBT_N_STREAMS]);
+  (void)hipStreamWaitEvent(g_streams[((waiter % RBT_N_STREAMS) + RBT_N_STREAMS) % RBT_N_STREAMS], e, 0);
+}
 // Device allocations are recycled: hipMalloc / hipFree of GOF-sized arenas cost milliseconds each (hipFree also drains the
 // device), and a transcoder calls with the same sizes over and over. Freed blocks go to a small best-fit pool; at most
 // RBT_POOL_KEEP blocks are kept, the rest is returned to the driver.

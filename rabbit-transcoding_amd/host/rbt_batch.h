@@ -14,7 +14,7 @@ namespace rbt {
 struct StreamIn { const uint8_t* p; size_t n; };
 struct FrameInfo { int stream; int nal_type; bool has_md5; uint8_t md5[3][16]; bool sao; };
 
-enum { T_PARSE = 0, T_RECON = 1, T_FILTER = 2, T_ANALYSE = 3, T_ENCODE = 4, T_ENTROPY = 5, T_ALL = 6, T_POOL = 7, T_COUNT = 8 };
+enum { T_PARSE = 0, T_RECON = 1, T_FILTER = 2, T_ANALYSE = 3, T_ENCODE = 4, T_ENTROPY = 5, T_ALL = 6, T_POOL = 7, T_INTER = 8, T_COUNT = 9 };
 
 struct Arena {           // bump allocator over one device allocation
   uint8_t* base = nullptr; size_t size = 0, used = 0;
@@ -29,6 +29,7 @@ struct DecodeBatch {
   std::vector<std::vector<int>> level_frames;
   bool ordered_parse = false;
   std::vector<int32_t> lists_keep;     // host staging of the index lists, alive until the copy has completed
+  std::vector<size_t> fr_off;          // offset of each level's frame list inside d_lists
   void* arena = nullptr; size_t arena_size = 0;
   RbtFrame* d_frames = nullptr; RbtSlice* d_slices = nullptr; uint8_t* d_rbsp = nullptr; int32_t* d_lists = nullptr;
   std::string err; int err_code = 0;
@@ -37,6 +38,8 @@ struct DecodeBatch {
 
 int decode_build(DecodeBatch& b, const StreamIn* streams, int n);
 int decode_launch(DecodeBatch& b);   // enqueue every decode kernel of the batch on the current stream (no wait)
+int decode_launch_parse(DecodeBatch& b);            // index lists + entropy decoding
+void decode_launch_level(DecodeBatch& b, size_t l);  // reconstruction + loop filters of dependency level l
 int decode_finish(DecodeBatch& b);   // wait for the batch's stream and check the per-picture error words
 int decode_run(DecodeBatch& b);      // launch + finish
 int decode_fetch(DecodeBatch& b, int stream, rbt_video* out, bool verify_md5);

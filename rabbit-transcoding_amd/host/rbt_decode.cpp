@@ -137,39 +137,45 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
 int decode_run(DecodeBatch& b) { int rc = decode_launch(b); return rc ? rc : decode_finish(b); }
 
 int decode_launch(DecodeBatch& b) {
+  int rc = decode_launch_parse(b);
+  if (rc) return rc;
+  rbtk::timer_begin(T_RECON);
+  for (size_t l = 0; l < b.level_frames.size(); l++) decode_launch_level(b, l);
+  rbtk::timer_end(T_RECON);
+  return 0;
+}
+int decode_launch_parse(DecodeBatch& b) {
   size_t nf = b.frames.size(), ns = b.slices.size();
   // index lists: slices grouped by level, frames grouped by level
-  std::vector<int32_t>& lists = b.lists_keep; lists.clear(); std::vector<size_t> sl_off, sl_cnt, fr_off;
+  std::vector<int32_t>& lists = b.lists_keep; lists.clear(); std::vector<size_t> sl_off, sl_cnt; b.fr_off.clear();
   for (auto& lf : b.level_frames) {
     sl_off.push_back(lists.size());
     for (int fi : lf) for (int k = 0; k < b.frames[fi].n_slices; k++) lists.push_back(b.frames[fi].first_slice + k);
     sl_cnt.push_back(lists.size() - sl_off.back());
   }
-  for (auto& lf : b.level_frames) { fr_off.push_back(lists.size()); for (int fi : lf) lists.push_back(fi); }
+  for (auto& lf : b.level_frames) { b.fr_off.push_back(lists.size()); for (int fi : lf) lists.push_back(fi); }
   if (lists.size() > (nf + ns) * 2) { b.err = "internal: list overflow"; return b.err_code = RBT_ERR_PARAM; }
   if (rbtk::h2d(b.d_lists, lists.data(), lists.size() * sizeof(int32_t))) { b.err = "device transfer failed"; return b.err_code = RBT_ERR_NO_DEVICE; }
   rbtk::timer_begin(T_PARSE);
   if (b.ordered_parse) { for (size_t l = 0; l < b.level_frames.size(); l++) rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists + sl_off[l], (int)sl_cnt[l]); }
   else rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists, (int)ns);
   rbtk::timer_end(T_PARSE);
-  rbtk::timer_begin(T_RECON);
-  for (size_t l = 0; l < b.level_frames.size(); l++) {
-    const std::vector<int>& lf = b.level_frames[l];
-    int mw = 0, mh = 0, mu = 0, ml = 0; std::vector<int> sao_frames;
-    for (int fi : lf) { const RbtStreamCfg& c = b.frames[fi].cfg; mw = std::max(mw, c.w_ctb); mh = std::max(mh, c.h_ctb); mu = std::max(mu, c.w4 * c.h4); ml = std::max(ml, c.w * c.h); }
-    rbtk::launch_recon(b.d_frames, b.d_slices, b.d_lists + fr_off[l], (int)lf.size(), mw, mh);
-    rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + fr_off[l], (int)lf.size(), mu);
-    // SAO frames of this level are a contiguous sub-list only if all (or none) use SAO; otherwise launch per frame run
-    size_t k = 0;
-    while (k < lf.size()) {
-      if (!b.info[lf[k]].sao) { k++; continue; }
-      size_t e = k; while (e < lf.size() && b.info[lf[e]].sao) e++;
-      rbtk::launch_sao(b.d_frames, b.d_slices, b.d_lists + fr_off[l] + k, (int)(e - k), ml);
-      k = e;
-    }
-  }
-  rbtk::timer_end(T_RECON);
   return 0;
+}
+void decode_launch_level(DecodeBatch& b, size_t l) {
+  const std::vector<int>& lf = b.level_frames[l];
+  int mw = 0, mh = 0, mu = 0, ml = 0;
+  for (int fi : lf) { const RbtStreamCfg& c = b.frames[fi].cfg; mw = std::max(mw, c.w_ctb); mh = std::max(mh, c.h_ctb); mu = std::max(mu, c.w4 * c.h4); ml = std::max(ml, c.w * c.h); }
+  rbtk::launch_recon(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l], (int)lf.size(), mw, mh);
+  rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l], (int)lf.size(), mu);
+  // SAO frames of this level are a contiguous sub-list only if all (or none) use SAO; otherwise launch per frame run
+  size_t k = 0;
+  while (k < lf.size()) {
+    if (!b.info[lf[k]].sao) { k++; continue; }
+    size_t e = k; while (e < lf.size() && b.info[lf[e]].sao) e++;
+    rbtk::launch_sao(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l] + k, (int)(e - k), ml);
+    k = e;
+  }
 }
 
 int decode_finish(DecodeBatch& b) {

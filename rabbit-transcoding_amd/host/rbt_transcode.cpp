@@ -25,6 +25,7 @@ struct EncodeBatch {
   RbtFrame* d_frames = nullptr; RbtSlice* d_slices = nullptr; int32_t* d_lists = nullptr; uint8_t* d_out = nullptr; uint8_t* d_packed = nullptr; uint32_t* d_dst = nullptr;
   size_t out_total = 0;
   std::vector<std::vector<uint16_t>> cs_keep;   // host staging of the ctb->slice maps, alive until the copies have completed
+  int main_stream = 0, aux_stream = -1;          // aux_stream >= 0: the intra part was enqueued there (its timers live there)
   std::vector<int32_t> lists_keep; size_t off_i = 0, off_ideb = 0, off_p = 0, off_sl = 0; int n_i = 0, n_ideb = 0, n_p = 0;   // index lists (encode_upload_lists)
   std::string err;
   ~EncodeBatch() { rbtk::dev_free(arena); }
@@ -130,8 +131,9 @@ static int encode_upload_lists(EncodeBatch& b) {
   if (rbtk::h2d(b.d_lists, lists.data(), lists.size() * sizeof(int32_t))) { b.err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
   return 0;
 }
-static int encode_launch(EncodeBatch& b) {
-  size_t nf = b.frames.size(), ns = b.slices.size();
+// intra pictures (analysis, closed-loop intra coding, deblocking): they only read their own source pictures
+static void encode_launch_intra(EncodeBatch& b) {
+  size_t nf = b.frames.size();
   int mw = 0, mh = 0, mu = 0, mc = 0, row_mode = 1;
   for (size_t i = 0; i < nf; i++) {
     const RbtStreamCfg& c = b.frames[i].cfg; mw = std::max(mw, c.w_ctb); mh = std::max(mh, c.h_ctb); mu = std::max(mu, c.w4 * c.h4); mc = std::max(mc, c.w_ctb * c.h_ctb);
@@ -143,14 +145,22 @@ static int encode_launch(EncodeBatch& b) {
   rbtk::timer_begin(T_ENCODE);
   rbtk::launch_enc_intra(b.d_frames, b.d_slices, b.d_lists + b.off_i, b.n_i, mw, mh, row_mode);
   rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_ideb, b.n_ideb, mu);
+  rbtk::timer_end(T_ENCODE);
+}
+// inter pictures (need the reconstructed intra pictures and their own sources), then the entropy coder for every slice
+static void encode_launch_rest(EncodeBatch& b) {
+  size_t nf = b.frames.size(), ns = b.slices.size();
+  int mu = 0, mc = 0;
+  for (size_t i = 0; i < nf; i++) { const RbtStreamCfg& c = b.frames[i].cfg; mu = std::max(mu, c.w4 * c.h4); mc = std::max(mc, c.w_ctb * c.h_ctb); }
+  rbtk::timer_begin(T_INTER);
   rbtk::launch_enc_inter(b.d_frames, b.d_slices, b.d_lists + b.off_p, b.n_p, mc);
   rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_p, b.n_p, mu);
-  rbtk::timer_end(T_ENCODE);
+  rbtk::timer_end(T_INTER);
   rbtk::timer_begin(T_ENTROPY);
   rbtk::launch_entropy(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_sl, (int)ns);
   rbtk::timer_end(T_ENTROPY);
-  return 0;
 }
+static int encode_launch(EncodeBatch& b) { encode_launch_intra(b); encode_launch_rest(b); return 0; }
 static int encode_finish(EncodeBatch& b, std::vector<std::vector<uint8_t>>& outs, rbt_stats& st) {
   size_t nf = b.frames.size(), ns = b.slices.size();
   if (rbtk::d2h(b.slices.data(), b.d_slices, ns * sizeof(RbtSlice))) { b.err = "kernel execution failed"; return RBT_ERR_NO_DEVICE; }
@@ -193,7 +203,10 @@ static int encode_finish(EncodeBatch& b, std::vector<std::vector<uint8_t>>& outs
     }
   }
   st.host_pack_ms += now_ms() - t1;
-  st.k_analyse_ms += rbtk::timer_ms(T_ANALYSE); st.k_encode_ms += rbtk::timer_ms(T_ENCODE); st.k_entropy_ms += rbtk::timer_ms(T_ENTROPY);
+  { int cur = b.main_stream; if (b.aux_stream >= 0) rbtk::set_stream(b.aux_stream);
+    st.k_analyse_ms += rbtk::timer_ms(T_ANALYSE); st.k_encode_ms += rbtk::timer_ms(T_ENCODE);
+    if (b.aux_stream >= 0) rbtk::set_stream(cur);
+    st.k_encode_ms += rbtk::timer_ms(T_INTER); st.k_entropy_ms += rbtk::timer_ms(T_ENTROPY); }
   return 0;
 }
 
@@ -280,13 +293,29 @@ int transcode_gof(rbt_stats& st, std::string& err, int n, const uint8_t* const* 
       if (rc) break;
       chained[i] = 1;
     }
-    rc = decode_launch(db[i]);
+    if (!chained[i]) { rc = decode_launch(db[i]); if (rc) { err = db[i].err; break; } continue; }
+    // Intra pictures of the output only read the decoded pictures they are re-encoded from. When those are complete
+    // before the last dependency level of the decoder, analysis + intra coding run on an auxiliary stream underneath the
+    // remaining reconstruction levels.
+    EncodeBatch& e = eb[i]; e.main_stream = i;
+    size_t n_levels = db[i].level_frames.size(), fork_level = 0;
+    for (size_t q = 0; q < e.frames.size(); q++) if (e.frame_is_idr[q]) fork_level = std::max(fork_level, (size_t)db[i].frames[db[i].stream_first[0] + (int)q].level);
+    const bool fork = k == 0 && n <= rbtk::RBT_AUX_STREAM && jobs.empty() && fork_level + 1 < n_levels;   // longest pipeline only: one spare stream
+    rc = decode_launch_parse(db[i]);
     if (rc) { err = db[i].err; break; }
-    if (chained[i]) {
-      if (!jobs.empty()) { rbtk::timer_begin(T_POOL); for (const PoolJob& j : jobs) rbtk::launch_pool(j.in, j.w, j.h, 2, j.y, j.cb, j.cr, j.grey); rbtk::timer_end(T_POOL); }
-      rc = encode_launch(eb[i]);
-      if (rc) err = eb[i].err;
+    rbtk::timer_begin(T_RECON);
+    for (size_t l = 0; l < n_levels; l++) {
+      decode_launch_level(db[i], l);
+      if (fork && l == fork_level) {
+        e.aux_stream = rbtk::RBT_AUX_STREAM;
+        rbtk::stream_wait(e.aux_stream, i);
+        rbtk::set_stream(e.aux_stream); encode_launch_intra(e); rbtk::set_stream(i);
+      }
     }
+    rbtk::timer_end(T_RECON);
+    if (!jobs.empty()) { rbtk::timer_begin(T_POOL); for (const PoolJob& j : jobs) rbtk::launch_pool(j.in, j.w, j.h, 2, j.y, j.cb, j.cr, j.grey); rbtk::timer_end(T_POOL); }
+    if (fork) rbtk::stream_wait(i, e.aux_stream); else encode_launch_intra(e);
+    encode_launch_rest(e);
   }
   // ---- phase B, shortest stream first: one sync per stream, then slice sizes -> pack -> NAL assembly ----
   std::vector<std::vector<uint8_t>> outs(n);

@@ -19,6 +19,7 @@ static double g_t[32][2];
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int dev_init(int) { return 0; }
 void set_stream(int) {}
+void stream_wait(int, int) {}
 const char* dev_name() { return "host emulation (test only)"; }
 void* dev_alloc(size_t n) { return malloc(n ? n : 1); }
 void dev_free(void* p) { free(p); }
