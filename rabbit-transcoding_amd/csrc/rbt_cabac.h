@@ -250,57 +250,99 @@ RBT_DEV void rbt_cd_localise(RbtCabacDec* d, const RbtCabacDec* c) {
 RBT_DEV int rbt_cd_overrun(const RbtCabacDec* c) { return c->widx * 32u - (uint32_t)c->nbuf > c->bits_total + 96u + (uint32_t)c->avail; }
 
 // ------------------------------------------------------------------------------------------------ encoder
+// Byte-oriented arithmetic encoder (the formulation of HM's TEncBinCABAC: `low` carries up to 23 pending bits, whole bytes
+// leave through a one-byte buffer plus a count of 0xFF bytes so that a late carry can still ripple). It produces the same
+// bits as the bit-serial PutBit / outstanding-bits procedure of 9.3.4.5, which the oracle implements.
 struct RbtCabacEnc {
   uint8_t* out; uint32_t cap, n;          // byte output (lane 0 stores)
-  uint32_t acc; int nacc;                 // bit accumulator
-  uint32_t low, range; int outstanding, first;
+  uint32_t low, range; int bits_left, n_buffered, buffered;
   RbtCtxStore cs;
   int overflow;
 };
-RBT_DEV void rbt_ce_write_bit(RbtCabacEnc* c, int b) {
-  c->acc = (c->acc << 1) | (uint32_t)(b & 1);
-  if (++c->nacc == 8) {
-    if (c->n < c->cap) { if (RBT_LANE0) c->out[c->n] = (uint8_t)c->acc; } else c->overflow = 1;
-    c->n++; c->acc = 0; c->nacc = 0;
+RBT_DEV void rbt_ce_put_byte(RbtCabacEnc* c, int b) {
+  if (c->n < c->cap) { if (RBT_LANE0) c->out[c->n] = (uint8_t)b; } else c->overflow = 1;
+  c->n++;
+}
+RBT_DEV void rbt_ce_write_out(RbtCabacEnc* c) {
+  const int lead = (int)(c->low >> (24 - c->bits_left));
+  c->bits_left += 8;
+  c->low &= 0xFFFFFFFFu >> c->bits_left;
+  if (lead == 0xFF) c->n_buffered++;
+  else if (c->n_buffered > 0) {
+    const int carry = lead >> 8;
+    rbt_ce_put_byte(c, c->buffered + carry);
+    c->buffered = lead & 0xFF;
+    const int fill = (0xFF + carry) & 0xFF;
+    while (c->n_buffered > 1) { rbt_ce_put_byte(c, fill); c->n_buffered--; }
+  } else { c->n_buffered = 1; c->buffered = lead; }
+}
+RBT_DEV void rbt_ce_start(RbtCabacEnc* c) { c->low = 0; c->range = 510; c->bits_left = 23; c->n_buffered = 0; c->buffered = 0xFF; }
+// encodes `bin` with context variable value st; returns the updated variable
+RBT_DEV int rbt_ce_core(RbtCabacEnc* c, int st, int bin) {
+  c->low = (uint32_t)RBT_UNI(c->low); c->range = (uint32_t)RBT_UNI(c->range); c->bits_left = RBT_UNI(c->bits_left);
+  const uint32_t s = (uint32_t)st >> 1, nmps = ~(uint32_t)st & 1u;
+  const uint32_t lps = (uint32_t)rbt_lps(&c->cs, (int)s, (int)((c->range >> 6) & 3));
+  const uint32_t tr = (uint32_t)rbt_trans(&c->cs, (int)s);
+  const uint32_t rm = c->range - lps, mf = ((uint32_t)bin ^ nmps) & 1u;      // mf = 1: bin is the MPS
+  const uint32_t range = mf ? rm : lps;
+  const int sh = __builtin_clz(range) - 23;                                  // 0 or 1 on the MPS path, up to 6 on the LPS path
+  c->low = (c->low + (mf ? 0u : rm)) << sh;
+  c->range = range << sh;
+  c->bits_left -= sh;
+  if (__builtin_expect(c->bits_left < 12, 0)) rbt_ce_write_out(c);
+  return (int)(((tr >> (mf << 3)) & 255u) ^ nmps);
+}
+RBT_DEV void rbt_ce_bin(RbtCabacEnc* c, int ctx, int bin) {     // any context (generic register select)
+  rbt_ctx_set(&c->cs, ctx, rbt_ce_core(c, rbt_ctx_get(&c->cs, ctx), bin));
+}
+#ifdef RBT_HOSTEMU
+#define RBT_CE_BIN_REG(NAME, REG, BASE) RBT_DEV void NAME(RbtCabacEnc* c, int lane, int bin) { rbt_ce_bin(c, (BASE) + lane, bin); }
+#else
+#define RBT_CE_BIN_REG(NAME, REG, BASE) RBT_DEV void NAME(RbtCabacEnc* c, int lane, int bin) { \
+  lane = RBT_UNI(lane); \
+  const int nst = rbt_ce_core(c, __builtin_amdgcn_readlane(c->cs.REG, lane), bin); \
+  c->cs.REG = rbt_writelane(c->cs.REG, nst, lane); }
+#endif
+RBT_CE_BIN_REG(rbt_ce_bin0, st0, 0)                                          // contexts below CTX_LAST_X
+RBT_CE_BIN_REG(rbt_ce_bin_sig, st1, CTX_SIG)
+RBT_CE_BIN_REG(rbt_ce_bin_res2, st2, (lane < 4 ? CTX_CSBF : CTX_GT1 - 4))
+RBT_CE_BIN_REG(rbt_ce_bin_last, st3, CTX_LAST_X)
+RBT_DEV void rbt_ce_bypass_n(RbtCabacEnc* c, uint32_t v, int n) {           // n bypass bins, MSB of the n-bit value first
+  c->low = (uint32_t)RBT_UNI(c->low); c->range = (uint32_t)RBT_UNI(c->range); c->bits_left = RBT_UNI(c->bits_left);
+  while (n > 8) {
+    n -= 8;
+    const uint32_t pat = v >> n;
+    c->low = (c->low << 8) + c->range * pat; v -= pat << n;
+    c->bits_left -= 8;
+    if (c->bits_left < 12) rbt_ce_write_out(c);
   }
+  c->low = (c->low << n) + c->range * v;
+  c->bits_left -= n;
+  if (c->bits_left < 12) rbt_ce_write_out(c);
 }
-RBT_DEV void rbt_ce_write_bits(RbtCabacEnc* c, uint32_t v, int n) { for (int i = n - 1; i >= 0; i--) rbt_ce_write_bit(c, (int)((v >> i) & 1)); }
-RBT_DEV void rbt_ce_put(RbtCabacEnc* c, int b) {
-  if (c->first) c->first = 0; else rbt_ce_write_bit(c, b);
-  while (c->outstanding > 0) { rbt_ce_write_bit(c, 1 - b); c->outstanding--; }
-}
-RBT_DEV void rbt_ce_renorm(RbtCabacEnc* c) {
-  while (c->range < 256) {
-    if (c->low < 256) rbt_ce_put(c, 0);
-    else if (c->low >= 512) { c->low -= 512; rbt_ce_put(c, 1); }
-    else { c->low -= 256; c->outstanding++; }
-    c->range <<= 1; c->low <<= 1;
+RBT_DEV void rbt_ce_bypass(RbtCabacEnc* c, int bin) { rbt_ce_bypass_n(c, (uint32_t)(bin & 1), 1); }
+RBT_DEV void rbt_ce_finish(RbtCabacEnc* c) {
+  if (c->low >> (32 - c->bits_left)) {
+    rbt_ce_put_byte(c, c->buffered + 1);
+    while (c->n_buffered > 1) { rbt_ce_put_byte(c, 0x00); c->n_buffered--; }
+    c->low -= 1u << (32 - c->bits_left);
+  } else {
+    if (c->n_buffered > 0) rbt_ce_put_byte(c, c->buffered);
+    while (c->n_buffered > 1) { rbt_ce_put_byte(c, 0xFF); c->n_buffered--; }
   }
+  // the remaining 24 - bits_left bits of low >> 8, then rbsp_stop_one_bit and zero bits up to the byte boundary
+  int nb = 24 - c->bits_left; uint32_t bits = (c->low >> 8) & ((1u << nb) - 1u);
+  bits = (bits << 1) | 1u; nb++;
+  while (nb & 7) { bits <<= 1; nb++; }
+  for (int k = nb - 8; k >= 0; k -= 8) rbt_ce_put_byte(c, (int)((bits >> k) & 0xFF));
 }
-RBT_DEV void rbt_ce_start(RbtCabacEnc* c) { c->low = 0; c->range = 510; c->first = 1; c->outstanding = 0; }
-RBT_DEV void rbt_ce_bin(RbtCabacEnc* c, int ctx, int bin) {
-  int st = rbt_ctx_get(&c->cs, ctx);
-  int s = st >> 1, mps = st & 1;
-  uint32_t lps = (uint32_t)rbt_lps(&c->cs, s, (int)((c->range >> 6) & 3));
-  c->range -= lps;
-  if (bin != mps) { c->low += c->range; c->range = lps; if (s == 0) mps = 1 - mps; s = rbt_next_lps(&c->cs, s); }
-  else s = s >= 62 ? s : s + 1;
-  rbt_ctx_set(&c->cs, ctx, (s << 1) | mps);
-  rbt_ce_renorm(c);
-}
-RBT_DEV void rbt_ce_bypass(RbtCabacEnc* c, int bin) {
-  c->low <<= 1;
-  if (bin) c->low += c->range;
-  if (c->low >= 1024) { rbt_ce_put(c, 1); c->low -= 1024; }
-  else if (c->low < 512) rbt_ce_put(c, 0);
-  else { c->low -= 512; c->outstanding++; }
-}
-RBT_DEV void rbt_ce_bypass_n(RbtCabacEnc* c, uint32_t v, int n) { for (int i = n - 1; i >= 0; i--) rbt_ce_bypass(c, (int)((v >> i) & 1)); }
+// end_of_slice_segment_flag; bin = 1 also flushes the encoder and writes the trailing bits (9.3.2.5, 7.3.2.5)
 RBT_DEV void rbt_ce_terminate(RbtCabacEnc* c, int bin) {
   c->range -= 2;
-  if (bin) {
-    c->low += c->range; c->range = 2; rbt_ce_renorm(c);
-    rbt_ce_put(c, (int)((c->low >> 9) & 1)); rbt_ce_write_bits(c, ((c->low >> 7) & 3) | 1, 2);
-  } else rbt_ce_renorm(c);
+  if (bin) { c->low = (c->low + c->range) << 7; c->range = 2 << 7; c->bits_left -= 7; }
+  else if (c->range >= 256) return;
+  else { c->low <<= 1; c->range <<= 1; c->bits_left--; }
+  if (c->bits_left < 12) rbt_ce_write_out(c);
+  if (bin) rbt_ce_finish(c);
 }
-RBT_DEV void rbt_ce_align_zero(RbtCabacEnc* c) { while (c->nacc) rbt_ce_write_bit(c, 0); }
+RBT_DEV void rbt_ce_align_zero(RbtCabacEnc* c) { (void)c; }     // rbt_ce_terminate(c, 1) already ends on a byte boundary

@@ -370,10 +370,10 @@ RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, int x0, int y0, int log2, i
   if (c_idx == 0) { ctx_off = 3 * (log2 - 2) + ((log2 - 1) >> 2); ctx_shift = (log2 + 1) >> 2; }
   else { ctx_off = 15; ctx_shift = log2 - 2; }
   int maxp = (log2 << 1) - 1, px = k_group_idx[cx], py = k_group_idx[cy];
-  for (int i = 0; i < px; i++) rbt_ce_bin(c, CTX_LAST_X + ctx_off + (i >> ctx_shift), 1);
-  if (px < maxp) rbt_ce_bin(c, CTX_LAST_X + ctx_off + (px >> ctx_shift), 0);
-  for (int i = 0; i < py; i++) rbt_ce_bin(c, CTX_LAST_Y + ctx_off + (i >> ctx_shift), 1);
-  if (py < maxp) rbt_ce_bin(c, CTX_LAST_Y + ctx_off + (py >> ctx_shift), 0);
+  for (int i = 0; i < px; i++) rbt_ce_bin_last(c, ctx_off + (i >> ctx_shift), 1);
+  if (px < maxp) rbt_ce_bin_last(c, ctx_off + (px >> ctx_shift), 0);
+  for (int i = 0; i < py; i++) rbt_ce_bin_last(c, 18 + ctx_off + (i >> ctx_shift), 1);
+  if (py < maxp) rbt_ce_bin_last(c, 18 + ctx_off + (py >> ctx_shift), 0);
   if (px > 3) rbt_ce_bypass_n(c, (uint32_t)(cx - k_min_in_group[px]), (px >> 1) - 1);
   if (py > 3) rbt_ce_bypass_n(c, (uint32_t)(cy - k_min_in_group[py]), (py >> 1) - 1);
   uint64_t csbf = 0;
@@ -383,7 +383,7 @@ RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, int x0, int y0, int log2, i
     int right = xs + 1 < sbw ? (int)((csbf >> (ys * 8 + xs + 1)) & 1) : 0, below = ys + 1 < sbw ? (int)((csbf >> ((ys + 1) * 8 + xs)) & 1) : 0;
     uint32_t mask = l->cg_mask[i];
     int infer_dc = 0, coded;
-    if (i < last_sb && i > 0) { coded = mask != 0; rbt_ce_bin(c, CTX_CSBF + rbt_min(right + below, 1) + (c_idx ? 2 : 0), coded); infer_dc = 1; }
+    if (i < last_sb && i > 0) { coded = mask != 0; rbt_ce_bin_res2(c, rbt_min(right + below, 1) + (c_idx ? 2 : 0), coded); infer_dc = 1; }
     else coded = 1;
     if (!coded) continue;
     csbf |= 1ull << (ys * 8 + xs);
@@ -403,7 +403,7 @@ RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, int x0, int y0, int log2, i
           if (c_idx == 0) { if (xs || ys) sc += 3; sc += log2 == 3 ? (scan_idx == 0 ? 9 : 15) : 21; }
           else sc += log2 == 3 ? 9 : 12;
         }
-        rbt_ce_bin(c, CTX_SIG + (c_idx == 0 ? sc : 27 + sc), sig);
+        rbt_ce_bin_sig(c, (c_idx == 0 ? sc : 27 + sc), sig);
         if (sig) infer_dc = 0;
       }
     }
@@ -415,12 +415,12 @@ RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, int x0, int y0, int log2, i
     while (m && k < 8) {
       int n = 31 - __builtin_clz(m); m &= ~(1u << n);
       int v = l->lvl[((ys << 2) + (pos_scan[n] >> 4)) * N + (xs << 2) + (pos_scan[n] & 15)], a = rbt_abs(v), g1 = a > 1;
-      rbt_ce_bin(c, CTX_GT1 + (ctx_set << 2) + greater1_ctx + (c_idx ? 16 : 0), g1);
+      rbt_ce_bin_res2(c, 4 + (ctx_set << 2) + greater1_ctx + (c_idx ? 16 : 0), g1);
       if (g1) { greater1_ctx = 0; if (first_g1 < 0) { first_g1 = k; first_g1_abs = a; } }
       else if (greater1_ctx > 0 && greater1_ctx < 3) greater1_ctx++;
       k++;
     }
-    if (first_g1 >= 0) rbt_ce_bin(c, CTX_GT2 + ctx_set + (c_idx ? 4 : 0), first_g1_abs > 2);
+    if (first_g1 >= 0) rbt_ce_bin_res2(c, 28 + ctx_set + (c_idx ? 4 : 0), first_g1_abs > 2);
     m = mask;
     while (m) { int n = 31 - __builtin_clz(m); m &= ~(1u << n); int v = l->lvl[((ys << 2) + (pos_scan[n] >> 4)) * N + (xs << 2) + (pos_scan[n] & 15)]; signs = (signs << 1) | (uint32_t)(v < 0); nsig++; }
     rbt_ce_bypass_n(c, signs, nsig);      // sign_data_hiding is off in RBT-E1 streams
@@ -461,17 +461,17 @@ RBT_DEV void en_write_cu(RbtEnt* s, int x0, int y0, int log2, int depth) {
   RbtCabacEnc* c = &s->c; const RbtFrame* f = s->f; const RbtStreamCfg* g = &f->cfg;
   int k8 = (y0 >> 3) * f->w8 + (x0 >> 3), flags = f->cu_flags[k8], mode = f->cu_mode[k8];
   int is_p = s->sl->slice_type == RBT_SLICE_P;
-  if (g->tq_bypass_enabled) rbt_ce_bin(c, CTX_CU_TQ_BYPASS, f->lossless ? 1 : 0);
+  if (g->tq_bypass_enabled) rbt_ce_bin0(c, CTX_CU_TQ_BYPASS, f->lossless ? 1 : 0);
   if (is_p) {
     int cl = en_cu_coded(s, x0, y0, x0 - 1, y0) && (f->cu_flags[(y0 >> 3) * f->w8 + ((x0 - 1) >> 3)] & RBT_CU_SKIP);
     int ca = en_cu_coded(s, x0, y0, x0, y0 - 1) && (f->cu_flags[((y0 - 1) >> 3) * f->w8 + (x0 >> 3)] & RBT_CU_SKIP);
-    rbt_ce_bin(c, CTX_CU_SKIP + (cl ? 1 : 0) + (ca ? 1 : 0), (flags & RBT_CU_SKIP) ? 1 : 0);
+    rbt_ce_bin0(c, CTX_CU_SKIP + (cl ? 1 : 0) + (ca ? 1 : 0), (flags & RBT_CU_SKIP) ? 1 : 0);
     if (flags & RBT_CU_SKIP) return;                 // merge_idx absent: MaxNumMergeCand == 1
-    rbt_ce_bin(c, CTX_PRED_MODE, 0);
-    rbt_ce_bin(c, CTX_PART_MODE, 1);
-    rbt_ce_bin(c, CTX_MERGE_FLAG, 1);
+    rbt_ce_bin0(c, CTX_PRED_MODE, 0);
+    rbt_ce_bin0(c, CTX_PART_MODE, 1);
+    rbt_ce_bin0(c, CTX_MERGE_FLAG, 1);
   } else {
-    if (log2 == g->log2_min_cb) rbt_ce_bin(c, CTX_PART_MODE, 1);
+    if (log2 == g->log2_min_cb) rbt_ce_bin0(c, CTX_PART_MODE, 1);
     int ca = 1, cb = 1;
     if (en_cu_coded(s, x0, y0, x0 - 1, y0)) ca = f->cu_mode[(y0 >> 3) * f->w8 + ((x0 - 1) >> 3)];
     if (en_cu_coded(s, x0, y0, x0, y0 - 1) && ((y0 - 1) >> g->log2_ctb) == (y0 >> g->log2_ctb)) cb = f->cu_mode[((y0 - 1) >> 3) * f->w8 + (x0 >> 3)];
@@ -480,7 +480,7 @@ RBT_DEV void en_write_cu(RbtEnt* s, int x0, int y0, int log2, int depth) {
     else { c0 = ca; c1 = cb; c2 = (ca != 0 && cb != 0) ? 0 : ((ca != 1 && cb != 1) ? 1 : 26); }
     int idx = mode == c0 ? 0 : (mode == c1 ? 1 : (mode == c2 ? 2 : -1));
     // the oracle keeps the LAST matching candidate; candidates are distinct, so first == last
-    rbt_ce_bin(c, CTX_PREV_INTRA_LUMA, idx >= 0);
+    rbt_ce_bin0(c, CTX_PREV_INTRA_LUMA, idx >= 0);
     if (idx >= 0) { rbt_ce_bypass(c, idx > 0); if (idx > 0) rbt_ce_bypass(c, idx > 1); }
     else {
       int t;
@@ -493,13 +493,13 @@ RBT_DEV void en_write_cu(RbtEnt* s, int x0, int y0, int log2, int depth) {
       if (rem > c0) rem--;
       rbt_ce_bypass_n(c, (uint32_t)rem, 5);
     }
-    rbt_ce_bin(c, CTX_INTRA_CHROMA, 0);              // intra_chroma_pred_mode = 4 (DM)
+    rbt_ce_bin0(c, CTX_INTRA_CHROMA, 0);              // intra_chroma_pred_mode = 4 (DM)
   }
   // transform tree: one TU per CU (max_transform_hierarchy_depth = 0, no split flag)
   int cbf_cb = (flags & RBT_CU_CBF_CB) != 0, cbf_cr = (flags & RBT_CU_CBF_CR) != 0, cbf_y = (flags & RBT_CU_CBF_Y) != 0;
-  rbt_ce_bin(c, CTX_CBF_CHROMA + 0, cbf_cb);
-  rbt_ce_bin(c, CTX_CBF_CHROMA + 0, cbf_cr);
-  if (!is_p || cbf_cb || cbf_cr) rbt_ce_bin(c, CTX_CBF_LUMA + 1, cbf_y);
+  rbt_ce_bin0(c, CTX_CBF_CHROMA + 0, cbf_cb);
+  rbt_ce_bin0(c, CTX_CBF_CHROMA + 0, cbf_cr);
+  if (!is_p || cbf_cb || cbf_cr) rbt_ce_bin0(c, CTX_CBF_LUMA + 1, cbf_y);
   int intra = !is_p;
   if (cbf_y) en_write_residual(s, 0, x0, y0, log2, en_scan_idx(intra, log2, 0, mode));
   if (cbf_cb) en_write_residual(s, 1, x0 >> 1, y0 >> 1, log2 - 1, en_scan_idx(intra, log2 - 1, 1, mode));
@@ -521,7 +521,7 @@ RBT_DEV void en_write_quadtree(RbtEnt* s, int x0, int y0, int log2) {
       if (can_flag) {
         int cl = en_cu_coded(s, n->x, n->y, n->x - 1, n->y) && (g->log2_ctb - f->cu_log2[(n->y >> 3) * f->w8 + ((n->x - 1) >> 3)]) > n->depth;
         int ca = en_cu_coded(s, n->x, n->y, n->x, n->y - 1) && (g->log2_ctb - f->cu_log2[((n->y - 1) >> 3) * f->w8 + (n->x >> 3)]) > n->depth;
-        rbt_ce_bin(&s->c, CTX_SPLIT_CU + (cl ? 1 : 0) + (ca ? 1 : 0), split);
+        rbt_ce_bin0(&s->c, CTX_SPLIT_CU + (cl ? 1 : 0) + (ca ? 1 : 0), split);
       }
       if (!split) { en_write_cu(s, n->x, n->y, n->log2, n->depth); sp--; continue; }
       n->state = 0;
@@ -539,7 +539,7 @@ RBT_DEV void en_entropy_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx,
   RbtEnt s; s.sl = &slices[slice_idx]; s.f = &frames[s.sl->frame]; s.slice_idx = slice_idx; s.l = l;
   const RbtSlice* sl = s.sl; const RbtStreamCfg* g = &s.f->cfg;
   rbt_ctx_init(&s.c.cs, sl->slice_type == RBT_SLICE_I ? 0 : 1, sl->qp);
-  s.c.out = out + sl->out_off; s.c.cap = sl->out_cap; s.c.n = 0; s.c.acc = 0; s.c.nacc = 0; s.c.overflow = 0;
+  s.c.out = out + sl->out_off; s.c.cap = sl->out_cap; s.c.n = 0; s.c.overflow = 0;
   rbt_ce_start(&s.c);
   for (int a = 0; a < sl->n_ctbs; a++) {
     int addr = sl->ctb_addr + a, rx = addr % g->w_ctb, ry = addr / g->w_ctb;
