@@ -28,6 +28,10 @@ struct RbtEncLds {
   uint8_t mode[3][16];
   uint8_t split[3][16];
   uint16_t cg_mask[64];      // entropy: significance mask of each 4x4 coefficient group (bit n = scan position n)
+  uint8_t scan[3][4][64];    // entropy: k_scan staged once per slice
+  int16_t lvl_c[2][16 * 16]; // entropy: chroma levels of the current CU (luma uses lvl)
+  uint8_t cu_l2[81], cu_md[81], cu_fl[81];   // entropy: cu_log2 / cu_mode / cu_flags of the CTB's 8x8 units and of the column / row before it:
+                                             // (uy + 1) * 9 + ux + 1, ux,uy = -1..7; cu_l2 = 0xFF where the unit is not available (6.4.1)
   uint16_t src[65 * 66];     // analysis: source samples of a 32x32 quadrant and what its blocks reference around it: (yy + 1) * 66 + xx + 1, xx,yy = -1..63
 };
 
@@ -342,100 +346,106 @@ RBT_DEV void en_inter_ctb(RbtFrame* frames, RbtFrame* f, const RbtSlice* slices,
 }
 
 // ------------------------------------------------------------------------------------------------ entropy coding
-struct RbtEnt { RbtFrame* f; const RbtSlice* sl; int slice_idx; RbtCabacEnc c; RBT_LDS_AS RbtEncLds* l; };
+struct RbtEnt { RbtFrame* f; const RbtSlice* sl; int slice_idx; RbtCabacEnc c; RBT_LDS_AS RbtEncLds* l;
+                int w, h, log2_ctb, log2_min_cb, tq_bypass_enabled, is_p, cx, cy; };
+// encoder scan tables use x | y << 4 in k_scan; the lane code wants sub-block entries unchanged and 4x4 positions as packed immediates
+RBT_DEV uint8_t k_scan_packed(int a, int b, int c) { return k_scan[a][b][c]; }
 
-// residual_coding (7.3.8.11) of the TB whose levels sit in the coefficient plane
-RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, int x0, int y0, int log2, int scan_idx) {
-  RbtCabacEnc* c = &s->c; RBT_LDS_AS RbtEncLds* l = s->l; const RbtFrame* f = s->f;
-  int N = 1 << log2, pw = c_idx ? f->cfg.cw : f->cfg.w;
-  const int16_t* cp = f->coef[c_idx];
-  RBT_PAR_FOR(i, N * N) { int x = i & (N - 1), y = i >> log2; l->lvl[i] = cp[(size_t)(y0 + y) * pw + x0 + x]; }
-  RBT_SYNC_LDS();
-  const uint8_t* sb_scan = k_scan[scan_idx][log2 - 2];
-  const uint8_t* pos_scan = k_scan[scan_idx][2];
-  int n_sb = 1 << (2 * (log2 - 2));
-  RBT_PAR_FOR(i, n_sb) {
-    int xs = sb_scan[i] & 15, ys = sb_scan[i] >> 4, m = 0;
-    for (int n = 0; n < 16; n++) if (l->lvl[((ys << 2) + (pos_scan[n] >> 4)) * N + (xs << 2) + (pos_scan[n] & 15)]) m |= 1 << n;
-    l->cg_mask[i] = (uint16_t)m;
+// 4x4 scan positions packed 4 bits per entry (x | y << 2): diagonal, horizontal, vertical; ctxIdxMap of 4x4 TBs (same
+// packed immediates as the parser uses)
+RBT_DEV uint64_t en_scan4_const(int scan_idx) { return scan_idx == 0 ? 0xFBE7AD369C258140ull : (scan_idx == 1 ? 0xFEDCBA9876543210ull : 0xFB73EA62D951C840ull); }
+#define EN_SIGCTX4 0x8877886654325410ull
+RBT_DEV int en_group_idx(int v) { if (v < 4) return v; const int lg = 31 - __builtin_clz((unsigned)v); return 2 * lg + ((v >> (lg - 1)) & 1); }   // last_sig_coeff prefix of position v
+RBT_DEV int en_min_in_group(int g) { return g < 4 ? g : (2 + (g & 1)) << ((g >> 1) - 1); }
+// residual_coding (7.3.8.11) of one TB. Its levels are already in LDS (`lv`, row stride N): en_load_cu_levels fetched the
+// three TBs of the CU with one HBM round trip. Same split as the parser: what is not a bin runs on the lanes (lane i =
+// sub-block i for the significance masks, lane p = scan position p of the current sub-block for contexts and levels), the
+// serial part is bins only.
+RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, const RBT_LDS_AS int16_t* lv, int log2, int scan_idx) {
+  RbtCabacEnc* c = &s->c; RBT_LDS_AS RbtEncLds* l = s->l;
+  log2 = RBT_UNI(log2); scan_idx = RBT_UNI(scan_idx);
+  const int N = 1 << log2, chroma = c_idx != 0;
+  const uint64_t ps = en_scan4_const(scan_idx);
+  const RBT_LDS_AS uint8_t* sb_scan = l->scan[scan_idx][log2 - 2];
+  const int n_sb = 1 << (2 * (log2 - 2));
+  RBT_VEC(int, v_sbscan); RBT_VEC(int, v_pos); RBT_VEC(int, v_cgmask);
+  RBT_VFOR(p, 64) {
+    const int e = p < n_sb ? (int)sb_scan[p] : 0; RBT_V(v_sbscan, p) = e; RBT_V(v_pos, p) = (int)((ps >> (4 * (p & 15))) & 15);
+    int m = 0;
+    if (p < n_sb) { const int xs = e & 15, ys = e >> 4; for (int n = 0; n < 16; n++) { const int q = (int)((ps >> (4 * n)) & 15); if (lv[((ys << 2) + (q >> 2)) * N + (xs << 2) + (q & 3)]) m |= 1 << n; } }
+    RBT_V(v_cgmask, p) = m;
   }
-  RBT_SYNC_LDS();
-  int last_sb = 0;
-  for (int i = n_sb - 1; i >= 0; i--) if (l->cg_mask[i]) { last_sb = i; break; }
-  int last_pos = 31 - __builtin_clz((unsigned)l->cg_mask[last_sb]);
-  int lx = ((sb_scan[last_sb] & 15) << 2) + (pos_scan[last_pos] & 15), ly = ((sb_scan[last_sb] >> 4) << 2) + (pos_scan[last_pos] >> 4);
-  int cx = lx, cy = ly;
-  if (scan_idx == 2) { cx = ly; cy = lx; }
-  int ctx_off, ctx_shift;
-  if (c_idx == 0) { ctx_off = 3 * (log2 - 2) + ((log2 - 1) >> 2); ctx_shift = (log2 + 1) >> 2; }
-  else { ctx_off = 15; ctx_shift = log2 - 2; }
-  int maxp = (log2 << 1) - 1, px = k_group_idx[cx], py = k_group_idx[cy];
-  for (int i = 0; i < px; i++) rbt_ce_bin_last(c, ctx_off + (i >> ctx_shift), 1);
-  if (px < maxp) rbt_ce_bin_last(c, ctx_off + (px >> ctx_shift), 0);
-  for (int i = 0; i < py; i++) rbt_ce_bin_last(c, 18 + ctx_off + (i >> ctx_shift), 1);
-  if (py < maxp) rbt_ce_bin_last(c, 18 + ctx_off + (py >> ctx_shift), 0);
-  if (px > 3) rbt_ce_bypass_n(c, (uint32_t)(cx - k_min_in_group[px]), (px >> 1) - 1);
-  if (py > 3) rbt_ce_bypass_n(c, (uint32_t)(cy - k_min_in_group[py]), (py >> 1) - 1);
+  uint64_t nz64; RBT_VBALLOT(nz64, p, 64, RBT_V(v_cgmask, p) != 0);
+  const int last_sb = nz64 ? 63 - __builtin_clzll(nz64) : 0;
+  const int last_mask = RBT_VGET(v_cgmask, last_sb), last_pos = last_mask ? 31 - __builtin_clz((unsigned)last_mask) : 0;
+  { const int e = RBT_VGET(v_sbscan, last_sb), q = (int)((ps >> (4 * last_pos)) & 15);
+    int cx = ((e & 15) << 2) + (q & 3), cy = ((e >> 4) << 2) + (q >> 2);
+    if (scan_idx == 2) { const int t = cx; cx = cy; cy = t; }
+    int ctx_off, ctx_shift;
+    if (c_idx == 0) { ctx_off = 3 * (log2 - 2) + ((log2 - 1) >> 2); ctx_shift = (log2 + 1) >> 2; }
+    else { ctx_off = 15; ctx_shift = log2 - 2; }
+    const int maxp = (log2 << 1) - 1, px = en_group_idx(cx), py = en_group_idx(cy);
+    for (int i = 0; i < px; i++) rbt_ce_bin_last(c, ctx_off + (i >> ctx_shift), 1);
+    if (px < maxp) rbt_ce_bin_last(c, ctx_off + (px >> ctx_shift), 0);
+    for (int i = 0; i < py; i++) rbt_ce_bin_last(c, 18 + ctx_off + (i >> ctx_shift), 1);
+    if (py < maxp) rbt_ce_bin_last(c, 18 + ctx_off + (py >> ctx_shift), 0);
+    if (px > 3) rbt_ce_bypass_n(c, (uint32_t)(cx - en_min_in_group(px)), (px >> 1) - 1);
+    if (py > 3) rbt_ce_bypass_n(c, (uint32_t)(cy - en_min_in_group(py)), (py >> 1) - 1); }
   uint64_t csbf = 0;
-  int sbw = 1 << (log2 - 2), greater1_ctx = 1, first_sb_done = 0;
+  const int sbw = 1 << (log2 - 2), sig_c0 = chroma ? 27 : 0;
+  int greater1_ctx = 1, first_sb_done = 0;
   for (int i = last_sb; i >= 0; i--) {
-    int xs = sb_scan[i] & 15, ys = sb_scan[i] >> 4;
-    int right = xs + 1 < sbw ? (int)((csbf >> (ys * 8 + xs + 1)) & 1) : 0, below = ys + 1 < sbw ? (int)((csbf >> ((ys + 1) * 8 + xs)) & 1) : 0;
-    uint32_t mask = l->cg_mask[i];
-    int infer_dc = 0, coded;
-    if (i < last_sb && i > 0) { coded = mask != 0; rbt_ce_bin_res2(c, rbt_min(right + below, 1) + (c_idx ? 2 : 0), coded); infer_dc = 1; }
-    else coded = 1;
-    if (!coded) continue;
+    const int sbv = RBT_VGET(v_sbscan, i), xs = sbv & 15, ys = sbv >> 4;
+    const int right = xs + 1 < sbw ? (int)((csbf >> (ys * 8 + xs + 1)) & 1) : 0, below = ys + 1 < sbw ? (int)((csbf >> ((ys + 1) * 8 + xs)) & 1) : 0;
+    const uint32_t mask = (uint32_t)RBT_VGET(v_cgmask, i);
+    int infer_dc = 0;
+    if (i < last_sb && i > 0) { rbt_ce_bin_res2(c, rbt_min(right + below, 1) + (chroma ? 2 : 0), mask != 0); if (!mask) continue; infer_dc = 1; }
     csbf |= 1ull << (ys * 8 + xs);
-    int start = i == last_sb ? last_pos - 1 : 15, prev_csbf = right | (below << 1);
-    for (int n = start; n >= 0; n--) {
-      int xp = pos_scan[n] & 15, yp = pos_scan[n] >> 4, xc = (xs << 2) + xp, yc = (ys << 2) + yp;
-      int sig = (int)((mask >> n) & 1);
-      if (n > 0 || !infer_dc) {
-        int sc;
-        if (log2 == 2) sc = k_sig_ctx_4x4[(yc << 2) + xc];
-        else if (xc + yc == 0) sc = 0;
-        else {
-          if (prev_csbf == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
-          else if (prev_csbf == 1) sc = yp == 0 ? 2 : (yp == 1 ? 1 : 0);
-          else if (prev_csbf == 2) sc = xp == 0 ? 2 : (xp == 1 ? 1 : 0);
-          else sc = 2;
-          if (c_idx == 0) { if (xs || ys) sc += 3; sc += log2 == 3 ? (scan_idx == 0 ? 9 : 15) : 21; }
-          else sc += log2 == 3 ? 9 : 12;
-        }
-        rbt_ce_bin_sig(c, (c_idx == 0 ? sc : 27 + sc), sig);
-        if (sig) infer_dc = 0;
-      }
+    const int prev_csbf = right | (below << 1);
+    const uint32_t pat = prev_csbf == 0 ? 0x00010516u : (prev_csbf == 1 ? 0x000055AAu : (prev_csbf == 2 ? 0x06060606u : 0xAAAAAAAAu));
+    const int cg_base = !chroma ? ((xs | ys) ? 3 : 0) + (log2 == 3 ? (scan_idx == 0 ? 9 : 15) : 21) : 27 + (log2 == 3 ? 9 : 12);
+    const int dc_cg = (xs | ys) == 0;
+    // lane p: sig_coeff_flag context and level of scan position p of this sub-block
+    RBT_VEC(int, v_sc); RBT_VEC(int, v_abs); uint64_t neg64;
+    RBT_VFOR(p, 16) {
+      const int p4 = RBT_V(v_pos, p);
+      RBT_V(v_sc, p) = log2 == 2 ? (int)((EN_SIGCTX4 >> (4 * p4)) & 15) + sig_c0 : ((dc_cg && p4 == 0) ? sig_c0 : cg_base + (int)((pat >> (2 * p4)) & 3));
+      const int v = lv[((ys << 2) + (p4 >> 2)) * N + (xs << 2) + (p4 & 3)];
+      RBT_V(v_abs, p) = v < 0 ? -v : v;
     }
+    RBT_VBALLOT(neg64, p, 16, lv[((ys << 2) + (RBT_V(v_pos, p) >> 2)) * N + (xs << 2) + (RBT_V(v_pos, p) & 3)] < 0);
+    const int start = i == last_sb ? last_pos - 1 : 15;
+    for (int n = start; n >= 1; n--) rbt_ce_bin_sig(c, RBT_VGET(v_sc, n), (int)((mask >> n) & 1));
+    if (start >= 0 && !(infer_dc && (mask >> 1) == 0)) rbt_ce_bin_sig(c, RBT_VGET(v_sc, 0), (int)(mask & 1));
+    if (!mask) continue;
     int ctx_set = (i == 0 || c_idx > 0) ? 0 : 2;
-    if (first_sb_done && greater1_ctx == 0) ctx_set++;
+    ctx_set += first_sb_done & (int)((uint32_t)(greater1_ctx - 1) >> 31);
     first_sb_done = 1; greater1_ctx = 1;
-    int first_g1 = -1, first_g1_abs = 0, k = 0;
-    uint32_t m = mask, signs = 0; int nsig = 0;
+    const int g1_base = (ctx_set << 2) + (chroma ? 16 : 0);
+    int first_g1 = -1, first_g1_abs = 0, k = 0, nsig = 0;
+    uint32_t m = mask, signs = 0;
     while (m && k < 8) {
-      int n = 31 - __builtin_clz(m); m &= ~(1u << n);
-      int v = l->lvl[((ys << 2) + (pos_scan[n] >> 4)) * N + (xs << 2) + (pos_scan[n] & 15)], a = rbt_abs(v), g1 = a > 1;
-      rbt_ce_bin_res2(c, 4 + (ctx_set << 2) + greater1_ctx + (c_idx ? 16 : 0), g1);
+      const int n = 31 - __builtin_clz(m); m &= ~(1u << n);
+      const int a = RBT_VGET(v_abs, n), g1 = a > 1;
+      rbt_ce_bin_res2(c, 4 + g1_base + greater1_ctx, g1);
       if (g1) { greater1_ctx = 0; if (first_g1 < 0) { first_g1 = k; first_g1_abs = a; } }
       else if (greater1_ctx > 0 && greater1_ctx < 3) greater1_ctx++;
       k++;
     }
-    if (first_g1 >= 0) rbt_ce_bin_res2(c, 28 + ctx_set + (c_idx ? 4 : 0), first_g1_abs > 2);
+    if (first_g1 >= 0) rbt_ce_bin_res2(c, 28 + ctx_set + (chroma ? 4 : 0), first_g1_abs > 2);
     m = mask;
-    while (m) { int n = 31 - __builtin_clz(m); m &= ~(1u << n); int v = l->lvl[((ys << 2) + (pos_scan[n] >> 4)) * N + (xs << 2) + (pos_scan[n] & 15)]; signs = (signs << 1) | (uint32_t)(v < 0); nsig++; }
+    while (m) { const int n = 31 - __builtin_clz(m); m &= ~(1u << n); signs = (signs << 1) | (uint32_t)((neg64 >> n) & 1); nsig++; }
     rbt_ce_bypass_n(c, signs, nsig);      // sign_data_hiding is off in RBT-E1 streams
     int rice = 0; k = 0; m = mask;
     while (m) {
-      int n = 31 - __builtin_clz(m); m &= ~(1u << n);
-      int a = rbt_abs((int)l->lvl[((ys << 2) + (pos_scan[n] >> 4)) * N + (xs << 2) + (pos_scan[n] & 15)]);
-      int base = k < 8 ? (k == first_g1 ? 3 : 2) : 1;
+      const int n = 31 - __builtin_clz(m); m &= ~(1u << n);
+      const int a = RBT_VGET(v_abs, n), base = k < 8 ? (k == first_g1 ? 3 : 2) : 1;
       if (a >= base) {
-        int v = a - base;
-        if (v < (4 << rice)) { int pre = v >> rice; for (int t = 0; t < pre; t++) rbt_ce_bypass(c, 1); rbt_ce_bypass(c, 0); rbt_ce_bypass_n(c, (uint32_t)(v & ((1 << rice) - 1)), rice); }
+        const int v = a - base;
+        if (v < (4 << rice)) { const int pre = v >> rice; rbt_ce_bypass_n(c, ((1u << pre) - 1u) << 1, pre + 1); rbt_ce_bypass_n(c, (uint32_t)(v & ((1 << rice) - 1)), rice); }
         else {
           int p = 4; while (v >= (((1 << (p - 2)) + 2) << rice)) p++;
-          for (int t = 0; t < p; t++) rbt_ce_bypass(c, 1);
-          rbt_ce_bypass(c, 0);
+          rbt_ce_bypass_n(c, ((1u << p) - 1u) << 1, p + 1);
           rbt_ce_bypass_n(c, (uint32_t)(v - (((1 << (p - 3)) + 2) << rice)), p - 3 + rice);
         }
         if (a > 3 * (1 << rice)) rice = rbt_min(rice + 1, 4);
@@ -443,38 +453,58 @@ RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, int x0, int y0, int log2, i
       k++;
     }
   }
-  RBT_SYNC_LDS();
-}
-RBT_DEV int en_cu_coded(const RbtEnt* s, int xc, int yc, int xn, int yn) {
-  // neighbour CU available for context derivation: inside the picture, same slice, earlier in decoding order
-  const RbtFrame* f = s->f; const RbtStreamCfg* g = &f->cfg;
-  if (xn < 0 || yn < 0 || xn >= g->w || yn >= g->h) return 0;
-  int L = g->log2_ctb, an = (yn >> L) * g->w_ctb + (xn >> L), ac = (yc >> L) * g->w_ctb + (xc >> L);
-  if (an > ac || f->ctb_slice[an] != f->ctb_slice[ac]) return 0;
-  return 1;   // left / above neighbours inside the same CTB always precede in z-order
 }
 RBT_DEV int en_scan_idx(int is_intra, int log2, int c_idx, int mode) {
   if (is_intra && (log2 == 2 || (log2 == 3 && c_idx == 0))) { if (mode >= 6 && mode <= 14) return 2; if (mode >= 22 && mode <= 30) return 1; }
   return 0;
 }
+// index of the 8x8 unit that holds luma position (x,y) in the staged CTB maps; x,y may lie one unit left of / above the CTB
+RBT_DEV int en_u(const RbtEnt* s, int x, int y) { return (((y - s->cy) >> 3) + 1) * 9 + ((x - s->cx) >> 3) + 1; }
+// stages cu_log2 / cu_mode / cu_flags of CTB (cx,cy) and of its left column / above row (with availability) into LDS
+RBT_DEV void en_stage_ctb(RbtEnt* s, int cx, int cy) {
+  const RbtFrame* f = s->f; RBT_LDS_AS RbtEncLds* l = s->l;
+  s->cx = cx; s->cy = cy;
+  const int L = s->log2_ctb, wc = (s->w + (1 << L) - 1) >> L, ac = (cy >> L) * wc + (cx >> L), my = f->ctb_slice[ac];
+  RBT_PAR_FOR(i, 81) {
+    const int ux = i % 9 - 1, uy = i / 9 - 1, x = cx + ux * 8, y = cy + uy * 8;
+    int l2 = 0xFF, md = 1, fl = 0;
+    if (x >= 0 && y >= 0 && x < s->w && y < s->h && ux < (1 << (L - 3)) && uy < (1 << (L - 3))) {
+      const int an = (y >> L) * wc + (x >> L);
+      if (an == ac || f->ctb_slice[an] == my) { const int k = (y >> 3) * f->w8 + (x >> 3); l2 = f->cu_log2[k]; md = f->cu_mode[k]; fl = f->cu_flags[k]; }
+    }
+    l->cu_l2[i] = (uint8_t)l2; l->cu_md[i] = (uint8_t)md; l->cu_fl[i] = (uint8_t)fl;
+  }
+  RBT_SYNC();
+}
 RBT_DEV void en_write_cu(RbtEnt* s, int x0, int y0, int log2, int depth) {
-  RbtCabacEnc* c = &s->c; const RbtFrame* f = s->f; const RbtStreamCfg* g = &f->cfg;
-  int k8 = (y0 >> 3) * f->w8 + (x0 >> 3), flags = f->cu_flags[k8], mode = f->cu_mode[k8];
-  int is_p = s->sl->slice_type == RBT_SLICE_P;
-  if (g->tq_bypass_enabled) rbt_ce_bin0(c, CTX_CU_TQ_BYPASS, f->lossless ? 1 : 0);
+  RbtCabacEnc* c = &s->c; const RbtFrame* f = s->f; RBT_LDS_AS RbtEncLds* l = s->l;
+  x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); log2 = RBT_UNI(log2);
+  const int u = en_u(s, x0, y0), flags = RBT_UNI(l->cu_fl[u]), mode = RBT_UNI(l->cu_md[u]);
+  const int cbf_cb = (flags & RBT_CU_CBF_CB) != 0, cbf_cr = (flags & RBT_CU_CBF_CR) != 0, cbf_y = (flags & RBT_CU_CBF_Y) != 0;
+  // the levels of the CU's TBs: one HBM round trip, issued before the header bins are coded
+  if (!(flags & RBT_CU_SKIP)) {
+    const int N = 1 << log2, Nc = N >> 1, pw = s->w, cw = s->w >> 1;
+    if (cbf_y) { const int16_t* cp = f->coef[0] + (size_t)y0 * pw + x0; RBT_PAR_FOR(i, N * N) l->lvl[i] = cp[(size_t)(i >> log2) * pw + (i & (N - 1))]; }
+    for (int q = 0; q < 2; q++) if (q ? cbf_cr : cbf_cb) {
+      const int16_t* cp = f->coef[1 + q] + (size_t)(y0 >> 1) * cw + (x0 >> 1); RBT_PAR_FOR(i, Nc * Nc) l->lvl_c[q][i] = cp[(size_t)(i >> (log2 - 1)) * cw + (i & (Nc - 1))];
+    }
+  }
+  const int is_p = s->is_p;
+  if (s->tq_bypass_enabled) rbt_ce_bin0(c, CTX_CU_TQ_BYPASS, f->lossless ? 1 : 0);
+  const int ul = u - 1, ua = u - 9;                                  // left / above 8x8 unit
+  const int av_l = RBT_UNI(l->cu_l2[ul]) != 0xFF, av_a = RBT_UNI(l->cu_l2[ua]) != 0xFF;
   if (is_p) {
-    int cl = en_cu_coded(s, x0, y0, x0 - 1, y0) && (f->cu_flags[(y0 >> 3) * f->w8 + ((x0 - 1) >> 3)] & RBT_CU_SKIP);
-    int ca = en_cu_coded(s, x0, y0, x0, y0 - 1) && (f->cu_flags[((y0 - 1) >> 3) * f->w8 + (x0 >> 3)] & RBT_CU_SKIP);
+    const int cl = av_l && (RBT_UNI(l->cu_fl[ul]) & RBT_CU_SKIP), ca = av_a && (RBT_UNI(l->cu_fl[ua]) & RBT_CU_SKIP);
     rbt_ce_bin0(c, CTX_CU_SKIP + (cl ? 1 : 0) + (ca ? 1 : 0), (flags & RBT_CU_SKIP) ? 1 : 0);
     if (flags & RBT_CU_SKIP) return;                 // merge_idx absent: MaxNumMergeCand == 1
     rbt_ce_bin0(c, CTX_PRED_MODE, 0);
     rbt_ce_bin0(c, CTX_PART_MODE, 1);
     rbt_ce_bin0(c, CTX_MERGE_FLAG, 1);
   } else {
-    if (log2 == g->log2_min_cb) rbt_ce_bin0(c, CTX_PART_MODE, 1);
+    if (log2 == s->log2_min_cb) rbt_ce_bin0(c, CTX_PART_MODE, 1);
     int ca = 1, cb = 1;
-    if (en_cu_coded(s, x0, y0, x0 - 1, y0)) ca = f->cu_mode[(y0 >> 3) * f->w8 + ((x0 - 1) >> 3)];
-    if (en_cu_coded(s, x0, y0, x0, y0 - 1) && ((y0 - 1) >> g->log2_ctb) == (y0 >> g->log2_ctb)) cb = f->cu_mode[((y0 - 1) >> 3) * f->w8 + (x0 >> 3)];
+    if (av_l) ca = RBT_UNI(l->cu_md[ul]);
+    if (av_a && y0 > s->cy) cb = RBT_UNI(l->cu_md[ua]);              // the above candidate only counts inside the same CTB
     int c0, c1, c2;
     if (ca == cb) { if (ca < 2) { c0 = 0; c1 = 1; c2 = 26; } else { c0 = ca; c1 = 2 + ((ca + 29) % 32); c2 = 2 + ((ca - 2 + 1) % 32); } }
     else { c0 = ca; c1 = cb; c2 = (ca != 0 && cb != 0) ? 0 : ((ca != 1 && cb != 1) ? 1 : 26); }
@@ -493,58 +523,69 @@ RBT_DEV void en_write_cu(RbtEnt* s, int x0, int y0, int log2, int depth) {
       if (rem > c0) rem--;
       rbt_ce_bypass_n(c, (uint32_t)rem, 5);
     }
-    rbt_ce_bin0(c, CTX_INTRA_CHROMA, 0);              // intra_chroma_pred_mode = 4 (DM)
+    rbt_ce_bin0(c, CTX_INTRA_CHROMA, 0);             // intra_chroma_pred_mode = 4 (DM)
   }
   // transform tree: one TU per CU (max_transform_hierarchy_depth = 0, no split flag)
-  int cbf_cb = (flags & RBT_CU_CBF_CB) != 0, cbf_cr = (flags & RBT_CU_CBF_CR) != 0, cbf_y = (flags & RBT_CU_CBF_Y) != 0;
   rbt_ce_bin0(c, CTX_CBF_CHROMA + 0, cbf_cb);
   rbt_ce_bin0(c, CTX_CBF_CHROMA + 0, cbf_cr);
   if (!is_p || cbf_cb || cbf_cr) rbt_ce_bin0(c, CTX_CBF_LUMA + 1, cbf_y);
-  int intra = !is_p;
-  if (cbf_y) en_write_residual(s, 0, x0, y0, log2, en_scan_idx(intra, log2, 0, mode));
-  if (cbf_cb) en_write_residual(s, 1, x0 >> 1, y0 >> 1, log2 - 1, en_scan_idx(intra, log2 - 1, 1, mode));
-  if (cbf_cr) en_write_residual(s, 2, x0 >> 1, y0 >> 1, log2 - 1, en_scan_idx(intra, log2 - 1, 2, mode));
+  const int intra = !is_p;
+  RBT_SYNC();                                          // levels have arrived in LDS
+  if (cbf_y) en_write_residual(s, 0, l->lvl, log2, en_scan_idx(intra, log2, 0, mode));
+  if (cbf_cb) en_write_residual(s, 1, l->lvl_c[0], log2 - 1, en_scan_idx(intra, log2 - 1, 1, mode));
+  if (cbf_cr) en_write_residual(s, 2, l->lvl_c[1], log2 - 1, en_scan_idx(intra, log2 - 1, 2, mode));
+  RBT_SYNC_LDS();
   (void)depth;
 }
 RBT_DEV void en_write_quadtree(RbtEnt* s, int x0, int y0, int log2) {
-  struct Node { int16_t x, y; int8_t log2, depth, state; };
-  Node st[5]; int sp = 0;
-  st[0].x = (int16_t)x0; st[0].y = (int16_t)y0; st[0].log2 = (int8_t)log2; st[0].depth = 0; st[0].state = -1;
-  const RbtFrame* f = s->f; const RbtStreamCfg* g = &f->cfg;
-  while (sp >= 0) {
-    Node* n = &st[sp];
-    int N = 1 << n->log2, h = N >> 1;
-    if (n->state < 0) {
-      int can_flag = n->x + N <= g->w && n->y + N <= g->h && n->log2 > g->log2_min_cb;
-      int split = f->cu_log2[(n->y >> 3) * f->w8 + (n->x >> 3)] < n->log2;
-      if (!can_flag) split = n->log2 > g->log2_min_cb;
+  // stack-free depth-first walk (per-level child counters packed in one register, see the parser's pz_coding_quadtree)
+  RBT_LDS_AS RbtEncLds* l = s->l;
+  int lvl = 0, x = x0, y = y0, lg = log2;
+  uint32_t states = 15u;
+  for (;;) {
+    lvl = RBT_UNI(lvl); x = RBT_UNI(x); y = RBT_UNI(y); lg = RBT_UNI(lg); states = (uint32_t)RBT_UNI(states);
+    int st = (int)((states >> (4 * lvl)) & 15u);
+    const int N = 1 << lg, h = N >> 1;
+    if (st == 15) {
+      const int can_flag = x + N <= s->w && y + N <= s->h && lg > s->log2_min_cb;
+      const int u = en_u(s, x, y);
+      int split = RBT_UNI(l->cu_l2[u]) < lg;
+      if (!can_flag) split = lg > s->log2_min_cb;
       if (can_flag) {
-        int cl = en_cu_coded(s, n->x, n->y, n->x - 1, n->y) && (g->log2_ctb - f->cu_log2[(n->y >> 3) * f->w8 + ((n->x - 1) >> 3)]) > n->depth;
-        int ca = en_cu_coded(s, n->x, n->y, n->x, n->y - 1) && (g->log2_ctb - f->cu_log2[((n->y - 1) >> 3) * f->w8 + (n->x >> 3)]) > n->depth;
+        const int l2l = RBT_UNI(l->cu_l2[u - 1]), l2a = RBT_UNI(l->cu_l2[u - 9]);
+        const int cl = l2l != 0xFF && (s->log2_ctb - l2l) > lvl, ca = l2a != 0xFF && (s->log2_ctb - l2a) > lvl;
         rbt_ce_bin0(&s->c, CTX_SPLIT_CU + (cl ? 1 : 0) + (ca ? 1 : 0), split);
       }
-      if (!split) { en_write_cu(s, n->x, n->y, n->log2, n->depth); sp--; continue; }
-      n->state = 0;
+      if (!split) { en_write_cu(s, x, y, lg, lvl); st = 4; } else st = 0;
     }
-    if (n->state >= 4) { sp--; continue; }
-    int k = n->state++;
-    int cx = n->x + (k & 1) * h, cy = n->y + (k >> 1) * h;
-    if (cx >= g->w || cy >= g->h) continue;
-    Node* ch = &st[sp + 1];
-    ch->x = (int16_t)cx; ch->y = (int16_t)cy; ch->log2 = (int8_t)(n->log2 - 1); ch->depth = (int8_t)(n->depth + 1); ch->state = -1;
-    sp++;
+    while (st < 4 && (x + (st & 1) * h >= s->w || y + (st >> 1) * h >= s->h)) st++;   // children outside the picture are skipped
+    if (st < 4) {
+      states = (states & ~(15u << (4 * lvl))) | ((uint32_t)(st + 1) << (4 * lvl));
+      x += (st & 1) * h; y += (st >> 1) * h; lg--; lvl++;
+      states = (states & ~(15u << (4 * lvl))) | (15u << (4 * lvl));
+    } else {
+      if (lvl == 0) break;
+      lvl--;
+      const int k = (int)((states >> (4 * lvl)) & 15u) - 1, hh = 1 << lg;
+      x -= (k & 1) * hh; y -= (k >> 1) * hh; lg++;
+    }
   }
 }
 RBT_DEV void en_entropy_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, uint8_t* out, RBT_LDS_AS RbtEncLds* l) {
-  RbtEnt s; s.sl = &slices[slice_idx]; s.f = &frames[s.sl->frame]; s.slice_idx = slice_idx; s.l = l;
+  RbtEnt s; s.sl = &slices[slice_idx]; s.f = &frames[RBT_UNI(s.sl->frame)]; s.slice_idx = slice_idx; s.l = l;
   const RbtSlice* sl = s.sl; const RbtStreamCfg* g = &s.f->cfg;
-  rbt_ctx_init(&s.c.cs, sl->slice_type == RBT_SLICE_I ? 0 : 1, sl->qp);
-  s.c.out = out + sl->out_off; s.c.cap = sl->out_cap; s.c.n = 0; s.c.overflow = 0;
+  s.w = RBT_UNI(g->w); s.h = RBT_UNI(g->h); s.log2_ctb = RBT_UNI(g->log2_ctb); s.log2_min_cb = RBT_UNI(g->log2_min_cb); s.tq_bypass_enabled = RBT_UNI(g->tq_bypass_enabled);
+  s.is_p = RBT_UNI(sl->slice_type) == RBT_SLICE_P; s.cx = s.cy = 0;
+  RBT_PAR_FOR(i, 3 * 4 * 64) l->scan[i / 256][(i / 64) & 3][i & 63] = k_scan_packed(i / 256, (i / 64) & 3, i & 63);
+  rbt_ctx_init(&s.c.cs, s.is_p ? 1 : 0, RBT_UNI(sl->qp));
+  s.c.out = rbt_uni_ptr(out + (uint32_t)RBT_UNI(sl->out_off)); s.c.cap = (uint32_t)RBT_UNI(sl->out_cap); s.c.n = 0; s.c.overflow = 0;
   rbt_ce_start(&s.c);
-  for (int a = 0; a < sl->n_ctbs; a++) {
-    int addr = sl->ctb_addr + a, rx = addr % g->w_ctb, ry = addr / g->w_ctb;
-    en_write_quadtree(&s, rx << g->log2_ctb, ry << g->log2_ctb, g->log2_ctb);
-    rbt_ce_terminate(&s.c, a == sl->n_ctbs - 1);
+  const int n_ctbs = RBT_UNI(sl->n_ctbs), first = RBT_UNI(sl->ctb_addr), wc = (s.w + (1 << s.log2_ctb) - 1) >> s.log2_ctb;
+  for (int a = 0; a < n_ctbs; a++) {
+    const int addr = first + a, rx = addr % wc, ry = addr / wc;
+    en_stage_ctb(&s, rx << s.log2_ctb, ry << s.log2_ctb);
+    en_write_quadtree(&s, rx << s.log2_ctb, ry << s.log2_ctb, s.log2_ctb);
+    rbt_ce_terminate(&s.c, a == n_ctbs - 1);
   }
   rbt_ce_align_zero(&s.c);
   if (RBT_LANE0) slices[slice_idx].out_size = s.c.overflow ? 0xFFFFFFFFu : s.c.n;
