@@ -179,7 +179,7 @@ template <int LOG2> RBT_DEV void en_fwd_transform_n(int is_dst, int bd, RBT_LDS_
     int k = i & (N - 1), y = i >> LOG2, s = 0;
 #pragma unroll
     for (int x = 0; x < N; x++) s += rc_tcoef(r, N, is_dst, k, x) * r->res[y * N + x];
-    r->tmp[i] = s1 > 0 ? (s + (1 << (s1 - 1))) >> s1 : s;
+    r->tmp[i] = (int16_t)(s1 > 0 ? (s + (1 << (s1 - 1))) >> s1 : s);
   }
   RBT_SYNC_LDS();
   RBT_PAR_FOR(i, N * N) {
@@ -257,34 +257,141 @@ RBT_DEV void en_fill_cu_maps(RbtFrame* f, int x0, int y0, int N, int pm_val, int
     f->edges[k] = (uint8_t)e;
   }
   if (set_flags) RBT_PAR_FOR(i, n8 * n8) { int k = ((y0 >> 3) + i / n8) * f->w8 + (x0 >> 3) + i % n8; f->cu_flags[k] = (uint8_t)cbf_bits_or_flags; }
-  RBT_SYNC();
 }
 
 // ------------------------------------------------------------------------------------------------ I pictures: one CTB
-RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtEncLds* l) {
-  const RbtStreamCfg* g = &f->cfg;
-  int ctb = 1 << g->log2_ctb, cx = (ctb_addr % g->w_ctb) << g->log2_ctb, cy = (ctb_addr / g->w_ctb) << g->log2_ctb;
+// ---- closed-loop intra coding of one CTB inside LDS --------------------------------------------------------------
+// Same staging as the decoder's rbt_recon_ctb: the reconstruction of the CTB, its border and the availability flags of the
+// 4x4 units around it live in LDS, every TB predicts / transforms / reconstructs there, and the CTB is written back with
+// coalesced row stores. Levels go straight to the coefficient plane (nobody waits for those stores).
+// The body and the row above it are separate arrays (the row above spans 2n+1 samples, the body n+1 per row): 17 KB per
+// workgroup instead of 29, which together with the rest keeps five workgroups (every CTB row of a 32-picture batch) on a CU.
+#define EN_TS_Y 65
+#define EN_TS_C 33
+struct RbtEncTile {
+  uint16_t y[64 * EN_TS_Y], top_y[130];                      // body: yy * stride + xx + 1 (xx = -1..63); top: xx + 1 (xx = -1..128)
+  uint16_t c[2][32 * EN_TS_C], top_c[2][66];
+  uint8_t uav[17 * RC_US];
+  uint16_t sb[32 * 32 + 2 * 16 * 16];                        // source samples of the current CU: Y, Cb, Cr
+  uint8_t cu_l2[64], cu_md[64];                              // cu_log2 / cu_mode of the CTB's 8x8 units (analysis result)
+};
+struct RbtEncTileLds { RbtReconLds rc; int16_t lvl[32 * 32]; RbtEncTile t; };
+RBT_DEV int en_quant_scale(int r) { const uint64_t lo = 26214ull | (23302ull << 16) | (20560ull << 32) | (18396ull << 48), hi = 16384ull | (14564ull << 16); return (int)(((r < 4 ? lo : hi) >> (16 * (r & 3))) & 0xFFFF); }
+// one intra TB: (x0,y0) relative to the CTB and (gx,gy) in the picture, both in samples of component c_idx; returns cbf
+RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLds* L, int c_idx, int x0, int y0, int gx, int gy, int log2, int mode, int qp,
+                             const RBT_LDS_AS uint16_t* src, int mark_l4, int mux, int muy) {
+  RBT_LDS_AS RbtEncTileLds* l = L; RBT_LDS_AS RbtReconLds* r = &L->rc; RBT_LDS_AS RbtEncTile* t = &L->t;
+  const int N = 1 << log2, sh = c_idx ? 1 : 0, bd = g->bit_depth, maxv = (1 << bd) - 1, n4 = (1 << g->log2_ctb) >> 2, pw = c_idx ? g->cw : g->w;
+  RBT_LDS_AS uint16_t* tile = c_idx == 0 ? t->y : t->c[c_idx - 1]; const int S = c_idx == 0 ? EN_TS_Y : EN_TS_C;
+  const RBT_LDS_AS uint16_t* top = c_idx == 0 ? t->top_y : t->top_c[c_idx - 1];
+  // reference samples: availability masks, substitution while gathering, smoothing, mode set-up
+  const int tot = 4 * N + 1;
+  uint64_t m0, m1 = 0; int m2 = 0;
+  RBT_VBALLOT(m0, p, rbt_min(tot, 64), rc_nb_av(t->uav, p, x0, y0, N, sh, n4));
+  if (tot > 64) { RBT_VBALLOT(m1, p, rbt_min(tot - 64, 64), rc_nb_av(t->uav, 64 + p, x0, y0, N, sh, n4)); }
+  if (tot > 128) m2 = rc_nb_av(t->uav, 128, x0, y0, N, sh, n4);
+  const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : (m2 ? 128 : -1));
+  RBT_PAR_FOR(i, tot) {
+    int v = 1 << (bd - 1);
+    if (first >= 0) { int j = rc_last_avail(i, m0, m1, m2); if (j < 0) j = first; int xn, yn; rc_nb_xy(j, x0, y0, N, &xn, &yn); v = yn < 0 ? top[xn + 1] : tile[yn * S + xn + 1]; }
+    r->nb[i] = v;
+  }
+  RBT_SYNC_LDS();
+  RBT_LDS_AS int32_t* fin = rc_intra_filter(g, c_idx, log2, mode, r->nb, r->nbf);
+  RcIntraCtx q; rc_intra_setup(g, c_idx, log2, mode, fin, r, &q);
+  // prediction and residual
+  RBT_PAR_FOR(i, N * N) { const int pv = rc_intra_sample(&q, fin, r, i & (N - 1), i >> log2); r->pred[i] = (uint16_t)pv; r->res[i] = (int16_t)((int)src[i] - pv); }
+  RBT_SYNC_LDS();
+  int nz;
+  if (f->lossless) {
+    int part = 0;
+    RBT_PAR_FOR(i, N * N) { l->lvl[i] = r->res[i]; part += r->res[i] != 0; }
+    nz = en_wave_sum(part, (RBT_LDS_AS RbtEncLds*)0);
+  } else {
+    en_fwd_transform(log2, c_idx == 0 && log2 == 2, bd, r);
+    const int qbits = 14 + qp / 6 + (15 - bd - log2), sc = en_quant_scale(qp % 6); int part = 0;
+    const long long add = (long long)171 << (qbits - 9);
+    RBT_PAR_FOR(i, N * N) {
+      const int cv = r->res[i], a = rbt_abs(cv);
+      long long qv = ((long long)a * sc + add) >> qbits;
+      if (qv > 32767) qv = 32767;
+      l->lvl[i] = (int16_t)(cv < 0 ? -qv : qv);
+      part += qv != 0;
+    }
+    nz = en_wave_sum(part, (RBT_LDS_AS RbtEncLds*)0);
+  }
+  RBT_SYNC_LDS();
+  { int16_t* cp = f->coef[c_idx] + (size_t)gy * pw + gx; RBT_PAR_FOR(i, N * N) cp[(size_t)(i >> log2) * pw + (i & (N - 1))] = l->lvl[i]; }
+  if (nz && !f->lossless) {
+    const int bd_shift = bd + log2 - 5, scale = (16 * rc_level_scale(qp % 6)) << (qp / 6);
+    const long long add = 1ll << (bd_shift - 1);
+    RBT_PAR_FOR(i, N * N) { long long v = ((long long)l->lvl[i] * scale + add) >> bd_shift; r->res[i] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+    RBT_SYNC_LDS();
+    rc_inv_transform(log2, c_idx == 0 && log2 == 2, 0, bd, r);
+  } else if (nz) {
+    RBT_PAR_FOR(i, N * N) r->res[i] = l->lvl[i];
+    RBT_SYNC_LDS();
+  }
+  RBT_PAR_FOR(i, N * N) {
+    const int x = i & (N - 1), y = i >> log2;
+    tile[(y0 + y) * S + x0 + x + 1] = (uint16_t)(nz ? rbt_clip3(0, maxv, (int)r->pred[i] + r->res[i]) : r->pred[i]);
+  }
+  if (mark_l4 >= 0) { RBT_PAR_FOR(i, 1 << (2 * mark_l4)) t->uav[(muy + (i >> mark_l4) + 1) * RC_US + mux + (i & ((1 << mark_l4) - 1)) + 1] = 1; }
+  RBT_SYNC_LDS();
+  return nz != 0;
+}
+// carry_left: the CTB to the left was coded by this wave just before (its reconstruction is still in the tile): take the
+// left border from LDS instead of reading back stores that may still be in flight
+RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtEncTileLds* L, int carry_left) {
+  const RbtStreamCfg gcopy = f->cfg; const RbtStreamCfg* g = &gcopy;
+  RBT_LDS_AS RbtEncTile* t = &L->t;
+  const int ctb = 1 << g->log2_ctb, n4 = ctb >> 2, n8 = ctb >> 3, rx = ctb_addr % g->w_ctb, ry = ctb_addr / g->w_ctb, cx = rx << g->log2_ctb, cy = ry << g->log2_ctb;
   const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
-  int qp_y = sl->qp, bd = g->bit_depth;
-  int qp_l = qp_y + 6 * (bd - 8), qp_cb = en_chroma_qp(f, sl, 1, qp_y), qp_cr = en_chroma_qp(f, sl, 2, qp_y);
-  int n8 = ctb / 8;
+  const int qp_y = sl->qp, bd = g->bit_depth;
+  const int qp_l = qp_y + 6 * (bd - 8), qp_cb = en_chroma_qp(f, sl, 1, qp_y), qp_cr = en_chroma_qp(f, sl, 2, qp_y);
+  // ---- borders, unit availability, analysis results ----
+  for (int c = 0; c < 3; c++) {
+    const int sh = c ? 1 : 0, nn = ctb >> sh, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, ox = cx >> sh, oy = cy >> sh, S = c ? EN_TS_C : EN_TS_Y;
+    const uint16_t* p = f->pix[c]; RBT_LDS_AS uint16_t* tile = c == 0 ? t->y : t->c[c - 1]; RBT_LDS_AS uint16_t* top = c == 0 ? t->top_y : t->top_c[c - 1];
+    if (carry_left) { RBT_PAR_FOR(i, nn) tile[i * S] = tile[i * S + nn]; RBT_SYNC_LDS(); }
+    else { RBT_PAR_FOR(i, nn) { int x = ox - 1, y = oy + i; tile[i * S] = (x >= 0 && y < ph) ? p[(size_t)y * pw + x] : 0; } }
+    RBT_PAR_FOR(i, 2 * nn + 1) { int x = ox + i - 1, y = oy - 1; top[i] = (x >= 0 && y >= 0 && x < pw) ? p[(size_t)y * pw + x] : 0; }
+  }
+  RBT_PAR_FOR(i, 17 * RC_US) {
+    int ux = i % RC_US - 1, uy = i / RC_US - 1, a = 0;
+    if ((uy < 0 && ux < 2 * n4) || (ux < 0 && uy < n4)) a = rc_unit_avail(f, ctb_addr, (cx >> 2) + ux, (cy >> 2) + uy);
+    t->uav[i] = (uint8_t)a;
+  }
+  RBT_PAR_FOR(i, n8 * n8) {
+    const int ux = i & (n8 - 1), uy = i / n8, x = cx + ux * 8, y = cy + uy * 8;
+    int l2 = 3, md = 1;
+    if (x < g->w && y < g->h) { const int k = (y >> 3) * f->w8 + (x >> 3); l2 = f->cu_log2[k]; md = f->cu_mode[k]; }
+    t->cu_l2[uy * 8 + ux] = (uint8_t)l2; t->cu_md[uy * 8 + ux] = (uint8_t)md;
+  }
+  RBT_SYNC();
   // leaf CUs in z-order: walk 8x8 units in Morton order, a CU is coded when its first unit is reached
   for (int z = 0; z < n8 * n8; z++) {
     int ux = 0, uy = 0;
     for (int b = 0; b < 3; b++) { ux |= ((z >> (2 * b)) & 1) << b; uy |= ((z >> (2 * b + 1)) & 1) << b; }
-    int x0 = cx + ux * 8, y0 = cy + uy * 8;
-    if (x0 >= g->w || y0 >= g->h) continue;
-    int k8 = (y0 >> 3) * f->w8 + (x0 >> 3);
-    int lg = f->cu_log2[k8], N = 1 << lg;
+    const int x0 = ux * 8, y0 = uy * 8;                              // relative to the CTB
+    if (cx + x0 >= g->w || cy + y0 >= g->h) continue;
+    const int lg = t->cu_l2[uy * 8 + ux], N = 1 << lg, Nc = N >> 1;
     if ((x0 & (N - 1)) || (y0 & (N - 1))) continue;
-    int mode = f->cu_mode[k8];
-    rc_intra_pred(f, f->pix[0], 0, x0, y0, lg, mode, &l->rc);
-    int cbf = en_code_tb(f, 0, x0, y0, lg, qp_l, 1, l) ? RBT_CU_CBF_Y : 0;
-    rc_intra_pred(f, f->pix[1], 1, x0 >> 1, y0 >> 1, lg - 1, mode, &l->rc);
-    if (en_code_tb(f, 1, x0 >> 1, y0 >> 1, lg - 1, qp_cb, 1, l)) cbf |= RBT_CU_CBF_CB;
-    rc_intra_pred(f, f->pix[2], 2, x0 >> 1, y0 >> 1, lg - 1, mode, &l->rc);
-    if (en_code_tb(f, 2, x0 >> 1, y0 >> 1, lg - 1, qp_cr, 1, l)) cbf |= RBT_CU_CBF_CR;
-    en_fill_cu_maps(f, x0, y0, N, RBT_MODE_INTRA | (f->lossless ? RBT_PM_TQ_BYPASS : 0) | ((cbf & RBT_CU_CBF_Y) ? RBT_PM_NZ : 0), qp_y, cbf, 1);
+    const int mode = t->cu_md[uy * 8 + ux];
+    // source samples of the CU's three TBs: one HBM round trip
+    { const uint16_t* sp = f->src[0] + (size_t)(cy + y0) * g->w + cx + x0; RBT_PAR_FOR(i, N * N) t->sb[i] = sp[(size_t)(i >> lg) * g->w + (i & (N - 1))]; }
+    for (int q = 0; q < 2; q++) { const uint16_t* sp = f->src[1 + q] + (size_t)((cy + y0) >> 1) * g->cw + ((cx + x0) >> 1); RBT_PAR_FOR(i, Nc * Nc) t->sb[1024 + 256 * q + i] = sp[(size_t)(i >> (lg - 1)) * g->cw + (i & (Nc - 1))]; }
+    RBT_SYNC();
+    int cbf = en_tile_intra_tb(g, f, L, 0, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, t->sb, lg - 2, x0 >> 2, y0 >> 2) ? RBT_CU_CBF_Y : 0;
+    if (en_tile_intra_tb(g, f, L, 1, x0 >> 1, y0 >> 1, (cx + x0) >> 1, (cy + y0) >> 1, lg - 1, mode, qp_cb, t->sb + 1024, -1, 0, 0)) cbf |= RBT_CU_CBF_CB;
+    if (en_tile_intra_tb(g, f, L, 2, x0 >> 1, y0 >> 1, (cx + x0) >> 1, (cy + y0) >> 1, lg - 1, mode, qp_cr, t->sb + 1280, -1, 0, 0)) cbf |= RBT_CU_CBF_CR;
+    en_fill_cu_maps(f, cx + x0, cy + y0, N, RBT_MODE_INTRA | (f->lossless ? RBT_PM_TQ_BYPASS : 0) | ((cbf & RBT_CU_CBF_Y) ? RBT_PM_NZ : 0), qp_y, cbf, 1);
+  }
+  // ---- write the CTB back (clipped to the picture) ----
+  for (int c = 0; c < 3; c++) {
+    const int sh = c ? 1 : 0, nn = ctb >> sh, lnn = g->log2_ctb - sh, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, ox = cx >> sh, oy = cy >> sh, S = c ? EN_TS_C : EN_TS_Y;
+    uint16_t* p = f->pix[c]; RBT_LDS_AS uint16_t* tile = c == 0 ? t->y : t->c[c - 1];
+    RBT_PAR_FOR(i, nn * nn) { int x = i & (nn - 1), y = i >> lnn; if (ox + x < pw && oy + y < ph) p[(size_t)(oy + y) * pw + ox + x] = tile[y * S + x + 1]; }
   }
 }
 

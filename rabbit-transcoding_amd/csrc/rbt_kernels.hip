@@ -159,20 +159,20 @@ __global__ void __launch_bounds__(64) k_enc_analyse(RbtFrame* frames, const RbtS
   en_analyse_ctb(f, slices, blockIdx.x, RBT_LDS_CAST(RbtEncLds, &lds));
 }
 __global__ void __launch_bounds__(64) k_enc_intra_rows(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
-  __shared__ RbtEncLds lds;
+  __shared__ RbtEncTileLds lds;
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   int row = blockIdx.x;
   if (row >= f->cfg.h_ctb) return;
-  rc_stage_tables(&RBT_LDS_CAST(RbtEncLds, &lds)->rc);
-  for (int x = 0; x < f->cfg.w_ctb; x++) en_intra_ctb(f, slices, row * f->cfg.w_ctb + x, RBT_LDS_CAST(RbtEncLds, &lds));
+  rc_stage_tables(&RBT_LDS_CAST(RbtEncTileLds, &lds)->rc);
+  for (int x = 0; x < f->cfg.w_ctb; x++) en_intra_ctb(f, slices, row * f->cfg.w_ctb + x, RBT_LDS_CAST(RbtEncTileLds, &lds), x > 0);
 }
 __global__ void __launch_bounds__(64) k_enc_intra_diag(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int d) {
-  __shared__ RbtEncLds lds;
+  __shared__ RbtEncTileLds lds;
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   int y = blockIdx.x, x = d - 2 * y;
   if (y >= f->cfg.h_ctb || x < 0 || x >= f->cfg.w_ctb) return;
-  rc_stage_tables(&RBT_LDS_CAST(RbtEncLds, &lds)->rc);
-  en_intra_ctb(f, slices, y * f->cfg.w_ctb + x, RBT_LDS_CAST(RbtEncLds, &lds));
+  rc_stage_tables(&RBT_LDS_CAST(RbtEncTileLds, &lds)->rc);
+  en_intra_ctb(f, slices, y * f->cfg.w_ctb + x, RBT_LDS_CAST(RbtEncTileLds, &lds), 0);
 }
 __global__ void __launch_bounds__(64) k_enc_inter(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
   __shared__ RbtEncLds lds;

@@ -13,7 +13,7 @@ struct RbtReconLds {
   int32_t ref[100];       // angular reference array, index offset 32
   uint8_t av[132];
   int16_t res[32 * 32];   // dequantised coefficients, then residual
-  int32_t tmp[32 * 32];   // first transform stage
+  int16_t tmp[32 * 32];   // first transform stage (16-bit by construction: 8.6.4.2 clips it, the forward stage's shift keeps it below 2^15)
   uint16_t pred[32 * 32];
   int8_t dct[32 * 32]; int8_t dst[16];   // transform matrices, staged once per workgroup (rc_stage_tables)
 };
@@ -219,7 +219,7 @@ template <int LOG2> RBT_DEV void rc_inv_transform_n(int is_dst, int sh, RBT_LDS_
     int x = i & (N - 1), y = i >> LOG2, s = 0;
 #pragma unroll
     for (int k = 0; k < N; k++) s += rc_tcoef(l, N, is_dst, k, y) * l->res[k * N + x];
-    l->tmp[i] = rbt_clip3(-32768, 32767, (s + 64) >> 7);
+    l->tmp[i] = (int16_t)rbt_clip3(-32768, 32767, (s + 64) >> 7);
   }
   RBT_SYNC_LDS();
   RBT_PAR_FOR(i, N * N) {
@@ -293,10 +293,10 @@ RBT_DEV void rc_nb_xy(int i, int x0, int y0, int N, int* xn, int* yn) {
   else if (i == 2 * N) { *xn = x0 - 1; *yn = y0 - 1; }
   else { *xn = x0 + (i - 2 * N - 1); *yn = y0 - 1; }
 }
-RBT_DEV int rc_nb_av(const RBT_LDS_AS RbtCtbTile* t, int i, int x0, int y0, int N, int sh, int n4) {
+RBT_DEV int rc_nb_av(const RBT_LDS_AS uint8_t* uav, int i, int x0, int y0, int N, int sh, int n4) {
   int xn, yn; rc_nb_xy(i, x0, y0, N, &xn, &yn);
   const int ux = (xn << sh) >> 2, uy = (yn << sh) >> 2;                  // -1 for the border column / row
-  return uy < n4 && t->uav[(uy + 1) * RC_US + ux + 1];
+  return uy < n4 && uav[(uy + 1) * RC_US + ux + 1];
 }
 // mark_l4 >= 0: also flags the TB's (1 << mark_l4)^2 luma units at (mux,muy) as decoded in the same pass
 RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int c_idx, int x0, int y0, int log2, int intra, int mode, int cbf, int ts, int tq_bypass, int qp,
@@ -328,9 +328,9 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int
     // sample its index is substituted from (8.4.4.2.2) - gather and substitution in one pass
     const int tot = 4 * N + 1;
     uint64_t m0 = 0, m1 = 0; int m2 = 0;
-    RBT_VBALLOT(m0, p, rbt_min(tot, 64), rc_nb_av(t, p, x0, y0, N, sh, n4));
-    if (tot > 64) { RBT_VBALLOT(m1, p, rbt_min(tot - 64, 64), rc_nb_av(t, 64 + p, x0, y0, N, sh, n4)); }
-    if (tot > 128) m2 = rc_nb_av(t, 128, x0, y0, N, sh, n4);
+    RBT_VBALLOT(m0, p, rbt_min(tot, 64), rc_nb_av(t->uav, p, x0, y0, N, sh, n4));
+    if (tot > 64) { RBT_VBALLOT(m1, p, rbt_min(tot - 64, 64), rc_nb_av(t->uav, 64 + p, x0, y0, N, sh, n4)); }
+    if (tot > 128) m2 = rc_nb_av(t->uav, 128, x0, y0, N, sh, n4);
     const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : (m2 ? 128 : -1));
     RBT_PAR_FOR(i, tot) {
       int v = 1 << (bd - 1);
