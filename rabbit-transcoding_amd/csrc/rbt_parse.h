@@ -873,6 +873,7 @@ RBT_DEV void pz_coding_quadtree(RbtParse* s, int x0, int y0, int log2) {
     lvl = PZ_WU(lvl); x = PZ_WU(x); y = PZ_WU(y); lg = PZ_WU(lg); states = (uint32_t)PZ_WU(states);
     int st = (int)((states >> (4 * lvl)) & 15u);
     int N = 1 << lg;
+    PZ_STAMP(s, 22);
     if (st == 15) {
       int split;
       if (x + N <= pzc_w(s) && y + N <= pzc_h(s) && lg > pzc_log2_min_cb(s)) {
@@ -880,8 +881,13 @@ RBT_DEV void pz_coding_quadtree(RbtParse* s, int x0, int y0, int log2) {
         int cl = nl >= 0 && (nl >> 14) > lvl, ca = na >= 0 && (na >> 14) > lvl;
         split = rbt_cd_bin(&s->c, CTX_SPLIT_CU + cl + ca);
       } else split = lg > pzc_log2_min_cb(s);
+      PZ_STAMP(s, 23);
       if (pzc_cu_qp_delta(s) && lg >= pzc_log2_ctb(s) - pzc_diff_cu_qp_delta_depth(s)) pz_start_qg(s, x, y);
-      if (!split) { pz_coding_unit(s, x, y, lg, lvl); st = 4; } else st = 0;
+      if (!split) { pz_coding_unit(s, x, y, lg, lvl); st = 4;
+#ifdef RBT_PROFILE
+        s->t_last = __builtin_readcyclecounter();
+#endif
+      } else st = 0;
     }
     // next child that lies inside the picture
     int h = N >> 1;
@@ -896,6 +902,7 @@ RBT_DEV void pz_coding_quadtree(RbtParse* s, int x0, int y0, int log2) {
       int k = (int)((states >> (4 * lvl)) & 15u) - 1, hh = 1 << lg;
       x -= (k & 1) * hh; y -= (k >> 1) * hh; lg++;
     }
+    PZ_STAMP(s, 24);
   }
 }
 
@@ -967,6 +974,7 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
   }
 #ifdef RBT_PROFILE
   if (RBT_LANE0) for (int i = 0; i < 22; i++) printf("stamp %d: %llu cycles, %u hits\n", i, lds->prof[i], lds->profn[i]);
+  if (RBT_LANE0) for (int i = 22; i < 26; i++) printf("stamp %d: %llu cycles, %u hits\n", i, lds->prof[i], lds->profn[i]);
   if (RBT_LANE0) printf("slice %d: total %llu cyc, residual %llu (%u TBs) [setup+last %llu, csbf+sig %llu, gt1/2 %llu, levels %llu], TU total (incl. residual) %llu, CU header %llu (%u CUs), ctb begin/end %llu, CU total %llu, fills %llu, mpm %llu, bins ctx %u bypass %u, bits %u\n", slice_idx, __builtin_readcyclecounter() - t_all_, s.t_res, s.n_res, s.t_a, s.t_b, s.t_c, s.t_d, s.t_tu, s.t_hdr, s.n_cu, s.t_ctb, s.t_cu, s.t_fill, s.t_mpm, s.c.n_bins, s.c.n_byp, s.c.widx * 32u - (uint32_t)s.c.nbuf);
 #endif
   if (RBT_LANE0) { slices[slice_idx].n_ctbs_decoded = count; if (s.error) s.f->error = s.error; }

@@ -105,3 +105,17 @@ def test_transcode_is_idempotent_in_structure(ctx):
     assert twice == O.transcode_substream(once, 1, 32)
     dec, w, h, bd, chk, fail = ctx.decode(twice)
     assert (w, h, dec.shape[0], fail) == (128, 128, 4, 0)
+
+
+def test_transcode_rejects_damaged_input(ctx):
+    """a slice whose data is damaged must surface as an error from the chained decode -> re-encode pipeline (the
+    encoder is enqueued behind the decoder without a host round trip, so it runs on whatever the decoder left)"""
+    R = rbt_lib.module()
+    so, sg, sa, _ = _r5_streams(128, 128, 2, 11)
+    bad = bytearray(sa)
+    r = np.random.default_rng(3)
+    for k in r.integers(len(bad) // 2, len(bad) - 8, 200): bad[int(k)] = int(r.integers(1, 255))
+    with pytest.raises(R.RbtError):
+        ctx.transcode_substream(bytes(bad[: len(bad) // 2 + len(bad) // 3]), R.RBT_VIDEO_ATTRIBUTE, 32)
+    # the context stays usable
+    assert ctx.transcode_substream(sg, R.RBT_VIDEO_GEOMETRY, 24) == O.transcode_substream(sg, 1, 24)

@@ -39,3 +39,14 @@ def test_encoder_and_transcode_bitstreams(ctx, log2_ctb, rows):
     so, _ = O.encode(occ, 64, 64, 8, 8, gop=1, lossless=1, i_qp_offset=0, log2_ctb=6, rows_per_slice=0)
     assert ctx.transcode_substream(sg, R.RBT_VIDEO_GEOMETRY, 24, log2_ctb=log2_ctb, rows_per_slice=rows) == O.transcode_substream(sg, 1, 24, log2_ctb=log2_ctb, rows_per_slice=rows)
     assert ctx.transcode_substream(so, R.RBT_VIDEO_OCCUPANCY, 8, log2_ctb=log2_ctb, rows_per_slice=rows) == O.transcode_substream(so, 0, 8, log2_ctb=log2_ctb, rows_per_slice=rows)
+
+
+def test_transcode_rejects_damaged_input(ctx):
+    R = rbt_lib.module()
+    geo, attr, occ = synth.make_gof(128, 128, 2, 11)
+    sa, _ = O.encode(attr, 128, 128, 10, 22, gop=2, log2_ctb=6, rows_per_slice=0)
+    bad = bytearray(sa)
+    r = np.random.default_rng(3)
+    for k in r.integers(len(bad) // 2, len(bad) - 8, 200): bad[int(k)] = int(r.integers(1, 255))
+    with pytest.raises(R.RbtError):
+        ctx.transcode_substream(bytes(bad[: len(bad) // 2 + len(bad) // 3]), R.RBT_VIDEO_ATTRIBUTE, 32)
