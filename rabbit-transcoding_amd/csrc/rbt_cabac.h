@@ -46,6 +46,17 @@ RBT_DEV int rbt_ctx_initval(int init_type, int qp, int i) {
 // transition word of pStateIdx s: bits 0..7 = (transIdxLps << 1 | (s == 0)) ^ 1, bits 8..15 = (transIdxMps << 1) ^ 1; the
 // selected byte XOR !valMps is the updated context variable
 RBT_DEV int rbt_trans_word(int s) { s &= 63; int nm = s < 62 ? s + 1 : s; return (((k_next_lps[s] << 1) | (s == 0)) ^ 1) | (((nm << 1) ^ 1) << 8); }
+// the constant lookup registers (rangeTabLPS, transitions); separate so that a resumed parser can rebuild them
+RBT_DEV void rbt_ctx_tables(RbtCtxStore* s) {
+#ifdef RBT_HOSTEMU
+  (void)s;
+#else
+  int l = (int)threadIdx.x & 63;
+  s->lps_tab = (int)(k_range_lps[l][0] | (k_range_lps[l][1] << 8) | (k_range_lps[l][2] << 16) | ((uint32_t)k_range_lps[l][3] << 24));
+  s->nxt_tab = k_next_lps[l];
+  s->trans_tab = rbt_trans_word(l);
+#endif
+}
 RBT_DEV void rbt_ctx_init(RbtCtxStore* s, int init_type, int qp) {
   qp = rbt_clip3(0, 51, qp);
 #ifdef RBT_HOSTEMU
@@ -56,9 +67,7 @@ RBT_DEV void rbt_ctx_init(RbtCtxStore* s, int init_type, int qp) {
   s->st1 = l < 44 ? rbt_ctx_initval(init_type, qp, CTX_SIG + l) : 0;
   s->st2 = l < 4 ? rbt_ctx_initval(init_type, qp, CTX_CSBF + l) : (l < 34 ? rbt_ctx_initval(init_type, qp, CTX_GT1 + l - 4) : 0);
   s->st3 = l < 36 ? rbt_ctx_initval(init_type, qp, CTX_LAST_X + l) : 0;
-  s->lps_tab = (int)(k_range_lps[l][0] | (k_range_lps[l][1] << 8) | (k_range_lps[l][2] << 16) | ((uint32_t)k_range_lps[l][3] << 24));
-  s->nxt_tab = k_next_lps[l];
-  s->trans_tab = rbt_trans_word(l);
+  rbt_ctx_tables(s);
 #endif
 }
 // generic access by context index (any syntax class)

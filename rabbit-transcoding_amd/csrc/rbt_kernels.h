@@ -29,8 +29,11 @@ void timer_end(int id);
 double timer_ms(int id);                  // valid after dev_sync()
 
 // decode
-void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices);
-void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb);
+// save == nullptr: every slice is parsed to its end; else resumable (one RbtParseSave of parse_save_bytes() per slice of the
+// batch, zero-initialised): each launch advances every unfinished slice up to CTB row row_limit
+void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices, void* save = nullptr, int row_limit = 0);
+size_t parse_save_bytes();
+void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int y_begin = 0, int y_end = 1 << 30);
 void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_units);
 void launch_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_luma_samples);
 

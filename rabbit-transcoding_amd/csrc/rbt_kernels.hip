@@ -95,16 +95,16 @@ double timer_ms(int id) { float ms = 0; if (hipEventElapsedTime(&ms, g_ev[g_cur]
 
 // ---------------------------------------------------------------------------------------------- decode kernels
 // one wave per slice segment: wave-uniform CABAC parse (rbt_parse.h)
-__global__ void __launch_bounds__(64) k_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list) {
+__global__ void __launch_bounds__(64) k_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, RbtParseSave* save, int row_limit) {
   __shared__ RbtParseLds lds;
-  rbt_parse_slice(frames, slices, slice_list[blockIdx.x], rbsp, RBT_LDS_CAST(RbtParseLds, &lds));
+  rbt_parse_slice(frames, slices, slice_list[blockIdx.x], rbsp, RBT_LDS_CAST(RbtParseLds, &lds), save, row_limit);
 }
 // one wave per CTB on anti-diagonal d (x + 2y == d): left, above-left, above and above-right CTBs are complete
-__global__ void __launch_bounds__(64) k_recon_diag(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int d) {
+__global__ void __launch_bounds__(64) k_recon_diag(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int d, int y_first) {
   __shared__ RbtReconCtbLds lds;
   int fi = frame_list[blockIdx.y];
   const RbtStreamCfg* g = &frames[fi].cfg;
-  int y = blockIdx.x, x = d - 2 * y;
+  int y = y_first + blockIdx.x, x = d - 2 * y;
   if (y >= g->h_ctb || x < 0 || x >= g->w_ctb) return;
   int addr = y * g->w_ctb + x;
   if (frames[fi].ctb_slice[addr] == 0xFFFF) return;     // CTB not covered by any decoded slice
@@ -124,16 +124,21 @@ __global__ void __launch_bounds__(256) k_sao(RbtFrame* frames, const RbtSlice* s
   rbt_sao_sample(f, slices, c, i % pw, i / pw);
 }
 
-void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices) {
+void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices, void* save, int row_limit) {
   if (n_slices <= 0) return;
-  hipLaunchKernelGGL(k_parse, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, rbsp, slice_list);
+  hipLaunchKernelGGL(k_parse, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, rbsp, slice_list, (RbtParseSave*)save, row_limit);
 }
-void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb) {
+size_t parse_save_bytes() { return sizeof(RbtParseSave); }
+// CTB rows [y_begin, y_end): the rows above y_begin are complete, the anti-diagonals that touch the range run in order
+void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int y_begin, int y_end) {
   if (n_frames <= 0) return;
-  int n_diag = max_w_ctb + 2 * (max_h_ctb - 1);
-  for (int d = 0; d < n_diag; d++) {
-    int rows = d / 2 + 1; if (rows > max_h_ctb) rows = max_h_ctb;
-    hipLaunchKernelGGL(k_recon_diag, dim3(rows, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list, d);
+  if (y_end > max_h_ctb) y_end = max_h_ctb;
+  if (y_begin >= y_end) return;
+  for (int d = 2 * y_begin; d <= max_w_ctb - 1 + 2 * (y_end - 1); d++) {
+    int y_hi = d / 2; if (y_hi > y_end - 1) y_hi = y_end - 1;              // x = d - 2y >= 0
+    int y_lo = (d - (max_w_ctb - 1) + 1) / 2; if (y_lo < y_begin) y_lo = y_begin;   // x <= w - 1
+    if (y_lo > y_hi) continue;
+    hipLaunchKernelGGL(k_recon_diag, dim3(y_hi - y_lo + 1, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list, d, y_lo);
   }
 }
 void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_units) {

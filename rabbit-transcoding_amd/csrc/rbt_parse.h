@@ -906,13 +906,26 @@ RBT_DEV void pz_coding_quadtree(RbtParse* s, int x0, int y0, int log2) {
   }
 }
 
-// Entry: parses one slice segment.
-RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, const uint8_t* rbsp, RBT_LDS_AS RbtParseLds* lds) {
+// HBM image of a suspended slice parser. The parser can stop in front of any CTB row (`row_limit`) and continue in a later
+// launch: the reconstruction of the rows that are complete then runs underneath the parsing of the rest of the picture.
+struct RbtParseSave {
+  uint32_t phase;                 // 0 not started, 1 suspended, 2 finished
+  int32_t sc[24];                 // scalar parser / engine state
+  uint32_t buf_lo, buf_hi;
+  uint32_t ctx[4][64];            // context variables (one word per lane and register)
+  uint32_t lds[(sizeof(RbtParseLds) + 3) / 4];
+};
+// Entry: parses one slice segment (save == nullptr: in one go; else up to CTB row `row_limit`, resuming where it stopped).
+RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, const uint8_t* rbsp, RBT_LDS_AS RbtParseLds* lds, RbtParseSave* save, int row_limit) {
   RbtParse s;
-  s.L = lds; s.left_ok = 0; s.corner_ok = 0; s.corner_pm = s.corner_dm = s.corner_ref = s.corner_mv = 0; s.ctb_x = s.ctb_y = 0;
-  RBT_PAR_FOR(i, 512) lds->above_slice[i] = 0xFFFF;
-  RBT_SYNC_LDS();
+  RbtParseSave* sv = save ? save + slice_idx : nullptr;
+  const int phase = sv ? RBT_UNI((int)sv->phase) : 0;
+  if (phase == 2) return;
   const RbtSlice* gs = &slices[slice_idx];
+  s.L = lds; s.left_ok = 0; s.corner_ok = 0; s.corner_pm = s.corner_dm = s.corner_ref = s.corner_mv = 0; s.ctb_x = s.ctb_y = 0;
+  if (phase == 0) { RBT_PAR_FOR(i, 512) lds->above_slice[i] = 0xFFFF; }
+  else { RBT_LDS_AS uint32_t* lw = (RBT_LDS_AS uint32_t*)lds; RBT_PAR_FOR(i, (int)(sizeof(RbtParseLds) / 4)) lw[i] = sv->lds[i]; }
+  RBT_SYNC();
   s.frames = frames; s.f = &frames[RBT_UNI(gs->frame)]; s.slice_idx = slice_idx; s.error = 0;
   s.s_bits = (uint32_t)RBT_UNI((gs->slice_type & 3) | ((gs->sao_luma & 1) << 2) | ((gs->sao_chroma & 1) << 3) | ((gs->temporal_mvp & 1) << 4) | ((gs->cabac_init_flag & 1) << 5) |
                                ((gs->max_merge_cand & 7) << 6) | ((gs->num_ref_idx & 31) << 9) | ((gs->collocated_ref_idx & 15) << 14));
@@ -936,16 +949,55 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
   RBT_PAR_FOR(i, 32) { lds->prof[i] = 0; lds->profn[i] = 0; }
   s.t_last = __builtin_readcyclecounter();
 #endif
-  rbt_ctx_init(&s.c.cs, init_type, pzs_qp(&s));
-  rbt_cd_start(&s.c, rbsp + (uint32_t)RBT_UNI(gs->data_off), (uint32_t)RBT_UNI(gs->data_size));
-  s.qp_y = pzs_qp(&s); s.qp_pred = pzs_qp(&s); s.qp_y_prev = pzs_qp(&s); s.is_cu_qp_delta_coded = 0; s.cu_qp_delta_val = 0;
-  s.last_pu_merge = 0; s.max_trafo_depth = 0; s.intra_chroma = 1; s.il_packed = 0x01010101;
   int n_ctb = pzc_w_ctb(&s) * pzc_h_ctb(&s), end = 0, addr = RBT_UNI(gs->ctb_addr);
   uint32_t count = 0;
+  rbt_cd_start(&s.c, rbsp + (uint32_t)RBT_UNI(gs->data_off), (uint32_t)RBT_UNI(gs->data_size));
+  if (phase == 0) {
+    rbt_ctx_init(&s.c.cs, init_type, pzs_qp(&s));
+    s.qp_y = pzs_qp(&s); s.qp_pred = pzs_qp(&s); s.qp_y_prev = pzs_qp(&s); s.is_cu_qp_delta_coded = 0; s.cu_qp_delta_val = 0;
+    s.last_pu_merge = 0; s.max_trafo_depth = 0; s.intra_chroma = 1; s.il_packed = 0x01010101;
+  } else {
+    // resume: scalar state, bit reservoir (the word cursor is re-based on the same aligned pointer), context registers
+    const int32_t* q = sv->sc;
+    s.left_ok = RBT_UNI(q[0]); s.corner_ok = RBT_UNI(q[1]); s.corner_pm = RBT_UNI(q[2]); s.corner_dm = RBT_UNI(q[3]); s.corner_ref = RBT_UNI(q[4]); s.corner_mv = RBT_UNI(q[5]);
+    s.qp_y = RBT_UNI(q[6]); s.qp_pred = RBT_UNI(q[7]); s.qp_y_prev = RBT_UNI(q[8]); s.is_cu_qp_delta_coded = RBT_UNI(q[9]); s.cu_qp_delta_val = RBT_UNI(q[10]);
+    s.il_packed = RBT_UNI(q[11]); s.intra_chroma = RBT_UNI(q[12]); s.max_trafo_depth = RBT_UNI(q[13]); s.last_pu_merge = RBT_UNI(q[14]);
+    addr = RBT_UNI(q[15]); count = (uint32_t)RBT_UNI(q[16]);
+    s.c.widx = (uint32_t)RBT_UNI(q[17]); s.c.nbuf = RBT_UNI(q[18]); s.c.range = (uint32_t)RBT_UNI(q[19]); s.c.value = (uint32_t)RBT_UNI(q[20]); s.c.avail = RBT_UNI(q[21]);
+    s.c.buf = ((uint64_t)(uint32_t)RBT_UNI(sv->buf_hi) << 32) | (uint32_t)RBT_UNI(sv->buf_lo);
+    s.c.next_raw = s.c.widx < s.c.n_words ? s.c.w[s.c.widx] : 0;
+#ifdef RBT_HOSTEMU
+    for (int i = 0; i < RBT_CTX_COUNT; i++) s.c.cs.st[i] = (uint8_t)sv->ctx[i >> 6][i & 63];
+#else
+    { const int ln = (int)threadIdx.x & 63; s.c.cs.st0 = (int)sv->ctx[0][ln]; s.c.cs.st1 = (int)sv->ctx[1][ln]; s.c.cs.st2 = (int)sv->ctx[2][ln]; s.c.cs.st3 = (int)sv->ctx[3][ln]; }
+    rbt_ctx_tables(&s.c.cs);
+#endif
+  }
   while (!end) {
     if (addr >= n_ctb) { s.error = 1; break; }
     addr = RBT_UNI(addr);
     int rx = RBT_UNI(addr % pzc_w_ctb(&s)), ry = RBT_UNI(addr / pzc_w_ctb(&s));
+    if (sv && ry >= row_limit) {
+      // suspend in front of this CTB
+      RBT_SYNC_LDS();
+      { RBT_LDS_AS uint32_t* lw = (RBT_LDS_AS uint32_t*)lds; RBT_PAR_FOR(i, (int)(sizeof(RbtParseLds) / 4)) sv->lds[i] = lw[i]; }
+#ifdef RBT_HOSTEMU
+      for (int i = 0; i < RBT_CTX_COUNT; i++) sv->ctx[i >> 6][i & 63] = s.c.cs.st[i];
+#else
+      { const int ln = (int)threadIdx.x & 63; sv->ctx[0][ln] = (uint32_t)s.c.cs.st0; sv->ctx[1][ln] = (uint32_t)s.c.cs.st1; sv->ctx[2][ln] = (uint32_t)s.c.cs.st2; sv->ctx[3][ln] = (uint32_t)s.c.cs.st3; }
+#endif
+      if (RBT_LANE0) {
+        int32_t* q = sv->sc;
+        q[0] = s.left_ok; q[1] = s.corner_ok; q[2] = s.corner_pm; q[3] = s.corner_dm; q[4] = s.corner_ref; q[5] = s.corner_mv;
+        q[6] = s.qp_y; q[7] = s.qp_pred; q[8] = s.qp_y_prev; q[9] = s.is_cu_qp_delta_coded; q[10] = s.cu_qp_delta_val;
+        q[11] = s.il_packed; q[12] = s.intra_chroma; q[13] = s.max_trafo_depth; q[14] = s.last_pu_merge;
+        q[15] = addr; q[16] = (int32_t)count;
+        q[17] = (int32_t)s.c.widx; q[18] = s.c.nbuf; q[19] = (int32_t)s.c.range; q[20] = (int32_t)s.c.value; q[21] = s.c.avail;
+        sv->buf_lo = (uint32_t)s.c.buf; sv->buf_hi = (uint32_t)(s.c.buf >> 32);
+        sv->phase = 1;
+      }
+      return;
+    }
     if (RBT_LANE0) s.f->ctb_slice[addr] = (uint16_t)slice_idx;
     s.ctb_addr = addr; s.n_cmds = 0;
     if (rx == 0) { s.left_ok = 0; s.corner_ok = 0; }
@@ -977,5 +1029,5 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
   if (RBT_LANE0) for (int i = 22; i < 26; i++) printf("stamp %d: %llu cycles, %u hits\n", i, lds->prof[i], lds->profn[i]);
   if (RBT_LANE0) printf("slice %d: total %llu cyc, residual %llu (%u TBs) [setup+last %llu, csbf+sig %llu, gt1/2 %llu, levels %llu], TU total (incl. residual) %llu, CU header %llu (%u CUs), ctb begin/end %llu, CU total %llu, fills %llu, mpm %llu, bins ctx %u bypass %u, bits %u\n", slice_idx, __builtin_readcyclecounter() - t_all_, s.t_res, s.n_res, s.t_a, s.t_b, s.t_c, s.t_d, s.t_tu, s.t_hdr, s.n_cu, s.t_ctb, s.t_cu, s.t_fill, s.t_mpm, s.c.n_bins, s.c.n_byp, s.c.widx * 32u - (uint32_t)s.c.nbuf);
 #endif
-  if (RBT_LANE0) { slices[slice_idx].n_ctbs_decoded = count; if (s.error) s.f->error = s.error; }
+  if (RBT_LANE0) { slices[slice_idx].n_ctbs_decoded = count; if (s.error) s.f->error = s.error; if (sv) sv->phase = 2; }
 }

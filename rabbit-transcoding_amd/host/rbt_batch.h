@@ -30,6 +30,8 @@ struct DecodeBatch {
   bool ordered_parse = false;
   std::vector<int32_t> lists_keep;     // host staging of the index lists, alive until the copy has completed
   std::vector<size_t> fr_off;          // offset of each level's frame list inside d_lists
+  void* d_save = nullptr;              // RbtParseSave per slice (resumable parsing), zero-initialised; nullptr when not requested
+  bool want_save = false;              // set before decode_build to reserve d_save
   void* arena = nullptr; size_t arena_size = 0;
   RbtFrame* d_frames = nullptr; RbtSlice* d_slices = nullptr; uint8_t* d_rbsp = nullptr; int32_t* d_lists = nullptr;
   std::string err; int err_code = 0;
@@ -39,6 +41,10 @@ struct DecodeBatch {
 int decode_build(DecodeBatch& b, const StreamIn* streams, int n);
 int decode_launch(DecodeBatch& b);   // enqueue every decode kernel of the batch on the current stream (no wait)
 int decode_launch_parse(DecodeBatch& b);            // index lists + entropy decoding
+int decode_upload_lists(DecodeBatch& b);            // index lists only (first half of decode_launch_parse)
+// Entropy decoding in `chunks` row bands with the reconstruction of each finished band of the level-0 pictures enqueued on
+// stream `aux` underneath the parsing of the next band; ends with level 0 complete (filters included) on the current stream.
+int decode_launch_chunked(DecodeBatch& b, int chunks, int main_stream, int aux_stream);
 void decode_launch_level(DecodeBatch& b, size_t l);  // reconstruction + loop filters of dependency level l
 int decode_finish(DecodeBatch& b);   // wait for the batch's stream and check the per-picture error words
 int decode_run(DecodeBatch& b);      // launch + finish

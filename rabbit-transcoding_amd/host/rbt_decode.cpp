@@ -100,6 +100,7 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
   std::vector<size_t> o_coef(nf), o_edges(nf), o_cnt(nf), o_pm(nf), o_cs(nf), o_pix(nf), o_out(nf), o_dm(nf), o_qp(nf), o_mv(nf), o_ref(nf), o_refpoc(nf), o_sao(nf), o_cmds(nf);
   for (size_t i = 0; i < nf; i++) { const RbtStreamCfg& c = b.frames[i].cfg; size_t u = (size_t)c.w4 * c.h4, nc = (size_t)c.w_ctb * c.h_ctb;
     o_coef[i] = a.reserve(frame_samples(c) * 2); o_edges[i] = a.reserve(u); o_cnt[i] = a.reserve(nc * 4); }
+  size_t o_save = b.want_save ? a.reserve(b.slices.size() * rbtk::parse_save_bytes()) : 0;
   size_t zero_end = a.reserve(0);
   for (size_t i = 0; i < nf; i++) { const RbtStreamCfg& c = b.frames[i].cfg; o_pm[i] = a.reserve((size_t)c.w4 * c.h4); }
   size_t pm_begin = o_pm[0], pm_end = a.reserve(0);
@@ -127,6 +128,7 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
     f.ref = (int8_t*)(base + o_ref[i]); f.refpoc = (int32_t*)(base + o_refpoc[i]); f.sao = (RbtSao*)(base + o_sao[i]); f.ctb_slice = (uint16_t*)(base + o_cs[i]);
     f.cmds = (RbtCmd*)(base + o_cmds[i]); f.cmd_count = (uint32_t*)(base + o_cnt[i]);
   }
+  b.d_save = b.want_save ? (void*)(base + o_save) : nullptr;
   b.d_frames = (RbtFrame*)(base + o_frames); b.d_slices = (RbtSlice*)(base + o_slices); b.d_rbsp = base + o_rbsp; b.d_lists = (int32_t*)(base + o_lists);
   if (rbtk::dev_memset(base, 0, zero_end) || rbtk::dev_memset(base + pm_begin, RBT_MODE_NONE, pm_end - pm_begin) || rbtk::dev_memset(base + cs_begin, 0xFF, cs_end - cs_begin) ||
       rbtk::h2d(b.d_frames, b.frames.data(), nf * sizeof(RbtFrame)) || rbtk::h2d(b.d_slices, b.slices.data(), b.slices.size() * sizeof(RbtSlice)) ||
@@ -144,29 +146,36 @@ int decode_launch(DecodeBatch& b) {
   rbtk::timer_end(T_RECON);
   return 0;
 }
-int decode_launch_parse(DecodeBatch& b) {
-  size_t nf = b.frames.size(), ns = b.slices.size();
+static void build_lists(DecodeBatch& b, std::vector<size_t>& sl_off, std::vector<size_t>& sl_cnt) {
   // index lists: slices grouped by level, frames grouped by level
-  std::vector<int32_t>& lists = b.lists_keep; lists.clear(); std::vector<size_t> sl_off, sl_cnt; b.fr_off.clear();
+  std::vector<int32_t>& lists = b.lists_keep; lists.clear(); b.fr_off.clear();
   for (auto& lf : b.level_frames) {
     sl_off.push_back(lists.size());
     for (int fi : lf) for (int k = 0; k < b.frames[fi].n_slices; k++) lists.push_back(b.frames[fi].first_slice + k);
     sl_cnt.push_back(lists.size() - sl_off.back());
   }
   for (auto& lf : b.level_frames) { b.fr_off.push_back(lists.size()); for (int fi : lf) lists.push_back(fi); }
-  if (lists.size() > (nf + ns) * 2) { b.err = "internal: list overflow"; return b.err_code = RBT_ERR_PARAM; }
-  if (rbtk::h2d(b.d_lists, lists.data(), lists.size() * sizeof(int32_t))) { b.err = "device transfer failed"; return b.err_code = RBT_ERR_NO_DEVICE; }
+}
+int decode_upload_lists(DecodeBatch& b) {
+  std::vector<size_t> sl_off, sl_cnt; build_lists(b, sl_off, sl_cnt);
+  if (b.lists_keep.size() > (b.frames.size() + b.slices.size()) * 2) { b.err = "internal: list overflow"; return b.err_code = RBT_ERR_PARAM; }
+  if (rbtk::h2d(b.d_lists, b.lists_keep.data(), b.lists_keep.size() * sizeof(int32_t))) { b.err = "device transfer failed"; return b.err_code = RBT_ERR_NO_DEVICE; }
+  return 0;
+}
+int decode_launch_parse(DecodeBatch& b) {
+  std::vector<size_t> sl_off, sl_cnt; build_lists(b, sl_off, sl_cnt);
+  if (b.lists_keep.size() > (b.frames.size() + b.slices.size()) * 2) { b.err = "internal: list overflow"; return b.err_code = RBT_ERR_PARAM; }
+  if (rbtk::h2d(b.d_lists, b.lists_keep.data(), b.lists_keep.size() * sizeof(int32_t))) { b.err = "device transfer failed"; return b.err_code = RBT_ERR_NO_DEVICE; }
   rbtk::timer_begin(T_PARSE);
   if (b.ordered_parse) { for (size_t l = 0; l < b.level_frames.size(); l++) rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists + sl_off[l], (int)sl_cnt[l]); }
-  else rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists, (int)ns);
+  else rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists, (int)b.slices.size());
   rbtk::timer_end(T_PARSE);
   return 0;
 }
-void decode_launch_level(DecodeBatch& b, size_t l) {
+static void level_filters(DecodeBatch& b, size_t l) {
   const std::vector<int>& lf = b.level_frames[l];
-  int mw = 0, mh = 0, mu = 0, ml = 0;
-  for (int fi : lf) { const RbtStreamCfg& c = b.frames[fi].cfg; mw = std::max(mw, c.w_ctb); mh = std::max(mh, c.h_ctb); mu = std::max(mu, c.w4 * c.h4); ml = std::max(ml, c.w * c.h); }
-  rbtk::launch_recon(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l], (int)lf.size(), mw, mh);
+  int mu = 0, ml = 0;
+  for (int fi : lf) { const RbtStreamCfg& c = b.frames[fi].cfg; mu = std::max(mu, c.w4 * c.h4); ml = std::max(ml, c.w * c.h); }
   rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l], (int)lf.size(), mu);
   // SAO frames of this level are a contiguous sub-list only if all (or none) use SAO; otherwise launch per frame run
   size_t k = 0;
@@ -176,6 +185,37 @@ void decode_launch_level(DecodeBatch& b, size_t l) {
     rbtk::launch_sao(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l] + k, (int)(e - k), ml);
     k = e;
   }
+}
+int decode_launch_chunked(DecodeBatch& b, int chunks, int main_stream, int aux_stream) {
+  int rc = decode_upload_lists(b);
+  if (rc) return rc;
+  const std::vector<int>& lf = b.level_frames[0];
+  int mw = 0, mh = 0, max_h_all = 0;
+  for (int fi : lf) { const RbtStreamCfg& c = b.frames[fi].cfg; mw = std::max(mw, c.w_ctb); mh = std::max(mh, c.h_ctb); }
+  for (auto& f : b.frames) max_h_all = std::max(max_h_all, (int)f.cfg.h_ctb);
+  rbtk::timer_begin(T_PARSE);
+  int y_prev = 0;
+  for (int c = 0; c < chunks; c++) {
+    int y_lim = c + 1 == chunks ? (1 << 30) : (max_h_all * (c + 1) + chunks - 1) / chunks;
+    rbtk::set_stream(main_stream);
+    rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists, (int)b.slices.size(), b.d_save, y_lim);
+    if (c + 1 == chunks) rbtk::timer_end(T_PARSE);
+    rbtk::stream_wait(aux_stream, main_stream);
+    rbtk::set_stream(aux_stream);
+    rbtk::launch_recon(b.d_frames, b.d_slices, b.d_lists + b.fr_off[0], (int)lf.size(), mw, mh, y_prev, y_lim);
+    y_prev = y_lim;
+  }
+  rbtk::set_stream(main_stream);
+  rbtk::stream_wait(main_stream, aux_stream);
+  level_filters(b, 0);
+  return 0;
+}
+void decode_launch_level(DecodeBatch& b, size_t l) {
+  const std::vector<int>& lf = b.level_frames[l];
+  int mw = 0, mh = 0;
+  for (int fi : lf) { const RbtStreamCfg& c = b.frames[fi].cfg; mw = std::max(mw, c.w_ctb); mh = std::max(mh, c.h_ctb); }
+  rbtk::launch_recon(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l], (int)lf.size(), mw, mh);
+  level_filters(b, l);
 }
 
 int decode_finish(DecodeBatch& b) {

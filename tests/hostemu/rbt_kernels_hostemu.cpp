@@ -32,17 +32,18 @@ void timer_begin(int id) { g_t[id][0] = now_ms(); }
 void timer_end(int id) { g_t[id][1] = now_ms(); }
 double timer_ms(int id) { return g_t[id][1] - g_t[id][0]; }
 
-void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices) {
+void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices, void* save, int row_limit) {
   static RbtParseLds plds;
-  for (int i = 0; i < n_slices; i++) rbt_parse_slice(frames, slices, slice_list[i], rbsp, &plds);
+  for (int i = 0; i < n_slices; i++) rbt_parse_slice(frames, slices, slice_list[i], rbsp, &plds, (RbtParseSave*)save, row_limit);
 }
-void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb) {
+size_t parse_save_bytes() { return sizeof(RbtParseSave); }
+void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int y_begin, int y_end) {
   static RbtReconCtbLds lds;
-  int n_diag = max_w_ctb + 2 * (max_h_ctb - 1);
-  for (int d = 0; d < n_diag; d++)
+  if (y_end > max_h_ctb) y_end = max_h_ctb;
+  for (int d = 2 * y_begin; d <= max_w_ctb - 1 + 2 * (y_end - 1); d++)
     for (int k = 0; k < n_frames; k++) {
       int fi = frame_list[k]; const RbtStreamCfg* g = &frames[fi].cfg;
-      for (int y = 0; y < g->h_ctb; y++) {
+      for (int y = y_begin; y < y_end && y < g->h_ctb; y++) {
         int x = d - 2 * y; if (x < 0 || x >= g->w_ctb) continue;
         int addr = y * g->w_ctb + x;
         if (frames[fi].ctb_slice[addr] == 0xFFFF) continue;

@@ -50,3 +50,17 @@ def test_transcode_rejects_damaged_input(ctx):
     for k in r.integers(len(bad) // 2, len(bad) - 8, 200): bad[int(k)] = int(r.integers(1, 255))
     with pytest.raises(R.RbtError):
         ctx.transcode_substream(bytes(bad[: len(bad) // 2 + len(bad) // 3]), R.RBT_VIDEO_ATTRIBUTE, 32)
+
+
+def test_banded_parse_is_bit_identical(monkeypatch):
+    """RBT_PARSE_BANDS: the resumable parser (suspend in front of a CTB row, resume in a later launch) gives the same streams"""
+    import subprocess, sys, os
+    code = ("import sys; sys.path.insert(0, 'tests'); import rbt_lib, synth, oracle_lib as O\n"
+            "R = rbt_lib.module(); c = R.Context(lib_path=rbt_lib.HOSTEMU_LIB)\n"
+            "geo, attr, occ = synth.make_gof(128, 192, 2, 21)\n"
+            "sa, _ = O.encode(attr, 128, 192, 10, 22, gop=2, log2_ctb=5, rows_per_slice=0)\n"
+            "assert c.transcode_substream(sa, R.RBT_VIDEO_ATTRIBUTE, 32) == O.transcode_substream(sa, 19, 32)\n")
+    env = dict(os.environ, RBT_PARSE_BANDS="3")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
