@@ -46,6 +46,7 @@ struct RbtParse {
   int qp_y, qp_pred, qp_y_prev, is_cu_qp_delta_coded, cu_qp_delta_val;
   int ctb_addr; uint32_t n_cmds;
   int cu_x, cu_y, cu_log2, cu_pred_mode, cu_part_mode, cu_tq_bypass;
+  int qp_key, qp_packed;             // qP of Y | Cb << 8 | Cr << 16 (incl. QpBdOffset) cached for QpY == qp_key (chroma mapping costs ~300 cycles)
   int il_packed, intra_chroma, max_trafo_depth, last_pu_merge;   // no arrays / index-selected fields here: they would pin the whole struct in scratch
   int error;
   // Register-resident neighbour context (one value per lane). Current CTB, four horizontally adjacent 4x4 units per lane:
@@ -282,6 +283,14 @@ RBT_DEV void pz_end_ctb(RbtParse* s, int rx, int ry) {
 RBT_DEV void pz_emit(RbtParse* s, const RbtCmd& cmd) {
   if ((int)s->n_cmds >= s->m_cap) { s->error = 3; return; }
   if (RBT_LANE0) s->m_cmds[(size_t)s->ctb_addr * s->m_cap + s->n_cmds] = cmd;
+  s->n_cmds++;
+}
+// the same record assembled as four words (one 16-byte store): type | x4 << 8 | y4 << 16 | log2 << 24, a | b << 8 | c << 16 | d << 24,
+// mvx | mvy << 16, qp[0] | qp[1] << 8 | qp[2] << 16
+struct alignas(16) RbtCmdWords { uint32_t w[4]; };
+RBT_DEV void pz_emit_words(RbtParse* s, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+  if ((int)s->n_cmds >= s->m_cap) { s->error = 3; return; }
+  if (RBT_LANE0) { RbtCmdWords v; v.w[0] = w0; v.w[1] = w1; v.w[2] = w2; v.w[3] = w3; *(RbtCmdWords*)&s->m_cmds[(size_t)s->ctb_addr * s->m_cap + s->n_cmds] = v; }
   s->n_cmds++;
 }
 
@@ -527,8 +536,8 @@ RBT_DEV void pz_transform_unit(RbtParse* s, int x0, int y0, int xb, int yb, int 
   pz_fill_tu(s, x0, y0, N, cbf_luma);
   PZ_STAMP(s, 7);
   int chroma_here = log2 > 2 || blk == 3;
-  RbtCmd cmd; cmd.type = RBT_CMD_TU; cmd.x4 = (uint8_t)((x0 & ((1 << pzc_log2_ctb(s)) - 1)) >> 2); cmd.y4 = (uint8_t)((y0 & ((1 << pzc_log2_ctb(s)) - 1)) >> 2);
-  cmd.log2 = (uint8_t)log2; cmd.b = (uint8_t)pz_il(s, part); cmd.c = (uint8_t)s->intra_chroma; cmd.d = (uint8_t)s->cu_tq_bypass; cmd.mvx = cmd.mvy = 0; cmd.pad = 0;
+  const int ctb_mask = (1 << pzc_log2_ctb(s)) - 1;
+  const uint32_t w0 = (uint32_t)RBT_CMD_TU | ((uint32_t)((x0 & ctb_mask) >> 2) << 8) | ((uint32_t)((y0 & ctb_mask) >> 2) << 16) | ((uint32_t)log2 << 24);
   int flags = (cbf_luma ? RBT_TU_CBF_Y : 0) | (intra ? RBT_TU_INTRA : 0) | (chroma_here ? RBT_TU_CHROMA : 0);
   if (chroma_here) flags |= (cbf_cb ? RBT_TU_CBF_CB : 0) | (cbf_cr ? RBT_TU_CBF_CR : 0);
   PZ_STAMP(s, 8);
@@ -541,9 +550,11 @@ RBT_DEV void pz_transform_unit(RbtParse* s, int x0, int y0, int xb, int yb, int 
     if (cbf_cr && !s->error && pz_residual(s, 2, xc, yc, l2c, sc)) flags |= RBT_TU_TS_CR;
   }
   PZ_STAMP(s, 10);
-  cmd.a = (uint8_t)flags;
-  cmd.qp[0] = (int8_t)(s->qp_y + 6 * (pzc_bit_depth(s) - 8)); cmd.qp[1] = (int8_t)pz_chroma_qp(s, 1); cmd.qp[2] = (int8_t)pz_chroma_qp(s, 2);
-  pz_emit(s, cmd);
+  if (s->qp_key != s->qp_y) {
+    s->qp_key = s->qp_y;
+    s->qp_packed = ((s->qp_y + 6 * (pzc_bit_depth(s) - 8)) & 255) | ((pz_chroma_qp(s, 1) & 255) << 8) | ((pz_chroma_qp(s, 2) & 255) << 16);
+  }
+  pz_emit_words(s, w0, (uint32_t)(flags & 255) | ((uint32_t)(pz_il(s, part) & 255) << 8) | ((uint32_t)(s->intra_chroma & 255) << 16) | ((uint32_t)(s->cu_tq_bypass & 255) << 24), 0u, (uint32_t)s->qp_packed);
   PZ_STAMP(s, 11);
 #ifdef RBT_PROFILE
   s->t_tu += __builtin_readcyclecounter() - ttu_;
@@ -951,6 +962,7 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
 #endif
   int n_ctb = pzc_w_ctb(&s) * pzc_h_ctb(&s), end = 0, addr = RBT_UNI(gs->ctb_addr);
   uint32_t count = 0;
+  s.qp_key = 0x7FFFFFFF; s.qp_packed = 0;
   rbt_cd_start(&s.c, rbsp + (uint32_t)RBT_UNI(gs->data_off), (uint32_t)RBT_UNI(gs->data_size));
   if (phase == 0) {
     rbt_ctx_init(&s.c.cs, init_type, pzs_qp(&s));
