@@ -130,22 +130,30 @@ RBT_DEV int pz_ld_mv(const RbtParse* s, int loc) {
   uint32_t a = RBT_VGET(s->r_mv0, l), b = RBT_VGET(s->r_mv1, l), c = RBT_VGET(s->r_mv2, l), d = RBT_VGET(s->r_mv3, l);
   return (int)(j == 0 ? a : (j == 1 ? b : (j == 2 ? c : d)));
 }
-RBT_DEV int pz_loc(const RbtParse* s, int xn, int yn) {
+// raw handle of luma position (xn,yn) from the geometry alone (no availability read): -1 = outside what is tracked
+RBT_DEV int pz_loc_raw(const RbtParse* s, int xn, int yn) {
   const int dx = xn - s->ctb_x, dy = yn - s->ctb_y, ctb = 1 << pzc_log2_ctb(s);
-  int loc;
-  if (dx < -1 || dy < -1) return -1;
-  if (dy < 0) { loc = (dx + 4) >> 2; if (loc > (ctb >> 2) + 1) return -1; loc += PZ_NB_BASE; }
-  else if (dy >= ctb) return -1;
-  else if (dx < 0) loc = PZ_NB_BASE + 32 + (dy >> 2);
-  else if (dx >= ctb) return -1;
-  else loc = (dy >> 2) * 16 + (dx >> 2);
+  if (dx < -1 || dy < -1 || dy >= ctb) return -1;
+  if (dy < 0) { const int i = (dx + 4) >> 2; return i > (ctb >> 2) + 1 ? -1 : PZ_NB_BASE + i; }
+  if (dx < 0) return PZ_NB_BASE + 32 + (dy >> 2);
+  if (dx >= ctb) return -1;
+  return (dy >> 2) * 16 + (dx >> 2);
+}
+RBT_DEV int pz_loc(const RbtParse* s, int xn, int yn) {
+  const int loc = pz_loc_raw(s, xn, yn);
+  if (loc < 0) return -1;
   return (pz_ld_pm(s, loc) & RBT_PM_MODE_MASK) == RBT_MODE_NONE ? -1 : loc;
 }
 RBT_DEV int pz_avail(const RbtParse* s, int xn, int yn) { return pz_loc(s, xn, yn) >= 0; }
 RBT_DEV int pz_mode(const RbtParse* s, int x, int y) { return pz_ld_pm(s, pz_loc(s, x, y)) & RBT_PM_MODE_MASK; }   // caller checked pz_avail
 RBT_DEV int pz_dm(const RbtParse* s, int x, int y) { return pz_ld_dm(s, pz_loc(s, x, y)); }
 // neighbour summary in one lookup: -1 = unavailable, else pm | dm << 8
-RBT_DEV int pz_nb(const RbtParse* s, int x, int y) { int loc = pz_loc(s, x, y); return loc < 0 ? -1 : (pz_ld_pm(s, loc) | (pz_ld_dm(s, loc) << 8)); }
+RBT_DEV int pz_nb(const RbtParse* s, int x, int y) {
+  const int loc = pz_loc_raw(s, x, y);
+  if (loc < 0) return -1;
+  const int pm = pz_ld_pm(s, loc), dm = pz_ld_dm(s, loc);            // both lane reads issued together: one VALU->SALU hand-over
+  return (pm & RBT_PM_MODE_MASK) == RBT_MODE_NONE ? -1 : (pm | (dm << 8));
+}
 RBT_DEV int pz_cur(const RbtParse* s, int x, int y) { return ((y - s->ctb_y) >> 2) * 16 + ((x - s->ctb_x) >> 2); }
 // ---- lane-parallel block updates: byte mask of the units of lane p that lie inside a block (unit coordinates in the CTB)
 RBT_DEV uint32_t pz_sq_mask(int p, int bx, int by, int n4) {            // aligned square, n4 = 1, 2, 4, 8 or 16 units
