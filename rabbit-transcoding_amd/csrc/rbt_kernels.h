@@ -15,7 +15,9 @@ int dev_init(int device);                 // 0 = ok
 // one per sub-bitstream pipeline, and the last one doubles as the auxiliary stream of the longest pipeline when free.
 enum { RBT_N_STREAMS = 4, RBT_AUX_STREAM = 3 };
 void set_stream(int i);
-void stream_wait(int waiter, int signaller);   // work enqueued on `waiter` from now on starts after everything enqueued on `signaller` so far
+void stream_wait(int waiter, int signaller);
+int stream_mark(int signaller);                // remembers the point reached on `signaller`; stream_wait_mark makes later work of `waiter` start after it
+void stream_wait_mark(int waiter, int mark);   // work enqueued on `waiter` from now on starts after everything enqueued on `signaller` so far
 const char* dev_name();
 void* dev_alloc(size_t n);                // nullptr on failure
 void dev_free(void* p);                   // returns the block to a recycling pool

@@ -36,6 +36,12 @@ int dev_init(int device) {
 }
 const char* dev_name() { return g_name; }
 void set_stream(int i) { g_cur = ((i % RBT_N_STREAMS) + RBT_N_STREAMS) % RBT_N_STREAMS; }
+int stream_mark(int signaller) {
+  int id = g_dep_next; g_dep_next = (g_dep_next + 1) % 64;
+  (void)hipEventRecord(g_dep_ev[id], g_streams[((signaller % RBT_N_STREAMS) + RBT_N_STREAMS) % RBT_N_STREAMS]);
+  return id;
+}
+void stream_wait_mark(int waiter, int mark) { (void)hipStreamWaitEvent(g_streams[((waiter % RBT_N_STREAMS) + RBT_N_STREAMS) % RBT_N_STREAMS], g_dep_ev[mark & 63], 0); }
 void stream_wait(int waiter, int signaller) {
   hipEvent_t e = g_dep_ev[g_dep_next]; g_dep_next = (g_dep_next + 1) % 64;
   (void)hipEventRecord(e, g_streams[((signaller % RBT_N_STREAMS) + RBT_N_STREAMS) % RBT_N_STREAMS]);

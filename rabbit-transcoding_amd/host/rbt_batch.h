@@ -14,7 +14,7 @@ namespace rbt {
 struct StreamIn { const uint8_t* p; size_t n; };
 struct FrameInfo { int stream; int nal_type; bool has_md5; uint8_t md5[3][16]; bool sao; };
 
-enum { T_PARSE = 0, T_RECON = 1, T_FILTER = 2, T_ANALYSE = 3, T_ENCODE = 4, T_ENTROPY = 5, T_ALL = 6, T_POOL = 7, T_INTER = 8, T_COUNT = 9 };
+enum { T_PARSE = 0, T_RECON = 1, T_FILTER = 2, T_ANALYSE = 3, T_ENCODE = 4, T_ENTROPY = 5, T_ALL = 6, T_POOL = 7, T_INTER = 8, T_ENTROPY_I = 9, T_COUNT = 10 };
 
 struct Arena {           // bump allocator over one device allocation
   uint8_t* base = nullptr; size_t size = 0, used = 0;

@@ -26,7 +26,7 @@ struct EncodeBatch {
   size_t out_total = 0;
   std::vector<std::vector<uint16_t>> cs_keep;   // host staging of the ctb->slice maps, alive until the copies have completed
   int main_stream = 0, aux_stream = -1;          // aux_stream >= 0: the intra part was enqueued there (its timers live there)
-  std::vector<int32_t> lists_keep; size_t off_i = 0, off_ideb = 0, off_p = 0, off_sl = 0; int n_i = 0, n_ideb = 0, n_p = 0;   // index lists (encode_upload_lists)
+  std::vector<int32_t> lists_keep; size_t off_i = 0, off_ideb = 0, off_p = 0, off_sl = 0, off_sl_p = 0; int n_i = 0, n_ideb = 0, n_p = 0, n_sl_i = 0, n_sl_p = 0;   // index lists (encode_upload_lists)
   std::string err;
   ~EncodeBatch() { rbtk::dev_free(arena); }
 };
@@ -127,7 +127,10 @@ static int encode_upload_lists(EncodeBatch& b) {
   b.off_i = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i]) { lists.push_back((int)i); b.n_i++; }
   b.off_ideb = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i] && !b.frames[i].lossless) { lists.push_back((int)i); b.n_ideb++; }
   b.off_p = lists.size(); for (size_t i = 0; i < nf; i++) if (!b.frame_is_idr[i]) { lists.push_back((int)i); b.n_p++; }
-  b.off_sl = lists.size(); for (size_t i = 0; i < ns; i++) lists.push_back((int)i);
+  // slice segments of the intra pictures first, then the rest: the two groups are entropy-coded by separate launches
+  b.n_sl_i = b.n_sl_p = 0;
+  b.off_sl = lists.size(); for (size_t i = 0; i < ns; i++) if (b.frame_is_idr[b.slices[i].frame]) { lists.push_back((int)i); b.n_sl_i++; }
+  b.off_sl_p = lists.size(); for (size_t i = 0; i < ns; i++) if (!b.frame_is_idr[b.slices[i].frame]) { lists.push_back((int)i); b.n_sl_p++; }
   if (rbtk::h2d(b.d_lists, lists.data(), lists.size() * sizeof(int32_t))) { b.err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
   return 0;
 }
@@ -147,9 +150,15 @@ static void encode_launch_intra(EncodeBatch& b) {
   rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_ideb, b.n_ideb, mu);
   rbtk::timer_end(T_ENCODE);
 }
+// entropy coding of the intra pictures' slices: needs nothing but their levels and CU data
+static void encode_launch_entropy_intra(EncodeBatch& b) {
+  rbtk::timer_begin(T_ENTROPY_I);
+  rbtk::launch_entropy(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_sl, b.n_sl_i);
+  rbtk::timer_end(T_ENTROPY_I);
+}
 // inter pictures (need the reconstructed intra pictures and their own sources), then the entropy coder for every slice
 static void encode_launch_rest(EncodeBatch& b) {
-  size_t nf = b.frames.size(), ns = b.slices.size();
+  size_t nf = b.frames.size();
   int mu = 0, mc = 0;
   for (size_t i = 0; i < nf; i++) { const RbtStreamCfg& c = b.frames[i].cfg; mu = std::max(mu, c.w4 * c.h4); mc = std::max(mc, c.w_ctb * c.h_ctb); }
   rbtk::timer_begin(T_INTER);
@@ -157,10 +166,10 @@ static void encode_launch_rest(EncodeBatch& b) {
   rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_p, b.n_p, mu);
   rbtk::timer_end(T_INTER);
   rbtk::timer_begin(T_ENTROPY);
-  rbtk::launch_entropy(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_sl, (int)ns);
+  rbtk::launch_entropy(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_sl_p, b.n_sl_p);
   rbtk::timer_end(T_ENTROPY);
 }
-static int encode_launch(EncodeBatch& b) { encode_launch_intra(b); encode_launch_rest(b); return 0; }
+static int encode_launch(EncodeBatch& b) { encode_launch_intra(b); encode_launch_entropy_intra(b); encode_launch_rest(b); return 0; }
 static int encode_finish(EncodeBatch& b, std::vector<std::vector<uint8_t>>& outs, rbt_stats& st) {
   size_t nf = b.frames.size(), ns = b.slices.size();
   if (rbtk::d2h(b.slices.data(), b.d_slices, ns * sizeof(RbtSlice))) { b.err = "kernel execution failed"; return RBT_ERR_NO_DEVICE; }
@@ -204,7 +213,7 @@ static int encode_finish(EncodeBatch& b, std::vector<std::vector<uint8_t>>& outs
   }
   st.host_pack_ms += now_ms() - t1;
   { int cur = b.main_stream; if (b.aux_stream >= 0) rbtk::set_stream(b.aux_stream);
-    st.k_analyse_ms += rbtk::timer_ms(T_ANALYSE); st.k_encode_ms += rbtk::timer_ms(T_ENCODE);
+    st.k_analyse_ms += rbtk::timer_ms(T_ANALYSE); st.k_encode_ms += rbtk::timer_ms(T_ENCODE); st.k_entropy_ms += rbtk::timer_ms(T_ENTROPY_I);
     if (b.aux_stream >= 0) rbtk::set_stream(cur);
     st.k_encode_ms += rbtk::timer_ms(T_INTER); st.k_entropy_ms += rbtk::timer_ms(T_ENTROPY); }
   return 0;
@@ -306,6 +315,7 @@ int transcode_gof(rbt_stats& st, std::string& err, int n, const uint8_t* const* 
     EncodeBatch& e = eb[i]; e.main_stream = i;
     size_t n_levels = db[i].level_frames.size(), fork_level = 0;
     for (size_t q = 0; q < e.frames.size(); q++) if (e.frame_is_idr[q]) fork_level = std::max(fork_level, (size_t)db[i].frames[db[i].stream_first[0] + (int)q].level);
+    int intra_done = 0;
     const bool fork = k == 0 && n <= rbtk::RBT_AUX_STREAM && jobs.empty() && fork_level + 1 < n_levels;   // longest pipeline only: one spare stream
     const bool banded = db[i].d_save != nullptr && !db[i].ordered_parse;
     rc = banded ? decode_launch_chunked(db[i], parse_bands(), i, rbtk::RBT_AUX_STREAM) : decode_launch_parse(db[i]);
@@ -316,13 +326,14 @@ int transcode_gof(rbt_stats& st, std::string& err, int n, const uint8_t* const* 
       if (fork && l == fork_level) {
         e.aux_stream = rbtk::RBT_AUX_STREAM;
         rbtk::stream_wait(e.aux_stream, i);
-        rbtk::set_stream(e.aux_stream); encode_launch_intra(e); rbtk::set_stream(i);
+        rbtk::set_stream(e.aux_stream); encode_launch_intra(e); intra_done = rbtk::stream_mark(e.aux_stream); encode_launch_entropy_intra(e); rbtk::set_stream(i);
       }
     }
     rbtk::timer_end(T_RECON);
     if (!jobs.empty()) { rbtk::timer_begin(T_POOL); for (const PoolJob& j : jobs) rbtk::launch_pool(j.in, j.w, j.h, 2, j.y, j.cb, j.cr, j.grey); rbtk::timer_end(T_POOL); }
-    if (fork) rbtk::stream_wait(i, e.aux_stream); else encode_launch_intra(e);
+    if (fork) rbtk::stream_wait_mark(i, intra_done); else { encode_launch_intra(e); encode_launch_entropy_intra(e); }
     encode_launch_rest(e);
+    if (fork) rbtk::stream_wait(i, e.aux_stream);      // the intra pictures' entropy coding on the auxiliary stream
   }
   // ---- phase B, shortest stream first: one sync per stream, then slice sizes -> pack -> NAL assembly ----
   std::vector<std::vector<uint8_t>> outs(n);

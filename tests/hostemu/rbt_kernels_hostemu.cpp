@@ -20,6 +20,8 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 int dev_init(int) { return 0; }
 void set_stream(int) {}
 void stream_wait(int, int) {}
+int stream_mark(int) { return 0; }
+void stream_wait_mark(int, int) {}
 const char* dev_name() { return "host emulation (test only)"; }
 void* dev_alloc(size_t n) { return malloc(n ? n : 1); }
 void dev_free(void* p) { free(p); }
