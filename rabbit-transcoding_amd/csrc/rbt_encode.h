@@ -125,9 +125,9 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
           for (int k = 0; k < 11; k++) {
             int mode = k_intra_cand[k];
             RBT_LDS_AS int32_t* fin = rc_intra_filter_needed(0, lg, mode) ? rl->nbf : rl->nb;
-            RcIntraCtx qc; rc_intra_setup(g, 0, lg, mode, fin, rl, &qc);
+            RcIntraCtx qc; rc_intra_setup(g, 0, lg, mode, fin, rl->ref, &qc);
             int part = 0;
-            RBT_PAR_FOR(i, S * S) { int x = i & (S - 1), y = i >> lg; part += rbt_abs((int)l->src[(by0 + y + 1) * 66 + bx0 + x + 1] - rc_intra_sample(&qc, fin, rl, x, y)); }
+            RBT_PAR_FOR(i, S * S) { int x = i & (S - 1), y = i >> lg; part += rbt_abs((int)l->src[(by0 + y + 1) * 66 + bx0 + x + 1] - rc_intra_sample(&qc, fin, rl->ref, x, y)); }
             int sad = en_wave_sum(part, l);
             if (sad < best) { best = sad; bmode = mode; }
             RBT_SYNC_LDS();                                     // rl->ref is rebuilt by the next mode
@@ -298,9 +298,9 @@ RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtE
   }
   RBT_SYNC_LDS();
   RBT_LDS_AS int32_t* fin = rc_intra_filter(g, c_idx, log2, mode, r->nb, r->nbf);
-  RcIntraCtx q; rc_intra_setup(g, c_idx, log2, mode, fin, r, &q);
+  RcIntraCtx q; rc_intra_setup(g, c_idx, log2, mode, fin, r->ref, &q);
   // prediction and residual
-  RBT_PAR_FOR(i, N * N) { const int pv = rc_intra_sample(&q, fin, r, i & (N - 1), i >> log2); r->pred[i] = (uint16_t)pv; r->res[i] = (int16_t)((int)src[i] - pv); }
+  RBT_PAR_FOR(i, N * N) { const int pv = rc_intra_sample(&q, fin, r->ref, i & (N - 1), i >> log2); r->pred[i] = (uint16_t)pv; r->res[i] = (int16_t)((int)src[i] - pv); }
   RBT_SYNC_LDS();
   int nz;
   if (f->lossless) {

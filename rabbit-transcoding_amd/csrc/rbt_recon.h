@@ -15,6 +15,7 @@ struct RbtReconLds {
   int16_t res[32 * 32];   // dequantised coefficients, then residual
   int16_t tmp[32 * 32];   // first transform stage (16-bit by construction: 8.6.4.2 clips it, the forward stage's shift keeps it below 2^15)
   uint16_t pred[32 * 32];
+  int32_t ref2[100];      // second angular reference array (Cb / Cr processed together)
   int8_t dct[32 * 32]; int8_t dst[16];   // transform matrices, staged once per workgroup (rc_stage_tables)
 };
 RBT_DEV void rc_stage_tables(RBT_LDS_AS RbtReconLds* l) {
@@ -127,7 +128,7 @@ RBT_DEV void rc_avail_masks(int tot, RBT_LDS_AS RbtReconLds* l, uint64_t* m0, ui
 // Prediction value of sample (x,y) of the TB from the final reference samples `nb` (planar / DC / angular incl. edge
 // filters). Angular modes read l->ref, DC reads `dc`; both are prepared by rc_intra_setup.
 struct RcIntraCtx { int N, log2, mode, c_idx, maxv, ang, ver, dc, edge; };
-RBT_DEV void rc_intra_setup(const RbtStreamCfg* g, int c_idx, int log2, int mode, RBT_LDS_AS int32_t* nb, RBT_LDS_AS RbtReconLds* l, RcIntraCtx* q) {
+RBT_DEV void rc_intra_setup(const RbtStreamCfg* g, int c_idx, int log2, int mode, RBT_LDS_AS int32_t* nb, RBT_LDS_AS int32_t* ref, RcIntraCtx* q) {
   const int N = 1 << log2, bd = g->bit_depth;
   q->N = N; q->log2 = log2; q->mode = mode; q->c_idx = c_idx; q->maxv = (1 << bd) - 1; q->ang = 0; q->ver = mode >= 18; q->dc = 0; q->edge = 0;
 #define RC_LEFT(y) nb[2 * N - 1 - (y)]
@@ -147,12 +148,12 @@ RBT_DEV void rc_intra_setup(const RbtStreamCfg* g, int c_idx, int log2, int mode
       if (x >= 0 && x <= N) v = ver ? RC_TOP(x - 1) : RC_LEFT(x - 1);
       else if (x < 0) { if (ang < 0 && last < -1 && x >= last) { int k = -1 + ((x * inv + 128) >> 8); v = ver ? RC_LEFT(k) : RC_TOP(k); } }
       else if (ang >= 0) v = ver ? RC_TOP(x - 1) : RC_LEFT(x - 1);
-      l->ref[x + 32] = v;
+      ref[x + 32] = v;
     }
     RBT_SYNC_LDS();
   }
 }
-RBT_DEV int rc_intra_sample(const RcIntraCtx* q, RBT_LDS_AS int32_t* nb, const RBT_LDS_AS RbtReconLds* l, int x, int y) {
+RBT_DEV int rc_intra_sample(const RcIntraCtx* q, const RBT_LDS_AS int32_t* nb, const RBT_LDS_AS int32_t* ref, int x, int y) {
   const int N = q->N, mode = q->mode;
   if (mode == 0) return ((N - 1 - x) * RC_LEFT(y) + (x + 1) * RC_TOP(N) + (N - 1 - y) * RC_TOP(x) + (y + 1) * RC_LEFT(N) + N) >> (q->log2 + 1);
   if (mode == 1) {
@@ -166,7 +167,7 @@ RBT_DEV int rc_intra_sample(const RcIntraCtx* q, RBT_LDS_AS int32_t* nb, const R
   }
   const int a = q->ver ? y : x, b = q->ver ? x : y;
   const int idx = ((a + 1) * q->ang) >> 5, fr = ((a + 1) * q->ang) & 31;
-  int v = fr ? ((32 - fr) * l->ref[32 + b + idx + 1] + fr * l->ref[32 + b + idx + 2] + 16) >> 5 : l->ref[32 + b + idx + 1];
+  int v = fr ? ((32 - fr) * ref[32 + b + idx + 1] + fr * ref[32 + b + idx + 2] + 16) >> 5 : ref[32 + b + idx + 1];
   if (q->edge) {
     if (mode == 26 && x == 0) v = rbt_clip3(0, q->maxv, RC_TOP(0) + ((RC_LEFT(y) - RC_LEFT(-1)) >> 1));
     if (mode == 10 && y == 0) v = rbt_clip3(0, q->maxv, RC_LEFT(0) + ((RC_TOP(x) - RC_TOP(-1)) >> 1));
@@ -193,8 +194,8 @@ RBT_DEV void rc_intra_finish(const RbtStreamCfg* g, int c_idx, int log2, int mod
     }
   }
   RBT_LDS_AS int32_t* fin = rc_intra_filter(g, c_idx, log2, mode, nb, alt);
-  RcIntraCtx q; rc_intra_setup(g, c_idx, log2, mode, fin, l, &q);
-  RBT_PAR_FOR(i, N * N) l->pred[i] = (uint16_t)rc_intra_sample(&q, fin, l, i & (N - 1), i >> log2);
+  RcIntraCtx q; rc_intra_setup(g, c_idx, log2, mode, fin, l->ref, &q);
+  RBT_PAR_FOR(i, N * N) l->pred[i] = (uint16_t)rc_intra_sample(&q, fin, l->ref, i & (N - 1), i >> log2);
   RBT_SYNC_LDS();
 }
 
@@ -241,6 +242,31 @@ RBT_DEV void rc_inv_transform(int log2, int is_dst, int ts, int bd, RBT_LDS_AS R
   else if (log2 == 3) rc_inv_transform_n<3>(0, sh, l);
   else if (log2 == 4) rc_inv_transform_n<4>(0, sh, l);
   else rc_inv_transform_n<5>(0, sh, l);
+}
+
+// two blocks of the same size at once (Cb and Cr of a TU): block b lives at res / tmp offset b * 256; m0 / m1 = block present
+template <int LOG2> RBT_DEV void rc_inv_transform_pair_n(int sh, int m0, int m1, RBT_LDS_AS RbtReconLds* l) {
+  constexpr int N = 1 << LOG2, NN = N * N;
+  RBT_PAR_FOR(i, 2 * NN) {
+    const int b = i >> (2 * LOG2), j = i & (NN - 1), x = j & (N - 1), y = j >> LOG2;
+    if (b ? m1 : m0) {
+      int s = 0;
+#pragma unroll
+      for (int k = 0; k < N; k++) s += rc_tcoef(l, N, 0, k, y) * l->res[b * 256 + k * N + x];
+      l->tmp[b * 256 + j] = (int16_t)rbt_clip3(-32768, 32767, (s + 64) >> 7);
+    }
+  }
+  RBT_SYNC_LDS();
+  RBT_PAR_FOR(i, 2 * NN) {
+    const int b = i >> (2 * LOG2), j = i & (NN - 1), x = j & (N - 1), y = j >> LOG2;
+    if (b ? m1 : m0) {
+      int s = 0;
+#pragma unroll
+      for (int k = 0; k < N; k++) s += rc_tcoef(l, N, 0, k, x) * l->tmp[b * 256 + y * N + k];
+      l->res[b * 256 + j] = (int16_t)((s + (1 << (sh - 1))) >> sh);
+    }
+  }
+  RBT_SYNC_LDS();
 }
 
 // ---- uni-directional motion compensation of one PU (8.5.3.3) from ref->out into f->pix ----
@@ -339,7 +365,7 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int
     }
     RBT_SYNC_LDS();
     fin = rc_intra_filter(g, c_idx, log2, mode, l->nb, l->nbf);
-    rc_intra_setup(g, c_idx, log2, mode, fin, l, &q);
+    rc_intra_setup(g, c_idx, log2, mode, fin, l->ref, &q);
   }
 #ifdef RBT_PROFILE
   p2_ = p3_ = __builtin_readcyclecounter();
@@ -347,7 +373,7 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int
   if (intra || cbf) {
     RBT_PAR_FOR(i, N * N) {
       int x = i & (N - 1), y = i >> log2, o = (y0 + y + 1) * S + x0 + x + 1;
-      int base = intra ? rc_intra_sample(&q, fin, l, x, y) : tile[o];
+      int base = intra ? rc_intra_sample(&q, fin, l->ref, x, y) : tile[o];
       tile[o] = (uint16_t)(cbf ? rbt_clip3(0, maxv, base + l->res[i]) : base);
     }
   }
@@ -356,6 +382,85 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int
 #ifdef RBT_PROFILE
   { unsigned long long p4_ = __builtin_readcyclecounter(); L->prof[0] += p1_ - p0_; L->prof[1] += p2_ - p1_; L->prof[2] += p3_ - p2_; L->prof[3] += p4_ - p3_; L->prof[4] += 1; }
 #endif
+}
+// Cb and Cr TB of one TU in the same passes. The two blocks share position, size, prediction mode and availability and
+// differ only in data, so every phase (and every wait for LDS) is paid once for both; chroma is never smoothed (8.4.4.2.3).
+RBT_DEV void rc_tile_tb_cpair(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int x0, int y0, int log2, int intra, int mode, int cbf_cb, int cbf_cr, int tq_bypass, int qp_cb, int qp_cr) {
+  RBT_LDS_AS RbtReconLds* l = &L->rc; RBT_LDS_AS RbtCtbTile* t = &L->t;
+  const int N = 1 << log2, NN = N * N, bd = g->bit_depth, maxv = (1 << bd) - 1, n = (1 << g->log2_ctb) >> 1, n4 = (1 << g->log2_ctb) >> 2, S = RC_TS_C;
+  if (cbf_cb | cbf_cr) {
+    if (tq_bypass) {
+      RBT_PAR_FOR(i, 2 * NN) { const int b = i >= NN, j = i - b * NN, x = j & (N - 1), y = j >> log2; if (b ? cbf_cr : cbf_cb) l->res[b * 256 + j] = t->coef_c[b][(y0 + y) * n + x0 + x]; }
+      RBT_SYNC_LDS();
+    } else {
+      const int bd_shift = bd + log2 - 5, sc_cb = (16 * rc_level_scale(qp_cb % 6)) << (qp_cb / 6), sc_cr = (16 * rc_level_scale(qp_cr % 6)) << (qp_cr / 6);
+      const long long add = 1ll << (bd_shift - 1);
+      RBT_PAR_FOR(i, 2 * NN) {
+        const int b = i >= NN, j = i - b * NN, x = j & (N - 1), y = j >> log2;
+        if (b ? cbf_cr : cbf_cb) {
+          long long v = ((long long)t->coef_c[b][(y0 + y) * n + x0 + x] * (b ? sc_cr : sc_cb) + add) >> bd_shift;
+          l->res[b * 256 + j] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+        }
+      }
+      RBT_SYNC_LDS();
+      const int sh = 20 - bd;
+      if (log2 == 2) rc_inv_transform_pair_n<2>(sh, cbf_cb, cbf_cr, l);
+      else if (log2 == 3) rc_inv_transform_pair_n<3>(sh, cbf_cb, cbf_cr, l);
+      else rc_inv_transform_pair_n<4>(sh, cbf_cb, cbf_cr, l);
+    }
+  }
+  RcIntraCtx q0, q1;
+  if (intra) {
+    const int tot = 4 * N + 1;                                           // <= 65: plane b keeps its references at nb[b * 66 ..]
+    uint64_t m0 = 0, m1 = 0; int m2 = 0;
+    RBT_VBALLOT(m0, p, rbt_min(tot, 64), rc_nb_av(t->uav, p, x0, y0, N, 1, n4));
+    if (tot > 64) { RBT_VBALLOT(m1, p, tot - 64, rc_nb_av(t->uav, 64 + p, x0, y0, N, 1, n4)); }
+    const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : -1);
+    RBT_PAR_FOR(i, 2 * tot) {
+      const int b = i >= tot, idx = i - b * tot;
+      int v = 1 << (bd - 1);
+      if (first >= 0) { int j = rc_last_avail(idx, m0, m1, m2); if (j < 0) j = first; int xn, yn; rc_nb_xy(j, x0, y0, N, &xn, &yn); v = t->c[b][(yn + 1) * S + xn + 1]; }
+      l->nb[b * 66 + idx] = v;
+    }
+    RBT_SYNC_LDS();
+    // mode set-up of both planes (rc_intra_setup, two at a time)
+    q0.N = N; q0.log2 = log2; q0.mode = mode; q0.c_idx = 1; q0.maxv = maxv; q0.ang = 0; q0.ver = mode >= 18; q0.dc = 0; q0.edge = 0; q1 = q0; q1.c_idx = 2;
+    if (mode == 1) {
+      int s0 = N, s1 = N;                                                // lanes 0..2N-1: plane 0 (top row then left column), 2N..4N-1: plane 1
+      for (int bit = 0; bit < bd; bit++) {
+        uint64_t m; RBT_VBALLOT(m, p, 4 * N, (l->nb[(p >= 2 * N ? 66 : 0) + ((p & (2 * N - 1)) < N ? 2 * N + 1 + (p & (2 * N - 1)) : 2 * N - 1 - ((p & (2 * N - 1)) - N))] >> bit) & 1);
+        s0 += __builtin_popcountll(m & ((1ull << (2 * N)) - 1)) << bit; s1 += __builtin_popcountll(m >> (2 * N)) << bit;
+      }
+      q0.dc = s0 >> (log2 + 1); q1.dc = s1 >> (log2 + 1);
+    } else if (mode >= 2) {
+      const int ang = rc_intra_angle(mode), ver = mode >= 18, last = (N * ang) >> 5, inv = (mode >= 11 && mode <= 25) ? rc_intra_inv_angle(mode) : 0;
+      q0.ang = q1.ang = ang;
+      RBT_PAR_FOR(i, 2 * (3 * N + 1)) {
+        const int b = i >= 3 * N + 1, x = i - b * (3 * N + 1) - N; int v = 0;
+        const RBT_LDS_AS int32_t* nb = l->nb + b * 66;
+#define RC_LEFT(y) nb[2 * N - 1 - (y)]
+#define RC_TOP(x) nb[2 * N + 1 + (x)]
+        if (x >= 0 && x <= N) v = ver ? RC_TOP(x - 1) : RC_LEFT(x - 1);
+        else if (x < 0) { if (ang < 0 && last < -1 && x >= last) { int k = -1 + ((x * inv + 128) >> 8); v = ver ? RC_LEFT(k) : RC_TOP(k); } }
+        else if (ang >= 0) v = ver ? RC_TOP(x - 1) : RC_LEFT(x - 1);
+#undef RC_LEFT
+#undef RC_TOP
+        (b ? l->ref2 : l->ref)[x + 32] = v;
+      }
+      RBT_SYNC_LDS();
+    }
+  }
+  if (intra || cbf_cb || cbf_cr) {
+    RBT_PAR_FOR(i, 2 * NN) {
+      const int b = i >= NN, j = i - b * NN, x = j & (N - 1), y = j >> log2, o = (y0 + y + 1) * S + x0 + x + 1, cbf = b ? cbf_cr : cbf_cb;
+      RBT_LDS_AS uint16_t* tile = t->c[b];
+      if (intra || cbf) {
+        const int base = intra ? rc_intra_sample(b ? &q1 : &q0, l->nb + b * 66, b ? l->ref2 : l->ref, x, y) : tile[o];
+        tile[o] = (uint16_t)(cbf ? rbt_clip3(0, maxv, base + l->res[b * 256 + j]) : base);
+      }
+    }
+  }
+  RBT_SYNC_LDS();
 }
 RBT_DEV void rc_tile_mark(RBT_LDS_AS RbtCtbTile* t, int ux, int uy, int w4, int h4, int flag) {   // any rectangle (prediction units)
   RBT_PAR_FOR(i, w4 * h4) t->uav[(uy + i / w4 + 1) * RC_US + ux + i % w4 + 1] = (uint8_t)flag;
@@ -433,8 +538,10 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
       rc_tile_tb(g, L, 0, x0, y0, log2, intra, c.b, fl & RBT_TU_CBF_Y, (fl & RBT_TU_TS_Y) != 0, c.d, c.qp[0], log2 - 2, c.x4, c.y4, intra || !g->cip);
       if (fl & RBT_TU_CHROMA) {
         const int xc = (log2 > 2 ? x0 : x0 - 4) >> 1, yc = (log2 > 2 ? y0 : y0 - 4) >> 1, l2c = log2 > 2 ? log2 - 1 : 2;
-        rc_tile_tb(g, L, 1, xc, yc, l2c, intra, c.c, fl & RBT_TU_CBF_CB, (fl & RBT_TU_TS_CB) != 0, c.d, c.qp[1], -1, 0, 0, 0);
-        rc_tile_tb(g, L, 2, xc, yc, l2c, intra, c.c, fl & RBT_TU_CBF_CR, (fl & RBT_TU_TS_CR) != 0, c.d, c.qp[2], -1, 0, 0, 0);
+        if (fl & (RBT_TU_TS_CB | RBT_TU_TS_CR)) {                      // transform skip (rare): one plane at a time
+          rc_tile_tb(g, L, 1, xc, yc, l2c, intra, c.c, fl & RBT_TU_CBF_CB, (fl & RBT_TU_TS_CB) != 0, c.d, c.qp[1], -1, 0, 0, 0);
+          rc_tile_tb(g, L, 2, xc, yc, l2c, intra, c.c, fl & RBT_TU_CBF_CR, (fl & RBT_TU_TS_CR) != 0, c.d, c.qp[2], -1, 0, 0, 0);
+        } else rc_tile_tb_cpair(g, L, xc, yc, l2c, intra, c.c, (fl & RBT_TU_CBF_CB) != 0, (fl & RBT_TU_CBF_CR) != 0, c.d, c.qp[1], c.qp[2]);
       }
     }
   }
