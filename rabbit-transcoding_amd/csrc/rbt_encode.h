@@ -190,6 +190,23 @@ template <int LOG2> RBT_DEV void en_fwd_transform_n(int is_dst, int bd, RBT_LDS_
   }
   RBT_SYNC_LDS();
 }
+template <int LOG2> RBT_DEV void en_fwd_transform_pair_n(int bd, RBT_LDS_AS RbtReconLds* r) {   // two blocks at res / tmp offsets 0 and 256
+  constexpr int N = 1 << LOG2, NN = N * N; const int s1 = LOG2 + bd - 9, s2 = LOG2 + 6;
+  RBT_PAR_FOR(i, 2 * NN) {
+    const int b = i >> (2 * LOG2), j = i & (NN - 1), k = j & (N - 1), y = j >> LOG2; int s = 0;
+#pragma unroll
+    for (int x = 0; x < N; x++) s += rc_tcoef(r, N, 0, k, x) * r->res[b * 256 + y * N + x];
+    r->tmp[b * 256 + j] = (int16_t)(s1 > 0 ? (s + (1 << (s1 - 1))) >> s1 : s);
+  }
+  RBT_SYNC_LDS();
+  RBT_PAR_FOR(i, 2 * NN) {
+    const int b = i >> (2 * LOG2), j = i & (NN - 1), kh = j & (N - 1), kv = j >> LOG2; int s = 0;
+#pragma unroll
+    for (int y = 0; y < N; y++) s += rc_tcoef(r, N, 0, kv, y) * r->tmp[b * 256 + y * N + kh];
+    r->res[b * 256 + j] = (int16_t)rbt_clip3(-32768, 32767, (s + (1 << (s2 - 1))) >> s2);
+  }
+  RBT_SYNC_LDS();
+}
 RBT_DEV void en_fwd_transform(int log2, int is_dst, int bd, RBT_LDS_AS RbtReconLds* r) {
   if (log2 == 2) en_fwd_transform_n<2>(is_dst, bd, r);
   else if (log2 == 3) en_fwd_transform_n<3>(0, bd, r);
@@ -340,6 +357,95 @@ RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtE
   RBT_SYNC_LDS();
   return nz != 0;
 }
+// Cb and Cr TB of one CU in the same passes (see rc_tile_tb_cpair); returns cbf_cb | cbf_cr << 1. src: Cb block, then Cr at +256.
+RBT_DEV int en_tile_intra_tb_cpair(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLds* L, int x0, int y0, int gx, int gy, int log2, int mode, int qp_cb, int qp_cr,
+                                   const RBT_LDS_AS uint16_t* src) {
+  RBT_LDS_AS RbtReconLds* r = &L->rc; RBT_LDS_AS RbtEncTile* t = &L->t;
+  const int N = 1 << log2, NN = N * N, bd = g->bit_depth, maxv = (1 << bd) - 1, n4 = (1 << g->log2_ctb) >> 2, pw = g->cw, S = EN_TS_C;
+  const int tot = 4 * N + 1;
+  uint64_t m0, m1 = 0; const int m2 = 0;
+  RBT_VBALLOT(m0, p, rbt_min(tot, 64), rc_nb_av(t->uav, p, x0, y0, N, 1, n4));
+  if (tot > 64) { RBT_VBALLOT(m1, p, tot - 64, rc_nb_av(t->uav, 64 + p, x0, y0, N, 1, n4)); }
+  const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : -1);
+  RBT_PAR_FOR(i, 2 * tot) {
+    const int b = i >= tot, idx = i - b * tot;
+    int v = 1 << (bd - 1);
+    if (first >= 0) { int j = rc_last_avail(idx, m0, m1, m2); if (j < 0) j = first; int xn, yn; rc_nb_xy(j, x0, y0, N, &xn, &yn); v = yn < 0 ? t->top_c[b][xn + 1] : t->c[b][yn * S + xn + 1]; }
+    r->nb[b * 66 + idx] = v;
+  }
+  RBT_SYNC_LDS();
+  RcIntraCtx q0, q1;
+  q0.N = N; q0.log2 = log2; q0.mode = mode; q0.c_idx = 1; q0.maxv = maxv; q0.ang = 0; q0.ver = mode >= 18; q0.dc = 0; q0.edge = 0; q1 = q0; q1.c_idx = 2;
+  if (mode == 1) {
+    int s0 = N, s1 = N;
+    for (int bit = 0; bit < bd; bit++) {
+      uint64_t m; RBT_VBALLOT(m, p, 4 * N, (r->nb[(p >= 2 * N ? 66 : 0) + ((p & (2 * N - 1)) < N ? 2 * N + 1 + (p & (2 * N - 1)) : 2 * N - 1 - ((p & (2 * N - 1)) - N))] >> bit) & 1);
+      s0 += __builtin_popcountll(m & ((1ull << (2 * N)) - 1)) << bit; s1 += __builtin_popcountll(m >> (2 * N)) << bit;
+    }
+    q0.dc = s0 >> (log2 + 1); q1.dc = s1 >> (log2 + 1);
+  } else if (mode >= 2) {
+    const int ang = rc_intra_angle(mode), ver = mode >= 18, last = (N * ang) >> 5, inv = (mode >= 11 && mode <= 25) ? rc_intra_inv_angle(mode) : 0;
+    q0.ang = q1.ang = ang;
+    RBT_PAR_FOR(i, 2 * (3 * N + 1)) {
+      const int b = i >= 3 * N + 1, x = i - b * (3 * N + 1) - N; int v = 0;
+      const RBT_LDS_AS int32_t* nb = r->nb + b * 66;
+#define RC_LEFT(y) nb[2 * N - 1 - (y)]
+#define RC_TOP(x) nb[2 * N + 1 + (x)]
+      if (x >= 0 && x <= N) v = ver ? RC_TOP(x - 1) : RC_LEFT(x - 1);
+      else if (x < 0) { if (ang < 0 && last < -1 && x >= last) { int k = -1 + ((x * inv + 128) >> 8); v = ver ? RC_LEFT(k) : RC_TOP(k); } }
+      else if (ang >= 0) v = ver ? RC_TOP(x - 1) : RC_LEFT(x - 1);
+#undef RC_LEFT
+#undef RC_TOP
+      (b ? r->ref2 : r->ref)[x + 32] = v;
+    }
+    RBT_SYNC_LDS();
+  }
+  // prediction and residual of both planes
+  RBT_PAR_FOR(i, 2 * NN) {
+    const int b = i >= NN, j = i - b * NN;
+    const int pv = rc_intra_sample(b ? &q1 : &q0, r->nb + b * 66, b ? r->ref2 : r->ref, j & (N - 1), j >> log2);
+    r->pred[b * 256 + j] = (uint16_t)pv; r->res[b * 256 + j] = (int16_t)((int)src[b * 256 + j] - pv);
+  }
+  RBT_SYNC_LDS();
+  int part = 0;                                                          // non-zero counts: Cb in the low half, Cr in the high half
+  if (f->lossless) {
+    RBT_PAR_FOR(i, 2 * NN) { const int b = i >= NN, j = i - b * NN; L->lvl[b * 256 + j] = r->res[b * 256 + j]; part += (r->res[b * 256 + j] != 0) << (16 * b); }
+  } else {
+    if (log2 == 2) en_fwd_transform_pair_n<2>(bd, r); else if (log2 == 3) en_fwd_transform_pair_n<3>(bd, r); else en_fwd_transform_pair_n<4>(bd, r);
+    const int qb_cb = 14 + qp_cb / 6 + (15 - bd - log2), qb_cr = 14 + qp_cr / 6 + (15 - bd - log2), sc_cb = en_quant_scale(qp_cb % 6), sc_cr = en_quant_scale(qp_cr % 6);
+    RBT_PAR_FOR(i, 2 * NN) {
+      const int b = i >= NN, j = i - b * NN, qbits = b ? qb_cr : qb_cb;
+      const int cv = r->res[b * 256 + j], a = rbt_abs(cv);
+      long long qv = ((long long)a * (b ? sc_cr : sc_cb) + ((long long)171 << (qbits - 9))) >> qbits;
+      if (qv > 32767) qv = 32767;
+      L->lvl[b * 256 + j] = (int16_t)(cv < 0 ? -qv : qv);
+      part += (qv != 0) << (16 * b);
+    }
+  }
+  const int nzp = en_wave_sum(part, (RBT_LDS_AS RbtEncLds*)0), nz0 = nzp & 0xFFFF, nz1 = nzp >> 16;
+  RBT_SYNC_LDS();
+  RBT_PAR_FOR(i, 2 * NN) { const int b = i >= NN, j = i - b * NN; f->coef[1 + b][(size_t)(gy + (j >> log2)) * pw + gx + (j & (N - 1))] = L->lvl[b * 256 + j]; }
+  if ((nz0 | nz1) && !f->lossless) {
+    const int bd_shift = bd + log2 - 5, sc_cb = (16 * rc_level_scale(qp_cb % 6)) << (qp_cb / 6), sc_cr = (16 * rc_level_scale(qp_cr % 6)) << (qp_cr / 6);
+    const long long add = 1ll << (bd_shift - 1);
+    RBT_PAR_FOR(i, 2 * NN) {
+      const int b = i >= NN, j = i - b * NN;
+      if (b ? nz1 : nz0) { long long v = ((long long)L->lvl[b * 256 + j] * (b ? sc_cr : sc_cb) + add) >> bd_shift; r->res[b * 256 + j] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+    }
+    RBT_SYNC_LDS();
+    const int sh = 20 - bd;
+    if (log2 == 2) rc_inv_transform_pair_n<2>(sh, nz0, nz1, r); else if (log2 == 3) rc_inv_transform_pair_n<3>(sh, nz0, nz1, r); else rc_inv_transform_pair_n<4>(sh, nz0, nz1, r);
+  } else if (nz0 | nz1) {
+    RBT_PAR_FOR(i, 2 * NN) { const int b = i >= NN, j = i - b * NN; r->res[b * 256 + j] = L->lvl[b * 256 + j]; }
+    RBT_SYNC_LDS();
+  }
+  RBT_PAR_FOR(i, 2 * NN) {
+    const int b = i >= NN, j = i - b * NN, x = j & (N - 1), y = j >> log2, nz = b ? nz1 : nz0;
+    t->c[b][(y0 + y) * S + x0 + x + 1] = (uint16_t)(nz ? rbt_clip3(0, maxv, (int)r->pred[b * 256 + j] + r->res[b * 256 + j]) : r->pred[b * 256 + j]);
+  }
+  RBT_SYNC_LDS();
+  return (nz0 != 0) | ((nz1 != 0) << 1);
+}
 // carry_left: the CTB to the left was coded by this wave just before (its reconstruction is still in the tile): take the
 // left border from LDS instead of reading back stores that may still be in flight
 RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtEncTileLds* L, int carry_left) {
@@ -383,8 +489,9 @@ RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT
     for (int q = 0; q < 2; q++) { const uint16_t* sp = f->src[1 + q] + (size_t)((cy + y0) >> 1) * g->cw + ((cx + x0) >> 1); RBT_PAR_FOR(i, Nc * Nc) t->sb[1024 + 256 * q + i] = sp[(size_t)(i >> (lg - 1)) * g->cw + (i & (Nc - 1))]; }
     RBT_SYNC();
     int cbf = en_tile_intra_tb(g, f, L, 0, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, t->sb, lg - 2, x0 >> 2, y0 >> 2) ? RBT_CU_CBF_Y : 0;
-    if (en_tile_intra_tb(g, f, L, 1, x0 >> 1, y0 >> 1, (cx + x0) >> 1, (cy + y0) >> 1, lg - 1, mode, qp_cb, t->sb + 1024, -1, 0, 0)) cbf |= RBT_CU_CBF_CB;
-    if (en_tile_intra_tb(g, f, L, 2, x0 >> 1, y0 >> 1, (cx + x0) >> 1, (cy + y0) >> 1, lg - 1, mode, qp_cr, t->sb + 1280, -1, 0, 0)) cbf |= RBT_CU_CBF_CR;
+    { const int cc = en_tile_intra_tb_cpair(g, f, L, x0 >> 1, y0 >> 1, (cx + x0) >> 1, (cy + y0) >> 1, lg - 1, mode, qp_cb, qp_cr, t->sb + 1024);
+      if (cc & 1) cbf |= RBT_CU_CBF_CB;
+      if (cc & 2) cbf |= RBT_CU_CBF_CR; }
     en_fill_cu_maps(f, cx + x0, cy + y0, N, RBT_MODE_INTRA | (f->lossless ? RBT_PM_TQ_BYPASS : 0) | ((cbf & RBT_CU_CBF_Y) ? RBT_PM_NZ : 0), qp_y, cbf, 1);
   }
   // ---- write the CTB back (clipped to the picture) ----
