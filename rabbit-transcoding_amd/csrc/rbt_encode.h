@@ -32,7 +32,6 @@ struct RbtEncLds {
   int16_t lvl_c[2][16 * 16]; // entropy: chroma levels of the current CU (luma uses lvl)
   uint8_t cu_l2[81], cu_md[81], cu_fl[81];   // entropy: cu_log2 / cu_mode / cu_flags of the CTB's 8x8 units and of the column / row before it:
                                              // (uy + 1) * 9 + ux + 1, ux,uy = -1..7; cu_l2 = 0xFF where the unit is not available (6.4.1)
-  uint16_t src[65 * 66];     // analysis: source samples of a 32x32 quadrant and what its blocks reference around it: (yy + 1) * 66 + xx + 1, xx,yy = -1..63
 };
 
 // sum of v over the lanes of the wave (host emulation: the PAR_FOR already accumulated everything)
@@ -70,13 +69,20 @@ RBT_DEV int en_avail(const EnCtbNb* q, int xc, int yc, int xn, int yn) {
   if (dx >= q->ctb) return 0;
   return rc_morton(dx >> 2, dy >> 2) < rc_morton((xc - q->cx) >> 2, (yc - q->cy) >> 2);
 }
+// The analysis kernel is throughput work (one wave per CTB, 400 CTBs per picture): what it keeps in LDS decides how many
+// waves share a SIMD and hide each other's LDS latency. 10 KB instead of the 30 KB of RbtEncLds: 14 workgroups per CU.
+struct RbtAnalyseLds {
+  int32_t nb[132], nbf[132], ref[100];   // reference samples of the current block (plain / smoothed), angular reference array
+  uint16_t src[65 * 66];                 // source samples of a 32x32 quadrant and what its blocks reference around it: (yy + 1) * 66 + xx + 1
+  int32_t cost[3][16]; uint8_t mode[3][16], split[3][16];
+};
 RBT_DEV int en_nb_av(const EnCtbNb* q, int i, int x0, int y0, int S) { int xn, yn; rc_nb_xy(i, x0, y0, S, &xn, &yn); return en_avail(q, x0, y0, xn, yn); }
-RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtEncLds* l) {
+RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtAnalyseLds* l) {
   const RbtStreamCfg gcopy = f->cfg; const RbtStreamCfg* g = &gcopy;
   int ctb = 1 << g->log2_ctb, rx = ctb_addr % g->w_ctb, ry = ctb_addr / g->w_ctb, cx = rx << g->log2_ctb, cy = ry << g->log2_ctb;
   const int my_slice = f->ctb_slice[ctb_addr];
   const RbtSlice* sl = &slices[my_slice];
-  RBT_LDS_AS RbtReconLds* rl = &l->rc;
+  RBT_LDS_AS RbtAnalyseLds* rl = l;
   EnCtbNb nbq; nbq.cx = cx; nbq.cy = cy; nbq.ctb = ctb; nbq.w = g->w; nbq.h = g->h;
   nbq.left = rx > 0 && f->ctb_slice[ctb_addr - 1] == my_slice;
   nbq.above = ry > 0 && f->ctb_slice[ctb_addr - g->w_ctb] == my_slice;
@@ -128,7 +134,7 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
             RcIntraCtx qc; rc_intra_setup(g, 0, lg, mode, fin, rl->ref, &qc);
             int part = 0;
             RBT_PAR_FOR(i, S * S) { int x = i & (S - 1), y = i >> lg; part += rbt_abs((int)l->src[(by0 + y + 1) * 66 + bx0 + x + 1] - rc_intra_sample(&qc, fin, rl->ref, x, y)); }
-            int sad = en_wave_sum(part, l);
+            int sad = en_wave_sum(part, (RBT_LDS_AS RbtEncLds*)0);
             if (sad < best) { best = sad; bmode = mode; }
             RBT_SYNC_LDS();                                     // rl->ref is rebuilt by the next mode
           }

@@ -164,10 +164,10 @@ __global__ void __launch_bounds__(256) k_pool(const uint16_t* in, int w, int fac
   if (i < (ow / 2) * (oh / 2)) { out_cb[i] = (uint16_t)chroma_value; out_cr[i] = (uint16_t)chroma_value; }
 }
 __global__ void __launch_bounds__(64) k_enc_analyse(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
-  __shared__ RbtEncLds lds;
+  __shared__ RbtAnalyseLds lds;
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   if ((int)blockIdx.x >= f->cfg.w_ctb * f->cfg.h_ctb) return;
-  en_analyse_ctb(f, slices, blockIdx.x, RBT_LDS_CAST(RbtEncLds, &lds));
+  en_analyse_ctb(f, slices, blockIdx.x, RBT_LDS_CAST(RbtAnalyseLds, &lds));
 }
 __global__ void __launch_bounds__(64) k_enc_intra_rows(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
   __shared__ RbtEncTileLds lds;
