@@ -20,17 +20,16 @@ RBT_CONST uint8_t k_intra_cand[11] = {0, 1, 26, 10, 2, 6, 14, 18, 22, 30, 34};
 #define RBT_SPLIT_BITS 24
 #define RBT_PARTIAL_COST 0x0FFFFFFF
 
-struct RbtEncLds {
+// Every kernel declares only the LDS it uses: the footprint per workgroup decides how many waves are resident per CU.
+struct RbtEncLds {             // inter coding (k_enc_inter)
   RbtReconLds rc;
   int16_t lvl[32 * 32];      // quantised levels of the current TB
-  int32_t red[64];           // wave reduction scratch
-  int32_t cost[3][16];       // analysis: best SAD per block [size][block]
-  uint8_t mode[3][16];
-  uint8_t split[3][16];
-  uint16_t cg_mask[64];      // entropy: significance mask of each 4x4 coefficient group (bit n = scan position n)
-  uint8_t scan[3][4][64];    // entropy: k_scan staged once per slice
-  int16_t lvl_c[2][16 * 16]; // entropy: chroma levels of the current CU (luma uses lvl)
-  uint8_t cu_l2[81], cu_md[81], cu_fl[81];   // entropy: cu_log2 / cu_mode / cu_flags of the CTB's 8x8 units and of the column / row before it:
+};
+struct RbtEntropyLds {         // entropy coder (k_entropy): 4.3 KB, every slice of a 64-picture batch resident at once
+  int16_t lvl[32 * 32];      // luma levels of the current CU
+  int16_t lvl_c[2][16 * 16]; // chroma levels of the current CU
+  uint8_t scan[3][4][64];    // k_scan staged once per slice
+  uint8_t cu_l2[81], cu_md[81], cu_fl[81];   // cu_log2 / cu_mode / cu_flags of the CTB's 8x8 units and of the column / row before it:
                                              // (uy + 1) * 9 + ux + 1, ux,uy = -1..7; cu_l2 = 0xFF where the unit is not available (6.4.1)
 };
 
@@ -566,7 +565,7 @@ RBT_DEV void en_inter_ctb(RbtFrame* frames, RbtFrame* f, const RbtSlice* slices,
 }
 
 // ------------------------------------------------------------------------------------------------ entropy coding
-struct RbtEnt { RbtFrame* f; const RbtSlice* sl; int slice_idx; RbtCabacEnc c; RBT_LDS_AS RbtEncLds* l;
+struct RbtEnt { RbtFrame* f; const RbtSlice* sl; int slice_idx; RbtCabacEnc c; RBT_LDS_AS RbtEntropyLds* l;
                 int w, h, log2_ctb, log2_min_cb, tq_bypass_enabled, is_p, cx, cy; };
 // encoder scan tables use x | y << 4 in k_scan; the lane code wants sub-block entries unchanged and 4x4 positions as packed immediates
 RBT_DEV uint8_t k_scan_packed(int a, int b, int c) { return k_scan[a][b][c]; }
@@ -582,7 +581,7 @@ RBT_DEV int en_min_in_group(int g) { return g < 4 ? g : (2 + (g & 1)) << ((g >> 
 // sub-block i for the significance masks, lane p = scan position p of the current sub-block for contexts and levels), the
 // serial part is bins only.
 RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, const RBT_LDS_AS int16_t* lv, int log2, int scan_idx) {
-  RbtCabacEnc* c = &s->c; RBT_LDS_AS RbtEncLds* l = s->l;
+  RbtCabacEnc* c = &s->c; RBT_LDS_AS RbtEntropyLds* l = s->l;
   log2 = RBT_UNI(log2); scan_idx = RBT_UNI(scan_idx);
   const int N = 1 << log2, chroma = c_idx != 0;
   const uint64_t ps = en_scan4_const(scan_idx);
@@ -682,7 +681,7 @@ RBT_DEV int en_scan_idx(int is_intra, int log2, int c_idx, int mode) {
 RBT_DEV int en_u(const RbtEnt* s, int x, int y) { return (((y - s->cy) >> 3) + 1) * 9 + ((x - s->cx) >> 3) + 1; }
 // stages cu_log2 / cu_mode / cu_flags of CTB (cx,cy) and of its left column / above row (with availability) into LDS
 RBT_DEV void en_stage_ctb(RbtEnt* s, int cx, int cy) {
-  const RbtFrame* f = s->f; RBT_LDS_AS RbtEncLds* l = s->l;
+  const RbtFrame* f = s->f; RBT_LDS_AS RbtEntropyLds* l = s->l;
   s->cx = cx; s->cy = cy;
   const int L = s->log2_ctb, wc = (s->w + (1 << L) - 1) >> L, ac = (cy >> L) * wc + (cx >> L), my = f->ctb_slice[ac];
   RBT_PAR_FOR(i, 81) {
@@ -697,7 +696,7 @@ RBT_DEV void en_stage_ctb(RbtEnt* s, int cx, int cy) {
   RBT_SYNC();
 }
 RBT_DEV void en_write_cu(RbtEnt* s, int x0, int y0, int log2, int depth) {
-  RbtCabacEnc* c = &s->c; const RbtFrame* f = s->f; RBT_LDS_AS RbtEncLds* l = s->l;
+  RbtCabacEnc* c = &s->c; const RbtFrame* f = s->f; RBT_LDS_AS RbtEntropyLds* l = s->l;
   x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); log2 = RBT_UNI(log2);
   const int u = en_u(s, x0, y0), flags = RBT_UNI(l->cu_fl[u]), mode = RBT_UNI(l->cu_md[u]);
   const int cbf_cb = (flags & RBT_CU_CBF_CB) != 0, cbf_cr = (flags & RBT_CU_CBF_CR) != 0, cbf_y = (flags & RBT_CU_CBF_Y) != 0;
@@ -759,7 +758,7 @@ RBT_DEV void en_write_cu(RbtEnt* s, int x0, int y0, int log2, int depth) {
 }
 RBT_DEV void en_write_quadtree(RbtEnt* s, int x0, int y0, int log2) {
   // stack-free depth-first walk (per-level child counters packed in one register, see the parser's pz_coding_quadtree)
-  RBT_LDS_AS RbtEncLds* l = s->l;
+  RBT_LDS_AS RbtEntropyLds* l = s->l;
   int lvl = 0, x = x0, y = y0, lg = log2;
   uint32_t states = 15u;
   for (;;) {
@@ -791,7 +790,7 @@ RBT_DEV void en_write_quadtree(RbtEnt* s, int x0, int y0, int log2) {
     }
   }
 }
-RBT_DEV void en_entropy_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, uint8_t* out, RBT_LDS_AS RbtEncLds* l) {
+RBT_DEV void en_entropy_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, uint8_t* out, RBT_LDS_AS RbtEntropyLds* l) {
   RbtEnt s; s.sl = &slices[slice_idx]; s.f = &frames[RBT_UNI(s.sl->frame)]; s.slice_idx = slice_idx; s.l = l;
   const RbtSlice* sl = s.sl; const RbtStreamCfg* g = &s.f->cfg;
   s.w = RBT_UNI(g->w); s.h = RBT_UNI(g->h); s.log2_ctb = RBT_UNI(g->log2_ctb); s.log2_min_cb = RBT_UNI(g->log2_min_cb); s.tq_bypass_enabled = RBT_UNI(g->tq_bypass_enabled);

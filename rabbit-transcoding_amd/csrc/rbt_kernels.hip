@@ -193,8 +193,8 @@ __global__ void __launch_bounds__(64) k_enc_inter(RbtFrame* frames, const RbtSli
   en_inter_ctb(frames, f, slices, blockIdx.x, RBT_LDS_CAST(RbtEncLds, &lds));
 }
 __global__ void __launch_bounds__(64) k_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list) {
-  __shared__ RbtEncLds lds;
-  en_entropy_slice(frames, slices, slice_list[blockIdx.x], out, RBT_LDS_CAST(RbtEncLds, &lds));
+  __shared__ RbtEntropyLds lds;
+  en_entropy_slice(frames, slices, slice_list[blockIdx.x], out, RBT_LDS_CAST(RbtEntropyLds, &lds));
 }
 
 __global__ void __launch_bounds__(256) k_pack(const uint8_t* out, const RbtSlice* slices, const uint32_t* dst_off, uint8_t* packed) {
