@@ -25,9 +25,8 @@ struct RbtEncLds {             // inter coding (k_enc_inter)
   RbtReconLds rc;
   int16_t lvl[32 * 32];      // quantised levels of the current TB
 };
-struct RbtEntropyLds {         // entropy coder (k_entropy): 4.3 KB, every slice of a 64-picture batch resident at once
-  int16_t lvl[32 * 32];      // luma levels of the current CU
-  int16_t lvl_c[2][16 * 16]; // chroma levels of the current CU
+struct RbtEntropyLds {         // entropy coder (k_entropy): 14 KB, every slice of a 64-picture batch resident at once
+  alignas(16) int16_t ctb_y[64 * 64]; alignas(16) int16_t ctb_c[2][32 * 32];   // levels of the current CTB (row stride = CTB size), fetched once per CTB
   uint8_t scan[3][4][64];    // k_scan staged once per slice
   uint8_t cu_l2[81], cu_md[81], cu_fl[81];   // cu_log2 / cu_mode / cu_flags of the CTB's 8x8 units and of the column / row before it:
                                              // (uy + 1) * 9 + ux + 1, ux,uy = -1..7; cu_l2 = 0xFF where the unit is not available (6.4.1)
@@ -580,10 +579,10 @@ RBT_DEV int en_min_in_group(int g) { return g < 4 ? g : (2 + (g & 1)) << ((g >> 
 // three TBs of the CU with one HBM round trip. Same split as the parser: what is not a bin runs on the lanes (lane i =
 // sub-block i for the significance masks, lane p = scan position p of the current sub-block for contexts and levels), the
 // serial part is bins only.
-RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, const RBT_LDS_AS int16_t* lv, int log2, int scan_idx) {
+RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, const RBT_LDS_AS int16_t* lv, int lst, int log2, int scan_idx) {
   RbtCabacEnc* c = &s->c; RBT_LDS_AS RbtEntropyLds* l = s->l;
-  log2 = RBT_UNI(log2); scan_idx = RBT_UNI(scan_idx);
-  const int N = 1 << log2, chroma = c_idx != 0;
+  log2 = RBT_UNI(log2); scan_idx = RBT_UNI(scan_idx); lst = RBT_UNI(lst);
+  const int chroma = c_idx != 0;
   const uint64_t ps = en_scan4_const(scan_idx);
   const RBT_LDS_AS uint8_t* sb_scan = l->scan[scan_idx][log2 - 2];
   const int n_sb = 1 << (2 * (log2 - 2));
@@ -591,7 +590,7 @@ RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, const RBT_LDS_AS int16_t* l
   RBT_VFOR(p, 64) {
     const int e = p < n_sb ? (int)sb_scan[p] : 0; RBT_V(v_sbscan, p) = e; RBT_V(v_pos, p) = (int)((ps >> (4 * (p & 15))) & 15);
     int m = 0;
-    if (p < n_sb) { const int xs = e & 15, ys = e >> 4; for (int n = 0; n < 16; n++) { const int q = (int)((ps >> (4 * n)) & 15); if (lv[((ys << 2) + (q >> 2)) * N + (xs << 2) + (q & 3)]) m |= 1 << n; } }
+    if (p < n_sb) { const int xs = e & 15, ys = e >> 4; for (int n = 0; n < 16; n++) { const int q = (int)((ps >> (4 * n)) & 15); if (lv[((ys << 2) + (q >> 2)) * lst + (xs << 2) + (q & 3)]) m |= 1 << n; } }
     RBT_V(v_cgmask, p) = m;
   }
   uint64_t nz64; RBT_VBALLOT(nz64, p, 64, RBT_V(v_cgmask, p) != 0);
@@ -629,10 +628,10 @@ RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, const RBT_LDS_AS int16_t* l
     RBT_VFOR(p, 16) {
       const int p4 = RBT_V(v_pos, p);
       RBT_V(v_sc, p) = log2 == 2 ? (int)((EN_SIGCTX4 >> (4 * p4)) & 15) + sig_c0 : ((dc_cg && p4 == 0) ? sig_c0 : cg_base + (int)((pat >> (2 * p4)) & 3));
-      const int v = lv[((ys << 2) + (p4 >> 2)) * N + (xs << 2) + (p4 & 3)];
+      const int v = lv[((ys << 2) + (p4 >> 2)) * lst + (xs << 2) + (p4 & 3)];
       RBT_V(v_abs, p) = v < 0 ? -v : v;
     }
-    RBT_VBALLOT(neg64, p, 16, lv[((ys << 2) + (RBT_V(v_pos, p) >> 2)) * N + (xs << 2) + (RBT_V(v_pos, p) & 3)] < 0);
+    RBT_VBALLOT(neg64, p, 16, lv[((ys << 2) + (RBT_V(v_pos, p) >> 2)) * lst + (xs << 2) + (RBT_V(v_pos, p) & 3)] < 0);
     const int start = i == last_sb ? last_pos - 1 : 15;
     for (int n = start; n >= 1; n--) rbt_ce_bin_sig(c, RBT_VGET(v_sc, n), (int)((mask >> n) & 1));
     if (start >= 0 && !(infer_dc && (mask >> 1) == 0)) rbt_ce_bin_sig(c, RBT_VGET(v_sc, 0), (int)(mask & 1));
@@ -693,6 +692,19 @@ RBT_DEV void en_stage_ctb(RbtEnt* s, int cx, int cy) {
     }
     l->cu_l2[i] = (uint8_t)l2; l->cu_md[i] = (uint8_t)md; l->cu_fl[i] = (uint8_t)fl;
   }
+  // the CTB's levels: 8-byte groups of four, several loads in flight (one HBM round trip per CTB instead of one per CU)
+  for (int c = 0; c < 3; c++) {
+    const int sh = c ? 1 : 0, nn = (1 << L) >> sh, pw = s->w >> sh, ph = s->h >> sh, ox = cx >> sh, oy = cy >> sh;
+    const RbtU2* cp = (const RbtU2*)(f->coef[c] + (size_t)oy * pw + ox); RBT_LDS_AS RbtU2* cd = (RBT_LDS_AS RbtU2*)(c == 0 ? l->ctb_y : l->ctb_c[c - 1]);
+    const int q4 = nn >> 2, lq4 = L - sh - 2, rows = rbt_min(nn, ph - oy), cols4 = rbt_min(nn, pw - ox) >> 2;
+#pragma unroll 4
+    RBT_PAR_FOR(i, nn * q4) {
+      const int x4 = i & (q4 - 1), y = i >> lq4;
+      RbtU2 v; v.x = 0; v.y = 0;
+      if (x4 < cols4 && y < rows) v = cp[((size_t)y * pw >> 2) + x4];
+      cd[i].x = v.x; cd[i].y = v.y;
+    }
+  }
   RBT_SYNC();
 }
 RBT_DEV void en_write_cu(RbtEnt* s, int x0, int y0, int log2, int depth) {
@@ -700,14 +712,6 @@ RBT_DEV void en_write_cu(RbtEnt* s, int x0, int y0, int log2, int depth) {
   x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); log2 = RBT_UNI(log2);
   const int u = en_u(s, x0, y0), flags = RBT_UNI(l->cu_fl[u]), mode = RBT_UNI(l->cu_md[u]);
   const int cbf_cb = (flags & RBT_CU_CBF_CB) != 0, cbf_cr = (flags & RBT_CU_CBF_CR) != 0, cbf_y = (flags & RBT_CU_CBF_Y) != 0;
-  // the levels of the CU's TBs: one HBM round trip, issued before the header bins are coded
-  if (!(flags & RBT_CU_SKIP)) {
-    const int N = 1 << log2, Nc = N >> 1, pw = s->w, cw = s->w >> 1;
-    if (cbf_y) { const int16_t* cp = f->coef[0] + (size_t)y0 * pw + x0; RBT_PAR_FOR(i, N * N) l->lvl[i] = cp[(size_t)(i >> log2) * pw + (i & (N - 1))]; }
-    for (int q = 0; q < 2; q++) if (q ? cbf_cr : cbf_cb) {
-      const int16_t* cp = f->coef[1 + q] + (size_t)(y0 >> 1) * cw + (x0 >> 1); RBT_PAR_FOR(i, Nc * Nc) l->lvl_c[q][i] = cp[(size_t)(i >> (log2 - 1)) * cw + (i & (Nc - 1))];
-    }
-  }
   const int is_p = s->is_p;
   if (s->tq_bypass_enabled) rbt_ce_bin0(c, CTX_CU_TQ_BYPASS, f->lossless ? 1 : 0);
   const int ul = u - 1, ua = u - 9;                                  // left / above 8x8 unit
@@ -749,11 +753,10 @@ RBT_DEV void en_write_cu(RbtEnt* s, int x0, int y0, int log2, int depth) {
   rbt_ce_bin0(c, CTX_CBF_CHROMA + 0, cbf_cr);
   if (!is_p || cbf_cb || cbf_cr) rbt_ce_bin0(c, CTX_CBF_LUMA + 1, cbf_y);
   const int intra = !is_p;
-  RBT_SYNC();                                          // levels have arrived in LDS
-  if (cbf_y) en_write_residual(s, 0, l->lvl, log2, en_scan_idx(intra, log2, 0, mode));
-  if (cbf_cb) en_write_residual(s, 1, l->lvl_c[0], log2 - 1, en_scan_idx(intra, log2 - 1, 1, mode));
-  if (cbf_cr) en_write_residual(s, 2, l->lvl_c[1], log2 - 1, en_scan_idx(intra, log2 - 1, 2, mode));
-  RBT_SYNC_LDS();
+  const int ctb = 1 << s->log2_ctb, rx0 = x0 - s->cx, ry0 = y0 - s->cy;
+  if (cbf_y) en_write_residual(s, 0, l->ctb_y + ry0 * ctb + rx0, ctb, log2, en_scan_idx(intra, log2, 0, mode));
+  if (cbf_cb) en_write_residual(s, 1, l->ctb_c[0] + (ry0 >> 1) * (ctb >> 1) + (rx0 >> 1), ctb >> 1, log2 - 1, en_scan_idx(intra, log2 - 1, 1, mode));
+  if (cbf_cr) en_write_residual(s, 2, l->ctb_c[1] + (ry0 >> 1) * (ctb >> 1) + (rx0 >> 1), ctb >> 1, log2 - 1, en_scan_idx(intra, log2 - 1, 2, mode));
   (void)depth;
 }
 RBT_DEV void en_write_quadtree(RbtEnt* s, int x0, int y0, int log2) {
