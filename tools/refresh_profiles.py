@@ -1,0 +1,43 @@
+"""Turns the rocprofv3 outputs a gpurun call merged into gpurun_out/ into the committed summaries under profiles/.
+Inputs: gpurun_out/bench_line.json, prof_kt/ (--kernel-trace --stats of 5 steps + 1 warm-up, input loaded
+from a file), prof_f/ and prof_w/ (--pmc FETCH_SIZE / WRITE_SIZE, one step), prof_tl/ (--kernel-trace of one timed step)."""
+import collections, csv, json, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+shutil.copy("gpurun_out/prof_kt/kt_kernel_stats.csv", f"profiles/{tag}_bench_kernel_stats.csv")
+shutil.copy("gpurun_out/bench_line.json", f"profiles/{tag}_bench_line.json")
+
+def agg(path, name):
+    d = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != name: continue
+        k = r["Kernel_Name"].split("(")[0].replace("rbtk::", ""); d[k][0] += 1; d[k][1] += float(r["Counter_Value"])
+    return d
+F = agg("gpurun_out/prof_f/f_counter_collection.csv", "FETCH_SIZE"); W = agg("gpurun_out/prof_w/w_counter_collection.csv", "WRITE_SIZE")
+out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two separate passes, --kernel-trace only), python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 "
+               "--load-input <R5 streams> on MI355X: one transcode step of the 32-frame 1280x1280 GOF, nothing else in the process. Values are KB summed over "
+               "every dispatch of the kernel in that step. FETCH_SIZE is reported uncorrected (MI355X_MICROARCH.md: under-reports wide coalesced reads; "
+               "these kernels issue narrow accesses).", "kernels": {}}
+for k in sorted(set(F) | set(W)):
+    if k.startswith("__"): continue
+    out["kernels"][k] = {"dispatches": F[k][0] or W[k][0], "FETCH_SIZE_KB": round(F[k][1], 1), "WRITE_SIZE_KB": round(W[k][1], 1)}
+json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
+
+rows = [r for r in csv.DictReader(open("gpurun_out/prof_tl/tl_kernel_trace.csv")) if r["Kernel_Name"].startswith("rbtk::")]
+for r in rows: r["s"] = int(r["Start_Timestamp"]); r["e"] = int(r["End_Timestamp"])
+parses = [r for r in rows if "k_parse" in r["Kernel_Name"]]
+t0 = min(r["s"] for r in parses[-3:]); last = [r for r in rows if r["s"] >= t0]; tend = max(r["e"] for r in last)
+with open(f"profiles/{tag}_timeline.txt", "w") as o:
+    o.write("# rocprofv3 --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --cpu-sample 0 --load-input <R5 streams> (MI355X); timed step only, ms from the first kernel\n")
+    o.write("# one HIP stream (queue) per sub-bitstream pipeline (occupancy, geometry, attribute) + the auxiliary stream of the longest one. step span %.2f ms\n" % ((tend - t0) / 1e6))
+    byq = collections.defaultdict(list)
+    for r in last: byq[r["Queue_Id"]].append(r)
+    for q, rs in byq.items():
+        o.write("queue %s dispatches %d\n" % (q, len(rs)))
+        cur = None
+        for r in rs + [None]:
+            name = r["Kernel_Name"].split("(")[0].replace("rbtk::", "") if r else None
+            if cur and cur[0] == name: cur[2] = r["e"]; cur[3] += 1; cur[4] += r["e"] - r["s"]
+            else:
+                if cur: o.write("   %-18s start %8.2f end %8.2f launches %4d busy %8.2f\n" % (cur[0], (cur[1] - t0) / 1e6, (cur[2] - t0) / 1e6, cur[3], cur[4] / 1e6))
+                cur = [name, r["s"], r["e"], 1, r["e"] - r["s"]] if r else None
+print(open(f"profiles/{tag}_timeline.txt").read())
