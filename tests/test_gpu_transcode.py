@@ -119,3 +119,19 @@ def test_transcode_rejects_damaged_input(ctx):
         ctx.transcode_substream(bytes(bad[: len(bad) // 2 + len(bad) // 3]), R.RBT_VIDEO_ATTRIBUTE, 32)
     # the context stays usable
     assert ctx.transcode_substream(sg, R.RBT_VIDEO_GEOMETRY, 24) == O.transcode_substream(sg, 1, 24)
+
+
+def test_transcode_gof_more_streams_than_pipelines(ctx):
+    """more sub-bitstreams than HIP streams (4): pipelines share streams, results must not change"""
+    R = rbt_lib.module()
+    so, sg, sa, _ = _r5_streams(128, 128, 1, 33)
+    P = R.StreamParams
+    streams = [sg, sa, sg, sa, sg, so]
+    params = [P(1, 24, 4, 5, 1, 1, 0), P(19, 32, 4, 5, 1, 1, 0), P(1, 32, 4, 4, 1, 1, 0), P(19, 42, 4, 5, 0, 1, 0), P(1, 28, 4, 5, 1, 1, 1), P(0, 8, 4, 5, 1, 1, 0)]
+    outs = ctx.transcode_gof(streams, params)
+    assert outs[0] == O.transcode_substream(sg, 1, 24)
+    assert outs[1] == O.transcode_substream(sa, 19, 32)
+    assert outs[2] == O.transcode_substream(sg, 1, 32, log2_ctb=4)
+    assert outs[3] == O.transcode_substream(sa, 19, 42, rows_per_slice=0)
+    assert outs[4] == ctx.transcode_substream(sg, 1, 28, verify_md5=1)
+    assert outs[5] == O.transcode_substream(so, 0, 8)

@@ -64,3 +64,20 @@ def test_banded_parse_is_bit_identical(monkeypatch):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_transcode_gof_more_streams_than_pipelines(ctx):
+    """more sub-bitstreams than HIP streams (4): pipelines share streams, results must not change"""
+    R = rbt_lib.module()
+    geo, attr, occ = synth.make_gof(64, 64, 1, 33)
+    sg, _ = O.encode(geo, 64, 64, 10, 16, gop=2, log2_ctb=5, rows_per_slice=0)
+    sa, _ = O.encode(attr, 64, 64, 10, 22, gop=2, log2_ctb=5, rows_per_slice=0)
+    P = R.StreamParams
+    streams = [sg, sa, sg, sa, sg]
+    params = [P(1, 24, 4, 5, 1, 1, 0), P(19, 32, 4, 5, 1, 1, 0), P(1, 32, 4, 4, 1, 1, 0), P(19, 42, 4, 5, 0, 1, 0), P(1, 28, 4, 5, 1, 1, 1)]
+    outs = ctx.transcode_gof(streams, params)
+    assert outs[0] == O.transcode_substream(sg, 1, 24)
+    assert outs[1] == O.transcode_substream(sa, 19, 32)
+    assert outs[2] == O.transcode_substream(sg, 1, 32, log2_ctb=4)
+    assert outs[3] == O.transcode_substream(sa, 19, 42, rows_per_slice=0)
+    assert outs[4] == ctx.transcode_substream(sg, 1, 28, verify_md5=1)
