@@ -23,6 +23,7 @@ struct oracle_hevc_decoder {
   hevc_meta* meta; hevc_frame* cur; int cur_idx; int cur_poc; int pic_open;
   int prev_tid0_poc;
   int md5_checked, md5_failed;
+  int last_conf_win[4];
   int slice_idx_in_pic;
   uint8_t pending_md5[3][16]; int have_md5;
   /* scan tables: [scanIdx 0 diag,1 hor,2 ver][log2 1..3][pos] -> x | y<<4 */
@@ -176,6 +177,7 @@ static int parse_slice_header(oracle_hevc_decoder* d, bitreader* b, int nal_type
   if (nal_type >= 16 && nal_type <= 23) h->no_output_of_prior_pics = br_bit(b);
   h->pps_id = br_ue(b); if (h->pps_id > 63 || !d->pps[h->pps_id].valid) { DEC_ERR("slice refers to missing PPS %d", h->pps_id); return -1; }
   hevc_pps* pps = &d->pps[h->pps_id]; hevc_sps* sps = &d->sps[pps->sps_id];
+  for (int i = 0; i < 4; i++) d->last_conf_win[i] = sps->conf_win[i];
   if (!sps->valid) { DEC_ERR("missing SPS"); return -1; }
   *sps_out = sps; *pps_out = pps;
   if (!h->first_slice_in_pic) {
@@ -842,5 +844,7 @@ int oracle_hevc_dec_decode(oracle_hevc_decoder* d, const uint8_t* p, size_t n) {
 }
 int oracle_hevc_dec_num_frames(const oracle_hevc_decoder* d) { return d->n_out; }
 const hevc_frame* oracle_hevc_dec_frame(const oracle_hevc_decoder* d, int i) { return i >= 0 && i < d->n_out ? d->out[i] : NULL; }
+/* conformance window (luma samples: left, right, top, bottom) of the SPS the last picture used */
+void oracle_hevc_dec_crop(const oracle_hevc_decoder* d, int out[4]) { for (int i = 0; i < 4; i++) out[i] = 2 * d->last_conf_win[i]; }
 int oracle_hevc_dec_md5_checked(const oracle_hevc_decoder* d) { return d->md5_checked; }
 int oracle_hevc_dec_md5_failed(const oracle_hevc_decoder* d) { return d->md5_failed; }

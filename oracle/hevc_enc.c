@@ -172,7 +172,8 @@ static void write_param_sets(enc* e, bytebuf* out) {
   w.bb.n = 0;
   bw_u(&w, 0, 4); bw_u(&w, 0, 3); bw_bit(&w, 1);
   write_ptl(&w, s->bit_depth);
-  bw_ue(&w, 0); bw_ue(&w, 1); bw_ue(&w, s->width); bw_ue(&w, s->height); bw_bit(&w, 0);
+  bw_ue(&w, 0); bw_ue(&w, 1); bw_ue(&w, s->width); bw_ue(&w, s->height);
+  if (s->conf_win[1] | s->conf_win[3]) { bw_bit(&w, 1); for (int i = 0; i < 4; i++) bw_ue(&w, s->conf_win[i]); } else bw_bit(&w, 0);
   bw_ue(&w, s->bit_depth - 8); bw_ue(&w, s->bit_depth - 8); bw_ue(&w, s->log2_max_poc_lsb - 4);
   bw_bit(&w, 1); bw_ue(&w, s->max_dec_pic_buffering - 1); bw_ue(&w, 0); bw_ue(&w, 0);
   bw_ue(&w, s->log2_min_cb - 3); bw_ue(&w, s->log2_diff_max_min_cb); bw_ue(&w, s->log2_min_tb - 2); bw_ue(&w, s->log2_diff_max_min_tb);
@@ -901,6 +902,7 @@ static void setup_stream(enc* e) {
   hevc_sps* s = &e->sps; hevc_pps* p = &e->pps; const oracle_enc_params* q = &e->p;
   memset(s, 0, sizeof(*s)); memset(p, 0, sizeof(*p));
   s->width = q->width; s->height = q->height; s->bit_depth = s->bit_depth_c = q->bit_depth; s->chroma_format_idc = 1;
+  s->conf_win[0] = s->conf_win[2] = 0; s->conf_win[1] = q->conf_win_right; s->conf_win[3] = q->conf_win_bottom;
   s->log2_max_poc_lsb = 8; s->max_dec_pic_buffering = 3;
   s->log2_ctb = q->log2_ctb ? q->log2_ctb : 5;
   s->log2_min_cb = 3; s->log2_diff_max_min_cb = s->log2_ctb - 3;

@@ -14,6 +14,7 @@ typedef struct {
   int ctb_rows_per_slice;   /* 0 = one slice per picture */
   int md5_sei;              /* emit decoded-picture-hash SEI */
   uint32_t stress_seed;     /* 0 = product decisions; != 0 = random-syntax generator for decoder test streams */
+  int conf_win_right, conf_win_bottom;   /* conformance window offsets in chroma sample units (7.4.3.2.1): width / height are the CODED size */
 } oracle_enc_params;
 
 /* Encodes n frames; appends an Annex-B stream to out. If recon != NULL it receives n newly allocated reconstructed

@@ -76,22 +76,60 @@ void oracle_or_pool(const uint16_t* in, int w, int h, int factor, uint16_t* out)
     }
 }
 
+/* ---- conformance window (7.4.3.2.1) ----
+ * libx265 (PCCTranscoder.cpp:706) codes pictures whose size is not a multiple of the minimum CU size by padding them and
+ * signalling the padding as the conformance window; decoders output the cropped picture. Same here: the coded size is
+ * the display size rounded up to 8 (all-intra) or 16 (I,P pairs: 16x16 inter CUs), padded by repeating the last
+ * column / row, and every consumer of decoded pictures sees the cropped size. */
+static hevc_frame* frame_crop(const hevc_frame* f, const int crop[4]) {
+  int w = f->w - crop[0] - crop[1], h = f->h - crop[2] - crop[3];
+  hevc_frame* o = hevc_frame_alloc(w, h, f->bit_depth);
+  for (int c = 0; c < 3; c++) { int sh = c ? 1 : 0, pw = c ? f->cw : f->w, ow = c ? o->cw : o->w, oh = c ? o->ch : o->h;
+    for (int y = 0; y < oh; y++) memcpy(o->p[c] + (size_t)y * ow, f->p[c] + (size_t)(y + (crop[2] >> sh)) * pw + (crop[0] >> sh), (size_t)ow * 2); }
+  return o;
+}
+static hevc_frame* frame_pad(const hevc_frame* f, int cw, int ch) {
+  hevc_frame* o = hevc_frame_alloc(cw, ch, f->bit_depth);
+  for (int c = 0; c < 3; c++) { int pw = c ? f->cw : f->w, ph = c ? f->ch : f->h, ow = c ? o->cw : o->w, oh = c ? o->ch : o->h;
+    for (int y = 0; y < oh; y++) for (int x = 0; x < ow; x++) o->p[c][(size_t)y * ow + x] = f->p[c][(size_t)(y < ph ? y : ph - 1) * pw + (x < pw ? x : pw - 1)]; }
+  return o;
+}
+static int has_crop(const int c[4]) { return c[0] | c[1] | c[2] | c[3]; }
+/* oracle_hevc_encode of pictures of any even size: pads to the coded size and signals the window; recon (if any) is cropped back */
+static int encode_any_size(oracle_enc_params* ep, const hevc_frame* const* src, int n, bytebuf* bb, hevc_frame** recon) {
+  int w = ep->width, h = ep->height, al = (ep->gop > 1 && !ep->stress_seed) ? 16 : 8, cw = (w + al - 1) / al * al, ch = (h + al - 1) / al * al;
+  if (w % 2 || h % 2) return -1;
+  if (cw == w && ch == h) return oracle_hevc_encode(ep, src, n, bb, recon);
+  hevc_frame** padded = (hevc_frame**)calloc((size_t)n, sizeof(void*));
+  for (int i = 0; i < n; i++) padded[i] = frame_pad(src[i], cw, ch);
+  ep->width = cw; ep->height = ch; ep->conf_win_right = (cw - w) / 2; ep->conf_win_bottom = (ch - h) / 2;
+  int rc = oracle_hevc_encode(ep, (const hevc_frame* const*)padded, n, bb, recon);
+  ep->width = w; ep->height = h;
+  if (rc == 0 && recon) { int crop[4] = {0, cw - w, 0, ch - h}; for (int i = 0; i < n; i++) { hevc_frame* c = frame_crop(recon[i], crop); hevc_frame_free(recon[i]); recon[i] = c; } }
+  for (int i = 0; i < n; i++) hevc_frame_free(padded[i]);
+  free(padded);
+  return rc;
+}
+
 int oracle_decode(const uint8_t* annexb, size_t n, oracle_video* out) {
   memset(out, 0, sizeof(*out));
   oracle_hevc_decoder* d = oracle_hevc_dec_create();
   int rc = oracle_hevc_dec_decode(d, annexb, n);
   int nf = oracle_hevc_dec_num_frames(d);
   if (rc == 0 && nf > 0) {
-    const hevc_frame* f0 = oracle_hevc_dec_frame(d, 0);
-    out->w = f0->w; out->h = f0->h; out->bit_depth = f0->bit_depth; out->n_frames = nf;
-    size_t fs = (size_t)f0->w * f0->h * 3 / 2;
+    int crop[4]; oracle_hevc_dec_crop(d, crop);
+    const hevc_frame* c0 = oracle_hevc_dec_frame(d, 0);
+    int w = c0->w - crop[0] - crop[1], h = c0->h - crop[2] - crop[3];
+    out->w = w; out->h = h; out->bit_depth = c0->bit_depth; out->n_frames = nf;
+    size_t ys = (size_t)w * h, cs = (size_t)(w / 2) * (h / 2), fs = ys + 2 * cs;
     out->data = (uint16_t*)malloc(fs * 2 * (size_t)nf);
     for (int i = 0; i < nf; i++) {
-      const hevc_frame* f = oracle_hevc_dec_frame(d, i);
-      if (f->w != f0->w || f->h != f0->h) { rc = -2; break; }
+      const hevc_frame* fc = oracle_hevc_dec_frame(d, i);
+      if (fc->w != c0->w || fc->h != c0->h) { rc = -2; break; }
+      hevc_frame* f = frame_crop(fc, crop);
       uint16_t* o = out->data + fs * (size_t)i;
-      memcpy(o, f->p[0], (size_t)f->w * f->h * 2); memcpy(o + (size_t)f->w * f->h, f->p[1], (size_t)f->cw * f->ch * 2);
-      memcpy(o + (size_t)f->w * f->h + (size_t)f->cw * f->ch, f->p[2], (size_t)f->cw * f->ch * 2);
+      memcpy(o, f->p[0], ys * 2); memcpy(o + ys, f->p[1], cs * 2); memcpy(o + ys + cs, f->p[2], cs * 2);
+      hevc_frame_free(f);
     }
   }
   out->md5_checked = oracle_hevc_dec_md5_checked(d); out->md5_failed = oracle_hevc_dec_md5_failed(d);
@@ -115,7 +153,7 @@ int oracle_encode(int w, int h, int bit_depth, int qp, int i_qp_offset, int gop,
   hevc_frame** rc_fr = (hevc_frame**)calloc((size_t)n_frames, sizeof(void*));
   for (int i = 0; i < n_frames; i++) fr[i] = frame_from_yuv(yuv + fs * (size_t)i, w, h, bit_depth);
   bytebuf bb = {0, 0, 0};
-  int rc = oracle_hevc_encode(&p, (const hevc_frame* const*)fr, n_frames, &bb, rc_fr);
+  int rc = encode_any_size(&p, (const hevc_frame* const*)fr, n_frames, &bb, rc_fr);
   for (int i = 0; i < n_frames; i++) {
     if (rc == 0 && recon) {
       uint16_t* o = recon + fs * (size_t)i; hevc_frame* f = rc_fr[i];
@@ -135,7 +173,10 @@ int oracle_transcode_substream(const uint8_t* annexb, size_t n, const oracle_tra
   if (oracle_hevc_dec_decode(d, annexb, n) || oracle_hevc_dec_md5_failed(d)) { oracle_hevc_dec_destroy(d); return -1; }
   int nf = oracle_hevc_dec_num_frames(d);
   if (nf <= 0) { oracle_hevc_dec_destroy(d); return -1; }
-  const hevc_frame* f0 = oracle_hevc_dec_frame(d, 0);
+  int crop[4]; oracle_hevc_dec_crop(d, crop);
+  hevc_frame** dec = (hevc_frame**)calloc((size_t)nf, sizeof(void*));      /* decoded pictures as a player sees them (cropped) */
+  for (int i = 0; i < nf; i++) dec[i] = has_crop(crop) ? frame_crop(oracle_hevc_dec_frame(d, i), crop) : (hevc_frame*)oracle_hevc_dec_frame(d, i);
+  const hevc_frame* f0 = dec[0];
   oracle_enc_params ep; memset(&ep, 0, sizeof(ep));
   ep.bit_depth = f0->bit_depth; ep.qp = p->qp; ep.log2_ctb = p->log2_ctb; ep.ctb_rows_per_slice = p->ctb_rows_per_slice; ep.md5_sei = p->md5_sei;
   hevc_frame** src = (hevc_frame**)calloc((size_t)nf, sizeof(void*));
@@ -147,21 +188,23 @@ int oracle_transcode_substream(const uint8_t* annexb, size_t n, const oracle_tra
     if (p->occupancy_precision == 4) {
       own = 1;
       for (int i = 0; i < nf; i++) {
-        const hevc_frame* f = oracle_hevc_dec_frame(d, i);
+        const hevc_frame* f = dec[i];
         src[i] = hevc_frame_alloc(ep.width, ep.height, f->bit_depth);
         oracle_or_pool(f->p[0], f->w, f->h, 2, src[i]->p[0]);
         /* the reference leaves the pooled chroma planes unwritten (:638-641); this restatement defines them as mid-grey */
         for (int c = 1; c < 3; c++) for (size_t k = 0; k < (size_t)src[i]->cw * src[i]->ch; k++) src[i]->p[c][k] = (uint16_t)(1 << (f->bit_depth - 1));
       }
-    } else for (int i = 0; i < nf; i++) src[i] = (hevc_frame*)oracle_hevc_dec_frame(d, i);
+    } else for (int i = 0; i < nf; i++) src[i] = dec[i];
   } else {
     /* geometry / attribute: gop 2, no B frames, CQP (PCCTranscoder.cpp:847-851, :883-895) */
     ep.gop = 2; ep.i_qp_offset = -3; ep.width = f0->w; ep.height = f0->h;
-    for (int i = 0; i < nf; i++) src[i] = (hevc_frame*)oracle_hevc_dec_frame(d, i);
+    for (int i = 0; i < nf; i++) src[i] = dec[i];
   }
   bytebuf bb = {0, 0, 0};
-  int rc = oracle_hevc_encode(&ep, (const hevc_frame* const*)src, nf, &bb, NULL);
+  int rc = encode_any_size(&ep, (const hevc_frame* const*)src, nf, &bb, NULL);
   if (own) for (int i = 0; i < nf; i++) hevc_frame_free(src[i]);
+  if (has_crop(crop)) for (int i = 0; i < nf; i++) hevc_frame_free(dec[i]);
+  free(dec);
   free(src); oracle_hevc_dec_destroy(d);
   if (rc) { free(bb.d); return rc; }
   *out = bb.d; *n_out = bb.n;

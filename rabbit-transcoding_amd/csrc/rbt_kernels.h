@@ -40,7 +40,8 @@ void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* fra
 void launch_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_luma_samples);
 
 // encode (RBT-E1)
-void launch_pool(const uint16_t* in, int w, int h, int factor, uint16_t* out, uint16_t* out_cb, uint16_t* out_cr, int chroma_value);
+void launch_pool(const uint16_t* in, int stride, int w, int h, int factor, uint16_t* out, uint16_t* out_cb, uint16_t* out_cr, int chroma_value);   // w x h region of a plane with row stride `stride`
+void launch_pad(const uint16_t* in, int stride, int x0, int y0, int w, int h, uint16_t* out, int dw, int dh);
 void launch_enc_analyse(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs);
 // row_mode != 0: every slice is one CTB row, rows are independent and each wave walks its row;
 // otherwise CTBs are scheduled on anti-diagonals like the decoder's reconstruction

@@ -158,7 +158,7 @@ void launch_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_l
 }
 
 // ---------------------------------------------------------------------------------------------- encode kernels
-__global__ void __launch_bounds__(256) k_pool(const uint16_t* in, int w, int factor, uint16_t* out, int ow, int oh, uint16_t* out_cb, uint16_t* out_cr, int chroma_value) {
+__global__ void __launch_bounds__(256) k_pool(const uint16_t* in, int w, int factor, uint16_t* out, int ow, int oh, uint16_t* out_cb, uint16_t* out_cr, int chroma_value) {   // w = row stride of `in`
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i < ow * oh) en_pool_sample(in, w, factor, out, ow, i % ow, i / ow);
   if (i < (ow / 2) * (oh / 2)) { out_cb[i] = (uint16_t)chroma_value; out_cr[i] = (uint16_t)chroma_value; }
@@ -206,9 +206,20 @@ void launch_pack(const uint8_t* out, const RbtSlice* slices, const uint32_t* dst
   if (n_slices <= 0) return;
   hipLaunchKernelGGL(k_pack, dim3(n_slices), dim3(256), 0, g_stream, out, slices, dst_off, packed);
 }
-void launch_pool(const uint16_t* in, int w, int h, int factor, uint16_t* out, uint16_t* out_cb, uint16_t* out_cr, int chroma_value) {
+// copies the w x h region at (x0,y0) of a plane with row stride `stride` into a dw x dh plane, repeating the last column / row
+// (source pictures of sizes the coded picture size has to be padded up to, conformance window 7.4.3.2.1)
+__global__ void __launch_bounds__(256) k_pad(const uint16_t* in, int stride, int x0, int y0, int w, int h, uint16_t* out, int dw, int dh) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= dw * dh) return;
+  int x = i % dw, y = i / dw;
+  out[i] = in[(size_t)(y0 + (y < h ? y : h - 1)) * stride + x0 + (x < w ? x : w - 1)];
+}
+void launch_pad(const uint16_t* in, int stride, int x0, int y0, int w, int h, uint16_t* out, int dw, int dh) {
+  hipLaunchKernelGGL(k_pad, dim3((dw * dh + 255) / 256), dim3(256), 0, g_stream, in, stride, x0, y0, w, h, out, dw, dh);
+}
+void launch_pool(const uint16_t* in, int stride, int w, int h, int factor, uint16_t* out, uint16_t* out_cb, uint16_t* out_cr, int chroma_value) {
   int ow = w / factor, oh = h / factor;
-  hipLaunchKernelGGL(k_pool, dim3((ow * oh + 255) / 256), dim3(256), 0, g_stream, in, w, factor, out, ow, oh, out_cb, out_cr, chroma_value);
+  hipLaunchKernelGGL(k_pool, dim3((ow * oh + 255) / 256), dim3(256), 0, g_stream, in, stride, factor, out, ow, oh, out_cb, out_cr, chroma_value);
 }
 void launch_enc_analyse(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs) {
   if (n_frames <= 0) return;

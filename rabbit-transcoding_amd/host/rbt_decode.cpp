@@ -232,21 +232,34 @@ int decode_fetch(DecodeBatch& b, int stream, rbt_video* out, bool verify_md5) {
   memset(out, 0, sizeof(*out));
   int first = b.stream_first[stream], n = b.stream_count[stream];
   if (n <= 0) return RBT_ERR_BITSTREAM;
-  const RbtStreamCfg& c = b.frames[first].cfg;
-  size_t fs = frame_samples(c);
-  out->width = c.w; out->height = c.h; out->bit_depth = c.bit_depth; out->n_frames = n;
-  out->data = (uint16_t*)malloc(fs * 2 * (size_t)n);
+  const RbtStreamCfg& c = b.frames[first].cfg; const Sps& sps = b.stream_sps[stream];
+  // output = coded picture minus the conformance window (7.4.3.2.1); the picture hash covers the whole coded picture
+  const int cl = 2 * sps.conf_win[0], ct = 2 * sps.conf_win[2], dw = c.w - cl - 2 * sps.conf_win[1], dh = c.h - ct - 2 * sps.conf_win[3];
+  if (dw <= 0 || dh <= 0) return RBT_ERR_BITSTREAM;
+  const bool crop = dw != c.w || dh != c.h;
+  size_t fs = frame_samples(c), ofs = (size_t)dw * dh + 2 * (size_t)(dw / 2) * (dh / 2);
+  out->width = dw; out->height = dh; out->bit_depth = c.bit_depth; out->n_frames = n;
+  out->data = (uint16_t*)malloc(ofs * 2 * (size_t)n);
   if (!out->data) return RBT_ERR_NOMEM;
+  std::vector<uint16_t> full(crop || verify_md5 ? fs : 0);
   for (int i = 0; i < n; i++) {
     const RbtFrame& f = b.frames[first + i];
-    if (rbtk::d2h(out->data + fs * (size_t)i, f.out[0], fs * 2)) return RBT_ERR_NO_DEVICE;
+    uint16_t* dst = out->data + ofs * (size_t)i;
+    uint16_t* p = crop ? full.data() : dst;
+    if (rbtk::d2h(p, f.out[0], fs * 2)) return RBT_ERR_NO_DEVICE;
     if (verify_md5 && b.info[first + i].has_md5) {
       out->md5_checked++;
-      const uint16_t* p = out->data + fs * (size_t)i; uint8_t h[16]; bool bad = false;
+      uint8_t h[16]; bool bad = false;
       md5_plane_u16(p, c.w, c.h, c.bit_depth, h); bad |= memcmp(h, b.info[first + i].md5[0], 16) != 0;
       md5_plane_u16(p + (size_t)c.w * c.h, c.cw, c.ch, c.bit_depth, h); bad |= memcmp(h, b.info[first + i].md5[1], 16) != 0;
       md5_plane_u16(p + (size_t)c.w * c.h + (size_t)c.cw * c.ch, c.cw, c.ch, c.bit_depth, h); bad |= memcmp(h, b.info[first + i].md5[2], 16) != 0;
       if (bad) out->md5_failed++;
+    }
+    if (crop) {
+      const uint16_t* src = full.data(); uint16_t* d = dst;
+      for (int k = 0; k < 3; k++) { const int sh = k ? 1 : 0, pw = c.w >> sh, ph = c.h >> sh, ow = dw >> sh, oh = dh >> sh;
+        for (int y = 0; y < oh; y++) memcpy(d + (size_t)y * ow, src + (size_t)(y + (ct >> sh)) * pw + (cl >> sh), (size_t)ow * 2);
+        src += (size_t)pw * ph; d += (size_t)ow * oh; }
     }
   }
   return 0;

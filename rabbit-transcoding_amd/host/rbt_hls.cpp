@@ -252,7 +252,8 @@ void write_param_sets(std::vector<uint8_t>& out, const Sps& s, const Pps& p) {
   BitWriter w;
   w.u(0, 4); w.u(0, 3); w.bit(1);
   write_ptl(w, s.bit_depth);
-  w.ue(0); w.ue(1); w.ue(s.width); w.ue(s.height); w.bit(0);
+  w.ue(0); w.ue(1); w.ue(s.width); w.ue(s.height);
+  if (s.conf_win[0] | s.conf_win[1] | s.conf_win[2] | s.conf_win[3]) { w.bit(1); for (int i = 0; i < 4; i++) w.ue(s.conf_win[i]); } else w.bit(0);
   w.ue(s.bit_depth - 8); w.ue(s.bit_depth - 8); w.ue(s.log2_max_poc_lsb - 4);
   w.bit(1); w.ue(s.max_dec_pic_buffering - 1); w.ue(0); w.ue(0);
   w.ue(s.log2_min_cb - 3); w.ue(s.log2_diff_max_min_cb); w.ue(s.log2_min_tb - 2); w.ue(s.log2_diff_max_min_tb);

@@ -13,9 +13,13 @@ namespace rbt {
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct EncStreamDesc {
-  int w, h, bd, n_frames, qp, i_qp_offset, gop, lossless, log2_ctb, rows, md5;
+  int w, h, bd, n_frames, qp, i_qp_offset, gop, lossless, log2_ctb, rows, md5;   // w, h: display size (any even numbers)
   std::vector<const uint16_t*> src[3];   // device planes per frame
+  int src_stride = 0, src_x0 = 0, src_y0 = 0;   // the planes are views: luma row stride (0 = w) and origin of the w x h region (luma samples)
 };
+// Pictures are coded at the display size rounded up to 8 (all-intra) or 16 (I,P pairs: 16x16 inter CUs) and the padding is
+// signalled as the conformance window (7.4.3.2.1), like libx265 does for the reference (PCCTranscoder.cpp:706).
+struct PadJob { const uint16_t* in; int stride, x0, y0, w, h; uint16_t* out; int dw, dh; };
 struct EncodeBatch {
   std::vector<EncStreamDesc> desc;
   std::vector<Sps> sps; std::vector<Pps> pps;
@@ -24,6 +28,7 @@ struct EncodeBatch {
   void* arena = nullptr; size_t arena_size = 0;
   RbtFrame* d_frames = nullptr; RbtSlice* d_slices = nullptr; int32_t* d_lists = nullptr; uint8_t* d_out = nullptr; uint8_t* d_packed = nullptr; uint32_t* d_dst = nullptr;
   size_t out_total = 0;
+  std::vector<PadJob> pad_jobs;                 // source pictures that have to be copied into padded planes before the encoder reads them
   std::vector<std::vector<uint16_t>> cs_keep;   // host staging of the ctb->slice maps, alive until the copies have completed
   int main_stream = 0, aux_stream = -1;          // aux_stream >= 0: the intra part was enqueued there (its timers live there)
   std::vector<int32_t> lists_keep; size_t off_i = 0, off_ideb = 0, off_p = 0, off_sl = 0, off_sl_p = 0; int n_i = 0, n_ideb = 0, n_p = 0, n_sl_i = 0, n_sl_p = 0;   // index lists (encode_upload_lists)
@@ -31,13 +36,15 @@ struct EncodeBatch {
   ~EncodeBatch() { rbtk::dev_free(arena); }
 };
 
+static int coded_size(int v, int gop) { int al = gop > 1 ? 16 : 8; return (v + al - 1) / al * al; }
 static void make_param_sets(const EncStreamDesc& d, Sps& s, Pps& p) {
   s = Sps(); p = Pps();
-  s.valid = true; s.width = d.w; s.height = d.h; s.bit_depth = d.bd; s.log2_max_poc_lsb = 8; s.max_dec_pic_buffering = 3;
+  const int cw = coded_size(d.w, d.gop), ch = coded_size(d.h, d.gop);
+  s.valid = true; s.width = cw; s.height = ch; s.conf_win[1] = (cw - d.w) / 2; s.conf_win[3] = (ch - d.h) / 2; s.bit_depth = d.bd; s.log2_max_poc_lsb = 8; s.max_dec_pic_buffering = 3;
   s.log2_ctb = d.log2_ctb ? d.log2_ctb : 5; s.log2_min_cb = 3; s.log2_diff_max_min_cb = s.log2_ctb - 3;
   s.log2_min_tb = 2; s.log2_max_tb = std::min(5, s.log2_ctb); s.log2_diff_max_min_tb = s.log2_max_tb - 2;
   s.num_st_rps = 1;
-  s.w_ctb = (d.w + (1 << s.log2_ctb) - 1) >> s.log2_ctb; s.h_ctb = (d.h + (1 << s.log2_ctb) - 1) >> s.log2_ctb;
+  s.w_ctb = (cw + (1 << s.log2_ctb) - 1) >> s.log2_ctb; s.h_ctb = (ch + (1 << s.log2_ctb) - 1) >> s.log2_ctb;
   p.valid = true; p.num_ref_idx_default = 1; p.init_qp = std::min(51, std::max(0, d.qp)); p.loop_filter_across_slices = 1;
   if (d.lossless) { p.transquant_bypass = 1; p.deblocking_control_present = 1; p.pps_deblocking_disabled = 1; p.loop_filter_across_slices = 0; }
 }
@@ -47,8 +54,7 @@ static int encode_build(EncodeBatch& b) {
   b.sps.resize(ns); b.pps.resize(ns); b.stream_first.resize(ns);
   for (size_t si = 0; si < ns; si++) {
     const EncStreamDesc& d = b.desc[si];
-    if (d.w % 8 || d.h % 8 || d.w <= 0 || d.h <= 0 || d.w > 8192 || d.h > 8192) { b.err = "picture size must be a multiple of 8"; return RBT_ERR_UNSUPPORTED; }
-    if (d.gop > 1 && (d.w % 16 || d.h % 16)) { b.err = "gop=2 needs a picture size that is a multiple of 16"; return RBT_ERR_UNSUPPORTED; }
+    if (d.w % 2 || d.h % 2 || d.w <= 0 || d.h <= 0 || d.w > 8192 || d.h > 8192) { b.err = "picture size must be even and at most 8192"; return RBT_ERR_UNSUPPORTED; }
     if (d.log2_ctb && (d.log2_ctb < 4 || d.log2_ctb > 6)) { b.err = "log2_ctb must be 4..6"; return RBT_ERR_PARAM; }
     make_param_sets(d, b.sps[si], b.pps[si]);
     const Sps& s = b.sps[si]; const Pps& p = b.pps[si];
@@ -58,7 +64,7 @@ static int encode_build(EncodeBatch& b) {
       RbtFrame f; memset(&f, 0, sizeof(f));
       fill_stream_cfg(s, p, f.cfg);
       f.poc = is_i ? 0 : (i % d.gop); f.level = is_i ? 0 : 1; f.first_slice = (int)b.slices.size();
-      f.w8 = d.w / 8; f.h8 = d.h / 8; f.lossless = d.lossless; f.ref_frame = is_i ? -1 : (int)b.frames.size() - 1; f.ref_poc = is_i ? 0 : f.poc - 1;
+      f.w8 = s.width / 8; f.h8 = s.height / 8; f.lossless = d.lossless; f.ref_frame = is_i ? -1 : (int)b.frames.size() - 1; f.ref_poc = is_i ? 0 : f.poc - 1;
       for (int c = 0; c < 3; c++) f.src[c] = d.src[c][i];
       int n_ctb = s.w_ctb * s.h_ctb, step = d.rows > 0 ? d.rows * s.w_ctb : n_ctb;
       for (int addr = 0; addr < n_ctb; addr += step) {
@@ -71,7 +77,7 @@ static int encode_build(EncodeBatch& b) {
         if (!is_i) { sl.ref_frame[0] = f.ref_frame; sl.ref_poc[0] = f.ref_poc; }
         // worst-case slice data: raw samples of the slice at 2 bytes each plus slack
         size_t rows = (size_t)(sl.n_ctbs + s.w_ctb - 1) / s.w_ctb;
-        sl.out_cap = (uint32_t)(rows * ((size_t)d.w << s.log2_ctb) * 3 + 4096);
+        sl.out_cap = (uint32_t)(rows * ((size_t)s.width << s.log2_ctb) * 3 + 4096);
         f.n_slices++;
         b.slices.push_back(sl);
       }
@@ -81,9 +87,11 @@ static int encode_build(EncodeBatch& b) {
   if (b.slices.size() >= 0xFFFF) { b.err = "too many slice segments in one call"; return RBT_ERR_UNSUPPORTED; }
   // ---- HBM layout ----
   Arena a; size_t nf = b.frames.size();
-  std::vector<size_t> o_pix(nf), o_coef(nf), o_pm(nf), o_edges(nf), o_qp(nf), o_mv(nf), o_ref(nf), o_refpoc(nf), o_cs(nf), o_cul(nf), o_cum(nf), o_cuf(nf);
+  std::vector<size_t> o_src(nf, (size_t)-1), o_pix(nf), o_coef(nf), o_pm(nf), o_edges(nf), o_qp(nf), o_mv(nf), o_ref(nf), o_refpoc(nf), o_cs(nf), o_cul(nf), o_cum(nf), o_cuf(nf);
   for (size_t i = 0; i < nf; i++) {
     const RbtStreamCfg& c = b.frames[i].cfg; size_t u = (size_t)c.w4 * c.h4, nc = (size_t)c.w_ctb * c.h_ctb, u8 = (size_t)b.frames[i].w8 * b.frames[i].h8;
+    { const EncStreamDesc& d = b.desc[b.frame_stream[i]];
+      if (c.w != d.w || c.h != d.h || d.src_x0 || d.src_y0 || (d.src_stride && d.src_stride != d.w)) o_src[i] = a.reserve(frame_samples(c) * 2); }
     o_pix[i] = a.reserve(frame_samples(c) * 2); o_coef[i] = a.reserve(frame_samples(c) * 2);
     o_pm[i] = a.reserve(u); o_edges[i] = a.reserve(u); o_qp[i] = a.reserve(u); o_mv[i] = a.reserve(u * 4); o_ref[i] = a.reserve(u); o_refpoc[i] = a.reserve(u * 4);
     o_cs[i] = a.reserve(nc * 2); o_cul[i] = a.reserve(u8); o_cum[i] = a.reserve(u8); o_cuf[i] = a.reserve(u8);
@@ -103,6 +111,12 @@ static int encode_build(EncodeBatch& b) {
     RbtFrame& f = b.frames[i]; const RbtStreamCfg& c = f.cfg; size_t ys = (size_t)c.w * c.h, cs = (size_t)c.cw * c.ch;
     f.pix[0] = (uint16_t*)(base + o_pix[i]); f.pix[1] = f.pix[0] + ys; f.pix[2] = f.pix[1] + cs;
     for (int k = 0; k < 3; k++) f.out[k] = f.pix[k];
+    if (o_src[i] != (size_t)-1) {
+      const EncStreamDesc& d = b.desc[b.frame_stream[i]]; const int st = d.src_stride ? d.src_stride : d.w;
+      uint16_t* pl[3] = {(uint16_t*)(base + o_src[i]), nullptr, nullptr}; pl[1] = pl[0] + ys; pl[2] = pl[1] + cs;
+      for (int k = 0; k < 3; k++) { const int sh = k ? 1 : 0;
+        b.pad_jobs.push_back(PadJob{f.src[k], st >> sh, d.src_x0 >> sh, d.src_y0 >> sh, d.w >> sh, d.h >> sh, pl[k], c.w >> sh, c.h >> sh}); f.src[k] = pl[k]; }
+    }
     f.coef[0] = (int16_t*)(base + o_coef[i]); f.coef[1] = f.coef[0] + ys; f.coef[2] = f.coef[1] + cs;
     f.pm = base + o_pm[i]; f.edges = base + o_edges[i]; f.qp = (int8_t*)(base + o_qp[i]); f.mv = (int16_t*)(base + o_mv[i]); f.ref = (int8_t*)(base + o_ref[i]);
     f.refpoc = (int32_t*)(base + o_refpoc[i]); f.ctb_slice = (uint16_t*)(base + o_cs[i]);
@@ -137,6 +151,7 @@ static int encode_upload_lists(EncodeBatch& b) {
 // intra pictures (analysis, closed-loop intra coding, deblocking): they only read their own source pictures
 static void encode_launch_intra(EncodeBatch& b) {
   size_t nf = b.frames.size();
+  for (const PadJob& j : b.pad_jobs) rbtk::launch_pad(j.in, j.stride, j.x0, j.y0, j.w, j.h, j.out, j.dw, j.dh);
   int mw = 0, mh = 0, mu = 0, mc = 0, row_mode = 1;
   for (size_t i = 0; i < nf; i++) {
     const RbtStreamCfg& c = b.frames[i].cfg; mw = std::max(mw, c.w_ctb); mh = std::max(mh, c.h_ctb); mu = std::max(mu, c.w4 * c.h4); mc = std::max(mc, c.w_ctb * c.h_ctb);
@@ -240,19 +255,23 @@ static int hand_out(const std::vector<std::vector<uint8_t>>& outs, uint8_t** out
 // exceeds the single maximum by more than the hidden reconstruction saves (4 bands: 311.9 ms, 2 bands: 302.6 ms, off:
 // 297.3 ms). Off by default; RBT_PARSE_BANDS=<n> in the environment turns it on for experiments.
 static int parse_bands() { static int v = -1; if (v < 0) { const char* e = getenv("RBT_PARSE_BANDS"); v = e ? atoi(e) : 1; if (v < 1) v = 1; if (v > 16) v = 16; } return v; }
-struct PoolJob { const uint16_t* in; int w, h; uint16_t *y, *cb, *cr; int grey; };
+struct PoolJob { const uint16_t* in; int stride, w, h; uint16_t *y, *cb, *cr; int grey; };
 // pool_jobs != nullptr: the OR-pool launches are recorded instead of issued (the decoder's kernels are not enqueued yet)
 static int setup_encode(DecodeBatch& db, const rbt_stream_params& p, EncodeBatch& eb, std::vector<void*>& pooled, std::string& err, std::vector<PoolJob>* pool_jobs = nullptr) {
   eb.desc.resize(1);
   EncStreamDesc& d = eb.desc[0]; int first = db.stream_first[0], cnt = db.stream_count[0];
-  const RbtStreamCfg& c = db.frames[first].cfg;
+  const RbtStreamCfg& c = db.frames[first].cfg; const Sps& isps = db.stream_sps[0];
+  // what a player shows of the input: the coded picture minus its conformance window
+  const int cl = 2 * isps.conf_win[0], ct = 2 * isps.conf_win[2], dw = c.w - cl - 2 * isps.conf_win[1], dh = c.h - ct - 2 * isps.conf_win[3];
+  if (dw <= 0 || dh <= 0) { err = "empty conformance window"; return RBT_ERR_BITSTREAM; }
   d.bd = c.bit_depth; d.n_frames = cnt; d.qp = p.qp; d.log2_ctb = p.log2_ctb; d.rows = p.ctb_rows_per_slice; d.md5 = p.md5_sei;
   for (int k = 0; k < 3; k++) d.src[k].resize(cnt);
+  auto view = [&](int k, int q) { return (const uint16_t*)db.frames[first + k].out[q]; };
   if (p.video_type == RBT_VIDEO_OCCUPANCY) {
     int factor = p.occupancy_precision / 2; if (factor < 1) factor = 1;
-    d.gop = 1; d.lossless = 1; d.i_qp_offset = 0; d.w = c.w / factor; d.h = c.h / factor;
+    d.gop = 1; d.lossless = 1; d.i_qp_offset = 0; d.w = dw / factor; d.h = dh / factor;
     if (p.occupancy_precision == 4) {
-      if (c.w % 4 || c.h % 4) { err = "occupancy map size must be a multiple of 4 to pool"; return RBT_ERR_UNSUPPORTED; }
+      if (dw % 4 || dh % 4) { err = "occupancy map size must be a multiple of 4 to pool"; return RBT_ERR_UNSUPPORTED; }
       size_t ys = (size_t)d.w * d.h, cs = (size_t)(d.w / 2) * (d.h / 2);
       uint16_t* buf = (uint16_t*)rbtk::dev_alloc((ys + 2 * cs) * 2 * (size_t)cnt);
       if (!buf) { err = "device allocation failed"; return RBT_ERR_NOMEM; }
@@ -260,16 +279,18 @@ static int setup_encode(DecodeBatch& db, const rbt_stream_params& p, EncodeBatch
       if (!pool_jobs) rbtk::timer_begin(T_POOL);
       for (int k = 0; k < cnt; k++) {
         uint16_t* y = buf + (ys + 2 * cs) * (size_t)k;
+        const uint16_t* in = view(k, 0) + (size_t)ct * c.w + cl;
         // the reference leaves the pooled chroma planes unwritten (PCCTranscoder.cpp:638-641); mid-grey here
-        if (pool_jobs) pool_jobs->push_back(PoolJob{db.frames[first + k].out[0], c.w, c.h, y, y + ys, y + ys + cs, 1 << (c.bit_depth - 1)});
-        else rbtk::launch_pool(db.frames[first + k].out[0], c.w, c.h, 2, y, y + ys, y + ys + cs, 1 << (c.bit_depth - 1));
+        if (pool_jobs) pool_jobs->push_back(PoolJob{in, c.w, dw, dh, y, y + ys, y + ys + cs, 1 << (c.bit_depth - 1)});
+        else rbtk::launch_pool(in, c.w, dw, dh, 2, y, y + ys, y + ys + cs, 1 << (c.bit_depth - 1));
         d.src[0][k] = y; d.src[1][k] = y + ys; d.src[2][k] = y + ys + cs;
       }
       if (!pool_jobs) rbtk::timer_end(T_POOL);
-    } else for (int k = 0; k < cnt; k++) for (int q = 0; q < 3; q++) d.src[q][k] = db.frames[first + k].out[q];
+    } else { d.src_stride = c.w; d.src_x0 = cl; d.src_y0 = ct; for (int k = 0; k < cnt; k++) for (int q = 0; q < 3; q++) d.src[q][k] = view(k, q); }
   } else {
-    d.gop = 2; d.lossless = 0; d.i_qp_offset = -3; d.w = c.w; d.h = c.h;
-    for (int k = 0; k < cnt; k++) for (int q = 0; q < 3; q++) d.src[q][k] = db.frames[first + k].out[q];
+    d.gop = 2; d.lossless = 0; d.i_qp_offset = -3; d.w = dw; d.h = dh;
+    d.src_stride = c.w; d.src_x0 = cl; d.src_y0 = ct;
+    for (int k = 0; k < cnt; k++) for (int q = 0; q < 3; q++) d.src[q][k] = view(k, q);
   }
   return 0;
 }
@@ -316,7 +337,7 @@ int transcode_gof(rbt_stats& st, std::string& err, int n, const uint8_t* const* 
     size_t n_levels = db[i].level_frames.size(), fork_level = 0;
     for (size_t q = 0; q < e.frames.size(); q++) if (e.frame_is_idr[q]) fork_level = std::max(fork_level, (size_t)db[i].frames[db[i].stream_first[0] + (int)q].level);
     int intra_done = 0;
-    const bool fork = k == 0 && n <= rbtk::RBT_AUX_STREAM && jobs.empty() && fork_level + 1 < n_levels;   // longest pipeline only: one spare stream
+    const bool fork = k == 0 && n <= rbtk::RBT_AUX_STREAM && jobs.empty() && e.pad_jobs.empty() && fork_level + 1 < n_levels;   // longest pipeline only: one spare stream
     const bool banded = db[i].d_save != nullptr && !db[i].ordered_parse;
     rc = banded ? decode_launch_chunked(db[i], parse_bands(), i, rbtk::RBT_AUX_STREAM) : decode_launch_parse(db[i]);
     if (rc) { err = db[i].err; break; }
@@ -330,7 +351,7 @@ int transcode_gof(rbt_stats& st, std::string& err, int n, const uint8_t* const* 
       }
     }
     rbtk::timer_end(T_RECON);
-    if (!jobs.empty()) { rbtk::timer_begin(T_POOL); for (const PoolJob& j : jobs) rbtk::launch_pool(j.in, j.w, j.h, 2, j.y, j.cb, j.cr, j.grey); rbtk::timer_end(T_POOL); }
+    if (!jobs.empty()) { rbtk::timer_begin(T_POOL); for (const PoolJob& j : jobs) rbtk::launch_pool(j.in, j.stride, j.w, j.h, 2, j.y, j.cb, j.cr, j.grey); rbtk::timer_end(T_POOL); }
     if (fork) rbtk::stream_wait_mark(i, intra_done); else { encode_launch_intra(e); encode_launch_entropy_intra(e); }
     encode_launch_rest(e);
     if (fork) rbtk::stream_wait(i, e.aux_stream);      // the intra pictures' entropy coding on the auxiliary stream
@@ -379,7 +400,7 @@ int encode_yuv(rbt_stats& st, std::string& err, const uint16_t* yuv, int w, int 
                uint8_t** out, size_t* n_out) {
   memset(&st, 0, sizeof(st));
   *out = nullptr; *n_out = 0;
-  if (w <= 0 || h <= 0 || w % 8 || h % 8 || bd < 8 || bd > 12) { err = "bad picture format"; return RBT_ERR_PARAM; }
+  if (w <= 0 || h <= 0 || w % 2 || h % 2 || bd < 8 || bd > 12) { err = "bad picture format"; return RBT_ERR_PARAM; }
   size_t ys = (size_t)w * h, cs = (size_t)(w / 2) * (h / 2), fs = ys + 2 * cs;
   uint16_t* buf = (uint16_t*)rbtk::dev_alloc(fs * 2 * (size_t)n_frames);
   if (!buf) { err = "device allocation failed"; return RBT_ERR_NOMEM; }
@@ -404,7 +425,7 @@ int or_pool_host(const uint16_t* plane, int w, int h, int factor, uint16_t* out)
   if (!buf) return RBT_ERR_NOMEM;
   struct G { void* p; ~G() { rbtk::dev_free(p); } } g{buf};
   if (rbtk::h2d(buf, plane, in_n * 2)) return RBT_ERR_NO_DEVICE;
-  rbtk::launch_pool(buf, w, h, factor, buf + in_n, buf + in_n + out_n, buf + in_n + out_n + out_n / 4, 0);
+  rbtk::launch_pool(buf, w, w, h, factor, buf + in_n, buf + in_n + out_n, buf + in_n + out_n + out_n / 4, 0);
   if (rbtk::d2h(out, buf + in_n, out_n * 2)) return RBT_ERR_NO_DEVICE;
   return 0;
 }

@@ -25,7 +25,8 @@ def main():
     open(os.path.join(HERE, "hevc_rom_tables.json"), "w").write(tables)
     cfgs = {"geo10_gop2": dict(w=64, h=64, bd=10, qp=24, gop=2, lossless=0, log2_ctb=5, rows=1),
             "occ8_lossless": dict(w=64, h=32, bd=8, qp=8, gop=1, lossless=1, log2_ctb=5, rows=1),
-            "attr10_ctb64_oneslice": dict(w=128, h=64, bd=10, qp=22, gop=2, lossless=0, log2_ctb=6, rows=0)}
+            "attr10_ctb64_oneslice": dict(w=128, h=64, bd=10, qp=22, gop=2, lossless=0, log2_ctb=6, rows=0),
+            "occ8_window_40x44": dict(w=40, h=44, bd=8, qp=8, gop=1, lossless=1, log2_ctb=5, rows=1)}   # coded 40x48, conformance window
     for name, c in cfgs.items():
         fr = np.full((2, c["w"] * c["h"] * 3 // 2), 100, np.uint16)
         bs, _ = O.encode(fr, c["w"], c["h"], c["bd"], c["qp"], gop=c["gop"], lossless=c["lossless"], log2_ctb=c["log2_ctb"], rows_per_slice=c["rows"])

@@ -100,7 +100,8 @@ def test_transcode_substream_pipeline():
 
 @pytest.mark.parametrize("name,cfg", [("geo10_gop2", dict(w=64, h=64, bd=10, qp=24, gop=2, lossless=0, log2_ctb=5, rows=1)),
                                       ("occ8_lossless", dict(w=64, h=32, bd=8, qp=8, gop=1, lossless=1, log2_ctb=5, rows=1)),
-                                      ("attr10_ctb64_oneslice", dict(w=128, h=64, bd=10, qp=22, gop=2, lossless=0, log2_ctb=6, rows=0))])
+                                      ("attr10_ctb64_oneslice", dict(w=128, h=64, bd=10, qp=22, gop=2, lossless=0, log2_ctb=6, rows=0)),
+                                      ("occ8_window_40x44", dict(w=40, h=44, bd=8, qp=8, gop=1, lossless=1, log2_ctb=5, rows=1, coded=(40, 48)))])
 def test_parameter_sets_match_reference_parser_golden(name, cfg):
     """The committed hls_*.json is what the REFERENCE's TDecCavlc read from the oracle encoder's VPS/SPS/PPS."""
     fr = np.full((2, cfg["w"] * cfg["h"] * 3 // 2), 100, np.uint16)
@@ -109,6 +110,9 @@ def test_parameter_sets_match_reference_parser_golden(name, cfg):
     parsed = json.load(open(os.path.join(GOLD, f"hls_{name}.json")))
     sps = [p for p in parsed if p["nal"] == "SPS"][0]
     pps = [p for p in parsed if p["nal"] == "PPS"][0]
-    assert (sps["width"], sps["height"], sps["bit_depth"], sps["bit_depth_c"], sps["chroma_format"]) == (cfg["w"], cfg["h"], cfg["bd"], cfg["bd"], 1)
+    # with a conformance window the SPS carries the CODED size; the bit depths sit after the window fields, so reading them
+    # right means the reference parser consumed the window syntax
+    cw, ch = cfg.get("coded", (cfg["w"], cfg["h"]))
+    assert (sps["width"], sps["height"], sps["bit_depth"], sps["bit_depth_c"], sps["chroma_format"]) == (cw, ch, cfg["bd"], cfg["bd"], 1)
     assert pps["init_qp"] == cfg["qp"] and pps["tq_bypass"] == cfg["lossless"] and pps["deblock_disabled"] == cfg["lossless"]
     assert pps["sign_hiding"] == 0 and pps["cu_qp_delta"] == 0 and pps["log2_par_mrg"] == 2 and pps["num_ref_idx_l0"] == 1
