@@ -70,7 +70,9 @@ int rbt_transcode_substream(rbt_ctx* ctx, const uint8_t* annexb_in, size_t n_in,
  * kernel launches. n <= 8 streams. */
 int rbt_transcode_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out);
 
-/* The two halves exposed on their own (SURVEY.md 8(b) alternative seam; used by the parity tests). */
+/* The two halves exposed on their own (SURVEY.md 8(b) alternative seam; used by the parity tests).
+ * Picture sizes: any even width / height. Sizes that are not multiples of 8 (all-intra) / 16 (gop 2) are coded padded with a
+ * conformance window in the SPS (as libx265 does for the reference); rbt_decode returns the cropped pictures. */
 int rbt_decode(rbt_ctx* ctx, const uint8_t* annexb, size_t n, int verify_md5, rbt_video* out);
 int rbt_encode(rbt_ctx* ctx, const uint16_t* yuv, int width, int height, int bit_depth, int n_frames, int qp, int gop, int lossless,
                int log2_ctb, int ctb_rows_per_slice, int md5_sei, uint8_t** annexb_out, size_t* n_out);
