@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=1280)
     ap.add_argument("--cpu-sample", type=int, default=16, help="point-cloud frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path)")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (with --backend gloo)")
     ap.add_argument("--save-input", default=None, help="write the generated R5 input streams to this .npz file and exit")
     ap.add_argument("--load-input", default=None, help="read the R5 input streams from a file written by --save-input (keeps the input "
                     "encoder's kernels out of a profile of the transcode step); the file must come from the same size / seed")
@@ -70,11 +72,16 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
     import rbt_lib
     R = rbt_lib.module()
-    ctx = R.Context(device=local_rank, rank=rank, world=world)   # raises without a GPU: no CPU fallback
+    dev = 0 if args.share_device else local_rank
+    tdev = f"cuda:{dev}" if args.backend == "nccl" else "cpu"          # where the collectives' tensors live
+    ctx = R.Context(device=dev, rank=rank, world=world)   # raises without a GPU: no CPU fallback
 
     w, h, n_pc = args.width, args.height, args.pc_frames
     geo, attr, occ = make_gof_maps(w, h, n_pc, 1051 + 1000 * rank)
@@ -98,14 +105,14 @@ def main():
         if world > 1:
             from importlib import import_module  # noqa: F401
             gs = rbt_lib.module_file("gof_shard")
-            gs.gather_streams(outs, device=f"cuda:{local_rank}")
+            gs.gather_streams(outs, device=tdev)
         return outs
 
     def sync():
         if world > 1:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if args.backend == "nccl": torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -121,7 +128,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     steps = args.steps
