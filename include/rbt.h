@@ -66,8 +66,10 @@ const char* rbt_version(void);
 /* transcodeVideo: one Annex-B HEVC sub-bitstream of a GOF -> re-encoded Annex-B stream (malloc'd, rbt_free). */
 int rbt_transcode_substream(rbt_ctx* ctx, const uint8_t* annexb_in, size_t n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out);
 
-/* transcodeData (PCCTranscoder.cpp:145-168): the sub-bitstreams of one GOF in one call so that their pictures share
- * kernel launches. n <= 8 streams. */
+/* transcodeData (PCCTranscoder.cpp:145-168): the sub-bitstreams of one GOF in one call, each as its own pipeline on its own
+ * HIP stream. More than three streams (the sub-bitstreams of several GOFs: one GOF leaves most of an MI355X idle) are grouped
+ * by video type into three pipelines. Outputs come back in input order. */
+#define RBT_MAX_STREAMS 96
 int rbt_transcode_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out);
 
 /* The two halves exposed on their own (SURVEY.md 8(b) alternative seam; used by the parity tests).

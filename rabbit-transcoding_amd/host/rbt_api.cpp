@@ -102,7 +102,7 @@ int rbt_transcode_substream(rbt_ctx* ctx, const uint8_t* annexb_in, size_t n_in,
   return rbt_transcode_gof(ctx, 1, &annexb_in, &n_in, p, annexb_out, n_out);
 }
 int rbt_transcode_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out) {
-  if (!ctx || n < 1 || n > 8 || !annexb_in || !n_in || !p || !annexb_out || !n_out) return RBT_ERR_PARAM;
+  if (!ctx || n < 1 || n > RBT_MAX_STREAMS || !annexb_in || !n_in || !p || !annexb_out || !n_out) return RBT_ERR_PARAM;
   std::lock_guard<std::mutex> lk(g_mu);
   return rbt::transcode_gof(ctx->stats, ctx->last_err, n, annexb_in, n_in, p, annexb_out, n_out);
 }

@@ -257,10 +257,11 @@ static int hand_out(const std::vector<std::vector<uint8_t>>& outs, uint8_t** out
 static int parse_bands() { static int v = -1; if (v < 0) { const char* e = getenv("RBT_PARSE_BANDS"); v = e ? atoi(e) : 1; if (v < 1) v = 1; if (v > 16) v = 16; } return v; }
 struct PoolJob { const uint16_t* in; int stride, w, h; uint16_t *y, *cb, *cr; int grey; };
 // pool_jobs != nullptr: the OR-pool launches are recorded instead of issued (the decoder's kernels are not enqueued yet)
-static int setup_encode(DecodeBatch& db, const rbt_stream_params& p, EncodeBatch& eb, std::vector<void*>& pooled, std::string& err, std::vector<PoolJob>* pool_jobs = nullptr) {
-  eb.desc.resize(1);
-  EncStreamDesc& d = eb.desc[0]; int first = db.stream_first[0], cnt = db.stream_count[0];
-  const RbtStreamCfg& c = db.frames[first].cfg; const Sps& isps = db.stream_sps[0];
+// stream `si` of the decode batch becomes stream `si` of the encode batch
+static int setup_encode(DecodeBatch& db, int si, const rbt_stream_params& p, EncodeBatch& eb, std::vector<void*>& pooled, std::string& err, std::vector<PoolJob>* pool_jobs = nullptr) {
+  if ((int)eb.desc.size() <= si) eb.desc.resize((size_t)si + 1);
+  EncStreamDesc& d = eb.desc[si]; int first = db.stream_first[si], cnt = db.stream_count[si];
+  const RbtStreamCfg& c = db.frames[first].cfg; const Sps& isps = db.stream_sps[si];
   // what a player shows of the input: the coded picture minus its conformance window
   const int cl = 2 * isps.conf_win[0], ct = 2 * isps.conf_win[2], dw = c.w - cl - 2 * isps.conf_win[1], dh = c.h - ct - 2 * isps.conf_win[3];
   if (dw <= 0 || dh <= 0) { err = "empty conformance window"; return RBT_ERR_BITSTREAM; }
@@ -303,81 +304,100 @@ int transcode_gof(rbt_stats& st, std::string& err, int n, const uint8_t* const* 
   double t_all = now_ms();
   memset(&st, 0, sizeof(st));
   for (int i = 0; i < n; i++) { out[i] = nullptr; n_out[i] = 0; }
-  std::vector<DecodeBatch> db(n); std::vector<EncodeBatch> eb(n);
+  // Pipelines: up to three sub-bitstreams get one pipeline (= HIP stream) each. A call with more (several GOFs at once:
+  // one GOF leaves most of the GPU idle) groups them by video type, so that the slices of all attribute streams parse
+  // in one launch, all geometry streams in another, ...
+  std::vector<std::vector<int>> groups;
+  if (n <= rbtk::RBT_AUX_STREAM) for (int i = 0; i < n; i++) groups.push_back({i});
+  else {
+    const int types[3] = {RBT_VIDEO_ATTRIBUTE, RBT_VIDEO_GEOMETRY, RBT_VIDEO_OCCUPANCY};
+    for (int t = 0; t < 3; t++) { std::vector<int> g; for (int i = 0; i < n; i++) if (p[i].video_type == types[t]) g.push_back(i); if (!g.empty()) groups.push_back(g); }
+    std::vector<int> rest; for (int i = 0; i < n; i++) if (p[i].video_type != types[0] && p[i].video_type != types[1] && p[i].video_type != types[2]) rest.push_back(i);
+    if (!rest.empty()) { if (groups.size() < 3) groups.push_back(rest); else groups.back().insert(groups.back().end(), rest.begin(), rest.end()); }
+  }
+  const int ng = (int)groups.size();
+  auto bytes_of = [&](int g) { size_t t = 0; for (int i : groups[g]) t += n_in[i]; return t; };
+  std::vector<DecodeBatch> db(ng); std::vector<EncodeBatch> eb(ng);
   std::vector<void*> pooled;
   struct Guard { std::vector<void*>& v; ~Guard() { rbtk::set_stream(0); for (void* q : v) rbtk::dev_free(q); } } guard{pooled};
-  std::vector<int> order(n); for (int i = 0; i < n; i++) order[i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n_in[a] > n_in[b]; });
-  // ---- phase A, longest stream first: build decoder and encoder batches, upload, then enqueue decode -> pool -> encode on
-  // the stream without a host round trip in between (PCCTranscoder.cpp:428-448, :466, :825-904). Streams that ask for the
+  std::vector<int> order(ng); for (int i = 0; i < ng; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return bytes_of(a) > bytes_of(b); });
+  // ---- phase A, longest pipeline first: build decoder and encoder batches, upload, then enqueue decode -> pool -> encode on
+  // the stream without a host round trip in between (PCCTranscoder.cpp:428-448, :466, :825-904). Pipelines that ask for the
   // input MD5 check keep the decoder / encoder split, because the check needs the decoded pictures on the host first.
   double t_gpu = now_ms();
-  std::vector<char> chained(n, 0);
+  std::vector<char> chained(ng, 0);
   int rc = 0;
-  for (int k = 0; k < n && !rc; k++) {
-    int i = order[k]; rbtk::set_stream(i);
-    StreamIn sin{in[i], n_in[i]};
+  for (int k = 0; k < ng && !rc; k++) {
+    const int gi = order[k]; const std::vector<int>& gs = groups[gi]; rbtk::set_stream(gi);
+    std::vector<StreamIn> sins; bool verify = false;
+    for (int i : gs) { sins.push_back(StreamIn{in[i], n_in[i]}); verify |= p[i].verify_md5 != 0; }
     double t0 = now_ms();
-    db[i].want_save = parse_bands() > 1 && k == 0 && n <= rbtk::RBT_AUX_STREAM && !p[i].verify_md5;
-    rc = decode_build(db[i], &sin, 1);
+    db[gi].want_save = parse_bands() > 1 && k == 0 && ng <= rbtk::RBT_AUX_STREAM && !verify;
+    rc = decode_build(db[gi], sins.data(), (int)sins.size());
     st.host_parse_ms += now_ms() - t0;
-    if (rc) { err = db[i].err; break; }
+    if (rc) { err = db[gi].err; break; }
     std::vector<PoolJob> jobs;
-    if (!p[i].verify_md5) {
-      rc = setup_encode(db[i], p[i], eb[i], pooled, err, &jobs);
-      if (!rc) { rc = encode_build(eb[i]); if (!rc) rc = encode_upload_lists(eb[i]); if (rc) err = eb[i].err; }
+    if (!verify) {
+      for (size_t q = 0; q < gs.size() && !rc; q++) rc = setup_encode(db[gi], (int)q, p[gs[q]], eb[gi], pooled, err, &jobs);
+      if (!rc) { rc = encode_build(eb[gi]); if (!rc) rc = encode_upload_lists(eb[gi]); if (rc) err = eb[gi].err; }
       if (rc) break;
-      chained[i] = 1;
+      chained[gi] = 1;
     }
-    if (!chained[i]) { rc = decode_launch(db[i]); if (rc) { err = db[i].err; break; } continue; }
+    if (!chained[gi]) { rc = decode_launch(db[gi]); if (rc) { err = db[gi].err; break; } continue; }
     // Intra pictures of the output only read the decoded pictures they are re-encoded from. When those are complete
     // before the last dependency level of the decoder, analysis + intra coding run on an auxiliary stream underneath the
     // remaining reconstruction levels.
-    EncodeBatch& e = eb[i]; e.main_stream = i;
-    size_t n_levels = db[i].level_frames.size(), fork_level = 0;
-    for (size_t q = 0; q < e.frames.size(); q++) if (e.frame_is_idr[q]) fork_level = std::max(fork_level, (size_t)db[i].frames[db[i].stream_first[0] + (int)q].level);
+    EncodeBatch& e = eb[gi]; e.main_stream = gi;
+    size_t n_levels = db[gi].level_frames.size(), fork_level = 0;
+    for (size_t q = 0; q < e.frames.size(); q++) if (e.frame_is_idr[q]) {
+      const int si = e.frame_stream[q], local = (int)q - e.stream_first[si];
+      fork_level = std::max(fork_level, (size_t)db[gi].frames[db[gi].stream_first[si] + local].level);
+    }
     int intra_done = 0;
-    const bool fork = k == 0 && n <= rbtk::RBT_AUX_STREAM && jobs.empty() && e.pad_jobs.empty() && fork_level + 1 < n_levels;   // longest pipeline only: one spare stream
-    const bool banded = db[i].d_save != nullptr && !db[i].ordered_parse;
-    rc = banded ? decode_launch_chunked(db[i], parse_bands(), i, rbtk::RBT_AUX_STREAM) : decode_launch_parse(db[i]);
-    if (rc) { err = db[i].err; break; }
+    const bool fork = k == 0 && ng <= rbtk::RBT_AUX_STREAM && jobs.empty() && e.pad_jobs.empty() && fork_level + 1 < n_levels;   // longest pipeline only: one spare stream
+    const bool banded = db[gi].d_save != nullptr && !db[gi].ordered_parse;
+    rc = banded ? decode_launch_chunked(db[gi], parse_bands(), gi, rbtk::RBT_AUX_STREAM) : decode_launch_parse(db[gi]);
+    if (rc) { err = db[gi].err; break; }
     rbtk::timer_begin(T_RECON);
     for (size_t l = 0; l < n_levels; l++) {
-      if (!(banded && l == 0)) decode_launch_level(db[i], l);
+      if (!(banded && l == 0)) decode_launch_level(db[gi], l);
       if (fork && l == fork_level) {
         e.aux_stream = rbtk::RBT_AUX_STREAM;
-        rbtk::stream_wait(e.aux_stream, i);
-        rbtk::set_stream(e.aux_stream); encode_launch_intra(e); intra_done = rbtk::stream_mark(e.aux_stream); encode_launch_entropy_intra(e); rbtk::set_stream(i);
+        rbtk::stream_wait(e.aux_stream, gi);
+        rbtk::set_stream(e.aux_stream); encode_launch_intra(e); intra_done = rbtk::stream_mark(e.aux_stream); encode_launch_entropy_intra(e); rbtk::set_stream(gi);
       }
     }
     rbtk::timer_end(T_RECON);
     if (!jobs.empty()) { rbtk::timer_begin(T_POOL); for (const PoolJob& j : jobs) rbtk::launch_pool(j.in, j.stride, j.w, j.h, 2, j.y, j.cb, j.cr, j.grey); rbtk::timer_end(T_POOL); }
-    if (fork) rbtk::stream_wait_mark(i, intra_done); else { encode_launch_intra(e); encode_launch_entropy_intra(e); }
+    if (fork) rbtk::stream_wait_mark(gi, intra_done); else { encode_launch_intra(e); encode_launch_entropy_intra(e); }
     encode_launch_rest(e);
-    if (fork) rbtk::stream_wait(i, e.aux_stream);      // the intra pictures' entropy coding on the auxiliary stream
+    if (fork) rbtk::stream_wait(gi, e.aux_stream);      // the intra pictures' entropy coding on the auxiliary stream
   }
-  // ---- phase B, shortest stream first: one sync per stream, then slice sizes -> pack -> NAL assembly ----
+  // ---- phase B, shortest pipeline first: one sync per stream, then slice sizes -> pack -> NAL assembly ----
   std::vector<std::vector<uint8_t>> outs(n);
-  for (int k = n - 1; k >= 0; k--) {
-    int i = order[k]; rbtk::set_stream(i);
+  for (int k = ng - 1; k >= 0; k--) {
+    const int gi = order[k]; const std::vector<int>& gs = groups[gi]; rbtk::set_stream(gi);
     if (rc) { rbtk::dev_sync(); continue; }              // drain the remaining streams before their arenas are released
-    if (db[i].frames.empty()) continue;
-    rc = decode_finish(db[i]);
-    if (rc) { err = db[i].err; continue; }
+    if (db[gi].frames.empty()) continue;
+    rc = decode_finish(db[gi]);
+    if (rc) { err = db[gi].err; continue; }
     st.k_parse_ms += rbtk::timer_ms(T_PARSE); st.k_recon_ms += rbtk::timer_ms(T_RECON);
     std::vector<std::vector<uint8_t>> o1;
-    if (chained[i]) rc = encode_finish(eb[i], o1, st);
+    if (chained[gi]) rc = encode_finish(eb[gi], o1, st);
     else {
-      rbt_video v; rc = decode_fetch(db[i], 0, &v, true); free(v.data);
-      if (rc) { err = "fetch failed"; continue; }
-      if (v.md5_failed) { err = "input MD5 mismatch"; rc = RBT_ERR_MD5; continue; }
-      rc = setup_encode(db[i], p[i], eb[i], pooled, err);
+      for (size_t q = 0; q < gs.size() && !rc; q++) if (p[gs[q]].verify_md5) {
+        rbt_video v; rc = decode_fetch(db[gi], (int)q, &v, true); free(v.data);
+        if (rc) { err = "fetch failed"; break; }
+        if (v.md5_failed) { err = "input MD5 mismatch"; rc = RBT_ERR_MD5; }
+      }
+      for (size_t q = 0; q < gs.size() && !rc; q++) rc = setup_encode(db[gi], (int)q, p[gs[q]], eb[gi], pooled, err);
       if (rc) continue;
-      rc = encode_build(eb[i]);
-      if (!rc) rc = encode_run(eb[i], o1, st);
+      rc = encode_build(eb[gi]);
+      if (!rc) rc = encode_run(eb[gi], o1, st);
     }
-    if (rc) { if (err.empty()) err = eb[i].err; continue; }
-    outs[i].swap(o1[0]);
+    if (rc) { if (err.empty()) err = eb[gi].err; continue; }
+    for (size_t q = 0; q < gs.size(); q++) outs[gs[q]].swap(o1[q]);
   }
   rbtk::set_stream(0);
   if (rc) return rc;
@@ -386,11 +406,11 @@ int transcode_gof(rbt_stats& st, std::string& err, int n, const uint8_t* const* 
   // SURVEY.md 8(d) algorithmic traffic: per coded picture of S samples (2 bytes each): decode writes S, P pictures read
   // their reference once; encode reads the source S, writes the reconstruction S (I) and reads the reference (P)
   uint64_t bytes = 0;
-  for (int i = 0; i < n; i++) {
-    for (size_t k = 0; k < db[i].frames.size(); k++) { uint64_t s2 = frame_samples(db[i].frames[k].cfg) * 2; bytes += s2 + (db[i].frames[k].level ? s2 : 0); }
-    for (size_t k = 0; k < eb[i].frames.size(); k++) { uint64_t s2 = frame_samples(eb[i].frames[k].cfg) * 2; bytes += s2 + s2; }
-    bytes += n_in[i] + n_out[i];
+  for (int g = 0; g < ng; g++) {
+    for (size_t k = 0; k < db[g].frames.size(); k++) { uint64_t s2 = frame_samples(db[g].frames[k].cfg) * 2; bytes += s2 + (db[g].frames[k].level ? s2 : 0); }
+    for (size_t k = 0; k < eb[g].frames.size(); k++) { uint64_t s2 = frame_samples(eb[g].frames[k].cfg) * 2; bytes += s2 + s2; }
   }
+  for (int i = 0; i < n; i++) bytes += n_in[i] + n_out[i];
   st.algorithmic_bytes = bytes;
   st.total_ms = now_ms() - t_all;
   return rc;

@@ -135,3 +135,14 @@ def test_transcode_gof_more_streams_than_pipelines(ctx):
     assert outs[3] == O.transcode_substream(sa, 19, 42, rows_per_slice=0)
     assert outs[4] == ctx.transcode_substream(sg, 1, 28, verify_md5=1)
     assert outs[5] == O.transcode_substream(so, 0, 8)
+
+
+def test_two_gofs_in_one_call_equal_single_gof_calls(ctx):
+    """sub-bitstreams of several GOFs in one call (grouped by video type into three pipelines) give the single-GOF outputs"""
+    R = rbt_lib.module()
+    a = _r5_streams(128, 128, 2, 101); b = _r5_streams(192, 128, 1, 202)
+    P = R.StreamParams
+    ps = [P(0, 8, 4, 5, 1, 1, 0), P(1, 24, 4, 5, 1, 1, 0), P(19, 32, 4, 5, 1, 1, 0)]
+    outs = ctx.transcode_gof([a[0], a[1], a[2], b[0], b[1], b[2]], ps + ps)
+    assert outs[:3] == ctx.transcode_gof([a[0], a[1], a[2]], ps)
+    assert outs[3:] == ctx.transcode_gof([b[0], b[1], b[2]], ps)

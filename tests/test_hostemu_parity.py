@@ -81,3 +81,17 @@ def test_transcode_gof_more_streams_than_pipelines(ctx):
     assert outs[2] == O.transcode_substream(sg, 1, 32, log2_ctb=4)
     assert outs[3] == O.transcode_substream(sa, 19, 42, rows_per_slice=0)
     assert outs[4] == ctx.transcode_substream(sg, 1, 28, verify_md5=1)
+
+
+def test_two_gofs_in_one_call_equal_single_gof_calls(ctx):
+    R = rbt_lib.module()
+    def gof(w, h, n, seed):
+        geo, attr, occ = synth.make_gof(w, h, n, seed)
+        return [O.encode(occ, w // 2, h // 2, 8, 8, gop=1, lossless=1, i_qp_offset=0, log2_ctb=6, rows_per_slice=0)[0],
+                O.encode(geo, w, h, 10, 16, gop=2, log2_ctb=6, rows_per_slice=0)[0], O.encode(attr, w, h, 10, 22, gop=2, log2_ctb=6, rows_per_slice=0)[0]]
+    a, b = gof(64, 64, 2, 101), gof(128, 64, 1, 202)
+    P = R.StreamParams
+    ps = [P(0, 8, 4, 5, 1, 1, 0), P(1, 24, 4, 5, 1, 1, 0), P(19, 32, 4, 5, 1, 1, 0)]
+    outs = ctx.transcode_gof(a + b, ps + ps)
+    assert outs[:3] == ctx.transcode_gof(a, ps) and outs[3:] == ctx.transcode_gof(b, ps)
+    assert outs[1] == O.transcode_substream(a[1], 1, 24) and outs[5] == O.transcode_substream(b[2], 19, 32)
