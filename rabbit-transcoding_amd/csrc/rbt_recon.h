@@ -298,13 +298,13 @@ template <class DP> RBT_DEV void rc_mc_plane(DP dst, int dstride, int dx0, int d
 // of that chain costs a store round trip plus a load round trip (~3-5 us per TB); here the CTB's samples, its border, the
 // availability of every 4x4 unit around it and its coefficient levels are fetched into LDS once, every TB works in LDS,
 // and the finished CTB is written back with coalesced row stores.
-#define RC_TS_Y 130      // tile strides: column -1 .. 2n (left border, the CTB, the above-right CTB for row -1)
-#define RC_TS_C 66
+#define RC_TS_Y 65       // body row stride: column -1 (left border) .. n-1; the row above (-1 .. 2n-1, incl. the above-right CTB) is a separate array
+#define RC_TS_C 33
 #define RC_US 34         // unit availability stride: ux = -1 .. 32
 struct alignas(8) RbtU2 { uint32_t x, y; };
 struct RbtCtbTile {
   alignas(16) int16_t coef_y[64 * 64]; alignas(16) int16_t coef_c[2][32 * 32];   // coefficient levels of the CTB (row stride = CTB size)
-  uint16_t y[65 * RC_TS_Y]; uint16_t c[2][33 * RC_TS_C];   // sample (xx,yy) relative to the CTB at (yy + 1) * stride + xx + 1
+  uint16_t y[64 * RC_TS_Y], top_y[130]; uint16_t c[2][32 * RC_TS_C], top_c[2][66];   // sample (xx,yy) relative to the CTB: body yy * stride + xx + 1, row above: top[xx + 1]
   uint8_t uav[17 * RC_US];                                  // 4x4 luma unit (ux,uy) usable as intra reference: (uy + 1) * RC_US + ux + 1
 };
 struct RbtReconCtbLds { RbtCtbTile t; RbtReconLds rc;
@@ -331,6 +331,7 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int
   RBT_LDS_AS RbtReconLds* l = &L->rc; RBT_LDS_AS RbtCtbTile* t = &L->t;
   const int N = 1 << log2, sh = c_idx ? 1 : 0, bd = g->bit_depth, maxv = (1 << bd) - 1, n = (1 << g->log2_ctb) >> sh, n4 = (1 << g->log2_ctb) >> 2;
   RBT_LDS_AS uint16_t* tile = c_idx == 0 ? t->y : t->c[c_idx - 1]; const int S = c_idx == 0 ? RC_TS_Y : RC_TS_C;
+  const RBT_LDS_AS uint16_t* top = c_idx == 0 ? t->top_y : t->top_c[c_idx - 1];
   RBT_LDS_AS int16_t* coef = c_idx == 0 ? t->coef_y : t->coef_c[c_idx - 1];
 #ifdef RBT_PROFILE
   unsigned long long p0_ = __builtin_readcyclecounter(), p1_ = p0_, p2_ = p0_, p3_ = p0_;
@@ -360,7 +361,7 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int
     const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : (m2 ? 128 : -1));
     RBT_PAR_FOR(i, tot) {
       int v = 1 << (bd - 1);
-      if (first >= 0) { int j = rc_last_avail(i, m0, m1, m2); if (j < 0) j = first; int xn, yn; rc_nb_xy(j, x0, y0, N, &xn, &yn); v = tile[(yn + 1) * S + xn + 1]; }
+      if (first >= 0) { int j = rc_last_avail(i, m0, m1, m2); if (j < 0) j = first; int xn, yn; rc_nb_xy(j, x0, y0, N, &xn, &yn); v = yn < 0 ? top[xn + 1] : tile[yn * S + xn + 1]; }
       l->nb[i] = v;
     }
     RBT_SYNC_LDS();
@@ -372,7 +373,7 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int
 #endif
   if (intra || cbf) {
     RBT_PAR_FOR(i, N * N) {
-      int x = i & (N - 1), y = i >> log2, o = (y0 + y + 1) * S + x0 + x + 1;
+      int x = i & (N - 1), y = i >> log2, o = (y0 + y) * S + x0 + x + 1;
       int base = intra ? rc_intra_sample(&q, fin, l->ref, x, y) : tile[o];
       tile[o] = (uint16_t)(cbf ? rbt_clip3(0, maxv, base + l->res[i]) : base);
     }
@@ -419,7 +420,7 @@ RBT_DEV void rc_tile_tb_cpair(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* 
     RBT_PAR_FOR(i, 2 * tot) {
       const int b = i >= tot, idx = i - b * tot;
       int v = 1 << (bd - 1);
-      if (first >= 0) { int j = rc_last_avail(idx, m0, m1, m2); if (j < 0) j = first; int xn, yn; rc_nb_xy(j, x0, y0, N, &xn, &yn); v = t->c[b][(yn + 1) * S + xn + 1]; }
+      if (first >= 0) { int j = rc_last_avail(idx, m0, m1, m2); if (j < 0) j = first; int xn, yn; rc_nb_xy(j, x0, y0, N, &xn, &yn); v = yn < 0 ? t->top_c[b][xn + 1] : t->c[b][yn * S + xn + 1]; }
       l->nb[b * 66 + idx] = v;
     }
     RBT_SYNC_LDS();
@@ -452,7 +453,7 @@ RBT_DEV void rc_tile_tb_cpair(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* 
   }
   if (intra || cbf_cb || cbf_cr) {
     RBT_PAR_FOR(i, 2 * NN) {
-      const int b = i >= NN, j = i - b * NN, x = j & (N - 1), y = j >> log2, o = (y0 + y + 1) * S + x0 + x + 1, cbf = b ? cbf_cr : cbf_cb;
+      const int b = i >= NN, j = i - b * NN, x = j & (N - 1), y = j >> log2, o = (y0 + y) * S + x0 + x + 1, cbf = b ? cbf_cr : cbf_cb;
       RBT_LDS_AS uint16_t* tile = t->c[b];
       if (intra || cbf) {
         const int base = intra ? rc_intra_sample(b ? &q1 : &q0, l->nb + b * 66, b ? l->ref2 : l->ref, x, y) : tile[o];
@@ -496,9 +497,9 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
   // ---- fetch: borders, unit availability, coefficient levels (one HBM round trip for everything) ----
   for (int c = 0; c < 3; c++) {
     const int sh = c ? 1 : 0, nn = ctb >> sh, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, ox = cx >> sh, oy = cy >> sh, S = c ? RC_TS_C : RC_TS_Y;
-    const uint16_t* p = f->pix[c]; RBT_LDS_AS uint16_t* tile = c == 0 ? t->y : t->c[c - 1];
-    RBT_PAR_FOR(i, 2 * nn + 1) { int x = ox + i - 1, y = oy - 1; tile[i] = (x >= 0 && y >= 0 && x < pw) ? p[(size_t)y * pw + x] : 0; }
-    RBT_PAR_FOR(i, nn) { int x = ox - 1, y = oy + i; tile[(i + 1) * S] = (x >= 0 && y < ph) ? p[(size_t)y * pw + x] : 0; }
+    const uint16_t* p = f->pix[c]; RBT_LDS_AS uint16_t* tile = c == 0 ? t->y : t->c[c - 1]; RBT_LDS_AS uint16_t* top = c == 0 ? t->top_y : t->top_c[c - 1];
+    RBT_PAR_FOR(i, 2 * nn + 1) { int x = ox + i - 1, y = oy - 1; top[i] = (x >= 0 && y >= 0 && x < pw) ? p[(size_t)y * pw + x] : 0; }
+    RBT_PAR_FOR(i, nn) { int x = ox - 1, y = oy + i; tile[i * S] = (x >= 0 && y < ph) ? p[(size_t)y * pw + x] : 0; }
     // coefficient levels: 4 per lane and load (8-byte aligned: widths are multiples of 8, chroma of 4), several loads in flight
     const RbtU2* cp = (const RbtU2*)(f->coef[c] + (size_t)oy * pw + ox); RBT_LDS_AS RbtU2* cd = (RBT_LDS_AS RbtU2*)(c == 0 ? t->coef_y : t->coef_c[c - 1]);
     const int q4 = nn >> 2, lq4 = g->log2_ctb - sh - 2, rows = rbt_min(nn, ph - oy), cols4 = rbt_min(nn, pw - ox) >> 2;
@@ -528,9 +529,9 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
     if (c.type == RBT_CMD_PU) {
       const RbtFrame* ref = &frames[sl->ref_frame[c.c]];
       const int w = c.a * 4, h = c.b * 4, mvx = c.mvx, mvy = c.mvy;
-      rc_mc_plane(t->y, RC_TS_Y, x0 + 1, y0 + 1, ref->out[0], g->w, g->h, cx + x0, cy + y0, w, h, mvx >> 2, mvy >> 2, mvx & 3, mvy & 3, 8, k_luma_filter[mvx & 3], k_luma_filter[mvy & 3], g->bit_depth);
+      rc_mc_plane(t->y, RC_TS_Y, x0 + 1, y0, ref->out[0], g->w, g->h, cx + x0, cy + y0, w, h, mvx >> 2, mvy >> 2, mvx & 3, mvy & 3, 8, k_luma_filter[mvx & 3], k_luma_filter[mvy & 3], g->bit_depth);
       for (int cc = 1; cc < 3; cc++)
-        rc_mc_plane(t->c[cc - 1], RC_TS_C, (x0 >> 1) + 1, (y0 >> 1) + 1, ref->out[cc], g->cw, g->ch, (cx + x0) >> 1, (cy + y0) >> 1, w >> 1, h >> 1, mvx >> 3, mvy >> 3, mvx & 7, mvy & 7, 4,
+        rc_mc_plane(t->c[cc - 1], RC_TS_C, (x0 >> 1) + 1, y0 >> 1, ref->out[cc], g->cw, g->ch, (cx + x0) >> 1, (cy + y0) >> 1, w >> 1, h >> 1, mvx >> 3, mvy >> 3, mvx & 7, mvy & 7, 4,
                     k_chroma_filter[mvx & 7], k_chroma_filter[mvy & 7], g->bit_depth);
       rc_tile_mark(t, c.x4, c.y4, c.a, c.b, !g->cip);
     } else if (c.type == RBT_CMD_TU) {
@@ -553,7 +554,7 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
     const int sh = c ? 1 : 0, nn = ctb >> sh, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, ox = cx >> sh, oy = cy >> sh, S = c ? RC_TS_C : RC_TS_Y;
     uint16_t* p = f->pix[c]; RBT_LDS_AS uint16_t* tile = c == 0 ? t->y : t->c[c - 1];
     const int lnn = g->log2_ctb - sh;
-    RBT_PAR_FOR(i, nn * nn) { int x = i & (nn - 1), y = i >> lnn; if (ox + x < pw && oy + y < ph) p[(size_t)(oy + y) * pw + ox + x] = tile[(y + 1) * S + x + 1]; }
+    RBT_PAR_FOR(i, nn * nn) { int x = i & (nn - 1), y = i >> lnn; if (ox + x < pw && oy + y < ph) p[(size_t)(oy + y) * pw + ox + x] = tile[y * S + x + 1]; }
   }
 #ifdef RBT_PROFILE
   if (RBT_LANE0 && frame_idx == 0 && ctb_addr == 190) printf("ctb %d: fetch %llu, cmds %llu (n %u), writeback %llu; TBs %llu: residual %llu, intra prep %llu, - %llu, predict+add %llu\n", ctb_addr, q1_ - q0_, q2_ - q1_, n,
