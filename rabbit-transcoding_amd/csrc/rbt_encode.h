@@ -565,7 +565,11 @@ RBT_DEV void en_inter_ctb(RbtFrame* frames, RbtFrame* f, const RbtSlice* slices,
 
 // ------------------------------------------------------------------------------------------------ entropy coding
 struct RbtEnt { RbtFrame* f; const RbtSlice* sl; int slice_idx; RbtCabacEnc c; RBT_LDS_AS RbtEntropyLds* l;
-                int w, h, log2_ctb, log2_min_cb, tq_bypass_enabled, is_p, cx, cy; };
+                int w, h, log2_ctb, log2_min_cb, tq_bypass_enabled, is_p, cx, cy;
+#ifdef RBT_PROFILE
+                unsigned long long t_stage, t_res, t_cu, t_resA, t_resB; unsigned n_cu, n_tb, n_bins;
+#endif
+};
 // encoder scan tables use x | y << 4 in k_scan; the lane code wants sub-block entries unchanged and 4x4 positions as packed immediates
 RBT_DEV uint8_t k_scan_packed(int a, int b, int c) { return k_scan[a][b][c]; }
 
@@ -581,17 +585,22 @@ RBT_DEV int en_min_in_group(int g) { return g < 4 ? g : (2 + (g & 1)) << ((g >> 
 // serial part is bins only.
 RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, const RBT_LDS_AS int16_t* lv, int lst, int log2, int scan_idx) {
   RbtCabacEnc* c = &s->c; RBT_LDS_AS RbtEntropyLds* l = s->l;
+#ifdef RBT_PROFILE
+  unsigned long long ta_ = __builtin_readcyclecounter(); s->n_tb++;
+#endif
   log2 = RBT_UNI(log2); scan_idx = RBT_UNI(scan_idx); lst = RBT_UNI(lst);
   const int chroma = c_idx != 0;
   const uint64_t ps = en_scan4_const(scan_idx);
   const RBT_LDS_AS uint8_t* sb_scan = l->scan[scan_idx][log2 - 2];
   const int n_sb = 1 << (2 * (log2 - 2));
   RBT_VEC(int, v_sbscan); RBT_VEC(int, v_pos); RBT_VEC(int, v_cgmask);
-  RBT_VFOR(p, 64) {
-    const int e = p < n_sb ? (int)sb_scan[p] : 0; RBT_V(v_sbscan, p) = e; RBT_V(v_pos, p) = (int)((ps >> (4 * (p & 15))) & 15);
-    int m = 0;
-    if (p < n_sb) { const int xs = e & 15, ys = e >> 4; for (int n = 0; n < 16; n++) { const int q = (int)((ps >> (4 * n)) & 15); if (lv[((ys << 2) + (q >> 2)) * lst + (xs << 2) + (q & 3)]) m |= 1 << n; } }
-    RBT_V(v_cgmask, p) = m;
+  RBT_VFOR(p, 64) { RBT_V(v_sbscan, p) = p < n_sb ? (int)sb_scan[p] : 0; RBT_V(v_pos, p) = (int)((ps >> (4 * (p & 15))) & 15); RBT_V(v_cgmask, p) = 0; }
+  // significance masks of the sub-blocks: 64 (sub-block, scan position) pairs per pass, one level read per lane, a ballot
+  // gives the masks of four sub-blocks at once
+  for (int pass = 0; pass * 4 < n_sb; pass++) {
+    uint64_t nzm;
+    RBT_VBALLOT(nzm, p, 64, (pass * 4 + (p >> 4)) < n_sb && lv[(((int)sb_scan[pass * 4 + (p >> 4)] >> 4 << 2) + (RBT_V(v_pos, p) >> 2)) * lst + (((int)sb_scan[pass * 4 + (p >> 4)] & 15) << 2) + (RBT_V(v_pos, p) & 3)] != 0);
+    for (int k = 0; k < 4 && pass * 4 + k < n_sb; k++) RBT_VSET(v_cgmask, pass * 4 + k, (int)((nzm >> (16 * k)) & 0xFFFF));
   }
   uint64_t nz64; RBT_VBALLOT(nz64, p, 64, RBT_V(v_cgmask, p) != 0);
   const int last_sb = nz64 ? 63 - __builtin_clzll(nz64) : 0;
@@ -609,6 +618,9 @@ RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, const RBT_LDS_AS int16_t* l
     if (py < maxp) rbt_ce_bin_last(c, 18 + ctx_off + (py >> ctx_shift), 0);
     if (px > 3) rbt_ce_bypass_n(c, (uint32_t)(cx - en_min_in_group(px)), (px >> 1) - 1);
     if (py > 3) rbt_ce_bypass_n(c, (uint32_t)(cy - en_min_in_group(py)), (py >> 1) - 1); }
+#ifdef RBT_PROFILE
+  unsigned long long tb_ = __builtin_readcyclecounter(); s->t_resA += tb_ - ta_;
+#endif
   uint64_t csbf = 0;
   const int sbw = 1 << (log2 - 2), sig_c0 = chroma ? 27 : 0;
   int greater1_ctx = 1, first_sb_done = 0;
@@ -680,6 +692,9 @@ RBT_DEV int en_scan_idx(int is_intra, int log2, int c_idx, int mode) {
 RBT_DEV int en_u(const RbtEnt* s, int x, int y) { return (((y - s->cy) >> 3) + 1) * 9 + ((x - s->cx) >> 3) + 1; }
 // stages cu_log2 / cu_mode / cu_flags of CTB (cx,cy) and of its left column / above row (with availability) into LDS
 RBT_DEV void en_stage_ctb(RbtEnt* s, int cx, int cy) {
+#ifdef RBT_PROFILE
+  unsigned long long ts_ = __builtin_readcyclecounter();
+#endif
   const RbtFrame* f = s->f; RBT_LDS_AS RbtEntropyLds* l = s->l;
   s->cx = cx; s->cy = cy;
   const int L = s->log2_ctb, wc = (s->w + (1 << L) - 1) >> L, ac = (cy >> L) * wc + (cx >> L), my = f->ctb_slice[ac];
@@ -706,9 +721,15 @@ RBT_DEV void en_stage_ctb(RbtEnt* s, int cx, int cy) {
     }
   }
   RBT_SYNC();
+#ifdef RBT_PROFILE
+  s->t_stage += __builtin_readcyclecounter() - ts_;
+#endif
 }
 RBT_DEV void en_write_cu(RbtEnt* s, int x0, int y0, int log2, int depth) {
   RbtCabacEnc* c = &s->c; const RbtFrame* f = s->f; RBT_LDS_AS RbtEntropyLds* l = s->l;
+#ifdef RBT_PROFILE
+  unsigned long long tc_ = __builtin_readcyclecounter(); s->n_cu++;
+#endif
   x0 = RBT_UNI(x0); y0 = RBT_UNI(y0); log2 = RBT_UNI(log2);
   const int u = en_u(s, x0, y0), flags = RBT_UNI(l->cu_fl[u]), mode = RBT_UNI(l->cu_md[u]);
   const int cbf_cb = (flags & RBT_CU_CBF_CB) != 0, cbf_cr = (flags & RBT_CU_CBF_CR) != 0, cbf_y = (flags & RBT_CU_CBF_Y) != 0;
@@ -753,10 +774,16 @@ RBT_DEV void en_write_cu(RbtEnt* s, int x0, int y0, int log2, int depth) {
   rbt_ce_bin0(c, CTX_CBF_CHROMA + 0, cbf_cr);
   if (!is_p || cbf_cb || cbf_cr) rbt_ce_bin0(c, CTX_CBF_LUMA + 1, cbf_y);
   const int intra = !is_p;
+#ifdef RBT_PROFILE
+  unsigned long long tr_ = __builtin_readcyclecounter(); s->t_cu += tr_ - tc_;
+#endif
   const int ctb = 1 << s->log2_ctb, rx0 = x0 - s->cx, ry0 = y0 - s->cy;
   if (cbf_y) en_write_residual(s, 0, l->ctb_y + ry0 * ctb + rx0, ctb, log2, en_scan_idx(intra, log2, 0, mode));
   if (cbf_cb) en_write_residual(s, 1, l->ctb_c[0] + (ry0 >> 1) * (ctb >> 1) + (rx0 >> 1), ctb >> 1, log2 - 1, en_scan_idx(intra, log2 - 1, 1, mode));
   if (cbf_cr) en_write_residual(s, 2, l->ctb_c[1] + (ry0 >> 1) * (ctb >> 1) + (rx0 >> 1), ctb >> 1, log2 - 1, en_scan_idx(intra, log2 - 1, 2, mode));
+#ifdef RBT_PROFILE
+  s->t_res += __builtin_readcyclecounter() - tr_;
+#endif
   (void)depth;
 }
 RBT_DEV void en_write_quadtree(RbtEnt* s, int x0, int y0, int log2) {
@@ -802,6 +829,9 @@ RBT_DEV void en_entropy_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx,
   rbt_ctx_init(&s.c.cs, s.is_p ? 1 : 0, RBT_UNI(sl->qp));
   s.c.out = rbt_uni_ptr(out + (uint32_t)RBT_UNI(sl->out_off)); s.c.cap = (uint32_t)RBT_UNI(sl->out_cap); s.c.n = 0; s.c.overflow = 0;
   rbt_ce_start(&s.c);
+#ifdef RBT_PROFILE
+  unsigned long long tall_ = __builtin_readcyclecounter(); s.t_stage = s.t_res = s.t_cu = s.t_resA = s.t_resB = 0; s.n_cu = s.n_tb = s.n_bins = 0;
+#endif
   const int n_ctbs = RBT_UNI(sl->n_ctbs), first = RBT_UNI(sl->ctb_addr), wc = (s.w + (1 << s.log2_ctb) - 1) >> s.log2_ctb;
   for (int a = 0; a < n_ctbs; a++) {
     const int addr = first + a, rx = addr % wc, ry = addr / wc;
@@ -810,6 +840,9 @@ RBT_DEV void en_entropy_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx,
     rbt_ce_terminate(&s.c, a == n_ctbs - 1);
   }
   rbt_ce_align_zero(&s.c);
+#ifdef RBT_PROFILE
+  if (RBT_LANE0 && slice_idx == 10) printf("entropy slice %d: total %llu cyc, stage %llu, cu header %llu (%u CUs), residual %llu (%u TBs; setup+last %llu), bytes %u\n", slice_idx, __builtin_readcyclecounter() - tall_, s.t_stage, s.t_cu, s.n_cu, s.t_res, s.n_tb, s.t_resA, s.c.n);
+#endif
   if (RBT_LANE0) slices[slice_idx].out_size = s.c.overflow ? 0xFFFFFFFFu : s.c.n;
 }
 

@@ -227,11 +227,17 @@ void append_nal(std::vector<uint8_t>& out, int type, const uint8_t* rbsp, size_t
   if (long_start_code) out.push_back(0);
   out.push_back(0); out.push_back(0); out.push_back(1);
   out.push_back((uint8_t)(type << 1)); out.push_back(1);
-  int z = 0;
-  for (size_t i = 0; i < n; i++) {
+  // emulation prevention (7.4.2): 00 00 0x (x <= 3) gets a 03 in front of its third byte. Zero bytes are found with memchr
+  // and the spans in between are appended in one go.
+  size_t i = 0; int z = 0;                             // z: zero bytes at the end of what has been emitted (max 2 matter)
+  while (i < n) {
     if (z >= 2 && rbsp[i] <= 3) { out.push_back(3); z = 0; }
-    out.push_back(rbsp[i]);
-    z = rbsp[i] == 0 ? z + 1 : 0;
+    if (rbsp[i] == 0) { out.push_back(0); z++; i++; continue; }
+    // non-zero byte: copy up to the next zero byte
+    const uint8_t* q = (const uint8_t*)memchr(rbsp + i, 0, n - i);
+    size_t e = q ? (size_t)(q - rbsp) : n;
+    out.insert(out.end(), rbsp + i, rbsp + e);
+    i = e; z = 0;
   }
 }
 static void write_ptl(BitWriter& w, int bit_depth) {
