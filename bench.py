@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--height", type=int, default=1280)
     ap.add_argument("--cpu-sample", type=int, default=16, help="point-cloud frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--multi-gof", type=int, default=8, help="also time G GOFs per call (extra field multi_gof; 0/1 = skip)")
+    ap.add_argument("--quality", type=int, default=1, help="report picture PSNR of the output vs the input (extra field quality; 0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (with --backend gloo)")
     ap.add_argument("--save-input", default=None, help="write the generated R5 input streams to this .npz file and exit")
@@ -178,6 +179,22 @@ def main():
         assert all(mo[3 * g + q] == outs[q] for g in range(G) for q in range(3))
         multi = {"gofs_per_call": G, "value": round(G * n_pc / mt, 3), "unit": "point-cloud frames/s", "ms_per_call": round(1000 * mt, 3)}
 
+    # informative: what the re-encode did to the pictures (luma PSNR of the R3 output's pictures against the R5 input's,
+    # both decoded by this library), and that the occupancy output is exactly the 2x2 OR-pool of the input occupancy
+    quality = None
+    if rank == 0 and world == 1 and args.quality:
+        def psnr_y(a_stream, b_stream, ww, hh, peak):
+            da, db = ctx.decode(a_stream)[0], ctx.decode(b_stream)[0]
+            ya, yb = da[:, :ww * hh].astype(np.float64), db[:, :ww * hh].astype(np.float64)
+            mse = float(np.mean((ya - yb) ** 2))
+            return round(10 * np.log10(peak * peak / mse), 2) if mse > 0 else float("inf")
+        oi, oo = ctx.decode(so)[0], ctx.decode(outs[0])[0]
+        ow, oh = w // 2, h // 2
+        pooled = (oi[:, :ow * oh].reshape(-1, oh // 2, 2, ow // 2, 2).max(axis=(2, 4)) > 0)
+        quality = {"geometry_psnr_y_db": psnr_y(sg, outs[1], w, h, 1023), "attribute_psnr_y_db": psnr_y(sa, outs[2], w, h, 1023),
+                   "occupancy_is_or_pool": bool(np.array_equal(oo[:, :(ow // 2) * (oh // 2)].reshape(-1, oh // 2, ow // 2) > 0, pooled)),
+                   "note": "R3 output pictures vs R5 input pictures (not D1/D2: no point-cloud reconstruction here)"}
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         import oracle_lib as O   # CPU checker, used here only as the timed CPU baseline ("port")
@@ -204,7 +221,7 @@ def main():
                 "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                              "traffic": traffic, "kernel_ms": {k_: round(v, 3) for k_, v in groups.items()},
                              "path_achieved_GBs": round(path_achieved, 3), "path_frac": round(path_achieved / HBM_PEAK_GBS, 6)},
-                "cpu_baseline": cpu, "multi_gof": multi,
+                "cpu_baseline": cpu, "multi_gof": multi, "quality": quality,
                 "host_ms": {"parse": round(st["host_parse_ms"], 3), "pack": round(st["host_pack_ms"], 3), "gpu": round(st["gpu_ms"], 3), "total": round(st["total_ms"], 3)}}
         print(json.dumps(line))
     if world > 1:
