@@ -5,7 +5,8 @@ Workload (config.workload): one 32-frame GOF of 1280x1280 V-PCC maps — 64 geom
 (yuv420p10, I/P pairs) and 32 occupancy pictures (640x640, 8 bit, lossless) — at "R5" (QP 16 / 22, occupancy
 precision 2), transcoded to R3 (geometryQP 24, attributeQP 32, occupancyPrecision 4). There is no 8i data and no HM
 here, so the maps are synthetic (tests/synth.py) and the R5 input is produced by this repository's own GPU encoder in
-HM-like structure (CTB 64, one slice per picture). One "step" = one rbt_transcode_gof call over the whole GOF.
+HM-like structure (CTB 64, one slice per picture). One "step" = one GOF through rbt_submit_gof + rbt_wait_gof (together:
+rbt_transcode_gof); --in-flight GOFs (default 8) are submitted ahead of the one being collected, as a transcoder walking a sequence does.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--pc-frames F]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -19,6 +20,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before anything initialises HIP: librbt shares 16 streams among the jobs in flight
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
@@ -52,13 +54,15 @@ def make_gof_maps(w, h, n_pc, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--pc-frames", type=int, default=32)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=1280)
     ap.add_argument("--cpu-sample", type=int, default=16, help="point-cloud frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--multi-gof", type=int, default=8, help="also time G GOFs per call (extra field multi_gof; 0/1 = skip)")
+    ap.add_argument("--in-flight", type=int, default=8, help="GOFs in flight (rbt_submit_gof ahead of rbt_wait_gof), 1..16; 1 = blocking calls")
+    ap.add_argument("--sweep", type=int, default=16, help="also time K GOFs at every in-flight depth 1..4 (extra field in_flight_sweep; 0/1 = skip)")
     ap.add_argument("--quality", type=int, default=1, help="report picture PSNR of the output vs the input (extra field quality; 0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (with --backend gloo)")
@@ -102,12 +106,28 @@ def main():
     params = [P(R.RBT_VIDEO_OCCUPANCY, 8, 4, 5, 1, 0, 0), P(R.RBT_VIDEO_GEOMETRY, 24, 4, 5, 1, 0, 0), P(R.RBT_VIDEO_ATTRIBUTE, 32, 4, 5, 1, 0, 0)]
     streams = [so, sg, sa]
 
-    def step():
-        outs = ctx.transcode_gof(streams, params)
+    # One step = one GOF through the hot path. The steps are issued the way a transcoder walks a sequence: rbt_submit_gof
+    # for GOF i+D-1 before rbt_wait_gof for GOF i (D = --in-flight GOFs in flight on disjoint HIP streams; D = 1 is the
+    # blocking rbt_transcode_gof). Every one of the K timed steps is submitted and collected inside the timed region.
+    D = max(1, min(args.in_flight, 16))
+    stats_acc = {}
+
+    def collect(job, acc):
+        outs = ctx.wait_gof(job)
+        if acc is not None:
+            for k, v in ctx.stats().items():
+                acc[k] = acc.get(k, 0.0) + v
         if world > 1:
-            from importlib import import_module  # noqa: F401
             gs = rbt_lib.module_file("gof_shard")
             gs.gather_streams(outs, device=tdev)
+        return outs
+
+    def run(n_steps, depth, acc):
+        q, outs = [], None
+        for _ in range(n_steps):
+            if len(q) == depth: outs = collect(q.pop(0), acc)
+            q.append(ctx.submit_gof(streams, params))
+        while q: outs = collect(q.pop(0), acc)
         return outs
 
     def sync():
@@ -116,16 +136,11 @@ def main():
             dist.barrier()
             if args.backend == "nccl": torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    stats_acc = {}
+    ctx.set_depth(D)
+    run(args.warmup, D, None)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        outs = step()
-        s = ctx.stats()
-        for k, v in s.items():
-            stats_acc[k] = stats_acc.get(k, 0.0) + v
+    outs = run(args.steps, D, stats_acc)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -164,7 +179,7 @@ def main():
             traffic = int(sum((pmc[k]["FETCH_SIZE_KB"] + pmc[k]["WRITE_SIZE_KB"]) * 1024 for k in kmap[dom]))
     except Exception:
         traffic = None
-    path_achieved = st["algorithmic_bytes"] / (st["gpu_ms"] * 1e-3) / 1e9 if st.get("gpu_ms", 0) > 0 else 0.0
+    path_achieved = st["algorithmic_bytes"] / (elapsed / steps) / 1e9   # whole path: SURVEY.md 8(d) bytes of one GOF over the time one GOF takes
 
     # informative extra (not the headline): G GOFs handed over in one call. One GOF's critical path is a few hundred serial
     # waves, so the GPU has room for several at once; a sequence of GOFs (configs[3]) can use that inside each GPU.
@@ -178,6 +193,20 @@ def main():
         mt = (time.perf_counter() - m0) / 2
         assert all(mo[3 * g + q] == outs[q] for g in range(G) for q in range(3))
         multi = {"gofs_per_call": G, "value": round(G * n_pc / mt, 3), "unit": "point-cloud frames/s", "ms_per_call": round(1000 * mt, 3)}
+
+    # informative extra: the same loop at every depth (D = 1 is the blocking call: its ms_per_gof is the latency of one GOF)
+    sweep = None
+    if world == 1 and args.sweep > 1:
+        sweep = []
+        for d in (1, 2, 4, 8, 16):
+            ctx.set_depth(d)
+            run(d, d, None)
+            p0 = time.perf_counter()
+            so_ = run(args.sweep, d, None)
+            pt = (time.perf_counter() - p0) / args.sweep
+            assert so_ == outs
+            sweep.append({"in_flight": d, "gofs": args.sweep, "value": round(n_pc / pt, 3), "ms_per_gof": round(1000 * pt, 3)})
+        ctx.set_depth(D)
 
     # informative: what the re-encode did to the pictures (luma PSNR of the R3 output's pictures against the R5 input's,
     # both decoded by this library), and that the occupancy output is exactly the 2x2 OR-pool of the input occupancy
@@ -217,12 +246,12 @@ def main():
                 "vs_baseline": None, "dtype": "u16/i32", "data": "synthetic",
                 "config": {"workload": f"{n_pc}-frame GOF, {w}x{h} V-PCC maps (2x{n_pc} geometry + 2x{n_pc} attribute yuv420p10 I/P pairs, {n_pc} occupancy {w // 2}x{h // 2} lossless), "
                                        f"R5 (QP16/22, prec 2) -> R3 (QP24/32, prec 4), synthetic longdress-like atlas",
-                           "gof_per_gpu": 1, "in_bytes": in_bytes, "out_bytes": out_bytes, "parallelism": f"gof-shard x{world}"},
+                           "gof_per_gpu": 1, "gofs_in_flight": D, "in_bytes": in_bytes, "out_bytes": out_bytes, "parallelism": f"gof-shard x{world}"},
                 "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                              "traffic": traffic, "kernel_ms": {k_: round(v, 3) for k_, v in groups.items()},
                              "path_achieved_GBs": round(path_achieved, 3), "path_frac": round(path_achieved / HBM_PEAK_GBS, 6)},
-                "cpu_baseline": cpu, "multi_gof": multi, "quality": quality,
-                "host_ms": {"parse": round(st["host_parse_ms"], 3), "pack": round(st["host_pack_ms"], 3), "gpu": round(st["gpu_ms"], 3), "total": round(st["total_ms"], 3)}}
+                "cpu_baseline": cpu, "multi_gof": multi, "in_flight_sweep": sweep, "quality": quality,
+                "host_ms": {"parse": round(st["host_parse_ms"], 3), "pack": round(st["host_pack_ms"], 3), "job_gpu_span": round(st["gpu_ms"], 3), "job_span": round(st["total_ms"], 3)}}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

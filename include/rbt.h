@@ -29,7 +29,8 @@ enum {
   RBT_ERR_UNSUPPORTED = -3,   /* stream uses a tool outside the V-PCC CTC toolset (B slices, tiles, PCM, ...) */
   RBT_ERR_PARAM = -4,
   RBT_ERR_NOMEM = -5,
-  RBT_ERR_MD5 = -6            /* decoded picture hash SEI mismatch on the input stream */
+  RBT_ERR_MD5 = -6,           /* decoded picture hash SEI mismatch on the input stream */
+  RBT_ERR_BUSY = -7           /* rbt_submit_gof: the announced number of transcodes is already in flight */
 };
 
 /* PCCVideoType values the reference passes (PCCBitstreamCommon.h:79-118) */
@@ -71,6 +72,22 @@ int rbt_transcode_substream(rbt_ctx* ctx, const uint8_t* annexb_in, size_t n_in,
  * by video type into three pipelines. Outputs come back in input order. */
 #define RBT_MAX_STREAMS 96
 int rbt_transcode_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out);
+
+/* rbt_transcode_gof in two halves, for the caller that walks a sequence GOF by GOF (the loop around transcodeData,
+ * PCCTranscoder.cpp:145-168): submit builds the batch and enqueues every kernel of the GOF, wait collects the streams.
+ * Several transcodes may be in flight; they use disjoint HIP streams, so the entropy decoding of GOF i+1 (a few hundred lone
+ * waves) runs underneath the entropy decoding, reconstruction and re-encode of GOF i. The input buffers may be released as soon
+ * as submit returns. Jobs may be waited for in any order; every submitted job must be waited for (rbt_destroy drains what is
+ * left). Results are identical to rbt_transcode_gof's.
+ * rbt_set_depth announces how many jobs the caller keeps in flight (1..RBT_MAX_JOBS, default 4; process-wide; refused with
+ * RBT_ERR_BUSY while jobs are in flight): the library has 16 HIP streams (more hardware queues slow every queue down on
+ * MI355X), so up to 4 jobs get four streams each, 5 get three, up to 8 get two. rbt_submit_gof returns RBT_ERR_BUSY when that
+ * many jobs are already in flight. */
+#define RBT_MAX_JOBS 16
+typedef struct rbt_job rbt_job;
+int rbt_set_depth(rbt_ctx* ctx, int max_in_flight);
+int rbt_submit_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, rbt_job** job);
+int rbt_wait_gof(rbt_ctx* ctx, rbt_job* job, uint8_t** annexb_out, size_t* n_out);
 
 /* The two halves exposed on their own (SURVEY.md 8(b) alternative seam; used by the parity tests).
  * Picture sizes: any even width / height. Sizes that are not multiples of 8 (all-intra) / 16 (gop 2) are coded padded with a

@@ -12,8 +12,8 @@
 #include <string.h>
 #include "hevc_tables.h"
 
-#define HEVC_MAX_W 4096
-#define HEVC_MAX_H 4096
+#define HEVC_MAX_W 8192
+#define HEVC_MAX_H 8192
 
 enum { NAL_TRAIL_N = 0, NAL_TRAIL_R = 1, NAL_IDR_W_RADL = 19, NAL_IDR_N_LP = 20, NAL_CRA = 21,
        NAL_VPS = 32, NAL_SPS = 33, NAL_PPS = 34, NAL_AUD = 35, NAL_EOS = 36, NAL_EOB = 37, NAL_FD = 38,

@@ -37,6 +37,9 @@ class Stats(C.Structure):
 
 def load(path=None):
     """Loads the shared library and declares the C ABI. Raises OSError if the HIP extension has not been built."""
+    # 16 HIP streams shared by the jobs in flight: the ROCm runtime multiplexes streams onto 4 hardware queues unless told otherwise, and
+    # it reads this when it initialises (librbt also sets it in rbt_create, which is too late if torch touched the GPU first)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     L = C.CDLL(path or LIB_PATH)
     L.rbt_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
     L.rbt_destroy.argtypes = [C.c_void_p]
@@ -48,6 +51,9 @@ def load(path=None):
     L.rbt_encode.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rbt_transcode_substream.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(StreamParams), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rbt_transcode_gof.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(StreamParams), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.rbt_submit_gof.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(StreamParams), C.POINTER(C.c_void_p)]
+    L.rbt_set_depth.argtypes = [C.c_void_p, C.c_int]
+    L.rbt_wait_gof.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rbt_or_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.rbt_sample_to_byte_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rbt_byte_to_sample_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
@@ -107,6 +113,31 @@ class Context:
         outs = (C.c_void_p * k)()
         ns = (C.c_size_t * k)()
         self._chk(self.L.rbt_transcode_gof(self.h, k, ins, sizes, ps, outs, ns))
+        res = []
+        for i in range(k):
+            res.append(C.string_at(outs[i], ns[i]) if outs[i] else b"")
+            self.L.rbt_free(outs[i])
+        return res
+
+    def set_depth(self, n):
+        """rbt_set_depth: how many GOFs the caller will keep in flight (1..8, default 4)"""
+        self._chk(self.L.rbt_set_depth(self.h, n))
+
+    def submit_gof(self, streams, params):
+        """rbt_submit_gof: enqueue one GOF; returns a job for wait_gof. Up to set_depth() jobs may be in flight."""
+        k = len(streams)
+        ins = (C.c_char_p * k)(*streams)
+        sizes = (C.c_size_t * k)(*[len(s) for s in streams])
+        ps = (StreamParams * k)(*params)
+        job = C.c_void_p()
+        self._chk(self.L.rbt_submit_gof(self.h, k, ins, sizes, ps, C.byref(job)))
+        return (job, k)
+
+    def wait_gof(self, job):
+        h, k = job
+        outs = (C.c_void_p * k)()
+        ns = (C.c_size_t * k)()
+        self._chk(self.L.rbt_wait_gof(self.h, h, outs, ns))
         res = []
         for i in range(k):
             res.append(C.string_at(outs[i], ns[i]) if outs[i] else b"")

@@ -13,7 +13,12 @@ int dev_init(int device);                 // 0 = ok
 // The HIP runtime multiplexes streams onto 4 hardware queues by default; two streams sharing a queue serialise (measured:
 // with 8 streams the geometry upload queued behind the attribute kernels and blocked the host for 285 ms). So: 4 streams,
 // one per sub-bitstream pipeline, and the last one doubles as the auxiliary stream of the longest pipeline when free.
-enum { RBT_N_STREAMS = 4, RBT_AUX_STREAM = 3 };
+// Several GOFs can be in flight (rbt_submit_gof). Host code names streams by "lane" = job slot * 4 + pipeline (timers are kept
+// per lane); map_lane binds a lane to one of the 16 HIP streams. dev_init asks the HIP runtime for 16 hardware queues
+// (GPU_MAX_HW_QUEUES) when it is the first HIP user of the process. Measured on MI355X: with 24 / 32 queues a lone GOF takes
+// 342 / 441 ms instead of 276 ms (the queues are time-sliced), so 16 it is; deeper pipelines give each job fewer streams.
+enum { RBT_AUX_STREAM = 3, RBT_STREAMS_PER_JOB = 4, RBT_JOB_SLOTS = 16, RBT_N_LANES = RBT_STREAMS_PER_JOB * RBT_JOB_SLOTS, RBT_N_STREAMS = 16 };
+void map_lane(int lane, int stream);
 void set_stream(int i);
 void stream_wait(int waiter, int signaller);
 int stream_mark(int signaller);                // remembers the point reached on `signaller`; stream_wait_mark makes later work of `waiter` start after it
@@ -33,7 +38,8 @@ double timer_ms(int id);                  // valid after dev_sync()
 // decode
 // save == nullptr: every slice is parsed to its end; else resumable (one RbtParseSave of parse_save_bytes() per slice of the
 // batch, zero-initialised): each launch advances every unfinished slice up to CTB row row_limit
-void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices, void* save = nullptr, int row_limit = 0);
+// max_w4: width of the widest picture of the launch in 4-sample units (<= 2048; selects the LDS footprint of the parser)
+void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices, int max_w4, void* save = nullptr, int row_limit = 0);
 size_t parse_save_bytes();
 void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int y_begin = 0, int y_end = 1 << 30);
 void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_units);

@@ -4,6 +4,7 @@
 #include <mutex>
 #include <vector>
 #include <cstdio>
+#include <cstdlib>
 #include "rbt_kernels.h"
 #include "rbt_parse.h"
 #include "rbt_recon.h"
@@ -13,16 +14,23 @@
 namespace rbtk {
 static hipStream_t g_streams[RBT_N_STREAMS] = {};
 static hipEvent_t g_dep_ev[64]; static int g_dep_next = 0;
-static int g_cur = 0;
-#define g_stream (g_streams[g_cur])
+static int g_cur = 0;                    // current lane
+static int g_map[RBT_N_LANES];           // lane -> HIP stream
+static bool g_map_init = false;
+static inline int lane_of(int i) { return ((i % RBT_N_LANES) + RBT_N_LANES) % RBT_N_LANES; }
+static inline hipStream_t stream_of(int lane) { return g_streams[g_map[lane_of(lane)]]; }
+#define g_stream (g_streams[g_map[g_cur]])
 static char g_name[256] = "";
 static char g_err[256] = "";
-static hipEvent_t g_ev[RBT_N_STREAMS][32][2];
+static hipEvent_t g_ev[RBT_N_LANES][16][2];
 static bool g_ev_init = false;
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(g_err, sizeof g_err, "%s: %s", #x, hipGetErrorString(e_)); return -1; } } while (0)
 
 int dev_init(int device) {
+  // one hardware queue per HIP stream (default: 4 queues shared by all streams); only honoured before the runtime initialises
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);
+  if (!g_map_init) { for (int i = 0; i < RBT_N_LANES; i++) g_map[i] = i % RBT_N_STREAMS; g_map_init = true; }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { snprintf(g_err, sizeof g_err, "no HIP device"); return -1; }
   if (device < 0 || device >= n) { snprintf(g_err, sizeof g_err, "device %d out of range (%d devices)", device, n); return -1; }
@@ -31,26 +39,27 @@ int dev_init(int device) {
   snprintf(g_name, sizeof g_name, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
   for (int k = 0; k < RBT_N_STREAMS; k++) if (!g_streams[k]) HIPCHK(hipStreamCreateWithFlags(&g_streams[k], hipStreamNonBlocking));
   if (!g_ev_init) { for (int i = 0; i < 64; i++) HIPCHK(hipEventCreateWithFlags(&g_dep_ev[i], hipEventDisableTiming));
-    for (int k = 0; k < RBT_N_STREAMS; k++) for (int i = 0; i < 32; i++) { HIPCHK(hipEventCreate(&g_ev[k][i][0])); HIPCHK(hipEventCreate(&g_ev[k][i][1])); } g_ev_init = true; }
+    for (int k = 0; k < RBT_N_LANES; k++) for (int i = 0; i < 16; i++) { HIPCHK(hipEventCreate(&g_ev[k][i][0])); HIPCHK(hipEventCreate(&g_ev[k][i][1])); } g_ev_init = true; }
   return 0;
 }
 const char* dev_name() { return g_name; }
-void set_stream(int i) { g_cur = ((i % RBT_N_STREAMS) + RBT_N_STREAMS) % RBT_N_STREAMS; }
+void set_stream(int i) { g_cur = lane_of(i); }
+void map_lane(int lane, int stream) { g_map[lane_of(lane)] = ((stream % RBT_N_STREAMS) + RBT_N_STREAMS) % RBT_N_STREAMS; }
 int stream_mark(int signaller) {
   int id = g_dep_next; g_dep_next = (g_dep_next + 1) % 64;
-  (void)hipEventRecord(g_dep_ev[id], g_streams[((signaller % RBT_N_STREAMS) + RBT_N_STREAMS) % RBT_N_STREAMS]);
+  (void)hipEventRecord(g_dep_ev[id], stream_of(signaller));
   return id;
 }
-void stream_wait_mark(int waiter, int mark) { (void)hipStreamWaitEvent(g_streams[((waiter % RBT_N_STREAMS) + RBT_N_STREAMS) % RBT_N_STREAMS], g_dep_ev[mark & 63], 0); }
+void stream_wait_mark(int waiter, int mark) { (void)hipStreamWaitEvent(stream_of(waiter), g_dep_ev[mark & 63], 0); }
 void stream_wait(int waiter, int signaller) {
   hipEvent_t e = g_dep_ev[g_dep_next]; g_dep_next = (g_dep_next + 1) % 64;
-  (void)hipEventRecord(e, g_streams[((signaller % RBT_N_STREAMS) + RBT_N_STREAMS) % RBT_N_STREAMS]);
-  (void)hipStreamWaitEvent(g_streams[((waiter % RBT_N_STREAMS) + RBT_N_STREAMS) % RBT_N_STREAMS], e, 0);
+  (void)hipEventRecord(e, stream_of(signaller));
+  (void)hipStreamWaitEvent(stream_of(waiter), e, 0);
 }
 // Device allocations are recycled: hipMalloc / hipFree of GOF-sized arenas cost milliseconds each (hipFree also drains the
 // device), and a transcoder calls with the same sizes over and over. Freed blocks go to a small best-fit pool; at most
 // RBT_POOL_KEEP blocks are kept, the rest is returned to the driver.
-enum { RBT_POOL_KEEP = 16 };
+enum { RBT_POOL_KEEP = 160 };
 struct PoolBlock { void* p; size_t n; };
 static std::vector<PoolBlock> g_pool_free, g_pool_live;
 static std::mutex g_pool_mu;
@@ -101,9 +110,11 @@ double timer_ms(int id) { float ms = 0; if (hipEventElapsedTime(&ms, g_ev[g_cur]
 
 // ---------------------------------------------------------------------------------------------- decode kernels
 // one wave per slice segment: wave-uniform CABAC parse (rbt_parse.h)
+// (CAP4: capacity of the parser's line buffers in 4-sample units; the variant fixes the LDS footprint of the workgroup)
+template <int CAP4>
 __global__ void __launch_bounds__(64) k_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, RbtParseSave* save, int row_limit) {
-  __shared__ RbtParseLds lds;
-  rbt_parse_slice(frames, slices, slice_list[blockIdx.x], rbsp, RBT_LDS_CAST(RbtParseLds, &lds), save, row_limit);
+  __shared__ alignas(16) uint32_t lds[(RBT_PARSE_LDS_BYTES(CAP4) + 3) / 4];
+  rbt_parse_slice(frames, slices, slice_list[blockIdx.x], rbsp, RBT_LDS_CAST(RbtParseLds, lds), CAP4, save, row_limit);
 }
 // one wave per CTB on anti-diagonal d (x + 2y == d): left, above-left, above and above-right CTBs are complete
 __global__ void __launch_bounds__(64) k_recon_diag(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int d, int y_first) {
@@ -130,9 +141,11 @@ __global__ void __launch_bounds__(256) k_sao(RbtFrame* frames, const RbtSlice* s
   rbt_sao_sample(f, slices, c, i % pw, i / pw);
 }
 
-void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices, void* save, int row_limit) {
+void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices, int max_w4, void* save, int row_limit) {
   if (n_slices <= 0) return;
-  hipLaunchKernelGGL(k_parse, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, rbsp, slice_list, (RbtParseSave*)save, row_limit);
+  if (max_w4 <= RBT_PARSE_CAP4_S) hipLaunchKernelGGL(k_parse<RBT_PARSE_CAP4_S>, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, rbsp, slice_list, (RbtParseSave*)save, row_limit);
+  else if (max_w4 <= RBT_PARSE_CAP4_M) hipLaunchKernelGGL(k_parse<RBT_PARSE_CAP4_M>, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, rbsp, slice_list, (RbtParseSave*)save, row_limit);
+  else hipLaunchKernelGGL(k_parse<RBT_PARSE_CAP4_L>, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, rbsp, slice_list, (RbtParseSave*)save, row_limit);
 }
 size_t parse_save_bytes() { return sizeof(RbtParseSave); }
 // CTB rows [y_begin, y_end): the rows above y_begin are complete, the anti-diagonals that touch the range run in order

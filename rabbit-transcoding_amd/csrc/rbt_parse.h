@@ -22,18 +22,30 @@
 #define RBT_TR(...) do { } while (0)
 #endif
 
-struct RbtParseLds {
+// LDS of one slice parser = this header + the line buffers of the CTB row above behind it (pz_above_*). The line buffers are
+// sized by the kernel variant (picture width, RBT_PARSE_CAP4_*): a parser is one lone wave, and its LDS footprint decides how
+// many parsers and how many reconstruction workgroups of other pictures fit on a CU next to each other.
+struct alignas(16) RbtParseLds {
   uint8_t cur_pm[256], cur_dm[256], cur_edges[256]; int8_t cur_qp[256], cur_ref[256]; int32_t cur_mv[256];   // current CTB, row stride 16 units
   uint8_t left_pm[16], left_dm[16]; int8_t left_ref[16]; int32_t left_mv[16];                                 // right column of the left CTB
-  uint8_t above_pm[2048], above_dm[2048]; int8_t above_ref[2048]; int32_t above_mv[2048];                     // bottom row of the CTB row above
-  uint16_t above_slice[512];                                                                                   // slice that decoded the CTB above (0xFFFF none)
-  RbtSao sao_above[512]; RbtSao sao_left;
+  RbtSao sao_left;
   uint8_t scan[3][4][64];                                                                                      // k_scan copied once per slice
 #ifdef RBT_PROFILE
   unsigned long long prof[32]; unsigned int profn[32];
 #endif
   int32_t ref_poc[RBT_MAX_REFS], ref_frame[RBT_MAX_REFS];   // RefPicList0 of the slice (indexed at run time: kept out of the register-resident parser state)
+  int32_t cap4, pad_[3];                                     // capacity of the line buffers in 4-sample units (multiple of 8)
 };
+// bottom row of the CTB row above: mv int32[cap4], pm / dm / ref bytes[cap4]; per CTB column (>= 16 samples wide, cap4 / 4 of
+// them): the slice that decoded the CTB above (0xFFFF none) and its SAO parameters
+enum { RBT_PARSE_CAP4_S = 384, RBT_PARSE_CAP4_M = 1024, RBT_PARSE_CAP4_L = 2048 };   // pictures up to 1536 / 4096 / 8192 samples wide
+#define RBT_PARSE_LDS_BYTES(cap4) (sizeof(RbtParseLds) + (size_t)(cap4) * 7 + (size_t)((cap4) / 4) * (2 + sizeof(RbtSao)))
+RBT_DEV RBT_LDS_AS int32_t* pz_above_mv(RBT_LDS_AS RbtParseLds* L) { return (RBT_LDS_AS int32_t*)(L + 1); }
+RBT_DEV RBT_LDS_AS uint8_t* pz_above_pm(RBT_LDS_AS RbtParseLds* L, int cap4) { return (RBT_LDS_AS uint8_t*)(L + 1) + 4 * cap4; }
+RBT_DEV RBT_LDS_AS uint8_t* pz_above_dm(RBT_LDS_AS RbtParseLds* L, int cap4) { return (RBT_LDS_AS uint8_t*)(L + 1) + 5 * cap4; }
+RBT_DEV RBT_LDS_AS int8_t* pz_above_ref(RBT_LDS_AS RbtParseLds* L, int cap4) { return (RBT_LDS_AS int8_t*)(L + 1) + 6 * cap4; }
+RBT_DEV RBT_LDS_AS uint16_t* pz_above_slice(RBT_LDS_AS RbtParseLds* L, int cap4) { return (RBT_LDS_AS uint16_t*)((RBT_LDS_AS uint8_t*)(L + 1) + 7 * cap4); }
+RBT_DEV RBT_LDS_AS RbtSao* pz_sao_above(RBT_LDS_AS RbtParseLds* L, int cap4) { return (RBT_LDS_AS RbtSao*)((RBT_LDS_AS uint8_t*)(L + 1) + 7 * cap4 + (cap4 / 4) * 2); }
 struct RbtParse {
   RBT_LDS_AS RbtParseLds* L; int ctb_x, ctb_y, left_ok, corner_ok, corner_pm, corner_dm, corner_ref, corner_mv;
   RbtFrame* f; const RbtFrame* frames; int slice_idx;
@@ -233,7 +245,9 @@ RBT_DEV void pz_fill_pu(RbtParse* s, int x, int y, int w, int h, int mode, int r
 RBT_DEV void pz_begin_ctb(RbtParse* s, int rx, int ry) {
   RBT_LDS_AS RbtParseLds* L = s->L;
   s->ctb_x = rx << pzc_log2_ctb(s); s->ctb_y = ry << pzc_log2_ctb(s);
-  const int cx4 = s->ctb_x >> 2;
+  const int cx4 = s->ctb_x >> 2, cap4 = RBT_UNI(L->cap4);
+  RBT_LDS_AS uint8_t *a_pm = pz_above_pm(L, cap4), *a_dm = pz_above_dm(L, cap4); RBT_LDS_AS int8_t* a_ref = pz_above_ref(L, cap4); RBT_LDS_AS int32_t* a_mv = pz_above_mv(L);
+  RBT_LDS_AS uint16_t* a_slice = pz_above_slice(L, cap4);
   RBT_VFOR(p, 64) {
     RBT_V(s->r_pm, p) = PZ_REP4(RBT_MODE_NONE); RBT_V(s->r_dm, p) = PZ_REP4(1); RBT_V(s->r_ed, p) = 0; RBT_V(s->r_qp, p) = 0; RBT_V(s->r_ref, p) = 0xFFFFFFFFu;
     RBT_V(s->r_mv0, p) = 0; RBT_V(s->r_mv1, p) = 0; RBT_V(s->r_mv2, p) = 0; RBT_V(s->r_mv3, p) = 0;
@@ -241,7 +255,7 @@ RBT_DEV void pz_begin_ctb(RbtParse* s, int rx, int ry) {
     if (p == 0) { if (s->corner_ok) { pm = (uint32_t)s->corner_pm; dm = (uint32_t)s->corner_dm; ref = (uint32_t)s->corner_ref & 255u; mv = (uint32_t)s->corner_mv; } }
     else if (p <= 17) {
       const int xa4 = cx4 - 1 + p;
-      if (ry > 0 && xa4 < pzc_w4(s) && L->above_slice[(xa4 << 2) >> pzc_log2_ctb(s)] == s->slice_idx) { pm = L->above_pm[xa4]; dm = L->above_dm[xa4]; ref = (uint8_t)L->above_ref[xa4]; mv = (uint32_t)L->above_mv[xa4]; }
+      if (ry > 0 && xa4 < pzc_w4(s) && a_slice[(xa4 << 2) >> pzc_log2_ctb(s)] == s->slice_idx) { pm = a_pm[xa4]; dm = a_dm[xa4]; ref = (uint8_t)a_ref[xa4]; mv = (uint32_t)a_mv[xa4]; }
     } else if (p >= 32 && p < 48) {
       if (s->left_ok) { pm = L->left_pm[p - 32]; dm = L->left_dm[p - 32]; ref = (uint8_t)L->left_ref[p - 32]; mv = (uint32_t)L->left_mv[p - 32]; }
     }
@@ -275,15 +289,18 @@ RBT_DEV void pz_end_ctb(RbtParse* s, int rx, int ry) {
     }
   }
   // above-left corner of the NEXT CTB = last unit of the old above row under this CTB
+  const int cap4 = RBT_UNI(L->cap4);
+  RBT_LDS_AS uint8_t *a_pm = pz_above_pm(L, cap4), *a_dm = pz_above_dm(L, cap4); RBT_LDS_AS int8_t* a_ref = pz_above_ref(L, cap4); RBT_LDS_AS int32_t* a_mv = pz_above_mv(L);
+  RBT_LDS_AS uint16_t* a_slice = pz_above_slice(L, cap4);
   int last = rbt_min(cx + ctb, pzc_w(s)) / 4 - 1;
-  int c_ok = ry > 0 && L->above_slice[rx] == s->slice_idx;
-  int c_pm = L->above_pm[last], c_dm = L->above_dm[last], c_ref = L->above_ref[last], c_mv = L->above_mv[last];
+  int c_ok = ry > 0 && a_slice[rx] == s->slice_idx;
+  int c_pm = a_pm[last], c_dm = a_dm[last], c_ref = a_ref[last], c_mv = a_mv[last];
   RBT_SYNC_LDS();
   s->corner_ok = c_ok; s->corner_pm = c_pm; s->corner_dm = c_dm; s->corner_ref = c_ref; s->corner_mv = c_mv;
   int rows = rbt_min(ctb, pzc_h(s) - cy) >> 2, cols = rbt_min(ctb, pzc_w(s) - cx) >> 2;
-  RBT_PAR_FOR(i, cols) { int k = (rows - 1) * 16 + i, a = (cx >> 2) + i; L->above_pm[a] = L->cur_pm[k]; L->above_dm[a] = L->cur_dm[k]; L->above_ref[a] = L->cur_ref[k]; L->above_mv[a] = L->cur_mv[k]; }
+  RBT_PAR_FOR(i, cols) { int k = (rows - 1) * 16 + i, a = (cx >> 2) + i; a_pm[a] = L->cur_pm[k]; a_dm[a] = L->cur_dm[k]; a_ref[a] = L->cur_ref[k]; a_mv[a] = L->cur_mv[k]; }
   RBT_PAR_FOR(i, 16) { int k = i * 16 + cols - 1; L->left_pm[i] = i < rows ? L->cur_pm[k] : RBT_MODE_NONE; L->left_dm[i] = L->cur_dm[k]; L->left_ref[i] = L->cur_ref[k]; L->left_mv[i] = L->cur_mv[k]; }
-  if (RBT_LANE0) L->above_slice[rx] = (uint16_t)s->slice_idx;
+  if (RBT_LANE0) a_slice[rx] = (uint16_t)s->slice_idx;
   s->left_ok = rx + 1 < pzc_w_ctb(s);
   if (rx + 1 >= pzc_w_ctb(s)) s->corner_ok = 0;
   RBT_SYNC_LDS();
@@ -320,9 +337,9 @@ RBT_DEV void pz_sao(RbtParse* s, int rx, int ry) {
   if (pzs_sao_luma(s) || pzs_sao_chroma(s)) {
     int merge_left = 0, merge_up = 0;
     if (rx > 0 && s->left_ok) merge_left = rbt_cd_bin(c, CTX_SAO_MERGE);
-    if (ry > 0 && !merge_left && s->L->above_slice[rx] == s->slice_idx) merge_up = rbt_cd_bin(c, CTX_SAO_MERGE);
+    if (ry > 0 && !merge_left && pz_above_slice(s->L, RBT_UNI(s->L->cap4))[rx] == s->slice_idx) merge_up = rbt_cd_bin(c, CTX_SAO_MERGE);
     if (merge_left) pz_sao_from_lds(&p, &s->L->sao_left);
-    else if (merge_up) pz_sao_from_lds(&p, &s->L->sao_above[rx]);
+    else if (merge_up) pz_sao_from_lds(&p, &pz_sao_above(s->L, RBT_UNI(s->L->cap4))[rx]);
     else {
       int bd = pzc_bit_depth(s), cmax = (1 << (rbt_min(bd, 10) - 5)) - 1;
       for (int ci = 0; ci < 3; ci++) {
@@ -345,7 +362,7 @@ RBT_DEV void pz_sao(RbtParse* s, int rx, int ry) {
       }
     }
   }
-  if (RBT_LANE0) { s->f->sao[ry * wc + rx] = p; pz_sao_to_lds(&s->L->sao_left, &p); pz_sao_to_lds(&s->L->sao_above[rx], &p); }
+  if (RBT_LANE0) { s->f->sao[ry * wc + rx] = p; pz_sao_to_lds(&s->L->sao_left, &p); pz_sao_to_lds(&pz_sao_above(s->L, s->L->cap4)[rx], &p); }
   RBT_SYNC_LDS();
 }
 
@@ -932,19 +949,21 @@ struct RbtParseSave {
   int32_t sc[24];                 // scalar parser / engine state
   uint32_t buf_lo, buf_hi;
   uint32_t ctx[4][64];            // context variables (one word per lane and register)
-  uint32_t lds[(sizeof(RbtParseLds) + 3) / 4];
+  uint32_t lds[(RBT_PARSE_LDS_BYTES(RBT_PARSE_CAP4_L) + 3) / 4];
 };
 // Entry: parses one slice segment (save == nullptr: in one go; else up to CTB row `row_limit`, resuming where it stopped).
-RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, const uint8_t* rbsp, RBT_LDS_AS RbtParseLds* lds, RbtParseSave* save, int row_limit) {
+// `lds` holds RBT_PARSE_LDS_BYTES(cap4) bytes; the launcher picks cap4 >= the width of every picture of the launch / 4.
+RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, const uint8_t* rbsp, RBT_LDS_AS RbtParseLds* lds, int cap4, RbtParseSave* save, int row_limit) {
   RbtParse s;
   RbtParseSave* sv = save ? save + slice_idx : nullptr;
   const int phase = sv ? RBT_UNI((int)sv->phase) : 0;
   if (phase == 2) return;
   const RbtSlice* gs = &slices[slice_idx];
   s.L = lds; s.left_ok = 0; s.corner_ok = 0; s.corner_pm = s.corner_dm = s.corner_ref = s.corner_mv = 0; s.ctb_x = s.ctb_y = 0;
-  if (phase == 0) { RBT_PAR_FOR(i, 512) lds->above_slice[i] = 0xFFFF; }
-  else { RBT_LDS_AS uint32_t* lw = (RBT_LDS_AS uint32_t*)lds; RBT_PAR_FOR(i, (int)(sizeof(RbtParseLds) / 4)) lw[i] = sv->lds[i]; }
+  if (phase == 0) { RBT_LDS_AS uint16_t* a_slice = pz_above_slice(lds, cap4); RBT_PAR_FOR(i, cap4 / 4) a_slice[i] = 0xFFFF; }
+  else { RBT_LDS_AS uint32_t* lw = (RBT_LDS_AS uint32_t*)lds; RBT_PAR_FOR(i, (int)(RBT_PARSE_LDS_BYTES(cap4) / 4)) lw[i] = sv->lds[i]; }
   RBT_SYNC();
+  if (RBT_LANE0) lds->cap4 = cap4;
   s.frames = frames; s.f = &frames[RBT_UNI(gs->frame)]; s.slice_idx = slice_idx; s.error = 0;
   s.s_bits = (uint32_t)RBT_UNI((gs->slice_type & 3) | ((gs->sao_luma & 1) << 2) | ((gs->sao_chroma & 1) << 3) | ((gs->temporal_mvp & 1) << 4) | ((gs->cabac_init_flag & 1) << 5) |
                                ((gs->max_merge_cand & 7) << 6) | ((gs->num_ref_idx & 31) << 9) | ((gs->collocated_ref_idx & 15) << 14));
@@ -1000,7 +1019,7 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
     if (sv && ry >= row_limit) {
       // suspend in front of this CTB
       RBT_SYNC_LDS();
-      { RBT_LDS_AS uint32_t* lw = (RBT_LDS_AS uint32_t*)lds; RBT_PAR_FOR(i, (int)(sizeof(RbtParseLds) / 4)) sv->lds[i] = lw[i]; }
+      { RBT_LDS_AS uint32_t* lw = (RBT_LDS_AS uint32_t*)lds; RBT_PAR_FOR(i, (int)(RBT_PARSE_LDS_BYTES(cap4) / 4)) sv->lds[i] = lw[i]; }
 #ifdef RBT_HOSTEMU
       for (int i = 0; i < RBT_CTX_COUNT; i++) sv->ctx[i >> 6][i & 63] = s.c.cs.st[i];
 #else

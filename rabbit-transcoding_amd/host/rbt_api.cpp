@@ -7,7 +7,11 @@
 #include "rbt_transcode.h"
 
 struct rbt_ctx { int device, rank, world; rbt_stats stats; std::string last_err; };
+struct rbt_job { rbt::GofJob* j; rbt_ctx* owner; };
 
+static rbt_job* g_jobs[RBT_MAX_JOBS] = {};
+static int g_depth = 4;                      // announced pipeline depth: decides how many HIP streams a job gets (rbt_transcode.cpp bind_streams)
+static_assert(RBT_MAX_JOBS == rbtk::RBT_JOB_SLOTS, "job slots");
 static std::mutex g_mu;   // one HIP stream / timer set per process; calls on one context are serial (as the reference's are)
 
 extern "C" {
@@ -23,6 +27,7 @@ const char* rbt_strerror(int code) {
     case RBT_ERR_PARAM: return "invalid parameter";
     case RBT_ERR_NOMEM: return "out of memory";
     case RBT_ERR_MD5: return "decoded picture hash mismatch on the input stream";
+    case RBT_ERR_BUSY: return "too many transcodes in flight";
     default: return "unknown error";
   }
 }
@@ -37,7 +42,14 @@ int rbt_create(rbt_ctx** ctx, int device, int world_rank, int world_size) {
   *ctx = c;
   return RBT_OK;
 }
-void rbt_destroy(rbt_ctx* ctx) { if (ctx) { std::lock_guard<std::mutex> lk(g_mu); rbtk::dev_release_pool(); } delete ctx; }
+void rbt_destroy(rbt_ctx* ctx) {
+  if (ctx) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int s = 0; s < RBT_MAX_JOBS; s++) if (g_jobs[s] && g_jobs[s]->owner == ctx) { rbt::gof_abandon(g_jobs[s]->j); delete g_jobs[s]; g_jobs[s] = nullptr; }
+    rbtk::dev_release_pool();
+  }
+  delete ctx;
+}
 int rbt_get_stats(rbt_ctx* ctx, rbt_stats* out) { if (!ctx || !out) return RBT_ERR_PARAM; *out = ctx->stats; return RBT_OK; }
 
 int rbt_decode(rbt_ctx* ctx, const uint8_t* annexb, size_t n, int verify_md5, rbt_video* out) {
@@ -103,8 +115,38 @@ int rbt_transcode_substream(rbt_ctx* ctx, const uint8_t* annexb_in, size_t n_in,
 }
 int rbt_transcode_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out) {
   if (!ctx || n < 1 || n > RBT_MAX_STREAMS || !annexb_in || !n_in || !p || !annexb_out || !n_out) return RBT_ERR_PARAM;
+  rbt_job* job = nullptr;
+  int rc = rbt_submit_gof(ctx, n, annexb_in, n_in, p, &job);
+  if (rc) return rc;
+  return rbt_wait_gof(ctx, job, annexb_out, n_out);
+}
+int rbt_submit_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, rbt_job** job) {
+  if (!ctx || n < 1 || n > RBT_MAX_STREAMS || !annexb_in || !n_in || !p || !job) return RBT_ERR_PARAM;
+  *job = nullptr;
   std::lock_guard<std::mutex> lk(g_mu);
-  return rbt::transcode_gof(ctx->stats, ctx->last_err, n, annexb_in, n_in, p, annexb_out, n_out);
+  int slot = -1;
+  for (int s = 0; s < g_depth && slot < 0; s++) if (!g_jobs[s]) slot = s;
+  if (slot < 0) return RBT_ERR_BUSY;
+  rbt_job* j = new rbt_job{rbt::gof_submit(slot, g_depth, n, annexb_in, n_in, p), ctx};
+  g_jobs[slot] = j; *job = j;
+  return RBT_OK;                       // errors of the build surface in rbt_wait_gof, which also releases the job
+}
+int rbt_set_depth(rbt_ctx* ctx, int max_in_flight) {
+  if (!ctx || max_in_flight < 1 || max_in_flight > RBT_MAX_JOBS) return RBT_ERR_PARAM;
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int s = 0; s < RBT_MAX_JOBS; s++) if (g_jobs[s]) return RBT_ERR_BUSY;
+  g_depth = max_in_flight;
+  return RBT_OK;
+}
+int rbt_wait_gof(rbt_ctx* ctx, rbt_job* job, uint8_t** annexb_out, size_t* n_out) {
+  if (!ctx || !job || !annexb_out || !n_out) return RBT_ERR_PARAM;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int slot = -1;
+  for (int s = 0; s < RBT_MAX_JOBS; s++) if (g_jobs[s] == job) slot = s;
+  if (slot < 0 || job->owner != ctx) return RBT_ERR_PARAM;
+  int rc = rbt::gof_wait(job->j, ctx->stats, ctx->last_err, annexb_out, n_out);
+  g_jobs[slot] = nullptr; delete job;
+  return rc;
 }
 int rbt_encode(rbt_ctx* ctx, const uint16_t* yuv, int width, int height, int bit_depth, int n_frames, int qp, int gop, int lossless,
                int log2_ctb, int ctb_rows_per_slice, int md5_sei, uint8_t** annexb_out, size_t* n_out) {

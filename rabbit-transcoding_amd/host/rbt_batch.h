@@ -27,9 +27,10 @@ struct DecodeBatch {
   std::vector<int> stream_first, stream_count;
   std::vector<Sps> stream_sps; std::vector<Pps> stream_pps;
   std::vector<std::vector<int>> level_frames;
-  bool ordered_parse = false;
+  bool ordered_parse = false, lists_uploaded = false;
   std::vector<int32_t> lists_keep;     // host staging of the index lists, alive until the copy has completed
   std::vector<size_t> fr_off;          // offset of each level's frame list inside d_lists
+  std::vector<size_t> sl_off, sl_cnt;  // slice list of each level inside d_lists
   void* d_save = nullptr;              // RbtParseSave per slice (resumable parsing), zero-initialised; nullptr when not requested
   bool want_save = false;              // set before decode_build to reserve d_save
   void* arena = nullptr; size_t arena_size = 0;

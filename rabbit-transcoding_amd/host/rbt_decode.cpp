@@ -146,7 +146,8 @@ int decode_launch(DecodeBatch& b) {
   rbtk::timer_end(T_RECON);
   return 0;
 }
-static void build_lists(DecodeBatch& b, std::vector<size_t>& sl_off, std::vector<size_t>& sl_cnt) {
+static void build_lists(DecodeBatch& b) {
+  std::vector<size_t>& sl_off = b.sl_off; std::vector<size_t>& sl_cnt = b.sl_cnt; sl_off.clear(); sl_cnt.clear();
   // index lists: slices grouped by level, frames grouped by level
   std::vector<int32_t>& lists = b.lists_keep; lists.clear(); b.fr_off.clear();
   for (auto& lf : b.level_frames) {
@@ -156,19 +157,22 @@ static void build_lists(DecodeBatch& b, std::vector<size_t>& sl_off, std::vector
   }
   for (auto& lf : b.level_frames) { b.fr_off.push_back(lists.size()); for (int fi : lf) lists.push_back(fi); }
 }
+static int max_w4(const DecodeBatch& b) { int m = 0; for (auto& f : b.frames) m = std::max(m, (int)f.cfg.w4); return m; }
 int decode_upload_lists(DecodeBatch& b) {
-  std::vector<size_t> sl_off, sl_cnt; build_lists(b, sl_off, sl_cnt);
+  if (b.lists_uploaded) return 0;
+  b.lists_uploaded = true;
+  build_lists(b);
   if (b.lists_keep.size() > (b.frames.size() + b.slices.size()) * 2) { b.err = "internal: list overflow"; return b.err_code = RBT_ERR_PARAM; }
   if (rbtk::h2d(b.d_lists, b.lists_keep.data(), b.lists_keep.size() * sizeof(int32_t))) { b.err = "device transfer failed"; return b.err_code = RBT_ERR_NO_DEVICE; }
   return 0;
 }
 int decode_launch_parse(DecodeBatch& b) {
-  std::vector<size_t> sl_off, sl_cnt; build_lists(b, sl_off, sl_cnt);
-  if (b.lists_keep.size() > (b.frames.size() + b.slices.size()) * 2) { b.err = "internal: list overflow"; return b.err_code = RBT_ERR_PARAM; }
-  if (rbtk::h2d(b.d_lists, b.lists_keep.data(), b.lists_keep.size() * sizeof(int32_t))) { b.err = "device transfer failed"; return b.err_code = RBT_ERR_NO_DEVICE; }
+  int rc = decode_upload_lists(b);
+  if (rc) return rc;
+  const std::vector<size_t>& sl_off = b.sl_off; const std::vector<size_t>& sl_cnt = b.sl_cnt;
   rbtk::timer_begin(T_PARSE);
-  if (b.ordered_parse) { for (size_t l = 0; l < b.level_frames.size(); l++) rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists + sl_off[l], (int)sl_cnt[l]); }
-  else rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists, (int)b.slices.size());
+  if (b.ordered_parse) { for (size_t l = 0; l < b.level_frames.size(); l++) rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists + sl_off[l], (int)sl_cnt[l], max_w4(b)); }
+  else rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists, (int)b.slices.size(), max_w4(b));
   rbtk::timer_end(T_PARSE);
   return 0;
 }
@@ -198,7 +202,7 @@ int decode_launch_chunked(DecodeBatch& b, int chunks, int main_stream, int aux_s
   for (int c = 0; c < chunks; c++) {
     int y_lim = c + 1 == chunks ? (1 << 30) : (max_h_all * (c + 1) + chunks - 1) / chunks;
     rbtk::set_stream(main_stream);
-    rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists, (int)b.slices.size(), b.d_save, y_lim);
+    rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists, (int)b.slices.size(), max_w4(b), b.d_save, y_lim);
     if (c + 1 == chunks) rbtk::timer_end(T_PARSE);
     rbtk::stream_wait(aux_stream, main_stream);
     rbtk::set_stream(aux_stream);

@@ -2,6 +2,7 @@
 // Replaces initEncoder / setEncoderOptions / encodeVideo / resize_frame2 of PCCTranscoder (PCCTranscoder.cpp:683-753,
 // :825-904, :548-592, :594-646) and the decode -> pool -> encode loop of transcodeVideo (:428-510).
 #include <algorithm>
+#include <memory>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -300,14 +301,40 @@ static int setup_encode(DecodeBatch& db, int si, const rbt_stream_params& p, Enc
 // gets its own decode/encode batch on its own HIP stream: every decode chain is enqueued up front, longest first, and
 // the host then walks the streams shortest first, so the pool / re-encode of the short streams (occupancy, geometry)
 // runs underneath the entropy-decoding chain of the longest one (attribute) instead of behind it.
-int transcode_gof(rbt_stats& st, std::string& err, int n, const uint8_t* const* in, const size_t* n_in, const rbt_stream_params* p, uint8_t** out, size_t* n_out) {
-  double t_all = now_ms();
-  memset(&st, 0, sizeof(st));
-  for (int i = 0; i < n; i++) { out[i] = nullptr; n_out[i] = 0; }
+// One transcode call in flight. rbt_transcode_gof = submit + wait; rbt_submit_gof / rbt_wait_gof expose the two halves so that
+// a caller can keep two GOFs in flight (job slots use disjoint HIP streams): the next GOF's entropy decoding then runs
+// underneath the previous GOF's reconstruction and re-encode.
+struct GofJob {
+  int n = 0, slot = 0, ng = 0, rc = 0;
+  std::vector<std::vector<int>> groups; std::vector<int> order;
+  std::vector<DecodeBatch> db; std::vector<EncodeBatch> eb; std::vector<char> chained;
+  std::vector<void*> pooled;
+  bool has_aux = true;
+  std::vector<rbt_stream_params> params; std::vector<size_t> n_in;
+  rbt_stats st; std::string err; double t_all = 0, t_gpu = 0;
+  ~GofJob() { for (void* q : pooled) rbtk::dev_free(q); }
+};
+static int job_stream(const GofJob& j, int pipeline) { return j.slot * rbtk::RBT_STREAMS_PER_JOB + pipeline; }
+
+// Streams of a job. The 16 HIP streams are shared out by the pipeline depth the caller announced (rbt_set_depth): up to 4 jobs
+// in flight get four streams each (three pipelines + the auxiliary stream), 5 get three (no auxiliary stream), up to 8 get two
+// (the longest pipeline alone, the others behind each other on the second).
+static void bind_streams(GofJob& j, int depth) {
+  const int spj = depth <= 4 ? 4 : depth == 5 ? 3 : depth <= 8 ? 2 : 1, base = j.slot * spj;
+  j.has_aux = spj == 4;
+  for (int k = 0; k < j.ng; k++) rbtk::map_lane(job_stream(j, j.order[k]), base + (k == 0 || spj == 1 ? 0 : 1 + (k - 1) % (std::min(spj, 3) - 1)));
+  rbtk::map_lane(job_stream(j, rbtk::RBT_AUX_STREAM), base + spj - 1);
+}
+
+GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const size_t* n_in, const rbt_stream_params* p) {
+  GofJob* J = new GofJob(); GofJob& j = *J;
+  j.t_all = now_ms(); j.n = n; j.slot = slot; memset(&j.st, 0, sizeof(j.st));
+  j.params.assign(p, p + n); j.n_in.assign(n_in, n_in + n);
+  rbt_stats& st = j.st; std::string& err = j.err;
   // Pipelines: up to three sub-bitstreams get one pipeline (= HIP stream) each. A call with more (several GOFs at once:
   // one GOF leaves most of the GPU idle) groups them by video type, so that the slices of all attribute streams parse
   // in one launch, all geometry streams in another, ...
-  std::vector<std::vector<int>> groups;
+  std::vector<std::vector<int>>& groups = j.groups;
   if (n <= rbtk::RBT_AUX_STREAM) for (int i = 0; i < n; i++) groups.push_back({i});
   else {
     const int types[3] = {RBT_VIDEO_ATTRIBUTE, RBT_VIDEO_GEOMETRY, RBT_VIDEO_OCCUPANCY};
@@ -315,84 +342,102 @@ int transcode_gof(rbt_stats& st, std::string& err, int n, const uint8_t* const* 
     std::vector<int> rest; for (int i = 0; i < n; i++) if (p[i].video_type != types[0] && p[i].video_type != types[1] && p[i].video_type != types[2]) rest.push_back(i);
     if (!rest.empty()) { if (groups.size() < 3) groups.push_back(rest); else groups.back().insert(groups.back().end(), rest.begin(), rest.end()); }
   }
-  const int ng = (int)groups.size();
+  const int ng = j.ng = (int)groups.size();
   auto bytes_of = [&](int g) { size_t t = 0; for (int i : groups[g]) t += n_in[i]; return t; };
-  std::vector<DecodeBatch> db(ng); std::vector<EncodeBatch> eb(ng);
-  std::vector<void*> pooled;
-  struct Guard { std::vector<void*>& v; ~Guard() { rbtk::set_stream(0); for (void* q : v) rbtk::dev_free(q); } } guard{pooled};
-  std::vector<int> order(ng); for (int i = 0; i < ng; i++) order[i] = i;
+  j.db.resize(ng); j.eb.resize(ng); j.chained.assign(ng, 0);
+  std::vector<DecodeBatch>& db = j.db; std::vector<EncodeBatch>& eb = j.eb; std::vector<char>& chained = j.chained; std::vector<void*>& pooled = j.pooled;
+  std::vector<int>& order = j.order; order.resize(ng); for (int i = 0; i < ng; i++) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return bytes_of(a) > bytes_of(b); });
-  // ---- phase A, longest pipeline first: build decoder and encoder batches, upload, then enqueue decode -> pool -> encode on
-  // the stream without a host round trip in between (PCCTranscoder.cpp:428-448, :466, :825-904). Pipelines that ask for the
-  // input MD5 check keep the decoder / encoder split, because the check needs the decoded pictures on the host first.
-  double t_gpu = now_ms();
-  std::vector<char> chained(ng, 0);
+  const int aux = job_stream(j, rbtk::RBT_AUX_STREAM);
+  bind_streams(j, depth);
+  // ---- phase A, longest pipeline first: build decoder and encoder batches and upload them; then enqueue decode -> pool ->
+  // encode on the stream without a host round trip in between (PCCTranscoder.cpp:428-448, :466, :825-904). Every upload of
+  // the job is issued before its first kernel: a copy from pageable memory blocks the host until the stream has reached it,
+  // and pipelines may share a stream. Pipelines that ask for the input MD5 check keep the decoder / encoder split, because
+  // the check needs the decoded pictures on the host first.
+  j.t_gpu = now_ms();
   int rc = 0;
+  std::vector<std::vector<PoolJob>> pool_jobs(ng);
   for (int k = 0; k < ng && !rc; k++) {
-    const int gi = order[k]; const std::vector<int>& gs = groups[gi]; rbtk::set_stream(gi);
+    const int gi = order[k], sid = job_stream(j, gi); const std::vector<int>& gs = groups[gi]; rbtk::set_stream(sid);
     std::vector<StreamIn> sins; bool verify = false;
     for (int i : gs) { sins.push_back(StreamIn{in[i], n_in[i]}); verify |= p[i].verify_md5 != 0; }
     double t0 = now_ms();
-    db[gi].want_save = parse_bands() > 1 && k == 0 && ng <= rbtk::RBT_AUX_STREAM && !verify;
+    db[gi].want_save = parse_bands() > 1 && k == 0 && j.has_aux && ng <= rbtk::RBT_AUX_STREAM && !verify;
     rc = decode_build(db[gi], sins.data(), (int)sins.size());
     st.host_parse_ms += now_ms() - t0;
+    if (!rc) rc = decode_upload_lists(db[gi]);
     if (rc) { err = db[gi].err; break; }
-    std::vector<PoolJob> jobs;
     if (!verify) {
-      for (size_t q = 0; q < gs.size() && !rc; q++) rc = setup_encode(db[gi], (int)q, p[gs[q]], eb[gi], pooled, err, &jobs);
+      for (size_t q = 0; q < gs.size() && !rc; q++) rc = setup_encode(db[gi], (int)q, p[gs[q]], eb[gi], pooled, err, &pool_jobs[gi]);
       if (!rc) { rc = encode_build(eb[gi]); if (!rc) rc = encode_upload_lists(eb[gi]); if (rc) err = eb[gi].err; }
       if (rc) break;
       chained[gi] = 1;
     }
+  }
+  for (int k = 0; k < ng && !rc; k++) {
+    const int gi = order[k], sid = job_stream(j, gi); rbtk::set_stream(sid);
+    const std::vector<PoolJob>& jobs = pool_jobs[gi];
     if (!chained[gi]) { rc = decode_launch(db[gi]); if (rc) { err = db[gi].err; break; } continue; }
     // Intra pictures of the output only read the decoded pictures they are re-encoded from. When those are complete
     // before the last dependency level of the decoder, analysis + intra coding run on an auxiliary stream underneath the
     // remaining reconstruction levels.
-    EncodeBatch& e = eb[gi]; e.main_stream = gi;
+    EncodeBatch& e = eb[gi]; e.main_stream = sid;
     size_t n_levels = db[gi].level_frames.size(), fork_level = 0;
     for (size_t q = 0; q < e.frames.size(); q++) if (e.frame_is_idr[q]) {
       const int si = e.frame_stream[q], local = (int)q - e.stream_first[si];
       fork_level = std::max(fork_level, (size_t)db[gi].frames[db[gi].stream_first[si] + local].level);
     }
     int intra_done = 0;
-    const bool fork = k == 0 && ng <= rbtk::RBT_AUX_STREAM && jobs.empty() && e.pad_jobs.empty() && fork_level + 1 < n_levels;   // longest pipeline only: one spare stream
+    const bool fork = k == 0 && j.has_aux && ng <= rbtk::RBT_AUX_STREAM && jobs.empty() && e.pad_jobs.empty() && fork_level + 1 < n_levels;   // longest pipeline only: one spare stream
     const bool banded = db[gi].d_save != nullptr && !db[gi].ordered_parse;
-    rc = banded ? decode_launch_chunked(db[gi], parse_bands(), gi, rbtk::RBT_AUX_STREAM) : decode_launch_parse(db[gi]);
+    rc = banded ? decode_launch_chunked(db[gi], parse_bands(), sid, aux) : decode_launch_parse(db[gi]);
     if (rc) { err = db[gi].err; break; }
     rbtk::timer_begin(T_RECON);
     for (size_t l = 0; l < n_levels; l++) {
       if (!(banded && l == 0)) decode_launch_level(db[gi], l);
       if (fork && l == fork_level) {
-        e.aux_stream = rbtk::RBT_AUX_STREAM;
-        rbtk::stream_wait(e.aux_stream, gi);
-        rbtk::set_stream(e.aux_stream); encode_launch_intra(e); intra_done = rbtk::stream_mark(e.aux_stream); encode_launch_entropy_intra(e); rbtk::set_stream(gi);
+        e.aux_stream = aux;
+        rbtk::stream_wait(e.aux_stream, sid);
+        rbtk::set_stream(e.aux_stream); encode_launch_intra(e); intra_done = rbtk::stream_mark(e.aux_stream); encode_launch_entropy_intra(e); rbtk::set_stream(sid);
       }
     }
     rbtk::timer_end(T_RECON);
-    if (!jobs.empty()) { rbtk::timer_begin(T_POOL); for (const PoolJob& j : jobs) rbtk::launch_pool(j.in, j.stride, j.w, j.h, 2, j.y, j.cb, j.cr, j.grey); rbtk::timer_end(T_POOL); }
-    if (fork) rbtk::stream_wait_mark(gi, intra_done); else { encode_launch_intra(e); encode_launch_entropy_intra(e); }
+    if (!jobs.empty()) { rbtk::timer_begin(T_POOL); for (const PoolJob& pj : jobs) rbtk::launch_pool(pj.in, pj.stride, pj.w, pj.h, 2, pj.y, pj.cb, pj.cr, pj.grey); rbtk::timer_end(T_POOL); }
+    if (fork) rbtk::stream_wait_mark(sid, intra_done); else { encode_launch_intra(e); encode_launch_entropy_intra(e); }
     encode_launch_rest(e);
-    if (fork) rbtk::stream_wait(gi, e.aux_stream);      // the intra pictures' entropy coding on the auxiliary stream
+    if (fork) rbtk::stream_wait(sid, e.aux_stream);      // the intra pictures' entropy coding on the auxiliary stream
   }
-  // ---- phase B, shortest pipeline first: one sync per stream, then slice sizes -> pack -> NAL assembly ----
+  j.rc = rc;
+  return J;
+}
+
+// phase B, shortest pipeline first: one sync per stream, then slice sizes -> pack -> NAL assembly. Consumes the job.
+int gof_wait(GofJob* J, rbt_stats& st_out, std::string& err_out, uint8_t** out, size_t* n_out) {
+  std::unique_ptr<GofJob> guard(J); GofJob& j = *J;
+  const int n = j.n, ng = j.ng; int rc = j.rc;
+  rbt_stats& st = j.st; std::string& err = j.err;
+  std::vector<DecodeBatch>& db = j.db; std::vector<EncodeBatch>& eb = j.eb; const rbt_stream_params* p = j.params.data();
+  for (int i = 0; i < n; i++) { out[i] = nullptr; n_out[i] = 0; }
   std::vector<std::vector<uint8_t>> outs(n);
   for (int k = ng - 1; k >= 0; k--) {
-    const int gi = order[k]; const std::vector<int>& gs = groups[gi]; rbtk::set_stream(gi);
+    const int gi = j.order[k], sid = job_stream(j, gi); const std::vector<int>& gs = j.groups[gi]; rbtk::set_stream(sid);
     if (rc) { rbtk::dev_sync(); continue; }              // drain the remaining streams before their arenas are released
     if (db[gi].frames.empty()) continue;
     rc = decode_finish(db[gi]);
     if (rc) { err = db[gi].err; continue; }
     st.k_parse_ms += rbtk::timer_ms(T_PARSE); st.k_recon_ms += rbtk::timer_ms(T_RECON);
     std::vector<std::vector<uint8_t>> o1;
-    if (chained[gi]) rc = encode_finish(eb[gi], o1, st);
+    if (j.chained[gi]) rc = encode_finish(eb[gi], o1, st);
     else {
       for (size_t q = 0; q < gs.size() && !rc; q++) if (p[gs[q]].verify_md5) {
         rbt_video v; rc = decode_fetch(db[gi], (int)q, &v, true); free(v.data);
         if (rc) { err = "fetch failed"; break; }
         if (v.md5_failed) { err = "input MD5 mismatch"; rc = RBT_ERR_MD5; }
       }
-      for (size_t q = 0; q < gs.size() && !rc; q++) rc = setup_encode(db[gi], (int)q, p[gs[q]], eb[gi], pooled, err);
+      for (size_t q = 0; q < gs.size() && !rc; q++) rc = setup_encode(db[gi], (int)q, p[gs[q]], eb[gi], j.pooled, err);
       if (rc) continue;
+      eb[gi].main_stream = sid;
       rc = encode_build(eb[gi]);
       if (!rc) rc = encode_run(eb[gi], o1, st);
     }
@@ -400,8 +445,8 @@ int transcode_gof(rbt_stats& st, std::string& err, int n, const uint8_t* const* 
     for (size_t q = 0; q < gs.size(); q++) outs[gs[q]].swap(o1[q]);
   }
   rbtk::set_stream(0);
-  if (rc) return rc;
-  st.gpu_ms = now_ms() - t_gpu;
+  if (rc) { err_out = err; st_out = st; return rc; }
+  st.gpu_ms = now_ms() - j.t_gpu;
   rc = hand_out(outs, out, n_out);
   // SURVEY.md 8(d) algorithmic traffic: per coded picture of S samples (2 bytes each): decode writes S, P pictures read
   // their reference once; encode reads the source S, writes the reconstruction S (I) and reads the reference (P)
@@ -410,10 +455,20 @@ int transcode_gof(rbt_stats& st, std::string& err, int n, const uint8_t* const* 
     for (size_t k = 0; k < db[g].frames.size(); k++) { uint64_t s2 = frame_samples(db[g].frames[k].cfg) * 2; bytes += s2 + (db[g].frames[k].level ? s2 : 0); }
     for (size_t k = 0; k < eb[g].frames.size(); k++) { uint64_t s2 = frame_samples(eb[g].frames[k].cfg) * 2; bytes += s2 + s2; }
   }
-  for (int i = 0; i < n; i++) bytes += n_in[i] + n_out[i];
+  for (int i = 0; i < n; i++) bytes += j.n_in[i] + n_out[i];
   st.algorithmic_bytes = bytes;
-  st.total_ms = now_ms() - t_all;
+  st.total_ms = now_ms() - j.t_all;
+  st_out = st; err_out = err;
   return rc;
+}
+void gof_abandon(GofJob* J) {   // a job nobody will wait for: drain its streams, then free it
+  if (!J) return;
+  for (int g = 0; g < J->ng; g++) { rbtk::set_stream(job_stream(*J, g)); rbtk::dev_sync(); }
+  rbtk::set_stream(job_stream(*J, rbtk::RBT_AUX_STREAM)); rbtk::dev_sync(); rbtk::set_stream(0);
+  delete J;
+}
+int transcode_gof(rbt_stats& st, std::string& err, int n, const uint8_t* const* in, const size_t* n_in, const rbt_stream_params* p, uint8_t** out, size_t* n_out) {
+  return gof_wait(gof_submit(0, 1, n, in, n_in, p), st, err, out, n_out);
 }
 
 int encode_yuv(rbt_stats& st, std::string& err, const uint16_t* yuv, int w, int h, int bd, int n_frames, int qp, int gop, int lossless, int log2_ctb, int rows, int md5,

@@ -19,6 +19,7 @@ static double g_t[32][2];
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int dev_init(int) { return 0; }
 void set_stream(int) {}
+void map_lane(int, int) {}
 void stream_wait(int, int) {}
 int stream_mark(int) { return 0; }
 void stream_wait_mark(int, int) {}
@@ -34,9 +35,10 @@ void timer_begin(int id) { g_t[id][0] = now_ms(); }
 void timer_end(int id) { g_t[id][1] = now_ms(); }
 double timer_ms(int id) { return g_t[id][1] - g_t[id][0]; }
 
-void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices, void* save, int row_limit) {
-  static RbtParseLds plds;
-  for (int i = 0; i < n_slices; i++) rbt_parse_slice(frames, slices, slice_list[i], rbsp, &plds, (RbtParseSave*)save, row_limit);
+void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices, int max_w4, void* save, int row_limit) {
+  alignas(16) static uint32_t plds[(RBT_PARSE_LDS_BYTES(RBT_PARSE_CAP4_L) + 3) / 4];
+  const int cap4 = max_w4 <= RBT_PARSE_CAP4_S ? RBT_PARSE_CAP4_S : max_w4 <= RBT_PARSE_CAP4_M ? RBT_PARSE_CAP4_M : RBT_PARSE_CAP4_L;
+  for (int i = 0; i < n_slices; i++) rbt_parse_slice(frames, slices, slice_list[i], rbsp, (RbtParseLds*)plds, cap4, (RbtParseSave*)save, row_limit);
 }
 size_t parse_save_bytes() { return sizeof(RbtParseSave); }
 void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int y_begin, int y_end) {

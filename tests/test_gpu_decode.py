@@ -55,3 +55,16 @@ def test_corrupt_stream_is_rejected(ctx):
     bs, _ = O.encode(m["geo"], 64, 64, 10, 24, gop=2)
     with pytest.raises(R.RbtError):
         ctx.decode(bs[:40])
+
+@pytest.mark.parametrize("w", [1536, 1552, 4096, 4112])
+def test_wide_pictures_use_the_larger_parser_variants(ctx, w):
+    """the slice parser's LDS line buffers come in three sizes (pictures up to 1536 / 4096 / 8192 samples wide): widths on
+    both sides of each boundary, several CTB rows so that every above-neighbour path reads the line buffers"""
+    h = 48
+    r = np.random.default_rng(w)
+    fr = r.integers(0, 1024, (2, w * h * 3 // 2)).astype(np.uint16)
+    fr[1] = np.clip(fr[0].astype(int) + r.integers(-2, 3, fr[0].shape), 0, 1023)
+    for log2_ctb, seed in ((4, 0), (6, 7)):
+        bs, rec = O.encode(fr, w, h, 10, qp=34, gop=2, stress_seed=seed, log2_ctb=log2_ctb)
+        dec, dw, dh, dbd, chk, fail = ctx.decode(bs)
+        assert (dw, dh, fail) == (w, h, 0) and np.array_equal(dec, rec)

@@ -146,3 +146,36 @@ def test_two_gofs_in_one_call_equal_single_gof_calls(ctx):
     outs = ctx.transcode_gof([a[0], a[1], a[2], b[0], b[1], b[2]], ps + ps)
     assert outs[:3] == ctx.transcode_gof([a[0], a[1], a[2]], ps)
     assert outs[3:] == ctx.transcode_gof([b[0], b[1], b[2]], ps)
+
+
+def test_two_jobs_in_flight_equal_blocking_calls(ctx):
+    """rbt_submit_gof / rbt_wait_gof: up to four GOFs in flight on disjoint HIP streams give the blocking call's outputs"""
+    R = rbt_lib.module()
+    a = list(_r5_streams(192, 128, 4, 303)[:3]); b = list(_r5_streams(128, 192, 4, 404)[:3])
+    P = R.StreamParams
+    ps = [P(0, 8, 4, 5, 1, 1, 0), P(1, 24, 4, 5, 1, 1, 0), P(19, 32, 4, 5, 1, 1, 0)]
+    want_a, want_b = ctx.transcode_gof(a, ps), ctx.transcode_gof(b, ps)
+    ctx.set_depth(4)
+    for _ in range(3):
+        ja = ctx.submit_gof(a, ps); jb = ctx.submit_gof(b, ps); jc = ctx.submit_gof(b, ps); jd = ctx.submit_gof(a, ps)
+        with pytest.raises(R.RbtError) as e:
+            ctx.submit_gof(a, ps)
+        assert e.value.code == -7
+        assert ctx.wait_gof(jb) == want_b and ctx.wait_gof(jd) == want_a and ctx.wait_gof(ja) == want_a and ctx.wait_gof(jc) == want_b
+    # steady-state pipeline: submit i+1 before waiting for i
+    seq = [a, b, a, b, a]
+    outs = []; prev = ctx.submit_gof(seq[0], ps)
+    for g in seq[1:]:
+        nxt = ctx.submit_gof(g, ps); outs.append(ctx.wait_gof(prev)); prev = nxt
+    outs.append(ctx.wait_gof(prev))
+    assert outs == [want_a, want_b, want_a, want_b, want_a]
+    # deeper pipelines give each job fewer HIP streams (5: three, 6..8: two): same outputs
+    for depth in (5, 8, 1):
+        ctx.set_depth(depth)
+        jobs = [ctx.submit_gof(a if i % 2 == 0 else b, ps) for i in range(depth)]
+        with pytest.raises(R.RbtError):
+            ctx.set_depth(2)                 # refused while jobs are in flight
+        for i, jb in enumerate(jobs):
+            assert ctx.wait_gof(jb) == (want_a if i % 2 == 0 else want_b)
+    ctx.set_depth(4)
+

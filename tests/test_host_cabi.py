@@ -21,7 +21,7 @@ def _lib_path():
 def test_every_declared_symbol_is_exported():
     hdr = open(os.path.join(ROOT, "include", "rbt.h")).read()
     names = set(re.findall(r"\b(rbt_[a-z_0-9]+)\s*\(", hdr))
-    assert {"rbt_create", "rbt_destroy", "rbt_transcode_substream", "rbt_transcode_gof", "rbt_decode", "rbt_encode", "rbt_or_pool",
+    assert {"rbt_create", "rbt_destroy", "rbt_transcode_substream", "rbt_transcode_gof", "rbt_submit_gof", "rbt_wait_gof", "rbt_set_depth", "rbt_decode", "rbt_encode", "rbt_or_pool",
             "rbt_free", "rbt_strerror", "rbt_version", "rbt_get_stats", "rbt_sample_to_byte_stream", "rbt_byte_to_sample_stream"} <= names
     L = ctypes.CDLL(_lib_path())
     for n in sorted(names):

@@ -95,3 +95,52 @@ def test_two_gofs_in_one_call_equal_single_gof_calls(ctx):
     outs = ctx.transcode_gof(a + b, ps + ps)
     assert outs[:3] == ctx.transcode_gof(a, ps) and outs[3:] == ctx.transcode_gof(b, ps)
     assert outs[1] == O.transcode_substream(a[1], 1, 24) and outs[5] == O.transcode_substream(b[2], 19, 32)
+
+
+def test_two_jobs_in_flight_equal_blocking_calls(ctx):
+    """rbt_submit_gof / rbt_wait_gof: four GOFs in flight, waited for out of order, give the blocking call's outputs;
+    a fifth submit is refused (RBT_ERR_BUSY) and the slots are free again afterwards"""
+    R = rbt_lib.module()
+    def gof(w, h, n, seed):
+        geo, attr, occ = synth.make_gof(w, h, n, seed)
+        return [O.encode(occ, w // 2, h // 2, 8, 8, gop=1, lossless=1, i_qp_offset=0, log2_ctb=6, rows_per_slice=0)[0],
+                O.encode(geo, w, h, 10, 16, gop=2, log2_ctb=6, rows_per_slice=0)[0], O.encode(attr, w, h, 10, 22, gop=2, log2_ctb=6, rows_per_slice=0)[0]]
+    a, b = gof(64, 64, 2, 303), gof(128, 64, 2, 404)
+    P = R.StreamParams
+    ps = [P(0, 8, 4, 5, 1, 1, 0), P(1, 24, 4, 5, 1, 1, 0), P(19, 32, 4, 5, 1, 1, 0)]
+    want_a, want_b = ctx.transcode_gof(a, ps), ctx.transcode_gof(b, ps)
+    ctx.set_depth(4)
+    ja = ctx.submit_gof(a, ps); jb = ctx.submit_gof(b, ps); jc = ctx.submit_gof(b, ps); jd = ctx.submit_gof(a, ps)
+    with pytest.raises(R.RbtError) as e:
+        ctx.submit_gof(a, ps)
+    assert e.value.code == -7
+    assert ctx.wait_gof(jb) == want_b and ctx.wait_gof(jd) == want_a and ctx.wait_gof(ja) == want_a and ctx.wait_gof(jc) == want_b
+    with pytest.raises(R.RbtError):          # a job can be waited for once
+        ctx.wait_gof(ja)
+    dmg = bytearray(a[2]); r = np.random.default_rng(3)
+    for k in r.integers(len(dmg) // 2, len(dmg) - 8, 200): dmg[int(k)] = int(r.integers(1, 255))
+    bad = [a[0], a[1], bytes(dmg[: len(dmg) // 2 + len(dmg) // 3])]
+    jc = ctx.submit_gof(bad, ps); jd = ctx.submit_gof(b, ps)
+    with pytest.raises(R.RbtError):
+        ctx.wait_gof(jc)
+    assert ctx.wait_gof(jd) == want_b        # a failed job leaves its neighbour alone
+    ctx.set_depth(8)
+    jobs = [ctx.submit_gof(a if i % 2 == 0 else b, ps) for i in range(8)]
+    with pytest.raises(R.RbtError):
+        ctx.set_depth(2)                     # refused while jobs are in flight
+    for i, jb in enumerate(jobs):
+        assert ctx.wait_gof(jb) == (want_a if i % 2 == 0 else want_b)
+    ctx.set_depth(4)
+
+@pytest.mark.parametrize("w", [1536, 1552, 4096, 4112])
+def test_wide_pictures_use_the_larger_parser_variants(ctx, w):
+    """the slice parser's LDS line buffers come in three sizes (pictures up to 1536 / 4096 / 8192 samples wide): widths on
+    both sides of each boundary, several CTB rows so that every above-neighbour path reads the line buffers"""
+    h = 48
+    r = np.random.default_rng(w)
+    fr = r.integers(0, 1024, (2, w * h * 3 // 2)).astype(np.uint16)
+    fr[1] = np.clip(fr[0].astype(int) + r.integers(-2, 3, fr[0].shape), 0, 1023)
+    for log2_ctb, seed in ((4, 0), (6, 7)):
+        bs, rec = O.encode(fr, w, h, 10, qp=34, gop=2, stress_seed=seed, log2_ctb=log2_ctb)
+        dec, dw, dh, dbd, chk, fail = ctx.decode(bs)
+        assert (dw, dh, fail) == (w, h, 0) and np.array_equal(dec, rec)
