@@ -112,8 +112,12 @@ def main():
     D = max(1, min(args.in_flight, 16))
     stats_acc = {}
 
+    host_t = {"submit": 0.0, "wait": 0.0}
+
     def collect(job, acc):
+        c0 = time.perf_counter()
         outs = ctx.wait_gof(job)
+        host_t["wait"] += time.perf_counter() - c0
         if acc is not None:
             for k, v in ctx.stats().items():
                 acc[k] = acc.get(k, 0.0) + v
@@ -126,7 +130,9 @@ def main():
         q, outs = [], None
         for _ in range(n_steps):
             if len(q) == depth: outs = collect(q.pop(0), acc)
+            c0 = time.perf_counter()
             q.append(ctx.submit_gof(streams, params))
+            host_t["submit"] += time.perf_counter() - c0
         while q: outs = collect(q.pop(0), acc)
         return outs
 
@@ -139,10 +145,12 @@ def main():
     ctx.set_depth(D)
     run(args.warmup, D, None)
     sync()
+    host_t["submit"] = host_t["wait"] = 0.0
     t0 = time.perf_counter()
     outs = run(args.steps, D, stats_acc)
     sync()
     elapsed = time.perf_counter() - t0
+    host_submit_ms, host_wait_ms = 1000 * host_t["submit"] / args.steps, 1000 * host_t["wait"] / args.steps
     if world > 1:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
@@ -251,7 +259,7 @@ def main():
                              "traffic": traffic, "kernel_ms": {k_: round(v, 3) for k_, v in groups.items()},
                              "path_achieved_GBs": round(path_achieved, 3), "path_frac": round(path_achieved / HBM_PEAK_GBS, 6)},
                 "cpu_baseline": cpu, "multi_gof": multi, "in_flight_sweep": sweep, "quality": quality,
-                "host_ms": {"parse": round(st["host_parse_ms"], 3), "pack": round(st["host_pack_ms"], 3), "job_gpu_span": round(st["gpu_ms"], 3), "job_span": round(st["total_ms"], 3)}}
+                "host_ms": {"parse": round(st["host_parse_ms"], 3), "pack": round(st["host_pack_ms"], 3), "submit_call": round(host_submit_ms, 3), "wait_call": round(host_wait_ms, 3), "job_gpu_span": round(st["gpu_ms"], 3), "job_span": round(st["total_ms"], 3)}}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -273,7 +273,8 @@ template <int LOG2> RBT_DEV void rc_inv_transform_pair_n(int sh, int m0, int m1,
 RBT_DEV int rc_refpix(const uint16_t* p, int w, int h, int x, int y) { return p[(size_t)rbt_clip3(0, h - 1, y) * w + rbt_clip3(0, w - 1, x)]; }
 // dst(x,y) = dst[(dy0 + y) * dstride + dx0 + x]: a picture plane in HBM or the CTB tile in LDS
 template <class DP> RBT_DEV void rc_mc_plane(DP dst, int dstride, int dx0, int dy0, const uint16_t* ref, int pw, int ph, int x0, int y0, int bw, int bh, int xint, int yint, int xf, int yf, int taps,
-                         const int8_t* fx, const int8_t* fy, int bd) {
+                         const int8_t* fx, const int8_t* fy, int bd, int add_res = 0) {
+  // add_res: dst holds the residual of the block (int16 bit patterns, 0 where nothing is coded); the sample is completed in place
   int sh1 = rbt_min(4, bd - 8), sh3 = 14 - bd, half = taps / 2 - 1, maxv = (1 << bd) - 1;
   int fsh = 14 - bd, fadd = fsh ? 1 << (fsh - 1) : 0;
   RBT_PAR_FOR(i, bw * bh) {
@@ -290,7 +291,8 @@ template <class DP> RBT_DEV void rc_mc_plane(DP dst, int dstride, int dx0, int d
       }
       v = s >> 6;
     }
-    dst[(dy0 + y) * dstride + dx0 + x] = (uint16_t)rbt_clip3(0, maxv, (v + fadd) >> fsh);
+    const int o = (dy0 + y) * dstride + dx0 + x, pr = rbt_clip3(0, maxv, (v + fadd) >> fsh);
+    dst[o] = (uint16_t)(add_res ? rbt_clip3(0, maxv, pr + (int16_t)dst[o]) : pr);
   }
 }
 // ---- decoder: one CTB reconstructed inside LDS ----------------------------------------------------------------------
@@ -298,12 +300,16 @@ template <class DP> RBT_DEV void rc_mc_plane(DP dst, int dstride, int dx0, int d
 // of that chain costs a store round trip plus a load round trip (~3-5 us per TB); here the CTB's samples, its border, the
 // availability of every 4x4 unit around it and its coefficient levels are fetched into LDS once, every TB works in LDS,
 // and the finished CTB is written back with coalesced row stores.
+// The coefficient levels are staged IN the tile: a sample position holds the level of that position until its TB is
+// reconstructed (a TB reads the levels of its own area, then overwrites them with samples). Inter blocks take two steps:
+// first every inter TB of the CTB turns its levels into the residual in place (inter residuals depend on nothing), then
+// the prediction units, in decoding order, complete pred + residual in place. A separate staging area for the levels cost
+// 12 KB of LDS per workgroup, i.e. 4 instead of 7 CTBs in flight per CU.
 #define RC_TS_Y 65       // body row stride: column -1 (left border) .. n-1; the row above (-1 .. 2n-1, incl. the above-right CTB) is a separate array
 #define RC_TS_C 33
 #define RC_US 34         // unit availability stride: ux = -1 .. 32
 struct alignas(8) RbtU2 { uint32_t x, y; };
 struct RbtCtbTile {
-  alignas(16) int16_t coef_y[64 * 64]; alignas(16) int16_t coef_c[2][32 * 32];   // coefficient levels of the CTB (row stride = CTB size)
   uint16_t y[64 * RC_TS_Y], top_y[130]; uint16_t c[2][32 * RC_TS_C], top_c[2][66];   // sample (xx,yy) relative to the CTB: body yy * stride + xx + 1, row above: top[xx + 1]
   uint8_t uav[17 * RC_US];                                  // 4x4 luma unit (ux,uy) usable as intra reference: (uy + 1) * RC_US + ux + 1
 };
@@ -329,20 +335,21 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int
                         int mark_l4, int mux, int muy, int mark_flag) {
   // (x0,y0): TB origin relative to the CTB, in samples of component c_idx
   RBT_LDS_AS RbtReconLds* l = &L->rc; RBT_LDS_AS RbtCtbTile* t = &L->t;
-  const int N = 1 << log2, sh = c_idx ? 1 : 0, bd = g->bit_depth, maxv = (1 << bd) - 1, n = (1 << g->log2_ctb) >> sh, n4 = (1 << g->log2_ctb) >> 2;
+  const int N = 1 << log2, sh = c_idx ? 1 : 0, bd = g->bit_depth, maxv = (1 << bd) - 1, n4 = (1 << g->log2_ctb) >> 2;
   RBT_LDS_AS uint16_t* tile = c_idx == 0 ? t->y : t->c[c_idx - 1]; const int S = c_idx == 0 ? RC_TS_Y : RC_TS_C;
   const RBT_LDS_AS uint16_t* top = c_idx == 0 ? t->top_y : t->top_c[c_idx - 1];
-  RBT_LDS_AS int16_t* coef = c_idx == 0 ? t->coef_y : t->coef_c[c_idx - 1];
+  const RBT_LDS_AS int16_t* coef = (const RBT_LDS_AS int16_t*)tile + 1;      // levels of the TB: where its samples will be (row stride S)
 #ifdef RBT_PROFILE
   unsigned long long p0_ = __builtin_readcyclecounter(), p1_ = p0_, p2_ = p0_, p3_ = p0_;
 #endif
   // residual first: it does not depend on the prediction, and the prediction pass can then add it on the fly
   if (cbf) {
     if (tq_bypass) {
-      RBT_PAR_FOR(i, N * N) { int x = i & (N - 1), y = i >> log2; l->res[i] = coef[(y0 + y) * n + x0 + x]; }
+      if (!intra) return;                                                    // inter + bypass: the levels are the residual already
+      RBT_PAR_FOR(i, N * N) { int x = i & (N - 1), y = i >> log2; l->res[i] = coef[(y0 + y) * S + x0 + x]; }
       RBT_SYNC_LDS();
     } else {
-      rc_dequant(coef, n, x0, y0, log2, qp, bd, l);
+      rc_dequant(coef, S, x0, y0, log2, qp, bd, l);
       rc_inv_transform(log2, c_idx == 0 && log2 == 2 && intra, ts, bd, l);
     }
   }
@@ -371,12 +378,14 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int
 #ifdef RBT_PROFILE
   p2_ = p3_ = __builtin_readcyclecounter();
 #endif
-  if (intra || cbf) {
+  if (intra) {
     RBT_PAR_FOR(i, N * N) {
       int x = i & (N - 1), y = i >> log2, o = (y0 + y) * S + x0 + x + 1;
-      int base = intra ? rc_intra_sample(&q, fin, l->ref, x, y) : tile[o];
+      int base = rc_intra_sample(&q, fin, l->ref, x, y);
       tile[o] = (uint16_t)(cbf ? rbt_clip3(0, maxv, base + l->res[i]) : base);
     }
+  } else if (cbf) {                                                          // inter: leave the residual where the levels were
+    RBT_PAR_FOR(i, N * N) { int x = i & (N - 1), y = i >> log2; tile[(y0 + y) * S + x0 + x + 1] = (uint16_t)l->res[i]; }
   }
   if (mark_l4 >= 0) { RBT_PAR_FOR(i, 1 << (2 * mark_l4)) t->uav[(muy + (i >> mark_l4) + 1) * RC_US + mux + (i & ((1 << mark_l4) - 1)) + 1] = (uint8_t)mark_flag; }
   RBT_SYNC_LDS();
@@ -388,10 +397,11 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int
 // differ only in data, so every phase (and every wait for LDS) is paid once for both; chroma is never smoothed (8.4.4.2.3).
 RBT_DEV void rc_tile_tb_cpair(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int x0, int y0, int log2, int intra, int mode, int cbf_cb, int cbf_cr, int tq_bypass, int qp_cb, int qp_cr) {
   RBT_LDS_AS RbtReconLds* l = &L->rc; RBT_LDS_AS RbtCtbTile* t = &L->t;
-  const int N = 1 << log2, NN = N * N, bd = g->bit_depth, maxv = (1 << bd) - 1, n = (1 << g->log2_ctb) >> 1, n4 = (1 << g->log2_ctb) >> 2, S = RC_TS_C;
+  const int N = 1 << log2, NN = N * N, bd = g->bit_depth, maxv = (1 << bd) - 1, n4 = (1 << g->log2_ctb) >> 2, S = RC_TS_C;
   if (cbf_cb | cbf_cr) {
     if (tq_bypass) {
-      RBT_PAR_FOR(i, 2 * NN) { const int b = i >= NN, j = i - b * NN, x = j & (N - 1), y = j >> log2; if (b ? cbf_cr : cbf_cb) l->res[b * 256 + j] = t->coef_c[b][(y0 + y) * n + x0 + x]; }
+      if (!intra) return;                                                    // inter + bypass: the levels are the residual already
+      RBT_PAR_FOR(i, 2 * NN) { const int b = i >= NN, j = i - b * NN, x = j & (N - 1), y = j >> log2; if (b ? cbf_cr : cbf_cb) l->res[b * 256 + j] = ((const RBT_LDS_AS int16_t*)t->c[b])[(y0 + y) * S + x0 + x + 1]; }
       RBT_SYNC_LDS();
     } else {
       const int bd_shift = bd + log2 - 5, sc_cb = (16 * rc_level_scale(qp_cb % 6)) << (qp_cb / 6), sc_cr = (16 * rc_level_scale(qp_cr % 6)) << (qp_cr / 6);
@@ -399,7 +409,7 @@ RBT_DEV void rc_tile_tb_cpair(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* 
       RBT_PAR_FOR(i, 2 * NN) {
         const int b = i >= NN, j = i - b * NN, x = j & (N - 1), y = j >> log2;
         if (b ? cbf_cr : cbf_cb) {
-          long long v = ((long long)t->coef_c[b][(y0 + y) * n + x0 + x] * (b ? sc_cr : sc_cb) + add) >> bd_shift;
+          long long v = ((long long)((const RBT_LDS_AS int16_t*)t->c[b])[(y0 + y) * S + x0 + x + 1] * (b ? sc_cr : sc_cb) + add) >> bd_shift;
           l->res[b * 256 + j] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
         }
       }
@@ -455,10 +465,10 @@ RBT_DEV void rc_tile_tb_cpair(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* 
     RBT_PAR_FOR(i, 2 * NN) {
       const int b = i >= NN, j = i - b * NN, x = j & (N - 1), y = j >> log2, o = (y0 + y) * S + x0 + x + 1, cbf = b ? cbf_cr : cbf_cb;
       RBT_LDS_AS uint16_t* tile = t->c[b];
-      if (intra || cbf) {
-        const int base = intra ? rc_intra_sample(b ? &q1 : &q0, l->nb + b * 66, b ? l->ref2 : l->ref, x, y) : tile[o];
+      if (intra) {
+        const int base = rc_intra_sample(b ? &q1 : &q0, l->nb + b * 66, b ? l->ref2 : l->ref, x, y);
         tile[o] = (uint16_t)(cbf ? rbt_clip3(0, maxv, base + l->res[b * 256 + j]) : base);
-      }
+      } else if (cbf) tile[o] = (uint16_t)l->res[b * 256 + j];           // inter: leave the residual where the levels were
     }
   }
   RBT_SYNC_LDS();
@@ -501,14 +511,15 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
     RBT_PAR_FOR(i, 2 * nn + 1) { int x = ox + i - 1, y = oy - 1; top[i] = (x >= 0 && y >= 0 && x < pw) ? p[(size_t)y * pw + x] : 0; }
     RBT_PAR_FOR(i, nn) { int x = ox - 1, y = oy + i; tile[i * S] = (x >= 0 && y < ph) ? p[(size_t)y * pw + x] : 0; }
     // coefficient levels: 4 per lane and load (8-byte aligned: widths are multiples of 8, chroma of 4), several loads in flight
-    const RbtU2* cp = (const RbtU2*)(f->coef[c] + (size_t)oy * pw + ox); RBT_LDS_AS RbtU2* cd = (RBT_LDS_AS RbtU2*)(c == 0 ? t->coef_y : t->coef_c[c - 1]);
+    const RbtU2* cp = (const RbtU2*)(f->coef[c] + (size_t)oy * pw + ox);
     const int q4 = nn >> 2, lq4 = g->log2_ctb - sh - 2, rows = rbt_min(nn, ph - oy), cols4 = rbt_min(nn, pw - ox) >> 2;
 #pragma unroll 4
     RBT_PAR_FOR(i, nn * q4) {
       const int x4 = i & (q4 - 1), y = i >> lq4;
       RbtU2 v; v.x = 0; v.y = 0;
       if (x4 < cols4 && y < rows) v = cp[((size_t)y * pw >> 2) + x4];
-      cd[i].x = v.x; cd[i].y = v.y;
+      RBT_LDS_AS uint16_t* d = tile + y * S + 4 * x4 + 1;                   // into the body of the tile (rows are not 8-byte aligned there)
+      d[0] = (uint16_t)v.x; d[1] = (uint16_t)(v.x >> 16); d[2] = (uint16_t)v.y; d[3] = (uint16_t)(v.y >> 16);
     }
   }
   RBT_PAR_FOR(i, 17 * RC_US) {
@@ -520,7 +531,27 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
 #ifdef RBT_PROFILE
   unsigned long long q1_ = __builtin_readcyclecounter();
 #endif
-  // ---- the CTB's commands, in decoding order ----
+  // ---- inter TBs first (P slices): levels -> residual in place ----
+  const int has_inter = sl->slice_type != RBT_SLICE_I;
+  if (has_inter) {
+    RbtCmd nx0; if (n) nx0 = cmds[0];
+    for (uint32_t k = 0; k < n; k++) {
+      const RbtCmd c = nx0;
+      if (k + 1 < n) nx0 = cmds[k + 1];
+      if (c.type != RBT_CMD_TU || (c.a & RBT_TU_INTRA)) continue;
+      const int x0 = c.x4 * 4, y0 = c.y4 * 4, fl = c.a, log2 = c.log2;
+      if (fl & RBT_TU_CBF_Y) rc_tile_tb(g, L, 0, x0, y0, log2, 0, c.b, 1, (fl & RBT_TU_TS_Y) != 0, c.d, c.qp[0], -1, 0, 0, 0);
+      if ((fl & RBT_TU_CHROMA) && (fl & (RBT_TU_CBF_CB | RBT_TU_CBF_CR))) {
+        const int xc = (log2 > 2 ? x0 : x0 - 4) >> 1, yc = (log2 > 2 ? y0 : y0 - 4) >> 1, l2c = log2 > 2 ? log2 - 1 : 2;
+        if (fl & (RBT_TU_TS_CB | RBT_TU_TS_CR)) {
+          if (fl & RBT_TU_CBF_CB) rc_tile_tb(g, L, 1, xc, yc, l2c, 0, c.c, 1, (fl & RBT_TU_TS_CB) != 0, c.d, c.qp[1], -1, 0, 0, 0);
+          if (fl & RBT_TU_CBF_CR) rc_tile_tb(g, L, 2, xc, yc, l2c, 0, c.c, 1, (fl & RBT_TU_TS_CR) != 0, c.d, c.qp[2], -1, 0, 0, 0);
+        } else rc_tile_tb_cpair(g, L, xc, yc, l2c, 0, c.c, (fl & RBT_TU_CBF_CB) != 0, (fl & RBT_TU_CBF_CR) != 0, c.d, c.qp[1], c.qp[2]);
+      }
+    }
+    RBT_SYNC_LDS();
+  }
+  // ---- the CTB's commands, in decoding order: prediction units complete pred + residual, intra TBs predict and add ----
   RbtCmd nxt; if (n) nxt = cmds[0];
   for (uint32_t k = 0; k < n; k++) {
     const RbtCmd c = nxt;
@@ -529,20 +560,20 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
     if (c.type == RBT_CMD_PU) {
       const RbtFrame* ref = &frames[sl->ref_frame[c.c]];
       const int w = c.a * 4, h = c.b * 4, mvx = c.mvx, mvy = c.mvy;
-      rc_mc_plane(t->y, RC_TS_Y, x0 + 1, y0, ref->out[0], g->w, g->h, cx + x0, cy + y0, w, h, mvx >> 2, mvy >> 2, mvx & 3, mvy & 3, 8, k_luma_filter[mvx & 3], k_luma_filter[mvy & 3], g->bit_depth);
+      rc_mc_plane(t->y, RC_TS_Y, x0 + 1, y0, ref->out[0], g->w, g->h, cx + x0, cy + y0, w, h, mvx >> 2, mvy >> 2, mvx & 3, mvy & 3, 8, k_luma_filter[mvx & 3], k_luma_filter[mvy & 3], g->bit_depth, 1);
       for (int cc = 1; cc < 3; cc++)
         rc_mc_plane(t->c[cc - 1], RC_TS_C, (x0 >> 1) + 1, y0 >> 1, ref->out[cc], g->cw, g->ch, (cx + x0) >> 1, (cy + y0) >> 1, w >> 1, h >> 1, mvx >> 3, mvy >> 3, mvx & 7, mvy & 7, 4,
-                    k_chroma_filter[mvx & 7], k_chroma_filter[mvy & 7], g->bit_depth);
+                    k_chroma_filter[mvx & 7], k_chroma_filter[mvy & 7], g->bit_depth, 1);
       rc_tile_mark(t, c.x4, c.y4, c.a, c.b, !g->cip);
-    } else if (c.type == RBT_CMD_TU) {
-      const int fl = c.a, log2 = c.log2, intra = (fl & RBT_TU_INTRA) != 0;
-      rc_tile_tb(g, L, 0, x0, y0, log2, intra, c.b, fl & RBT_TU_CBF_Y, (fl & RBT_TU_TS_Y) != 0, c.d, c.qp[0], log2 - 2, c.x4, c.y4, intra || !g->cip);
+    } else if (c.type == RBT_CMD_TU && (c.a & RBT_TU_INTRA)) {
+      const int fl = c.a, log2 = c.log2;
+      rc_tile_tb(g, L, 0, x0, y0, log2, 1, c.b, fl & RBT_TU_CBF_Y, (fl & RBT_TU_TS_Y) != 0, c.d, c.qp[0], log2 - 2, c.x4, c.y4, 1);
       if (fl & RBT_TU_CHROMA) {
         const int xc = (log2 > 2 ? x0 : x0 - 4) >> 1, yc = (log2 > 2 ? y0 : y0 - 4) >> 1, l2c = log2 > 2 ? log2 - 1 : 2;
         if (fl & (RBT_TU_TS_CB | RBT_TU_TS_CR)) {                      // transform skip (rare): one plane at a time
-          rc_tile_tb(g, L, 1, xc, yc, l2c, intra, c.c, fl & RBT_TU_CBF_CB, (fl & RBT_TU_TS_CB) != 0, c.d, c.qp[1], -1, 0, 0, 0);
-          rc_tile_tb(g, L, 2, xc, yc, l2c, intra, c.c, fl & RBT_TU_CBF_CR, (fl & RBT_TU_TS_CR) != 0, c.d, c.qp[2], -1, 0, 0, 0);
-        } else rc_tile_tb_cpair(g, L, xc, yc, l2c, intra, c.c, (fl & RBT_TU_CBF_CB) != 0, (fl & RBT_TU_CBF_CR) != 0, c.d, c.qp[1], c.qp[2]);
+          rc_tile_tb(g, L, 1, xc, yc, l2c, 1, c.c, fl & RBT_TU_CBF_CB, (fl & RBT_TU_TS_CB) != 0, c.d, c.qp[1], -1, 0, 0, 0);
+          rc_tile_tb(g, L, 2, xc, yc, l2c, 1, c.c, fl & RBT_TU_CBF_CR, (fl & RBT_TU_TS_CR) != 0, c.d, c.qp[2], -1, 0, 0, 0);
+        } else rc_tile_tb_cpair(g, L, xc, yc, l2c, 1, c.c, (fl & RBT_TU_CBF_CB) != 0, (fl & RBT_TU_CBF_CR) != 0, c.d, c.qp[1], c.qp[2]);
       }
     }
   }
