@@ -73,8 +73,8 @@ int rbt_transcode_substream(rbt_ctx* ctx, const uint8_t* annexb_in, size_t n_in,
 #define RBT_MAX_STREAMS 96
 int rbt_transcode_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out);
 
-/* rbt_transcode_gof in two halves, for the caller that walks a sequence GOF by GOF (the loop around transcodeData,
- * PCCTranscoder.cpp:145-168): submit builds the batch and enqueues every kernel of the GOF, wait collects the streams.
+/* rbt_transcode_gof in two halves, for the caller that walks a sequence GOF by GOF (PccAppTranscoder.cpp:307-341 calls
+ * transcode -> transcodeData, PCCTranscoder.cpp:66-70 / :145-168, once per GOF): submit builds the batch and enqueues every kernel of the GOF, wait collects the streams.
  * Several transcodes may be in flight; they use disjoint HIP streams, so the entropy decoding of GOF i+1 (a few hundred lone
  * waves) runs underneath the entropy decoding, reconstruction and re-encode of GOF i. The input buffers may be released as soon
  * as submit returns. Jobs may be waited for in any order; every submitted job must be waited for (rbt_destroy drains what is

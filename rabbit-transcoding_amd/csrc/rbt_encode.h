@@ -25,12 +25,16 @@ struct RbtEncLds {             // inter coding (k_enc_inter)
   RbtReconLds rc;
   int16_t lvl[32 * 32];      // quantised levels of the current TB
 };
-struct RbtEntropyLds {         // entropy coder (k_entropy): 14 KB, every slice of a 64-picture batch resident at once
-  alignas(16) int16_t ctb_y[64 * 64]; alignas(16) int16_t ctb_c[2][32 * 32];   // levels of the current CTB (row stride = CTB size), fetched once per CTB
+struct RbtEntropyLds {         // entropy coder (k_entropy): every slice of a 64-picture batch resident at once
   uint8_t scan[3][4][64];    // k_scan staged once per slice
   uint8_t cu_l2[81], cu_md[81], cu_fl[81];   // cu_log2 / cu_mode / cu_flags of the CTB's 8x8 units and of the column / row before it:
                                              // (uy + 1) * 9 + ux + 1, ux,uy = -1..7; cu_l2 = 0xFF where the unit is not available (6.4.1)
+  // levels of the current CTB (n = CTB size, row stride n / n/2), fetched once per CTB: Y at 0, Cb at n*n, Cr at n*n*5/4. LAST member:
+  // the kernel variant for CTBs up to 32x32 declares only RBT_ENTROPY_LDS_BYTES(5) of it (4.3 instead of 13 KB per slice)
+  alignas(16) int16_t lv[64 * 64 * 3 / 2];
 };
+#define RBT_ENTROPY_LDS_BYTES(tl2) (sizeof(RbtEntropyLds) - sizeof(int16_t) * (64 * 64 * 3 / 2 - (3 << (2 * (tl2) - 1))))
+RBT_DEV RBT_LDS_AS int16_t* en_lv(RBT_LDS_AS RbtEntropyLds* l, int c, int log2_ctb) { const int nn = 1 << (2 * log2_ctb); return l->lv + (c == 0 ? 0 : c == 1 ? nn : nn + (nn >> 2)); }
 
 // sum of v over the lanes of the wave (host emulation: the PAR_FOR already accumulated everything)
 RBT_DEV int en_wave_sum(int v, RBT_LDS_AS RbtEncLds* l) {
@@ -287,23 +291,24 @@ RBT_DEV void en_fill_cu_maps(RbtFrame* f, int x0, int y0, int N, int pm_val, int
 // coalesced row stores. Levels go straight to the coefficient plane (nobody waits for those stores).
 // The body and the row above it are separate arrays (the row above spans 2n+1 samples, the body n+1 per row): 17 KB per
 // workgroup instead of 29, which together with the rest keeps five workgroups (every CTB row of a 32-picture batch) on a CU.
-#define EN_TS_Y 65
-#define EN_TS_C 33
-struct RbtEncTile {
-  uint16_t y[64 * EN_TS_Y], top_y[130];                      // body: yy * stride + xx + 1 (xx = -1..63); top: xx + 1 (xx = -1..128)
-  uint16_t c[2][32 * EN_TS_C], top_c[2][66];
-  uint8_t uav[17 * RC_US];
+// TL2 = log2 of the largest CTB the kernel variant handles (5 or 6). The transcoder codes with 32x32 CTBs by default, and a
+// tile sized for 64x64 costs 28 KB of LDS per workgroup instead of 18 (5 instead of 8 slices in flight per CU).
+template <int TL2> struct RbtEncTileT {
+  static constexpr int TS_Y = (1 << TL2) + 1, TS_C = (1 << (TL2 - 1)) + 1;   // body row strides: column -1 (left border) .. n-1
+  uint16_t y[(1 << TL2) * TS_Y], top_y[2 * (1 << TL2) + 2];   // body: yy * stride + xx + 1 (xx = -1..n-1); top: xx + 1 (xx = -1..2n-1)
+  uint16_t c[2][(1 << (TL2 - 1)) * TS_C], top_c[2][(1 << TL2) + 2];
+  uint8_t uav[((1 << (TL2 - 2)) + 1) * RC_US];
   uint16_t sb[32 * 32 + 2 * 16 * 16];                        // source samples of the current CU: Y, Cb, Cr
   uint8_t cu_l2[64], cu_md[64];                              // cu_log2 / cu_mode of the CTB's 8x8 units (analysis result)
 };
-struct RbtEncTileLds { RbtReconLds rc; int16_t lvl[32 * 32]; RbtEncTile t; };
+template <int TL2> struct RbtEncTileLdsT { RbtReconLds rc; int16_t lvl[32 * 32]; RbtEncTileT<TL2> t; };
 RBT_DEV int en_quant_scale(int r) { const uint64_t lo = 26214ull | (23302ull << 16) | (20560ull << 32) | (18396ull << 48), hi = 16384ull | (14564ull << 16); return (int)(((r < 4 ? lo : hi) >> (16 * (r & 3))) & 0xFFFF); }
 // one intra TB: (x0,y0) relative to the CTB and (gx,gy) in the picture, both in samples of component c_idx; returns cbf
-RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLds* L, int c_idx, int x0, int y0, int gx, int gy, int log2, int mode, int qp,
+template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int c_idx, int x0, int y0, int gx, int gy, int log2, int mode, int qp,
                              const RBT_LDS_AS uint16_t* src, int mark_l4, int mux, int muy) {
-  RBT_LDS_AS RbtEncTileLds* l = L; RBT_LDS_AS RbtReconLds* r = &L->rc; RBT_LDS_AS RbtEncTile* t = &L->t;
+  RBT_LDS_AS RbtEncTileLdsT<TL2>* l = L; RBT_LDS_AS RbtReconLds* r = &L->rc; RBT_LDS_AS RbtEncTileT<TL2>* t = &L->t;
   const int N = 1 << log2, sh = c_idx ? 1 : 0, bd = g->bit_depth, maxv = (1 << bd) - 1, n4 = (1 << g->log2_ctb) >> 2, pw = c_idx ? g->cw : g->w;
-  RBT_LDS_AS uint16_t* tile = c_idx == 0 ? t->y : t->c[c_idx - 1]; const int S = c_idx == 0 ? EN_TS_Y : EN_TS_C;
+  RBT_LDS_AS uint16_t* tile = c_idx == 0 ? t->y : t->c[c_idx - 1]; const int S = c_idx == 0 ? RbtEncTileT<TL2>::TS_Y : RbtEncTileT<TL2>::TS_C;
   const RBT_LDS_AS uint16_t* top = c_idx == 0 ? t->top_y : t->top_c[c_idx - 1];
   // reference samples: availability masks, substitution while gathering, smoothing, mode set-up
   const int tot = 4 * N + 1;
@@ -362,10 +367,10 @@ RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtE
   return nz != 0;
 }
 // Cb and Cr TB of one CU in the same passes (see rc_tile_tb_cpair); returns cbf_cb | cbf_cr << 1. src: Cb block, then Cr at +256.
-RBT_DEV int en_tile_intra_tb_cpair(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLds* L, int x0, int y0, int gx, int gy, int log2, int mode, int qp_cb, int qp_cr,
+template <int TL2> RBT_DEV int en_tile_intra_tb_cpair(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int x0, int y0, int gx, int gy, int log2, int mode, int qp_cb, int qp_cr,
                                    const RBT_LDS_AS uint16_t* src) {
-  RBT_LDS_AS RbtReconLds* r = &L->rc; RBT_LDS_AS RbtEncTile* t = &L->t;
-  const int N = 1 << log2, NN = N * N, bd = g->bit_depth, maxv = (1 << bd) - 1, n4 = (1 << g->log2_ctb) >> 2, pw = g->cw, S = EN_TS_C;
+  RBT_LDS_AS RbtReconLds* r = &L->rc; RBT_LDS_AS RbtEncTileT<TL2>* t = &L->t;
+  const int N = 1 << log2, NN = N * N, bd = g->bit_depth, maxv = (1 << bd) - 1, n4 = (1 << g->log2_ctb) >> 2, pw = g->cw, S = RbtEncTileT<TL2>::TS_C;
   const int tot = 4 * N + 1;
   uint64_t m0, m1 = 0; const int m2 = 0;
   RBT_VBALLOT(m0, p, rbt_min(tot, 64), rc_nb_av(t->uav, p, x0, y0, N, 1, n4));
@@ -452,22 +457,22 @@ RBT_DEV int en_tile_intra_tb_cpair(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_A
 }
 // carry_left: the CTB to the left was coded by this wave just before (its reconstruction is still in the tile): take the
 // left border from LDS instead of reading back stores that may still be in flight
-RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtEncTileLds* L, int carry_left) {
+template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int carry_left) {
   const RbtStreamCfg gcopy = f->cfg; const RbtStreamCfg* g = &gcopy;
-  RBT_LDS_AS RbtEncTile* t = &L->t;
+  RBT_LDS_AS RbtEncTileT<TL2>* t = &L->t;
   const int ctb = 1 << g->log2_ctb, n4 = ctb >> 2, n8 = ctb >> 3, rx = ctb_addr % g->w_ctb, ry = ctb_addr / g->w_ctb, cx = rx << g->log2_ctb, cy = ry << g->log2_ctb;
   const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
   const int qp_y = sl->qp, bd = g->bit_depth;
   const int qp_l = qp_y + 6 * (bd - 8), qp_cb = en_chroma_qp(f, sl, 1, qp_y), qp_cr = en_chroma_qp(f, sl, 2, qp_y);
   // ---- borders, unit availability, analysis results ----
   for (int c = 0; c < 3; c++) {
-    const int sh = c ? 1 : 0, nn = ctb >> sh, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, ox = cx >> sh, oy = cy >> sh, S = c ? EN_TS_C : EN_TS_Y;
+    const int sh = c ? 1 : 0, nn = ctb >> sh, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, ox = cx >> sh, oy = cy >> sh, S = c ? RbtEncTileT<TL2>::TS_C : RbtEncTileT<TL2>::TS_Y;
     const uint16_t* p = f->pix[c]; RBT_LDS_AS uint16_t* tile = c == 0 ? t->y : t->c[c - 1]; RBT_LDS_AS uint16_t* top = c == 0 ? t->top_y : t->top_c[c - 1];
     if (carry_left) { RBT_PAR_FOR(i, nn) tile[i * S] = tile[i * S + nn]; RBT_SYNC_LDS(); }
     else { RBT_PAR_FOR(i, nn) { int x = ox - 1, y = oy + i; tile[i * S] = (x >= 0 && y < ph) ? p[(size_t)y * pw + x] : 0; } }
     RBT_PAR_FOR(i, 2 * nn + 1) { int x = ox + i - 1, y = oy - 1; top[i] = (x >= 0 && y >= 0 && x < pw) ? p[(size_t)y * pw + x] : 0; }
   }
-  RBT_PAR_FOR(i, 17 * RC_US) {
+  RBT_PAR_FOR(i, ((1 << (TL2 - 2)) + 1) * RC_US) {
     int ux = i % RC_US - 1, uy = i / RC_US - 1, a = 0;
     if ((uy < 0 && ux < 2 * n4) || (ux < 0 && uy < n4)) a = rc_unit_avail(f, ctb_addr, (cx >> 2) + ux, (cy >> 2) + uy);
     t->uav[i] = (uint8_t)a;
@@ -500,7 +505,7 @@ RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT
   }
   // ---- write the CTB back (clipped to the picture) ----
   for (int c = 0; c < 3; c++) {
-    const int sh = c ? 1 : 0, nn = ctb >> sh, lnn = g->log2_ctb - sh, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, ox = cx >> sh, oy = cy >> sh, S = c ? EN_TS_C : EN_TS_Y;
+    const int sh = c ? 1 : 0, nn = ctb >> sh, lnn = g->log2_ctb - sh, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, ox = cx >> sh, oy = cy >> sh, S = c ? RbtEncTileT<TL2>::TS_C : RbtEncTileT<TL2>::TS_Y;
     uint16_t* p = f->pix[c]; RBT_LDS_AS uint16_t* tile = c == 0 ? t->y : t->c[c - 1];
     RBT_PAR_FOR(i, nn * nn) { int x = i & (nn - 1), y = i >> lnn; if (ox + x < pw && oy + y < ph) p[(size_t)(oy + y) * pw + ox + x] = tile[y * S + x + 1]; }
   }
@@ -710,7 +715,7 @@ RBT_DEV void en_stage_ctb(RbtEnt* s, int cx, int cy) {
   // the CTB's levels: 8-byte groups of four, several loads in flight (one HBM round trip per CTB instead of one per CU)
   for (int c = 0; c < 3; c++) {
     const int sh = c ? 1 : 0, nn = (1 << L) >> sh, pw = s->w >> sh, ph = s->h >> sh, ox = cx >> sh, oy = cy >> sh;
-    const RbtU2* cp = (const RbtU2*)(f->coef[c] + (size_t)oy * pw + ox); RBT_LDS_AS RbtU2* cd = (RBT_LDS_AS RbtU2*)(c == 0 ? l->ctb_y : l->ctb_c[c - 1]);
+    const RbtU2* cp = (const RbtU2*)(f->coef[c] + (size_t)oy * pw + ox); RBT_LDS_AS RbtU2* cd = (RBT_LDS_AS RbtU2*)en_lv(l, c, L);
     const int q4 = nn >> 2, lq4 = L - sh - 2, rows = rbt_min(nn, ph - oy), cols4 = rbt_min(nn, pw - ox) >> 2;
 #pragma unroll 4
     RBT_PAR_FOR(i, nn * q4) {
@@ -778,9 +783,9 @@ RBT_DEV void en_write_cu(RbtEnt* s, int x0, int y0, int log2, int depth) {
   unsigned long long tr_ = __builtin_readcyclecounter(); s->t_cu += tr_ - tc_;
 #endif
   const int ctb = 1 << s->log2_ctb, rx0 = x0 - s->cx, ry0 = y0 - s->cy;
-  if (cbf_y) en_write_residual(s, 0, l->ctb_y + ry0 * ctb + rx0, ctb, log2, en_scan_idx(intra, log2, 0, mode));
-  if (cbf_cb) en_write_residual(s, 1, l->ctb_c[0] + (ry0 >> 1) * (ctb >> 1) + (rx0 >> 1), ctb >> 1, log2 - 1, en_scan_idx(intra, log2 - 1, 1, mode));
-  if (cbf_cr) en_write_residual(s, 2, l->ctb_c[1] + (ry0 >> 1) * (ctb >> 1) + (rx0 >> 1), ctb >> 1, log2 - 1, en_scan_idx(intra, log2 - 1, 2, mode));
+  if (cbf_y) en_write_residual(s, 0, en_lv(l, 0, s->log2_ctb) + ry0 * ctb + rx0, ctb, log2, en_scan_idx(intra, log2, 0, mode));
+  if (cbf_cb) en_write_residual(s, 1, en_lv(l, 1, s->log2_ctb) + (ry0 >> 1) * (ctb >> 1) + (rx0 >> 1), ctb >> 1, log2 - 1, en_scan_idx(intra, log2 - 1, 1, mode));
+  if (cbf_cr) en_write_residual(s, 2, en_lv(l, 2, s->log2_ctb) + (ry0 >> 1) * (ctb >> 1) + (rx0 >> 1), ctb >> 1, log2 - 1, en_scan_idx(intra, log2 - 1, 2, mode));
 #ifdef RBT_PROFILE
   s->t_res += __builtin_readcyclecounter() - tr_;
 #endif

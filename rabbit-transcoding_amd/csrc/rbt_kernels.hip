@@ -182,21 +182,24 @@ __global__ void __launch_bounds__(64) k_enc_analyse(RbtFrame* frames, const RbtS
   if ((int)blockIdx.x >= f->cfg.w_ctb * f->cfg.h_ctb) return;
   en_analyse_ctb(f, slices, blockIdx.x, RBT_LDS_CAST(RbtAnalyseLds, &lds));
 }
+// (TL2: log2 of the largest CTB of the launch; fixes the size of the reconstruction tile in LDS)
+template <int TL2>
 __global__ void __launch_bounds__(64) k_enc_intra_rows(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
-  __shared__ RbtEncTileLds lds;
+  __shared__ RbtEncTileLdsT<TL2> lds;
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   int row = blockIdx.x;
   if (row >= f->cfg.h_ctb) return;
-  rc_stage_tables(&RBT_LDS_CAST(RbtEncTileLds, &lds)->rc);
-  for (int x = 0; x < f->cfg.w_ctb; x++) en_intra_ctb(f, slices, row * f->cfg.w_ctb + x, RBT_LDS_CAST(RbtEncTileLds, &lds), x > 0);
+  rc_stage_tables(&RBT_LDS_CAST(RbtEncTileLdsT<TL2>, &lds)->rc);
+  for (int x = 0; x < f->cfg.w_ctb; x++) en_intra_ctb<TL2>(f, slices, row * f->cfg.w_ctb + x, RBT_LDS_CAST(RbtEncTileLdsT<TL2>, &lds), x > 0);
 }
+template <int TL2>
 __global__ void __launch_bounds__(64) k_enc_intra_diag(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int d) {
-  __shared__ RbtEncTileLds lds;
+  __shared__ RbtEncTileLdsT<TL2> lds;
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   int y = blockIdx.x, x = d - 2 * y;
   if (y >= f->cfg.h_ctb || x < 0 || x >= f->cfg.w_ctb) return;
-  rc_stage_tables(&RBT_LDS_CAST(RbtEncTileLds, &lds)->rc);
-  en_intra_ctb(f, slices, y * f->cfg.w_ctb + x, RBT_LDS_CAST(RbtEncTileLds, &lds), 0);
+  rc_stage_tables(&RBT_LDS_CAST(RbtEncTileLdsT<TL2>, &lds)->rc);
+  en_intra_ctb<TL2>(f, slices, y * f->cfg.w_ctb + x, RBT_LDS_CAST(RbtEncTileLdsT<TL2>, &lds), 0);
 }
 __global__ void __launch_bounds__(64) k_enc_inter(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
   __shared__ RbtEncLds lds;
@@ -205,9 +208,10 @@ __global__ void __launch_bounds__(64) k_enc_inter(RbtFrame* frames, const RbtSli
   rc_stage_tables(&RBT_LDS_CAST(RbtEncLds, &lds)->rc);
   en_inter_ctb(frames, f, slices, blockIdx.x, RBT_LDS_CAST(RbtEncLds, &lds));
 }
+template <int TL2>
 __global__ void __launch_bounds__(64) k_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list) {
-  __shared__ RbtEntropyLds lds;
-  en_entropy_slice(frames, slices, slice_list[blockIdx.x], out, RBT_LDS_CAST(RbtEntropyLds, &lds));
+  __shared__ alignas(16) uint32_t lds[(RBT_ENTROPY_LDS_BYTES(TL2) + 3) / 4];
+  en_entropy_slice(frames, slices, slice_list[blockIdx.x], out, RBT_LDS_CAST(RbtEntropyLds, lds));
 }
 
 __global__ void __launch_bounds__(256) k_pack(const uint8_t* out, const RbtSlice* slices, const uint32_t* dst_off, uint8_t* packed) {
@@ -238,21 +242,28 @@ void launch_enc_analyse(RbtFrame* frames, const RbtSlice* slices, const int32_t*
   if (n_frames <= 0) return;
   hipLaunchKernelGGL(k_enc_analyse, dim3(max_ctbs, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
 }
-void launch_enc_intra(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int row_mode) {
+void launch_enc_intra(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int row_mode, int max_log2_ctb) {
   if (n_frames <= 0) return;
-  if (row_mode) { hipLaunchKernelGGL(k_enc_intra_rows, dim3(max_h_ctb, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list); return; }
+  const bool small = max_log2_ctb <= 5;
+  if (row_mode) {
+    if (small) hipLaunchKernelGGL(k_enc_intra_rows<5>, dim3(max_h_ctb, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
+    else hipLaunchKernelGGL(k_enc_intra_rows<6>, dim3(max_h_ctb, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
+    return;
+  }
   int n_diag = max_w_ctb + 2 * (max_h_ctb - 1);
   for (int d = 0; d < n_diag; d++) {
     int rows = d / 2 + 1; if (rows > max_h_ctb) rows = max_h_ctb;
-    hipLaunchKernelGGL(k_enc_intra_diag, dim3(rows, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list, d);
+    if (small) hipLaunchKernelGGL(k_enc_intra_diag<5>, dim3(rows, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list, d);
+    else hipLaunchKernelGGL(k_enc_intra_diag<6>, dim3(rows, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list, d);
   }
 }
 void launch_enc_inter(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs) {
   if (n_frames <= 0) return;
   hipLaunchKernelGGL(k_enc_inter, dim3(max_ctbs, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
 }
-void launch_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list, int n_slices) {
+void launch_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list, int n_slices, int max_log2_ctb) {
   if (n_slices <= 0) return;
-  hipLaunchKernelGGL(k_entropy, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, out, slice_list);
+  if (max_log2_ctb <= 5) hipLaunchKernelGGL(k_entropy<5>, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, out, slice_list);
+  else hipLaunchKernelGGL(k_entropy<6>, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, out, slice_list);
 }
 }  // namespace rbtk

@@ -7,18 +7,21 @@
 #include "rbt_tables.h"
 #include "rbt_types.h"
 
-struct RbtReconLds {
+// Scratch of one TB. The decoder's CTB kernel declares only the core (its smoothed / angular reference arrays alias `tmp`,
+// which is dead once the residual is in `res`): LDS per workgroup decides how many CTBs are in flight on a CU.
+struct RbtReconLdsCore {
   int32_t nb[132];        // neighbour samples: [0] = p[-1][2N-1] .. [2N-1] = p[-1][0], [2N] = corner, [2N+1+x] = p[x][-1]
-  int32_t nbf[132];       // filtered neighbours
-  int32_t ref[100];       // angular reference array, index offset 32
-  uint8_t av[132];
-  int16_t res[32 * 32];   // dequantised coefficients, then residual
-  int16_t tmp[32 * 32];   // first transform stage (16-bit by construction: 8.6.4.2 clips it, the forward stage's shift keeps it below 2^15)
-  uint16_t pred[32 * 32];
-  int32_t ref2[100];      // second angular reference array (Cb / Cr processed together)
+  alignas(16) int16_t res[32 * 32];   // dequantised coefficients, then residual
+  alignas(16) int16_t tmp[32 * 32];   // first transform stage (16-bit by construction: 8.6.4.2 clips it, the forward stage's shift keeps it below 2^15)
   int8_t dct[32 * 32]; int8_t dst[16];   // transform matrices, staged once per workgroup (rc_stage_tables)
 };
-RBT_DEV void rc_stage_tables(RBT_LDS_AS RbtReconLds* l) {
+struct RbtReconLds : RbtReconLdsCore {   // encoder kernels: prediction kept next to the residual
+  int32_t nbf[132];       // filtered neighbours
+  int32_t ref[100];       // angular reference array, index offset 32
+  int32_t ref2[100];      // second angular reference array (Cb / Cr processed together)
+  uint16_t pred[32 * 32];
+};
+RBT_DEV void rc_stage_tables(RBT_LDS_AS RbtReconLdsCore* l) {
   RBT_PAR_FOR(i, 1024) l->dct[i] = k_dct32[i >> 5][i & 31];
   RBT_PAR_FOR(i, 16) l->dst[i] = k_dst4[i >> 2][i & 3];
   RBT_SYNC_LDS();
@@ -42,29 +45,8 @@ RBT_DEV int rc_avail(const RbtFrame* f, int xc, int yc, int xn, int yn) {
   if (g->cip && (f->pm[(yn >> 2) * g->w4 + (xn >> 2)] & RBT_PM_MODE_MASK) != RBT_MODE_INTRA) return 0;
   return 1;
 }
-RBT_DEV int rc_tcoef(const RBT_LDS_AS RbtReconLds* l, int N, int is_dst, int k, int n) { return is_dst ? l->dst[k * 4 + n] : l->dct[k * (32 / N) * 32 + n]; }
+RBT_DEV int rc_tcoef(const RBT_LDS_AS RbtReconLdsCore* l, int N, int is_dst, int k, int n) { return is_dst ? l->dst[k * 4 + n] : l->dct[k * (32 / N) * 32 + n]; }
 
-// ---- intra prediction of one TB into lds->pred (8.4.4.2) ----
-// Step 1 (two variants): gather the 4N+1 neighbour samples and their availability into l->nb / l->av.
-// Step 2 (rc_intra_finish): substitution, smoothing filter and the prediction itself, all in LDS.
-RBT_DEV void rc_intra_finish(const RbtStreamCfg* g, int c_idx, int log2, int mode, RBT_LDS_AS RbtReconLds* l);
-// variant A: neighbours from a picture plane in HBM (`src`), availability from the picture's maps
-RBT_DEV void rc_intra_pred(const RbtFrame* f, const uint16_t* src, int c_idx, int x0, int y0, int log2, int mode, RBT_LDS_AS RbtReconLds* l) {
-  const RbtStreamCfg* g = &f->cfg;
-  int N = 1 << log2, sh = c_idx ? 1 : 0, pw = c_idx ? g->cw : g->w;
-  int xcL = x0 << sh, ycL = y0 << sh, tot = 4 * N + 1;
-  RBT_PAR_FOR(i, tot) {
-    int xn, yn;
-    if (i < 2 * N) { xn = x0 - 1; yn = y0 + (2 * N - 1 - i); }
-    else if (i == 2 * N) { xn = x0 - 1; yn = y0 - 1; }
-    else { xn = x0 + (i - 2 * N - 1); yn = y0 - 1; }
-    int a = rc_avail(f, xcL, ycL, xn << sh, yn << sh);
-    l->av[i] = (uint8_t)a;
-    l->nb[i] = a ? src[(size_t)yn * pw + xn] : 0;
-  }
-  RBT_SYNC_LDS();
-  rc_intra_finish(g, c_idx, log2, mode, l);
-}
 // Small normative tables as packed immediates (no memory access on the dependent path of a TB):
 // intraPredAngle (Table 8-5), invAngle (Table 8-6) and levelScale (8.6.3)
 RBT_DEV int rc_intra_angle(int mode) {           // modes 2..34
@@ -117,14 +99,6 @@ RBT_DEV RBT_LDS_AS int32_t* rc_intra_filter(const RbtStreamCfg* g, int c_idx, in
   rc_intra_filter_apply(g, log2, nb, alt);
   return alt;
 }
-// availability masks of the 4N+1 gathered neighbours (l->av) -> m[0] (indices 0..63), m[1] (64..127), *m2 (128)
-RBT_DEV void rc_avail_masks(int tot, RBT_LDS_AS RbtReconLds* l, uint64_t* m0, uint64_t* m1, int* m2) {
-  uint64_t a, b = 0; int c = 0;
-  RBT_VBALLOT(a, p, rbt_min(tot, 64), l->av[p]);
-  if (tot > 64) { RBT_VBALLOT(b, p, rbt_min(tot - 64, 64), l->av[64 + p]); }
-  if (tot > 128) c = l->av[128];
-  *m0 = a; *m1 = b; *m2 = c;
-}
 // Prediction value of sample (x,y) of the TB from the final reference samples `nb` (planar / DC / angular incl. edge
 // filters). Angular modes read l->ref, DC reads `dc`; both are prepared by rc_intra_setup.
 struct RcIntraCtx { int N, log2, mode, c_idx, maxv, ang, ver, dc, edge; };
@@ -176,31 +150,8 @@ RBT_DEV int rc_intra_sample(const RcIntraCtx* q, const RBT_LDS_AS int32_t* nb, c
 }
 #undef RC_LEFT
 #undef RC_TOP
-// variant-A tail: l->nb / l->av gathered by the caller -> l->pred
-RBT_DEV void rc_intra_finish(const RbtStreamCfg* g, int c_idx, int log2, int mode, RBT_LDS_AS RbtReconLds* l) {
-  const int N = 1 << log2, bd = g->bit_depth, tot = 4 * N + 1;
-  RBT_LDS_AS int32_t* nb = l->nb; RBT_LDS_AS int32_t* alt = l->nbf;      // current / scratch neighbour arrays (swapped, not copied)
-  {
-    uint64_t m0, m1; int m2;
-    rc_avail_masks(tot, l, &m0, &m1, &m2);
-    const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : (m2 ? 128 : -1));
-    const int all = __builtin_popcountll(m0) + __builtin_popcountll(m1) + m2 == tot;
-    if (first < 0) { RBT_PAR_FOR(i, tot) nb[i] = 1 << (bd - 1); RBT_SYNC_LDS(); }
-    else if (!all) {
-      // unavailable samples before the first available one take its value; later ones copy the nearest below
-      RBT_PAR_FOR(i, tot) { int j = rc_last_avail(i, m0, m1, m2); alt[i] = nb[j >= 0 ? j : first]; }
-      RBT_SYNC_LDS();
-      RBT_LDS_AS int32_t* t = nb; nb = alt; alt = t;
-    }
-  }
-  RBT_LDS_AS int32_t* fin = rc_intra_filter(g, c_idx, log2, mode, nb, alt);
-  RcIntraCtx q; rc_intra_setup(g, c_idx, log2, mode, fin, l->ref, &q);
-  RBT_PAR_FOR(i, N * N) l->pred[i] = (uint16_t)rc_intra_sample(&q, fin, l->ref, i & (N - 1), i >> log2);
-  RBT_SYNC_LDS();
-}
-
 // ---- scaling (8.6.3, flat lists) of the TB's levels from the coefficient plane into lds->res ----
-template <class CP> RBT_DEV void rc_dequant(CP plane, int pst, int x0, int y0, int log2, int qp, int bd, RBT_LDS_AS RbtReconLds* l) {
+template <class CP> RBT_DEV void rc_dequant(CP plane, int pst, int x0, int y0, int log2, int qp, int bd, RBT_LDS_AS RbtReconLdsCore* l) {
   int N = 1 << log2, bd_shift = bd + log2 - 5;
   int scale = (16 * rc_level_scale(qp % 6)) << (qp / 6);
   long long add = 1ll << (bd_shift - 1);
@@ -214,7 +165,7 @@ template <class CP> RBT_DEV void rc_dequant(CP plane, int pst, int x0, int y0, i
 // ---- inverse transform of lds->res in place (8.6.4.2) ----
 // Specialised per size so that the dot products unroll fully: with a run-time trip count every iteration would wait for
 // its own LDS reads (~130 cycles each) instead of having all of them in flight.
-template <int LOG2> RBT_DEV void rc_inv_transform_n(int is_dst, int sh, RBT_LDS_AS RbtReconLds* l) {
+template <int LOG2> RBT_DEV void rc_inv_transform_n(int is_dst, int sh, RBT_LDS_AS RbtReconLdsCore* l) {
   constexpr int N = 1 << LOG2;
   RBT_PAR_FOR(i, N * N) {
     int x = i & (N - 1), y = i >> LOG2, s = 0;
@@ -231,7 +182,7 @@ template <int LOG2> RBT_DEV void rc_inv_transform_n(int is_dst, int sh, RBT_LDS_
   }
   RBT_SYNC_LDS();
 }
-RBT_DEV void rc_inv_transform(int log2, int is_dst, int ts, int bd, RBT_LDS_AS RbtReconLds* l) {
+RBT_DEV void rc_inv_transform(int log2, int is_dst, int ts, int bd, RBT_LDS_AS RbtReconLdsCore* l) {
   int N = 1 << log2, sh = 20 - bd;
   if (ts) {
     RBT_PAR_FOR(i, N * N) l->res[i] = (int16_t)((((int)l->res[i] << 7) + (1 << (sh - 1))) >> sh);
@@ -245,7 +196,7 @@ RBT_DEV void rc_inv_transform(int log2, int is_dst, int ts, int bd, RBT_LDS_AS R
 }
 
 // two blocks of the same size at once (Cb and Cr of a TU): block b lives at res / tmp offset b * 256; m0 / m1 = block present
-template <int LOG2> RBT_DEV void rc_inv_transform_pair_n(int sh, int m0, int m1, RBT_LDS_AS RbtReconLds* l) {
+template <int LOG2> RBT_DEV void rc_inv_transform_pair_n(int sh, int m0, int m1, RBT_LDS_AS RbtReconLdsCore* l) {
   constexpr int N = 1 << LOG2, NN = N * N;
   RBT_PAR_FOR(i, 2 * NN) {
     const int b = i >> (2 * LOG2), j = i & (NN - 1), x = j & (N - 1), y = j >> LOG2;
@@ -313,7 +264,7 @@ struct RbtCtbTile {
   uint16_t y[64 * RC_TS_Y], top_y[130]; uint16_t c[2][32 * RC_TS_C], top_c[2][66];   // sample (xx,yy) relative to the CTB: body yy * stride + xx + 1, row above: top[xx + 1]
   uint8_t uav[17 * RC_US];                                  // 4x4 luma unit (ux,uy) usable as intra reference: (uy + 1) * RC_US + ux + 1
 };
-struct RbtReconCtbLds { RbtCtbTile t; RbtReconLds rc;
+struct RbtReconCtbLds { RbtCtbTile t; RbtReconLdsCore rc;
 #ifdef RBT_PROFILE
   unsigned long long prof[8];
 #endif
@@ -334,7 +285,8 @@ RBT_DEV int rc_nb_av(const RBT_LDS_AS uint8_t* uav, int i, int x0, int y0, int N
 RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int c_idx, int x0, int y0, int log2, int intra, int mode, int cbf, int ts, int tq_bypass, int qp,
                         int mark_l4, int mux, int muy, int mark_flag) {
   // (x0,y0): TB origin relative to the CTB, in samples of component c_idx
-  RBT_LDS_AS RbtReconLds* l = &L->rc; RBT_LDS_AS RbtCtbTile* t = &L->t;
+  RBT_LDS_AS RbtReconLdsCore* l = &L->rc; RBT_LDS_AS RbtCtbTile* t = &L->t;
+  RBT_LDS_AS int32_t* const l_nbf = (RBT_LDS_AS int32_t*)l->tmp; RBT_LDS_AS int32_t* const l_ref = l_nbf + 132;   // alias tmp (dead after the transform)
   const int N = 1 << log2, sh = c_idx ? 1 : 0, bd = g->bit_depth, maxv = (1 << bd) - 1, n4 = (1 << g->log2_ctb) >> 2;
   RBT_LDS_AS uint16_t* tile = c_idx == 0 ? t->y : t->c[c_idx - 1]; const int S = c_idx == 0 ? RC_TS_Y : RC_TS_C;
   const RBT_LDS_AS uint16_t* top = c_idx == 0 ? t->top_y : t->top_c[c_idx - 1];
@@ -372,8 +324,8 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int
       l->nb[i] = v;
     }
     RBT_SYNC_LDS();
-    fin = rc_intra_filter(g, c_idx, log2, mode, l->nb, l->nbf);
-    rc_intra_setup(g, c_idx, log2, mode, fin, l->ref, &q);
+    fin = rc_intra_filter(g, c_idx, log2, mode, l->nb, l_nbf);
+    rc_intra_setup(g, c_idx, log2, mode, fin, l_ref, &q);
   }
 #ifdef RBT_PROFILE
   p2_ = p3_ = __builtin_readcyclecounter();
@@ -381,7 +333,7 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int
   if (intra) {
     RBT_PAR_FOR(i, N * N) {
       int x = i & (N - 1), y = i >> log2, o = (y0 + y) * S + x0 + x + 1;
-      int base = rc_intra_sample(&q, fin, l->ref, x, y);
+      int base = rc_intra_sample(&q, fin, l_ref, x, y);
       tile[o] = (uint16_t)(cbf ? rbt_clip3(0, maxv, base + l->res[i]) : base);
     }
   } else if (cbf) {                                                          // inter: leave the residual where the levels were
@@ -396,7 +348,8 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int
 // Cb and Cr TB of one TU in the same passes. The two blocks share position, size, prediction mode and availability and
 // differ only in data, so every phase (and every wait for LDS) is paid once for both; chroma is never smoothed (8.4.4.2.3).
 RBT_DEV void rc_tile_tb_cpair(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int x0, int y0, int log2, int intra, int mode, int cbf_cb, int cbf_cr, int tq_bypass, int qp_cb, int qp_cr) {
-  RBT_LDS_AS RbtReconLds* l = &L->rc; RBT_LDS_AS RbtCtbTile* t = &L->t;
+  RBT_LDS_AS RbtReconLdsCore* l = &L->rc; RBT_LDS_AS RbtCtbTile* t = &L->t;
+  RBT_LDS_AS int32_t* const l_ref = (RBT_LDS_AS int32_t*)l->tmp + 132; RBT_LDS_AS int32_t* const l_ref2 = l_ref + 100;   // alias tmp (dead after the transform)
   const int N = 1 << log2, NN = N * N, bd = g->bit_depth, maxv = (1 << bd) - 1, n4 = (1 << g->log2_ctb) >> 2, S = RC_TS_C;
   if (cbf_cb | cbf_cr) {
     if (tq_bypass) {
@@ -456,7 +409,7 @@ RBT_DEV void rc_tile_tb_cpair(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* 
         else if (ang >= 0) v = ver ? RC_TOP(x - 1) : RC_LEFT(x - 1);
 #undef RC_LEFT
 #undef RC_TOP
-        (b ? l->ref2 : l->ref)[x + 32] = v;
+        (b ? l_ref2 : l_ref)[x + 32] = v;
       }
       RBT_SYNC_LDS();
     }
@@ -466,7 +419,7 @@ RBT_DEV void rc_tile_tb_cpair(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* 
       const int b = i >= NN, j = i - b * NN, x = j & (N - 1), y = j >> log2, o = (y0 + y) * S + x0 + x + 1, cbf = b ? cbf_cr : cbf_cb;
       RBT_LDS_AS uint16_t* tile = t->c[b];
       if (intra) {
-        const int base = rc_intra_sample(b ? &q1 : &q0, l->nb + b * 66, b ? l->ref2 : l->ref, x, y);
+        const int base = rc_intra_sample(b ? &q1 : &q0, l->nb + b * 66, b ? l_ref2 : l_ref, x, y);
         tile[o] = (uint16_t)(cbf ? rbt_clip3(0, maxv, base + l->res[b * 256 + j]) : base);
       } else if (cbf) tile[o] = (uint16_t)l->res[b * 256 + j];           // inter: leave the residual where the levels were
     }

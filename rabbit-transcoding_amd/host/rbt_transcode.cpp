@@ -153,23 +153,24 @@ static int encode_upload_lists(EncodeBatch& b) {
 static void encode_launch_intra(EncodeBatch& b) {
   size_t nf = b.frames.size();
   for (const PadJob& j : b.pad_jobs) rbtk::launch_pad(j.in, j.stride, j.x0, j.y0, j.w, j.h, j.out, j.dw, j.dh);
-  int mw = 0, mh = 0, mu = 0, mc = 0, row_mode = 1;
+  int mw = 0, mh = 0, mu = 0, mc = 0, row_mode = 1, ml2 = 0;
   for (size_t i = 0; i < nf; i++) {
-    const RbtStreamCfg& c = b.frames[i].cfg; mw = std::max(mw, c.w_ctb); mh = std::max(mh, c.h_ctb); mu = std::max(mu, c.w4 * c.h4); mc = std::max(mc, c.w_ctb * c.h_ctb);
+    const RbtStreamCfg& c = b.frames[i].cfg; ml2 = std::max(ml2, (int)c.log2_ctb); mw = std::max(mw, c.w_ctb); mh = std::max(mh, c.h_ctb); mu = std::max(mu, c.w4 * c.h4); mc = std::max(mc, c.w_ctb * c.h_ctb);
     if (b.desc[b.frame_stream[i]].rows != 1) row_mode = 0;
   }
   rbtk::timer_begin(T_ANALYSE);
   rbtk::launch_enc_analyse(b.d_frames, b.d_slices, b.d_lists + b.off_i, b.n_i, mc);
   rbtk::timer_end(T_ANALYSE);
   rbtk::timer_begin(T_ENCODE);
-  rbtk::launch_enc_intra(b.d_frames, b.d_slices, b.d_lists + b.off_i, b.n_i, mw, mh, row_mode);
+  rbtk::launch_enc_intra(b.d_frames, b.d_slices, b.d_lists + b.off_i, b.n_i, mw, mh, row_mode, ml2);
   rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_ideb, b.n_ideb, mu);
   rbtk::timer_end(T_ENCODE);
 }
 // entropy coding of the intra pictures' slices: needs nothing but their levels and CU data
+static int max_log2_ctb(const EncodeBatch& b) { int m = 0; for (auto& f : b.frames) m = std::max(m, (int)f.cfg.log2_ctb); return m; }
 static void encode_launch_entropy_intra(EncodeBatch& b) {
   rbtk::timer_begin(T_ENTROPY_I);
-  rbtk::launch_entropy(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_sl, b.n_sl_i);
+  rbtk::launch_entropy(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_sl, b.n_sl_i, max_log2_ctb(b));
   rbtk::timer_end(T_ENTROPY_I);
 }
 // inter pictures (need the reconstructed intra pictures and their own sources), then the entropy coder for every slice
@@ -182,7 +183,7 @@ static void encode_launch_rest(EncodeBatch& b) {
   rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_p, b.n_p, mu);
   rbtk::timer_end(T_INTER);
   rbtk::timer_begin(T_ENTROPY);
-  rbtk::launch_entropy(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_sl_p, b.n_sl_p);
+  rbtk::launch_entropy(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_sl_p, b.n_sl_p, max_log2_ctb(b));
   rbtk::timer_end(T_ENTROPY);
 }
 static int encode_launch(EncodeBatch& b) { encode_launch_intra(b); encode_launch_entropy_intra(b); encode_launch_rest(b); return 0; }

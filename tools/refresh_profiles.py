@@ -6,11 +6,14 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 shutil.copy("gpurun_out/prof_kt/kt_kernel_stats.csv", f"profiles/{tag}_bench_kernel_stats.csv")
 shutil.copy("gpurun_out/bench_line.json", f"profiles/{tag}_bench_line.json")
 
+def kname(n):   # "void rbtk::k_parse<384>(RbtFrame*, ...)" -> "k_parse"
+    return n.split("(")[0].replace("void ", "").replace("rbtk::", "").split("<")[0]
+
 def agg(path, name):
     d = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != name: continue
-        k = r["Kernel_Name"].split("(")[0].replace("rbtk::", ""); d[k][0] += 1; d[k][1] += float(r["Counter_Value"])
+        k = kname(r["Kernel_Name"]); d[k][0] += 1; d[k][1] += float(r["Counter_Value"])
     return d
 F = agg("gpurun_out/prof_f/f_counter_collection.csv", "FETCH_SIZE"); W = agg("gpurun_out/prof_w/w_counter_collection.csv", "WRITE_SIZE")
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two separate passes, --kernel-trace only), python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 "
@@ -22,7 +25,7 @@ for k in sorted(set(F) | set(W)):
     out["kernels"][k] = {"dispatches": F[k][0] or W[k][0], "FETCH_SIZE_KB": round(F[k][1], 1), "WRITE_SIZE_KB": round(W[k][1], 1)}
 json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
 
-rows = [r for r in csv.DictReader(open("gpurun_out/prof_tl/tl_kernel_trace.csv")) if r["Kernel_Name"].startswith("rbtk::")]
+rows = [r for r in csv.DictReader(open("gpurun_out/prof_tl/tl_kernel_trace.csv")) if "rbtk::" in r["Kernel_Name"]]
 for r in rows: r["s"] = int(r["Start_Timestamp"]); r["e"] = int(r["End_Timestamp"])
 parses = [r for r in rows if "k_parse" in r["Kernel_Name"]]
 t0 = min(r["s"] for r in parses[-3:]); last = [r for r in rows if r["s"] >= t0]; tend = max(r["e"] for r in last)
@@ -35,7 +38,7 @@ with open(f"profiles/{tag}_timeline.txt", "w") as o:
         o.write("queue %s dispatches %d\n" % (q, len(rs)))
         cur = None
         for r in rs + [None]:
-            name = r["Kernel_Name"].split("(")[0].replace("rbtk::", "") if r else None
+            name = kname(r["Kernel_Name"]) if r else None
             if cur and cur[0] == name: cur[2] = r["e"]; cur[3] += 1; cur[4] += r["e"] - r["s"]
             else:
                 if cur: o.write("   %-18s start %8.2f end %8.2f launches %4d busy %8.2f\n" % (cur[0], (cur[1] - t0) / 1e6, (cur[2] - t0) / 1e6, cur[3], cur[4] / 1e6))
