@@ -6,7 +6,7 @@ Workload (config.workload): one 32-frame GOF of 1280x1280 V-PCC maps — 64 geom
 precision 2), transcoded to R3 (geometryQP 24, attributeQP 32, occupancyPrecision 4). There is no 8i data and no HM
 here, so the maps are synthetic (tests/synth.py) and the R5 input is produced by this repository's own GPU encoder in
 HM-like structure (CTB 64, one slice per picture). One "step" = one GOF through rbt_submit_gof + rbt_wait_gof (together:
-rbt_transcode_gof); --in-flight GOFs (default 8) are submitted ahead of the one being collected, as a transcoder walking a sequence does.
+rbt_transcode_gof); --in-flight GOFs (default 16) are submitted ahead of the one being collected, as a transcoder walking a sequence does.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--pc-frames F]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -54,15 +54,15 @@ def make_gof_maps(w, h, n_pc, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--pc-frames", type=int, default=32)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=1280)
     ap.add_argument("--cpu-sample", type=int, default=16, help="point-cloud frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--multi-gof", type=int, default=8, help="also time G GOFs per call (extra field multi_gof; 0/1 = skip)")
-    ap.add_argument("--in-flight", type=int, default=8, help="GOFs in flight (rbt_submit_gof ahead of rbt_wait_gof), 1..16; 1 = blocking calls")
-    ap.add_argument("--sweep", type=int, default=16, help="also time K GOFs at every in-flight depth 1..4 (extra field in_flight_sweep; 0/1 = skip)")
+    ap.add_argument("--in-flight", type=int, default=16, help="GOFs in flight (rbt_submit_gof ahead of rbt_wait_gof), 1..16; 1 = blocking calls")
+    ap.add_argument("--sweep", type=int, default=32, help="also time K GOFs at every in-flight depth 1..4 (extra field in_flight_sweep; 0/1 = skip)")
     ap.add_argument("--quality", type=int, default=1, help="report picture PSNR of the output vs the input (extra field quality; 0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (with --backend gloo)")

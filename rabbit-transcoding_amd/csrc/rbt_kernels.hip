@@ -116,6 +116,13 @@ __global__ void __launch_bounds__(64) k_parse(RbtFrame* frames, RbtSlice* slices
   __shared__ alignas(16) uint32_t lds[(RBT_PARSE_LDS_BYTES(CAP4) + 3) / 4];
   rbt_parse_slice(frames, slices, slice_list[blockIdx.x], rbsp, RBT_LDS_CAST(RbtParseLds, lds), CAP4, save, row_limit);
 }
+// the same over slices of several batches (each task names its batch's tables)
+template <int CAP4>
+__global__ void __launch_bounds__(64) k_parse_tasks(const RbtParseTask* tasks) {
+  __shared__ alignas(16) uint32_t lds[(RBT_PARSE_LDS_BYTES(CAP4) + 3) / 4];
+  const RbtParseTask t = tasks[blockIdx.x];
+  rbt_parse_slice(t.frames, t.slices, t.slice, t.rbsp, RBT_LDS_CAST(RbtParseLds, lds), CAP4, nullptr, 0);
+}
 // one wave per CTB on anti-diagonal d (x + 2y == d): left, above-left, above and above-right CTBs are complete
 __global__ void __launch_bounds__(64) k_recon_diag(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int d, int y_first) {
   __shared__ RbtReconCtbLds lds;
@@ -146,6 +153,12 @@ void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const
   if (max_w4 <= RBT_PARSE_CAP4_S) hipLaunchKernelGGL(k_parse<RBT_PARSE_CAP4_S>, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, rbsp, slice_list, (RbtParseSave*)save, row_limit);
   else if (max_w4 <= RBT_PARSE_CAP4_M) hipLaunchKernelGGL(k_parse<RBT_PARSE_CAP4_M>, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, rbsp, slice_list, (RbtParseSave*)save, row_limit);
   else hipLaunchKernelGGL(k_parse<RBT_PARSE_CAP4_L>, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, rbsp, slice_list, (RbtParseSave*)save, row_limit);
+}
+void launch_parse_tasks(const RbtParseTask* tasks, int n_tasks, int max_w4) {
+  if (n_tasks <= 0) return;
+  if (max_w4 <= RBT_PARSE_CAP4_S) hipLaunchKernelGGL(k_parse_tasks<RBT_PARSE_CAP4_S>, dim3(n_tasks), dim3(64), 0, g_stream, tasks);
+  else if (max_w4 <= RBT_PARSE_CAP4_M) hipLaunchKernelGGL(k_parse_tasks<RBT_PARSE_CAP4_M>, dim3(n_tasks), dim3(64), 0, g_stream, tasks);
+  else hipLaunchKernelGGL(k_parse_tasks<RBT_PARSE_CAP4_L>, dim3(n_tasks), dim3(64), 0, g_stream, tasks);
 }
 size_t parse_save_bytes() { return sizeof(RbtParseSave); }
 // CTB rows [y_begin, y_end): the rows above y_begin are complete, the anti-diagonals that touch the range run in order

@@ -93,6 +93,11 @@ struct RbtFrame {
 #define RBT_CU_CBF_CR 4
 #define RBT_CU_SKIP 8
 
+struct RbtSlice;
+struct RbtFrame;
+// One slice segment of a merged entropy-decoding launch (slices of several batches in one grid: rbt_kernels.h launch_parse_tasks)
+struct RbtParseTask { RbtFrame* frames; RbtSlice* slices; const uint8_t* rbsp; int32_t slice; int32_t pad; };
+
 struct RbtSlice {                // one per slice segment, parsed on the host (7.3.6)
   int32_t frame;                 // index into the batch frame table
   uint32_t data_off, data_size;  // slice_segment_data() inside the batch RBSP buffer (emulation prevention removed)

@@ -28,6 +28,7 @@ struct DecodeBatch {
   std::vector<Sps> stream_sps; std::vector<Pps> stream_pps;
   std::vector<std::vector<int>> level_frames;
   bool ordered_parse = false, lists_uploaded = false;
+  bool parse_external = false;         // the batch's slices are parsed by a merged launch of the caller (launch_parse_tasks)
   std::vector<int32_t> lists_keep;     // host staging of the index lists, alive until the copy has completed
   std::vector<size_t> fr_off;          // offset of each level's frame list inside d_lists
   std::vector<size_t> sl_off, sl_cnt;  // slice list of each level inside d_lists
@@ -43,6 +44,7 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n);
 int decode_launch(DecodeBatch& b);   // enqueue every decode kernel of the batch on the current stream (no wait)
 int decode_launch_parse(DecodeBatch& b);            // index lists + entropy decoding
 int decode_upload_lists(DecodeBatch& b);            // index lists only (first half of decode_launch_parse)
+int decode_max_w4(const DecodeBatch& b);            // width of the widest picture in 4-sample units
 // Entropy decoding in `chunks` row bands with the reconstruction of each finished band of the level-0 pictures enqueued on
 // stream `aux` underneath the parsing of the next band; ends with level 0 complete (filters included) on the current stream.
 int decode_launch_chunked(DecodeBatch& b, int chunks, int main_stream, int aux_stream);

@@ -158,6 +158,7 @@ static void build_lists(DecodeBatch& b) {
   for (auto& lf : b.level_frames) { b.fr_off.push_back(lists.size()); for (int fi : lf) lists.push_back(fi); }
 }
 static int max_w4(const DecodeBatch& b) { int m = 0; for (auto& f : b.frames) m = std::max(m, (int)f.cfg.w4); return m; }
+int decode_max_w4(const DecodeBatch& b) { return max_w4(b); }
 int decode_upload_lists(DecodeBatch& b) {
   if (b.lists_uploaded) return 0;
   b.lists_uploaded = true;
@@ -169,6 +170,7 @@ int decode_upload_lists(DecodeBatch& b) {
 int decode_launch_parse(DecodeBatch& b) {
   int rc = decode_upload_lists(b);
   if (rc) return rc;
+  if (b.parse_external) return 0;
   const std::vector<size_t>& sl_off = b.sl_off; const std::vector<size_t>& sl_cnt = b.sl_cnt;
   rbtk::timer_begin(T_PARSE);
   if (b.ordered_parse) { for (size_t l = 0; l < b.level_frames.size(); l++) rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists + sl_off[l], (int)sl_cnt[l], max_w4(b)); }

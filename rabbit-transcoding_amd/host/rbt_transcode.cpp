@@ -311,6 +311,9 @@ struct GofJob {
   std::vector<DecodeBatch> db; std::vector<EncodeBatch> eb; std::vector<char> chained;
   std::vector<void*> pooled;
   bool has_aux = true;
+  std::vector<int> phys;                       // HIP stream of each pipeline
+  std::vector<char> parse_timed;               // pipeline recorded its own T_PARSE timer
+  std::vector<std::vector<RbtParseTask>> tasks_keep;   // host staging of merged parse launches, alive until the job is collected
   std::vector<rbt_stream_params> params; std::vector<size_t> n_in;
   rbt_stats st; std::string err; double t_all = 0, t_gpu = 0;
   ~GofJob() { for (void* q : pooled) rbtk::dev_free(q); }
@@ -323,7 +326,8 @@ static int job_stream(const GofJob& j, int pipeline) { return j.slot * rbtk::RBT
 static void bind_streams(GofJob& j, int depth) {
   const int spj = depth <= 4 ? 4 : depth == 5 ? 3 : depth <= 8 ? 2 : 1, base = j.slot * spj;
   j.has_aux = spj == 4;
-  for (int k = 0; k < j.ng; k++) rbtk::map_lane(job_stream(j, j.order[k]), base + (k == 0 || spj == 1 ? 0 : 1 + (k - 1) % (std::min(spj, 3) - 1)));
+  j.phys.assign(j.ng, 0);
+  for (int k = 0; k < j.ng; k++) { j.phys[j.order[k]] = base + (k == 0 || spj == 1 ? 0 : 1 + (k - 1) % (std::min(spj, 3) - 1)); rbtk::map_lane(job_stream(j, j.order[k]), j.phys[j.order[k]]); }
   rbtk::map_lane(job_stream(j, rbtk::RBT_AUX_STREAM), base + spj - 1);
 }
 
@@ -376,6 +380,27 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
       chained[gi] = 1;
     }
   }
+  // Pipelines that share a HIP stream would parse one after the other; their slices go into one merged launch instead, so
+  // that all parsers of the stream run side by side and only the (short) tails of the pipelines follow each other.
+  j.parse_timed.assign(ng, 1);
+  for (int k = 0; k < ng && !rc; k++) {
+    const int lead = order[k];
+    if (!chained[lead] || db[lead].parse_external) continue;
+    std::vector<int> grp;
+    for (int q = k; q < ng; q++) { const int gi = order[q]; if (j.phys[gi] == j.phys[lead] && chained[gi] && !db[gi].ordered_parse && !db[gi].d_save) grp.push_back(gi); }
+    if (grp.size() < 2 || grp[0] != lead) continue;
+    j.tasks_keep.emplace_back(); std::vector<RbtParseTask>& tasks = j.tasks_keep.back(); int mw4 = 0;
+    for (int gi : grp) {
+      for (size_t i = 0; i < db[gi].slices.size(); i++) tasks.push_back(RbtParseTask{db[gi].d_frames, db[gi].d_slices, db[gi].d_rbsp, db[gi].lists_keep[i], 0});
+      mw4 = std::max(mw4, decode_max_w4(db[gi])); db[gi].parse_external = true; j.parse_timed[gi] = gi == lead;
+    }
+    RbtParseTask* d_tasks = (RbtParseTask*)rbtk::dev_alloc(tasks.size() * sizeof(RbtParseTask));
+    if (!d_tasks) { err = "device allocation failed"; rc = RBT_ERR_NOMEM; break; }
+    pooled.push_back(d_tasks);
+    rbtk::set_stream(job_stream(j, lead));
+    if (rbtk::h2d(d_tasks, tasks.data(), tasks.size() * sizeof(RbtParseTask))) { err = "device transfer failed"; rc = RBT_ERR_NO_DEVICE; break; }
+    rbtk::timer_begin(T_PARSE); rbtk::launch_parse_tasks(d_tasks, (int)tasks.size(), mw4); rbtk::timer_end(T_PARSE);
+  }
   for (int k = 0; k < ng && !rc; k++) {
     const int gi = order[k], sid = job_stream(j, gi); rbtk::set_stream(sid);
     const std::vector<PoolJob>& jobs = pool_jobs[gi];
@@ -427,7 +452,8 @@ int gof_wait(GofJob* J, rbt_stats& st_out, std::string& err_out, uint8_t** out, 
     if (db[gi].frames.empty()) continue;
     rc = decode_finish(db[gi]);
     if (rc) { err = db[gi].err; continue; }
-    st.k_parse_ms += rbtk::timer_ms(T_PARSE); st.k_recon_ms += rbtk::timer_ms(T_RECON);
+    if (j.parse_timed.empty() || j.parse_timed[gi]) st.k_parse_ms += rbtk::timer_ms(T_PARSE);
+    st.k_recon_ms += rbtk::timer_ms(T_RECON);
     std::vector<std::vector<uint8_t>> o1;
     if (j.chained[gi]) rc = encode_finish(eb[gi], o1, st);
     else {

@@ -40,6 +40,11 @@ void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const
   const int cap4 = max_w4 <= RBT_PARSE_CAP4_S ? RBT_PARSE_CAP4_S : max_w4 <= RBT_PARSE_CAP4_M ? RBT_PARSE_CAP4_M : RBT_PARSE_CAP4_L;
   for (int i = 0; i < n_slices; i++) rbt_parse_slice(frames, slices, slice_list[i], rbsp, (RbtParseLds*)plds, cap4, (RbtParseSave*)save, row_limit);
 }
+void launch_parse_tasks(const RbtParseTask* tasks, int n_tasks, int max_w4) {
+  alignas(16) static uint32_t plds[(RBT_PARSE_LDS_BYTES(RBT_PARSE_CAP4_L) + 3) / 4];
+  const int cap4 = max_w4 <= RBT_PARSE_CAP4_S ? RBT_PARSE_CAP4_S : max_w4 <= RBT_PARSE_CAP4_M ? RBT_PARSE_CAP4_M : RBT_PARSE_CAP4_L;
+  for (int i = 0; i < n_tasks; i++) rbt_parse_slice(tasks[i].frames, tasks[i].slices, tasks[i].slice, tasks[i].rbsp, (RbtParseLds*)plds, cap4, nullptr, 0);
+}
 size_t parse_save_bytes() { return sizeof(RbtParseSave); }
 void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int y_begin, int y_end) {
   static RbtReconCtbLds lds;

@@ -169,8 +169,9 @@ def test_two_jobs_in_flight_equal_blocking_calls(ctx):
         nxt = ctx.submit_gof(g, ps); outs.append(ctx.wait_gof(prev)); prev = nxt
     outs.append(ctx.wait_gof(prev))
     assert outs == [want_a, want_b, want_a, want_b, want_a]
-    # deeper pipelines give each job fewer HIP streams (5: three, 6..8: two): same outputs
-    for depth in (5, 8, 1):
+    # deeper pipelines give each job fewer HIP streams (5: three, 6..8: two, 9..16: one, parsers of pipelines that share a
+    # stream in one merged launch): same outputs
+    for depth in (5, 8, 16, 1):
         ctx.set_depth(depth)
         jobs = [ctx.submit_gof(a if i % 2 == 0 else b, ps) for i in range(depth)]
         with pytest.raises(R.RbtError):

@@ -124,12 +124,13 @@ def test_two_jobs_in_flight_equal_blocking_calls(ctx):
     with pytest.raises(R.RbtError):
         ctx.wait_gof(jc)
     assert ctx.wait_gof(jd) == want_b        # a failed job leaves its neighbour alone
-    ctx.set_depth(8)
-    jobs = [ctx.submit_gof(a if i % 2 == 0 else b, ps) for i in range(8)]
-    with pytest.raises(R.RbtError):
-        ctx.set_depth(2)                     # refused while jobs are in flight
-    for i, jb in enumerate(jobs):
-        assert ctx.wait_gof(jb) == (want_a if i % 2 == 0 else want_b)
+    for depth in (8, 16):                    # 8: two streams per job, 16: one (the parsers of pipelines sharing a stream go into one launch)
+        ctx.set_depth(depth)
+        jobs = [ctx.submit_gof(a if i % 2 == 0 else b, ps) for i in range(depth)]
+        with pytest.raises(R.RbtError):
+            ctx.set_depth(2)                 # refused while jobs are in flight
+        for i, jb in enumerate(jobs):
+            assert ctx.wait_gof(jb) == (want_a if i % 2 == 0 else want_b)
     ctx.set_depth(4)
 
 @pytest.mark.parametrize("w", [1536, 1552, 4096, 4112])
