@@ -1,6 +1,8 @@
 """Turns the rocprofv3 outputs a gpurun call merged into gpurun_out/ into the committed summaries under profiles/.
-Inputs: gpurun_out/bench_line.json, prof_kt/ (--kernel-trace --stats of 5 steps + 1 warm-up, input loaded
-from a file), prof_f/ and prof_w/ (--pmc FETCH_SIZE / WRITE_SIZE, one step), prof_tl/ (--kernel-trace of one timed step)."""
+Inputs: gpurun_out/bench_line.json (python bench.py), prof_kt/ (rocprofv3 --kernel-trace --stats of the same
+command without its informative extras: --cpu-sample 0 --multi-gof 0 --quality 0 --sweep 0, input loaded from a file), prof_f/
+and prof_w/ (--pmc FETCH_SIZE / WRITE_SIZE, one blocking step: --steps 1 --warmup 0 --in-flight 1), prof_tl/ (--kernel-trace
+of one blocking step: --steps 1 --warmup 1 --in-flight 1)."""
 import collections, csv, json, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 shutil.copy("gpurun_out/prof_kt/kt_kernel_stats.csv", f"profiles/{tag}_bench_kernel_stats.csv")
@@ -16,7 +18,7 @@ def agg(path, name):
         k = kname(r["Kernel_Name"]); d[k][0] += 1; d[k][1] += float(r["Counter_Value"])
     return d
 F = agg("gpurun_out/prof_f/f_counter_collection.csv", "FETCH_SIZE"); W = agg("gpurun_out/prof_w/w_counter_collection.csv", "WRITE_SIZE")
-out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two separate passes, --kernel-trace only), python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 "
+out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two separate passes, --kernel-trace only), python3 bench.py --steps 1 --warmup 0 --in-flight 1 --cpu-sample 0 "
                "--load-input <R5 streams> on MI355X: one transcode step of the 32-frame 1280x1280 GOF, nothing else in the process. Values are KB summed over "
                "every dispatch of the kernel in that step. FETCH_SIZE is reported uncorrected (MI355X_MICROARCH.md: under-reports wide coalesced reads; "
                "these kernels issue narrow accesses).", "kernels": {}}
@@ -30,7 +32,7 @@ for r in rows: r["s"] = int(r["Start_Timestamp"]); r["e"] = int(r["End_Timestamp
 parses = [r for r in rows if "k_parse" in r["Kernel_Name"]]
 t0 = min(r["s"] for r in parses[-3:]); last = [r for r in rows if r["s"] >= t0]; tend = max(r["e"] for r in last)
 with open(f"profiles/{tag}_timeline.txt", "w") as o:
-    o.write("# rocprofv3 --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --cpu-sample 0 --load-input <R5 streams> (MI355X); timed step only, ms from the first kernel\n")
+    o.write("# rocprofv3 --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --in-flight 1 --cpu-sample 0 --load-input <R5 streams> (MI355X): one GOF alone (blocking call); timed step only, ms from the first kernel\n")
     o.write("# one HIP stream (queue) per sub-bitstream pipeline (occupancy, geometry, attribute) + the auxiliary stream of the longest one. step span %.2f ms\n" % ((tend - t0) / 1e6))
     byq = collections.defaultdict(list)
     for r in last: byq[r["Queue_Id"]].append(r)
