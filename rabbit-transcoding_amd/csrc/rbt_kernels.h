@@ -38,6 +38,8 @@ double timer_ms(int id);                  // valid after dev_sync()
 // decode
 // save == nullptr: every slice is parsed to its end; else resumable (one RbtParseSave of parse_save_bytes() per slice of the
 // batch, zero-initialised): each launch advances every unfinished slice up to CTB row row_limit
+// pictures of several batches on one wavefront (every anti-diagonal is one launch over all of them)
+void launch_recon_refs(const RbtFrameRef* refs, int n_frames, int max_w_ctb, int max_h_ctb);
 // slices of several batches in one launch (pipelines that share a HIP stream: their parsers then run side by side)
 void launch_parse_tasks(const RbtParseTask* tasks, int n_tasks, int max_w4);
 // max_w4: width of the widest picture of the launch in 4-sample units (<= 2048; selects the LDS footprint of the parser)

@@ -134,6 +134,17 @@ __global__ void __launch_bounds__(64) k_recon_diag(RbtFrame* frames, const RbtSl
   if (frames[fi].ctb_slice[addr] == 0xFFFF) return;     // CTB not covered by any decoded slice
   rbt_recon_ctb(frames, slices, fi, addr, RBT_LDS_CAST(RbtReconCtbLds, &lds));
 }
+// the same over pictures of several batches
+__global__ void __launch_bounds__(64) k_recon_diag_refs(const RbtFrameRef* refs, int d, int y_first) {
+  __shared__ RbtReconCtbLds lds;
+  const RbtFrameRef r = refs[blockIdx.y];
+  const RbtStreamCfg* g = &r.frames[r.frame].cfg;
+  int y = y_first + blockIdx.x, x = d - 2 * y;
+  if (y >= g->h_ctb || x < 0 || x >= g->w_ctb) return;
+  int addr = y * g->w_ctb + x;
+  if (r.frames[r.frame].ctb_slice[addr] == 0xFFFF) return;     // CTB not covered by any decoded slice
+  rbt_recon_ctb(r.frames, r.slices, r.frame, addr, RBT_LDS_CAST(RbtReconCtbLds, &lds));
+}
 __global__ void __launch_bounds__(256) k_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int dir) {
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   int unit = blockIdx.x * 256 + threadIdx.x;
@@ -171,6 +182,15 @@ void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame
     int y_lo = (d - (max_w_ctb - 1) + 1) / 2; if (y_lo < y_begin) y_lo = y_begin;   // x <= w - 1
     if (y_lo > y_hi) continue;
     hipLaunchKernelGGL(k_recon_diag, dim3(y_hi - y_lo + 1, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list, d, y_lo);
+  }
+}
+void launch_recon_refs(const RbtFrameRef* refs, int n_frames, int max_w_ctb, int max_h_ctb) {
+  if (n_frames <= 0) return;
+  for (int d = 0; d <= max_w_ctb - 1 + 2 * (max_h_ctb - 1); d++) {
+    int y_hi = d / 2; if (y_hi > max_h_ctb - 1) y_hi = max_h_ctb - 1;
+    int y_lo = (d - (max_w_ctb - 1) + 1) / 2; if (y_lo < 0) y_lo = 0;
+    if (y_lo > y_hi) continue;
+    hipLaunchKernelGGL(k_recon_diag_refs, dim3(y_hi - y_lo + 1, n_frames), dim3(64), 0, g_stream, refs, d, y_lo);
   }
 }
 void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_units) {

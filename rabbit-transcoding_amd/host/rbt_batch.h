@@ -28,6 +28,7 @@ struct DecodeBatch {
   std::vector<Sps> stream_sps; std::vector<Pps> stream_pps;
   std::vector<std::vector<int>> level_frames;
   bool ordered_parse = false, lists_uploaded = false;
+  bool recon_external = false;         // ... and reconstructed by merged per-level launches (launch_recon_refs + decode_launch_filters)
   bool parse_external = false;         // the batch's slices are parsed by a merged launch of the caller (launch_parse_tasks)
   std::vector<int32_t> lists_keep;     // host staging of the index lists, alive until the copy has completed
   std::vector<size_t> fr_off;          // offset of each level's frame list inside d_lists
@@ -49,6 +50,7 @@ int decode_max_w4(const DecodeBatch& b);            // width of the widest pictu
 // stream `aux` underneath the parsing of the next band; ends with level 0 complete (filters included) on the current stream.
 int decode_launch_chunked(DecodeBatch& b, int chunks, int main_stream, int aux_stream);
 void decode_launch_level(DecodeBatch& b, size_t l);  // reconstruction + loop filters of dependency level l
+void decode_launch_filters(DecodeBatch& b, size_t l); // loop filters of level l only
 int decode_finish(DecodeBatch& b);   // wait for the batch's stream and check the per-picture error words
 int decode_run(DecodeBatch& b);      // launch + finish
 int decode_fetch(DecodeBatch& b, int stream, rbt_video* out, bool verify_md5);

@@ -178,7 +178,7 @@ int decode_launch_parse(DecodeBatch& b) {
   rbtk::timer_end(T_PARSE);
   return 0;
 }
-static void level_filters(DecodeBatch& b, size_t l) {
+void decode_launch_filters(DecodeBatch& b, size_t l) {
   const std::vector<int>& lf = b.level_frames[l];
   int mu = 0, ml = 0;
   for (int fi : lf) { const RbtStreamCfg& c = b.frames[fi].cfg; mu = std::max(mu, c.w4 * c.h4); ml = std::max(ml, c.w * c.h); }
@@ -213,7 +213,7 @@ int decode_launch_chunked(DecodeBatch& b, int chunks, int main_stream, int aux_s
   }
   rbtk::set_stream(main_stream);
   rbtk::stream_wait(main_stream, aux_stream);
-  level_filters(b, 0);
+  decode_launch_filters(b, 0);
   return 0;
 }
 void decode_launch_level(DecodeBatch& b, size_t l) {
@@ -221,7 +221,7 @@ void decode_launch_level(DecodeBatch& b, size_t l) {
   int mw = 0, mh = 0;
   for (int fi : lf) { const RbtStreamCfg& c = b.frames[fi].cfg; mw = std::max(mw, c.w_ctb); mh = std::max(mh, c.h_ctb); }
   rbtk::launch_recon(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l], (int)lf.size(), mw, mh);
-  level_filters(b, l);
+  decode_launch_filters(b, l);
 }
 
 int decode_finish(DecodeBatch& b) {

@@ -314,6 +314,8 @@ struct GofJob {
   std::vector<int> phys;                       // HIP stream of each pipeline
   std::vector<char> parse_timed;               // pipeline recorded its own T_PARSE timer
   std::vector<std::vector<RbtParseTask>> tasks_keep;   // host staging of merged parse launches, alive until the job is collected
+  std::vector<std::vector<RbtFrameRef>> refs_keep;     // ... and of merged reconstruction launches
+  std::vector<char> recon_timed;
   std::vector<rbt_stream_params> params; std::vector<size_t> n_in;
   rbt_stats st; std::string err; double t_all = 0, t_gpu = 0;
   ~GofJob() { for (void* q : pooled) rbtk::dev_free(q); }
@@ -382,7 +384,7 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
   }
   // Pipelines that share a HIP stream would parse one after the other; their slices go into one merged launch instead, so
   // that all parsers of the stream run side by side and only the (short) tails of the pipelines follow each other.
-  j.parse_timed.assign(ng, 1);
+  j.parse_timed.assign(ng, 1); j.recon_timed.assign(ng, 1);
   for (int k = 0; k < ng && !rc; k++) {
     const int lead = order[k];
     if (!chained[lead] || db[lead].parse_external) continue;
@@ -394,12 +396,34 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
       for (size_t i = 0; i < db[gi].slices.size(); i++) tasks.push_back(RbtParseTask{db[gi].d_frames, db[gi].d_slices, db[gi].d_rbsp, db[gi].lists_keep[i], 0});
       mw4 = std::max(mw4, decode_max_w4(db[gi])); db[gi].parse_external = true; j.parse_timed[gi] = gi == lead;
     }
+    // ... and the pictures of one dependency level of all of them go on one wavefront (58 launches per level instead of 58
+    // per level and pipeline, one after the other)
+    size_t n_levels = 0; for (int gi : grp) n_levels = std::max(n_levels, db[gi].level_frames.size());
+    j.refs_keep.emplace_back(); std::vector<RbtFrameRef>& refs = j.refs_keep.back();
+    std::vector<size_t> lv_off(n_levels + 1, 0); std::vector<int> lv_w(n_levels, 0), lv_h(n_levels, 0);
+    for (size_t l = 0; l < n_levels; l++) {
+      lv_off[l] = refs.size();
+      for (int gi : grp) if (l < db[gi].level_frames.size()) for (int fi : db[gi].level_frames[l]) {
+        refs.push_back(RbtFrameRef{db[gi].d_frames, db[gi].d_slices, fi, 0});
+        lv_w[l] = std::max(lv_w[l], (int)db[gi].frames[fi].cfg.w_ctb); lv_h[l] = std::max(lv_h[l], (int)db[gi].frames[fi].cfg.h_ctb);
+      }
+    }
+    lv_off[n_levels] = refs.size();
     RbtParseTask* d_tasks = (RbtParseTask*)rbtk::dev_alloc(tasks.size() * sizeof(RbtParseTask));
-    if (!d_tasks) { err = "device allocation failed"; rc = RBT_ERR_NOMEM; break; }
-    pooled.push_back(d_tasks);
+    RbtFrameRef* d_refs = (RbtFrameRef*)rbtk::dev_alloc(refs.size() * sizeof(RbtFrameRef));
+    if (d_tasks) pooled.push_back(d_tasks);
+    if (d_refs) pooled.push_back(d_refs);
+    if (!d_tasks || !d_refs) { err = "device allocation failed"; rc = RBT_ERR_NOMEM; break; }
     rbtk::set_stream(job_stream(j, lead));
-    if (rbtk::h2d(d_tasks, tasks.data(), tasks.size() * sizeof(RbtParseTask))) { err = "device transfer failed"; rc = RBT_ERR_NO_DEVICE; break; }
+    if (rbtk::h2d(d_tasks, tasks.data(), tasks.size() * sizeof(RbtParseTask)) || rbtk::h2d(d_refs, refs.data(), refs.size() * sizeof(RbtFrameRef))) { err = "device transfer failed"; rc = RBT_ERR_NO_DEVICE; break; }
     rbtk::timer_begin(T_PARSE); rbtk::launch_parse_tasks(d_tasks, (int)tasks.size(), mw4); rbtk::timer_end(T_PARSE);
+    rbtk::timer_begin(T_RECON);
+    for (size_t l = 0; l < n_levels; l++) {
+      rbtk::launch_recon_refs(d_refs + lv_off[l], (int)(lv_off[l + 1] - lv_off[l]), lv_w[l], lv_h[l]);
+      for (int gi : grp) if (l < db[gi].level_frames.size()) decode_launch_filters(db[gi], l);
+    }
+    rbtk::timer_end(T_RECON);
+    for (int gi : grp) { db[gi].recon_external = true; j.recon_timed[gi] = gi == lead; }
   }
   for (int k = 0; k < ng && !rc; k++) {
     const int gi = order[k], sid = job_stream(j, gi); rbtk::set_stream(sid);
@@ -419,8 +443,8 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
     const bool banded = db[gi].d_save != nullptr && !db[gi].ordered_parse;
     rc = banded ? decode_launch_chunked(db[gi], parse_bands(), sid, aux) : decode_launch_parse(db[gi]);
     if (rc) { err = db[gi].err; break; }
-    rbtk::timer_begin(T_RECON);
-    for (size_t l = 0; l < n_levels; l++) {
+    if (!db[gi].recon_external) rbtk::timer_begin(T_RECON);
+    for (size_t l = 0; l < n_levels && !db[gi].recon_external; l++) {
       if (!(banded && l == 0)) decode_launch_level(db[gi], l);
       if (fork && l == fork_level) {
         e.aux_stream = aux;
@@ -428,7 +452,7 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
         rbtk::set_stream(e.aux_stream); encode_launch_intra(e); intra_done = rbtk::stream_mark(e.aux_stream); encode_launch_entropy_intra(e); rbtk::set_stream(sid);
       }
     }
-    rbtk::timer_end(T_RECON);
+    if (!db[gi].recon_external) rbtk::timer_end(T_RECON);
     if (!jobs.empty()) { rbtk::timer_begin(T_POOL); for (const PoolJob& pj : jobs) rbtk::launch_pool(pj.in, pj.stride, pj.w, pj.h, 2, pj.y, pj.cb, pj.cr, pj.grey); rbtk::timer_end(T_POOL); }
     if (fork) rbtk::stream_wait_mark(sid, intra_done); else { encode_launch_intra(e); encode_launch_entropy_intra(e); }
     encode_launch_rest(e);
@@ -453,7 +477,7 @@ int gof_wait(GofJob* J, rbt_stats& st_out, std::string& err_out, uint8_t** out, 
     rc = decode_finish(db[gi]);
     if (rc) { err = db[gi].err; continue; }
     if (j.parse_timed.empty() || j.parse_timed[gi]) st.k_parse_ms += rbtk::timer_ms(T_PARSE);
-    st.k_recon_ms += rbtk::timer_ms(T_RECON);
+    if (j.recon_timed.empty() || j.recon_timed[gi]) st.k_recon_ms += rbtk::timer_ms(T_RECON);
     std::vector<std::vector<uint8_t>> o1;
     if (j.chained[gi]) rc = encode_finish(eb[gi], o1, st);
     else {

@@ -46,6 +46,19 @@ void launch_parse_tasks(const RbtParseTask* tasks, int n_tasks, int max_w4) {
   for (int i = 0; i < n_tasks; i++) rbt_parse_slice(tasks[i].frames, tasks[i].slices, tasks[i].slice, tasks[i].rbsp, (RbtParseLds*)plds, cap4, nullptr, 0);
 }
 size_t parse_save_bytes() { return sizeof(RbtParseSave); }
+void launch_recon_refs(const RbtFrameRef* refs, int n_frames, int max_w_ctb, int max_h_ctb) {
+  static RbtReconCtbLds lds;
+  for (int d = 0; d <= max_w_ctb - 1 + 2 * (max_h_ctb - 1); d++)
+    for (int k = 0; k < n_frames; k++) {
+      RbtFrame* frames = refs[k].frames; int fi = refs[k].frame; const RbtStreamCfg* g = &frames[fi].cfg;
+      for (int y = 0; y < g->h_ctb; y++) {
+        int x = d - 2 * y; if (x < 0 || x >= g->w_ctb) continue;
+        int addr = y * g->w_ctb + x;
+        if (frames[fi].ctb_slice[addr] == 0xFFFF) continue;
+        rbt_recon_ctb(frames, refs[k].slices, fi, addr, &lds);
+      }
+    }
+}
 void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int y_begin, int y_end) {
   static RbtReconCtbLds lds;
   if (y_end > max_h_ctb) y_end = max_h_ctb;
