@@ -10,9 +10,9 @@ namespace rbtk {
 int dev_init(int device);                 // 0 = ok
 // Independent sub-bitstreams run on separate HIP streams so that the short pipelines (occupancy, geometry) overlap the
 // long entropy-decoding chain of the attribute stream. All calls below act on the currently selected stream.
-// The HIP runtime multiplexes streams onto 4 hardware queues by default; two streams sharing a queue serialise (measured:
-// with 8 streams the geometry upload queued behind the attribute kernels and blocked the host for 285 ms). So: 4 streams,
-// one per sub-bitstream pipeline, and the last one doubles as the auxiliary stream of the longest pipeline when free.
+// The HIP runtime multiplexes streams onto 4 hardware queues by default; two streams sharing a queue serialise, and a copy
+// from pageable memory blocks the host until its queue has drained (measured: 285 ms). A job with four streams uses one per
+// sub-bitstream pipeline, and the last one is the auxiliary stream of the longest pipeline.
 // Several GOFs can be in flight (rbt_submit_gof). Host code names streams by "lane" = job slot * 4 + pipeline (timers are kept
 // per lane); map_lane binds a lane to one of the 16 HIP streams. dev_init asks the HIP runtime for 16 hardware queues
 // (GPU_MAX_HW_QUEUES) when it is the first HIP user of the process. Measured on MI355X: with 24 / 32 queues a lone GOF takes
