@@ -21,10 +21,13 @@ F = agg("gpurun_out/prof_f/f_counter_collection.csv", "FETCH_SIZE"); W = agg("gp
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two separate passes, --kernel-trace only), python3 bench.py --steps 1 --warmup 0 --in-flight 1 --cpu-sample 0 "
                "--load-input <R5 streams> on MI355X: one transcode step of the 32-frame 1280x1280 GOF, nothing else in the process. Values are KB summed over "
                "every dispatch of the kernel in that step. FETCH_SIZE is reported uncorrected (MI355X_MICROARCH.md: under-reports wide coalesced reads; "
-               "these kernels issue narrow accesses).", "kernels": {}}
+               "these kernels issue narrow accesses). kernel_ms / HBM_GBps: time of the dispatches in the FETCH_SIZE pass and (FETCH + WRITE) / time; MI355X peak 8000 GB/s.", "kernels": {}}
+dur = collections.defaultdict(float)     # kernel time of the same (FETCH_SIZE) pass; counter collection serialises the dispatches
+for r in csv.DictReader(open("gpurun_out/prof_f/f_kernel_trace.csv")): dur[kname(r["Kernel_Name"])] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 for k in sorted(set(F) | set(W)):
     if k.startswith("__"): continue
-    out["kernels"][k] = {"dispatches": F[k][0] or W[k][0], "FETCH_SIZE_KB": round(F[k][1], 1), "WRITE_SIZE_KB": round(W[k][1], 1)}
+    out["kernels"][k] = {"dispatches": F[k][0] or W[k][0], "FETCH_SIZE_KB": round(F[k][1], 1), "WRITE_SIZE_KB": round(W[k][1], 1), "kernel_ms": round(dur[k], 3),
+                         "HBM_GBps": round((F[k][1] + W[k][1]) * 1024 / (dur[k] * 1e-3) / 1e9, 1) if dur[k] > 0 else None}
 json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
 
 rows = [r for r in csv.DictReader(open("gpurun_out/prof_tl/tl_kernel_trace.csv")) if "rbtk::" in r["Kernel_Name"]]
