@@ -143,6 +143,9 @@ def main():
             if args.backend == "nccl": torch.cuda.synchronize()
 
     ctx.set_depth(D)
+    # set-up, untimed: one job per slot, so that every slot's device arenas exist (librbt recycles them) even when W < D
+    primed = D if args.warmup < D else 0
+    if primed: run(primed, D, None)
     run(args.warmup, D, None)
     sync()
     host_t["submit"] = host_t["wait"] = 0.0
@@ -289,7 +292,7 @@ def main():
                 "vs_baseline": None, "dtype": "u16/i32", "data": "synthetic",
                 "config": {"workload": f"{n_pc}-frame GOF, {w}x{h} V-PCC maps (2x{n_pc} geometry + 2x{n_pc} attribute yuv420p10 I/P pairs, {n_pc} occupancy {w // 2}x{h // 2} lossless), "
                                        f"R5 (QP16/22, prec 2) -> R3 (QP24/32, prec 4), synthetic longdress-like atlas",
-                           "gof_per_gpu": 1, "gofs_in_flight": D, "in_bytes": in_bytes, "out_bytes": out_bytes, "parallelism": f"gof-shard x{world}"},
+                           "gof_per_gpu": 1, "gofs_in_flight": D, "setup_jobs_before_warmup": primed, "in_bytes": in_bytes, "out_bytes": out_bytes, "parallelism": f"gof-shard x{world}"},
                 "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                              "traffic": traffic, "kernel_ms": {k_: round(v, 3) for k_, v in groups.items()},
                              "path_achieved_GBs": round(path_achieved, 3), "path_frac": round(path_achieved / HBM_PEAK_GBS, 6)},
