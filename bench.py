@@ -109,7 +109,7 @@ def main():
     # One step = one GOF through the hot path. The steps are issued the way a transcoder walks a sequence: rbt_submit_gof
     # for GOF i+D-1 before rbt_wait_gof for GOF i (D = --in-flight GOFs in flight on disjoint HIP streams; D = 1 is the
     # blocking rbt_transcode_gof). Every one of the K timed steps is submitted and collected inside the timed region.
-    D = max(1, min(args.in_flight, 16))
+    D = max(1, min(args.in_flight, 16, args.steps))   # never announce a deeper pipeline than the run has steps: shallower pipelines get more streams per job
     stats_acc = {}
 
     host_t = {"submit": 0.0, "wait": 0.0}
