@@ -123,8 +123,13 @@ __global__ void __launch_bounds__(64) k_parse_tasks(const RbtParseTask* tasks) {
   const RbtParseTask t = tasks[blockIdx.x];
   rbt_parse_slice(t.frames, t.slices, t.slice, t.rbsp, RBT_LDS_CAST(RbtParseLds, lds), CAP4, nullptr, 0);
 }
-// one wave per CTB on anti-diagonal d (x + 2y == d): left, above-left, above and above-right CTBs are complete
-__global__ void __launch_bounds__(64) k_recon_diag(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int d, int y_first) {
+// one workgroup (two waves: luma chain, Cb/Cr chain - rbt_recon.h RbtReconRole) per CTB on anti-diagonal d (x + 2y == d):
+// left, above-left, above and above-right CTBs are complete
+__device__ __forceinline__ void recon_ctb_roles(RbtFrame* frames, const RbtSlice* slices, int fi, int addr, RBT_LDS_AS RbtReconCtbLds* L) {
+  if (threadIdx.x < 64) rbt_recon_ctb<RC_ROLE_LUMA>(frames, slices, fi, addr, &L->t, &L->role[0]);
+  else rbt_recon_ctb<RC_ROLE_CHROMA>(frames, slices, fi, addr, &L->t, &L->role[1]);
+}
+__global__ void __launch_bounds__(128) k_recon_diag(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int d, int y_first) {
   __shared__ RbtReconCtbLds lds;
   int fi = frame_list[blockIdx.y];
   const RbtStreamCfg* g = &frames[fi].cfg;
@@ -132,10 +137,10 @@ __global__ void __launch_bounds__(64) k_recon_diag(RbtFrame* frames, const RbtSl
   if (y >= g->h_ctb || x < 0 || x >= g->w_ctb) return;
   int addr = y * g->w_ctb + x;
   if (frames[fi].ctb_slice[addr] == 0xFFFF) return;     // CTB not covered by any decoded slice
-  rbt_recon_ctb(frames, slices, fi, addr, RBT_LDS_CAST(RbtReconCtbLds, &lds));
+  recon_ctb_roles(frames, slices, fi, addr, RBT_LDS_CAST(RbtReconCtbLds, &lds));
 }
 // the same over pictures of several batches
-__global__ void __launch_bounds__(64) k_recon_diag_refs(const RbtFrameRef* refs, int d, int y_first) {
+__global__ void __launch_bounds__(128) k_recon_diag_refs(const RbtFrameRef* refs, int d, int y_first) {
   __shared__ RbtReconCtbLds lds;
   const RbtFrameRef r = refs[blockIdx.y];
   const RbtStreamCfg* g = &r.frames[r.frame].cfg;
@@ -143,7 +148,7 @@ __global__ void __launch_bounds__(64) k_recon_diag_refs(const RbtFrameRef* refs,
   if (y >= g->h_ctb || x < 0 || x >= g->w_ctb) return;
   int addr = y * g->w_ctb + x;
   if (r.frames[r.frame].ctb_slice[addr] == 0xFFFF) return;     // CTB not covered by any decoded slice
-  rbt_recon_ctb(r.frames, r.slices, r.frame, addr, RBT_LDS_CAST(RbtReconCtbLds, &lds));
+  recon_ctb_roles(r.frames, r.slices, r.frame, addr, RBT_LDS_CAST(RbtReconCtbLds, &lds));
 }
 __global__ void __launch_bounds__(256) k_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int dir) {
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
@@ -181,7 +186,7 @@ void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame
     int y_hi = d / 2; if (y_hi > y_end - 1) y_hi = y_end - 1;              // x = d - 2y >= 0
     int y_lo = (d - (max_w_ctb - 1) + 1) / 2; if (y_lo < y_begin) y_lo = y_begin;   // x <= w - 1
     if (y_lo > y_hi) continue;
-    hipLaunchKernelGGL(k_recon_diag, dim3(y_hi - y_lo + 1, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list, d, y_lo);
+    hipLaunchKernelGGL(k_recon_diag, dim3(y_hi - y_lo + 1, n_frames), dim3(128), 0, g_stream, frames, slices, frame_list, d, y_lo);
   }
 }
 void launch_recon_refs(const RbtFrameRef* refs, int n_frames, int max_w_ctb, int max_h_ctb) {
@@ -190,7 +195,7 @@ void launch_recon_refs(const RbtFrameRef* refs, int n_frames, int max_w_ctb, int
     int y_hi = d / 2; if (y_hi > max_h_ctb - 1) y_hi = max_h_ctb - 1;
     int y_lo = (d - (max_w_ctb - 1) + 1) / 2; if (y_lo < 0) y_lo = 0;
     if (y_lo > y_hi) continue;
-    hipLaunchKernelGGL(k_recon_diag_refs, dim3(y_hi - y_lo + 1, n_frames), dim3(64), 0, g_stream, refs, d, y_lo);
+    hipLaunchKernelGGL(k_recon_diag_refs, dim3(y_hi - y_lo + 1, n_frames), dim3(128), 0, g_stream, refs, d, y_lo);
   }
 }
 void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_units) {

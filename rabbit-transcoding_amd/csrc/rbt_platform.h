@@ -44,12 +44,13 @@ __device__ int rbt_llvm_writelane(int v, int lane, int old) __asm("llvm.amdgcn.w
 static __device__ __forceinline__ int rbt_writelane(int old, int v, int lane) { return rbt_llvm_writelane(v, lane, old); }
 #define RBT_DEV static __device__ __forceinline__
 #define RBT_CONST static __device__ const
-#define RBT_PAR_FOR(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += (int)blockDim.x)
+// (wave-local: kernels that use it run single-wave workgroups, or one wave per role - k_recon_diag)
+#define RBT_PAR_FOR(i, n) for (int i = (int)threadIdx.x & 63; i < (int)(n); i += 64)
 #define RBT_SYNC() __syncthreads()
 // single-wave workgroups only: orders LDS traffic between the lanes of the wave without waiting for outstanding global
 // stores (a __syncthreads() would wait for every store round trip to HBM)
 #define RBT_SYNC_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define RBT_LANE0 (threadIdx.x == 0)
+#define RBT_LANE0 ((threadIdx.x & 63) == 0)
 #define RBT_NTHREADS ((int)blockDim.x)
 // LDS objects are always reached through address_space(3) pointers (ds_* instructions). A generic (flat) pointer into
 // LDS is unsafe on gfx950: the compiler may fold part of an index into the instruction's immediate offset, and a base

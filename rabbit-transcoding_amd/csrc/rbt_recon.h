@@ -262,13 +262,15 @@ template <class DP> RBT_DEV void rc_mc_plane(DP dst, int dstride, int dx0, int d
 struct alignas(8) RbtU2 { uint32_t x, y; };
 struct RbtCtbTile {
   uint16_t y[64 * RC_TS_Y], top_y[130]; uint16_t c[2][32 * RC_TS_C], top_c[2][66];   // sample (xx,yy) relative to the CTB: body yy * stride + xx + 1, row above: top[xx + 1]
-  uint8_t uav[17 * RC_US];                                  // 4x4 luma unit (ux,uy) usable as intra reference: (uy + 1) * RC_US + ux + 1
 };
-struct RbtReconCtbLds { RbtCtbTile t; RbtReconLdsCore rc;
-#ifdef RBT_PROFILE
-  unsigned long long prof[8];
-#endif
-};
+// The luma TBs of a CTB form one serial chain and its Cb/Cr TBs another; nothing connects the two (prediction reads samples of
+// the own component, the intra-reference availability of a 4x4 unit follows the decoding order for both). The workgroup has two
+// waves: wave 0 walks the CTB's commands for luma, wave 1 for Cb/Cr, each with its own TB scratch and its own copy of the unit
+// availability (both apply the same marks in the same order); they share the tile and never synchronise. The CTB takes the time
+// of the longer chain instead of the sum (Cb/Cr were 46 % of a CTB).
+enum { RC_ROLE_ALL = 0, RC_ROLE_LUMA = 1, RC_ROLE_CHROMA = 2 };
+struct RbtReconRole { RbtReconLdsCore rc; uint8_t uav[17 * RC_US]; };   // uav: 4x4 luma unit (ux,uy) usable as intra reference: (uy + 1) * RC_US + ux + 1
+struct RbtReconCtbLds { RbtCtbTile t; RbtReconRole role[2]; };
 
 // neighbour index i of a TB at (x0,y0): 0 .. 2N-1 left column bottom-up, 2N corner, 2N+1 .. 4N top row left to right
 RBT_DEV void rc_nb_xy(int i, int x0, int y0, int N, int* xn, int* yn) {
@@ -282,18 +284,15 @@ RBT_DEV int rc_nb_av(const RBT_LDS_AS uint8_t* uav, int i, int x0, int y0, int N
   return uy < n4 && uav[(uy + 1) * RC_US + ux + 1];
 }
 // mark_l4 >= 0: also flags the TB's (1 << mark_l4)^2 luma units at (mux,muy) as decoded in the same pass
-RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int c_idx, int x0, int y0, int log2, int intra, int mode, int cbf, int ts, int tq_bypass, int qp,
+RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtCtbTile* t, RBT_LDS_AS RbtReconRole* R, int c_idx, int x0, int y0, int log2, int intra, int mode, int cbf, int ts, int tq_bypass, int qp,
                         int mark_l4, int mux, int muy, int mark_flag) {
   // (x0,y0): TB origin relative to the CTB, in samples of component c_idx
-  RBT_LDS_AS RbtReconLdsCore* l = &L->rc; RBT_LDS_AS RbtCtbTile* t = &L->t;
+  RBT_LDS_AS RbtReconLdsCore* l = &R->rc; RBT_LDS_AS uint8_t* uav = R->uav;
   RBT_LDS_AS int32_t* const l_nbf = (RBT_LDS_AS int32_t*)l->tmp; RBT_LDS_AS int32_t* const l_ref = l_nbf + 132;   // alias tmp (dead after the transform)
   const int N = 1 << log2, sh = c_idx ? 1 : 0, bd = g->bit_depth, maxv = (1 << bd) - 1, n4 = (1 << g->log2_ctb) >> 2;
   RBT_LDS_AS uint16_t* tile = c_idx == 0 ? t->y : t->c[c_idx - 1]; const int S = c_idx == 0 ? RC_TS_Y : RC_TS_C;
   const RBT_LDS_AS uint16_t* top = c_idx == 0 ? t->top_y : t->top_c[c_idx - 1];
   const RBT_LDS_AS int16_t* coef = (const RBT_LDS_AS int16_t*)tile + 1;      // levels of the TB: where its samples will be (row stride S)
-#ifdef RBT_PROFILE
-  unsigned long long p0_ = __builtin_readcyclecounter(), p1_ = p0_, p2_ = p0_, p3_ = p0_;
-#endif
   // residual first: it does not depend on the prediction, and the prediction pass can then add it on the fly
   if (cbf) {
     if (tq_bypass) {
@@ -305,18 +304,15 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int
       rc_inv_transform(log2, c_idx == 0 && log2 == 2 && intra, ts, bd, l);
     }
   }
-#ifdef RBT_PROFILE
-  p1_ = __builtin_readcyclecounter();
-#endif
   RBT_LDS_AS int32_t* fin = l->nb; RcIntraCtx q;
   if (intra) {
     // availability of the 4N+1 neighbours straight from the unit flags (no LDS round trip), then every lane fetches the
     // sample its index is substituted from (8.4.4.2.2) - gather and substitution in one pass
     const int tot = 4 * N + 1;
     uint64_t m0 = 0, m1 = 0; int m2 = 0;
-    RBT_VBALLOT(m0, p, rbt_min(tot, 64), rc_nb_av(t->uav, p, x0, y0, N, sh, n4));
-    if (tot > 64) { RBT_VBALLOT(m1, p, rbt_min(tot - 64, 64), rc_nb_av(t->uav, 64 + p, x0, y0, N, sh, n4)); }
-    if (tot > 128) m2 = rc_nb_av(t->uav, 128, x0, y0, N, sh, n4);
+    RBT_VBALLOT(m0, p, rbt_min(tot, 64), rc_nb_av(uav, p, x0, y0, N, sh, n4));
+    if (tot > 64) { RBT_VBALLOT(m1, p, rbt_min(tot - 64, 64), rc_nb_av(uav, 64 + p, x0, y0, N, sh, n4)); }
+    if (tot > 128) m2 = rc_nb_av(uav, 128, x0, y0, N, sh, n4);
     const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : (m2 ? 128 : -1));
     RBT_PAR_FOR(i, tot) {
       int v = 1 << (bd - 1);
@@ -327,9 +323,6 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int
     fin = rc_intra_filter(g, c_idx, log2, mode, l->nb, l_nbf);
     rc_intra_setup(g, c_idx, log2, mode, fin, l_ref, &q);
   }
-#ifdef RBT_PROFILE
-  p2_ = p3_ = __builtin_readcyclecounter();
-#endif
   if (intra) {
     RBT_PAR_FOR(i, N * N) {
       int x = i & (N - 1), y = i >> log2, o = (y0 + y) * S + x0 + x + 1;
@@ -339,16 +332,13 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int
   } else if (cbf) {                                                          // inter: leave the residual where the levels were
     RBT_PAR_FOR(i, N * N) { int x = i & (N - 1), y = i >> log2; tile[(y0 + y) * S + x0 + x + 1] = (uint16_t)l->res[i]; }
   }
-  if (mark_l4 >= 0) { RBT_PAR_FOR(i, 1 << (2 * mark_l4)) t->uav[(muy + (i >> mark_l4) + 1) * RC_US + mux + (i & ((1 << mark_l4) - 1)) + 1] = (uint8_t)mark_flag; }
+  if (mark_l4 >= 0) { RBT_PAR_FOR(i, 1 << (2 * mark_l4)) uav[(muy + (i >> mark_l4) + 1) * RC_US + mux + (i & ((1 << mark_l4) - 1)) + 1] = (uint8_t)mark_flag; }
   RBT_SYNC_LDS();
-#ifdef RBT_PROFILE
-  { unsigned long long p4_ = __builtin_readcyclecounter(); L->prof[0] += p1_ - p0_; L->prof[1] += p2_ - p1_; L->prof[2] += p3_ - p2_; L->prof[3] += p4_ - p3_; L->prof[4] += 1; }
-#endif
 }
 // Cb and Cr TB of one TU in the same passes. The two blocks share position, size, prediction mode and availability and
 // differ only in data, so every phase (and every wait for LDS) is paid once for both; chroma is never smoothed (8.4.4.2.3).
-RBT_DEV void rc_tile_tb_cpair(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* L, int x0, int y0, int log2, int intra, int mode, int cbf_cb, int cbf_cr, int tq_bypass, int qp_cb, int qp_cr) {
-  RBT_LDS_AS RbtReconLdsCore* l = &L->rc; RBT_LDS_AS RbtCtbTile* t = &L->t;
+RBT_DEV void rc_tile_tb_cpair(const RbtStreamCfg* g, RBT_LDS_AS RbtCtbTile* t, RBT_LDS_AS RbtReconRole* R, int x0, int y0, int log2, int intra, int mode, int cbf_cb, int cbf_cr, int tq_bypass, int qp_cb, int qp_cr) {
+  RBT_LDS_AS RbtReconLdsCore* l = &R->rc; RBT_LDS_AS uint8_t* uav = R->uav;
   RBT_LDS_AS int32_t* const l_ref = (RBT_LDS_AS int32_t*)l->tmp + 132; RBT_LDS_AS int32_t* const l_ref2 = l_ref + 100;   // alias tmp (dead after the transform)
   const int N = 1 << log2, NN = N * N, bd = g->bit_depth, maxv = (1 << bd) - 1, n4 = (1 << g->log2_ctb) >> 2, S = RC_TS_C;
   if (cbf_cb | cbf_cr) {
@@ -377,8 +367,8 @@ RBT_DEV void rc_tile_tb_cpair(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* 
   if (intra) {
     const int tot = 4 * N + 1;                                           // <= 65: plane b keeps its references at nb[b * 66 ..]
     uint64_t m0 = 0, m1 = 0; int m2 = 0;
-    RBT_VBALLOT(m0, p, rbt_min(tot, 64), rc_nb_av(t->uav, p, x0, y0, N, 1, n4));
-    if (tot > 64) { RBT_VBALLOT(m1, p, tot - 64, rc_nb_av(t->uav, 64 + p, x0, y0, N, 1, n4)); }
+    RBT_VBALLOT(m0, p, rbt_min(tot, 64), rc_nb_av(uav, p, x0, y0, N, 1, n4));
+    if (tot > 64) { RBT_VBALLOT(m1, p, tot - 64, rc_nb_av(uav, 64 + p, x0, y0, N, 1, n4)); }
     const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : -1);
     RBT_PAR_FOR(i, 2 * tot) {
       const int b = i >= tot, idx = i - b * tot;
@@ -426,12 +416,12 @@ RBT_DEV void rc_tile_tb_cpair(const RbtStreamCfg* g, RBT_LDS_AS RbtReconCtbLds* 
   }
   RBT_SYNC_LDS();
 }
-RBT_DEV void rc_tile_mark(RBT_LDS_AS RbtCtbTile* t, int ux, int uy, int w4, int h4, int flag) {   // any rectangle (prediction units)
-  RBT_PAR_FOR(i, w4 * h4) t->uav[(uy + i / w4 + 1) * RC_US + ux + i % w4 + 1] = (uint8_t)flag;
+RBT_DEV void rc_tile_mark(RBT_LDS_AS uint8_t* uav, int ux, int uy, int w4, int h4, int flag) {   // any rectangle (prediction units)
+  RBT_PAR_FOR(i, w4 * h4) uav[(uy + i / w4 + 1) * RC_US + ux + i % w4 + 1] = (uint8_t)flag;
   RBT_SYNC_LDS();
 }
-RBT_DEV void rc_tile_mark_sq(RBT_LDS_AS RbtCtbTile* t, int ux, int uy, int l4, int flag) {           // square of 1 << l4 units (transform units)
-  RBT_PAR_FOR(i, 1 << (2 * l4)) t->uav[(uy + (i >> l4) + 1) * RC_US + ux + (i & ((1 << l4) - 1)) + 1] = (uint8_t)flag;
+RBT_DEV void rc_tile_mark_sq(RBT_LDS_AS uint8_t* uav, int ux, int uy, int l4, int flag) {           // square of 1 << l4 units (transform units)
+  RBT_PAR_FOR(i, 1 << (2 * l4)) uav[(uy + (i >> l4) + 1) * RC_US + ux + (i & ((1 << l4) - 1)) + 1] = (uint8_t)flag;
   RBT_SYNC_LDS();
 }
 // usable-as-intra-reference flag of the 4x4 unit (gxu,gyu) of the picture for CTB ac (a unit outside the current CTB)
@@ -443,22 +433,21 @@ RBT_DEV int rc_unit_avail(const RbtFrame* f, int ac, int gxu, int gyu) {
   if (g->cip && (f->pm[gyu * g->w4 + gxu] & RBT_PM_MODE_MASK) != RBT_MODE_INTRA) return 0;
   return 1;
 }
-RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_idx, int ctb_addr, RBT_LDS_AS RbtReconCtbLds* L) {
+// ROLE: RC_ROLE_LUMA / RC_ROLE_CHROMA = the calling wave's half of the CTB (see RbtReconRole); RC_ROLE_ALL = everything on one wave.
+template <int ROLE>
+RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_idx, int ctb_addr, RBT_LDS_AS RbtCtbTile* t, RBT_LDS_AS RbtReconRole* R) {
+  constexpr bool DO_Y = ROLE != RC_ROLE_CHROMA, DO_C = ROLE != RC_ROLE_LUMA;
   RbtFrame* f = &frames[frame_idx];
   const RbtStreamCfg gcopy = f->cfg;                                     // private copy: not reloaded after every store
-  const RbtStreamCfg* g = &gcopy; RBT_LDS_AS RbtCtbTile* t = &L->t;
+  const RbtStreamCfg* g = &gcopy;
   const int ctb = 1 << g->log2_ctb, n4 = ctb >> 2, cx = (ctb_addr % g->w_ctb) << g->log2_ctb, cy = (ctb_addr / g->w_ctb) << g->log2_ctb;
   uint32_t n = f->cmd_count[ctb_addr];
   if ((int)n > f->cmd_cap) n = (uint32_t)f->cmd_cap;
   const RbtCmd* cmds = f->cmds + (size_t)ctb_addr * f->cmd_cap;
   const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
-#ifdef RBT_PROFILE
-  unsigned long long q0_ = __builtin_readcyclecounter();
-  for (int i = 0; i < 8; i++) L->prof[i] = 0;
-#endif
-  rc_stage_tables(&L->rc);
+  rc_stage_tables(&R->rc);
   // ---- fetch: borders, unit availability, coefficient levels (one HBM round trip for everything) ----
-  for (int c = 0; c < 3; c++) {
+  for (int c = DO_Y ? 0 : 1; c < (DO_C ? 3 : 1); c++) {
     const int sh = c ? 1 : 0, nn = ctb >> sh, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, ox = cx >> sh, oy = cy >> sh, S = c ? RC_TS_C : RC_TS_Y;
     const uint16_t* p = f->pix[c]; RBT_LDS_AS uint16_t* tile = c == 0 ? t->y : t->c[c - 1]; RBT_LDS_AS uint16_t* top = c == 0 ? t->top_y : t->top_c[c - 1];
     RBT_PAR_FOR(i, 2 * nn + 1) { int x = ox + i - 1, y = oy - 1; top[i] = (x >= 0 && y >= 0 && x < pw) ? p[(size_t)y * pw + x] : 0; }
@@ -478,12 +467,9 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
   RBT_PAR_FOR(i, 17 * RC_US) {
     int ux = i % RC_US - 1, uy = i / RC_US - 1, a = 0;
     if ((uy < 0 && ux < 2 * n4) || (ux < 0 && uy < n4)) a = rc_unit_avail(f, ctb_addr, (cx >> 2) + ux, (cy >> 2) + uy);
-    t->uav[i] = (uint8_t)a;
+    R->uav[i] = (uint8_t)a;
   }
-  RBT_SYNC();
-#ifdef RBT_PROFILE
-  unsigned long long q1_ = __builtin_readcyclecounter();
-#endif
+  RBT_SYNC_LDS();                                                         // everything a wave reads below it fetched itself
   // ---- inter TBs first (P slices): levels -> residual in place ----
   const int has_inter = sl->slice_type != RBT_SLICE_I;
   if (has_inter) {
@@ -493,13 +479,13 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
       if (k + 1 < n) nx0 = cmds[k + 1];
       if (c.type != RBT_CMD_TU || (c.a & RBT_TU_INTRA)) continue;
       const int x0 = c.x4 * 4, y0 = c.y4 * 4, fl = c.a, log2 = c.log2;
-      if (fl & RBT_TU_CBF_Y) rc_tile_tb(g, L, 0, x0, y0, log2, 0, c.b, 1, (fl & RBT_TU_TS_Y) != 0, c.d, c.qp[0], -1, 0, 0, 0);
-      if ((fl & RBT_TU_CHROMA) && (fl & (RBT_TU_CBF_CB | RBT_TU_CBF_CR))) {
+      if (DO_Y && (fl & RBT_TU_CBF_Y)) rc_tile_tb(g, t, R, 0, x0, y0, log2, 0, c.b, 1, (fl & RBT_TU_TS_Y) != 0, c.d, c.qp[0], -1, 0, 0, 0);
+      if (DO_C && (fl & RBT_TU_CHROMA) && (fl & (RBT_TU_CBF_CB | RBT_TU_CBF_CR))) {
         const int xc = (log2 > 2 ? x0 : x0 - 4) >> 1, yc = (log2 > 2 ? y0 : y0 - 4) >> 1, l2c = log2 > 2 ? log2 - 1 : 2;
         if (fl & (RBT_TU_TS_CB | RBT_TU_TS_CR)) {
-          if (fl & RBT_TU_CBF_CB) rc_tile_tb(g, L, 1, xc, yc, l2c, 0, c.c, 1, (fl & RBT_TU_TS_CB) != 0, c.d, c.qp[1], -1, 0, 0, 0);
-          if (fl & RBT_TU_CBF_CR) rc_tile_tb(g, L, 2, xc, yc, l2c, 0, c.c, 1, (fl & RBT_TU_TS_CR) != 0, c.d, c.qp[2], -1, 0, 0, 0);
-        } else rc_tile_tb_cpair(g, L, xc, yc, l2c, 0, c.c, (fl & RBT_TU_CBF_CB) != 0, (fl & RBT_TU_CBF_CR) != 0, c.d, c.qp[1], c.qp[2]);
+          if (fl & RBT_TU_CBF_CB) rc_tile_tb(g, t, R, 1, xc, yc, l2c, 0, c.c, 1, (fl & RBT_TU_TS_CB) != 0, c.d, c.qp[1], -1, 0, 0, 0);
+          if (fl & RBT_TU_CBF_CR) rc_tile_tb(g, t, R, 2, xc, yc, l2c, 0, c.c, 1, (fl & RBT_TU_TS_CR) != 0, c.d, c.qp[2], -1, 0, 0, 0);
+        } else rc_tile_tb_cpair(g, t, R, xc, yc, l2c, 0, c.c, (fl & RBT_TU_CBF_CB) != 0, (fl & RBT_TU_CBF_CR) != 0, c.d, c.qp[1], c.qp[2]);
       }
     }
     RBT_SYNC_LDS();
@@ -513,35 +499,29 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
     if (c.type == RBT_CMD_PU) {
       const RbtFrame* ref = &frames[sl->ref_frame[c.c]];
       const int w = c.a * 4, h = c.b * 4, mvx = c.mvx, mvy = c.mvy;
-      rc_mc_plane(t->y, RC_TS_Y, x0 + 1, y0, ref->out[0], g->w, g->h, cx + x0, cy + y0, w, h, mvx >> 2, mvy >> 2, mvx & 3, mvy & 3, 8, k_luma_filter[mvx & 3], k_luma_filter[mvy & 3], g->bit_depth, 1);
-      for (int cc = 1; cc < 3; cc++)
+      if (DO_Y) rc_mc_plane(t->y, RC_TS_Y, x0 + 1, y0, ref->out[0], g->w, g->h, cx + x0, cy + y0, w, h, mvx >> 2, mvy >> 2, mvx & 3, mvy & 3, 8, k_luma_filter[mvx & 3], k_luma_filter[mvy & 3], g->bit_depth, 1);
+      if (DO_C) for (int cc = 1; cc < 3; cc++)
         rc_mc_plane(t->c[cc - 1], RC_TS_C, (x0 >> 1) + 1, y0 >> 1, ref->out[cc], g->cw, g->ch, (cx + x0) >> 1, (cy + y0) >> 1, w >> 1, h >> 1, mvx >> 3, mvy >> 3, mvx & 7, mvy & 7, 4,
                     k_chroma_filter[mvx & 7], k_chroma_filter[mvy & 7], g->bit_depth, 1);
-      rc_tile_mark(t, c.x4, c.y4, c.a, c.b, !g->cip);
+      rc_tile_mark(R->uav, c.x4, c.y4, c.a, c.b, !g->cip);
     } else if (c.type == RBT_CMD_TU && (c.a & RBT_TU_INTRA)) {
       const int fl = c.a, log2 = c.log2;
-      rc_tile_tb(g, L, 0, x0, y0, log2, 1, c.b, fl & RBT_TU_CBF_Y, (fl & RBT_TU_TS_Y) != 0, c.d, c.qp[0], log2 - 2, c.x4, c.y4, 1);
-      if (fl & RBT_TU_CHROMA) {
+      if (DO_Y) rc_tile_tb(g, t, R, 0, x0, y0, log2, 1, c.b, fl & RBT_TU_CBF_Y, (fl & RBT_TU_TS_Y) != 0, c.d, c.qp[0], log2 - 2, c.x4, c.y4, 1);
+      else rc_tile_mark_sq(R->uav, c.x4, c.y4, log2 - 2, 1);             // the mark the luma TB leaves behind
+      if (DO_C && (fl & RBT_TU_CHROMA)) {
         const int xc = (log2 > 2 ? x0 : x0 - 4) >> 1, yc = (log2 > 2 ? y0 : y0 - 4) >> 1, l2c = log2 > 2 ? log2 - 1 : 2;
         if (fl & (RBT_TU_TS_CB | RBT_TU_TS_CR)) {                      // transform skip (rare): one plane at a time
-          rc_tile_tb(g, L, 1, xc, yc, l2c, 1, c.c, fl & RBT_TU_CBF_CB, (fl & RBT_TU_TS_CB) != 0, c.d, c.qp[1], -1, 0, 0, 0);
-          rc_tile_tb(g, L, 2, xc, yc, l2c, 1, c.c, fl & RBT_TU_CBF_CR, (fl & RBT_TU_TS_CR) != 0, c.d, c.qp[2], -1, 0, 0, 0);
-        } else rc_tile_tb_cpair(g, L, xc, yc, l2c, 1, c.c, (fl & RBT_TU_CBF_CB) != 0, (fl & RBT_TU_CBF_CR) != 0, c.d, c.qp[1], c.qp[2]);
+          rc_tile_tb(g, t, R, 1, xc, yc, l2c, 1, c.c, fl & RBT_TU_CBF_CB, (fl & RBT_TU_TS_CB) != 0, c.d, c.qp[1], -1, 0, 0, 0);
+          rc_tile_tb(g, t, R, 2, xc, yc, l2c, 1, c.c, fl & RBT_TU_CBF_CR, (fl & RBT_TU_TS_CR) != 0, c.d, c.qp[2], -1, 0, 0, 0);
+        } else rc_tile_tb_cpair(g, t, R, xc, yc, l2c, 1, c.c, (fl & RBT_TU_CBF_CB) != 0, (fl & RBT_TU_CBF_CR) != 0, c.d, c.qp[1], c.qp[2]);
       }
     }
   }
-#ifdef RBT_PROFILE
-  unsigned long long q2_ = __builtin_readcyclecounter();
-#endif
   // ---- write the CTB back (clipped to the picture) ----
-  for (int c = 0; c < 3; c++) {
+  for (int c = DO_Y ? 0 : 1; c < (DO_C ? 3 : 1); c++) {
     const int sh = c ? 1 : 0, nn = ctb >> sh, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, ox = cx >> sh, oy = cy >> sh, S = c ? RC_TS_C : RC_TS_Y;
     uint16_t* p = f->pix[c]; RBT_LDS_AS uint16_t* tile = c == 0 ? t->y : t->c[c - 1];
     const int lnn = g->log2_ctb - sh;
     RBT_PAR_FOR(i, nn * nn) { int x = i & (nn - 1), y = i >> lnn; if (ox + x < pw && oy + y < ph) p[(size_t)(oy + y) * pw + ox + x] = tile[y * S + x + 1]; }
   }
-#ifdef RBT_PROFILE
-  if (RBT_LANE0 && frame_idx == 0 && ctb_addr == 190) printf("ctb %d: fetch %llu, cmds %llu (n %u), writeback %llu; TBs %llu: residual %llu, intra prep %llu, - %llu, predict+add %llu\n", ctb_addr, q1_ - q0_, q2_ - q1_, n,
-      __builtin_readcyclecounter() - q2_, L->prof[4], L->prof[0], L->prof[1], L->prof[2], L->prof[3]);
-#endif
 }

@@ -55,7 +55,8 @@ void launch_recon_refs(const RbtFrameRef* refs, int n_frames, int max_w_ctb, int
         int x = d - 2 * y; if (x < 0 || x >= g->w_ctb) continue;
         int addr = y * g->w_ctb + x;
         if (frames[fi].ctb_slice[addr] == 0xFFFF) continue;
-        rbt_recon_ctb(frames, refs[k].slices, fi, addr, &lds);
+        rbt_recon_ctb<RC_ROLE_LUMA>(frames, refs[k].slices, fi, addr, &lds.t, &lds.role[0]);     // the two roles are independent:
+        rbt_recon_ctb<RC_ROLE_CHROMA>(frames, refs[k].slices, fi, addr, &lds.t, &lds.role[1]);   // one after the other emulates them
       }
     }
 }
@@ -69,7 +70,8 @@ void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame
         int x = d - 2 * y; if (x < 0 || x >= g->w_ctb) continue;
         int addr = y * g->w_ctb + x;
         if (frames[fi].ctb_slice[addr] == 0xFFFF) continue;
-        rbt_recon_ctb(frames, slices, fi, addr, &lds);
+        rbt_recon_ctb<RC_ROLE_LUMA>(frames, slices, fi, addr, &lds.t, &lds.role[0]);
+        rbt_recon_ctb<RC_ROLE_CHROMA>(frames, slices, fi, addr, &lds.t, &lds.role[1]);
       }
     }
 }
