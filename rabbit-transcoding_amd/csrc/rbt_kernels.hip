@@ -129,7 +129,7 @@ __device__ __forceinline__ void recon_ctb_roles(RbtFrame* frames, const RbtSlice
   if (threadIdx.x < 64) rbt_recon_ctb<RC_ROLE_LUMA>(frames, slices, fi, addr, &L->t, &L->role[0]);
   else rbt_recon_ctb<RC_ROLE_CHROMA>(frames, slices, fi, addr, &L->t, &L->role[1]);
 }
-__global__ void __launch_bounds__(128) k_recon_diag(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int d, int y_first) {
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) k_recon_diag(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int d, int y_first) {
   __shared__ RbtReconCtbLds lds;
   int fi = frame_list[blockIdx.y];
   const RbtStreamCfg* g = &frames[fi].cfg;
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(128) k_recon_diag(RbtFrame* frames, const RbtS
   recon_ctb_roles(frames, slices, fi, addr, RBT_LDS_CAST(RbtReconCtbLds, &lds));
 }
 // the same over pictures of several batches
-__global__ void __launch_bounds__(128) k_recon_diag_refs(const RbtFrameRef* refs, int d, int y_first) {
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) k_recon_diag_refs(const RbtFrameRef* refs, int d, int y_first) {
   __shared__ RbtReconCtbLds lds;
   const RbtFrameRef r = refs[blockIdx.y];
   const RbtStreamCfg* g = &r.frames[r.frame].cfg;
