@@ -144,7 +144,7 @@ def main():
 
     ctx.set_depth(D)
     # set-up, untimed: one job per slot, so that every slot's device arenas exist (librbt recycles them) even when W < D
-    primed = D if args.warmup < D else 0
+    primed = D if (args.warmup < D and D > 1) else 0
     if primed: run(primed, D, None)
     run(args.warmup, D, None)
     sync()
