@@ -1,0 +1,68 @@
+"""The C ABI driven from C++ (the reference's language): examples/rbt_pipeline.cpp walks GOFs with rbt_submit_gof ahead of
+rbt_wait_gof, the way INTEGRATION.md patches the application's GOF loop. CPU: it must fail loudly without a GPU. GPU: its outputs
+must equal the oracle's."""
+import os
+import struct
+import subprocess
+import numpy as np
+import pytest
+import oracle_lib as O
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "rabbit-transcoding_amd", "rbt_pipeline")
+
+
+def _exe():
+    if not os.path.exists(EXE):
+        pytest.skip("rbt_pipeline not built (make -C rabbit-transcoding_amd)")
+    return EXE
+
+
+def _write(path, gofs):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", len(gofs)))
+        for g in gofs:
+            for s in g:
+                f.write(struct.pack("<I", len(s))); f.write(s)
+
+
+def _read(path):
+    b = open(path, "rb").read(); n, = struct.unpack_from("<I", b, 0); o = 4; gofs = []
+    for _ in range(n):
+        g = []
+        for _ in range(3):
+            sz, = struct.unpack_from("<I", b, o); o += 4; g.append(b[o:o + sz]); o += sz
+        gofs.append(g)
+    return gofs
+
+
+def _gofs(n):
+    out = []
+    for k in range(n):
+        w, h = [(64, 64), (128, 64), (96, 96)][k % 3]
+        geo, attr, occ = synth.make_gof(w, h, 1 + k % 2, 700 + k)
+        out.append([O.encode(occ, w // 2, h // 2, 8, 8, gop=1, lossless=1, i_qp_offset=0, log2_ctb=6, rows_per_slice=0)[0],
+                    O.encode(geo, w, h, 10, 16, gop=2, log2_ctb=6, rows_per_slice=0)[0], O.encode(attr, w, h, 10, 22, gop=2, log2_ctb=6, rows_per_slice=0)[0]])
+    return out
+
+
+def test_cpp_host_fails_loudly_without_a_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    _write(tmp_path / "in.gofs", _gofs(1))
+    r = subprocess.run([_exe(), str(tmp_path / "in.gofs"), str(tmp_path / "out.gofs")], capture_output=True, text=True)
+    assert r.returncode == 1 and "no usable HIP device" in r.stderr and not (tmp_path / "out.gofs").exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth", [1, 3, 16])
+def test_cpp_host_pipeline_equals_oracle(tmp_path, depth):
+    gofs = _gofs(7)
+    _write(tmp_path / "in.gofs", gofs)
+    subprocess.check_call([_exe(), str(tmp_path / "in.gofs"), str(tmp_path / "out.gofs"), str(depth)])
+    got = _read(tmp_path / "out.gofs")
+    assert len(got) == len(gofs)
+    for g, o in zip(gofs, got):
+        assert o[0] == O.transcode_substream(g[0], 0, 8) and o[1] == O.transcode_substream(g[1], 1, 24) and o[2] == O.transcode_substream(g[2], 19, 32)
