@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(64) k_enc_analyse(RbtFrame* frames, const RbtS
 }
 // (TL2: log2 of the largest CTB of the launch; fixes the size of the reconstruction tile in LDS)
 template <int TL2>
-__global__ void __launch_bounds__(64) k_enc_intra_rows(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) k_enc_intra_rows(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
   __shared__ RbtEncTileLdsT<TL2> lds;
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   int row = blockIdx.x;
