@@ -74,15 +74,18 @@ int rbt_transcode_substream(rbt_ctx* ctx, const uint8_t* annexb_in, size_t n_in,
 int rbt_transcode_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out);
 
 /* rbt_transcode_gof in two halves, for the caller that walks a sequence GOF by GOF (PccAppTranscoder.cpp:307-341 calls
- * transcode -> transcodeData, PCCTranscoder.cpp:66-70 / :145-168, once per GOF): submit builds the batch and enqueues every kernel of the GOF, wait collects the streams.
+ * transcode -> transcodeData, PCCTranscoder.cpp:66-70 / :145-168, once per GOF): submit builds the batch and enqueues every
+ * kernel of the GOF, wait collects the streams.
  * Several transcodes may be in flight; they use disjoint HIP streams, so the entropy decoding of GOF i+1 (a few hundred lone
  * waves) runs underneath the entropy decoding, reconstruction and re-encode of GOF i. The input buffers may be released as soon
  * as submit returns. Jobs may be waited for in any order; every submitted job must be waited for (rbt_destroy drains what is
- * left). Results are identical to rbt_transcode_gof's.
+ * left). Results are identical to rbt_transcode_gof's. Calls on one process are serialised by the library (a wait blocks a
+ * concurrent submit from another thread).
  * rbt_set_depth announces how many jobs the caller keeps in flight (1..RBT_MAX_JOBS, default 4; process-wide; refused with
  * RBT_ERR_BUSY while jobs are in flight): the library has 16 HIP streams (more hardware queues slow every queue down on
- * MI355X), so up to 4 jobs get four streams each, 5 get three, up to 8 get two. rbt_submit_gof returns RBT_ERR_BUSY when that
- * many jobs are already in flight. */
+ * MI355X), so up to 4 jobs get four streams each, 5 get three, up to 8 two, up to 16 one (pipelines that share a stream run
+ * their entropy decoding and their reconstruction in merged launches). rbt_submit_gof returns RBT_ERR_BUSY when that many
+ * jobs are already in flight. */
 #define RBT_MAX_JOBS 16
 typedef struct rbt_job rbt_job;
 int rbt_set_depth(rbt_ctx* ctx, int max_in_flight);
