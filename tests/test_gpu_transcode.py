@@ -180,3 +180,21 @@ def test_two_jobs_in_flight_equal_blocking_calls(ctx):
             assert ctx.wait_gof(jb) == (want_a if i % 2 == 0 else want_b)
     ctx.set_depth(4)
 
+
+def test_destroy_with_jobs_in_flight_drains_them():
+    """rbt_destroy on a context that still owns submitted jobs waits for their streams and frees them; the library stays usable"""
+    R = rbt_lib.module()
+    a = list(_r5_streams(128, 128, 2, 909)[:3])
+    P = R.StreamParams
+    ps = [P(0, 8, 4, 5, 1, 1, 0), P(1, 24, 4, 5, 1, 1, 0), P(19, 32, 4, 5, 1, 1, 0)]
+    c1 = R.Context(device=0)
+    want = c1.transcode_gof(a, ps)
+    c1.set_depth(3)
+    for _ in range(3): c1.submit_gof(a, ps)
+    c1.close()                                   # three jobs never waited for
+    c2 = R.Context(device=0)
+    c2.set_depth(16)
+    jobs = [c2.submit_gof(a, ps) for _ in range(16)]     # every slot is free again
+    assert all(c2.wait_gof(j) == want for j in jobs)
+    c2.close()
+

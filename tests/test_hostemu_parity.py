@@ -145,3 +145,23 @@ def test_wide_pictures_use_the_larger_parser_variants(ctx, w):
         bs, rec = O.encode(fr, w, h, 10, qp=34, gop=2, stress_seed=seed, log2_ctb=log2_ctb)
         dec, dw, dh, dbd, chk, fail = ctx.decode(bs)
         assert (dw, dh, fail) == (w, h, 0) and np.array_equal(dec, rec)
+
+
+def test_destroy_with_jobs_in_flight_drains_them(ctx):
+    """rbt_destroy on a context that still owns submitted jobs waits for their streams and frees them; the slots are free again"""
+    R = rbt_lib.module()
+    geo, attr, occ = synth.make_gof(64, 64, 1, 909)
+    a = [O.encode(occ, 32, 32, 8, 8, gop=1, lossless=1, i_qp_offset=0, log2_ctb=6, rows_per_slice=0)[0],
+         O.encode(geo, 64, 64, 10, 16, gop=2, log2_ctb=6, rows_per_slice=0)[0], O.encode(attr, 64, 64, 10, 22, gop=2, log2_ctb=6, rows_per_slice=0)[0]]
+    P = R.StreamParams
+    ps = [P(0, 8, 4, 5, 1, 1, 0), P(1, 24, 4, 5, 1, 1, 0), P(19, 32, 4, 5, 1, 1, 0)]
+    want = ctx.transcode_gof(a, ps)
+    c1 = R.Context(lib_path=rbt_lib.HOSTEMU_LIB)
+    c1.set_depth(3)
+    for _ in range(3): c1.submit_gof(a, ps)
+    c1.close()                                   # three jobs never waited for
+    ctx.set_depth(16)
+    jobs = [ctx.submit_gof(a, ps) for _ in range(16)]    # every slot is free again
+    assert all(ctx.wait_gof(j) == want for j in jobs)
+    ctx.set_depth(4)
+
