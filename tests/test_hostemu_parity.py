@@ -165,3 +165,24 @@ def test_destroy_with_jobs_in_flight_drains_them(ctx):
     assert all(ctx.wait_gof(j) == want for j in jobs)
     ctx.set_depth(4)
 
+
+def test_job_api_argument_checks(ctx):
+    """bad arguments are refused with RBT_ERR_PARAM before anything is enqueued; a job belongs to the context that submitted it"""
+    import ctypes as C
+    R = rbt_lib.module(); L = ctx.L
+    job = C.c_void_p()
+    assert L.rbt_submit_gof(ctx.h, 0, None, None, None, C.byref(job)) == -4
+    assert L.rbt_submit_gof(None, 1, None, None, None, C.byref(job)) == -4
+    assert L.rbt_set_depth(ctx.h, 0) == -4 and L.rbt_set_depth(ctx.h, 17) == -4
+    outs = (C.c_void_p * 1)(); ns = (C.c_size_t * 1)()
+    assert L.rbt_wait_gof(ctx.h, None, outs, ns) == -4
+    geo, attr, occ = synth.make_gof(64, 64, 1, 5)
+    s1 = O.encode(geo, 64, 64, 10, 16, gop=2, log2_ctb=6, rows_per_slice=0)[0]
+    other = R.Context(lib_path=rbt_lib.HOSTEMU_LIB)
+    j = ctx.submit_gof([s1], [R.StreamParams(1, 24, 4, 5, 1, 1, 0)])
+    with pytest.raises(R.RbtError) as e:
+        other.wait_gof(j)                        # not its job
+    assert e.value.code == -4
+    assert ctx.wait_gof(j) == [O.transcode_substream(s1, 1, 24)]
+    other.close()
+
