@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "librbt.so")
+LIB_PATH = os.environ.get("RBT_LIB_PATH") or os.path.join(_DIR, "librbt.so")   # RBT_LIB_PATH: another build of the same library (experiments)
 
 RBT_VIDEO_OCCUPANCY, RBT_VIDEO_GEOMETRY, RBT_VIDEO_ATTRIBUTE = 0, 1, 19
 

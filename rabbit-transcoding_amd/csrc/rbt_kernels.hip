@@ -6,7 +6,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include "rbt_kernels.h"
-#include "rbt_parse.h"
 #include "rbt_recon.h"
 #include "rbt_filter.h"
 #include "rbt_encode.h"
@@ -20,6 +19,7 @@ static bool g_map_init = false;
 static inline int lane_of(int i) { return ((i % RBT_N_LANES) + RBT_N_LANES) % RBT_N_LANES; }
 static inline hipStream_t stream_of(int lane) { return g_streams[g_map[lane_of(lane)]]; }
 #define g_stream (g_streams[g_map[g_cur]])
+hipStream_t current_stream() { return g_stream; }   // for rbt_kernels_parse.hip
 static char g_name[256] = "";
 static char g_err[256] = "";
 static hipEvent_t g_ev[RBT_N_LANES][16][2];
@@ -109,20 +109,7 @@ void timer_end(int id) { (void)hipEventRecord(g_ev[g_cur][id][1], g_stream); }
 double timer_ms(int id) { float ms = 0; if (hipEventElapsedTime(&ms, g_ev[g_cur][id][0], g_ev[g_cur][id][1]) != hipSuccess) return 0; return ms; }
 
 // ---------------------------------------------------------------------------------------------- decode kernels
-// one wave per slice segment: wave-uniform CABAC parse (rbt_parse.h)
-// (CAP4: capacity of the parser's line buffers in 4-sample units; the variant fixes the LDS footprint of the workgroup)
-template <int CAP4>
-__global__ void __launch_bounds__(64) k_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, RbtParseSave* save, int row_limit) {
-  __shared__ alignas(16) uint32_t lds[(RBT_PARSE_LDS_BYTES(CAP4) + 3) / 4];
-  rbt_parse_slice(frames, slices, slice_list[blockIdx.x], rbsp, RBT_LDS_CAST(RbtParseLds, lds), CAP4, save, row_limit);
-}
-// the same over slices of several batches (each task names its batch's tables)
-template <int CAP4>
-__global__ void __launch_bounds__(64) k_parse_tasks(const RbtParseTask* tasks) {
-  __shared__ alignas(16) uint32_t lds[(RBT_PARSE_LDS_BYTES(CAP4) + 3) / 4];
-  const RbtParseTask t = tasks[blockIdx.x];
-  rbt_parse_slice(t.frames, t.slices, t.slice, t.rbsp, RBT_LDS_CAST(RbtParseLds, lds), CAP4, nullptr, 0);
-}
+// (the slice parser's kernels live in rbt_kernels_parse.hip: that file is compiled for speed, this one for size)
 // one workgroup (two waves: luma chain, Cb/Cr chain - rbt_recon.h RbtReconRole) per CTB on anti-diagonal d (x + 2y == d):
 // left, above-left, above and above-right CTBs are complete
 __device__ __forceinline__ void recon_ctb_roles(RbtFrame* frames, const RbtSlice* slices, int fi, int addr, RBT_LDS_AS RbtReconCtbLds* L) {
@@ -164,19 +151,6 @@ __global__ void __launch_bounds__(256) k_sao(RbtFrame* frames, const RbtSlice* s
   rbt_sao_sample(f, slices, c, i % pw, i / pw);
 }
 
-void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices, int max_w4, void* save, int row_limit) {
-  if (n_slices <= 0) return;
-  if (max_w4 <= RBT_PARSE_CAP4_S) hipLaunchKernelGGL(k_parse<RBT_PARSE_CAP4_S>, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, rbsp, slice_list, (RbtParseSave*)save, row_limit);
-  else if (max_w4 <= RBT_PARSE_CAP4_M) hipLaunchKernelGGL(k_parse<RBT_PARSE_CAP4_M>, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, rbsp, slice_list, (RbtParseSave*)save, row_limit);
-  else hipLaunchKernelGGL(k_parse<RBT_PARSE_CAP4_L>, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, rbsp, slice_list, (RbtParseSave*)save, row_limit);
-}
-void launch_parse_tasks(const RbtParseTask* tasks, int n_tasks, int max_w4) {
-  if (n_tasks <= 0) return;
-  if (max_w4 <= RBT_PARSE_CAP4_S) hipLaunchKernelGGL(k_parse_tasks<RBT_PARSE_CAP4_S>, dim3(n_tasks), dim3(64), 0, g_stream, tasks);
-  else if (max_w4 <= RBT_PARSE_CAP4_M) hipLaunchKernelGGL(k_parse_tasks<RBT_PARSE_CAP4_M>, dim3(n_tasks), dim3(64), 0, g_stream, tasks);
-  else hipLaunchKernelGGL(k_parse_tasks<RBT_PARSE_CAP4_L>, dim3(n_tasks), dim3(64), 0, g_stream, tasks);
-}
-size_t parse_save_bytes() { return sizeof(RbtParseSave); }
 // CTB rows [y_begin, y_end): the rows above y_begin are complete, the anti-diagonals that touch the range run in order
 void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int y_begin, int y_end) {
   if (n_frames <= 0) return;
