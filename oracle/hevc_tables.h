@@ -3,7 +3,7 @@
  * Normative ITU-T H.265 constants used by the CPU restatement of the transcode hot path.
  * The reference delegates all HEVC arithmetic to libavcodec/libx265 (PCCTranscoder.cpp:428-448,548-592);
  * the tables that ARE in the reference tree (dependencies/PccLibHevcParser) are cross-checked against this
- * file by tests/test_tables.py:
+ * file by tests/test_oracle_tables.py (golden: tests/golden/hevc_rom_tables.json):
  *   DCT/DST matrices      source/PccHevcTComRom.cpp:471-616
  *   quant/dequant scales  source/PccHevcTComRom.cpp:457-465
  *   chroma QP map         source/PccHevcTComRom.cpp:635-642

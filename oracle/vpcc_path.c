@@ -5,7 +5,9 @@
  *   PCCVideoBitstream::byteStreamToSampleStream  :85-112, getEndOfNaluPosition :174-184
  *   PCCTranscoder::resize_frame2                 source/lib/PccLibTranscoder/source/PCCTranscoder.cpp:594-646
  *   PCCTranscoder::transcodeVideo                :374-546 (decode loop :428-448, pool :466, encoder options :825-904)
- * The first three are pinned against the compiled reference (oracle/_ref, tests/golden/stream_conv_*.bin).
+ * PARITY UNPINNED for these four: PccLibBitstreamCommon / PccLibTranscoder need a cmake-generated PCCConfig.h (and libav*), so
+ * they cannot be compiled here without stand-ins, and the reference holds no fixtures for them. The restatements follow the
+ * source text line by line (including the newFrame quirk at :146); tests/test_oracle_codec.py checks round trips only.
  */
 #include "vpcc_path.h"
 #include "hevc_dec.h"
@@ -236,4 +238,17 @@ int oracle_scan_raster(int scan_idx, int log2, int i) {
   int xs = sc[scan_idx][log2 - 2][sb] & 15, ys = sc[scan_idx][log2 - 2][sb] >> 4;
   int x = (xs << 2) + (sc[scan_idx][2][p] & 15), y = (ys << 2) + (sc[scan_idx][2][p] >> 4);
   return (y << log2) + x;
+}
+/* tables restated from H.265 itself (absent from the reference): exposed so that tests/test_tables_product.py can check
+ * that the product's copy (csrc/rbt_tables.h) is the same restatement */
+int oracle_table(const char* name, int i, int j) {
+  if (!strcmp(name, "range_lps")) return k_range_lps[i][j];
+  if (!strcmp(name, "next_lps")) return k_next_lps[i];
+  if (!strcmp(name, "intra_angle")) return k_intra_angle[i];
+  if (!strcmp(name, "intra_inv_angle")) return k_intra_inv_angle[i];
+  if (!strcmp(name, "luma_filter")) return k_luma_filter[i][j];
+  if (!strcmp(name, "chroma_filter")) return k_chroma_filter[i][j];
+  if (!strcmp(name, "beta")) return k_beta_table[i];
+  if (!strcmp(name, "tc")) return k_tc_table[i];
+  return -99999;
 }

@@ -120,7 +120,7 @@ class Context:
         return res
 
     def set_depth(self, n):
-        """rbt_set_depth: how many GOFs the caller will keep in flight (1..8, default 4)"""
+        """rbt_set_depth: how many GOFs the caller will keep in flight (1..16 = RBT_MAX_JOBS, default 4)"""
         self._chk(self.L.rbt_set_depth(self.h, n))
 
     def submit_gof(self, streams, params):

@@ -87,3 +87,27 @@ void launch_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_l
 }
 #include "rbt_kernels_hostemu_enc.inc"
 }  // namespace rbtk
+
+// ---- accessors of the PRODUCT's normative tables (csrc/rbt_tables.h) for tests/test_tables_product.py ----
+extern "C" int rbt_hostemu_table(const char* name, int i, int j, int k) {
+  if (!strcmp(name, "dct32")) return k_dct32[i][j];
+  if (!strcmp(name, "dst4")) return k_dst4[i][j];
+  if (!strcmp(name, "quant_scale")) return k_quant_scale[i];
+  if (!strcmp(name, "dequant_scale")) return k_dequant_scale[i];
+  if (!strcmp(name, "chroma_qp")) return rbt_chroma_qp(i);
+  if (!strcmp(name, "range_lps")) return k_range_lps[i][j];
+  if (!strcmp(name, "next_lps")) return k_next_lps[i];
+  if (!strcmp(name, "ctx_count")) return RBT_CTX_COUNT;
+  if (!strcmp(name, "ctx_init")) return k_ctx_init[i][j];
+  if (!strcmp(name, "sig_ctx_4x4")) return k_sig_ctx_4x4[i];
+  if (!strcmp(name, "intra_angle")) return k_intra_angle[i];
+  if (!strcmp(name, "intra_inv_angle")) return k_intra_inv_angle[i];
+  if (!strcmp(name, "luma_filter")) return k_luma_filter[i][j];
+  if (!strcmp(name, "chroma_filter")) return k_chroma_filter[i][j];
+  if (!strcmp(name, "beta")) return k_beta_table[i];
+  if (!strcmp(name, "tc")) return k_tc_table[i];
+  if (!strcmp(name, "scan")) return k_scan[i][j][k];     // [scan_idx][log2 block size in 4x4 units... see rbt_tables.h][pos] = x | y << 4
+  if (!strcmp(name, "group_idx")) return k_group_idx[i];
+  if (!strcmp(name, "min_in_group")) return k_min_in_group[i];
+  return -99999;
+}
