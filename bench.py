@@ -8,10 +8,12 @@ here, so the maps are synthetic (tests/synth.py) and the R5 input is produced by
 HM-like structure (CTB 64, one slice per picture). One "step" = one GOF through rbt_submit_gof + rbt_wait_gof (together:
 rbt_transcode_gof); --in-flight GOFs (default 16) are submitted ahead of the one being collected, as a transcoder walking a sequence does.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--pc-frames F]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--pc-frames F]          (N > 1 without a launcher: starts the N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-N > 1: weak scaling — every rank transcodes its own GOF, then the re-encoded NAL units are gathered on rank 0 with RCCL.
+N > 1: weak scaling — every rank walks its own sequence of K GOFs (one process per GPU), the re-encoded NAL units of every GOF are
+gathered on rank 0 with RCCL inside the timed region. Extra legs: sequence_walk (configs[3]: 300 frames GOF-sharded, strong scaling,
+stitched output checked against the unsharded walk) and rate_fanout (configs[4]: R1..R5, one target rate per rank).
 """
 import argparse
 import json
@@ -51,6 +53,25 @@ def make_gof_maps(w, h, n_pc, seed):
     return np.stack(geo), np.stack(attr), np.stack(occ)
 
 
+def launch_ranks(n):
+    """python bench.py --gpus N without a launcher: start the N ranks as child processes (one per GPU) and pass rank 0's line through.
+    This parent never touches the GPU (no HIP call, no torch.cuda, librbt not loaded), so nothing that initialised a GPU is ever
+    re-executed; the children are ordinary new processes."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p_ in procs:
+        rc = max(rc, abs(p_.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,8 +90,14 @@ def main():
     ap.add_argument("--save-input", default=None, help="write the generated R5 input streams to this .npz file and exit")
     ap.add_argument("--load-input", default=None, help="read the R5 input streams from a file written by --save-input (keeps the input "
                     "encoder's kernels out of a profile of the transcode step); the file must come from the same size / seed")
+    ap.add_argument("--walk-frames", type=int, default=300, help="also walk a sequence of this many point-cloud frames GOF-sharded over the ranks "
+                    "(BASELINE.json configs[3]: 300 = 9 x 32 + 12; extra field sequence_walk; 0 = skip)")
+    ap.add_argument("--fanout-gofs", type=int, default=2, help="also transcode this many GOFs to every rate point R1..R5, one target rate per rank "
+                    "(BASELINE.json configs[4]; extra field rate_fanout; 0 = skip)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,7 +117,7 @@ def main():
     ctx = R.Context(device=dev, rank=rank, world=world)   # raises without a GPU: no CPU fallback
 
     w, h, n_pc = args.width, args.height, args.pc_frames
-    geo, attr, occ = make_gof_maps(w, h, n_pc, 1051 + 1000 * rank)
+    geo, attr, occ = make_gof_maps(w, h, n_pc, 1051)     # every rank walks the same synthetic sequence (weak scaling: K GOFs per rank)
     # R5 input in HM-like structure, produced by the GPU encoder (outside the timed region)
     if args.load_input:
         z = np.load(args.load_input)
@@ -206,12 +233,59 @@ def main():
              "note": "largest slice's bits / duration of the entropy-decoding launch that contains it (about 1.17 bins per bit)"}
     path_achieved = st["algorithmic_bytes"] / (elapsed / steps) / 1e9   # whole path: SURVEY.md 8(d) bytes of one GOF over the time one GOF takes
 
+    # configs[3]: a sequence of --walk-frames point-cloud frames (300 = 9 GOFs of 32 + one of 12), GOF g on rank g mod world, D GOFs in flight
+    # per GPU, re-encoded NAL units gathered on rank 0 (strong scaling: the sequence is fixed). Rank 0 then walks the whole sequence alone
+    # and checks that the stitched output is identical.
+    gs = rbt_lib.module_file("gof_shard")
+    walk = None
+    if args.walk_frames > 0 and n_pc > 1:
+        seq = gs.make_sequence(streams, args.walk_frames, n_pc)
+        gs.transcode_sequence(ctx, seq, params, rank=rank, world=world, depth=D, device=tdev)          # untimed pass: arenas of this shape exist
+        sync()
+        w0 = time.perf_counter()
+        stitched = gs.transcode_sequence(ctx, seq, params, rank=rank, world=world, depth=D, device=tdev)
+        sync()
+        wt = time.perf_counter() - w0
+        if world > 1:
+            import torch
+            t = torch.tensor([wt], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wt = float(t.item())
+        if rank == 0:
+            c1 = R.Context(device=dev, rank=0, world=1) if world > 1 else ctx
+            alone = gs.transcode_sequence(c1, seq, params, depth=D)
+            if c1 is not ctx: c1.close()
+            walk = {"frames": args.walk_frames, "gofs": [len(gs.split_pairs(g[0])) for g in seq], "ranks": world, "value": round(args.walk_frames / wt, 3), "unit": "point-cloud frames/s",
+                    "seconds": round(wt, 4), "scaling": "strong", "out_bytes": sum(len(s_) for g in stitched for s_ in g), "stitched_equals_unsharded": stitched == alone}
+    # configs[4]: every rate point R1..R5 from the R5 input, target rate i on rank i mod world (decode replicated; a rank that holds several
+    # rates hands each GOF over once and the library decodes it once)
+    fanout = None
+    if args.fanout_gofs > 0:
+        fseq = [streams] * args.fanout_gofs
+        gs.transcode_fanout(ctx, R, fseq[:1], rank=rank, world=world, depth=D, device=tdev)
+        sync()
+        f0 = time.perf_counter()
+        fan = gs.transcode_fanout(ctx, R, fseq, rank=rank, world=world, depth=D, device=tdev)
+        sync()
+        ft = time.perf_counter() - f0
+        if world > 1:
+            import torch
+            t = torch.tensor([ft], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ft = float(t.item())
+        if rank == 0:
+            fanout = {"gofs": args.fanout_gofs, "rates": {f"R{r}": {"geoQP": gs.RATE_POINTS[r][0], "attrQP": gs.RATE_POINTS[r][1], "occPrecision": gs.RATE_POINTS[r][2],
+                                                                    "out_bytes_per_gof": sum(len(s_) for s_ in fan[r][0])} for r in sorted(fan)},
+                      "active_ranks": min(world, 5), "value": round(5 * args.fanout_gofs * n_pc / ft, 3), "unit": "output point-cloud frames/s (5 rate points)", "seconds": round(ft, 4),
+                      "R3_equals_single_rate_call": fan[3][0] == outs}
+    ctx.set_depth(D)
+
     # informative extra (not the headline): G GOFs handed over in one call. One GOF's critical path is a few hundred serial
     # waves, so the GPU has room for several at once; a sequence of GOFs (configs[3]) can use that inside each GPU.
     multi = None
     if world == 1 and args.multi_gof > 1:
         G = args.multi_gof
-        ms, mp = streams * G, params * G
+        ms, mp = [bytes(bytearray(s_)) for _ in range(G) for s_ in streams], params * G     # distinct buffers: identical ones would be decoded once
         ctx.transcode_gof(ms, mp)
         m0 = time.perf_counter()
         for _ in range(2): mo = ctx.transcode_gof(ms, mp)
@@ -259,14 +333,14 @@ def main():
                ctx.encode(geo[:2 * k], w, h, 10, 16, gop=2, log2_ctb=6, rows_per_slice=0, md5_sei=0),
                ctx.encode(attr[:2 * k], w, h, 10, 22, gop=2, log2_ctb=6, rows_per_slice=0, md5_sei=0)]
         c0 = time.perf_counter()
-        O.transcode_substream(sub[0], 0, 8, md5_sei=0)
-        O.transcode_substream(sub[1], 1, 24, md5_sei=0)
-        O.transcode_substream(sub[2], 19, 32, md5_sei=0)
+        cpu_out = [O.transcode_substream(sub[0], 0, 8, md5_sei=0), O.transcode_substream(sub[1], 1, 24, md5_sei=0), O.transcode_substream(sub[2], 19, 32, md5_sei=0)]
         ct = time.perf_counter() - c0
+        cpu_parity = cpu_out == ctx.transcode_gof(sub, params)     # full-size parity for free: the GPU path on the same sample, byte for byte
         import shutil
         x265 = "ffmpeg present" if shutil.which("ffmpeg") else "libx265 / ffmpeg unavailable on this box"
         cpu = {"value": round(k / ct, 4), "unit": "point-cloud frames/s", "cores": 1, "kind": "port",
-               "sample": f"first {k} point-cloud frames of the same GOF, oracle/liboracle.so (scalar C restatement; {x265}), {ct:.1f} s"}
+               "sample": f"first {k} point-cloud frames of the same GOF, oracle/liboracle.so (scalar C restatement; {x265}), {ct:.1f} s",
+               "output_equals_gpu_path": bool(cpu_parity)}
         # the same restatement on the host cores of this GPU's share: the point-cloud frames of a GOF are independent (I/P pairs,
         # all-intra occupancy), so every worker process takes every N-th frame of the whole GOF
         import subprocess, tempfile
@@ -296,7 +370,7 @@ def main():
                 "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                              "traffic": traffic, "kernel_ms": {k_: round(v, 3) for k_, v in groups.items()},
                              "path_achieved_GBs": round(path_achieved, 3), "path_frac": round(path_achieved / HBM_PEAK_GBS, 6)},
-                "cabac": cabac, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "multi_gof": multi, "in_flight_sweep": sweep, "quality": quality,
+                "cabac": cabac, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "sequence_walk": walk, "rate_fanout": fanout, "multi_gof": multi, "in_flight_sweep": sweep, "quality": quality,
                 "host_ms": {"parse": round(st["host_parse_ms"], 3), "pack": round(st["host_pack_ms"], 3), "submit_call": round(host_submit_ms, 3), "wait_call": round(host_wait_ms, 3), "job_gpu_span": round(st["gpu_ms"], 3), "job_span": round(st["total_ms"], 3)}}
         print(json.dumps(line))
     if world > 1:

@@ -58,7 +58,16 @@ typedef struct {             /* timings of the last call, milliseconds */
   uint64_t algorithmic_bytes; /* SURVEY.md 8(d) accounting of the call */
 } rbt_stats;
 
+/* One context per host thread and GPU. `device` is the HIP device the context's work runs on; streams, timers, job slots and the
+ * recycling pool of device memory are per device, so contexts on different devices may be used concurrently from different threads
+ * (contexts on the same device share its 16 HIP streams and job slots and are serialised by the library).
+ * world_rank / world_size describe the multi-GPU job the context is part of (one process per GPU): the library owns
+ * the GOF sharding rule (rbt_owns_gof), the NAL gather itself runs in the host program over RCCL. 0 <= world_rank < world_size. */
 int rbt_create(rbt_ctx** ctx, int device, int world_rank, int world_size);
+/* GOF g of a sequence is transcoded by rank g mod world_size; a host that walks the sequence GOF by GOF (PccAppTranscoder.cpp:307-341)
+ * on every rank skips what its context does not own. Returns 1 / 0. */
+int rbt_owns_gof(const rbt_ctx* ctx, int gof_index);
+int rbt_world(const rbt_ctx* ctx, int* world_rank, int* world_size);
 void rbt_destroy(rbt_ctx* ctx);
 const char* rbt_strerror(int code);
 void rbt_free(void* p);
@@ -68,7 +77,10 @@ const char* rbt_version(void);
 int rbt_transcode_substream(rbt_ctx* ctx, const uint8_t* annexb_in, size_t n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out);
 
 /* transcodeData (PCCTranscoder.cpp:145-168): the sub-bitstreams of one GOF in one call, each as its own pipeline on its own
- * HIP stream. More than three streams (the sub-bitstreams of several GOFs: one GOF leaves most of an MI355X idle) are grouped
+ * HIP stream. As in the reference (:150), an occupancy stream is only transcoded when occupancy_precision == 4; with any other
+ * precision it is returned unchanged (rbt_transcode_substream, like transcodeVideo, re-encodes whatever it is handed).
+ * Entries that name the same input buffer (same pointer and size) with different parameters are decoded once and re-encoded once
+ * per entry: the rate fan-out of BASELINE.json configs[4] (R1..R5 from one R5 input) on one GPU. More than three streams (the sub-bitstreams of several GOFs: one GOF leaves most of an MI355X idle) are grouped
  * by video type into three pipelines. Outputs come back in input order. */
 #define RBT_MAX_STREAMS 96
 int rbt_transcode_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out);
@@ -79,9 +91,9 @@ int rbt_transcode_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, cons
  * Several transcodes may be in flight; they use disjoint HIP streams, so the entropy decoding of GOF i+1 (a few hundred lone
  * waves) runs underneath the entropy decoding, reconstruction and re-encode of GOF i. The input buffers may be released as soon
  * as submit returns. Jobs may be waited for in any order; every submitted job must be waited for (rbt_destroy drains what is
- * left). Results are identical to rbt_transcode_gof's. Calls on one process are serialised by the library (a wait blocks a
- * concurrent submit from another thread).
- * rbt_set_depth announces how many jobs the caller keeps in flight (1..RBT_MAX_JOBS, default 4; process-wide; refused with
+ * left). Results are identical to rbt_transcode_gof's. Calls on one device are serialised by the library (a wait blocks a
+ * concurrent submit from another thread on the same GPU).
+ * rbt_set_depth announces how many jobs the caller keeps in flight (1..RBT_MAX_JOBS, default 4; per device; refused with
  * RBT_ERR_BUSY while jobs are in flight): the library has 16 HIP streams (more hardware queues slow every queue down on
  * MI355X), so up to 4 jobs get four streams each, 5 get three, up to 8 two, up to 16 one (pipelines that share a stream run
  * their entropy decoding and their reconstruction in merged launches). rbt_submit_gof returns RBT_ERR_BUSY when that many

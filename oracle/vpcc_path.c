@@ -213,6 +213,19 @@ int oracle_transcode_substream(const uint8_t* annexb, size_t n, const oracle_tra
   return 0;
 }
 
+/* PCCTranscoder::transcodeData (PCCTranscoder.cpp:145-168), fast path: the occupancy sub-bitstream is only transcoded when
+ * occupancyPrecision_ == 4 (:150-155); geometry (:158-160) and attribute (:163-165) always are. Streams are Annex-B here (the
+ * reference converts with sampleStreamToByteStream in front of every transcodeVideo call, :152,159,164). */
+int oracle_transcode_data(int n, const uint8_t* const* in, const size_t* n_in, const oracle_transcode_params* p, uint8_t** out, size_t* n_out) {
+  for (int i = 0; i < n; i++) { out[i] = NULL; n_out[i] = 0; }
+  for (int i = 0; i < n; i++) {
+    if (p[i].video_type == 0 && p[i].occupancy_precision != 4) {
+      out[i] = (uint8_t*)malloc(n_in[i] ? n_in[i] : 1); memcpy(out[i], in[i], n_in[i]); n_out[i] = n_in[i];
+    } else { int rc = oracle_transcode_substream(in[i], n_in[i], &p[i], &out[i], &n_out[i]); if (rc) return rc; }
+  }
+  return 0;
+}
+
 /* ---- table accessors for tests/test_oracle_tables.py (pinning against the reference ROM) ---- */
 int oracle_dct_coef(int N, int k, int n) { return hevc_dct_coef(N, k, n); }
 int oracle_dst_coef(int k, int n) { return k_dst4[k][n]; }

@@ -34,5 +34,7 @@ int oracle_encode(int w, int h, int bit_depth, int qp, int i_qp_offset, int gop,
                   int md5_sei, uint32_t stress_seed, const uint16_t* yuv, int n_frames, uint8_t** out, size_t* n_out, uint16_t* recon);
 /* PCCTranscoder::transcodeVideo (PCCTranscoder.cpp:374-546) on an Annex-B sub-bitstream */
 int oracle_transcode_substream(const uint8_t* annexb, size_t n, const oracle_transcode_params* p, uint8_t** out, size_t* n_out);
+/* PCCTranscoder::transcodeData (PCCTranscoder.cpp:145-168): occupancy only when occupancy_precision == 4, then geometry, attribute */
+int oracle_transcode_data(int n, const uint8_t* const* in, const size_t* n_in, const oracle_transcode_params* p, uint8_t** out, size_t* n_out);
 void oracle_free(void* p);
 #endif

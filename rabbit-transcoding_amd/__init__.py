@@ -43,6 +43,8 @@ def load(path=None):
     L = C.CDLL(path or LIB_PATH)
     L.rbt_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
     L.rbt_destroy.argtypes = [C.c_void_p]
+    L.rbt_owns_gof.argtypes = [C.c_void_p, C.c_int]
+    L.rbt_world.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.rbt_strerror.restype = C.c_char_p
     L.rbt_strerror.argtypes = [C.c_int]
     L.rbt_version.restype = C.c_char_p
@@ -70,6 +72,10 @@ class Context:
         rc = self.L.rbt_create(C.byref(self.h), device, rank, world)
         if rc != 0:
             raise RbtError(rc, self.L.rbt_strerror(rc).decode())
+
+    def owns_gof(self, g):
+        """rbt_owns_gof: GOF g of a sequence belongs to rank g mod world"""
+        return bool(self.L.rbt_owns_gof(self.h, g))
 
     def close(self):
         if self.h:

@@ -7,7 +7,8 @@
 #include "rbt_types.h"
 
 namespace rbtk {
-int dev_init(int device);                 // 0 = ok
+int dev_init(int device);                 // 0 = ok; creates the device's streams / events on first use and selects the device for this thread
+int dev_select(int device);               // makes an initialised device the calling thread's current one (every C-ABI entry point calls it)
 // Independent sub-bitstreams run on separate HIP streams so that the short pipelines (occupancy, geometry) overlap the
 // long entropy-decoding chain of the attribute stream. All calls below act on the currently selected stream.
 // The HIP runtime multiplexes streams onto 4 hardware queues by default; two streams sharing a queue serialise, and a copy

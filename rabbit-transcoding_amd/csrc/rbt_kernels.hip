@@ -1,5 +1,5 @@
-// HIP kernels + launchers for gfx950 (MI355X). See rbt_kernels.h. One stream per context; kernels of a call are
-// enqueued back-to-back, the host synchronises once per phase that needs results.
+// HIP kernels + launchers for gfx950 (MI355X). See rbt_kernels.h. Kernels of a call are enqueued back-to-back on the streams of
+// the calling context's device, the host synchronises once per phase that needs results.
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <vector>
@@ -11,102 +11,126 @@
 #include "rbt_encode.h"
 
 namespace rbtk {
-static hipStream_t g_streams[RBT_N_STREAMS] = {};
-static hipEvent_t g_dep_ev[64]; static int g_dep_next = 0;
-static int g_cur = 0;                    // current lane
-static int g_map[RBT_N_LANES];           // lane -> HIP stream
-static bool g_map_init = false;
+// Everything the host code touches on a GPU is per DEVICE: 16 HIP streams, the timer / dependency events, the lane -> stream
+// map and the recycling pool of device allocations. A host thread works on the device it selected last (dev_select, called
+// by every C-ABI entry point with its context's device), so contexts on different devices run concurrently from different
+// threads; contexts on the same device share that device's streams (rbt_api.cpp serialises them with the device's mutex).
+enum { RBT_MAX_DEVICES = 16, RBT_POOL_KEEP = 160 };
+struct PoolBlock { void* p; size_t n; };
+struct Dev {
+  int id = -1;
+  hipStream_t streams[RBT_N_STREAMS] = {};
+  hipEvent_t dep_ev[64]; int dep_next = 0;
+  int map[RBT_N_LANES];                 // lane -> HIP stream
+  hipEvent_t ev[RBT_N_LANES][16][2];
+  char name[256] = "";
+  std::vector<PoolBlock> pool_free, pool_live; std::mutex pool_mu;
+};
+static Dev* g_devs[RBT_MAX_DEVICES] = {};
+static std::mutex g_devs_mu;
+static thread_local Dev* t_dev = nullptr;      // device selected by this host thread
+static thread_local int t_cur = 0;             // ... and its current lane
+static thread_local char t_err[256] = "";
 static inline int lane_of(int i) { return ((i % RBT_N_LANES) + RBT_N_LANES) % RBT_N_LANES; }
-static inline hipStream_t stream_of(int lane) { return g_streams[g_map[lane_of(lane)]]; }
-#define g_stream (g_streams[g_map[g_cur]])
+static inline hipStream_t stream_of(int lane) { return t_dev->streams[t_dev->map[lane_of(lane)]]; }
+#define g_stream (t_dev->streams[t_dev->map[t_cur]])
 hipStream_t current_stream() { return g_stream; }   // for rbt_kernels_parse.hip
-static char g_name[256] = "";
-static char g_err[256] = "";
-static hipEvent_t g_ev[RBT_N_LANES][16][2];
-static bool g_ev_init = false;
 
-#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(g_err, sizeof g_err, "%s: %s", #x, hipGetErrorString(e_)); return -1; } } while (0)
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(t_err, sizeof t_err, "%s: %s", #x, hipGetErrorString(e_)); return -1; } } while (0)
 
 int dev_init(int device) {
   // one hardware queue per HIP stream (default: 4 queues shared by all streams); only honoured before the runtime initialises
   setenv("GPU_MAX_HW_QUEUES", "16", 0);
-  if (!g_map_init) { for (int i = 0; i < RBT_N_LANES; i++) g_map[i] = i % RBT_N_STREAMS; g_map_init = true; }
   int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { snprintf(g_err, sizeof g_err, "no HIP device"); return -1; }
-  if (device < 0 || device >= n) { snprintf(g_err, sizeof g_err, "device %d out of range (%d devices)", device, n); return -1; }
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { snprintf(t_err, sizeof t_err, "no HIP device"); return -1; }
+  if (device < 0 || device >= n || device >= RBT_MAX_DEVICES) { snprintf(t_err, sizeof t_err, "device %d out of range (%d devices)", device, n); return -1; }
+  std::lock_guard<std::mutex> lk(g_devs_mu);
   HIPCHK(hipSetDevice(device));
-  hipDeviceProp_t p; HIPCHK(hipGetDeviceProperties(&p, device));
-  snprintf(g_name, sizeof g_name, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
-  for (int k = 0; k < RBT_N_STREAMS; k++) if (!g_streams[k]) HIPCHK(hipStreamCreateWithFlags(&g_streams[k], hipStreamNonBlocking));
-  if (!g_ev_init) { for (int i = 0; i < 64; i++) HIPCHK(hipEventCreateWithFlags(&g_dep_ev[i], hipEventDisableTiming));
-    for (int k = 0; k < RBT_N_LANES; k++) for (int i = 0; i < 16; i++) { HIPCHK(hipEventCreate(&g_ev[k][i][0])); HIPCHK(hipEventCreate(&g_ev[k][i][1])); } g_ev_init = true; }
+  if (!g_devs[device]) {
+    Dev* d = new Dev(); d->id = device;
+    for (int i = 0; i < RBT_N_LANES; i++) d->map[i] = i % RBT_N_STREAMS;
+    hipDeviceProp_t p; HIPCHK(hipGetDeviceProperties(&p, device));
+    snprintf(d->name, sizeof d->name, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    for (int k = 0; k < RBT_N_STREAMS; k++) HIPCHK(hipStreamCreateWithFlags(&d->streams[k], hipStreamNonBlocking));
+    for (int i = 0; i < 64; i++) HIPCHK(hipEventCreateWithFlags(&d->dep_ev[i], hipEventDisableTiming));
+    for (int k = 0; k < RBT_N_LANES; k++) for (int i = 0; i < 16; i++) { HIPCHK(hipEventCreate(&d->ev[k][i][0])); HIPCHK(hipEventCreate(&d->ev[k][i][1])); }
+    g_devs[device] = d;
+  }
+  t_dev = g_devs[device]; t_cur = 0;
   return 0;
 }
-const char* dev_name() { return g_name; }
-void set_stream(int i) { g_cur = lane_of(i); }
-void map_lane(int lane, int stream) { g_map[lane_of(lane)] = ((stream % RBT_N_STREAMS) + RBT_N_STREAMS) % RBT_N_STREAMS; }
+int dev_select(int device) {
+  if (device < 0 || device >= RBT_MAX_DEVICES || !g_devs[device]) return -1;
+  if (t_dev != g_devs[device]) { HIPCHK(hipSetDevice(device)); t_dev = g_devs[device]; t_cur = 0; }
+  return 0;
+}
+const char* dev_name() { return t_dev ? t_dev->name : ""; }
+void set_stream(int i) { t_cur = lane_of(i); }
+void map_lane(int lane, int stream) { t_dev->map[lane_of(lane)] = ((stream % RBT_N_STREAMS) + RBT_N_STREAMS) % RBT_N_STREAMS; }
 int stream_mark(int signaller) {
-  int id = g_dep_next; g_dep_next = (g_dep_next + 1) % 64;
-  (void)hipEventRecord(g_dep_ev[id], stream_of(signaller));
+  int id = t_dev->dep_next; t_dev->dep_next = (t_dev->dep_next + 1) % 64;
+  (void)hipEventRecord(t_dev->dep_ev[id], stream_of(signaller));
   return id;
 }
-void stream_wait_mark(int waiter, int mark) { (void)hipStreamWaitEvent(stream_of(waiter), g_dep_ev[mark & 63], 0); }
+void stream_wait_mark(int waiter, int mark) { (void)hipStreamWaitEvent(stream_of(waiter), t_dev->dep_ev[mark & 63], 0); }
 void stream_wait(int waiter, int signaller) {
-  hipEvent_t e = g_dep_ev[g_dep_next]; g_dep_next = (g_dep_next + 1) % 64;
+  hipEvent_t e = t_dev->dep_ev[t_dev->dep_next]; t_dev->dep_next = (t_dev->dep_next + 1) % 64;
   (void)hipEventRecord(e, stream_of(signaller));
   (void)hipStreamWaitEvent(stream_of(waiter), e, 0);
 }
 // Device allocations are recycled: hipMalloc / hipFree of GOF-sized arenas cost milliseconds each (hipFree also drains the
 // device), and a transcoder calls with the same sizes over and over. Freed blocks go to a small best-fit pool; at most
 // RBT_POOL_KEEP blocks are kept, the rest is returned to the driver.
-enum { RBT_POOL_KEEP = 160 };
-struct PoolBlock { void* p; size_t n; };
-static std::vector<PoolBlock> g_pool_free, g_pool_live;
-static std::mutex g_pool_mu;
 void* dev_alloc(size_t n) {
   if (!n) n = 1;
-  std::lock_guard<std::mutex> lk(g_pool_mu);
+  Dev* D = t_dev; if (!D) return nullptr;
+  std::lock_guard<std::mutex> lk(D->pool_mu);
   int best = -1;
-  for (size_t i = 0; i < g_pool_free.size(); i++)
-    if (g_pool_free[i].n >= n && g_pool_free[i].n <= n + n / 4 + (1u << 20) && (best < 0 || g_pool_free[i].n < g_pool_free[(size_t)best].n)) best = (int)i;
+  for (size_t i = 0; i < D->pool_free.size(); i++)
+    if (D->pool_free[i].n >= n && D->pool_free[i].n <= n + n / 4 + (1u << 20) && (best < 0 || D->pool_free[i].n < D->pool_free[(size_t)best].n)) best = (int)i;
   PoolBlock b;
-  if (best >= 0) { b = g_pool_free[(size_t)best]; g_pool_free.erase(g_pool_free.begin() + best); }
+  if (best >= 0) { b = D->pool_free[(size_t)best]; D->pool_free.erase(D->pool_free.begin() + best); }
   else {
     b.p = nullptr; b.n = n;
     if (hipMalloc(&b.p, n) != hipSuccess) {
-      for (auto& f : g_pool_free) (void)hipFree(f.p);                 // give everything back and try once more
-      g_pool_free.clear();
+      for (auto& f : D->pool_free) (void)hipFree(f.p);                 // give everything back and try once more
+      D->pool_free.clear();
       if (hipMalloc(&b.p, n) != hipSuccess) return nullptr;
     }
   }
-  g_pool_live.push_back(b);
+  D->pool_live.push_back(b);
   return b.p;
 }
 void dev_free(void* p) {
   if (!p) return;
-  std::lock_guard<std::mutex> lk(g_pool_mu);
-  for (size_t i = 0; i < g_pool_live.size(); i++) if (g_pool_live[i].p == p) {
-    g_pool_free.push_back(g_pool_live[i]); g_pool_live.erase(g_pool_live.begin() + (long)i);
-    while (g_pool_free.size() > RBT_POOL_KEEP) {                      // drop the smallest block
-      size_t k = 0; for (size_t j = 1; j < g_pool_free.size(); j++) if (g_pool_free[j].n < g_pool_free[k].n) k = j;
-      (void)hipFree(g_pool_free[k].p); g_pool_free.erase(g_pool_free.begin() + (long)k);
+  // the block may belong to another device than the one this thread works on (a job destroyed from another context's call)
+  for (int k = -1; k < RBT_MAX_DEVICES; k++) {
+    Dev* D = k < 0 ? t_dev : g_devs[k]; if (!D || (k >= 0 && D == t_dev)) continue;
+    std::lock_guard<std::mutex> lk(D->pool_mu);
+    for (size_t i = 0; i < D->pool_live.size(); i++) if (D->pool_live[i].p == p) {
+      D->pool_free.push_back(D->pool_live[i]); D->pool_live.erase(D->pool_live.begin() + (long)i);
+      while (D->pool_free.size() > RBT_POOL_KEEP) {                      // drop the smallest block
+        size_t s = 0; for (size_t j = 1; j < D->pool_free.size(); j++) if (D->pool_free[j].n < D->pool_free[s].n) s = j;
+        (void)hipFree(D->pool_free[s].p); D->pool_free.erase(D->pool_free.begin() + (long)s);
+      }
+      return;
     }
-    return;
   }
   (void)hipFree(p);
 }
 void dev_release_pool() {
-  std::lock_guard<std::mutex> lk(g_pool_mu);
-  for (auto& f : g_pool_free) (void)hipFree(f.p);
-  g_pool_free.clear();
+  Dev* D = t_dev; if (!D) return;
+  std::lock_guard<std::mutex> lk(D->pool_mu);
+  for (auto& f : D->pool_free) (void)hipFree(f.p);
+  D->pool_free.clear();
 }
 int h2d(void* d, const void* h, size_t n) { HIPCHK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, g_stream)); return 0; }
 int d2h(void* h, const void* d, size_t n) { HIPCHK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, g_stream)); HIPCHK(hipStreamSynchronize(g_stream)); return 0; }
 int dev_memset(void* d, int v, size_t n) { HIPCHK(hipMemsetAsync(d, v, n, g_stream)); return 0; }
 int dev_sync() { HIPCHK(hipStreamSynchronize(g_stream)); HIPCHK(hipGetLastError()); return 0; }
-void timer_begin(int id) { (void)hipEventRecord(g_ev[g_cur][id][0], g_stream); }
-void timer_end(int id) { (void)hipEventRecord(g_ev[g_cur][id][1], g_stream); }
-double timer_ms(int id) { float ms = 0; if (hipEventElapsedTime(&ms, g_ev[g_cur][id][0], g_ev[g_cur][id][1]) != hipSuccess) return 0; return ms; }
+void timer_begin(int id) { (void)hipEventRecord(t_dev->ev[t_cur][id][0], g_stream); }
+void timer_end(int id) { (void)hipEventRecord(t_dev->ev[t_cur][id][1], g_stream); }
+double timer_ms(int id) { float ms = 0; if (hipEventElapsedTime(&ms, t_dev->ev[t_cur][id][0], t_dev->ev[t_cur][id][1]) != hipSuccess) return 0; return ms; }
 
 // ---------------------------------------------------------------------------------------------- decode kernels
 // (the slice parser's kernels live in rbt_kernels_parse.hip: that file is compiled for speed, this one for size)

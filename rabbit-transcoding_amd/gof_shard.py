@@ -1,17 +1,45 @@
-"""GOF sharding across the GPUs of a node and the gather of the re-encoded NAL units.
+"""Multi-GPU host side of the transcoder: GOF sharding, rate fan-out and the gather of the re-encoded NAL units.
 
-A V3C group of frames is self-contained (it starts with a VPS, PCCBitstreamReader.cpp:78-96, and every video
-sub-bitstream restarts with an IDR), so GOFs shard across ranks with no data-path collective; the only exchange is
-the gather of the re-encoded sub-bitstreams (<= ~2 MB per GOF at R3) onto rank 0, which writes the output file
-(PccAppTranscoder.cpp:345-348). One process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm,
-"gloo" in the CPU tests).
+A V3C group of frames is self-contained (it starts with a VPS, PCCBitstreamReader.cpp:78-96, and every video sub-bitstream
+restarts with an IDR), so GOFs shard across ranks with no data-path collective; the only exchange is the gather of the
+re-encoded sub-bitstreams (<= ~3 MB per GOF) onto rank 0, which writes the output file (PccAppTranscoder.cpp:345-348).
+One process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+  transcode_sequence  BASELINE.json configs[3]: a sequence of GOFs (300 frames = 9 x 32 + 12) sharded over the ranks; mirrors the
+                      per-GOF loop of PccAppTranscoder.cpp:307-341 with several GOFs in flight per GPU (rbt_submit_gof / rbt_wait_gof)
+  transcode_fanout    BASELINE.json configs[4]: every rate point R1..R5 from one R5 input, one target rate per GPU (decode replicated,
+                      no broadcast of decoded pictures); a rank that holds several rates decodes once and re-encodes once per rate
 """
-from typing import List, Sequence
+from typing import Dict, List, Sequence
+
+# cfg/rate/ctc-r{1..5}.cfg:5-11: geometryQP, attributeQP, occupancyPrecision
+RATE_POINTS = {1: (32, 42, 4), 2: (28, 37, 4), 3: (24, 32, 4), 4: (20, 27, 4), 5: (16, 22, 2)}
+VIDEO_OCCUPANCY, VIDEO_GEOMETRY, VIDEO_ATTRIBUTE = 0, 1, 19    # PCCVideoType (PCCBitstreamCommon.h:79-118)
+
+
+def gof_lengths(n_frames: int, gof: int = 32) -> List[int]:
+    """Point-cloud frames per GOF of a sequence (groupOfFramesSize, cfg/sequence/longdress_vox10.cfg:10): 300 -> 9 x 32 + 12."""
+    return [min(gof, n_frames - s) for s in range(0, n_frames, gof)]
 
 
 def gofs_of_rank(n_gofs: int, rank: int, world: int) -> List[int]:
-    """GOF g is processed by rank g mod world (round-robin keeps ranks balanced when n_gofs is not a multiple)."""
+    """GOF g is processed by rank g mod world (round-robin keeps ranks balanced when n_gofs is not a multiple). Same rule as
+    rbt_owns_gof (include/rbt.h)."""
     return [g for g in range(n_gofs) if g % world == rank]
+
+
+def rates_of_rank(rates: Sequence[int], rank: int, world: int) -> List[int]:
+    """Rate fan-out: target rate i of the list goes to rank i mod world (8 GPUs, 5 rates: ranks 0..4 one rate each, 5..7 idle)."""
+    return [r for i, r in enumerate(rates) if i % world == rank]
+
+
+def rate_params(R, rate: int, log2_ctb: int = 5, rows_per_slice: int = 1, md5_sei: int = 0):
+    """rbt_stream_params of the [occupancy, geometry, attribute] sub-bitstreams for CTC rate point `rate` (1..5).
+    R = the rabbit_transcoding_amd module (StreamParams)."""
+    gq, aq, prec = RATE_POINTS[rate]
+    P = R.StreamParams
+    return [P(VIDEO_OCCUPANCY, 8, prec, log2_ctb, rows_per_slice, md5_sei, 0), P(VIDEO_GEOMETRY, gq, prec, log2_ctb, rows_per_slice, md5_sei, 0),
+            P(VIDEO_ATTRIBUTE, aq, prec, log2_ctb, rows_per_slice, md5_sei, 0)]
 
 
 def gather_streams(local: Sequence[bytes], group=None, device="cpu") -> List[List[bytes]]:
@@ -28,9 +56,9 @@ def gather_streams(local: Sequence[bytes], group=None, device="cpu") -> List[Lis
     counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(counts, n_local, group=group)
     max_n = int(max(int(c.item()) for c in counts))
-    sizes_p = torch.zeros(max_n, dtype=torch.int64, device=device)
+    sizes_p = torch.zeros(max(1, max_n), dtype=torch.int64, device=device)
     sizes_p[: len(local)] = sizes
-    all_sizes = [torch.zeros(max_n, dtype=torch.int64, device=device) for _ in range(world)]
+    all_sizes = [torch.zeros(max(1, max_n), dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(all_sizes, sizes_p, group=group)
     totals = [int(s.sum().item()) for s in all_sizes]
     cap = max(1, max(totals))
@@ -65,3 +93,89 @@ def stitch(gathered: List[List[bytes]], n_gofs: int, streams_per_gof: int) -> Li
             for s in range(streams_per_gof):
                 res[g][s] = gathered[r][i * streams_per_gof + s]
     return res
+
+
+def _walk(ctx, jobs, depth):
+    """Runs (streams, params) jobs through rbt_submit_gof / rbt_wait_gof with `depth` of them in flight, in order."""
+    depth = max(1, min(depth, 16, len(jobs) or 1))
+    ctx.set_depth(depth)
+    q, outs = [], []
+    for streams, params in jobs:
+        if len(q) == depth:
+            outs.append(ctx.wait_gof(q.pop(0)))
+        q.append(ctx.submit_gof(streams, params))
+    while q:
+        outs.append(ctx.wait_gof(q.pop(0)))
+    return outs
+
+
+def transcode_sequence(ctx, gofs: Sequence[Sequence[bytes]], params, rank: int = 0, world: int = 1, depth: int = 16, group=None, device="cpu"):
+    """configs[3]. gofs[g] = [occupancy, geometry, attribute] Annex-B sub-bitstreams of GOF g; every rank holds the whole compressed
+    input (PccAppTranscoder loads the file first, PccAppTranscoder.cpp:289). Each rank transcodes the GOFs its context owns
+    (rbt_owns_gof) with up to `depth` in flight; the outputs are gathered on rank 0.
+    Returns on rank 0 the output in GOF order (result[g][s]), None elsewhere. world == 1 needs no process group."""
+    n = len(gofs)
+    mine = [g for g in range(n) if ctx.owns_gof(g)]
+    assert mine == gofs_of_rank(n, rank, world)
+    outs = _walk(ctx, [(list(gofs[g]), params) for g in mine], depth)
+    local = [s for o in outs for s in o]
+    if world == 1:
+        return stitch([local], n, len(params))
+    gathered = gather_streams(local, group=group, device=device)
+    return stitch(gathered, n, len(params)) if rank == 0 else None
+
+
+def transcode_fanout(ctx, R, gofs: Sequence[Sequence[bytes]], rates: Sequence[int] = (1, 2, 3, 4, 5), rank: int = 0, world: int = 1, depth: int = 16,
+                     group=None, device="cpu", **enc) -> Dict[int, List[List[bytes]]]:
+    """configs[4]. Every GOF of the sequence is transcoded to every rate point of `rates`; rate i belongs to rank i mod world
+    (rates_of_rank). A rank with several rates hands each GOF over once with all its rates (the library decodes identical inputs once).
+    Returns on rank 0 {rate: result[g][s]}, None elsewhere."""
+    mine = rates_of_rank(rates, rank, world)
+    jobs = []
+    for g in gofs:
+        streams, params = [], []
+        for r in mine:
+            streams += list(g)
+            params += rate_params(R, r, **enc)
+        if streams:
+            jobs.append((streams, params))
+    outs = _walk(ctx, jobs, depth) if jobs else []
+    local = [s for o in outs for s in o]             # per GOF: rate-major, then [occ, geo, attr]
+    gathered = [local] if world == 1 else gather_streams(local, group=group, device=device)
+    if rank != 0:
+        return None
+    res = {}
+    for rk in range(world):
+        rs = rates_of_rank(rates, rk, world)
+        for gi in range(len(gofs)):
+            for ri, r in enumerate(rs):
+                base = (gi * len(rs) + ri) * 3
+                res.setdefault(r, []).append(gathered[rk][base:base + 3])
+    return res
+
+
+def split_pairs(stream: bytes) -> List[bytes]:
+    """Splits an Annex-B sub-bitstream made of closed GOPs, each starting with its own VPS (parameter sets repeated with every IDR,
+    as libx265 does behind PCCTranscoder.cpp:706 and as the CTC streams do), into one byte string per closed GOP. Used to cut the
+    12-frame tail GOF of a 300-frame sequence out of a 32-frame one and to make the GOFs of a synthetic sequence differ."""
+    cuts, i = [], stream.find(b"\x00\x00\x01")
+    while i >= 0:
+        if (stream[i + 3] >> 1) & 63 == 32:          # VPS
+            cuts.append(i - 1 if i > 0 and stream[i - 1] == 0 else i)
+        i = stream.find(b"\x00\x00\x01", i + 3)
+    assert cuts and cuts[0] == 0, "stream does not start with a VPS"
+    cuts.append(len(stream))
+    return [stream[a:b] for a, b in zip(cuts, cuts[1:])]
+
+
+def make_sequence(gof: Sequence[bytes], n_frames: int, gof_size: int = 32) -> List[List[bytes]]:
+    """A synthetic sequence of ceil(n_frames / gof_size) GOFs from ONE [occupancy, geometry, attribute] GOF of gof_size frames:
+    GOF g holds the point-cloud frames (7 g + i) mod gof_size, i < its length - every GOF differs and the last one is shorter
+    (300 frames -> 9 x 32 + 12). Valid because every point-cloud frame is a closed GOP in all three sub-bitstreams."""
+    parts = [split_pairs(s) for s in gof]
+    assert all(len(p) == gof_size for p in parts), [len(p) for p in parts]
+    seq = []
+    for g, n in enumerate(gof_lengths(n_frames, gof_size)):
+        idx = [(7 * g + i) % gof_size for i in range(n)]
+        seq.append([b"".join(p[k] for k in idx) for p in parts])
+    return seq

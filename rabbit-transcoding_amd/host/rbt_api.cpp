@@ -9,10 +9,13 @@
 struct rbt_ctx { int device, rank, world; rbt_stats stats; std::string last_err; };
 struct rbt_job { rbt::GofJob* j; rbt_ctx* owner; };
 
-static rbt_job* g_jobs[RBT_MAX_JOBS] = {};
-static int g_depth = 4;                      // announced pipeline depth: decides how many HIP streams a job gets (rbt_transcode.cpp bind_streams)
+// Job slots, pipeline depth and the lock are per DEVICE (the 16 HIP streams a job's lanes map onto are the device's, rbt_kernels.hip):
+// contexts on different devices run concurrently, contexts on one device share its slots and are serialised, as are the calls on one
+// context (the reference's transcoder is called serially too).
+struct DevState { rbt_job* jobs[RBT_MAX_JOBS] = {}; int depth = 4; std::mutex mu; };
+static DevState g_dev[16];
 static_assert(RBT_MAX_JOBS == rbtk::RBT_JOB_SLOTS, "job slots");
-static std::mutex g_mu;   // one HIP stream / timer set per process; calls on one context are serial (as the reference's are)
+#define RBT_ENTER(ctx) DevState& D = g_dev[(ctx)->device]; std::lock_guard<std::mutex> lk(D.mu); if (rbtk::dev_select((ctx)->device)) return RBT_ERR_NO_DEVICE
 
 extern "C" {
 
@@ -36,7 +39,9 @@ void rbt_free(void* p) { free(p); }
 int rbt_create(rbt_ctx** ctx, int device, int world_rank, int world_size) {
   if (!ctx) return RBT_ERR_PARAM;
   *ctx = nullptr;
-  std::lock_guard<std::mutex> lk(g_mu);
+  if (world_size < 1 || world_rank < 0 || world_rank >= world_size) return RBT_ERR_PARAM;
+  if (device < 0 || device >= 16) return RBT_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(g_dev[device].mu);
   if (rbtk::dev_init(device)) return RBT_ERR_NO_DEVICE;
   rbt_ctx* c = new rbt_ctx(); c->device = device; c->rank = world_rank; c->world = world_size; memset(&c->stats, 0, sizeof(c->stats));
   *ctx = c;
@@ -44,17 +49,23 @@ int rbt_create(rbt_ctx** ctx, int device, int world_rank, int world_size) {
 }
 void rbt_destroy(rbt_ctx* ctx) {
   if (ctx) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    for (int s = 0; s < RBT_MAX_JOBS; s++) if (g_jobs[s] && g_jobs[s]->owner == ctx) { rbt::gof_abandon(g_jobs[s]->j); delete g_jobs[s]; g_jobs[s] = nullptr; }
-    rbtk::dev_release_pool();
+    DevState& D = g_dev[ctx->device]; std::lock_guard<std::mutex> lk(D.mu);
+    if (!rbtk::dev_select(ctx->device)) {
+      for (int s = 0; s < RBT_MAX_JOBS; s++) if (D.jobs[s] && D.jobs[s]->owner == ctx) { rbt::gof_abandon(D.jobs[s]->j); delete D.jobs[s]; D.jobs[s] = nullptr; }
+      rbtk::dev_release_pool();
+    }
   }
   delete ctx;
 }
+// GOF sharding rule of the multi-GPU transcoder: GOF g of a sequence belongs to rank g mod world_size. A host that
+// walks the sequence GOF by GOF (PccAppTranscoder.cpp:307-341) on every rank skips the GOFs its context does not own.
+int rbt_owns_gof(const rbt_ctx* ctx, int gof_index) { return ctx && gof_index >= 0 && gof_index % ctx->world == ctx->rank; }
+int rbt_world(const rbt_ctx* ctx, int* rank, int* size) { if (!ctx) return RBT_ERR_PARAM; if (rank) *rank = ctx->rank; if (size) *size = ctx->world; return RBT_OK; }
 int rbt_get_stats(rbt_ctx* ctx, rbt_stats* out) { if (!ctx || !out) return RBT_ERR_PARAM; *out = ctx->stats; return RBT_OK; }
 
 int rbt_decode(rbt_ctx* ctx, const uint8_t* annexb, size_t n, int verify_md5, rbt_video* out) {
   if (!ctx || !annexb || !out) return RBT_ERR_PARAM;
-  std::lock_guard<std::mutex> lk(g_mu);
+  RBT_ENTER(ctx);
   memset(out, 0, sizeof(*out));
   rbt::DecodeBatch b; rbt::StreamIn in{annexb, n};
   int rc = rbt::decode_build(b, &in, 1);
@@ -110,8 +121,14 @@ int rbt_sample_to_byte_stream(const uint8_t* in, size_t n, uint8_t** out, size_t
   return RBT_OK;
 }
 
+static int submit(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, rbt_job** job, bool gof_rule);
+// transcodeVideo re-encodes whatever it is handed (an occupancy stream with occupancyPrecision != 4 is re-encoded without pooling)
 int rbt_transcode_substream(rbt_ctx* ctx, const uint8_t* annexb_in, size_t n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out) {
-  return rbt_transcode_gof(ctx, 1, &annexb_in, &n_in, p, annexb_out, n_out);
+  if (!ctx || !annexb_in || !p || !annexb_out || !n_out) return RBT_ERR_PARAM;
+  rbt_job* job = nullptr;
+  int rc = submit(ctx, 1, &annexb_in, &n_in, p, &job, false);
+  if (rc) return rc;
+  return rbt_wait_gof(ctx, job, annexb_out, n_out);
 }
 int rbt_transcode_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out) {
   if (!ctx || n < 1 || n > RBT_MAX_STREAMS || !annexb_in || !n_in || !p || !annexb_out || !n_out) return RBT_ERR_PARAM;
@@ -120,43 +137,44 @@ int rbt_transcode_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, cons
   if (rc) return rc;
   return rbt_wait_gof(ctx, job, annexb_out, n_out);
 }
-int rbt_submit_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, rbt_job** job) {
+int rbt_submit_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, rbt_job** job) { return submit(ctx, n, annexb_in, n_in, p, job, true); }
+static int submit(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, rbt_job** job, bool gof_rule) {
   if (!ctx || n < 1 || n > RBT_MAX_STREAMS || !annexb_in || !n_in || !p || !job) return RBT_ERR_PARAM;
   *job = nullptr;
-  std::lock_guard<std::mutex> lk(g_mu);
+  RBT_ENTER(ctx);
   int slot = -1;
-  for (int s = 0; s < g_depth && slot < 0; s++) if (!g_jobs[s]) slot = s;
+  for (int s = 0; s < D.depth && slot < 0; s++) if (!D.jobs[s]) slot = s;
   if (slot < 0) return RBT_ERR_BUSY;
-  rbt_job* j = new rbt_job{rbt::gof_submit(slot, g_depth, n, annexb_in, n_in, p), ctx};
-  g_jobs[slot] = j; *job = j;
+  rbt_job* j = new rbt_job{rbt::gof_submit(slot, D.depth, n, annexb_in, n_in, p, gof_rule), ctx};
+  D.jobs[slot] = j; *job = j;
   return RBT_OK;                       // errors of the build surface in rbt_wait_gof, which also releases the job
 }
 int rbt_set_depth(rbt_ctx* ctx, int max_in_flight) {
   if (!ctx || max_in_flight < 1 || max_in_flight > RBT_MAX_JOBS) return RBT_ERR_PARAM;
-  std::lock_guard<std::mutex> lk(g_mu);
-  for (int s = 0; s < RBT_MAX_JOBS; s++) if (g_jobs[s]) return RBT_ERR_BUSY;
-  g_depth = max_in_flight;
+  RBT_ENTER(ctx);
+  for (int s = 0; s < RBT_MAX_JOBS; s++) if (D.jobs[s]) return RBT_ERR_BUSY;
+  D.depth = max_in_flight;
   return RBT_OK;
 }
 int rbt_wait_gof(rbt_ctx* ctx, rbt_job* job, uint8_t** annexb_out, size_t* n_out) {
   if (!ctx || !job || !annexb_out || !n_out) return RBT_ERR_PARAM;
-  std::lock_guard<std::mutex> lk(g_mu);
+  RBT_ENTER(ctx);
   int slot = -1;
-  for (int s = 0; s < RBT_MAX_JOBS; s++) if (g_jobs[s] == job) slot = s;
+  for (int s = 0; s < RBT_MAX_JOBS; s++) if (D.jobs[s] == job) slot = s;
   if (slot < 0 || job->owner != ctx) return RBT_ERR_PARAM;
   int rc = rbt::gof_wait(job->j, ctx->stats, ctx->last_err, annexb_out, n_out);
-  g_jobs[slot] = nullptr; delete job;
+  D.jobs[slot] = nullptr; delete job;
   return rc;
 }
 int rbt_encode(rbt_ctx* ctx, const uint16_t* yuv, int width, int height, int bit_depth, int n_frames, int qp, int gop, int lossless,
                int log2_ctb, int ctb_rows_per_slice, int md5_sei, uint8_t** annexb_out, size_t* n_out) {
   if (!ctx || !yuv || !annexb_out || !n_out || n_frames < 1) return RBT_ERR_PARAM;
-  std::lock_guard<std::mutex> lk(g_mu);
+  RBT_ENTER(ctx);
   return rbt::encode_yuv(ctx->stats, ctx->last_err, yuv, width, height, bit_depth, n_frames, qp, gop, lossless, log2_ctb, ctb_rows_per_slice, md5_sei, annexb_out, n_out);
 }
 int rbt_or_pool(rbt_ctx* ctx, const uint16_t* plane, int width, int height, int factor, uint16_t* out) {
   if (!ctx || !plane || !out || factor < 1 || width % factor || height % factor) return RBT_ERR_PARAM;
-  std::lock_guard<std::mutex> lk(g_mu);
+  RBT_ENTER(ctx);
   return rbt::or_pool_host(plane, width, height, factor, out);
 }
 

@@ -259,10 +259,11 @@ static int hand_out(const std::vector<std::vector<uint8_t>>& outs, uint8_t** out
 static int parse_bands() { static int v = -1; if (v < 0) { const char* e = getenv("RBT_PARSE_BANDS"); v = e ? atoi(e) : 1; if (v < 1) v = 1; if (v > 16) v = 16; } return v; }
 struct PoolJob { const uint16_t* in; int stride, w, h; uint16_t *y, *cb, *cr; int grey; };
 // pool_jobs != nullptr: the OR-pool launches are recorded instead of issued (the decoder's kernels are not enqueued yet)
-// stream `si` of the decode batch becomes stream `si` of the encode batch
-static int setup_encode(DecodeBatch& db, int si, const rbt_stream_params& p, EncodeBatch& eb, std::vector<void*>& pooled, std::string& err, std::vector<PoolJob>* pool_jobs = nullptr) {
-  if ((int)eb.desc.size() <= si) eb.desc.resize((size_t)si + 1);
-  EncStreamDesc& d = eb.desc[si]; int first = db.stream_first[si], cnt = db.stream_count[si];
+// stream `si` of the decode batch becomes stream `ei` of the encode batch (several target rate points may re-encode one decoded
+// stream: BASELINE.json configs[4], rate fan-out)
+static int setup_encode(DecodeBatch& db, int si, int ei, const rbt_stream_params& p, EncodeBatch& eb, std::vector<void*>& pooled, std::string& err, std::vector<PoolJob>* pool_jobs = nullptr) {
+  if ((int)eb.desc.size() <= ei) eb.desc.resize((size_t)ei + 1);
+  EncStreamDesc& d = eb.desc[ei]; int first = db.stream_first[si], cnt = db.stream_count[si];
   const RbtStreamCfg& c = db.frames[first].cfg; const Sps& isps = db.stream_sps[si];
   // what a player shows of the input: the coded picture minus its conformance window
   const int cl = 2 * isps.conf_win[0], ct = 2 * isps.conf_win[2], dw = c.w - cl - 2 * isps.conf_win[1], dh = c.h - ct - 2 * isps.conf_win[3];
@@ -317,6 +318,9 @@ struct GofJob {
   std::vector<std::vector<RbtFrameRef>> refs_keep;     // ... and of merged reconstruction launches
   std::vector<char> recon_timed;
   std::vector<rbt_stream_params> params; std::vector<size_t> n_in;
+  std::vector<std::vector<uint8_t>> passthrough;   // transcodeData (PCCTranscoder.cpp:150): occupancy is only transcoded when occupancyPrecision == 4; else the stream stays as it is
+  std::vector<char> is_pass;
+  std::vector<std::vector<int>> dec_of;            // per pipeline: decode stream of each of its (encode) streams - identical inputs are decoded once
   rbt_stats st; std::string err; double t_all = 0, t_gpu = 0;
   ~GofJob() { for (void* q : pooled) rbtk::dev_free(q); }
 };
@@ -333,7 +337,7 @@ static void bind_streams(GofJob& j, int depth) {
   rbtk::map_lane(job_stream(j, rbtk::RBT_AUX_STREAM), base + spj - 1);
 }
 
-GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const size_t* n_in, const rbt_stream_params* p) {
+GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const size_t* n_in, const rbt_stream_params* p, bool gof_rule) {
   GofJob* J = new GofJob(); GofJob& j = *J;
   j.t_all = now_ms(); j.n = n; j.slot = slot; memset(&j.st, 0, sizeof(j.st));
   j.params.assign(p, p + n); j.n_in.assign(n_in, n_in + n);
@@ -342,15 +346,30 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
   // one GOF leaves most of the GPU idle) groups them by video type, so that the slices of all attribute streams parse
   // in one launch, all geometry streams in another, ...
   std::vector<std::vector<int>>& groups = j.groups;
-  if (n <= rbtk::RBT_AUX_STREAM) for (int i = 0; i < n; i++) groups.push_back({i});
+  j.passthrough.resize(n); j.is_pass.assign(n, 0);
+  int n_live = 0;
+  for (int i = 0; i < n; i++) {
+    if (gof_rule && p[i].video_type == RBT_VIDEO_OCCUPANCY && p[i].occupancy_precision != 4) { j.is_pass[i] = 1; j.passthrough[i].assign(in[i], in[i] + n_in[i]); }
+    else n_live++;
+  }
+  if (n_live <= rbtk::RBT_AUX_STREAM) { for (int i = 0; i < n; i++) if (!j.is_pass[i]) groups.push_back({i}); }
   else {
     const int types[3] = {RBT_VIDEO_ATTRIBUTE, RBT_VIDEO_GEOMETRY, RBT_VIDEO_OCCUPANCY};
-    for (int t = 0; t < 3; t++) { std::vector<int> g; for (int i = 0; i < n; i++) if (p[i].video_type == types[t]) g.push_back(i); if (!g.empty()) groups.push_back(g); }
-    std::vector<int> rest; for (int i = 0; i < n; i++) if (p[i].video_type != types[0] && p[i].video_type != types[1] && p[i].video_type != types[2]) rest.push_back(i);
+    for (int t = 0; t < 3; t++) { std::vector<int> g; for (int i = 0; i < n; i++) if (!j.is_pass[i] && p[i].video_type == types[t]) g.push_back(i); if (!g.empty()) groups.push_back(g); }
+    std::vector<int> rest; for (int i = 0; i < n; i++) if (!j.is_pass[i] && p[i].video_type != types[0] && p[i].video_type != types[1] && p[i].video_type != types[2]) rest.push_back(i);
     if (!rest.empty()) { if (groups.size() < 3) groups.push_back(rest); else groups.back().insert(groups.back().end(), rest.begin(), rest.end()); }
   }
   const int ng = j.ng = (int)groups.size();
-  auto bytes_of = [&](int g) { size_t t = 0; for (int i : groups[g]) t += n_in[i]; return t; };
+  // Streams of a pipeline that are the same input (same buffer: one sub-bitstream re-encoded at several rate points) are decoded once
+  j.dec_of.resize(ng);
+  std::vector<std::vector<int>> uniq(ng);          // per pipeline: the stream indices that are decoded
+  for (int g = 0; g < ng; g++) for (int i : groups[g]) {
+    int d = -1;
+    for (size_t q = 0; q < uniq[g].size(); q++) if (in[uniq[g][q]] == in[i] && n_in[uniq[g][q]] == n_in[i] && !p[i].verify_md5 && !p[uniq[g][q]].verify_md5) { d = (int)q; break; }
+    if (d < 0) { d = (int)uniq[g].size(); uniq[g].push_back(i); }
+    j.dec_of[g].push_back(d);
+  }
+  auto bytes_of = [&](int g) { size_t t = 0; for (int i : uniq[g]) t += n_in[i]; return t; };
   j.db.resize(ng); j.eb.resize(ng); j.chained.assign(ng, 0);
   std::vector<DecodeBatch>& db = j.db; std::vector<EncodeBatch>& eb = j.eb; std::vector<char>& chained = j.chained; std::vector<void*>& pooled = j.pooled;
   std::vector<int>& order = j.order; order.resize(ng); for (int i = 0; i < ng; i++) order[i] = i;
@@ -368,7 +387,8 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
   for (int k = 0; k < ng && !rc; k++) {
     const int gi = order[k], sid = job_stream(j, gi); const std::vector<int>& gs = groups[gi]; rbtk::set_stream(sid);
     std::vector<StreamIn> sins; bool verify = false;
-    for (int i : gs) { sins.push_back(StreamIn{in[i], n_in[i]}); verify |= p[i].verify_md5 != 0; }
+    for (int i : uniq[gi]) sins.push_back(StreamIn{in[i], n_in[i]});
+    for (int i : gs) verify |= p[i].verify_md5 != 0;
     double t0 = now_ms();
     db[gi].want_save = parse_bands() > 1 && k == 0 && j.has_aux && ng <= rbtk::RBT_AUX_STREAM && !verify;
     rc = decode_build(db[gi], sins.data(), (int)sins.size());
@@ -376,7 +396,7 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
     if (!rc) rc = decode_upload_lists(db[gi]);
     if (rc) { err = db[gi].err; break; }
     if (!verify) {
-      for (size_t q = 0; q < gs.size() && !rc; q++) rc = setup_encode(db[gi], (int)q, p[gs[q]], eb[gi], pooled, err, &pool_jobs[gi]);
+      for (size_t q = 0; q < gs.size() && !rc; q++) rc = setup_encode(db[gi], j.dec_of[gi][q], (int)q, p[gs[q]], eb[gi], pooled, err, &pool_jobs[gi]);
       if (!rc) { rc = encode_build(eb[gi]); if (!rc) rc = encode_upload_lists(eb[gi]); if (rc) err = eb[gi].err; }
       if (rc) break;
       chained[gi] = 1;
@@ -435,8 +455,8 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
     EncodeBatch& e = eb[gi]; e.main_stream = sid;
     size_t n_levels = db[gi].level_frames.size(), fork_level = 0;
     for (size_t q = 0; q < e.frames.size(); q++) if (e.frame_is_idr[q]) {
-      const int si = e.frame_stream[q], local = (int)q - e.stream_first[si];
-      fork_level = std::max(fork_level, (size_t)db[gi].frames[db[gi].stream_first[si] + local].level);
+      const int si = e.frame_stream[q], local = (int)q - e.stream_first[si], ds = j.dec_of[gi][si];
+      fork_level = std::max(fork_level, (size_t)db[gi].frames[db[gi].stream_first[ds] + local].level);
     }
     int intra_done = 0;
     const bool fork = k == 0 && j.has_aux && ng <= rbtk::RBT_AUX_STREAM && jobs.empty() && e.pad_jobs.empty() && fork_level + 1 < n_levels;   // longest pipeline only: one spare stream
@@ -482,11 +502,11 @@ int gof_wait(GofJob* J, rbt_stats& st_out, std::string& err_out, uint8_t** out, 
     if (j.chained[gi]) rc = encode_finish(eb[gi], o1, st);
     else {
       for (size_t q = 0; q < gs.size() && !rc; q++) if (p[gs[q]].verify_md5) {
-        rbt_video v; rc = decode_fetch(db[gi], (int)q, &v, true); free(v.data);
+        rbt_video v; rc = decode_fetch(db[gi], j.dec_of[gi][q], &v, true); free(v.data);
         if (rc) { err = "fetch failed"; break; }
         if (v.md5_failed) { err = "input MD5 mismatch"; rc = RBT_ERR_MD5; }
       }
-      for (size_t q = 0; q < gs.size() && !rc; q++) rc = setup_encode(db[gi], (int)q, p[gs[q]], eb[gi], j.pooled, err);
+      for (size_t q = 0; q < gs.size() && !rc; q++) rc = setup_encode(db[gi], j.dec_of[gi][q], (int)q, p[gs[q]], eb[gi], j.pooled, err);
       if (rc) continue;
       eb[gi].main_stream = sid;
       rc = encode_build(eb[gi]);
@@ -497,6 +517,7 @@ int gof_wait(GofJob* J, rbt_stats& st_out, std::string& err_out, uint8_t** out, 
   }
   rbtk::set_stream(0);
   if (rc) { err_out = err; st_out = st; return rc; }
+  for (int i = 0; i < n; i++) if (j.is_pass[i]) outs[i].swap(j.passthrough[i]);
   st.gpu_ms = now_ms() - j.t_gpu;
   rc = hand_out(outs, out, n_out);
   // SURVEY.md 8(d) algorithmic traffic: per coded picture of S samples (2 bytes each): decode writes S, P pictures read
@@ -519,7 +540,7 @@ void gof_abandon(GofJob* J) {   // a job nobody will wait for: drain its streams
   delete J;
 }
 int transcode_gof(rbt_stats& st, std::string& err, int n, const uint8_t* const* in, const size_t* n_in, const rbt_stream_params* p, uint8_t** out, size_t* n_out) {
-  return gof_wait(gof_submit(0, 1, n, in, n_in, p), st, err, out, n_out);
+  return gof_wait(gof_submit(0, 1, n, in, n_in, p, true), st, err, out, n_out);
 }
 
 int encode_yuv(rbt_stats& st, std::string& err, const uint16_t* yuv, int w, int h, int bd, int n_frames, int qp, int gop, int lossless, int log2_ctb, int rows, int md5,

@@ -18,6 +18,7 @@ namespace rbtk {
 static double g_t[32][2];
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int dev_init(int) { return 0; }
+int dev_select(int) { return 0; }
 void set_stream(int) {}
 void map_lane(int, int) {}
 void stream_wait(int, int) {}

@@ -36,6 +36,7 @@ def lib():
         L.oracle_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(OracleVideo)]
         L.oracle_encode.argtypes = [C.c_int] * 10 + [C.c_uint32, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
         L.oracle_transcode_substream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(TranscodeParams), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.oracle_transcode_data.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(TranscodeParams), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.oracle_sample_to_byte_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.oracle_byte_to_sample_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.oracle_or_pool.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -86,6 +87,24 @@ def transcode_substream(stream: bytes, video_type, qp, occupancy_precision=4, lo
     if rc != 0:
         raise RuntimeError(f"oracle transcode failed rc={rc}")
     return _take(out, n_out)
+
+
+def transcode_data(streams, params):
+    """PCCTranscoder::transcodeData on Annex-B sub-bitstreams; params: list of (video_type, qp, occupancy_precision, log2_ctb, rows_per_slice, md5_sei)"""
+    k = len(streams)
+    ins = (C.c_char_p * k)(*streams)
+    sizes = (C.c_size_t * k)(*[len(s) for s in streams])
+    ps = (TranscodeParams * k)(*[TranscodeParams(*p) for p in params])
+    outs = (C.c_void_p * k)()
+    ns = (C.c_size_t * k)()
+    rc = lib().oracle_transcode_data(k, ins, sizes, ps, outs, ns)
+    if rc != 0:
+        raise RuntimeError(f"oracle transcode_data failed rc={rc}")
+    res = []
+    for i in range(k):
+        res.append(C.string_at(outs[i], ns[i]) if outs[i] else b"")
+        lib().oracle_free(outs[i])
+    return res
 
 
 def sample_to_byte_stream(b: bytes):

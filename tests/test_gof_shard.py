@@ -1,43 +1,94 @@
-"""Multi-rank path on CPU: GOF sharding + gather of the re-encoded sub-bitstreams with world_size 2 over
-gloo. The transcode itself is replaced by a tagging function here (no GPU in this container); the N-GPU path in bench.py
-uses the same gather with backend nccl (RCCL)."""
+"""Multi-rank path (BASELINE.json configs[3] and configs[4]) on CPU: world_size 2 over gloo, every rank running the REAL
+flow - shard -> rbt_submit_gof / rbt_wait_gof -> gather -> stitch - on the test-only host build of the kernel bodies (tests/hostemu; no GPU
+in this container). The stitched output must equal the unsharded run byte for byte, and the oracle's transcodeData per GOF. bench.py
+--gpus N runs the same functions with backend nccl (RCCL)."""
 import os
-import sys
+import subprocess
 import torch.multiprocessing as mp
+import pytest
 import rbt_lib
 
+W, H, GOF, FRAMES = 64, 64, 4, 14          # 14 frames in GOFs of 4 -> 4 + 4 + 4 + 2: a shorter tail GOF like 300 = 9 x 32 + 12
 
-def _worker(rank, world, port, n_gofs, q):
+
+def _sequence():
+    import oracle_lib as O
+    import synth
+    gs = rbt_lib.module_file("gof_shard")
+    geo, attr, occ = synth.make_gof(W, H, GOF, 5)
+    sg, _ = O.encode(geo, W, H, 10, 16, gop=2, log2_ctb=6, rows_per_slice=0, md5_sei=0)
+    sa, _ = O.encode(attr, W, H, 10, 22, gop=2, log2_ctb=6, rows_per_slice=0, md5_sei=0)
+    so, _ = O.encode(occ, W // 2, H // 2, 8, 8, gop=1, lossless=1, i_qp_offset=0, log2_ctb=6, rows_per_slice=0, md5_sei=0)
+    return gs.make_sequence([so, sg, sa], FRAMES, GOF)
+
+
+def _worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    gs = rbt_lib.module_file("gof_shard")
-    mine = gs.gofs_of_rank(n_gofs, rank, world)
-    local = []
-    for g in mine:      # three sub-bitstreams per GOF, variable length, content identifies (gof, stream)
-        for s in range(3):
-            local.append(bytes([g, s]) * (10 + 7 * g + s))
-    gathered = gs.gather_streams(local)
+    R = rbt_lib.module(); gs = rbt_lib.module_file("gof_shard")
+    ctx = R.Context(lib_path=rbt_lib.HOSTEMU_LIB, rank=rank, world=world)
+    seq = _sequence()
+    out = gs.transcode_sequence(ctx, seq, gs.rate_params(R, 3), rank=rank, world=world, depth=2)
+    fan = gs.transcode_fanout(ctx, R, seq[2:], rates=(1, 2, 3, 4, 5), rank=rank, world=world, depth=2)
     if rank == 0:
-        q.put(gs.stitch(gathered, n_gofs, 3))
+        q.put((out, fan))
     dist.barrier()
     dist.destroy_process_group()
+    ctx.close()
 
 
-def test_gof_sharding_and_gather_world2():
+@pytest.fixture(scope="module")
+def hostemu():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(__file__), "hostemu")])
+
+
+def test_sharding_rules():
     gs = rbt_lib.module_file("gof_shard")
+    assert gs.gof_lengths(300) == [32] * 9 + [12] and gs.gof_lengths(32) == [32] and gs.gof_lengths(14, 4) == [4, 4, 4, 2]
     assert gs.gofs_of_rank(10, 0, 8) == [0, 8] and gs.gofs_of_rank(10, 1, 8) == [1, 9] and gs.gofs_of_rank(10, 7, 8) == [7]
     assert sorted(sum((gs.gofs_of_rank(10, r, 3) for r in range(3)), [])) == list(range(10))
+    assert [gs.rates_of_rank((1, 2, 3, 4, 5), r, 8) for r in range(8)] == [[1], [2], [3], [4], [5], [], [], []]
+    assert gs.rates_of_rank((1, 2, 3, 4, 5), 0, 2) == [1, 3, 5] and gs.rates_of_rank((1, 2, 3, 4, 5), 1, 2) == [2, 4]
+    # cfg/rate/ctc-r{1..5}.cfg:5-11
+    assert gs.RATE_POINTS == {1: (32, 42, 4), 2: (28, 37, 4), 3: (24, 32, 4), 4: (20, 27, 4), 5: (16, 22, 2)}
+
+
+def test_context_owns_gofs_like_the_python_rule(hostemu):
+    R = rbt_lib.module(); gs = rbt_lib.module_file("gof_shard")
+    for world in (1, 2, 3, 8):
+        for rank in range(world):
+            c = R.Context(lib_path=rbt_lib.HOSTEMU_LIB, rank=rank, world=world)
+            assert [g for g in range(10) if c.owns_gof(g)] == gs.gofs_of_rank(10, rank, world)
+            c.close()
+    for rank, world in ((-1, 2), (2, 2), (0, 0)):
+        with pytest.raises(R.RbtError) as e:
+            R.Context(lib_path=rbt_lib.HOSTEMU_LIB, rank=rank, world=world)
+        assert e.value.code == -4      # RBT_ERR_PARAM
+
+
+def test_sequence_and_fanout_world2_equal_unsharded_and_oracle(hostemu):
+    import oracle_lib as O
+    R = rbt_lib.module(); gs = rbt_lib.module_file("gof_shard")
+    seq = _sequence()
+    assert [len(gs.split_pairs(g[1])) for g in seq] == [4, 4, 4, 2]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    n_gofs, world, port = 5, 2, 29517
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_gofs, q)) for r in range(world)]
+    world, port = 2, 29517
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = q.get(timeout=120)
+    out, fan = q.get(timeout=600)
     for p in procs:
-        p.join(60)
+        p.join(120)
         assert p.exitcode == 0
-    for g in range(n_gofs):
-        for s in range(3):
-            assert res[g][s] == bytes([g, s]) * (10 + 7 * g + s)
+    # unsharded: one context walks the whole sequence
+    c = R.Context(lib_path=rbt_lib.HOSTEMU_LIB)
+    assert out == gs.transcode_sequence(c, seq, gs.rate_params(R, 3), depth=3)
+    assert fan == gs.transcode_fanout(c, R, seq[2:], depth=1)
+    c.close()
+    # the oracle's transcodeData, GOF by GOF (PCCTranscoder.cpp:145-168)
+    assert out == [O.transcode_data(g, [(0, 8, 4, 5, 1, 0), (1, 24, 4, 5, 1, 0), (19, 32, 4, 5, 1, 0)]) for g in seq]
+    for r, (gq, aq, pr) in gs.RATE_POINTS.items():
+        assert fan[r] == [O.transcode_data(g, [(0, 8, pr, 5, 1, 0), (1, gq, pr, 5, 1, 0), (19, aq, pr, 5, 1, 0)]) for g in seq[2:]]
+    assert fan[5][0][0] == seq[2][0]       # R5 keeps occupancy precision 2: the reference does not touch the occupancy stream (:150)
