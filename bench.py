@@ -4,8 +4,10 @@
 Workload (config.workload): one 32-frame GOF of 1280x1280 V-PCC maps — 64 geometry + 64 attribute pictures
 (yuv420p10, I/P pairs) and 32 occupancy pictures (640x640, 8 bit, lossless) — at "R5" (QP 16 / 22, occupancy
 precision 2), transcoded to R3 (geometryQP 24, attributeQP 32, occupancyPrecision 4). There is no 8i data and no HM
-here, so the maps are synthetic (tests/synth.py) and the R5 input is produced by this repository's own GPU encoder in
-HM-like structure (CTB 64, one slice per picture). One "step" = one GOF through rbt_submit_gof + rbt_wait_gof (together:
+here, so the maps are synthetic (tests/synth.py) and the R5 input is the committed fixture tests/golden/hm_r5_1280x1280_f32_*.annexb:
+those maps coded with the toolset of the CTC input streams (cfg/hm/ctc-hm-*-ai.cfg: CTU 64, TU 4..32, 35 intra modes, quarter-sample motion
+search, AMP, transform skip, SAO, hash SEI; one slice per picture) by the oracle's HM-like encoder (tests/golden/make_hm_gof.py, run in the
+build container). --input e1 codes the input with this library's own encoder instead (other sizes). One "step" = one GOF through rbt_submit_gof + rbt_wait_gof (together:
 rbt_transcode_gof); --in-flight GOFs (default 16) are submitted ahead of the one being collected, as a transcoder walking a sequence does.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--pc-frames F]          (N > 1 without a launcher: starts the N ranks itself)
@@ -31,26 +33,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
 def make_gof_maps(w, h, n_pc, seed):
-    """n_pc point-cloud frames: 4 base atlases jittered by a few pixels per frame."""
     import synth
-    bases = [synth.make_maps(w, h, seed + k) for k in range(min(4, n_pc))]
-    geo, attr, occ = [], [], []
-    ys, cs = w * h, (w // 2) * (h // 2)
-
-    def roll(frame, ww, hh, d):
-        y = np.roll(frame[: ww * hh].reshape(hh, ww), d, axis=1).ravel()
-        c = (ww // 2) * (hh // 2)
-        u = np.roll(frame[ww * hh: ww * hh + c].reshape(hh // 2, ww // 2), d // 2, axis=1).ravel()
-        v = np.roll(frame[ww * hh + c:].reshape(hh // 2, ww // 2), d // 2, axis=1).ravel()
-        return np.concatenate([y, u, v])
-    for i in range(n_pc):
-        b = bases[i % len(bases)]
-        d = 2 * (i // len(bases))
-        geo += [roll(b["geo"][0], w, h, d), roll(b["geo"][1], w, h, d)]
-        attr += [roll(b["attr"][0], w, h, d), roll(b["attr"][1], w, h, d)]
-        occ += [roll(b["occ"][0], w // 2, h // 2, d // 2)]
-    del ys, cs
-    return np.stack(geo), np.stack(attr), np.stack(occ)
+    return synth.make_gof_maps(w, h, n_pc, seed)
 
 
 def launch_ranks(n):
@@ -90,6 +74,8 @@ def main():
     ap.add_argument("--save-input", default=None, help="write the generated R5 input streams to this .npz file and exit")
     ap.add_argument("--load-input", default=None, help="read the R5 input streams from a file written by --save-input (keeps the input "
                     "encoder's kernels out of a profile of the transcode step); the file must come from the same size / seed")
+    ap.add_argument("--input", default="auto", choices=["auto", "hm", "e1"], help="R5 input: hm = the committed HM-like fixture (tests/golden/hm_r5_*.annexb: CTC toolset, "
+                    "coded by the oracle's HM-like encoder, tests/golden/make_hm_gof.py); e1 = coded on the fly by this library's own encoder (any size); auto = hm when the fixture fits")
     ap.add_argument("--walk-frames", type=int, default=300, help="also walk a sequence of this many point-cloud frames GOF-sharded over the ranks "
                     "(BASELINE.json configs[3]: 300 = 9 x 32 + 12; extra field sequence_walk; 0 = skip)")
     ap.add_argument("--fanout-gofs", type=int, default=2, help="also transcode this many GOFs to every rate point R1..R5, one target rate per rank "
@@ -117,9 +103,27 @@ def main():
     ctx = R.Context(device=dev, rank=rank, world=world)   # raises without a GPU: no CPU fallback
 
     w, h, n_pc = args.width, args.height, args.pc_frames
-    geo, attr, occ = make_gof_maps(w, h, n_pc, 1051)     # every rank walks the same synthetic sequence (weak scaling: K GOFs per rank)
-    # R5 input in HM-like structure, produced by the GPU encoder (outside the timed region)
-    if args.load_input:
+    gs = rbt_lib.module_file("gof_shard")
+    # R5 input. Default: the committed fixture - the synthetic maps below coded with the CTC toolset (SAO, transform skip, AMP, quarter-sample
+    # motion, TU trees, 35 intra modes; one slice per picture, CTB 64) by the oracle's HM-like encoder in the build container. Every rank
+    # walks the same sequence (weak scaling: K GOFs per rank).
+    fixture = None
+    man_path = os.path.join(ROOT, "tests", "golden", "hm_r5_manifest.json")
+    if args.input != "e1" and not args.load_input and os.path.exists(man_path):
+        man = json.load(open(man_path)).get(f"{w}x{h}_f32")
+        if man and n_pc <= 32:
+            fixture = {k: b"".join(gs.split_pairs(open(os.path.join(ROOT, "tests", "golden", v["file"]), "rb").read())[:n_pc]) for k, v in man["streams"].items()}
+    if args.input == "hm" and fixture is None:
+        sys.exit("--input hm: no committed fixture for this size (tests/golden/make_hm_gof.py)")
+    input_kind = "hm-like fixture (oracle HM-like encoder: SAO, TS, AMP, quarter-pel ME, TU trees, 35 intra modes)" if fixture else "RBT-E1 (this library's encoder, CTB 64, one slice per picture)"
+    if fixture:
+        sg, sa, so = fixture["geo"], fixture["attr"], fixture["occ"]
+        geo = attr = occ = None
+    else:
+        geo, attr, occ = make_gof_maps(w, h, n_pc, 1051)
+    if fixture:
+        pass
+    elif args.load_input:
         z = np.load(args.load_input)
         sg, sa, so = z["sg"].tobytes(), z["sa"].tobytes(), z["so"].tobytes()
     else:
@@ -236,7 +240,6 @@ def main():
     # configs[3]: a sequence of --walk-frames point-cloud frames (300 = 9 GOFs of 32 + one of 12), GOF g on rank g mod world, D GOFs in flight
     # per GPU, re-encoded NAL units gathered on rank 0 (strong scaling: the sequence is fixed). Rank 0 then walks the whole sequence alone
     # and checks that the stitched output is identical.
-    gs = rbt_lib.module_file("gof_shard")
     walk = None
     if args.walk_frames > 0 and n_pc > 1:
         seq = gs.make_sequence(streams, args.walk_frames, n_pc)
@@ -329,9 +332,8 @@ def main():
         import oracle_lib as O   # CPU checker, used here only as the timed CPU baseline ("port")
         k = min(args.cpu_sample, n_pc)
         # bounded sample of the same workload: the first k point-cloud frames of the same GOF
-        sub = [ctx.encode(occ[:k], w // 2, h // 2, 8, 8, gop=1, lossless=1, log2_ctb=6, rows_per_slice=0, md5_sei=0),
-               ctx.encode(geo[:2 * k], w, h, 10, 16, gop=2, log2_ctb=6, rows_per_slice=0, md5_sei=0),
-               ctx.encode(attr[:2 * k], w, h, 10, 22, gop=2, log2_ctb=6, rows_per_slice=0, md5_sei=0)]
+        pairs = [gs.split_pairs(s_) for s_ in streams]      # every point-cloud frame is a closed GOP in all three sub-bitstreams
+        sub = [b"".join(p_[:k]) for p_ in pairs]
         c0 = time.perf_counter()
         cpu_out = [O.transcode_substream(sub[0], 0, 8, md5_sei=0), O.transcode_substream(sub[1], 1, 24, md5_sei=0), O.transcode_substream(sub[2], 19, 32, md5_sei=0)]
         ct = time.perf_counter() - c0
@@ -347,9 +349,7 @@ def main():
         ncore = max(1, min(16, os.cpu_count() or 1, n_pc))
         per = {"n": np.array(n_pc)}
         for q in range(n_pc):
-            per[f"o{q}"] = np.frombuffer(ctx.encode(occ[q:q + 1], w // 2, h // 2, 8, 8, gop=1, lossless=1, log2_ctb=6, rows_per_slice=0, md5_sei=0), np.uint8)
-            per[f"g{q}"] = np.frombuffer(ctx.encode(geo[2 * q:2 * q + 2], w, h, 10, 16, gop=2, log2_ctb=6, rows_per_slice=0, md5_sei=0), np.uint8)
-            per[f"a{q}"] = np.frombuffer(ctx.encode(attr[2 * q:2 * q + 2], w, h, 10, 22, gop=2, log2_ctb=6, rows_per_slice=0, md5_sei=0), np.uint8)
+            per[f"o{q}"] = np.frombuffer(pairs[0][q], np.uint8); per[f"g{q}"] = np.frombuffer(pairs[1][q], np.uint8); per[f"a{q}"] = np.frombuffer(pairs[2][q], np.uint8)
         with tempfile.TemporaryDirectory() as td:
             f = os.path.join(td, "frames.npz"); np.savez(f, **per)
             worker = os.path.join(ROOT, "tests", "cpu_baseline_worker.py")
@@ -365,7 +365,7 @@ def main():
                 "steps": steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "u16/i32", "data": "synthetic",
                 "config": {"workload": f"{n_pc}-frame GOF, {w}x{h} V-PCC maps (2x{n_pc} geometry + 2x{n_pc} attribute yuv420p10 I/P pairs, {n_pc} occupancy {w // 2}x{h // 2} lossless), "
-                                       f"R5 (QP16/22, prec 2) -> R3 (QP24/32, prec 4), synthetic longdress-like atlas",
+                                       f"R5 (QP16/22, prec 2) -> R3 (QP24/32, prec 4), synthetic longdress-like atlas", "input": input_kind,
                            "gof_per_gpu": 1, "gofs_in_flight": D, "setup_jobs_before_warmup": primed, "in_bytes": in_bytes, "out_bytes": out_bytes, "parallelism": f"gof-shard x{world}"},
                 "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                              "traffic": traffic, "kernel_ms": {k_: round(v, 3) for k_, v in groups.items()},

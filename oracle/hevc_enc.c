@@ -14,11 +14,17 @@
  *     dead-zone 85/512.
  *   - lossless (occupancy): cu_transquant_bypass, same quadtree/mode analysis.
  *   - deblocking on (off for lossless), SAO off.
+ * hm_like != 0 (oracle-only, not mirrored on the GPU) makes deterministic "HM-like" decisions with the coding tools of the CTC input
+ * streams (cfg/hm/ctc-hm-geometry-ai.cfg: CTU 64 :10-11, TU 4..32 :13-16, motion search :33-34, TransformSkip :47, SAO :68, AMP :69,
+ * sign data hiding and TMVP as HM defaults): 35 intra modes + NxN, TU split and 4x4 transform skip by a small RD comparison,
+ * integer + quarter-pel motion search with merge / AMVP coding, asymmetric partitions, per-CTB SAO from source statistics.
+ * It produces the benchmark's R5 input (tests/golden/make_hm_gof.py).
  * stress_seed != 0 turns the same bitstream writer into a seeded random-syntax generator that exercises the decoder
  * tools of the CTC input streams the product encoder never emits (all 35 intra modes, NxN, TU trees, transform skip,
  * AMP, AMVP, TMVP, SAO, cu_qp_delta, sign data hiding, multiple slices).
  */
 #include "hevc_enc.h"
+#include <limits.h>
 
 #define ENC_ERR(...) do { fprintf(stderr, "[oracle hevc_enc] " __VA_ARGS__); fprintf(stderr, "\n"); } while (0)
 
@@ -115,6 +121,13 @@ typedef struct {
   int16_t lvl[3][64 * 64];     /* levels of the current CU, plane stride 64 */
   /* product-mode analysis of the current CTB */
   uint8_t an_mode[4][64]; int an_cost[4][64]; uint8_t an_split[4][64];   /* [size idx 0:8 1:16 2:32 3:64][block] */
+  /* HM-like mode (hm_like) */
+  int hm, hm_pass, in_trial, hm_force_intra;
+  struct { long ts, tb4, nxn, cu_intra, cu_inter, cu_skip, tu_split, part2, amp, merge, amvp, frac_mv, nonzero_mv, sao_band, sao_edge, sao_merge, sao_off, intra_in_p; } hs;   /* tool usage (ORACLE_HM_STATS=1 prints it) */
+  struct { uint8_t split, intra, part; int16_t mv[2][2]; } hn[4][64];   /* P pictures: decision per CU node [size idx][block] */
+  uint8_t hm_nxn[64], hm_nxn_mode[64][4], hm_chroma[3][64];               /* intra: NxN at 8x8, chroma mode index per block */
+  int64_t last_ssd; int last_bits;                                         /* of the last recon_tb call */
+  hevc_sao* hm_sao;                                                        /* decided SAO parameters per CTB (pass 2) */
   /* history */
   hevc_frame* dpb[2]; hevc_colinfo dpbcol[2]; int dpb_poc[2]; int n_dpb;
 } enc;
@@ -204,6 +217,7 @@ static void write_param_sets(enc* e, bytebuf* out) {
   emit_nal(out, NAL_PPS, w.bb.d, w.bb.n, 1);
   free(w.bb.d);
 }
+static inline int64_t imin64(int64_t a, int64_t b) { return a < b ? a : b; }
 static int ceil_log2(unsigned v) { int n = 0; while ((1u << n) < v) n++; return n; }
 static void write_slice_header(enc* e, bitwriter* w, int first, int ctb_addr) {
   hevc_sps* s = &e->sps; hevc_pps* p = &e->pps; hevc_slice_hdr* h = &e->sh;
@@ -393,6 +407,59 @@ static void random_levels(enc* e, int log2, int16_t* lv, int st) {
     lv[y * st + x] = (int16_t)(rndp(&e->r, 50) ? -v : v);
   }
 }
+/* ---- HM-like mode helpers ---- */
+static int ilog2u(unsigned v) { int n = 0; while (v > 1) { v >>= 1; n++; } return n; }
+static int hm_level_bits(const int16_t* lq, int n) {   /* rough rate of a TB's levels: position + magnitude + sign per non-zero level */
+  int b = 0;
+  for (int i = 0; i < n; i++) { int a = iabs(lq[i]); if (a) b += 3 + 2 * ilog2u((unsigned)a); }
+  return b ? b + 3 : 1;
+}
+static int64_t hm_lambda256(enc* e) { int64_t l = k_lambda16[clip3(0, 75, e->slice_qp + 6 * (e->sps.bit_depth - 8))]; return l * l; }   /* lambda_ssd * 256 */
+/* sign data hiding, encoder side (9.3.4.3 / 7.4.9.11): where the decoder will infer the sign of the lowest-frequency level of a coefficient
+ * group from the parity of the group's sum, make the parity agree by changing the magnitude of the group's highest-frequency level by one */
+static void hm_sign_hide(enc* e, int log2, int scan_idx, int16_t* coeff, int st) {
+  const uint8_t* sb_scan = e->scan[scan_idx][log2 - 2];
+  const uint8_t* pos_scan = e->scan[scan_idx][2];
+  int n_sb = 1 << (2 * (log2 - 2));
+  for (int i = 0; i < n_sb; i++) {
+    int xs = sb_scan[i] & 15, ys = sb_scan[i] >> 4, first = -1, last = -1, sum = 0;
+    for (int n = 0; n < 16; n++) {
+      int v = coeff[((ys << 2) + (pos_scan[n] >> 4)) * st + (xs << 2) + (pos_scan[n] & 15)];
+      if (v) { if (first < 0) first = n; last = n; sum += iabs(v); }
+    }
+    if (first < 0 || last - first <= 3) continue;
+    int vf = coeff[((ys << 2) + (pos_scan[first] >> 4)) * st + (xs << 2) + (pos_scan[first] & 15)];
+    if ((sum & 1) == (vf < 0)) continue;
+    int16_t* q = &coeff[((ys << 2) + (pos_scan[last] >> 4)) * st + (xs << 2) + (pos_scan[last] & 15)];
+    int a = iabs(*q); a = a > 1 ? a - 1 : 2;
+    *q = (int16_t)(*q < 0 ? -a : a);
+  }
+}
+/* after the regular transform + quantisation of a TB (levels in lq, N x N): sign hiding, and for 4x4 TBs the choice between the
+ * transform and transform skip (7.3.8.11 transform_skip_flag) by distortion + lambda * rate. Returns cbf. */
+static int hm_tb_finish(enc* e, int c_idx, int log2, int intra_mode, int qp, int is_dst, const int16_t* res, int16_t* lq, int* ts_out) {
+  int N = 1 << log2, NN = N * N, bd = e->sps.bit_depth;
+  int scan_idx = tb_scan_idx(e->cu_pred_mode, log2, c_idx, intra_mode);
+  if (e->pps.sign_data_hiding) hm_sign_hide(e, log2, scan_idx, lq, N);
+  *ts_out = 0;
+  if (log2 == 2 && e->pps.transform_skip_enabled) {
+    int16_t ct[16], lt[16], dq[16], r0[16], r1[16];
+    int tsh = 15 - bd - log2;
+    for (int i = 0; i < NN; i++) ct[i] = (int16_t)clip3(-32768, 32767, res[i] << tsh);
+    hevc_quant(ct, lt, log2, qp, bd, e->cu_pred_mode == MODE_INTRA);
+    if (e->pps.sign_data_hiding) hm_sign_hide(e, log2, scan_idx, lt, N);
+    int64_t d0 = 0, d1 = 0, lam = hm_lambda256(e);
+    hevc_dequant(lq, dq, log2, qp, bd); hevc_inv_transform(dq, r0, log2, is_dst, bd);
+    hevc_dequant(lt, dq, log2, qp, bd); hevc_inv_transform_skip(dq, r1, log2, bd);
+    for (int i = 0; i < NN; i++) { int a = res[i] - r0[i], b = res[i] - r1[i]; d0 += a * a; d1 += b * b; }
+    int64_t c0 = d0 * 256 + lam * hm_level_bits(lq, NN), c1 = d1 * 256 + lam * (hm_level_bits(lt, NN) + 1);
+    int nz1 = 0; for (int i = 0; i < NN; i++) nz1 |= lt[i] != 0;
+    if (nz1 && c1 < c0) { memcpy(lq, lt, sizeof(lt)); *ts_out = 1; }
+  }
+  int cbf = 0; for (int i = 0; i < NN; i++) cbf |= lq[i] != 0;
+  return cbf;
+}
+
 /* predicts (intra), derives levels (product: residual->T->Q; stress: random) and reconstructs one TB.
  * Returns cbf. Levels are left in e->lvl[c_idx] at the TB's offset inside the CU (stride 64). */
 static int recon_tb(enc* e, int c_idx, int x0, int y0, int log2, int intra_mode, int* ts_out) {
@@ -416,16 +483,20 @@ static int recon_tb(enc* e, int c_idx, int x0, int y0, int log2, int intra_mode,
     for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) res[y * N + x] = (int16_t)((int)sp[(size_t)y * pw + x] - (int)p[(size_t)y * pw + x]);
     if (e->cu_tq_bypass) { memcpy(lq, res, sizeof(int16_t) * N * N); for (int i = 0; i < N * N; i++) cbf |= lq[i] != 0; }
     else { hevc_fwd_transform(res, coef, log2, is_dst, bd); cbf = hevc_quant(coef, lq, log2, qp, bd, e->cu_pred_mode == MODE_INTRA) != 0; }
+    if (e->hm && !e->cu_tq_bypass) { cbf = hm_tb_finish(e, c_idx, log2, intra_mode, qp, is_dst, res, lq, &ts); if (!e->in_trial && e->hm_pass != 1 && log2 == 2 && cbf) { e->hs.tb4++; e->hs.ts += ts; } }
     for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) lv[y * 64 + x] = lq[y * N + x];
   }
   *ts_out = ts;
+  if (e->hm) { e->last_bits = hm_level_bits(lq, N * N); e->last_ssd = 0; if (!cbf) for (int i = 0; i < N * N; i++) e->last_ssd += (int64_t)res[i] * res[i]; }
   if (!cbf) return 0;
+  int16_t res_src[32 * 32]; if (e->hm) memcpy(res_src, res, sizeof(int16_t) * N * N);
   if (e->cu_tq_bypass) memcpy(res, lq, sizeof(int16_t) * N * N);
   else {
     hevc_dequant(lq, dq, log2, qp, bd);
     if (ts) hevc_inv_transform_skip(dq, res, log2, bd); else hevc_inv_transform(dq, res, log2, is_dst, bd);
   }
   for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) p[(size_t)y * pw + x] = (uint16_t)clip3(0, maxv, p[(size_t)y * pw + x] + res[y * N + x]);
+  if (e->hm) for (int i = 0; i < N * N; i++) { int d = res_src[i] - res[i]; e->last_ssd += (int64_t)d * d; }
   return 1;
 }
 
@@ -439,6 +510,33 @@ static void start_quant_group(enc* e, int xqg, int yqg) {
   e->qp_pred = (qa + qb + 1) >> 1;
 }
 
+/* HM-like: split_transform_flag of the luma TB at (x0,y0) by coding it both ways on the reconstruction (luma only) and comparing
+ * distortion + lambda * rate; the picture area and the intra availability marks are put back afterwards */
+static int hm_decide_tu_split(enc* e, int x0, int y0, int log2) {
+  hevc_frame* f = e->rec; hevc_meta* m = e->m; int N = 1 << log2, h = N >> 1, ts;
+  int intra = e->cu_pred_mode == MODE_INTRA, nxn = intra && e->cu_part_mode == PART_NxN, half_cu = 1 << (e->cu_log2 - 1);
+  static uint16_t save[32 * 32]; static int16_t lsave[32 * 32];
+  int16_t* lv0 = e->lvl[0] + (y0 - e->cu_y) * 64 + (x0 - e->cu_x);
+  for (int y = 0; y < N; y++) { memcpy(save + y * N, f->p[0] + (size_t)(y0 + y) * f->w + x0, (size_t)N * 2); memcpy(lsave + y * N, lv0 + y * 64, (size_t)N * 2); }
+  int64_t lam = hm_lambda256(e), c_whole, c_split = lam * 3;
+  e->in_trial = 1;
+  int part = nxn ? ((y0 - e->cu_y) >= half_cu ? 2 : 0) + ((x0 - e->cu_x) >= half_cu ? 1 : 0) : 0;
+  recon_tb(e, 0, x0, y0, log2, e->intra_luma[part], &ts);
+  c_whole = e->last_ssd * 256 + lam * e->last_bits;
+  for (int y = 0; y < N; y++) memcpy(f->p[0] + (size_t)(y0 + y) * f->w + x0, save + y * N, (size_t)N * 2);
+  for (int b = 0; b < 4; b++) {
+    int xs = x0 + (b & 1) * h, ys = y0 + (b >> 1) * h;
+    int pp = nxn ? ((ys - e->cu_y) >= half_cu ? 2 : 0) + ((xs - e->cu_x) >= half_cu ? 1 : 0) : 0;
+    recon_tb(e, 0, xs, ys, log2 - 1, e->intra_luma[pp], &ts);
+    c_split += e->last_ssd * 256 + lam * e->last_bits;
+    if (intra) set_rect8(m->done, m->w4, xs, ys, h, h, 1);
+  }
+  if (intra) set_rect8(m->done, m->w4, x0, y0, N, N, 0);
+  for (int y = 0; y < N; y++) { memcpy(f->p[0] + (size_t)(y0 + y) * f->w + x0, save + y * N, (size_t)N * 2); memcpy(lv0 + y * 64, lsave + y * N, (size_t)N * 2); }
+  e->in_trial = 0;
+  return c_split < c_whole;
+}
+
 /* recon phase of the transform tree; returns node index. Parent cbf_cb/cbf_cr = OR over children. */
 static int tt_recon(enc* e, int x0, int y0, int xb, int yb, int log2, int depth, int blk, int* cb_out, int* cr_out) {
   hevc_meta* m = e->m; const hevc_sps* sps = &e->sps;
@@ -448,9 +546,10 @@ static int tt_recon(enc* e, int x0, int y0, int xb, int yb, int log2, int depth,
   int inter_split = sps->max_th_depth_inter == 0 && e->cu_pred_mode != MODE_INTRA && e->cu_part_mode != PART_2Nx2N && depth == 0;
   int split;
   if (log2 <= sps->log2_max_tb && log2 > sps->log2_min_tb && depth < e->max_trafo_depth && !(intra_split && depth == 0))
-    split = e->stress ? rndp(&e->r, 35) : 0;
+    split = e->stress ? rndp(&e->r, 35) : (e->hm && !e->in_trial && depth < 2 ? hm_decide_tu_split(e, x0, y0, log2) : 0);
   else split = (log2 > sps->log2_max_tb || (intra_split && depth == 0) || inter_split) ? 1 : 0;
   nd->split = (uint8_t)split;
+  if (split && e->hm && e->hm_pass != 1 && log2 <= sps->log2_max_tb && !(intra_split && depth == 0)) e->hs.tu_split++;
   if (split) {
     int h = 1 << (log2 - 1), cb = 0, cr = 0, a, b;
     tt_recon(e, x0, y0, x0, y0, log2 - 1, depth + 1, 0, &a, &b); cb |= a; cr |= b;
@@ -530,11 +629,30 @@ static void write_mvd_comp_rest(cabac_enc* c, int d) {
   ce_bypass(c, d < 0);
 }
 /* decides (stress: random; product: merge idx 0 = zero motion) and performs prediction of one PU */
-static void pu_decide_predict(enc* e, pu_t* pu, int part_idx, int skip) {
+static int mvd_bits(int d) { int a = iabs(d); return a ? 2 + 2 * ilog2u((unsigned)a) + 1 : 1; }
+static void pu_decide_predict(enc* e, pu_t* pu, int part_idx, int skip, const int16_t* want_mv) {
   hevc_meta* m = e->m;
   e->mp.part_mode = e->cu_part_mode;
   pu->merge = skip ? 1 : (e->stress ? rndp(&e->r, 50) : 1);
-  if (pu->merge) {
+  if (e->hm) {
+    /* the motion search chose the vector: code it as a merge index when a merging candidate carries it, else by AMVP with the predictor
+     * that leaves the shorter difference */
+    pu->merge = 0;
+    for (int i = 0; i < e->sh.max_merge_cand && !pu->merge; i++) {
+      hevc_mvcand c = hevc_merge_candidate(&e->mp, pu->x, pu->y, pu->w, pu->h, part_idx, i);
+      if (c.x == want_mv[0] && c.y == want_mv[1] && c.ref == 0) { pu->merge = 1; pu->merge_idx = i; pu->mv = c; }
+    }
+    if (!pu->merge) {
+      int best = 1 << 30;
+      for (int fl = 0; fl < 2; fl++) {
+        hevc_mvcand pr = hevc_amvp_candidate(&e->mp, pu->x, pu->y, pu->w, pu->h, 0, fl);
+        int b = mvd_bits(want_mv[0] - pr.x) + mvd_bits(want_mv[1] - pr.y);
+        if (b < best) { best = b; pu->mvp_flag = fl; pu->mvd_x = want_mv[0] - pr.x; pu->mvd_y = want_mv[1] - pr.y; }
+      }
+      pu->ref_idx = 0; pu->mv.x = want_mv[0]; pu->mv.y = want_mv[1]; pu->mv.ref = 0;
+    }
+    if (e->hm_pass != 1) { if (pu->merge) e->hs.merge++; else e->hs.amvp++; if (want_mv[0] | want_mv[1]) e->hs.nonzero_mv++; if ((want_mv[0] | want_mv[1]) & 3) e->hs.frac_mv++; }
+  } else if (pu->merge) {
     pu->merge_idx = e->stress ? rndn(&e->r, e->sh.max_merge_cand) : 0;
     pu->mv = hevc_merge_candidate(&e->mp, pu->x, pu->y, pu->w, pu->h, part_idx, pu->merge_idx);
     if (!e->stress && (pu->mv.x || pu->mv.y || pu->mv.ref)) ENC_ERR("product encoder: merge candidate 0 is not zero motion");
@@ -577,7 +695,7 @@ static void pu_write(enc* e, const pu_t* pu, int skip) {
 }
 
 /* ================================================================================================ coding unit */
-typedef struct { int pred_mode, part_mode, skip, tq_bypass; int intra_luma[4]; int intra_chroma_idx; } cu_decision;
+typedef struct { int pred_mode, part_mode, skip, tq_bypass; int intra_luma[4]; int intra_chroma_idx; int16_t mv[4][2]; } cu_decision;
 
 static void encode_cu(enc* e, int x0, int y0, int log2, int depth, const cu_decision* d) {
   cabac_enc* c = &e->c; hevc_meta* m = e->m; const hevc_sps* sps = &e->sps;
@@ -624,7 +742,7 @@ static void encode_cu(enc* e, int x0, int y0, int log2, int depth, const cu_deci
     for (int i = 0; i < np; i++) {
       pu_t* pu = &e->pu[e->n_pu++]; memset(pu, 0, sizeof(*pu));
       pu->x = x0 + geo[d->part_mode][i][0]; pu->y = y0 + geo[d->part_mode][i][1]; pu->w = geo[d->part_mode][i][2]; pu->h = geo[d->part_mode][i][3];
-      pu_decide_predict(e, pu, i, d->skip);
+      pu_decide_predict(e, pu, i, d->skip, d->mv[i]);
     }
   }
   int any_cbf = 0;
@@ -764,6 +882,257 @@ static void analyse_ctb_intra(enc* e, int cx, int cy) {
   }
 }
 
+/* ================================================================================================ HM-like analysis */
+static int hm_lam16(enc* e) { return k_lambda16[clip3(0, 75, e->slice_qp + 6 * (e->sps.bit_depth - 8))]; }
+static const int k_chroma_cand[4] = {0, 26, 10, 1};
+static int chroma_mode_of(int idx, int luma) { return idx == 4 ? luma : (k_chroma_cand[idx] == luma ? 34 : k_chroma_cand[idx]); }
+/* Intra candidates of every block of the CTB (sizes 8, 16, 32; 4x4 partitions of the 8x8 blocks): all 35 modes, predicted open-loop from
+ * SOURCE neighbours, cost = 16 * SAD + lambda * mode bits (kept in an_cost / an_mode); chroma mode = the cheapest of the five candidates. */
+static void hm_analyse_intra(enc* e, int cx, int cy) {
+  hevc_meta* m = e->m; const hevc_sps* sps = &e->sps;
+  int ctb = 1 << sps->log2_ctb, lam = hm_lam16(e);
+  hevc_frame srcview = *e->src;
+  uint16_t pred[32 * 32];
+  for (int si = 0; si < 3; si++) {
+    int S = 8 << si; if (S > ctb) break;
+    int nb = ctb / S;
+    for (int z = 0; z < nb * nb; z++) {
+      int bx = 0, by = 0;
+      for (int b = 0; b < 4; b++) { bx |= ((z >> (2 * b)) & 1) << b; by |= ((z >> (2 * b + 1)) & 1) << b; }
+      int x0 = cx + bx * S, y0 = cy + by * S, bi = by * nb + bx;
+      e->an_cost[si][bi] = 0x7FFFFFFF; e->an_mode[si][bi] = 0; e->hm_chroma[si][bi] = 4; if (si == 0) e->hm_nxn[bi] = 0;
+      if (x0 >= sps->width || y0 >= sps->height) { e->an_cost[si][bi] = 0; continue; }
+      if (x0 + S > sps->width || y0 + S > sps->height) { e->an_cost[si][bi] = 0x0FFFFFFF; set_rect8(m->done, m->w4, x0, y0, imin(S, sps->width - x0), imin(S, sps->height - y0), 1); continue; }
+      const uint16_t* sp = e->src->p[0] + (size_t)y0 * e->src->w + x0;
+      for (int mode = 0; mode < 35; mode++) {
+        hevc_intra_pred_buf(&srcview, m, 0, x0, y0, 3 + si, mode, pred);
+        int sad = 0;
+        for (int y = 0; y < S; y++) for (int x = 0; x < S; x++) sad += iabs((int)sp[(size_t)y * e->src->w + x] - (int)pred[y * S + x]);
+        int c = sad * 16 + lam * (mode < 2 ? 2 : 5);
+        if (c < e->an_cost[si][bi]) { e->an_cost[si][bi] = c; e->an_mode[si][bi] = (uint8_t)mode; }
+      }
+      if (si == 0) {   /* NxN: four 4x4 prediction blocks */
+        int tot = lam * 4;
+        for (int q = 0; q < 4; q++) {
+          int xq = x0 + (q & 1) * 4, yq = y0 + (q >> 1) * 4, best = 0x7FFFFFFF, bm = 0;
+          const uint16_t* sq = e->src->p[0] + (size_t)yq * e->src->w + xq;
+          for (int mode = 0; mode < 35; mode++) {
+            hevc_intra_pred_buf(&srcview, m, 0, xq, yq, 2, mode, pred);
+            int sad = 0;
+            for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) sad += iabs((int)sq[(size_t)y * e->src->w + x] - (int)pred[y * 4 + x]);
+            int c = sad * 16 + lam * (mode < 2 ? 2 : 5);
+            if (c < best) { best = c; bm = mode; }
+          }
+          e->hm_nxn_mode[bi][q] = (uint8_t)bm; tot += best;
+          set_rect8(m->done, m->w4, xq, yq, 4, 4, 1);
+        }
+        set_rect8(m->done, m->w4, x0, y0, 8, 8, 0);
+        if (tot < e->an_cost[0][bi]) { e->an_cost[0][bi] = tot; e->hm_nxn[bi] = 1; }
+      }
+      /* chroma prediction mode (intra_chroma_pred_mode 0..3 = planar / vertical / horizontal / DC, 4 = the luma mode) */
+      int luma = (si == 0 && e->hm_nxn[bi]) ? e->hm_nxn_mode[bi][0] : e->an_mode[si][bi], l2c = imax(2, 2 + si), Sc = 1 << l2c, bestc = 0x7FFFFFFF;
+      for (int idx = 4; idx >= 0; idx--) {
+        int cm = chroma_mode_of(idx, luma), sad = 0;
+        for (int ci = 1; ci < 3; ci++) {
+          hevc_intra_pred_buf(&srcview, m, ci, x0 >> 1, y0 >> 1, l2c, cm, pred);
+          const uint16_t* sc = e->src->p[ci] + (size_t)(y0 >> 1) * e->src->cw + (x0 >> 1);
+          for (int y = 0; y < Sc; y++) for (int x = 0; x < Sc; x++) sad += iabs((int)sc[(size_t)y * e->src->cw + x] - (int)pred[y * Sc + x]);
+        }
+        int c = sad * 16 + lam * (idx == 4 ? 1 : 3);
+        if (c < bestc) { bestc = c; e->hm_chroma[si][bi] = (uint8_t)idx; }
+      }
+      set_rect8(m->done, m->w4, x0, y0, S, S, 1);
+    }
+    set_rect8(m->done, m->w4, cx, cy, imin(ctb, sps->width - cx), imin(ctb, sps->height - cy), 0);
+  }
+  int pen = (lam * SPLIT_BITS) >> 4;
+  for (int si = 1; si < 3; si++) {
+    int S = 8 << si; if (S > ctb) break;
+    int nb = ctb / S, nbc = nb * 2;
+    for (int by = 0; by < nb; by++) for (int bx = 0; bx < nb; bx++) {
+      int bi = by * nb + bx;
+      int64_t child = (int64_t)e->an_cost[si - 1][(2 * by) * nbc + 2 * bx] + e->an_cost[si - 1][(2 * by) * nbc + 2 * bx + 1] +
+                      e->an_cost[si - 1][(2 * by + 1) * nbc + 2 * bx] + e->an_cost[si - 1][(2 * by + 1) * nbc + 2 * bx + 1] + pen * 16;
+      int split = child < e->an_cost[si][bi];
+      e->an_split[si][bi] = (uint8_t)split;
+      if (split) e->an_cost[si][bi] = (int)imin64(child, 0x0FFFFFFF);
+    }
+  }
+}
+
+/* ---- motion search (cfg/hm/ctc-hm-geometry-ai.cfg:33-36): integer full search in a small window, then half- and quarter-sample refinement ---- */
+static int sad_int(const hevc_frame* src, const hevc_frame* ref, int x, int y, int w, int h, int dx, int dy) {
+  int s = 0;
+  for (int j = 0; j < h; j++) {
+    int yy = clip3(0, ref->h - 1, y + j + dy);
+    const uint16_t* sp = src->p[0] + (size_t)(y + j) * src->w + x; const uint16_t* rp = ref->p[0] + (size_t)yy * ref->w;
+    for (int i = 0; i < w; i++) s += iabs((int)sp[i] - (int)rp[clip3(0, ref->w - 1, x + i + dx)]);
+  }
+  return s;
+}
+static int sad_frac(const hevc_frame* src, const hevc_frame* ref, int x, int y, int w, int h, int mvx, int mvy) {
+  static uint16_t pb[64 * 64];
+  hevc_mc_luma_buf(ref, x, y, w, h, mvx, mvy, pb);
+  int s = 0;
+  for (int j = 0; j < h; j++) { const uint16_t* sp = src->p[0] + (size_t)(y + j) * src->w + x; for (int i = 0; i < w; i++) s += iabs((int)sp[i] - (int)pb[j * w + i]); }
+  return s;
+}
+/* returns 16 * SAD + lambda * vector bits of the best vector found for the w x h block at (x,y); start / result in quarter samples */
+static int hm_me(enc* e, int x, int y, int w, int h, int sx, int sy, int range, int16_t mv[2]) {
+  const hevc_frame* src = e->src; const hevc_frame* ref = e->ref[0]; int lam = hm_lam16(e);
+  int s0 = sad_int(src, ref, x, y, w, h, 0, 0);
+  int best = s0 * 16 + lam * 2, bx = 0, by = 0, bsad = s0;
+  if (s0 * 2 <= w * h) { mv[0] = mv[1] = 0; return best; }          /* as good as it gets: keep the zero vector */
+  int cx0 = sx >> 2, cy0 = sy >> 2;
+  for (int dy = cy0 - range; dy <= cy0 + range; dy++) for (int dx = cx0 - range; dx <= cx0 + range; dx++) {
+    if (!dx && !dy) continue;
+    int sd = sad_int(src, ref, x, y, w, h, dx, dy), c = sd * 16 + lam * (mvd_bits(4 * dx) + mvd_bits(4 * dy));
+    if (c < best) { best = c; bx = dx; by = dy; bsad = sd; }
+  }
+  int mx = bx * 4, my = by * 4;
+  if (bsad > w * h) {
+    for (int step = 2; step >= 1; step--) {
+      int cxq = mx, cyq = my;
+      for (int dy = -step; dy <= step; dy += step) for (int dx = -step; dx <= step; dx += step) {
+        if (!dx && !dy) continue;
+        int sd = sad_frac(src, ref, x, y, w, h, cxq + dx, cyq + dy), c = sd * 16 + lam * (mvd_bits(cxq + dx) + mvd_bits(cyq + dy));
+        if (c < best) { best = c; mx = cxq + dx; my = cyq + dy; }
+      }
+    }
+  }
+  mv[0] = (int16_t)mx; mv[1] = (int16_t)my;
+  return best;
+}
+static const int8_t k_part_geo[8][2][4] = {   /* x, y, w, h of the prediction units in quarters of the CU size */
+  {{0, 0, 4, 4}, {0, 0, 0, 0}}, {{0, 0, 4, 2}, {0, 2, 4, 2}}, {{0, 0, 2, 4}, {2, 0, 2, 4}}, {{0, 0, 0, 0}, {0, 0, 0, 0}},
+  {{0, 0, 4, 1}, {0, 1, 4, 3}}, {{0, 0, 4, 3}, {0, 3, 4, 1}}, {{0, 0, 1, 4}, {1, 0, 3, 4}}, {{0, 0, 3, 4}, {3, 0, 1, 4}}};
+/* P pictures: decides the CU quadtree under the node at (x0,y0), top-down; returns its cost (16 * SAD + lambda * bits) */
+static int64_t hm_inter_decide(enc* e, int x0, int y0, int log2, int cx, int cy) {
+  const hevc_sps* sps = &e->sps; int N = 1 << log2, si = log2 - 3, nb = (1 << sps->log2_ctb) / N, bi = ((y0 - cy) / N) * nb + (x0 - cx) / N, lam = hm_lam16(e);
+  memset(&e->hn[si][bi], 0, sizeof(e->hn[si][bi]));
+  if (x0 >= sps->width || y0 >= sps->height) return 0;
+  int inside = x0 + N <= sps->width && y0 + N <= sps->height;
+  int64_t here = INT64_MAX;
+  if (inside) {
+    int16_t mv[2], mv2[2][2];
+    int c = hm_me(e, x0, y0, N, N, 0, 0, 4, mv);
+    here = c; e->hn[si][bi].part = PART_2Nx2N; e->hn[si][bi].mv[0][0] = mv[0]; e->hn[si][bi].mv[0][1] = mv[1];
+    int sad0 = c / 16;
+    if (sad0 > 2 * N * N) {                 /* the whole block does not predict well: two prediction units, symmetric and asymmetric (AMP) */
+      for (int pm = PART_2NxN; pm <= PART_nRx2N; pm++) {
+        if (pm == PART_NxN) continue;
+        if (pm >= PART_2NxnU && (!sps->amp_enabled || log2 == sps->log2_min_cb)) continue;
+        int64_t t = lam * (pm >= PART_2NxnU ? 4 : 2);
+        for (int k = 0; k < 2; k++) {
+          const int8_t* g = k_part_geo[pm][k];
+          t += hm_me(e, x0 + g[0] * N / 4, y0 + g[1] * N / 4, g[2] * N / 4, g[3] * N / 4, mv[0], mv[1], 2, mv2[k]);
+        }
+        if (t < here) { here = t; e->hn[si][bi].part = (uint8_t)pm; memcpy(e->hn[si][bi].mv, mv2, sizeof(mv2)); }
+      }
+    }
+    /* intra in a P picture: the open-loop cost flatters it (real neighbours are reconstructed, not source), so it has to win clearly */
+    int64_t ic = log2 <= 5 && e->an_cost[si][bi] < 0x0FFFFFFF ? (int64_t)e->an_cost[si][bi] * 3 / 2 + lam * 8 : INT64_MAX;
+    if (ic < here) { here = ic; e->hn[si][bi].intra = 1; }
+    if (log2 == sps->log2_min_cb || here <= (int64_t)8 * N * N + lam * 2) return here;   /* smallest CU, or a match good enough to stop (average error 1/2) */
+  }
+  int h = N >> 1;
+  int64_t sp = (int64_t)lam * 2 + hm_inter_decide(e, x0, y0, log2 - 1, cx, cy) + hm_inter_decide(e, x0 + h, y0, log2 - 1, cx, cy) +
+               hm_inter_decide(e, x0, y0 + h, log2 - 1, cx, cy) + hm_inter_decide(e, x0 + h, y0 + h, log2 - 1, cx, cy);
+  if (!inside || sp < here) { e->hn[si][bi].split = 1; return sp; }
+  return here;
+}
+
+/* ---- SAO parameter decision (cfg/hm/ctc-hm-geometry-ai.cfg:68): per CTB and component, offsets from the statistics of source minus deblocked
+ * reconstruction, band or one of the four edge classes by distortion reduction minus lambda * rate ---- */
+static void hm_sao_decide(enc* e) {
+  hevc_meta* m = e->m; const hevc_frame* rec = e->rec; const hevc_frame* src = e->src;
+  int bd = rec->bit_depth, ctb = 1 << m->log2_ctb;
+  int64_t lam = hm_lambda256(e);
+  static const int8_t eo_dx[4][2] = {{-1, 1}, {0, 0}, {-1, 1}, {1, -1}};
+  static const int8_t eo_dy[4][2] = {{0, 0}, {-1, 1}, {-1, 1}, {-1, 1}};
+  for (int cyi = 0; cyi < m->h_ctb; cyi++) for (int cxi = 0; cxi < m->w_ctb; cxi++) {
+    hevc_sao* out = &e->hm_sao[cyi * m->w_ctb + cxi]; memset(out, 0, sizeof(*out));
+    int64_t gain[3][6]; int offs[3][6][4], bpos[3];   /* [component][0 = band, 1..4 = edge class 0..3] */
+    for (int c = 0; c < 3; c++) {
+      int sh = c ? 1 : 0, pw = c ? rec->cw : rec->w, ph = c ? rec->ch : rec->h;
+      int x0 = (cxi * ctb) >> sh, y0 = (cyi * ctb) >> sh, x1 = imin(pw, x0 + (ctb >> sh)), y1 = imin(ph, y0 + (ctb >> sh));
+      const uint16_t* rp = rec->p[c]; const uint16_t* sp = src->p[c];
+      int64_t bsum[32], ecnt[4][4], esum[4][4]; int bcnt[32];
+      memset(bsum, 0, sizeof(bsum)); memset(bcnt, 0, sizeof(bcnt)); memset(ecnt, 0, sizeof(ecnt)); memset(esum, 0, sizeof(esum));
+      for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++) {
+        int v = rp[(size_t)y * pw + x], d = (int)sp[(size_t)y * pw + x] - v;
+        bcnt[v >> (bd - 5)]++; bsum[v >> (bd - 5)] += d;
+        for (int cls = 0; cls < 4; cls++) {
+          int xa = x + eo_dx[cls][0], ya = y + eo_dy[cls][0], xb = x + eo_dx[cls][1], yb = y + eo_dy[cls][1];
+          if (xa < 0 || ya < 0 || xb < 0 || yb < 0 || xa >= pw || xb >= pw || ya >= ph || yb >= ph) continue;
+          int va = rp[(size_t)ya * pw + xa], vb = rp[(size_t)yb * pw + xb];
+          int k = 2 + (v > va) - (v < va) + (v > vb) - (v < vb);
+          if (k == 2) continue;
+          int cat = k < 2 ? k : k - 1;     /* 0: local minimum, 1: concave corner, 2: convex corner, 3: local maximum = offset index */
+          ecnt[cls][cat]++; esum[cls][cat] += d;
+        }
+      }
+      /* band offset: the four consecutive bands with the largest gain */
+      int64_t bg[32]; int bo[32];
+      for (int b = 0; b < 32; b++) {
+        int o = bcnt[b] ? (int)((bsum[b] >= 0 ? bsum[b] + bcnt[b] / 2 : bsum[b] - bcnt[b] / 2) / bcnt[b]) : 0; o = clip3(-7, 7, o);
+        bo[b] = o; bg[b] = 2 * (int64_t)o * bsum[b] - (int64_t)bcnt[b] * o * o;
+      }
+      gain[c][0] = -1; bpos[c] = 0;
+      for (int b = 0; b <= 28; b++) { int64_t g = bg[b] + bg[b + 1] + bg[b + 2] + bg[b + 3]; if (g > gain[c][0]) { gain[c][0] = g; bpos[c] = b; } }
+      for (int k = 0; k < 4; k++) offs[c][0][k] = bo[bpos[c] + k];
+      gain[c][0] = gain[c][0] * 256 - lam * 18;
+      for (int cls = 0; cls < 4; cls++) {
+        int64_t g = 0;
+        for (int k = 0; k < 4; k++) {
+          int o = ecnt[cls][k] ? (int)((esum[cls][k] >= 0 ? esum[cls][k] + ecnt[cls][k] / 2 : esum[cls][k] - ecnt[cls][k] / 2) / ecnt[cls][k]) : 0;
+          o = k < 2 ? clip3(0, 7, o) : clip3(-7, 0, o);
+          offs[c][1 + cls][k] = o; g += 2 * (int64_t)o * esum[cls][k] - ecnt[cls][k] * (int64_t)o * o;
+        }
+        gain[c][1 + cls] = g * 256 - lam * 12;
+      }
+    }
+    /* luma on its own; Cb and Cr share type and edge class (7.3.8.3) */
+    int bt = -1; int64_t bgn = 0;
+    for (int t = 0; t < 5; t++) if (gain[0][t] > bgn) { bgn = gain[0][t]; bt = t; }
+    if (bt >= 0) { out->type[0] = bt == 0 ? 1 : 2; out->band_pos[0] = (uint8_t)bpos[0]; out->eo_class[0] = (uint8_t)(bt ? bt - 1 : 0); for (int k = 0; k < 4; k++) out->offset[0][k] = (int8_t)offs[0][bt][k]; }
+    bt = -1; bgn = 0;
+    for (int t = 0; t < 5; t++) if (gain[1][t] + gain[2][t] > bgn) { bgn = gain[1][t] + gain[2][t]; bt = t; }
+    if (bt >= 0) for (int c = 1; c < 3; c++) { out->type[c] = bt == 0 ? 1 : 2; out->band_pos[c] = (uint8_t)bpos[c]; out->eo_class[c] = (uint8_t)(bt ? bt - 1 : 0); for (int k = 0; k < 4; k++) out->offset[c][k] = (int8_t)offs[c][bt][k]; }
+    /* a type whose offsets are all zero costs bits for nothing */
+    for (int c = 0; c < 3; c++) { int any = 0; for (int k = 0; k < 4; k++) any |= out->offset[c][k]; if (!any && c != 2) { if (c == 0) out->type[0] = 0; else if (!(out->offset[2][0] | out->offset[2][1] | out->offset[2][2] | out->offset[2][3])) out->type[1] = out->type[2] = 0; } }
+    for (int c = 0; c < 3; c++) if (!out->type[c]) { out->band_pos[c] = 0; out->eo_class[c] = 0; memset(out->offset[c], 0, 4); }
+    if (out->type[1] != 2) out->eo_class[1] = out->eo_class[2] = 0;
+  }
+}
+/* sao() syntax of one CTB from decided parameters (7.3.8.3): merge with the left / upper CTB when they carry the same parameters */
+static void hm_write_sao(enc* e, int rx, int ry) {
+  hevc_meta* m = e->m; cabac_enc* c = &e->c;
+  hevc_sao* p = &m->sao[ry * m->w_ctb + rx];
+  memset(p, 0, sizeof(*p));
+  if (!e->sh.sao_luma && !e->sh.sao_chroma) return;
+  const hevc_sao* want = &e->hm_sao[ry * m->w_ctb + rx];
+  int can_left = rx > 0 && m->ctb_slice[ry * m->w_ctb + rx - 1] == e->slice_idx;
+  int can_up = ry > 0 && m->ctb_slice[(ry - 1) * m->w_ctb + rx] == e->slice_idx;
+  int merge_left = can_left && !memcmp(want, &m->sao[ry * m->w_ctb + rx - 1], sizeof(*want));
+  int merge_up = !merge_left && can_up && !memcmp(want, &m->sao[(ry - 1) * m->w_ctb + rx], sizeof(*want));
+  if (can_left) ce_bin(c, CTX_SAO_MERGE, merge_left);
+  if (can_up && !merge_left) ce_bin(c, CTX_SAO_MERGE, merge_up);
+  *p = *want;
+  if (merge_left || merge_up) { e->hs.sao_merge++; return; }
+  for (int ci = 0; ci < 2; ci++) { if (p->type[ci] == 1) e->hs.sao_band++; else if (p->type[ci] == 2) e->hs.sao_edge++; else e->hs.sao_off++; }
+  int bd = e->sps.bit_depth, cmax = (1 << (imin(bd, 10) - 5)) - 1;
+  for (int ci = 0; ci < 3; ci++) {
+    if (ci < 2) { int t = p->type[ci]; ce_bin(c, CTX_SAO_TYPE, t != 0); if (t) ce_bypass(c, t == 2); }
+    if (!p->type[ci]) continue;
+    for (int i = 0; i < 4; i++) { int a = iabs(p->offset[ci][i]); for (int k = 0; k < a; k++) ce_bypass(c, 1); if (a < cmax) ce_bypass(c, 0); }
+    if (p->type[ci] == 1) {
+      for (int i = 0; i < 4; i++) if (p->offset[ci][i]) ce_bypass(c, p->offset[ci][i] < 0);
+      ce_bypass_n(c, p->band_pos[ci], 5);
+    } else if (ci < 2) ce_bypass_n(c, p->eo_class[ci], 2);
+  }
+}
+
 /* ================================================================================================ quadtree */
 static void encode_quadtree(enc* e, int x0, int y0, int log2, int depth, int cx, int cy);
 
@@ -776,9 +1145,14 @@ static void encode_quadtree(enc* e, int x0, int y0, int log2, int depth, int cx,
   int split;
   cu_decision d; memset(&d, 0, sizeof(d));
   d.tq_bypass = e->p.lossless ? 1 : 0; d.intra_chroma_idx = 4; d.pred_mode = MODE_INTRA;
+  int hsi = log2 - 3, hnb = (1 << sps->log2_ctb) >> log2, hbi = ((y0 - cy) >> log2) * hnb + ((x0 - cx) >> log2);
+  int hm_intra_here = 0;      /* HM-like P picture: this node (and what is below it) is intra coded */
   if (e->stress) {
     split = can_flag ? rndp(&e->r, log2 >= 5 ? 70 : (log2 == 4 ? 45 : 30)) : 0;
-  } else if (e->sh.slice_type == SLICE_I) {
+  } else if (e->hm && e->sh.slice_type != SLICE_I && !e->hm_force_intra) {
+    split = e->hn[hsi][hbi].split;
+    if (!split && e->hn[hsi][hbi].intra) { hm_intra_here = 1; e->hm_force_intra = 1; split = log2 > 3 ? e->an_split[hsi][hbi] : 0; }
+  } else if (e->sh.slice_type == SLICE_I || e->hm_force_intra) {
     if (log2 > 5) split = 1;
     else if (log2 == 3) split = 0;
     else { int S = N, nb = (1 << sps->log2_ctb) / S; split = e->an_split[log2 - 3][((y0 - cy) / S) * nb + (x0 - cx) / S]; }
@@ -800,6 +1174,7 @@ static void encode_quadtree(enc* e, int x0, int y0, int log2, int depth, int cx,
     if (x0 + h < sps->width) encode_quadtree(e, x0 + h, y0, log2 - 1, depth + 1, cx, cy);
     if (y0 + h < sps->height) encode_quadtree(e, x0, y0 + h, log2 - 1, depth + 1, cx, cy);
     if (x0 + h < sps->width && y0 + h < sps->height) encode_quadtree(e, x0 + h, y0 + h, log2 - 1, depth + 1, cx, cy);
+    if (hm_intra_here) e->hm_force_intra = 0;
     return;
   }
   if (e->stress) {
@@ -819,11 +1194,22 @@ static void encode_quadtree(enc* e, int x0, int y0, int log2, int depth, int cx,
       for (int i = 0; i < 4; i++) d.intra_luma[i] = rndp(r, 25) ? rndn(r, 2) : rndn(r, 35);
       d.intra_chroma_idx = rndn(r, 5);
     }
-  } else if (e->sh.slice_type == SLICE_I) {
+  } else if (e->sh.slice_type == SLICE_I || e->hm_force_intra) {
     int S = N, nb = (1 << sps->log2_ctb) / S;
     d.intra_luma[0] = e->an_mode[log2 - 3][((y0 - cy) / S) * nb + (x0 - cx) / S];
+    if (e->hm) {
+      d.intra_chroma_idx = e->hm_chroma[hsi][hbi];
+      if (log2 == 3 && e->hm_nxn[hbi]) { d.part_mode = PART_NxN; for (int i = 0; i < 4; i++) d.intra_luma[i] = e->hm_nxn_mode[hbi][i]; }
+    }
+  } else if (e->hm) {
+    d.pred_mode = MODE_INTER; d.part_mode = e->hn[hsi][hbi].part; memcpy(d.mv, e->hn[hsi][hbi].mv, sizeof(e->hn[hsi][hbi].mv));
   } else { d.pred_mode = MODE_INTER; d.part_mode = PART_2Nx2N; d.skip = log2 > 4; }
   encode_cu(e, x0, y0, log2, depth, &d);
+  if (e->hm && e->hm_pass != 1) {
+    if (e->cu_skip) e->hs.cu_skip++; else if (e->cu_pred_mode == MODE_INTRA) { e->hs.cu_intra++; if (d.part_mode == PART_NxN) e->hs.nxn++; if (e->sh.slice_type != SLICE_I) e->hs.intra_in_p++; }
+    else { e->hs.cu_inter++; if (d.part_mode != PART_2Nx2N) e->hs.part2++; if (d.part_mode >= PART_2NxnU) e->hs.amp++; }
+  }
+  if (hm_intra_here) e->hm_force_intra = 0;
 }
 
 /* P pictures (product): zero-motion prediction from the reference; a 16x16 CU is a skip when all its quantised
@@ -911,6 +1297,14 @@ static void setup_stream(enc* e) {
   p->init_qp = clip3(0, 51, q->qp); p->loop_filter_across_slices = 1;
   e->max_merge_cand = 1;
   if (q->lossless) { p->transquant_bypass_enabled = 1; p->deblocking_control_present = 1; p->pps_deblocking_disabled = 1; p->loop_filter_across_slices = 0; }
+  if (e->hm) {   /* cfg/hm/ctc-hm-geometry-ai.cfg:10-16,47,68,69 + HM defaults (SignHideFlag, TMVPMode, MaxNumMergeCand) */
+    s->log2_ctb = q->log2_ctb ? q->log2_ctb : 6; s->log2_diff_max_min_cb = s->log2_ctb - 3;
+    s->log2_max_tb = imin(5, s->log2_ctb); s->log2_diff_max_min_tb = s->log2_max_tb - 2;
+    s->max_th_depth_inter = 2; s->max_th_depth_intra = 2;
+    s->amp_enabled = 1; s->sao_enabled = !q->lossless; s->strong_intra_smoothing = 1; s->temporal_mvp_enabled = 1;
+    p->sign_data_hiding = !q->lossless; p->transform_skip_enabled = !q->lossless;
+    e->max_merge_cand = 5;
+  }
   if (e->stress) {
     rng* r = &e->r;
     s->log2_ctb = q->log2_ctb ? q->log2_ctb : 4 + rndn(r, 3);
@@ -938,25 +1332,9 @@ static void setup_stream(enc* e) {
   s->pic_w_ctb = (s->width + (1 << s->log2_ctb) - 1) >> s->log2_ctb; s->pic_h_ctb = (s->height + (1 << s->log2_ctb) - 1) >> s->log2_ctb;
 }
 
-static void encode_picture(enc* e, const hevc_frame* src, int idx, bytebuf* out, hevc_frame** recon_out) {
+/* the slice segments of the current picture: headers, CTB loop (analysis, CU coding), NAL output */
+static void encode_slices(enc* e, int is_i, int st_rps_idx, bytebuf* out) {
   hevc_sps* s = &e->sps; hevc_pps* p = &e->pps; hevc_meta* m = e->m; rng* r = &e->r;
-  int is_i;
-  if (e->stress) is_i = idx == 0 || (idx % 5 == 0 && (e->p.stress_seed & 1));
-  else is_i = e->p.gop <= 1 || (idx % e->p.gop) == 0;
-  e->is_idr = is_i; e->slice_type = is_i ? SLICE_I : SLICE_P;
-  if (is_i) { e->poc = 0; e->n_dpb = 0; write_param_sets(e, out); } else e->poc++;
-  e->src = src; e->rec = hevc_frame_alloc(s->width, s->height, s->bit_depth);
-  hevc_meta_reset(m);
-  m->constrained_intra_pred = p->constrained_intra_pred; m->cb_qp_offset = p->cb_qp_offset; m->cr_qp_offset = p->cr_qp_offset; m->strong_intra_smoothing = s->strong_intra_smoothing;
-  /* reference list */
-  e->n_ref = 0;
-  int st_rps_idx = 0;
-  if (!is_i) {
-    int nref_avail = imin(e->n_dpb, e->two_refs ? 2 : 1);
-    st_rps_idx = nref_avail - 1;
-    for (int i = 0; i < nref_avail; i++) { e->ref[i] = e->dpb[i]; e->refcol[i] = &e->dpbcol[i]; e->ref_poc[i] = e->dpb_poc[i]; }
-    e->n_ref = nref_avail;
-  }
   int n_ctb = s->pic_w_ctb * s->pic_h_ctb, ctb = 1 << s->log2_ctb;
   int addr = 0;
   /* picture-level choices that must agree across the slices of a picture */
@@ -985,7 +1363,9 @@ static void encode_picture(enc* e, const hevc_frame* src, int idx, bytebuf* out,
       if (p->slice_chroma_qp_offsets_present) { h->cb_qp_offset = rndn(r, 5) - 2; h->cr_qp_offset = rndn(r, 5) - 2; }
       if (p->deblocking_override_enabled && rndp(r, 50)) { h->deblocking_disabled = rndp(r, 20); if (!h->deblocking_disabled) { h->beta_offset_div2 = rndn(r, 9) - 4; h->tc_offset_div2 = rndn(r, 9) - 4; } else { h->beta_offset_div2 = p->beta_offset_div2; h->tc_offset_div2 = p->tc_offset_div2; } }
       if (p->loop_filter_across_slices && (h->sao_luma || h->sao_chroma || !h->deblocking_disabled)) h->loop_filter_across_slices = rndp(r, 70);
-    } else h->qp = clip3(0, 51, is_i ? e->p.qp + e->p.i_qp_offset : e->p.qp);
+    } else h->qp = clip3(0, 51, is_i ? e->p.qp + e->p.i_qp_offset : e->p.qp + (e->hm ? e->p.p_qp_offset : 0));
+    if (e->hm && !is_i) { h->temporal_mvp = s->temporal_mvp_enabled; h->collocated_ref_idx = 0; }
+    if (e->hm && e->hm_pass == 2) { h->sao_luma = 1; h->sao_chroma = 1; }
     e->slice_qp = h->qp; e->slice_idx = m->n_slices++;
     hevc_slice_meta* sm = &m->slices[e->slice_idx]; memset(sm, 0, sizeof(*sm));
     sm->deblocking_disabled = (uint8_t)h->deblocking_disabled; sm->loop_filter_across = (uint8_t)h->loop_filter_across_slices;
@@ -1003,7 +1383,11 @@ static void encode_picture(enc* e, const hevc_frame* src, int idx, bytebuf* out,
       int rx = a % s->pic_w_ctb, ry = a / s->pic_w_ctb;
       m->ctb_slice[a] = (uint16_t)e->slice_idx;
       if (e->stress) write_sao(e, rx, ry);
-      else { if (is_i) analyse_ctb_intra(e, rx * ctb, ry * ctb); else analyse_ctb_inter(e, rx * ctb, ry * ctb); }
+      else if (e->hm) {
+        hm_write_sao(e, rx, ry);
+        hm_analyse_intra(e, rx * ctb, ry * ctb);
+        if (!is_i) hm_inter_decide(e, rx * ctb, ry * ctb, s->log2_ctb, rx * ctb, ry * ctb);
+      } else { if (is_i) analyse_ctb_intra(e, rx * ctb, ry * ctb); else analyse_ctb_inter(e, rx * ctb, ry * ctb); }
       encode_quadtree(e, rx * ctb, ry * ctb, s->log2_ctb, 0, rx * ctb, ry * ctb);
       ce_terminate(&e->c, a == end_addr - 1);
     }
@@ -1011,6 +1395,40 @@ static void encode_picture(enc* e, const hevc_frame* src, int idx, bytebuf* out,
     emit_nal(out, is_i ? NAL_IDR_W_RADL : NAL_TRAIL_R, e->c.w.bb.d, e->c.w.bb.n, addr == 0);
     addr = end_addr;
   }
+}
+
+static void encode_picture(enc* e, const hevc_frame* src, int idx, bytebuf* out, hevc_frame** recon_out) {
+  hevc_sps* s = &e->sps; hevc_pps* p = &e->pps; hevc_meta* m = e->m;
+  int is_i;
+  if (e->stress) is_i = idx == 0 || (idx % 5 == 0 && (e->p.stress_seed & 1));
+  else is_i = e->p.gop <= 1 || (idx % e->p.gop) == 0;
+  e->is_idr = is_i; e->slice_type = is_i ? SLICE_I : SLICE_P;
+  if (is_i) { e->poc = 0; e->n_dpb = 0; write_param_sets(e, out); } else e->poc++;
+  e->src = src; e->rec = hevc_frame_alloc(s->width, s->height, s->bit_depth);
+  hevc_meta_reset(m);
+  m->constrained_intra_pred = p->constrained_intra_pred; m->cb_qp_offset = p->cb_qp_offset; m->cr_qp_offset = p->cr_qp_offset; m->strong_intra_smoothing = s->strong_intra_smoothing;
+  /* reference list */
+  e->n_ref = 0;
+  int st_rps_idx = 0;
+  if (!is_i) {
+    int nref_avail = imin(e->n_dpb, e->two_refs ? 2 : 1);
+    st_rps_idx = nref_avail - 1;
+    for (int i = 0; i < nref_avail; i++) { e->ref[i] = e->dpb[i]; e->refcol[i] = &e->dpbcol[i]; e->ref_poc[i] = e->dpb_poc[i]; }
+    e->n_ref = nref_avail;
+  }
+  if (e->hm && s->sao_enabled) {
+    /* SAO parameters come from the deblocked reconstruction but are coded in front of each CTB: code the picture once without SAO to get
+     * that reconstruction, decide the parameters, then code it again (the CU decisions use no entropy-coder state, so they repeat exactly) */
+    bytebuf scratch = {0, 0, 0};
+    e->hm_pass = 1; encode_slices(e, is_i, st_rps_idx, &scratch); free(scratch.d);
+    hevc_deblock(e->rec, m);
+    e->hm_sao = (hevc_sao*)calloc((size_t)m->w_ctb * m->h_ctb, sizeof(hevc_sao));
+    hm_sao_decide(e);
+    hevc_meta_reset(m);
+    m->constrained_intra_pred = p->constrained_intra_pred; m->cb_qp_offset = p->cb_qp_offset; m->cr_qp_offset = p->cr_qp_offset; m->strong_intra_smoothing = s->strong_intra_smoothing;
+    e->hm_pass = 2; encode_slices(e, is_i, st_rps_idx, out);
+    free(e->hm_sao); e->hm_sao = NULL;
+  } else { e->hm_pass = 0; encode_slices(e, is_i, st_rps_idx, out); }
   /* collocated motion of this picture, loop filters, hash */
   hevc_colinfo ci; ci.poc = e->poc; ci.w4 = m->w4; ci.h4 = m->h4;
   size_t n4 = (size_t)m->w4 * m->h4;
@@ -1039,12 +1457,16 @@ int oracle_hevc_encode(const oracle_enc_params* p, const hevc_frame* const* fram
   if (p->width % 8 || p->height % 8 || p->width > HEVC_MAX_W || p->height > HEVC_MAX_H) { ENC_ERR("picture size must be a multiple of 8"); return -1; }
   if (!p->stress_seed && p->gop > 1 && (p->width % 16 || p->height % 16)) { ENC_ERR("gop=2 needs a picture size that is a multiple of 16"); return -1; }
   enc* e = (enc*)calloc(1, sizeof(enc));
-  e->p = *p; e->stress = p->stress_seed != 0; e->r.s = p->stress_seed ? p->stress_seed : 1;
+  e->p = *p; e->stress = p->stress_seed != 0; e->hm = !e->stress && p->hm_like; e->r.s = p->stress_seed ? p->stress_seed : 1;
   build_scans(e); setup_stream(e);
   e->m = hevc_meta_alloc(p->width, p->height, e->sps.log2_ctb);
   /* frames freed here unless handed to the caller: keep a list */
   hevc_frame** owned = (hevc_frame**)calloc((size_t)n, sizeof(void*));
   for (int i = 0; i < n; i++) { encode_picture(e, frames[i], i, out, owned); }
+  if (e->hm && getenv("ORACLE_HM_STATS"))
+    fprintf(stderr, "[oracle hm] CUs intra %ld (NxN %ld, in P %ld) inter %ld (2 PUs %ld, AMP %ld) skip %ld | PUs merge %ld amvp %ld, vectors non-zero %ld fractional %ld | TU splits %ld | 4x4 TBs %ld, transform skip %ld | SAO band %ld edge %ld off %ld merged CTBs %ld\n",
+            e->hs.cu_intra, e->hs.nxn, e->hs.intra_in_p, e->hs.cu_inter, e->hs.part2, e->hs.amp, e->hs.cu_skip, e->hs.merge, e->hs.amvp, e->hs.nonzero_mv, e->hs.frac_mv, e->hs.tu_split, e->hs.tb4, e->hs.ts,
+            e->hs.sao_band, e->hs.sao_edge, e->hs.sao_off, e->hs.sao_merge);
   if (recon) memcpy(recon, owned, sizeof(void*) * (size_t)n); else for (int i = 0; i < n; i++) hevc_frame_free(owned[i]);
   for (int i = 0; i < e->n_dpb; i++) { free(e->dpbcol[i].mv); free(e->dpbcol[i].refpoc); }
   free(owned); free(e->c.w.bb.d); hevc_meta_free(e->m); free(e);

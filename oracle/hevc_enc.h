@@ -15,6 +15,10 @@ typedef struct {
   int md5_sei;              /* emit decoded-picture-hash SEI */
   uint32_t stress_seed;     /* 0 = product decisions; != 0 = random-syntax generator for decoder test streams */
   int conf_win_right, conf_win_bottom;   /* conformance window offsets in chroma sample units (7.4.3.2.1): width / height are the CODED size */
+  int hm_like;              /* 1 = "HM-like" decisions: the coding tools of the CTC input streams (cfg/hm/ctc-hm-geometry-ai.cfg: CTU 64, TU 4..32
+                               :10-16, motion search :33-34, TransformSkip :47, SAO :68, AMP :69) chosen by a deterministic search instead of
+                               RBT-E1's restricted set; produces the benchmark's R5 input (tests/golden/make_hm_gof.py). Not mirrored on the GPU. */
+  int p_qp_offset;          /* hm_like: QP offset of P pictures (GOP table QPoffset: geometry -3, attribute 0; :29) */
 } oracle_enc_params;
 
 /* Encodes n frames; appends an Annex-B stream to out. If recon != NULL it receives n newly allocated reconstructed

@@ -271,6 +271,31 @@ void hevc_inter_pred(hevc_frame* f, const hevc_frame* ref, int x0, int y0, int w
              k_chroma_filter[mvx & 7], k_chroma_filter[mvy & 7], f->bit_depth);
 }
 
+/* luma prediction block (8.5.3.3.3 + the uni-directional weighting of 8.5.3.3.4.2) into out[w*h]; separable evaluation of the same
+ * arithmetic as mc_block (row filter >> shift1, column filter >> 6), used by the HM-like encoder's motion search */
+void hevc_mc_luma_buf(const hevc_frame* ref, int x0, int y0, int w, int h, int mvx, int mvy, uint16_t* out) {
+  int bd = ref->bit_depth, sh1 = imin(4, bd - 8), sh3 = 14 - bd, maxv = (1 << bd) - 1, fsh = 14 - bd, fadd = fsh ? 1 << (fsh - 1) : 0;
+  int xf = mvx & 3, yf = mvy & 3, xi0 = x0 + (mvx >> 2), yi0 = y0 + (mvy >> 2);
+  const int8_t* fx = k_luma_filter[xf]; const int8_t* fy = k_luma_filter[yf];
+  static int row[(64 + 8) * 64];
+  for (int y = -3; y < h + 4; y++) {
+    if (!yf && (y < 0 || y >= h)) continue;
+    for (int x = 0; x < w; x++) {
+      int v;
+      if (!xf) v = refpix(ref->p[0], ref->w, ref->h, xi0 + x, yi0 + y);
+      else { int s = 0; for (int k = 0; k < 8; k++) s += fx[k] * refpix(ref->p[0], ref->w, ref->h, xi0 + x + k - 3, yi0 + y); v = s >> sh1; }
+      row[(y + 3) * 64 + x] = v;
+    }
+  }
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      int v;
+      if (!yf) v = xf ? row[(y + 3) * 64 + x] : row[(y + 3) * 64 + x] << sh3;
+      else { int s = 0; for (int k = 0; k < 8; k++) s += fy[k] * row[(y + k) * 64 + x]; v = xf ? s >> 6 : s >> sh1; }
+      out[y * w + x] = (uint16_t)clip3(0, maxv, (v + fadd) >> fsh);
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------ deblocking (8.7.2) */
 /* bS of the edge between 4x4 units ip (P side) and iq (Q side); tu = transform edge */
 static int edge_bs(const hevc_meta* m, int ip, int iq, int tu, const hevc_slice_meta* sp, const hevc_slice_meta* sq) {

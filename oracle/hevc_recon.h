@@ -75,6 +75,9 @@ void hevc_intra_mpm(const hevc_meta* m, int xp, int yp, int cand[3]);
 /* uni-directional inter prediction of a luma block + its chroma, writes final clipped samples into f */
 void hevc_inter_pred(hevc_frame* f, const hevc_frame* ref, int x0, int y0, int w, int h, int mvx, int mvy);
 
+/* the luma block hevc_inter_pred would write, into out[w*h] (w, h <= 64) */
+void hevc_mc_luma_buf(const hevc_frame* ref, int x0, int y0, int w, int h, int mvx, int mvy, uint16_t* out);
+
 /* motion vector prediction (8.5.3.2.2 - 8.5.3.2.9), list 0 only */
 typedef struct { int16_t x, y; int ref; } hevc_mvcand;
 typedef struct { int16_t* mv; int32_t* refpoc; int poc; int w4, h4; } hevc_colinfo;   /* refpoc INT_MIN = not inter */

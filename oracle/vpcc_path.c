@@ -169,6 +169,29 @@ int oracle_encode(int w, int h, int bit_depth, int qp, int i_qp_offset, int gop,
   return rc;
 }
 
+/* the same with every encoder parameter (hm_like, p_qp_offset, ...) */
+int oracle_encode_ex(const oracle_enc_params* params, const uint16_t* yuv, int n_frames, uint8_t** out, size_t* n_out, uint16_t* recon) {
+  oracle_enc_params p = *params;
+  int w = p.width, h = p.height;
+  size_t fs = (size_t)w * h * 3 / 2;
+  hevc_frame** fr = (hevc_frame**)calloc((size_t)n_frames, sizeof(void*));
+  hevc_frame** rc_fr = (hevc_frame**)calloc((size_t)n_frames, sizeof(void*));
+  for (int i = 0; i < n_frames; i++) fr[i] = frame_from_yuv(yuv + fs * (size_t)i, w, h, p.bit_depth);
+  bytebuf bb = {0, 0, 0};
+  int rc = encode_any_size(&p, (const hevc_frame* const*)fr, n_frames, &bb, rc_fr);
+  for (int i = 0; i < n_frames; i++) {
+    if (rc == 0 && recon) {
+      uint16_t* o = recon + fs * (size_t)i; hevc_frame* f = rc_fr[i];
+      memcpy(o, f->p[0], (size_t)w * h * 2); memcpy(o + (size_t)w * h, f->p[1], (size_t)f->cw * f->ch * 2);
+      memcpy(o + (size_t)w * h + (size_t)f->cw * f->ch, f->p[2], (size_t)f->cw * f->ch * 2);
+    }
+    hevc_frame_free(fr[i]); hevc_frame_free(rc_fr[i]);
+  }
+  free(fr); free(rc_fr);
+  *out = bb.d; *n_out = bb.n;
+  return rc;
+}
+
 int oracle_transcode_substream(const uint8_t* annexb, size_t n, const oracle_transcode_params* p, uint8_t** out, size_t* n_out) {
   *out = NULL; *n_out = 0;
   oracle_hevc_decoder* d = oracle_hevc_dec_create();

@@ -4,6 +4,7 @@
 #define ORACLE_VPCC_PATH_H
 #include <stddef.h>
 #include <stdint.h>
+#include "hevc_enc.h"
 
 typedef struct {
   int w, h, bit_depth, n_frames;
@@ -32,6 +33,7 @@ int oracle_decode(const uint8_t* annexb, size_t n, oracle_video* out);
 /* encode: yuv = n_frames x planar 4:2:0 uint16; params as oracle_enc_params fields */
 int oracle_encode(int w, int h, int bit_depth, int qp, int i_qp_offset, int gop, int lossless, int log2_ctb, int rows_per_slice,
                   int md5_sei, uint32_t stress_seed, const uint16_t* yuv, int n_frames, uint8_t** out, size_t* n_out, uint16_t* recon);
+int oracle_encode_ex(const oracle_enc_params* params, const uint16_t* yuv, int n_frames, uint8_t** out, size_t* n_out, uint16_t* recon);
 /* PCCTranscoder::transcodeVideo (PCCTranscoder.cpp:374-546) on an Annex-B sub-bitstream */
 int oracle_transcode_substream(const uint8_t* annexb, size_t n, const oracle_transcode_params* p, uint8_t** out, size_t* n_out);
 /* PCCTranscoder::transcodeData (PCCTranscoder.cpp:145-168): occupancy only when occupancy_precision == 4, then geometry, attribute */

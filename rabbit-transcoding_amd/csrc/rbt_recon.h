@@ -220,30 +220,59 @@ template <int LOG2> RBT_DEV void rc_inv_transform_pair_n(int sh, int m0, int m1,
   RBT_SYNC_LDS();
 }
 
-// ---- uni-directional motion compensation of one PU (8.5.3.3) from ref->out into f->pix ----
+// ---- uni-directional motion compensation of one PU (8.5.3.3) from ref->out into the CTB tile ----
+// Separable, staged through LDS: the PU is walked in sub-blocks of up to 32 x 16 samples; for each one the wave loads the reference
+// window (sub-block + filter halo, clamped to the picture: 8.5.3.3.3 reference padding) from HBM once with row-major coalesced loads,
+// filters its rows into a 16-bit intermediate (H.265's shift1 keeps it in 16 bits), then its columns straight into the destination,
+// completing prediction + residual in the same pass. Per luma sample of a 2-D fractional vector: 8 + 8 * (16 + 7) / 16 multiply-adds
+// on LDS operands instead of 72 on clamped HBM loads; every reference sample is fetched once per sub-block instead of up to 64 times.
+// The window and the intermediate live in the TB scratch of the calling wave (res / tmp: idle while prediction units are processed).
 RBT_DEV int rc_refpix(const uint16_t* p, int w, int h, int x, int y) { return p[(size_t)rbt_clip3(0, h - 1, y) * w + rbt_clip3(0, w - 1, x)]; }
 // dst(x,y) = dst[(dy0 + y) * dstride + dx0 + x]: a picture plane in HBM or the CTB tile in LDS
-template <class DP> RBT_DEV void rc_mc_plane(DP dst, int dstride, int dx0, int dy0, const uint16_t* ref, int pw, int ph, int x0, int y0, int bw, int bh, int xint, int yint, int xf, int yf, int taps,
-                         const int8_t* fx, const int8_t* fy, int bd, int add_res = 0) {
-  // add_res: dst holds the residual of the block (int16 bit patterns, 0 where nothing is coded); the sample is completed in place
-  int sh1 = rbt_min(4, bd - 8), sh3 = 14 - bd, half = taps / 2 - 1, maxv = (1 << bd) - 1;
-  int fsh = 14 - bd, fadd = fsh ? 1 << (fsh - 1) : 0;
-  RBT_PAR_FOR(i, bw * bh) {
-    int x = i % bw, y = i / bw, xi = x0 + xint + x, yi = y0 + yint + y, v;
-    if (!xf && !yf) v = rc_refpix(ref, pw, ph, xi, yi) << sh3;
-    else if (!yf) { int s = 0; for (int k = 0; k < taps; k++) s += fx[k] * rc_refpix(ref, pw, ph, xi + k - half, yi); v = s >> sh1; }
-    else if (!xf) { int s = 0; for (int k = 0; k < taps; k++) s += fy[k] * rc_refpix(ref, pw, ph, xi, yi + k - half); v = s >> sh1; }
-    else {
-      int s = 0;
-      for (int j = 0; j < taps; j++) {
-        int t = 0;
-        for (int k = 0; k < taps; k++) t += fx[k] * rc_refpix(ref, pw, ph, xi + k - half, yi + j - half);
-        s += fy[j] * (t >> sh1);
-      }
-      v = s >> 6;
+// add_res: dst holds the residual of the block (int16 bit patterns, 0 where nothing is coded); the sample is completed in place
+template <int TAPS, class DP> RBT_DEV void rc_mc_plane(DP dst, int dstride, int dx0, int dy0, const uint16_t* ref, int pw, int ph, int x0, int y0, int bw, int bh, int xint, int yint, int xf, int yf,
+                         const int8_t* fx, const int8_t* fy, int bd, int add_res, RBT_LDS_AS RbtReconLdsCore* l) {
+  constexpr int HALF = TAPS / 2 - 1, SBW = 32, SBH = 16;
+  static_assert((SBW + 7) * (SBH + 7) <= 32 * 32 && SBW * (SBH + 7) <= 32 * 32, "window and intermediate fit the TB scratch");
+  const int sh1 = rbt_min(4, bd - 8), maxv = (1 << bd) - 1, fsh = 14 - bd, fadd = fsh ? 1 << (fsh - 1) : 0;
+  if (!xf && !yf) {                                                         // integer vector: (ref << shift3 + round) >> shift3 == ref
+    RBT_PAR_FOR(i, bw * bh) {
+      const int y = i / bw, x = i - y * bw, o = (dy0 + y) * dstride + dx0 + x, pr = rc_refpix(ref, pw, ph, x0 + xint + x, y0 + yint + y);
+      dst[o] = (uint16_t)(add_res ? rbt_clip3(0, maxv, pr + (int16_t)dst[o]) : pr);
     }
-    const int o = (dy0 + y) * dstride + dx0 + x, pr = rbt_clip3(0, maxv, (v + fadd) >> fsh);
-    dst[o] = (uint16_t)(add_res ? rbt_clip3(0, maxv, pr + (int16_t)dst[o]) : pr);
+    return;
+  }
+  int cx[TAPS], cy[TAPS];
+#pragma unroll
+  for (int k = 0; k < TAPS; k++) { cx[k] = fx[k]; cy[k] = fy[k]; }
+  RBT_LDS_AS uint16_t* const win = (RBT_LDS_AS uint16_t*)l->res; RBT_LDS_AS int16_t* const mid = l->tmp;
+  const int hx = xf ? HALF : 0, hy = yf ? HALF : 0, ex = xf ? TAPS - 1 : 0, ey = yf ? TAPS - 1 : 0;
+  for (int sy = 0; sy < bh; sy += SBH) for (int sx = 0; sx < bw; sx += SBW) {
+    const int sw = rbt_min(SBW, bw - sx), shh = rbt_min(SBH, bh - sy), ww = sw + ex, wh = shh + ey;
+    const int gx = x0 + xint + sx - hx, gy = y0 + yint + sy - hy;
+    RBT_PAR_FOR(i, ww * wh) { const int r = i / ww, c = i - r * ww; win[i] = (uint16_t)rc_refpix(ref, pw, ph, gx + c, gy + r); }
+    RBT_SYNC_LDS();
+    RBT_PAR_FOR(i, sw * wh) {                                               // rows
+      const int r = i / sw, x = i - r * sw; int v;
+      if (xf) { int s = 0;
+#pragma unroll
+        for (int k = 0; k < TAPS; k++) s += cx[k] * win[r * ww + x + k];
+        v = s >> sh1; }
+      else v = win[r * ww + x];
+      mid[i] = (int16_t)v;
+    }
+    RBT_SYNC_LDS();
+    RBT_PAR_FOR(i, sw * shh) {                                              // columns, rounding, residual
+      const int y = i / sw, x = i - y * sw; int v;
+      if (yf) { int s = 0;
+#pragma unroll
+        for (int j = 0; j < TAPS; j++) s += cy[j] * mid[(y + j) * sw + x];
+        v = xf ? s >> 6 : s >> sh1; }
+      else v = mid[i];
+      const int o = (dy0 + sy + y) * dstride + dx0 + sx + x, pr = rbt_clip3(0, maxv, (v + fadd) >> fsh);
+      dst[o] = (uint16_t)(add_res ? rbt_clip3(0, maxv, pr + (int16_t)dst[o]) : pr);
+    }
+    RBT_SYNC_LDS();                                                         // the next sub-block reuses window and intermediate
   }
 }
 // ---- decoder: one CTB reconstructed inside LDS ----------------------------------------------------------------------
@@ -499,10 +528,10 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
     if (c.type == RBT_CMD_PU) {
       const RbtFrame* ref = &frames[sl->ref_frame[c.c]];
       const int w = c.a * 4, h = c.b * 4, mvx = c.mvx, mvy = c.mvy;
-      if (DO_Y) rc_mc_plane(t->y, RC_TS_Y, x0 + 1, y0, ref->out[0], g->w, g->h, cx + x0, cy + y0, w, h, mvx >> 2, mvy >> 2, mvx & 3, mvy & 3, 8, k_luma_filter[mvx & 3], k_luma_filter[mvy & 3], g->bit_depth, 1);
+      if (DO_Y) rc_mc_plane<8>(t->y, RC_TS_Y, x0 + 1, y0, ref->out[0], g->w, g->h, cx + x0, cy + y0, w, h, mvx >> 2, mvy >> 2, mvx & 3, mvy & 3, k_luma_filter[mvx & 3], k_luma_filter[mvy & 3], g->bit_depth, 1, &R->rc);
       if (DO_C) for (int cc = 1; cc < 3; cc++)
-        rc_mc_plane(t->c[cc - 1], RC_TS_C, (x0 >> 1) + 1, y0 >> 1, ref->out[cc], g->cw, g->ch, (cx + x0) >> 1, (cy + y0) >> 1, w >> 1, h >> 1, mvx >> 3, mvy >> 3, mvx & 7, mvy & 7, 4,
-                    k_chroma_filter[mvx & 7], k_chroma_filter[mvy & 7], g->bit_depth, 1);
+        rc_mc_plane<4>(t->c[cc - 1], RC_TS_C, (x0 >> 1) + 1, y0 >> 1, ref->out[cc], g->cw, g->ch, (cx + x0) >> 1, (cy + y0) >> 1, w >> 1, h >> 1, mvx >> 3, mvy >> 3, mvx & 7, mvy & 7,
+                       k_chroma_filter[mvx & 7], k_chroma_filter[mvy & 7], g->bit_depth, 1, &R->rc);
       rc_tile_mark(R->uav, c.x4, c.y4, c.a, c.b, !g->cip);
     } else if (c.type == RBT_CMD_TU && (c.a & RBT_TU_INTRA)) {
       const int fl = c.a, log2 = c.log2;

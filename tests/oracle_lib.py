@@ -22,6 +22,12 @@ class TranscodeParams(C.Structure):
                 ("ctb_rows_per_slice", C.c_int), ("md5_sei", C.c_int)]
 
 
+class EncParams(C.Structure):
+    """oracle_enc_params (oracle/hevc_enc.h)"""
+    _fields_ = [(n, C.c_int) for n in ("width", "height", "bit_depth", "qp", "i_qp_offset", "gop", "lossless", "log2_ctb", "ctb_rows_per_slice", "md5_sei")] + \
+               [("stress_seed", C.c_uint32)] + [(n, C.c_int) for n in ("conf_win_right", "conf_win_bottom", "hm_like", "p_qp_offset")]
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"])
 
@@ -35,6 +41,7 @@ def lib():
         L = C.CDLL(path)
         L.oracle_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(OracleVideo)]
         L.oracle_encode.argtypes = [C.c_int] * 10 + [C.c_uint32, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
+        L.oracle_encode_ex.argtypes = [C.POINTER(EncParams), C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
         L.oracle_transcode_substream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(TranscodeParams), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.oracle_transcode_data.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(TranscodeParams), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.oracle_sample_to_byte_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
@@ -74,6 +81,20 @@ def encode(frames: np.ndarray, w, h, bit_depth, qp, gop=2, i_qp_offset=-3, lossl
     recon = np.zeros_like(frames) if want_recon else None
     rc = lib().oracle_encode(w, h, bit_depth, qp, i_qp_offset, gop, lossless, log2_ctb, rows_per_slice, md5_sei, stress_seed,
                              frames.ctypes.data, n, C.byref(out), C.byref(n_out), recon.ctypes.data if want_recon else None)
+    if rc != 0:
+        raise RuntimeError(f"oracle encode failed rc={rc}")
+    return _take(out, n_out), recon
+
+
+def encode_hm(frames: np.ndarray, w, h, bit_depth, qp, gop=2, i_qp_offset=-3, p_qp_offset=0, lossless=0, log2_ctb=6, md5_sei=1, want_recon=True):
+    """The oracle's HM-like encoder (oracle/hevc_enc.c, hm_like): the coding tools of the CTC input streams, one slice per picture."""
+    frames = np.ascontiguousarray(frames, dtype=np.uint16)
+    n = frames.shape[0]
+    assert frames.shape[1] == w * h * 3 // 2
+    p = EncParams(w, h, bit_depth, qp, i_qp_offset, gop, lossless, log2_ctb, 0, md5_sei, 0, 0, 0, 1, p_qp_offset)
+    out, n_out = C.c_void_p(), C.c_size_t()
+    recon = np.zeros_like(frames) if want_recon else None
+    rc = lib().oracle_encode_ex(C.byref(p), frames.ctypes.data, n, C.byref(out), C.byref(n_out), recon.ctypes.data if want_recon else None)
     if rc != 0:
         raise RuntimeError(f"oracle encode failed rc={rc}")
     return _take(out, n_out), recon

@@ -104,3 +104,25 @@ def make_gof(w, h, n_pc_frames, seed0, bit_depth=10):
         m = make_maps(w, h, seed0, bit_depth, jitter=i)
         geo.append(m["geo"]); attr.append(m["attr"]); occ.append(m["occ"])
     return np.concatenate(geo), np.concatenate(attr), np.concatenate(occ)
+
+
+def make_gof_maps(w, h, n_pc, seed):
+    """n_pc point-cloud frames: 4 base atlases jittered by a few pixels per frame."""
+    bases = [make_maps(w, h, seed + k) for k in range(min(4, n_pc))]
+    geo, attr, occ = [], [], []
+    ys, cs = w * h, (w // 2) * (h // 2)
+
+    def roll(frame, ww, hh, d):
+        y = np.roll(frame[: ww * hh].reshape(hh, ww), d, axis=1).ravel()
+        c = (ww // 2) * (hh // 2)
+        u = np.roll(frame[ww * hh: ww * hh + c].reshape(hh // 2, ww // 2), d // 2, axis=1).ravel()
+        v = np.roll(frame[ww * hh + c:].reshape(hh // 2, ww // 2), d // 2, axis=1).ravel()
+        return np.concatenate([y, u, v])
+    for i in range(n_pc):
+        b = bases[i % len(bases)]
+        d = 2 * (i // len(bases))
+        geo += [roll(b["geo"][0], w, h, d), roll(b["geo"][1], w, h, d)]
+        attr += [roll(b["attr"][0], w, h, d), roll(b["attr"][1], w, h, d)]
+        occ += [roll(b["occ"][0], w // 2, h // 2, d // 2)]
+    del ys, cs
+    return np.stack(geo), np.stack(attr), np.stack(occ)

@@ -116,3 +116,31 @@ def test_parameter_sets_match_reference_parser_golden(name, cfg):
     assert (sps["width"], sps["height"], sps["bit_depth"], sps["bit_depth_c"], sps["chroma_format"]) == (cw, ch, cfg["bd"], cfg["bd"], 1)
     assert pps["init_qp"] == cfg["qp"] and pps["tq_bypass"] == cfg["lossless"] and pps["deblock_disabled"] == cfg["lossless"]
     assert pps["sign_hiding"] == 0 and pps["cu_qp_delta"] == 0 and pps["log2_par_mrg"] == 2 and pps["num_ref_idx_l0"] == 1
+
+
+def test_hm_like_encoder_round_trip_and_toolset():
+    """the oracle's HM-like mode (bench input generator): its streams decode to the encoder's reconstruction (hash SEI included), and the
+    parameter sets announce the CTC toolset"""
+    import synth
+    m = synth.make_maps(192, 128, 9)
+    for key, qp, po in (("geo", 16, -3), ("attr", 22, 0)):
+        bs, rec = O.encode_hm(m[key], 192, 128, 10, qp, p_qp_offset=po)
+        dec, w, h, bd, chk, fail = O.decode(bs)
+        assert (w, h, bd, chk, fail) == (192, 128, 10, 2, 0) and np.array_equal(dec, rec)
+    bs, rec = O.encode_hm(m["occ"], 96, 64, 8, 8, gop=1, i_qp_offset=0, lossless=1)
+    assert np.array_equal(O.decode(bs)[0], rec) and np.array_equal(rec, m["occ"])     # lossless
+
+
+def test_benchmark_fixture_matches_manifest_and_first_frame_decodes():
+    import hashlib, json, os
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    man = json.load(open(os.path.join(gold, "hm_r5_manifest.json")))["1280x1280_f32"]
+    import rbt_lib
+    gs = rbt_lib.module_file("gof_shard")
+    for kind, n_pic in (("occ", 1), ("geo", 2)):
+        b = open(os.path.join(gold, man["streams"][kind]["file"]), "rb").read()
+        assert len(b) == man["streams"][kind]["bytes"] and hashlib.md5(b).hexdigest() == man["streams"][kind]["md5"]
+        pairs = gs.split_pairs(b)
+        assert len(pairs) == 32
+        dec, w, h, bd, chk, fail = O.decode(pairs[0])
+        assert dec.shape[0] == n_pic and fail == 0 and (kind == "occ" or chk == n_pic)
