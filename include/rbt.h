@@ -120,6 +120,47 @@ int rbt_byte_to_sample_stream(const uint8_t* in, size_t n, uint8_t** out, size_t
 
 int rbt_get_stats(rbt_ctx* ctx, rbt_stats* out);
 
+/* ---- decoder-side verification stage: what turns transcoded maps into the D1 figure of the metric ----
+ * Replaces PCCCodec::generateOccupancyMap (PCCCodec.cpp:1584-1606), generateBlockToPatchFromOccupancyMapVideo (:1725-1763),
+ * generatePointCloud / generatePoints (:517-978, :327-515) and the colour fetch of colorPointCloud (:1308-1449) for the configuration of the
+ * CTC streams (two geometry maps with absolute D1; no EOM, raw patches, point-local reconstruction or patch border filtering; one tile),
+ * and the point-to-point part of QualityMetrics::compute (PCCMetrics.cpp:75-231, :44-48, :299-309). */
+typedef struct {             /* the fields of PCCPatch the reconstruction reads (PCCPatch.h) */
+  int32_t u0, v0, size_u0, size_v0;      /* position / size in the atlas in occupancy-resolution blocks */
+  int32_t u1, v1, d1;                    /* 3-D offset along the tangent, bitangent and normal axis */
+  int32_t normal_axis, tangent_axis, bitangent_axis;   /* 0..2, all different */
+  int32_t projection_mode;               /* 0: depth + d1, 1: d1 - depth */
+  int32_t orientation;                   /* PATCH_ORIENTATION_* (PCCCommon.h:128-137) */
+  int32_t lod_x, lod_y;
+} rbt_patch;
+typedef struct {
+  int32_t width, height;                 /* atlas frame size (multiples of occupancy_resolution) */
+  int32_t occupancy_resolution;          /* 16 in the CTC (cfg/common/ctc-common.cfg) */
+  int32_t occupancy_precision;           /* atlas size / occupancy video size: 2 at R5, 4 after the transcoder's OR-pool */
+  int32_t map_count, absolute_d1, remove_duplicate_points, threshold_lossy_om;
+} rbt_atlas_params;
+typedef struct {             /* host memory, released with rbt_cloud_free */
+  int n_points;
+  int16_t* xyz;              /* 3 per point, in the order PCCCodec::generatePointCloud emits them */
+  uint16_t* yuv;             /* 3 per point: the attribute samples at the point's pixel (chroma at the co-sited 4:2:0 sample; the reference
+                                converts to 4:4:4 first, PccLibColorConverter, out of scope) */
+  uint8_t* occupancy_map;    /* width x height: the up-scaled, binarised occupancy map */
+  uint32_t* block_to_patch;  /* (width / res) x (height / res): patch index + 1 */
+} rbt_cloud;
+/* occ_luma: occupancy video luma, (width / precision) x (height / precision); geo_d0 / geo_d1: luma of the near / far geometry map, width x
+ * height samples of geo_bit_depth bits (mapped to 8 bits like PCCImage::set, PCCImage.h:107-124); attr_t0 / attr_t1: planar 4:2:0 attribute
+ * pictures or NULL. */
+int rbt_reconstruct(rbt_ctx* ctx, const rbt_atlas_params* atlas, const rbt_patch* patches, int n_patches, const uint16_t* occ_luma, const uint16_t* geo_d0,
+                    const uint16_t* geo_d1, int geo_bit_depth, const uint16_t* attr_t0, const uint16_t* attr_t1, int attr_bit_depth, rbt_cloud* out);
+void rbt_cloud_free(rbt_cloud* c);
+typedef struct {
+  int n_a, n_b;                          /* points after merging duplicates (PCCMetricsParameters.cpp:50) */
+  uint64_t sse_ab, sse_ba, max_ab, max_ba;   /* sum / maximum of squared nearest-neighbour distances, A -> B and B -> A (exact integers) */
+  float mse_ab, mse_ba, psnr_ab, psnr_ba, psnr;   /* psnr = 10 log10(3 peak^2 / max(mse_ab, mse_ba)) (PCCMetrics.cpp:44-48, :299-309) */
+} rbt_d1_result;
+/* point-to-point (D1) metric between two clouds; coordinates 0..1023 (peak = 1023 in the CTC). */
+int rbt_d1(rbt_ctx* ctx, const int16_t* xyz_a, int n_a, const int16_t* xyz_b, int n_b, int peak, rbt_d1_result* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,200 @@
+/* ORACLE — test infrastructure only (see oracle/README.md). Never linked into the product library.
+ *
+ * CPU restatement of the decoder-side verification stage, for the configuration the CTC streams use
+ * (two geometry maps in one interleaved video with absolute D1, no EOM, no raw patches, no point-local reconstruction, no patch border
+ * filtering, one tile per atlas frame, removeDuplicatePoints on):
+ *   PCCImage::set                                        source/lib/PccLibCommon/include/PCCImage.h:90-131    (10-bit video sample -> 8-bit map value)
+ *   PCCCodec::generateOccupancyMap                       source/lib/PccLibCommon/source/PCCCodec.cpp:1584-1606
+ *   PCCCodec::generateBlockToPatchFromOccupancyMapVideo  :1725-1763
+ *   PCCPatch::patch2Canvas / patchBlock2CanvasBlock      source/lib/PccLibCommon/source/PCCPatch.cpp:192-251 / :253-305
+ *   PCCPatch::generatePoint / generateNormalCoordinate   include/PCCPatch.h:177-207
+ *   PCCCodec::generatePointCloud                         :517-978 (occupancy upscale :556-570, patch / block / pixel loops :628-668, the
+ *                                                        non-EOM branch :781-838) with generatePoints :327-515 (the last branch :497-513)
+ *   PCCCodec::colorPointCloud                            :1308-1449 (the `f < mapCount` fetch :1417-1421)
+ *   QualityMetrics::compute                              source/lib/PccLibMetrics/source/PCCMetrics.cpp:75-231 (point-to-point part), getPSNR :44-48,
+ *                                                        symmetric result :299-309, duplicate points merged first (PCCMetricsParameters.cpp:50)
+ * PARITY UNPINNED: PccLibCommon / PccLibMetrics need a cmake-generated PCCConfig.h (plus TBB and nanoflann) and the reference holds no
+ * fixtures for this stage; the restatement follows the source text. The 4:2:0 -> 4:4:4 conversion of the attribute video in front of
+ * colorPointCloud is PccLibColorConverter (out of scope): chroma is fetched at the co-sited half-resolution sample here.
+ */
+#include "pcc_recon.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* PCCCommon.h:128-137 */
+enum { OR_DEFAULT = 0, OR_SWAP, OR_ROT180, OR_MIRROR, OR_MROT180, OR_ROT270, OR_MROT90, OR_ROT90 };
+
+/* PCCPatch::patch2Canvas (PCCPatch.cpp:192-251); returns 0 when (x,y) leaves the canvas (the reference exits) */
+static int patch2canvas(const oracle_patch* p, int res, int u, int v, int cw, int ch, int* x, int* y) {
+  const int su = p->size_u0 * res, sv = p->size_v0 * res, ox = p->u0 * res, oy = p->v0 * res;
+  switch (p->orientation) {
+    case OR_DEFAULT: *x = u + ox; *y = v + oy; break;
+    case OR_ROT90: *x = (sv - 1 - v) + ox; *y = u + oy; break;
+    case OR_ROT180: *x = (su - 1 - u) + ox; *y = (sv - 1 - v) + oy; break;
+    case OR_ROT270: *x = v + ox; *y = (su - 1 - u) + oy; break;
+    case OR_MIRROR: *x = (su - 1 - u) + ox; *y = v + oy; break;
+    case OR_MROT90: *x = (sv - 1 - v) + ox; *y = (su - 1 - u) + oy; break;
+    case OR_MROT180: *x = u + ox; *y = (sv - 1 - v) + oy; break;
+    case OR_SWAP: *x = v + ox; *y = u + oy; break;    /* == MROT270 */
+    default: return 0;
+  }
+  return *x >= 0 && *y >= 0 && *x < cw && *y < ch;
+}
+/* PCCPatch::patchBlock2CanvasBlock (PCCPatch.cpp:253-305): -1 outside */
+static int block2canvas(const oracle_patch* p, int ub, int vb, int bw, int bh) {
+  int x, y;
+  switch (p->orientation) {
+    case OR_DEFAULT: x = ub + p->u0; y = vb + p->v0; break;
+    case OR_ROT90: x = (p->size_v0 - 1 - vb) + p->u0; y = ub + p->v0; break;
+    case OR_ROT180: x = (p->size_u0 - 1 - ub) + p->u0; y = (p->size_v0 - 1 - vb) + p->v0; break;
+    case OR_ROT270: x = vb + p->u0; y = (p->size_u0 - 1 - ub) + p->v0; break;
+    case OR_MIRROR: x = (p->size_u0 - 1 - ub) + p->u0; y = vb + p->v0; break;
+    case OR_MROT90: x = (p->size_v0 - 1 - vb) + p->u0; y = (p->size_u0 - 1 - ub) + p->v0; break;
+    case OR_MROT180: x = ub + p->u0; y = (p->size_v0 - 1 - vb) + p->v0; break;
+    case OR_SWAP: x = vb + p->u0; y = ub + p->v0; break;
+    default: return -1;
+  }
+  if (x < 0 || y < 0 || x >= bw || y >= bh) return -1;
+  return x + bw * y;
+}
+/* PCCImage::set (PCCImage.h:107-124): video sample of `bd` bits -> the 8-bit value the decoder works with */
+static int to8(int v, int bd) { int sh = bd - 8; if (sh <= 0) return v; int r = (v + (1 << (sh - 1))) >> sh; return r > 255 ? 255 : r; }
+/* PCCPatch::generatePoint (PCCPatch.h:177-207) */
+static void gen_point(const oracle_patch* p, int u, int v, int depth, int16_t out[3]) {
+  int n;
+  if (p->projection_mode == 0) n = depth + p->d1; else { n = p->d1 - depth; if (n < 0) n = 0; }
+  out[p->normal_axis] = (int16_t)n;
+  out[p->tangent_axis] = (int16_t)(u * p->lod_x + p->u1);
+  out[p->bitangent_axis] = (int16_t)(v * p->lod_y + p->v1);
+}
+
+int oracle_reconstruct(const oracle_atlas* a, const oracle_patch* patches, int n_patches, const uint16_t* occ, const uint16_t* d0, const uint16_t* d1, int geo_bd,
+                       const uint16_t* t0, const uint16_t* t1, int attr_bd, oracle_cloud* out) {
+  const int W = a->width, H = a->height, res = a->occupancy_resolution, prec = a->occupancy_precision, ow = W / prec;
+  const int bw = W / res, bh = H / res;
+  memset(out, 0, sizeof(*out));
+  if (W % res || H % res || W % prec || H % prec || res < 1 || prec < 1) return -1;
+  /* generateOccupancyMap (:1584-1606): nearest-neighbour upscale, binarised against thresholdLossyOM */
+  uint8_t* om = (uint8_t*)calloc((size_t)W * H, 1);
+  for (int v = 0; v < H; v++) for (int u = 0; u < W; u++) om[(size_t)v * W + u] = occ[(size_t)(v / prec) * ow + u / prec] > a->threshold_lossy_om;
+  /* generateBlockToPatchFromOccupancyMapVideo (:1725-1763): a block belongs to the LAST patch that has an occupied pixel in it */
+  uint32_t* b2p = (uint32_t*)calloc((size_t)bw * bh, sizeof(uint32_t));
+  for (int pi = 0; pi < n_patches; pi++) {
+    const oracle_patch* p = &patches[pi];
+    for (int v0 = 0; v0 < p->size_v0; v0++) for (int u0 = 0; u0 < p->size_u0; u0++) {
+      int bi = block2canvas(p, u0, v0, bw, bh), nz = 0;
+      if (bi < 0) { free(om); free(b2p); return -2; }
+      for (int v1 = 0; v1 < res; v1++) for (int u1 = 0; u1 < res; u1++) {
+        int x, y;
+        if (!patch2canvas(p, res, u0 * res + u1, v0 * res + v1, W, H, &x, &y)) { free(om); free(b2p); return -2; }
+        nz += occ[(size_t)(y / prec) * ow + x / prec] != 0;
+      }
+      if (nz > 0) b2p[bi] = (uint32_t)pi + 1;
+    }
+  }
+  /* generatePointCloud (:628-838) */
+  size_t cap = 1024, n = 0;
+  int16_t* xyz = (int16_t*)malloc(cap * 6); uint16_t* col = (uint16_t*)malloc(cap * 6);
+  const int cw = W / 2;
+  for (int pi = 0; pi < n_patches; pi++) {
+    const oracle_patch* p = &patches[pi];
+    for (int v0 = 0; v0 < p->size_v0; v0++) for (int u0 = 0; u0 < p->size_u0; u0++) {
+      if (b2p[block2canvas(p, u0, v0, bw, bh)] != (uint32_t)pi + 1) continue;
+      for (int v1 = 0; v1 < res; v1++) for (int u1 = 0; u1 < res; u1++) {
+        int u = u0 * res + u1, v = v0 * res + v1, x, y;
+        patch2canvas(p, res, u, v, W, H, &x, &y);
+        if (!om[(size_t)y * W + x]) continue;
+        int16_t pt[2][3];
+        gen_point(p, u, v, to8(d0[(size_t)y * W + x], geo_bd), pt[0]);
+        int np = 1;
+        if (a->map_count > 1) {   /* generatePoints :497-513 */
+          if (a->absolute_d1) gen_point(p, u, v, to8(d1[(size_t)y * W + x], geo_bd), pt[1]);
+          else { memcpy(pt[1], pt[0], 6); int dv = to8(d1[(size_t)y * W + x], geo_bd); pt[1][p->normal_axis] = (int16_t)(pt[1][p->normal_axis] + (p->projection_mode == 0 ? dv : -dv)); }
+          np = 2;
+        }
+        for (int i = 0; i < np; i++) {
+          if (a->remove_duplicate_points && i > 0 && !memcmp(pt[i], pt[0], 6)) continue;   /* :793-794 */
+          if (n == cap) { cap *= 2; xyz = (int16_t*)realloc(xyz, cap * 6); col = (uint16_t*)realloc(col, cap * 6); }
+          memcpy(xyz + 3 * n, pt[i], 6);
+          const uint16_t* t = i == 0 ? t0 : t1;    /* colorPointCloud :1417-1421: frame shift + f, pixel (x,y) */
+          if (t) { col[3 * n] = t[(size_t)y * W + x]; col[3 * n + 1] = t[(size_t)W * H + (size_t)(y / 2) * cw + x / 2]; col[3 * n + 2] = t[(size_t)W * H + (size_t)cw * (H / 2) + (size_t)(y / 2) * cw + x / 2]; }
+          else col[3 * n] = col[3 * n + 1] = col[3 * n + 2] = (uint16_t)(1 << (attr_bd - 1));
+          n++;
+        }
+      }
+    }
+  }
+  out->n = (int)n; out->xyz = xyz; out->yuv = col; out->occupancy_map = om; out->block_to_patch = b2p;
+  return 0;
+}
+void oracle_cloud_free(oracle_cloud* c) { free(c->xyz); free(c->yuv); free(c->occupancy_map); free(c->block_to_patch); memset(c, 0, sizeof(*c)); }
+
+/* ---- D1 (point-to-point) ---- */
+static int cmp_pt(const void* a, const void* b) {
+  const int16_t* p = (const int16_t*)a; const int16_t* q = (const int16_t*)b;
+  if (p[2] != q[2]) return p[2] - q[2];
+  if (p[1] != q[1]) return p[1] - q[1];
+  return p[0] - q[0];
+}
+/* duplicate points are merged before the comparison (dropDuplicates_ = 2, PCCMetrics.cpp:355-360): sort + unique */
+static int16_t* unique_points(const int16_t* p, int n, int* nu) {
+  int16_t* q = (int16_t*)malloc((size_t)(n ? n : 1) * 6); memcpy(q, p, (size_t)n * 6);
+  qsort(q, (size_t)n, 6, cmp_pt);
+  int m = 0;
+  for (int i = 0; i < n; i++) if (!m || memcmp(q + 3 * (m - 1), q + 3 * i, 6)) { memmove(q + 3 * m, q + 3 * i, 6); m++; }
+  *nu = m; return q;
+}
+/* sum over the points of A of the squared distance to the nearest point of B: uniform grid of 8^3 cells over B, rings of cells
+ * around the query until no closer point can exist (the reference uses a kd-tree, PCCMetrics.cpp:85-97; the nearest distance is the same) */
+static uint64_t sse_a_to_b(const int16_t* A, int na, const int16_t* B, int nb, uint64_t* max_d2) {
+  enum { CS = 3, G = 1 << (16 - CS) };     /* cells of 8 units; coordinates are taken modulo nothing: they must be 0..65535 >> 3 */
+  int gmax = 0;
+  for (int i = 0; i < nb; i++) for (int c = 0; c < 3; c++) { int g = B[3 * i + c] >> CS; if (g > gmax) gmax = g; }
+  for (int i = 0; i < na; i++) for (int c = 0; c < 3; c++) { int g = A[3 * i + c] >> CS; if (g > gmax) gmax = g; }
+  const int D = gmax + 1; (void)G;
+  int* start = (int*)calloc((size_t)D * D * D + 1, sizeof(int)); int* order = (int*)malloc(sizeof(int) * (size_t)(nb ? nb : 1));
+#define CELL(x, y, z) ((((size_t)(z) * D) + (y)) * D + (x))
+  for (int i = 0; i < nb; i++) start[CELL(B[3 * i] >> CS, B[3 * i + 1] >> CS, B[3 * i + 2] >> CS) + 1]++;
+  for (size_t i = 0; i < (size_t)D * D * D; i++) start[i + 1] += start[i];
+  int* fill = (int*)malloc(sizeof(int) * (size_t)D * D * D); memcpy(fill, start, sizeof(int) * (size_t)D * D * D);
+  for (int i = 0; i < nb; i++) order[fill[CELL(B[3 * i] >> CS, B[3 * i + 1] >> CS, B[3 * i + 2] >> CS)]++] = i;
+  uint64_t sse = 0, mx = 0;
+  for (int i = 0; i < na; i++) {
+    const int ax = A[3 * i], ay = A[3 * i + 1], az = A[3 * i + 2], cx = ax >> CS, cy = ay >> CS, cz = az >> CS;
+    int64_t best = INT64_MAX;
+    for (int r = 0; r < D + 1; r++) {
+      for (int z = cz - r; z <= cz + r; z++) for (int y = cy - r; y <= cy + r; y++) for (int x = cx - r; x <= cx + r; x++) {
+        if (x < 0 || y < 0 || z < 0 || x >= D || y >= D || z >= D) continue;
+        if (abs(x - cx) != r && abs(y - cy) != r && abs(z - cz) != r) continue;   /* the ring only */
+        for (int k = start[CELL(x, y, z)]; k < start[CELL(x, y, z) + 1]; k++) {
+          const int16_t* b = B + 3 * order[k]; int64_t dx = b[0] - ax, dy = b[1] - ay, dz = b[2] - az, d = dx * dx + dy * dy + dz * dz;
+          if (d < best) best = d;
+        }
+      }
+      /* every point in a cell outside ring r is at least r * 8 away along one axis (the query lies inside its own cell) */
+      if (best != INT64_MAX && best <= (int64_t)(r << CS) * (r << CS)) break;
+    }
+    sse += (uint64_t)best; if ((uint64_t)best > mx) mx = (uint64_t)best;
+  }
+#undef CELL
+  free(start); free(order); free(fill);
+  *max_d2 = mx;
+  return sse;
+}
+int oracle_d1(const int16_t* a, int na, const int16_t* b, int nb, int peak, oracle_d1_result* out) {
+  memset(out, 0, sizeof(*out));
+  if (na <= 0 || nb <= 0) return -1;
+  for (int i = 0; i < 3 * na; i++) if (a[i] < 0) return -1;
+  for (int i = 0; i < 3 * nb; i++) if (b[i] < 0) return -1;
+  int ua, ub; int16_t* A = unique_points(a, na, &ua); int16_t* B = unique_points(b, nb, &ub);
+  out->n_a = ua; out->n_b = ub;
+  out->sse_ab = sse_a_to_b(A, ua, B, ub, &out->max_ab); out->sse_ba = sse_a_to_b(B, ub, A, ua, &out->max_ba);
+  free(A); free(B);
+  /* QualityMetrics::compute :204-206 (float mse, getPSNR with factor 3), symmetric = the worse direction (:299-309) */
+  float mse_ab = (float)((double)out->sse_ab / ua), mse_ba = (float)((double)out->sse_ba / ub);
+  out->mse_ab = mse_ab; out->mse_ba = mse_ba;
+  float p = (float)peak, m = mse_ab > mse_ba ? mse_ab : mse_ba;
+  out->psnr_ab = 10 * log10f(3 * p * p / mse_ab); out->psnr_ba = 10 * log10f(3 * p * p / mse_ba); out->psnr = 10 * log10f(3 * p * p / m);
+  return 0;
+}

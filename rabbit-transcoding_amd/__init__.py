@@ -35,6 +35,24 @@ class Stats(C.Structure):
                                           "k_recon_ms", "k_filter_ms", "k_analyse_ms", "k_encode_ms", "k_entropy_ms")] + [("algorithmic_bytes", C.c_uint64)]
 
 
+class Patch(C.Structure):
+    """rbt_patch: the fields of PCCPatch the reconstruction reads"""
+    _fields_ = [(n, C.c_int32) for n in ("u0", "v0", "size_u0", "size_v0", "u1", "v1", "d1", "normal_axis", "tangent_axis", "bitangent_axis", "projection_mode", "orientation", "lod_x", "lod_y")]
+
+
+class AtlasParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("width", "height", "occupancy_resolution", "occupancy_precision", "map_count", "absolute_d1", "remove_duplicate_points", "threshold_lossy_om")]
+
+
+class Cloud(C.Structure):
+    _fields_ = [("n_points", C.c_int), ("xyz", C.POINTER(C.c_int16)), ("yuv", C.POINTER(C.c_uint16)), ("occupancy_map", C.POINTER(C.c_uint8)), ("block_to_patch", C.POINTER(C.c_uint32))]
+
+
+class D1Result(C.Structure):
+    _fields_ = [("n_a", C.c_int), ("n_b", C.c_int), ("sse_ab", C.c_uint64), ("sse_ba", C.c_uint64), ("max_ab", C.c_uint64), ("max_ba", C.c_uint64),
+                ("mse_ab", C.c_float), ("mse_ba", C.c_float), ("psnr_ab", C.c_float), ("psnr_ba", C.c_float), ("psnr", C.c_float)]
+
+
 def load(path=None):
     """Loads the shared library and declares the C ABI. Raises OSError if the HIP extension has not been built."""
     # 16 HIP streams shared by the jobs in flight: the ROCm runtime multiplexes streams onto 4 hardware queues unless told otherwise, and
@@ -60,6 +78,9 @@ def load(path=None):
     L.rbt_sample_to_byte_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rbt_byte_to_sample_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rbt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.rbt_reconstruct.argtypes = [C.c_void_p, C.POINTER(AtlasParams), C.POINTER(Patch), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Cloud)]
+    L.rbt_cloud_free.argtypes = [C.POINTER(Cloud)]
+    L.rbt_d1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(D1Result)]
     return L
 
 
@@ -156,6 +177,27 @@ class Context:
         out = np.zeros((h // factor, w // factor), np.uint16)
         self._chk(self.L.rbt_or_pool(self.h, plane.ctypes.data, w, h, factor, out.ctypes.data))
         return out
+
+    def reconstruct(self, atlas, patches, occ, d0, d1, geo_bd=10, t0=None, t1=None, attr_bd=10):
+        """rbt_reconstruct: (xyz int16 [n,3], yuv uint16 [n,3], occupancy_map uint8 [h,w], block_to_patch uint32 [h/res, w/res])
+        atlas: AtlasParams; patches: list of Patch; occ / d0 / d1: luma planes (2-D arrays); t0 / t1: planar 4:2:0 frames (1-D) or None"""
+        ps = (Patch * max(1, len(patches)))(*patches)
+        arr = [np.ascontiguousarray(x, dtype=np.uint16) if x is not None else None for x in (occ, d0, d1, t0, t1)]
+        ptr = [x.ctypes.data if x is not None else None for x in arr]
+        c = Cloud()
+        self._chk(self.L.rbt_reconstruct(self.h, C.byref(atlas), ps, len(patches), ptr[0], ptr[1], ptr[2], geo_bd, ptr[3], ptr[4], attr_bd, C.byref(c)))
+        n, w, h, res = c.n_points, atlas.width, atlas.height, atlas.occupancy_resolution
+        xyz = np.ctypeslib.as_array(c.xyz, shape=(max(n, 1), 3))[:n].copy(); yuv = np.ctypeslib.as_array(c.yuv, shape=(max(n, 1), 3))[:n].copy()
+        om = np.ctypeslib.as_array(c.occupancy_map, shape=(h, w)).copy(); b2p = np.ctypeslib.as_array(c.block_to_patch, shape=(h // res, w // res)).copy()
+        self.L.rbt_cloud_free(C.byref(c))
+        return xyz, yuv, om, b2p
+
+    def d1(self, a, b, peak=1023):
+        """rbt_d1: point-to-point metric between two clouds (int16 [n,3]) -> dict"""
+        a = np.ascontiguousarray(a, dtype=np.int16); b = np.ascontiguousarray(b, dtype=np.int16)
+        r = D1Result()
+        self._chk(self.L.rbt_d1(self.h, a.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0], peak, C.byref(r)))
+        return {n: getattr(r, n) for n, _ in D1Result._fields_}
 
     def stats(self):
         s = Stats()

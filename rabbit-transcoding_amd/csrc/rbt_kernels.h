@@ -5,7 +5,9 @@
 #include <cstddef>
 #include <cstdint>
 #include "rbt_types.h"
+#include "../../include/rbt.h"
 
+struct RbtPccParams;
 namespace rbtk {
 int dev_init(int device);                 // 0 = ok; creates the device's streams / events on first use and selects the device for this thread
 int dev_select(int device);               // makes an initialised device the calling thread's current one (every C-ABI entry point calls it)
@@ -61,4 +63,13 @@ void launch_enc_inter(RbtFrame* frames, const RbtSlice* slices, const int32_t* f
 void launch_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list, int n_slices, int max_log2_ctb);
 // gathers the slice data of every slice segment into one contiguous buffer (dst_off = exclusive prefix sum of out_size)
 void launch_pack(const uint8_t* out, const RbtSlice* slices, const uint32_t* dst_off, uint8_t* packed, int n_slices);
+// verification stage (rbt_pcc.h). items: one (patch << 16 | block inside the patch) word per patch block, in the reference's visiting order
+void launch_pcc_occmap(const RbtPccParams* P, const uint16_t* occ, uint8_t* om);
+void launch_pcc_owner(const RbtPccParams* P, const rbt_patch* patches, const uint32_t* items, int n_items, const uint16_t* occ, uint32_t* b2p);
+void launch_pcc_count(const RbtPccParams* P, const rbt_patch* patches, const uint32_t* items, int n_items, const uint16_t* occ, const uint16_t* d0, const uint16_t* d1, const uint32_t* b2p, uint32_t* counts);
+void launch_scan_u32(const uint32_t* in, uint32_t* out, int n);      // out[i] = sum of in[0..i), out[n] = total
+void launch_pcc_emit(const RbtPccParams* P, const rbt_patch* patches, const uint32_t* items, int n_items, const uint16_t* occ, const uint16_t* d0, const uint16_t* d1, const uint16_t* t0, const uint16_t* t1,
+                     const uint32_t* b2p, const uint32_t* offsets, int16_t* xyz, uint16_t* yuv);
+void launch_vol_set(const int16_t* xyz, int n, uint32_t* vol, uint8_t* first, uint32_t* n_unique);
+void launch_vol_nn(const int16_t* xyz, const uint8_t* first, int n, const uint32_t* vol_other, unsigned long long* sse, uint32_t* max_d2);
 }  // namespace rbtk

@@ -9,6 +9,7 @@
 #include "rbt_recon.h"
 #include "rbt_filter.h"
 #include "rbt_encode.h"
+#include "rbt_pcc.h"
 
 namespace rbtk {
 // Everything the host code touches on a GPU is per DEVICE: 16 HIP streams, the timer / dependency events, the lane -> stream
@@ -301,5 +302,95 @@ void launch_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int3
   if (n_slices <= 0) return;
   if (max_log2_ctb <= 5) hipLaunchKernelGGL(k_entropy<5>, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, out, slice_list);
   else hipLaunchKernelGGL(k_entropy<6>, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, out, slice_list);
+}
+// ---------------------------------------------------------------------------------------------- verification stage (rbt_pcc.h)
+__global__ void __launch_bounds__(256) k_pcc_occmap(RbtPccParams P, const uint16_t* occ, uint8_t* om) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < P.w * P.h) { const int u = i % P.w, v = i / P.w; om[i] = occ[(size_t)(v / P.prec) * P.ow + u / P.prec] > P.threshold; }
+}
+// one workgroup per (patch, block): a block belongs to the LAST patch with an occupied pixel in it (the reference overwrites in patch order)
+__global__ void __launch_bounds__(256) k_pcc_owner(RbtPccParams P, const rbt_patch* patches, const uint32_t* items, const uint16_t* occ, uint32_t* b2p) {
+  const uint32_t it = items[blockIdx.x]; const int pi = (int)(it >> 16), blk = (int)(it & 0xFFFF);
+  const rbt_patch* p = &patches[pi]; const int ub = blk % p->size_u0, vb = blk / p->size_u0;
+  int any = 0;
+  for (int q = threadIdx.x; q < P.res * P.res; q += 256) any |= pc_pixel_occupied_video(&P, p, occ, ub, vb, q);
+  any = __syncthreads_or(any);
+  if (any && threadIdx.x == 0) atomicMax(&b2p[pc_block2canvas(p, ub, vb, P.bw)], (uint32_t)pi + 1);
+}
+__device__ __forceinline__ int pcc_block_scan(int v, int* total) {     // exclusive prefix sum over the 256 threads of the workgroup
+  __shared__ int sh[256];
+  sh[threadIdx.x] = v; __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) { int t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0; __syncthreads(); sh[threadIdx.x] += t; __syncthreads(); }
+  *total = sh[255];
+  const int r = sh[threadIdx.x] - v; __syncthreads();
+  return r;
+}
+__global__ void __launch_bounds__(256) k_pcc_count(RbtPccParams P, const rbt_patch* patches, const uint32_t* items, const uint16_t* occ, const uint16_t* d0, const uint16_t* d1, const uint32_t* b2p, uint32_t* counts) {
+  const uint32_t it = items[blockIdx.x]; const int pi = (int)(it >> 16), blk = (int)(it & 0xFFFF);
+  const rbt_patch* p = &patches[pi]; const int ub = blk % p->size_u0, vb = blk / p->size_u0;
+  int n = 0;
+  if (b2p[pc_block2canvas(p, ub, vb, P.bw)] == (uint32_t)pi + 1)
+    for (int q = threadIdx.x; q < P.res * P.res; q += 256) n += pc_pixel_points(&P, p, occ, d0, d1, nullptr, nullptr, ub, vb, q, nullptr, nullptr);
+  int total; pcc_block_scan(n, &total);
+  if (threadIdx.x == 0) counts[blockIdx.x] = (uint32_t)total;
+}
+__global__ void __launch_bounds__(256) k_pcc_emit(RbtPccParams P, const rbt_patch* patches, const uint32_t* items, const uint16_t* occ, const uint16_t* d0, const uint16_t* d1, const uint16_t* t0, const uint16_t* t1,
+                                                  const uint32_t* b2p, const uint32_t* offsets, int16_t* xyz, uint16_t* yuv) {
+  const uint32_t it = items[blockIdx.x]; const int pi = (int)(it >> 16), blk = (int)(it & 0xFFFF);
+  const rbt_patch* p = &patches[pi]; const int ub = blk % p->size_u0, vb = blk / p->size_u0;
+  if (b2p[pc_block2canvas(p, ub, vb, P.bw)] != (uint32_t)pi + 1) return;         // uniform over the workgroup
+  uint32_t base = offsets[blockIdx.x];
+  for (int q0 = 0; q0 < P.res * P.res; q0 += 256) {                                 // pixels in raster order inside the block (v1, u1)
+    const int q = q0 + threadIdx.x;
+    int16_t pts[6]; uint16_t col[6];
+    const int n = q < P.res * P.res ? pc_pixel_points(&P, p, occ, d0, d1, t0, t1, ub, vb, q, pts, col) : 0;
+    int total; const int off = pcc_block_scan(n, &total);
+    for (int i = 0; i < n; i++) for (int c = 0; c < 3; c++) { xyz[3 * (size_t)(base + off + i) + c] = pts[3 * i + c]; yuv[3 * (size_t)(base + off + i) + c] = col[3 * i + c]; }
+    base += (uint32_t)total;
+  }
+}
+// exclusive prefix sum of n <= a few 10^4 counts in one workgroup: every thread sums a contiguous chunk, the chunk sums are scanned in LDS
+__global__ void __launch_bounds__(1024) k_scan_u32(const uint32_t* in, uint32_t* out, int n) {
+  __shared__ uint32_t sh[1024];
+  const int chunk = (n + 1023) / 1024, b = threadIdx.x * chunk, e = min(n, b + chunk);
+  uint32_t s = 0; for (int i = b; i < e; i++) s += in[i];
+  sh[threadIdx.x] = s; __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) { uint32_t t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0; __syncthreads(); sh[threadIdx.x] += t; __syncthreads(); }
+  uint32_t run = sh[threadIdx.x] - s;
+  for (int i = b; i < e; i++) { out[i] = run; run += in[i]; }
+  if (threadIdx.x == 1023) out[n] = sh[1023];
+}
+__global__ void __launch_bounds__(256) k_vol_set(const int16_t* xyz, int n, uint32_t* vol, uint8_t* first, uint32_t* n_unique) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+  const uint32_t bit = 1u << (x & 31), old = atomicOr(&vol[pc_voxel_word(x, y, z)], bit);
+  const int f = !(old & bit);                                                       // the first point at this position represents its duplicates
+  first[i] = (uint8_t)f;
+  if (f) atomicAdd(n_unique, 1u);
+}
+__global__ void __launch_bounds__(256) k_vol_nn(const int16_t* xyz, const uint8_t* first, int n, const uint32_t* vol_other, unsigned long long* sse, uint32_t* max_d2) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  uint32_t d = 0;
+  if (i < n && first[i]) d = pc_nearest_d2(vol_other, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+  unsigned long long s = d; uint32_t m = d;
+  for (int o = 32; o; o >>= 1) { s += __shfl_down(s, o, 64); const uint32_t t = __shfl_down(m, o, 64); m = t > m ? t : m; }
+  if ((threadIdx.x & 63) == 0 && s) { atomicAdd(sse, s); atomicMax(max_d2, m); }
+}
+void launch_pcc_occmap(const RbtPccParams* P, const uint16_t* occ, uint8_t* om) { hipLaunchKernelGGL(k_pcc_occmap, dim3((P->w * P->h + 255) / 256), dim3(256), 0, g_stream, *P, occ, om); }
+void launch_pcc_owner(const RbtPccParams* P, const rbt_patch* patches, const uint32_t* items, int n_items, const uint16_t* occ, uint32_t* b2p) {
+  if (n_items > 0) hipLaunchKernelGGL(k_pcc_owner, dim3(n_items), dim3(256), 0, g_stream, *P, patches, items, occ, b2p);
+}
+void launch_pcc_count(const RbtPccParams* P, const rbt_patch* patches, const uint32_t* items, int n_items, const uint16_t* occ, const uint16_t* d0, const uint16_t* d1, const uint32_t* b2p, uint32_t* counts) {
+  if (n_items > 0) hipLaunchKernelGGL(k_pcc_count, dim3(n_items), dim3(256), 0, g_stream, *P, patches, items, occ, d0, d1, b2p, counts);
+}
+void launch_scan_u32(const uint32_t* in, uint32_t* out, int n) { hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, g_stream, in, out, n); }
+void launch_pcc_emit(const RbtPccParams* P, const rbt_patch* patches, const uint32_t* items, int n_items, const uint16_t* occ, const uint16_t* d0, const uint16_t* d1, const uint16_t* t0, const uint16_t* t1,
+                     const uint32_t* b2p, const uint32_t* offsets, int16_t* xyz, uint16_t* yuv) {
+  if (n_items > 0) hipLaunchKernelGGL(k_pcc_emit, dim3(n_items), dim3(256), 0, g_stream, *P, patches, items, occ, d0, d1, t0, t1, b2p, offsets, xyz, yuv);
+}
+void launch_vol_set(const int16_t* xyz, int n, uint32_t* vol, uint8_t* first, uint32_t* n_unique) { if (n > 0) hipLaunchKernelGGL(k_vol_set, dim3((n + 255) / 256), dim3(256), 0, g_stream, xyz, n, vol, first, n_unique); }
+void launch_vol_nn(const int16_t* xyz, const uint8_t* first, int n, const uint32_t* vol_other, unsigned long long* sse, uint32_t* max_d2) {
+  if (n > 0) hipLaunchKernelGGL(k_vol_nn, dim3((n + 255) / 256), dim3(256), 0, g_stream, xyz, first, n, vol_other, sse, max_d2);
 }
 }  // namespace rbtk

@@ -5,6 +5,7 @@
 #include <mutex>
 #include "rbt_batch.h"
 #include "rbt_transcode.h"
+#include "rbt_pcc.h"
 
 struct rbt_ctx { int device, rank, world; rbt_stats stats; std::string last_err; };
 struct rbt_job { rbt::GofJob* j; rbt_ctx* owner; };
@@ -176,6 +177,21 @@ int rbt_or_pool(rbt_ctx* ctx, const uint16_t* plane, int width, int height, int 
   if (!ctx || !plane || !out || factor < 1 || width % factor || height % factor) return RBT_ERR_PARAM;
   RBT_ENTER(ctx);
   return rbt::or_pool_host(plane, width, height, factor, out);
+}
+
+int rbt_reconstruct(rbt_ctx* ctx, const rbt_atlas_params* atlas, const rbt_patch* patches, int n_patches, const uint16_t* occ_luma, const uint16_t* geo_d0,
+                    const uint16_t* geo_d1, int geo_bit_depth, const uint16_t* attr_t0, const uint16_t* attr_t1, int attr_bit_depth, rbt_cloud* out) {
+  if (!ctx || !atlas || (!patches && n_patches) || !occ_luma || !geo_d0 || !out) return RBT_ERR_PARAM;
+  RBT_ENTER(ctx);
+  int rc = rbt::pcc_reconstruct(ctx->last_err, atlas, patches, n_patches, occ_luma, geo_d0, geo_d1, geo_bit_depth, attr_t0, attr_t1, attr_bit_depth, out);
+  if (rc) rbt_cloud_free(out);
+  return rc;
+}
+void rbt_cloud_free(rbt_cloud* c) { if (!c) return; free(c->xyz); free(c->yuv); free(c->occupancy_map); free(c->block_to_patch); memset(c, 0, sizeof(*c)); }
+int rbt_d1(rbt_ctx* ctx, const int16_t* xyz_a, int n_a, const int16_t* xyz_b, int n_b, int peak, rbt_d1_result* out) {
+  if (!ctx || !xyz_a || !xyz_b || !out) return RBT_ERR_PARAM;
+  RBT_ENTER(ctx);
+  return rbt::pcc_d1(ctx->last_err, xyz_a, n_a, xyz_b, n_b, peak, out);
 }
 
 }  // extern "C"

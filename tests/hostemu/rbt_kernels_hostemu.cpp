@@ -13,6 +13,7 @@
 #include "../../rabbit-transcoding_amd/csrc/rbt_recon.h"
 #include "../../rabbit-transcoding_amd/csrc/rbt_filter.h"
 #include "../../rabbit-transcoding_amd/csrc/rbt_encode.h"
+#include "../../rabbit-transcoding_amd/csrc/rbt_pcc.h"
 
 namespace rbtk {
 static double g_t[32][2];
@@ -87,6 +88,33 @@ void launch_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_l
   }
 }
 #include "rbt_kernels_hostemu_enc.inc"
+// verification stage: the same per-element routines, visited serially
+void launch_pcc_occmap(const RbtPccParams* P, const uint16_t* occ, uint8_t* om) { for (int i = 0; i < P->w * P->h; i++) om[i] = occ[(size_t)(i / P->w / P->prec) * P->ow + (i % P->w) / P->prec] > P->threshold; }
+void launch_pcc_owner(const RbtPccParams* P, const rbt_patch* patches, const uint32_t* items, int n_items, const uint16_t* occ, uint32_t* b2p) {
+  for (int k = 0; k < n_items; k++) { const int pi = (int)(items[k] >> 16), blk = (int)(items[k] & 0xFFFF); const rbt_patch* p = &patches[pi]; const int ub = blk % p->size_u0, vb = blk / p->size_u0; int any = 0;
+    for (int q = 0; q < P->res * P->res; q++) any |= pc_pixel_occupied_video(P, p, occ, ub, vb, q);
+    if (any) { uint32_t* d = &b2p[pc_block2canvas(p, ub, vb, P->bw)]; if ((uint32_t)pi + 1 > *d) *d = (uint32_t)pi + 1; } }
+}
+void launch_pcc_count(const RbtPccParams* P, const rbt_patch* patches, const uint32_t* items, int n_items, const uint16_t* occ, const uint16_t* d0, const uint16_t* d1, const uint32_t* b2p, uint32_t* counts) {
+  for (int k = 0; k < n_items; k++) { const int pi = (int)(items[k] >> 16), blk = (int)(items[k] & 0xFFFF); const rbt_patch* p = &patches[pi]; const int ub = blk % p->size_u0, vb = blk / p->size_u0; uint32_t n = 0;
+    if (b2p[pc_block2canvas(p, ub, vb, P->bw)] == (uint32_t)pi + 1) for (int q = 0; q < P->res * P->res; q++) n += (uint32_t)pc_pixel_points(P, p, occ, d0, d1, nullptr, nullptr, ub, vb, q, nullptr, nullptr);
+    counts[k] = n; }
+}
+void launch_scan_u32(const uint32_t* in, uint32_t* out, int n) { uint32_t r = 0; for (int i = 0; i < n; i++) { out[i] = r; r += in[i]; } out[n] = r; }
+void launch_pcc_emit(const RbtPccParams* P, const rbt_patch* patches, const uint32_t* items, int n_items, const uint16_t* occ, const uint16_t* d0, const uint16_t* d1, const uint16_t* t0, const uint16_t* t1,
+                     const uint32_t* b2p, const uint32_t* offsets, int16_t* xyz, uint16_t* yuv) {
+  for (int k = 0; k < n_items; k++) { const int pi = (int)(items[k] >> 16), blk = (int)(items[k] & 0xFFFF); const rbt_patch* p = &patches[pi]; const int ub = blk % p->size_u0, vb = blk / p->size_u0;
+    if (b2p[pc_block2canvas(p, ub, vb, P->bw)] != (uint32_t)pi + 1) continue;
+    size_t o = offsets[k];
+    for (int q = 0; q < P->res * P->res; q++) o += (size_t)pc_pixel_points(P, p, occ, d0, d1, t0, t1, ub, vb, q, xyz + 3 * o, yuv + 3 * o); }
+}
+void launch_vol_set(const int16_t* xyz, int n, uint32_t* vol, uint8_t* first, uint32_t* n_unique) {
+  for (int i = 0; i < n; i++) { const int x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2]; uint32_t* w = &vol[pc_voxel_word(x, y, z)]; const uint32_t bit = 1u << (x & 31);
+    first[i] = !(*w & bit); *w |= bit; if (first[i]) (*n_unique)++; }
+}
+void launch_vol_nn(const int16_t* xyz, const uint8_t* first, int n, const uint32_t* vol_other, unsigned long long* sse, uint32_t* max_d2) {
+  for (int i = 0; i < n; i++) if (first[i]) { const uint32_t d = pc_nearest_d2(vol_other, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]); *sse += d; if (d > *max_d2) *max_d2 = d; }
+}
 }  // namespace rbtk
 
 // ---- accessors of the PRODUCT's normative tables (csrc/rbt_tables.h) for tests/test_tables_product.py ----

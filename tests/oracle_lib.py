@@ -28,6 +28,23 @@ class EncParams(C.Structure):
                [("stress_seed", C.c_uint32)] + [(n, C.c_int) for n in ("conf_win_right", "conf_win_bottom", "hm_like", "p_qp_offset")]
 
 
+class OPatch(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("u0", "v0", "size_u0", "size_v0", "u1", "v1", "d1", "normal_axis", "tangent_axis", "bitangent_axis", "projection_mode", "orientation", "lod_x", "lod_y")]
+
+
+class OAtlas(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("width", "height", "occupancy_resolution", "occupancy_precision", "map_count", "absolute_d1", "remove_duplicate_points", "threshold_lossy_om")]
+
+
+class OCloud(C.Structure):
+    _fields_ = [("n", C.c_int), ("xyz", C.POINTER(C.c_int16)), ("yuv", C.POINTER(C.c_uint16)), ("occupancy_map", C.POINTER(C.c_uint8)), ("block_to_patch", C.POINTER(C.c_uint32))]
+
+
+class OD1(C.Structure):
+    _fields_ = [("n_a", C.c_int), ("n_b", C.c_int), ("sse_ab", C.c_uint64), ("sse_ba", C.c_uint64), ("max_ab", C.c_uint64), ("max_ba", C.c_uint64),
+                ("mse_ab", C.c_float), ("mse_ba", C.c_float), ("psnr_ab", C.c_float), ("psnr_ba", C.c_float), ("psnr", C.c_float)]
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"])
 
@@ -44,6 +61,9 @@ def lib():
         L.oracle_encode_ex.argtypes = [C.POINTER(EncParams), C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
         L.oracle_transcode_substream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(TranscodeParams), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.oracle_transcode_data.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(TranscodeParams), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.oracle_reconstruct.argtypes = [C.POINTER(OAtlas), C.POINTER(OPatch), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(OCloud)]
+        L.oracle_cloud_free.argtypes = [C.POINTER(OCloud)]
+        L.oracle_d1.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(OD1)]
         L.oracle_sample_to_byte_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.oracle_byte_to_sample_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.oracle_or_pool.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -154,3 +174,28 @@ def md5(b: bytes):
     out = C.create_string_buffer(16)
     lib().oracle_md5(b, len(b), out)
     return out.raw
+
+
+def reconstruct(atlas, patches, occ, d0, d1, geo_bd=10, t0=None, t1=None, attr_bd=10):
+    """oracle_reconstruct; atlas / patches: any ctypes structures with the rbt_atlas_params / rbt_patch field layout"""
+    a = OAtlas(*[getattr(atlas, n) for n, _ in OAtlas._fields_])
+    ps = (OPatch * max(1, len(patches)))(*[OPatch(*[getattr(p, n) for n, _ in OPatch._fields_]) for p in patches])
+    arr = [np.ascontiguousarray(x, dtype=np.uint16) if x is not None else None for x in (occ, d0, d1, t0, t1)]
+    ptr = [x.ctypes.data if x is not None else None for x in arr]
+    c = OCloud()
+    rc = lib().oracle_reconstruct(C.byref(a), ps, len(patches), ptr[0], ptr[1], ptr[2], geo_bd, ptr[3], ptr[4], attr_bd, C.byref(c))
+    if rc != 0:
+        raise RuntimeError(f"oracle reconstruct failed rc={rc}")
+    n, w, h, res = c.n, a.width, a.height, a.occupancy_resolution
+    xyz = np.ctypeslib.as_array(c.xyz, shape=(max(n, 1), 3))[:n].copy(); yuv = np.ctypeslib.as_array(c.yuv, shape=(max(n, 1), 3))[:n].copy()
+    om = np.ctypeslib.as_array(c.occupancy_map, shape=(h, w)).copy(); b2p = np.ctypeslib.as_array(c.block_to_patch, shape=(h // res, w // res)).copy()
+    lib().oracle_cloud_free(C.byref(c))
+    return xyz, yuv, om, b2p
+
+
+def d1(a, b, peak=1023):
+    a = np.ascontiguousarray(a, dtype=np.int16); b = np.ascontiguousarray(b, dtype=np.int16)
+    r = OD1()
+    if lib().oracle_d1(a.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0], peak, C.byref(r)) != 0:
+        raise RuntimeError("oracle d1 failed")
+    return {n: getattr(r, n) for n, _ in OD1._fields_}

@@ -126,3 +126,13 @@ def make_gof_maps(w, h, n_pc, seed):
         occ += [roll(b["occ"][0], w // 2, h // 2, d // 2)]
     del ys, cs
     return np.stack(geo), np.stack(attr), np.stack(occ)
+
+
+def atlas_patches(R, w, h, seed):
+    """rbt_patch list of the synthetic atlas make_maps(w, h, seed) draws (atlas_layout): every rectangle is a patch in default orientation,
+    projected along one axis, placed in a 1024^3 volume (coordinates stay below 1024: peak 1023 of the D1 metric)."""
+    _, rects = atlas_layout(w, h, seed)
+    out = []
+    for i, (x, y, pw, ph) in enumerate(rects):
+        out.append(R.Patch(x // 16, y // 16, pw // 16, ph // 16, (i * 97) % (1023 - pw), (i * 53) % (1023 - ph), (i * 31) % 700, i % 3, (i + 1) % 3, (i + 2) % 3, 0, 0, 1, 1))
+    return out

@@ -1,0 +1,72 @@
+"""GPU build of the verification stage through the C ABI vs the oracle: point lists identical (order included),
+occupancy / block-to-patch integer maps identical, D1 sums identical; random atlases with every orientation, plus the benchmark's full-size atlas
+after a real R5 -> R3 transcode."""
+import json
+import os
+import numpy as np
+import pytest
+import oracle_lib as O
+import rbt_lib
+import pcc_cases
+import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    R = rbt_lib.module()
+    c = R.Context(device=0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_reconstruction_matches_oracle_point_for_point(ctx, seed):
+    R = rbt_lib.module()
+    case = pcc_cases.random_atlas(R, seed, *((1280, 1280) if seed == 7 else (None, None)))
+    got, want = ctx.reconstruct(*case), O.reconstruct(*case)
+    assert got[0].shape == want[0].shape and got[0].shape[0] > 0
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_d1_matches_oracle(ctx, seed):
+    r = np.random.default_rng(seed)
+    n = 200000 if seed == 0 else 3000
+    a = r.integers(100, 400 if seed == 0 else 160, (n, 3)).astype(np.int16)
+    b = np.clip(a[r.permutation(n)[: n * 5 // 6]] + r.integers(-2, 3, (n * 5 // 6, 3)), 0, 1023).astype(np.int16)
+    if seed == 3: b = np.concatenate([b, np.array([[1000, 1000, 1000]], np.int16)])
+    got, want = ctx.d1(a, b), O.d1(a, b)
+    for k in ("n_a", "n_b", "sse_ab", "sse_ba", "max_ab", "max_ba"):
+        assert got[k] == want[k], k
+    assert got["psnr"] == pytest.approx(want["psnr"], abs=1e-4)
+
+
+def test_full_size_frame_after_transcode(ctx):
+    """point-cloud frame 0 of the benchmark fixture: decode the R5 input and the R3 output of the whole path, rebuild both clouds from the synthetic
+    atlas, compare with the oracle's reconstruction of the same maps, and D1 between them"""
+    R = rbt_lib.module(); gs = rbt_lib.module_file("gof_shard")
+    man = json.load(open(os.path.join(GOLD, "hm_r5_manifest.json")))["1280x1280_f32"]
+    gof = [gs.split_pairs(open(os.path.join(GOLD, man["streams"][k]["file"]), "rb").read())[0] for k in ("occ", "geo", "attr")]
+    out = ctx.transcode_gof(gof, gs.rate_params(R, 3))
+    w = h = 1280
+    patches = synth.atlas_patches(R, w, h, 1051)
+    clouds = []
+    for streams, prec in ((gof, 2), (out, 4)):
+        occ = ctx.decode(streams[0])[0][0][: (w // prec) * (h // prec)].reshape(h // prec, w // prec)
+        geo = ctx.decode(streams[1])[0]; att = ctx.decode(streams[2])[0]
+        d0, d1 = geo[0][: w * h].reshape(h, w), geo[1][: w * h].reshape(h, w)
+        atlas = R.AtlasParams(w, h, 16, prec, 2, 1, 1, 0)
+        got = ctx.reconstruct(atlas, patches, occ, d0, d1, 10, att[0], att[1], 10)
+        want = O.reconstruct(atlas, patches, occ, d0, d1, 10, att[0], att[1], 10)
+        for g, x in zip(got, want):
+            assert np.array_equal(g, x)
+        assert got[0].shape[0] > 100000
+        clouds.append(got[0])
+    got, want = ctx.d1(clouds[0], clouds[1]), O.d1(clouds[0], clouds[1])
+    for k in ("n_a", "n_b", "sse_ab", "sse_ba", "max_ab", "max_ba"):
+        assert got[k] == want[k], k
+    assert 40 < got["psnr"] < 100
