@@ -119,6 +119,9 @@ int rbt_sample_to_byte_stream(const uint8_t* in, size_t n, uint8_t** out, size_t
 int rbt_byte_to_sample_stream(const uint8_t* in, size_t n, uint8_t** out, size_t* n_out);
 
 int rbt_get_stats(rbt_ctx* ctx, rbt_stats* out);
+/* Device self-test of the 32-point transform stages on the matrix cores (v_mfma_i32_32x32x32_i8) against the vector-ALU form of the same stages:
+ * n_blocks blocks of 32 x 32 int16 (coefficients for the inverse, residuals for the forward transform); *n_mismatch = differing output samples. */
+int rbt_selftest_transform32(rbt_ctx* ctx, const int16_t* blocks, int n_blocks, int bit_depth, uint32_t* n_mismatch);
 
 /* ---- decoder-side verification stage: what turns transcoded maps into the D1 figure of the metric ----
  * Replaces PCCCodec::generateOccupancyMap (PCCCodec.cpp:1584-1606), generateBlockToPatchFromOccupancyMapVideo (:1725-1763),

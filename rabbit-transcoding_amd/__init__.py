@@ -78,6 +78,7 @@ def load(path=None):
     L.rbt_sample_to_byte_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rbt_byte_to_sample_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rbt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.rbt_selftest_transform32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
     L.rbt_reconstruct.argtypes = [C.c_void_p, C.POINTER(AtlasParams), C.POINTER(Patch), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Cloud)]
     L.rbt_cloud_free.argtypes = [C.POINTER(Cloud)]
     L.rbt_d1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(D1Result)]
@@ -198,6 +199,13 @@ class Context:
         r = D1Result()
         self._chk(self.L.rbt_d1(self.h, a.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0], peak, C.byref(r)))
         return {n: getattr(r, n) for n, _ in D1Result._fields_}
+
+    def selftest_transform32(self, blocks, bit_depth=10):
+        """rbt_selftest_transform32: matrix-core vs vector-ALU 32-point transforms on int16 blocks [n, 1024]; returns the number of differing samples"""
+        blocks = np.ascontiguousarray(blocks, dtype=np.int16)
+        bad = C.c_uint32()
+        self._chk(self.L.rbt_selftest_transform32(self.h, blocks.ctypes.data, blocks.shape[0], bit_depth, C.byref(bad)))
+        return bad.value
 
     def stats(self):
         s = Stats()

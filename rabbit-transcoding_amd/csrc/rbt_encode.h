@@ -215,11 +215,20 @@ template <int LOG2> RBT_DEV void en_fwd_transform_pair_n(int bd, RBT_LDS_AS RbtR
   }
   RBT_SYNC_LDS();
 }
+// 32 x 32 on the matrix cores: tmp[y][k] = (sum_x res[y][x] T[k][x] + round) >> s1, then res[kv][kh] = clip16((sum_y T[kv][y] tmp[y][kh] + round) >> s2)
+RBT_DEV void en_fwd_transform_32(int bd, RBT_LDS_AS RbtReconLdsCore* r) {
+#ifdef RBT_HOSTEMU
+  en_fwd_transform_n<5>(0, bd, r);
+#else
+  mf_mm32<false>(r->dct, 32, 1, r->res, r->tmp, 5 + bd - 9, 0);
+  mf_mm32<true>(r->dct, 32, 1, r->tmp, r->res, 5 + 6, 1);
+#endif
+}
 RBT_DEV void en_fwd_transform(int log2, int is_dst, int bd, RBT_LDS_AS RbtReconLdsCore* r) {
   if (log2 == 2) en_fwd_transform_n<2>(is_dst, bd, r);
   else if (log2 == 3) en_fwd_transform_n<3>(0, bd, r);
   else if (log2 == 4) en_fwd_transform_n<4>(0, bd, r);
-  else en_fwd_transform_n<5>(0, bd, r);
+  else en_fwd_transform_32(bd, r);
 }
 // dead-zone quantiser of l->rc.res into l->lvl; returns the number of non-zero levels
 RBT_DEV int en_quant(int log2, int qp, int bd, int is_intra, RBT_LDS_AS RbtEncLds* l) {

@@ -63,6 +63,8 @@ void launch_enc_inter(RbtFrame* frames, const RbtSlice* slices, const int32_t* f
 void launch_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list, int n_slices, int max_log2_ctb);
 // gathers the slice data of every slice segment into one contiguous buffer (dst_off = exclusive prefix sum of out_size)
 void launch_pack(const uint8_t* out, const RbtSlice* slices, const uint32_t* dst_off, uint8_t* packed, int n_slices);
+// matrix-core transform stages against the vector-ALU stages on n blocks of 32 x 32 int16 (0 = ok; *n_bad = differing samples)
+int selftest_transform32(const int16_t* blocks, int n, int bd, uint32_t* n_bad);
 // verification stage (rbt_pcc.h). items: one (patch << 16 | block inside the patch) word per patch block, in the reference's visiting order
 void launch_pcc_occmap(const RbtPccParams* P, const uint16_t* occ, uint8_t* om);
 void launch_pcc_owner(const RbtPccParams* P, const rbt_patch* patches, const uint32_t* items, int n_items, const uint16_t* occ, uint32_t* b2p);

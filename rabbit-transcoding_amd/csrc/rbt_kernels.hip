@@ -303,6 +303,38 @@ void launch_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int3
   if (max_log2_ctb <= 5) hipLaunchKernelGGL(k_entropy<5>, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, out, slice_list);
   else hipLaunchKernelGGL(k_entropy<6>, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, out, slice_list);
 }
+// ---------------------------------------------------------------------------------------------- self-test
+// The 32-point transform stages on the matrix cores (rbt_mfma.h) against the vector-ALU form of the same stages, on the device, for every block
+// of `in` (n blocks of 32 x 32 int16): mismatches are counted in *bad. mode 0: inverse (sh = 20 - bd), 1: forward.
+__global__ void __launch_bounds__(64) k_selftest_t32(const int16_t* in, int n, int bd, uint32_t* bad) {
+  __shared__ RbtReconLdsCore lds;
+  RBT_LDS_AS RbtReconLdsCore* l = RBT_LDS_CAST(RbtReconLdsCore, &lds);
+  rc_stage_tables(l);
+  uint32_t miss = 0;
+  for (int b = blockIdx.x; b < n; b += gridDim.x) for (int mode = 0; mode < 2; mode++) {
+    int16_t want[16];
+    for (int i = threadIdx.x; i < 1024; i += 64) l->res[i] = in[(size_t)b * 1024 + i];
+    RBT_SYNC_LDS();
+    if (mode == 0) rc_inv_transform_n<5>(0, 20 - bd, l); else en_fwd_transform_n<5>(0, bd, l);
+    for (int k = 0; k < 16; k++) want[k] = l->res[threadIdx.x + 64 * k];
+    RBT_SYNC_LDS();
+    for (int i = threadIdx.x; i < 1024; i += 64) l->res[i] = in[(size_t)b * 1024 + i];
+    RBT_SYNC_LDS();
+    if (mode == 0) rc_inv_transform_32(20 - bd, l); else en_fwd_transform_32(bd, l);
+    for (int k = 0; k < 16; k++) miss += want[k] != l->res[threadIdx.x + 64 * k];
+    RBT_SYNC_LDS();
+  }
+  if (miss) atomicAdd(bad, miss);
+}
+int selftest_transform32(const int16_t* blocks, int n, int bd, uint32_t* n_bad) {
+  int16_t* d_in = (int16_t*)dev_alloc((size_t)n * 2048); uint32_t* d_bad = (uint32_t*)dev_alloc(4);
+  if (!d_in || !d_bad) { dev_free(d_in); dev_free(d_bad); return -1; }
+  int rc = h2d(d_in, blocks, (size_t)n * 2048) | dev_memset(d_bad, 0, 4);
+  if (!rc) { hipLaunchKernelGGL(k_selftest_t32, dim3(n < 256 ? n : 256), dim3(64), 0, g_stream, d_in, n, bd, d_bad); rc = d2h(n_bad, d_bad, 4) | dev_sync(); }
+  dev_free(d_in); dev_free(d_bad);
+  return rc;
+}
+
 // ---------------------------------------------------------------------------------------------- verification stage (rbt_pcc.h)
 __global__ void __launch_bounds__(256) k_pcc_occmap(RbtPccParams P, const uint16_t* occ, uint8_t* om) {
   const int i = blockIdx.x * 256 + threadIdx.x;

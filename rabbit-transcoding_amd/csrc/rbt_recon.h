@@ -6,6 +6,7 @@
 #pragma once
 #include "rbt_tables.h"
 #include "rbt_types.h"
+#include "rbt_mfma.h"
 
 // Scratch of one TB. The decoder's CTB kernel declares only the core (its smoothed / angular reference arrays alias `tmp`,
 // which is dead once the residual is in `res`): LDS per workgroup decides how many CTBs are in flight on a CU.
@@ -182,6 +183,15 @@ template <int LOG2> RBT_DEV void rc_inv_transform_n(int is_dst, int sh, RBT_LDS_
   }
   RBT_SYNC_LDS();
 }
+// 32 x 32: both stages on the matrix cores (rbt_mfma.h). tmp[y][x] = clip16((sum_k T[k][y] res[k][x] + 64) >> 7), then res[y][x] = (sum_k tmp[y][k] T[k][x] + round) >> sh
+RBT_DEV void rc_inv_transform_32(int sh, RBT_LDS_AS RbtReconLdsCore* l) {
+#ifdef RBT_HOSTEMU
+  rc_inv_transform_n<5>(0, sh, l);
+#else
+  mf_mm32<true>(l->dct, 1, 32, l->res, l->tmp, 7, 1);
+  mf_mm32<false>(l->dct, 1, 32, l->tmp, l->res, sh, 0);
+#endif
+}
 RBT_DEV void rc_inv_transform(int log2, int is_dst, int ts, int bd, RBT_LDS_AS RbtReconLdsCore* l) {
   int N = 1 << log2, sh = 20 - bd;
   if (ts) {
@@ -192,7 +202,7 @@ RBT_DEV void rc_inv_transform(int log2, int is_dst, int ts, int bd, RBT_LDS_AS R
   if (log2 == 2) rc_inv_transform_n<2>(is_dst, sh, l);
   else if (log2 == 3) rc_inv_transform_n<3>(0, sh, l);
   else if (log2 == 4) rc_inv_transform_n<4>(0, sh, l);
-  else rc_inv_transform_n<5>(0, sh, l);
+  else rc_inv_transform_32(sh, l);
 }
 
 // two blocks of the same size at once (Cb and Cr of a TU): block b lives at res / tmp offset b * 256; m0 / m1 = block present

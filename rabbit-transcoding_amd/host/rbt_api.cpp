@@ -179,6 +179,11 @@ int rbt_or_pool(rbt_ctx* ctx, const uint16_t* plane, int width, int height, int 
   return rbt::or_pool_host(plane, width, height, factor, out);
 }
 
+int rbt_selftest_transform32(rbt_ctx* ctx, const int16_t* blocks, int n_blocks, int bit_depth, uint32_t* n_mismatch) {
+  if (!ctx || !blocks || n_blocks < 1 || bit_depth < 8 || bit_depth > 12 || !n_mismatch) return RBT_ERR_PARAM;
+  RBT_ENTER(ctx);
+  return rbtk::selftest_transform32(blocks, n_blocks, bit_depth, n_mismatch) ? RBT_ERR_NO_DEVICE : RBT_OK;
+}
 int rbt_reconstruct(rbt_ctx* ctx, const rbt_atlas_params* atlas, const rbt_patch* patches, int n_patches, const uint16_t* occ_luma, const uint16_t* geo_d0,
                     const uint16_t* geo_d1, int geo_bit_depth, const uint16_t* attr_t0, const uint16_t* attr_t1, int attr_bit_depth, rbt_cloud* out) {
   if (!ctx || !atlas || (!patches && n_patches) || !occ_luma || !geo_d0 || !out) return RBT_ERR_PARAM;

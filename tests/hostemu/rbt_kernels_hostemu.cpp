@@ -88,6 +88,7 @@ void launch_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_l
   }
 }
 #include "rbt_kernels_hostemu_enc.inc"
+int selftest_transform32(const int16_t*, int, int, uint32_t* n_bad) { *n_bad = 0; return 0; }   // no matrix cores here
 // verification stage: the same per-element routines, visited serially
 void launch_pcc_occmap(const RbtPccParams* P, const uint16_t* occ, uint8_t* om) { for (int i = 0; i < P->w * P->h; i++) om[i] = occ[(size_t)(i / P->w / P->prec) * P->ow + (i % P->w) / P->prec] > P->threshold; }
 void launch_pcc_owner(const RbtPccParams* P, const rbt_patch* patches, const uint32_t* items, int n_items, const uint16_t* occ, uint32_t* b2p) {

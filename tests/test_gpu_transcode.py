@@ -198,3 +198,14 @@ def test_destroy_with_jobs_in_flight_drains_them():
     assert all(c2.wait_gof(j) == want for j in jobs)
     c2.close()
 
+
+
+def test_matrix_core_transforms_equal_vector_alu(ctx):
+    """32-point transform stages on v_mfma_i32_32x32x32_i8 (csrc/rbt_mfma.h) vs the vector-ALU stages, on the device: random, sparse and extreme blocks"""
+    r = np.random.default_rng(5)
+    blocks = [r.integers(-32768, 32768, 1024), r.integers(-600, 600, 1024), np.full(1024, 32767), np.full(1024, -32768), np.zeros(1024)]
+    sp = np.zeros(1024, np.int64); sp[[0, 1, 32, 33, 5 * 32 + 7]] = [4000, -3000, 2500, -32768, 32767]; blocks.append(sp)
+    for k in range(26): blocks.append(r.integers(-32768, 32768, 1024) * (r.random(1024) < 0.05))
+    alt = np.where((np.arange(1024) // 32 + np.arange(1024)) % 2 == 0, 32767, -32768); blocks.append(alt)
+    for bd in (8, 10):
+        assert ctx.selftest_transform32(np.stack(blocks).astype(np.int16), bd) == 0
