@@ -212,10 +212,12 @@ def main():
            "cabac_encode": enc_pix + out_bytes}                # levels in, slice data out
     achieved = alg[dom] / (groups[dom] * 1e-3) / 1e9 if groups[dom] > 0 else 0.0
     # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-    # runs of this same command: profiles/r01_pmc_traffic.json); counters cannot be read live from inside the benchmark
+    # runs of this same command: profiles/r02_pmc_traffic.json, tools/refresh_profiles.py); counters cannot be read live from inside the benchmark
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")     # HM-like input; the round-1 file belongs to the RBT-E1-coded input
+        if not fixture or not os.path.exists(pmc_file): pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        pmc = json.load(open(pmc_file))["kernels"]
         kmap = {"cabac_parse": ["k_parse"], "intra_analysis": ["k_enc_analyse"], "cabac_encode": ["k_entropy"]}
         if dom in kmap and n_pc == 32 and (w, h) == (1280, 1280):
             traffic = int(sum((pmc[k]["FETCH_SIZE_KB"] + pmc[k]["WRITE_SIZE_KB"]) * 1024 for k in kmap[dom]))

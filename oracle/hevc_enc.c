@@ -8,8 +8,9 @@
  *     gop=1 -> all IDR (occupancy); parameter sets repeated with every IDR.
  *   - CQP: P slices at qp, I slices at qp + i_qp_offset (x265 CQP with ipratio 1.4 => -3).
  *   - one slice per `ctb_rows_per_slice` CTB rows so entropy coding and intra reconstruction parallelise per row.
- *   - I pictures: CU quadtree 32/16/8 chosen bottom-up from open-loop (source-neighbour) intra SAD, 11 candidate
- *     modes, TU = CU, chroma DM; dead-zone quantiser 171/512.
+ *   - I pictures: CU quadtree 32/16/8 chosen bottom-up from open-loop (source-neighbour) intra SAD over all 35 modes by a
+ *     two-step search (11 coarse candidates, then the angular modes within two of the best), TU = CU, chroma DM; dead-zone
+ *     quantiser 171/512.
  *   - P pictures: 16x16 CUs merged (zero MV) + residual, skip when all levels are zero, skips merged up the tree;
  *     dead-zone 85/512.
  *   - lossless (occupancy): cu_transquant_bypass, same quadtree/mode analysis.
@@ -853,8 +854,13 @@ static void analyse_ctb_intra(enc* e, int cx, int cy) {
       if (x0 >= sps->width || y0 >= sps->height) { e->an_cost[si][bi] = 0; continue; }
       if (x0 + S > sps->width || y0 + S > sps->height) {   /* block straddles the picture edge: never a CU, but its inside part counts as coded */
         e->an_cost[si][bi] = 0x0FFFFFFF; set_rect8(m->done, m->w4, x0, y0, imin(S, sps->width - x0), imin(S, sps->height - y0), 1); continue; }
-      for (int k = 0; k < 11; k++) {
-        int mode = k_intra_cand[k];
+      /* 11 coarse candidates (planar, DC, every fourth angular mode), then the angular modes within two of the best coarse one: every one of
+       * the 35 modes is within reach, at most 15 are evaluated; ties keep the earlier candidate */
+      int coarse = 0;
+      for (int k = 0; k < 15; k++) {
+        int mode;
+        if (k < 11) mode = k_intra_cand[k];
+        else { if (k == 11) coarse = e->an_mode[si][bi]; if (coarse < 2) break; mode = coarse + (k == 11 ? -2 : k == 12 ? -1 : k == 13 ? 1 : 2); if (mode < 2 || mode > 34) continue; }
         hevc_intra_pred_buf(&srcview, m, 0, x0, y0, 3 + si, mode, pred);
         int sad = 0;
         const uint16_t* sp = e->src->p[0] + (size_t)y0 * e->src->w + x0;

@@ -130,8 +130,12 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
           }
           RBT_SYNC_LDS();
           rc_intra_filter_apply(g, lg, rl->nb, rl->nbf);
-          for (int k = 0; k < 11; k++) {
-            int mode = k_intra_cand[k];
+          // 11 coarse candidates, then the angular modes within two of the best coarse one (oracle/hevc_enc.c analyse_ctb_intra)
+          int coarse = 0;
+          for (int k = 0; k < 15; k++) {
+            int mode;
+            if (k < 11) mode = k_intra_cand[k];
+            else { if (k == 11) coarse = bmode; if (coarse < 2) break; mode = coarse + (k == 11 ? -2 : k == 12 ? -1 : k == 13 ? 1 : 2); if (mode < 2 || mode > 34) continue; }
             RBT_LDS_AS int32_t* fin = rc_intra_filter_needed(0, lg, mode) ? rl->nbf : rl->nb;
             RcIntraCtx qc; rc_intra_setup(g, 0, lg, mode, fin, rl->ref, &qc);
             int part = 0;
