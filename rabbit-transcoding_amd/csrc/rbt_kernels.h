@@ -43,6 +43,10 @@ double timer_ms(int id);                  // valid after dev_sync()
 // batch, zero-initialised): each launch advances every unfinished slice up to CTB row row_limit
 // pictures of several batches on one wavefront (every anti-diagonal is one launch over all of them)
 void launch_recon_refs(const RbtFrameRef* refs, int n_frames, int max_w_ctb, int max_h_ctb);
+// One launch per dependency level instead of one per anti-diagonal: every workgroup takes a ticket (atomic counter, *ticket zeroed beforehand), tickets walk the
+// pictures' CTBs in dependency order, a CTB waits for the done flags of its left and above-right neighbours (RbtFrame::ctb_done, zeroed beforehand).
+// max_ctbs = CTBs of the largest picture. Tickets are handed out in start order, so every flag a workgroup waits for belongs to one that already runs.
+void launch_recon_level(const RbtFrameRef* refs, int n_frames, int max_ctbs, uint32_t* ticket);
 // slices of several batches in one launch (pipelines that share a HIP stream: their parsers then run side by side)
 void launch_parse_tasks(const RbtParseTask* tasks, int n_tasks, int max_w4);
 // max_w4: width of the widest picture of the launch in 4-sample units (<= 2048; selects the LDS footprint of the parser)

@@ -162,6 +162,40 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
   if (r.frames[r.frame].ctb_slice[addr] == 0xFFFF) return;     // CTB not covered by any decoded slice
   recon_ctb_roles(r.frames, r.slices, r.frame, addr, RBT_LDS_CAST(RbtReconCtbLds, &lds));
 }
+// ---- one launch per dependency level: CTB-to-CTB hand-off through done flags in HBM ----
+// Producer (each of the two waves for its half of the CTB): stores -> agent-scope release (writes the XCD's L2 back) -> s_waitcnt vmcnt(0) -> relaxed flag store.
+// Consumer: relaxed agent-scope poll of the flag (served by L2, never a stale L1 line) -> agent-scope acquire (invalidates this CU's L1) -> its own loads.
+// (MI355X_MICROARCH.md, inter-workgroup visibility: per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed by another CU's stores.)
+// Every wave reaches its flag store on every path - a corrupt picture, an uncovered CTB or a wait that ran out of patience sets the picture's error word and goes on -
+// so the grid always drains.
+__device__ __forceinline__ void recon_wait_flag(const uint32_t* flag, RbtFrame* f) {
+  int spins = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > (1 << 23)) { f->error = 90; break; }      // seconds: the predecessor runs on this GPU already (ticket order), something is broken
+  }
+}
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) k_recon_level(const RbtFrameRef* refs, int n_frames, uint32_t* ticket) {
+  __shared__ RbtReconCtbLds lds;
+  __shared__ uint32_t s_ticket;
+  if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const uint32_t t = s_ticket;
+  const RbtFrameRef r = refs[t % (uint32_t)n_frames];
+  RbtFrame* f = &r.frames[r.frame];
+  const int w = f->cfg.w_ctb, n_ctb = w * f->cfg.h_ctb, i = (int)(t / (uint32_t)n_frames);
+  if (i >= n_ctb) return;                                     // this picture has fewer CTBs than the largest one of the launch
+  const int xy = r.order[i], x = xy & 255, y = xy >> 8, addr = y * w + x, role = (int)threadIdx.x >> 6;
+  uint32_t* done = f->ctb_done;
+  // left neighbour; above-right neighbour (it waited for the one above, which waited for the one above-left) or, in the last column, the one above
+  if (x > 0) recon_wait_flag(&done[2 * (addr - 1) + role], f);
+  if (y > 0) recon_wait_flag(&done[2 * (addr - w + (x + 1 < w ? 1 : 0)) + role], f);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (f->ctb_slice[addr] != 0xFFFF) recon_ctb_roles(r.frames, r.slices, r.frame, addr, RBT_LDS_CAST(RbtReconCtbLds, &lds));
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(&done[2 * addr + role], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __global__ void __launch_bounds__(256) k_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int dir) {
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   int unit = blockIdx.x * 256 + threadIdx.x;
@@ -196,6 +230,10 @@ void launch_recon_refs(const RbtFrameRef* refs, int n_frames, int max_w_ctb, int
     if (y_lo > y_hi) continue;
     hipLaunchKernelGGL(k_recon_diag_refs, dim3(y_hi - y_lo + 1, n_frames), dim3(128), 0, g_stream, refs, d, y_lo);
   }
+}
+void launch_recon_level(const RbtFrameRef* refs, int n_frames, int max_ctbs, uint32_t* ticket) {
+  if (n_frames <= 0 || max_ctbs <= 0) return;
+  hipLaunchKernelGGL(k_recon_level, dim3((unsigned)n_frames * (unsigned)max_ctbs), dim3(128), 0, g_stream, refs, n_frames, ticket);
 }
 void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_units) {
   if (n_frames <= 0) return;

@@ -78,6 +78,7 @@ struct RbtFrame {
   int32_t level;                 // dependency level inside the batch (0: no references inside the batch)
   int32_t n_slices, first_slice;
   int32_t error;                 // set by kernels (non-zero = corrupt / unsupported stream)
+  uint32_t* ctb_done;            // per CTB two words (luma chain, Cb/Cr chain): set when that half of the CTB is reconstructed (k_recon_level)
   // ---- encoder side (RBT-E1) ----
   const uint16_t* src[3];        // source planes (the decoder's `out` planes or the pooled occupancy map)
   uint8_t* cu_log2;              // per 8x8 unit: log2 size of the coding unit covering it
@@ -98,7 +99,8 @@ struct RbtFrame;
 // One slice segment of a merged entropy-decoding launch (slices of several batches in one grid: rbt_kernels.h launch_parse_tasks)
 struct RbtParseTask { RbtFrame* frames; RbtSlice* slices; const uint8_t* rbsp; int32_t slice; int32_t pad; };
 // One picture of a merged reconstruction launch (pictures of several batches on the same wavefront: launch_recon_refs)
-struct RbtFrameRef { RbtFrame* frames; const RbtSlice* slices; int32_t frame; int32_t pad; };
+// order: the picture's CTBs in dependency order (anti-diagonals x + 2y ascending), x | y << 8 each (launch_recon_level)
+struct RbtFrameRef { RbtFrame* frames; const RbtSlice* slices; const uint16_t* order; int32_t frame; int32_t pad; };
 
 struct RbtSlice {                // one per slice segment, parsed on the host (7.3.6)
   int32_t frame;                 // index into the batch frame table

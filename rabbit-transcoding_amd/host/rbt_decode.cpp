@@ -97,9 +97,10 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
   // ---- HBM layout: [zero region | pm region (0x03) | ctb_slice region (0xFF) | rest] ----
   Arena a;
   size_t nf = b.frames.size();
-  std::vector<size_t> o_coef(nf), o_edges(nf), o_cnt(nf), o_pm(nf), o_cs(nf), o_pix(nf), o_out(nf), o_dm(nf), o_qp(nf), o_mv(nf), o_ref(nf), o_refpoc(nf), o_sao(nf), o_cmds(nf);
+  std::vector<size_t> o_coef(nf), o_edges(nf), o_cnt(nf), o_done(nf), o_pm(nf), o_cs(nf), o_pix(nf), o_out(nf), o_dm(nf), o_qp(nf), o_mv(nf), o_ref(nf), o_refpoc(nf), o_sao(nf), o_cmds(nf);
   for (size_t i = 0; i < nf; i++) { const RbtStreamCfg& c = b.frames[i].cfg; size_t u = (size_t)c.w4 * c.h4, nc = (size_t)c.w_ctb * c.h_ctb;
-    o_coef[i] = a.reserve(frame_samples(c) * 2); o_edges[i] = a.reserve(u); o_cnt[i] = a.reserve(nc * 4); }
+    o_coef[i] = a.reserve(frame_samples(c) * 2); o_edges[i] = a.reserve(u); o_cnt[i] = a.reserve(nc * 4); o_done[i] = a.reserve(nc * 8); }
+  size_t o_tickets = a.reserve(64 * 4);
   size_t o_save = b.want_save ? a.reserve(b.slices.size() * rbtk::parse_save_bytes()) : 0;
   size_t zero_end = a.reserve(0);
   for (size_t i = 0; i < nf; i++) { const RbtStreamCfg& c = b.frames[i].cfg; o_pm[i] = a.reserve((size_t)c.w4 * c.h4); }
@@ -115,6 +116,16 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
   }
   size_t o_frames = a.reserve(nf * sizeof(RbtFrame)), o_slices = a.reserve(b.slices.size() * sizeof(RbtSlice));
   size_t o_rbsp = a.reserve(b.rbsp.size() + 16), o_lists = a.reserve((nf + b.slices.size()) * 2 * sizeof(int32_t));
+  // CTB dependency order (anti-diagonals x + 2y ascending, top to bottom inside one) per distinct picture geometry, and the pictures of every level as RbtFrameRef
+  b.order_keep.clear(); b.order_off.assign(nf, 0);
+  { std::vector<std::pair<std::pair<int, int>, size_t>> seen;
+    for (size_t i = 0; i < nf; i++) { const int w = b.frames[i].cfg.w_ctb, h = b.frames[i].cfg.h_ctb; size_t off = (size_t)-1;
+      for (auto& s_ : seen) if (s_.first == std::make_pair(w, h)) off = s_.second;
+      if (off == (size_t)-1) { off = b.order_keep.size(); seen.push_back({{w, h}, off});
+        if (w > 255 || h > 255) { b.err = "picture too large"; return b.err_code = RBT_ERR_UNSUPPORTED; }
+        for (int d = 0; d <= w - 1 + 2 * (h - 1); d++) for (int y = 0; y < h; y++) { int x = d - 2 * y; if (x >= 0 && x < w) b.order_keep.push_back((uint16_t)(x | (y << 8))); } }
+      b.order_off[i] = off; } }
+  size_t o_order = a.reserve(b.order_keep.size() * 2), o_refs = a.reserve(nf * sizeof(RbtFrameRef));
   b.arena_size = a.reserve(0);
   b.arena = rbtk::dev_alloc(b.arena_size);
   if (!b.arena) { b.err = "device allocation failed"; return b.err_code = RBT_ERR_NOMEM; }
@@ -126,15 +137,23 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
     f.coef[0] = (int16_t*)(base + o_coef[i]); f.coef[1] = f.coef[0] + ys; f.coef[2] = f.coef[1] + cs;
     f.pm = base + o_pm[i]; f.edges = base + o_edges[i]; f.dm = base + o_dm[i]; f.qp = (int8_t*)(base + o_qp[i]); f.mv = (int16_t*)(base + o_mv[i]);
     f.ref = (int8_t*)(base + o_ref[i]); f.refpoc = (int32_t*)(base + o_refpoc[i]); f.sao = (RbtSao*)(base + o_sao[i]); f.ctb_slice = (uint16_t*)(base + o_cs[i]);
-    f.cmds = (RbtCmd*)(base + o_cmds[i]); f.cmd_count = (uint32_t*)(base + o_cnt[i]);
+    f.cmds = (RbtCmd*)(base + o_cmds[i]); f.cmd_count = (uint32_t*)(base + o_cnt[i]); f.ctb_done = (uint32_t*)(base + o_done[i]);
   }
+  b.d_order = (uint16_t*)(base + o_order); b.d_refs = (RbtFrameRef*)(base + o_refs); b.d_tickets = (uint32_t*)(base + o_tickets);
+  b.refs_keep.clear(); b.refs_off.clear();
+  for (auto& lf : b.level_frames) { b.refs_off.push_back(b.refs_keep.size()); for (int fi : lf) b.refs_keep.push_back(RbtFrameRef{(RbtFrame*)(base + o_frames), (const RbtSlice*)(base + o_slices), b.d_order + b.order_off[fi], fi, 0}); }
+  if (b.level_frames.size() > 32) { b.err = "too many dependency levels"; return b.err_code = RBT_ERR_UNSUPPORTED; }
   b.d_save = b.want_save ? (void*)(base + o_save) : nullptr;
   b.d_frames = (RbtFrame*)(base + o_frames); b.d_slices = (RbtSlice*)(base + o_slices); b.d_rbsp = base + o_rbsp; b.d_lists = (int32_t*)(base + o_lists);
   if (rbtk::dev_memset(base, 0, zero_end) || rbtk::dev_memset(base + pm_begin, RBT_MODE_NONE, pm_end - pm_begin) || rbtk::dev_memset(base + cs_begin, 0xFF, cs_end - cs_begin) ||
       rbtk::h2d(b.d_frames, b.frames.data(), nf * sizeof(RbtFrame)) || rbtk::h2d(b.d_slices, b.slices.data(), b.slices.size() * sizeof(RbtSlice)) ||
-      rbtk::h2d(b.d_rbsp, b.rbsp.data(), b.rbsp.size())) { b.err = "device transfer failed"; return b.err_code = RBT_ERR_NO_DEVICE; }
+      rbtk::h2d(b.d_rbsp, b.rbsp.data(), b.rbsp.size()) || rbtk::h2d(b.d_order, b.order_keep.data(), b.order_keep.size() * 2) ||
+      rbtk::h2d(b.d_refs, b.refs_keep.data(), b.refs_keep.size() * sizeof(RbtFrameRef))) { b.err = "device transfer failed"; return b.err_code = RBT_ERR_NO_DEVICE; }
   return 0;
 }
+
+// RBT_RECON_DIAG=1: one launch per anti-diagonal (the round-1 scheme) instead of one per level with CTB-to-CTB flags; for A/B measurements
+bool recon_by_diagonals() { static int v = -1; if (v < 0) { const char* e = getenv("RBT_RECON_DIAG"); v = e && atoi(e) ? 1 : 0; } return v != 0; }
 
 int decode_run(DecodeBatch& b) { int rc = decode_launch(b); return rc ? rc : decode_finish(b); }
 
@@ -220,7 +239,8 @@ void decode_launch_level(DecodeBatch& b, size_t l) {
   const std::vector<int>& lf = b.level_frames[l];
   int mw = 0, mh = 0;
   for (int fi : lf) { const RbtStreamCfg& c = b.frames[fi].cfg; mw = std::max(mw, c.w_ctb); mh = std::max(mh, c.h_ctb); }
-  rbtk::launch_recon(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l], (int)lf.size(), mw, mh);
+  if (recon_by_diagonals()) rbtk::launch_recon(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l], (int)lf.size(), mw, mh);
+  else rbtk::launch_recon_level(b.d_refs + b.refs_off[l], (int)lf.size(), mw * mh, b.d_tickets + l);
   decode_launch_filters(b, l);
 }
 

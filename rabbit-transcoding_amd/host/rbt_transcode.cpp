@@ -424,7 +424,7 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
     for (size_t l = 0; l < n_levels; l++) {
       lv_off[l] = refs.size();
       for (int gi : grp) if (l < db[gi].level_frames.size()) for (int fi : db[gi].level_frames[l]) {
-        refs.push_back(RbtFrameRef{db[gi].d_frames, db[gi].d_slices, fi, 0});
+        refs.push_back(RbtFrameRef{db[gi].d_frames, db[gi].d_slices, db[gi].d_order + db[gi].order_off[fi], fi, 0});
         lv_w[l] = std::max(lv_w[l], (int)db[gi].frames[fi].cfg.w_ctb); lv_h[l] = std::max(lv_h[l], (int)db[gi].frames[fi].cfg.h_ctb);
       }
     }
@@ -439,7 +439,9 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
     rbtk::timer_begin(T_PARSE); rbtk::launch_parse_tasks(d_tasks, (int)tasks.size(), mw4); rbtk::timer_end(T_PARSE);
     rbtk::timer_begin(T_RECON);
     for (size_t l = 0; l < n_levels; l++) {
-      rbtk::launch_recon_refs(d_refs + lv_off[l], (int)(lv_off[l + 1] - lv_off[l]), lv_w[l], lv_h[l]);
+      // the merged launch of level l uses the lead batch's spare ticket counter 32 + l (its own levels use 0..31)
+      if (recon_by_diagonals()) rbtk::launch_recon_refs(d_refs + lv_off[l], (int)(lv_off[l + 1] - lv_off[l]), lv_w[l], lv_h[l]);
+      else rbtk::launch_recon_level(d_refs + lv_off[l], (int)(lv_off[l + 1] - lv_off[l]), lv_w[l] * lv_h[l], db[lead].d_tickets + 32 + l);
       for (int gi : grp) if (l < db[gi].level_frames.size()) decode_launch_filters(db[gi], l);
     }
     rbtk::timer_end(T_RECON);

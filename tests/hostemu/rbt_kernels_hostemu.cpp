@@ -62,6 +62,17 @@ void launch_recon_refs(const RbtFrameRef* refs, int n_frames, int max_w_ctb, int
       }
     }
 }
+void launch_recon_level(const RbtFrameRef* refs, int n_frames, int max_ctbs, uint32_t*) {
+  static RbtReconCtbLds lds;
+  for (int i = 0; i < max_ctbs; i++) for (int k = 0; k < n_frames; k++) {      // ticket order: CTB i of every picture, then CTB i + 1
+    RbtFrame* frames = refs[k].frames; int fi = refs[k].frame; const RbtStreamCfg* g = &frames[fi].cfg;
+    if (i >= g->w_ctb * g->h_ctb) continue;
+    int xy = refs[k].order[i], addr = (xy >> 8) * g->w_ctb + (xy & 255);
+    if (frames[fi].ctb_slice[addr] == 0xFFFF) continue;
+    rbt_recon_ctb<RC_ROLE_LUMA>(frames, refs[k].slices, fi, addr, &lds.t, &lds.role[0]);
+    rbt_recon_ctb<RC_ROLE_CHROMA>(frames, refs[k].slices, fi, addr, &lds.t, &lds.role[1]);
+  }
+}
 void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int y_begin, int y_end) {
   static RbtReconCtbLds lds;
   if (y_end > max_h_ctb) y_end = max_h_ctb;
