@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
   RbtFrame* f = &r.frames[r.frame];
   const int w = f->cfg.w_ctb, n_ctb = w * f->cfg.h_ctb, i = (int)(t / (uint32_t)n_frames);
   if (i >= n_ctb) return;                                     // this picture has fewer CTBs than the largest one of the launch
-  const int xy = r.order[i], x = xy & 255, y = xy >> 8, addr = y * w + x, role = (int)threadIdx.x >> 6;
+  const int xy = (int)r.order[i], x = xy & 0xFFFF, y = xy >> 16, addr = y * w + x, role = (int)threadIdx.x >> 6;
   uint32_t* done = f->ctb_done;
   // left neighbour; above-right neighbour (it waited for the one above, which waited for the one above-left) or, in the last column, the one above
   if (x > 0) recon_wait_flag(&done[2 * (addr - 1) + role], f);

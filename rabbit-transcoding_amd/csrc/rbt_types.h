@@ -99,8 +99,8 @@ struct RbtFrame;
 // One slice segment of a merged entropy-decoding launch (slices of several batches in one grid: rbt_kernels.h launch_parse_tasks)
 struct RbtParseTask { RbtFrame* frames; RbtSlice* slices; const uint8_t* rbsp; int32_t slice; int32_t pad; };
 // One picture of a merged reconstruction launch (pictures of several batches on the same wavefront: launch_recon_refs)
-// order: the picture's CTBs in dependency order (anti-diagonals x + 2y ascending), x | y << 8 each (launch_recon_level)
-struct RbtFrameRef { RbtFrame* frames; const RbtSlice* slices; const uint16_t* order; int32_t frame; int32_t pad; };
+// order: the picture's CTBs in dependency order (anti-diagonals x + 2y ascending), x | y << 16 each (launch_recon_level)
+struct RbtFrameRef { RbtFrame* frames; const RbtSlice* slices; const uint32_t* order; int32_t frame; int32_t pad; };
 
 struct RbtSlice {                // one per slice segment, parsed on the host (7.3.6)
   int32_t frame;                 // index into the batch frame table

@@ -33,9 +33,9 @@ struct DecodeBatch {
   std::vector<int32_t> lists_keep;     // host staging of the index lists, alive until the copy has completed
   std::vector<size_t> fr_off;          // offset of each level's frame list inside d_lists
   std::vector<size_t> sl_off, sl_cnt;  // slice list of each level inside d_lists
-  std::vector<uint16_t> order_keep; std::vector<size_t> order_off;   // CTB dependency order per picture (host staging, offset per frame)
+  std::vector<uint32_t> order_keep; std::vector<size_t> order_off;   // CTB dependency order per picture (host staging, offset per frame)
   std::vector<RbtFrameRef> refs_keep; std::vector<size_t> refs_off;   // the pictures of each level as RbtFrameRef (launch_recon_level)
-  uint16_t* d_order = nullptr; RbtFrameRef* d_refs = nullptr; uint32_t* d_tickets = nullptr;   // one ticket counter per level + spare ones for merged launches
+  uint32_t* d_order = nullptr; RbtFrameRef* d_refs = nullptr; uint32_t* d_tickets = nullptr;   // one ticket counter per level + spare ones for merged launches
   void* d_save = nullptr;              // RbtParseSave per slice (resumable parsing), zero-initialised; nullptr when not requested
   bool want_save = false;              // set before decode_build to reserve d_save
   void* arena = nullptr; size_t arena_size = 0;

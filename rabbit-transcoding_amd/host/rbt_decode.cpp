@@ -122,10 +122,9 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
     for (size_t i = 0; i < nf; i++) { const int w = b.frames[i].cfg.w_ctb, h = b.frames[i].cfg.h_ctb; size_t off = (size_t)-1;
       for (auto& s_ : seen) if (s_.first == std::make_pair(w, h)) off = s_.second;
       if (off == (size_t)-1) { off = b.order_keep.size(); seen.push_back({{w, h}, off});
-        if (w > 255 || h > 255) { b.err = "picture too large"; return b.err_code = RBT_ERR_UNSUPPORTED; }
-        for (int d = 0; d <= w - 1 + 2 * (h - 1); d++) for (int y = 0; y < h; y++) { int x = d - 2 * y; if (x >= 0 && x < w) b.order_keep.push_back((uint16_t)(x | (y << 8))); } }
+        for (int d = 0; d <= w - 1 + 2 * (h - 1); d++) for (int y = 0; y < h; y++) { int x = d - 2 * y; if (x >= 0 && x < w) b.order_keep.push_back((uint32_t)x | ((uint32_t)y << 16)); } }
       b.order_off[i] = off; } }
-  size_t o_order = a.reserve(b.order_keep.size() * 2), o_refs = a.reserve(nf * sizeof(RbtFrameRef));
+  size_t o_order = a.reserve(b.order_keep.size() * 4), o_refs = a.reserve(nf * sizeof(RbtFrameRef));
   b.arena_size = a.reserve(0);
   b.arena = rbtk::dev_alloc(b.arena_size);
   if (!b.arena) { b.err = "device allocation failed"; return b.err_code = RBT_ERR_NOMEM; }
@@ -139,7 +138,7 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
     f.ref = (int8_t*)(base + o_ref[i]); f.refpoc = (int32_t*)(base + o_refpoc[i]); f.sao = (RbtSao*)(base + o_sao[i]); f.ctb_slice = (uint16_t*)(base + o_cs[i]);
     f.cmds = (RbtCmd*)(base + o_cmds[i]); f.cmd_count = (uint32_t*)(base + o_cnt[i]); f.ctb_done = (uint32_t*)(base + o_done[i]);
   }
-  b.d_order = (uint16_t*)(base + o_order); b.d_refs = (RbtFrameRef*)(base + o_refs); b.d_tickets = (uint32_t*)(base + o_tickets);
+  b.d_order = (uint32_t*)(base + o_order); b.d_refs = (RbtFrameRef*)(base + o_refs); b.d_tickets = (uint32_t*)(base + o_tickets);
   b.refs_keep.clear(); b.refs_off.clear();
   for (auto& lf : b.level_frames) { b.refs_off.push_back(b.refs_keep.size()); for (int fi : lf) b.refs_keep.push_back(RbtFrameRef{(RbtFrame*)(base + o_frames), (const RbtSlice*)(base + o_slices), b.d_order + b.order_off[fi], fi, 0}); }
   if (b.level_frames.size() > 32) { b.err = "too many dependency levels"; return b.err_code = RBT_ERR_UNSUPPORTED; }
@@ -147,7 +146,7 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
   b.d_frames = (RbtFrame*)(base + o_frames); b.d_slices = (RbtSlice*)(base + o_slices); b.d_rbsp = base + o_rbsp; b.d_lists = (int32_t*)(base + o_lists);
   if (rbtk::dev_memset(base, 0, zero_end) || rbtk::dev_memset(base + pm_begin, RBT_MODE_NONE, pm_end - pm_begin) || rbtk::dev_memset(base + cs_begin, 0xFF, cs_end - cs_begin) ||
       rbtk::h2d(b.d_frames, b.frames.data(), nf * sizeof(RbtFrame)) || rbtk::h2d(b.d_slices, b.slices.data(), b.slices.size() * sizeof(RbtSlice)) ||
-      rbtk::h2d(b.d_rbsp, b.rbsp.data(), b.rbsp.size()) || rbtk::h2d(b.d_order, b.order_keep.data(), b.order_keep.size() * 2) ||
+      rbtk::h2d(b.d_rbsp, b.rbsp.data(), b.rbsp.size()) || rbtk::h2d(b.d_order, b.order_keep.data(), b.order_keep.size() * 4) ||
       rbtk::h2d(b.d_refs, b.refs_keep.data(), b.refs_keep.size() * sizeof(RbtFrameRef))) { b.err = "device transfer failed"; return b.err_code = RBT_ERR_NO_DEVICE; }
   return 0;
 }

@@ -67,7 +67,7 @@ void launch_recon_level(const RbtFrameRef* refs, int n_frames, int max_ctbs, uin
   for (int i = 0; i < max_ctbs; i++) for (int k = 0; k < n_frames; k++) {      // ticket order: CTB i of every picture, then CTB i + 1
     RbtFrame* frames = refs[k].frames; int fi = refs[k].frame; const RbtStreamCfg* g = &frames[fi].cfg;
     if (i >= g->w_ctb * g->h_ctb) continue;
-    int xy = refs[k].order[i], addr = (xy >> 8) * g->w_ctb + (xy & 255);
+    int xy = (int)refs[k].order[i], addr = (xy >> 16) * g->w_ctb + (xy & 0xFFFF);
     if (frames[fi].ctb_slice[addr] == 0xFFFF) continue;
     rbt_recon_ctb<RC_ROLE_LUMA>(frames, refs[k].slices, fi, addr, &lds.t, &lds.role[0]);
     rbt_recon_ctb<RC_ROLE_CHROMA>(frames, refs[k].slices, fi, addr, &lds.t, &lds.role[1]);
