@@ -171,8 +171,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
 __device__ __forceinline__ void recon_wait_flag(const uint32_t* flag, RbtFrame* f) {
   int spins = 0;
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-    __builtin_amdgcn_s_sleep(2);
-    if (++spins > (1 << 23)) { f->error = 90; break; }      // seconds: the predecessor runs on this GPU already (ticket order), something is broken
+    __builtin_amdgcn_s_sleep(32);                               // ~2k cycles between polls: a CTB takes 100+ us, and a polling wave should leave the issue slots to working ones
+    if (++spins > (1 << 20)) { f->error = 90; break; }      // seconds: the predecessor runs on this GPU already (ticket order), something is broken
   }
 }
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) k_recon_level(const RbtFrameRef* refs, int n_frames, uint32_t* ticket) {

@@ -45,7 +45,8 @@ struct DecodeBatch {
 };
 
 int decode_build(DecodeBatch& b, const StreamIn* streams, int n);
-bool recon_by_diagonals();           // RBT_RECON_DIAG=1
+bool recon_by_diagonals();           // per-diagonal launches instead of the flag kernel (see rbt_decode.cpp)
+void recon_set_depth(int depth);     // jobs the caller keeps in flight (rbt_set_depth)
 int decode_launch(DecodeBatch& b);   // enqueue every decode kernel of the batch on the current stream (no wait)
 int decode_launch_parse(DecodeBatch& b);            // index lists + entropy decoding
 int decode_upload_lists(DecodeBatch& b);            // index lists only (first half of decode_launch_parse)

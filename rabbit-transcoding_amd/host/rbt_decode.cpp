@@ -151,8 +151,18 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
   return 0;
 }
 
-// RBT_RECON_DIAG=1: one launch per anti-diagonal (the round-1 scheme) instead of one per level with CTB-to-CTB flags; for A/B measurements
-bool recon_by_diagonals() { static int v = -1; if (v < 0) { const char* e = getenv("RBT_RECON_DIAG"); v = e && atoi(e) ? 1 : 0; } return v != 0; }
+// Reconstruction of a dependency level: one launch with CTB-to-CTB done flags (launch_recon_level), or one launch per anti-diagonal.
+// Measured on MI355X (HM-like 32-frame GOF): the flag kernel shortens the level itself by 13-19 % (blocking call 352.1 -> 349.3 ms, reconstruction 64 -> 52 ms per job),
+// but with 16 GOFs in flight its resident waiting workgroups hold LDS and wave slots the other jobs' analysis / intra-coding kernels need (those go from 25-27 / 31 ms
+// to 40 / 49 ms per job): 598 against 635 frames/s. So: flags while few jobs are in flight (<= 4: the GPU is mostly idle), diagonals beyond.
+// RBT_RECON_DIAG=1 / RBT_RECON_LEVEL=1 force one or the other.
+static int g_jobs_in_flight_hint = 1;
+void recon_set_depth(int depth) { g_jobs_in_flight_hint = depth; }
+bool recon_by_diagonals() {
+  static int force = -1;
+  if (force < 0) { const char* d = getenv("RBT_RECON_DIAG"); const char* l = getenv("RBT_RECON_LEVEL"); force = d && atoi(d) ? 1 : (l && atoi(l) ? 2 : 0); }
+  return force == 1 || (force == 0 && g_jobs_in_flight_hint > 4);
+}
 
 int decode_run(DecodeBatch& b) { int rc = decode_launch(b); return rc ? rc : decode_finish(b); }
 
