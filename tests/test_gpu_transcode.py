@@ -216,3 +216,23 @@ def test_matrix_core_transforms_equal_vector_alu(ctx):
     alt = np.where((np.arange(1024) // 32 + np.arange(1024)) % 2 == 0, 32767, -32768); blocks.append(alt)
     for bd in (8, 10):
         assert ctx.selftest_transform32(np.stack(blocks).astype(np.int16), bd) == 0
+
+
+def test_stream_conversions_in_the_gpu_run(ctx):
+    """rbt_sample_to_byte_stream / rbt_byte_to_sample_stream (PCCVideoBitstream.cpp:85-172) need no device, but they are part of the path the GPU box
+    runs: a re-encoded sub-bitstream framed the way transcodeVideo leaves it (byteStreamToSampleStream, :517) and back, vs the oracle restatement"""
+    import ctypes
+    R = rbt_lib.module()
+    so, sg, sa, _ = _r5_streams(128, 128, 2, 19)
+    out = ctx.transcode_substream(sg, R.RBT_VIDEO_GEOMETRY, 24)
+    L = ctx.L
+    p, n = ctypes.c_void_p(), ctypes.c_size_t()
+    assert L.rbt_byte_to_sample_stream(out, len(out), ctypes.byref(p), ctypes.byref(n)) == 0
+    ss = ctypes.string_at(p, n.value); L.rbt_free(p)
+    assert ss == O.byte_to_sample_stream(out)
+    assert L.rbt_sample_to_byte_stream(ss, len(ss), ctypes.byref(p), ctypes.byref(n)) == 0
+    bs = ctypes.string_at(p, n.value); L.rbt_free(p)
+    assert bs == O.sample_to_byte_stream(ss)
+    # the reference's start-code rule re-frames the stream (4-byte codes only for the first NAL, parameter sets / SEI and after a VCL NAL);
+    # the NAL payloads must survive the round trip, and the result must still transcode to the same output
+    assert ctx.transcode_substream(bs, R.RBT_VIDEO_GEOMETRY, 24) == ctx.transcode_substream(out, R.RBT_VIDEO_GEOMETRY, 24)
