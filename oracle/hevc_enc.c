@@ -14,7 +14,8 @@
  *   - P pictures: 16x16 CUs merged (zero MV) + residual, skip when all levels are zero, skips merged up the tree;
  *     dead-zone 85/512.
  *   - lossless (occupancy): cu_transquant_bypass, same quadtree/mode analysis.
- *   - deblocking on (off for lossless), SAO off.
+ *   - deblocking on (off for lossless); SAO on (off for lossless): per CTB and component, band or edge offsets from the statistics of source
+ *     minus deblocked reconstruction (hm_sao_decide), merged with the left CTB when equal.
  * hm_like != 0 (oracle-only, not mirrored on the GPU) makes deterministic "HM-like" decisions with the coding tools of the CTC input
  * streams (cfg/hm/ctc-hm-geometry-ai.cfg: CTU 64 :10-11, TU 4..32 :13-16, motion search :33-34, TransformSkip :47, SAO :68, AMP :69,
  * sign data hiding and TMVP as HM defaults): 35 intra modes + NxN, TU split and 4x4 transform skip by a small RD comparison,
@@ -1290,6 +1291,8 @@ static void write_sao(enc* e, int rx, int ry) {
 }
 
 /* ================================================================================================ pictures */
+/* RBT-E1 codes SAO unless RBT_ENC_SAO=0 (development switch, read by the library the same way) */
+static int e1_sao_on(void) { const char* v = getenv("RBT_ENC_SAO"); return !v || atoi(v) != 0; }
 static void setup_stream(enc* e) {
   hevc_sps* s = &e->sps; hevc_pps* p = &e->pps; const oracle_enc_params* q = &e->p;
   memset(s, 0, sizeof(*s)); memset(p, 0, sizeof(*p));
@@ -1303,6 +1306,7 @@ static void setup_stream(enc* e) {
   p->init_qp = clip3(0, 51, q->qp); p->loop_filter_across_slices = 1;
   e->max_merge_cand = 1;
   if (q->lossless) { p->transquant_bypass_enabled = 1; p->deblocking_control_present = 1; p->pps_deblocking_disabled = 1; p->loop_filter_across_slices = 0; }
+  if (!e->stress && !e->hm && !q->lossless && e1_sao_on()) s->sao_enabled = 1;
   if (e->hm) {   /* cfg/hm/ctc-hm-geometry-ai.cfg:10-16,47,68,69 + HM defaults (SignHideFlag, TMVPMode, MaxNumMergeCand) */
     s->log2_ctb = q->log2_ctb ? q->log2_ctb : 6; s->log2_diff_max_min_cb = s->log2_ctb - 3;
     s->log2_max_tb = imin(5, s->log2_ctb); s->log2_diff_max_min_tb = s->log2_max_tb - 2;
@@ -1371,7 +1375,7 @@ static void encode_slices(enc* e, int is_i, int st_rps_idx, bytebuf* out) {
       if (p->loop_filter_across_slices && (h->sao_luma || h->sao_chroma || !h->deblocking_disabled)) h->loop_filter_across_slices = rndp(r, 70);
     } else h->qp = clip3(0, 51, is_i ? e->p.qp + e->p.i_qp_offset : e->p.qp + (e->hm ? e->p.p_qp_offset : 0));
     if (e->hm && !is_i) { h->temporal_mvp = s->temporal_mvp_enabled; h->collocated_ref_idx = 0; }
-    if (e->hm && e->hm_pass == 2) { h->sao_luma = 1; h->sao_chroma = 1; }
+    if (!e->stress && e->hm_pass == 2) { h->sao_luma = 1; h->sao_chroma = 1; }
     e->slice_qp = h->qp; e->slice_idx = m->n_slices++;
     hevc_slice_meta* sm = &m->slices[e->slice_idx]; memset(sm, 0, sizeof(*sm));
     sm->deblocking_disabled = (uint8_t)h->deblocking_disabled; sm->loop_filter_across = (uint8_t)h->loop_filter_across_slices;
@@ -1393,7 +1397,7 @@ static void encode_slices(enc* e, int is_i, int st_rps_idx, bytebuf* out) {
         hm_write_sao(e, rx, ry);
         hm_analyse_intra(e, rx * ctb, ry * ctb);
         if (!is_i) hm_inter_decide(e, rx * ctb, ry * ctb, s->log2_ctb, rx * ctb, ry * ctb);
-      } else { if (is_i) analyse_ctb_intra(e, rx * ctb, ry * ctb); else analyse_ctb_inter(e, rx * ctb, ry * ctb); }
+      } else { if (s->sao_enabled) hm_write_sao(e, rx, ry); if (is_i) analyse_ctb_intra(e, rx * ctb, ry * ctb); else analyse_ctb_inter(e, rx * ctb, ry * ctb); }
       encode_quadtree(e, rx * ctb, ry * ctb, s->log2_ctb, 0, rx * ctb, ry * ctb);
       ce_terminate(&e->c, a == end_addr - 1);
     }
@@ -1422,7 +1426,7 @@ static void encode_picture(enc* e, const hevc_frame* src, int idx, bytebuf* out,
     for (int i = 0; i < nref_avail; i++) { e->ref[i] = e->dpb[i]; e->refcol[i] = &e->dpbcol[i]; e->ref_poc[i] = e->dpb_poc[i]; }
     e->n_ref = nref_avail;
   }
-  if (e->hm && s->sao_enabled) {
+  if (!e->stress && s->sao_enabled) {
     /* SAO parameters come from the deblocked reconstruction but are coded in front of each CTB: code the picture once without SAO to get
      * that reconstruction, decide the parameters, then code it again (the CU decisions use no entropy-coder state, so they repeat exactly) */
     bytebuf scratch = {0, 0, 0};

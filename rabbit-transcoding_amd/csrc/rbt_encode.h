@@ -844,6 +844,101 @@ RBT_DEV void en_write_quadtree(RbtEnt* s, int x0, int y0, int log2) {
     }
   }
 }
+// ------------------------------------------------------------------------------------------------ SAO parameter decision
+// One wave per CTB, after deblocking: per component the statistics of source minus deblocked reconstruction - count and sum per band (32) and per edge
+// class x category (4 x 4) - accumulated with LDS adds, then offsets = rounded means clipped to +-7 (edge categories keep their sign), the type with the
+// largest distortion reduction minus lambda * rate; Cb and Cr share type and edge class (7.3.8.3). Mirrors hm_sao_decide in oracle/hevc_enc.c exactly.
+struct RbtSaoLds { int32_t bcnt[3][32], bsum[3][32], ecnt[3][16], esum[3][16]; };
+RBT_DEV int en_sao_round_div(int sum, int cnt) { return cnt ? (sum >= 0 ? sum + cnt / 2 : sum - cnt / 2) / cnt : 0; }
+RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtSaoLds* L) {
+  const RbtStreamCfg gcopy = f->cfg; const RbtStreamCfg* g = &gcopy;
+  const int ctb = 1 << g->log2_ctb, cxi = ctb_addr % g->w_ctb, cyi = ctb_addr / g->w_ctb, bd = g->bit_depth;
+  const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
+  RBT_PAR_FOR(i, (int)(sizeof(RbtSaoLds) / 4)) ((RBT_LDS_AS int32_t*)L)[i] = 0;
+  RBT_SYNC_LDS();
+  for (int c = 0; c < 3; c++) {
+    const int sh = c ? 1 : 0, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, n = ctb >> sh, lgn = g->log2_ctb - sh;
+    const int x0 = (cxi * ctb) >> sh, y0 = (cyi * ctb) >> sh;
+    const uint16_t* rp = f->pix[c]; const uint16_t* sp = f->src[c];
+    RBT_PAR_FOR(i, n * n) {
+      const int x = x0 + (i & (n - 1)), y = y0 + (i >> lgn);
+      if (x < pw && y < ph) {
+        const int v = rp[(size_t)y * pw + x], d = (int)sp[(size_t)y * pw + x] - v, b = v >> (bd - 5);
+        RBT_LDS_ADD(&L->bcnt[c][b], 1); RBT_LDS_ADD(&L->bsum[c][b], d);
+        for (int cls = 0; cls < 4; cls++) {
+          const int dxa = cls == 1 ? 0 : (cls == 3 ? 1 : -1), dya = cls == 0 ? 0 : -1, xa = x + dxa, ya = y + dya, xb = x - dxa, yb = y - dya;
+          if (xa < 0 || ya < 0 || xb < 0 || yb < 0 || xa >= pw || xb >= pw || ya >= ph || yb >= ph) continue;
+          const int va = rp[(size_t)ya * pw + xa], vb = rp[(size_t)yb * pw + xb], k = 2 + (v > va) - (v < va) + (v > vb) - (v < vb);
+          if (k == 2) continue;
+          const int cat = k < 2 ? k : k - 1;
+          RBT_LDS_ADD(&L->ecnt[c][cls * 4 + cat], 1); RBT_LDS_ADD(&L->esum[c][cls * 4 + cat], d);
+        }
+      }
+    }
+  }
+  RBT_SYNC_LDS();
+  // the decision is a few hundred scalar operations on the LDS tables: every lane computes it (uniformly), lane 0 stores it
+  const long long lam16 = k_lambda16[rbt_clip3(0, 75, sl->qp + 6 * (bd - 8))], lam = lam16 * lam16;
+  long long gain[3][5]; int offs[3][5][4], bpos[3];
+  for (int c = 0; c < 3; c++) {
+    long long best = -1; int bp = 0;
+    long long bg[32];
+    for (int b = 0; b < 32; b++) { const int cnt = L->bcnt[c][b], sum = L->bsum[c][b], o = rbt_clip3(-7, 7, en_sao_round_div(sum, cnt)); bg[b] = 2ll * o * sum - (long long)cnt * o * o; }
+    for (int b = 0; b <= 28; b++) { const long long gsum = bg[b] + bg[b + 1] + bg[b + 2] + bg[b + 3]; if (gsum > best) { best = gsum; bp = b; } }
+    bpos[c] = bp;
+    for (int k = 0; k < 4; k++) offs[c][0][k] = rbt_clip3(-7, 7, en_sao_round_div(L->bsum[c][bp + k], L->bcnt[c][bp + k]));
+    gain[c][0] = best * 256 - lam * 18;
+    for (int cls = 0; cls < 4; cls++) {
+      long long gs = 0;
+      for (int k = 0; k < 4; k++) {
+        const int cnt = L->ecnt[c][cls * 4 + k], sum = L->esum[c][cls * 4 + k]; int o = en_sao_round_div(sum, cnt);
+        o = k < 2 ? rbt_clip3(0, 7, o) : rbt_clip3(-7, 0, o);
+        offs[c][1 + cls][k] = o; gs += 2ll * o * sum - (long long)cnt * o * o;
+      }
+      gain[c][1 + cls] = gs * 256 - lam * 12;
+    }
+  }
+  RbtSao out; for (int i = 0; i < (int)sizeof(out); i++) ((uint8_t*)&out)[i] = 0;
+  int bt = -1; long long bgn = 0;
+  for (int t = 0; t < 5; t++) if (gain[0][t] > bgn) { bgn = gain[0][t]; bt = t; }
+  if (bt >= 0) { out.type[0] = bt == 0 ? 1 : 2; out.band_pos[0] = (uint8_t)bpos[0]; out.eo_class[0] = (uint8_t)(bt ? bt - 1 : 0); for (int k = 0; k < 4; k++) out.offset[0][k] = (int8_t)offs[0][bt][k]; }
+  bt = -1; bgn = 0;
+  for (int t = 0; t < 5; t++) if (gain[1][t] + gain[2][t] > bgn) { bgn = gain[1][t] + gain[2][t]; bt = t; }
+  if (bt >= 0) for (int c = 1; c < 3; c++) { out.type[c] = bt == 0 ? 1 : 2; out.band_pos[c] = (uint8_t)bpos[c]; out.eo_class[c] = (uint8_t)(bt ? bt - 1 : 0); for (int k = 0; k < 4; k++) out.offset[c][k] = (int8_t)offs[c][bt][k]; }
+  // a type whose offsets are all zero costs bits for nothing
+  { const int any0 = out.offset[0][0] | out.offset[0][1] | out.offset[0][2] | out.offset[0][3];
+    const int any1 = out.offset[1][0] | out.offset[1][1] | out.offset[1][2] | out.offset[1][3], any2 = out.offset[2][0] | out.offset[2][1] | out.offset[2][2] | out.offset[2][3];
+    if (!any0) out.type[0] = 0;
+    if (!any1 && !any2) out.type[1] = out.type[2] = 0; }
+  for (int c = 0; c < 3; c++) if (!out.type[c]) { out.band_pos[c] = 0; out.eo_class[c] = 0; for (int k = 0; k < 4; k++) out.offset[c][k] = 0; }
+  if (out.type[1] != 2) out.eo_class[1] = out.eo_class[2] = 0;
+  if (RBT_LANE0) f->sao[ctb_addr] = out;
+  RBT_SYNC_LDS();
+}
+// sao() of one CTB (7.3.8.3) from the decided parameters: merged with the left / upper CTB of the same slice when they carry the same parameters
+RBT_DEV int en_sao_same(const RbtSao* a, const RbtSao* b) { int same = 1; for (int i = 0; i < (int)sizeof(RbtSao); i++) same &= ((const uint8_t*)a)[i] == ((const uint8_t*)b)[i]; return same; }
+RBT_DEV void en_write_sao(RbtCabacEnc* c, const RbtFrame* f, int addr, int rx, int ry, int wc, int bd) {
+  const RbtSao p = f->sao[addr];
+  const int my = f->ctb_slice[addr], can_left = rx > 0 && f->ctb_slice[addr - 1] == my, can_up = ry > 0 && f->ctb_slice[addr - wc] == my;
+  int merge_left = 0, merge_up = 0;
+  if (can_left) { const RbtSao q = f->sao[addr - 1]; merge_left = en_sao_same(&p, &q); }
+  if (can_up && !merge_left) { const RbtSao q = f->sao[addr - wc]; merge_up = en_sao_same(&p, &q); }
+  merge_left = RBT_UNI(merge_left); merge_up = RBT_UNI(merge_up);
+  if (can_left) rbt_ce_bin0(c, CTX_SAO_MERGE, merge_left);
+  if (can_up && !merge_left) rbt_ce_bin0(c, CTX_SAO_MERGE, merge_up);
+  if (merge_left || merge_up) return;
+  const int cmax = (1 << (rbt_min(bd, 10) - 5)) - 1;
+  for (int ci = 0; ci < 3; ci++) {
+    const int t = RBT_UNI(p.type[ci]);
+    if (ci < 2) { rbt_ce_bin0(c, CTX_SAO_TYPE, t != 0); if (t) rbt_ce_bypass(c, t == 2); }
+    if (!t) continue;
+    for (int i = 0; i < 4; i++) { const int a = RBT_UNI(rbt_abs(p.offset[ci][i])); if (a) rbt_ce_bypass_n(c, (1u << a) - 1u, a); if (a < cmax) rbt_ce_bypass(c, 0); }
+    if (t == 1) {
+      for (int i = 0; i < 4; i++) { const int o = RBT_UNI(p.offset[ci][i]); if (o) rbt_ce_bypass(c, o < 0); }
+      rbt_ce_bypass_n(c, (uint32_t)RBT_UNI(p.band_pos[ci]), 5);
+    } else if (ci < 2) rbt_ce_bypass_n(c, (uint32_t)RBT_UNI(p.eo_class[ci]), 2);
+  }
+}
 RBT_DEV void en_entropy_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, uint8_t* out, RBT_LDS_AS RbtEntropyLds* l) {
   RbtEnt s; s.sl = &slices[slice_idx]; s.f = &frames[RBT_UNI(s.sl->frame)]; s.slice_idx = slice_idx; s.l = l;
   const RbtSlice* sl = s.sl; const RbtStreamCfg* g = &s.f->cfg;
@@ -859,6 +954,7 @@ RBT_DEV void en_entropy_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx,
   const int n_ctbs = RBT_UNI(sl->n_ctbs), first = RBT_UNI(sl->ctb_addr), wc = (s.w + (1 << s.log2_ctb) - 1) >> s.log2_ctb;
   for (int a = 0; a < n_ctbs; a++) {
     const int addr = first + a, rx = addr % wc, ry = addr / wc;
+    if (RBT_UNI(sl->sao_luma | sl->sao_chroma)) en_write_sao(&s.c, s.f, addr, rx, ry, wc, RBT_UNI(g->bit_depth));
     en_stage_ctb(&s, rx << s.log2_ctb, ry << s.log2_ctb);
     en_write_quadtree(&s, rx << s.log2_ctb, ry << s.log2_ctb, s.log2_ctb);
     rbt_ce_terminate(&s.c, a == n_ctbs - 1);

@@ -5,7 +5,10 @@
 #include "rbt_tables.h"
 #include "rbt_types.h"
 
-RBT_DEV int fl_slice_at(const RbtFrame* f, int x, int y) { return f->ctb_slice[(y >> f->cfg.log2_ctb) * f->cfg.w_ctb + (x >> f->cfg.log2_ctb)]; }
+// slice index of the CTB that holds luma sample (x,y). A CTB no decoded slice covers (0xFFFF: truncated or damaged stream, reported as an error by the host)
+// answers with the picture's first slice, so that every table read stays in bounds whatever the stream did.
+RBT_DEV int fl_slice_of_ctb(const RbtFrame* f, int ctb) { const int v = f->ctb_slice[ctb]; return v == 0xFFFF ? f->first_slice : v; }
+RBT_DEV int fl_slice_at(const RbtFrame* f, int x, int y) { return fl_slice_of_ctb(f, (y >> f->cfg.log2_ctb) * f->cfg.w_ctb + (x >> f->cfg.log2_ctb)); }
 
 // bS of the edge on the left (dir 0) / top (dir 1) boundary of the 4x4 unit at luma (x,y); 0 = not filtered
 RBT_DEV int fl_bs(const RbtFrame* f, const RbtSlice* slices, int x, int y, int dir) {
@@ -117,7 +120,7 @@ RBT_DEV void rbt_sao_sample(RbtFrame* f, const RbtSlice* slices, int c, int x, i
   int xl = x << sh, yl = y << sh;
   int ctb = (yl >> g->log2_ctb) * g->w_ctb + (xl >> g->log2_ctb);
   const RbtSao* s = &f->sao[ctb];
-  const RbtSlice* sl = &slices[f->ctb_slice[ctb]];
+  const RbtSlice* sl = &slices[fl_slice_of_ctb(f, ctb)];
   const uint16_t* sp = f->pix[c];
   int v = sp[(size_t)y * pw + x], outv = v;
   int type = s->type[c];
@@ -130,7 +133,7 @@ RBT_DEV void rbt_sao_sample(RbtFrame* f, const RbtSlice* slices, int c, int x, i
       int dxa = cls == 1 ? 0 : (cls == 3 ? 1 : -1), dya = cls == 0 ? 0 : -1;
       int xa = x + dxa, ya = y + dya, xb = x - dxa, yb = y - dya;
       if (xa >= 0 && ya >= 0 && xb >= 0 && yb >= 0 && xa < pw && xb < pw && ya < ph && yb < ph) {
-        int sa_ = fl_slice_at(f, xa << sh, ya << sh), sb_ = fl_slice_at(f, xb << sh, yb << sh), sc_ = f->ctb_slice[ctb];
+        int sa_ = fl_slice_at(f, xa << sh, ya << sh), sb_ = fl_slice_at(f, xb << sh, yb << sh), sc_ = fl_slice_of_ctb(f, ctb);
         int ok = !((sa_ != sc_ && !slices[sa_ > sc_ ? sa_ : sc_].lf_across) || (sb_ != sc_ && !slices[sb_ > sc_ ? sb_ : sc_].lf_across));
         if (ok) {
           int va = sp[(size_t)ya * pw + xa], vb = sp[(size_t)yb * pw + xb];

@@ -64,6 +64,8 @@ void launch_enc_analyse(RbtFrame* frames, const RbtSlice* slices, const int32_t*
 // otherwise CTBs are scheduled on anti-diagonals like the decoder's reconstruction
 void launch_enc_intra(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int row_mode, int max_log2_ctb);
 void launch_enc_inter(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs);
+// SAO parameters of every CTB of the listed (deblocked) pictures from source-vs-reconstruction statistics; launch_sao then applies them
+void launch_enc_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs);
 void launch_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list, int n_slices, int max_log2_ctb);
 // gathers the slice data of every slice segment into one contiguous buffer (dst_off = exclusive prefix sum of out_size)
 void launch_pack(const uint8_t* out, const RbtSlice* slices, const uint32_t* dst_off, uint8_t* packed, int n_slices);

@@ -72,6 +72,13 @@ static __device__ __forceinline__ int rbt_writelane(int old, int v, int lane) { 
 #endif
 #endif
 
+// integer add on an LDS word from any lane of the workgroup (ds_add_u32); a plain add in the serial host emulation
+#ifdef RBT_HOSTEMU
+#define RBT_LDS_ADD(p, v) (*(p) += (v))
+#else
+#define RBT_LDS_ADD(p, v) ((void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+#endif
+
 // Bit-field read of a packed wave-uniform word. On the GPU it is one scalar instruction the compiler may neither hoist nor
 // keep alive: rarely used parameters then cost one SGPR per word instead of one (spilled) SGPR per field.
 template <int SH, int N> RBT_DEV uint32_t rbt_bfe(uint32_t w) {

@@ -260,6 +260,12 @@ int decode_finish(DecodeBatch& b) {
   std::vector<RbtFrame> fr(nf);
   if (rbtk::d2h(fr.data(), b.d_frames, nf * sizeof(RbtFrame))) { b.err = "device transfer failed"; return b.err_code = RBT_ERR_NO_DEVICE; }
   for (size_t i = 0; i < nf; i++) if (fr[i].error) { b.err = "slice data decoding failed (code " + std::to_string(fr[i].error) + ")"; return b.err_code = RBT_ERR_BITSTREAM; }
+  // every CTB of every picture must have been decoded by exactly one slice segment (a truncated stream leaves pictures with holes)
+  std::vector<RbtSlice> sl(b.slices.size());
+  if (rbtk::d2h(sl.data(), b.d_slices, sl.size() * sizeof(RbtSlice))) { b.err = "device transfer failed"; return b.err_code = RBT_ERR_NO_DEVICE; }
+  std::vector<uint64_t> covered(nf, 0);
+  for (auto& s_ : sl) covered[(size_t)s_.frame] += s_.n_ctbs_decoded;
+  for (size_t i = 0; i < nf; i++) if (covered[i] != (uint64_t)b.frames[i].cfg.w_ctb * b.frames[i].cfg.h_ctb) { b.err = "picture " + std::to_string(i) + " is not completely covered by slice data"; return b.err_code = RBT_ERR_BITSTREAM; }
   return 0;
 }
 

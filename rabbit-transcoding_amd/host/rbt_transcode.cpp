@@ -15,6 +15,7 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 
 struct EncStreamDesc {
   int w, h, bd, n_frames, qp, i_qp_offset, gop, lossless, log2_ctb, rows, md5;   // w, h: display size (any even numbers)
+  int sao = 0;                           // SAO on (every stream that is not lossless, unless RBT_ENC_SAO=0)
   std::vector<const uint16_t*> src[3];   // device planes per frame
   int src_stride = 0, src_x0 = 0, src_y0 = 0;   // the planes are views: luma row stride (0 = w) and origin of the w x h region (luma samples)
 };
@@ -32,11 +33,13 @@ struct EncodeBatch {
   std::vector<PadJob> pad_jobs;                 // source pictures that have to be copied into padded planes before the encoder reads them
   std::vector<std::vector<uint16_t>> cs_keep;   // host staging of the ctb->slice maps, alive until the copies have completed
   int main_stream = 0, aux_stream = -1;          // aux_stream >= 0: the intra part was enqueued there (its timers live there)
-  std::vector<int32_t> lists_keep; size_t off_i = 0, off_ideb = 0, off_p = 0, off_sl = 0, off_sl_p = 0; int n_i = 0, n_ideb = 0, n_p = 0, n_sl_i = 0, n_sl_p = 0;   // index lists (encode_upload_lists)
+  std::vector<int32_t> lists_keep; size_t off_i = 0, off_ideb = 0, off_p = 0, off_sl = 0, off_sl_p = 0, off_isao = 0, off_psao = 0; int n_i = 0, n_ideb = 0, n_p = 0, n_sl_i = 0, n_sl_p = 0, n_isao = 0, n_psao = 0;   // index lists (encode_upload_lists)
   std::string err;
   ~EncodeBatch() { rbtk::dev_free(arena); }
 };
 
+// RBT-E1 codes SAO unless RBT_ENC_SAO=0 (development switch, read by the oracle the same way)
+static int e1_sao_on() { static int v = -1; if (v < 0) { const char* e = getenv("RBT_ENC_SAO"); v = !e || atoi(e) != 0; } return v; }
 static int coded_size(int v, int gop) { int al = gop > 1 ? 16 : 8; return (v + al - 1) / al * al; }
 static void make_param_sets(const EncStreamDesc& d, Sps& s, Pps& p) {
   s = Sps(); p = Pps();
@@ -44,7 +47,7 @@ static void make_param_sets(const EncStreamDesc& d, Sps& s, Pps& p) {
   s.valid = true; s.width = cw; s.height = ch; s.conf_win[1] = (cw - d.w) / 2; s.conf_win[3] = (ch - d.h) / 2; s.bit_depth = d.bd; s.log2_max_poc_lsb = 8; s.max_dec_pic_buffering = 3;
   s.log2_ctb = d.log2_ctb ? d.log2_ctb : 5; s.log2_min_cb = 3; s.log2_diff_max_min_cb = s.log2_ctb - 3;
   s.log2_min_tb = 2; s.log2_max_tb = std::min(5, s.log2_ctb); s.log2_diff_max_min_tb = s.log2_max_tb - 2;
-  s.num_st_rps = 1;
+  s.num_st_rps = 1; s.sao = d.sao;
   s.w_ctb = (cw + (1 << s.log2_ctb) - 1) >> s.log2_ctb; s.h_ctb = (ch + (1 << s.log2_ctb) - 1) >> s.log2_ctb;
   p.valid = true; p.num_ref_idx_default = 1; p.init_qp = std::min(51, std::max(0, d.qp)); p.loop_filter_across_slices = 1;
   if (d.lossless) { p.transquant_bypass = 1; p.deblocking_control_present = 1; p.pps_deblocking_disabled = 1; p.loop_filter_across_slices = 0; }
@@ -57,7 +60,8 @@ static int encode_build(EncodeBatch& b) {
     const EncStreamDesc& d = b.desc[si];
     if (d.w % 2 || d.h % 2 || d.w <= 0 || d.h <= 0 || d.w > 8192 || d.h > 8192) { b.err = "picture size must be even and at most 8192"; return RBT_ERR_UNSUPPORTED; }
     if (d.log2_ctb && (d.log2_ctb < 4 || d.log2_ctb > 6)) { b.err = "log2_ctb must be 4..6"; return RBT_ERR_PARAM; }
-    make_param_sets(d, b.sps[si], b.pps[si]);
+    b.desc[si].sao = !d.lossless && e1_sao_on();
+    make_param_sets(b.desc[si], b.sps[si], b.pps[si]);
     const Sps& s = b.sps[si]; const Pps& p = b.pps[si];
     b.stream_first[si] = (int)b.frames.size();
     for (int i = 0; i < d.n_frames; i++) {
@@ -74,7 +78,7 @@ static int encode_build(EncodeBatch& b) {
         sl.slice_type = (int8_t)(is_i ? RBT_SLICE_I : RBT_SLICE_P);
         sl.qp = (int8_t)std::min(51, std::max(0, is_i ? d.qp + d.i_qp_offset : d.qp));
         sl.deblocking_disabled = (uint8_t)p.pps_deblocking_disabled; sl.lf_across = (uint8_t)p.loop_filter_across_slices;
-        sl.max_merge_cand = 1; sl.num_ref_idx = 1; sl.poc = f.poc;
+        sl.max_merge_cand = 1; sl.num_ref_idx = 1; sl.poc = f.poc; sl.sao_luma = sl.sao_chroma = (uint8_t)b.desc[si].sao;
         if (!is_i) { sl.ref_frame[0] = f.ref_frame; sl.ref_poc[0] = f.ref_poc; }
         // worst-case slice data: raw samples of the slice at 2 bytes each plus slack
         size_t rows = (size_t)(sl.n_ctbs + s.w_ctb - 1) / s.w_ctb;
@@ -88,17 +92,18 @@ static int encode_build(EncodeBatch& b) {
   if (b.slices.size() >= 0xFFFF) { b.err = "too many slice segments in one call"; return RBT_ERR_UNSUPPORTED; }
   // ---- HBM layout ----
   Arena a; size_t nf = b.frames.size();
-  std::vector<size_t> o_src(nf, (size_t)-1), o_pix(nf), o_coef(nf), o_pm(nf), o_edges(nf), o_qp(nf), o_mv(nf), o_ref(nf), o_refpoc(nf), o_cs(nf), o_cul(nf), o_cum(nf), o_cuf(nf);
+  std::vector<size_t> o_src(nf, (size_t)-1), o_pix(nf), o_sout(nf), o_sao(nf), o_coef(nf), o_pm(nf), o_edges(nf), o_qp(nf), o_mv(nf), o_ref(nf), o_refpoc(nf), o_cs(nf), o_cul(nf), o_cum(nf), o_cuf(nf);
   for (size_t i = 0; i < nf; i++) {
     const RbtStreamCfg& c = b.frames[i].cfg; size_t u = (size_t)c.w4 * c.h4, nc = (size_t)c.w_ctb * c.h_ctb, u8 = (size_t)b.frames[i].w8 * b.frames[i].h8;
     { const EncStreamDesc& d = b.desc[b.frame_stream[i]];
       if (c.w != d.w || c.h != d.h || d.src_x0 || d.src_y0 || (d.src_stride && d.src_stride != d.w)) o_src[i] = a.reserve(frame_samples(c) * 2); }
     o_pix[i] = a.reserve(frame_samples(c) * 2); o_coef[i] = a.reserve(frame_samples(c) * 2);
+    o_sout[i] = b.desc[b.frame_stream[i]].sao ? a.reserve(frame_samples(c) * 2) : o_pix[i]; o_sao[i] = a.reserve(nc * sizeof(RbtSao));
     o_pm[i] = a.reserve(u); o_edges[i] = a.reserve(u); o_qp[i] = a.reserve(u); o_mv[i] = a.reserve(u * 4); o_ref[i] = a.reserve(u); o_refpoc[i] = a.reserve(u * 4);
     o_cs[i] = a.reserve(nc * 2); o_cul[i] = a.reserve(u8); o_cum[i] = a.reserve(u8); o_cuf[i] = a.reserve(u8);
   }
   size_t o_frames = a.reserve(nf * sizeof(RbtFrame)), o_slices = a.reserve(b.slices.size() * sizeof(RbtSlice));
-  size_t o_lists = a.reserve((nf + b.slices.size()) * 2 * sizeof(int32_t)), o_dst = a.reserve(b.slices.size() * sizeof(uint32_t));
+  size_t o_lists = a.reserve((nf + b.slices.size()) * 3 * sizeof(int32_t)), o_dst = a.reserve(b.slices.size() * sizeof(uint32_t));
   size_t out_cap_total = 0; for (auto& sl : b.slices) { sl.out_off = (uint32_t)out_cap_total; out_cap_total += sl.out_cap; }
   if (out_cap_total >= 0xFFFFFFFFull) { b.err = "output buffer too large for one call"; return RBT_ERR_UNSUPPORTED; }
   size_t o_out = a.reserve(out_cap_total), o_packed = a.reserve(out_cap_total / 2 + 65536);
@@ -111,7 +116,7 @@ static int encode_build(EncodeBatch& b) {
     std::vector<uint16_t>& cs_host = b.cs_keep[i];
     RbtFrame& f = b.frames[i]; const RbtStreamCfg& c = f.cfg; size_t ys = (size_t)c.w * c.h, cs = (size_t)c.cw * c.ch;
     f.pix[0] = (uint16_t*)(base + o_pix[i]); f.pix[1] = f.pix[0] + ys; f.pix[2] = f.pix[1] + cs;
-    for (int k = 0; k < 3; k++) f.out[k] = f.pix[k];
+    f.out[0] = (uint16_t*)(base + o_sout[i]); f.out[1] = f.out[0] + ys; f.out[2] = f.out[1] + cs; f.sao = (RbtSao*)(base + o_sao[i]);
     if (o_src[i] != (size_t)-1) {
       const EncStreamDesc& d = b.desc[b.frame_stream[i]]; const int st = d.src_stride ? d.src_stride : d.w;
       uint16_t* pl[3] = {(uint16_t*)(base + o_src[i]), nullptr, nullptr}; pl[1] = pl[0] + ys; pl[2] = pl[1] + cs;
@@ -142,6 +147,9 @@ static int encode_upload_lists(EncodeBatch& b) {
   b.off_i = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i]) { lists.push_back((int)i); b.n_i++; }
   b.off_ideb = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i] && !b.frames[i].lossless) { lists.push_back((int)i); b.n_ideb++; }
   b.off_p = lists.size(); for (size_t i = 0; i < nf; i++) if (!b.frame_is_idr[i]) { lists.push_back((int)i); b.n_p++; }
+  b.n_isao = b.n_psao = 0;
+  b.off_isao = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i] && b.desc[b.frame_stream[i]].sao) { lists.push_back((int)i); b.n_isao++; }
+  b.off_psao = lists.size(); for (size_t i = 0; i < nf; i++) if (!b.frame_is_idr[i] && b.desc[b.frame_stream[i]].sao) { lists.push_back((int)i); b.n_psao++; }
   // slice segments of the intra pictures first, then the rest: the two groups are entropy-coded by separate launches
   b.n_sl_i = b.n_sl_p = 0;
   b.off_sl = lists.size(); for (size_t i = 0; i < ns; i++) if (b.frame_is_idr[b.slices[i].frame]) { lists.push_back((int)i); b.n_sl_i++; }
@@ -153,9 +161,9 @@ static int encode_upload_lists(EncodeBatch& b) {
 static void encode_launch_intra(EncodeBatch& b) {
   size_t nf = b.frames.size();
   for (const PadJob& j : b.pad_jobs) rbtk::launch_pad(j.in, j.stride, j.x0, j.y0, j.w, j.h, j.out, j.dw, j.dh);
-  int mw = 0, mh = 0, mu = 0, mc = 0, row_mode = 1, ml2 = 0;
+  int mw = 0, mh = 0, mu = 0, mc = 0, row_mode = 1, ml2 = 0, ml = 0;
   for (size_t i = 0; i < nf; i++) {
-    const RbtStreamCfg& c = b.frames[i].cfg; ml2 = std::max(ml2, (int)c.log2_ctb); mw = std::max(mw, c.w_ctb); mh = std::max(mh, c.h_ctb); mu = std::max(mu, c.w4 * c.h4); mc = std::max(mc, c.w_ctb * c.h_ctb);
+    const RbtStreamCfg& c = b.frames[i].cfg; ml = std::max(ml, c.w * c.h); ml2 = std::max(ml2, (int)c.log2_ctb); mw = std::max(mw, c.w_ctb); mh = std::max(mh, c.h_ctb); mu = std::max(mu, c.w4 * c.h4); mc = std::max(mc, c.w_ctb * c.h_ctb);
     if (b.desc[b.frame_stream[i]].rows != 1) row_mode = 0;
   }
   rbtk::timer_begin(T_ANALYSE);
@@ -164,6 +172,8 @@ static void encode_launch_intra(EncodeBatch& b) {
   rbtk::timer_begin(T_ENCODE);
   rbtk::launch_enc_intra(b.d_frames, b.d_slices, b.d_lists + b.off_i, b.n_i, mw, mh, row_mode, ml2);
   rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_ideb, b.n_ideb, mu);
+  rbtk::launch_enc_sao(b.d_frames, b.d_slices, b.d_lists + b.off_isao, b.n_isao, mc);
+  rbtk::launch_sao(b.d_frames, b.d_slices, b.d_lists + b.off_isao, b.n_isao, ml);
   rbtk::timer_end(T_ENCODE);
 }
 // entropy coding of the intra pictures' slices: needs nothing but their levels and CU data
@@ -176,11 +186,13 @@ static void encode_launch_entropy_intra(EncodeBatch& b) {
 // inter pictures (need the reconstructed intra pictures and their own sources), then the entropy coder for every slice
 static void encode_launch_rest(EncodeBatch& b) {
   size_t nf = b.frames.size();
-  int mu = 0, mc = 0;
-  for (size_t i = 0; i < nf; i++) { const RbtStreamCfg& c = b.frames[i].cfg; mu = std::max(mu, c.w4 * c.h4); mc = std::max(mc, c.w_ctb * c.h_ctb); }
+  int mu = 0, mc = 0, ml = 0;
+  for (size_t i = 0; i < nf; i++) { const RbtStreamCfg& c = b.frames[i].cfg; mu = std::max(mu, c.w4 * c.h4); mc = std::max(mc, c.w_ctb * c.h_ctb); ml = std::max(ml, c.w * c.h); }
   rbtk::timer_begin(T_INTER);
   rbtk::launch_enc_inter(b.d_frames, b.d_slices, b.d_lists + b.off_p, b.n_p, mc);
   rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_p, b.n_p, mu);
+  rbtk::launch_enc_sao(b.d_frames, b.d_slices, b.d_lists + b.off_psao, b.n_psao, mc);
+  rbtk::launch_sao(b.d_frames, b.d_slices, b.d_lists + b.off_psao, b.n_psao, ml);
   rbtk::timer_end(T_INTER);
   rbtk::timer_begin(T_ENTROPY);
   rbtk::launch_entropy(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_sl_p, b.n_sl_p, max_log2_ctb(b));
@@ -211,7 +223,7 @@ static int encode_finish(EncodeBatch& b, std::vector<std::vector<uint8_t>>& outs
     for (int k = 0; k < f.n_slices; k++) {
       const RbtSlice& sl = b.slices[f.first_slice + k];
       SliceHdr h; h.first_slice_in_pic = k == 0; h.segment_addr = sl.ctb_addr; h.slice_type = sl.slice_type; h.poc = sl.poc; h.num_ref_idx = 1; h.max_merge_cand = 1; h.qp = sl.qp;
-      h.deblocking_disabled = sl.deblocking_disabled; h.beta_offset_div2 = p.beta_offset_div2; h.tc_offset_div2 = p.tc_offset_div2; h.lf_across = sl.lf_across;
+      h.sao_luma = sl.sao_luma; h.sao_chroma = sl.sao_chroma; h.deblocking_disabled = sl.deblocking_disabled; h.beta_offset_div2 = p.beta_offset_div2; h.tc_offset_div2 = p.tc_offset_div2; h.lf_across = sl.lf_across;
       BitWriter w; write_slice_header(w, s, p, h, idr, 0);
       w.b.insert(w.b.end(), packed.begin() + dst[f.first_slice + k], packed.begin() + dst[f.first_slice + k] + sl.out_size);
       append_nal(out, idr ? NAL_IDR_W_RADL : NAL_TRAIL_R, w.b.data(), w.b.size(), k == 0);
@@ -219,7 +231,7 @@ static int encode_finish(EncodeBatch& b, std::vector<std::vector<uint8_t>>& outs
     if (b.desc[si].md5) {
       // decoded picture hash SEI: needs the reconstructed picture on the host (diagnostic option, off in the benchmark)
       const RbtStreamCfg& c = f.cfg; size_t fs = frame_samples(c); rec.resize(fs);
-      if (rbtk::d2h(rec.data(), f.pix[0], fs * 2)) { b.err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
+      if (rbtk::d2h(rec.data(), f.out[0], fs * 2)) { b.err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
       uint8_t sei[52]; sei[0] = 132; sei[1] = 49; sei[2] = 0;
       md5_plane_u16(rec.data(), c.w, c.h, c.bit_depth, sei + 3);
       md5_plane_u16(rec.data() + (size_t)c.w * c.h, c.cw, c.ch, c.bit_depth, sei + 19);
