@@ -11,6 +11,7 @@
 #pragma once
 #include "rbt_cabac.h"
 #include "rbt_recon.h"
+#include "rbt_filter.h"
 
 RBT_CONST uint16_t k_lambda16[76] = {3,    3,    4,    4,    5,    5,    6,    7,    8,    9,    10,   11,   12,   14,   15,   17,   19,   22,   24,
                                      27,   30,   34,   38,   43,   48,   54,   61,   68,   77,   86,   97,   108,  122,  137,  153,  172,  193,  217,
@@ -848,55 +849,67 @@ RBT_DEV void en_write_quadtree(RbtEnt* s, int x0, int y0, int log2) {
 // One wave per CTB, after deblocking: per component the statistics of source minus deblocked reconstruction - count and sum per band (32) and per edge
 // class x category (4 x 4) - accumulated with LDS adds, then offsets = rounded means clipped to +-7 (edge categories keep their sign), the type with the
 // largest distortion reduction minus lambda * rate; Cb and Cr share type and edge class (7.3.8.3). Mirrors hm_sao_decide in oracle/hevc_enc.c exactly.
-struct RbtSaoLds { int32_t bcnt[3][32], bsum[3][32], ecnt[3][16], esum[3][16]; };
+// The same wave then applies the offsets to its CTB (needs rbt_filter.h).
+// Cost matters here (1600 CTBs x 128 pictures per GOF): the edge statistics live in registers (16 (class, category) pairs, predicated adds, one wave
+// reduction each at the end - no LDS traffic per sample), the band statistics go to eight LDS copies selected by the lane (neighbouring samples share a
+// band, a single table would serialise the adds of the whole wave), the offsets are computed with the lanes over the table entries (one division per lane).
+// Measured on MI355X, encoder stages per job with 16 GOFs in flight: no SAO 33 ms; one LDS table + decision on every lane 62 ms; this version 48 ms;
+// staging the CTB and its halo in LDS with packed 8 / 16-bit register statistics 57 ms (11 KB of LDS per wave cost more residency than the loads it saved).
+struct RbtSaoLds { int32_t bcnt[8][32], bsum[8][32]; int32_t ecnt[16], esum[16]; int32_t off[48], gain[48]; };
 RBT_DEV int en_sao_round_div(int sum, int cnt) { return cnt ? (sum >= 0 ? sum + cnt / 2 : sum - cnt / 2) / cnt : 0; }
 RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtSaoLds* L) {
   const RbtStreamCfg gcopy = f->cfg; const RbtStreamCfg* g = &gcopy;
   const int ctb = 1 << g->log2_ctb, cxi = ctb_addr % g->w_ctb, cyi = ctb_addr / g->w_ctb, bd = g->bit_depth;
   const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
-  RBT_PAR_FOR(i, (int)(sizeof(RbtSaoLds) / 4)) ((RBT_LDS_AS int32_t*)L)[i] = 0;
-  RBT_SYNC_LDS();
+  const long long lam16 = k_lambda16[rbt_clip3(0, 75, sl->qp + 6 * (bd - 8))], lam = lam16 * lam16;
+  long long gain[3][5]; int offs[3][5][4], bpos[3];
   for (int c = 0; c < 3; c++) {
     const int sh = c ? 1 : 0, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, n = ctb >> sh, lgn = g->log2_ctb - sh;
     const int x0 = (cxi * ctb) >> sh, y0 = (cyi * ctb) >> sh;
     const uint16_t* rp = f->pix[c]; const uint16_t* sp = f->src[c];
+    RBT_PAR_FOR(i, 8 * 32) { L->bcnt[i >> 5][i & 31] = 0; L->bsum[i >> 5][i & 31] = 0; }
+    RBT_SYNC_LDS();
+    int ecnt[16], esum[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) { ecnt[q] = 0; esum[q] = 0; }
     RBT_PAR_FOR(i, n * n) {
       const int x = x0 + (i & (n - 1)), y = y0 + (i >> lgn);
       if (x < pw && y < ph) {
-        const int v = rp[(size_t)y * pw + x], d = (int)sp[(size_t)y * pw + x] - v, b = v >> (bd - 5);
-        RBT_LDS_ADD(&L->bcnt[c][b], 1); RBT_LDS_ADD(&L->bsum[c][b], d);
+        const int v = rp[(size_t)y * pw + x], d = (int)sp[(size_t)y * pw + x] - v, b = rbt_min(31, v >> (bd - 5)), copy = i & 7;
+        RBT_LDS_ADD(&L->bcnt[copy][b], 1); RBT_LDS_ADD(&L->bsum[copy][b], d);
+#pragma unroll
         for (int cls = 0; cls < 4; cls++) {
           const int dxa = cls == 1 ? 0 : (cls == 3 ? 1 : -1), dya = cls == 0 ? 0 : -1, xa = x + dxa, ya = y + dya, xb = x - dxa, yb = y - dya;
-          if (xa < 0 || ya < 0 || xb < 0 || yb < 0 || xa >= pw || xb >= pw || ya >= ph || yb >= ph) continue;
-          const int va = rp[(size_t)ya * pw + xa], vb = rp[(size_t)yb * pw + xb], k = 2 + (v > va) - (v < va) + (v > vb) - (v < vb);
-          if (k == 2) continue;
-          const int cat = k < 2 ? k : k - 1;
-          RBT_LDS_ADD(&L->ecnt[c][cls * 4 + cat], 1); RBT_LDS_ADD(&L->esum[c][cls * 4 + cat], d);
+          const int inside = !(xa < 0 || ya < 0 || xb < 0 || yb < 0 || xa >= pw || xb >= pw || ya >= ph || yb >= ph);
+          const int va = rp[(size_t)rbt_clip3(0, ph - 1, ya) * pw + rbt_clip3(0, pw - 1, xa)], vb = rp[(size_t)rbt_clip3(0, ph - 1, yb) * pw + rbt_clip3(0, pw - 1, xb)];
+          const int k = 2 + (v > va) - (v < va) + (v > vb) - (v < vb), cat = k < 2 ? k : k - 1;       // k == 2: no category
+#pragma unroll
+          for (int q = 0; q < 4; q++) { const int hit = inside && k != 2 && cat == q; ecnt[cls * 4 + q] += hit; esum[cls * 4 + q] += hit ? d : 0; }
         }
       }
     }
-  }
-  RBT_SYNC_LDS();
-  // the decision is a few hundred scalar operations on the LDS tables: every lane computes it (uniformly), lane 0 stores it
-  const long long lam16 = k_lambda16[rbt_clip3(0, 75, sl->qp + 6 * (bd - 8))], lam = lam16 * lam16;
-  long long gain[3][5]; int offs[3][5][4], bpos[3];
-  for (int c = 0; c < 3; c++) {
-    long long best = -1; int bp = 0;
-    long long bg[32];
-    for (int b = 0; b < 32; b++) { const int cnt = L->bcnt[c][b], sum = L->bsum[c][b], o = rbt_clip3(-7, 7, en_sao_round_div(sum, cnt)); bg[b] = 2ll * o * sum - (long long)cnt * o * o; }
-    for (int b = 0; b <= 28; b++) { const long long gsum = bg[b] + bg[b + 1] + bg[b + 2] + bg[b + 3]; if (gsum > best) { best = gsum; bp = b; } }
-    bpos[c] = bp;
-    for (int k = 0; k < 4; k++) offs[c][0][k] = rbt_clip3(-7, 7, en_sao_round_div(L->bsum[c][bp + k], L->bcnt[c][bp + k]));
-    gain[c][0] = best * 256 - lam * 18;
+#pragma unroll
+    for (int q = 0; q < 16; q++) { const int cn = en_wave_sum(ecnt[q], (RBT_LDS_AS RbtEncLds*)0), sm = en_wave_sum(esum[q], (RBT_LDS_AS RbtEncLds*)0); if (RBT_LANE0) { L->ecnt[q] = cn; L->esum[q] = sm; } }
+    RBT_SYNC_LDS();
+    // offsets and distortion reductions, lanes over the 32 bands and the 16 (class, category) pairs
+    RBT_PAR_FOR(j, 48) {
+      int cnt, sum, o;
+      if (j < 32) { cnt = 0; sum = 0; for (int q = 0; q < 8; q++) { cnt += L->bcnt[q][j]; sum += L->bsum[q][j]; } o = rbt_clip3(-7, 7, en_sao_round_div(sum, cnt)); }
+      else { cnt = L->ecnt[j - 32]; sum = L->esum[j - 32]; o = en_sao_round_div(sum, cnt); o = ((j - 32) & 3) < 2 ? rbt_clip3(0, 7, o) : rbt_clip3(-7, 0, o); }
+      L->off[j] = o; L->gain[j] = 2 * o * sum - cnt * o * o;
+    }
+    RBT_SYNC_LDS();
+    { long long best = -1; int bp = 0;
+      for (int b = 0; b <= 28; b++) { const long long gsum = (long long)L->gain[b] + L->gain[b + 1] + L->gain[b + 2] + L->gain[b + 3]; if (gsum > best) { best = gsum; bp = b; } }
+      bpos[c] = bp;
+      for (int k = 0; k < 4; k++) offs[c][0][k] = L->off[bp + k];
+      gain[c][0] = best * 256 - lam * 18; }
     for (int cls = 0; cls < 4; cls++) {
       long long gs = 0;
-      for (int k = 0; k < 4; k++) {
-        const int cnt = L->ecnt[c][cls * 4 + k], sum = L->esum[c][cls * 4 + k]; int o = en_sao_round_div(sum, cnt);
-        o = k < 2 ? rbt_clip3(0, 7, o) : rbt_clip3(-7, 0, o);
-        offs[c][1 + cls][k] = o; gs += 2ll * o * sum - (long long)cnt * o * o;
-      }
+      for (int k = 0; k < 4; k++) { offs[c][1 + cls][k] = L->off[32 + cls * 4 + k]; gs += L->gain[32 + cls * 4 + k]; }
       gain[c][1 + cls] = gs * 256 - lam * 12;
     }
+    RBT_SYNC_LDS();
   }
   RbtSao out; for (int i = 0; i < (int)sizeof(out); i++) ((uint8_t*)&out)[i] = 0;
   int bt = -1; long long bgn = 0;
@@ -913,6 +926,11 @@ RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_L
   for (int c = 0; c < 3; c++) if (!out.type[c]) { out.band_pos[c] = 0; out.eo_class[c] = 0; for (int k = 0; k < 4; k++) out.offset[c][k] = 0; }
   if (out.type[1] != 2) out.eo_class[1] = out.eo_class[2] = 0;
   if (RBT_LANE0) f->sao[ctb_addr] = out;
+  // ... and applied on the spot (8.7.3): the CTB's samples go from the deblocked picture to the output picture with the parameters still in registers
+  for (int c = 0; c < 3; c++) {
+    const int sh = c ? 1 : 0, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, n = ctb >> sh, lgn = g->log2_ctb - sh, x0 = (cxi * ctb) >> sh, y0 = (cyi * ctb) >> sh;
+    RBT_PAR_FOR(i, n * n) { const int x = x0 + (i & (n - 1)), y = y0 + (i >> lgn); if (x < pw && y < ph) rbt_sao_sample_p(f, slices, c, x, y, &out); }
+  }
   RBT_SYNC_LDS();
 }
 // sao() of one CTB (7.3.8.3) from the decided parameters: merged with the left / upper CTB of the same slice when they carry the same parameters

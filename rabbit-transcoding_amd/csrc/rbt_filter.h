@@ -114,12 +114,12 @@ RBT_DEV void rbt_deblock_unit(RbtFrame* f, const RbtSlice* slices, int unit, int
 }
 
 // SAO of one sample of component c: reads f->pix (deblocked), writes f->out
-RBT_DEV void rbt_sao_sample(RbtFrame* f, const RbtSlice* slices, int c, int x, int y) {
+// SAO of one sample with the parameters *s of its CTB (the encoder applies them right after deciding them: en_sao_ctb)
+RBT_DEV void rbt_sao_sample_p(RbtFrame* f, const RbtSlice* slices, int c, int x, int y, const RbtSao* s) {
   const RbtStreamCfg* g = &f->cfg;
   int sh = c ? 1 : 0, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, bd = g->bit_depth, maxv = (1 << bd) - 1;
   int xl = x << sh, yl = y << sh;
   int ctb = (yl >> g->log2_ctb) * g->w_ctb + (xl >> g->log2_ctb);
-  const RbtSao* s = &f->sao[ctb];
   const RbtSlice* sl = &slices[fl_slice_of_ctb(f, ctb)];
   const uint16_t* sp = f->pix[c];
   int v = sp[(size_t)y * pw + x], outv = v;
@@ -145,4 +145,8 @@ RBT_DEV void rbt_sao_sample(RbtFrame* f, const RbtSlice* slices, int c, int x, i
     }
   }
   f->out[c][(size_t)y * pw + x] = (uint16_t)outv;
+}
+RBT_DEV void rbt_sao_sample(RbtFrame* f, const RbtSlice* slices, int c, int x, int y) {
+  const RbtStreamCfg* g = &f->cfg; const int sh = c ? 1 : 0;
+  rbt_sao_sample_p(f, slices, c, x, y, &f->sao[(((y << sh) >> g->log2_ctb)) * g->w_ctb + ((x << sh) >> g->log2_ctb)]);
 }

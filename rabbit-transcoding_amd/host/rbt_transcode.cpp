@@ -172,8 +172,7 @@ static void encode_launch_intra(EncodeBatch& b) {
   rbtk::timer_begin(T_ENCODE);
   rbtk::launch_enc_intra(b.d_frames, b.d_slices, b.d_lists + b.off_i, b.n_i, mw, mh, row_mode, ml2);
   rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_ideb, b.n_ideb, mu);
-  rbtk::launch_enc_sao(b.d_frames, b.d_slices, b.d_lists + b.off_isao, b.n_isao, mc);
-  rbtk::launch_sao(b.d_frames, b.d_slices, b.d_lists + b.off_isao, b.n_isao, ml);
+  rbtk::launch_enc_sao(b.d_frames, b.d_slices, b.d_lists + b.off_isao, b.n_isao, mc);   // decides and applies
   rbtk::timer_end(T_ENCODE);
 }
 // entropy coding of the intra pictures' slices: needs nothing but their levels and CU data
@@ -192,7 +191,6 @@ static void encode_launch_rest(EncodeBatch& b) {
   rbtk::launch_enc_inter(b.d_frames, b.d_slices, b.d_lists + b.off_p, b.n_p, mc);
   rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_p, b.n_p, mu);
   rbtk::launch_enc_sao(b.d_frames, b.d_slices, b.d_lists + b.off_psao, b.n_psao, mc);
-  rbtk::launch_sao(b.d_frames, b.d_slices, b.d_lists + b.off_psao, b.n_psao, ml);
   rbtk::timer_end(T_INTER);
   rbtk::timer_begin(T_ENTROPY);
   rbtk::launch_entropy(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_sl_p, b.n_sl_p, max_log2_ctb(b));
