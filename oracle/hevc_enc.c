@@ -1059,6 +1059,11 @@ static void hm_sao_decide(enc* e) {
   static const int8_t eo_dy[4][2] = {{0, 0}, {-1, 1}, {-1, 1}, {-1, 1}};
   for (int cyi = 0; cyi < m->h_ctb; cyi++) for (int cxi = 0; cxi < m->w_ctb; cxi++) {
     hevc_sao* out = &e->hm_sao[cyi * m->w_ctb + cxi]; memset(out, 0, sizeof(*out));
+    if (!e->hm) {   /* RBT-E1: a CTB made of skipped CUs only is a copy of the (already filtered) reference - no statistics, no offsets */
+      int all_skip = 1;
+      for (int y = cyi * ctb; y < imin(rec->h, (cyi + 1) * ctb) && all_skip; y += 4) for (int x = cxi * ctb; x < imin(rec->w, (cxi + 1) * ctb); x += 4) if (m->pred_mode[meta_idx(m, x, y)] != MODE_SKIP) { all_skip = 0; break; }
+      if (all_skip) continue;
+    }
     int64_t gain[3][6]; int offs[3][6][4], bpos[3];   /* [component][0 = band, 1..4 = edge class 0..3] */
     for (int c = 0; c < 3; c++) {
       int sh = c ? 1 : 0, pw = c ? rec->cw : rec->w, ph = c ? rec->ch : rec->h;

@@ -863,7 +863,15 @@ RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_L
   const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
   const long long lam16 = k_lambda16[rbt_clip3(0, 75, sl->qp + 6 * (bd - 8))], lam = lam16 * lam16;
   long long gain[3][5]; int offs[3][5][4], bpos[3];
-  for (int c = 0; c < 3; c++) {
+  // a CTB made of skipped CUs only is a copy of the (already filtered) reference: no statistics, no offsets (P pictures are mostly that)
+  int all_skip = 0;
+  if (f->ref_frame >= 0) {
+    const int n8 = ctb >> 3; uint64_t m0 = 0, m1 = 0;
+    RBT_VBALLOT(m0, p, rbt_min(64, n8 * n8), (cxi * n8 + p % n8 >= f->w8) || (cyi * n8 + p / n8 >= f->h8) || (f->cu_flags[(cyi * n8 + p / n8) * f->w8 + cxi * n8 + p % n8] & RBT_CU_SKIP));
+    m1 = n8 * n8 >= 64 ? ~0ull : (1ull << (n8 * n8)) - 1;
+    all_skip = m0 == m1;
+  }
+  for (int c = 0; c < 3 && !all_skip; c++) {
     const int sh = c ? 1 : 0, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, n = ctb >> sh, lgn = g->log2_ctb - sh;
     const int x0 = (cxi * ctb) >> sh, y0 = (cyi * ctb) >> sh;
     const uint16_t* rp = f->pix[c]; const uint16_t* sp = f->src[c];
@@ -912,6 +920,7 @@ RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_L
     RBT_SYNC_LDS();
   }
   RbtSao out; for (int i = 0; i < (int)sizeof(out); i++) ((uint8_t*)&out)[i] = 0;
+  if (all_skip) for (int c = 0; c < 3; c++) for (int t = 0; t < 5; t++) gain[c][t] = 0;
   int bt = -1; long long bgn = 0;
   for (int t = 0; t < 5; t++) if (gain[0][t] > bgn) { bgn = gain[0][t]; bt = t; }
   if (bt >= 0) { out.type[0] = bt == 0 ? 1 : 2; out.band_pos[0] = (uint8_t)bpos[0]; out.eo_class[0] = (uint8_t)(bt ? bt - 1 : 0); for (int k = 0; k < 4; k++) out.offset[0][k] = (int8_t)offs[0][bt][k]; }
