@@ -1115,6 +1115,7 @@ static void hm_sao_decide(enc* e) {
     for (int c = 0; c < 3; c++) { int any = 0; for (int k = 0; k < 4; k++) any |= out->offset[c][k]; if (!any && c != 2) { if (c == 0) out->type[0] = 0; else if (!(out->offset[2][0] | out->offset[2][1] | out->offset[2][2] | out->offset[2][3])) out->type[1] = out->type[2] = 0; } }
     for (int c = 0; c < 3; c++) if (!out->type[c]) { out->band_pos[c] = 0; out->eo_class[c] = 0; memset(out->offset[c], 0, 4); }
     if (out->type[1] != 2) out->eo_class[1] = out->eo_class[2] = 0;
+    for (int c = 0; c < 3; c++) if (out->type[c] != 1) out->band_pos[c] = 0;     /* fields the syntax does not carry stay zero: equal parameters compare equal (merge) */
   }
 }
 /* sao() syntax of one CTB from decided parameters (7.3.8.3): merge with the left / upper CTB when they carry the same parameters */

@@ -855,14 +855,13 @@ RBT_DEV void en_write_quadtree(RbtEnt* s, int x0, int y0, int log2) {
 // band, a single table would serialise the adds of the whole wave), the offsets are computed with the lanes over the table entries (one division per lane).
 // Measured on MI355X, encoder stages per job with 16 GOFs in flight: no SAO 33 ms; one LDS table + decision on every lane 62 ms; this version 48 ms;
 // staging the CTB and its halo in LDS with packed 8 / 16-bit register statistics 57 ms (11 KB of LDS per wave cost more residency than the loads it saved).
-struct RbtSaoLds { int32_t bcnt[8][32], bsum[8][32]; int32_t ecnt[16], esum[16]; int32_t off[48], gain[48]; };
+struct RbtSaoLds { int32_t bcnt[8][32], bsum[8][32]; int32_t ecnt[16], esum[16]; int32_t off[3][48], gain[48]; long long tgain[3][5]; int32_t bpos[3]; };   // candidates of all three components stay in LDS: private arrays indexed at run time would live in scratch memory
 RBT_DEV int en_sao_round_div(int sum, int cnt) { return cnt ? (sum >= 0 ? sum + cnt / 2 : sum - cnt / 2) / cnt : 0; }
 RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtSaoLds* L) {
   const RbtStreamCfg gcopy = f->cfg; const RbtStreamCfg* g = &gcopy;
   const int ctb = 1 << g->log2_ctb, cxi = ctb_addr % g->w_ctb, cyi = ctb_addr / g->w_ctb, bd = g->bit_depth;
   const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
   const long long lam16 = k_lambda16[rbt_clip3(0, 75, sl->qp + 6 * (bd - 8))], lam = lam16 * lam16;
-  long long gain[3][5]; int offs[3][5][4], bpos[3];
   // a CTB made of skipped CUs only is a copy of the (already filtered) reference: no statistics, no offsets (P pictures are mostly that)
   int all_skip = 0;
   if (f->ref_frame >= 0) {
@@ -904,29 +903,28 @@ RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_L
       int cnt, sum, o;
       if (j < 32) { cnt = 0; sum = 0; for (int q = 0; q < 8; q++) { cnt += L->bcnt[q][j]; sum += L->bsum[q][j]; } o = rbt_clip3(-7, 7, en_sao_round_div(sum, cnt)); }
       else { cnt = L->ecnt[j - 32]; sum = L->esum[j - 32]; o = en_sao_round_div(sum, cnt); o = ((j - 32) & 3) < 2 ? rbt_clip3(0, 7, o) : rbt_clip3(-7, 0, o); }
-      L->off[j] = o; L->gain[j] = 2 * o * sum - cnt * o * o;
+      L->off[c][j] = o; L->gain[j] = 2 * o * sum - cnt * o * o;
     }
     RBT_SYNC_LDS();
     { long long best = -1; int bp = 0;
       for (int b = 0; b <= 28; b++) { const long long gsum = (long long)L->gain[b] + L->gain[b + 1] + L->gain[b + 2] + L->gain[b + 3]; if (gsum > best) { best = gsum; bp = b; } }
-      bpos[c] = bp;
-      for (int k = 0; k < 4; k++) offs[c][0][k] = L->off[bp + k];
-      gain[c][0] = best * 256 - lam * 18; }
+      if (RBT_LANE0) { L->bpos[c] = bp; L->tgain[c][0] = best * 256 - lam * 18; } }
     for (int cls = 0; cls < 4; cls++) {
       long long gs = 0;
-      for (int k = 0; k < 4; k++) { offs[c][1 + cls][k] = L->off[32 + cls * 4 + k]; gs += L->gain[32 + cls * 4 + k]; }
-      gain[c][1 + cls] = gs * 256 - lam * 12;
+      for (int k = 0; k < 4; k++) gs += L->gain[32 + cls * 4 + k];
+      if (RBT_LANE0) L->tgain[c][1 + cls] = gs * 256 - lam * 12;
     }
     RBT_SYNC_LDS();
   }
   RbtSao out; for (int i = 0; i < (int)sizeof(out); i++) ((uint8_t*)&out)[i] = 0;
-  if (all_skip) for (int c = 0; c < 3; c++) for (int t = 0; t < 5; t++) gain[c][t] = 0;
   int bt = -1; long long bgn = 0;
-  for (int t = 0; t < 5; t++) if (gain[0][t] > bgn) { bgn = gain[0][t]; bt = t; }
-  if (bt >= 0) { out.type[0] = bt == 0 ? 1 : 2; out.band_pos[0] = (uint8_t)bpos[0]; out.eo_class[0] = (uint8_t)(bt ? bt - 1 : 0); for (int k = 0; k < 4; k++) out.offset[0][k] = (int8_t)offs[0][bt][k]; }
+  if (!all_skip) for (int t = 0; t < 5; t++) if (L->tgain[0][t] > bgn) { bgn = L->tgain[0][t]; bt = t; }
+  if (bt >= 0) { out.type[0] = bt == 0 ? 1 : 2; out.band_pos[0] = (uint8_t)(bt == 0 ? L->bpos[0] : 0); out.eo_class[0] = (uint8_t)(bt ? bt - 1 : 0);
+    for (int k = 0; k < 4; k++) out.offset[0][k] = (int8_t)(bt == 0 ? L->off[0][L->bpos[0] + k] : L->off[0][32 + (bt - 1) * 4 + k]); }
   bt = -1; bgn = 0;
-  for (int t = 0; t < 5; t++) if (gain[1][t] + gain[2][t] > bgn) { bgn = gain[1][t] + gain[2][t]; bt = t; }
-  if (bt >= 0) for (int c = 1; c < 3; c++) { out.type[c] = bt == 0 ? 1 : 2; out.band_pos[c] = (uint8_t)bpos[c]; out.eo_class[c] = (uint8_t)(bt ? bt - 1 : 0); for (int k = 0; k < 4; k++) out.offset[c][k] = (int8_t)offs[c][bt][k]; }
+  if (!all_skip) for (int t = 0; t < 5; t++) if (L->tgain[1][t] + L->tgain[2][t] > bgn) { bgn = L->tgain[1][t] + L->tgain[2][t]; bt = t; }
+  if (bt >= 0) for (int c = 1; c < 3; c++) { out.type[c] = bt == 0 ? 1 : 2; out.band_pos[c] = (uint8_t)(bt == 0 ? L->bpos[c] : 0); out.eo_class[c] = (uint8_t)(bt ? bt - 1 : 0);
+    for (int k = 0; k < 4; k++) out.offset[c][k] = (int8_t)(bt == 0 ? L->off[c][L->bpos[c] + k] : L->off[c][32 + (bt - 1) * 4 + k]); }
   // a type whose offsets are all zero costs bits for nothing
   { const int any0 = out.offset[0][0] | out.offset[0][1] | out.offset[0][2] | out.offset[0][3];
     const int any1 = out.offset[1][0] | out.offset[1][1] | out.offset[1][2] | out.offset[1][3], any2 = out.offset[2][0] | out.offset[2][1] | out.offset[2][2] | out.offset[2][3];

@@ -319,20 +319,60 @@ RBT_DEV void pz_emit_words(RbtParse* s, uint32_t w0, uint32_t w1, uint32_t w2, u
   s->n_cmds++;
 }
 
-// RbtSao <-> LDS copies (struct assignment across address spaces is not defined; RbtSao is 24 plain bytes)
-RBT_DEV void pz_sao_from_lds(RbtSao* d, const RBT_LDS_AS RbtSao* l) {
-  for (int i = 0; i < 3; i++) { d->type[i] = l->type[i]; d->band_pos[i] = l->band_pos[i]; d->eo_class[i] = l->eo_class[i]; for (int k = 0; k < 4; k++) d->offset[i][k] = l->offset[i][k]; }
-  d->pad[0] = d->pad[1] = d->pad[2] = 0;
+// SAO parameters of the current CTB while they are parsed: plain ints reached through compile-time indices only, so they stay in registers (the 24-byte
+// RbtSao with its byte arrays, indexed by a run-time component, lived in scratch memory: a round trip to it per access on the slice's latency chain).
+struct PzSao { int type[3], band[3], eo[3], off[3][4]; };
+// RbtSao is 24 plain bytes = six words: type[3] band_pos[3] eo_class[3] offset[3][4] pad[3]
+RBT_DEV uint32_t pz_sao_word(const PzSao* p, int w) {
+  const uint32_t by[24] = {(uint32_t)p->type[0], (uint32_t)p->type[1], (uint32_t)p->type[2], (uint32_t)p->band[0], (uint32_t)p->band[1], (uint32_t)p->band[2], (uint32_t)p->eo[0], (uint32_t)p->eo[1],
+                           (uint32_t)p->eo[2], (uint32_t)p->off[0][0], (uint32_t)p->off[0][1], (uint32_t)p->off[0][2], (uint32_t)p->off[0][3], (uint32_t)p->off[1][0], (uint32_t)p->off[1][1], (uint32_t)p->off[1][2],
+                           (uint32_t)p->off[1][3], (uint32_t)p->off[2][0], (uint32_t)p->off[2][1], (uint32_t)p->off[2][2], (uint32_t)p->off[2][3], 0u, 0u, 0u};
+  return (by[4 * w] & 255u) | ((by[4 * w + 1] & 255u) << 8) | ((by[4 * w + 2] & 255u) << 16) | ((by[4 * w + 3] & 255u) << 24);
 }
-RBT_DEV void pz_sao_to_lds(RBT_LDS_AS RbtSao* l, const RbtSao* d) {
-  for (int i = 0; i < 3; i++) { l->type[i] = d->type[i]; l->band_pos[i] = d->band_pos[i]; l->eo_class[i] = d->eo_class[i]; for (int k = 0; k < 4; k++) l->offset[i][k] = d->offset[i][k]; }
+RBT_DEV void pz_sao_unpack(PzSao* p, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5) {
+#define PZ_B(w, k) (int)(((w) >> (8 * (k))) & 255u)
+#define PZ_S(w, k) (int)(int8_t)(((w) >> (8 * (k))) & 255u)
+  p->type[0] = PZ_B(w0, 0); p->type[1] = PZ_B(w0, 1); p->type[2] = PZ_B(w0, 2); p->band[0] = PZ_B(w0, 3); p->band[1] = PZ_B(w1, 0); p->band[2] = PZ_B(w1, 1);
+  p->eo[0] = PZ_B(w1, 2); p->eo[1] = PZ_B(w1, 3); p->eo[2] = PZ_B(w2, 0);
+  p->off[0][0] = PZ_S(w2, 1); p->off[0][1] = PZ_S(w2, 2); p->off[0][2] = PZ_S(w2, 3); p->off[0][3] = PZ_S(w3, 0);
+  p->off[1][0] = PZ_S(w3, 1); p->off[1][1] = PZ_S(w3, 2); p->off[1][2] = PZ_S(w3, 3); p->off[1][3] = PZ_S(w4, 0);
+  p->off[2][0] = PZ_S(w4, 1); p->off[2][1] = PZ_S(w4, 2); p->off[2][2] = PZ_S(w4, 3); p->off[2][3] = PZ_S(w5, 0);
+#undef PZ_B
+#undef PZ_S
+}
+RBT_DEV void pz_sao_from_lds(PzSao* d, const RBT_LDS_AS RbtSao* l) { const RBT_LDS_AS uint32_t* w = (const RBT_LDS_AS uint32_t*)l; pz_sao_unpack(d, w[0], w[1], w[2], w[3], w[4], w[5]); }
+// sao_offset_abs / sign / band_position / eo_class of component CI (7.3.8.3)
+template <int CI> RBT_DEV void pz_sao_comp(RbtParse* s, RbtCabacDec* c, PzSao* p, int bd, int cmax) {
+  if ((CI == 0 && !pzs_sao_luma(s)) || (CI > 0 && !pzs_sao_chroma(s))) return;
+  if (CI == 2) p->type[2] = p->type[1];
+  else { int t = 0; if (rbt_cd_bin(c, CTX_SAO_TYPE)) t = rbt_cd_bypass(c) ? 2 : 1; p->type[CI] = t; }
+  const int type = p->type[CI];
+  if (!type) return;
+  int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  while (a0 < cmax && rbt_cd_bypass(c)) a0++;
+  while (a1 < cmax && rbt_cd_bypass(c)) a1++;
+  while (a2 < cmax && rbt_cd_bypass(c)) a2++;
+  while (a3 < cmax && rbt_cd_bypass(c)) a3++;
+  if (type == 1) {
+    if (a0 && rbt_cd_bypass(c)) a0 = -a0;
+    if (a1 && rbt_cd_bypass(c)) a1 = -a1;
+    if (a2 && rbt_cd_bypass(c)) a2 = -a2;
+    if (a3 && rbt_cd_bypass(c)) a3 = -a3;
+    p->band[CI] = (int)rbt_cd_bypass_n(c, 5);
+  } else {
+    a2 = -a2; a3 = -a3;
+    if (CI == 0) p->eo[0] = (int)rbt_cd_bypass_n(c, 2);
+    else if (CI == 1) p->eo[1] = (int)rbt_cd_bypass_n(c, 2);
+    else p->eo[2] = p->eo[1];
+  }
+  const int sc = 1 << (bd - rbt_min(bd, 10));
+  p->off[CI][0] = a0 * sc; p->off[CI][1] = a1 * sc; p->off[CI][2] = a2 * sc; p->off[CI][3] = a3 * sc;
 }
 // ------------------------------------------------------------------------------------------------ SAO (7.3.8.3)
 RBT_DEV void pz_sao(RbtParse* s, int rx, int ry) {
   RbtCabacDec* c = &s->c;
   rx = PZ_WU(rx); ry = PZ_WU(ry);
-  RbtSao p; for (int i = 0; i < 3; i++) { p.type[i] = p.band_pos[i] = p.eo_class[i] = 0; for (int k = 0; k < 4; k++) p.offset[i][k] = 0; }
-  p.pad[0] = p.pad[1] = p.pad[2] = 0;
+  PzSao p; pz_sao_unpack(&p, 0u, 0u, 0u, 0u, 0u, 0u);
   int wc = pzc_w_ctb(s);
   if (pzs_sao_luma(s) || pzs_sao_chroma(s)) {
     int merge_left = 0, merge_up = 0;
@@ -342,27 +382,14 @@ RBT_DEV void pz_sao(RbtParse* s, int rx, int ry) {
     else if (merge_up) pz_sao_from_lds(&p, &pz_sao_above(s->L, RBT_UNI(s->L->cap4))[rx]);
     else {
       int bd = pzc_bit_depth(s), cmax = (1 << (rbt_min(bd, 10) - 5)) - 1;
-      for (int ci = 0; ci < 3; ci++) {
-        if ((ci == 0 && !pzs_sao_luma(s)) || (ci > 0 && !pzs_sao_chroma(s))) continue;
-        if (ci == 2) p.type[2] = p.type[1];
-        else { int t = 0; if (rbt_cd_bin(c, CTX_SAO_TYPE)) t = rbt_cd_bypass(c) ? 2 : 1; p.type[ci] = (uint8_t)t; }
-        if (!p.type[ci]) continue;
-        int absv[4];
-        for (int i = 0; i < 4; i++) { int v = 0; while (v < cmax && rbt_cd_bypass(c)) v++; absv[i] = v; }
-        if (p.type[ci] == 1) {
-          for (int i = 0; i < 4; i++) if (absv[i] && rbt_cd_bypass(c)) absv[i] = -absv[i];
-          p.band_pos[ci] = (uint8_t)rbt_cd_bypass_n(c, 5);
-        } else {
-          absv[2] = -absv[2]; absv[3] = -absv[3];
-          if (ci == 0) p.eo_class[0] = (uint8_t)rbt_cd_bypass_n(c, 2);
-          else if (ci == 1) p.eo_class[1] = (uint8_t)rbt_cd_bypass_n(c, 2);
-          else p.eo_class[2] = p.eo_class[1];
-        }
-        for (int i = 0; i < 4; i++) p.offset[ci][i] = (int8_t)(absv[i] * (1 << (bd - rbt_min(bd, 10))));
-      }
+      pz_sao_comp<0>(s, c, &p, bd, cmax); pz_sao_comp<1>(s, c, &p, bd, cmax); pz_sao_comp<2>(s, c, &p, bd, cmax);
     }
   }
-  if (RBT_LANE0) { s->f->sao[ry * wc + rx] = p; pz_sao_to_lds(&s->L->sao_left, &p); pz_sao_to_lds(&pz_sao_above(s->L, s->L->cap4)[rx], &p); }
+  if (RBT_LANE0) {
+    uint32_t* g = (uint32_t*)&s->f->sao[ry * wc + rx]; RBT_LDS_AS uint32_t* l = (RBT_LDS_AS uint32_t*)&s->L->sao_left; RBT_LDS_AS uint32_t* a = (RBT_LDS_AS uint32_t*)&pz_sao_above(s->L, s->L->cap4)[rx];
+#pragma unroll
+    for (int w = 0; w < 6; w++) { const uint32_t v = pz_sao_word(&p, w); g[w] = v; l[w] = v; a[w] = v; }
+  }
   RBT_SYNC_LDS();
 }
 
@@ -654,9 +681,8 @@ RBT_DEV int pz_scale_mv(int mv, int tb, int td) {
 RBT_DEV int pz_temporal(const RbtParse* s, int xpb, int ypb, int w, int h, int ref_idx, RbtMv* out) {
   if (!pzs_temporal_mvp(s)) return 0;
   const RbtFrame* col = &s->frames[s->L->ref_frame[pzs_collocated_ref_idx(s)]];
-  int cx[2] = {xpb + w, xpb + (w >> 1)}, cy[2] = {ypb + h, ypb + (h >> 1)};
   for (int k = 0; k < 2; k++) {
-    int x = cx[k], y = cy[k];
+    int x = k ? xpb + (w >> 1) : xpb + w, y = k ? ypb + (h >> 1) : ypb + h;
     if (k == 0 && ((ypb >> pzc_log2_ctb(s)) != (y >> pzc_log2_ctb(s)) || x >= pzc_w(s) || y >= pzc_h(s))) continue;
     x = (x >> 4) << 4; y = (y >> 4) << 4;
     int i = (y >> 2) * pzc_w4(s) + (x >> 2);
@@ -672,50 +698,60 @@ RBT_DEV int pz_temporal(const RbtParse* s, int xpb, int ypb, int w, int h, int r
 }
 RBT_DEV RbtMv pz_merge(const RbtParse* s, int xpb, int ypb, int w, int h, int part_idx, int merge_idx) {
   int pm = s->cu_part_mode, maxc = pzs_max_merge_cand(s);
-  RbtMv list[6]; int n = 0;
+  // up to five candidates in named variables (a private array filled through a run-time index would live in scratch memory)
+  RbtMv l0 = {0, 0, 0}, l1 = l0, l2 = l0, l3 = l0, l4 = l0; int n = 0;
+#define PZ_PUSH(q) do { const RbtMv q_ = (q); if (n == 0) l0 = q_; else if (n == 1) l1 = q_; else if (n == 2) l2 = q_; else if (n == 3) l3 = q_; else if (n == 4) l4 = q_; n++; } while (0)
   RbtMv ca1 = {0, 0, 0}, cb1 = {0, 0, 0};
   int a1 = pz_pu_avail(s, xpb - 1, ypb + h - 1) && !((pm == RBT_PART_Nx2N || pm == RBT_PART_nLx2N || pm == RBT_PART_nRx2N) && part_idx == 1);
-  if (a1) { ca1 = pz_mv_at(s, xpb - 1, ypb + h - 1); list[n++] = ca1; }
+  if (a1) { ca1 = pz_mv_at(s, xpb - 1, ypb + h - 1); PZ_PUSH(ca1); }
   int b1 = pz_pu_avail(s, xpb + w - 1, ypb - 1) && !((pm == RBT_PART_2NxN || pm == RBT_PART_2NxnU || pm == RBT_PART_2NxnD) && part_idx == 1);
   int b1_in = 0, b0_in = 0, a0_in = 0;
-  if (b1) { cb1 = pz_mv_at(s, xpb + w - 1, ypb - 1); if (!(a1 && pz_mv_same(ca1, cb1))) { list[n++] = cb1; b1_in = 1; } }
-  if (pz_pu_avail(s, xpb + w, ypb - 1)) { RbtMv q = pz_mv_at(s, xpb + w, ypb - 1); if (!(b1 && pz_mv_same(cb1, q))) { list[n++] = q; b0_in = 1; } }
-  if (pz_pu_avail(s, xpb - 1, ypb + h)) { RbtMv q = pz_mv_at(s, xpb - 1, ypb + h); if (!(a1 && pz_mv_same(ca1, q))) { list[n++] = q; a0_in = 1; } }
+  if (b1) { cb1 = pz_mv_at(s, xpb + w - 1, ypb - 1); if (!(a1 && pz_mv_same(ca1, cb1))) { PZ_PUSH(cb1); b1_in = 1; } }
+  if (pz_pu_avail(s, xpb + w, ypb - 1)) { RbtMv q = pz_mv_at(s, xpb + w, ypb - 1); if (!(b1 && pz_mv_same(cb1, q))) { PZ_PUSH(q); b0_in = 1; } }
+  if (pz_pu_avail(s, xpb - 1, ypb + h)) { RbtMv q = pz_mv_at(s, xpb - 1, ypb + h); if (!(a1 && pz_mv_same(ca1, q))) { PZ_PUSH(q); a0_in = 1; } }
   if (a1 + b1_in + b0_in + a0_in != 4 && pz_pu_avail(s, xpb - 1, ypb - 1)) {
     RbtMv q = pz_mv_at(s, xpb - 1, ypb - 1);
-    if (!(a1 && pz_mv_same(ca1, q)) && !(b1 && pz_mv_same(cb1, q))) list[n++] = q;
+    if (!(a1 && pz_mv_same(ca1, q)) && !(b1 && pz_mv_same(cb1, q))) PZ_PUSH(q);
   }
   if (n > maxc) n = maxc;
-  if (n < maxc) { RbtMv t; if (pz_temporal(s, xpb, ypb, w, h, 0, &t)) list[n++] = t; }
+  if (n < maxc) { RbtMv t; if (pz_temporal(s, xpb, ypb, w, h, 0, &t)) PZ_PUSH(t); }
   int zero_idx = 0;
-  while (n < maxc) { RbtMv z = {0, 0, zero_idx < pzs_num_ref_idx(s) ? zero_idx : 0}; list[n++] = z; zero_idx++; }
-  RbtMv r = list[0];
-  for (int i = 1; i < 5; i++) if (i == merge_idx) r = list[i];     // avoid dynamic private-array indexing
+  while (n < maxc) { RbtMv z = {0, 0, zero_idx < pzs_num_ref_idx(s) ? zero_idx : 0}; PZ_PUSH(z); zero_idx++; }
+#undef PZ_PUSH
+  RbtMv r = merge_idx == 0 ? l0 : (merge_idx == 1 ? l1 : (merge_idx == 2 ? l2 : (merge_idx == 3 ? l3 : l4)));
   return r;
 }
 RBT_DEV RbtMv pz_amvp(const RbtParse* s, int xpb, int ypb, int w, int h, int ref_idx, int mvp_flag) {
   int tgt = s->L->ref_poc[ref_idx], cur = pzs_poc(s);
-  int xa[2] = {xpb - 1, xpb - 1}, ya[2] = {ypb + h, ypb + h - 1};
-  int xb[3] = {xpb + w, xpb + w - 1, xpb - 1}, yb[3] = {ypb - 1, ypb - 1, ypb - 1};
-  int ava[2], avb[3];
-  for (int k = 0; k < 2; k++) ava[k] = pz_pu_avail(s, xa[k], ya[k]);
-  for (int k = 0; k < 3; k++) avb[k] = pz_pu_avail(s, xb[k], yb[k]);
+  // spatial candidates A0, A1 (left: below-left, left) and B0, B1, B2 (above: above-right, above, above-left); positions by arithmetic and availability
+  // as bit masks - small private arrays indexed by a run-time k would live in scratch memory
+#define PZ_XA(k) (xpb - 1)
+#define PZ_YA(k) (ypb + h - (k))
+#define PZ_XB(k) ((k) == 0 ? xpb + w : ((k) == 1 ? xpb + w - 1 : xpb - 1))
+#define PZ_YB(k) (ypb - 1)
+  int ava = 0, avb = 0;
+  for (int k = 0; k < 2; k++) ava |= (pz_pu_avail(s, PZ_XA(k), PZ_YA(k)) ? 1 : 0) << k;
+  for (int k = 0; k < 3; k++) avb |= (pz_pu_avail(s, PZ_XB(k), PZ_YB(k)) ? 1 : 0) << k;
   int fa = 0, fb = 0; RbtMv ma = {0, 0, 0}, mb = {0, 0, 0};
-  for (int k = 0; k < 2 && !fa; k++) if (ava[k]) { RbtMv q = pz_mv_at(s, xa[k], ya[k]); if (s->L->ref_poc[q.ref] == tgt) { ma = q; fa = 1; } }
-  for (int k = 0; k < 2 && !fa; k++) if (ava[k]) {
-    RbtMv q = pz_mv_at(s, xa[k], ya[k]); int td = cur - s->L->ref_poc[q.ref], tb = cur - tgt;
+  for (int k = 0; k < 2 && !fa; k++) if ((ava >> k) & 1) { RbtMv q = pz_mv_at(s, PZ_XA(k), PZ_YA(k)); if (s->L->ref_poc[q.ref] == tgt) { ma = q; fa = 1; } }
+  for (int k = 0; k < 2 && !fa; k++) if ((ava >> k) & 1) {
+    RbtMv q = pz_mv_at(s, PZ_XA(k), PZ_YA(k)); int td = cur - s->L->ref_poc[q.ref], tb = cur - tgt;
     ma = q; fa = 1; if (td != tb && td != 0) { ma.x = pz_scale_mv(q.x, tb, td); ma.y = pz_scale_mv(q.y, tb, td); }
   }
-  int is_scaled = ava[0] || ava[1];
-  for (int k = 0; k < 3 && !fb; k++) if (avb[k]) { RbtMv q = pz_mv_at(s, xb[k], yb[k]); if (s->L->ref_poc[q.ref] == tgt) { mb = q; fb = 1; } }
+  int is_scaled = ava != 0;
+  for (int k = 0; k < 3 && !fb; k++) if ((avb >> k) & 1) { RbtMv q = pz_mv_at(s, PZ_XB(k), PZ_YB(k)); if (s->L->ref_poc[q.ref] == tgt) { mb = q; fb = 1; } }
   if (!is_scaled && fb) { ma = mb; fa = 1; }
   if (!is_scaled) {
     fb = 0;
-    for (int k = 0; k < 3 && !fb; k++) if (avb[k]) {
-      RbtMv q = pz_mv_at(s, xb[k], yb[k]); int td = cur - s->L->ref_poc[q.ref], tb = cur - tgt;
+    for (int k = 0; k < 3 && !fb; k++) if ((avb >> k) & 1) {
+      RbtMv q = pz_mv_at(s, PZ_XB(k), PZ_YB(k)); int td = cur - s->L->ref_poc[q.ref], tb = cur - tgt;
       mb = q; fb = 1; if (td != tb && td != 0) { mb.x = pz_scale_mv(q.x, tb, td); mb.y = pz_scale_mv(q.y, tb, td); }
     }
   }
+#undef PZ_XA
+#undef PZ_YA
+#undef PZ_XB
+#undef PZ_YB
   RbtMv l0 = {0, 0, ref_idx}, l1 = {0, 0, ref_idx}; int n = 0;
   if (fa) { l0 = ma; n = 1; }
   if (fb && !(fa && ma.x == mb.x && ma.y == mb.y)) { if (n == 0) l0 = mb; else l1 = mb; n++; }
@@ -822,12 +858,15 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
     RBT_SYNC_LDS();
     PZ_STAMP(s, 17);
     int np = s->cu_part_mode == RBT_PART_NxN ? 4 : 1, pb = N >> (np == 4);
-    int prev[4], mpm_idx[4], rem[4];
-    for (int i = 0; i < np; i++) prev[i] = rbt_cd_bin(c, CTX_PREV_INTRA_LUMA);
+    // per prediction unit: prev_intra_luma_pred_flag, then mpm_idx or rem_intra_luma_pred_mode - packed into two words (private arrays indexed by a
+    // run-time i live in scratch memory: two round trips to it per CU on the latency chain of the slice)
+    uint32_t prev_bits = 0, val_bytes = 0;
+    for (int i = 0; i < np; i++) prev_bits |= (uint32_t)rbt_cd_bin(c, CTX_PREV_INTRA_LUMA) << i;
     for (int i = 0; i < np; i++) {
-      mpm_idx[i] = 0; rem[i] = 0;
-      if (prev[i]) { mpm_idx[i] = rbt_cd_bypass(c); if (mpm_idx[i]) mpm_idx[i] += rbt_cd_bypass(c); }
-      else rem[i] = (int)rbt_cd_bypass_n(c, 5);
+      int v;
+      if ((prev_bits >> i) & 1) { v = rbt_cd_bypass(c); if (v) v += rbt_cd_bypass(c); }
+      else v = (int)rbt_cd_bypass_n(c, 5);
+      val_bytes |= (uint32_t)v << (8 * i);
     }
     PZ_STAMP(s, 18);
     for (int i = 0; i < np; i++) {
@@ -839,14 +878,16 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
 #ifdef RBT_PROFILE
       s->t_mpm += __builtin_readcyclecounter() - tm_;
 #endif
-      int mode;
-      if (prev[i]) mode = mpm_idx[i] == 0 ? cand[0] : (mpm_idx[i] == 1 ? cand[1] : cand[2]);
+      int mode; const int pv = (int)((prev_bits >> i) & 1u), val = (int)((val_bytes >> (8 * i)) & 255u);
+      if (pv) mode = val == 0 ? cand[0] : (val == 1 ? cand[1] : cand[2]);
       else {
         if (cand[0] > cand[1]) { int t = cand[0]; cand[0] = cand[1]; cand[1] = t; }
         if (cand[0] > cand[2]) { int t = cand[0]; cand[0] = cand[2]; cand[2] = t; }
         if (cand[1] > cand[2]) { int t = cand[1]; cand[1] = cand[2]; cand[2] = t; }
-        mode = rem[i];
-        for (int k = 0; k < 3; k++) if (mode >= cand[k]) mode++;
+        mode = val;
+        if (mode >= cand[0]) mode++;
+        if (mode >= cand[1]) mode++;
+        if (mode >= cand[2]) mode++;
       }
       pz_set_il(s, i, mode);
       pz_fill_dm(s, xp, yp, pb, (depth << 6) | mode);

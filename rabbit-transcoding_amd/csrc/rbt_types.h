@@ -35,7 +35,7 @@ struct RbtStreamCfg {            // SPS + PPS fields the kernels need
   int8_t cb_qp_offset, cr_qp_offset, pad2, pad3;
 };
 
-struct RbtSao { uint8_t type[3], band_pos[3], eo_class[3]; int8_t offset[3][4]; uint8_t pad[3]; };   // 24 bytes
+struct alignas(4) RbtSao { uint8_t type[3], band_pos[3], eo_class[3]; int8_t offset[3][4]; uint8_t pad[3]; };   // 24 bytes
 
 struct RbtCmd {                  // 16 bytes, one per CU / PU / TU in decode order inside a CTB
   uint8_t type;                  // 1 PU, 2 TU
