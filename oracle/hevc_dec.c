@@ -813,6 +813,61 @@ static void parse_sei(oracle_hevc_decoder* d, const uint8_t* rbsp, size_t n) {
 }
 
 /* ================================================================================================ API */
+/* every slice segment header of an Annex-B stream as the oracle's parser reads it, 18 ints per slice (tests/test_slice_headers.py pins them against the
+ * reference's TDecCavlc::parseSliceHeader, tests/golden/slices_*.json). Returns the slice count, -1 on a parse error. */
+int oracle_slice_headers(const uint8_t* p, size_t n, int* out, int cap) {
+  oracle_hevc_decoder* d = (oracle_hevc_decoder*)calloc(1, sizeof(*d));
+  int k = 0; size_t i = 0;
+  while (i + 3 < n) {
+    if (!(p[i] == 0 && p[i + 1] == 0 && p[i + 2] == 1)) { i++; continue; }
+    size_t st = i + 3, e = st;
+    while (e + 2 < n && !(p[e] == 0 && p[e + 1] == 0 && (p[e + 2] == 1 || (p[e + 2] == 0 && e + 3 < n && p[e + 3] == 1)))) e++;
+    if (e + 2 >= n) e = n;
+    int type = (p[st] >> 1) & 63;
+    uint8_t* rb = (uint8_t*)malloc(e - st + 1); size_t m = 0; int z = 0;
+    for (size_t q = st + 2; q < e; q++) { if (z >= 2 && p[q] == 3) { z = 0; continue; } z = p[q] == 0 ? z + 1 : 0; rb[m++] = p[q]; }
+    bitreader b = {rb, m, 0};
+    int rc = 0;
+    if (type == NAL_SPS) rc = parse_sps(d, &b);
+    else if (type == NAL_PPS) rc = parse_pps(d, &b);
+    else if (type < 32) {
+      hevc_slice_hdr h; hevc_sps* sps; hevc_pps* pps; memset(&h, 0, sizeof(h));
+      rc = parse_slice_header(d, &b, type, &h, &sps, &pps);
+      if (!rc) {   /* PicOrderCntVal (8.3.1), as start_picture derives it */
+        if (type == NAL_IDR_W_RADL || type == NAL_IDR_N_LP) h.poc = 0;
+        else { int max_lsb = 1 << sps->log2_max_poc_lsb, prev_lsb = d->prev_tid0_poc & (max_lsb - 1), prev_msb = d->prev_tid0_poc - prev_lsb, msb = prev_msb;
+          if (h.poc_lsb < prev_lsb && prev_lsb - h.poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb; else if (h.poc_lsb > prev_lsb && h.poc_lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
+          h.poc = msb + h.poc_lsb; }
+      }
+      if (!rc && k < cap) { int* o = out + 18 * k; int intra = h.slice_type == SLICE_I;
+        o[0] = type; o[1] = h.segment_addr; o[2] = h.slice_type; o[3] = h.poc; o[4] = h.temporal_mvp; o[5] = h.sao_luma; o[6] = h.sao_chroma; o[7] = intra ? 0 : h.num_ref_idx[0];
+        o[8] = h.cabac_init_flag; o[9] = intra ? 0 : h.collocated_ref_idx; o[10] = intra ? 0 : h.max_merge_cand; o[11] = h.qp; o[12] = h.cb_qp_offset; o[13] = h.cr_qp_offset;
+        o[14] = h.deblocking_disabled; o[15] = h.beta_offset_div2; o[16] = h.tc_offset_div2; o[17] = h.loop_filter_across_slices; }
+      if (!rc) { k++; d->prev_tid0_poc = h.poc; }
+    }
+    free(rb);
+    if (rc) { free(d); return -1; }
+    i = e;
+  }
+  free(d);
+  return k;
+}
+/* log2_max_poc_lsb, log2_ctb, sao, tmvp, num_st_rps of the first SPS of the stream (what the reference harness needs to be told, oracle/ref_harness.cpp) */
+int oracle_sps_fields(const uint8_t* p, size_t n, int out[5]) {
+  oracle_hevc_decoder* d = (oracle_hevc_decoder*)calloc(1, sizeof(*d));
+  int rc = -1;
+  for (size_t i = 0; i + 4 < n && rc; i++) if (p[i] == 0 && p[i + 1] == 0 && p[i + 2] == 1 && ((p[i + 3] >> 1) & 63) == NAL_SPS) {
+    size_t st = i + 3, e = st; while (e + 2 < n && !(p[e] == 0 && p[e + 1] == 0 && p[e + 2] <= 1)) e++;
+    if (e + 2 >= n) e = n;
+    uint8_t* rb = (uint8_t*)malloc(e - st + 1); size_t m = 0; int z = 0;
+    for (size_t q = st + 2; q < e; q++) { if (z >= 2 && p[q] == 3) { z = 0; continue; } z = p[q] == 0 ? z + 1 : 0; rb[m++] = p[q]; }
+    bitreader b = {rb, m, 0};
+    if (!parse_sps(d, &b)) for (int k = 0; k < 16; k++) if (d->sps[k].valid) { hevc_sps* s = &d->sps[k]; out[0] = s->log2_max_poc_lsb; out[1] = s->log2_ctb; out[2] = s->sao_enabled; out[3] = s->temporal_mvp_enabled; out[4] = s->num_st_rps; rc = 0; break; }
+    free(rb);
+  }
+  free(d);
+  return rc;
+}
 oracle_hevc_decoder* oracle_hevc_dec_create(void) { oracle_hevc_decoder* d = (oracle_hevc_decoder*)calloc(1, sizeof(*d)); build_scans(d); return d; }
 void oracle_hevc_dec_destroy(oracle_hevc_decoder* d) {
   if (!d) return;

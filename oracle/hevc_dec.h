@@ -17,4 +17,5 @@ const hevc_frame* oracle_hevc_dec_frame(const oracle_hevc_decoder* d, int i);
 void oracle_hevc_dec_crop(const oracle_hevc_decoder* d, int out[4]);   /* luma samples to drop: left, right, top, bottom */
 int oracle_hevc_dec_md5_checked(const oracle_hevc_decoder* d);
 int oracle_hevc_dec_md5_failed(const oracle_hevc_decoder* d);
+int oracle_slice_headers(const uint8_t* annexb, size_t n, int* out, int cap);   /* 18 ints per slice segment header, see hevc_dec.c */
 #endif

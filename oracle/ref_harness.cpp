@@ -2,6 +2,7 @@
 // (/root/reference/dependencies/PccLibHevcParser, compiled in place by oracle/ref_build.sh into oracle/_ref/).
 // It exists to pin the restatement:
 //   tables            -> dumps the normative ROM the reference carries (PccHevcTComRom.cpp:457-465,471-616,635-642,700-709)
+//   slices <annexb file> ... -> every slice segment header through the reference's parseSliceHeader (PccHevcTDecCAVLC.cpp:1138)
 //   hls <annexb file> -> parses every VPS/SPS/PPS of an Annex-B stream with the reference's TDecCavlc
 //                        (PccHevcTDecCAVLC.cpp:189 parsePPS, :651 parseSPS, :1043 parseVPS) and prints the fields
 // No reference source is copied: the reference files are compiled from where they lie.
@@ -16,6 +17,12 @@ using namespace pcc_hevc;
 // internal linkage, so they cannot be linked against: compile that translation unit as part of this one instead
 // (ref_build.sh passes -I<reference>/dependencies/PccLibHevcParser/source and leaves its object out of the link).
 #include "PccHevcTComRom.cpp"
+
+// The reference declares calculateParameterSetChangedFlagPccHevc inside namespace pcc_hevc (PccHevcTComSlice.h:1739) but defines it at global scope
+// (PccHevcTComSlice.cpp:2492, after a using-directive), so ParameterSetMap::storePS - instantiated here, never in the reference's own code - does not link.
+// Forward the namespaced name to the reference's own definition (no behaviour of ours involved).
+Void calculateParameterSetChangedFlagPccHevc(Bool& bChanged, const std::vector<UChar>* pOldData, const std::vector<UChar>* pNewData);
+namespace pcc_hevc { Void calculateParameterSetChangedFlagPccHevc(Bool& bChanged, const std::vector<UChar>* pOldData, const std::vector<UChar>* pNewData) { ::calculateParameterSetChangedFlagPccHevc(bChanged, pOldData, pNewData); } }
 
 static std::vector<uint8_t> readFile(const char* p) {
   std::vector<uint8_t> v; FILE* f = fopen(p, "rb"); if (!f) { perror(p); exit(2); }
@@ -88,6 +95,57 @@ int main(int argc, char** argv) {
     delete dec;
     return 0;
   }
-  fprintf(stderr, "usage: %s tables | hls <annexb>\n", argv[0]);
+  if (argc >= 8 && !strcmp(argv[1], "slices")) {
+    // slices <annexb> <log2_max_poc_lsb> <log2_ctb> <sao> <tmvp> <num_st_rps>: every slice segment header of the stream through the reference's
+    // TDecCavlc::parseSliceHeader (PccHevcTDecCAVLC.cpp:1138). The reference's parseSPS stops storing fields after the bit depths (:732, the rest is
+    // commented out), so the SPS fields the slice header syntax depends on are set from the command line (the caller's own parse of the same SPS);
+    // short-term RPS i of the SPS = the i + 1 preceding pictures, all used (what oracle/hevc_enc.c writes). The PPS is the reference's own parse.
+    std::vector<uint8_t> buf = readFile(argv[2]);
+    const int bitsPoc = atoi(argv[3]), log2Ctb = atoi(argv[4]), sao = atoi(argv[5]), tmvp = atoi(argv[6]), nRps = atoi(argv[7]);
+    const int size = (int)buf.size(); const uint8_t* data = buf.data();
+    TDecCavlc* dec = new TDecCavlc();
+    ParameterSetManager psm;
+    int index = 0, sc = data[2] == 0 ? 4 : 3, n = 0, prevPoc = 0;
+    printf("[\n");
+    for (int i = sc; i <= size; i++) {
+      if (i == size || (i + 3 < size && data[i] == 0 && data[i + 1] == 0 && ((data[i + 2] == 0 && data[i + 3] == 1) || data[i + 2] == 1))) {
+        int type = (data[index + sc] & 126) >> 1;
+        std::vector<uint8_t> rb; int z = 0;
+        for (int k = index + sc + 2; k < i; k++) { if (z >= 2 && data[k] == 3) { z = 0; continue; } z = data[k] == 0 ? z + 1 : 0; rb.push_back(data[k]); }
+        dec->setBuffer((UChar*)rb.data(), (int)rb.size());
+        std::vector<UChar> nalu(rb.begin(), rb.end());
+        if (type == NAL_UNIT_VPS) { TComVPS* vps = new TComVPS(); dec->parseVPS(vps); psm.storeVPS(vps, nalu); }
+        if (type == NAL_UNIT_SPS) {
+          TComSPS* s = new TComSPS(); dec->parseSPS(s);
+          s->setBitsForPOC(bitsPoc); s->setMaxCUWidth(1u << log2Ctb); s->setMaxCUHeight(1u << log2Ctb); s->setUseSAO(sao != 0); s->setSPSTemporalMVPEnabledFlag(tmvp != 0);
+          s->setLongTermRefsPresent(false); s->setMaxDecPicBuffering(6, 0);
+          s->createRPSList(nRps);
+          for (int r = 0; r < nRps; r++) {
+            TComReferencePictureSet* rps = s->getRPSList()->getReferencePictureSet(r);
+            rps->setInterRPSPrediction(false); rps->setNumberOfNegativePictures(r + 1); rps->setNumberOfPositivePictures(0); rps->setNumberOfPictures(r + 1);
+            for (int j = 0; j <= r; j++) { rps->setDeltaPOC(j, -(j + 1)); rps->setUsed(j, true); }
+          }
+          psm.storeSPS(s, nalu);
+        }
+        if (type == NAL_UNIT_PPS) { TComPPS* p = new TComPPS(); dec->parsePPS(p); psm.storePPS(p, nalu); }
+        if (type < 32) {
+          TComSlice slice; slice.initSlice(); slice.setNalUnitType((NalUnitType)type); slice.setTLayer(0);
+          dec->parseSliceHeader(&slice, &psm, prevPoc);
+          printf("%s{\"nal_type\":%d,\"address\":%d,\"slice_type\":%d,\"poc\":%d,\"tmvp\":%d,\"sao_luma\":%d,\"sao_chroma\":%d,\"num_ref_idx\":%d,\"cabac_init\":%d,"
+                 "\"col_ref_idx\":%d,\"max_merge_cand\":%d,\"qp\":%d,\"cb_qp_offset\":%d,\"cr_qp_offset\":%d,\"deblocking_disabled\":%d,\"beta_offset_div2\":%d,"
+                 "\"tc_offset_div2\":%d,\"lf_across\":%d}\n", n++ ? "," : "", type, (int)slice.getSliceSegmentCurStartCtuTsAddr(), (int)slice.getSliceType(), slice.getPOC(),
+                 (int)slice.getEnableTMVPFlag(), (int)slice.getSaoEnabledFlag(CHANNEL_TYPE_LUMA), (int)slice.getSaoEnabledFlag(CHANNEL_TYPE_CHROMA),
+                 slice.isIntra() ? 0 : slice.getNumRefIdx(REF_PIC_LIST_0), (int)slice.getCabacInitFlag(), slice.isIntra() ? 0 : (int)slice.getColRefIdx(),
+                 slice.isIntra() ? 0 : (int)slice.getMaxNumMergeCand(), slice.getSliceQp(), slice.getSliceChromaQpDelta(COMPONENT_Cb), slice.getSliceChromaQpDelta(COMPONENT_Cr),
+                 (int)slice.getDeblockingFilterDisable(), slice.getDeblockingFilterBetaOffsetDiv2(), slice.getDeblockingFilterTcOffsetDiv2(), (int)slice.getLFCrossSliceBoundaryFlag());
+          prevPoc = slice.getPOC();
+        }
+        if (i < size) { sc = data[i + 2] == 0 ? 4 : 3; index = i; i += sc; }
+      }
+    }
+    printf("]\n");
+    return 0;
+  }
+  fprintf(stderr, "usage: %s tables | hls <annexb> | slices <annexb> <log2_max_poc_lsb> <log2_ctb> <sao> <tmvp> <num_st_rps>\n", argv[0]);
   return 1;
 }

@@ -37,6 +37,30 @@ def main():
         json.loads(out)
         open(os.path.join(HERE, f"hls_{name}.json"), "w").write(out)
         print(name, len(bs), "bytes")
+    slice_goldens()
+
+
+def slice_goldens():
+    """slices_<name>.annexb / .json: every slice segment header of oracle-coded streams through the reference's parseSliceHeader (hevc_hls_ref slices).
+    The SPS fields that syntax depends on (the reference's parseSPS does not store them) are passed on the command line from the oracle's own settings."""
+    import synth
+    m = synth.make_maps(128, 128, 3)
+    zeros = np.zeros((5, 96 * 64 * 3 // 2), np.uint16)
+    cases = {"e1_geo_rows": (O.encode(m["geo"], 128, 128, 10, 24, gop=2, log2_ctb=5, rows_per_slice=1)[0], [8, 5, 1, 0, 1]),
+             "e1_occ_lossless": (O.encode(m["occ"], 64, 64, 8, 8, gop=1, lossless=1, i_qp_offset=0, log2_ctb=5, rows_per_slice=1)[0], [8, 5, 0, 0, 1]),
+             "hm_attr": (O.encode_hm(m["attr"], 128, 128, 10, 22)[0], [8, 6, 1, 1, 1])}
+    for seed in (3, 7, 12, 21):       # random-syntax streams: several slices per picture, two references, TMVP, cabac_init, chroma offsets, deblocking overrides
+        bs = O.encode(zeros, 96, 64, 10, qp=30, gop=2, stress_seed=seed, log2_ctb=0)[0]
+        sps = O.sps_fields(bs)
+        cases[f"stress{seed}"] = (bs, [sps["log2_max_poc_lsb"], sps["log2_ctb"], sps["sao"], sps["tmvp"], sps["num_st_rps"]])
+    for name, (bs, a) in cases.items():
+        p = os.path.join(HERE, f"slices_{name}.annexb")
+        open(p, "wb").write(bs)
+        out = subprocess.check_output([REF, "slices", p] + [str(x) for x in a]).decode()
+        out = "".join(l + "\n" for l in out.splitlines() if l[:1] in "[],{")
+        json.loads(out)
+        open(os.path.join(HERE, f"slices_{name}.json"), "w").write(out)
+        print("slices", name, len(bs), "bytes", len(json.loads(out)), "slice headers")
 
 
 if __name__ == "__main__":

@@ -14,6 +14,7 @@
 #include "../../rabbit-transcoding_amd/csrc/rbt_filter.h"
 #include "../../rabbit-transcoding_amd/csrc/rbt_encode.h"
 #include "../../rabbit-transcoding_amd/csrc/rbt_pcc.h"
+#include "../../rabbit-transcoding_amd/host/rbt_hls.h"
 
 namespace rbtk {
 static double g_t[32][2];
@@ -151,4 +152,33 @@ extern "C" int rbt_hostemu_table(const char* name, int i, int j, int k) {
   if (!strcmp(name, "group_idx")) return k_group_idx[i];
   if (!strcmp(name, "min_in_group")) return k_min_in_group[i];
   return -99999;
+}
+
+// ---- the PRODUCT's host-side slice segment header parser (host/rbt_hls.cpp) on every slice of an Annex-B stream, 18 ints per slice, for
+// tests/test_slice_headers.py (pinned against the reference's TDecCavlc::parseSliceHeader through tests/golden/slices_*.json). Returns the slice count.
+extern "C" int rbt_hostemu_slice_headers(const uint8_t* annexb, size_t n, int* out, int cap) {
+  std::vector<uint8_t> rbsp; std::vector<rbt::Nal> nals; rbt::split_annexb(annexb, n, rbsp, nals);
+  rbt::ParamSets* ps = new rbt::ParamSets(); std::string err; int k = 0, prev_poc = 0;
+  for (auto& nal : nals) {
+    const uint8_t* r = rbsp.data() + nal.rbsp_off;
+    if (nal.type == 33) rbt::parse_sps(*ps, r, nal.rbsp_size, err);
+    else if (nal.type == 34) rbt::parse_pps(*ps, r, nal.rbsp_size, err);
+    else if (nal.type < 32) {
+      rbt::SliceHdr h; if (rbt::parse_slice_header(*ps, r, nal.rbsp_size, nal.type, h, err)) { delete ps; return -1; }
+      { // PicOrderCntVal (8.3.1) the way host/rbt_decode.cpp derives it from slice_pic_order_cnt_lsb
+        const rbt::Sps& sp = ps->sps[ps->pps[h.pps_id].sps_id];
+        if (nal.type == 19 || nal.type == 20) h.poc = 0;
+        else { const int max_lsb = 1 << sp.log2_max_poc_lsb, prev_lsb = prev_poc & (max_lsb - 1), prev_msb = prev_poc - prev_lsb; int msb = prev_msb;
+          if (h.poc_lsb < prev_lsb && prev_lsb - h.poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb; else if (h.poc_lsb > prev_lsb && h.poc_lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
+          h.poc = msb + h.poc_lsb; }
+        prev_poc = h.poc; }
+      if (k < cap) { int* o = out + 18 * k; const int intra = h.slice_type == RBT_SLICE_I;
+        o[0] = nal.type; o[1] = h.segment_addr; o[2] = h.slice_type; o[3] = h.poc; o[4] = h.temporal_mvp; o[5] = h.sao_luma; o[6] = h.sao_chroma; o[7] = intra ? 0 : h.num_ref_idx;
+        o[8] = h.cabac_init_flag; o[9] = intra ? 0 : h.collocated_ref_idx; o[10] = intra ? 0 : h.max_merge_cand; o[11] = h.qp; o[12] = h.cb_qp_offset; o[13] = h.cr_qp_offset;
+        o[14] = h.deblocking_disabled; o[15] = h.beta_offset_div2; o[16] = h.tc_offset_div2; o[17] = h.lf_across; }
+      k++;
+    }
+  }
+  delete ps;
+  return k;
 }

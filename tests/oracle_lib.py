@@ -199,3 +199,25 @@ def d1(a, b, peak=1023):
     if lib().oracle_d1(a.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0], peak, C.byref(r)) != 0:
         raise RuntimeError("oracle d1 failed")
     return {n: getattr(r, n) for n, _ in OD1._fields_}
+
+
+def sps_fields(stream: bytes):
+    out = (C.c_int * 5)()
+    if lib().oracle_sps_fields(stream, len(stream), out) != 0:
+        raise RuntimeError("no SPS")
+    return dict(zip(("log2_max_poc_lsb", "log2_ctb", "sao", "tmvp", "num_st_rps"), list(out)))
+
+
+SLICE_FIELDS = ("nal_type", "address", "slice_type", "poc", "tmvp", "sao_luma", "sao_chroma", "num_ref_idx", "cabac_init", "col_ref_idx", "max_merge_cand", "qp",
+                "cb_qp_offset", "cr_qp_offset", "deblocking_disabled", "beta_offset_div2", "tc_offset_div2", "lf_across")
+
+
+def slice_headers(stream: bytes, fn=None):
+    """every slice segment header as the oracle's parser reads it (fn: another library's accessor with the same signature, e.g. the product's host parser)"""
+    cap = 4096
+    out = (C.c_int * (18 * cap))()
+    f = fn or lib().oracle_slice_headers
+    n = f(stream, C.c_size_t(len(stream)), out, cap)
+    if n < 0:
+        raise RuntimeError("slice header parse failed")
+    return [dict(zip(SLICE_FIELDS, out[18 * k:18 * k + 18])) for k in range(n)]
