@@ -8,9 +8,9 @@
  *     gop=1 -> all IDR (occupancy); parameter sets repeated with every IDR.
  *   - CQP: P slices at qp, I slices at qp + i_qp_offset (x265 CQP with ipratio 1.4 => -3).
  *   - one slice per `ctb_rows_per_slice` CTB rows so entropy coding and intra reconstruction parallelise per row.
- *   - I pictures: CU quadtree 32/16/8 chosen bottom-up from open-loop (source-neighbour) intra SAD over all 35 modes by a
- *     two-step search (11 coarse candidates, then the angular modes within two of the best), TU = CU, chroma DM; dead-zone
- *     quantiser 171/512.
+ *   - I pictures: CU quadtree 32/16/8 chosen bottom-up from open-loop (source-neighbour) intra SAD; modes of the 16x16 and 32x32 blocks from all 35
+ *     by a two-step search (11 coarse candidates, then the angular modes within two of the best), modes of the 8x8 blocks from planar, DC, vertical,
+ *     horizontal and the neighbourhood of their 16x16 block's mode; TU = CU, chroma DM; dead-zone quantiser 171/512.
  *   - P pictures: 16x16 CUs merged (zero MV) + residual, skip when all levels are zero, skips merged up the tree;
  *     dead-zone 85/512.
  *   - lossless (occupancy): cu_transquant_bypass, same quadtree/mode analysis.
@@ -842,8 +842,8 @@ static void analyse_ctb_intra(enc* e, int cx, int cy) {
   int ctb = 1 << sps->log2_ctb;
   hevc_frame srcview = *e->src;   /* intra prediction from SOURCE neighbours (open loop) */
   uint16_t pred[32 * 32];
-  for (int si = 0; si < 3; si++) {
-    int S = 8 << si; if (S > ctb) break;
+  for (int si = 2; si >= 0; si--) {     /* largest blocks first: the 8x8 blocks take their candidates from the 16x16 block around them */
+    int S = 8 << si; if (S > ctb) continue;
     int nb = ctb / S;
     /* visit blocks of size S in z-order */
     for (int z = 0; z < nb * nb; z++) {
@@ -855,12 +855,21 @@ static void analyse_ctb_intra(enc* e, int cx, int cy) {
       if (x0 >= sps->width || y0 >= sps->height) { e->an_cost[si][bi] = 0; continue; }
       if (x0 + S > sps->width || y0 + S > sps->height) {   /* block straddles the picture edge: never a CU, but its inside part counts as coded */
         e->an_cost[si][bi] = 0x0FFFFFFF; set_rect8(m->done, m->w4, x0, y0, imin(S, sps->width - x0), imin(S, sps->height - y0), 1); continue; }
-      /* 11 coarse candidates (planar, DC, every fourth angular mode), then the angular modes within two of the best coarse one: every one of
-       * the 35 modes is within reach, at most 15 are evaluated; ties keep the earlier candidate */
+      /* 16x16 and 32x32: 11 coarse candidates (planar, DC, every fourth angular mode), then the angular modes within two of the best coarse one: every one
+       * of the 35 modes is within reach, at most 15 are evaluated. 8x8 inside a complete 16x16 block: planar, DC, vertical, horizontal and the angular modes
+       * within two of the 16x16 block's mode (modes 2, 18, 34 when that one is not angular): at most 9. Ties keep the earlier candidate. */
+      int parent = -1;
+      if (si == 0 && ctb >= 16 && e->an_cost[1][(by / 2) * (nb / 2) + bx / 2] < 0x0FFFFFFF) parent = e->an_mode[1][(by / 2) * (nb / 2) + bx / 2];
       int coarse = 0;
       for (int k = 0; k < 15; k++) {
         int mode;
-        if (k < 11) mode = k_intra_cand[k];
+        if (parent >= 0) {
+          static const int base4[4] = {0, 1, 26, 10}, alt3[3] = {2, 18, 34};
+          if (k >= 9) break;
+          if (k < 4) mode = base4[k];
+          else if (parent >= 2) { mode = parent + (k - 6); if (mode < 2 || mode > 34 || mode == 10 || mode == 26) continue; }
+          else { if (k >= 7) break; mode = alt3[k - 4]; }
+        } else if (k < 11) mode = k_intra_cand[k];
         else { if (k == 11) coarse = e->an_mode[si][bi]; if (coarse < 2) break; mode = coarse + (k == 11 ? -2 : k == 12 ? -1 : k == 13 ? 1 : 2); if (mode < 2 || mode > 34) continue; }
         hevc_intra_pred_buf(&srcview, m, 0, x0, y0, 3 + si, mode, pred);
         int sad = 0;

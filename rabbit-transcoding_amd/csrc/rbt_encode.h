@@ -109,8 +109,8 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
     }
     RBT_PAR_FOR(i, 65) { const int x = qx - 1, y = qy + i - 1; l->src[i * 66] = (x >= 0 && y >= 0 && y < g->h) ? srcp[(size_t)y * g->w + x] : 0; }
     RBT_SYNC_LDS();
-    for (int si = 0; si < 3; si++) {
-      int S = 8 << si; if (S > qs) break;
+    for (int si = 2; si >= 0; si--) {                      // largest blocks first: the 8x8 blocks take their candidates from the 16x16 block around them
+      int S = 8 << si; if (S > qs) continue;
       int nb = qs / S, lg = 3 + si;
       for (int b = 0; b < nb * nb; b++) {
         int x0 = qx + (b % nb) * S, y0 = qy + (b / nb) * S, best = 0x7FFFFFFF, bmode = 0;
@@ -131,11 +131,19 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
           }
           RBT_SYNC_LDS();
           rc_intra_filter_apply(g, lg, rl->nb, rl->nbf);
-          // 11 coarse candidates, then the angular modes within two of the best coarse one (oracle/hevc_enc.c analyse_ctb_intra)
+          // 16x16 / 32x32: 11 coarse candidates, then the angular modes within two of the best coarse one; 8x8 inside a complete 16x16 block: planar, DC,
+          // vertical, horizontal and the angular modes within two of the 16x16 block's mode (2, 18, 34 when that is not angular) (oracle/hevc_enc.c analyse_ctb_intra)
+          int parent = -1;
+          if (si == 0 && qs >= 16) { const int pb = ((b / nb) >> 1) * (nb >> 1) + ((b % nb) >> 1); if (RBT_UNI(l->cost[1][pb]) < RBT_PARTIAL_COST) parent = RBT_UNI(l->mode[1][pb]); }
           int coarse = 0;
           for (int k = 0; k < 15; k++) {
             int mode;
-            if (k < 11) mode = k_intra_cand[k];
+            if (parent >= 0) {
+              if (k >= 9) break;
+              if (k < 4) mode = k == 0 ? 0 : (k == 1 ? 1 : (k == 2 ? 26 : 10));
+              else if (parent >= 2) { mode = parent + (k - 6); if (mode < 2 || mode > 34 || mode == 10 || mode == 26) continue; }
+              else { if (k >= 7) break; mode = k == 4 ? 2 : (k == 5 ? 18 : 34); }
+            } else if (k < 11) mode = k_intra_cand[k];
             else { if (k == 11) coarse = bmode; if (coarse < 2) break; mode = coarse + (k == 11 ? -2 : k == 12 ? -1 : k == 13 ? 1 : 2); if (mode < 2 || mode > 34) continue; }
             RBT_LDS_AS int32_t* fin = rc_intra_filter_needed(0, lg, mode) ? rl->nbf : rl->nb;
             RcIntraCtx qc; rc_intra_setup(g, 0, lg, mode, fin, rl->ref, &qc);
