@@ -10,7 +10,8 @@
  *   - one slice per `ctb_rows_per_slice` CTB rows so entropy coding and intra reconstruction parallelise per row.
  *   - I pictures: CU quadtree 32/16/8 chosen bottom-up from open-loop (source-neighbour) intra SAD; modes of the 16x16 and 32x32 blocks from all 35
  *     by a two-step search (11 coarse candidates, then the angular modes within two of the best), modes of the 8x8 blocks from planar, DC, vertical,
- *     horizontal and the neighbourhood of their 16x16 block's mode; TU = CU, chroma DM; dead-zone quantiser 171/512.
+ *     horizontal and the neighbourhood of their 16x16 block's mode; blocks inside a block that already predicts to within 2 per sample on average
+ *     are not looked at (that block is not split; lossless streams: only when it predicts exactly); TU = CU, chroma DM; dead-zone quantiser 171/512.
  *   - P pictures: 16x16 CUs merged (zero MV) + residual, skip when all levels are zero, skips merged up the tree;
  *     dead-zone 85/512.
  *   - lossless (occupancy): cu_transquant_bypass, same quadtree/mode analysis.
@@ -837,6 +838,9 @@ static void encode_cu(enc* e, int x0, int y0, int log2, int depth, const cu_deci
 
 /* ================================================================================================ product-mode analysis */
 /* z-order availability at the granularity of the analysed block is realised by marking m->done block by block. */
+#define AN_GOOD 2              /* average absolute prediction error (in sample units of the coded bit depth) below which a block is not subdivided further */
+#define AN_SKIPPED 0x0FFFFFFE   /* cost of a block that was not evaluated because its parent is good enough: never chosen by the split decision */
+static long e_evals_skipped, e_evals;
 static void analyse_ctb_intra(enc* e, int cx, int cy) {
   hevc_meta* m = e->m; const hevc_sps* sps = &e->sps;
   int ctb = 1 << sps->log2_ctb;
@@ -860,8 +864,14 @@ static void analyse_ctb_intra(enc* e, int cx, int cy) {
        * within two of the 16x16 block's mode (modes 2, 18, 34 when that one is not angular): at most 9. Ties keep the earlier candidate. */
       int parent = -1;
       if (si == 0 && ctb >= 16 && e->an_cost[1][(by / 2) * (nb / 2) + bx / 2] < 0x0FFFFFFF) parent = e->an_mode[1][(by / 2) * (nb / 2) + bx / 2];
+      /* a block whose parent already predicts to within AN_GOOD per sample on average is not looked at: the parent will not be split (its children cost "infinity") */
+      if (si < 2 && 2 * S <= ctb) {
+        int pc = e->an_cost[si + 1][(by / 2) * (nb / 2) + bx / 2];
+        if (pc <= (e->p.lossless ? 0 : AN_GOOD) * 4 * S * S || pc == AN_SKIPPED) { e->an_cost[si][bi] = AN_SKIPPED; e_evals_skipped++; set_rect8(m->done, m->w4, x0, y0, S, S, 1); continue; }
+      }
       int coarse = 0;
       for (int k = 0; k < 15; k++) {
+        if (e->an_cost[si][bi] == 0) break;      /* cannot get better */
         int mode;
         if (parent >= 0) {
           static const int base4[4] = {0, 1, 26, 10}, alt3[3] = {2, 18, 34};
@@ -871,7 +881,7 @@ static void analyse_ctb_intra(enc* e, int cx, int cy) {
           else { if (k >= 7) break; mode = alt3[k - 4]; }
         } else if (k < 11) mode = k_intra_cand[k];
         else { if (k == 11) coarse = e->an_mode[si][bi]; if (coarse < 2) break; mode = coarse + (k == 11 ? -2 : k == 12 ? -1 : k == 13 ? 1 : 2); if (mode < 2 || mode > 34) continue; }
-        hevc_intra_pred_buf(&srcview, m, 0, x0, y0, 3 + si, mode, pred);
+        hevc_intra_pred_buf(&srcview, m, 0, x0, y0, 3 + si, mode, pred); e_evals++;
         int sad = 0;
         const uint16_t* sp = e->src->p[0] + (size_t)y0 * e->src->w + x0;
         for (int y = 0; y < S; y++) for (int x = 0; x < S; x++) sad += iabs((int)sp[(size_t)y * e->src->w + x] - (int)pred[y * S + x]);
@@ -1488,6 +1498,7 @@ int oracle_hevc_encode(const oracle_enc_params* p, const hevc_frame* const* fram
   /* frames freed here unless handed to the caller: keep a list */
   hevc_frame** owned = (hevc_frame**)calloc((size_t)n, sizeof(void*));
   for (int i = 0; i < n; i++) { encode_picture(e, frames[i], i, out, owned); }
+  if (getenv("ORACLE_AN_STATS")) fprintf(stderr, "[oracle an] evaluations %ld, blocks skipped %ld\n", e_evals, e_evals_skipped);
   if (e->hm && getenv("ORACLE_HM_STATS"))
     fprintf(stderr, "[oracle hm] CUs intra %ld (NxN %ld, in P %ld) inter %ld (2 PUs %ld, AMP %ld) skip %ld | PUs merge %ld amvp %ld, vectors non-zero %ld fractional %ld | TU splits %ld | 4x4 TBs %ld, transform skip %ld | SAO band %ld edge %ld off %ld merged CTBs %ld\n",
             e->hs.cu_intra, e->hs.nxn, e->hs.intra_in_p, e->hs.cu_inter, e->hs.part2, e->hs.amp, e->hs.cu_skip, e->hs.merge, e->hs.amvp, e->hs.nonzero_mv, e->hs.frac_mv, e->hs.tu_split, e->hs.tb4, e->hs.ts,

@@ -20,6 +20,8 @@ RBT_CONST uint16_t k_lambda16[76] = {3,    3,    4,    4,    5,    5,    6,    7
 RBT_CONST uint8_t k_intra_cand[11] = {0, 1, 26, 10, 2, 6, 14, 18, 22, 30, 34};
 #define RBT_SPLIT_BITS 24
 #define RBT_PARTIAL_COST 0x0FFFFFFF
+#define RBT_AN_GOOD 2               // average absolute prediction error per sample at which a block is not subdivided further (oracle AN_GOOD; 0 for lossless streams)
+#define RBT_AN_SKIPPED 0x0FFFFFFE    // cost of a block not evaluated because the block around it is good enough: never chosen by the split decision
 
 // Every kernel declares only the LDS it uses: the footprint per workgroup decides how many waves are resident per CU.
 struct RbtEncLds {             // inter coding (k_enc_inter)
@@ -116,6 +118,8 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
         int x0 = qx + (b % nb) * S, y0 = qy + (b / nb) * S, best = 0x7FFFFFFF, bmode = 0;
         if (x0 >= g->w || y0 >= g->h) best = 0;
         else if (x0 + S > g->w || y0 + S > g->h) best = RBT_PARTIAL_COST;
+        else if (si < 2 && 2 * S <= qs && (RBT_UNI(l->cost[si + 1][((b / nb) >> 1) * (nb >> 1) + ((b % nb) >> 1)]) <= (f->lossless ? 0 : RBT_AN_GOOD) * 4 * S * S ||
+                                            RBT_UNI(l->cost[si + 1][((b / nb) >> 1) * (nb >> 1) + ((b % nb) >> 1)]) == RBT_AN_SKIPPED)) best = RBT_AN_SKIPPED;   // the block around it is good enough: it will not be split
         else {
           // reference samples once per block: availability masks, substitution (8.4.4.2.2) while gathering, and the smoothed copy
           const int tot = 4 * S + 1, bx0 = x0 - qx, by0 = y0 - qy;
@@ -138,6 +142,7 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
           int coarse = 0;
           for (int k = 0; k < 15; k++) {
             int mode;
+            if (best == 0) break;                               // cannot get better
             if (parent >= 0) {
               if (k >= 9) break;
               if (k < 4) mode = k == 0 ? 0 : (k == 1 ? 1 : (k == 2 ? 26 : 10));
