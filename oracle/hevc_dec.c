@@ -25,6 +25,10 @@ struct oracle_hevc_decoder {
   int md5_checked, md5_failed;
   int last_conf_win[4];
   int slice_idx_in_pic;
+  /* slice-level state that dependent slice segments (7.3.6.1) and wavefront rows (9.3.1) inherit */
+  hevc_slice_hdr last_sh; int last_slice_idx, have_last_sh;   /* header and slice index of the slice's independent segment */
+  uint8_t ds_ctx[CTX_COUNT]; int ds_qp_y;                     /* context variables / QpY at the end of the previous slice segment (TableStateIdxDs) */
+  uint8_t wpp_ctx[CTX_COUNT];                                 /* context variables after the second CTB of the CTB row above (TableStateIdxWpp) */
   uint8_t pending_md5[3][16]; int have_md5;
   /* scan tables: [scanIdx 0 diag,1 hor,2 ver][log2 1..3][pos] -> x | y<<4 */
   uint8_t scan[3][4][64];
@@ -154,7 +158,7 @@ static int parse_pps(oracle_hevc_decoder* d, bitreader* b) {
   p.cb_qp_offset = br_se(b); p.cr_qp_offset = br_se(b); p.slice_chroma_qp_offsets_present = br_bit(b);
   p.weighted_pred = br_bit(b); p.weighted_bipred = br_bit(b);
   p.transquant_bypass_enabled = br_bit(b); p.tiles_enabled = br_bit(b); p.entropy_coding_sync = br_bit(b);
-  if (p.tiles_enabled || p.entropy_coding_sync) { DEC_ERR("tiles / WPP unsupported"); return -1; }
+  if (p.tiles_enabled) { DEC_ERR("tiles unsupported"); return -1; }
   if (p.weighted_pred) { DEC_ERR("weighted prediction unsupported"); return -1; }
   p.loop_filter_across_slices = br_bit(b);
   p.deblocking_control_present = br_bit(b);
@@ -184,7 +188,11 @@ static int parse_slice_header(oracle_hevc_decoder* d, bitreader* b, int nal_type
     if (pps->dependent_slice_segments_enabled) h->dependent = br_bit(b);
     h->segment_addr = br_u(b, ceil_log2(sps->pic_w_ctb * sps->pic_h_ctb));
   }
-  if (h->dependent) { DEC_ERR("dependent slice segments unsupported"); return -1; }
+  if (h->dependent) {   /* everything up to the entry points is that of the slice's independent segment */
+    if (!d->have_last_sh) { DEC_ERR("dependent slice segment without a slice"); return -1; }
+    int addr = h->segment_addr; *h = d->last_sh; h->first_slice_in_pic = 0; h->dependent = 1; h->segment_addr = addr; h->nal_type = nal_type;
+    goto entry_points;
+  }
   for (int i = 0; i < pps->num_extra_slice_header_bits; i++) br_bit(b);
   h->slice_type = br_ue(b);
   if (h->slice_type == SLICE_B) { DEC_ERR("B slices unsupported"); return -1; }
@@ -220,11 +228,18 @@ static int parse_slice_header(oracle_hevc_decoder* d, bitreader* b, int nal_type
   if (ovr) { h->deblocking_disabled = br_bit(b); if (!h->deblocking_disabled) { h->beta_offset_div2 = br_se(b); h->tc_offset_div2 = br_se(b); } }
   h->loop_filter_across_slices = pps->loop_filter_across_slices;
   if (pps->loop_filter_across_slices && (h->sao_luma || h->sao_chroma || !h->deblocking_disabled)) h->loop_filter_across_slices = br_bit(b);
+  h->qp = pps->init_qp + h->qp_delta;
+entry_points:
+  h->num_entry_points = 0;
+  if (pps->entropy_coding_sync) {   /* the offsets only matter to a decoder that starts the substreams in parallel: read and dropped */
+    h->num_entry_points = (int)br_ue(b);
+    if (h->num_entry_points > sps->pic_h_ctb) { DEC_ERR("slice header: %d entry points", h->num_entry_points); return -1; }
+    if (h->num_entry_points > 0) { int len = (int)br_ue(b) + 1; if (len > 32) return -1; for (int i = 0; i < h->num_entry_points; i++) br_u(b, len); }
+  }
   if (pps->slice_header_extension_present) { int n = br_ue(b); for (int i = 0; i < n; i++) br_u(b, 8); }
   if (!br_bit(b)) { DEC_ERR("slice header: alignment bit missing"); return -1; }
   while (!br_aligned(b)) br_bit(b);
   h->data_bit_offset = b->pos;
-  h->qp = pps->init_qp + h->qp_delta;
   return 0;
 }
 
@@ -744,7 +759,7 @@ static int start_picture(oracle_hevc_decoder* d, const hevc_sps* sps, const hevc
   hevc_meta_reset(d->meta);
   d->meta->constrained_intra_pred = pps->constrained_intra_pred; d->meta->cb_qp_offset = pps->cb_qp_offset; d->meta->cr_qp_offset = pps->cr_qp_offset;
   d->meta->strong_intra_smoothing = sps->strong_intra_smoothing;
-  d->pic_open = 1; d->slice_idx_in_pic = 0;
+  d->pic_open = 1; d->slice_idx_in_pic = 0; d->have_last_sh = 0;
   return 0;
 }
 
@@ -758,9 +773,17 @@ static int decode_slice(oracle_hevc_decoder* d, const uint8_t* rbsp, size_t n, i
   else { s->sh.poc = d->cur_poc; }
   s->f = d->cur; s->m = d->meta;
   hevc_meta* m = s->m;
-  if (m->n_slices >= 1024) { free(s); return -1; }
-  s->slice_idx = m->n_slices++;
-  hevc_slice_meta* sm = &m->slices[s->slice_idx]; memset(sm, 0, sizeof(*sm));
+  if (s->sh.dependent && s->sh.segment_addr == 0) { DEC_ERR("dependent slice segment at CTB 0"); free(s); return -1; }
+  hevc_slice_meta dummy_sm;
+  hevc_slice_meta* sm;
+  if (s->sh.dependent) { s->slice_idx = d->last_slice_idx; sm = &dummy_sm; }   /* same slice: availability, loop filter and reference lists of its independent segment */
+  else {
+    if (m->n_slices >= 1024) { free(s); return -1; }
+    s->slice_idx = m->n_slices++;
+    sm = &m->slices[s->slice_idx];
+    d->last_sh = s->sh; d->last_slice_idx = s->slice_idx; d->have_last_sh = 1;
+  }
+  memset(sm, 0, sizeof(*sm));
   sm->deblocking_disabled = (uint8_t)s->sh.deblocking_disabled; sm->loop_filter_across = (uint8_t)s->sh.loop_filter_across_slices;
   sm->sao_luma = (uint8_t)s->sh.sao_luma; sm->sao_chroma = (uint8_t)s->sh.sao_chroma;
   sm->beta_offset_div2 = (int8_t)s->sh.beta_offset_div2; sm->tc_offset_div2 = (int8_t)s->sh.tc_offset_div2; sm->slice_type = (int8_t)s->sh.slice_type;
@@ -776,9 +799,12 @@ static int decode_slice(oracle_hevc_decoder* d, const uint8_t* rbsp, size_t n, i
     }
   }
   int init_type = s->sh.slice_type == SLICE_I ? 0 : (s->sh.cabac_init_flag ? 2 : 1);
-  cabac_init_ctx(s->c.st, init_type, s->sh.qp);
+  /* 9.3.1: a dependent slice segment goes on with the context variables (and QpY predictor, 8.6.1) the previous segment ended with; the wavefront rule
+   * at the start of a CTB row (below) overrides this */
+  if (s->sh.dependent) { memcpy(s->c.st, d->ds_ctx, CTX_COUNT); s->qp_y = d->ds_qp_y; }
+  else { cabac_init_ctx(s->c.st, init_type, s->sh.qp); s->qp_y = s->sh.qp; }
   cabac_start(&s->c, rbsp, n, s->sh.data_bit_offset);
-  s->qp_y = s->sh.qp; s->qp_pred = s->sh.qp;
+  s->qp_pred = s->sh.qp;
   s->mp.m = m; s->mp.max_merge_cand = s->sh.max_merge_cand; s->mp.num_ref_idx = s->sh.num_ref_idx[0]; s->mp.ref_poc = s->ref_poc;
   s->mp.cur_poc = d->cur_poc; s->mp.col = (s->sh.temporal_mvp && s->sh.slice_type == SLICE_P) ? s->refcol[s->sh.collocated_ref_idx] : NULL;
   s->mp.log2_ctb = sps->log2_ctb; s->mp.pic_w = sps->width; s->mp.pic_h = sps->height;
@@ -787,13 +813,28 @@ static int decode_slice(oracle_hevc_decoder* d, const uint8_t* rbsp, size_t n, i
     if (ctb_addr >= n_ctb) { DEC_ERR("slice data runs past the picture"); s->error = 1; break; }
     int rx = ctb_addr % sps->pic_w_ctb, ry = ctb_addr / sps->pic_w_ctb;
     m->ctb_slice[ctb_addr] = (uint16_t)s->slice_idx;
+    if (pps->entropy_coding_sync && rx == 0) {
+      /* first CTB of a row (9.3.1): the context variables of the CTB above-right after it was parsed, when that CTB is available (6.4.1: inside the
+       * picture and in the same slice), the initial ones otherwise; QpY prediction restarts from SliceQpY (8.6.1) */
+      cabac_init_ctx(s->c.st, init_type, s->sh.qp);
+      if (ry > 0 && sps->pic_w_ctb > 1 && m->ctb_slice[ctb_addr - sps->pic_w_ctb + 1] == s->slice_idx) memcpy(s->c.st, d->wpp_ctx, CTX_COUNT);
+      s->qp_y = s->sh.qp;
+    }
     parse_sao(s, rx, ry);
     coding_quadtree(s, rx << sps->log2_ctb, ry << sps->log2_ctb, sps->log2_ctb, 0);
     if (s->error) break;
+    if (pps->entropy_coding_sync && rx == 1) memcpy(d->wpp_ctx, s->c.st, CTX_COUNT);   /* storage process after the second CTB of a row */
     end = cabac_terminate(&s->c);
     ctb_addr++;
+    if (!end && pps->entropy_coding_sync && ctb_addr % sps->pic_w_ctb == 0) {
+      /* end_of_subset_one_bit, byte_alignment(): the bit that ended the arithmetic codeword is the alignment bit (9.3.2.5); the next CTB row is
+       * its own arithmetic codeword starting at the next byte */
+      if (!cabac_terminate(&s->c)) { DEC_ERR("end_of_subset_one_bit is 0"); s->error = 1; break; }
+      cabac_start(&s->c, rbsp, n, (s->c.bitpos + 7) & ~(size_t)7);
+    }
     if (s->c.bitpos > n * 8 + 64) { DEC_ERR("CABAC read past the end of slice data"); s->error = 1; break; }
   }
+  memcpy(d->ds_ctx, s->c.st, CTX_COUNT); d->ds_qp_y = s->qp_y;   /* storage process at the end of a slice segment (dependent_slice_segments_enabled_flag) */
   int err = s->error; free(s);
   if (err) { DEC_ERR("slice decode failed (ctb %d)", ctb_addr); return -1; }
   return 0;
@@ -833,7 +874,7 @@ int oracle_slice_headers(const uint8_t* p, size_t n, int* out, int cap) {
     else if (type < 32) {
       hevc_slice_hdr h; hevc_sps* sps; hevc_pps* pps; memset(&h, 0, sizeof(h));
       rc = parse_slice_header(d, &b, type, &h, &sps, &pps);
-      if (!rc) {   /* PicOrderCntVal (8.3.1), as start_picture derives it */
+      if (!rc && !h.dependent) {   /* PicOrderCntVal (8.3.1), as start_picture derives it; a dependent segment repeats its slice's */
         if (type == NAL_IDR_W_RADL || type == NAL_IDR_N_LP) h.poc = 0;
         else { int max_lsb = 1 << sps->log2_max_poc_lsb, prev_lsb = d->prev_tid0_poc & (max_lsb - 1), prev_msb = d->prev_tid0_poc - prev_lsb, msb = prev_msb;
           if (h.poc_lsb < prev_lsb && prev_lsb - h.poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb; else if (h.poc_lsb > prev_lsb && h.poc_lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
@@ -843,7 +884,7 @@ int oracle_slice_headers(const uint8_t* p, size_t n, int* out, int cap) {
         o[0] = type; o[1] = h.segment_addr; o[2] = h.slice_type; o[3] = h.poc; o[4] = h.temporal_mvp; o[5] = h.sao_luma; o[6] = h.sao_chroma; o[7] = intra ? 0 : h.num_ref_idx[0];
         o[8] = h.cabac_init_flag; o[9] = intra ? 0 : h.collocated_ref_idx; o[10] = intra ? 0 : h.max_merge_cand; o[11] = h.qp; o[12] = h.cb_qp_offset; o[13] = h.cr_qp_offset;
         o[14] = h.deblocking_disabled; o[15] = h.beta_offset_div2; o[16] = h.tc_offset_div2; o[17] = h.loop_filter_across_slices; }
-      if (!rc) { k++; d->prev_tid0_poc = h.poc; }
+      if (!rc) { k++; d->prev_tid0_poc = h.poc; if (!h.dependent) { d->last_sh = h; d->have_last_sh = 1; } }
     }
     free(rb);
     if (rc) { free(d); return -1; }

@@ -131,6 +131,8 @@ typedef struct {
   uint8_t hm_nxn[64], hm_nxn_mode[64][4], hm_chroma[3][64];               /* intra: NxN at 8x8, chroma mode index per block */
   int64_t last_ssd; int last_bits;                                         /* of the last recon_tb call */
   hevc_sao* hm_sao;                                                        /* decided SAO parameters per CTB (pass 2) */
+  /* wavefront rows / dependent slice segments (9.3.1): context variables after the second CTB of the row above, and at the end of the previous segment */
+  uint8_t wpp_ctx[CTX_COUNT], ds_ctx[CTX_COUNT]; int ds_qp_y;
   /* history */
   hevc_frame* dpb[2]; hevc_colinfo dpbcol[2]; int dpb_poc[2]; int n_dpb;
 } enc;
@@ -202,14 +204,14 @@ static void write_param_sets(enc* e, bytebuf* out) {
   emit_nal(out, NAL_SPS, w.bb.d, w.bb.n, 1);
   /* PPS */
   w.bb.n = 0;
-  bw_ue(&w, 0); bw_ue(&w, 0); bw_bit(&w, 0); bw_bit(&w, 0); bw_u(&w, 0, 3);
+  bw_ue(&w, 0); bw_ue(&w, 0); bw_bit(&w, p->dependent_slice_segments_enabled); bw_bit(&w, 0); bw_u(&w, 0, 3);
   bw_bit(&w, p->sign_data_hiding); bw_bit(&w, p->cabac_init_present);
   bw_ue(&w, p->num_ref_idx_default[0] - 1); bw_ue(&w, 0);
   bw_se(&w, p->init_qp - 26); bw_bit(&w, p->constrained_intra_pred); bw_bit(&w, p->transform_skip_enabled);
   bw_bit(&w, p->cu_qp_delta_enabled); if (p->cu_qp_delta_enabled) bw_ue(&w, p->diff_cu_qp_delta_depth);
   bw_se(&w, p->cb_qp_offset); bw_se(&w, p->cr_qp_offset); bw_bit(&w, p->slice_chroma_qp_offsets_present);
   bw_bit(&w, 0); bw_bit(&w, 0);
-  bw_bit(&w, p->transquant_bypass_enabled); bw_bit(&w, 0); bw_bit(&w, 0);
+  bw_bit(&w, p->transquant_bypass_enabled); bw_bit(&w, 0); bw_bit(&w, p->entropy_coding_sync);
   bw_bit(&w, p->loop_filter_across_slices);
   bw_bit(&w, p->deblocking_control_present);
   if (p->deblocking_control_present) {
@@ -222,12 +224,31 @@ static void write_param_sets(enc* e, bytebuf* out) {
 }
 static inline int64_t imin64(int64_t a, int64_t b) { return a < b ? a : b; }
 static int ceil_log2(unsigned v) { int n = 0; while ((1u << n) < v) n++; return n; }
-static void write_slice_header(enc* e, bitwriter* w, int first, int ctb_addr) {
+/* bytes of p[0..n) once emulation prevention (7.4.2) is applied: what entry_point_offset_minus1 counts (7.4.7.1) */
+static size_t escaped_size(const uint8_t* p, size_t n) {
+  size_t k = n; int z = 0;
+  for (size_t i = 0; i < n; i++) { if (z >= 2 && p[i] <= 3) { k++; z = 0; } z = p[i] == 0 ? z + 1 : 0; }
+  return k;
+}
+static void write_entry_points(enc* e, bitwriter* w, const size_t* sub_size, int n_sub) {
+  if (e->pps.entropy_coding_sync) {
+    bw_ue(w, (uint32_t)(n_sub - 1));
+    if (n_sub > 1) {
+      size_t mx = 1; for (int i = 0; i + 1 < n_sub; i++) if (sub_size[i] > mx) mx = sub_size[i];
+      int len = ceil_log2((unsigned)mx); if (len < 1) len = 1;       /* values are size - 1 < 2^len */
+      bw_ue(w, (uint32_t)(len - 1));
+      for (int i = 0; i + 1 < n_sub; i++) bw_u(w, (uint32_t)(sub_size[i] - 1), len);
+    }
+  }
+  bw_bit(w, 1); bw_align_zero(w);
+}
+static void write_slice_header(enc* e, bitwriter* w, int first, int ctb_addr, int dependent, const size_t* sub_size, int n_sub) {
   hevc_sps* s = &e->sps; hevc_pps* p = &e->pps; hevc_slice_hdr* h = &e->sh;
   bw_bit(w, first);
   if (e->is_idr) bw_bit(w, 0);
   bw_ue(w, 0);
-  if (!first) bw_u(w, ctb_addr, ceil_log2(s->pic_w_ctb * s->pic_h_ctb));
+  if (!first) { if (p->dependent_slice_segments_enabled) bw_bit(w, dependent); bw_u(w, ctb_addr, ceil_log2(s->pic_w_ctb * s->pic_h_ctb)); }
+  if (dependent) { write_entry_points(e, w, sub_size, n_sub); return; }
   bw_ue(w, h->slice_type);
   if (!e->is_idr) {
     bw_u(w, e->poc & ((1 << s->log2_max_poc_lsb) - 1), s->log2_max_poc_lsb);
@@ -251,7 +272,7 @@ static void write_slice_header(enc* e, bitwriter* w, int first, int ctb_addr) {
     if (ovr) { bw_bit(w, h->deblocking_disabled); if (!h->deblocking_disabled) { bw_se(w, h->beta_offset_div2); bw_se(w, h->tc_offset_div2); } }
   }
   if (p->loop_filter_across_slices && (h->sao_luma || h->sao_chroma || !h->deblocking_disabled)) bw_bit(w, h->loop_filter_across_slices);
-  bw_bit(w, 1); bw_align_zero(w);
+  write_entry_points(e, w, sub_size, n_sub);
 }
 
 /* ================================================================================================ residual writer (7.3.8.11) */
@@ -1332,6 +1353,7 @@ static void setup_stream(enc* e) {
   e->max_merge_cand = 1;
   if (q->lossless) { p->transquant_bypass_enabled = 1; p->deblocking_control_present = 1; p->pps_deblocking_disabled = 1; p->loop_filter_across_slices = 0; }
   if (!e->stress && !e->hm && !q->lossless && e1_sao_on()) s->sao_enabled = 1;
+  if (!e->stress && !e->hm && q->ctb_rows_per_slice < 0) { p->entropy_coding_sync = 1; p->dependent_slice_segments_enabled = 1; }   /* wavefront rows, one dependent slice segment each */
   if (e->hm) {   /* cfg/hm/ctc-hm-geometry-ai.cfg:10-16,47,68,69 + HM defaults (SignHideFlag, TMVPMode, MaxNumMergeCand) */
     s->log2_ctb = q->log2_ctb ? q->log2_ctb : 6; s->log2_diff_max_min_cb = s->log2_ctb - 3;
     s->log2_max_tb = imin(5, s->log2_ctb); s->log2_diff_max_min_tb = s->log2_max_tb - 2;
@@ -1363,6 +1385,7 @@ static void setup_stream(enc* e) {
     p->init_qp = 20 + rndn(r, 15);
     e->max_merge_cand = 1 + rndn(r, 5);
     p->num_ref_idx_default[0] = 1 + (e->two_refs && rndp(r, 50));
+    p->entropy_coding_sync = rndp(r, 40); p->dependent_slice_segments_enabled = rndp(r, 40);
   }
   s->pic_w_ctb = (s->width + (1 << s->log2_ctb) - 1) >> s->log2_ctb; s->pic_h_ctb = (s->height + (1 << s->log2_ctb) - 1) >> s->log2_ctb;
 }
@@ -1379,44 +1402,58 @@ static void encode_slices(enc* e, int is_i, int st_rps_idx, bytebuf* out) {
     pic_tmvp = s->temporal_mvp_enabled ? rndp(r, 70) : 0;
     pic_col = (pic_tmvp && pic_num_ref > 1) ? rndn(r, pic_num_ref) : 0;
   }
+  int seg_no = 0;
   while (addr < n_ctb) {
-    /* slice extent */
-    int end_addr;
-    if (e->stress) end_addr = rndp(r, 50) ? n_ctb : imin(n_ctb, addr + 1 + rndn(r, n_ctb));
+    /* extent of the slice segment; dependent segments (7.3.6.1) continue the slice of the segment before them */
+    int end_addr, dependent = 0;
+    if (e->stress) { end_addr = rndp(r, 50) ? n_ctb : imin(n_ctb, addr + 1 + rndn(r, n_ctb)); dependent = addr > 0 && p->dependent_slice_segments_enabled && rndp(r, 60); }
+    else if (e->p.ctb_rows_per_slice < 0) { end_addr = imin(n_ctb, (addr / s->pic_w_ctb + 1) * s->pic_w_ctb); dependent = addr > 0; }   /* wavefront: one dependent segment per CTB row */
     else if (e->p.ctb_rows_per_slice > 0) end_addr = imin(n_ctb, (addr / s->pic_w_ctb + e->p.ctb_rows_per_slice) * s->pic_w_ctb);
     else end_addr = n_ctb;
-    hevc_slice_hdr* h = &e->sh; memset(h, 0, sizeof(*h));
-    h->slice_type = e->slice_type; h->st_rps_idx = st_rps_idx;
-    h->num_ref_idx[0] = p->num_ref_idx_default[0]; h->max_merge_cand = e->max_merge_cand;
-    h->deblocking_disabled = p->pps_deblocking_disabled; h->beta_offset_div2 = p->beta_offset_div2; h->tc_offset_div2 = p->tc_offset_div2;
-    h->loop_filter_across_slices = p->loop_filter_across_slices;
-    if (e->stress) {
-      h->qp = clip3(4, 48, p->init_qp + rndn(r, 21) - 10);
-      if (!is_i) { h->num_ref_idx[0] = pic_num_ref; h->temporal_mvp = pic_tmvp; h->collocated_ref_idx = pic_col; }
-      if (s->sao_enabled) { h->sao_luma = rndp(r, 70); h->sao_chroma = rndp(r, 70); }
-      if (p->cabac_init_present && !is_i) h->cabac_init_flag = rndp(r, 50);
-      if (p->slice_chroma_qp_offsets_present) { h->cb_qp_offset = rndn(r, 5) - 2; h->cr_qp_offset = rndn(r, 5) - 2; }
-      if (p->deblocking_override_enabled && rndp(r, 50)) { h->deblocking_disabled = rndp(r, 20); if (!h->deblocking_disabled) { h->beta_offset_div2 = rndn(r, 9) - 4; h->tc_offset_div2 = rndn(r, 9) - 4; } else { h->beta_offset_div2 = p->beta_offset_div2; h->tc_offset_div2 = p->tc_offset_div2; } }
-      if (p->loop_filter_across_slices && (h->sao_luma || h->sao_chroma || !h->deblocking_disabled)) h->loop_filter_across_slices = rndp(r, 70);
-    } else h->qp = clip3(0, 51, is_i ? e->p.qp + e->p.i_qp_offset : e->p.qp + (e->hm ? e->p.p_qp_offset : 0));
-    if (e->hm && !is_i) { h->temporal_mvp = s->temporal_mvp_enabled; h->collocated_ref_idx = 0; }
-    if (!e->stress && e->hm_pass == 2) { h->sao_luma = 1; h->sao_chroma = 1; }
-    e->slice_qp = h->qp; e->slice_idx = m->n_slices++;
-    hevc_slice_meta* sm = &m->slices[e->slice_idx]; memset(sm, 0, sizeof(*sm));
-    sm->deblocking_disabled = (uint8_t)h->deblocking_disabled; sm->loop_filter_across = (uint8_t)h->loop_filter_across_slices;
-    sm->sao_luma = (uint8_t)h->sao_luma; sm->sao_chroma = (uint8_t)h->sao_chroma; sm->beta_offset_div2 = (int8_t)h->beta_offset_div2; sm->tc_offset_div2 = (int8_t)h->tc_offset_div2;
-    sm->slice_type = (int8_t)h->slice_type;
-    for (int i = 0; i < h->num_ref_idx[0]; i++) sm->ref_poc[i] = e->ref_poc[i];
-    e->mp.m = m; e->mp.max_merge_cand = h->max_merge_cand; e->mp.num_ref_idx = h->num_ref_idx[0]; e->mp.ref_poc = e->ref_poc; e->mp.cur_poc = e->poc;
-    e->mp.col = (h->temporal_mvp && !is_i) ? e->refcol[h->collocated_ref_idx] : NULL; e->mp.log2_ctb = s->log2_ctb; e->mp.pic_w = s->width; e->mp.pic_h = s->height;
+    hevc_slice_hdr* h = &e->sh;
+    int init_type = 0;
+    if (!dependent) {
+      memset(h, 0, sizeof(*h));
+      h->slice_type = e->slice_type; h->st_rps_idx = st_rps_idx;
+      h->num_ref_idx[0] = p->num_ref_idx_default[0]; h->max_merge_cand = e->max_merge_cand;
+      h->deblocking_disabled = p->pps_deblocking_disabled; h->beta_offset_div2 = p->beta_offset_div2; h->tc_offset_div2 = p->tc_offset_div2;
+      h->loop_filter_across_slices = p->loop_filter_across_slices;
+      if (e->stress) {
+        h->qp = clip3(4, 48, p->init_qp + rndn(r, 21) - 10);
+        if (!is_i) { h->num_ref_idx[0] = pic_num_ref; h->temporal_mvp = pic_tmvp; h->collocated_ref_idx = pic_col; }
+        if (s->sao_enabled) { h->sao_luma = rndp(r, 70); h->sao_chroma = rndp(r, 70); }
+        if (p->cabac_init_present && !is_i) h->cabac_init_flag = rndp(r, 50);
+        if (p->slice_chroma_qp_offsets_present) { h->cb_qp_offset = rndn(r, 5) - 2; h->cr_qp_offset = rndn(r, 5) - 2; }
+        if (p->deblocking_override_enabled && rndp(r, 50)) { h->deblocking_disabled = rndp(r, 20); if (!h->deblocking_disabled) { h->beta_offset_div2 = rndn(r, 9) - 4; h->tc_offset_div2 = rndn(r, 9) - 4; } else { h->beta_offset_div2 = p->beta_offset_div2; h->tc_offset_div2 = p->tc_offset_div2; } }
+        if (p->loop_filter_across_slices && (h->sao_luma || h->sao_chroma || !h->deblocking_disabled)) h->loop_filter_across_slices = rndp(r, 70);
+      } else h->qp = clip3(0, 51, is_i ? e->p.qp + e->p.i_qp_offset : e->p.qp + (e->hm ? e->p.p_qp_offset : 0));
+      if (e->hm && !is_i) { h->temporal_mvp = s->temporal_mvp_enabled; h->collocated_ref_idx = 0; }
+      if (!e->stress && e->hm_pass == 2) { h->sao_luma = 1; h->sao_chroma = 1; }
+      e->slice_qp = h->qp; e->slice_idx = m->n_slices++;
+      hevc_slice_meta* sm = &m->slices[e->slice_idx]; memset(sm, 0, sizeof(*sm));
+      sm->deblocking_disabled = (uint8_t)h->deblocking_disabled; sm->loop_filter_across = (uint8_t)h->loop_filter_across_slices;
+      sm->sao_luma = (uint8_t)h->sao_luma; sm->sao_chroma = (uint8_t)h->sao_chroma; sm->beta_offset_div2 = (int8_t)h->beta_offset_div2; sm->tc_offset_div2 = (int8_t)h->tc_offset_div2;
+      sm->slice_type = (int8_t)h->slice_type;
+      for (int i = 0; i < h->num_ref_idx[0]; i++) sm->ref_poc[i] = e->ref_poc[i];
+      e->mp.m = m; e->mp.max_merge_cand = h->max_merge_cand; e->mp.num_ref_idx = h->num_ref_idx[0]; e->mp.ref_poc = e->ref_poc; e->mp.cur_poc = e->poc;
+      e->mp.col = (h->temporal_mvp && !is_i) ? e->refcol[h->collocated_ref_idx] : NULL; e->mp.log2_ctb = s->log2_ctb; e->mp.pic_w = s->width; e->mp.pic_h = s->height;
+    }
+    init_type = is_i ? 0 : (h->cabac_init_flag ? 2 : 1);
+    /* slice segment data first (its substream sizes go into the header), each CTB row of a wavefront stream as its own arithmetic codeword */
     e->c.w.bb.n = 0; e->c.w.acc = 0; e->c.w.nacc = 0;
-    write_slice_header(e, &e->c.w, addr == 0, addr);
-    ce_init_ctx(&e->c, is_i ? 0 : (h->cabac_init_flag ? 2 : 1), h->qp);
+    if (dependent) { memcpy(e->c.st, e->ds_ctx, CTX_COUNT); e->qp_y = e->ds_qp_y; }
+    else { ce_init_ctx(&e->c, init_type, h->qp); e->qp_y = h->qp; }
     ce_start(&e->c);
-    e->qp_y = h->qp; e->qp_pred = h->qp; e->is_cu_qp_delta_coded = 0; e->cu_qp_delta_val = 0;
+    e->qp_pred = h->qp; e->is_cu_qp_delta_coded = 0; e->cu_qp_delta_val = 0;
+    size_t sub_size[512]; int n_sub = 0; size_t sub_start = 0;
     for (int a = addr; a < end_addr; a++) {
       int rx = a % s->pic_w_ctb, ry = a / s->pic_w_ctb;
       m->ctb_slice[a] = (uint16_t)e->slice_idx;
+      if (p->entropy_coding_sync && rx == 0) {   /* 9.3.1: start of a CTB row */
+        ce_init_ctx(&e->c, init_type, h->qp);
+        if (ry > 0 && s->pic_w_ctb > 1 && m->ctb_slice[a - s->pic_w_ctb + 1] == e->slice_idx) memcpy(e->c.st, e->wpp_ctx, CTX_COUNT);
+        e->qp_y = h->qp;
+      }
       if (e->stress) write_sao(e, rx, ry);
       else if (e->hm) {
         hm_write_sao(e, rx, ry);
@@ -1424,12 +1461,26 @@ static void encode_slices(enc* e, int is_i, int st_rps_idx, bytebuf* out) {
         if (!is_i) hm_inter_decide(e, rx * ctb, ry * ctb, s->log2_ctb, rx * ctb, ry * ctb);
       } else { if (s->sao_enabled) hm_write_sao(e, rx, ry); if (is_i) analyse_ctb_intra(e, rx * ctb, ry * ctb); else analyse_ctb_inter(e, rx * ctb, ry * ctb); }
       encode_quadtree(e, rx * ctb, ry * ctb, s->log2_ctb, 0, rx * ctb, ry * ctb);
+      if (p->entropy_coding_sync && rx == 1) memcpy(e->wpp_ctx, e->c.st, CTX_COUNT);
       ce_terminate(&e->c, a == end_addr - 1);
+      if (a != end_addr - 1 && p->entropy_coding_sync && (a + 1) % s->pic_w_ctb == 0) {
+        ce_terminate(&e->c, 1); bw_align_zero(&e->c.w);      /* end_of_subset_one_bit, byte_alignment() */
+        sub_size[n_sub++] = escaped_size(e->c.w.bb.d + sub_start, e->c.w.bb.n - sub_start); sub_start = e->c.w.bb.n;
+        ce_start(&e->c);
+      }
     }
     bw_align_zero(&e->c.w);
-    emit_nal(out, is_i ? NAL_IDR_W_RADL : NAL_TRAIL_R, e->c.w.bb.d, e->c.w.bb.n, addr == 0);
-    addr = end_addr;
+    sub_size[n_sub++] = escaped_size(e->c.w.bb.d + sub_start, e->c.w.bb.n - sub_start);
+    memcpy(e->ds_ctx, e->c.st, CTX_COUNT); e->ds_qp_y = e->qp_y;
+    bitwriter hw; memset(&hw, 0, sizeof(hw));
+    write_slice_header(e, &hw, addr == 0, addr, dependent, sub_size, n_sub);
+    size_t tot = hw.bb.n + e->c.w.bb.n; uint8_t* nal = (uint8_t*)malloc(tot ? tot : 1);
+    memcpy(nal, hw.bb.d, hw.bb.n); memcpy(nal + hw.bb.n, e->c.w.bb.d, e->c.w.bb.n);
+    emit_nal(out, is_i ? NAL_IDR_W_RADL : NAL_TRAIL_R, nal, tot, addr == 0);
+    free(nal); free(hw.bb.d);
+    addr = end_addr; seg_no++;
   }
+  (void)seg_no;
 }
 
 static void encode_picture(enc* e, const hevc_frame* src, int idx, bytebuf* out, hevc_frame** recon_out) {

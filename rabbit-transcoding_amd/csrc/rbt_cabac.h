@@ -90,6 +90,23 @@ RBT_DEV void rbt_ctx_set(RbtCtxStore* s, int ctx, int v) {
   s->st2 = (r == 2 && me == lane) ? v : s->st2; s->st3 = (r == 3 && me == lane) ? v : s->st3;
 #endif
 }
+// copies of all context variables in LDS (wavefront storage / synchronisation processes, 9.3.2.2 / 9.3.2.4): 4 x 64 bytes, register r lane l at r * 64 + l
+RBT_DEV void rbt_ctx_store(const RbtCtxStore* s, RBT_LDS_AS uint8_t* dst) {
+#ifdef RBT_HOSTEMU
+  for (int i = 0; i < RBT_CTX_COUNT; i++) dst[i] = s->st[i];
+#else
+  const int l = (int)threadIdx.x & 63;
+  dst[l] = (uint8_t)s->st0; dst[64 + l] = (uint8_t)s->st1; dst[128 + l] = (uint8_t)s->st2; dst[192 + l] = (uint8_t)s->st3;
+#endif
+}
+RBT_DEV void rbt_ctx_load(RbtCtxStore* s, const RBT_LDS_AS uint8_t* src) {
+#ifdef RBT_HOSTEMU
+  for (int i = 0; i < RBT_CTX_COUNT; i++) s->st[i] = src[i];
+#else
+  const int l = (int)threadIdx.x & 63;
+  s->st0 = src[l]; s->st1 = src[64 + l]; s->st2 = src[128 + l]; s->st3 = src[192 + l];
+#endif
+}
 RBT_DEV int rbt_lps(const RbtCtxStore* s, int state, int q) {
 #ifdef RBT_HOSTEMU
   (void)s; return k_range_lps[state][q];
@@ -160,6 +177,15 @@ RBT_DEV void rbt_cd_start(RbtCabacDec* c, const uint8_t* p, uint32_t size) {
   c->range = 510;
   c->value = rbt_cd_bits(c, 9) << RBT_CD_SCALE; c->avail = 0;
   rbt_cd_refill(c);
+}
+// After a terminating bin equal to 1 that does not end the slice segment (end_of_subset_one_bit): the engine has consumed exactly the bits up to and
+// including the one that ended the codeword (9 at start, one per renormalisation shift = everything pulled from the stream minus `avail`); the next
+// codeword starts at the next byte boundary.
+RBT_DEV void rbt_cd_restart_aligned(RbtCabacDec* c) {
+  const uint32_t used = (uint32_t)RBT_UNI(c->widx) * 32u - (uint32_t)RBT_UNI(c->nbuf) - (uint32_t)RBT_UNI(c->avail);   // bits from the aligned base
+  const uint32_t byte = (used + 7u) >> 3, total = (uint32_t)RBT_UNI(c->bits_total) >> 3;
+  const uint8_t* base = (const uint8_t*)rbt_uni_ptr((const uint32_t*)(uintptr_t)c->w);
+  rbt_cd_start(c, base + byte, total > byte ? total - byte : 0u);
 }
 // Decodes one bin given the context variable value `st` (pStateIdx << 1 | valMps); stores the updated variable to *nst.
 template <bool AU> RBT_DEV int rbt_cd_core(RbtCabacDec* c, int st, int* nst) {

@@ -34,6 +34,7 @@ struct alignas(16) RbtParseLds {
   unsigned long long prof[32]; unsigned int profn[32];
 #endif
   int32_t ref_poc[RBT_MAX_REFS], ref_frame[RBT_MAX_REFS];   // RefPicList0 of the slice (indexed at run time: kept out of the register-resident parser state)
+  uint8_t wpp_ctx[4 * 64];                                   // context variables after the second CTB of the CTB row above (9.3.2.2 storage process, TableStateIdxWpp)
   int32_t cap4, pad_[3];                                     // capacity of the line buffers in 4-sample units (multiple of 8)
 };
 // bottom row of the CTB row above: mv int32[cap4], pm / dm / ref bytes[cap4]; per CTB column (>= 16 samples wide, cap4 / 4 of
@@ -1000,6 +1001,9 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
   const int phase = sv ? RBT_UNI((int)sv->phase) : 0;
   if (phase == 2) return;
   const RbtSlice* gs = &slices[slice_idx];
+  if (RBT_UNI((int)gs->dependent)) return;                   // parsed by the wave of its slice's first segment (next_seg chain)
+  const int wpp = RBT_UNI((int)gs->wpp);
+  int seg = slice_idx;                                       // the slice segment being read
   s.L = lds; s.left_ok = 0; s.corner_ok = 0; s.corner_pm = s.corner_dm = s.corner_ref = s.corner_mv = 0; s.ctb_x = s.ctb_y = 0;
   if (phase == 0) { RBT_LDS_AS uint16_t* a_slice = pz_above_slice(lds, cap4); RBT_PAR_FOR(i, cap4 / 4) a_slice[i] = 0xFFFF; }
   else { RBT_LDS_AS uint32_t* lw = (RBT_LDS_AS uint32_t*)lds; RBT_PAR_FOR(i, (int)(RBT_PARSE_LDS_BYTES(cap4) / 4)) lw[i] = sv->lds[i]; }
@@ -1031,7 +1035,8 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
   int n_ctb = pzc_w_ctb(&s) * pzc_h_ctb(&s), end = 0, addr = RBT_UNI(gs->ctb_addr);
   uint32_t count = 0;
   s.qp_key = 0x7FFFFFFF; s.qp_packed = 0;
-  rbt_cd_start(&s.c, rbsp + (uint32_t)RBT_UNI(gs->data_off), (uint32_t)RBT_UNI(gs->data_size));
+  if (phase != 0) seg = RBT_UNI(sv->sc[22]);
+  rbt_cd_start(&s.c, rbsp + (uint32_t)RBT_UNI(slices[seg].data_off), (uint32_t)RBT_UNI(slices[seg].data_size));
   if (phase == 0) {
     rbt_ctx_init(&s.c.cs, init_type, pzs_qp(&s));
     s.qp_y = pzs_qp(&s); s.qp_pred = pzs_qp(&s); s.qp_y_prev = pzs_qp(&s); s.is_cu_qp_delta_coded = 0; s.cu_qp_delta_val = 0;
@@ -1071,7 +1076,7 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
         q[0] = s.left_ok; q[1] = s.corner_ok; q[2] = s.corner_pm; q[3] = s.corner_dm; q[4] = s.corner_ref; q[5] = s.corner_mv;
         q[6] = s.qp_y; q[7] = s.qp_pred; q[8] = s.qp_y_prev; q[9] = s.is_cu_qp_delta_coded; q[10] = s.cu_qp_delta_val;
         q[11] = s.il_packed; q[12] = s.intra_chroma; q[13] = s.max_trafo_depth; q[14] = s.last_pu_merge;
-        q[15] = addr; q[16] = (int32_t)count;
+        q[15] = addr; q[16] = (int32_t)count; q[22] = seg;
         q[17] = (int32_t)s.c.widx; q[18] = s.c.nbuf; q[19] = (int32_t)s.c.range; q[20] = (int32_t)s.c.value; q[21] = s.c.avail;
         sv->buf_lo = (uint32_t)s.c.buf; sv->buf_hi = (uint32_t)(s.c.buf >> 32);
         sv->phase = 1;
@@ -1081,6 +1086,14 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
     if (RBT_LANE0) s.f->ctb_slice[addr] = (uint16_t)slice_idx;
     s.ctb_addr = addr; s.n_cmds = 0;
     if (rx == 0) { s.left_ok = 0; s.corner_ok = 0; }
+    if (wpp && rx == 0) {
+      // first CTB of a row of a wavefront stream (9.3.1): the context variables of the CTB above-right after it was parsed when that CTB is
+      // available (inside the picture, same slice), the initial ones otherwise; QpY prediction restarts from SliceQpY (8.6.1)
+      RBT_SYNC_LDS();
+      const int tr_ok = ry > 0 && pzc_w_ctb(&s) > 1 && RBT_UNI((int)pz_above_slice(lds, cap4)[1]) == slice_idx;
+      if (tr_ok) rbt_ctx_load(&s.c.cs, lds->wpp_ctx); else rbt_ctx_init(&s.c.cs, init_type, pzs_qp(&s));
+      s.qp_y = pzs_qp(&s);
+    }
 #ifdef RBT_PROFILE
     unsigned long long tb_ = __builtin_readcyclecounter();
 #endif
@@ -1099,9 +1112,24 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
 #ifdef RBT_PROFILE
     s.t_ctb += __builtin_readcyclecounter() - te_;
 #endif
+    if (wpp && rx == 1) { rbt_ctx_store(&s.c.cs, lds->wpp_ctx); }   // storage process after the second CTB of a row
     end = rbt_cd_terminate(&s.c);
     addr++; count++;
     if (rbt_cd_overrun(&s.c)) { s.error = 2; break; }
+    if (!end && wpp && RBT_UNI(addr % pzc_w_ctb(&s)) == 0) {
+      // end_of_subset_one_bit, byte_alignment(): the bit that ended the arithmetic codeword is the alignment bit; the next CTB row is its own
+      // codeword from the next byte on
+      if (!rbt_cd_terminate(&s.c)) { s.error = 1; break; }
+      rbt_cd_restart_aligned(&s.c);
+    }
+    if (end) {
+      const int nxt = RBT_UNI(slices[seg].next_seg);
+      if (nxt >= 0) {   // dependent slice segment: same slice, the context variables and the QpY predictor go on (9.3.1, 8.6.1); its own arithmetic codeword
+        if (RBT_UNI(slices[nxt].ctb_addr) != addr) { s.error = 1; break; }
+        seg = nxt; end = 0;
+        rbt_cd_start(&s.c, rbsp + (uint32_t)RBT_UNI(slices[seg].data_off), (uint32_t)RBT_UNI(slices[seg].data_size));
+      }
+    }
     RBT_SYNC_LDS();
   }
 #ifdef RBT_PROFILE

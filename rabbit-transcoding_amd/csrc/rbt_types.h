@@ -109,7 +109,11 @@ struct RbtSlice {                // one per slice segment, parsed on the host (7
   int8_t slice_type, qp, cb_qp_offset, cr_qp_offset;
   uint8_t sao_luma, sao_chroma, deblocking_disabled, lf_across;
   int8_t beta_offset_div2, tc_offset_div2;
-  uint8_t temporal_mvp, cabac_init_flag, max_merge_cand, num_ref_idx, collocated_ref_idx, pad[3];
+  uint8_t temporal_mvp, cabac_init_flag, max_merge_cand, num_ref_idx, collocated_ref_idx;
+  uint8_t dependent;             // dependent slice segment (7.3.6.1): continues the slice of the segment before it; every other header field repeats that slice's
+  uint8_t wpp;                   // entropy_coding_sync_enabled_flag of the PPS: CTB rows are separate arithmetic codewords with inherited context variables (9.3.1)
+  uint8_t pad;
+  int32_t next_seg;              // decoder: the next dependent segment of the same slice (-1: none); one wave parses the whole chain
   int32_t ref_frame[RBT_MAX_REFS];   // batch frame index of RefPicList0[i]
   int32_t ref_poc[RBT_MAX_REFS];
   int32_t poc;

@@ -21,6 +21,7 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
     (void)rbsp_start;
     ParamSets* ps = new ParamSets();
     std::vector<DpbEntry> dpb; int prev_tid0_poc = 0, cur = -1;
+    SliceHdr head_hdr; int head_idx = -1, last_seg = -1;   // the independent segment of the current slice, the last segment of its chain
     b.stream_first[si] = (int)b.frames.size();
     for (const Nal& nal : nals) {
       const uint8_t* r = b.rbsp.data() + nal.rbsp_off; int rc = 0;
@@ -28,7 +29,7 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
       else if (nal.type == NAL_PPS) rc = parse_pps(*ps, r, nal.rbsp_size, b.err);
       else if (nal.type == NAL_SEI_SUFFIX) { if (cur >= 0) { FrameInfo& fi = b.info[cur]; if (parse_md5_sei(r, nal.rbsp_size, fi.md5)) fi.has_md5 = true; } }
       else if (nal.type <= NAL_TRAIL_R || (nal.type >= 16 && nal.type <= 21)) {
-        SliceHdr h; rc = parse_slice_header(*ps, r, nal.rbsp_size, nal.type, h, b.err);
+        SliceHdr h; rc = parse_slice_header(*ps, r, nal.rbsp_size, nal.type, h, b.err, head_idx >= 0 ? &head_hdr : nullptr);
         if (rc) { delete ps; b.err_code = rc == -3 ? RBT_ERR_UNSUPPORTED : RBT_ERR_BITSTREAM; return b.err_code; }
         const Pps& pps = ps->pps[h.pps_id]; const Sps& sps = ps->sps[pps.sps_id];
         if (h.first_slice_in_pic) {
@@ -55,6 +56,7 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
           FrameInfo fi; memset(&fi, 0, sizeof(fi)); fi.stream = si; fi.nal_type = nal.type; b.info.push_back(fi);
           b.stream_count[si]++; b.stream_sps[si] = sps; b.stream_pps[si] = pps;
           dpb.insert(dpb.begin(), DpbEntry{h.poc, cur});
+          head_idx = -1;
         } else if (cur < 0) { delete ps; b.err = "slice segment before the first picture"; return b.err_code = RBT_ERR_BITSTREAM; }
         else h.poc = b.frames[cur].poc;
         RbtSlice s; memset(&s, 0, sizeof(s));
@@ -81,6 +83,13 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
           }
         }
         if (h.sao_luma || h.sao_chroma) b.info[cur].sao = true;
+        s.wpp = (uint8_t)pps.entropy_coding_sync; s.next_seg = -1;
+        if (h.dependent) {
+          // same slice as the segment before it: parsed by that slice's wave (next_seg chain), not a task of its own
+          if (head_idx < 0 || last_seg < 0) { delete ps; b.err = "dependent slice segment without a slice"; return b.err_code = RBT_ERR_BITSTREAM; }
+          s.dependent = 1; b.slices[last_seg].next_seg = (int32_t)b.slices.size();
+        } else { head_hdr = h; head_idx = (int)b.slices.size(); }
+        last_seg = (int)b.slices.size();
         b.frames[cur].n_slices++;
         b.slices.push_back(s);
       } else if (nal.type >= 2 && nal.type <= 9) { rc = -3; b.err = "unsupported VCL NAL unit type"; }

@@ -131,8 +131,8 @@ int parse_pps(ParamSets& ps, const uint8_t* rbsp, size_t n, std::string& err) {
   p.cu_qp_delta = b.bit(); if (p.cu_qp_delta) p.diff_cu_qp_delta_depth = b.ue();
   p.cb_qp_offset = b.se(); p.cr_qp_offset = b.se(); p.slice_chroma_qp_offsets_present = b.bit();
   int wp = b.bit(); b.bit();
-  p.transquant_bypass = b.bit(); int tiles = b.bit(), wpp = b.bit();
-  if (tiles || wpp) { err = "tiles / wavefront entry points are not supported"; return -3; }
+  p.transquant_bypass = b.bit(); int tiles = b.bit(); p.entropy_coding_sync = b.bit();
+  if (tiles) { err = "tiles are not supported"; return -3; }
   if (wp) { err = "weighted prediction is not supported"; return -3; }
   p.loop_filter_across_slices = b.bit(); p.deblocking_control_present = b.bit();
   if (p.deblocking_control_present) {
@@ -147,7 +147,7 @@ int parse_pps(ParamSets& ps, const uint8_t* rbsp, size_t n, std::string& err) {
   return 0;
 }
 
-int parse_slice_header(ParamSets& ps, const uint8_t* rbsp, size_t n, int nal_type, SliceHdr& h, std::string& err) {
+int parse_slice_header(ParamSets& ps, const uint8_t* rbsp, size_t n, int nal_type, SliceHdr& h, std::string& err, const SliceHdr* head) {
   BitReader b{rbsp, n, 16};
   h = SliceHdr(); h.nal_type = nal_type;
   h.first_slice_in_pic = b.bit();
@@ -157,7 +157,10 @@ int parse_slice_header(ParamSets& ps, const uint8_t* rbsp, size_t n, int nal_typ
   if (!s.valid) { err = "slice refers to a missing SPS"; return -2; }
   int dependent = 0;
   if (!h.first_slice_in_pic) { if (p.dependent_slice_segments) dependent = b.bit(); h.segment_addr = b.u(ceil_log2(s.w_ctb * s.h_ctb)); }
-  if (dependent) { err = "dependent slice segments are not supported"; return -3; }
+  if (dependent) {   // 7.3.6.1: everything up to the entry points is that of the slice's independent segment
+    if (!head || h.segment_addr == 0) { err = "dependent slice segment without a slice"; return -2; }
+    const int addr = h.segment_addr; h = *head; h.nal_type = nal_type; h.first_slice_in_pic = 0; h.segment_addr = addr; h.dependent = 1;
+  } else {
   for (int i = 0; i < p.num_extra_slice_header_bits; i++) b.bit();
   h.slice_type = b.ue();
   if (h.slice_type == RBT_SLICE_B) { err = "B slices are not supported"; return -3; }
@@ -190,6 +193,13 @@ int parse_slice_header(ParamSets& ps, const uint8_t* rbsp, size_t n, int nal_typ
   if (ovr) { h.deblocking_disabled = b.bit(); if (!h.deblocking_disabled) { h.beta_offset_div2 = b.se(); h.tc_offset_div2 = b.se(); } }
   h.lf_across = p.loop_filter_across_slices;
   if (p.loop_filter_across_slices && (h.sao_luma || h.sao_chroma || !h.deblocking_disabled)) h.lf_across = b.bit();
+  }
+  h.num_entry_points = 0;
+  if (p.entropy_coding_sync) {   // the substreams are parsed one after the other by one wave: the offsets are read and dropped
+    h.num_entry_points = (int)b.ue();
+    if (h.num_entry_points > s.h_ctb) { err = "slice header: entry points"; return -2; }
+    if (h.num_entry_points > 0) { const int len = (int)b.ue() + 1; if (len > 32) { err = "slice header: entry points"; return -2; } for (int i = 0; i < h.num_entry_points; i++) b.u(len); }
+  }
   if (p.slice_header_extension_present) { int k = b.ue(); for (int i = 0; i < k; i++) b.u(8); }
   if (!b.bit()) { err = "slice header alignment"; return -2; }
   while (!b.aligned()) b.bit();

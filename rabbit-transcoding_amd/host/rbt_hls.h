@@ -46,14 +46,14 @@ struct Sps {
 };
 struct Pps {
   bool valid = false;
-  int pps_id = 0, sps_id = 0, dependent_slice_segments = 0, output_flag_present = 0, num_extra_slice_header_bits = 0;
+  int pps_id = 0, sps_id = 0, entropy_coding_sync = 0, dependent_slice_segments = 0, output_flag_present = 0, num_extra_slice_header_bits = 0;
   int sign_data_hiding = 0, cabac_init_present = 0, num_ref_idx_default = 1, init_qp = 26, constrained_intra_pred = 0, transform_skip = 0;
   int cu_qp_delta = 0, diff_cu_qp_delta_depth = 0, cb_qp_offset = 0, cr_qp_offset = 0, slice_chroma_qp_offsets_present = 0;
   int transquant_bypass = 0, loop_filter_across_slices = 0, deblocking_control_present = 0, deblocking_override_enabled = 0;
   int pps_deblocking_disabled = 0, beta_offset_div2 = 0, tc_offset_div2 = 0, lists_modification_present = 0, slice_header_extension_present = 0;
 };
 struct SliceHdr {
-  int nal_type = 0, first_slice_in_pic = 0, pps_id = 0, segment_addr = 0, slice_type = RBT_SLICE_I;
+  int nal_type = 0, first_slice_in_pic = 0, pps_id = 0, segment_addr = 0, slice_type = RBT_SLICE_I, dependent = 0, num_entry_points = 0;
   int poc_lsb = 0, poc = 0; Rps rps; int temporal_mvp = 0, sao_luma = 0, sao_chroma = 0, num_ref_idx = 1, cabac_init_flag = 0;
   int collocated_ref_idx = 0, max_merge_cand = 5, qp = 26, cb_qp_offset = 0, cr_qp_offset = 0;
   int deblocking_disabled = 0, beta_offset_div2 = 0, tc_offset_div2 = 0, lf_across = 0;
@@ -68,7 +68,8 @@ void split_annexb(const uint8_t* p, size_t n, std::vector<uint8_t>& rbsp, std::v
 struct ParamSets { Sps sps[16]; Pps pps[64]; };
 int parse_sps(ParamSets& ps, const uint8_t* rbsp, size_t n, std::string& err);   // rbsp starts at the NAL header
 int parse_pps(ParamSets& ps, const uint8_t* rbsp, size_t n, std::string& err);
-int parse_slice_header(ParamSets& ps, const uint8_t* rbsp, size_t n, int nal_type, SliceHdr& h, std::string& err);
+// `head`: the header of the slice's independent segment (what a dependent slice segment repeats), nullptr when there is none yet
+int parse_slice_header(ParamSets& ps, const uint8_t* rbsp, size_t n, int nal_type, SliceHdr& h, std::string& err, const SliceHdr* head = nullptr);
 bool parse_md5_sei(const uint8_t* rbsp, size_t n, uint8_t md5[3][16]);
 
 void fill_stream_cfg(const Sps& s, const Pps& p, RbtStreamCfg& c);
