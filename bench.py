@@ -76,6 +76,8 @@ def main():
                     "encoder's kernels out of a profile of the transcode step); the file must come from the same size / seed")
     ap.add_argument("--input", default="auto", choices=["auto", "hm", "e1"], help="R5 input: hm = the committed HM-like fixture (tests/golden/hm_r5_*.annexb: CTC toolset, "
                     "coded by the oracle's HM-like encoder, tests/golden/make_hm_gof.py); e1 = coded on the fly by this library's own encoder (any size); auto = hm when the fixture fits")
+    ap.add_argument("--rows", type=int, default=-1, help="encoder slice structure (rbt_stream_params.ctb_rows_per_slice): -1 = wavefront mode, one slice per picture coded as one "
+                    "dependent slice segment per CTB row (entropy_coding_sync); 1 = one independent slice per CTB row; 0 = one slice per picture")
     ap.add_argument("--walk-frames", type=int, default=300, help="also walk a sequence of this many point-cloud frames GOF-sharded over the ranks "
                     "(BASELINE.json configs[3]: 300 = 9 x 32 + 12; extra field sequence_walk; 0 = skip)")
     ap.add_argument("--fanout-gofs", type=int, default=2, help="also transcode this many GOFs to every rate point R1..R5, one target rate per rank "
@@ -134,7 +136,7 @@ def main():
         np.savez(args.save_input, sg=np.frombuffer(sg, np.uint8), sa=np.frombuffer(sa, np.uint8), so=np.frombuffer(so, np.uint8))
         return
     P = R.StreamParams
-    params = [P(R.RBT_VIDEO_OCCUPANCY, 8, 4, 5, 1, 0, 0), P(R.RBT_VIDEO_GEOMETRY, 24, 4, 5, 1, 0, 0), P(R.RBT_VIDEO_ATTRIBUTE, 32, 4, 5, 1, 0, 0)]
+    params = [P(R.RBT_VIDEO_OCCUPANCY, 8, 4, 5, args.rows, 0, 0), P(R.RBT_VIDEO_GEOMETRY, 24, 4, 5, args.rows, 0, 0), P(R.RBT_VIDEO_ATTRIBUTE, 32, 4, 5, args.rows, 0, 0)]
     streams = [so, sg, sa]
 
     # One step = one GOF through the hot path. The steps are issued the way a transcoder walks a sequence: rbt_submit_gof
@@ -267,10 +269,10 @@ def main():
     fanout = None
     if args.fanout_gofs > 0:
         fseq = [streams] * args.fanout_gofs
-        gs.transcode_fanout(ctx, R, fseq[:1], rank=rank, world=world, depth=D, device=tdev)
+        gs.transcode_fanout(ctx, R, fseq[:1], rank=rank, world=world, depth=D, device=tdev, rows_per_slice=args.rows)
         sync()
         f0 = time.perf_counter()
-        fan = gs.transcode_fanout(ctx, R, fseq, rank=rank, world=world, depth=D, device=tdev)
+        fan = gs.transcode_fanout(ctx, R, fseq, rank=rank, world=world, depth=D, device=tdev, rows_per_slice=args.rows)
         sync()
         ft = time.perf_counter() - f0
         if world > 1:
@@ -358,7 +360,7 @@ def main():
         pairs = [gs.split_pairs(s_) for s_ in streams]      # every point-cloud frame is a closed GOP in all three sub-bitstreams
         sub = [b"".join(p_[:k]) for p_ in pairs]
         c0 = time.perf_counter()
-        cpu_out = [O.transcode_substream(sub[0], 0, 8, md5_sei=0), O.transcode_substream(sub[1], 1, 24, md5_sei=0), O.transcode_substream(sub[2], 19, 32, md5_sei=0)]
+        cpu_out = [O.transcode_substream(sub[0], 0, 8, md5_sei=0, rows_per_slice=args.rows), O.transcode_substream(sub[1], 1, 24, md5_sei=0, rows_per_slice=args.rows), O.transcode_substream(sub[2], 19, 32, md5_sei=0, rows_per_slice=args.rows)]
         ct = time.perf_counter() - c0
         cpu_parity = cpu_out == ctx.transcode_gof(sub, params)     # full-size parity for free: the GPU path on the same sample, byte for byte
         import shutil
@@ -376,7 +378,7 @@ def main():
         with tempfile.TemporaryDirectory() as td:
             f = os.path.join(td, "frames.npz"); np.savez(f, **per)
             worker = os.path.join(ROOT, "tests", "cpu_baseline_worker.py")
-            procs = [subprocess.Popen([sys.executable, worker, f, str(i), str(ncore)], stdout=subprocess.PIPE, text=True) for i in range(ncore)]
+            procs = [subprocess.Popen([sys.executable, worker, f, str(i), str(ncore), str(args.rows)], stdout=subprocess.PIPE, text=True) for i in range(ncore)]
             res = [p_.communicate(timeout=600)[0].split() for p_ in procs]
         if all(p_.returncode == 0 for p_ in procs) and sum(int(r_[0]) for r_ in res) == n_pc:
             mt = max(float(r_[1]) for r_ in res)

@@ -107,6 +107,23 @@ RBT_DEV void rbt_ctx_load(RbtCtxStore* s, const RBT_LDS_AS uint8_t* src) {
   s->st0 = src[l]; s->st1 = src[64 + l]; s->st2 = src[128 + l]; s->st3 = src[192 + l];
 #endif
 }
+// the same copies in global memory (the entropy coder hands them from the wave of one CTB row to the wave of the next)
+RBT_DEV void rbt_ctx_store_g(const RbtCtxStore* s, uint8_t* dst) {
+#ifdef RBT_HOSTEMU
+  for (int i = 0; i < RBT_CTX_COUNT; i++) dst[i] = s->st[i];
+#else
+  const int l = (int)threadIdx.x & 63;
+  dst[l] = (uint8_t)s->st0; dst[64 + l] = (uint8_t)s->st1; dst[128 + l] = (uint8_t)s->st2; dst[192 + l] = (uint8_t)s->st3;
+#endif
+}
+RBT_DEV void rbt_ctx_load_g(RbtCtxStore* s, const uint8_t* src) {
+#ifdef RBT_HOSTEMU
+  for (int i = 0; i < RBT_CTX_COUNT; i++) s->st[i] = src[i];
+#else
+  const int l = (int)threadIdx.x & 63;
+  s->st0 = src[l]; s->st1 = src[64 + l]; s->st2 = src[128 + l]; s->st3 = src[192 + l];
+#endif
+}
 RBT_DEV int rbt_lps(const RbtCtxStore* s, int state, int q) {
 #ifdef RBT_HOSTEMU
   (void)s; return k_range_lps[state][q];

@@ -984,6 +984,12 @@ RBT_DEV void en_entropy_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx,
   s.is_p = RBT_UNI(sl->slice_type) == RBT_SLICE_P; s.cx = s.cy = 0;
   RBT_PAR_FOR(i, 3 * 4 * 64) l->scan[i / 256][(i / 64) & 3][i & 63] = k_scan_packed(i / 256, (i / 64) & 3, i & 63);
   rbt_ctx_init(&s.c.cs, s.is_p ? 1 : 0, RBT_UNI(sl->qp));
+  const int wave_mode = RBT_UNI((int)sl->wpp), wc0 = (s.w + (1 << s.log2_ctb) - 1) >> s.log2_ctb, row0 = RBT_UNI(sl->ctb_addr) / wc0, hc0 = RBT_UNI(g->h_ctb);
+  if (wave_mode && row0 > 0 && wc0 > 1) {
+    // wavefront mode (every segment is one CTB row of a one-slice picture): the context variables of the row above after its second CTB (9.3.1)
+    rbt_flag_wait(&s.f->row_done[hc0 + row0 - 1], 2u, &s.f->error);
+    rbt_ctx_load_g(&s.c.cs, s.f->row_ctx + (size_t)(row0 - 1) * 256);
+  }
   s.c.out = rbt_uni_ptr(out + (uint32_t)RBT_UNI(sl->out_off)); s.c.cap = (uint32_t)RBT_UNI(sl->out_cap); s.c.n = 0; s.c.overflow = 0;
   rbt_ce_start(&s.c);
 #ifdef RBT_PROFILE
@@ -995,6 +1001,7 @@ RBT_DEV void en_entropy_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx,
     if (RBT_UNI(sl->sao_luma | sl->sao_chroma)) en_write_sao(&s.c, s.f, addr, rx, ry, wc, RBT_UNI(g->bit_depth));
     en_stage_ctb(&s, rx << s.log2_ctb, ry << s.log2_ctb);
     en_write_quadtree(&s, rx << s.log2_ctb, ry << s.log2_ctb, s.log2_ctb);
+    if (wave_mode && rx == 1) { rbt_ctx_store_g(&s.c.cs, s.f->row_ctx + (size_t)ry * 256); RBT_FLAG_PUBLISH(&s.f->row_done[hc0 + ry], 2u); }
     rbt_ce_terminate(&s.c, a == n_ctbs - 1);
   }
   rbt_ce_align_zero(&s.c);

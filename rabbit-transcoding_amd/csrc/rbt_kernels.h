@@ -60,13 +60,15 @@ void launch_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_l
 void launch_pool(const uint16_t* in, int stride, int w, int h, int factor, uint16_t* out, uint16_t* out_cb, uint16_t* out_cr, int chroma_value);   // w x h region of a plane with row stride `stride`
 void launch_pad(const uint16_t* in, int stride, int x0, int y0, int w, int h, uint16_t* out, int dw, int dh);
 void launch_enc_analyse(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs);
-// row_mode != 0: every slice is one CTB row, rows are independent and each wave walks its row;
+// row_mode 1: every slice is one CTB row, rows are independent and each wave walks its row; 2: wavefront mode (rows of a picture wait for each other, k_enc_intra_wave);
 // otherwise CTBs are scheduled on anti-diagonals like the decoder's reconstruction
-void launch_enc_intra(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int row_mode, int max_log2_ctb);
+void launch_enc_intra(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int row_mode, int max_log2_ctb, uint32_t* ticket = nullptr);
 void launch_enc_inter(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs);
 // SAO parameters of every CTB of the listed (deblocked) pictures from source-vs-reconstruction statistics; launch_sao then applies them
 void launch_enc_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs);
 void launch_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list, int n_slices, int max_log2_ctb);
+// wavefront mode: every slice segment (one per CTB row) of the listed pictures; rows of a picture hand their context variables down (rbt_kernels.hip k_entropy_wave)
+void launch_entropy_wave(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int max_log2_ctb, uint32_t* ticket);
 // gathers the slice data of every slice segment into one contiguous buffer (dst_off = exclusive prefix sum of out_size)
 void launch_pack(const uint8_t* out, const RbtSlice* slices, const uint32_t* dst_off, uint8_t* packed, int n_slices);
 // matrix-core transform stages against the vector-ALU stages on n blocks of 32 x 32 int16 (0 = ok; *n_bad = differing samples)

@@ -267,6 +267,32 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
   rc_stage_tables(&RBT_LDS_CAST(RbtEncTileLdsT<TL2>, &lds)->rc);
   for (int x = 0; x < f->cfg.w_ctb; x++) en_intra_ctb<TL2>(f, slices, row * f->cfg.w_ctb + x, RBT_LDS_CAST(RbtEncTileLdsT<TL2>, &lds), x > 0);
 }
+// Wavefront mode (one slice per picture, one dependent slice segment per CTB row): rows of a picture predict from each other, so CTB x of row r is coded
+// once row r - 1 has finished CTB x + 1 (its above-right neighbour; the last CTB of the row for the last column). With that two-CTB lag at most w_ctb / 2
+// rows of a picture are in progress at any time, so a picture gets K = ceil(w_ctb / 2) waves instead of one per row (which would sit on their LDS
+// waiting for most of their lives). A wave takes its picture from a launch ticket (start order) and then rows from the picture's own counter, the next
+// row not handed out yet, until none is left: rows are handed out in order to waves that are running, so the row a wave waits for is always being worked
+// on by a running wave and the launch makes progress however few of its waves the GPU holds at a time.
+__device__ __forceinline__ int wave_next_row(uint32_t* counter) {
+  int r = 0;
+  if ((threadIdx.x & 63) == 0) r = (int)atomicAdd(counter, 1u);
+  return __builtin_amdgcn_readfirstlane(r);
+}
+template <int TL2>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) k_enc_intra_wave(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, uint32_t* ticket) {
+  __shared__ RbtEncTileLdsT<TL2> lds;
+  const uint32_t t = (uint32_t)wave_next_row(ticket);
+  RbtFrame* f = &frames[frame_list[t % (uint32_t)n_frames]];
+  const int w = f->cfg.w_ctb, h = f->cfg.h_ctb;
+  rc_stage_tables(&RBT_LDS_CAST(RbtEncTileLdsT<TL2>, &lds)->rc);
+  uint32_t* done = f->row_done;
+  for (int row = wave_next_row(&done[2 * h]); row < h; row = wave_next_row(&done[2 * h]))
+    for (int x = 0; x < w; x++) {
+      if (row > 0) rbt_flag_wait(&done[row - 1], (uint32_t)(x + 2 < w ? x + 2 : w), &f->error);
+      en_intra_ctb<TL2>(f, slices, row * w + x, RBT_LDS_CAST(RbtEncTileLdsT<TL2>, &lds), x > 0);
+      RBT_FLAG_PUBLISH(&done[row], x + 1);
+    }
+}
 template <int TL2>
 __global__ void __launch_bounds__(64) k_enc_intra_diag(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int d) {
   __shared__ RbtEncTileLdsT<TL2> lds;
@@ -293,6 +319,17 @@ template <int TL2>
 __global__ void __launch_bounds__(64) k_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list) {
   __shared__ alignas(16) uint32_t lds[(RBT_ENTROPY_LDS_BYTES(TL2) + 3) / 4];
   en_entropy_slice(frames, slices, slice_list[blockIdx.x], out, RBT_LDS_CAST(RbtEntropyLds, lds));
+}
+// Wavefront mode: the segment of CTB row r starts from the context variables row r - 1 had after its second CTB (en_entropy_slice waits for them); as in
+// k_enc_intra_wave a picture gets K = ceil(w_ctb / 2) waves, each taking the next row not handed out yet (segment of row r = the picture's first_slice + r).
+template <int TL2>
+__global__ void __launch_bounds__(64) k_entropy_wave(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* frame_list, int n_frames, uint32_t* ticket) {
+  __shared__ alignas(16) uint32_t lds[(RBT_ENTROPY_LDS_BYTES(TL2) + 3) / 4];
+  const uint32_t t = (uint32_t)wave_next_row(ticket);
+  const RbtFrame* f = &frames[frame_list[t % (uint32_t)n_frames]];
+  const int h = f->cfg.h_ctb, first = f->first_slice;
+  uint32_t* next = &f->row_done[2 * h + 1];
+  for (int row = wave_next_row(next); row < h; row = wave_next_row(next)) en_entropy_slice(frames, slices, first + row, out, RBT_LDS_CAST(RbtEntropyLds, lds));
 }
 
 __global__ void __launch_bounds__(256) k_pack(const uint8_t* out, const RbtSlice* slices, const uint32_t* dst_off, uint8_t* packed) {
@@ -323,9 +360,16 @@ void launch_enc_analyse(RbtFrame* frames, const RbtSlice* slices, const int32_t*
   if (n_frames <= 0) return;
   hipLaunchKernelGGL(k_enc_analyse, dim3(max_ctbs, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
 }
-void launch_enc_intra(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int row_mode, int max_log2_ctb) {
+static int wave_rows_in_flight(int max_w_ctb, int max_h_ctb) { int K = (max_w_ctb + 1) / 2; if (K < 1) K = 1; return K > max_h_ctb ? max_h_ctb : K; }
+void launch_enc_intra(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int row_mode, int max_log2_ctb, uint32_t* ticket) {
   if (n_frames <= 0) return;
   const bool small = max_log2_ctb <= 5;
+  if (row_mode == 2) {
+    const int K = wave_rows_in_flight(max_w_ctb, max_h_ctb);
+    if (small) hipLaunchKernelGGL(k_enc_intra_wave<5>, dim3(K * n_frames), dim3(64), 0, g_stream, frames, slices, frame_list, n_frames, ticket);
+    else hipLaunchKernelGGL(k_enc_intra_wave<6>, dim3(K * n_frames), dim3(64), 0, g_stream, frames, slices, frame_list, n_frames, ticket);
+    return;
+  }
   if (row_mode) {
     if (small) hipLaunchKernelGGL(k_enc_intra_rows<5>, dim3(max_h_ctb, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
     else hipLaunchKernelGGL(k_enc_intra_rows<6>, dim3(max_h_ctb, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
@@ -350,6 +394,12 @@ void launch_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int3
   if (n_slices <= 0) return;
   if (max_log2_ctb <= 5) hipLaunchKernelGGL(k_entropy<5>, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, out, slice_list);
   else hipLaunchKernelGGL(k_entropy<6>, dim3(n_slices), dim3(64), 0, g_stream, frames, slices, out, slice_list);
+}
+void launch_entropy_wave(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int max_log2_ctb, uint32_t* ticket) {
+  if (n_frames <= 0) return;
+  const int K = wave_rows_in_flight(max_w_ctb, max_h_ctb);
+  if (max_log2_ctb <= 5) hipLaunchKernelGGL(k_entropy_wave<5>, dim3(K * n_frames), dim3(64), 0, g_stream, frames, slices, out, frame_list, n_frames, ticket);
+  else hipLaunchKernelGGL(k_entropy_wave<6>, dim3(K * n_frames), dim3(64), 0, g_stream, frames, slices, out, frame_list, n_frames, ticket);
 }
 // ---------------------------------------------------------------------------------------------- self-test
 // The 32-point transform stages on the matrix cores (rbt_mfma.h) against the vector-ALU form of the same stages, on the device, for every block

@@ -79,6 +79,27 @@ static __device__ __forceinline__ int rbt_writelane(int old, int v, int lane) { 
 #define RBT_LDS_ADD(p, v) ((void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
 #endif
 
+// Progress counters between workgroups of one launch (wavefront dependencies between CTB rows). The producer makes its global stores visible to the
+// whole device (release fence at agent scope: per-XCD L2 write-back) and waits for them before it publishes the counter; the consumer polls the counter
+// with a relaxed agent-scope load, sleeping in between so that a waiting wave leaves the issue slots to working ones, and then invalidates its caches
+// (acquire). The poll is bounded: a wave that ran out of patience reports through *err and goes on, so the grid always drains. In the serial host
+// emulation the producer has always run already.
+#ifdef RBT_HOSTEMU
+#define RBT_FLAG_PUBLISH(p, v) (*(p) = (uint32_t)(v))
+RBT_DEV void rbt_flag_wait(const uint32_t* p, uint32_t need, int32_t* err) { if (*p < need) *err = 91; }
+#else
+#define RBT_FLAG_PUBLISH(p, v) do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+  if (RBT_LANE0) __hip_atomic_store((p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+RBT_DEV void rbt_flag_wait(const uint32_t* p, uint32_t need, int32_t* err) {
+  int spins = 0;
+  while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+    __builtin_amdgcn_s_sleep(32);
+    if (++spins > (1 << 20)) { *err = 91; break; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+#endif
+
 // Bit-field read of a packed wave-uniform word. On the GPU it is one scalar instruction the compiler may neither hoist nor
 // keep alive: rarely used parameters then cost one SGPR per word instead of one (spilled) SGPR per field.
 template <int SH, int N> RBT_DEV uint32_t rbt_bfe(uint32_t w) {

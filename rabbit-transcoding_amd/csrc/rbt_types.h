@@ -88,6 +88,11 @@ struct RbtFrame {
   int32_t lossless;              // every CU cu_transquant_bypass (x265 lossless=1, PCCTranscoder.cpp:841)
   int32_t ref_frame;             // P pictures: batch index of the reference picture (zero-motion merge), else -1
   int32_t ref_poc;
+  // wavefront mode (one dependent slice segment per CTB row): CTBs finished per row by the closed-loop intra stage [0, h_ctb) and by the entropy
+  // coder [h_ctb, 2 h_ctb), then the next row to hand out in each of the two stages, zeroed per job; the entropy coder's context variables after the
+  // second CTB of each row, 256 bytes per row
+  uint32_t* row_done;
+  uint8_t* row_ctx;
 };
 #define RBT_CU_CBF_Y 1
 #define RBT_CU_CBF_CB 2

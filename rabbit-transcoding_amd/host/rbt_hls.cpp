@@ -281,14 +281,14 @@ void write_param_sets(std::vector<uint8_t>& out, const Sps& s, const Pps& p) {
   w.bit(0); w.bit(0); w.trailing();
   append_nal(out, NAL_SPS, w.b.data(), w.b.size(), true);
   BitWriter q;
-  q.ue(0); q.ue(0); q.bit(0); q.bit(0); q.u(0, 3);
+  q.ue(0); q.ue(0); q.bit(p.dependent_slice_segments); q.bit(0); q.u(0, 3);
   q.bit(p.sign_data_hiding); q.bit(p.cabac_init_present);
   q.ue(p.num_ref_idx_default - 1); q.ue(0);
   q.se(p.init_qp - 26); q.bit(p.constrained_intra_pred); q.bit(p.transform_skip);
   q.bit(p.cu_qp_delta); if (p.cu_qp_delta) q.ue(p.diff_cu_qp_delta_depth);
   q.se(p.cb_qp_offset); q.se(p.cr_qp_offset); q.bit(p.slice_chroma_qp_offsets_present);
   q.bit(0); q.bit(0);
-  q.bit(p.transquant_bypass); q.bit(0); q.bit(0);
+  q.bit(p.transquant_bypass); q.bit(0); q.bit(p.entropy_coding_sync);
   q.bit(p.loop_filter_across_slices);
   q.bit(p.deblocking_control_present);
   if (p.deblocking_control_present) {
@@ -302,7 +302,12 @@ void write_slice_header(BitWriter& w, const Sps& s, const Pps& p, const SliceHdr
   w.bit(h.first_slice_in_pic);
   if (is_idr) w.bit(0);
   w.ue(0);
-  if (!h.first_slice_in_pic) w.u(h.segment_addr, ceil_log2(s.w_ctb * s.h_ctb));
+  if (!h.first_slice_in_pic) { if (p.dependent_slice_segments) w.bit(h.dependent); w.u(h.segment_addr, ceil_log2(s.w_ctb * s.h_ctb)); }
+  if (h.dependent) {   // 7.3.6.1: nothing but the entry points (none: every segment this encoder writes is one CTB row) and the alignment
+    if (p.entropy_coding_sync) w.ue(0);
+    w.bit(1); w.align_zero();
+    return;
+  }
   w.ue(h.slice_type);
   if (!is_idr) {
     w.u(h.poc & ((1 << s.log2_max_poc_lsb) - 1), s.log2_max_poc_lsb);
@@ -326,6 +331,7 @@ void write_slice_header(BitWriter& w, const Sps& s, const Pps& p, const SliceHdr
     if (ovr) { w.bit(h.deblocking_disabled); if (!h.deblocking_disabled) { w.se(h.beta_offset_div2); w.se(h.tc_offset_div2); } }
   }
   if (p.loop_filter_across_slices && (h.sao_luma || h.sao_chroma || !h.deblocking_disabled)) w.bit(h.lf_across);
+  if (p.entropy_coding_sync) w.ue(0);   // num_entry_point_offsets
   w.bit(1); w.align_zero();
 }
 

@@ -32,6 +32,7 @@ struct EncodeBatch {
   size_t out_total = 0;
   std::vector<PadJob> pad_jobs;                 // source pictures that have to be copied into padded planes before the encoder reads them
   std::vector<std::vector<uint16_t>> cs_keep;   // host staging of the ctb->slice maps, alive until the copies have completed
+  uint8_t* d_zero = nullptr; size_t zero_bytes = 0; bool wpp = false;   // launch tickets (3 words) + row progress of the wavefront mode
   int main_stream = 0, aux_stream = -1;          // aux_stream >= 0: the intra part was enqueued there (its timers live there)
   std::vector<int32_t> lists_keep; size_t off_i = 0, off_ideb = 0, off_p = 0, off_sl = 0, off_sl_p = 0, off_isao = 0, off_psao = 0; int n_i = 0, n_ideb = 0, n_p = 0, n_sl_i = 0, n_sl_p = 0, n_isao = 0, n_psao = 0;   // index lists (encode_upload_lists)
   std::string err;
@@ -51,6 +52,7 @@ static void make_param_sets(const EncStreamDesc& d, Sps& s, Pps& p) {
   s.w_ctb = (cw + (1 << s.log2_ctb) - 1) >> s.log2_ctb; s.h_ctb = (ch + (1 << s.log2_ctb) - 1) >> s.log2_ctb;
   p.valid = true; p.num_ref_idx_default = 1; p.init_qp = std::min(51, std::max(0, d.qp)); p.loop_filter_across_slices = 1;
   if (d.lossless) { p.transquant_bypass = 1; p.deblocking_control_present = 1; p.pps_deblocking_disabled = 1; p.loop_filter_across_slices = 0; }
+  if (d.rows < 0) { p.entropy_coding_sync = 1; p.dependent_slice_segments = 1; }   // wavefront rows, one dependent slice segment each (oracle/hevc_enc.c setup_stream)
 }
 
 static int encode_build(EncodeBatch& b) {
@@ -60,6 +62,7 @@ static int encode_build(EncodeBatch& b) {
     const EncStreamDesc& d = b.desc[si];
     if (d.w % 2 || d.h % 2 || d.w <= 0 || d.h <= 0 || d.w > 8192 || d.h > 8192) { b.err = "picture size must be even and at most 8192"; return RBT_ERR_UNSUPPORTED; }
     if (d.log2_ctb && (d.log2_ctb < 4 || d.log2_ctb > 6)) { b.err = "log2_ctb must be 4..6"; return RBT_ERR_PARAM; }
+    if ((d.rows < 0) != (b.desc[0].rows < 0)) { b.err = "streams of one call must agree on the wavefront mode (ctb_rows_per_slice < 0)"; return RBT_ERR_PARAM; }
     b.desc[si].sao = !d.lossless && e1_sao_on();
     make_param_sets(b.desc[si], b.sps[si], b.pps[si]);
     const Sps& s = b.sps[si]; const Pps& p = b.pps[si];
@@ -71,9 +74,10 @@ static int encode_build(EncodeBatch& b) {
       f.poc = is_i ? 0 : (i % d.gop); f.level = is_i ? 0 : 1; f.first_slice = (int)b.slices.size();
       f.w8 = s.width / 8; f.h8 = s.height / 8; f.lossless = d.lossless; f.ref_frame = is_i ? -1 : (int)b.frames.size() - 1; f.ref_poc = is_i ? 0 : f.poc - 1;
       for (int c = 0; c < 3; c++) f.src[c] = d.src[c][i];
-      int n_ctb = s.w_ctb * s.h_ctb, step = d.rows > 0 ? d.rows * s.w_ctb : n_ctb;
+      int n_ctb = s.w_ctb * s.h_ctb, step = d.rows > 0 ? d.rows * s.w_ctb : (d.rows < 0 ? s.w_ctb : n_ctb);
       for (int addr = 0; addr < n_ctb; addr += step) {
         RbtSlice sl; memset(&sl, 0, sizeof(sl));
+        sl.next_seg = -1; sl.wpp = (uint8_t)(d.rows < 0); sl.dependent = (uint8_t)(d.rows < 0 && addr > 0);
         sl.frame = (int)b.frames.size(); sl.ctb_addr = addr; sl.n_ctbs = std::min(step, n_ctb - addr);
         sl.slice_type = (int8_t)(is_i ? RBT_SLICE_I : RBT_SLICE_P);
         sl.qp = (int8_t)std::min(51, std::max(0, is_i ? d.qp + d.i_qp_offset : d.qp));
@@ -92,6 +96,12 @@ static int encode_build(EncodeBatch& b) {
   if (b.slices.size() >= 0xFFFF) { b.err = "too many slice segments in one call"; return RBT_ERR_UNSUPPORTED; }
   // ---- HBM layout ----
   Arena a; size_t nf = b.frames.size();
+  // wavefront bookkeeping: three launch tickets, then per picture 2 * h_ctb progress words and two next-row counters (zeroed before the first kernel of every job)
+  bool any_wpp = false; for (auto& d : b.desc) any_wpp |= d.rows < 0;
+  std::vector<size_t> o_rowdone(nf, 0), o_rowctx(nf, 0);
+  size_t o_zero = a.reserve(64), zero_bytes = 64;
+  if (any_wpp) for (size_t i = 0; i < nf; i++) { size_t n = ((size_t)b.frames[i].cfg.h_ctb * 2 + 2) * sizeof(uint32_t); o_rowdone[i] = a.reserve(n); zero_bytes = o_rowdone[i] + n - o_zero; }
+  if (any_wpp) for (size_t i = 0; i < nf; i++) o_rowctx[i] = a.reserve((size_t)b.frames[i].cfg.h_ctb * 256);
   std::vector<size_t> o_src(nf, (size_t)-1), o_pix(nf), o_sout(nf), o_sao(nf), o_coef(nf), o_pm(nf), o_edges(nf), o_qp(nf), o_mv(nf), o_ref(nf), o_refpoc(nf), o_cs(nf), o_cul(nf), o_cum(nf), o_cuf(nf);
   for (size_t i = 0; i < nf; i++) {
     const RbtStreamCfg& c = b.frames[i].cfg; size_t u = (size_t)c.w4 * c.h4, nc = (size_t)c.w_ctb * c.h_ctb, u8 = (size_t)b.frames[i].w8 * b.frames[i].h8;
@@ -127,12 +137,16 @@ static int encode_build(EncodeBatch& b) {
     f.pm = base + o_pm[i]; f.edges = base + o_edges[i]; f.qp = (int8_t*)(base + o_qp[i]); f.mv = (int16_t*)(base + o_mv[i]); f.ref = (int8_t*)(base + o_ref[i]);
     f.refpoc = (int32_t*)(base + o_refpoc[i]); f.ctb_slice = (uint16_t*)(base + o_cs[i]);
     f.cu_log2 = base + o_cul[i]; f.cu_mode = base + o_cum[i]; f.cu_flags = base + o_cuf[i];
+    if (any_wpp) { f.row_done = (uint32_t*)(base + o_rowdone[i]); f.row_ctx = base + o_rowctx[i]; }
     cs_host.assign((size_t)c.w_ctb * c.h_ctb, 0);
-    for (int k = 0; k < f.n_slices; k++) { const RbtSlice& sl = b.slices[f.first_slice + k]; for (int q = 0; q < sl.n_ctbs; q++) cs_host[sl.ctb_addr + q] = (uint16_t)(f.first_slice + k); }
+    // per CTB: the SLICE it belongs to (index of the slice's independent segment): availability, QP and loop filter flags are per slice
+    { int head = f.first_slice;
+      for (int k = 0; k < f.n_slices; k++) { const RbtSlice& sl = b.slices[f.first_slice + k]; if (!sl.dependent) head = f.first_slice + k; for (int q = 0; q < sl.n_ctbs; q++) cs_host[sl.ctb_addr + q] = (uint16_t)head; } }
     if (rbtk::h2d(f.ctb_slice, cs_host.data(), cs_host.size() * 2)) { b.err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
   }
   b.d_frames = (RbtFrame*)(base + o_frames); b.d_slices = (RbtSlice*)(base + o_slices); b.d_lists = (int32_t*)(base + o_lists); b.d_dst = (uint32_t*)(base + o_dst);
   b.d_out = base + o_out; b.d_packed = base + o_packed; b.out_total = out_cap_total;
+  b.d_zero = base + o_zero; b.zero_bytes = zero_bytes; b.wpp = any_wpp;
   if (rbtk::h2d(b.d_frames, b.frames.data(), nf * sizeof(RbtFrame)) || rbtk::h2d(b.d_slices, b.slices.data(), b.slices.size() * sizeof(RbtSlice))) { b.err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
   return 0;
 }
@@ -166,20 +180,24 @@ static void encode_launch_intra(EncodeBatch& b) {
     const RbtStreamCfg& c = b.frames[i].cfg; ml = std::max(ml, c.w * c.h); ml2 = std::max(ml2, (int)c.log2_ctb); mw = std::max(mw, c.w_ctb); mh = std::max(mh, c.h_ctb); mu = std::max(mu, c.w4 * c.h4); mc = std::max(mc, c.w_ctb * c.h_ctb);
     if (b.desc[b.frame_stream[i]].rows != 1) row_mode = 0;
   }
+  if (b.wpp) { row_mode = 2; rbtk::dev_memset(b.d_zero, 0, b.zero_bytes); }   // every stream of the batch is in wavefront mode (encode_build checks)
   rbtk::timer_begin(T_ANALYSE);
   rbtk::launch_enc_analyse(b.d_frames, b.d_slices, b.d_lists + b.off_i, b.n_i, mc);
   rbtk::timer_end(T_ANALYSE);
   rbtk::timer_begin(T_ENCODE);
-  rbtk::launch_enc_intra(b.d_frames, b.d_slices, b.d_lists + b.off_i, b.n_i, mw, mh, row_mode, ml2);
+  rbtk::launch_enc_intra(b.d_frames, b.d_slices, b.d_lists + b.off_i, b.n_i, mw, mh, row_mode, ml2, (uint32_t*)b.d_zero);
   rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_ideb, b.n_ideb, mu);
   rbtk::launch_enc_sao(b.d_frames, b.d_slices, b.d_lists + b.off_isao, b.n_isao, mc);   // decides and applies
   rbtk::timer_end(T_ENCODE);
 }
 // entropy coding of the intra pictures' slices: needs nothing but their levels and CU data
 static int max_log2_ctb(const EncodeBatch& b) { int m = 0; for (auto& f : b.frames) m = std::max(m, (int)f.cfg.log2_ctb); return m; }
+static int max_w_ctb(const EncodeBatch& b) { int m = 0; for (auto& f : b.frames) m = std::max(m, (int)f.cfg.w_ctb); return m; }
+static int max_h_ctb(const EncodeBatch& b) { int m = 0; for (auto& f : b.frames) m = std::max(m, (int)f.cfg.h_ctb); return m; }
 static void encode_launch_entropy_intra(EncodeBatch& b) {
   rbtk::timer_begin(T_ENTROPY_I);
-  rbtk::launch_entropy(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_sl, b.n_sl_i, max_log2_ctb(b));
+  if (b.wpp) rbtk::launch_entropy_wave(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_i, b.n_i, max_w_ctb(b), max_h_ctb(b), max_log2_ctb(b), (uint32_t*)b.d_zero + 1);
+  else rbtk::launch_entropy(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_sl, b.n_sl_i, max_log2_ctb(b));
   rbtk::timer_end(T_ENTROPY_I);
 }
 // inter pictures (need the reconstructed intra pictures and their own sources), then the entropy coder for every slice
@@ -193,7 +211,8 @@ static void encode_launch_rest(EncodeBatch& b) {
   rbtk::launch_enc_sao(b.d_frames, b.d_slices, b.d_lists + b.off_psao, b.n_psao, mc);
   rbtk::timer_end(T_INTER);
   rbtk::timer_begin(T_ENTROPY);
-  rbtk::launch_entropy(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_sl_p, b.n_sl_p, max_log2_ctb(b));
+  if (b.wpp) rbtk::launch_entropy_wave(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_p, b.n_p, max_w_ctb(b), max_h_ctb(b), max_log2_ctb(b), (uint32_t*)b.d_zero + 2);
+  else rbtk::launch_entropy(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_sl_p, b.n_sl_p, max_log2_ctb(b));
   rbtk::timer_end(T_ENTROPY);
 }
 static int encode_launch(EncodeBatch& b) { encode_launch_intra(b); encode_launch_entropy_intra(b); encode_launch_rest(b); return 0; }
@@ -220,7 +239,7 @@ static int encode_finish(EncodeBatch& b, std::vector<std::vector<uint8_t>>& outs
     if (idr) write_param_sets(out, s, p);
     for (int k = 0; k < f.n_slices; k++) {
       const RbtSlice& sl = b.slices[f.first_slice + k];
-      SliceHdr h; h.first_slice_in_pic = k == 0; h.segment_addr = sl.ctb_addr; h.slice_type = sl.slice_type; h.poc = sl.poc; h.num_ref_idx = 1; h.max_merge_cand = 1; h.qp = sl.qp;
+      SliceHdr h; h.first_slice_in_pic = k == 0; h.dependent = sl.dependent; h.segment_addr = sl.ctb_addr; h.slice_type = sl.slice_type; h.poc = sl.poc; h.num_ref_idx = 1; h.max_merge_cand = 1; h.qp = sl.qp;
       h.sao_luma = sl.sao_luma; h.sao_chroma = sl.sao_chroma; h.deblocking_disabled = sl.deblocking_disabled; h.beta_offset_div2 = p.beta_offset_div2; h.tc_offset_div2 = p.tc_offset_div2; h.lf_across = sl.lf_across;
       BitWriter w; write_slice_header(w, s, p, h, idr, 0);
       w.b.insert(w.b.end(), packed.begin() + dst[f.first_slice + k], packed.begin() + dst[f.first_slice + k] + sl.out_size);

@@ -17,7 +17,7 @@ def ctx():
     c.close()
 
 
-@pytest.mark.parametrize("log2_ctb,rows", [(5, 1), (6, 0), (4, 2), (5, 0), (6, 1)])
+@pytest.mark.parametrize("log2_ctb,rows", [(5, 1), (6, 0), (4, 2), (5, 0), (6, 1), (5, -1), (6, -1), (4, -1)])   # rows -1: wavefront mode
 def test_encoder_bitstream_identical(ctx, log2_ctb, rows):
     m = synth.make_maps(256, 192, 41)
     for key, qp in (("geo", 24), ("attr", 32), ("geo", 40), ("attr", 12)):

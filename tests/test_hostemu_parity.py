@@ -29,7 +29,7 @@ def test_decode_stress_streams(ctx, seed):
     assert (dw, dh, dbd, chk, fail) == (w, h, bd, 5, 0) and np.array_equal(dec, rec)
 
 
-@pytest.mark.parametrize("log2_ctb,rows", [(5, 1), (6, 0), (4, 2)])
+@pytest.mark.parametrize("log2_ctb,rows", [(5, 1), (6, 0), (4, 2), (5, -1), (6, -1), (4, -1)])   # rows -1: wavefront mode (one dependent slice segment per CTB row)
 def test_encoder_and_transcode_bitstreams(ctx, log2_ctb, rows):
     R = rbt_lib.module()
     geo, attr, occ = synth.make_gof(128, 128, 2, 21)
