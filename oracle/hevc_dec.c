@@ -854,7 +854,7 @@ static void parse_sei(oracle_hevc_decoder* d, const uint8_t* rbsp, size_t n) {
 }
 
 /* ================================================================================================ API */
-/* every slice segment header of an Annex-B stream as the oracle's parser reads it, 18 ints per slice (tests/test_slice_headers.py pins them against the
+/* every slice segment header of an Annex-B stream as the oracle's parser reads it, 19 ints per slice (tests/test_slice_headers.py pins them against the
  * reference's TDecCavlc::parseSliceHeader, tests/golden/slices_*.json). Returns the slice count, -1 on a parse error. */
 int oracle_slice_headers(const uint8_t* p, size_t n, int* out, int cap) {
   oracle_hevc_decoder* d = (oracle_hevc_decoder*)calloc(1, sizeof(*d));
@@ -880,7 +880,7 @@ int oracle_slice_headers(const uint8_t* p, size_t n, int* out, int cap) {
           if (h.poc_lsb < prev_lsb && prev_lsb - h.poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb; else if (h.poc_lsb > prev_lsb && h.poc_lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
           h.poc = msb + h.poc_lsb; }
       }
-      if (!rc && k < cap) { int* o = out + 18 * k; int intra = h.slice_type == SLICE_I;
+      if (!rc && k < cap) { int* o = out + 19 * k; int intra = h.slice_type == SLICE_I; o[18] = h.dependent;
         o[0] = type; o[1] = h.segment_addr; o[2] = h.slice_type; o[3] = h.poc; o[4] = h.temporal_mvp; o[5] = h.sao_luma; o[6] = h.sao_chroma; o[7] = intra ? 0 : h.num_ref_idx[0];
         o[8] = h.cabac_init_flag; o[9] = intra ? 0 : h.collocated_ref_idx; o[10] = intra ? 0 : h.max_merge_cand; o[11] = h.qp; o[12] = h.cb_qp_offset; o[13] = h.cr_qp_offset;
         o[14] = h.deblocking_disabled; o[15] = h.beta_offset_div2; o[16] = h.tc_offset_div2; o[17] = h.loop_filter_across_slices; }

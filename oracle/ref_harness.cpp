@@ -82,11 +82,11 @@ int main(int argc, char** argv) {
         if (type == NAL_UNIT_PPS) {
           TComPPS* p = dec->getPPS(); dec->parsePPS(p);
           printf("%s{\"nal\":\"PPS\",\"init_qp\":%d,\"sign_hiding\":%d,\"cabac_init_present\":%d,\"num_ref_idx_l0\":%d,\"cip\":%d,\"transform_skip\":%d,"
-                 "\"cu_qp_delta\":%d,\"tq_bypass\":%d,\"lf_across_slices\":%d,\"deblock_ctrl\":%d,\"deblock_disabled\":%d,\"log2_par_mrg\":%d}\n", n++ ? "," : "",
+                 "\"cu_qp_delta\":%d,\"tq_bypass\":%d,\"lf_across_slices\":%d,\"deblock_ctrl\":%d,\"deblock_disabled\":%d,\"log2_par_mrg\":%d,\"dependent_slice_segments\":%d,\"entropy_coding_sync\":%d}\n", n++ ? "," : "",
                  26 + p->getPicInitQPMinus26(), (int)p->getSignDataHidingEnabledFlag(), (int)p->getCabacInitPresentFlag(), (int)p->getNumRefIdxL0DefaultActive(),
                  (int)p->getConstrainedIntraPred(), (int)p->getUseTransformSkip(), (int)p->getUseDQP(), (int)p->getTransquantBypassEnabledFlag(),
                  (int)p->getLoopFilterAcrossSlicesEnabledFlag(), (int)p->getDeblockingFilterControlPresentFlag(), (int)p->getPPSDeblockingFilterDisabledFlag(),
-                 2 + (int)p->getLog2ParallelMergeLevelMinus2());
+                 2 + (int)p->getLog2ParallelMergeLevelMinus2(), (int)p->getDependentSliceSegmentsEnabledFlag(), (int)p->getEntropyCodingSyncEnabledFlag());
         }
         if (i < size) { sc = data[i + 2] == 0 ? 4 : 3; index = i; i += sc; }
       }
@@ -131,13 +131,22 @@ int main(int argc, char** argv) {
         if (type < 32) {
           TComSlice slice; slice.initSlice(); slice.setNalUnitType((NalUnitType)type); slice.setTLayer(0);
           dec->parseSliceHeader(&slice, &psm, prevPoc);
-          printf("%s{\"nal_type\":%d,\"address\":%d,\"slice_type\":%d,\"poc\":%d,\"tmvp\":%d,\"sao_luma\":%d,\"sao_chroma\":%d,\"num_ref_idx\":%d,\"cabac_init\":%d,"
+          // a dependent slice segment carries nothing but its address: parseSliceHeader leaves the slice object as initSlice made it and the reference's
+          // caller fills it from the previous segment (TDecTop, copySliceInfo); the same is done here with the values of the slice's independent segment
+          static int v[16];
+          const int dep = slice.getDependentSliceSegmentFlag() ? 1 : 0;
+          if (!dep) {
+            v[0] = (int)slice.getSliceType(); v[1] = slice.getPOC(); v[2] = (int)slice.getEnableTMVPFlag(); v[3] = (int)slice.getSaoEnabledFlag(CHANNEL_TYPE_LUMA);
+            v[4] = (int)slice.getSaoEnabledFlag(CHANNEL_TYPE_CHROMA); v[5] = slice.isIntra() ? 0 : slice.getNumRefIdx(REF_PIC_LIST_0); v[6] = (int)slice.getCabacInitFlag();
+            v[7] = slice.isIntra() ? 0 : (int)slice.getColRefIdx(); v[8] = slice.isIntra() ? 0 : (int)slice.getMaxNumMergeCand(); v[9] = slice.getSliceQp();
+            v[10] = slice.getSliceChromaQpDelta(COMPONENT_Cb); v[11] = slice.getSliceChromaQpDelta(COMPONENT_Cr); v[12] = (int)slice.getDeblockingFilterDisable();
+            v[13] = slice.getDeblockingFilterBetaOffsetDiv2(); v[14] = slice.getDeblockingFilterTcOffsetDiv2(); v[15] = (int)slice.getLFCrossSliceBoundaryFlag();
+          }
+          printf("%s{\"nal_type\":%d,\"address\":%d,\"dependent\":%d,\"slice_type\":%d,\"poc\":%d,\"tmvp\":%d,\"sao_luma\":%d,\"sao_chroma\":%d,\"num_ref_idx\":%d,\"cabac_init\":%d,"
                  "\"col_ref_idx\":%d,\"max_merge_cand\":%d,\"qp\":%d,\"cb_qp_offset\":%d,\"cr_qp_offset\":%d,\"deblocking_disabled\":%d,\"beta_offset_div2\":%d,"
-                 "\"tc_offset_div2\":%d,\"lf_across\":%d}\n", n++ ? "," : "", type, (int)slice.getSliceSegmentCurStartCtuTsAddr(), (int)slice.getSliceType(), slice.getPOC(),
-                 (int)slice.getEnableTMVPFlag(), (int)slice.getSaoEnabledFlag(CHANNEL_TYPE_LUMA), (int)slice.getSaoEnabledFlag(CHANNEL_TYPE_CHROMA),
-                 slice.isIntra() ? 0 : slice.getNumRefIdx(REF_PIC_LIST_0), (int)slice.getCabacInitFlag(), slice.isIntra() ? 0 : (int)slice.getColRefIdx(),
-                 slice.isIntra() ? 0 : (int)slice.getMaxNumMergeCand(), slice.getSliceQp(), slice.getSliceChromaQpDelta(COMPONENT_Cb), slice.getSliceChromaQpDelta(COMPONENT_Cr),
-                 (int)slice.getDeblockingFilterDisable(), slice.getDeblockingFilterBetaOffsetDiv2(), slice.getDeblockingFilterTcOffsetDiv2(), (int)slice.getLFCrossSliceBoundaryFlag());
+                 "\"tc_offset_div2\":%d,\"lf_across\":%d}\n", n++ ? "," : "", type, (int)slice.getSliceSegmentCurStartCtuTsAddr(), dep, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9],
+                 v[10], v[11], v[12], v[13], v[14], v[15]);
+          if (dep) { prevPoc = v[1]; if (i < size) { sc = data[i + 2] == 0 ? 4 : 3; index = i; i += sc; } continue; }
           prevPoc = slice.getPOC();
         }
         if (i < size) { sc = data[i + 2] == 0 ? 4 : 3; index = i; i += sc; }

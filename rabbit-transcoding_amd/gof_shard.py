@@ -15,6 +15,9 @@ from typing import Dict, List, Sequence
 # cfg/rate/ctc-r{1..5}.cfg:5-11: geometryQP, attributeQP, occupancyPrecision
 RATE_POINTS = {1: (32, 42, 4), 2: (28, 37, 4), 3: (24, 32, 4), 4: (20, 27, 4), 5: (16, 22, 2)}
 VIDEO_OCCUPANCY, VIDEO_GEOMETRY, VIDEO_ATTRIBUTE = 0, 1, 19    # PCCVideoType (PCCBitstreamCommon.h:79-118)
+# encoder slice structure (rbt_stream_params.ctb_rows_per_slice): wavefront mode, one slice per picture coded as one dependent slice segment per CTB row
+# with entropy_coding_sync (libx265, which the reference encodes with, has wavefront rows on by default as well)
+DEFAULT_ROWS = -1
 
 
 def gof_lengths(n_frames: int, gof: int = 32) -> List[int]:
@@ -33,7 +36,7 @@ def rates_of_rank(rates: Sequence[int], rank: int, world: int) -> List[int]:
     return [r for i, r in enumerate(rates) if i % world == rank]
 
 
-def rate_params(R, rate: int, log2_ctb: int = 5, rows_per_slice: int = 1, md5_sei: int = 0):
+def rate_params(R, rate: int, log2_ctb: int = 5, rows_per_slice: int = DEFAULT_ROWS, md5_sei: int = 0):
     """rbt_stream_params of the [occupancy, geometry, attribute] sub-bitstreams for CTC rate point `rate` (1..5).
     R = the rabbit_transcoding_amd module (StreamParams)."""
     gq, aq, prec = RATE_POINTS[rate]

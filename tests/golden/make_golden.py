@@ -26,7 +26,8 @@ def main():
     cfgs = {"geo10_gop2": dict(w=64, h=64, bd=10, qp=24, gop=2, lossless=0, log2_ctb=5, rows=1),
             "occ8_lossless": dict(w=64, h=32, bd=8, qp=8, gop=1, lossless=1, log2_ctb=5, rows=1),
             "attr10_ctb64_oneslice": dict(w=128, h=64, bd=10, qp=22, gop=2, lossless=0, log2_ctb=6, rows=0),
-            "occ8_window_40x44": dict(w=40, h=44, bd=8, qp=8, gop=1, lossless=1, log2_ctb=5, rows=1)}   # coded 40x48, conformance window
+            "occ8_window_40x44": dict(w=40, h=44, bd=8, qp=8, gop=1, lossless=1, log2_ctb=5, rows=1),   # coded 40x48, conformance window
+            "geo10_wave": dict(w=64, h=64, bd=10, qp=24, gop=2, lossless=0, log2_ctb=5, rows=-1)}      # wavefront mode: entropy_coding_sync + dependent slice segments
     for name, c in cfgs.items():
         fr = np.full((2, c["w"] * c["h"] * 3 // 2), 100, np.uint16)
         bs, _ = O.encode(fr, c["w"], c["h"], c["bd"], c["qp"], gop=c["gop"], lossless=c["lossless"], log2_ctb=c["log2_ctb"], rows_per_slice=c["rows"])
@@ -40,6 +41,9 @@ def main():
     slice_goldens()
 
 
+WAVE_SEEDS = (13, 17)    # random-syntax streams with entropy_coding_sync (13: with dependent slice segments as well)
+
+
 def slice_goldens():
     """slices_<name>.annexb / .json: every slice segment header of oracle-coded streams through the reference's parseSliceHeader (hevc_hls_ref slices).
     The SPS fields that syntax depends on (the reference's parseSPS does not store them) are passed on the command line from the oracle's own settings."""
@@ -48,8 +52,9 @@ def slice_goldens():
     zeros = np.zeros((5, 96 * 64 * 3 // 2), np.uint16)
     cases = {"e1_geo_rows": (O.encode(m["geo"], 128, 128, 10, 24, gop=2, log2_ctb=5, rows_per_slice=1)[0], [8, 5, 1, 0, 1]),
              "e1_occ_lossless": (O.encode(m["occ"], 64, 64, 8, 8, gop=1, lossless=1, i_qp_offset=0, log2_ctb=5, rows_per_slice=1)[0], [8, 5, 0, 0, 1]),
-             "hm_attr": (O.encode_hm(m["attr"], 128, 128, 10, 22)[0], [8, 6, 1, 1, 1])}
-    for seed in (3, 7, 12, 21):       # random-syntax streams: several slices per picture, two references, TMVP, cabac_init, chroma offsets, deblocking overrides
+             "hm_attr": (O.encode_hm(m["attr"], 128, 128, 10, 22)[0], [8, 6, 1, 1, 1]),
+             "e1_geo_wave": (O.encode(m["geo"], 128, 128, 10, 24, gop=2, log2_ctb=5, rows_per_slice=-1)[0], [8, 5, 1, 0, 1])}   # wavefront mode: dependent slice segments, entry point syntax
+    for seed in WAVE_SEEDS + (3, 7, 12, 21):       # random-syntax streams: several slices per picture, two references, TMVP, cabac_init, chroma offsets, deblocking overrides
         bs = O.encode(zeros, 96, 64, 10, qp=30, gop=2, stress_seed=seed, log2_ctb=0)[0]
         sps = O.sps_fields(bs)
         cases[f"stress{seed}"] = (bs, [sps["log2_max_poc_lsb"], sps["log2_ctb"], sps["sao"], sps["tmvp"], sps["num_st_rps"]])

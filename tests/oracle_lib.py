@@ -209,15 +209,15 @@ def sps_fields(stream: bytes):
 
 
 SLICE_FIELDS = ("nal_type", "address", "slice_type", "poc", "tmvp", "sao_luma", "sao_chroma", "num_ref_idx", "cabac_init", "col_ref_idx", "max_merge_cand", "qp",
-                "cb_qp_offset", "cr_qp_offset", "deblocking_disabled", "beta_offset_div2", "tc_offset_div2", "lf_across")
+                "cb_qp_offset", "cr_qp_offset", "deblocking_disabled", "beta_offset_div2", "tc_offset_div2", "lf_across", "dependent")
 
 
 def slice_headers(stream: bytes, fn=None):
     """every slice segment header as the oracle's parser reads it (fn: another library's accessor with the same signature, e.g. the product's host parser)"""
     cap = 4096
-    out = (C.c_int * (18 * cap))()
+    out = (C.c_int * (19 * cap))()
     f = fn or lib().oracle_slice_headers
     n = f(stream, C.c_size_t(len(stream)), out, cap)
     if n < 0:
         raise RuntimeError("slice header parse failed")
-    return [dict(zip(SLICE_FIELDS, out[18 * k:18 * k + 18])) for k in range(n)]
+    return [dict(zip(SLICE_FIELDS, out[19 * k:19 * k + 19])) for k in range(n)]

@@ -88,7 +88,7 @@ def test_sequence_and_fanout_world2_equal_unsharded_and_oracle(hostemu):
     assert fan == gs.transcode_fanout(c, R, seq[2:], depth=1)
     c.close()
     # the oracle's transcodeData, GOF by GOF (PCCTranscoder.cpp:145-168)
-    assert out == [O.transcode_data(g, [(0, 8, 4, 5, 1, 0), (1, 24, 4, 5, 1, 0), (19, 32, 4, 5, 1, 0)]) for g in seq]
+    assert out == [O.transcode_data(g, [(0, 8, 4, 5, gs.DEFAULT_ROWS, 0), (1, 24, 4, 5, gs.DEFAULT_ROWS, 0), (19, 32, 4, 5, gs.DEFAULT_ROWS, 0)]) for g in seq]
     for r, (gq, aq, pr) in gs.RATE_POINTS.items():
-        assert fan[r] == [O.transcode_data(g, [(0, 8, pr, 5, 1, 0), (1, gq, pr, 5, 1, 0), (19, aq, pr, 5, 1, 0)]) for g in seq[2:]]
+        assert fan[r] == [O.transcode_data(g, [(0, 8, pr, 5, gs.DEFAULT_ROWS, 0), (1, gq, pr, 5, gs.DEFAULT_ROWS, 0), (19, aq, pr, 5, gs.DEFAULT_ROWS, 0)]) for g in seq[2:]]
     assert fan[5][0][0] == seq[2][0]       # R5 keeps occupancy precision 2: the reference does not touch the occupancy stream (:150)

@@ -52,4 +52,4 @@ def test_fixture_first_frame_transcode_vs_oracle(ctx):
     R = rbt_lib.module(); gs = rbt_lib.module_file("gof_shard")
     gof = [gs.split_pairs(_fixture(k))[0] for k in ("occ", "geo", "attr")]
     out = ctx.transcode_gof(gof, gs.rate_params(R, 3))
-    assert out == O.transcode_data(gof, [(0, 8, 4, 5, 1, 0), (1, 24, 4, 5, 1, 0), (19, 32, 4, 5, 1, 0)])
+    assert out == O.transcode_data(gof, [(0, 8, 4, 5, gs.DEFAULT_ROWS, 0), (1, 24, 4, 5, gs.DEFAULT_ROWS, 0), (19, 32, 4, 5, gs.DEFAULT_ROWS, 0)])

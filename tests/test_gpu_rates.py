@@ -29,7 +29,7 @@ def _gof(w, h, n_pc, seed):
 
 def _oracle(gof, rate):
     gq, aq, pr = gs.RATE_POINTS[rate]
-    return O.transcode_data(gof, [(0, 8, pr, 5, 1, 0), (1, gq, pr, 5, 1, 0), (19, aq, pr, 5, 1, 0)])
+    return O.transcode_data(gof, [(0, 8, pr, 5, gs.DEFAULT_ROWS, 0), (1, gq, pr, 5, gs.DEFAULT_ROWS, 0), (19, aq, pr, 5, gs.DEFAULT_ROWS, 0)])
 
 
 @pytest.mark.parametrize("rate", [1, 2, 3, 4, 5])

@@ -101,7 +101,8 @@ def test_transcode_substream_pipeline():
 @pytest.mark.parametrize("name,cfg", [("geo10_gop2", dict(w=64, h=64, bd=10, qp=24, gop=2, lossless=0, log2_ctb=5, rows=1)),
                                       ("occ8_lossless", dict(w=64, h=32, bd=8, qp=8, gop=1, lossless=1, log2_ctb=5, rows=1)),
                                       ("attr10_ctb64_oneslice", dict(w=128, h=64, bd=10, qp=22, gop=2, lossless=0, log2_ctb=6, rows=0)),
-                                      ("occ8_window_40x44", dict(w=40, h=44, bd=8, qp=8, gop=1, lossless=1, log2_ctb=5, rows=1, coded=(40, 48)))])
+                                      ("occ8_window_40x44", dict(w=40, h=44, bd=8, qp=8, gop=1, lossless=1, log2_ctb=5, rows=1, coded=(40, 48))),
+                                      ("geo10_wave", dict(w=64, h=64, bd=10, qp=24, gop=2, lossless=0, log2_ctb=5, rows=-1))])
 def test_parameter_sets_match_reference_parser_golden(name, cfg):
     """The committed hls_*.json is what the REFERENCE's TDecCavlc read from the oracle encoder's VPS/SPS/PPS."""
     fr = np.full((2, cfg["w"] * cfg["h"] * 3 // 2), 100, np.uint16)
@@ -116,6 +117,8 @@ def test_parameter_sets_match_reference_parser_golden(name, cfg):
     assert (sps["width"], sps["height"], sps["bit_depth"], sps["bit_depth_c"], sps["chroma_format"]) == (cw, ch, cfg["bd"], cfg["bd"], 1)
     assert pps["init_qp"] == cfg["qp"] and pps["tq_bypass"] == cfg["lossless"] and pps["deblock_disabled"] == cfg["lossless"]
     assert pps["sign_hiding"] == 0 and pps["cu_qp_delta"] == 0 and pps["log2_par_mrg"] == 2 and pps["num_ref_idx_l0"] == 1
+    wave = int(cfg["rows"] < 0)
+    assert (pps["entropy_coding_sync"], pps["dependent_slice_segments"]) == (wave, wave)
 
 
 def test_hm_like_encoder_round_trip_and_toolset():
