@@ -126,6 +126,7 @@ typedef struct {
   uint8_t an_mode[4][64]; int an_cost[4][64]; uint8_t an_split[4][64];   /* [size idx 0:8 1:16 2:32 3:64][block] */
   /* HM-like mode (hm_like) */
   int hm, hm_pass, in_trial, hm_force_intra;
+  int tu_rd;                   /* transform trees are decided by coding both ways (hm_decide_tu_split): the HM-like mode (two levels) and RBT-E1 intra CUs (one level) */
   struct { long ts, tb4, nxn, cu_intra, cu_inter, cu_skip, tu_split, part2, amp, merge, amvp, frac_mv, nonzero_mv, sao_band, sao_edge, sao_merge, sao_off, intra_in_p; } hs;   /* tool usage (ORACLE_HM_STATS=1 prints it) */
   struct { uint8_t split, intra, part; int16_t mv[2][2]; } hn[4][64];   /* P pictures: decision per CU node [size idx][block] */
   uint8_t hm_nxn[64], hm_nxn_mode[64][4], hm_chroma[3][64];               /* intra: NxN at 8x8, chroma mode index per block */
@@ -511,16 +512,16 @@ static int recon_tb(enc* e, int c_idx, int x0, int y0, int log2, int intra_mode,
     for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) lv[y * 64 + x] = lq[y * N + x];
   }
   *ts_out = ts;
-  if (e->hm) { e->last_bits = hm_level_bits(lq, N * N); e->last_ssd = 0; if (!cbf) for (int i = 0; i < N * N; i++) e->last_ssd += (int64_t)res[i] * res[i]; }
+  if (e->tu_rd) { e->last_bits = hm_level_bits(lq, N * N); e->last_ssd = 0; if (!cbf) for (int i = 0; i < N * N; i++) e->last_ssd += (int64_t)res[i] * res[i]; }
   if (!cbf) return 0;
-  int16_t res_src[32 * 32]; if (e->hm) memcpy(res_src, res, sizeof(int16_t) * N * N);
+  int16_t res_src[32 * 32]; if (e->tu_rd) memcpy(res_src, res, sizeof(int16_t) * N * N);
   if (e->cu_tq_bypass) memcpy(res, lq, sizeof(int16_t) * N * N);
   else {
     hevc_dequant(lq, dq, log2, qp, bd);
     if (ts) hevc_inv_transform_skip(dq, res, log2, bd); else hevc_inv_transform(dq, res, log2, is_dst, bd);
   }
   for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) p[(size_t)y * pw + x] = (uint16_t)clip3(0, maxv, p[(size_t)y * pw + x] + res[y * N + x]);
-  if (e->hm) for (int i = 0; i < N * N; i++) { int d = res_src[i] - res[i]; e->last_ssd += (int64_t)d * d; }
+  if (e->tu_rd) for (int i = 0; i < N * N; i++) { int d = res_src[i] - res[i]; e->last_ssd += (int64_t)d * d; }
   return 1;
 }
 
@@ -547,6 +548,10 @@ static int hm_decide_tu_split(enc* e, int x0, int y0, int log2) {
   int part = nxn ? ((y0 - e->cu_y) >= half_cu ? 2 : 0) + ((x0 - e->cu_x) >= half_cu ? 1 : 0) : 0;
   recon_tb(e, 0, x0, y0, log2, e->intra_luma[part], &ts);
   c_whole = e->last_ssd * 256 + lam * e->last_bits;
+  if (!e->hm && e->last_ssd * 256 < (lam >> 2) * N * N) {   /* RBT-E1: a block that one transform codes to within lambda^2 / 4 per sample is not tried as four */
+    for (int y = 0; y < N; y++) { memcpy(f->p[0] + (size_t)(y0 + y) * f->w + x0, save + y * N, (size_t)N * 2); memcpy(lv0 + y * 64, lsave + y * N, (size_t)N * 2); }
+    e->in_trial = 0; return 0;
+  }
   for (int y = 0; y < N; y++) memcpy(f->p[0] + (size_t)(y0 + y) * f->w + x0, save + y * N, (size_t)N * 2);
   for (int b = 0; b < 4; b++) {
     int xs = x0 + (b & 1) * h, ys = y0 + (b >> 1) * h;
@@ -570,7 +575,7 @@ static int tt_recon(enc* e, int x0, int y0, int xb, int yb, int log2, int depth,
   int inter_split = sps->max_th_depth_inter == 0 && e->cu_pred_mode != MODE_INTRA && e->cu_part_mode != PART_2Nx2N && depth == 0;
   int split;
   if (log2 <= sps->log2_max_tb && log2 > sps->log2_min_tb && depth < e->max_trafo_depth && !(intra_split && depth == 0))
-    split = e->stress ? rndp(&e->r, 35) : (e->hm && !e->in_trial && depth < 2 ? hm_decide_tu_split(e, x0, y0, log2) : 0);
+    split = e->stress ? rndp(&e->r, 35) : (e->tu_rd && !e->in_trial && depth < 2 ? hm_decide_tu_split(e, x0, y0, log2) : 0);
   else split = (log2 > sps->log2_max_tb || (intra_split && depth == 0) || inter_split) ? 1 : 0;
   nd->split = (uint8_t)split;
   if (split && e->hm && e->hm_pass != 1 && log2 <= sps->log2_max_tb && !(intra_split && depth == 0)) e->hs.tu_split++;
@@ -1353,6 +1358,8 @@ static void setup_stream(enc* e) {
   e->max_merge_cand = 1;
   if (q->lossless) { p->transquant_bypass_enabled = 1; p->deblocking_control_present = 1; p->pps_deblocking_disabled = 1; p->loop_filter_across_slices = 0; }
   if (!e->stress && !e->hm && !q->lossless && e1_sao_on()) s->sao_enabled = 1;
+  e->tu_rd = e->hm;
+  if (!e->stress && !e->hm && !q->lossless) { s->max_th_depth_intra = 1; e->tu_rd = 1; }   /* RBT-E1: an intra CU is one transform unit or four, whichever codes its luma cheaper */
   if (!e->stress && !e->hm && q->ctb_rows_per_slice < 0) { p->entropy_coding_sync = 1; p->dependent_slice_segments_enabled = 1; }   /* wavefront rows, one dependent slice segment each */
   if (e->hm) {   /* cfg/hm/ctc-hm-geometry-ai.cfg:10-16,47,68,69 + HM defaults (SignHideFlag, TMVPMode, MaxNumMergeCand) */
     s->log2_ctb = q->log2_ctb ? q->log2_ctb : 6; s->log2_diff_max_min_cb = s->log2_ctb - 3;

@@ -297,6 +297,7 @@ RBT_DEV int en_code_tb(RbtFrame* f, int c_idx, int x0, int y0, int log2, int qp,
   RBT_SYNC();
   return nz != 0;
 }
+// (a CU of 16 or 32 coded as four transform units calls this once per unit: the unit's left and top borders are transform edges for the deblocking filter)
 RBT_DEV void en_fill_cu_maps(RbtFrame* f, int x0, int y0, int N, int pm_val, int qp_y, int cbf_bits_or_flags, int set_flags) {
   const RbtStreamCfg* g = &f->cfg;
   int n4 = N >> 2, n8 = N >> 3;
@@ -327,6 +328,9 @@ template <int TL2> struct RbtEncTileT {
   uint8_t uav[((1 << (TL2 - 2)) + 1) * RC_US];
   uint16_t sb[32 * 32 + 2 * 16 * 16];                        // source samples of the current CU: Y, Cb, Cr
   uint8_t cu_l2[64], cu_md[64];                              // cu_log2 / cu_mode of the CTB's 8x8 units (analysis result)
+  // one TU or four (en_intra_cu_luma): levels and reconstruction of the CU's luma coded as ONE transform block, kept while it is coded as four;
+  // levels of the current quarter; source samples of the current quarter (luma, or Cb at 0 and Cr at 256)
+  int16_t lv0[32 * 32]; uint16_t rec0[32 * 32]; int16_t lv1[16 * 16]; uint16_t ss[512];
 };
 // TB scratch of the intra-coding kernel: the core + the prediction. The smoothed / angular reference arrays alias `tmp` (dead until
 // the forward transform) and the quantised levels alias the luma part of `sb` (the source samples are consumed when the residual is
@@ -336,9 +340,12 @@ template <int TL2> struct RbtEncTileLdsT { RbtEncIntraScratch rc; RbtEncTileT<TL
 RBT_DEV int en_quant_scale(int r) { const uint64_t lo = 26214ull | (23302ull << 16) | (20560ull << 32) | (18396ull << 48), hi = 16384ull | (14564ull << 16); return (int)(((r < 4 ? lo : hi) >> (16 * (r & 3))) & 0xFFFF); }
 // one intra TB: (x0,y0) relative to the CTB and (gx,gy) in the picture, both in samples of component c_idx; returns cbf
 template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int c_idx, int x0, int y0, int gx, int gy, int log2, int mode, int qp,
-                             const RBT_LDS_AS uint16_t* src, int mark_l4, int mux, int muy) {
+                             const RBT_LDS_AS uint16_t* src, int mark_l4, int mux, int muy, RBT_LDS_AS int16_t* lvl_buf = nullptr, long long* cost = nullptr, int lam2 = 0, int* ssd_out = nullptr) {
   RBT_LDS_AS RbtEncIntraScratch* r = &L->rc; RBT_LDS_AS RbtEncTileT<TL2>* t = &L->t;
-  RBT_LDS_AS int32_t* const r_nbf = (RBT_LDS_AS int32_t*)r->tmp; RBT_LDS_AS int32_t* const r_ref = r_nbf + 132; RBT_LDS_AS int16_t* const lvl = (RBT_LDS_AS int16_t*)t->sb;
+  // lvl_buf: where the levels go (default: over the luma part of `sb`, i.e. over the source once the residual is formed). cost (needs a lvl_buf that leaves
+  // `src` alone): distortion * 256 + lam2 * rate of the block as the oracle's recon_tb / hm_decide_tu_split count them - squared error of the residual
+  // against its reconstruction (before clipping), 3 + 2 * floor(log2 |level|) bits per non-zero level plus 3, or 1 bit for an empty block
+  RBT_LDS_AS int32_t* const r_nbf = (RBT_LDS_AS int32_t*)r->tmp; RBT_LDS_AS int32_t* const r_ref = r_nbf + 132; RBT_LDS_AS int16_t* const lvl = lvl_buf ? lvl_buf : (RBT_LDS_AS int16_t*)t->sb;
   const int N = 1 << log2, sh = c_idx ? 1 : 0, bd = g->bit_depth, maxv = (1 << bd) - 1, n4 = (1 << g->log2_ctb) >> 2, pw = c_idx ? g->cw : g->w;
   RBT_LDS_AS uint16_t* tile = c_idx == 0 ? t->y : t->c[c_idx - 1]; const int S = c_idx == 0 ? RbtEncTileT<TL2>::TS_Y : RbtEncTileT<TL2>::TS_C;
   const RBT_LDS_AS uint16_t* top = c_idx == 0 ? t->top_y : t->top_c[c_idx - 1];
@@ -395,8 +402,54 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
     tile[(y0 + y) * S + x0 + x + 1] = (uint16_t)(nz ? rbt_clip3(0, maxv, (int)r->pred[i] + r->res[i]) : r->pred[i]);
   }
   if (mark_l4 >= 0) { RBT_PAR_FOR(i, 1 << (2 * mark_l4)) t->uav[(muy + (i >> mark_l4) + 1) * RC_US + mux + (i & ((1 << mark_l4) - 1)) + 1] = 1; }
+  if (cost) {
+    int ps = 0, pb = 0;
+    RBT_PAR_FOR(i, N * N) {
+      const int d = (int)src[i] - (int)r->pred[i] - (nz ? (int)r->res[i] : 0), a = rbt_abs((int)lvl[i]);
+      ps += d * d;                                                       // at most 16 samples per lane and 1024 per block: fits 32 bits
+      if (a) pb += 3 + 2 * (31 - __builtin_clz((unsigned)a));
+    }
+    const int ssd = en_wave_sum(ps, (RBT_LDS_AS RbtEncLds*)0), bits = en_wave_sum(pb, (RBT_LDS_AS RbtEncLds*)0);
+    *cost = (long long)ssd * 256 + (long long)lam2 * (bits ? bits + 3 : 1);
+    if (ssd_out) *ssd_out = ssd;
+  }
   RBT_SYNC_LDS();
   return nz != 0;
+}
+// Luma of one intra CU of a stream with max_transform_hierarchy_depth_intra = 1 (RBT-E1, not lossless): coded as one transform block, then as four
+// (each quarter predicted from the reconstruction so far, quarters before it included) unless one block already codes it to within lambda^2 / 4 per
+// sample, and the cheaper way is kept (oracle/hevc_enc.c
+// hm_decide_tu_split: luma only, distortion * 256 + lambda^2 * rate, 3 lambda^2 for the split). Returns the luma cbf of the CU, or with *split = 1 the
+// cbf of quarter i in bit i. On return the tile holds the chosen reconstruction, the coefficient plane the chosen levels and every 4x4 unit of the CU
+// is marked available.
+template <int TL2> RBT_DEV int en_intra_cu_luma(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int x0, int y0, int gx, int gy, int lg, int mode, int qp, int lam2, int* split) {
+  RBT_LDS_AS RbtEncTileT<TL2>* t = &L->t;
+  const int N = 1 << lg, h = N >> 1, S = RbtEncTileT<TL2>::TS_Y;
+  long long c_whole = 0, c_split = 3ll * lam2, cq = 0;
+  int ssd0 = 0;
+  const int cbf0 = en_tile_intra_tb(g, f, L, 0, x0, y0, gx, gy, lg, mode, qp, t->sb, -1, 0, 0, t->lv0, &c_whole, lam2, &ssd0);
+  *split = 0;
+  if ((long long)ssd0 * 256 < (long long)(lam2 >> 2) * N * N) {     // coded to within lambda^2 / 4 per sample by one transform: not tried as four
+    RBT_PAR_FOR(i, 1 << (2 * (lg - 2))) t->uav[((y0 >> 2) + (i >> (lg - 2)) + 1) * RC_US + (x0 >> 2) + (i & ((1 << (lg - 2)) - 1)) + 1] = 1;
+    RBT_SYNC_LDS();
+    return cbf0;
+  }
+  RBT_PAR_FOR(i, N * N) t->rec0[i] = t->y[(y0 + (i >> lg)) * S + x0 + (i & (N - 1)) + 1];
+  RBT_SYNC_LDS();
+  int cbf1 = 0;
+  for (int b = 0; b < 4; b++) {
+    const int ox = (b & 1) * h, oy = (b >> 1) * h;
+    RBT_PAR_FOR(i, h * h) t->ss[i] = t->sb[(oy + (i >> (lg - 1))) * N + ox + (i & (h - 1))];
+    RBT_SYNC_LDS();
+    if (en_tile_intra_tb(g, f, L, 0, x0 + ox, y0 + oy, gx + ox, gy + oy, lg - 1, mode, qp, t->ss, lg - 3, (x0 + ox) >> 2, (y0 + oy) >> 2, t->lv1, &cq, lam2)) cbf1 |= 1 << b;
+    c_split += cq;
+  }
+  *split = c_split < c_whole;
+  if (*split) return cbf1;
+  RBT_PAR_FOR(i, N * N) t->y[(y0 + (i >> lg)) * S + x0 + (i & (N - 1)) + 1] = t->rec0[i];
+  { int16_t* cp = f->coef[0] + (size_t)gy * g->w + gx; RBT_PAR_FOR(i, N * N) cp[(size_t)(i >> lg) * g->w + (i & (N - 1))] = t->lv0[i]; }
+  RBT_SYNC_LDS();
+  return cbf0;
 }
 // Cb and Cr TB of one CU in the same passes (see rc_tile_tb_cpair); returns cbf_cb | cbf_cr << 1. src: Cb block, then Cr at +256.
 template <int TL2> RBT_DEV int en_tile_intra_tb_cpair(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int x0, int y0, int gx, int gy, int log2, int mode, int qp_cb, int qp_cr,
@@ -497,6 +550,7 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
   const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
   const int qp_y = sl->qp, bd = g->bit_depth;
   const int qp_l = qp_y + 6 * (bd - 8), qp_cb = en_chroma_qp(f, sl, 1, qp_y), qp_cr = en_chroma_qp(f, sl, 2, qp_y);
+  const int tu_rd = !f->lossless && g->th_depth_intra > 0, lam16 = k_lambda16[rbt_clip3(0, 75, qp_l)], lam2 = lam16 * lam16;
   // ---- borders, unit availability, analysis results ----
   for (int c = 0; c < 3; c++) {
     const int sh = c ? 1 : 0, nn = ctb >> sh, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, ox = cx >> sh, oy = cy >> sh, S = c ? RbtEncTileT<TL2>::TS_C : RbtEncTileT<TL2>::TS_Y;
@@ -530,11 +584,31 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
     { const uint16_t* sp = f->src[0] + (size_t)(cy + y0) * g->w + cx + x0; RBT_PAR_FOR(i, N * N) t->sb[i] = sp[(size_t)(i >> lg) * g->w + (i & (N - 1))]; }
     for (int q = 0; q < 2; q++) { const uint16_t* sp = f->src[1 + q] + (size_t)((cy + y0) >> 1) * g->cw + ((cx + x0) >> 1); RBT_PAR_FOR(i, Nc * Nc) t->sb[1024 + 256 * q + i] = sp[(size_t)(i >> (lg - 1)) * g->cw + (i & (Nc - 1))]; }
     RBT_SYNC();
-    int cbf = en_tile_intra_tb(g, f, L, 0, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, t->sb, lg - 2, x0 >> 2, y0 >> 2) ? RBT_CU_CBF_Y : 0;
+    int split = 0, cbf = 0, cy4 = 0;
+    if (tu_rd) cy4 = en_intra_cu_luma(g, f, L, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, lam2, &split);
+    else cy4 = en_tile_intra_tb(g, f, L, 0, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, t->sb, lg - 2, x0 >> 2, y0 >> 2);
+    if (split && lg >= 4) {
+      // four transform units, each with its own Cb / Cr blocks: chroma block b is predicted when the units 0..b of the CU are reconstructed, not more
+      const int hh = N >> 1, hc = Nc >> 1, n4u = hh >> 2;
+      RBT_PAR_FOR(i, 4 * n4u * n4u) { const int ux = i % (2 * n4u), uy = i / (2 * n4u); t->uav[((y0 >> 2) + uy + 1) * RC_US + (x0 >> 2) + ux + 1] = 0; }
+      RBT_SYNC_LDS();
+      for (int b = 0; b < 4; b++) {
+        const int ox = (b & 1) * hh, oy = (b >> 1) * hh;
+        RBT_PAR_FOR(i, n4u * n4u) t->uav[(((y0 + oy) >> 2) + i / n4u + 1) * RC_US + ((x0 + ox) >> 2) + i % n4u + 1] = 1;
+        RBT_PAR_FOR(i, 2 * hc * hc) { const int q = i >= hc * hc, j = i - q * hc * hc; t->ss[q * 256 + j] = t->sb[1024 + 256 * q + ((oy >> 1) + j / hc) * Nc + (ox >> 1) + j % hc]; }
+        RBT_SYNC_LDS();
+        const int cc = en_tile_intra_tb_cpair(g, f, L, (x0 + ox) >> 1, (y0 + oy) >> 1, (cx + x0 + ox) >> 1, (cy + y0 + oy) >> 1, lg - 2, mode, qp_cb, qp_cr, t->ss);
+        const int fl = RBT_CU_TU_SPLIT | ((cy4 >> b) & 1 ? RBT_CU_CBF_Y : 0) | ((cc & 1) ? RBT_CU_CBF_CB : 0) | ((cc & 2) ? RBT_CU_CBF_CR : 0);
+        en_fill_cu_maps(f, cx + x0 + ox, cy + y0 + oy, hh, RBT_MODE_INTRA | ((fl & RBT_CU_CBF_Y) ? RBT_PM_NZ : 0), qp_y, fl, 1);
+      }
+      continue;
+    }
     { const int cc = en_tile_intra_tb_cpair(g, f, L, x0 >> 1, y0 >> 1, (cx + x0) >> 1, (cy + y0) >> 1, lg - 1, mode, qp_cb, qp_cr, t->sb + 1024);
       if (cc & 1) cbf |= RBT_CU_CBF_CB;
       if (cc & 2) cbf |= RBT_CU_CBF_CR; }
-    en_fill_cu_maps(f, cx + x0, cy + y0, N, RBT_MODE_INTRA | (f->lossless ? RBT_PM_TQ_BYPASS : 0) | ((cbf & RBT_CU_CBF_Y) ? RBT_PM_NZ : 0), qp_y, cbf, 1);
+    if (split) cbf |= RBT_CU_TU_SPLIT | ((cy4 & 1) ? RBT_CU_CBF_Y : 0) | ((cy4 >> 1) * RBT_CU_CBF_Y1);   // 8x8 CU as four 4x4 luma blocks: their cbf bits
+    else if (cy4) cbf |= RBT_CU_CBF_Y;
+    en_fill_cu_maps(f, cx + x0, cy + y0, N, RBT_MODE_INTRA | (f->lossless ? RBT_PM_TQ_BYPASS : 0) | (cy4 ? RBT_PM_NZ : 0), qp_y, cbf, 1);
   }
   // ---- write the CTB back (clipped to the picture) ----
   for (int c = 0; c < 3; c++) {
@@ -603,7 +677,7 @@ RBT_DEV void en_inter_ctb(RbtFrame* frames, RbtFrame* f, const RbtSlice* slices,
 
 // ------------------------------------------------------------------------------------------------ entropy coding
 struct RbtEnt { RbtFrame* f; const RbtSlice* sl; int slice_idx; RbtCabacEnc c; RBT_LDS_AS RbtEntropyLds* l;
-                int w, h, log2_ctb, log2_min_cb, tq_bypass_enabled, is_p, cx, cy;
+                int w, h, log2_ctb, log2_min_cb, tq_bypass_enabled, is_p, cx, cy, th_intra;
 #ifdef RBT_PROFILE
                 unsigned long long t_stage, t_res, t_cu, t_resA, t_resB; unsigned n_cu, n_tb, n_bins;
 #endif
@@ -807,15 +881,55 @@ RBT_DEV void en_write_cu(RbtEnt* s, int x0, int y0, int log2, int depth) {
     }
     rbt_ce_bin0(c, CTX_INTRA_CHROMA, 0);             // intra_chroma_pred_mode = 4 (DM)
   }
-  // transform tree: one TU per CU (max_transform_hierarchy_depth = 0, no split flag)
+  const int intra = !is_p;
+  const int ctb = 1 << s->log2_ctb, rx0 = x0 - s->cx, ry0 = y0 - s->cy;
+  // transform tree (7.3.8.8): inter CUs are one TU (max_transform_hierarchy_depth_inter = 0, no flag); intra CUs of a stream with
+  // max_transform_hierarchy_depth_intra = 1 are one TU or four (split_transform_flag at depth 0)
+  if (intra && s->th_intra > 0) {
+    const int split = (flags & RBT_CU_TU_SPLIT) != 0;
+    rbt_ce_bin0(c, CTX_SPLIT_TRANSFORM + 5 - log2, split);
+    if (split) {
+      const int h = 1 << (log2 - 1);
+      int fl[4], pcb = cbf_cb, pcr = cbf_cr;
+      if (log2 > 3) {   // the 8x8 units of a quarter carry that quarter's cbf bits
+        pcb = pcr = 0;
+        for (int b = 0; b < 4; b++) { fl[b] = RBT_UNI(l->cu_fl[en_u(s, x0 + (b & 1) * h, y0 + (b >> 1) * h)]); pcb |= (fl[b] & RBT_CU_CBF_CB) != 0; pcr |= (fl[b] & RBT_CU_CBF_CR) != 0; }
+      } else for (int b = 0; b < 4; b++) fl[b] = (flags & (b ? RBT_CU_CBF_Y1 << (b - 1) : RBT_CU_CBF_Y)) ? RBT_CU_CBF_Y : 0;
+      rbt_ce_bin0(c, CTX_CBF_CHROMA + 0, pcb);
+      rbt_ce_bin0(c, CTX_CBF_CHROMA + 0, pcr);
+#ifdef RBT_PROFILE
+      unsigned long long tr_ = __builtin_readcyclecounter(); s->t_cu += tr_ - tc_;
+#endif
+      for (int b = 0; b < 4; b++) {
+        const int qx = rx0 + (b & 1) * h, qy = ry0 + (b >> 1) * h;
+        int qcb = 0, qcr = 0;
+        if (log2 > 3) {
+          if (pcb) { qcb = (fl[b] & RBT_CU_CBF_CB) != 0; rbt_ce_bin0(c, CTX_CBF_CHROMA + 1, qcb); }
+          if (pcr) { qcr = (fl[b] & RBT_CU_CBF_CR) != 0; rbt_ce_bin0(c, CTX_CBF_CHROMA + 1, qcr); }
+        }
+        const int qy_cbf = (fl[b] & RBT_CU_CBF_Y) != 0;
+        rbt_ce_bin0(c, CTX_CBF_LUMA + 0, qy_cbf);
+        if (qy_cbf) en_write_residual(s, 0, en_lv(l, 0, s->log2_ctb) + qy * ctb + qx, ctb, log2 - 1, en_scan_idx(1, log2 - 1, 0, mode));
+        if (log2 > 3) {
+          if (qcb) en_write_residual(s, 1, en_lv(l, 1, s->log2_ctb) + (qy >> 1) * (ctb >> 1) + (qx >> 1), ctb >> 1, log2 - 2, en_scan_idx(1, log2 - 2, 1, mode));
+          if (qcr) en_write_residual(s, 2, en_lv(l, 2, s->log2_ctb) + (qy >> 1) * (ctb >> 1) + (qx >> 1), ctb >> 1, log2 - 2, en_scan_idx(1, log2 - 2, 2, mode));
+        } else if (b == 3) {   // 4x4 luma blocks: the chroma blocks of the 8x8 unit follow the fourth
+          if (pcb) en_write_residual(s, 1, en_lv(l, 1, s->log2_ctb) + (ry0 >> 1) * (ctb >> 1) + (rx0 >> 1), ctb >> 1, 2, en_scan_idx(1, 2, 1, mode));
+          if (pcr) en_write_residual(s, 2, en_lv(l, 2, s->log2_ctb) + (ry0 >> 1) * (ctb >> 1) + (rx0 >> 1), ctb >> 1, 2, en_scan_idx(1, 2, 2, mode));
+        }
+      }
+#ifdef RBT_PROFILE
+      s->t_res += __builtin_readcyclecounter() - tr_;
+#endif
+      return;
+    }
+  }
   rbt_ce_bin0(c, CTX_CBF_CHROMA + 0, cbf_cb);
   rbt_ce_bin0(c, CTX_CBF_CHROMA + 0, cbf_cr);
   if (!is_p || cbf_cb || cbf_cr) rbt_ce_bin0(c, CTX_CBF_LUMA + 1, cbf_y);
-  const int intra = !is_p;
 #ifdef RBT_PROFILE
   unsigned long long tr_ = __builtin_readcyclecounter(); s->t_cu += tr_ - tc_;
 #endif
-  const int ctb = 1 << s->log2_ctb, rx0 = x0 - s->cx, ry0 = y0 - s->cy;
   if (cbf_y) en_write_residual(s, 0, en_lv(l, 0, s->log2_ctb) + ry0 * ctb + rx0, ctb, log2, en_scan_idx(intra, log2, 0, mode));
   if (cbf_cb) en_write_residual(s, 1, en_lv(l, 1, s->log2_ctb) + (ry0 >> 1) * (ctb >> 1) + (rx0 >> 1), ctb >> 1, log2 - 1, en_scan_idx(intra, log2 - 1, 1, mode));
   if (cbf_cr) en_write_residual(s, 2, en_lv(l, 2, s->log2_ctb) + (ry0 >> 1) * (ctb >> 1) + (rx0 >> 1), ctb >> 1, log2 - 1, en_scan_idx(intra, log2 - 1, 2, mode));
@@ -981,6 +1095,7 @@ RBT_DEV void en_entropy_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx,
   RbtEnt s; s.sl = &slices[slice_idx]; s.f = &frames[RBT_UNI(s.sl->frame)]; s.slice_idx = slice_idx; s.l = l;
   const RbtSlice* sl = s.sl; const RbtStreamCfg* g = &s.f->cfg;
   s.w = RBT_UNI(g->w); s.h = RBT_UNI(g->h); s.log2_ctb = RBT_UNI(g->log2_ctb); s.log2_min_cb = RBT_UNI(g->log2_min_cb); s.tq_bypass_enabled = RBT_UNI(g->tq_bypass_enabled);
+  s.th_intra = RBT_UNI(g->th_depth_intra);
   s.is_p = RBT_UNI(sl->slice_type) == RBT_SLICE_P; s.cx = s.cy = 0;
   RBT_PAR_FOR(i, 3 * 4 * 64) l->scan[i / 256][(i / 64) & 3][i & 63] = k_scan_packed(i / 256, (i / 64) & 3, i & 63);
   rbt_ctx_init(&s.c.cs, s.is_p ? 1 : 0, RBT_UNI(sl->qp));

@@ -98,6 +98,10 @@ struct RbtFrame {
 #define RBT_CU_CBF_CB 2
 #define RBT_CU_CBF_CR 4
 #define RBT_CU_SKIP 8
+// intra CU coded as four transform units (RBT-E1 codes an intra CU as one TU or four): in CUs of 16 and 32 every 8x8 unit then carries the cbf bits of
+// the TU that covers it; in an 8x8 CU the luma cbf of the 4x4 TUs 1..3 sits in the three bits above (TU 0 in RBT_CU_CBF_Y), Cb / Cr are the CU's
+#define RBT_CU_TU_SPLIT 16
+#define RBT_CU_CBF_Y1 32
 
 struct RbtSlice;
 struct RbtFrame;
