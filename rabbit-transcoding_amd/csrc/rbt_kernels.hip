@@ -360,7 +360,13 @@ void launch_enc_analyse(RbtFrame* frames, const RbtSlice* slices, const int32_t*
   if (n_frames <= 0) return;
   hipLaunchKernelGGL(k_enc_analyse, dim3(max_ctbs, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
 }
-static int wave_rows_in_flight(int max_w_ctb, int max_h_ctb) { int K = (max_w_ctb + 1) / 2; if (K < 1) K = 1; return K > max_h_ctb ? max_h_ctb : K; }
+// Waves per picture of the wavefront kernels. w_ctb / 2 is all a picture can use (two-CTB lag between rows) and gives the shortest launch; while the first
+// rows ramp up and the last ramp down those waves wait, holding their LDS. With many jobs in flight the GPU is full anyway and idle residents only take
+// room from the other jobs' kernels: an eighth of the width then (measured with 16 GOFs in flight, 1280 x 1280, 40 CTBs wide: 625 / 642 / 660 / 631 / 548
+// frames/s with 20 / 10 / 5 / 4 / 2 waves per picture). set_jobs_in_flight; RBT_WAVE_DIV overrides the divisor.
+static int g_wave_div = 2;
+void set_jobs_in_flight(int depth) { static int env = -1; if (env < 0) { const char* e = getenv("RBT_WAVE_DIV"); env = e ? atoi(e) : 0; } g_wave_div = env > 0 ? env : (depth > 4 ? 8 : 2); }
+static int wave_rows_in_flight(int max_w_ctb, int max_h_ctb) { int K = (max_w_ctb + g_wave_div - 1) / g_wave_div; if (K < 1) K = 1; return K > max_h_ctb ? max_h_ctb : K; }
 void launch_enc_intra(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int row_mode, int max_log2_ctb, uint32_t* ticket) {
   if (n_frames <= 0) return;
   const bool small = max_log2_ctb <= 5;

@@ -405,7 +405,7 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return bytes_of(a) > bytes_of(b); });
   const int aux = job_stream(j, rbtk::RBT_AUX_STREAM);
   bind_streams(j, depth);
-  recon_set_depth(depth);
+  recon_set_depth(depth); rbtk::set_jobs_in_flight(depth);
   // ---- phase A, longest pipeline first: build decoder and encoder batches and upload them; then enqueue decode -> pool ->
   // encode on the stream without a host round trip in between (PCCTranscoder.cpp:428-448, :466, :825-904). Every upload of
   // the job is issued before its first kernel: a copy from pageable memory blocks the host until the stream has reached it,
