@@ -273,6 +273,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 // waiting for most of their lives). A wave takes its picture from a launch ticket (start order) and then rows from the picture's own counter, the next
 // row not handed out yet, until none is left: rows are handed out in order to waves that are running, so the row a wave waits for is always being worked
 // on by a running wave and the launch makes progress however few of its waves the GPU holds at a time.
+#ifndef WAVE_PUBLISH_EVERY
+#define WAVE_PUBLISH_EVERY 2
+#endif
 __device__ __forceinline__ int wave_next_row(uint32_t* counter) {
   int r = 0;
   if ((threadIdx.x & 63) == 0) r = (int)atomicAdd(counter, 1u);
@@ -286,12 +289,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
   const int w = f->cfg.w_ctb, h = f->cfg.h_ctb;
   rc_stage_tables(&RBT_LDS_CAST(RbtEncTileLdsT<TL2>, &lds)->rc);
   uint32_t* done = f->row_done;
-  for (int row = wave_next_row(&done[2 * h]); row < h; row = wave_next_row(&done[2 * h]))
+  for (int row = wave_next_row(&done[2 * h]); row < h; row = wave_next_row(&done[2 * h])) {
+    uint32_t seen = 0;
     for (int x = 0; x < w; x++) {
-      if (row > 0) rbt_flag_wait(&done[row - 1], (uint32_t)(x + 2 < w ? x + 2 : w), &f->error);
+      if (row > 0) seen = rbt_flag_wait_seen(&done[row - 1], (uint32_t)(x + 2 < w ? x + 2 : w), seen, &f->error);
       en_intra_ctb<TL2>(f, slices, row * w + x, RBT_LDS_CAST(RbtEncTileLdsT<TL2>, &lds), x > 0);
-      RBT_FLAG_PUBLISH(&done[row], x + 1);
+      if (((x + 1) & (WAVE_PUBLISH_EVERY - 1)) == 0 || x + 1 == w) RBT_FLAG_PUBLISH(&done[row], x + 1);   // a release (L2 write-back) per few CTBs, not per CTB
     }
+  }
 }
 template <int TL2>
 __global__ void __launch_bounds__(64) k_enc_intra_diag(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int d) {

@@ -87,6 +87,7 @@ static __device__ __forceinline__ int rbt_writelane(int old, int v, int lane) { 
 #ifdef RBT_HOSTEMU
 #define RBT_FLAG_PUBLISH(p, v) (*(p) = (uint32_t)(v))
 RBT_DEV void rbt_flag_wait(const uint32_t* p, uint32_t need, int32_t* err) { if (*p < need) *err = 91; }
+RBT_DEV uint32_t rbt_flag_wait_seen(const uint32_t* p, uint32_t need, uint32_t seen, int32_t* err) { if (*p < need) *err = 91; (void)seen; return *p; }
 #else
 #define RBT_FLAG_PUBLISH(p, v) do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
   if (RBT_LANE0) __hip_atomic_store((p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
@@ -97,6 +98,18 @@ RBT_DEV void rbt_flag_wait(const uint32_t* p, uint32_t need, int32_t* err) {
     if (++spins > (1 << 20)) { *err = 91; break; }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// the same for a consumer that follows one counter: `seen` is the value its last wait returned (everything published up to it is visible already), so
+// nothing is polled or invalidated until more is needed; returns the value to remember
+RBT_DEV uint32_t rbt_flag_wait_seen(const uint32_t* p, uint32_t need, uint32_t seen, int32_t* err) {
+  if (need <= seen) return seen;
+  int spins = 0; uint32_t v;
+  while ((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+    __builtin_amdgcn_s_sleep(32);
+    if (++spins > (1 << 20)) { *err = 91; v = need; break; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 #endif
 
