@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
   if (rc != RBT_OK) { fprintf(stderr, "rbt_create: %s\n", rbt_strerror(rc)); return 1; }   // no GPU: there is no CPU path
   if ((rc = rbt_set_depth(ctx, depth)) != RBT_OK) { fprintf(stderr, "rbt_set_depth: %s\n", rbt_strerror(rc)); return 1; }
   // PCCTranscoderParameters -> rbt_stream_params (R3 by default: geometryQP 24, attributeQP 32, occupancyPrecision 4)
-  rbt_stream_params p[3] = {{RBT_VIDEO_OCCUPANCY, 8, 4, 0, 1, 1, 0}, {RBT_VIDEO_GEOMETRY, geo_qp, 4, 0, 1, 1, 0}, {RBT_VIDEO_ATTRIBUTE, att_qp, 4, 0, 1, 1, 0}};
+  rbt_stream_params p[3] = {{RBT_VIDEO_OCCUPANCY, 8, 4, 0, -1, 1, 0}, {RBT_VIDEO_GEOMETRY, geo_qp, 4, 0, -1, 1, 0}, {RBT_VIDEO_ATTRIBUTE, att_qp, 4, 0, -1, 1, 0}};   // ctb_rows_per_slice -1: wavefront rows
   std::vector<Gof> out(in.size());
   std::deque<std::pair<rbt_job*, size_t>> inflight;
   auto collect = [&]() -> int {

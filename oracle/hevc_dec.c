@@ -5,9 +5,11 @@
  * dependency absent from /root/reference, so this follows ITU-T H.265 (04/2013 tools) for the toolset
  * the V-PCC CTC streams use (cfg/hm/ctc-hm-geometry-ai.cfg, ctc-hm-attribute-ai.cfg, ctc-hm-occupancy-map-ai-main10.cfg):
  * Main/Main10 4:2:0, I and P slices, CTB 16..64, TU 4..32, transform skip, cu_transquant_bypass, AMP, merge/AMVP,
- * TMVP, sign data hiding, cu_qp_delta, deblocking, SAO, decoded-picture-hash SEI (MD5).
- * Not supported (rejected with an error): B slices, tiles, WPP entry points, PCM, scaling lists, weighted prediction,
- * long-term reference pictures.
+ * TMVP, sign data hiding, cu_qp_delta, deblocking, SAO, decoded-picture-hash SEI (MD5); dependent slice segments (7.3.6.1)
+ * and wavefront streams (entropy_coding_sync_enabled_flag: what libx265 writes by default, and RBT-E1's wavefront mode) - context
+ * variables of the CTB above-right at the start of a CTB row (9.3.1), end_of_subset_one_bit and a new arithmetic codeword per row
+ * (entry point offsets are read and not needed by a decoder that reads the rows one after the other).
+ * Not supported (rejected with an error): B slices, tiles, PCM, scaling lists, weighted prediction, long-term reference pictures.
  * PARITY: unpinned against libavcodec (not available here). Self-checks: MD5 SEI, encoder-recon == decoder output.
  */
 #include <limits.h>

@@ -7,11 +7,16 @@
  *   - closed GOPs: gop=2 -> IDR,P pairs (P predicts from its IDR with zero motion: V-PCC map D1/T1 vs D0/T0),
  *     gop=1 -> all IDR (occupancy); parameter sets repeated with every IDR.
  *   - CQP: P slices at qp, I slices at qp + i_qp_offset (x265 CQP with ipratio 1.4 => -3).
- *   - one slice per `ctb_rows_per_slice` CTB rows so entropy coding and intra reconstruction parallelise per row.
+ *   - slice structure by `ctb_rows_per_slice`: n > 0 = independent slices of n CTB rows (0: one per picture); -1 = wavefront mode: ONE slice per picture coded
+ *     as one dependent slice segment (7.3.6.1) per CTB row with entropy_coding_sync_enabled_flag: rows predict from each other and start from the context
+ *     variables the row above had after its second CTB (9.3.1), every row its own NAL unit; intra reconstruction and entropy coding run as row wavefronts.
  *   - I pictures: CU quadtree 32/16/8 chosen bottom-up from open-loop (source-neighbour) intra SAD; modes of the 16x16 and 32x32 blocks from all 35
  *     by a two-step search (11 coarse candidates, then the angular modes within two of the best), modes of the 8x8 blocks from planar, DC, vertical,
  *     horizontal and the neighbourhood of their 16x16 block's mode; blocks inside a block that already predicts to within 2 per sample on average
- *     are not looked at (that block is not split; lossless streams: only when it predicts exactly); TU = CU, chroma DM; dead-zone quantiser 171/512.
+ *     are not looked at (that block is not split; lossless streams: only when it predicts exactly); chroma DM; dead-zone quantiser 171/512.
+ *     An intra CU is one transform unit or four (max_transform_hierarchy_depth_intra 1; not in lossless streams): hm_decide_tu_split codes the luma block
+ *     as one block and, unless that is within lambda^2 / 4 per sample already, as four on the reconstruction, and keeps the cheaper (distortion * 256 +
+ *     lambda^2 * rate); 8x8 CUs split into 4x4 DST blocks with one 4x4 Cb / Cr block each, larger CUs' chroma follows the luma tree.
  *   - P pictures: 16x16 CUs merged (zero MV) + residual, skip when all levels are zero, skips merged up the tree;
  *     dead-zone 85/512.
  *   - lossless (occupancy): cu_transquant_bypass, same quadtree/mode analysis.
@@ -24,7 +29,8 @@
  * It produces the benchmark's R5 input (tests/golden/make_hm_gof.py).
  * stress_seed != 0 turns the same bitstream writer into a seeded random-syntax generator that exercises the decoder
  * tools of the CTC input streams the product encoder never emits (all 35 intra modes, NxN, TU trees, transform skip,
- * AMP, AMVP, TMVP, SAO, cu_qp_delta, sign data hiding, multiple slices).
+ * AMP, AMVP, TMVP, SAO, cu_qp_delta, sign data hiding, multiple slices, dependent slice segments, wavefront streams with
+ * multi-row segments and entry points).
  */
 #include "hevc_enc.h"
 #include <limits.h>

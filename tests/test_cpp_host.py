@@ -65,4 +65,4 @@ def test_cpp_host_pipeline_equals_oracle(tmp_path, depth):
     got = _read(tmp_path / "out.gofs")
     assert len(got) == len(gofs)
     for g, o in zip(gofs, got):
-        assert o[0] == O.transcode_substream(g[0], 0, 8) and o[1] == O.transcode_substream(g[1], 1, 24) and o[2] == O.transcode_substream(g[2], 19, 32)
+        assert o[0] == O.transcode_substream(g[0], 0, 8, rows_per_slice=-1) and o[1] == O.transcode_substream(g[1], 1, 24, rows_per_slice=-1) and o[2] == O.transcode_substream(g[2], 19, 32, rows_per_slice=-1)
