@@ -22,6 +22,7 @@ extern "C" {
 
 const char* rbt_version(void) { return "rabbit-transcoding_amd 0.1 (RBT-E1 encoder, gfx950)"; }
 
+const char* rbt_last_error(rbt_ctx* ctx) { return ctx ? ctx->last_err.c_str() : ""; }
 const char* rbt_strerror(int code) {
   switch (code) {
     case RBT_OK: return "ok";
