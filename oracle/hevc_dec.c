@@ -721,6 +721,7 @@ static void finish_picture(oracle_hevc_decoder* d) {
   size_t n4 = (size_t)m->w4 * m->h4;
   ci->mv = (int16_t*)malloc(n4 * 4); ci->refpoc = (int32_t*)malloc(n4 * 4);
   memcpy(ci->mv, m->mv, n4 * 4);
+  ci->imode = (uint8_t*)malloc(n4); for (size_t i = 0; i < n4; i++) ci->imode[i] = m->pred_mode[i] == MODE_INTRA ? m->intra_mode[i] : 255;   /* for a transcoder's re-encode (oracle_hevc_dec_imodes) */
   for (int y = 0; y < m->h4; y++) for (int x = 0; x < m->w4; x++) {
     size_t i = (size_t)y * m->w4 + x;
     if (m->pred_mode[i] == MODE_INTRA || m->pred_mode[i] == META_UNDECODED) ci->refpoc[i] = INT_MIN;
@@ -914,7 +915,7 @@ int oracle_sps_fields(const uint8_t* p, size_t n, int out[5]) {
 oracle_hevc_decoder* oracle_hevc_dec_create(void) { oracle_hevc_decoder* d = (oracle_hevc_decoder*)calloc(1, sizeof(*d)); build_scans(d); return d; }
 void oracle_hevc_dec_destroy(oracle_hevc_decoder* d) {
   if (!d) return;
-  for (int i = 0; i < d->n_out; i++) { hevc_frame_free(d->out[i]); free(d->col[i].mv); free(d->col[i].refpoc); }
+  for (int i = 0; i < d->n_out; i++) { hevc_frame_free(d->out[i]); free(d->col[i].mv); free(d->col[i].refpoc); free(d->col[i].imode); }
   free(d->out); free(d->col); hevc_meta_free(d->meta); free(d);
 }
 int oracle_hevc_dec_decode(oracle_hevc_decoder* d, const uint8_t* p, size_t n) {
@@ -942,6 +943,8 @@ int oracle_hevc_dec_decode(oracle_hevc_decoder* d, const uint8_t* p, size_t n) {
 }
 int oracle_hevc_dec_num_frames(const oracle_hevc_decoder* d) { return d->n_out; }
 const hevc_frame* oracle_hevc_dec_frame(const oracle_hevc_decoder* d, int i) { return i >= 0 && i < d->n_out ? d->out[i] : NULL; }
+/* per 4x4 unit of decoded picture i (row stride = ceil(width / 4)): the luma intra prediction mode the stream codes there, 255 where the unit is not intra coded */
+const uint8_t* oracle_hevc_dec_imodes(const oracle_hevc_decoder* d, int i) { return i >= 0 && i < d->n_out ? d->col[i].imode : NULL; }
 /* conformance window (luma samples: left, right, top, bottom) of the SPS the last picture used */
 void oracle_hevc_dec_crop(const oracle_hevc_decoder* d, int out[4]) { for (int i = 0; i < 4; i++) out[i] = 2 * d->last_conf_win[i]; }
 int oracle_hevc_dec_md5_checked(const oracle_hevc_decoder* d) { return d->md5_checked; }

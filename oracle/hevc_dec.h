@@ -13,6 +13,7 @@ void oracle_hevc_dec_destroy(oracle_hevc_decoder* d);
 int oracle_hevc_dec_decode(oracle_hevc_decoder* d, const uint8_t* annexb, size_t n);
 int oracle_hevc_dec_num_frames(const oracle_hevc_decoder* d);
 const hevc_frame* oracle_hevc_dec_frame(const oracle_hevc_decoder* d, int i);
+const uint8_t* oracle_hevc_dec_imodes(const oracle_hevc_decoder* d, int i);   /* per 4x4 unit: coded luma intra mode, 255 = not intra */
 /* number of pictures whose MD5 SEI was checked / failed */
 void oracle_hevc_dec_crop(const oracle_hevc_decoder* d, int out[4]);   /* luma samples to drop: left, right, top, bottom */
 int oracle_hevc_dec_md5_checked(const oracle_hevc_decoder* d);

@@ -14,6 +14,7 @@
  *     by a two-step search (11 coarse candidates, then the angular modes within two of the best), modes of the 8x8 blocks from planar, DC, vertical,
  *     horizontal and the neighbourhood of their 16x16 block's mode; blocks inside a block that already predicts to within 2 per sample on average
  *     are not looked at (that block is not split; lossless streams: only when it predicts exactly); chroma DM; dead-zone quantiser 171/512.
+ *     As the second half of a transcoder (hint_modes) the search is replaced by planar, DC and the input stream's modes at the block's four quarters.
  *     An intra CU is one transform unit or four (max_transform_hierarchy_depth_intra 1; not in lossless streams): hm_decide_tu_split codes the luma block
  *     as one block and, unless that is within lambda^2 / 4 per sample already, as four on the reconstruction, and keeps the cheaper (distortion * 256 +
  *     lambda^2 * rate); 8x8 CUs split into 4x4 DST blocks with one 4x4 Cb / Cr block each, larger CUs' chroma follows the luma tree.
@@ -132,6 +133,7 @@ typedef struct {
   uint8_t an_mode[4][64]; int an_cost[4][64]; uint8_t an_split[4][64];   /* [size idx 0:8 1:16 2:32 3:64][block] */
   /* HM-like mode (hm_like) */
   int hm, hm_pass, in_trial, hm_force_intra;
+  const uint8_t* hints;        /* intra mode hints of the current picture (oracle_enc_params.hint_modes), NULL = none */
   int tu_rd;                   /* transform trees are decided by coding both ways (hm_decide_tu_split): the HM-like mode (two levels) and RBT-E1 intra CUs (one level) */
   struct { long ts, tb4, nxn, cu_intra, cu_inter, cu_skip, tu_split, part2, amp, merge, amvp, frac_mv, nonzero_mv, sao_band, sao_edge, sao_merge, sao_off, intra_in_p; } hs;   /* tool usage (ORACLE_HM_STATS=1 prints it) */
   struct { uint8_t split, intra, part; int16_t mv[2][2]; } hn[4][64];   /* P pictures: decision per CU node [size idx][block] */
@@ -902,10 +904,25 @@ static void analyse_ctb_intra(enc* e, int cx, int cy) {
         if (pc <= (e->p.lossless ? 0 : AN_GOOD) * 4 * S * S || pc == AN_SKIPPED) { e->an_cost[si][bi] = AN_SKIPPED; e_evals_skipped++; set_rect8(m->done, m->w4, x0, y0, S, S, 1); continue; }
       }
       int coarse = 0;
+      /* transcoder: planar, DC and the modes the input stream coded at the block's four quarters (distinct ones, in that order; vertical and horizontal
+       * instead where the input has no intra mode) */
+      int hcand[6], nh = 0;
+      if (e->hints) {
+        int any = 0;
+        hcand[nh++] = 0; hcand[nh++] = 1;
+        for (int q = 0; q < 4; q++) {
+          int hx = (x0 + (q & 1) * (S / 2)) >> 2, hy = (y0 + (q >> 1) * (S / 2)) >> 2;
+          int v = hx < e->p.hint_w4 && hy < e->p.hint_h4 ? e->hints[(size_t)hy * e->p.hint_w4 + hx] : 255, dup = 0;
+          for (int t = 0; t < nh; t++) dup |= hcand[t] == v;
+          if (v < 35) { any = 1; if (!dup) hcand[nh++] = v; }
+        }
+        if (!any) { hcand[nh++] = 26; hcand[nh++] = 10; }
+      }
       for (int k = 0; k < 15; k++) {
         if (e->an_cost[si][bi] == 0) break;      /* cannot get better */
         int mode;
-        if (parent >= 0) {
+        if (e->hints) { if (k >= nh) break; mode = hcand[k]; }
+        else if (parent >= 0) {
           static const int base4[4] = {0, 1, 26, 10}, alt3[3] = {2, 18, 34};
           if (k >= 9) break;
           if (k < 4) mode = base4[k];
@@ -1503,6 +1520,7 @@ static void encode_picture(enc* e, const hevc_frame* src, int idx, bytebuf* out,
   else is_i = e->p.gop <= 1 || (idx % e->p.gop) == 0;
   e->is_idr = is_i; e->slice_type = is_i ? SLICE_I : SLICE_P;
   if (is_i) { e->poc = 0; e->n_dpb = 0; write_param_sets(e, out); } else e->poc++;
+  e->hints = (e->p.hint_modes && !e->stress && !e->hm) ? e->p.hint_modes[idx] : NULL;
   e->src = src; e->rec = hevc_frame_alloc(s->width, s->height, s->bit_depth);
   hevc_meta_reset(m);
   m->constrained_intra_pred = p->constrained_intra_pred; m->cb_qp_offset = p->cb_qp_offset; m->cr_qp_offset = p->cr_qp_offset; m->strong_intra_smoothing = s->strong_intra_smoothing;

@@ -19,6 +19,10 @@ typedef struct {
                                :10-16, motion search :33-34, TransformSkip :47, SAO :68, AMP :69) chosen by a deterministic search instead of
                                RBT-E1's restricted set; produces the benchmark's R5 input (tests/golden/make_hm_gof.py). Not mirrored on the GPU. */
   int p_qp_offset;          /* hm_like: QP offset of P pictures (GOP table QPoffset: geometry -3, attribute 0; :29) */
+  /* RBT-E1 as the second half of a transcoder: the luma intra modes the INPUT stream coded, per frame and 4x4 unit (255 = not intra; row stride hint_w4,
+   * hint_h4 rows; NULL = none, the encoder searches on its own). Where given, the intra analysis tries planar, DC and the input's modes at the four
+   * quarters of a block instead of searching the 35 modes (the input's encoder chose them with full rate-distortion optimisation). */
+  const uint8_t* const* hint_modes; int hint_w4, hint_h4;
 } oracle_enc_params;
 
 /* Encodes n frames; appends an Annex-B stream to out. If recon != NULL it receives n newly allocated reconstructed

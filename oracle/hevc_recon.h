@@ -80,7 +80,7 @@ void hevc_mc_luma_buf(const hevc_frame* ref, int x0, int y0, int w, int h, int m
 
 /* motion vector prediction (8.5.3.2.2 - 8.5.3.2.9), list 0 only */
 typedef struct { int16_t x, y; int ref; } hevc_mvcand;
-typedef struct { int16_t* mv; int32_t* refpoc; int poc; int w4, h4; } hevc_colinfo;   /* refpoc INT_MIN = not inter */
+typedef struct { int16_t* mv; int32_t* refpoc; int poc; int w4, h4; uint8_t* imode; } hevc_colinfo;   /* refpoc INT_MIN = not inter */
 typedef struct {
   const hevc_meta* m; int part_mode; int max_merge_cand; int num_ref_idx; const int* ref_poc; int cur_poc;
   const hevc_colinfo* col;       /* collocated picture motion, NULL when slice_temporal_mvp_enabled_flag == 0 */

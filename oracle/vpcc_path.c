@@ -226,7 +226,15 @@ int oracle_transcode_substream(const uint8_t* annexb, size_t n, const oracle_tra
     for (int i = 0; i < nf; i++) src[i] = dec[i];
   }
   bytebuf bb = {0, 0, 0};
+  /* geometry / attribute: the input stream's intra modes come along as hints (same sample grid: not with a conformance window offset at the left / top) */
+  const uint8_t** hints = (const uint8_t**)calloc((size_t)nf, sizeof(void*));
+  if (p->video_type != 0 && crop[0] == 0 && crop[2] == 0) {
+    const hevc_frame* fd = oracle_hevc_dec_frame(d, 0);
+    for (int i = 0; i < nf; i++) hints[i] = oracle_hevc_dec_imodes(d, i);
+    ep.hint_modes = hints; ep.hint_w4 = (fd->w + 3) / 4; ep.hint_h4 = (fd->h + 3) / 4;
+  }
   int rc = encode_any_size(&ep, (const hevc_frame* const*)src, nf, &bb, NULL);
+  free(hints);
   if (own) for (int i = 0; i < nf; i++) hevc_frame_free(src[i]);
   if (has_crop(crop)) for (int i = 0; i < nf; i++) hevc_frame_free(dec[i]);
   free(dec);

@@ -94,6 +94,7 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
   nbq.above_left = rx > 0 && ry > 0 && f->ctb_slice[ctb_addr - g->w_ctb - 1] == my_slice;
   nbq.above_right = ry > 0 && rx + 1 < g->w_ctb && f->ctb_slice[ctb_addr - g->w_ctb + 1] == my_slice;
   const uint16_t* srcp = f->src[0];
+  const int hints = f->hint_dm != nullptr, hint_w4 = f->hint_w4, hint_h4 = f->hint_h4;
   // CTBs larger than 32 are analysed as independent 32x32 quadrants (a 64x64 intra CU is always split)
   int nq = ctb > 32 ? 2 : 1, qs = ctb > 32 ? 32 : ctb;
   for (int q = 0; q < nq * nq; q++) {
@@ -139,11 +140,30 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
           // vertical, horizontal and the angular modes within two of the 16x16 block's mode (2, 18, 34 when that is not angular) (oracle/hevc_enc.c analyse_ctb_intra)
           int parent = -1;
           if (si == 0 && qs >= 16) { const int pb = ((b / nb) >> 1) * (nb >> 1) + ((b % nb) >> 1); if (RBT_UNI(l->cost[1][pb]) < RBT_PARTIAL_COST) parent = RBT_UNI(l->mode[1][pb]); }
+          // transcoder: planar, DC and the modes the input stream coded at the block's four quarters (distinct ones, in that order; vertical and horizontal
+          // instead where the input has no intra mode) - oracle/hevc_enc.c analyse_ctb_intra, hint_modes. Candidates packed 6 bits each.
+          uint64_t hc = 0; int nh = 0;
+          if (hints) {
+            int any = 0;
+            hc = 1ull << 6; nh = 2;
+            for (int q = 0; q < 4; q++) {
+              const int hx = (x0 + (q & 1) * (S >> 1)) >> 2, hy = (y0 + (q >> 1) * (S >> 1)) >> 2;
+              int v = 255;
+              if (hx < hint_w4 && hy < hint_h4) { const size_t hk = (size_t)hy * hint_w4 + hx; if ((RBT_UNI(f->hint_pm[hk]) & RBT_PM_MODE_MASK) == RBT_MODE_INTRA) v = RBT_UNI(f->hint_dm[hk]) & 63; }
+              if (v < 35) {
+                any = 1;
+                int dup = 0; for (int t = 0; t < nh; t++) dup |= (int)((hc >> (6 * t)) & 63) == v;
+                if (!dup) { hc |= (uint64_t)v << (6 * nh); nh++; }
+              }
+            }
+            if (!any) { hc |= (26ull << 12) | (10ull << 18); nh = 4; }
+          }
           int coarse = 0;
           for (int k = 0; k < 15; k++) {
             int mode;
             if (best == 0) break;                               // cannot get better
-            if (parent >= 0) {
+            if (hints) { if (k >= nh) break; mode = (int)((hc >> (6 * k)) & 63); }
+            else if (parent >= 0) {
               if (k >= 9) break;
               if (k < 4) mode = k == 0 ? 0 : (k == 1 ? 1 : (k == 2 ? 26 : 10));
               else if (parent >= 2) { mode = parent + (k - 6); if (mode < 2 || mode > 34 || mode == 10 || mode == 26) continue; }

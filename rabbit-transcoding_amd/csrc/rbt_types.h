@@ -93,6 +93,10 @@ struct RbtFrame {
   // second CTB of each row, 256 bytes per row
   uint32_t* row_done;
   uint8_t* row_ctx;
+  // transcoder: the decoded INPUT picture's per-4x4 maps (pm: prediction mode, dm: luma intra mode in bits 0..5), hint_w4 x hint_h4 units, or nullptr.
+  // Where given, the intra analysis tries planar, DC and the input stream's modes at a block's four quarters instead of searching (en_analyse_ctb).
+  const uint8_t* hint_pm; const uint8_t* hint_dm;
+  int32_t hint_w4, hint_h4;
 };
 #define RBT_CU_CBF_Y 1
 #define RBT_CU_CBF_CB 2

@@ -124,7 +124,7 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
     o_sao[i] = a.reserve(nc * sizeof(RbtSao)); o_cmds[i] = a.reserve(nc * (size_t)b.frames[i].cmd_cap * sizeof(RbtCmd));
   }
   size_t o_frames = a.reserve(nf * sizeof(RbtFrame)), o_slices = a.reserve(b.slices.size() * sizeof(RbtSlice));
-  size_t o_rbsp = a.reserve(b.rbsp.size() + 16), o_lists = a.reserve((nf + b.slices.size()) * 2 * sizeof(int32_t));
+  size_t o_rbsp = a.reserve(b.rbsp.size() + 64), o_lists = a.reserve((nf + b.slices.size()) * 2 * sizeof(int32_t));
   // CTB dependency order (anti-diagonals x + 2y ascending, top to bottom inside one) per distinct picture geometry, and the pictures of every level as RbtFrameRef
   b.order_keep.clear(); b.order_off.assign(nf, 0);
   { std::vector<std::pair<std::pair<int, int>, size_t>> seen;

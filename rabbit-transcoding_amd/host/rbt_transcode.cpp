@@ -15,6 +15,7 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 
 struct EncStreamDesc {
   int w, h, bd, n_frames, qp, i_qp_offset, gop, lossless, log2_ctb, rows, md5;   // w, h: display size (any even numbers)
+  std::vector<const uint8_t*> hint_pm, hint_dm; int hint_w4 = 0, hint_h4 = 0;       // per frame: the decoded input picture's 4x4 maps (device), empty = no hints
   int sao = 0;                           // SAO on (every stream that is not lossless, unless RBT_ENC_SAO=0)
   std::vector<const uint16_t*> src[3];   // device planes per frame
   int src_stride = 0, src_x0 = 0, src_y0 = 0;   // the planes are views: luma row stride (0 = w) and origin of the w x h region (luma samples)
@@ -74,6 +75,7 @@ static int encode_build(EncodeBatch& b) {
       f.poc = is_i ? 0 : (i % d.gop); f.level = is_i ? 0 : 1; f.first_slice = (int)b.slices.size();
       f.w8 = s.width / 8; f.h8 = s.height / 8; f.lossless = d.lossless; f.ref_frame = is_i ? -1 : (int)b.frames.size() - 1; f.ref_poc = is_i ? 0 : f.poc - 1;
       for (int c = 0; c < 3; c++) f.src[c] = d.src[c][i];
+      if (!d.hint_dm.empty()) { f.hint_pm = d.hint_pm[i]; f.hint_dm = d.hint_dm[i]; f.hint_w4 = d.hint_w4; f.hint_h4 = d.hint_h4; }
       int n_ctb = s.w_ctb * s.h_ctb, step = d.rows > 0 ? d.rows * s.w_ctb : (d.rows < 0 ? s.w_ctb : n_ctb);
       for (int addr = 0; addr < n_ctb; addr += step) {
         RbtSlice sl; memset(&sl, 0, sizeof(sl));
@@ -324,6 +326,11 @@ static int setup_encode(DecodeBatch& db, int si, int ei, const rbt_stream_params
     d.gop = 2; d.lossless = 0; d.i_qp_offset = -3; d.w = dw; d.h = dh;
     d.src_stride = c.w; d.src_x0 = cl; d.src_y0 = ct;
     for (int k = 0; k < cnt; k++) for (int q = 0; q < 3; q++) d.src[q][k] = view(k, q);
+    // the input stream's intra modes come along as hints for the re-encode (same sample grid: not with a window offset at the left / top; oracle/vpcc_path.c)
+    if (cl == 0 && ct == 0) {
+      d.hint_pm.resize(cnt); d.hint_dm.resize(cnt); d.hint_w4 = c.w4; d.hint_h4 = c.h4;
+      for (int k = 0; k < cnt; k++) { d.hint_pm[k] = db.frames[first + k].pm; d.hint_dm[k] = db.frames[first + k].dm; }
+    }
   }
   return 0;
 }

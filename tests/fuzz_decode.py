@@ -12,7 +12,10 @@ first, n = int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len
 m = synth.make_maps(192, 128, 9)
 streams = [O.encode_hm(m["geo"], 192, 128, 10, 16, p_qp_offset=-3)[0], O.encode_hm(m["attr"], 192, 128, 10, 22)[0],
            O.encode(np.zeros((5, 96 * 64 * 3 // 2), np.uint16), 96, 64, 10, qp=30, gop=2, stress_seed=7, log2_ctb=0)[0],
-           O.encode(np.zeros((5, 128 * 80 * 3 // 2), np.uint16), 128, 80, 8, qp=30, gop=2, stress_seed=12, log2_ctb=0)[0]]
+           O.encode(np.zeros((5, 128 * 80 * 3 // 2), np.uint16), 128, 80, 8, qp=30, gop=2, stress_seed=12, log2_ctb=0)[0],
+           O.encode(np.zeros((5, 96 * 64 * 3 // 2), np.uint16), 96, 64, 10, qp=30, gop=2, stress_seed=13, log2_ctb=0)[0],      # wavefront rows + dependent slice segments
+           O.encode(np.zeros((5, 96 * 64 * 3 // 2), np.uint16), 96, 64, 10, qp=30, gop=2, stress_seed=17, log2_ctb=0)[0],      # wavefront rows, entry points
+           O.encode(m["geo"], 192, 128, 10, 24, gop=2, rows_per_slice=-1)[0]]                                                   # RBT-E1 wavefront mode
 caught = ok = 0
 for seed in range(first, first + n):
     r = np.random.default_rng(seed)
@@ -25,7 +28,7 @@ for seed in range(first, first + n):
         else: s[int(k)] = int(r.integers(0, 256))
     if mode == 1: s = s[: int(r.integers(len(s) // 3, len(s)))]
     try:
-        if os.environ.get("RBT_FUZZ_TRANSCODE"): ctx.transcode_substream(bytes(s), R.RBT_VIDEO_ATTRIBUTE, 32, md5_sei=0)     # the chained pipeline: the encoder runs on whatever the decoder left
+        if os.environ.get("RBT_FUZZ_TRANSCODE"): ctx.transcode_substream(bytes(s), R.RBT_VIDEO_ATTRIBUTE, 32, md5_sei=0, rows_per_slice=-1 if seed % 2 else 1)     # the chained pipeline: the encoder runs on whatever the decoder left
         else: ctx.decode(bytes(s), verify_md5=False)
         ok += 1
     except R.RbtError:

@@ -41,6 +41,20 @@ def test_encoder_and_transcode_bitstreams(ctx, log2_ctb, rows):
     assert ctx.transcode_substream(so, R.RBT_VIDEO_OCCUPANCY, 8, log2_ctb=log2_ctb, rows_per_slice=rows) == O.transcode_substream(so, 0, 8, log2_ctb=log2_ctb, rows_per_slice=rows)
 
 
+def test_transcode_of_hm_like_input_uses_its_intra_modes(ctx):
+    """a transcode hands the input stream's intra modes to the re-encoder's analysis (planar, DC + the input's modes at a block's four quarters): on
+    HM-like input (NxN, 35 modes: up to six distinct candidates per block) the re-encode differs from the encoder run on the decoded pictures alone,
+    and equals the oracle's"""
+    R = rbt_lib.module()
+    m = synth.make_maps(192, 128, 9)
+    for key, vt, q0, q1 in (("geo", R.RBT_VIDEO_GEOMETRY, 16, 24), ("attr", R.RBT_VIDEO_ATTRIBUTE, 22, 32)):
+        bs, _ = O.encode_hm(m[key], 192, 128, 10, q0)
+        out = ctx.transcode_substream(bs, vt, q1, log2_ctb=5, rows_per_slice=-1, md5_sei=0)
+        assert out == O.transcode_substream(bs, int(vt), q1, 4, 5, -1, 0)
+        dec, *_ = O.decode(bs)
+        assert out != O.encode(dec, 192, 128, 10, q1, gop=2, log2_ctb=5, rows_per_slice=-1, md5_sei=0)[0]
+
+
 def test_transcode_rejects_damaged_input(ctx):
     R = rbt_lib.module()
     geo, attr, occ = synth.make_gof(128, 128, 2, 11)

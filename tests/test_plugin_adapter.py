@@ -1,7 +1,7 @@
 """include/rbt_pcc_plugin.h - this codec behind the reference's PCCVirtualVideoDecoder<T>::decode / PCCVirtualVideoEncoder<T>::encode.
 The adapter templates are compiled against tests/plugin/pcc_interface_double.h (a test double of the few reference members they touch; the reference's
 own PccLibCommon cannot be built here) and driven the way the reference drives a plug-in: decode a sub-bitstream into a PCCVideo, re-encode it at another
-QP, keep the reconstruction. Result == the oracle's transcode of the same stream (what rbt_transcode_substream gives). CPU: host build of the kernels;
+QP, keep the reconstruction. Result == the oracle's decoder followed by the oracle's encoder on the same stream. CPU: host build of the kernels;
 GPU: the product library."""
 import os
 import subprocess
@@ -30,7 +30,10 @@ def _run(exe, tmp_path):
         r = subprocess.run([exe, str(fin), str(qp), str(lossless), str(fout), str(frec)], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
         out = fout.read_bytes()
-        assert out == O.transcode_substream(src, vt, qp, rows_per_slice=-1, md5_sei=0)          # the adapter's defaults: wavefront rows, no hash SEI
+        pics, w, h, bd, _, _ = O.decode(src)
+        # the plug-in seam hands over pictures only (no intra mode hints from the input stream, unlike rbt_transcode_substream): == the oracle's encoder
+        # on the decoded pictures with the adapter's defaults (wavefront rows, no hash SEI)
+        assert out == O.encode(pics, w, h, bd, qp, gop=2, rows_per_slice=-1, md5_sei=0)[0]
         dec, w, h, bd, _, _ = O.decode(out)
         assert np.array_equal(np.frombuffer(frec.read_bytes(), np.uint16).reshape(dec.shape), dec)   # videoRec = what a decoder makes of the stream
 
