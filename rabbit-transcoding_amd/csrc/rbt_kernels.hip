@@ -251,6 +251,15 @@ __global__ void __launch_bounds__(256) k_pool(const uint16_t* in, int w, int fac
   if (i < ow * oh) en_pool_sample(in, w, factor, out, ow, i % ow, i / ow);
   if (i < (ow / 2) * (oh / 2)) { out_cb[i] = (uint16_t)chroma_value; out_cr[i] = (uint16_t)chroma_value; }
 }
+// up to 32 pictures of the same size in one launch (blockIdx.y = picture; the input pointers travel in the kernel arguments, the outputs are evenly spaced)
+struct PoolIn { const uint16_t* p[32]; };
+__global__ void __launch_bounds__(256) k_pool_many(PoolIn in, int w, int factor, uint16_t* out, size_t out_step, int ow, int oh, int chroma_value) {
+  const uint16_t* src = in.p[blockIdx.y];
+  uint16_t* y = out + out_step * blockIdx.y; uint16_t* cb = y + (size_t)ow * oh; uint16_t* cr = cb + (size_t)(ow / 2) * (oh / 2);
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < ow * oh) en_pool_sample(src, w, factor, y, ow, i % ow, i / ow);
+  if (i < (ow / 2) * (oh / 2)) { cb[i] = (uint16_t)chroma_value; cr[i] = (uint16_t)chroma_value; }
+}
 __global__ void __launch_bounds__(64) k_enc_analyse(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
   __shared__ RbtAnalyseLds lds;
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
@@ -360,6 +369,14 @@ void launch_pad(const uint16_t* in, int stride, int x0, int y0, int w, int h, ui
 void launch_pool(const uint16_t* in, int stride, int w, int h, int factor, uint16_t* out, uint16_t* out_cb, uint16_t* out_cr, int chroma_value) {
   int ow = w / factor, oh = h / factor;
   hipLaunchKernelGGL(k_pool, dim3((ow * oh + 255) / 256), dim3(256), 0, g_stream, in, stride, factor, out, ow, oh, out_cb, out_cr, chroma_value);
+}
+void launch_pool_many(const uint16_t* const* in, int n, int stride, int w, int h, int factor, uint16_t* out, size_t out_step, int chroma_value) {
+  const int ow = w / factor, oh = h / factor;
+  for (int k = 0; k < n; k += 32) {
+    PoolIn a; const int m = n - k < 32 ? n - k : 32;
+    for (int i = 0; i < 32; i++) a.p[i] = in[k + (i < m ? i : 0)];
+    hipLaunchKernelGGL(k_pool_many, dim3((ow * oh + 255) / 256, m), dim3(256), 0, g_stream, a, stride, factor, out + out_step * k, out_step, ow, oh, chroma_value);
+  }
 }
 void launch_enc_analyse(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs) {
   if (n_frames <= 0) return;

@@ -112,8 +112,11 @@ static int encode_build(EncodeBatch& b) {
     o_pix[i] = a.reserve(frame_samples(c) * 2); o_coef[i] = a.reserve(frame_samples(c) * 2);
     o_sout[i] = b.desc[b.frame_stream[i]].sao ? a.reserve(frame_samples(c) * 2) : o_pix[i]; o_sao[i] = a.reserve(nc * sizeof(RbtSao));
     o_pm[i] = a.reserve(u); o_edges[i] = a.reserve(u); o_qp[i] = a.reserve(u); o_mv[i] = a.reserve(u * 4); o_ref[i] = a.reserve(u); o_refpoc[i] = a.reserve(u * 4);
-    o_cs[i] = a.reserve(nc * 2); o_cul[i] = a.reserve(u8); o_cum[i] = a.reserve(u8); o_cuf[i] = a.reserve(u8);
+    o_cul[i] = a.reserve(u8); o_cum[i] = a.reserve(u8); o_cuf[i] = a.reserve(u8);
   }
+  // the CTB -> slice maps of all pictures sit back to back: one upload per batch instead of one per picture (a copy is a queue entry of its own)
+  size_t cs_words = 0; for (size_t i = 0; i < nf; i++) { o_cs[i] = cs_words; cs_words += (size_t)b.frames[i].cfg.w_ctb * b.frames[i].cfg.h_ctb; }
+  const size_t o_cs_all = a.reserve(cs_words * 2);
   size_t o_frames = a.reserve(nf * sizeof(RbtFrame)), o_slices = a.reserve(b.slices.size() * sizeof(RbtSlice));
   size_t o_lists = a.reserve((nf + b.slices.size()) * 3 * sizeof(int32_t)), o_dst = a.reserve(b.slices.size() * sizeof(uint32_t));
   size_t out_cap_total = 0; for (auto& sl : b.slices) { sl.out_off = (uint32_t)out_cap_total; out_cap_total += sl.out_cap; }
@@ -123,9 +126,9 @@ static int encode_build(EncodeBatch& b) {
   b.arena = rbtk::dev_alloc(b.arena_size);
   if (!b.arena) { b.err = "device allocation failed"; return RBT_ERR_NOMEM; }
   uint8_t* base = (uint8_t*)b.arena;
-  b.cs_keep.resize(nf);
+  b.cs_keep.assign(1, std::vector<uint16_t>(cs_words, 0));
   for (size_t i = 0; i < nf; i++) {
-    std::vector<uint16_t>& cs_host = b.cs_keep[i];
+    uint16_t* cs_host = b.cs_keep[0].data() + o_cs[i];
     RbtFrame& f = b.frames[i]; const RbtStreamCfg& c = f.cfg; size_t ys = (size_t)c.w * c.h, cs = (size_t)c.cw * c.ch;
     f.pix[0] = (uint16_t*)(base + o_pix[i]); f.pix[1] = f.pix[0] + ys; f.pix[2] = f.pix[1] + cs;
     f.out[0] = (uint16_t*)(base + o_sout[i]); f.out[1] = f.out[0] + ys; f.out[2] = f.out[1] + cs; f.sao = (RbtSao*)(base + o_sao[i]);
@@ -137,15 +140,14 @@ static int encode_build(EncodeBatch& b) {
     }
     f.coef[0] = (int16_t*)(base + o_coef[i]); f.coef[1] = f.coef[0] + ys; f.coef[2] = f.coef[1] + cs;
     f.pm = base + o_pm[i]; f.edges = base + o_edges[i]; f.qp = (int8_t*)(base + o_qp[i]); f.mv = (int16_t*)(base + o_mv[i]); f.ref = (int8_t*)(base + o_ref[i]);
-    f.refpoc = (int32_t*)(base + o_refpoc[i]); f.ctb_slice = (uint16_t*)(base + o_cs[i]);
+    f.refpoc = (int32_t*)(base + o_refpoc[i]); f.ctb_slice = (uint16_t*)(base + o_cs_all) + o_cs[i];
     f.cu_log2 = base + o_cul[i]; f.cu_mode = base + o_cum[i]; f.cu_flags = base + o_cuf[i];
     if (any_wpp) { f.row_done = (uint32_t*)(base + o_rowdone[i]); f.row_ctx = base + o_rowctx[i]; }
-    cs_host.assign((size_t)c.w_ctb * c.h_ctb, 0);
     // per CTB: the SLICE it belongs to (index of the slice's independent segment): availability, QP and loop filter flags are per slice
     { int head = f.first_slice;
       for (int k = 0; k < f.n_slices; k++) { const RbtSlice& sl = b.slices[f.first_slice + k]; if (!sl.dependent) head = f.first_slice + k; for (int q = 0; q < sl.n_ctbs; q++) cs_host[sl.ctb_addr + q] = (uint16_t)head; } }
-    if (rbtk::h2d(f.ctb_slice, cs_host.data(), cs_host.size() * 2)) { b.err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
   }
+  if (rbtk::h2d(base + o_cs_all, b.cs_keep[0].data(), cs_words * 2)) { b.err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
   b.d_frames = (RbtFrame*)(base + o_frames); b.d_slices = (RbtSlice*)(base + o_slices); b.d_lists = (int32_t*)(base + o_lists); b.d_dst = (uint32_t*)(base + o_dst);
   b.d_out = base + o_out; b.d_packed = base + o_packed; b.out_total = out_cap_total;
   b.d_zero = base + o_zero; b.zero_bytes = zero_bytes; b.wpp = any_wpp;
@@ -512,7 +514,19 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
       }
     }
     if (!db[gi].recon_external) rbtk::timer_end(T_RECON);
-    if (!jobs.empty()) { rbtk::timer_begin(T_POOL); for (const PoolJob& pj : jobs) rbtk::launch_pool(pj.in, pj.stride, pj.w, pj.h, 2, pj.y, pj.cb, pj.cr, pj.grey); rbtk::timer_end(T_POOL); }
+    if (!jobs.empty()) {
+      // the pictures of one stream are of one size and their pooled copies evenly spaced (setup_encode): one launch per run of such jobs
+      rbtk::timer_begin(T_POOL);
+      for (size_t a0 = 0; a0 < jobs.size();) {
+        size_t a1 = a0 + 1; const PoolJob& p0 = jobs[a0];
+        const size_t step = a1 < jobs.size() ? (size_t)(jobs[a1].y - p0.y) : 0;
+        while (a1 < jobs.size() && jobs[a1].stride == p0.stride && jobs[a1].w == p0.w && jobs[a1].h == p0.h && jobs[a1].grey == p0.grey && (size_t)(jobs[a1].y - p0.y) == step * (a1 - a0)) a1++;
+        std::vector<const uint16_t*> ins; for (size_t q = a0; q < a1; q++) ins.push_back(jobs[q].in);
+        rbtk::launch_pool_many(ins.data(), (int)ins.size(), p0.stride, p0.w, p0.h, 2, p0.y, step, p0.grey);
+        a0 = a1;
+      }
+      rbtk::timer_end(T_POOL);
+    }
     if (fork) rbtk::stream_wait_mark(sid, intra_done); else { encode_launch_intra(e); encode_launch_entropy_intra(e); }
     encode_launch_rest(e);
     if (fork) rbtk::stream_wait(sid, e.aux_stream);      // the intra pictures' entropy coding on the auxiliary stream
