@@ -65,6 +65,8 @@ def load(path=None):
     L.rbt_world.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.rbt_strerror.restype = C.c_char_p
     L.rbt_strerror.argtypes = [C.c_int]
+    L.rbt_last_error.restype = C.c_char_p
+    L.rbt_last_error.argtypes = [C.c_void_p]
     L.rbt_version.restype = C.c_char_p
     L.rbt_free.argtypes = [C.c_void_p]
     L.rbt_decode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(Video)]
@@ -106,7 +108,8 @@ class Context:
 
     def _chk(self, rc):
         if rc != 0:
-            raise RbtError(rc, self.L.rbt_strerror(rc).decode())
+            detail = self.L.rbt_last_error(self.h).decode()
+            raise RbtError(rc, self.L.rbt_strerror(rc).decode() + (": " + detail if detail else ""))
 
     def _take(self, ptr, n):
         out = C.string_at(ptr, n.value) if ptr.value else b""

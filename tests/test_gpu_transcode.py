@@ -17,6 +17,19 @@ def ctx():
     c.close()
 
 
+@pytest.mark.parametrize("w,h,log2_ctb,n,bd,lossless", [(32, 96, 5, 2, 10, 0), (16, 64, 4, 3, 10, 0), (200, 120, 5, 4, 10, 0), (256, 192, 6, 2, 10, 0), (72, 40, 5, 2, 8, 1), (640, 352, 5, 2, 10, 0)])
+def test_wavefront_mode_edge_sizes(ctx, w, h, log2_ctb, n, bd, lossless):
+    """wavefront mode on the GPU (rows of a picture on different waves, progress counters between them) where its rules bend: pictures one CTB wide,
+    conformance windows, 64x64 CTBs, lossless, and a picture wide enough for several waves per picture; noise content. Encoder == oracle, decoder reads it back."""
+    fr = np.random.default_rng(w * 131 + h).integers(0, 1 << bd, size=(n, w * h * 3 // 2), dtype=np.uint16)
+    for qp in (22, 34):
+        a, ra = O.encode(fr, w, h, bd, qp, gop=1 if lossless else 2, i_qp_offset=0 if lossless else -3, lossless=lossless, log2_ctb=log2_ctb, rows_per_slice=-1)
+        b = ctx.encode(fr, w, h, bd, qp, gop=1 if lossless else 2, lossless=lossless, log2_ctb=log2_ctb, rows_per_slice=-1)
+        assert a == b
+        dec, dw, dh, dbd, chk, fail = ctx.decode(b)
+        assert (dw, dh, dbd, chk, fail) == (w, h, bd, n, 0) and np.array_equal(dec, ra)
+
+
 @pytest.mark.parametrize("log2_ctb,rows", [(5, 1), (6, 0), (4, 2), (5, 0), (6, 1), (5, -1), (6, -1), (4, -1)])   # rows -1: wavefront mode
 def test_encoder_bitstream_identical(ctx, log2_ctb, rows):
     m = synth.make_maps(256, 192, 41)

@@ -41,6 +41,21 @@ def test_encoder_and_transcode_bitstreams(ctx, log2_ctb, rows):
     assert ctx.transcode_substream(so, R.RBT_VIDEO_OCCUPANCY, 8, log2_ctb=log2_ctb, rows_per_slice=rows) == O.transcode_substream(so, 0, 8, log2_ctb=log2_ctb, rows_per_slice=rows)
 
 
+@pytest.mark.parametrize("w,h,log2_ctb,n,bd,lossless", [(32, 96, 5, 2, 10, 0), (16, 64, 4, 3, 10, 0), (200, 120, 5, 4, 10, 0), (96, 80, 4, 3, 10, 0), (256, 192, 6, 2, 10, 0), (64, 64, 5, 2, 8, 1), (72, 40, 5, 2, 8, 1)])
+def test_wavefront_mode_edge_sizes(ctx, w, h, log2_ctb, n, bd, lossless):
+    """wavefront mode (one dependent slice segment per CTB row, context variables from the CTB above-right) where its rules bend: pictures one CTB wide
+    (no above-right CTB: every row starts from the initial variables), sizes that need a conformance window, 64x64 CTBs, lossless; noise content, so that
+    every row carries bins and the one-or-four transform-unit decision goes both ways. Encoder == oracle, and both decoders read the result back."""
+    fr = np.random.default_rng(w * 131 + h).integers(0, 1 << bd, size=(n, w * h * 3 // 2), dtype=np.uint16)
+    for qp in (22, 34):
+        a, ra = O.encode(fr, w, h, bd, qp, gop=1 if lossless else 2, i_qp_offset=0 if lossless else -3, lossless=lossless, log2_ctb=log2_ctb, rows_per_slice=-1)
+        b = ctx.encode(fr, w, h, bd, qp, gop=1 if lossless else 2, lossless=lossless, log2_ctb=log2_ctb, rows_per_slice=-1)
+        assert a == b
+        dec, dw, dh, dbd, chk, fail = ctx.decode(b)
+        assert (dw, dh, dbd, chk, fail) == (w, h, bd, n, 0) and np.array_equal(dec, ra)
+        if lossless: assert np.array_equal(dec, fr)
+
+
 def test_transcode_of_hm_like_input_uses_its_intra_modes(ctx):
     """a transcode hands the input stream's intra modes to the re-encoder's analysis (planar, DC + the input's modes at a block's four quarters): on
     HM-like input (NxN, 35 modes: up to six distinct candidates per block) the re-encode differs from the encoder run on the decoded pictures alone,
