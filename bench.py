@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=16, help="point-cloud frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--multi-gof", type=int, default=8, help="also time G GOFs per call (extra field multi_gof; 0/1 = skip)")
     ap.add_argument("--in-flight", type=int, default=16, help="GOFs in flight (rbt_submit_gof ahead of rbt_wait_gof), 1..16; 1 = blocking calls")
+    ap.add_argument("--gofs-per-job", type=int, default=2, help="GOFs handed over per rbt_submit_gof call (a step stays one GOF; --steps is rounded up to a multiple)")
     ap.add_argument("--sweep", type=int, default=64, help="also time K GOFs at every in-flight depth 1..4 (extra field in_flight_sweep; 0/1 = skip)")
     ap.add_argument("--quality", type=int, default=1, help="report picture PSNR of the output vs the input (extra field quality; 0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path)")
@@ -142,7 +143,7 @@ def main():
     # One step = one GOF through the hot path. The steps are issued the way a transcoder walks a sequence: rbt_submit_gof
     # for GOF i+D-1 before rbt_wait_gof for GOF i (D = --in-flight GOFs in flight on disjoint HIP streams; D = 1 is the
     # blocking rbt_transcode_gof). Every one of the K timed steps is submitted and collected inside the timed region.
-    D = max(1, min(args.in_flight, 16, args.steps))   # never announce a deeper pipeline than the run has steps: shallower pipelines get more streams per job
+    D = max(1, min(args.in_flight, 16, (args.steps + max(1, args.gofs_per_job) - 1) // max(1, args.gofs_per_job)))   # never announce a deeper pipeline than the run has steps: shallower pipelines get more streams per job
     stats_acc = {}
 
     host_t = {"submit": 0.0, "wait": 0.0}
@@ -159,15 +160,28 @@ def main():
             gs.gather_streams(outs, device=tdev)
         return outs
 
-    def run(n_steps, depth, acc):
+    # G GOFs per job (--gofs-per-job): with 16 jobs in flight every job owns one hardware queue, and a GPU that still has room is better used by giving each
+    # queue's launches the pictures of two GOFs than by queueing a 17th job (MI355X time-slices more than 16 queues). Distinct buffers per GOF (the library
+    # decodes entries that name the same buffer once), handed over in one rbt_submit_gof call; a step stays ONE GOF.
+    G = max(1, args.gofs_per_job)
+    job_cache = {}
+
+    def job_of(g):
+        if g not in job_cache:
+            job_cache[g] = ([bytes(bytearray(x)) for _ in range(g) for x in streams] if g > 1 else streams, list(params) * g)
+        return job_cache[g]
+
+    def run(n_steps, depth, acc, g=None):
+        g = g or G
+        js, jp = job_of(g)
         q, outs = [], None
-        for _ in range(n_steps):
+        for _ in range((n_steps + g - 1) // g):
             if len(q) == depth: outs = collect(q.pop(0), acc)
             c0 = time.perf_counter()
-            q.append(ctx.submit_gof(streams, params))
+            q.append(ctx.submit_gof(js, jp))
             host_t["submit"] += time.perf_counter() - c0
         while q: outs = collect(q.pop(0), acc)
-        return outs
+        return outs[:3] if outs else outs
 
     def sync():
         if world > 1:
@@ -177,8 +191,8 @@ def main():
 
     ctx.set_depth(D)
     # set-up, untimed: one job per slot, so that every slot's device arenas exist (librbt recycles them) even when W < D
-    primed = D if (args.warmup < D and D > 1) else 0
-    if primed: run(primed, D, None)
+    primed = D if (args.warmup < D * G and D > 1) else 0
+    if primed: run(primed * G, D, None)
     run(args.warmup, D, None)
     sync()
     host_t["submit"] = host_t["wait"] = 0.0
@@ -186,6 +200,7 @@ def main():
     outs = run(args.steps, D, stats_acc)
     sync()
     elapsed = time.perf_counter() - t0
+    args.steps = (args.steps + G - 1) // G * G
     host_submit_ms, host_wait_ms = 1000 * host_t["submit"] / args.steps, 1000 * host_t["wait"] / args.steps
     if world > 1:
         import torch
@@ -194,7 +209,8 @@ def main():
         elapsed = float(t.item())
     steps = args.steps
     fps = world * n_pc * steps / elapsed
-    st = {k: v / steps for k, v in stats_acc.items()}
+    n_jobs = steps // G                                        # kernel timings are per job = per launch group (a job's launches cover its G GOFs)
+    st = {k: v / n_jobs for k, v in stats_acc.items()}
 
     # dominant kernel group of the path (GPU-side hipEvent timings taken on the launch stream inside librbt)
     groups = {"cabac_parse": st["k_parse_ms"], "reconstruct+loopfilter": st["k_recon_ms"], "intra_analysis": st["k_analyse_ms"],
@@ -212,7 +228,7 @@ def main():
            "intra_analysis": enc_pix // 2,                     # I-picture source samples
            "encode_recon": 3 * enc_pix + enc_pix // 2,         # source in, levels + reconstruction out, P reference in
            "cabac_encode": enc_pix + out_bytes}                # levels in, slice data out
-    achieved = alg[dom] / (groups[dom] * 1e-3) / 1e9 if groups[dom] > 0 else 0.0
+    achieved = G * alg[dom] / (groups[dom] * 1e-3) / 1e9 if groups[dom] > 0 else 0.0      # a launch covers the G GOFs of its job
     # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
     # runs of this same command: profiles/r02_pmc_traffic.json, tools/refresh_profiles.py); counters cannot be read live from inside the benchmark
     traffic = None
@@ -222,7 +238,7 @@ def main():
         pmc = json.load(open(pmc_file))["kernels"]
         kmap = {"cabac_parse": ["k_parse"], "intra_analysis": ["k_enc_analyse"], "cabac_encode": ["k_entropy"]}
         if dom in kmap and n_pc == 32 and (w, h) == (1280, 1280):
-            traffic = int(sum((pmc[k]["FETCH_SIZE_KB"] + pmc[k]["WRITE_SIZE_KB"]) * 1024 for k in kmap[dom]))
+            traffic = G * int(sum((pmc[k]["FETCH_SIZE_KB"] + pmc[k]["WRITE_SIZE_KB"]) * 1024 for k in kmap[dom]))   # counters were taken on one GOF
     except Exception:
         traffic = None
     # the practical bound of the path is the seriality of entropy decoding: bits per second through one slice's chain
@@ -239,7 +255,7 @@ def main():
     cabac = {"slices_per_gof": len(sl_sizes), "largest_slice_kbit": round(max(sl_sizes) * 8 / 1000, 1),
              "Mbit_per_s_through_largest_slice": round(max(sl_sizes) * 8 / 1e6 / (st["k_parse_ms"] * 1e-3), 2) if D > 8 and st["k_parse_ms"] > 0 else None,
              "note": "largest slice's bits / duration of the entropy-decoding launch that contains it (about 1.17 bins per bit)"}
-    path_achieved = st["algorithmic_bytes"] / (elapsed / steps) / 1e9   # whole path: SURVEY.md 8(d) bytes of one GOF over the time one GOF takes
+    path_achieved = st["algorithmic_bytes"] / G / (elapsed / steps) / 1e9   # whole path: SURVEY.md 8(d) bytes of one GOF over the time one GOF takes
 
     # configs[3]: a sequence of --walk-frames point-cloud frames (300 = 9 GOFs of 32 + one of 12), GOF g on rank g mod world, D GOFs in flight
     # per GPU, re-encoded NAL units gathered on rank 0 (strong scaling: the sequence is fixed). Rank 0 then walks the whole sequence alone
@@ -291,24 +307,24 @@ def main():
     # waves, so the GPU has room for several at once; a sequence of GOFs (configs[3]) can use that inside each GPU.
     multi = None
     if world == 1 and args.multi_gof > 1:
-        G = args.multi_gof
-        ms, mp = [bytes(bytearray(s_)) for _ in range(G) for s_ in streams], params * G     # distinct buffers: identical ones would be decoded once
+        MG = args.multi_gof
+        ms, mp = [bytes(bytearray(s_)) for _ in range(MG) for s_ in streams], params * MG     # distinct buffers: identical ones would be decoded once
         ctx.transcode_gof(ms, mp)
         m0 = time.perf_counter()
         for _ in range(2): mo = ctx.transcode_gof(ms, mp)
         mt = (time.perf_counter() - m0) / 2
-        assert all(mo[3 * g + q] == outs[q] for g in range(G) for q in range(3))
-        multi = {"gofs_per_call": G, "value": round(G * n_pc / mt, 3), "unit": "point-cloud frames/s", "ms_per_call": round(1000 * mt, 3)}
+        assert all(mo[3 * g + q] == outs[q] for g in range(MG) for q in range(3))
+        multi = {"gofs_per_call": MG, "value": round(MG * n_pc / mt, 3), "unit": "point-cloud frames/s", "ms_per_call": round(1000 * mt, 3)}
 
-    # informative extra: the same loop at every depth (D = 1 is the blocking call: its ms_per_gof is the latency of one GOF)
+    # informative extra: the same loop with ONE GOF per job at every depth (D = 1 is the blocking call: its ms_per_gof is the latency of one GOF)
     sweep = None
     if world == 1 and args.sweep > 1:
         sweep = []
         for d in (1, 2, 4, 8, 16):
             ctx.set_depth(d)
-            run(d, d, None)
+            run(d, d, None, 1)
             p0 = time.perf_counter()
-            so_ = run(args.sweep, d, None)
+            so_ = run(args.sweep, d, None, 1)
             pt = (time.perf_counter() - p0) / args.sweep
             assert so_ == outs
             sweep.append({"in_flight": d, "gofs": args.sweep, "value": round(n_pc / pt, 3), "ms_per_gof": round(1000 * pt, 3)})
@@ -393,7 +409,7 @@ def main():
                                        f"R5 (QP16/22, prec 2) -> R3 (QP24/32, prec 4), synthetic longdress-like atlas", "input": input_kind,
                            "encoder": ("RBT-E1, wavefront mode (one slice per picture, a dependent slice segment per CTB row, entropy_coding_sync)" if args.rows < 0 else f"RBT-E1, {args.rows or 'all'} CTB row(s) per slice")
                                       + ", 35 intra modes, one-or-four transform units per intra CU, SAO, closed (I,P) pairs, CQP",
-                           "gof_per_gpu": 1, "gofs_in_flight": D, "setup_jobs_before_warmup": primed, "in_bytes": in_bytes, "out_bytes": out_bytes, "parallelism": f"gof-shard x{world}"},
+                           "gof_per_gpu": 1, "jobs_in_flight": D, "gofs_per_job": G, "gofs_in_flight": D * G, "setup_jobs_before_warmup": primed, "in_bytes": in_bytes, "out_bytes": out_bytes, "parallelism": f"gof-shard x{world}"},
                 "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                              "traffic": traffic, "kernel_ms": {k_: round(v, 3) for k_, v in groups.items()},
                              "path_achieved_GBs": round(path_achieved, 3), "path_frac": round(path_achieved / HBM_PEAK_GBS, 6)},

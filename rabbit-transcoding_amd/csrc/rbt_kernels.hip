@@ -94,9 +94,10 @@ void* dev_alloc(size_t n) {
   else {
     b.p = nullptr; b.n = n;
     if (hipMalloc(&b.p, n) != hipSuccess) {
+      (void)hipGetLastError();                                        // the failed allocation is handled here: it must not surface later as a "kernel" error
       for (auto& f : D->pool_free) (void)hipFree(f.p);                 // give everything back and try once more
       D->pool_free.clear();
-      if (hipMalloc(&b.p, n) != hipSuccess) return nullptr;
+      if (hipMalloc(&b.p, n) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     }
   }
   D->pool_live.push_back(b);
