@@ -7,9 +7,9 @@ QUIET="--cpu-sample 0 --multi-gof 0 --quality 0 --sweep 0 --walk-frames 0 --fano
 timeout -k 10 900 python3 $R/bench.py > $O/bench_line.json 2> $O/bench_line.err || exit 1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -o kt -- python3 $R/bench.py --steps 32 --warmup 16 $QUIET > $O/prof_kt.log 2>&1 || exit 2
-ONE="--steps 1 --warmup 0 --in-flight 1 $QUIET"
+ONE="--steps 1 --warmup 0 --in-flight 1 --gofs-per-job 1 $QUIET"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/prof_f -o f -- python3 $R/bench.py $ONE > $O/prof_f.log 2>&1 || exit 3
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/prof_w -o w -- python3 $R/bench.py $ONE > $O/prof_w.log 2>&1 || exit 4
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_VALU_MFMA_BUSY_CYCLES -d $O/prof_sq -o sq -- python3 $R/bench.py $ONE > $O/prof_sq.log 2>&1 || exit 5
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/prof_tl -o tl -- python3 $R/bench.py --steps 1 --warmup 1 --in-flight 1 $QUIET > $O/prof_tl.log 2>&1 || exit 6
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/prof_tl -o tl -- python3 $R/bench.py --steps 1 --warmup 1 --in-flight 1 --gofs-per-job 1 $QUIET > $O/prof_tl.log 2>&1 || exit 6
 ls $O/prof_f $O/prof_w $O/prof_sq $O/prof_tl
