@@ -261,6 +261,7 @@ def main():
     # per GPU, re-encoded NAL units gathered on rank 0 (strong scaling: the sequence is fixed). Rank 0 then walks the whole sequence alone
     # and checks that the stitched output is identical.
     walk = None
+    ctx.trim()        # the legs below run other job shapes than the headline loop: its arenas (32 GOFs' worth) go back to the driver first
     if args.walk_frames > 0 and n_pc > 1:
         seq = gs.make_sequence(streams, args.walk_frames, n_pc)
         gs.transcode_sequence(ctx, seq, params, rank=rank, world=world, depth=D, device=tdev)          # untimed pass: arenas of this shape exist
@@ -283,6 +284,7 @@ def main():
     # configs[4]: every rate point R1..R5 from the R5 input, target rate i on rank i mod world (decode replicated; a rank that holds several
     # rates hands each GOF over once and the library decodes it once)
     fanout = None
+    ctx.trim()
     if args.fanout_gofs > 0:
         fseq = [streams] * args.fanout_gofs
         gs.transcode_fanout(ctx, R, fseq[:1], rank=rank, world=world, depth=D, device=tdev, rows_per_slice=args.rows)

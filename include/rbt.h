@@ -107,6 +107,10 @@ typedef struct rbt_job rbt_job;
 int rbt_set_depth(rbt_ctx* ctx, int max_in_flight);
 int rbt_submit_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, rbt_job** job);
 int rbt_wait_gof(rbt_ctx* ctx, rbt_job* job, uint8_t** annexb_out, size_t* n_out);
+/* The library keeps the device memory of collected jobs for the next job of the same shape (hipMalloc / hipFree of GOF-sized arenas cost milliseconds
+ * and hipFree drains the device). rbt_trim hands that cache back to the driver: worth calling when the workload changes shape (other picture sizes, other
+ * numbers of streams per job), so that the old shapes do not crowd the 288 GB. RBT_ERR_BUSY while jobs are in flight on the device. */
+int rbt_trim(rbt_ctx* ctx);
 
 /* The two halves exposed on their own (SURVEY.md 8(b) alternative seam; used by the parity tests).
  * Picture sizes: any even width / height. Sizes that are not multiples of 8 (all-intra) / 16 (gop 2) are coded padded with a

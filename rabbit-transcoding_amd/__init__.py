@@ -75,6 +75,7 @@ def load(path=None):
     L.rbt_transcode_gof.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(StreamParams), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rbt_submit_gof.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(StreamParams), C.POINTER(C.c_void_p)]
     L.rbt_set_depth.argtypes = [C.c_void_p, C.c_int]
+    L.rbt_trim.argtypes = [C.c_void_p]
     L.rbt_wait_gof.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rbt_or_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.rbt_sample_to_byte_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
@@ -153,6 +154,10 @@ class Context:
     def set_depth(self, n):
         """rbt_set_depth: how many GOFs the caller will keep in flight (1..16 = RBT_MAX_JOBS, default 4)"""
         self._chk(self.L.rbt_set_depth(self.h, n))
+
+    def trim(self):
+        """rbt_trim: hand the cached device memory of earlier jobs back to the driver (call when the workload changes shape)"""
+        self._chk(self.L.rbt_trim(self.h))
 
     def submit_gof(self, streams, params):
         """rbt_submit_gof: enqueue one GOF; returns a job for wait_gof. Up to set_depth() jobs may be in flight."""

@@ -158,6 +158,13 @@ int rbt_set_depth(rbt_ctx* ctx, int max_in_flight) {
   D.depth = max_in_flight;
   return RBT_OK;
 }
+int rbt_trim(rbt_ctx* ctx) {
+  if (!ctx) return RBT_ERR_PARAM;
+  RBT_ENTER(ctx);
+  for (int s = 0; s < RBT_MAX_JOBS; s++) if (D.jobs[s]) return RBT_ERR_BUSY;
+  rbtk::dev_release_pool();
+  return RBT_OK;
+}
 int rbt_wait_gof(rbt_ctx* ctx, rbt_job* job, uint8_t** annexb_out, size_t* n_out) {
   if (!ctx || !job || !annexb_out || !n_out) return RBT_ERR_PARAM;
   RBT_ENTER(ctx);
