@@ -18,7 +18,7 @@ RBT_CONST uint16_t k_lambda16[76] = {3,    3,    4,    4,    5,    5,    6,    7
                                      244,  273,  307,  344,  387,  434,  487,  547,  614,  689,  773,  868,  974,  1093, 1227, 1378, 1546, 1736, 1948,
                                      2187, 2454, 2755, 3092, 3471, 3896, 4373, 4909, 5510, 6185, 6942, 7792, 8747, 9818, 11020, 12370, 13884, 15585, 17493};
 RBT_CONST uint8_t k_intra_cand[11] = {0, 1, 26, 10, 2, 6, 14, 18, 22, 30, 34};
-#define RBT_SPLIT_BITS 24
+#define RBT_SPLIT_BITS 48     // oracle SPLIT_BITS
 #define RBT_PARTIAL_COST 0x0FFFFFFF
 #define RBT_AN_GOOD 2               // average absolute prediction error per sample at which a block is not subdivided further (oracle AN_GOOD; 0 for lossless streams)
 #define RBT_AN_SKIPPED 0x0FFFFFFE    // cost of a block not evaluated because the block around it is good enough: never chosen by the split decision
