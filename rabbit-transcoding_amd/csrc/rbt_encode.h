@@ -1,12 +1,16 @@
 // RBT-E1 encoder kernels: the MI355X replacement of the libx265 encode the reference drives through libavcodec
 // (PCCTranscoder.cpp:548-592 encodeVideo, :825-904 setEncoderOptions) and of resize_frame2 (:594-646).
 // Bit-exact counterpart of oracle/hevc_enc.c (product mode). Stages, all one 64-lane wave per work item:
-//   en_analyse_ctb     open-loop intra analysis of one CTB: 11 candidate modes x {8,16,32}, bottom-up quadtree (parallel
-//                      over every CTB of every I picture)
-//   en_intra_ctb       closed-loop intra coding of one CTB: predict, forward DCT, dead-zone quantiser, reconstruction
-//                      (serial along a slice, parallel over slices = CTB rows and pictures)
+//   en_analyse_ctb     open-loop intra analysis of one CTB, blocks of 32 -> 16 -> 8: a two-step search over the 35 modes (or, in a transcode, planar,
+//                      DC and the input stream's own modes), blocks inside a well-predicted block skipped, bottom-up quadtree (parallel over every CTB
+//                      of every I picture)
+//   en_intra_ctb       closed-loop intra coding of one CTB: predict, forward DST/DCT, dead-zone quantiser, reconstruction; every CU as one transform unit
+//                      or four, decided on the reconstruction (serial along a CTB row; rows are independent slices or, in wavefront mode, follow the
+//                      row above at a distance of two CTBs)
 //   en_inter_ctb       P pictures: zero-motion merge from the reconstructed IDR, 16x16 CUs, skip merging (fully parallel)
-//   en_entropy_slice   wave-uniform CABAC encoding of one slice segment (parallel over slices)
+//   en_sao_ctb         SAO parameters of one CTB from source-vs-reconstruction statistics, applied by the same wave
+//   en_entropy_slice   wave-uniform CABAC encoding of one slice segment (independent slices in parallel; wavefront mode: a row starts from the context
+//                      variables the row above had after its second CTB)
 //   en_pool_sample     2x2 OR-pool of the occupancy map
 #pragma once
 #include "rbt_cabac.h"
