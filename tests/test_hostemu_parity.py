@@ -224,3 +224,20 @@ def test_job_api_argument_checks(ctx):
     assert ctx.wait_gof(j) == [O.transcode_substream(s1, 1, 24)]
     other.close()
 
+
+
+def test_last_error_text_and_trim(ctx):
+    """rbt_last_error names what a failing call objected to; rbt_trim hands the cached device memory back (refused while jobs are in flight)"""
+    R = rbt_lib.module()
+    geo, attr, occ = synth.make_gof(64, 64, 1, 5)
+    src, _ = O.encode(geo, 64, 64, 10, 16, gop=2, log2_ctb=5, rows_per_slice=1)
+    bad = bytearray(src); i = bad.find(b"\x00\x00\x01\x42"); bad[i + 5:i + 20] = b"\xff" * 15   # an SPS that does not parse
+    with pytest.raises(R.RbtError) as ei:
+        ctx.decode(bytes(bad))
+    assert len(str(ei.value)) > len("rbt error")            # code text plus the library's own sentence
+    job = ctx.submit_gof([src], [R.StreamParams(R.RBT_VIDEO_GEOMETRY, 24, 4, 5, -1, 0, 0)])
+    with pytest.raises(R.RbtError):
+        ctx.trim()                                           # RBT_ERR_BUSY: a job is in flight
+    out = ctx.wait_gof(job)
+    ctx.trim()
+    assert ctx.transcode_gof([src], [R.StreamParams(R.RBT_VIDEO_GEOMETRY, 24, 4, 5, -1, 0, 0)]) == out   # works the same from an empty cache
