@@ -6,13 +6,13 @@ R=rbt_lib.module()
 ctx=R.Context(device=0) if os.environ.get("SWEEP_GPU") else R.Context(lib_path=rbt_lib.HOSTEMU_LIB)
 bad=0
 r=np.random.default_rng(7)
-for it in range(36):
+for it in range(int(os.environ.get("SWEEP_N","36"))):
     w=int(r.choice([64,96,128,192,256])); h=int(r.choice([64,96,128,160]))
     n_pc=int(r.choice([1,2])); seed=int(r.integers(1,10000))
     geo,attr,occ=synth.make_gof(w,h,n_pc,seed) if (w%32==0 and h%32==0) else (None,None,None)
     if geo is None: continue
-    lc=int(r.choice([4,5,6])); rows=int(r.choice([0,1,2])); qg=int(r.choice([20,24,28,32,40])); qa=int(r.choice([27,32,37,42]))
-    lcin=int(r.choice([4,5,6])); rin=int(r.choice([0,1,3]))
+    lc=int(r.choice([4,5,6])); rows=int(r.choice([0,1,2,-1,-1])); qg=int(r.choice([20,24,28,32,40])); qa=int(r.choice([27,32,37,42]))
+    lcin=int(r.choice([4,5,6])); rin=int(r.choice([0,1,3,-1]))
     sg,_=O.encode(geo,w,h,10,16,gop=2,log2_ctb=lcin,rows_per_slice=rin)
     sa,_=O.encode(attr,w,h,10,22,gop=2,log2_ctb=lcin,rows_per_slice=rin)
     so,_=O.encode(occ,w//2,h//2,8,8,gop=1,lossless=1,i_qp_offset=0,log2_ctb=lcin,rows_per_slice=rin)
