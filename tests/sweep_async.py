@@ -12,8 +12,8 @@ for it in range(12):
     w = int(r.choice([64, 128, 192, 256])); h = int(r.choice([64, 96, 128, 160])); h -= h % 32
     n_pc = int(r.choice([1, 2, 3])); seed = int(r.integers(1, 10000))
     geo, attr, occ = synth.make_gof(w, h, n_pc, seed)
-    lc = int(r.choice([4, 5, 6])); rows = int(r.choice([0, 1, 2])); qg = int(r.choice([20, 24, 32, 40])); qa = int(r.choice([27, 32, 42]))
-    lcin = int(r.choice([4, 5, 6])); rin = int(r.choice([0, 1, 3])); vmd5 = int(r.random() < 0.25)
+    lc = int(r.choice([4, 5, 6])); rows = int(r.choice([0, 1, 2, -1, -1])); qg = int(r.choice([20, 24, 32, 40])); qa = int(r.choice([27, 32, 42]))
+    lcin = int(r.choice([4, 5, 6])); rin = int(r.choice([0, 1, 3, -1])); vmd5 = int(r.random() < 0.25)
     ins = [O.encode(occ, w // 2, h // 2, 8, 8, gop=1, lossless=1, i_qp_offset=0, log2_ctb=lcin, rows_per_slice=rin)[0],
            O.encode(geo, w, h, 10, 16, gop=2, log2_ctb=lcin, rows_per_slice=rin)[0], O.encode(attr, w, h, 10, 22, gop=2, log2_ctb=lcin, rows_per_slice=rin)[0]]
     ps = [P(0, 8, 4, lc, rows, 1, vmd5), P(1, qg, 4, lc, rows, 1, vmd5), P(19, qa, 4, lc, rows, 1, vmd5)]
