@@ -48,9 +48,9 @@ void launch_recon_refs(const RbtFrameRef* refs, int n_frames, int max_w_ctb, int
 // max_ctbs = CTBs of the largest picture. Tickets are handed out in start order, so every flag a workgroup waits for belongs to one that already runs.
 void launch_recon_level(const RbtFrameRef* refs, int n_frames, int max_ctbs, uint32_t* ticket);
 // slices of several batches in one launch (pipelines that share a HIP stream: their parsers then run side by side)
-void launch_parse_tasks(const RbtParseTask* tasks, int n_tasks, int max_w4);
+void launch_parse_tasks(const RbtParseTask* tasks, int n_tasks, int max_w4, uint32_t* ticket = nullptr);   // ticket: a zeroed word; hands the list out in start order (needed when it holds row tasks)
 // max_w4: width of the widest picture of the launch in 4-sample units (<= 2048; selects the LDS footprint of the parser)
-void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices, int max_w4, void* save = nullptr, int row_limit = 0);
+void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices, int max_w4, void* save = nullptr, int row_limit = 0, uint32_t* ticket = nullptr);
 size_t parse_save_bytes();
 void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int y_begin = 0, int y_end = 1 << 30);
 void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_units);

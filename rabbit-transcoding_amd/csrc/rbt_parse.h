@@ -243,6 +243,27 @@ RBT_DEV void pz_fill_pu(RbtParse* s, int x, int y, int w, int h, int mode, int r
   PZ_TF1();
 }
 // start of a CTB: nothing of it is decoded yet; fetch the surrounding units from the LDS line buffers
+// Row task of a wavefront stream (first CTB row of this wave, ry > 0): the row above was parsed by another wave. Its bottom line of units, its slice and its
+// SAO parameters for CTB column `col` come from the picture's own maps (written by that wave's pz_end_ctb / pz_sao before it published its progress) into the
+// line buffers this wave would have filled itself.
+RBT_DEV void pz_import_above(RbtParse* s, int col, int ry) {
+  RBT_LDS_AS RbtParseLds* L = s->L; const RbtFrame* f = s->f;
+  const int cap4 = RBT_UNI(L->cap4), l2 = pzc_log2_ctb(s), n4 = 1 << (l2 - 2), w4 = pzc_w4(s), wc = pzc_w_ctb(s), x40 = col << (l2 - 2);
+  if (col >= wc) return;
+  const int cnt = rbt_min(n4, w4 - x40); const size_t g0 = (size_t)((ry << (l2 - 2)) - 1) * w4 + x40;
+  RBT_LDS_AS uint8_t *a_pm = pz_above_pm(L, cap4), *a_dm = pz_above_dm(L, cap4); RBT_LDS_AS int8_t* a_ref = pz_above_ref(L, cap4); RBT_LDS_AS int32_t* a_mv = pz_above_mv(L);
+  RBT_PAR_FOR(i, cnt) {
+    const size_t gk = g0 + i;
+    a_pm[x40 + i] = f->pm[gk]; a_dm[x40 + i] = f->dm[gk]; a_ref[x40 + i] = f->ref[gk];
+    a_mv[x40 + i] = (int32_t)((uint32_t)(uint16_t)f->mv[2 * gk] | ((uint32_t)(uint16_t)f->mv[2 * gk + 1] << 16));
+  }
+  if (RBT_LANE0) {
+    pz_above_slice(L, cap4)[col] = f->ctb_slice[(size_t)(ry - 1) * wc + col];
+    const uint32_t* g = (const uint32_t*)&f->sao[(size_t)(ry - 1) * wc + col]; RBT_LDS_AS uint32_t* a = (RBT_LDS_AS uint32_t*)&pz_sao_above(L, cap4)[col];
+    for (int w = 0; w < 6; w++) a[w] = g[w];
+  }
+  RBT_SYNC_LDS();
+}
 RBT_DEV void pz_begin_ctb(RbtParse* s, int rx, int ry) {
   RBT_LDS_AS RbtParseLds* L = s->L;
   s->ctb_x = rx << pzc_log2_ctb(s); s->ctb_y = ry << pzc_log2_ctb(s);
@@ -997,13 +1018,18 @@ struct RbtParseSave {
 // `lds` holds RBT_PARSE_LDS_BYTES(cap4) bytes; the launcher picks cap4 >= the width of every picture of the launch / 4.
 RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, const uint8_t* rbsp, RBT_LDS_AS RbtParseLds* lds, int cap4, RbtParseSave* save, int row_limit) {
   RbtParse s;
-  RbtParseSave* sv = save ? save + slice_idx : nullptr;
+  RbtParseSave* sv = save ? save + slice_idx : nullptr;   // (own index: slice_idx is re-pointed at the slice's head further down)
   const int phase = sv ? RBT_UNI((int)sv->phase) : 0;
   if (phase == 2) return;
   const RbtSlice* gs = &slices[slice_idx];
-  if (RBT_UNI((int)gs->dependent)) return;                   // parsed by the wave of its slice's first segment (next_seg chain)
+  if (RBT_UNI((int)gs->dependent) && !RBT_UNI((int)gs->row_task)) return;   // parsed by the wave of the segment before it (next_seg chain)
   const int wpp = RBT_UNI((int)gs->wpp);
   int seg = slice_idx;                                       // the slice segment being read
+  const int own_idx = slice_idx;                             // where this wave reports (n_ctbs_decoded, resume state)
+  slice_idx = RBT_UNI(gs->head);                             // the SLICE this wave's CTBs belong to: availability, ctb_slice
+  // row task: this wave starts at a CTB row of a wavefront stream whose upper neighbour another wave parses
+  int import_row = -1;                                       // set before the CTB loop
+  uint32_t seen_above = 0;
   s.L = lds; s.left_ok = 0; s.corner_ok = 0; s.corner_pm = s.corner_dm = s.corner_ref = s.corner_mv = 0; s.ctb_x = s.ctb_y = 0;
   if (phase == 0) { RBT_LDS_AS uint16_t* a_slice = pz_above_slice(lds, cap4); RBT_PAR_FOR(i, cap4 / 4) a_slice[i] = 0xFFFF; }
   else { RBT_LDS_AS uint32_t* lw = (RBT_LDS_AS uint32_t*)lds; RBT_PAR_FOR(i, (int)(RBT_PARSE_LDS_BYTES(cap4) / 4)) lw[i] = sv->lds[i]; }
@@ -1033,6 +1059,7 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
   s.t_last = __builtin_readcyclecounter();
 #endif
   int n_ctb = pzc_w_ctb(&s) * pzc_h_ctb(&s), end = 0, addr = RBT_UNI(gs->ctb_addr);
+  if (RBT_UNI((int)gs->row_task)) import_row = addr / pzc_w_ctb(&s);
   uint32_t count = 0;
   s.qp_key = 0x7FFFFFFF; s.qp_packed = 0;
   if (phase != 0) seg = RBT_UNI(sv->sc[22]);
@@ -1086,12 +1113,23 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
     if (RBT_LANE0) s.f->ctb_slice[addr] = (uint16_t)slice_idx;
     s.ctb_addr = addr; s.n_cmds = 0;
     if (rx == 0) { s.left_ok = 0; s.corner_ok = 0; }
+    if (import_row >= 0 && ry != import_row) import_row = -1;           // further rows of this wave have their upper neighbour in its own line buffers
+    if (import_row == ry) {
+      // wait until the wave of the row above has parsed the CTB above-right (the last one of the row for the last column), then take over what this CTB
+      // needs of that row: its own column at the start of the row, the next column always
+      const int wc = pzc_w_ctb(&s);
+      seen_above = rbt_flag_wait_seen(&s.f->prow_done[ry - 1], (uint32_t)(rx + 2 < wc ? rx + 2 : wc), seen_above, &s.f->error);
+      if (rx == 0) pz_import_above(&s, 0, ry);
+      pz_import_above(&s, rx + 1, ry);
+    }
     if (wpp && rx == 0) {
       // first CTB of a row of a wavefront stream (9.3.1): the context variables of the CTB above-right after it was parsed when that CTB is
       // available (inside the picture, same slice), the initial ones otherwise; QpY prediction restarts from SliceQpY (8.6.1)
       RBT_SYNC_LDS();
       const int tr_ok = ry > 0 && pzc_w_ctb(&s) > 1 && RBT_UNI((int)pz_above_slice(lds, cap4)[1]) == slice_idx;
-      if (tr_ok) rbt_ctx_load(&s.c.cs, lds->wpp_ctx); else rbt_ctx_init(&s.c.cs, init_type, pzs_qp(&s));
+      if (!tr_ok) rbt_ctx_init(&s.c.cs, init_type, pzs_qp(&s));
+      else if (import_row == ry) rbt_ctx_load_g(&s.c.cs, s.f->prow_ctx + (size_t)(ry - 1) * 256);
+      else rbt_ctx_load(&s.c.cs, lds->wpp_ctx);
       s.qp_y = pzs_qp(&s);
     }
 #ifdef RBT_PROFILE
@@ -1112,7 +1150,8 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
 #ifdef RBT_PROFILE
     s.t_ctb += __builtin_readcyclecounter() - te_;
 #endif
-    if (wpp && rx == 1) { rbt_ctx_store(&s.c.cs, lds->wpp_ctx); }   // storage process after the second CTB of a row
+    if (wpp && rx == 1) { rbt_ctx_store(&s.c.cs, lds->wpp_ctx); rbt_ctx_store_g(&s.c.cs, s.f->prow_ctx + (size_t)ry * 256); }   // storage process after the second CTB of a row
+    if (wpp) RBT_FLAG_PUBLISH(&s.f->prow_done[ry], rx + 1);                // the maps of this CTB and (rx == 1) the context variables are written: a row task below may go on
     end = rbt_cd_terminate(&s.c);
     addr++; count++;
     if (rbt_cd_overrun(&s.c)) { s.error = 2; break; }
@@ -1137,5 +1176,7 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
   if (RBT_LANE0) for (int i = 22; i < 26; i++) printf("stamp %d: %llu cycles, %u hits\n", i, lds->prof[i], lds->profn[i]);
   if (RBT_LANE0) printf("slice %d: total %llu cyc, residual %llu (%u TBs) [setup+last %llu, csbf+sig %llu, gt1/2 %llu, levels %llu], TU total (incl. residual) %llu, CU header %llu (%u CUs), ctb begin/end %llu, CU total %llu, fills %llu, mpm %llu, bins ctx %u bypass %u, bits %u\n", slice_idx, __builtin_readcyclecounter() - t_all_, s.t_res, s.n_res, s.t_a, s.t_b, s.t_c, s.t_d, s.t_tu, s.t_hdr, s.n_cu, s.t_ctb, s.t_cu, s.t_fill, s.t_mpm, s.c.n_bins, s.c.n_byp, s.c.widx * 32u - (uint32_t)s.c.nbuf);
 #endif
-  if (RBT_LANE0) { slices[slice_idx].n_ctbs_decoded = count; if (s.error) s.f->error = s.error; if (sv) sv->phase = 2; }
+  if (RBT_LANE0) { slices[own_idx].n_ctbs_decoded = count; if (s.error) s.f->error = s.error; if (sv) sv->phase = 2; }
+  // a wave that gave up lets the row below go on at once (the picture is marked bad; nobody waits out the bound for rows that will not come)
+  if (s.error && wpp && addr < n_ctb) { const int wc = pzc_w_ctb(&s); RBT_FLAG_PUBLISH(&s.f->prow_done[addr / wc], wc); }
 }

@@ -107,6 +107,7 @@ RBT_DEV uint32_t rbt_flag_wait_seen(const uint32_t* p, uint32_t need, uint32_t s
   while ((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
     __builtin_amdgcn_s_sleep(32);
     if (++spins > (1 << 20)) { *err = 91; v = need; break; }
+    if ((spins & 63) == 0 && __hip_atomic_load((const uint32_t*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { v = need; break; }   // the picture is bad already: do not wait for what may never come
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);

@@ -79,6 +79,9 @@ struct RbtFrame {
   int32_t n_slices, first_slice;
   int32_t error;                 // set by kernels (non-zero = corrupt / unsupported stream)
   uint32_t* ctb_done;            // per CTB two words (luma chain, Cb/Cr chain): set when that half of the CTB is reconstructed (k_recon_level)
+  // wavefront streams (decoder): CTBs parsed per CTB row (zeroed per job) and the context variables after the second CTB of every row (256 bytes each),
+  // for the wave that parses the row below (what else it needs of this row - the bottom line of its units, slice, SAO - it reads from the maps above)
+  uint32_t* prow_done; uint8_t* prow_ctx;
   // ---- encoder side (RBT-E1) ----
   const uint16_t* src[3];        // source planes (the decoder's `out` planes or the pooled occupancy map)
   uint8_t* cu_log2;              // per 8x8 unit: log2 size of the coding unit covering it
@@ -110,7 +113,7 @@ struct RbtFrame {
 struct RbtSlice;
 struct RbtFrame;
 // One slice segment of a merged entropy-decoding launch (slices of several batches in one grid: rbt_kernels.h launch_parse_tasks)
-struct RbtParseTask { RbtFrame* frames; RbtSlice* slices; const uint8_t* rbsp; int32_t slice; int32_t pad; };
+struct RbtParseTask { RbtFrame* frames; RbtSlice* slices; const uint8_t* rbsp; int32_t slice; int32_t pad; };   // handed to waves in list order (a row task waits for the task of the row above it)
 // One picture of a merged reconstruction launch (pictures of several batches on the same wavefront: launch_recon_refs)
 // order: the picture's CTBs in dependency order (anti-diagonals x + 2y ascending), x | y << 16 each (launch_recon_level)
 struct RbtFrameRef { RbtFrame* frames; const RbtSlice* slices; const uint32_t* order; int32_t frame; int32_t pad; };
@@ -125,8 +128,10 @@ struct RbtSlice {                // one per slice segment, parsed on the host (7
   uint8_t temporal_mvp, cabac_init_flag, max_merge_cand, num_ref_idx, collocated_ref_idx;
   uint8_t dependent;             // dependent slice segment (7.3.6.1): continues the slice of the segment before it; every other header field repeats that slice's
   uint8_t wpp;                   // entropy_coding_sync_enabled_flag of the PPS: CTB rows are separate arithmetic codewords with inherited context variables (9.3.1)
-  uint8_t pad;
-  int32_t next_seg;              // decoder: the next dependent segment of the same slice (-1: none); one wave parses the whole chain
+  uint8_t row_task;              // decoder, wavefront streams: this segment starts a CTB row and is parsed by a wave of its own, which takes the state of the row
+                                 // above (context variables after its second CTB, bottom line of its units) from the wave that parses that row (rbt_parse.h)
+  int32_t next_seg;              // decoder: the next dependent segment of the same slice that is NOT a row task (-1: none); the same wave goes on with it
+  int32_t head;                  // decoder: index of the independent segment that heads this segment's slice (= own index for an independent one)
   int32_t ref_frame[RBT_MAX_REFS];   // batch frame index of RefPicList0[i]
   int32_t ref_poc[RBT_MAX_REFS];
   int32_t poc;

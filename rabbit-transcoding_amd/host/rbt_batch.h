@@ -35,6 +35,7 @@ struct DecodeBatch {
   std::vector<size_t> sl_off, sl_cnt;  // slice list of each level inside d_lists
   std::vector<uint32_t> order_keep; std::vector<size_t> order_off;   // CTB dependency order per picture (host staging, offset per frame)
   std::vector<RbtFrameRef> refs_keep; std::vector<size_t> refs_off;   // the pictures of each level as RbtFrameRef (launch_recon_level)
+  bool has_row_tasks = false;      // some segment of a wavefront stream is parsed by a wave of its own (ordered hand-out of the parse tasks, no banded parsing)
   uint32_t* d_order = nullptr; RbtFrameRef* d_refs = nullptr; uint32_t* d_tickets = nullptr;   // one ticket counter per level + spare ones for merged launches
   void* d_save = nullptr;              // RbtParseSave per slice (resumable parsing), zero-initialised; nullptr when not requested
   bool want_save = false;              // set before decode_build to reserve d_save

@@ -83,11 +83,17 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
           }
         }
         if (h.sao_luma || h.sao_chroma) b.info[cur].sao = true;
-        s.wpp = (uint8_t)pps.entropy_coding_sync; s.next_seg = -1;
+        s.wpp = (uint8_t)pps.entropy_coding_sync; s.next_seg = -1; s.head = (int32_t)b.slices.size();
+        // a segment of a wavefront stream that starts a CTB row gets a wave of its own (it takes what it needs of the row above from that row's wave:
+        // rbt_parse.h); RBT_WPP_PARALLEL=0 keeps one wave per slice
+        static const int row_tasks = [] { const char* e = getenv("RBT_WPP_PARALLEL"); return !e || atoi(e) != 0; }();
+        s.row_task = (uint8_t)(pps.entropy_coding_sync && row_tasks && h.segment_addr > 0 && h.segment_addr % sps.w_ctb == 0);
+        if (s.row_task) b.has_row_tasks = true;
         if (h.dependent) {
-          // same slice as the segment before it: parsed by that slice's wave (next_seg chain), not a task of its own
+          // same slice as the segment before it: parsed by the wave that parsed that one (next_seg chain) unless it starts a row of a wavefront stream
           if (head_idx < 0 || last_seg < 0) { delete ps; b.err = "dependent slice segment without a slice"; return b.err_code = RBT_ERR_BITSTREAM; }
-          s.dependent = 1; b.slices[last_seg].next_seg = (int32_t)b.slices.size();
+          s.dependent = 1; s.head = head_idx;
+          if (!s.row_task) b.slices[last_seg].next_seg = (int32_t)b.slices.size();
         } else { head_hdr = h; head_idx = (int)b.slices.size(); }
         last_seg = (int)b.slices.size();
         b.frames[cur].n_slices++;
@@ -98,6 +104,7 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
     delete ps;
   }
   if (b.frames.empty()) { b.err = "no pictures in the input"; return b.err_code = RBT_ERR_BITSTREAM; }
+  if (b.has_row_tasks) b.want_save = false;                              // banded (resumable) parsing re-launches the list; row tasks need one ordered launch
   if (b.slices.size() >= 0xFFFF) { b.err = "too many slice segments"; return b.err_code = RBT_ERR_UNSUPPORTED; }
   int n_levels = 0; for (auto& f : b.frames) n_levels = std::max(n_levels, f.level + 1);
   b.level_frames.assign(n_levels, {});
@@ -109,7 +116,10 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
   std::vector<size_t> o_coef(nf), o_edges(nf), o_cnt(nf), o_done(nf), o_pm(nf), o_cs(nf), o_pix(nf), o_out(nf), o_dm(nf), o_qp(nf), o_mv(nf), o_ref(nf), o_refpoc(nf), o_sao(nf), o_cmds(nf);
   for (size_t i = 0; i < nf; i++) { const RbtStreamCfg& c = b.frames[i].cfg; size_t u = (size_t)c.w4 * c.h4, nc = (size_t)c.w_ctb * c.h_ctb;
     o_coef[i] = a.reserve(frame_samples(c) * 2); o_edges[i] = a.reserve(u); o_cnt[i] = a.reserve(nc * 4); o_done[i] = a.reserve(nc * 8); }
-  size_t o_tickets = a.reserve(64 * 4);
+  size_t o_tickets = a.reserve(128 * 4);
+  // wavefront streams: progress counters of the CTB rows (zeroed with the rest of this region)
+  std::vector<size_t> o_prow_done(nf, 0), o_prow_ctx(nf, 0); std::vector<int> wpp_frame(nf, 0);
+  for (size_t i = 0; i < nf; i++) { wpp_frame[i] = b.stream_pps[b.info[i].stream].entropy_coding_sync; if (wpp_frame[i]) o_prow_done[i] = a.reserve((size_t)b.frames[i].cfg.h_ctb * 4); }
   size_t o_save = b.want_save ? a.reserve(b.slices.size() * rbtk::parse_save_bytes()) : 0;
   size_t zero_end = a.reserve(0);
   for (size_t i = 0; i < nf; i++) { const RbtStreamCfg& c = b.frames[i].cfg; o_pm[i] = a.reserve((size_t)c.w4 * c.h4); }
@@ -123,6 +133,7 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
     o_dm[i] = a.reserve(u); o_qp[i] = a.reserve(u); o_mv[i] = a.reserve(u * 4); o_ref[i] = a.reserve(u); o_refpoc[i] = a.reserve(u * 4);
     o_sao[i] = a.reserve(nc * sizeof(RbtSao)); o_cmds[i] = a.reserve(nc * (size_t)b.frames[i].cmd_cap * sizeof(RbtCmd));
   }
+  for (size_t i = 0; i < nf; i++) if (wpp_frame[i]) o_prow_ctx[i] = a.reserve((size_t)b.frames[i].cfg.h_ctb * 256);
   size_t o_frames = a.reserve(nf * sizeof(RbtFrame)), o_slices = a.reserve(b.slices.size() * sizeof(RbtSlice));
   size_t o_rbsp = a.reserve(b.rbsp.size() + 64), o_lists = a.reserve((nf + b.slices.size()) * 2 * sizeof(int32_t));
   // CTB dependency order (anti-diagonals x + 2y ascending, top to bottom inside one) per distinct picture geometry, and the pictures of every level as RbtFrameRef
@@ -146,6 +157,7 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
     f.pm = base + o_pm[i]; f.edges = base + o_edges[i]; f.dm = base + o_dm[i]; f.qp = (int8_t*)(base + o_qp[i]); f.mv = (int16_t*)(base + o_mv[i]);
     f.ref = (int8_t*)(base + o_ref[i]); f.refpoc = (int32_t*)(base + o_refpoc[i]); f.sao = (RbtSao*)(base + o_sao[i]); f.ctb_slice = (uint16_t*)(base + o_cs[i]);
     f.cmds = (RbtCmd*)(base + o_cmds[i]); f.cmd_count = (uint32_t*)(base + o_cnt[i]); f.ctb_done = (uint32_t*)(base + o_done[i]);
+    if (wpp_frame[i]) { f.prow_done = (uint32_t*)(base + o_prow_done[i]); f.prow_ctx = base + o_prow_ctx[i]; }
   }
   b.d_order = (uint32_t*)(base + o_order); b.d_refs = (RbtFrameRef*)(base + o_refs); b.d_tickets = (uint32_t*)(base + o_tickets);
   b.refs_keep.clear(); b.refs_off.clear();
@@ -210,8 +222,9 @@ int decode_launch_parse(DecodeBatch& b) {
   if (b.parse_external) return 0;
   const std::vector<size_t>& sl_off = b.sl_off; const std::vector<size_t>& sl_cnt = b.sl_cnt;
   rbtk::timer_begin(T_PARSE);
-  if (b.ordered_parse) { for (size_t l = 0; l < b.level_frames.size(); l++) rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists + sl_off[l], (int)sl_cnt[l], max_w4(b)); }
-  else rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists, (int)b.slices.size(), max_w4(b));
+  uint32_t* tk = b.has_row_tasks ? b.d_tickets + 64 : nullptr;          // row tasks wait for earlier list entries: hand the list out in start order
+  if (b.ordered_parse) { for (size_t l = 0; l < b.level_frames.size(); l++) rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists + sl_off[l], (int)sl_cnt[l], max_w4(b), nullptr, 0, tk ? tk + l : nullptr); }
+  else rbtk::launch_parse(b.d_frames, b.d_slices, b.d_rbsp, b.d_lists, (int)b.slices.size(), max_w4(b), nullptr, 0, tk);
   rbtk::timer_end(T_PARSE);
   return 0;
 }

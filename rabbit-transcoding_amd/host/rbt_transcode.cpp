@@ -475,7 +475,8 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
     if (!d_tasks || !d_refs) { err = "device allocation failed"; rc = RBT_ERR_NOMEM; break; }
     rbtk::set_stream(job_stream(j, lead));
     if (rbtk::h2d(d_tasks, tasks.data(), tasks.size() * sizeof(RbtParseTask)) || rbtk::h2d(d_refs, refs.data(), refs.size() * sizeof(RbtFrameRef))) { err = "device transfer failed"; rc = RBT_ERR_NO_DEVICE; break; }
-    rbtk::timer_begin(T_PARSE); rbtk::launch_parse_tasks(d_tasks, (int)tasks.size(), mw4); rbtk::timer_end(T_PARSE);
+    bool row_tasks = false; for (int gi : grp) row_tasks |= db[gi].has_row_tasks;
+    rbtk::timer_begin(T_PARSE); rbtk::launch_parse_tasks(d_tasks, (int)tasks.size(), mw4, row_tasks ? db[lead].d_tickets + 96 : nullptr); rbtk::timer_end(T_PARSE);
     rbtk::timer_begin(T_RECON);
     for (size_t l = 0; l < n_levels; l++) {
       // the merged launch of level l uses the lead batch's spare ticket counter 32 + l (its own levels use 0..31)

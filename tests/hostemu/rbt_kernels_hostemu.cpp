@@ -39,12 +39,12 @@ void timer_begin(int id) { g_t[id][0] = now_ms(); }
 void timer_end(int id) { g_t[id][1] = now_ms(); }
 double timer_ms(int id) { return g_t[id][1] - g_t[id][0]; }
 
-void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices, int max_w4, void* save, int row_limit) {
+void launch_parse(RbtFrame* frames, RbtSlice* slices, const uint8_t* rbsp, const int32_t* slice_list, int n_slices, int max_w4, void* save, int row_limit, uint32_t*) {
   alignas(16) static uint32_t plds[(RBT_PARSE_LDS_BYTES(RBT_PARSE_CAP4_L) + 3) / 4];
   const int cap4 = max_w4 <= RBT_PARSE_CAP4_S ? RBT_PARSE_CAP4_S : max_w4 <= RBT_PARSE_CAP4_M ? RBT_PARSE_CAP4_M : RBT_PARSE_CAP4_L;
   for (int i = 0; i < n_slices; i++) rbt_parse_slice(frames, slices, slice_list[i], rbsp, (RbtParseLds*)plds, cap4, (RbtParseSave*)save, row_limit);
 }
-void launch_parse_tasks(const RbtParseTask* tasks, int n_tasks, int max_w4) {
+void launch_parse_tasks(const RbtParseTask* tasks, int n_tasks, int max_w4, uint32_t*) {
   alignas(16) static uint32_t plds[(RBT_PARSE_LDS_BYTES(RBT_PARSE_CAP4_L) + 3) / 4];
   const int cap4 = max_w4 <= RBT_PARSE_CAP4_S ? RBT_PARSE_CAP4_S : max_w4 <= RBT_PARSE_CAP4_M ? RBT_PARSE_CAP4_M : RBT_PARSE_CAP4_L;
   for (int i = 0; i < n_tasks; i++) rbt_parse_slice(tasks[i].frames, tasks[i].slices, tasks[i].slice, tasks[i].rbsp, (RbtParseLds*)plds, cap4, nullptr, 0);
