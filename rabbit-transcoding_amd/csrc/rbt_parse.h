@@ -243,23 +243,39 @@ RBT_DEV void pz_fill_pu(RbtParse* s, int x, int y, int w, int h, int mode, int r
   PZ_TF1();
 }
 // start of a CTB: nothing of it is decoded yet; fetch the surrounding units from the LDS line buffers
-// Row task of a wavefront stream (first CTB row of this wave, ry > 0): the row above was parsed by another wave. Its bottom line of units, its slice and its
-// SAO parameters for CTB column `col` come from the picture's own maps (written by that wave's pz_end_ctb / pz_sao before it published its progress) into the
-// line buffers this wave would have filled itself.
+// Hand-over between the waves of two CTB rows of a wavefront stream. The record of row r (RbtFrame::prow_line, 256-byte aligned and only ever written by
+// the wave of row r: the reading wave's own stores never touch its cache lines) holds the row's bottom line of units, its slice per CTB and its SAO parameters:
+//   mv int32[w4] | RbtSao[w_ctb] | slice u16[w_ctb] | pm bytes[w4] | dm bytes[w4] | ref bytes[w4]
+struct PzRowRec { int32_t* mv; RbtSao* sao; uint16_t* slice; uint8_t *pm, *dm; int8_t* ref; };
+RBT_DEV PzRowRec pz_row_rec(const RbtParse* s, int row) {
+  uint8_t* p = s->f->prow_line + (size_t)row * s->f->prow_line_bytes; const int w4 = pzc_w4(s), wc = pzc_w_ctb(s);
+  PzRowRec r; r.mv = (int32_t*)p; r.sao = (RbtSao*)(p + (size_t)4 * w4); r.slice = (uint16_t*)(p + (size_t)4 * w4 + sizeof(RbtSao) * wc);
+  r.pm = p + (size_t)4 * w4 + (sizeof(RbtSao) + 2) * wc; r.dm = r.pm + w4; r.ref = (int8_t*)(r.dm + w4);
+  return r;
+}
+// producer: after pz_end_ctb of CTB (rx, ry) the line buffers hold this row's bottom line for the CTB's columns
+RBT_DEV void pz_export_row(RbtParse* s, int rx, int ry) {
+  RBT_LDS_AS RbtParseLds* L = s->L; const int cap4 = RBT_UNI(L->cap4), l2 = pzc_log2_ctb(s), n4 = 1 << (l2 - 2), w4 = pzc_w4(s), x40 = rx << (l2 - 2), cnt = rbt_min(n4, w4 - x40);
+  const PzRowRec r = pz_row_rec(s, ry);
+  RBT_LDS_AS uint8_t *a_pm = pz_above_pm(L, cap4), *a_dm = pz_above_dm(L, cap4); RBT_LDS_AS int8_t* a_ref = pz_above_ref(L, cap4); RBT_LDS_AS int32_t* a_mv = pz_above_mv(L);
+  RBT_PAR_FOR(i, cnt) { r.pm[x40 + i] = a_pm[x40 + i]; r.dm[x40 + i] = a_dm[x40 + i]; r.ref[x40 + i] = a_ref[x40 + i]; r.mv[x40 + i] = a_mv[x40 + i]; }
+  if (RBT_LANE0) {
+    r.slice[rx] = pz_above_slice(L, cap4)[rx];
+    uint32_t* g = (uint32_t*)&r.sao[rx]; const RBT_LDS_AS uint32_t* a = (const RBT_LDS_AS uint32_t*)&pz_sao_above(L, cap4)[rx];
+    for (int w = 0; w < 6; w++) g[w] = a[w];
+  }
+}
+// consumer (row task, first CTB row of this wave): CTB column `col` of the row above into the line buffers this wave would have filled itself
 RBT_DEV void pz_import_above(RbtParse* s, int col, int ry) {
-  RBT_LDS_AS RbtParseLds* L = s->L; const RbtFrame* f = s->f;
+  RBT_LDS_AS RbtParseLds* L = s->L;
   const int cap4 = RBT_UNI(L->cap4), l2 = pzc_log2_ctb(s), n4 = 1 << (l2 - 2), w4 = pzc_w4(s), wc = pzc_w_ctb(s), x40 = col << (l2 - 2);
   if (col >= wc) return;
-  const int cnt = rbt_min(n4, w4 - x40); const size_t g0 = (size_t)((ry << (l2 - 2)) - 1) * w4 + x40;
+  const int cnt = rbt_min(n4, w4 - x40); const PzRowRec r = pz_row_rec(s, ry - 1);
   RBT_LDS_AS uint8_t *a_pm = pz_above_pm(L, cap4), *a_dm = pz_above_dm(L, cap4); RBT_LDS_AS int8_t* a_ref = pz_above_ref(L, cap4); RBT_LDS_AS int32_t* a_mv = pz_above_mv(L);
-  RBT_PAR_FOR(i, cnt) {
-    const size_t gk = g0 + i;
-    a_pm[x40 + i] = f->pm[gk]; a_dm[x40 + i] = f->dm[gk]; a_ref[x40 + i] = f->ref[gk];
-    a_mv[x40 + i] = (int32_t)((uint32_t)(uint16_t)f->mv[2 * gk] | ((uint32_t)(uint16_t)f->mv[2 * gk + 1] << 16));
-  }
+  RBT_PAR_FOR(i, cnt) { a_pm[x40 + i] = r.pm[x40 + i]; a_dm[x40 + i] = r.dm[x40 + i]; a_ref[x40 + i] = r.ref[x40 + i]; a_mv[x40 + i] = r.mv[x40 + i]; }
   if (RBT_LANE0) {
-    pz_above_slice(L, cap4)[col] = f->ctb_slice[(size_t)(ry - 1) * wc + col];
-    const uint32_t* g = (const uint32_t*)&f->sao[(size_t)(ry - 1) * wc + col]; RBT_LDS_AS uint32_t* a = (RBT_LDS_AS uint32_t*)&pz_sao_above(L, cap4)[col];
+    pz_above_slice(L, cap4)[col] = r.slice[col];
+    const uint32_t* g = (const uint32_t*)&r.sao[col]; RBT_LDS_AS uint32_t* a = (RBT_LDS_AS uint32_t*)&pz_sao_above(L, cap4)[col];
     for (int w = 0; w < 6; w++) a[w] = g[w];
   }
   RBT_SYNC_LDS();
@@ -1029,6 +1045,7 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
   slice_idx = RBT_UNI(gs->head);                             // the SLICE this wave's CTBs belong to: availability, ctb_slice
   // row task: this wave starts at a CTB row of a wavefront stream whose upper neighbour another wave parses
   int import_row = -1;                                       // set before the CTB loop
+  int ctb_limit = RBT_UNI(gs->ctb_limit); uint32_t seg_first = 0;   // of the segment being read: CTBs it may hold (0: to its end), value of `count` at its start
   uint32_t seen_above = 0;
   s.L = lds; s.left_ok = 0; s.corner_ok = 0; s.corner_pm = s.corner_dm = s.corner_ref = s.corner_mv = 0; s.ctb_x = s.ctb_y = 0;
   if (phase == 0) { RBT_LDS_AS uint16_t* a_slice = pz_above_slice(lds, cap4); RBT_PAR_FOR(i, cap4 / 4) a_slice[i] = 0xFFFF; }
@@ -1060,6 +1077,9 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
 #endif
   int n_ctb = pzc_w_ctb(&s) * pzc_h_ctb(&s), end = 0, addr = RBT_UNI(gs->ctb_addr);
   if (RBT_UNI((int)gs->row_task)) import_row = addr / pzc_w_ctb(&s);
+  // a wave that starts in the middle of a CTB row (a slice that begins there) shares the row's progress counter with the wave of the row's first part:
+  // it adds to the counter only once that part is complete, so the counter always means "the row is parsed up to here"
+  int prefix_row = wpp && addr % pzc_w_ctb(&s) ? addr / pzc_w_ctb(&s) : -1; const int prefix_need = addr % pzc_w_ctb(&s);
   uint32_t count = 0;
   s.qp_key = 0x7FFFFFFF; s.qp_packed = 0;
   if (phase != 0) seg = RBT_UNI(sv->sc[22]);
@@ -1151,7 +1171,11 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
     s.t_ctb += __builtin_readcyclecounter() - te_;
 #endif
     if (wpp && rx == 1) { rbt_ctx_store(&s.c.cs, lds->wpp_ctx); rbt_ctx_store_g(&s.c.cs, s.f->prow_ctx + (size_t)ry * 256); }   // storage process after the second CTB of a row
-    if (wpp) RBT_FLAG_PUBLISH(&s.f->prow_done[ry], rx + 1);                // the maps of this CTB and (rx == 1) the context variables are written: a row task below may go on
+    if (wpp) {
+      pz_export_row(&s, rx, ry);
+      if (prefix_row == ry) { rbt_flag_wait(&s.f->prow_done[ry], (uint32_t)prefix_need, &s.f->error); prefix_row = -1; }
+      RBT_FLAG_PUBLISH(&s.f->prow_done[ry], rx + 1);
+    }   // bottom line of this CTB and (rx == 1) the context variables are out: a row task below may go on
     end = rbt_cd_terminate(&s.c);
     addr++; count++;
     if (rbt_cd_overrun(&s.c)) { s.error = 2; break; }
@@ -1159,13 +1183,15 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
       // end_of_subset_one_bit, byte_alignment(): the bit that ended the arithmetic codeword is the alignment bit; the next CTB row is its own
       // codeword from the next byte on
       if (!rbt_cd_terminate(&s.c)) { s.error = 1; break; }
+      if (ctb_limit > 0 && (int)(count - seg_first) == ctb_limit) break;   // this wave had one substream of the segment: the next row is another wave's
       rbt_cd_restart_aligned(&s.c);
     }
+    if (!end && ctb_limit > 0 && (int)(count - seg_first) >= ctb_limit) { s.error = 1; break; }   // the substream should have ended here
     if (end) {
       const int nxt = RBT_UNI(slices[seg].next_seg);
       if (nxt >= 0) {   // dependent slice segment: same slice, the context variables and the QpY predictor go on (9.3.1, 8.6.1); its own arithmetic codeword
         if (RBT_UNI(slices[nxt].ctb_addr) != addr) { s.error = 1; break; }
-        seg = nxt; end = 0;
+        seg = nxt; end = 0; ctb_limit = RBT_UNI(slices[seg].ctb_limit); seg_first = count;
         rbt_cd_start(&s.c, rbsp + (uint32_t)RBT_UNI(slices[seg].data_off), (uint32_t)RBT_UNI(slices[seg].data_size));
       }
     }

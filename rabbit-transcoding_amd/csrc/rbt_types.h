@@ -79,9 +79,10 @@ struct RbtFrame {
   int32_t n_slices, first_slice;
   int32_t error;                 // set by kernels (non-zero = corrupt / unsupported stream)
   uint32_t* ctb_done;            // per CTB two words (luma chain, Cb/Cr chain): set when that half of the CTB is reconstructed (k_recon_level)
-  // wavefront streams (decoder): CTBs parsed per CTB row (zeroed per job) and the context variables after the second CTB of every row (256 bytes each),
-  // for the wave that parses the row below (what else it needs of this row - the bottom line of its units, slice, SAO - it reads from the maps above)
-  uint32_t* prow_done; uint8_t* prow_ctx;
+  // wavefront streams (decoder): what the wave of one CTB row hands to the wave of the row below: CTBs parsed (zeroed per job), the context variables after
+  // the second CTB (256 bytes per row), and the row's bottom line (prow_line_bytes per row, a multiple of 256 so that no cache line is shared with anything the
+  // reading wave writes itself: mv int32[w4] | RbtSao[w_ctb] | slice u16[w_ctb] | pm, dm, ref bytes[w4] each)
+  uint32_t* prow_done; uint8_t* prow_ctx; uint8_t* prow_line; int32_t prow_line_bytes;
   // ---- encoder side (RBT-E1) ----
   const uint16_t* src[3];        // source planes (the decoder's `out` planes or the pooled occupancy map)
   uint8_t* cu_log2;              // per 8x8 unit: log2 size of the coding unit covering it
@@ -132,6 +133,7 @@ struct RbtSlice {                // one per slice segment, parsed on the host (7
                                  // above (context variables after its second CTB, bottom line of its units) from the wave that parses that row (rbt_parse.h)
   int32_t next_seg;              // decoder: the next dependent segment of the same slice that is NOT a row task (-1: none); the same wave goes on with it
   int32_t head;                  // decoder: index of the independent segment that heads this segment's slice (= own index for an independent one)
+  int32_t ctb_limit;             // decoder: > 0: this entry is ONE substream (CTB row) of a segment with entry points: stop after that many CTBs, at end_of_subset_one_bit
   int32_t ref_frame[RBT_MAX_REFS];   // batch frame index of RefPicList0[i]
   int32_t ref_poc[RBT_MAX_REFS];
   int32_t poc;

@@ -87,7 +87,7 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
         // a segment of a wavefront stream that starts a CTB row gets a wave of its own (it takes what it needs of the row above from that row's wave:
         // rbt_parse.h); RBT_WPP_PARALLEL=0 keeps one wave per slice
         static const int row_tasks = [] { const char* e = getenv("RBT_WPP_PARALLEL"); return !e || atoi(e) != 0; }();
-        s.row_task = (uint8_t)(pps.entropy_coding_sync && row_tasks && h.segment_addr > 0 && h.segment_addr % sps.w_ctb == 0);
+        s.row_task = (uint8_t)(pps.entropy_coding_sync && row_tasks && h.dependent && h.segment_addr % sps.w_ctb == 0);   // (an independent segment needs nothing of the row above: it is a wave of its own anyway)
         if (s.row_task) b.has_row_tasks = true;
         if (h.dependent) {
           // same slice as the segment before it: parsed by the wave that parsed that one (next_seg chain) unless it starts a row of a wavefront stream
@@ -97,7 +97,30 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
         } else { head_hdr = h; head_idx = (int)b.slices.size(); }
         last_seg = (int)b.slices.size();
         b.frames[cur].n_slices++;
+        // A segment of a wavefront stream that spans several CTB rows names its substreams by entry points (x265's form): every substream after the first starts
+        // a row and becomes a row task of its own. The offsets count bytes AS SENT (emulation prevention bytes included, 7.4.7.1): mapped through the
+        // positions where such bytes were removed. Offsets that do not add up leave the segment to one wave, which finds the rows by itself.
+        std::vector<RbtSlice> rows;
+        if (s.wpp && row_tasks && !h.entry_sizes.empty()) {
+          auto sent_to_rbsp = [&](size_t e) { size_t k = 0; while (k < nal.epb.size() && nal.epb[k] < e) k++; return e - k; };   // offset in the NAL as sent -> offset in its RBSP
+          size_t e0 = h.data_byte_offset; { size_t k = 0; while (k < nal.epb.size() && (size_t)nal.epb[k] - k < h.data_byte_offset) k++; e0 += k; }
+          const int wc = sps.w_ctb, first_row_ctbs = wc - h.segment_addr % wc; bool ok = true;
+          std::vector<size_t> u(1, h.data_byte_offset); size_t e = e0;
+          for (uint32_t sz : h.entry_sizes) { e += sz; const size_t x = sent_to_rbsp(e); if (x <= u.back() || x >= nal.rbsp_size) { ok = false; break; } u.push_back(x); }
+          if (ok && (size_t)h.segment_addr + first_row_ctbs + (h.entry_sizes.size() - 1) * (size_t)wc < (size_t)wc * sps.h_ctb) {
+            s.data_size = (uint32_t)(u[1] - u[0]); s.ctb_limit = first_row_ctbs;
+            for (size_t i = 1; i < u.size(); i++) {
+              RbtSlice t = s; t.dependent = 1; t.row_task = 1; t.next_seg = -1; t.head = s.head;
+              t.ctb_addr = h.segment_addr + first_row_ctbs + (int)(i - 1) * wc;
+              t.data_off = (uint32_t)(nal.rbsp_off + u[i]); t.data_size = (uint32_t)((i + 1 < u.size() ? u[i + 1] : nal.rbsp_size) - u[i]);
+              t.ctb_limit = i + 1 < u.size() ? wc : 0;               // the last substream ends with the segment
+              rows.push_back(t);
+            }
+            b.has_row_tasks = true;
+          }
+        }
         b.slices.push_back(s);
+        for (const RbtSlice& t : rows) { last_seg = (int)b.slices.size(); b.frames[cur].n_slices++; b.slices.push_back(t); }
       } else if (nal.type >= 2 && nal.type <= 9) { rc = -3; b.err = "unsupported VCL NAL unit type"; }
       if (rc) { delete ps; b.err_code = rc == -3 ? RBT_ERR_UNSUPPORTED : RBT_ERR_BITSTREAM; return b.err_code; }
     }
@@ -133,7 +156,12 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
     o_dm[i] = a.reserve(u); o_qp[i] = a.reserve(u); o_mv[i] = a.reserve(u * 4); o_ref[i] = a.reserve(u); o_refpoc[i] = a.reserve(u * 4);
     o_sao[i] = a.reserve(nc * sizeof(RbtSao)); o_cmds[i] = a.reserve(nc * (size_t)b.frames[i].cmd_cap * sizeof(RbtCmd));
   }
-  for (size_t i = 0; i < nf; i++) if (wpp_frame[i]) o_prow_ctx[i] = a.reserve((size_t)b.frames[i].cfg.h_ctb * 256);
+  std::vector<size_t> o_prow_line(nf, 0);
+  for (size_t i = 0; i < nf; i++) if (wpp_frame[i]) {
+    const RbtStreamCfg& c = b.frames[i].cfg;
+    b.frames[i].prow_line_bytes = (int32_t)(((size_t)c.w4 * 7 + (size_t)c.w_ctb * (2 + sizeof(RbtSao)) + 255) & ~(size_t)255);
+    o_prow_ctx[i] = a.reserve((size_t)c.h_ctb * 256 + 256); o_prow_line[i] = a.reserve((size_t)c.h_ctb * b.frames[i].prow_line_bytes + 256);
+  }
   size_t o_frames = a.reserve(nf * sizeof(RbtFrame)), o_slices = a.reserve(b.slices.size() * sizeof(RbtSlice));
   size_t o_rbsp = a.reserve(b.rbsp.size() + 64), o_lists = a.reserve((nf + b.slices.size()) * 2 * sizeof(int32_t));
   // CTB dependency order (anti-diagonals x + 2y ascending, top to bottom inside one) per distinct picture geometry, and the pictures of every level as RbtFrameRef
@@ -157,7 +185,8 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
     f.pm = base + o_pm[i]; f.edges = base + o_edges[i]; f.dm = base + o_dm[i]; f.qp = (int8_t*)(base + o_qp[i]); f.mv = (int16_t*)(base + o_mv[i]);
     f.ref = (int8_t*)(base + o_ref[i]); f.refpoc = (int32_t*)(base + o_refpoc[i]); f.sao = (RbtSao*)(base + o_sao[i]); f.ctb_slice = (uint16_t*)(base + o_cs[i]);
     f.cmds = (RbtCmd*)(base + o_cmds[i]); f.cmd_count = (uint32_t*)(base + o_cnt[i]); f.ctb_done = (uint32_t*)(base + o_done[i]);
-    if (wpp_frame[i]) { f.prow_done = (uint32_t*)(base + o_prow_done[i]); f.prow_ctx = base + o_prow_ctx[i]; }
+    if (wpp_frame[i]) { f.prow_done = (uint32_t*)(base + o_prow_done[i]); f.prow_ctx = (uint8_t*)(((uintptr_t)(base + o_prow_ctx[i]) + 255) & ~(uintptr_t)255);
+                        f.prow_line = (uint8_t*)(((uintptr_t)(base + o_prow_line[i]) + 255) & ~(uintptr_t)255); }
   }
   b.d_order = (uint32_t*)(base + o_order); b.d_refs = (RbtFrameRef*)(base + o_refs); b.d_tickets = (uint32_t*)(base + o_tickets);
   b.refs_keep.clear(); b.refs_off.clear();

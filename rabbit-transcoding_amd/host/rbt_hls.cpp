@@ -37,6 +37,7 @@ void split_annexb(const uint8_t* p, size_t n, std::vector<uint8_t>& rbsp, std::v
           j = k + 1;
         }
         rbsp.insert(rbsp.end(), p + i, p + cut);
+        if (cut < ne) nal.epb.push_back((uint32_t)(cut - ns));
         i = cut < ne ? cut + 1 : ne;                  // skip the emulation prevention byte
       }
       nal.rbsp_size = rbsp.size() - nal.rbsp_off;
@@ -194,11 +195,11 @@ int parse_slice_header(ParamSets& ps, const uint8_t* rbsp, size_t n, int nal_typ
   h.lf_across = p.loop_filter_across_slices;
   if (p.loop_filter_across_slices && (h.sao_luma || h.sao_chroma || !h.deblocking_disabled)) h.lf_across = b.bit();
   }
-  h.num_entry_points = 0;
-  if (p.entropy_coding_sync) {   // the substreams are parsed one after the other by one wave: the offsets are read and dropped
+  h.num_entry_points = 0; h.entry_sizes.clear();                 // (a dependent segment starts as a copy of its slice's first header: not its entry points)
+  if (p.entropy_coding_sync) {   // the offsets let the decoder give every CTB row of the segment a wave of its own (rbt_decode.cpp)
     h.num_entry_points = (int)b.ue();
     if (h.num_entry_points > s.h_ctb) { err = "slice header: entry points"; return -2; }
-    if (h.num_entry_points > 0) { const int len = (int)b.ue() + 1; if (len > 32) { err = "slice header: entry points"; return -2; } for (int i = 0; i < h.num_entry_points; i++) b.u(len); }
+    if (h.num_entry_points > 0) { const int len = (int)b.ue() + 1; if (len > 32) { err = "slice header: entry points"; return -2; } for (int i = 0; i < h.num_entry_points; i++) h.entry_sizes.push_back((uint32_t)b.u(len) + 1u); }
   }
   if (p.slice_header_extension_present) { int k = b.ue(); for (int i = 0; i < k; i++) b.u(8); }
   if (!b.bit()) { err = "slice header alignment"; return -2; }

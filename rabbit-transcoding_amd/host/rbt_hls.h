@@ -58,9 +58,11 @@ struct SliceHdr {
   int collocated_ref_idx = 0, max_merge_cand = 5, qp = 26, cb_qp_offset = 0, cr_qp_offset = 0;
   int deblocking_disabled = 0, beta_offset_div2 = 0, tc_offset_div2 = 0, lf_across = 0;
   size_t data_byte_offset = 0;      // of slice_segment_data() inside the RBSP
+  std::vector<uint32_t> entry_sizes; // entry_point_offset_minus1[i] + 1: bytes of substream i as sent (emulation prevention bytes included)
 };
 
-struct Nal { int type; size_t rbsp_off, rbsp_size; };   // inside the unescaped batch buffer
+struct Nal { int type; size_t rbsp_off, rbsp_size; std::vector<uint32_t> epb; };   // inside the unescaped batch buffer; epb: where emulation prevention bytes were
+                                                                                    // removed, as offsets into the NAL unit AS SENT (entry point offsets count them, 7.4.7.1)
 
 // Splits an Annex-B stream and appends the unescaped NAL units (2-byte header included) to `rbsp`.
 void split_annexb(const uint8_t* p, size_t n, std::vector<uint8_t>& rbsp, std::vector<Nal>& nals);
