@@ -10,6 +10,7 @@
  *   - slice structure by `ctb_rows_per_slice`: n > 0 = independent slices of n CTB rows (0: one per picture); -1 = wavefront mode: ONE slice per picture coded
  *     as one dependent slice segment (7.3.6.1) per CTB row with entropy_coding_sync_enabled_flag: rows predict from each other and start from the context
  *     variables the row above had after its second CTB (9.3.1), every row its own NAL unit; intra reconstruction and entropy coding run as row wavefronts.
+ *     -2 (oracle only, for decoder tests) = the same wavefront rows in x265's form: one slice segment per picture, the rows behind entry point offsets.
  *   - I pictures: CU quadtree 32/16/8 chosen bottom-up from open-loop (source-neighbour) intra SAD; modes of the 16x16 and 32x32 blocks from all 35
  *     by a two-step search (11 coarse candidates, then the angular modes within two of the best), modes of the 8x8 blocks from planar, DC, vertical,
  *     horizontal and the neighbourhood of their 16x16 block's mode; blocks inside a block that already predicts to within 2 per sample on average
@@ -1383,7 +1384,7 @@ static void setup_stream(enc* e) {
   if (!e->stress && !e->hm && !q->lossless && e1_sao_on()) s->sao_enabled = 1;
   e->tu_rd = e->hm;
   if (!e->stress && !e->hm && !q->lossless) { s->max_th_depth_intra = 1; e->tu_rd = 1; }   /* RBT-E1: an intra CU is one transform unit or four, whichever codes its luma cheaper */
-  if (!e->stress && !e->hm && q->ctb_rows_per_slice < 0) { p->entropy_coding_sync = 1; p->dependent_slice_segments_enabled = 1; }   /* wavefront rows, one dependent slice segment each */
+  if (!e->stress && !e->hm && q->ctb_rows_per_slice < 0) { p->entropy_coding_sync = 1; p->dependent_slice_segments_enabled = q->ctb_rows_per_slice == -1; }   /* wavefront rows, one dependent slice segment each */
   if (e->hm) {   /* cfg/hm/ctc-hm-geometry-ai.cfg:10-16,47,68,69 + HM defaults (SignHideFlag, TMVPMode, MaxNumMergeCand) */
     s->log2_ctb = q->log2_ctb ? q->log2_ctb : 6; s->log2_diff_max_min_cb = s->log2_ctb - 3;
     s->log2_max_tb = imin(5, s->log2_ctb); s->log2_diff_max_min_tb = s->log2_max_tb - 2;
@@ -1437,6 +1438,7 @@ static void encode_slices(enc* e, int is_i, int st_rps_idx, bytebuf* out) {
     /* extent of the slice segment; dependent segments (7.3.6.1) continue the slice of the segment before them */
     int end_addr, dependent = 0;
     if (e->stress) { end_addr = rndp(r, 50) ? n_ctb : imin(n_ctb, addr + 1 + rndn(r, n_ctb)); dependent = addr > 0 && p->dependent_slice_segments_enabled && rndp(r, 60); }
+    else if (e->p.ctb_rows_per_slice == -2) end_addr = n_ctb;                                                                            /* wavefront, x265's form: one slice segment per picture, rows behind entry points */
     else if (e->p.ctb_rows_per_slice < 0) { end_addr = imin(n_ctb, (addr / s->pic_w_ctb + 1) * s->pic_w_ctb); dependent = addr > 0; }   /* wavefront: one dependent segment per CTB row */
     else if (e->p.ctb_rows_per_slice > 0) end_addr = imin(n_ctb, (addr / s->pic_w_ctb + e->p.ctb_rows_per_slice) * s->pic_w_ctb);
     else end_addr = n_ctb;

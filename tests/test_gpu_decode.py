@@ -28,7 +28,7 @@ def test_stress_streams(ctx, seed):
     assert np.array_equal(dec, rec)
 
 
-@pytest.mark.parametrize("log2_ctb,rows", [(5, 1), (6, 0), (4, 2), (5, -1), (6, -1)])
+@pytest.mark.parametrize("log2_ctb,rows", [(5, 1), (6, 0), (4, 2), (5, -1), (6, -1), (5, -2), (4, -2)])   # -1: wavefront rows as dependent slice segments, -2: behind entry points (x265's form)
 def test_product_streams(ctx, log2_ctb, rows):
     m = synth.make_maps(256, 192, 31)
     for key, qp in (("geo", 16), ("attr", 22)):

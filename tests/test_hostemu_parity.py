@@ -241,3 +241,17 @@ def test_last_error_text_and_trim(ctx):
     out = ctx.wait_gof(job)
     ctx.trim()
     assert ctx.transcode_gof([src], [R.StreamParams(R.RBT_VIDEO_GEOMETRY, 24, 4, 5, -1, 0, 0)]) == out   # works the same from an empty cache
+
+
+@pytest.mark.parametrize("log2_ctb", [4, 5, 6])
+def test_wavefront_rows_behind_entry_points(ctx, log2_ctb):
+    """x265's form of a wavefront stream: one slice segment per picture, its CTB rows behind entry point offsets (the oracle writes it with rows_per_slice=-2).
+    The decoder cuts the segment into one parse task per row; result == the oracle's decode, and a transcode of it == the oracle's."""
+    R = rbt_lib.module()
+    m = synth.make_maps(256, 192, 31)
+    for key, vt, q0, q1 in (("geo", R.RBT_VIDEO_GEOMETRY, 16, 24), ("attr", R.RBT_VIDEO_ATTRIBUTE, 22, 32)):
+        bs, rec = O.encode(m[key], 256, 192, 10, q0, gop=2, log2_ctb=log2_ctb, rows_per_slice=-2)
+        assert len(O.slice_headers(bs)) == 2                                      # two pictures, one segment each
+        dec, w, h, bd, chk, fail = ctx.decode(bs)
+        assert (chk, fail) == (2, 0) and np.array_equal(dec, rec)
+        assert ctx.transcode_substream(bs, vt, q1, log2_ctb=5, rows_per_slice=-1, md5_sei=0) == O.transcode_substream(bs, int(vt), q1, 4, 5, -1, 0)
