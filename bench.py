@@ -281,6 +281,25 @@ def main():
             if c1 is not ctx: c1.close()
             walk = {"frames": args.walk_frames, "gofs": [len(gs.split_pairs(g[0])) for g in seq], "ranks": world, "value": round(args.walk_frames / wt, 3), "unit": "point-cloud frames/s",
                     "seconds": round(wt, 4), "scaling": "strong", "out_bytes": sum(len(s_) for g in stitched for s_ in g), "stitched_equals_unsharded": stitched == alone}
+        # the same sequence as a V3C sample stream, file in -> file out (rbt_transcode_v3c: the loop of PccAppTranscoder.cpp:277-349 around transcodeData;
+        # includes the sample stream <-> byte stream conversions and the container write on the host; sharded like the walk above, partial files merged on rank 0)
+        data = gs.wrap_v3c(R, seq, lib=ctx.L)
+        gq, aq, prec = params[1].qp, params[2].qp, params[0].occupancy_precision
+        kw = dict(occupancy_precision=prec, rows_per_slice=args.rows, gofs_per_job=G)
+        gs.transcode_v3c(ctx, R, data, gq, aq, rank=rank, world=world, depth=D, device=tdev, **kw)
+        sync()
+        c0 = time.perf_counter()
+        merged = gs.transcode_v3c(ctx, R, data, gq, aq, rank=rank, world=world, depth=D, device=tdev, **kw)
+        sync()
+        ct = time.perf_counter() - c0
+        if world > 1:
+            import torch
+            t = torch.tensor([ct], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ct = float(t.item())
+        if rank == 0:
+            walk["container"] = {"value": round(args.walk_frames / ct, 3), "unit": "point-cloud frames/s", "seconds": round(ct, 4), "bytes_in": len(data), "bytes_out": len(merged),
+                                 "gofs_per_job": G, "video_units_equal_walk": gs.unwrap_v3c(R, merged, lib=ctx.L) == stitched}
     # configs[4]: every rate point R1..R5 from the R5 input, target rate i on rank i mod world (decode replicated; a rank that holds several
     # rates hands each GOF over once and the library decodes it once)
     fanout = None

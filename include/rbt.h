@@ -172,6 +172,44 @@ typedef struct {
 /* point-to-point (D1) metric between two clouds; coordinates 0..1023 (peak = 1023 in the CTC). */
 int rbt_d1(rbt_ctx* ctx, const int16_t* xyz_a, int n_a, const int16_t* xyz_b, int n_b, int peak, rbt_d1_result* out);
 
+/* ---- V3C sample stream: the container either side of the path ----
+ * What PccAppTranscoder's decompressVideo does around transcodeData (PccAppTranscoder.cpp:277-349): read the sample stream (PCCBitstreamReader::read,
+ * PCCBitstreamReader.cpp:51-70, C.2: one header byte with the unit size precision, then size + unit), walk it GOF by GOF (a GOF starts at each
+ * V3C_VPS unit, :72-96), transcode the video units of every GOF, collect the units of all GOFs (PCCBitstreamWriter::encode, PCCBitstreamWriter.cpp:96-237) and
+ * write them as ONE sample stream whose unit size precision follows the largest unit (PCCBitstreamWriter::write, :57-91).
+ * The library does not parse the V3C parameter set or the atlas sub-bitstream: the reference reads both into its context and writes them back
+ * (with the end-of-tile patch type its reader dropped put back, PCCTranscoder::addEndTile :906-914), which for a stream its own writer made reproduces
+ * the bytes; here V3C_VPS and V3C_AD units are copied. The payload of an OVD / GVD / AVD unit is the video sub-bitstream in sample stream form
+ * (PCCBitstream::readVideoStream, PCCBitstream.cpp:88-97; unit size - 4, PCCBitstreamReader.cpp:225). */
+enum { RBT_V3C_VPS = 0, RBT_V3C_AD = 1, RBT_V3C_OVD = 2, RBT_V3C_GVD = 3, RBT_V3C_AVD = 4 };   /* V3CUnitType, PCCBitstreamCommon.h:133-137 */
+typedef struct {
+  int type;                  /* vuh_unit_type (first 5 bits of the unit, PCCBitstreamReader.cpp:1381-1383) */
+  int gof;                   /* GOF the unit belongs to (units in front of the first V3C_VPS: 0) */
+  int parameter_set_id, atlas_id;                     /* v3cUnitHeader, PCCBitstreamReader.cpp:182-211; 0 where the unit type has none */
+  int attribute_index, attribute_dimension_index, map_index, auxiliary_video;
+  int video_type;            /* RBT_VIDEO_* the unit's sub-bitstream is filed under where transcodeData looks for it (videoSubStream, :98-158): OVD -> occupancy,
+                                GVD without auxiliary video -> geometry, AVD without auxiliary video, partition 0 -> attribute; -1 for every other unit */
+  size_t offset, size;       /* the unit (4-byte header + payload) inside the input */
+} rbt_v3c_unit;
+/* Lists the units of a sample stream (host only, no GPU needed; *units is malloc'd, rbt_free). RBT_ERR_BITSTREAM if a unit overruns the input. */
+int rbt_v3c_index(const uint8_t* in, size_t n, rbt_v3c_unit** units, int* n_units);
+/* PCCBitstreamWriter::write (:57-91) + sampleStreamV3CHeader / sampleStreamV3CUnit (:1492-1507): precision = min(max(ceil(ceilLog2(largest unit) / 8), 1), 8)
+ * bytes, at least forced_precision_bytes (forcedSsvhUnitSizePrecisionBytes_); then every unit behind its size. Host only. */
+int rbt_v3c_write(const uint8_t* const* unit, const size_t* unit_size, int n_units, int forced_precision_bytes, uint8_t** out, size_t* n_out);
+typedef struct {
+  int occupancy_precision;   /* occupancyPrecision_: the occupancy video is transcoded (2x2 OR-pool, lossless) only when 4 (PCCTranscoder.cpp:150) */
+  int geometry_qp, attribute_qp;                      /* geometryQP_, attributeQP_ */
+  int forced_unit_size_precision_bytes;               /* forcedSsvhUnitSizePrecisionBytes_, 0 = none */
+  int log2_ctb, ctb_rows_per_slice, md5_sei, verify_md5;   /* as in rbt_stream_params */
+  int gofs_per_job;          /* GOFs handed to the GPU per job, 0 / 1 = one (two fill an MI355X better when 16 jobs are in flight) */
+} rbt_v3c_params;
+/* The whole walk: index, per GOF the video units through rbt_submit_gof / rbt_wait_gof with as many jobs in flight as rbt_set_depth announced, write.
+ * Video units transcodeData does not look at (auxiliary video, attribute partitions beyond the first) are copied; a GOF with several
+ * geometry or attribute map streams (multipleMapStreamsPresentFlag) is refused (RBT_ERR_UNSUPPORTED) - the reference looks for VIDEO_GEOMETRY / VIDEO_ATTRIBUTE, which such a GOF does not have.
+ * In a multi-GPU job (rbt_create with world_size > 1) the output holds the GOFs this rank owns (rbt_owns_gof) and nothing else: rank 0 of the host
+ * program gathers the partial streams and merges them with rbt_v3c_index + rbt_v3c_write (gof_shard.transcode_v3c does). */
+int rbt_transcode_v3c(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_params* p, uint8_t** out, size_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

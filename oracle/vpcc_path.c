@@ -257,6 +257,71 @@ int oracle_transcode_data(int n, const uint8_t* const* in, const size_t* n_in, c
   return 0;
 }
 
+/* ---- V3C sample stream walk (PccAppTranscoder.cpp:277-349) ---- */
+/* PCCBitstreamCommon.h:526-566 */
+static int v3c_floor_log2(uint32_t x) { int r = -1; while (x) { r++; x >>= 1; } return r; }
+static int v3c_ceil_log2(uint32_t x) { return x == 0 ? -1 : v3c_floor_log2(x - 1) + 1; }
+typedef struct { int type; uint8_t* d; size_t n; } v3c_unit_t;
+int oracle_v3c_transcode(const uint8_t* in, size_t n, int occupancy_precision, int geometry_qp, int attribute_qp, int forced_precision_bytes,
+                         int log2_ctb, int ctb_rows_per_slice, int md5_sei, uint8_t** out, size_t* n_out) {
+  *out = NULL; *n_out = 0;
+  if (n < 1) return -1;
+  /* PCCBitstreamReader::read (:51-70): u(3) precision - 1, u(5); then size u(8 * precision) + unit while data is left */
+  int prec_in = (in[0] >> 5) + 1, rc = 0;
+  size_t cap = 16, cnt = 0, pos = 1;
+  v3c_unit_t* u = (v3c_unit_t*)malloc(cap * sizeof(*u));
+  while (pos < n && !rc) {
+    uint64_t sz = 0;
+    if (pos + (size_t)prec_in > n) { rc = -1; break; }
+    for (int i = 0; i < prec_in; i++) sz = (sz << 8) | in[pos++];
+    if (sz < 4 || sz > n - pos) { rc = -1; break; }
+    if (cnt == cap) { cap *= 2; u = (v3c_unit_t*)realloc(u, cap * sizeof(*u)); }
+    u[cnt].type = in[pos] >> 3;                                  /* :1381-1383 */
+    u[cnt].d = (uint8_t*)malloc((size_t)sz); memcpy(u[cnt].d, in + pos, (size_t)sz); u[cnt].n = (size_t)sz;
+    cnt++; pos += (size_t)sz;
+  }
+  /* per unit (the GOF loop of :307-341 only groups them; no state crosses units here): transcodeData (PCCTranscoder.cpp:145-168) on the three videos it names */
+  for (size_t k = 0; k < cnt && !rc; k++) {
+    uint32_t h = ((uint32_t)u[k].d[0] << 24) | ((uint32_t)u[k].d[1] << 16) | ((uint32_t)u[k].d[2] << 8) | u[k].d[3];
+    oracle_transcode_params tp; memset(&tp, 0, sizeof(tp));
+    tp.occupancy_precision = occupancy_precision; tp.log2_ctb = log2_ctb; tp.ctb_rows_per_slice = ctb_rows_per_slice; tp.md5_sei = md5_sei;
+    if (u[k].type == 2) { if (occupancy_precision != 4) continue; tp.video_type = 0; tp.qp = 8; }                       /* V3C_OVD; :150 */
+    else if (u[k].type == 3) { if ((h >> 12) & 1) continue; tp.video_type = 1; tp.qp = geometry_qp; }                   /* V3C_GVD, no auxiliary video -> VIDEO_GEOMETRY */
+    else if (u[k].type == 4) { if ((h & 1) || ((h >> 5) & 31)) continue; tp.video_type = 19; tp.qp = attribute_qp; }    /* V3C_AVD, no auxiliary video, partition 0 -> VIDEO_ATTRIBUTE */
+    else continue;
+    if (u[k].n <= 4) continue;
+    uint8_t *bs = NULL, *tr = NULL, *ss = NULL; size_t bn = 0, tn = 0, sn = 0;
+    rc = oracle_sample_to_byte_stream(u[k].d + 4, u[k].n - 4, &bs, &bn);
+    if (!rc) rc = oracle_transcode_substream(bs, bn, &tp, &tr, &tn);
+    if (!rc) rc = oracle_byte_to_sample_stream(tr, tn, &ss, &sn);
+    if (!rc) {
+      uint8_t* nd = (uint8_t*)malloc(4 + sn); memcpy(nd, u[k].d, 4); memcpy(nd + 4, ss, sn);
+      free(u[k].d); u[k].d = nd; u[k].n = 4 + sn;
+    }
+    free(bs); free(tr); free(ss);
+  }
+  if (!rc) {
+    /* PCCBitstreamWriter::write (:57-91) */
+    uint32_t max_unit = 0;
+    for (size_t k = 0; k < cnt; k++) if (max_unit < (uint32_t)u[k].n) max_unit = (uint32_t)u[k].n;
+    int cl = v3c_ceil_log2(max_unit);
+    int prec = (int)((cl + 7) / 8); if (cl <= 0) prec = 0;      /* ceil(cl / 8.0) for cl = -1, 0 is 0 */
+    if (prec < 1) prec = 1;
+    if (prec > 8) prec = 8;
+    if (prec < forced_precision_bytes) prec = forced_precision_bytes;
+    bytebuf b = {0, 0, 0};
+    bb_put(&b, (uint8_t)((prec - 1) << 5));
+    for (size_t k = 0; k < cnt; k++) {
+      for (int i = prec - 1; i >= 0; i--) bb_put(&b, i >= 8 ? 0 : (uint8_t)((uint64_t)u[k].n >> (8 * i)));
+      for (size_t i = 0; i < u[k].n; i++) bb_put(&b, u[k].d[i]);
+    }
+    *out = b.d; *n_out = b.n;
+  }
+  for (size_t k = 0; k < cnt; k++) free(u[k].d);
+  free(u);
+  return rc;
+}
+
 /* ---- table accessors for tests/test_oracle_tables.py (pinning against the reference ROM) ---- */
 int oracle_dct_coef(int N, int k, int n) { return hevc_dct_coef(N, k, n); }
 int oracle_dst_coef(int k, int n) { return k_dst4[k][n]; }

@@ -38,5 +38,11 @@ int oracle_encode_ex(const oracle_enc_params* params, const uint16_t* yuv, int n
 int oracle_transcode_substream(const uint8_t* annexb, size_t n, const oracle_transcode_params* p, uint8_t** out, size_t* n_out);
 /* PCCTranscoder::transcodeData (PCCTranscoder.cpp:145-168): occupancy only when occupancy_precision == 4, then geometry, attribute */
 int oracle_transcode_data(int n, const uint8_t* const* in, const size_t* n_in, const oracle_transcode_params* p, uint8_t** out, size_t* n_out);
+/* The V3C sample stream around transcodeData, as PccAppTranscoder's decompressVideo walks it (PccAppTranscoder.cpp:277-349): read (PCCBitstreamReader.cpp:51-70,
+ * :1369-1387), GOF by GOF (:72-96), video units replaced by their transcodes (payload = sub-bitstream in sample stream form, PCCBitstream.cpp:88-111),
+ * all units written as one sample stream (PCCBitstreamWriter.cpp:57-91, :1492-1507). V3C_VPS / V3C_AD units are carried over as bytes.
+ * geometry / attribute: params of those two videos; occupancy transcoded (qp 8, lossless) only when occupancy_precision == 4. */
+int oracle_v3c_transcode(const uint8_t* in, size_t n, int occupancy_precision, int geometry_qp, int attribute_qp, int forced_precision_bytes,
+                         int log2_ctb, int ctb_rows_per_slice, int md5_sei, uint8_t** out, size_t* n_out);
 void oracle_free(void* p);
 #endif

@@ -53,6 +53,20 @@ class D1Result(C.Structure):
                 ("mse_ab", C.c_float), ("mse_ba", C.c_float), ("psnr_ab", C.c_float), ("psnr_ba", C.c_float), ("psnr", C.c_float)]
 
 
+class V3CUnit(C.Structure):
+    """rbt_v3c_unit: one unit of a V3C sample stream"""
+    _fields_ = [(n, C.c_int) for n in ("type", "gof", "parameter_set_id", "atlas_id", "attribute_index", "attribute_dimension_index", "map_index", "auxiliary_video", "video_type")] + \
+               [("offset", C.c_size_t), ("size", C.c_size_t)]
+
+
+class V3CParams(C.Structure):
+    """rbt_v3c_params: PCCTranscoderParameters as the container walk needs them"""
+    _fields_ = [(n, C.c_int) for n in ("occupancy_precision", "geometry_qp", "attribute_qp", "forced_unit_size_precision_bytes", "log2_ctb", "ctb_rows_per_slice", "md5_sei", "verify_md5", "gofs_per_job")]
+
+
+RBT_V3C_VPS, RBT_V3C_AD, RBT_V3C_OVD, RBT_V3C_GVD, RBT_V3C_AVD = range(5)
+
+
 def load(path=None):
     """Loads the shared library and declares the C ABI. Raises OSError if the HIP extension has not been built."""
     # 16 HIP streams shared by the jobs in flight: the ROCm runtime multiplexes streams onto 4 hardware queues unless told otherwise, and
@@ -85,7 +99,59 @@ def load(path=None):
     L.rbt_reconstruct.argtypes = [C.c_void_p, C.POINTER(AtlasParams), C.POINTER(Patch), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Cloud)]
     L.rbt_cloud_free.argtypes = [C.POINTER(Cloud)]
     L.rbt_d1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(D1Result)]
+    L.rbt_v3c_index.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(V3CUnit)), C.POINTER(C.c_int)]
+    L.rbt_v3c_write.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.rbt_transcode_v3c.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(V3CParams), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     return L
+
+
+def _convert(fn, data, L):
+    out, n = C.c_void_p(), C.c_size_t()
+    rc = fn(data, len(data), C.byref(out), C.byref(n))
+    if rc != 0:
+        raise RbtError(rc, L.rbt_strerror(rc).decode())
+    res = C.string_at(out, n.value)
+    L.rbt_free(out)
+    return res
+
+
+def byte_to_sample_stream(data: bytes, lib=None):
+    """rbt_byte_to_sample_stream (PCCVideoBitstream::byteStreamToSampleStream): Annex-B -> 4-byte sizes (host only)"""
+    L = lib or load()
+    return _convert(L.rbt_byte_to_sample_stream, data, L)
+
+
+def sample_to_byte_stream(data: bytes, lib=None):
+    """rbt_sample_to_byte_stream (PCCVideoBitstream::sampleStreamToByteStream): 4-byte sizes -> Annex-B (host only)"""
+    L = lib or load()
+    return _convert(L.rbt_sample_to_byte_stream, data, L)
+
+
+def v3c_index(data: bytes, lib=None):
+    """rbt_v3c_index: the units of a V3C sample stream as a list of dicts (host only: works without a GPU)"""
+    L = lib or load()
+    u, n = C.POINTER(V3CUnit)(), C.c_int()
+    rc = L.rbt_v3c_index(data, len(data), C.byref(u), C.byref(n))
+    if rc != 0:
+        raise RbtError(rc, L.rbt_strerror(rc).decode())
+    out = [{f: getattr(u[i], f) for f, _ in V3CUnit._fields_} for i in range(n.value)]
+    L.rbt_free(u)
+    return out
+
+
+def v3c_write(units, forced_precision_bytes=0, lib=None):
+    """rbt_v3c_write: a V3C sample stream from a list of units (bytes, each with its 4-byte header; host only)"""
+    L = lib or load()
+    k = len(units)
+    arr = (C.c_char_p * max(1, k))(*units)
+    sizes = (C.c_size_t * max(1, k))(*[len(x) for x in units])
+    out, n = C.c_void_p(), C.c_size_t()
+    rc = L.rbt_v3c_write(arr, sizes, k, forced_precision_bytes, C.byref(out), C.byref(n))
+    if rc != 0:
+        raise RbtError(rc, L.rbt_strerror(rc).decode())
+    res = C.string_at(out, n.value)
+    L.rbt_free(out)
+    return res
 
 
 class Context:
@@ -150,6 +216,14 @@ class Context:
             res.append(C.string_at(outs[i], ns[i]) if outs[i] else b"")
             self.L.rbt_free(outs[i])
         return res
+
+    def transcode_v3c(self, data: bytes, geometry_qp, attribute_qp, occupancy_precision=4, forced_precision_bytes=0, log2_ctb=5, rows_per_slice=-1, md5_sei=0,
+                      verify_md5=0, gofs_per_job=1):
+        """rbt_transcode_v3c: a whole V3C sample stream (every GOF this context owns) -> transcoded sample stream"""
+        p = V3CParams(occupancy_precision, geometry_qp, attribute_qp, forced_precision_bytes, log2_ctb, rows_per_slice, md5_sei, verify_md5, gofs_per_job)
+        out, n = C.c_void_p(), C.c_size_t()
+        self._chk(self.L.rbt_transcode_v3c(self.h, data, len(data), C.byref(p), C.byref(out), C.byref(n)))
+        return self._take(out, n)
 
     def set_depth(self, n):
         """rbt_set_depth: how many GOFs the caller will keep in flight (1..16 = RBT_MAX_JOBS, default 4)"""

@@ -157,6 +157,59 @@ def transcode_fanout(ctx, R, gofs: Sequence[Sequence[bytes]], rates: Sequence[in
     return res
 
 
+def wrap_v3c(R, gofs: Sequence[Sequence[bytes]], precision_bytes: int = 0, lib=None) -> bytes:
+    """A V3C sample stream around a sequence of [occupancy, geometry, attribute] Annex-B GOFs: per GOF the units PCCBitstreamWriter::encode emits for a
+    single-atlas, single-stream sequence (:96-237) - V3C_VPS, V3C_AD, V3C_OVD, V3C_GVD, V3C_AVD with the unit headers of :309-333. The parameter set and
+    atlas payloads are placeholders (the transcoder carries those units over unread); used where a container is wanted around synthetic video."""
+    import struct
+    units = []
+    for g, s in enumerate(gofs):
+        units.append(struct.pack(">I", 0 << 27) + bytes([g & 255]) * 32)
+        units.append(struct.pack(">I", 1 << 27) + bytes([(g + 1) & 255]) * 2048)
+        for t, b in zip((2, 3, 4), s):
+            units.append(struct.pack(">I", t << 27) + R.byte_to_sample_stream(b, lib))
+    return R.v3c_write(units, precision_bytes, lib)
+
+
+def unwrap_v3c(R, data: bytes, lib=None) -> List[List[bytes]]:
+    """Inverse of wrap_v3c on the video units: result[g] = the Annex-B [occupancy, geometry, attribute] sub-bitstreams of GOF g"""
+    out = {}
+    for u in R.v3c_index(data, lib):
+        if u["video_type"] >= 0:
+            out.setdefault(u["gof"], []).append(R.sample_to_byte_stream(data[u["offset"] + 4:u["offset"] + u["size"]], lib))
+    return [out[g] for g in sorted(out)]
+
+
+def merge_v3c(R, parts: Sequence[bytes], forced_precision_bytes: int = 0, lib=None) -> bytes:
+    """Merges the V3C sample streams the ranks made of one input (rbt_transcode_v3c with world_size = len(parts): part r holds the GOFs r, r + world, ...
+    in order) into the stream one rank would have written: units in GOF order, unit size precision by the writer's rule over ALL units
+    (PCCBitstreamWriter::write is called once, after the last GOF: PccAppTranscoder.cpp:343-348)."""
+    world = len(parts)
+    per_rank = []
+    for p in parts:
+        gofs = {}
+        for u in R.v3c_index(p, lib):
+            gofs.setdefault(u["gof"], []).append(p[u["offset"]:u["offset"] + u["size"]])
+        per_rank.append([gofs[k] for k in sorted(gofs)])
+    units, g = [], 0
+    while any(g // world < len(per_rank[r]) for r in range(world) if g % world == r):
+        units += per_rank[g % world][g // world]
+        g += 1
+    assert g == sum(len(x) for x in per_rank), "ranks do not hold a round-robin split of one stream"
+    return R.v3c_write(units, forced_precision_bytes, lib)
+
+
+def transcode_v3c(ctx, R, data: bytes, geometry_qp: int, attribute_qp: int, rank: int = 0, world: int = 1, depth: int = 16, group=None, device="cpu", **kw):
+    """The container form of transcode_sequence: every rank holds the input file (PccAppTranscoder.cpp:289), transcodes the GOFs its context owns
+    (rbt_transcode_v3c), rank 0 gathers the partial streams and writes the output. Returns the output on rank 0, None elsewhere."""
+    ctx.set_depth(max(1, min(depth, 16)))
+    part = ctx.transcode_v3c(data, geometry_qp, attribute_qp, **kw)
+    if world == 1:
+        return part
+    gathered = gather_streams([part], group=group, device=device)
+    return merge_v3c(R, [g[0] for g in gathered], kw.get("forced_precision_bytes", 0), lib=ctx.L) if rank == 0 else None
+
+
 def split_pairs(stream: bytes) -> List[bytes]:
     """Splits an Annex-B sub-bitstream made of closed GOPs, each starting with its own VPS (parameter sets repeated with every IDR,
     as libx265 does behind PCCTranscoder.cpp:706 and as the CTC streams do), into one byte string per closed GOP. Used to cut the

@@ -1,0 +1,158 @@
+// rabbit-transcoding_amd — the V3C sample stream either side of the hot path, written on top of the library's own C ABI.
+// Restates what PccAppTranscoder's decompressVideo does around transcodeData (PccAppTranscoder.cpp:277-349):
+//   PCCBitstreamReader::read            PCCBitstreamReader.cpp:51-70     header + units of the sample stream (C.2, :1369-1387)
+//   PCCBitstreamReader::decode          :72-96                           a GOF ends in front of the next V3C_VPS unit
+//   v3cUnitHeader                       :182-211                         the 32-bit unit header
+//   videoSubStream / readVideoStream    :98-158, PCCBitstream.cpp:88-97  payload of a video unit = the sub-bitstream, unit size - 4 bytes (:225)
+//   PCCBitstreamWriter::encode / write  PCCBitstreamWriter.cpp:96-237, :57-91, :1492-1507
+// V3C_VPS and V3C_AD units are copied, not parsed (include/rbt.h).
+#include "../../include/rbt.h"
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <deque>
+#include <string>
+
+namespace {
+struct Buf { uint8_t* p = nullptr; size_t n = 0; };
+// floorLog2 / ceilLog2 of PCCBitstreamCommon.h:526-566
+int ceil_log2(uint32_t x) { if (x == 0) return -1; x -= 1; int r = -1; while (x) { r++; x >>= 1; } return r + 1; }
+}
+
+extern "C" {
+
+int rbt_v3c_index(const uint8_t* in, size_t n, rbt_v3c_unit** units, int* n_units) {
+  if (!in || !units || !n_units || n < 1) return RBT_ERR_PARAM;
+  *units = nullptr; *n_units = 0;
+  const int prec = (in[0] >> 5) + 1;                                          // ssvh_unit_size_precision_bytes_minus1 u(3), 5 reserved bits
+  std::vector<rbt_v3c_unit> v;
+  size_t pos = 1; int gof = -1;
+  while (pos < n) {                                                           // bitstream.moreData()
+    if (pos + prec > n) return RBT_ERR_BITSTREAM;
+    uint64_t sz = 0; for (int i = 0; i < prec; i++) sz = (sz << 8) | in[pos + i];
+    pos += prec;
+    if (sz < 4 || sz > n - pos) return RBT_ERR_BITSTREAM;
+    const uint32_t h = ((uint32_t)in[pos] << 24) | ((uint32_t)in[pos + 1] << 16) | ((uint32_t)in[pos + 2] << 8) | in[pos + 3];
+    rbt_v3c_unit u; memset(&u, 0, sizeof(u));
+    u.type = (int)(h >> 27); u.offset = pos; u.size = (size_t)sz; u.video_type = -1;
+    if (u.type >= RBT_V3C_AD && u.type <= RBT_V3C_AVD) { u.parameter_set_id = (h >> 23) & 15; u.atlas_id = (h >> 17) & 63; }
+    if (u.type == RBT_V3C_AVD) { u.attribute_index = (h >> 10) & 127; u.attribute_dimension_index = (h >> 5) & 31; u.map_index = (h >> 1) & 15; u.auxiliary_video = h & 1; }
+    else if (u.type == RBT_V3C_GVD) { u.map_index = (h >> 13) & 15; u.auxiliary_video = (h >> 12) & 1; }
+    if (u.type == RBT_V3C_VPS || gof < 0) gof++;
+    u.gof = gof;
+    if (u.type == RBT_V3C_OVD) u.video_type = RBT_VIDEO_OCCUPANCY;
+    else if (u.type == RBT_V3C_GVD && !u.auxiliary_video) u.video_type = RBT_VIDEO_GEOMETRY;
+    else if (u.type == RBT_V3C_AVD && !u.auxiliary_video && u.attribute_dimension_index == 0) u.video_type = RBT_VIDEO_ATTRIBUTE;
+    v.push_back(u);
+    pos += (size_t)sz;
+  }
+  *units = (rbt_v3c_unit*)malloc(sizeof(rbt_v3c_unit) * (v.size() ? v.size() : 1));
+  if (!*units) return RBT_ERR_NOMEM;
+  if (!v.empty()) memcpy(*units, v.data(), sizeof(rbt_v3c_unit) * v.size());
+  *n_units = (int)v.size();
+  return RBT_OK;
+}
+
+int rbt_v3c_write(const uint8_t* const* unit, const size_t* unit_size, int n_units, int forced_precision_bytes, uint8_t** out, size_t* n_out) {
+  if (!out || !n_out || n_units < 0 || (n_units && (!unit || !unit_size)) || forced_precision_bytes < 0 || forced_precision_bytes > 8) return RBT_ERR_PARAM;
+  uint32_t max_size = 0; size_t total = 1;                                    // the reference keeps the maximum in 32 bits (:66-69)
+  for (int i = 0; i < n_units; i++) { if (!unit[i] || unit_size[i] > 0xFFFFFFFFull) return RBT_ERR_PARAM; if (max_size < (uint32_t)unit_size[i]) max_size = (uint32_t)unit_size[i]; total += unit_size[i]; }
+  int bits = ceil_log2(max_size);
+  int prec = (bits + 7) / 8;                                                  // ceil(ceilLog2(max) / 8.0); ceilLog2(0) = -1 gives 0
+  if (bits < 0) prec = 0;
+  if (prec < 1) prec = 1;
+  if (prec > 8) prec = 8;
+  if (prec < forced_precision_bytes) prec = forced_precision_bytes;
+  total += (size_t)prec * (size_t)n_units;
+  uint8_t* o = (uint8_t*)malloc(total); if (!o) return RBT_ERR_NOMEM;
+  size_t pos = 0;
+  o[pos++] = (uint8_t)((prec - 1) << 5);
+  for (int i = 0; i < n_units; i++) {
+    for (int b = prec - 1; b >= 0; b--) o[pos++] = b >= 8 ? 0 : (uint8_t)((uint64_t)unit_size[i] >> (8 * b));   // bitstream.write(size, 8 * precision): the low bits of the value
+    memcpy(o + pos, unit[i], unit_size[i]); pos += unit_size[i];
+  }
+  *out = o; *n_out = pos;
+  return RBT_OK;
+}
+
+int rbt_transcode_v3c(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_params* p, uint8_t** out, size_t* n_out) {
+  if (!ctx || !in || !p || !out || !n_out) return RBT_ERR_PARAM;
+  *out = nullptr; *n_out = 0;
+  rbt_v3c_unit* units = nullptr; int nu = 0;
+  int rc = rbt_v3c_index(in, n, &units, &nu);
+  if (rc) return rc;
+  std::vector<rbt_v3c_unit> U(units, units + nu); rbt_free(units);
+  const int n_gofs = nu ? U.back().gof + 1 : 0;
+  // per GOF: the units transcodeData replaces (PCCTranscoder.cpp:145-168)
+  struct Pick { int unit; int video_type; };
+  std::vector<std::vector<Pick>> picks(n_gofs);
+  for (int g = 0, i = 0; g < n_gofs; g++) {
+    int n_geo = 0, n_attr = 0;
+    for (; i < nu && U[i].gof == g; i++) {
+      if (!rbt_owns_gof(ctx, g)) continue;
+      if (U[i].video_type == RBT_VIDEO_GEOMETRY) n_geo++;
+      if (U[i].video_type == RBT_VIDEO_ATTRIBUTE) n_attr++;
+      if (U[i].video_type == RBT_VIDEO_OCCUPANCY && p->occupancy_precision != 4) continue;         // :150: left as it is
+      if (U[i].video_type >= 0 && U[i].size > 4) picks[g].push_back({i, U[i].video_type});
+    }
+    if (n_geo > 1 || n_attr > 1) return RBT_ERR_UNSUPPORTED;                                          // separate map streams: VIDEO_GEOMETRY_D0.. / VIDEO_ATTRIBUTE_T0.., which transcodeData never asks for
+  }
+  std::vector<Buf> repl(nu);                                                                           // new payloads (sample stream form) of the picked units
+  auto cleanup = [&]() { for (auto& b : repl) free(b.p); };
+  // jobs: the picked units of `per` consecutive owned GOFs each, as many in flight as the context allows (RBT_ERR_BUSY tells)
+  struct Job { rbt_job* j; std::vector<int> unit; };
+  std::deque<Job> q;
+  auto collect = [&]() -> int {
+    Job jb = q.front(); q.pop_front();
+    std::vector<uint8_t*> o(jb.unit.size(), nullptr); std::vector<size_t> on(jb.unit.size(), 0);
+    int r = rbt_wait_gof(ctx, jb.j, o.data(), on.data());
+    for (size_t k = 0; k < jb.unit.size(); k++) {
+      if (!r) r = rbt_byte_to_sample_stream(o[k], on[k], &repl[jb.unit[k]].p, &repl[jb.unit[k]].n);   // transcodeVideo ends with it (PCCTranscoder.cpp:517)
+      rbt_free(o[k]);
+    }
+    return r;
+  };
+  const int per = p->gofs_per_job > 1 ? p->gofs_per_job : 1;
+  std::vector<int> owned; for (int g = 0; g < n_gofs; g++) if (rbt_owns_gof(ctx, g) && !picks[g].empty()) owned.push_back(g);
+  for (size_t a = 0; a < owned.size() && !rc; a += per) {
+    std::vector<Buf> conv; std::vector<const uint8_t*> ip; std::vector<size_t> in_n; std::vector<rbt_stream_params> sp; Job jb{nullptr, {}};
+    for (size_t b = a; b < a + per && b < owned.size() && !rc; b++)
+      for (const Pick& pk : picks[owned[b]]) {
+        Buf c; rc = rbt_sample_to_byte_stream(in + U[pk.unit].offset + 4, U[pk.unit].size - 4, &c.p, &c.n);   // transcodeData :152,159,164
+        if (rc) break;
+        conv.push_back(c); jb.unit.push_back(pk.unit);
+        rbt_stream_params s; memset(&s, 0, sizeof(s));
+        s.video_type = pk.video_type; s.qp = pk.video_type == RBT_VIDEO_GEOMETRY ? p->geometry_qp : (pk.video_type == RBT_VIDEO_ATTRIBUTE ? p->attribute_qp : 8);
+        s.occupancy_precision = p->occupancy_precision; s.log2_ctb = p->log2_ctb; s.ctb_rows_per_slice = p->ctb_rows_per_slice; s.md5_sei = p->md5_sei; s.verify_md5 = p->verify_md5;
+        sp.push_back(s);
+      }
+    for (auto& c : conv) { ip.push_back(c.p); in_n.push_back(c.n); }
+    if (!rc && (int)ip.size() > RBT_MAX_STREAMS) rc = RBT_ERR_PARAM;
+    while (!rc) {
+      rc = rbt_submit_gof(ctx, (int)ip.size(), ip.data(), in_n.data(), sp.data(), &jb.j);
+      if (rc == RBT_ERR_BUSY && !q.empty()) { rc = collect(); continue; }     // every slot taken: take the oldest result first
+      break;
+    }
+    for (auto& c : conv) free(c.p);                                            // the inputs may go as soon as submit returns
+    if (!rc) q.push_back(jb);
+  }
+  while (!q.empty()) { int r = collect(); if (!rc) rc = r; }
+  if (rc) { cleanup(); return rc; }
+  // PCCBitstreamWriter::encode: the units of every (owned) GOF in order, video units with their 4 header bytes in front of the new payload
+  std::vector<Buf> made; std::vector<const uint8_t*> up; std::vector<size_t> un;
+  for (int i = 0; i < nu; i++) {
+    if (!rbt_owns_gof(ctx, U[i].gof)) continue;
+    if (repl[i].p) {
+      Buf m; m.n = 4 + repl[i].n; m.p = (uint8_t*)malloc(m.n);
+      if (!m.p) { rc = RBT_ERR_NOMEM; break; }
+      memcpy(m.p, in + U[i].offset, 4); memcpy(m.p + 4, repl[i].p, repl[i].n);
+      made.push_back(m); up.push_back(m.p); un.push_back(m.n);
+    } else { up.push_back(in + U[i].offset); un.push_back(U[i].size); }
+  }
+  if (!rc) rc = rbt_v3c_write(up.data(), un.data(), (int)up.size(), p->forced_unit_size_precision_bytes, out, n_out);
+  for (auto& m : made) free(m.p);
+  cleanup();
+  return rc;
+}
+
+}  // extern "C"

@@ -22,6 +22,15 @@ def _sequence():
     return gs.make_sequence([so, sg, sa], FRAMES, GOF)
 
 
+def _container(seq):
+    """the same sequence as a V3C sample stream (tests/v3c_synth.py)"""
+    import v3c_synth as V
+    units = []
+    for g, s in enumerate(seq):
+        units += V.gof_units(s, 300 + g, aux=(g == 2))
+    return V.sample_stream(units, 3)
+
+
 def _worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -31,8 +40,9 @@ def _worker(rank, world, port, q):
     seq = _sequence()
     out = gs.transcode_sequence(ctx, seq, gs.rate_params(R, 3), rank=rank, world=world, depth=2)
     fan = gs.transcode_fanout(ctx, R, seq[2:], rates=(1, 2, 3, 4, 5), rank=rank, world=world, depth=2)
+    v3c = gs.transcode_v3c(ctx, R, _container(seq), 24, 32, rank=rank, world=world, depth=2)
     if rank == 0:
-        q.put((out, fan))
+        q.put((out, fan, v3c))
     dist.barrier()
     dist.destroy_process_group()
     ctx.close()
@@ -78,7 +88,7 @@ def test_sequence_and_fanout_world2_equal_unsharded_and_oracle(hostemu):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out, fan = q.get(timeout=600)
+    out, fan, v3c = q.get(timeout=600)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -91,4 +101,7 @@ def test_sequence_and_fanout_world2_equal_unsharded_and_oracle(hostemu):
     assert out == [O.transcode_data(g, [(0, 8, 4, 5, gs.DEFAULT_ROWS, 0), (1, 24, 4, 5, gs.DEFAULT_ROWS, 0), (19, 32, 4, 5, gs.DEFAULT_ROWS, 0)]) for g in seq]
     for r, (gq, aq, pr) in gs.RATE_POINTS.items():
         assert fan[r] == [O.transcode_data(g, [(0, 8, pr, 5, gs.DEFAULT_ROWS, 0), (1, gq, pr, 5, gs.DEFAULT_ROWS, 0), (19, aq, pr, 5, gs.DEFAULT_ROWS, 0)]) for g in seq[2:]]
+    # the container walk, sharded: the merged file is the one a single rank writes and the one the oracle's restatement of PccAppTranscoder's loop writes
+    assert v3c == O.v3c_transcode(_container(seq), 24, 32, 4)
+    c = R.Context(lib_path=rbt_lib.HOSTEMU_LIB); assert v3c == c.transcode_v3c(_container(seq), 24, 32); c.close()
     assert fan[5][0][0] == seq[2][0]       # R5 keeps occupancy precision 2: the reference does not touch the occupancy stream (:150)

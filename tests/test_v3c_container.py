@@ -1,0 +1,157 @@
+"""the V3C sample stream either side of the hot path (rbt_v3c_index / rbt_v3c_write / rbt_transcode_v3c, include/rbt.h) against an
+independent Python construction of the container (tests/v3c_synth.py) and against the oracle's restatement of the walk (oracle_v3c_transcode).
+The index / write halves need no GPU; the transcode runs on the host build of the kernels here and on the GPU in test_gpu_v3c.py."""
+import os
+import subprocess
+import numpy as np
+import pytest
+import oracle_lib as O
+import rbt_lib
+import v3c_synth as V
+
+
+@pytest.fixture(scope="module")
+def R():
+    return rbt_lib.module()
+
+
+@pytest.fixture(scope="module")
+def hlib(R):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(__file__), "hostemu")])
+    return R.load(rbt_lib.HOSTEMU_LIB)
+
+
+@pytest.fixture(scope="module")
+def ctx(R, hlib):
+    c = R.Context(lib_path=rbt_lib.HOSTEMU_LIB)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def container():
+    """3 GOFs (2 / 1 / 2 point-cloud frames, different sizes), the second with auxiliary video units and a second attribute partition"""
+    gofs = [V.gof_streams(64, 64, 2, 11), V.gof_streams(128, 64, 1, 12), V.gof_streams(96, 96, 2, 13)]
+    units = []
+    for g, s in enumerate(gofs):
+        units += V.gof_units(s, 100 + g, aux=(g == 1), extra_attr_partition=(g == 1))
+    return gofs, units
+
+
+@pytest.mark.parametrize("precision", [2, 3, 4, 8])
+def test_index_lists_every_unit(R, hlib, container, precision):
+    gofs, units = container
+    data = V.sample_stream(units, precision)
+    idx = R.v3c_index(data, hlib)
+    assert len(idx) == len(units)
+    assert [u["type"] for u in idx] == [x[0] >> 3 for x in units]
+    assert [data[u["offset"]:u["offset"] + u["size"]] for u in idx] == units
+    assert [u["gof"] for u in idx] == [0] * 5 + [1] * 8 + [2] * 5
+    # the three videos transcodeData names, per GOF; auxiliary video and the second attribute partition are not among them
+    assert [u["video_type"] for u in idx if u["gof"] == 1] == [-1, -1, 0, 1, -1, 19, -1, -1]
+    aux = [u for u in idx if u["auxiliary_video"]]
+    assert [u["type"] for u in aux] == [V.GVD, V.AVD] and idx[12]["attribute_dimension_index"] == 1
+
+
+def test_index_rejects_truncated_streams(R, hlib, container):
+    data = V.sample_stream(container[1], 3)
+    for cut in (len(data) - 1, len(data) - 100, 3, 2):
+        with pytest.raises(R.RbtError) as e:
+            R.v3c_index(data[:cut], hlib)
+        assert e.value.code == -2
+    assert R.v3c_index(data[:1], hlib) == []                                     # a header and no units
+
+
+@pytest.mark.parametrize("largest,forced,want", [(5, 0, 1), (255, 0, 1), (257, 0, 2), (65535, 0, 2), (65537, 0, 3), (70000, 0, 3), (300, 4, 4), (70000, 2, 3)])
+def test_write_precision_follows_the_largest_unit(R, hlib, largest, forced, want):
+    """PCCBitstreamWriter::write (:57-91): min(max(ceil(ceilLog2(largest unit) / 8), 1), 8) bytes, at least the forced value"""
+    units = [V.unit_header(V.VPS) + bytes(20), V.unit_header(V.AD) + bytes(largest - 4), V.unit_header(V.OVD) + b"\x01" * 9]
+    data = R.v3c_write(units, forced, hlib)
+    assert data == V.sample_stream(units, want)
+    assert V.parse(data) == (want, units)
+
+
+def test_write_keeps_the_reference_rule_at_powers_of_256(R, hlib):
+    """ceilLog2(256) = 8 -> one byte, which cannot hold 256: the reference's rule as written (PCCBitstreamWriter.cpp:71-72). Restated as it is (a caller who meets it
+    forces the precision, forcedSsvhUnitSizePrecisionBytes_); the size byte wraps to 0."""
+    units = [V.unit_header(V.AD) + bytes(252)]
+    data = R.v3c_write(units, 0, hlib)
+    assert data[0] == 0 and data[1] == 0 and len(data) == 2 + 256
+    assert V.parse(R.v3c_write(units, 2, hlib)) == (2, units)
+
+
+def test_transcode_v3c_equals_oracle_and_manual_walk(R, ctx, container):
+    gofs, units = container
+    data = V.sample_stream(units, 3)
+    got = ctx.transcode_v3c(data, 24, 32, occupancy_precision=4)
+    assert got == O.v3c_transcode(data, 24, 32, 4)
+    # the same through the sub-bitstream entry points, assembled by the Python container code
+    P = R.StreamParams
+    want_units = []
+    for g, s in enumerate(gofs):
+        o = [ctx.transcode_substream(s[0], 0, 8, 4, 5, -1, 0), ctx.transcode_substream(s[1], 1, 24, 4, 5, -1, 0), ctx.transcode_substream(s[2], 19, 32, 4, 5, -1, 0)]
+        src = [u for u, i in zip(units, R.v3c_index(data, ctx.L)) if i["gof"] == g]
+        k = 0
+        for u, i in zip(src, [i for i in R.v3c_index(data, ctx.L) if i["gof"] == g]):
+            if i["video_type"] >= 0:
+                want_units.append(u[:4] + O.byte_to_sample_stream(o[k])); k += 1
+            else:
+                want_units.append(u)
+    prec, out_units = V.parse(got)
+    assert out_units == want_units and prec == 2
+    # parameter sets and atlas data are carried over; the output is smaller and indexes like the input
+    oi = R.v3c_index(got, ctx.L)
+    assert [(u["type"], u["gof"], u["video_type"]) for u in oi] == [(u["type"], u["gof"], u["video_type"]) for u in R.v3c_index(data, ctx.L)]
+    assert len(got) < len(data)
+
+
+def test_transcode_v3c_leaves_occupancy_alone_unless_precision_4(R, ctx, container):
+    gofs, units = container
+    data = V.sample_stream(units[:5], 2)
+    got = ctx.transcode_v3c(data, 28, 37, occupancy_precision=2, forced_precision_bytes=4)
+    assert got == O.v3c_transcode(data, 28, 37, 2, 4)
+    prec, out_units = V.parse(got)
+    assert prec == 4 and out_units[2] == units[2] and out_units[:2] == units[:2] and out_units[3] != units[3]
+
+
+@pytest.mark.parametrize("depth,per", [(1, 1), (2, 1), (3, 2), (16, 2)])
+def test_transcode_v3c_same_bytes_at_every_depth(R, ctx, container, depth, per):
+    gofs, units = container
+    data = V.sample_stream(units, 3)
+    ctx.set_depth(depth)
+    try:
+        assert ctx.transcode_v3c(data, 24, 32, gofs_per_job=per) == O.v3c_transcode(data, 24, 32, 4)
+    finally:
+        ctx.set_depth(4)
+
+
+def test_transcode_v3c_refuses_separate_map_streams(R, ctx, container):
+    gofs, units = container
+    u = list(units[:5])
+    u.insert(4, V.unit_header(V.GVD, map_idx=1) + units[3][4:])                  # geometry D0 and D1 as separate streams
+    with pytest.raises(R.RbtError) as e:
+        ctx.transcode_v3c(V.sample_stream(u, 3), 24, 32)
+    assert e.value.code == -3
+
+
+def test_transcode_v3c_reports_damaged_video_units(R, ctx, container):
+    gofs, units = container
+    u = list(units[:5])
+    u[3] = u[3][:4] + u[3][4:200]                                                # sample stream cut in the middle of a NAL unit
+    with pytest.raises(R.RbtError) as e:
+        ctx.transcode_v3c(V.sample_stream(u, 3), 24, 32)
+    assert e.value.code == -2
+
+
+def test_sharded_outputs_merge_into_the_unsharded_stream(R, hlib, container):
+    """multi-GPU form: every rank's output holds the GOFs it owns; merged in GOF order by index + write == the single-rank output"""
+    gofs, units = container
+    data = V.sample_stream(units, 3)
+    gs = rbt_lib.module_file("gof_shard")
+    whole = O.v3c_transcode(data, 24, 32, 4)
+    parts = []
+    for r in range(2):
+        c = R.Context(rank=r, world=2, lib_path=rbt_lib.HOSTEMU_LIB)
+        parts.append(c.transcode_v3c(data, 24, 32)); c.close()
+    assert [sorted({u["gof"] for u in R.v3c_index(p, hlib)}) for p in parts] == [[0, 1], [0]]   # rank 0: GOFs 0 and 2 (renumbered), rank 1: GOF 1
+    assert gs.merge_v3c(R, parts, lib=hlib) == whole
