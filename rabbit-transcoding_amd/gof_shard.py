@@ -171,12 +171,15 @@ def wrap_v3c(R, gofs: Sequence[Sequence[bytes]], precision_bytes: int = 0, lib=N
     return R.v3c_write(units, precision_bytes, lib)
 
 
-def unwrap_v3c(R, data: bytes, lib=None) -> List[List[bytes]]:
-    """Inverse of wrap_v3c on the video units: result[g] = the Annex-B [occupancy, geometry, attribute] sub-bitstreams of GOF g"""
+def unwrap_v3c(R, data: bytes, lib=None, annexb: bool = True) -> List[List[bytes]]:
+    """The video units of a V3C sample stream: result[g] = the [occupancy, geometry, attribute] sub-bitstreams of GOF g, as Annex-B byte streams
+    (sampleStreamToByteStream, which chooses start code lengths by its own rule: not the inverse of byteStreamToSampleStream byte for byte) or, with
+    annexb=False, in the sample stream form they are stored in."""
     out = {}
     for u in R.v3c_index(data, lib):
         if u["video_type"] >= 0:
-            out.setdefault(u["gof"], []).append(R.sample_to_byte_stream(data[u["offset"] + 4:u["offset"] + u["size"]], lib))
+            payload = data[u["offset"] + 4:u["offset"] + u["size"]]
+            out.setdefault(u["gof"], []).append(R.sample_to_byte_stream(payload, lib) if annexb else payload)
     return [out[g] for g in sorted(out)]
 
 

@@ -155,3 +155,16 @@ def test_sharded_outputs_merge_into_the_unsharded_stream(R, hlib, container):
         parts.append(c.transcode_v3c(data, 24, 32)); c.close()
     assert [sorted({u["gof"] for u in R.v3c_index(p, hlib)}) for p in parts] == [[0, 1], [0]]   # rank 0: GOFs 0 and 2 (renumbered), rank 1: GOF 1
     assert gs.merge_v3c(R, parts, lib=hlib) == whole
+
+
+def test_wrap_and_unwrap_helpers(R, ctx, container):
+    """gof_shard.wrap_v3c / unwrap_v3c (bench.py's container leg): the video units of a wrapped sequence hold the sub-bitstreams in sample stream form, and a
+    transcode of the container carries exactly what the per-GOF walk produces"""
+    gs = rbt_lib.module_file("gof_shard")
+    gofs, _ = container
+    data = gs.wrap_v3c(R, gofs, lib=ctx.L)
+    assert gs.unwrap_v3c(R, data, lib=ctx.L, annexb=False) == [[O.byte_to_sample_stream(s) for s in g] for g in gofs]
+    assert [[O.decode(s)[0].tobytes() for s in g] for g in gs.unwrap_v3c(R, data, lib=ctx.L)] == [[O.decode(s)[0].tobytes() for s in g] for g in gofs]
+    walk = gs.transcode_sequence(ctx, gofs, gs.rate_params(R, 3), depth=2)
+    out = gs.transcode_v3c(ctx, R, data, 24, 32, depth=2)
+    assert gs.unwrap_v3c(R, out, lib=ctx.L, annexb=False) == [[O.byte_to_sample_stream(s) for s in g] for g in walk]
