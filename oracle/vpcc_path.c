@@ -5,7 +5,8 @@
  *   PCCVideoBitstream::byteStreamToSampleStream  :85-112, getEndOfNaluPosition :174-184
  *   PCCTranscoder::resize_frame2                 source/lib/PccLibTranscoder/source/PCCTranscoder.cpp:594-646
  *   PCCTranscoder::transcodeVideo                :374-546 (decode loop :428-448, pool :466, encoder options :825-904)
- * PARITY UNPINNED for these four: PccLibBitstreamCommon / PccLibTranscoder need a cmake-generated PCCConfig.h (and libav*), so
+ *   decompressVideo's sample stream walk         source/app/PccAppTranscoder/PccAppTranscoder.cpp:277-349 (PCCBitstreamReader.cpp:51-96, PCCBitstreamWriter.cpp:57-91)
+ * PARITY UNPINNED for these five: PccLibBitstreamCommon / PccLibTranscoder need a cmake-generated PCCConfig.h (and libav*), so
  * they cannot be compiled here without stand-ins, and the reference holds no fixtures for them. The restatements follow the
  * source text line by line (including the newFrame quirk at :146); tests/test_oracle_codec.py checks round trips only.
  */
