@@ -299,7 +299,8 @@ def main():
             ct = float(t.item())
         if rank == 0:
             walk["container"] = {"value": round(args.walk_frames / ct, 3), "unit": "point-cloud frames/s", "seconds": round(ct, 4), "bytes_in": len(data), "bytes_out": len(merged),
-                                 "gofs_per_job": G, "video_units_equal_walk": gs.unwrap_v3c(R, merged, lib=ctx.L, annexb=False) == [[R.byte_to_sample_stream(s_, ctx.L) for s_ in g] for g in stitched]}
+                                 "gofs_per_job": G, "stat_in": {k: v for k, v in R.v3c_stats(data, ctx.L).items() if k.startswith("total")}, "stat_out": {k: v for k, v in R.v3c_stats(merged, ctx.L).items() if k.startswith("total")},
+                                 "video_units_equal_walk": gs.unwrap_v3c(R, merged, lib=ctx.L, annexb=False) == [[R.byte_to_sample_stream(s_, ctx.L) for s_ in g] for g in stitched]}
     # configs[4]: every rate point R1..R5 from the R5 input, target rate i on rank i mod world (decode replicated; a rank that holds several
     # rates hands each GOF over once and the library decodes it once)
     fanout = None

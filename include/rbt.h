@@ -196,6 +196,15 @@ int rbt_v3c_index(const uint8_t* in, size_t n, rbt_v3c_unit** units, int* n_unit
 /* PCCBitstreamWriter::write (:57-91) + sampleStreamV3CHeader / sampleStreamV3CUnit (:1492-1507): precision = min(max(ceil(ceilLog2(largest unit) / 8), 1), 8)
  * bytes, at least forced_precision_bytes (forcedSsvhUnitSizePrecisionBytes_); then every unit behind its size. Host only. */
 int rbt_v3c_write(const uint8_t* const* unit, const size_t* unit_size, int n_units, int forced_precision_bytes, uint8_t** out, size_t* n_out);
+/* PCCBitstreamStat as decompressVideo prints it for the input and the output file (PccAppTranscoder.cpp:351-352, PCCBitstream.h:48-154), from the bytes alone. Host only. */
+typedef struct {
+  int n_units, n_gofs, unit_size_precision_bytes;
+  uint64_t header;                                    /* sample stream header + the size fields of all units (PCCBitstreamReader.cpp:51-70) */
+  uint64_t unit_size[5];                              /* V3CUnitSize[type]: unit headers + payloads */
+  uint64_t occupancy_video, geometry_video, geometry_aux_video, attribute_video, attribute_aux_video;   /* videoBinSize: payloads of the video units */
+  uint64_t total_metadata, total_geometry, total_attribute, total;   /* getTotalMetadata() + header, getTotalGeometry(), getTotalAttribute(), their sum (:138-148) */
+} rbt_v3c_stat;
+int rbt_v3c_stats(const uint8_t* in, size_t n, rbt_v3c_stat* out);
 typedef struct {
   int occupancy_precision;   /* occupancyPrecision_: the occupancy video is transcoded (2x2 OR-pool, lossless) only when 4 (PCCTranscoder.cpp:150) */
   int geometry_qp, attribute_qp;                      /* geometryQP_, attributeQP_ */

@@ -64,6 +64,12 @@ class V3CParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("occupancy_precision", "geometry_qp", "attribute_qp", "forced_unit_size_precision_bytes", "log2_ctb", "ctb_rows_per_slice", "md5_sei", "verify_md5", "gofs_per_job")]
 
 
+class V3CStat(C.Structure):
+    """rbt_v3c_stat: PCCBitstreamStat of a V3C sample stream"""
+    _fields_ = [("n_units", C.c_int), ("n_gofs", C.c_int), ("unit_size_precision_bytes", C.c_int), ("header", C.c_uint64), ("unit_size", C.c_uint64 * 5)] + \
+               [(n, C.c_uint64) for n in ("occupancy_video", "geometry_video", "geometry_aux_video", "attribute_video", "attribute_aux_video", "total_metadata", "total_geometry", "total_attribute", "total")]
+
+
 RBT_V3C_VPS, RBT_V3C_AD, RBT_V3C_OVD, RBT_V3C_GVD, RBT_V3C_AVD = range(5)
 
 
@@ -101,6 +107,7 @@ def load(path=None):
     L.rbt_d1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(D1Result)]
     L.rbt_v3c_index.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(V3CUnit)), C.POINTER(C.c_int)]
     L.rbt_v3c_write.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.rbt_v3c_stats.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(V3CStat)]
     L.rbt_transcode_v3c.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(V3CParams), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     return L
 
@@ -137,6 +144,16 @@ def v3c_index(data: bytes, lib=None):
     out = [{f: getattr(u[i], f) for f, _ in V3CUnit._fields_} for i in range(n.value)]
     L.rbt_free(u)
     return out
+
+
+def v3c_stats(data: bytes, lib=None):
+    """rbt_v3c_stats: the PCCBitstreamStat figures of a V3C sample stream as a dict (host only)"""
+    L = lib or load()
+    st = V3CStat()
+    rc = L.rbt_v3c_stats(data, len(data), C.byref(st))
+    if rc != 0:
+        raise RbtError(rc, L.rbt_strerror(rc).decode())
+    return {n: (list(getattr(st, n)) if n == "unit_size" else getattr(st, n)) for n, _ in V3CStat._fields_}
 
 
 def v3c_write(units, forced_precision_bytes=0, lib=None):

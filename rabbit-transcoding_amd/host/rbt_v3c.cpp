@@ -75,6 +75,31 @@ int rbt_v3c_write(const uint8_t* const* unit, const size_t* unit_size, int n_uni
   return RBT_OK;
 }
 
+int rbt_v3c_stats(const uint8_t* in, size_t n, rbt_v3c_stat* out) {
+  if (!in || !out || n < 1) return RBT_ERR_PARAM;
+  memset(out, 0, sizeof(*out));
+  rbt_v3c_unit* u = nullptr; int nu = 0;
+  int rc = rbt_v3c_index(in, n, &u, &nu);
+  if (rc) return rc;
+  out->n_units = nu; out->n_gofs = nu ? u[nu - 1].gof + 1 : 0; out->unit_size_precision_bytes = (in[0] >> 5) + 1;
+  out->header = 1 + (uint64_t)out->unit_size_precision_bytes * (uint64_t)nu;
+  for (int i = 0; i < nu; i++) {
+    if (u[i].type > RBT_V3C_AVD) continue;                                    // reserved unit types are not counted by the reference either
+    out->unit_size[u[i].type] += u[i].size;
+    const uint64_t pay = u[i].size - 4;
+    if (u[i].type == RBT_V3C_OVD) out->occupancy_video += pay;
+    else if (u[i].type == RBT_V3C_GVD) (u[i].auxiliary_video ? out->geometry_aux_video : out->geometry_video) += pay;
+    else if (u[i].type == RBT_V3C_AVD) (u[i].auxiliary_video ? out->attribute_aux_video : out->attribute_video) += pay;
+  }
+  rbt_free(u);
+  uint64_t all = 0; for (int t = 0; t < 5; t++) all += out->unit_size[t];
+  out->total_geometry = out->geometry_video + out->geometry_aux_video;
+  out->total_attribute = out->attribute_video + out->attribute_aux_video;
+  out->total_metadata = all - out->total_geometry - out->total_attribute + out->header;
+  out->total = out->total_metadata + out->total_geometry + out->total_attribute;
+  return RBT_OK;
+}
+
 int rbt_transcode_v3c(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_params* p, uint8_t** out, size_t* n_out) {
   if (!ctx || !in || !p || !out || !n_out) return RBT_ERR_PARAM;
   *out = nullptr; *n_out = 0;

@@ -168,3 +168,19 @@ def test_wrap_and_unwrap_helpers(R, ctx, container):
     walk = gs.transcode_sequence(ctx, gofs, gs.rate_params(R, 3), depth=2)
     out = gs.transcode_v3c(ctx, R, data, 24, 32, depth=2)
     assert gs.unwrap_v3c(R, out, lib=ctx.L, annexb=False) == [[O.byte_to_sample_stream(s) for s in g] for g in walk]
+
+
+def test_stats_add_up_like_the_reference_report(R, hlib, container):
+    """rbt_v3c_stats == PCCBitstreamStat::trace's figures (PCCBitstream.h:48-154) computed here from the unit list"""
+    gofs, units = container
+    data = V.sample_stream(units, 3)
+    st = R.v3c_stats(data, hlib)
+    by_type = [sum(len(u) for u in units if u[0] >> 3 == t) for t in range(5)]
+    aux = lambda u: (u[3] & 1) if u[0] >> 3 == V.AVD else (u[2] >> 4) & 1
+    geo = sum(len(u) - 4 for u in units if u[0] >> 3 == V.GVD); att = sum(len(u) - 4 for u in units if u[0] >> 3 == V.AVD)
+    assert st["unit_size"] == by_type and (st["n_units"], st["n_gofs"], st["unit_size_precision_bytes"]) == (len(units), 3, 3)
+    assert st["header"] == 1 + 3 * len(units) and st["total"] == len(data)
+    assert st["geometry_video"] + st["geometry_aux_video"] == geo == st["total_geometry"] and st["attribute_video"] + st["attribute_aux_video"] == att == st["total_attribute"]
+    assert st["geometry_aux_video"] == sum(len(u) - 4 for u in units if u[0] >> 3 == V.GVD and aux(u)) == 300
+    assert st["occupancy_video"] == sum(len(u) - 4 for u in units if u[0] >> 3 == V.OVD)
+    assert st["total_metadata"] == len(data) - geo - att
