@@ -67,7 +67,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=16, help="point-cloud frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--multi-gof", type=int, default=8, help="also time G GOFs per call (extra field multi_gof; 0/1 = skip)")
     ap.add_argument("--in-flight", type=int, default=16, help="GOFs in flight (rbt_submit_gof ahead of rbt_wait_gof), 1..16; 1 = blocking calls")
-    ap.add_argument("--gofs-per-job", type=int, default=2, help="GOFs handed over per rbt_submit_gof call (a step stays one GOF; --steps is rounded up to a multiple)")
+    ap.add_argument("--gofs-per-job", type=int, default=0, help="GOFs handed over per rbt_submit_gof call (a step stays one GOF; the K steps are spread evenly over ceil(K / G) jobs). "
+                    "0 = choose by the length of the run: 2 for a long run (16 jobs x 2 GOFs keep the GPU full), ceil(K / 7) for a run shorter than 48 steps (a run that is "
+                    "all ramp-up and drain does better with few jobs that own two hardware queues each than with many that own one)")
     ap.add_argument("--sweep", type=int, default=64, help="also time K GOFs at every in-flight depth 1..4 (extra field in_flight_sweep; 0/1 = skip)")
     ap.add_argument("--quality", type=int, default=1, help="report picture PSNR of the output vs the input (extra field quality; 0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path)")
@@ -143,6 +145,8 @@ def main():
     # One step = one GOF through the hot path. The steps are issued the way a transcoder walks a sequence: rbt_submit_gof
     # for GOF i+D-1 before rbt_wait_gof for GOF i (D = --in-flight GOFs in flight on disjoint HIP streams; D = 1 is the
     # blocking rbt_transcode_gof). Every one of the K timed steps is submitted and collected inside the timed region.
+    if args.gofs_per_job <= 0:
+        args.gofs_per_job = 2 if args.steps >= 48 else max(1, (args.steps + 6) // 7)
     D = max(1, min(args.in_flight, 16, (args.steps + max(1, args.gofs_per_job) - 1) // max(1, args.gofs_per_job)))   # never announce a deeper pipeline than the run has steps: shallower pipelines get more streams per job
     stats_acc = {}
 
@@ -173,9 +177,11 @@ def main():
 
     def run(n_steps, depth, acc, g=None):
         g = g or G
-        js, jp = job_of(g)
+        nj = (n_steps + g - 1) // g                                             # exactly n_steps GOFs, spread evenly over the jobs (20 steps, G = 3: 3 3 3 3 3 3 2)
+        sizes = [n_steps // nj + (1 if i < n_steps % nj else 0) for i in range(nj)] if nj else []
         q, outs = [], None
-        for _ in range((n_steps + g - 1) // g):
+        for sz in sizes:
+            js, jp = job_of(sz)
             if len(q) == depth: outs = collect(q.pop(0), acc)
             c0 = time.perf_counter()
             q.append(ctx.submit_gof(js, jp))
@@ -200,7 +206,6 @@ def main():
     outs = run(args.steps, D, stats_acc)
     sync()
     elapsed = time.perf_counter() - t0
-    args.steps = (args.steps + G - 1) // G * G
     host_submit_ms, host_wait_ms = 1000 * host_t["submit"] / args.steps, 1000 * host_t["wait"] / args.steps
     if world > 1:
         import torch
@@ -209,7 +214,8 @@ def main():
         elapsed = float(t.item())
     steps = args.steps
     fps = world * n_pc * steps / elapsed
-    n_jobs = steps // G                                        # kernel timings are per job = per launch group (a job's launches cover its G GOFs)
+    n_jobs = (steps + G - 1) // G                              # kernel timings are per job = per launch group (a job's launches cover its GOFs)
+    gpj = steps / n_jobs                                       # GOFs per job of the timed run (G unless K is not a multiple)
     st = {k: v / n_jobs for k, v in stats_acc.items()}
 
     # dominant kernel group of the path (GPU-side hipEvent timings taken on the launch stream inside librbt)
@@ -228,7 +234,7 @@ def main():
            "intra_analysis": enc_pix // 2,                     # I-picture source samples
            "encode_recon": 3 * enc_pix + enc_pix // 2,         # source in, levels + reconstruction out, P reference in
            "cabac_encode": enc_pix + out_bytes}                # levels in, slice data out
-    achieved = G * alg[dom] / (groups[dom] * 1e-3) / 1e9 if groups[dom] > 0 else 0.0      # a launch covers the G GOFs of its job
+    achieved = gpj * alg[dom] / (groups[dom] * 1e-3) / 1e9 if groups[dom] > 0 else 0.0      # a launch covers the GOFs of its job
     # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
     # runs of this same command: profiles/r02_pmc_traffic.json, tools/refresh_profiles.py); counters cannot be read live from inside the benchmark
     traffic = None
@@ -238,7 +244,7 @@ def main():
         pmc = json.load(open(pmc_file))["kernels"]
         kmap = {"cabac_parse": ["k_parse"], "intra_analysis": ["k_enc_analyse"], "cabac_encode": ["k_entropy"]}
         if dom in kmap and n_pc == 32 and (w, h) == (1280, 1280):
-            traffic = G * int(sum((pmc[k]["FETCH_SIZE_KB"] + pmc[k]["WRITE_SIZE_KB"]) * 1024 for k in kmap[dom]))   # counters were taken on one GOF
+            traffic = int(gpj * sum((pmc[k]["FETCH_SIZE_KB"] + pmc[k]["WRITE_SIZE_KB"]) * 1024 for k in kmap[dom]))   # counters were taken on one GOF
     except Exception:
         traffic = None
     # the practical bound of the path is the seriality of entropy decoding: bits per second through one slice's chain
@@ -255,7 +261,7 @@ def main():
     cabac = {"slices_per_gof": len(sl_sizes), "largest_slice_kbit": round(max(sl_sizes) * 8 / 1000, 1),
              "Mbit_per_s_through_largest_slice": round(max(sl_sizes) * 8 / 1e6 / (st["k_parse_ms"] * 1e-3), 2) if D > 8 and st["k_parse_ms"] > 0 else None,
              "note": "largest slice's bits / duration of the entropy-decoding launch that contains it (about 1.17 bins per bit)"}
-    path_achieved = st["algorithmic_bytes"] / G / (elapsed / steps) / 1e9   # whole path: SURVEY.md 8(d) bytes of one GOF over the time one GOF takes
+    path_achieved = st["algorithmic_bytes"] / gpj / (elapsed / steps) / 1e9   # whole path: SURVEY.md 8(d) bytes of one GOF over the time one GOF takes
 
     # configs[3]: a sequence of --walk-frames point-cloud frames (300 = 9 GOFs of 32 + one of 12), GOF g on rank g mod world, D GOFs in flight
     # per GPU, re-encoded NAL units gathered on rank 0 (strong scaling: the sequence is fixed). Rank 0 then walks the whole sequence alone
@@ -431,7 +437,7 @@ def main():
                                        f"R5 (QP16/22, prec 2) -> R3 (QP24/32, prec 4), synthetic longdress-like atlas", "input": input_kind,
                            "encoder": ("RBT-E1, wavefront mode (one slice per picture, a dependent slice segment per CTB row, entropy_coding_sync)" if args.rows < 0 else f"RBT-E1, {args.rows or 'all'} CTB row(s) per slice")
                                       + ", 35 intra modes, one-or-four transform units per intra CU, SAO, closed (I,P) pairs, CQP",
-                           "gof_per_gpu": 1, "jobs_in_flight": D, "gofs_per_job": G, "gofs_in_flight": D * G, "setup_jobs_before_warmup": primed, "in_bytes": in_bytes, "out_bytes": out_bytes, "parallelism": f"gof-shard x{world}"},
+                           "gof_per_gpu": 1, "jobs_in_flight": D, "gofs_per_job": round(gpj, 3), "gofs_in_flight": round(D * gpj), "setup_jobs_before_warmup": primed, "in_bytes": in_bytes, "out_bytes": out_bytes, "parallelism": f"gof-shard x{world}"},
                 "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                              "traffic": traffic, "kernel_ms": {k_: round(v, 3) for k_, v in groups.items()},
                              "path_achieved_GBs": round(path_achieved, 3), "path_frac": round(path_achieved / HBM_PEAK_GBS, 6)},
