@@ -1,7 +1,7 @@
 """Turns the rocprofv3 outputs a gpurun call merged into gpurun_out/ into the committed summaries under profiles/ (every file there
 comes from this script: profiles/<tag>_bench_line.json, _bench_kernel_stats.csv, _pmc_traffic.json, _pmc_sq.json, _timeline.txt).
 Inputs (tools/profile_round.sh runs them on the GPU box): gpurun_out/bench_line.json (python bench.py), prof_kt/
-(rocprofv3 --kernel-trace --stats --output-format csv of the bench command without its informative extras: --steps 32 --warmup 16
+(rocprofv3 --kernel-trace --stats --output-format csv of the bench command without its informative extras: --steps 32 --warmup 16 --gofs-per-job 2
 --cpu-sample 0 --multi-gof 0 --quality 0 --sweep 0 --walk-frames 0 --fanout-gofs 0), prof_f/ and prof_w/ (--pmc FETCH_SIZE / WRITE_SIZE,
 separate passes, one blocking step: --steps 1 --warmup 0 --in-flight 1), prof_sq/ (--pmc SQ instruction / matrix-core counters, same
 step), prof_tl/ (--kernel-trace of one blocking step: --steps 1 --warmup 1 --in-flight 1)."""
@@ -9,6 +9,8 @@ import collections, csv, json, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 shutil.copy("gpurun_out/prof_kt/kt_kernel_stats.csv", f"profiles/{tag}_bench_kernel_stats.csv")
 shutil.copy("gpurun_out/bench_line.json", f"profiles/{tag}_bench_line.json")
+import os
+if os.path.exists("gpurun_out/bench_line_driver.json"): shutil.copy("gpurun_out/bench_line_driver.json", f"profiles/{tag}_bench_line_driver.json")   # python bench.py --gpus 1 --steps 20 --warmup 5
 
 def kname(n):   # "void rbtk::k_parse<384>(RbtFrame*, ...)" -> "k_parse"
     return n.split("(")[0].replace("void ", "").replace("rbtk::", "").split("<")[0]
