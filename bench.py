@@ -146,7 +146,7 @@ def main():
     # for GOF i+D-1 before rbt_wait_gof for GOF i (D = --in-flight GOFs in flight on disjoint HIP streams; D = 1 is the
     # blocking rbt_transcode_gof). Every one of the K timed steps is submitted and collected inside the timed region.
     if args.gofs_per_job <= 0:
-        args.gofs_per_job = 2 if args.steps >= 48 else max(1, (args.steps + 6) // 7)
+        args.gofs_per_job = gs.job_shape(args.steps)[0]       # 2 for a long run, ceil(K / 7) for one shorter than 48 steps
     D = max(1, min(args.in_flight, 16, (args.steps + max(1, args.gofs_per_job) - 1) // max(1, args.gofs_per_job)))   # never announce a deeper pipeline than the run has steps: shallower pipelines get more streams per job
     stats_acc = {}
 
@@ -177,8 +177,7 @@ def main():
 
     def run(n_steps, depth, acc, g=None):
         g = g or G
-        nj = (n_steps + g - 1) // g                                             # exactly n_steps GOFs, spread evenly over the jobs (20 steps, G = 3: 3 3 3 3 3 3 2)
-        sizes = [n_steps // nj + (1 if i < n_steps % nj else 0) for i in range(nj)] if nj else []
+        sizes = gs.spread(n_steps, g)                                           # exactly n_steps GOFs, spread evenly over the jobs (20 steps, G = 3: 3 3 3 3 3 3 2)
         q, outs = [], None
         for sz in sizes:
             js, jp = job_of(sz)
@@ -270,10 +269,11 @@ def main():
     ctx.trim()        # the legs below run other job shapes than the headline loop: its arenas (32 GOFs' worth) go back to the driver first
     if args.walk_frames > 0 and n_pc > 1:
         seq = gs.make_sequence(streams, args.walk_frames, n_pc)
-        gs.transcode_sequence(ctx, seq, params, rank=rank, world=world, depth=D, device=tdev)          # untimed pass: arenas of this shape exist
+        WD = min(16, args.in_flight)
+        gs.transcode_sequence(ctx, seq, params, rank=rank, world=world, depth=WD, device=tdev, gofs_per_job=0)          # untimed pass: arenas of this shape exist
         sync()
         w0 = time.perf_counter()
-        stitched = gs.transcode_sequence(ctx, seq, params, rank=rank, world=world, depth=D, device=tdev)
+        stitched = gs.transcode_sequence(ctx, seq, params, rank=rank, world=world, depth=WD, device=tdev, gofs_per_job=0)
         sync()
         wt = time.perf_counter() - w0
         if world > 1:
@@ -283,19 +283,20 @@ def main():
             wt = float(t.item())
         if rank == 0:
             c1 = R.Context(device=dev, rank=0, world=1) if world > 1 else ctx
-            alone = gs.transcode_sequence(c1, seq, params, depth=D)
+            alone = gs.transcode_sequence(c1, seq, params, depth=WD)
             if c1 is not ctx: c1.close()
             walk = {"frames": args.walk_frames, "gofs": [len(gs.split_pairs(g[0])) for g in seq], "ranks": world, "value": round(args.walk_frames / wt, 3), "unit": "point-cloud frames/s",
-                    "seconds": round(wt, 4), "scaling": "strong", "out_bytes": sum(len(s_) for g in stitched for s_ in g), "stitched_equals_unsharded": stitched == alone}
+                    "seconds": round(wt, 4), "scaling": "strong", "out_bytes": sum(len(s_) for g in stitched for s_ in g), "stitched_equals_unsharded": stitched == alone,
+                    "job_shape": dict(zip(("gofs_per_job", "jobs_in_flight"), gs.job_shape(len(gs.gofs_of_rank(len(seq), 0, world)), WD)))}
         # the same sequence as a V3C sample stream, file in -> file out (rbt_transcode_v3c: the loop of PccAppTranscoder.cpp:277-349 around transcodeData;
         # includes the sample stream <-> byte stream conversions and the container write on the host; sharded like the walk above, partial files merged on rank 0)
         data = gs.wrap_v3c(R, seq, lib=ctx.L)
         gq, aq, prec = params[1].qp, params[2].qp, params[0].occupancy_precision
-        kw = dict(occupancy_precision=prec, rows_per_slice=args.rows, gofs_per_job=G)
-        gs.transcode_v3c(ctx, R, data, gq, aq, rank=rank, world=world, depth=D, device=tdev, **kw)
+        kw = dict(occupancy_precision=prec, rows_per_slice=args.rows, gofs_per_job=0)
+        gs.transcode_v3c(ctx, R, data, gq, aq, rank=rank, world=world, depth=WD, device=tdev, **dict(kw))
         sync()
         c0 = time.perf_counter()
-        merged = gs.transcode_v3c(ctx, R, data, gq, aq, rank=rank, world=world, depth=D, device=tdev, **kw)
+        merged = gs.transcode_v3c(ctx, R, data, gq, aq, rank=rank, world=world, depth=WD, device=tdev, **dict(kw))
         sync()
         ct = time.perf_counter() - c0
         if world > 1:
@@ -305,7 +306,7 @@ def main():
             ct = float(t.item())
         if rank == 0:
             walk["container"] = {"value": round(args.walk_frames / ct, 3), "unit": "point-cloud frames/s", "seconds": round(ct, 4), "bytes_in": len(data), "bytes_out": len(merged),
-                                 "gofs_per_job": G, "stat_in": {k: v for k, v in R.v3c_stats(data, ctx.L).items() if k.startswith("total")}, "stat_out": {k: v for k, v in R.v3c_stats(merged, ctx.L).items() if k.startswith("total")},
+                                 "stat_in": {k: v for k, v in R.v3c_stats(data, ctx.L).items() if k.startswith("total")}, "stat_out": {k: v for k, v in R.v3c_stats(merged, ctx.L).items() if k.startswith("total")},
                                  "video_units_equal_walk": gs.unwrap_v3c(R, merged, lib=ctx.L, annexb=False) == [[R.byte_to_sample_stream(s_, ctx.L) for s_ in g] for g in stitched]}
     # configs[4]: every rate point R1..R5 from the R5 input, target rate i on rank i mod world (decode replicated; a rank that holds several
     # rates hands each GOF over once and the library decodes it once)

@@ -112,15 +112,40 @@ def _walk(ctx, jobs, depth):
     return outs
 
 
-def transcode_sequence(ctx, gofs: Sequence[Sequence[bytes]], params, rank: int = 0, world: int = 1, depth: int = 16, group=None, device="cpu"):
+def job_shape(n_gofs: int, max_depth: int = 16):
+    """(GOFs per job, jobs in flight) for a walk of n_gofs GOFs on one GPU. A long walk keeps 16 jobs of 2 GOFs in flight (every job owns one hardware queue,
+    two GOFs per launch fill the GPU: DESIGN.md 5); a walk shorter than 48 GOFs is all ramp-up and drain and does better as at most 7 jobs, which then own two
+    or more queues each (rbt_set_depth), so that a job's geometry and attribute pipelines run side by side. Measured with tools/short_run_sweep.sh."""
+    import os
+    if os.environ.get("RBT_WALK_SHAPE"):                         # experiments: "G,D"
+        g, d = (int(x) for x in os.environ["RBT_WALK_SHAPE"].split(","))
+        return g, d
+    if n_gofs >= 48:
+        return 2, max(1, min(max_depth, 16))
+    g = max(1, (n_gofs + 6) // 7)
+    return g, max(1, min(max_depth, 16, (n_gofs + g - 1) // g))
+
+
+def spread(n: int, g: int) -> List[int]:
+    """n GOFs over ceil(n / g) jobs, as evenly as possible: 20, 3 -> 3 3 3 3 3 3 2"""
+    nj = (n + g - 1) // g
+    return [n // nj + (1 if i < n % nj else 0) for i in range(nj)] if nj else []
+
+
+def transcode_sequence(ctx, gofs: Sequence[Sequence[bytes]], params, rank: int = 0, world: int = 1, depth: int = 16, group=None, device="cpu", gofs_per_job: int = 1):
     """configs[3]. gofs[g] = [occupancy, geometry, attribute] Annex-B sub-bitstreams of GOF g; every rank holds the whole compressed
     input (PccAppTranscoder loads the file first, PccAppTranscoder.cpp:289). Each rank transcodes the GOFs its context owns
-    (rbt_owns_gof) with up to `depth` in flight; the outputs are gathered on rank 0.
-    Returns on rank 0 the output in GOF order (result[g][s]), None elsewhere. world == 1 needs no process group."""
+    (rbt_owns_gof) with up to `depth` jobs in flight, `gofs_per_job` consecutive GOFs of its share per job (0: both by job_shape); the outputs
+    are gathered on rank 0. Returns on rank 0 the output in GOF order (result[g][s]), None elsewhere. world == 1 needs no process group."""
     n = len(gofs)
     mine = [g for g in range(n) if ctx.owns_gof(g)]
     assert mine == gofs_of_rank(n, rank, world)
-    outs = _walk(ctx, [(list(gofs[g]), params) for g in mine], depth)
+    if gofs_per_job <= 0:
+        gofs_per_job, depth = job_shape(len(mine), depth)
+    jobs, pos = [], 0
+    for sz in spread(len(mine), max(1, gofs_per_job)):
+        jobs.append(([s for g in mine[pos:pos + sz] for s in gofs[g]], list(params) * sz)); pos += sz
+    outs = _walk(ctx, jobs, depth)
     local = [s for o in outs for s in o]
     if world == 1:
         return stitch([local], n, len(params))
@@ -205,6 +230,9 @@ def merge_v3c(R, parts: Sequence[bytes], forced_precision_bytes: int = 0, lib=No
 def transcode_v3c(ctx, R, data: bytes, geometry_qp: int, attribute_qp: int, rank: int = 0, world: int = 1, depth: int = 16, group=None, device="cpu", **kw):
     """The container form of transcode_sequence: every rank holds the input file (PccAppTranscoder.cpp:289), transcodes the GOFs its context owns
     (rbt_transcode_v3c), rank 0 gathers the partial streams and writes the output. Returns the output on rank 0, None elsewhere."""
+    if kw.get("gofs_per_job", 1) <= 0:                           # both by the number of GOFs this rank owns
+        n_gofs = (R.v3c_index(data, ctx.L) or [{"gof": -1}])[-1]["gof"] + 1
+        kw["gofs_per_job"], depth = job_shape(len(gofs_of_rank(n_gofs, rank, world)), depth)
     ctx.set_depth(max(1, min(depth, 16)))
     part = ctx.transcode_v3c(data, geometry_qp, attribute_qp, **kw)
     if world == 1:

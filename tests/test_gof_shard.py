@@ -64,6 +64,14 @@ def test_sharding_rules():
     assert gs.RATE_POINTS == {1: (32, 42, 4), 2: (28, 37, 4), 3: (24, 32, 4), 4: (20, 27, 4), 5: (16, 22, 2)}
 
 
+def test_job_shapes():
+    gs = rbt_lib.module_file("gof_shard")
+    assert gs.spread(20, 3) == [3, 3, 3, 3, 3, 3, 2] and gs.spread(20, 2) == [2] * 10 and gs.spread(5, 3) == [3, 2] and gs.spread(0, 2) == [] and gs.spread(1, 4) == [1]
+    assert all(sum(gs.spread(n, g)) == n and max(gs.spread(n, g)) <= g for n in range(1, 70) for g in range(1, 9))
+    assert gs.job_shape(256) == (2, 16) and gs.job_shape(48) == (2, 16) and gs.job_shape(20) == (3, 7) and gs.job_shape(10) == (2, 5) and gs.job_shape(1) == (1, 1)
+    assert gs.job_shape(20, 4) == (3, 4) and gs.job_shape(2) == (1, 2)
+
+
 def test_context_owns_gofs_like_the_python_rule(hostemu):
     R = rbt_lib.module(); gs = rbt_lib.module_file("gof_shard")
     for world in (1, 2, 3, 8):
@@ -95,6 +103,8 @@ def test_sequence_and_fanout_world2_equal_unsharded_and_oracle(hostemu):
     # unsharded: one context walks the whole sequence
     c = R.Context(lib_path=rbt_lib.HOSTEMU_LIB)
     assert out == gs.transcode_sequence(c, seq, gs.rate_params(R, 3), depth=3)
+    assert out == gs.transcode_sequence(c, seq, gs.rate_params(R, 3), depth=2, gofs_per_job=3)      # 4 GOFs as jobs of 2 + 2
+    assert out == gs.transcode_sequence(c, seq, gs.rate_params(R, 3), gofs_per_job=0)               # shape by job_shape
     assert fan == gs.transcode_fanout(c, R, seq[2:], depth=1)
     c.close()
     # the oracle's transcodeData, GOF by GOF (PCCTranscoder.cpp:145-168)
