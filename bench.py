@@ -68,8 +68,8 @@ def main():
     ap.add_argument("--multi-gof", type=int, default=8, help="also time G GOFs per call (extra field multi_gof; 0/1 = skip)")
     ap.add_argument("--in-flight", type=int, default=16, help="GOFs in flight (rbt_submit_gof ahead of rbt_wait_gof), 1..16; 1 = blocking calls")
     ap.add_argument("--gofs-per-job", type=int, default=0, help="GOFs handed over per rbt_submit_gof call (a step stays one GOF; the K steps are spread evenly over ceil(K / G) jobs). "
-                    "0 = choose by the length of the run: 2 for a long run (16 jobs x 2 GOFs keep the GPU full), ceil(K / 7) for a run shorter than 48 steps (a run that is "
-                    "all ramp-up and drain does better with few jobs that own two hardware queues each than with many that own one)")
+                    "0 = choose by the length of the run (gof_shard.job_shape): 2 for a long run (16 jobs x 2 GOFs keep the GPU full); a run shorter than 48 steps is all ramp-up and "
+                    "drain and does better with few jobs (7, or 2 up to 12 steps) that own several hardware queues each than with many that own one)")
     ap.add_argument("--sweep", type=int, default=64, help="also time K GOFs at every in-flight depth 1..4 (extra field in_flight_sweep; 0/1 = skip)")
     ap.add_argument("--quality", type=int, default=1, help="report picture PSNR of the output vs the input (extra field quality; 0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path)")
@@ -146,7 +146,7 @@ def main():
     # for GOF i+D-1 before rbt_wait_gof for GOF i (D = --in-flight GOFs in flight on disjoint HIP streams; D = 1 is the
     # blocking rbt_transcode_gof). Every one of the K timed steps is submitted and collected inside the timed region.
     if args.gofs_per_job <= 0:
-        args.gofs_per_job = gs.job_shape(args.steps)[0]       # 2 for a long run, ceil(K / 7) for one shorter than 48 steps
+        args.gofs_per_job = gs.job_shape(args.steps)[0]       # 2 for a long run, ceil(K / 7) for one shorter than 48 steps, ceil(K / 2) up to 12
     D = max(1, min(args.in_flight, 16, (args.steps + max(1, args.gofs_per_job) - 1) // max(1, args.gofs_per_job)))   # never announce a deeper pipeline than the run has steps: shallower pipelines get more streams per job
     stats_acc = {}
 

@@ -114,7 +114,7 @@ def _walk(ctx, jobs, depth):
 
 def job_shape(n_gofs: int, max_depth: int = 16):
     """(GOFs per job, jobs in flight) for a walk of n_gofs GOFs on one GPU. A long walk keeps 16 jobs of 2 GOFs in flight (every job owns one hardware queue,
-    two GOFs per launch fill the GPU: DESIGN.md 5); a walk shorter than 48 GOFs is all ramp-up and drain and does better as at most 7 jobs, which then own two
+    two GOFs per launch fill the GPU: DESIGN.md 5); a walk shorter than 48 GOFs is all ramp-up and drain and does better as at most 7 jobs (2 up to 12 GOFs), which then own two
     or more queues each (rbt_set_depth), so that a job's geometry and attribute pipelines run side by side. Measured with tools/short_run_sweep.sh."""
     import os
     if os.environ.get("RBT_WALK_SHAPE"):                         # experiments: "G,D"
@@ -122,7 +122,8 @@ def job_shape(n_gofs: int, max_depth: int = 16):
         return g, d
     if n_gofs >= 48:
         return 2, max(1, min(max_depth, 16))
-    g = max(1, (n_gofs + 6) // 7)
+    jobs = 2 if n_gofs <= 12 else 7                              # measured on one MI355X: 10 GOFs 470 / 544 / 573 / 601 / 563 fps as 10 / 5 / 3 / 2 / 1 jobs; 20 GOFs 484 / 650 / 798 / 784 / 731
+    g = max(1, (n_gofs + jobs - 1) // jobs)                      # as 16 / 10 / 7 / 5 / 4 jobs; 40 GOFs 769 / 843 / 848 / 843 / 831 as 20 / 14 / 10 / 7 / 5 jobs
     return g, max(1, min(max_depth, 16, (n_gofs + g - 1) // g))
 
 
