@@ -155,6 +155,13 @@ def test_sharded_outputs_merge_into_the_unsharded_stream(R, hlib, container):
         parts.append(c.transcode_v3c(data, 24, 32)); c.close()
     assert [sorted({u["gof"] for u in R.v3c_index(p, hlib)}) for p in parts] == [[0, 1], [0]]   # rank 0: GOFs 0 and 2 (renumbered), rank 1: GOF 1
     assert gs.merge_v3c(R, parts, lib=hlib) == whole
+    # more ranks than GOFs: the idle rank hands back a header and no units
+    parts = []
+    for r in range(4):
+        c = R.Context(rank=r, world=4, lib_path=rbt_lib.HOSTEMU_LIB)
+        parts.append(c.transcode_v3c(data, 24, 32, forced_precision_bytes=4)); c.close()
+    assert len(parts[3]) == 1 and R.v3c_index(parts[3], hlib) == []
+    assert gs.merge_v3c(R, parts, 4, lib=hlib) == O.v3c_transcode(data, 24, 32, 4, 4)
 
 
 def test_wrap_and_unwrap_helpers(R, ctx, container):
