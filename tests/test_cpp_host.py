@@ -66,3 +66,27 @@ def test_cpp_host_pipeline_equals_oracle(tmp_path, depth):
     assert len(got) == len(gofs)
     for g, o in zip(gofs, got):
         assert o[0] == O.transcode_substream(g[0], 0, 8, rows_per_slice=-1) and o[1] == O.transcode_substream(g[1], 1, 24, rows_per_slice=-1) and o[2] == O.transcode_substream(g[2], 19, 32, rows_per_slice=-1)
+
+
+@pytest.mark.gpu
+def test_cpp_host_v3c_file_equals_oracle(tmp_path):
+    """the file-level form (rbt_pipeline --v3c): V3C sample stream in, V3C sample stream out == the oracle's restatement of PccAppTranscoder's loop"""
+    import v3c_synth as V
+    units = []
+    for g, s in enumerate(_gofs(5)):
+        units += V.gof_units(s, 40 + g, aux=(g == 2))
+    data = V.sample_stream(units, 3)
+    (tmp_path / "in.bin").write_bytes(data)
+    r = subprocess.run([_exe(), "--v3c", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "4", "28", "37"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "out.bin").read_bytes() == O.v3c_transcode(data, 28, 37, 4)
+    assert r.stdout.startswith("5 GOFs, 27 units;") and f"total {len(data)} ->" in r.stdout
+
+
+def test_cpp_host_v3c_fails_loudly_without_a_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    (tmp_path / "in.bin").write_bytes(bytes([0x40]))
+    r = subprocess.run([_exe(), "--v3c", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 1 and "no usable HIP device" in r.stderr and not (tmp_path / "out.bin").exists()
