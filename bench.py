@@ -85,6 +85,12 @@ def main():
                     "(BASELINE.json configs[3]: 300 = 9 x 32 + 12; extra field sequence_walk; 0 = skip)")
     ap.add_argument("--fanout-gofs", type=int, default=2, help="also transcode this many GOFs to every rate point R1..R5, one target rate per rank "
                     "(BASELINE.json configs[4]; extra field rate_fanout; 0 = skip)")
+    ap.add_argument("--v3c-input", default=None, help="a V3C sample stream file (e.g. a real longdress_r5.bin; SURVEY.md 8(d)): transcoded unchanged, whole file, GOF-sharded over "
+                    "the ranks, with --geometry-qp / --attribute-qp / --occupancy-precision (extra field v3c_file; the headline stays on the synthetic GOF)")
+    ap.add_argument("--v3c-output", default=None, help="where rank 0 writes the transcoded file of --v3c-input")
+    ap.add_argument("--geometry-qp", type=int, default=24)
+    ap.add_argument("--attribute-qp", type=int, default=32)
+    ap.add_argument("--occupancy-precision", type=int, default=4)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -308,6 +314,44 @@ def main():
             walk["container"] = {"value": round(args.walk_frames / ct, 3), "unit": "point-cloud frames/s", "seconds": round(ct, 4), "bytes_in": len(data), "bytes_out": len(merged),
                                  "stat_in": {k: v for k, v in R.v3c_stats(data, ctx.L).items() if k.startswith("total")}, "stat_out": {k: v for k, v in R.v3c_stats(merged, ctx.L).items() if k.startswith("total")},
                                  "video_units_equal_walk": gs.unwrap_v3c(R, merged, lib=ctx.L, annexb=False) == [[R.byte_to_sample_stream(s_, ctx.L) for s_ in g] for g in stitched]}
+    # a V3C sample stream file handed over at run time: file in -> file out, as PccAppTranscoder does it (rbt_transcode_v3c), sharded like the walk
+    v3c_file = None
+    if args.v3c_input:
+        ctx.trim()
+        data = open(args.v3c_input, "rb").read()
+        try:
+            idx = R.v3c_index(data, ctx.L)
+            # point-cloud frames = pictures of the geometry video / maps per frame (2 in the CTC): pictures counted as slice segments with first_slice_segment_in_pic_flag
+            def pictures(payload):
+                bs, n_pic, i = R.sample_to_byte_stream(payload, ctx.L), 0, 0
+                i = bs.find(b"\x00\x00\x01")
+                while i >= 0:
+                    if ((bs[i + 3] >> 1) & 63) < 32 and i + 5 < len(bs) and bs[i + 5] & 0x80: n_pic += 1
+                    i = bs.find(b"\x00\x00\x01", i + 3)
+                return n_pic
+            n_pics = sum(pictures(data[u["offset"] + 4:u["offset"] + u["size"]]) for u in idx if u["video_type"] == R.RBT_VIDEO_GEOMETRY)
+            kw = dict(occupancy_precision=args.occupancy_precision, rows_per_slice=args.rows, gofs_per_job=0)
+            WD = min(16, args.in_flight)
+            gs.transcode_v3c(ctx, R, data, args.geometry_qp, args.attribute_qp, rank=rank, world=world, depth=WD, device=tdev, **dict(kw))     # untimed pass
+            sync()
+            v0 = time.perf_counter()
+            merged = gs.transcode_v3c(ctx, R, data, args.geometry_qp, args.attribute_qp, rank=rank, world=world, depth=WD, device=tdev, **dict(kw))
+            sync()
+            vt = time.perf_counter() - v0
+            if world > 1:
+                import torch
+                t = torch.tensor([vt], dtype=torch.float64, device=tdev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                vt = float(t.item())
+            if rank == 0:
+                if args.v3c_output: open(args.v3c_output, "wb").write(merged)
+                v3c_file = {"file": os.path.basename(args.v3c_input), "gofs": idx[-1]["gof"] + 1 if idx else 0, "geometry_pictures": n_pics, "frames": n_pics // 2, "ranks": world,
+                            "value": round(n_pics / 2 / vt, 3), "unit": "point-cloud frames/s (two geometry maps per frame)", "seconds": round(vt, 4), "geometry_qp": args.geometry_qp,
+                            "attribute_qp": args.attribute_qp, "occupancy_precision": args.occupancy_precision,
+                            "stat_in": {k: v for k, v in R.v3c_stats(data, ctx.L).items() if k.startswith("total")}, "stat_out": {k: v for k, v in R.v3c_stats(merged, ctx.L).items() if k.startswith("total")}}
+        except R.RbtError as e:
+            if world > 1: raise
+            v3c_file = {"file": os.path.basename(args.v3c_input), "error": str(e)}
     # configs[4]: every rate point R1..R5 from the R5 input, target rate i on rank i mod world (decode replicated; a rank that holds several
     # rates hands each GOF over once and the library decodes it once)
     fanout = None
@@ -442,7 +486,7 @@ def main():
                 "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                              "traffic": traffic, "kernel_ms": {k_: round(v, 3) for k_, v in groups.items()},
                              "path_achieved_GBs": round(path_achieved, 3), "path_frac": round(path_achieved / HBM_PEAK_GBS, 6)},
-                "cabac": cabac, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "sequence_walk": walk, "rate_fanout": fanout, "multi_gof": multi, "in_flight_sweep": sweep, "quality": quality,
+                "cabac": cabac, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "sequence_walk": walk, "v3c_file": v3c_file, "rate_fanout": fanout, "multi_gof": multi, "in_flight_sweep": sweep, "quality": quality,
                 "host_ms": {"parse": round(st["host_parse_ms"], 3), "pack": round(st["host_pack_ms"], 3), "submit_call": round(host_submit_ms, 3), "wait_call": round(host_wait_ms, 3), "job_gpu_span": round(st["gpu_ms"], 3), "job_span": round(st["total_ms"], 3)}}
         print(json.dumps(line))
     if world > 1:
