@@ -35,7 +35,7 @@ static int v3c_main(int argc, char** argv) {
   const int depth = argc > 4 ? atoi(argv[4]) : 8;
   rbt_v3c_params vp; memset(&vp, 0, sizeof(vp));
   vp.geometry_qp = argc > 5 ? atoi(argv[5]) : 24; vp.attribute_qp = argc > 6 ? atoi(argv[6]) : 32; vp.occupancy_precision = argc > 7 ? atoi(argv[7]) : 4;
-  vp.ctb_rows_per_slice = -1; vp.gofs_per_job = 2;
+  vp.ctb_rows_per_slice = -1; vp.gofs_per_job = 0;   // job shape by the length of the walk (rbt_job_shape), `depth` is the cap
   std::vector<uint8_t> in;
   FILE* f = fopen(argv[2], "rb"); if (!f) { fprintf(stderr, "cannot read %s\n", argv[2]); return 2; }
   fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET); in.resize(sz > 0 ? (size_t)sz : 0);

@@ -105,6 +105,10 @@ int rbt_transcode_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, cons
 #define RBT_MAX_JOBS 16
 typedef struct rbt_job rbt_job;
 int rbt_set_depth(rbt_ctx* ctx, int max_in_flight);
+int rbt_get_depth(rbt_ctx* ctx);   /* the announced depth (> 0) or RBT_ERR_PARAM */
+/* How to cut a walk of n_gofs GOFs into jobs on one GPU, as measured: 16 jobs of 2 GOFs for a long walk; a walk shorter than 48 GOFs is all ramp-up and
+ * drain and does better as at most 7 jobs (2 jobs up to 12 GOFs) of ceil(n / jobs) GOFs, which then own several hardware queues each. max_jobs caps the jobs in flight. */
+int rbt_job_shape(int n_gofs, int max_jobs, int* gofs_per_job, int* jobs_in_flight);
 int rbt_submit_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, rbt_job** job);
 int rbt_wait_gof(rbt_ctx* ctx, rbt_job* job, uint8_t** annexb_out, size_t* n_out);
 /* The library keeps the device memory of collected jobs for the next job of the same shape (hipMalloc / hipFree of GOF-sized arenas cost milliseconds
@@ -210,9 +214,11 @@ typedef struct {
   int geometry_qp, attribute_qp;                      /* geometryQP_, attributeQP_ */
   int forced_unit_size_precision_bytes;               /* forcedSsvhUnitSizePrecisionBytes_, 0 = none */
   int log2_ctb, ctb_rows_per_slice, md5_sei, verify_md5;   /* as in rbt_stream_params */
-  int gofs_per_job;          /* GOFs handed to the GPU per job, 0 / 1 = one (two fill an MI355X better when 16 jobs are in flight) */
+  int gofs_per_job;          /* GOFs handed to the GPU per job; 0 = by rbt_job_shape from the number of GOFs this context owns, which also lowers the announced depth for
+                              * the duration of the call when the walk is short (the depth announced with rbt_set_depth is the cap and is restored) */
 } rbt_v3c_params;
-/* The whole walk: index, per GOF the video units through rbt_submit_gof / rbt_wait_gof with as many jobs in flight as rbt_set_depth announced, write.
+/* The whole walk: index, per GOF the video units through rbt_submit_gof / rbt_wait_gof with as many jobs in flight as rbt_set_depth announced (fewer for a short walk
+ * with gofs_per_job = 0), write.
  * Video units transcodeData does not look at (auxiliary video, attribute partitions beyond the first) are copied; a GOF with several
  * geometry or attribute map streams (multipleMapStreamsPresentFlag) is refused (RBT_ERR_UNSUPPORTED) - the reference looks for VIDEO_GEOMETRY / VIDEO_ATTRIBUTE, which such a GOF does not have.
  * In a multi-GPU job (rbt_create with world_size > 1) the output holds the GOFs this rank owns (rbt_owns_gof) and nothing else: rank 0 of the host

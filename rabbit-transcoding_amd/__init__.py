@@ -96,6 +96,8 @@ def load(path=None):
     L.rbt_submit_gof.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(StreamParams), C.POINTER(C.c_void_p)]
     L.rbt_set_depth.argtypes = [C.c_void_p, C.c_int]
     L.rbt_trim.argtypes = [C.c_void_p]
+    L.rbt_get_depth.argtypes = [C.c_void_p]
+    L.rbt_job_shape.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.rbt_wait_gof.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rbt_or_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.rbt_sample_to_byte_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
@@ -120,6 +122,16 @@ def _convert(fn, data, L):
     res = C.string_at(out, n.value)
     L.rbt_free(out)
     return res
+
+
+def job_shape(n_gofs, max_jobs=16, lib=None):
+    """rbt_job_shape: (GOFs per job, jobs in flight) for a walk of n_gofs GOFs on one GPU"""
+    L = lib or load()
+    g, d = C.c_int(), C.c_int()
+    rc = L.rbt_job_shape(n_gofs, max_jobs, C.byref(g), C.byref(d))
+    if rc != 0:
+        raise RbtError(rc, L.rbt_strerror(rc).decode())
+    return g.value, d.value
 
 
 def byte_to_sample_stream(data: bytes, lib=None):
@@ -236,7 +248,7 @@ class Context:
 
     def transcode_v3c(self, data: bytes, geometry_qp, attribute_qp, occupancy_precision=4, forced_precision_bytes=0, log2_ctb=5, rows_per_slice=-1, md5_sei=0,
                       verify_md5=0, gofs_per_job=1):
-        """rbt_transcode_v3c: a whole V3C sample stream (every GOF this context owns) -> transcoded sample stream"""
+        """rbt_transcode_v3c: a whole V3C sample stream (every GOF this context owns) -> transcoded sample stream; gofs_per_job=0: job shape by rbt_job_shape"""
         p = V3CParams(occupancy_precision, geometry_qp, attribute_qp, forced_precision_bytes, log2_ctb, rows_per_slice, md5_sei, verify_md5, gofs_per_job)
         out, n = C.c_void_p(), C.c_size_t()
         self._chk(self.L.rbt_transcode_v3c(self.h, data, len(data), C.byref(p), C.byref(out), C.byref(n)))
@@ -245,6 +257,10 @@ class Context:
     def set_depth(self, n):
         """rbt_set_depth: how many GOFs the caller will keep in flight (1..16 = RBT_MAX_JOBS, default 4)"""
         self._chk(self.L.rbt_set_depth(self.h, n))
+
+    def get_depth(self):
+        """rbt_get_depth: the depth announced with set_depth"""
+        return self.L.rbt_get_depth(self.h)
 
     def trim(self):
         """rbt_trim: hand the cached device memory of earlier jobs back to the driver (call when the workload changes shape)"""

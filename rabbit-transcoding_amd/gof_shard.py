@@ -230,10 +230,8 @@ def merge_v3c(R, parts: Sequence[bytes], forced_precision_bytes: int = 0, lib=No
 
 def transcode_v3c(ctx, R, data: bytes, geometry_qp: int, attribute_qp: int, rank: int = 0, world: int = 1, depth: int = 16, group=None, device="cpu", **kw):
     """The container form of transcode_sequence: every rank holds the input file (PccAppTranscoder.cpp:289), transcodes the GOFs its context owns
-    (rbt_transcode_v3c), rank 0 gathers the partial streams and writes the output. Returns the output on rank 0, None elsewhere."""
-    if kw.get("gofs_per_job", 1) <= 0:                           # both by the number of GOFs this rank owns
-        n_gofs = (R.v3c_index(data, ctx.L) or [{"gof": -1}])[-1]["gof"] + 1
-        kw["gofs_per_job"], depth = job_shape(len(gofs_of_rank(n_gofs, rank, world)), depth)
+    (rbt_transcode_v3c; gofs_per_job=0 lets the library cut them into jobs by rbt_job_shape, with `depth` as the cap), rank 0 gathers the partial streams and
+    writes the output. Returns the output on rank 0, None elsewhere."""
     ctx.set_depth(max(1, min(depth, 16)))
     part = ctx.transcode_v3c(data, geometry_qp, attribute_qp, **kw)
     if world == 1:

@@ -158,6 +158,23 @@ int rbt_set_depth(rbt_ctx* ctx, int max_in_flight) {
   D.depth = max_in_flight;
   return RBT_OK;
 }
+int rbt_get_depth(rbt_ctx* ctx) {
+  if (!ctx) return RBT_ERR_PARAM;
+  RBT_ENTER(ctx);
+  return D.depth;
+}
+// Measured on one MI355X (tools/short_run_sweep.sh, tools/walk_shape_sweep.sh): a long walk keeps max_jobs jobs of 2 GOFs in flight; a walk shorter than 48 GOFs
+// is all ramp-up and drain and runs as at most 7 jobs (2 up to 12 GOFs), which then own several hardware queues each. Same rule as gof_shard.job_shape.
+int rbt_job_shape(int n_gofs, int max_jobs, int* gofs_per_job, int* jobs_in_flight) {
+  if (n_gofs < 0 || max_jobs < 1 || !gofs_per_job || !jobs_in_flight) return RBT_ERR_PARAM;
+  if (max_jobs > RBT_MAX_JOBS) max_jobs = RBT_MAX_JOBS;
+  if (n_gofs >= 48) { *gofs_per_job = 2; *jobs_in_flight = max_jobs; return RBT_OK; }
+  const int jobs = n_gofs <= 12 ? 2 : 7;
+  int g = (n_gofs + jobs - 1) / jobs; if (g < 1) g = 1;
+  int d = (n_gofs + g - 1) / g; if (d > max_jobs) d = max_jobs; if (d < 1) d = 1;
+  *gofs_per_job = g; *jobs_in_flight = d;
+  return RBT_OK;
+}
 int rbt_trim(rbt_ctx* ctx) {
   if (!ctx) return RBT_ERR_PARAM;
   RBT_ENTER(ctx);

@@ -137,11 +137,21 @@ int rbt_transcode_v3c(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_p
     }
     return r;
   };
-  const int per = p->gofs_per_job > 1 ? p->gofs_per_job : 1;
   std::vector<int> owned; for (int g = 0; g < n_gofs; g++) if (rbt_owns_gof(ctx, g) && !picks[g].empty()) owned.push_back(g);
-  for (size_t a = 0; a < owned.size() && !rc; a += per) {
+  int per = p->gofs_per_job > 1 ? p->gofs_per_job : 1, announced = 0;
+  if (p->gofs_per_job <= 0) {                                                 // job shape by the length of the walk; a short one runs with fewer, larger jobs
+    int d = 0; announced = rbt_get_depth(ctx);
+    if (announced < 1 || rbt_job_shape((int)owned.size(), announced, &per, &d) != RBT_OK) { cleanup(); return RBT_ERR_PARAM; }
+    if (d == announced || rbt_set_depth(ctx, d) != RBT_OK) announced = 0;    // nothing to restore (jobs of another walk in flight: keep the caller's depth)
+  }
+  // the owned GOFs spread evenly over ceil(n / per) jobs (20 GOFs, 3 per job: 3 3 3 3 3 3 2)
+  std::vector<size_t> cut{0};
+  { const size_t n_own = owned.size(), nj = (n_own + per - 1) / per;
+    for (size_t i = 0; i < nj; i++) cut.push_back(cut.back() + n_own / nj + (i < n_own % nj ? 1 : 0)); }
+  for (size_t ji = 0; ji + 1 < cut.size() && !rc; ji++) {
+    const size_t a = cut[ji], a_end = cut[ji + 1];
     std::vector<Buf> conv; std::vector<const uint8_t*> ip; std::vector<size_t> in_n; std::vector<rbt_stream_params> sp; Job jb{nullptr, {}};
-    for (size_t b = a; b < a + per && b < owned.size() && !rc; b++)
+    for (size_t b = a; b < a_end && !rc; b++)
       for (const Pick& pk : picks[owned[b]]) {
         Buf c; rc = rbt_sample_to_byte_stream(in + U[pk.unit].offset + 4, U[pk.unit].size - 4, &c.p, &c.n);   // transcodeData :152,159,164
         if (rc) break;
@@ -162,6 +172,7 @@ int rbt_transcode_v3c(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_p
     if (!rc) q.push_back(jb);
   }
   while (!q.empty()) { int r = collect(); if (!rc) rc = r; }
+  if (announced) rbt_set_depth(ctx, announced);
   if (rc) { cleanup(); return rc; }
   // PCCBitstreamWriter::encode: the units of every (owned) GOF in order, video units with their 4 header bytes in front of the new payload
   std::vector<Buf> made; std::vector<const uint8_t*> up; std::vector<size_t> un;

@@ -114,13 +114,14 @@ def test_transcode_v3c_leaves_occupancy_alone_unless_precision_4(R, ctx, contain
     assert prec == 4 and out_units[2] == units[2] and out_units[:2] == units[:2] and out_units[3] != units[3]
 
 
-@pytest.mark.parametrize("depth,per", [(1, 1), (2, 1), (3, 2), (16, 2)])
+@pytest.mark.parametrize("depth,per", [(1, 1), (2, 1), (3, 2), (16, 2), (16, 0), (1, 0)])   # per 0: job shape by rbt_job_shape (3 GOFs: 2 jobs of 2 + 1)
 def test_transcode_v3c_same_bytes_at_every_depth(R, ctx, container, depth, per):
     gofs, units = container
     data = V.sample_stream(units, 3)
     ctx.set_depth(depth)
     try:
         assert ctx.transcode_v3c(data, 24, 32, gofs_per_job=per) == O.v3c_transcode(data, 24, 32, 4)
+        assert ctx.get_depth() == depth                                          # a short walk lowers the depth only for the call
     finally:
         ctx.set_depth(4)
 
