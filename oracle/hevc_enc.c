@@ -476,7 +476,7 @@ static int hm_tb_finish(enc* e, int c_idx, int log2, int intra_mode, int qp, int
   int scan_idx = tb_scan_idx(e->cu_pred_mode, log2, c_idx, intra_mode);
   if (e->pps.sign_data_hiding) hm_sign_hide(e, log2, scan_idx, lq, N);
   *ts_out = 0;
-  if (log2 == 2 && e->pps.transform_skip_enabled) {
+  if (log2 == 2 && e->pps.transform_skip_enabled && (e->hm || (c_idx == 0 && e->cu_pred_mode == MODE_INTRA))) {   /* RBT-E1: the 4x4 luma blocks of intra CUs only */
     int16_t ct[16], lt[16], dq[16], r0[16], r1[16];
     int tsh = 15 - bd - log2;
     for (int i = 0; i < NN; i++) ct[i] = (int16_t)clip3(-32768, 32767, res[i] << tsh);
@@ -517,7 +517,7 @@ static int recon_tb(enc* e, int c_idx, int x0, int y0, int log2, int intra_mode,
     for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) res[y * N + x] = (int16_t)((int)sp[(size_t)y * pw + x] - (int)p[(size_t)y * pw + x]);
     if (e->cu_tq_bypass) { memcpy(lq, res, sizeof(int16_t) * N * N); for (int i = 0; i < N * N; i++) cbf |= lq[i] != 0; }
     else { hevc_fwd_transform(res, coef, log2, is_dst, bd); cbf = hevc_quant(coef, lq, log2, qp, bd, e->cu_pred_mode == MODE_INTRA) != 0; }
-    if (e->hm && !e->cu_tq_bypass) { cbf = hm_tb_finish(e, c_idx, log2, intra_mode, qp, is_dst, res, lq, &ts); if (!e->in_trial && e->hm_pass != 1 && log2 == 2 && cbf) { e->hs.tb4++; e->hs.ts += ts; } }
+    if ((e->hm || e->pps.transform_skip_enabled) && !e->cu_tq_bypass) { cbf = hm_tb_finish(e, c_idx, log2, intra_mode, qp, is_dst, res, lq, &ts); if (!e->in_trial && e->hm_pass != 1 && log2 == 2 && cbf) { e->hs.tb4++; e->hs.ts += ts; } }
     for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) lv[y * 64 + x] = lq[y * N + x];
   }
   *ts_out = ts;
@@ -1367,6 +1367,7 @@ static void write_sao(enc* e, int rx, int ry) {
 
 /* ================================================================================================ pictures */
 /* RBT-E1 codes SAO unless RBT_ENC_SAO=0 (development switch, read by the library the same way) */
+static int e1_ts_on(void) { const char* v = getenv("RBT_ENC_TS"); return !v || atoi(v) != 0; }   /* transform skip for the 4x4 luma blocks (experiments: RBT_ENC_TS=0, library and oracle alike) */
 static int e1_sao_on(void) { const char* v = getenv("RBT_ENC_SAO"); return !v || atoi(v) != 0; }
 static void setup_stream(enc* e) {
   hevc_sps* s = &e->sps; hevc_pps* p = &e->pps; const oracle_enc_params* q = &e->p;
@@ -1383,7 +1384,7 @@ static void setup_stream(enc* e) {
   if (q->lossless) { p->transquant_bypass_enabled = 1; p->deblocking_control_present = 1; p->pps_deblocking_disabled = 1; p->loop_filter_across_slices = 0; }
   if (!e->stress && !e->hm && !q->lossless && e1_sao_on()) s->sao_enabled = 1;
   e->tu_rd = e->hm;
-  if (!e->stress && !e->hm && !q->lossless) { s->max_th_depth_intra = 1; e->tu_rd = 1; }   /* RBT-E1: an intra CU is one transform unit or four, whichever codes its luma cheaper */
+  if (!e->stress && !e->hm && !q->lossless) { s->max_th_depth_intra = 1; e->tu_rd = 1; p->transform_skip_enabled = e1_ts_on(); }   /* RBT-E1: an intra CU is one transform unit or four, whichever codes its luma cheaper */
   if (!e->stress && !e->hm && q->ctb_rows_per_slice < 0) { p->entropy_coding_sync = 1; p->dependent_slice_segments_enabled = q->ctb_rows_per_slice == -1; }   /* wavefront rows, one dependent slice segment each */
   if (e->hm) {   /* cfg/hm/ctc-hm-geometry-ai.cfg:10-16,47,68,69 + HM defaults (SignHideFlag, TMVPMode, MaxNumMergeCand) */
     s->log2_ctb = q->log2_ctb ? q->log2_ctb : 6; s->log2_diff_max_min_cb = s->log2_ctb - 3;

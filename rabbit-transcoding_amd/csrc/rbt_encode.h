@@ -364,7 +364,7 @@ template <int TL2> struct RbtEncTileLdsT { RbtEncIntraScratch rc; RbtEncTileT<TL
 RBT_DEV int en_quant_scale(int r) { const uint64_t lo = 26214ull | (23302ull << 16) | (20560ull << 32) | (18396ull << 48), hi = 16384ull | (14564ull << 16); return (int)(((r < 4 ? lo : hi) >> (16 * (r & 3))) & 0xFFFF); }
 // one intra TB: (x0,y0) relative to the CTB and (gx,gy) in the picture, both in samples of component c_idx; returns cbf
 template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int c_idx, int x0, int y0, int gx, int gy, int log2, int mode, int qp,
-                             const RBT_LDS_AS uint16_t* src, int mark_l4, int mux, int muy, RBT_LDS_AS int16_t* lvl_buf = nullptr, long long* cost = nullptr, int lam2 = 0, int* ssd_out = nullptr) {
+                             const RBT_LDS_AS uint16_t* src, int mark_l4, int mux, int muy, RBT_LDS_AS int16_t* lvl_buf = nullptr, long long* cost = nullptr, int lam2 = 0, int* ssd_out = nullptr, int* ts_out = nullptr) {
   RBT_LDS_AS RbtEncIntraScratch* r = &L->rc; RBT_LDS_AS RbtEncTileT<TL2>* t = &L->t;
   // lvl_buf: where the levels go (default: over the luma part of `sb`, i.e. over the source once the residual is formed). cost (needs a lvl_buf that leaves
   // `src` alone): distortion * 256 + lam2 * rate of the block as the oracle's recon_tb / hm_decide_tu_split count them - squared error of the residual
@@ -391,6 +391,9 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
   // prediction and residual
   RBT_PAR_FOR(i, N * N) { const int pv = rc_intra_sample(&q, fin, r_ref, i & (N - 1), i >> log2); r->pred[i] = (uint16_t)pv; r->res[i] = (int16_t)((int)src[i] - pv); }
   RBT_SYNC_LDS();
+  // ts_out (4x4 luma blocks of a stream with transform_skip_enabled_flag, lvl_buf with 64 entries): the block is also coded without the transform and the
+  // cheaper way kept (oracle/hevc_enc.c hm_tb_finish): residual kept at lvl_buf + 32, transform-skip levels at + 16, their reconstruction at + 48
+  if (ts_out) { *ts_out = 0; RBT_PAR_FOR(i, 16) lvl[32 + i] = r->res[i]; }
   int nz;
   if (f->lossless) {
     int part = 0;
@@ -410,7 +413,6 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
     nz = en_wave_sum(part, (RBT_LDS_AS RbtEncLds*)0);
   }
   RBT_SYNC_LDS();
-  { int16_t* cp = f->coef[c_idx] + (size_t)gy * pw + gx; RBT_PAR_FOR(i, N * N) cp[(size_t)(i >> log2) * pw + (i & (N - 1))] = lvl[i]; }
   if (nz && !f->lossless) {
     const int bd_shift = bd + log2 - 5, scale = (16 * rc_level_scale(qp % 6)) << (qp / 6);
     const long long add = 1ll << (bd_shift - 1);
@@ -421,6 +423,35 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
     RBT_PAR_FOR(i, N * N) r->res[i] = lvl[i];
     RBT_SYNC_LDS();
   }
+  if (ts_out && !f->lossless) {
+    // transform skip (7.3.8.11 transform_skip_flag, 8.6.4.2): the residual scaled by 2^(15 - bitDepth - 2) is quantised like coefficients; both ways are
+    // priced as distortion * 256 + lambda^2 * rate, the flag costs one bit more, and transform skip needs a non-zero level
+    const int tsh = 15 - bd - 2, qbits = 14 + qp / 6 + (15 - bd - log2), sc = en_quant_scale(qp % 6), bd_shift = bd + log2 - 5, scale = (16 * rc_level_scale(qp % 6)) << (qp / 6), ish = 20 - bd;
+    const long long qadd = (long long)171 << (qbits - 9), dadd = 1ll << (bd_shift - 1);
+    int p_nz = 0, p_d0 = 0, p_d1 = 0, p_b0 = 0, p_b1 = 0;
+    RBT_PAR_FOR(i, 16) {
+      const int rs = lvl[32 + i], cv = rbt_clip3(-32768, 32767, rs << tsh), a = rbt_abs(cv);
+      long long qv = ((long long)a * sc + qadd) >> qbits;
+      if (qv > 32767) qv = 32767;
+      const int lt = (int)(cv < 0 ? -qv : qv);
+      long long dq = ((long long)lt * scale + dadd) >> bd_shift; dq = dq < -32768 ? -32768 : (dq > 32767 ? 32767 : dq);
+      const int r1 = (int)((((int)dq << 7) + (1 << (ish - 1))) >> ish), r0 = nz ? (int)r->res[i] : 0, a0 = rbt_abs((int)lvl[i]);
+      lvl[16 + i] = (int16_t)lt; lvl[48 + i] = (int16_t)r1;
+      p_nz += lt != 0; p_d0 += (rs - r0) * (rs - r0); p_d1 += (rs - r1) * (rs - r1);
+      if (a0) p_b0 += 3 + 2 * (31 - __builtin_clz((unsigned)a0));
+      if (qv) p_b1 += 3 + 2 * (31 - __builtin_clz((unsigned)qv));
+    }
+    const int nz1 = en_wave_sum(p_nz, (RBT_LDS_AS RbtEncLds*)0), d0 = en_wave_sum(p_d0, (RBT_LDS_AS RbtEncLds*)0), d1 = en_wave_sum(p_d1, (RBT_LDS_AS RbtEncLds*)0);
+    const int b0 = en_wave_sum(p_b0, (RBT_LDS_AS RbtEncLds*)0), b1 = en_wave_sum(p_b1, (RBT_LDS_AS RbtEncLds*)0);
+    const long long c0 = (long long)d0 * 256 + (long long)lam2 * (b0 ? b0 + 3 : 1), c1 = (long long)d1 * 256 + (long long)lam2 * ((b1 ? b1 + 3 : 1) + 1);
+    RBT_SYNC_LDS();
+    if (nz1 && c1 < c0) {
+      RBT_PAR_FOR(i, 16) { lvl[i] = lvl[16 + i]; r->res[i] = lvl[48 + i]; }
+      nz = nz1; *ts_out = 1;
+      RBT_SYNC_LDS();
+    }
+  }
+  { int16_t* cp = f->coef[c_idx] + (size_t)gy * pw + gx; RBT_PAR_FOR(i, N * N) cp[(size_t)(i >> log2) * pw + (i & (N - 1))] = lvl[i]; }
   RBT_PAR_FOR(i, N * N) {
     const int x = i & (N - 1), y = i >> log2;
     tile[(y0 + y) * S + x0 + x + 1] = (uint16_t)(nz ? rbt_clip3(0, maxv, (int)r->pred[i] + r->res[i]) : r->pred[i]);
@@ -446,13 +477,13 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
 // hm_decide_tu_split: luma only, distortion * 256 + lambda^2 * rate, 3 lambda^2 for the split). Returns the luma cbf of the CU, or with *split = 1 the
 // cbf of quarter i in bit i. On return the tile holds the chosen reconstruction, the coefficient plane the chosen levels and every 4x4 unit of the CU
 // is marked available.
-template <int TL2> RBT_DEV int en_intra_cu_luma(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int x0, int y0, int gx, int gy, int lg, int mode, int qp, int lam2, int* split) {
+template <int TL2> RBT_DEV int en_intra_cu_luma(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int x0, int y0, int gx, int gy, int lg, int mode, int qp, int lam2, int* split, int* ts_bits) {
   RBT_LDS_AS RbtEncTileT<TL2>* t = &L->t;
   const int N = 1 << lg, h = N >> 1, S = RbtEncTileT<TL2>::TS_Y;
   long long c_whole = 0, c_split = 3ll * lam2, cq = 0;
   int ssd0 = 0;
   const int cbf0 = en_tile_intra_tb(g, f, L, 0, x0, y0, gx, gy, lg, mode, qp, t->sb, -1, 0, 0, t->lv0, &c_whole, lam2, &ssd0);
-  *split = 0;
+  *split = 0; *ts_bits = 0;
   if ((long long)ssd0 * 256 < (long long)(lam2 >> 2) * N * N) {     // coded to within lambda^2 / 4 per sample by one transform: not tried as four
     RBT_PAR_FOR(i, 1 << (2 * (lg - 2))) t->uav[((y0 >> 2) + (i >> (lg - 2)) + 1) * RC_US + (x0 >> 2) + (i & ((1 << (lg - 2)) - 1)) + 1] = 1;
     RBT_SYNC_LDS();
@@ -460,16 +491,18 @@ template <int TL2> RBT_DEV int en_intra_cu_luma(const RbtStreamCfg* g, RbtFrame*
   }
   RBT_PAR_FOR(i, N * N) t->rec0[i] = t->y[(y0 + (i >> lg)) * S + x0 + (i & (N - 1)) + 1];
   RBT_SYNC_LDS();
-  int cbf1 = 0;
+  int cbf1 = 0, tsm = 0;
   for (int b = 0; b < 4; b++) {
     const int ox = (b & 1) * h, oy = (b >> 1) * h;
     RBT_PAR_FOR(i, h * h) t->ss[i] = t->sb[(oy + (i >> (lg - 1))) * N + ox + (i & (h - 1))];
     RBT_SYNC_LDS();
-    if (en_tile_intra_tb(g, f, L, 0, x0 + ox, y0 + oy, gx + ox, gy + oy, lg - 1, mode, qp, t->ss, lg - 3, (x0 + ox) >> 2, (y0 + oy) >> 2, t->lv1, &cq, lam2)) cbf1 |= 1 << b;
+    int ts = 0;
+    if (en_tile_intra_tb(g, f, L, 0, x0 + ox, y0 + oy, gx + ox, gy + oy, lg - 1, mode, qp, t->ss, lg - 3, (x0 + ox) >> 2, (y0 + oy) >> 2, t->lv1, &cq, lam2, nullptr, (lg == 3 && g->transform_skip) ? &ts : nullptr)) cbf1 |= 1 << b;
+    tsm |= ts << b;
     c_split += cq;
   }
   *split = c_split < c_whole;
-  if (*split) return cbf1;
+  if (*split) { *ts_bits = tsm; return cbf1; }
   RBT_PAR_FOR(i, N * N) t->y[(y0 + (i >> lg)) * S + x0 + (i & (N - 1)) + 1] = t->rec0[i];
   { int16_t* cp = f->coef[0] + (size_t)gy * g->w + gx; RBT_PAR_FOR(i, N * N) cp[(size_t)(i >> lg) * g->w + (i & (N - 1))] = t->lv0[i]; }
   RBT_SYNC_LDS();
@@ -608,8 +641,8 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
     { const uint16_t* sp = f->src[0] + (size_t)(cy + y0) * g->w + cx + x0; RBT_PAR_FOR(i, N * N) t->sb[i] = sp[(size_t)(i >> lg) * g->w + (i & (N - 1))]; }
     for (int q = 0; q < 2; q++) { const uint16_t* sp = f->src[1 + q] + (size_t)((cy + y0) >> 1) * g->cw + ((cx + x0) >> 1); RBT_PAR_FOR(i, Nc * Nc) t->sb[1024 + 256 * q + i] = sp[(size_t)(i >> (lg - 1)) * g->cw + (i & (Nc - 1))]; }
     RBT_SYNC();
-    int split = 0, cbf = 0, cy4 = 0;
-    if (tu_rd) cy4 = en_intra_cu_luma(g, f, L, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, lam2, &split);
+    int split = 0, cbf = 0, cy4 = 0, ts_bits = 0;
+    if (tu_rd) cy4 = en_intra_cu_luma(g, f, L, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, lam2, &split, &ts_bits);
     else cy4 = en_tile_intra_tb(g, f, L, 0, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, t->sb, lg - 2, x0 >> 2, y0 >> 2);
     if (split && lg >= 4) {
       // four transform units, each with its own Cb / Cr blocks: chroma block b is predicted when the units 0..b of the CU are reconstructed, not more
@@ -633,6 +666,7 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
     if (split) cbf |= RBT_CU_TU_SPLIT | ((cy4 & 1) ? RBT_CU_CBF_Y : 0) | ((cy4 >> 1) * RBT_CU_CBF_Y1);   // 8x8 CU as four 4x4 luma blocks: their cbf bits
     else if (cy4) cbf |= RBT_CU_CBF_Y;
     en_fill_cu_maps(f, cx + x0, cy + y0, N, RBT_MODE_INTRA | (f->lossless ? RBT_PM_TQ_BYPASS : 0) | (cy4 ? RBT_PM_NZ : 0), qp_y, cbf, 1);
+    if (lg == 3 && g->transform_skip && RBT_LANE0) f->cu_ts[((cy + y0) >> 3) * f->w8 + ((cx + x0) >> 3)] = (uint8_t)ts_bits;   // transform_skip_flag of the four 4x4 luma blocks
   }
   // ---- write the CTB back (clipped to the picture) ----
   for (int c = 0; c < 3; c++) {
@@ -719,13 +753,14 @@ RBT_DEV int en_min_in_group(int g) { return g < 4 ? g : (2 + (g & 1)) << ((g >> 
 // three TBs of the CU with one HBM round trip. Same split as the parser: what is not a bin runs on the lanes (lane i =
 // sub-block i for the significance masks, lane p = scan position p of the current sub-block for contexts and levels), the
 // serial part is bins only.
-RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, const RBT_LDS_AS int16_t* lv, int lst, int log2, int scan_idx) {
+RBT_DEV void en_write_residual(RbtEnt* s, int c_idx, const RBT_LDS_AS int16_t* lv, int lst, int log2, int scan_idx, int ts = 0) {
   RbtCabacEnc* c = &s->c; RBT_LDS_AS RbtEntropyLds* l = s->l;
 #ifdef RBT_PROFILE
   unsigned long long ta_ = __builtin_readcyclecounter(); s->n_tb++;
 #endif
   log2 = RBT_UNI(log2); scan_idx = RBT_UNI(scan_idx); lst = RBT_UNI(lst);
   const int chroma = c_idx != 0;
+  if (log2 == 2 && s->f->cfg.transform_skip && !s->f->lossless) rbt_ce_bin0(c, CTX_TRANSFORM_SKIP + chroma, RBT_UNI(ts));   // transform_skip_flag (7.3.8.11): RBT-E1 only ever sets it for luma
   const uint64_t ps = en_scan4_const(scan_idx);
   const RBT_LDS_AS uint8_t* sb_scan = l->scan[scan_idx][log2 - 2];
   const int n_sb = 1 << (2 * (log2 - 2));
@@ -914,6 +949,7 @@ RBT_DEV void en_write_cu(RbtEnt* s, int x0, int y0, int log2, int depth) {
     rbt_ce_bin0(c, CTX_SPLIT_TRANSFORM + 5 - log2, split);
     if (split) {
       const int h = 1 << (log2 - 1);
+      const int cu_ts = (log2 == 3 && s->f->cfg.transform_skip) ? RBT_UNI(s->f->cu_ts[(y0 >> 3) * s->f->w8 + (x0 >> 3)]) : 0;
       int fl[4], pcb = cbf_cb, pcr = cbf_cr;
       if (log2 > 3) {   // the 8x8 units of a quarter carry that quarter's cbf bits
         pcb = pcr = 0;
@@ -933,7 +969,7 @@ RBT_DEV void en_write_cu(RbtEnt* s, int x0, int y0, int log2, int depth) {
         }
         const int qy_cbf = (fl[b] & RBT_CU_CBF_Y) != 0;
         rbt_ce_bin0(c, CTX_CBF_LUMA + 0, qy_cbf);
-        if (qy_cbf) en_write_residual(s, 0, en_lv(l, 0, s->log2_ctb) + qy * ctb + qx, ctb, log2 - 1, en_scan_idx(1, log2 - 1, 0, mode));
+        if (qy_cbf) en_write_residual(s, 0, en_lv(l, 0, s->log2_ctb) + qy * ctb + qx, ctb, log2 - 1, en_scan_idx(1, log2 - 1, 0, mode), log2 == 3 ? (cu_ts >> b) & 1 : 0);
         if (log2 > 3) {
           if (qcb) en_write_residual(s, 1, en_lv(l, 1, s->log2_ctb) + (qy >> 1) * (ctb >> 1) + (qx >> 1), ctb >> 1, log2 - 2, en_scan_idx(1, log2 - 2, 1, mode));
           if (qcr) en_write_residual(s, 2, en_lv(l, 2, s->log2_ctb) + (qy >> 1) * (ctb >> 1) + (qx >> 1), ctb >> 1, log2 - 2, en_scan_idx(1, log2 - 2, 2, mode));

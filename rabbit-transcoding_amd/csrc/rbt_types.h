@@ -88,6 +88,7 @@ struct RbtFrame {
   uint8_t* cu_log2;              // per 8x8 unit: log2 size of the coding unit covering it
   uint8_t* cu_mode;              // per 8x8 unit: luma intra prediction mode of that CU
   uint8_t* cu_flags;             // per 8x8 unit: RBT_CU_* bits of that CU
+  uint8_t* cu_ts;                // per 8x8 unit (encoder, streams with transform skip): transform_skip_flag of the 4x4 luma blocks 0..3 of an 8x8 CU coded as four
   int32_t w8, h8;
   int32_t lossless;              // every CU cu_transquant_bypass (x265 lossless=1, PCCTranscoder.cpp:841)
   int32_t ref_frame;             // P pictures: batch index of the reference picture (zero-motion merge), else -1

@@ -41,6 +41,8 @@ struct EncodeBatch {
 };
 
 // RBT-E1 codes SAO unless RBT_ENC_SAO=0 (development switch, read by the oracle the same way)
+// ... and transform skip for the 4x4 luma blocks unless RBT_ENC_TS=0
+static int e1_ts_on() { static int v = -1; if (v < 0) { const char* e = getenv("RBT_ENC_TS"); v = !e || atoi(e) != 0; } return v; }
 static int e1_sao_on() { static int v = -1; if (v < 0) { const char* e = getenv("RBT_ENC_SAO"); v = !e || atoi(e) != 0; } return v; }
 static int coded_size(int v, int gop) { int al = gop > 1 ? 16 : 8; return (v + al - 1) / al * al; }
 static void make_param_sets(const EncStreamDesc& d, Sps& s, Pps& p) {
@@ -52,6 +54,7 @@ static void make_param_sets(const EncStreamDesc& d, Sps& s, Pps& p) {
   s.num_st_rps = 1; s.sao = d.sao; s.max_th_depth_intra = d.lossless ? 0 : 1;   // an intra CU is one transform unit or four (oracle/hevc_enc.c setup_stream)
   s.w_ctb = (cw + (1 << s.log2_ctb) - 1) >> s.log2_ctb; s.h_ctb = (ch + (1 << s.log2_ctb) - 1) >> s.log2_ctb;
   p.valid = true; p.num_ref_idx_default = 1; p.init_qp = std::min(51, std::max(0, d.qp)); p.loop_filter_across_slices = 1;
+  p.transform_skip = !d.lossless && e1_ts_on();   // the 4x4 luma blocks are coded with or without the transform, whichever is cheaper (oracle/hevc_enc.c hm_tb_finish)
   if (d.lossless) { p.transquant_bypass = 1; p.deblocking_control_present = 1; p.pps_deblocking_disabled = 1; p.loop_filter_across_slices = 0; }
   if (d.rows < 0) { p.entropy_coding_sync = 1; p.dependent_slice_segments = 1; }   // wavefront rows, one dependent slice segment each (oracle/hevc_enc.c setup_stream)
 }
@@ -104,7 +107,7 @@ static int encode_build(EncodeBatch& b) {
   size_t o_zero = a.reserve(64), zero_bytes = 64;
   if (any_wpp) for (size_t i = 0; i < nf; i++) { size_t n = ((size_t)b.frames[i].cfg.h_ctb * 2 + 2) * sizeof(uint32_t); o_rowdone[i] = a.reserve(n); zero_bytes = o_rowdone[i] + n - o_zero; }
   if (any_wpp) for (size_t i = 0; i < nf; i++) o_rowctx[i] = a.reserve((size_t)b.frames[i].cfg.h_ctb * 256);
-  std::vector<size_t> o_src(nf, (size_t)-1), o_pix(nf), o_sout(nf), o_sao(nf), o_coef(nf), o_pm(nf), o_edges(nf), o_qp(nf), o_mv(nf), o_ref(nf), o_refpoc(nf), o_cs(nf), o_cul(nf), o_cum(nf), o_cuf(nf);
+  std::vector<size_t> o_src(nf, (size_t)-1), o_pix(nf), o_sout(nf), o_sao(nf), o_coef(nf), o_pm(nf), o_edges(nf), o_qp(nf), o_mv(nf), o_ref(nf), o_refpoc(nf), o_cs(nf), o_cul(nf), o_cum(nf), o_cuf(nf), o_cut(nf);
   for (size_t i = 0; i < nf; i++) {
     const RbtStreamCfg& c = b.frames[i].cfg; size_t u = (size_t)c.w4 * c.h4, nc = (size_t)c.w_ctb * c.h_ctb, u8 = (size_t)b.frames[i].w8 * b.frames[i].h8;
     { const EncStreamDesc& d = b.desc[b.frame_stream[i]];
@@ -112,7 +115,7 @@ static int encode_build(EncodeBatch& b) {
     o_pix[i] = a.reserve(frame_samples(c) * 2); o_coef[i] = a.reserve(frame_samples(c) * 2);
     o_sout[i] = b.desc[b.frame_stream[i]].sao ? a.reserve(frame_samples(c) * 2) : o_pix[i]; o_sao[i] = a.reserve(nc * sizeof(RbtSao));
     o_pm[i] = a.reserve(u); o_edges[i] = a.reserve(u); o_qp[i] = a.reserve(u); o_mv[i] = a.reserve(u * 4); o_ref[i] = a.reserve(u); o_refpoc[i] = a.reserve(u * 4);
-    o_cul[i] = a.reserve(u8); o_cum[i] = a.reserve(u8); o_cuf[i] = a.reserve(u8);
+    o_cul[i] = a.reserve(u8); o_cum[i] = a.reserve(u8); o_cuf[i] = a.reserve(u8); o_cut[i] = a.reserve(u8);
   }
   // the CTB -> slice maps of all pictures sit back to back: one upload per batch instead of one per picture (a copy is a queue entry of its own)
   size_t cs_words = 0; for (size_t i = 0; i < nf; i++) { o_cs[i] = cs_words; cs_words += (size_t)b.frames[i].cfg.w_ctb * b.frames[i].cfg.h_ctb; }
@@ -141,7 +144,7 @@ static int encode_build(EncodeBatch& b) {
     f.coef[0] = (int16_t*)(base + o_coef[i]); f.coef[1] = f.coef[0] + ys; f.coef[2] = f.coef[1] + cs;
     f.pm = base + o_pm[i]; f.edges = base + o_edges[i]; f.qp = (int8_t*)(base + o_qp[i]); f.mv = (int16_t*)(base + o_mv[i]); f.ref = (int8_t*)(base + o_ref[i]);
     f.refpoc = (int32_t*)(base + o_refpoc[i]); f.ctb_slice = (uint16_t*)(base + o_cs_all) + o_cs[i];
-    f.cu_log2 = base + o_cul[i]; f.cu_mode = base + o_cum[i]; f.cu_flags = base + o_cuf[i];
+    f.cu_log2 = base + o_cul[i]; f.cu_mode = base + o_cum[i]; f.cu_flags = base + o_cuf[i]; f.cu_ts = base + o_cut[i];
     if (any_wpp) { f.row_done = (uint32_t*)(base + o_rowdone[i]); f.row_ctx = base + o_rowctx[i]; }
     // per CTB: the SLICE it belongs to (index of the slice's independent segment): availability, QP and loop filter flags are per slice
     { int head = f.first_slice;
