@@ -18,7 +18,8 @@
  *     As the second half of a transcoder (hint_modes) the search is replaced by planar, DC and the input stream's modes at the block's four quarters.
  *     An intra CU is one transform unit or four (max_transform_hierarchy_depth_intra 1; not in lossless streams): hm_decide_tu_split codes the luma block
  *     as one block and, unless that is within lambda^2 / 4 per sample already, as four on the reconstruction, and keeps the cheaper (distortion * 256 +
- *     lambda^2 * rate); 8x8 CUs split into 4x4 DST blocks with one 4x4 Cb / Cr block each, larger CUs' chroma follows the luma tree.
+ *     lambda^2 * rate); 8x8 CUs split into 4x4 blocks with one 4x4 Cb / Cr block each, larger CUs' chroma follows the luma tree. A 4x4 luma block is coded with the
+ *     DST or with transform skip (transform_skip_enabled_flag), whichever is cheaper by the same measure with one bit for the flag (hm_tb_finish; not RBT_ENC_TS=0).
  *   - P pictures: 16x16 CUs merged (zero MV) + residual, skip when all levels are zero, skips merged up the tree;
  *     dead-zone 85/512.
  *   - lossless (occupancy): cu_transquant_bypass, same quadtree/mode analysis.

@@ -5,7 +5,7 @@
 //                      DC and the input stream's own modes), blocks inside a well-predicted block skipped, bottom-up quadtree (parallel over every CTB
 //                      of every I picture)
 //   en_intra_ctb       closed-loop intra coding of one CTB: predict, forward DST/DCT, dead-zone quantiser, reconstruction; every CU as one transform unit
-//                      or four, decided on the reconstruction (serial along a CTB row; rows are independent slices or, in wavefront mode, follow the
+//                      or four, decided on the reconstruction, 4x4 luma blocks with the DST or transform skip (serial along a CTB row; rows are independent slices or, in wavefront mode, follow the
 //                      row above at a distance of two CTBs)
 //   en_inter_ctb       P pictures: zero-motion merge from the reconstructed IDR, 16x16 CUs, skip merging (fully parallel)
 //   en_sao_ctb         SAO parameters of one CTB from source-vs-reconstruction statistics, applied by the same wave
