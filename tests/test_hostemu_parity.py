@@ -255,3 +255,26 @@ def test_wavefront_rows_behind_entry_points(ctx, log2_ctb):
         dec, w, h, bd, chk, fail = ctx.decode(bs)
         assert (chk, fail) == (2, 0) and np.array_equal(dec, rec)
         assert ctx.transcode_substream(bs, vt, q1, log2_ctb=5, rows_per_slice=-1, md5_sei=0) == O.transcode_substream(bs, int(vt), q1, 4, 5, -1, 0)
+
+
+def test_transform_skip_blocks_are_chosen_and_mirrored(ctx, monkeypatch):
+    """RBT-E1 codes a 4x4 luma block with the DST or with transform skip, whichever is cheaper (oracle hm_tb_finish, csrc en_tile_intra_tb). A depth map made of
+    small steps is where skipping wins: the stream must differ from the one coded with RBT_ENC_TS=0 (the oracle reads the switch per call), equal the oracle's
+    with it, carry transform_skip_enabled_flag, and decode to the encoder's reconstruction."""
+    w, h = 128, 96
+    r = np.random.default_rng(5)
+    y = (r.integers(0, 6, (h // 4, w // 4)) * 37 + 300).repeat(4, 0).repeat(4, 1)            # 4x4 plateaus with steps between them
+    y[:, w // 2:] += r.integers(0, 2, (h, w // 2)) * 9                                        # and a noisy half
+    fr = np.concatenate([y.ravel(), np.full(w * h // 2, 512)]).astype(np.uint16)[None, :].repeat(2, 0)
+    bs = ctx.encode(fr, w, h, 10, 24, gop=2, log2_ctb=5, rows_per_slice=-1)
+    on, rec = O.encode(fr, w, h, 10, 24, gop=2, log2_ctb=5, rows_per_slice=-1)
+    assert bs == on
+    monkeypatch.setenv("RBT_ENC_TS", "0")
+    off, _ = O.encode(fr, w, h, 10, 24, gop=2, log2_ctb=5, rows_per_slice=-1)
+    monkeypatch.delenv("RBT_ENC_TS")
+    assert off != on and len(on) < len(off)
+    dec, _, _, _, chk, fail = ctx.decode(bs)
+    assert (chk, fail) == (2, 0) and np.array_equal(dec, rec)
+    # lossless streams have no transform to skip: the flag stays off
+    lo = ctx.encode(fr[:1], w, h, 10, 8, gop=1, lossless=1, log2_ctb=5, rows_per_slice=0)
+    assert lo == O.encode(fr[:1], w, h, 10, 8, gop=1, lossless=1, i_qp_offset=0, log2_ctb=5, rows_per_slice=0)[0]
