@@ -192,3 +192,18 @@ def test_stats_add_up_like_the_reference_report(R, hlib, container):
     assert st["geometry_aux_video"] == sum(len(u) - 4 for u in units if u[0] >> 3 == V.GVD and aux(u)) == 300
     assert st["occupancy_video"] == sum(len(u) - 4 for u in units if u[0] >> 3 == V.OVD)
     assert st["total_metadata"] == len(data) - geo - att
+
+
+def test_transcode_v3c_empty_and_video_less_streams(R, ctx, container):
+    """a sample stream with no units, and GOFs without video units (parameter set and atlas only), go through untouched apart from the size precision"""
+    assert ctx.transcode_v3c(bytes([0x40]), 24, 32) == bytes([0x00]) == O.v3c_transcode(bytes([0x40]), 24, 32, 4)
+    _, units = container
+    meta = [u for u in units if u[0] >> 3 in (V.VPS, V.AD)]
+    data = V.sample_stream(meta, 4)
+    got = ctx.transcode_v3c(data, 24, 32, gofs_per_job=0)
+    assert got == O.v3c_transcode(data, 24, 32, 4) and V.parse(got) == (2, meta)
+    # a video unit with an empty payload (header only) is carried over as it is
+    odd = units[:2] + [V.unit_header(V.OVD)] + units[3:5]
+    data = V.sample_stream(odd, 3)
+    got = ctx.transcode_v3c(data, 24, 32)
+    assert got == O.v3c_transcode(data, 24, 32, 4) and V.parse(got)[1][2] == V.unit_header(V.OVD)
