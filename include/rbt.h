@@ -224,6 +224,12 @@ typedef struct {
  * In a multi-GPU job (rbt_create with world_size > 1) the output holds the GOFs this rank owns (rbt_owns_gof) and nothing else: rank 0 of the host
  * program gathers the partial streams and merges them with rbt_v3c_index + rbt_v3c_write (gof_shard.transcode_v3c does). */
 int rbt_transcode_v3c(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_params* p, uint8_t** out, size_t* n_out);
+/* The same walk with the output handed over GOF by GOF, in GOF order, as soon as the job that holds a GOF has been collected (the jobs behind it are still running): the
+ * sink gets the units of one GOF this context owns - carried-over units point into `in`, transcoded ones into memory that is released when the sink returns. A sink that
+ * writes a sample stream itself chooses the unit size precision up front (PCCBitstreamWriter::write derives it from the largest unit of the whole file, which a streaming
+ * writer does not know yet: forcedSsvhUnitSizePrecisionBytes_ = 4 is what fits every file). A non-zero return of the sink ends the walk (RBT_ERR_PARAM; jobs in flight are drained). */
+typedef int (*rbt_v3c_sink)(void* user, int gof, int n_units, const uint8_t* const* unit, const size_t* unit_size);
+int rbt_transcode_v3c_stream(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_params* p, rbt_v3c_sink sink, void* user);
 
 #ifdef __cplusplus
 }

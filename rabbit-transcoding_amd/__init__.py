@@ -70,6 +70,7 @@ class V3CStat(C.Structure):
                [(n, C.c_uint64) for n in ("occupancy_video", "geometry_video", "geometry_aux_video", "attribute_video", "attribute_aux_video", "total_metadata", "total_geometry", "total_attribute", "total")]
 
 
+V3C_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))   # rbt_v3c_sink
 RBT_V3C_VPS, RBT_V3C_AD, RBT_V3C_OVD, RBT_V3C_GVD, RBT_V3C_AVD = range(5)
 
 
@@ -110,6 +111,7 @@ def load(path=None):
     L.rbt_v3c_index.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(V3CUnit)), C.POINTER(C.c_int)]
     L.rbt_v3c_write.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rbt_v3c_stats.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(V3CStat)]
+    L.rbt_transcode_v3c_stream.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(V3CParams), V3C_SINK, C.c_void_p]
     L.rbt_transcode_v3c.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(V3CParams), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     return L
 
@@ -253,6 +255,15 @@ class Context:
         out, n = C.c_void_p(), C.c_size_t()
         self._chk(self.L.rbt_transcode_v3c(self.h, data, len(data), C.byref(p), C.byref(out), C.byref(n)))
         return self._take(out, n)
+
+    def transcode_v3c_stream(self, data: bytes, sink, geometry_qp, attribute_qp, occupancy_precision=4, log2_ctb=5, rows_per_slice=-1, md5_sei=0, verify_md5=0, gofs_per_job=0):
+        """rbt_transcode_v3c_stream: sink(gof, [unit bytes, ...]) is called once per GOF this context owns, in GOF order, while later GOFs are still on the GPU; a truthy
+        return of the sink ends the walk"""
+        p = V3CParams(occupancy_precision, geometry_qp, attribute_qp, 0, log2_ctb, rows_per_slice, md5_sei, verify_md5, gofs_per_job)
+
+        def cb(_user, gof, n_units, unit, unit_size):
+            return 1 if sink(gof, [C.string_at(unit[i], unit_size[i]) for i in range(n_units)]) else 0
+        self._chk(self.L.rbt_transcode_v3c_stream(self.h, data, len(data), C.byref(p), V3C_SINK(cb), None))
 
     def set_depth(self, n):
         """rbt_set_depth: how many GOFs the caller will keep in flight (1..16 = RBT_MAX_JOBS, default 4)"""

@@ -100,14 +100,16 @@ int rbt_v3c_stats(const uint8_t* in, size_t n, rbt_v3c_stat* out) {
   return RBT_OK;
 }
 
-int rbt_transcode_v3c(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_params* p, uint8_t** out, size_t* n_out) {
-  if (!ctx || !in || !p || !out || !n_out) return RBT_ERR_PARAM;
-  *out = nullptr; *n_out = 0;
+int rbt_transcode_v3c_stream(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_params* p, rbt_v3c_sink sink, void* user) {
+  if (!ctx || !in || !p || !sink) return RBT_ERR_PARAM;
   rbt_v3c_unit* units = nullptr; int nu = 0;
   int rc = rbt_v3c_index(in, n, &units, &nu);
   if (rc) return rc;
   std::vector<rbt_v3c_unit> U(units, units + nu); rbt_free(units);
   const int n_gofs = nu ? U.back().gof + 1 : 0;
+  std::vector<int> first(n_gofs + 1, nu);                                                              // first unit of every GOF
+  for (int i = nu - 1; i >= 0; i--) first[U[i].gof] = i;
+  for (int g = n_gofs - 1; g >= 0; g--) if (first[g] == nu) first[g] = first[g + 1];
   // per GOF: the units transcodeData replaces (PCCTranscoder.cpp:145-168)
   struct Pick { int unit; int video_type; };
   std::vector<std::vector<Pick>> picks(n_gofs);
@@ -123,11 +125,34 @@ int rbt_transcode_v3c(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_p
     if (n_geo > 1 || n_attr > 1) return RBT_ERR_UNSUPPORTED;                                          // separate map streams: VIDEO_GEOMETRY_D0.. / VIDEO_ATTRIBUTE_T0.., which transcodeData never asks for
   }
   std::vector<Buf> repl(nu);                                                                           // new payloads (sample stream form) of the picked units
-  auto cleanup = [&]() { for (auto& b : repl) free(b.p); };
+  auto cleanup = [&]() { for (auto& b : repl) { free(b.p); b.p = nullptr; } };
+  // PCCBitstreamWriter::encode, GOF by GOF: the units of every owned GOF below `upto` that has not been handed over yet, in order, video units with their 4 header
+  // bytes in front of the new payload
+  int next_gof = 0;
+  auto deliver = [&](int upto) -> int {
+    for (; next_gof < upto; next_gof++) {
+      const int g = next_gof;
+      if (!rbt_owns_gof(ctx, g)) continue;
+      std::vector<Buf> made; std::vector<const uint8_t*> up; std::vector<size_t> un; int r = RBT_OK;
+      for (int i = first[g]; i < first[g + 1] && !r; i++) {
+        if (repl[i].p) {
+          Buf m; m.n = 4 + repl[i].n; m.p = (uint8_t*)malloc(m.n);
+          if (!m.p) { r = RBT_ERR_NOMEM; break; }
+          memcpy(m.p, in + U[i].offset, 4); memcpy(m.p + 4, repl[i].p, repl[i].n);
+          free(repl[i].p); repl[i].p = nullptr;
+          made.push_back(m); up.push_back(m.p); un.push_back(m.n);
+        } else { up.push_back(in + U[i].offset); un.push_back(U[i].size); }
+      }
+      if (!r && sink(user, g, (int)up.size(), up.data(), un.data()) != 0) r = RBT_ERR_PARAM;        // the sink gave up
+      for (auto& m : made) free(m.p);
+      if (r) { next_gof++; return r; }
+    }
+    return RBT_OK;
+  };
   // jobs: the picked units of `per` consecutive owned GOFs each, as many in flight as the context allows (RBT_ERR_BUSY tells)
-  struct Job { rbt_job* j; std::vector<int> unit; };
+  struct Job { rbt_job* j; std::vector<int> unit; int last_gof; };
   std::deque<Job> q;
-  auto collect = [&]() -> int {
+  auto collect = [&](bool hand_over) -> int {
     Job jb = q.front(); q.pop_front();
     std::vector<uint8_t*> o(jb.unit.size(), nullptr); std::vector<size_t> on(jb.unit.size(), 0);
     int r = rbt_wait_gof(ctx, jb.j, o.data(), on.data());
@@ -135,6 +160,7 @@ int rbt_transcode_v3c(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_p
       if (!r) r = rbt_byte_to_sample_stream(o[k], on[k], &repl[jb.unit[k]].p, &repl[jb.unit[k]].n);   // transcodeVideo ends with it (PCCTranscoder.cpp:517)
       rbt_free(o[k]);
     }
+    if (!r && hand_over) r = deliver(jb.last_gof + 1);                                               // jobs are collected in order: everything up to this job's last GOF is complete
     return r;
   };
   std::vector<int> owned; for (int g = 0; g < n_gofs; g++) if (rbt_owns_gof(ctx, g) && !picks[g].empty()) owned.push_back(g);
@@ -150,7 +176,7 @@ int rbt_transcode_v3c(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_p
     for (size_t i = 0; i < nj; i++) cut.push_back(cut.back() + n_own / nj + (i < n_own % nj ? 1 : 0)); }
   for (size_t ji = 0; ji + 1 < cut.size() && !rc; ji++) {
     const size_t a = cut[ji], a_end = cut[ji + 1];
-    std::vector<Buf> conv; std::vector<const uint8_t*> ip; std::vector<size_t> in_n; std::vector<rbt_stream_params> sp; Job jb{nullptr, {}};
+    std::vector<Buf> conv; std::vector<const uint8_t*> ip; std::vector<size_t> in_n; std::vector<rbt_stream_params> sp; Job jb{nullptr, {}, owned[a_end - 1]};
     for (size_t b = a; b < a_end && !rc; b++)
       for (const Pick& pk : picks[owned[b]]) {
         Buf c; rc = rbt_sample_to_byte_stream(in + U[pk.unit].offset + 4, U[pk.unit].size - 4, &c.p, &c.n);   // transcodeData :152,159,164
@@ -165,30 +191,35 @@ int rbt_transcode_v3c(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_p
     if (!rc && (int)ip.size() > RBT_MAX_STREAMS) rc = RBT_ERR_PARAM;
     while (!rc) {
       rc = rbt_submit_gof(ctx, (int)ip.size(), ip.data(), in_n.data(), sp.data(), &jb.j);
-      if (rc == RBT_ERR_BUSY && !q.empty()) { rc = collect(); continue; }     // every slot taken: take the oldest result first
+      if (rc == RBT_ERR_BUSY && !q.empty()) { rc = collect(true); continue; }  // every slot taken: take the oldest result first (and hand its GOFs over)
       break;
     }
     for (auto& c : conv) free(c.p);                                            // the inputs may go as soon as submit returns
     if (!rc) q.push_back(jb);
   }
-  while (!q.empty()) { int r = collect(); if (!rc) rc = r; }
+  while (!q.empty()) { int r = collect(!rc); if (!rc) rc = r; }               // after an error the remaining jobs are only drained
   if (announced) rbt_set_depth(ctx, announced);
-  if (rc) { cleanup(); return rc; }
-  // PCCBitstreamWriter::encode: the units of every (owned) GOF in order, video units with their 4 header bytes in front of the new payload
-  std::vector<Buf> made; std::vector<const uint8_t*> up; std::vector<size_t> un;
-  for (int i = 0; i < nu; i++) {
-    if (!rbt_owns_gof(ctx, U[i].gof)) continue;
-    if (repl[i].p) {
-      Buf m; m.n = 4 + repl[i].n; m.p = (uint8_t*)malloc(m.n);
-      if (!m.p) { rc = RBT_ERR_NOMEM; break; }
-      memcpy(m.p, in + U[i].offset, 4); memcpy(m.p + 4, repl[i].p, repl[i].n);
-      made.push_back(m); up.push_back(m.p); un.push_back(m.n);
-    } else { up.push_back(in + U[i].offset); un.push_back(U[i].size); }
-  }
-  if (!rc) rc = rbt_v3c_write(up.data(), un.data(), (int)up.size(), p->forced_unit_size_precision_bytes, out, n_out);
-  for (auto& m : made) free(m.p);
+  if (!rc) rc = deliver(n_gofs);                                              // GOFs behind the last job (no video units of their own)
   cleanup();
   return rc;
+}
+
+// the whole file at once: the stream walk with a sink that keeps every unit, then PCCBitstreamWriter::write over all of them
+namespace { struct Keep { std::vector<std::vector<uint8_t>> unit; };
+int keep_units(void* user, int, int n_units, const uint8_t* const* unit, const size_t* unit_size) {
+  Keep* k = (Keep*)user;
+  for (int i = 0; i < n_units; i++) k->unit.emplace_back(unit[i], unit[i] + unit_size[i]);
+  return 0;
+} }
+int rbt_transcode_v3c(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_params* p, uint8_t** out, size_t* n_out) {
+  if (!ctx || !in || !p || !out || !n_out) return RBT_ERR_PARAM;
+  *out = nullptr; *n_out = 0;
+  Keep k;
+  int rc = rbt_transcode_v3c_stream(ctx, in, n, p, keep_units, &k);
+  if (rc) return rc;
+  std::vector<const uint8_t*> up; std::vector<size_t> un;
+  for (auto& u : k.unit) { up.push_back(u.data()); un.push_back(u.size()); }
+  return rbt_v3c_write(up.data(), un.data(), (int)up.size(), p->forced_unit_size_precision_bytes, out, n_out);
 }
 
 }  // extern "C"

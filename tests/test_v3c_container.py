@@ -207,3 +207,25 @@ def test_transcode_v3c_empty_and_video_less_streams(R, ctx, container):
     data = V.sample_stream(odd, 3)
     got = ctx.transcode_v3c(data, 24, 32)
     assert got == O.v3c_transcode(data, 24, 32, 4) and V.parse(got)[1][2] == V.unit_header(V.OVD)
+
+
+@pytest.mark.parametrize("depth,per", [(1, 1), (2, 1), (16, 0), (2, 2)])
+def test_stream_walk_hands_gofs_over_in_order(R, ctx, container, depth, per):
+    """rbt_transcode_v3c_stream: one sink call per GOF, in order, and the units written as one sample stream are the file rbt_transcode_v3c makes"""
+    gofs, units = container
+    extra = [V.unit_header(V.VPS) + b"tail-gof-without-video", V.unit_header(V.AD) + bytes(40)]       # a GOF with no video units at the end
+    data = V.sample_stream(units + extra, 3)
+    seen, got = [], []
+    ctx.set_depth(depth)
+    try:
+        ctx.transcode_v3c_stream(data, lambda g, us: (seen.append(g), got.extend(us)) and None, 24, 32, gofs_per_job=per)
+        assert seen == [0, 1, 2, 3]
+        assert R.v3c_write(got, 0, ctx.L) == ctx.transcode_v3c(data, 24, 32) == O.v3c_transcode(data, 24, 32, 4)
+        # a sink that gives up after the first GOF ends the walk with an error; the context stays usable
+        calls = []
+        with pytest.raises(R.RbtError) as e:
+            ctx.transcode_v3c_stream(data, lambda g, us: calls.append(g) or True, 24, 32, gofs_per_job=per)
+        assert e.value.code == -4 and calls == [0]
+        assert ctx.transcode_v3c(data, 24, 32) == O.v3c_transcode(data, 24, 32, 4) and ctx.get_depth() == depth
+    finally:
+        ctx.set_depth(4)
