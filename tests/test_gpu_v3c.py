@@ -69,3 +69,16 @@ def test_full_size_gof_in_a_container(R, ctx):
     got = ctx.transcode_v3c(data, 24, 32)
     assert got == O.v3c_transcode(data, 24, 32, 4)
     assert len(got) < len(data) // 2
+
+
+@pytest.mark.parametrize("depth,per", [(1, 1), (4, 1), (16, 0)])
+def test_stream_walk_on_the_gpu(R, ctx, container, depth, per):
+    """rbt_transcode_v3c_stream: GOFs handed to the sink in order while later jobs run; written as one sample stream they are the file rbt_transcode_v3c makes"""
+    seen, got = [], []
+    ctx.set_depth(depth)
+    try:
+        ctx.transcode_v3c_stream(container, lambda g, us: (seen.append(g), got.extend(us)) and None, 24, 32, gofs_per_job=per)
+    finally:
+        ctx.set_depth(4)
+    assert seen == [0, 1, 2, 3, 4]
+    assert R.v3c_write(got, 0, ctx.L) == O.v3c_transcode(container, 24, 32, 4)
