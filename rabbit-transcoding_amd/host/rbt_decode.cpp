@@ -333,26 +333,32 @@ int decode_fetch(DecodeBatch& b, int stream, rbt_video* out, bool verify_md5) {
   out->width = dw; out->height = dh; out->bit_depth = c.bit_depth; out->n_frames = n;
   out->data = (uint16_t*)malloc(ofs * 2 * (size_t)n);
   if (!out->data) return RBT_ERR_NOMEM;
-  std::vector<uint16_t> full(crop || verify_md5 ? fs : 0);
+  // with a conformance window the whole coded pictures are kept next to the cropped output while their hashes are checked (all planes side by side, md5_planes_u16)
+  const bool keep = crop && verify_md5;
+  std::vector<uint16_t> full(crop ? (keep ? fs * (size_t)n : fs) : 0);
+  std::vector<Md5PlaneJob> jobs; std::vector<uint8_t> hashes((size_t)n * 48);
   for (int i = 0; i < n; i++) {
     const RbtFrame& f = b.frames[first + i];
     uint16_t* dst = out->data + ofs * (size_t)i;
-    uint16_t* p = crop ? full.data() : dst;
+    uint16_t* p = crop ? full.data() + (keep ? fs * (size_t)i : 0) : dst;
     if (rbtk::d2h(p, f.out[0], fs * 2)) return RBT_ERR_NO_DEVICE;
     if (verify_md5 && b.info[first + i].has_md5) {
-      out->md5_checked++;
-      uint8_t h[16]; bool bad = false;
-      md5_plane_u16(p, c.w, c.h, c.bit_depth, h); bad |= memcmp(h, b.info[first + i].md5[0], 16) != 0;
-      md5_plane_u16(p + (size_t)c.w * c.h, c.cw, c.ch, c.bit_depth, h); bad |= memcmp(h, b.info[first + i].md5[1], 16) != 0;
-      md5_plane_u16(p + (size_t)c.w * c.h + (size_t)c.cw * c.ch, c.cw, c.ch, c.bit_depth, h); bad |= memcmp(h, b.info[first + i].md5[2], 16) != 0;
-      if (bad) out->md5_failed++;
+      jobs.push_back({p, c.w, c.h, c.bit_depth, &hashes[(size_t)i * 48]});
+      jobs.push_back({p + (size_t)c.w * c.h, c.cw, c.ch, c.bit_depth, &hashes[(size_t)i * 48 + 16]});
+      jobs.push_back({p + (size_t)c.w * c.h + (size_t)c.cw * c.ch, c.cw, c.ch, c.bit_depth, &hashes[(size_t)i * 48 + 32]});
     }
     if (crop) {
-      const uint16_t* src = full.data(); uint16_t* d = dst;
+      const uint16_t* full_i = p;
+      const uint16_t* src = full_i; uint16_t* d = dst;
       for (int k = 0; k < 3; k++) { const int sh = k ? 1 : 0, pw = c.w >> sh, ph = c.h >> sh, ow = dw >> sh, oh = dh >> sh;
         for (int y = 0; y < oh; y++) memcpy(d + (size_t)y * ow, src + (size_t)(y + (ct >> sh)) * pw + (cl >> sh), (size_t)ow * 2);
         src += (size_t)pw * ph; d += (size_t)ow * oh; }
     }
+  }
+  md5_planes_u16(jobs.data(), jobs.size());
+  for (int i = 0; i < n; i++) if (verify_md5 && b.info[first + i].has_md5) {
+    out->md5_checked++;
+    if (memcmp(&hashes[(size_t)i * 48], b.info[first + i].md5[0], 16) || memcmp(&hashes[(size_t)i * 48 + 16], b.info[first + i].md5[1], 16) || memcmp(&hashes[(size_t)i * 48 + 32], b.info[first + i].md5[2], 16)) out->md5_failed++;
   }
   return 0;
 }

@@ -2,6 +2,9 @@
 #include <cstring>
 #include "rbt_hls.h"
 #include <cmath>
+#include <algorithm>
+#include <atomic>
+#include <thread>
 
 namespace rbt {
 
@@ -376,6 +379,18 @@ void md5_plane_u16(const uint16_t* p, int w, int h, int bit_depth, uint8_t out[1
   if (bit_depth <= 8) { std::vector<uint8_t> row(w); for (int y = 0; y < h; y++) { for (int x = 0; x < w; x++) row[x] = (uint8_t)p[(size_t)y * w + x]; m.update(row.data(), w); } }
   else m.update((const uint8_t*)p, (size_t)w * h * 2);   // little-endian host: samples are already 2 bytes LSB first
   m.finish(out);
+}
+
+// The hashes of many planes at once: MD5 is a serial chain of ~5 cycles per step (~0.6 GB/s on one core, whatever the code looks like), and a 32-frame GOF of 1280x1280
+// maps is 630 MB of samples - one chain per plane on the host's cores instead (a 16-core share hashes the GOF in ~70 ms instead of 1.1 s).
+void md5_planes_u16(const Md5PlaneJob* jobs, size_t n) {
+  unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 4;
+  const size_t nt = std::min<size_t>(std::min<size_t>(hw, 32), n);
+  if (nt <= 1) { for (size_t i = 0; i < n; i++) md5_plane_u16(jobs[i].p, jobs[i].w, jobs[i].h, jobs[i].bit_depth, jobs[i].out); return; }
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < nt; t++) th.emplace_back([&]() { for (size_t i; (i = next.fetch_add(1)) < n;) md5_plane_u16(jobs[i].p, jobs[i].w, jobs[i].h, jobs[i].bit_depth, jobs[i].out); });
+  for (auto& t : th) t.join();
 }
 
 }  // namespace rbt

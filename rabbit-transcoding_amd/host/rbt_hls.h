@@ -83,5 +83,7 @@ void write_param_sets(std::vector<uint8_t>& out, const Sps& s, const Pps& p);
 void write_slice_header(BitWriter& w, const Sps& s, const Pps& p, const SliceHdr& h, bool is_idr, int st_rps_idx);
 
 void md5_plane_u16(const uint16_t* p, int w, int h, int bit_depth, uint8_t out[16]);
+struct Md5PlaneJob { const uint16_t* p; int w, h, bit_depth; uint8_t* out; };
+void md5_planes_u16(const Md5PlaneJob* jobs, size_t n);   // the same for many planes, one chain per host thread
 
 }  // namespace rbt

@@ -239,7 +239,20 @@ static int encode_finish(EncodeBatch& b, std::vector<std::vector<uint8_t>>& outs
   // ---- NAL packing (parameter sets, slice headers, emulation prevention) ----
   double t1 = now_ms();
   outs.assign(b.desc.size(), {});
-  std::vector<uint16_t> rec;
+  // decoded picture hash SEI (md5_sei): the reconstructed pictures come to the host once and their planes are hashed side by side (md5_planes_u16)
+  std::vector<uint16_t> rec; std::vector<size_t> rec_off(nf, 0); std::vector<uint8_t> hashes(nf * 48);
+  { size_t tot = 0; for (size_t i = 0; i < nf; i++) if (b.desc[b.frame_stream[i]].md5) { rec_off[i] = tot; tot += frame_samples(b.frames[i].cfg); }
+    if (tot) {
+      rec.resize(tot); std::vector<Md5PlaneJob> jobs;
+      for (size_t i = 0; i < nf; i++) if (b.desc[b.frame_stream[i]].md5) {
+        const RbtFrame& f = b.frames[i]; const RbtStreamCfg& c = f.cfg; uint16_t* r = rec.data() + rec_off[i];
+        if (rbtk::d2h(r, f.out[0], frame_samples(c) * 2)) { b.err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
+        jobs.push_back({r, c.w, c.h, c.bit_depth, &hashes[i * 48]});
+        jobs.push_back({r + (size_t)c.w * c.h, c.cw, c.ch, c.bit_depth, &hashes[i * 48 + 16]});
+        jobs.push_back({r + (size_t)c.w * c.h + (size_t)c.cw * c.ch, c.cw, c.ch, c.bit_depth, &hashes[i * 48 + 32]});
+      }
+      md5_planes_u16(jobs.data(), jobs.size());
+    } }
   for (size_t i = 0; i < nf; i++) {
     int si = b.frame_stream[i]; const Sps& s = b.sps[si]; const Pps& p = b.pps[si]; std::vector<uint8_t>& out = outs[si]; const RbtFrame& f = b.frames[i];
     bool idr = b.frame_is_idr[i] != 0;
@@ -253,13 +266,8 @@ static int encode_finish(EncodeBatch& b, std::vector<std::vector<uint8_t>>& outs
       append_nal(out, idr ? NAL_IDR_W_RADL : NAL_TRAIL_R, w.b.data(), w.b.size(), k == 0);
     }
     if (b.desc[si].md5) {
-      // decoded picture hash SEI: needs the reconstructed picture on the host (diagnostic option, off in the benchmark)
-      const RbtStreamCfg& c = f.cfg; size_t fs = frame_samples(c); rec.resize(fs);
-      if (rbtk::d2h(rec.data(), f.out[0], fs * 2)) { b.err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
       uint8_t sei[52]; sei[0] = 132; sei[1] = 49; sei[2] = 0;
-      md5_plane_u16(rec.data(), c.w, c.h, c.bit_depth, sei + 3);
-      md5_plane_u16(rec.data() + (size_t)c.w * c.h, c.cw, c.ch, c.bit_depth, sei + 19);
-      md5_plane_u16(rec.data() + (size_t)c.w * c.h + (size_t)c.cw * c.ch, c.cw, c.ch, c.bit_depth, sei + 35);
+      memcpy(sei + 3, &hashes[i * 48], 48);
       sei[51] = 0x80;
       append_nal(out, NAL_SEI_SUFFIX, sei, 52, false);
     }
