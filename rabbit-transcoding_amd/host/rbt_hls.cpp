@@ -385,7 +385,8 @@ void md5_plane_u16(const uint16_t* p, int w, int h, int bit_depth, uint8_t out[1
 // maps is 630 MB of samples - one chain per plane on the host's cores instead (a 16-core share hashes the GOF in ~70 ms instead of 1.1 s).
 void md5_planes_u16(const Md5PlaneJob* jobs, size_t n) {
   unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 4;
-  const size_t nt = std::min<size_t>(std::min<size_t>(hw, 32), n);
+  size_t total = 0; for (size_t i = 0; i < n; i++) total += (size_t)jobs[i].w * jobs[i].h;
+  const size_t nt = total < (1u << 20) ? 1 : std::min<size_t>(std::min<size_t>(hw, 32), n);   // small pictures: not worth starting threads for
   if (nt <= 1) { for (size_t i = 0; i < n; i++) md5_plane_u16(jobs[i].p, jobs[i].w, jobs[i].h, jobs[i].bit_depth, jobs[i].out); return; }
   std::atomic<size_t> next{0};
   std::vector<std::thread> th;
