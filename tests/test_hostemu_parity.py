@@ -278,3 +278,17 @@ def test_transform_skip_blocks_are_chosen_and_mirrored(ctx, monkeypatch):
     # lossless streams have no transform to skip: the flag stays off
     lo = ctx.encode(fr[:1], w, h, 10, 8, gop=1, lossless=1, log2_ctb=5, rows_per_slice=0)
     assert lo == O.encode(fr[:1], w, h, 10, 8, gop=1, lossless=1, i_qp_offset=0, log2_ctb=5, rows_per_slice=0)[0]
+
+
+@pytest.mark.parametrize("w,h,log2_ctb,rows", [(128, 96, 5, -1), (64, 64, 4, 1), (192, 128, 6, 0)])
+def test_transform_skip_8_bit_streams(ctx, w, h, log2_ctb, rows):
+    """the same choice in 8-bit streams (the residual is scaled by 2^5 instead of 2^3 before the quantiser): encoder == oracle, decoder reads it back"""
+    r = np.random.default_rng(w)
+    y = (r.integers(0, 6, (h // 4, w // 4)) * 9 + 60).repeat(4, 0).repeat(4, 1) + r.integers(0, 3, (h, w))
+    fr = np.concatenate([y.ravel(), r.integers(100, 140, w * h // 2)]).astype(np.uint16)[None, :].repeat(2, 0)
+    for qp in (18, 27, 36):
+        bs = ctx.encode(fr, w, h, 8, qp, gop=2, log2_ctb=log2_ctb, rows_per_slice=rows)
+        on, rec = O.encode(fr, w, h, 8, qp, gop=2, log2_ctb=log2_ctb, rows_per_slice=rows)
+        assert bs == on
+        dec, _, _, bd, chk, fail = ctx.decode(bs)
+        assert (bd, chk, fail) == (8, 2, 0) and np.array_equal(dec, rec)
