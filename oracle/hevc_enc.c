@@ -100,6 +100,14 @@ static void ce_terminate(cabac_enc* c, int bin) {
   } else ce_renorm(c);
 }
 
+/* bit accounting by syntax class (ORACLE_BIT_STATS=1, development only): position of the arithmetic coder in bits, up to a constant */
+#include <math.h>
+enum { BS_SAO, BS_CU_HDR, BS_TU_FLAGS, BS_RES_Y, BS_RES_C, BS_N };
+static double g_bs[2][BS_N]; static int g_bs_on = -1; static long g_cu_n[7], g_cu_mpm[7], g_cu_tusplit[7], g_cu_cbf0[7];
+static double ce_pos(const cabac_enc* c) { return 8.0 * (double)c->w.bb.n + c->w.nacc + c->outstanding - log2((double)c->range); }
+#define BS_BEGIN(e) double bs_p0_ = (g_bs_on > 0 && (e)->hm_pass != 1) ? ce_pos(&(e)->c) : 0
+#define BS_END(e, cls) do { if (g_bs_on > 0 && (e)->hm_pass != 1) g_bs[(e)->slice_type == SLICE_I ? 0 : 1][cls] += ce_pos(&(e)->c) - bs_p0_; } while (0)
+
 /* ================================================================================================ encoder state */
 typedef struct { uint32_t s; } rng;
 static uint32_t rnd(rng* r) { uint32_t x = r->s; x ^= x << 13; x ^= x >> 17; x ^= x << 5; r->s = x; return x; }
@@ -495,6 +503,22 @@ static int hm_tb_finish(enc* e, int c_idx, int log2, int intra_mode, int qp, int
   return cbf;
 }
 
+static int x_env(const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; }
+/* experimental quantiser: rounding offset (in 1/512 of a level) by the level below and the position class */
+static int quant_rd(const int16_t* coef, int16_t* lvl, int log2, int qp, int bd, int is_intra) {
+  static int init = 0, o[2][4];
+  if (!init) { const char* v = getenv("RBT_X_RQ"); int a[8] = {171, 171, 171, 171, 85, 85, 85, 85}; if (v) sscanf(v, "%d,%d,%d,%d,%d,%d,%d,%d", a, a + 1, a + 2, a + 3, a + 4, a + 5, a + 6, a + 7); for (int i = 0; i < 8; i++) o[i / 4][i % 4] = a[i]; init = 1; }
+  int N = 1 << log2, nz = 0, qbits = 14 + qp / 6 + (15 - bd - log2), sc = k_quant_scale[qp % 6];
+  for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) {
+    int i = y * N + x, a = iabs(coef[i]);
+    int64_t t = (int64_t)a * sc, lf = t >> qbits;
+    int cls = lf == 0 ? (x + y <= x_env("RBT_X_RQ_LOW", 2) ? 0 : 1) : (lf == 1 ? 2 : 3);
+    int64_t l = (t + ((int64_t)o[is_intra ? 0 : 1][cls] << (qbits - 9))) >> qbits;
+    if (l > 32767) l = 32767;
+    lvl[i] = (int16_t)(coef[i] < 0 ? -l : l); nz += l != 0;
+  }
+  return nz;
+}
 /* predicts (intra), derives levels (product: residual->T->Q; stress: random) and reconstructs one TB.
  * Returns cbf. Levels are left in e->lvl[c_idx] at the TB's offset inside the CU (stride 64). */
 static int recon_tb(enc* e, int c_idx, int x0, int y0, int log2, int intra_mode, int* ts_out) {
@@ -517,7 +541,7 @@ static int recon_tb(enc* e, int c_idx, int x0, int y0, int log2, int intra_mode,
     const uint16_t* sp = e->src->p[c_idx] + (size_t)y0 * pw + x0;
     for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) res[y * N + x] = (int16_t)((int)sp[(size_t)y * pw + x] - (int)p[(size_t)y * pw + x]);
     if (e->cu_tq_bypass) { memcpy(lq, res, sizeof(int16_t) * N * N); for (int i = 0; i < N * N; i++) cbf |= lq[i] != 0; }
-    else { hevc_fwd_transform(res, coef, log2, is_dst, bd); cbf = hevc_quant(coef, lq, log2, qp, bd, e->cu_pred_mode == MODE_INTRA) != 0; }
+    else { hevc_fwd_transform(res, coef, log2, is_dst, bd); cbf = (getenv("RBT_X_RQ") && !e->hm ? quant_rd : hevc_quant)(coef, lq, log2, qp, bd, e->cu_pred_mode == MODE_INTRA) != 0; }
     if ((e->hm || e->pps.transform_skip_enabled) && !e->cu_tq_bypass) { cbf = hm_tb_finish(e, c_idx, log2, intra_mode, qp, is_dst, res, lq, &ts); if (!e->in_trial && e->hm_pass != 1 && log2 == 2 && cbf) { e->hs.tb4++; e->hs.ts += ts; } }
     for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) lv[y * 64 + x] = lq[y * N + x];
   }
@@ -644,14 +668,19 @@ static void tt_write(enc* e, int depth, int pcb, int pcr) {
   }
   int part = 0;
   if (intra_split) part = ((nd->y - e->cu_y) >= (1 << (e->cu_log2 - 1)) ? 2 : 0) + ((nd->x - e->cu_x) >= (1 << (e->cu_log2 - 1)) ? 1 : 0);
-  if (nd->cbf_y)
+  if (nd->cbf_y) {
+    BS_BEGIN(e);
     write_residual(e, log2, 0, tb_scan_idx(e->cu_pred_mode, log2, 0, e->intra_luma[part]), e->lvl[0] + (nd->y - e->cu_y) * 64 + (nd->x - e->cu_x), 64, nd->ts[0]);
+    BS_END(e, BS_RES_Y);
+  }
   if (nd->chroma_here) {
     int l2c = log2 > 2 ? log2 - 1 : 2;
     int xo = ((log2 > 2 ? nd->x : nd->x - 4) - e->cu_x) >> 1, yo = ((log2 > 2 ? nd->y : nd->y - 4) - e->cu_y) >> 1;
     int sc = tb_scan_idx(e->cu_pred_mode, l2c, 1, e->intra_chroma);
+    BS_BEGIN(e);
     if (cbf_cb && nd->cbf_cb) write_residual(e, l2c, 1, sc, e->lvl[1] + yo * 64 + xo, 64, nd->ts[1]);
     if (cbf_cr && nd->cbf_cr) write_residual(e, l2c, 2, sc, e->lvl[2] + yo * 64 + xo, 64, nd->ts[2]);
+    BS_END(e, BS_RES_C);
   }
 }
 
@@ -816,9 +845,10 @@ static void encode_cu(enc* e, int x0, int y0, int log2, int depth, const cu_deci
   set_rect8((uint8_t*)m->qp, m->w4, x0, y0, N, N, (uint8_t)(int8_t)e->qp_y);
   set_rect8(m->done, m->w4, x0, y0, N, N, 1);
   /* ---- write phase ---- */
+  BS_BEGIN(e);
   if (e->pps.transquant_bypass_enabled) ce_bin(c, CTX_CU_TQ_BYPASS, e->cu_tq_bypass);
   if (e->sh.slice_type != SLICE_I) ce_bin(c, CTX_CU_SKIP + ctx_skip, e->cu_skip);
-  if (e->cu_skip) { pu_write(e, &e->pu[0], 1); return; }
+  if (e->cu_skip) { pu_write(e, &e->pu[0], 1); BS_END(e, BS_CU_HDR); return; }
   if (e->sh.slice_type != SLICE_I) ce_bin(c, CTX_PRED_MODE, e->cu_pred_mode == MODE_INTRA);
   int pm = d->part_mode;
   if (e->cu_pred_mode == MODE_INTRA) {
@@ -829,6 +859,7 @@ static void encode_cu(enc* e, int x0, int y0, int log2, int depth, const cu_deci
       prev[i] = 0; idx[i] = 0;
       for (int k = 0; k < 3; k++) if (mpm[i][k] == e->intra_luma[i]) { prev[i] = 1; idx[i] = k; }
       ce_bin(c, CTX_PREV_INTRA_LUMA, prev[i]);
+      if (g_bs_on > 0 && e->hm_pass != 1 && e->slice_type == SLICE_I) { g_cu_n[log2]++; g_cu_mpm[log2] += prev[i]; g_cu_tusplit[log2] += e->nodes[0].split; g_cu_cbf0[log2] += !e->nodes[0].split && !e->nodes[0].cbf_y; }
     }
     for (int i = 0; i < np; i++) {
       if (prev[i]) { ce_bypass(c, idx[i] > 0); if (idx[i] > 0) ce_bypass(c, idx[i] > 1); }
@@ -863,12 +894,15 @@ static void encode_cu(enc* e, int x0, int y0, int log2, int depth, const cu_deci
     for (int i = 0; i < e->n_pu; i++) pu_write(e, &e->pu[i], 0);
     if (!(pm == PART_2Nx2N && e->pu[0].merge)) ce_bin(c, CTX_RQT_ROOT_CBF, e->rqt_root_cbf);
   }
+  BS_END(e, BS_CU_HDR);
   if (e->rqt_root_cbf) {
+    BS_BEGIN(e);
     /* the write phase must see is_cu_qp_delta_coded as it was before this CU's recon phase */
     int coded_after = e->is_cu_qp_delta_coded || (qp_trial && any_cbf);
     if (qp_trial) e->is_cu_qp_delta_coded = 0;
     tt_write(e, 0, 0, 0);
     e->is_cu_qp_delta_coded = coded_after;
+    BS_END(e, BS_TU_FLAGS);   /* includes the residuals: subtracted when printed */
   }
 }
 
@@ -877,6 +911,29 @@ static void encode_cu(enc* e, int x0, int y0, int log2, int depth, const cu_deci
 #define AN_GOOD 2              /* average absolute prediction error (in sample units of the coded bit depth) below which a block is not subdivided further */
 #define AN_SKIPPED 0x0FFFFFFE   /* cost of a block that was not evaluated because its parent is good enough: never chosen by the split decision */
 static long e_evals_skipped, e_evals;
+/* sum of absolute 8x8 Hadamard coefficients of the residual src - pred over an S x S block (S >= 8), (sum + 4) >> 3 per tile: white noise costs about its SAD, a smooth residual much less */
+static int satd_block(const uint16_t* sp, int sw, const uint16_t* pred, int S) {
+  int tot = 0;
+  for (int ty = 0; ty < S; ty += 8) for (int tx = 0; tx < S; tx += 8) {
+    int d[64], t[64];
+    for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) d[y * 8 + x] = (int)sp[(size_t)(ty + y) * sw + tx + x] - (int)pred[(ty + y) * S + tx + x];
+    for (int y = 0; y < 8; y++) {      /* rows */
+      int* r = d + y * 8; int a[8];
+      for (int k = 0; k < 4; k++) { a[k] = r[k] + r[k + 4]; a[k + 4] = r[k] - r[k + 4]; }
+      int b[8] = {a[0] + a[2], a[1] + a[3], a[0] - a[2], a[1] - a[3], a[4] + a[6], a[5] + a[7], a[4] - a[6], a[5] - a[7]};
+      for (int k = 0; k < 4; k++) { t[y * 8 + 2 * k] = b[2 * k] + b[2 * k + 1]; t[y * 8 + 2 * k + 1] = b[2 * k] - b[2 * k + 1]; }
+    }
+    int sum = 0;
+    for (int x = 0; x < 8; x++) {      /* columns */
+      int a[8];
+      for (int k = 0; k < 4; k++) { a[k] = t[k * 8 + x] + t[(k + 4) * 8 + x]; a[k + 4] = t[k * 8 + x] - t[(k + 4) * 8 + x]; }
+      int b[8] = {a[0] + a[2], a[1] + a[3], a[0] - a[2], a[1] - a[3], a[4] + a[6], a[5] + a[7], a[4] - a[6], a[5] - a[7]};
+      for (int k = 0; k < 4; k++) sum += iabs(b[2 * k] + b[2 * k + 1]) + iabs(b[2 * k] - b[2 * k + 1]);
+    }
+    tot += (sum + 4) >> 3;
+  }
+  return tot;
+}
 static void analyse_ctb_intra(enc* e, int cx, int cy) {
   hevc_meta* m = e->m; const hevc_sps* sps = &e->sps;
   int ctb = 1 << sps->log2_ctb;
@@ -903,7 +960,7 @@ static void analyse_ctb_intra(enc* e, int cx, int cy) {
       /* a block whose parent already predicts to within AN_GOOD per sample on average is not looked at: the parent will not be split (its children cost "infinity") */
       if (si < 2 && 2 * S <= ctb) {
         int pc = e->an_cost[si + 1][(by / 2) * (nb / 2) + bx / 2];
-        if (pc <= (e->p.lossless ? 0 : AN_GOOD) * 4 * S * S || pc == AN_SKIPPED) { e->an_cost[si][bi] = AN_SKIPPED; e_evals_skipped++; set_rect8(m->done, m->w4, x0, y0, S, S, 1); continue; }
+        if (pc <= (e->p.lossless ? 0 : x_env("RBT_X_AN_GOOD", AN_GOOD * 4)) * S * S || pc == AN_SKIPPED) { e->an_cost[si][bi] = AN_SKIPPED; e_evals_skipped++; set_rect8(m->done, m->w4, x0, y0, S, S, 1); continue; }
       }
       int coarse = 0;
       /* transcoder: planar, DC and the modes the input stream coded at the block's four quarters (distinct ones, in that order; vertical and horizontal
@@ -935,8 +992,13 @@ static void analyse_ctb_intra(enc* e, int cx, int cy) {
         hevc_intra_pred_buf(&srcview, m, 0, x0, y0, 3 + si, mode, pred); e_evals++;
         int sad = 0;
         const uint16_t* sp = e->src->p[0] + (size_t)y0 * e->src->w + x0;
-        for (int y = 0; y < S; y++) for (int x = 0; x < S; x++) sad += iabs((int)sp[(size_t)y * e->src->w + x] - (int)pred[y * S + x]);
+        if (x_env("RBT_X_SATD", 0) == 1) sad = satd_block(sp, e->src->w, pred, S);
+        else for (int y = 0; y < S; y++) for (int x = 0; x < S; x++) sad += iabs((int)sp[(size_t)y * e->src->w + x] - (int)pred[y * S + x]);
         if (sad < e->an_cost[si][bi]) { e->an_cost[si][bi] = sad; e->an_mode[si][bi] = (uint8_t)mode; }
+      }
+      if (x_env("RBT_X_SATD", 0) == 2 && e->an_cost[si][bi] > 0) {   /* mode by SAD, block cost by SATD of that mode */
+        hevc_intra_pred_buf(&srcview, m, 0, x0, y0, 3 + si, e->an_mode[si][bi], pred);
+        e->an_cost[si][bi] = satd_block(e->src->p[0] + (size_t)y0 * e->src->w + x0, e->src->w, pred, S);
       }
       set_rect8(m->done, m->w4, x0, y0, S, S, 1);
     }
@@ -944,7 +1006,7 @@ static void analyse_ctb_intra(enc* e, int cx, int cy) {
   }
   /* bottom-up split decisions */
   int lam = k_lambda16[clip3(0, 75, e->slice_qp + 6 * (sps->bit_depth - 8))];
-  int pen = (lam * SPLIT_BITS) >> 4;
+  int pen = (lam * x_env("RBT_X_SPLIT_BITS", SPLIT_BITS)) >> 4;
   for (int si = 1; si < 3; si++) {
     int S = 8 << si; if (S > ctb) break;
     int nb = ctb / S, nbc = nb * 2;
@@ -1248,7 +1310,9 @@ static void encode_quadtree(enc* e, int x0, int y0, int log2, int depth, int cx,
   if (can_flag) {
     int cl = hevc_avail_cu(m, x0, y0, x0 - 1, y0) && m->cu_depth[meta_idx(m, x0 - 1, y0)] > depth;
     int ca = hevc_avail_cu(m, x0, y0, x0, y0 - 1) && m->cu_depth[meta_idx(m, x0, y0 - 1)] > depth;
+    BS_BEGIN(e);
     ce_bin(c, CTX_SPLIT_CU + cl + ca, split);
+    BS_END(e, BS_CU_HDR);
   }
   if (e->pps.cu_qp_delta_enabled && log2 >= sps->log2_ctb - e->pps.diff_cu_qp_delta_depth) start_quant_group(e, x0, y0);
   if (split) {
@@ -1280,6 +1344,25 @@ static void encode_quadtree(enc* e, int x0, int y0, int log2, int depth, int cx,
   } else if (e->sh.slice_type == SLICE_I || e->hm_force_intra) {
     int S = N, nb = (1 << sps->log2_ctb) / S;
     d.intra_luma[0] = e->an_mode[log2 - 3][((y0 - cy) / S) * nb + (x0 - cx) / S];
+    if (!e->hm && x_env("RBT_X_REFINE", 0)) {
+      /* closed-loop mode refinement: the analysis' mode, the three most probable modes, planar and DC predicted from the RECONSTRUCTED neighbours; SAD (or SATD) * 16 + lambda * mode bits */
+      int mpm[3], cand[6], nc = 0, lam = k_lambda16[clip3(0, 75, e->slice_qp + 6 * (sps->bit_depth - 8))];
+      hevc_intra_mpm(m, x0, y0, mpm);
+      int pre[6] = {d.intra_luma[0], mpm[0], mpm[1], mpm[2], 0, 1};
+      for (int i = 0; i < 6; i++) { int dup = 0; for (int t = 0; t < nc; t++) dup |= cand[t] == pre[i]; if (!dup) cand[nc++] = pre[i]; }
+      static uint16_t pred[32 * 32]; int best = 0x7FFFFFFF, bm = d.intra_luma[0];
+      const uint16_t* sp = e->src->p[0] + (size_t)y0 * e->src->w + x0;
+      for (int i = 0; i < nc; i++) {
+        hevc_intra_pred_buf(e->rec, m, 0, x0, y0, log2, cand[i], pred);
+        int sad = 0;
+        if (x_env("RBT_X_REFINE", 0) == 2) sad = satd_block(sp, e->src->w, pred, N);
+        else for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) sad += iabs((int)sp[(size_t)y * e->src->w + x] - (int)pred[y * N + x]);
+        int bits = cand[i] == mpm[0] ? 2 : (cand[i] == mpm[1] || cand[i] == mpm[2]) ? 3 : 6;
+        int c = sad * 16 + lam * bits;
+        if (c < best) { best = c; bm = cand[i]; }
+      }
+      d.intra_luma[0] = bm;
+    }
     if (e->hm) {
       d.intra_chroma_idx = e->hm_chroma[hsi][hbi];
       if (log2 == 3 && e->hm_nxn[hbi]) { d.part_mode = PART_NxN; for (int i = 0; i < 4; i++) d.intra_luma[i] = e->hm_nxn_mode[hbi][i]; }
@@ -1493,7 +1576,7 @@ static void encode_slices(enc* e, int is_i, int st_rps_idx, bytebuf* out) {
         hm_write_sao(e, rx, ry);
         hm_analyse_intra(e, rx * ctb, ry * ctb);
         if (!is_i) hm_inter_decide(e, rx * ctb, ry * ctb, s->log2_ctb, rx * ctb, ry * ctb);
-      } else { if (s->sao_enabled) hm_write_sao(e, rx, ry); if (is_i) analyse_ctb_intra(e, rx * ctb, ry * ctb); else analyse_ctb_inter(e, rx * ctb, ry * ctb); }
+      } else { if (s->sao_enabled) { BS_BEGIN(e); hm_write_sao(e, rx, ry); BS_END(e, BS_SAO); } if (is_i) analyse_ctb_intra(e, rx * ctb, ry * ctb); else analyse_ctb_inter(e, rx * ctb, ry * ctb); }
       encode_quadtree(e, rx * ctb, ry * ctb, s->log2_ctb, 0, rx * ctb, ry * ctb);
       if (p->entropy_coding_sync && rx == 1) memcpy(e->wpp_ctx, e->c.st, CTX_COUNT);
       ce_terminate(&e->c, a == end_addr - 1);
@@ -1579,6 +1662,7 @@ int oracle_hevc_encode(const oracle_enc_params* p, const hevc_frame* const* fram
   if (!p->stress_seed && p->gop > 1 && (p->width % 16 || p->height % 16)) { ENC_ERR("gop=2 needs a picture size that is a multiple of 16"); return -1; }
   enc* e = (enc*)calloc(1, sizeof(enc));
   e->p = *p; e->stress = p->stress_seed != 0; e->hm = !e->stress && p->hm_like; e->r.s = p->stress_seed ? p->stress_seed : 1;
+  if (g_bs_on < 0) g_bs_on = getenv("ORACLE_BIT_STATS") != NULL;
   build_scans(e); setup_stream(e);
   e->m = hevc_meta_alloc(p->width, p->height, e->sps.log2_ctb);
   /* frames freed here unless handed to the caller: keep a list */
@@ -1589,6 +1673,13 @@ int oracle_hevc_encode(const oracle_enc_params* p, const hevc_frame* const* fram
     fprintf(stderr, "[oracle hm] CUs intra %ld (NxN %ld, in P %ld) inter %ld (2 PUs %ld, AMP %ld) skip %ld | PUs merge %ld amvp %ld, vectors non-zero %ld fractional %ld | TU splits %ld | 4x4 TBs %ld, transform skip %ld | SAO band %ld edge %ld off %ld merged CTBs %ld\n",
             e->hs.cu_intra, e->hs.nxn, e->hs.intra_in_p, e->hs.cu_inter, e->hs.part2, e->hs.amp, e->hs.cu_skip, e->hs.merge, e->hs.amvp, e->hs.nonzero_mv, e->hs.frac_mv, e->hs.tu_split, e->hs.tb4, e->hs.ts,
             e->hs.sao_band, e->hs.sao_edge, e->hs.sao_off, e->hs.sao_merge);
+  if (g_bs_on > 0) for (int t = 0; t < 2; t++) {
+    fprintf(stderr, "[oracle bits %c] sao %.0f cu_hdr %.0f tu_flags %.0f res_y %.0f res_c %.0f (bytes)\n", t ? 'P' : 'I', g_bs[t][BS_SAO] / 8, g_bs[t][BS_CU_HDR] / 8,
+            (g_bs[t][BS_TU_FLAGS] - g_bs[t][BS_RES_Y] - g_bs[t][BS_RES_C]) / 8, g_bs[t][BS_RES_Y] / 8, g_bs[t][BS_RES_C] / 8);
+    memset(g_bs[t], 0, sizeof(g_bs[t]));
+    if (t) { for (int l = 3; l <= 6; l++) if (g_cu_n[l]) fprintf(stderr, "[oracle I CUs] %dx%d: %ld, mpm %ld, tu split %ld, luma cbf 0 %ld\n", 1 << l, 1 << l, g_cu_n[l], g_cu_mpm[l], g_cu_tusplit[l], g_cu_cbf0[l]);
+      memset(g_cu_n, 0, sizeof(g_cu_n)); memset(g_cu_mpm, 0, sizeof(g_cu_mpm)); memset(g_cu_tusplit, 0, sizeof(g_cu_tusplit)); memset(g_cu_cbf0, 0, sizeof(g_cu_cbf0)); }
+  }
   if (recon) memcpy(recon, owned, sizeof(void*) * (size_t)n); else for (int i = 0; i < n; i++) hevc_frame_free(owned[i]);
   for (int i = 0; i < e->n_dpb; i++) { free(e->dpbcol[i].mv); free(e->dpbcol[i].refpoc); }
   free(owned); free(e->c.w.bb.d); hevc_meta_free(e->m); free(e);

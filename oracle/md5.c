@@ -1,6 +1,6 @@
 /* ORACLE — test infrastructure only. MD5 (RFC 1321) for the HEVC decoded-picture-hash SEI the CTC streams carry
  * (cfg/hm/ctc-hm-geometry-ai.cfg:65). The reference vendors dependencies/libmd5/libmd5.c for the same purpose;
- * this is an independent restatement, pinned against python hashlib in tests/test_oracle_units.py. */
+ * this is an independent restatement, pinned against python hashlib in tests/test_oracle_codec.py::test_md5_against_hashlib. */
 #include <math.h>
 #include "hevc_common.h"
 

@@ -88,7 +88,7 @@ int oracle_reconstruct(const oracle_atlas* a, const oracle_patch* patches, int n
       for (int v1 = 0; v1 < res; v1++) for (int u1 = 0; u1 < res; u1++) {
         int x, y;
         if (!patch2canvas(p, res, u0 * res + u1, v0 * res + v1, W, H, &x, &y)) { free(om); free(b2p); return -2; }
-        nz += occ[(size_t)(y / prec) * ow + x / prec] != 0;
+        nz += occ[(size_t)(y / prec) * ow + x / prec] > a->threshold_lossy_om;   /* generateOccupancyMap has binarised the video frame in place by now (PCCCodec.cpp:1599-1600, call order PCCDecoder.cpp:363-376): :1754 reads 0 / 1 */
       }
       if (nz > 0) b2p[bi] = (uint32_t)pi + 1;
     }

@@ -59,7 +59,7 @@ RBT_DEV void pc_gen_point(const rbt_patch* p, int u, int v, int depth, int16_t* 
 // work item = (patch, block) pair `item` (items[] = patch index << 16 | block index inside the patch), lane = pixel inside the block
 RBT_DEV int pc_pixel_occupied_video(const RbtPccParams* P, const rbt_patch* p, const uint16_t* occ, int ub, int vb, int q) {   // :1748-1755
   int x, y; pc_patch2canvas(p, P->res, ub * P->res + q % P->res, vb * P->res + q / P->res, &x, &y);
-  return occ[(size_t)(y / P->prec) * P->ow + x / P->prec] != 0;
+  return occ[(size_t)(y / P->prec) * P->ow + x / P->prec] > P->threshold;   // the frame generateOccupancyMap binarised in place (PCCCodec.cpp:1599-1600), not the raw sample
 }
 // the points pixel q of block (ub, vb) of patch p contributes (0..2); pts / col may be null (count only)
 RBT_DEV int pc_pixel_points(const RbtPccParams* P, const rbt_patch* p, const uint16_t* occ, const uint16_t* d0, const uint16_t* d1, const uint16_t* t0, const uint16_t* t1,

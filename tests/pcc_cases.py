@@ -26,11 +26,18 @@ def random_atlas(R, seed, w=None, h=None):
                                1 if r.random() < 0.8 else 2, 1))
     occ_full = (r.random((h // prec, w // prec)) < 0.7)
     occ_full &= np.kron(used, np.ones((res // prec, res // prec), bool))
+    thr = 0
     if seed % 3 == 0: occ = occ_full.astype(np.uint16) * int(r.integers(1, 255))
     else: occ = occ_full.astype(np.uint16)
+    if seed % 8 == 7:
+        # lossy occupancy (thresholdLossyOM = 2): samples in 1..2 are NOT occupied and must not make a patch own a block (PCCCodec.cpp:1599-1600 binarises the frame
+        # before generateBlockToPatchFromOccupancyMapVideo :1754 reads it); some blocks hold nothing but such samples
+        thr = 2
+        low = np.kron(r.random((bh, bw)) < 0.4, np.ones((res // prec, res // prec), bool))
+        occ = np.where(occ_full, np.where(low, r.integers(1, 3, occ_full.shape), r.integers(3, 200, occ_full.shape)), 0).astype(np.uint16)
     d0 = r.integers(0, 1024, (h, w)).astype(np.uint16)
     d1 = np.clip(d0.astype(int) + r.integers(0, 12, (h, w)) * (r.random((h, w)) < 0.5), 0, 1023).astype(np.uint16)
     t0 = r.integers(0, 1024, w * h * 3 // 2).astype(np.uint16)
     t1 = r.integers(0, 1024, w * h * 3 // 2).astype(np.uint16)
-    atlas = R.AtlasParams(w, h, res, prec, 2, 1 if seed % 5 else 0, 1 if seed % 7 != 6 else 0, 0)
+    atlas = R.AtlasParams(w, h, res, prec, 2, 1 if seed % 5 else 0, 1 if seed % 7 != 6 else 0, thr)
     return atlas, patches, occ, d0, d1, 10, t0, t1, 10

@@ -48,6 +48,21 @@ def test_known_answer_single_patch(ctx):
     assert xyz.tolist() == want and np.all(yuv == 512)
 
 
+def test_lossy_occupancy_threshold_decides_block_ownership(ctx):
+    """thresholdLossyOM = 2: generateOccupancyMap binarises the occupancy frame in place (PCCCodec.cpp:1599-1600) BEFORE
+    generateBlockToPatchFromOccupancyMapVideo reads it (:1754), so a block whose samples are all in 1..2 is owned by no patch"""
+    R = rbt_lib.module()
+    atlas = R.AtlasParams(32, 32, 16, 1, 1, 1, 1, 2)
+    occ = np.zeros((32, 32), np.uint16)
+    occ[0:16, 0:16] = 2            # block (0, 0): only samples at the threshold
+    occ[16:32, 0:16] = 1; occ[20, 5] = 3    # block (0, 1): one sample above it
+    d0 = np.full((32, 32), 40, np.uint16)
+    p = R.Patch(0, 0, 1, 2, 0, 0, 0, 2, 0, 1, 0, 0, 1, 1)
+    for rec in (ctx.reconstruct, O.reconstruct):
+        xyz, yuv, om, b2p = rec(atlas, [p], occ, d0, d0, 10)
+        assert b2p.tolist() == [[0, 0], [1, 0]] and om.sum() == 1 and xyz.tolist() == [[5, 20, 10]]
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_d1_matches_oracle(ctx, seed):
     r = np.random.default_rng(seed)
