@@ -144,6 +144,7 @@ typedef struct {
   /* HM-like mode (hm_like) */
   int hm, hm_pass, in_trial, hm_force_intra;
   const uint8_t* hints;        /* intra mode hints of the current picture (oracle_enc_params.hint_modes), NULL = none */
+  int e1_satd, e1_refine, e1_rq;   /* RBT-E1 decision tools (product mode): SATD block costs, closed-loop mode choice, level-dependent rounding */
   int tu_rd;                   /* transform trees are decided by coding both ways (hm_decide_tu_split): the HM-like mode (two levels) and RBT-E1 intra CUs (one level) */
   struct { long ts, tb4, nxn, cu_intra, cu_inter, cu_skip, tu_split, part2, amp, merge, amvp, frac_mv, nonzero_mv, sao_band, sao_edge, sao_merge, sao_off, intra_in_p; } hs;   /* tool usage (ORACLE_HM_STATS=1 prints it) */
   struct { uint8_t split, intra, part; int16_t mv[2][2]; } hn[4][64];   /* P pictures: decision per CU node [size idx][block] */
@@ -503,17 +504,22 @@ static int hm_tb_finish(enc* e, int c_idx, int log2, int intra_mode, int qp, int
   return cbf;
 }
 
-static int x_env(const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; }
-/* experimental quantiser: rounding offset (in 1/512 of a level) by the level below and the position class */
-static int quant_rd(const int16_t* coef, int16_t* lvl, int log2, int qp, int bd, int is_intra) {
-  static int init = 0, o[2][4];
-  if (!init) { const char* v = getenv("RBT_X_RQ"); int a[8] = {171, 171, 171, 171, 85, 85, 85, 85}; if (v) sscanf(v, "%d,%d,%d,%d,%d,%d,%d,%d", a, a + 1, a + 2, a + 3, a + 4, a + 5, a + 6, a + 7); for (int i = 0; i < 8; i++) o[i / 4][i % 4] = a[i]; init = 1; }
+/* development switches, read by the library the same way (ablation: what each decision tool does to bytes and quality) */
+static int e1_env(const char* n) { const char* v = getenv(n); return !v || atoi(v) != 0; }
+static int e1_satd_on(void) { return e1_env("RBT_ENC_SATD"); }       /* block costs of the intra analysis by SATD instead of SAD */
+static int e1_refine_on(void) { return e1_env("RBT_ENC_REFINE"); }   /* closed-loop choice of the intra mode among the analysis' mode, the most probable modes, planar and DC */
+static int e1_rq_on(void) { return e1_env("RBT_ENC_RQ"); }           /* rounding offset of the intra quantiser by level and position instead of 171 / 512 */
+/* RBT-E1 quantiser of intra blocks: the dead zone follows what the next level costs. A level that would be the block's only reason to code a position (floor
+ * level 0) needs more than 0.63 of a step near the DC corner (x + y <= 2: such positions are usually significant anyway) and more than 0.69 elsewhere;
+ * going from 1 to 2 needs 0.61, higher levels 0.55 (their extra bits are few, the distortion saved is not). Offsets in 1/512 of a level: 190, 160, 200,
+ * 230; the fixed 171 / 512 (HM's intra default) stays for inter blocks' 85 / 512 and for transform-skip blocks, which have no frequency positions. */
+static int e1_quant_intra(const int16_t* coef, int16_t* lvl, int log2, int qp, int bd) {
   int N = 1 << log2, nz = 0, qbits = 14 + qp / 6 + (15 - bd - log2), sc = k_quant_scale[qp % 6];
   for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) {
     int i = y * N + x, a = iabs(coef[i]);
     int64_t t = (int64_t)a * sc, lf = t >> qbits;
-    int cls = lf == 0 ? (x + y <= x_env("RBT_X_RQ_LOW", 2) ? 0 : 1) : (lf == 1 ? 2 : 3);
-    int64_t l = (t + ((int64_t)o[is_intra ? 0 : 1][cls] << (qbits - 9))) >> qbits;
+    int off = lf == 0 ? (x + y <= 2 ? 190 : 160) : (lf == 1 ? 200 : 230);
+    int64_t l = (t + ((int64_t)off << (qbits - 9))) >> qbits;
     if (l > 32767) l = 32767;
     lvl[i] = (int16_t)(coef[i] < 0 ? -l : l); nz += l != 0;
   }
@@ -541,7 +547,7 @@ static int recon_tb(enc* e, int c_idx, int x0, int y0, int log2, int intra_mode,
     const uint16_t* sp = e->src->p[c_idx] + (size_t)y0 * pw + x0;
     for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) res[y * N + x] = (int16_t)((int)sp[(size_t)y * pw + x] - (int)p[(size_t)y * pw + x]);
     if (e->cu_tq_bypass) { memcpy(lq, res, sizeof(int16_t) * N * N); for (int i = 0; i < N * N; i++) cbf |= lq[i] != 0; }
-    else { hevc_fwd_transform(res, coef, log2, is_dst, bd); cbf = (getenv("RBT_X_RQ") && !e->hm ? quant_rd : hevc_quant)(coef, lq, log2, qp, bd, e->cu_pred_mode == MODE_INTRA) != 0; }
+    else { hevc_fwd_transform(res, coef, log2, is_dst, bd); cbf = (e->e1_rq && e->cu_pred_mode == MODE_INTRA ? e1_quant_intra(coef, lq, log2, qp, bd) : hevc_quant(coef, lq, log2, qp, bd, e->cu_pred_mode == MODE_INTRA)) != 0; }
     if ((e->hm || e->pps.transform_skip_enabled) && !e->cu_tq_bypass) { cbf = hm_tb_finish(e, c_idx, log2, intra_mode, qp, is_dst, res, lq, &ts); if (!e->in_trial && e->hm_pass != 1 && log2 == 2 && cbf) { e->hs.tb4++; e->hs.ts += ts; } }
     for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) lv[y * 64 + x] = lq[y * N + x];
   }
@@ -911,7 +917,9 @@ static void encode_cu(enc* e, int x0, int y0, int log2, int depth, const cu_deci
 #define AN_GOOD 2              /* average absolute prediction error (in sample units of the coded bit depth) below which a block is not subdivided further */
 #define AN_SKIPPED 0x0FFFFFFE   /* cost of a block that was not evaluated because its parent is good enough: never chosen by the split decision */
 static long e_evals_skipped, e_evals;
-/* sum of absolute 8x8 Hadamard coefficients of the residual src - pred over an S x S block (S >= 8), (sum + 4) >> 3 per tile: white noise costs about its SAD, a smooth residual much less */
+/* SATD of the residual src - pred of an S x S block (S = 8, 16, 32): sum of the absolute 8x8 Hadamard coefficients of its 8x8 tiles, (sum + 4) >> 3 - white
+ * noise costs about its SAD, a smooth residual much less. (Any butterfly pairing that is linear in the index bits gives the same SUM of magnitudes: the GPU pairs
+ * lanes i and 7 - i where this loop pairs i and i + 4.) */
 static int satd_block(const uint16_t* sp, int sw, const uint16_t* pred, int S) {
   int tot = 0;
   for (int ty = 0; ty < S; ty += 8) for (int tx = 0; tx < S; tx += 8) {
@@ -930,9 +938,9 @@ static int satd_block(const uint16_t* sp, int sw, const uint16_t* pred, int S) {
       int b[8] = {a[0] + a[2], a[1] + a[3], a[0] - a[2], a[1] - a[3], a[4] + a[6], a[5] + a[7], a[4] - a[6], a[5] - a[7]};
       for (int k = 0; k < 4; k++) sum += iabs(b[2 * k] + b[2 * k + 1]) + iabs(b[2 * k] - b[2 * k + 1]);
     }
-    tot += (sum + 4) >> 3;
+    tot += sum;
   }
-  return tot;
+  return (tot + 4) >> 3;
 }
 static void analyse_ctb_intra(enc* e, int cx, int cy) {
   hevc_meta* m = e->m; const hevc_sps* sps = &e->sps;
@@ -960,7 +968,7 @@ static void analyse_ctb_intra(enc* e, int cx, int cy) {
       /* a block whose parent already predicts to within AN_GOOD per sample on average is not looked at: the parent will not be split (its children cost "infinity") */
       if (si < 2 && 2 * S <= ctb) {
         int pc = e->an_cost[si + 1][(by / 2) * (nb / 2) + bx / 2];
-        if (pc <= (e->p.lossless ? 0 : x_env("RBT_X_AN_GOOD", AN_GOOD * 4)) * S * S || pc == AN_SKIPPED) { e->an_cost[si][bi] = AN_SKIPPED; e_evals_skipped++; set_rect8(m->done, m->w4, x0, y0, S, S, 1); continue; }
+        if (pc <= (e->p.lossless ? 0 : AN_GOOD) * 4 * S * S || pc == AN_SKIPPED) { e->an_cost[si][bi] = AN_SKIPPED; e_evals_skipped++; set_rect8(m->done, m->w4, x0, y0, S, S, 1); continue; }
       }
       int coarse = 0;
       /* transcoder: planar, DC and the modes the input stream coded at the block's four quarters (distinct ones, in that order; vertical and horizontal
@@ -992,11 +1000,10 @@ static void analyse_ctb_intra(enc* e, int cx, int cy) {
         hevc_intra_pred_buf(&srcview, m, 0, x0, y0, 3 + si, mode, pred); e_evals++;
         int sad = 0;
         const uint16_t* sp = e->src->p[0] + (size_t)y0 * e->src->w + x0;
-        if (x_env("RBT_X_SATD", 0) == 1) sad = satd_block(sp, e->src->w, pred, S);
-        else for (int y = 0; y < S; y++) for (int x = 0; x < S; x++) sad += iabs((int)sp[(size_t)y * e->src->w + x] - (int)pred[y * S + x]);
+        for (int y = 0; y < S; y++) for (int x = 0; x < S; x++) sad += iabs((int)sp[(size_t)y * e->src->w + x] - (int)pred[y * S + x]);
         if (sad < e->an_cost[si][bi]) { e->an_cost[si][bi] = sad; e->an_mode[si][bi] = (uint8_t)mode; }
       }
-      if (x_env("RBT_X_SATD", 0) == 2 && e->an_cost[si][bi] > 0) {   /* mode by SAD, block cost by SATD of that mode */
+      if (e->e1_satd && e->an_cost[si][bi] > 0) {   /* the mode by SAD, the block's cost (what the split decisions compare) by the SATD of that mode: a residual a transform codes in a few levels is cheap */
         hevc_intra_pred_buf(&srcview, m, 0, x0, y0, 3 + si, e->an_mode[si][bi], pred);
         e->an_cost[si][bi] = satd_block(e->src->p[0] + (size_t)y0 * e->src->w + x0, e->src->w, pred, S);
       }
@@ -1006,7 +1013,7 @@ static void analyse_ctb_intra(enc* e, int cx, int cy) {
   }
   /* bottom-up split decisions */
   int lam = k_lambda16[clip3(0, 75, e->slice_qp + 6 * (sps->bit_depth - 8))];
-  int pen = (lam * x_env("RBT_X_SPLIT_BITS", SPLIT_BITS)) >> 4;
+  int pen = (lam * SPLIT_BITS) >> 4;
   for (int si = 1; si < 3; si++) {
     int S = 8 << si; if (S > ctb) break;
     int nb = ctb / S, nbc = nb * 2;
@@ -1278,6 +1285,24 @@ static void hm_write_sao(enc* e, int rx, int ry) {
   }
 }
 
+/* RBT-E1, closed-loop choice of a CU's luma intra mode: the analysis' mode (chosen open loop, from source neighbours), the three most probable modes
+ * (8.4.2: known here, the neighbouring CUs are coded), planar and DC - distinct ones, in that order - predicted from the RECONSTRUCTED neighbours;
+ * cost = 16 * SATD + lambda * bits, bits = 2 for the first most probable mode, 3 for the other two, 6 for any other mode; ties keep the earlier candidate */
+static int e1_refine_mode(enc* e, int x0, int y0, int log2, int an_mode) {
+  hevc_meta* m = e->m; int N = 1 << log2, mpm[3], cand[6], nc = 0, lam = k_lambda16[clip3(0, 75, e->slice_qp + 6 * (e->sps.bit_depth - 8))];
+  hevc_intra_mpm(m, x0, y0, mpm);
+  int pre[6] = {an_mode, mpm[0], mpm[1], mpm[2], 0, 1};
+  for (int i = 0; i < 6; i++) { int dup = 0; for (int t = 0; t < nc; t++) dup |= cand[t] == pre[i]; if (!dup) cand[nc++] = pre[i]; }
+  static uint16_t pred[32 * 32]; int best = 0x7FFFFFFF, bm = an_mode;
+  const uint16_t* sp = e->src->p[0] + (size_t)y0 * e->src->w + x0;
+  for (int i = 0; i < nc; i++) {
+    hevc_intra_pred_buf(e->rec, m, 0, x0, y0, log2, cand[i], pred);
+    int c = satd_block(sp, e->src->w, pred, N) * 16 + lam * (cand[i] == mpm[0] ? 2 : (cand[i] == mpm[1] || cand[i] == mpm[2]) ? 3 : 6);
+    if (c < best) { best = c; bm = cand[i]; }
+  }
+  return bm;
+}
+
 /* ================================================================================================ quadtree */
 static void encode_quadtree(enc* e, int x0, int y0, int log2, int depth, int cx, int cy);
 
@@ -1344,25 +1369,7 @@ static void encode_quadtree(enc* e, int x0, int y0, int log2, int depth, int cx,
   } else if (e->sh.slice_type == SLICE_I || e->hm_force_intra) {
     int S = N, nb = (1 << sps->log2_ctb) / S;
     d.intra_luma[0] = e->an_mode[log2 - 3][((y0 - cy) / S) * nb + (x0 - cx) / S];
-    if (!e->hm && x_env("RBT_X_REFINE", 0)) {
-      /* closed-loop mode refinement: the analysis' mode, the three most probable modes, planar and DC predicted from the RECONSTRUCTED neighbours; SAD (or SATD) * 16 + lambda * mode bits */
-      int mpm[3], cand[6], nc = 0, lam = k_lambda16[clip3(0, 75, e->slice_qp + 6 * (sps->bit_depth - 8))];
-      hevc_intra_mpm(m, x0, y0, mpm);
-      int pre[6] = {d.intra_luma[0], mpm[0], mpm[1], mpm[2], 0, 1};
-      for (int i = 0; i < 6; i++) { int dup = 0; for (int t = 0; t < nc; t++) dup |= cand[t] == pre[i]; if (!dup) cand[nc++] = pre[i]; }
-      static uint16_t pred[32 * 32]; int best = 0x7FFFFFFF, bm = d.intra_luma[0];
-      const uint16_t* sp = e->src->p[0] + (size_t)y0 * e->src->w + x0;
-      for (int i = 0; i < nc; i++) {
-        hevc_intra_pred_buf(e->rec, m, 0, x0, y0, log2, cand[i], pred);
-        int sad = 0;
-        if (x_env("RBT_X_REFINE", 0) == 2) sad = satd_block(sp, e->src->w, pred, N);
-        else for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) sad += iabs((int)sp[(size_t)y * e->src->w + x] - (int)pred[y * N + x]);
-        int bits = cand[i] == mpm[0] ? 2 : (cand[i] == mpm[1] || cand[i] == mpm[2]) ? 3 : 6;
-        int c = sad * 16 + lam * bits;
-        if (c < best) { best = c; bm = cand[i]; }
-      }
-      d.intra_luma[0] = bm;
-    }
+    if (e->e1_refine) d.intra_luma[0] = e1_refine_mode(e, x0, y0, log2, d.intra_luma[0]);
     if (e->hm) {
       d.intra_chroma_idx = e->hm_chroma[hsi][hbi];
       if (log2 == 3 && e->hm_nxn[hbi]) { d.part_mode = PART_NxN; for (int i = 0; i < 4; i++) d.intra_luma[i] = e->hm_nxn_mode[hbi][i]; }
@@ -1468,6 +1475,7 @@ static void setup_stream(enc* e) {
   if (q->lossless) { p->transquant_bypass_enabled = 1; p->deblocking_control_present = 1; p->pps_deblocking_disabled = 1; p->loop_filter_across_slices = 0; }
   if (!e->stress && !e->hm && !q->lossless && e1_sao_on()) s->sao_enabled = 1;
   e->tu_rd = e->hm;
+  if (!e->stress && !e->hm) { e->e1_satd = e1_satd_on(); e->e1_refine = e1_refine_on(); e->e1_rq = !q->lossless && e1_rq_on(); }
   if (!e->stress && !e->hm && !q->lossless) { s->max_th_depth_intra = 1; e->tu_rd = 1; p->transform_skip_enabled = e1_ts_on(); }   /* RBT-E1: an intra CU is one transform unit or four, whichever codes its luma cheaper */
   if (!e->stress && !e->hm && q->ctb_rows_per_slice < 0) { p->entropy_coding_sync = 1; p->dependent_slice_segments_enabled = q->ctb_rows_per_slice == -1; }   /* wavefront rows, one dependent slice segment each */
   if (e->hm) {   /* cfg/hm/ctc-hm-geometry-ai.cfg:10-16,47,68,69 + HM defaults (SignHideFlag, TMVPMode, MaxNumMergeCand) */

@@ -58,6 +58,34 @@ RBT_DEV int en_wave_sum(int v, RBT_LDS_AS RbtEncLds* l) {
   return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
 #endif
 }
+// SATD building block (oracle/hevc_enc.c satd_block): absolute 8x8 Hadamard coefficients of one 8x8 tile of residuals, lane p = sample (p & 7, p >> 3).
+// Six butterfly stages over the lane index bits without touching LDS: the mirror inside 8 lanes (pairs i and 7 - i instead of i and i + 4: applied to the
+// samples, a pairing that is linear in the index bits only permutes the coefficients, and only the SUM of magnitudes is used; it has to come first), quad
+// swaps, the rotation by 8 inside a row of 16, a swizzle across 16 and a permute across 32. EN_HAD8X8_ACC adds the tile's magnitudes to an accumulator that en_wave_sum reduces at the end.
+#ifdef RBT_HOSTEMU
+static inline int en_had8x8_sum_host(const int* r) {
+  int t[64], sum = 0;
+  for (int y = 0; y < 8; y++) for (int k = 0; k < 8; k++) { int s = 0; for (int x = 0; x < 8; x++) s += (__builtin_popcount(k & x) & 1) ? -r[y * 8 + x] : r[y * 8 + x]; t[y * 8 + k] = s; }
+  for (int k = 0; k < 8; k++) for (int x = 0; x < 8; x++) { int s = 0; for (int y = 0; y < 8; y++) s += (__builtin_popcount(k & y) & 1) ? -t[y * 8 + x] : t[y * 8 + x]; sum += s < 0 ? -s : s; }
+  return sum;
+}
+#define EN_HAD8X8_ACC(vr, acc) (acc) += en_had8x8_sum_host(vr)
+#else
+RBT_DEV int en_had_stage(int v, int partner, int upper) { return upper ? partner - v : partner + v; }
+RBT_DEV int en_had8x8_abs(int v) {
+  const int lane = (int)threadIdx.x & 63;
+  v = en_had_stage(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false), lane & 4);    // row_half_mirror: FIRST, while the lane bits still index samples
+  v = en_had_stage(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false), lane & 1);     // quad_perm:[1,0,3,2]
+  v = en_had_stage(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false), lane & 2);     // quad_perm:[2,3,0,1]
+  v = en_had_stage(v, __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false), lane & 8);    // row_ror:8
+  v = en_had_stage(v, __builtin_amdgcn_ds_swizzle(v, 0x401F), lane & 16);                      // lane ^ 16 (bit mode: and 0x1F, or 0, xor 0x10)
+  v = en_had_stage(v, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, v), lane & 32);
+  return v < 0 ? -v : v;
+}
+#define EN_HAD8X8_ACC(vr, acc) (acc) += en_had8x8_abs(vr)
+#endif
+// rounding offset of the intra quantiser in 1/512 of a level (oracle/hevc_enc.c e1_quant_intra): by the level below and, for a first level, the position
+RBT_DEV int en_rq_offset(int lf_is0, int lf_is1, int xy_sum) { return lf_is0 ? (xy_sum <= 2 ? 190 : 160) : (lf_is1 ? 200 : 230); }
 RBT_DEV int en_chroma_qp(const RbtFrame* f, const RbtSlice* sl, int c_idx, int qp_y) {
   int off = c_idx == 1 ? f->cfg.cb_qp_offset + sl->cb_qp_offset : f->cfg.cr_qp_offset + sl->cr_qp_offset;
   int bdo = 6 * (f->cfg.bit_depth - 8);
@@ -98,7 +126,7 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
   nbq.above_left = rx > 0 && ry > 0 && f->ctb_slice[ctb_addr - g->w_ctb - 1] == my_slice;
   nbq.above_right = ry > 0 && rx + 1 < g->w_ctb && f->ctb_slice[ctb_addr - g->w_ctb + 1] == my_slice;
   const uint16_t* srcp = f->src[0];
-  const int hints = f->hint_dm != nullptr, hint_w4 = f->hint_w4, hint_h4 = f->hint_h4;
+  const int hints = f->hint_dm != nullptr, hint_w4 = f->hint_w4, hint_h4 = f->hint_h4, satd_on = f->enc_tools & RBT_ET_SATD;
   // CTBs larger than 32 are analysed as independent 32x32 quadrants (a 64x64 intra CU is always split)
   int nq = ctb > 32 ? 2 : 1, qs = ctb > 32 ? 32 : ctb;
   for (int q = 0; q < nq * nq; q++) {
@@ -181,6 +209,20 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
             int sad = en_wave_sum(part, (RBT_LDS_AS RbtEncLds*)0);
             if (sad < best) { best = sad; bmode = mode; }
             RBT_SYNC_LDS();                                     // rl->ref is rebuilt by the next mode
+          }
+          if (satd_on && best > 0) {
+            // the mode by SAD, the block's cost (what the split decisions compare) by the SATD of that mode (oracle/hevc_enc.c analyse_ctb_intra, satd_block)
+            RBT_LDS_AS int32_t* fin = rc_intra_filter_needed(0, lg, bmode) ? rl->nbf : rl->nb;
+            RcIntraCtx qc; rc_intra_setup(g, 0, lg, bmode, fin, rl->ref, &qc);
+            int acc = 0; const int tw = S >> 3;
+            for (int tix = 0; tix < tw * tw; tix++) {
+              const int tx = (tix % tw) * 8, ty = (tix / tw) * 8;
+              RBT_VEC(int, v_r);
+              RBT_VFOR(p, 64) { const int x = tx + (p & 7), y = ty + (p >> 3); RBT_V(v_r, p) = (int)l->src[(by0 + y + 1) * 66 + bx0 + x + 1] - rc_intra_sample(&qc, fin, rl->ref, x, y); }
+              EN_HAD8X8_ACC(v_r, acc);
+            }
+            best = (en_wave_sum(acc, (RBT_LDS_AS RbtEncLds*)0) + 4) >> 3;
+            RBT_SYNC_LDS();
           }
         }
     if (RBT_LANE0) { l->cost[si][b] = best; l->mode[si][b] = (uint8_t)bmode; }
@@ -351,7 +393,8 @@ template <int TL2> struct RbtEncTileT {
   uint16_t c[2][(1 << (TL2 - 1)) * TS_C], top_c[2][(1 << TL2) + 2];
   uint8_t uav[((1 << (TL2 - 2)) + 1) * RC_US];
   uint16_t sb[32 * 32 + 2 * 16 * 16];                        // source samples of the current CU: Y, Cb, Cr
-  uint8_t cu_l2[64], cu_md[64];                              // cu_log2 / cu_mode of the CTB's 8x8 units (analysis result)
+  uint8_t cu_l2[64], cu_md[64];                              // cu_log2 / cu_mode of the CTB's 8x8 units (analysis result; cu_md: the closed-loop choice once a CU is coded)
+  uint8_t left_md[16];                                       // luma modes of the 8x8 units in the last column of the CTB to the left ([8] = that CTB is available, 6.4.1)
   // one TU or four (en_intra_cu_luma): levels and reconstruction of the CU's luma coded as ONE transform block, kept while it is coded as four;
   // levels of the current quarter; source samples of the current quarter (luma, or Cb at 0 and Cr at 256)
   int16_t lv0[32 * 32]; uint16_t rec0[32 * 32]; int16_t lv1[16 * 16]; uint16_t ss[512];
@@ -402,10 +445,12 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
   } else {
     en_fwd_transform(log2, c_idx == 0 && log2 == 2, bd, r);
     const int qbits = 14 + qp / 6 + (15 - bd - log2), sc = en_quant_scale(qp % 6); int part = 0;
-    const long long add = (long long)171 << (qbits - 9);
+    const int rq = f->enc_tools & RBT_ET_RQ;
     RBT_PAR_FOR(i, N * N) {
       const int cv = r->res[i], a = rbt_abs(cv);
-      long long qv = ((long long)a * sc + add) >> qbits;
+      const long long tq = (long long)a * sc; const int lf = (int)(tq >> qbits);
+      const int off = rq ? en_rq_offset(lf == 0, lf == 1, (i & (N - 1)) + (i >> log2)) : 171;      // oracle/hevc_enc.c e1_quant_intra
+      long long qv = (tq + ((long long)off << (qbits - 9))) >> qbits;
       if (qv > 32767) qv = 32767;
       lvl[i] = (int16_t)(cv < 0 ? -qv : qv);
       part += qv != 0;
@@ -470,6 +515,53 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
   }
   RBT_SYNC_LDS();
   return nz != 0;
+}
+// Closed-loop choice of a CU's luma intra mode (oracle/hevc_enc.c e1_refine_mode): the analysis' mode (chosen open loop, from source neighbours), the three
+// most probable modes (8.4.2: ca / cb = candIntraPredModeA / B, the modes of the coded CUs to the left and above, DC where there is none in reach), planar
+// and DC - distinct ones, in that order - predicted from the RECONSTRUCTED neighbours in the tile; cost = 16 * SATD + lambda * bits (2 for the first most
+// probable mode, 3 for the other two, 6 otherwise), ties keep the earlier candidate. src: the CU's source samples, row stride N.
+template <int TL2> RBT_DEV int en_refine_mode(const RbtStreamCfg* g, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int x0, int y0, int lg, int an_mode, int ca, int cb, int lam16, const RBT_LDS_AS uint16_t* src) {
+  RBT_LDS_AS RbtEncIntraScratch* r = &L->rc; RBT_LDS_AS RbtEncTileT<TL2>* t = &L->t;
+  RBT_LDS_AS int32_t* const r_nbf = (RBT_LDS_AS int32_t*)r->tmp; RBT_LDS_AS int32_t* const r_ref = r_nbf + 132;
+  const int N = 1 << lg, bd = g->bit_depth, n4 = (1 << g->log2_ctb) >> 2, S = RbtEncTileT<TL2>::TS_Y;
+  int m0, m1, m2;
+  if (ca == cb) { if (ca < 2) { m0 = 0; m1 = 1; m2 = 26; } else { m0 = ca; m1 = 2 + ((ca + 29) & 31); m2 = 2 + ((ca - 1) & 31); } }
+  else { m0 = ca; m1 = cb; m2 = (ca != 0 && cb != 0) ? 0 : ((ca != 1 && cb != 1) ? 1 : 26); }
+  uint64_t cand = 0; int nc = 0;
+  { const int pre[6] = {an_mode, m0, m1, m2, 0, 1};
+#pragma unroll
+    for (int i = 0; i < 6; i++) { int dup = 0; for (int k = 0; k < nc; k++) dup |= (int)((cand >> (6 * k)) & 63) == pre[i]; if (!dup) { cand |= (uint64_t)pre[i] << (6 * nc); nc++; } } }
+  // reference samples from the reconstruction (as en_tile_intra_tb gathers them) and their smoothed copy, once for all candidates
+  const int tot = 4 * N + 1;
+  uint64_t b0, b1 = 0; int b2 = 0;
+  RBT_VBALLOT(b0, p, rbt_min(tot, 64), rc_nb_av(t->uav, p, x0, y0, N, 0, n4));
+  if (tot > 64) { RBT_VBALLOT(b1, p, rbt_min(tot - 64, 64), rc_nb_av(t->uav, 64 + p, x0, y0, N, 0, n4)); }
+  if (tot > 128) b2 = rc_nb_av(t->uav, 128, x0, y0, N, 0, n4);
+  const int first = b0 ? __builtin_ctzll(b0) : (b1 ? 64 + __builtin_ctzll(b1) : (b2 ? 128 : -1));
+  RBT_PAR_FOR(i, tot) {
+    int v = 1 << (bd - 1);
+    if (first >= 0) { int j = rc_last_avail(i, b0, b1, b2); if (j < 0) j = first; int xn, yn; rc_nb_xy(j, x0, y0, N, &xn, &yn); v = yn < 0 ? t->top_y[xn + 1] : t->y[yn * S + xn + 1]; }
+    r->nb[i] = v;
+  }
+  RBT_SYNC_LDS();
+  rc_intra_filter_apply(g, lg, r->nb, r_nbf);
+  int best = 0x7FFFFFFF, bm = an_mode; const int tw = N >> 3;
+  for (int k = 0; k < nc; k++) {
+    const int mode = (int)((cand >> (6 * k)) & 63);
+    RBT_LDS_AS int32_t* fin = rc_intra_filter_needed(0, lg, mode) ? r_nbf : r->nb;
+    RcIntraCtx q; rc_intra_setup(g, 0, lg, mode, fin, r_ref, &q);
+    int acc = 0;
+    for (int tix = 0; tix < tw * tw; tix++) {
+      const int tx = (tix % tw) * 8, ty = (tix / tw) * 8;
+      RBT_VEC(int, v_r);
+      RBT_VFOR(p, 64) { const int x = tx + (p & 7), y = ty + (p >> 3); RBT_V(v_r, p) = (int)src[y * N + x] - rc_intra_sample(&q, fin, r_ref, x, y); }
+      EN_HAD8X8_ACC(v_r, acc);
+    }
+    const int c = ((en_wave_sum(acc, (RBT_LDS_AS RbtEncLds*)0) + 4) >> 3) * 16 + lam16 * (mode == m0 ? 2 : (mode == m1 || mode == m2) ? 3 : 6);
+    if (c < best) { best = c; bm = mode; }
+    RBT_SYNC_LDS();                                     // r_ref is rebuilt by the next candidate
+  }
+  return bm;
 }
 // Luma of one intra CU of a stream with max_transform_hierarchy_depth_intra = 1 (RBT-E1, not lossless): coded as one transform block, then as four
 // (each quarter predicted from the reconstruction so far, quarters before it included) unless one block already codes it to within lambda^2 / 4 per
@@ -565,10 +657,13 @@ template <int TL2> RBT_DEV int en_tile_intra_tb_cpair(const RbtStreamCfg* g, Rbt
   } else {
     if (log2 == 2) en_fwd_transform_pair_n<2>(bd, r); else if (log2 == 3) en_fwd_transform_pair_n<3>(bd, r); else en_fwd_transform_pair_n<4>(bd, r);
     const int qb_cb = 14 + qp_cb / 6 + (15 - bd - log2), qb_cr = 14 + qp_cr / 6 + (15 - bd - log2), sc_cb = en_quant_scale(qp_cb % 6), sc_cr = en_quant_scale(qp_cr % 6);
+    const int rq = f->enc_tools & RBT_ET_RQ;
     RBT_PAR_FOR(i, 2 * NN) {
       const int b = i >= NN, j = i - b * NN, qbits = b ? qb_cr : qb_cb;
       const int cv = r->res[b * 256 + j], a = rbt_abs(cv);
-      long long qv = ((long long)a * (b ? sc_cr : sc_cb) + ((long long)171 << (qbits - 9))) >> qbits;
+      const long long tq = (long long)a * (b ? sc_cr : sc_cb); const int lf = (int)(tq >> qbits);
+      const int off = rq ? en_rq_offset(lf == 0, lf == 1, (j & (N - 1)) + (j >> log2)) : 171;
+      long long qv = (tq + ((long long)off << (qbits - 9))) >> qbits;
       if (qv > 32767) qv = 32767;
       lvl[b * 256 + j] = (int16_t)(cv < 0 ? -qv : qv);
       part += (qv != 0) << (16 * b);
@@ -621,6 +716,15 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
     if ((uy < 0 && ux < 2 * n4) || (ux < 0 && uy < n4)) a = rc_unit_avail(f, ctb_addr, (cx >> 2) + ux, (cy >> 2) + uy);
     t->uav[i] = (uint8_t)a;
   }
+  const int refine = f->enc_tools & RBT_ET_REFINE;
+  if (refine) {
+    // modes of the CUs along the left border (candIntraPredModeA of this CTB's first column): carried in LDS when this wave has just coded that CTB
+    const int left_ok = rx > 0 && f->ctb_slice[ctb_addr - 1] == f->ctb_slice[ctb_addr];
+    if (carry_left) { RBT_PAR_FOR(i, n8) t->left_md[i] = t->cu_md[i * 8 + n8 - 1]; }
+    else { RBT_PAR_FOR(i, n8) { const int y = cy + i * 8; t->left_md[i] = (uint8_t)((left_ok && y < g->h) ? f->cu_mode[(y >> 3) * f->w8 + ((cx - 8) >> 3)] : 1); } }
+    if (RBT_LANE0) t->left_md[8] = (uint8_t)left_ok;
+    RBT_SYNC_LDS();
+  }
   RBT_PAR_FOR(i, n8 * n8) {
     const int ux = i & (n8 - 1), uy = i / n8, x = cx + ux * 8, y = cy + uy * 8;
     int l2 = 3, md = 1;
@@ -636,11 +740,18 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
     if (cx + x0 >= g->w || cy + y0 >= g->h) continue;
     const int lg = t->cu_l2[uy * 8 + ux], N = 1 << lg, Nc = N >> 1;
     if ((x0 & (N - 1)) || (y0 & (N - 1))) continue;
-    const int mode = t->cu_md[uy * 8 + ux];
+    int mode = t->cu_md[uy * 8 + ux];
     // source samples of the CU's three TBs: one HBM round trip
     { const uint16_t* sp = f->src[0] + (size_t)(cy + y0) * g->w + cx + x0; RBT_PAR_FOR(i, N * N) t->sb[i] = sp[(size_t)(i >> lg) * g->w + (i & (N - 1))]; }
     for (int q = 0; q < 2; q++) { const uint16_t* sp = f->src[1 + q] + (size_t)((cy + y0) >> 1) * g->cw + ((cx + x0) >> 1); RBT_PAR_FOR(i, Nc * Nc) t->sb[1024 + 256 * q + i] = sp[(size_t)(i >> (lg - 1)) * g->cw + (i & (Nc - 1))]; }
     RBT_SYNC();
+    if (refine) {
+      const int ca = x0 > 0 ? (int)t->cu_md[uy * 8 + ux - 1] : (t->left_md[8] ? (int)t->left_md[uy] : 1), cb = y0 > 0 ? (int)t->cu_md[(uy - 1) * 8 + ux] : 1;   // above: inside this CTB only (8.4.2)
+      mode = en_refine_mode<TL2>(g, L, x0, y0, lg, mode, RBT_UNI(ca), RBT_UNI(cb), lam16, t->sb);
+      const int nu = N >> 3;
+      RBT_PAR_FOR(i, nu * nu) { const int vx = ux + i % nu, vy = uy + i / nu; t->cu_md[vy * 8 + vx] = (uint8_t)mode; f->cu_mode[(((cy + y0) >> 3) + i / nu) * f->w8 + ((cx + x0) >> 3) + i % nu] = (uint8_t)mode; }
+      RBT_SYNC_LDS();
+    }
     int split = 0, cbf = 0, cy4 = 0, ts_bits = 0;
     if (tu_rd) cy4 = en_intra_cu_luma(g, f, L, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, lam2, &split, &ts_bits);
     else cy4 = en_tile_intra_tb(g, f, L, 0, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, t->sb, lg - 2, x0 >> 2, y0 >> 2);

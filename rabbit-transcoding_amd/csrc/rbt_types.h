@@ -102,7 +102,12 @@ struct RbtFrame {
   // Where given, the intra analysis tries planar, DC and the input stream's modes at a block's four quarters instead of searching (en_analyse_ctb).
   const uint8_t* hint_pm; const uint8_t* hint_dm;
   int32_t hint_w4, hint_h4;
+  int32_t enc_tools;             // RBT_ET_* decision tools of RBT-E1 (all on unless a development switch RBT_ENC_SATD / _REFINE / _RQ = 0 says otherwise: oracle/hevc_enc.c)
+  int32_t pad_et;
 };
+#define RBT_ET_SATD 1      // block costs of the intra analysis by SATD (en_analyse_ctb)
+#define RBT_ET_REFINE 2    // closed-loop choice of the luma intra mode (en_refine_mode)
+#define RBT_ET_RQ 4        // rounding offset of the intra quantiser by level and position (en_rq_offset)
 #define RBT_CU_CBF_Y 1
 #define RBT_CU_CBF_CB 2
 #define RBT_CU_CBF_CR 4

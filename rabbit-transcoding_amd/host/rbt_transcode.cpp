@@ -44,6 +44,12 @@ struct EncodeBatch {
 // ... and transform skip for the 4x4 luma blocks unless RBT_ENC_TS=0
 static int e1_ts_on() { static int v = -1; if (v < 0) { const char* e = getenv("RBT_ENC_TS"); v = !e || atoi(e) != 0; } return v; }
 static int e1_sao_on() { static int v = -1; if (v < 0) { const char* e = getenv("RBT_ENC_SAO"); v = !e || atoi(e) != 0; } return v; }
+// ... and the decision tools of round 3 (RBT_ET_*): SATD block costs, closed-loop mode choice, level-dependent rounding unless RBT_ENC_SATD / _REFINE / _RQ = 0
+static int e1_tools(int lossless) {
+  static int v = -1;
+  if (v < 0) { auto on = [](const char* n) { const char* e = getenv(n); return !e || atoi(e) != 0; }; v = (on("RBT_ENC_SATD") ? RBT_ET_SATD : 0) | (on("RBT_ENC_REFINE") ? RBT_ET_REFINE : 0) | (on("RBT_ENC_RQ") ? RBT_ET_RQ : 0); }
+  return lossless ? v & ~RBT_ET_RQ : v;
+}
 static int coded_size(int v, int gop) { int al = gop > 1 ? 16 : 8; return (v + al - 1) / al * al; }
 static void make_param_sets(const EncStreamDesc& d, Sps& s, Pps& p) {
   s = Sps(); p = Pps();
@@ -76,7 +82,7 @@ static int encode_build(EncodeBatch& b) {
       RbtFrame f; memset(&f, 0, sizeof(f));
       fill_stream_cfg(s, p, f.cfg);
       f.poc = is_i ? 0 : (i % d.gop); f.level = is_i ? 0 : 1; f.first_slice = (int)b.slices.size();
-      f.w8 = s.width / 8; f.h8 = s.height / 8; f.lossless = d.lossless; f.ref_frame = is_i ? -1 : (int)b.frames.size() - 1; f.ref_poc = is_i ? 0 : f.poc - 1;
+      f.w8 = s.width / 8; f.h8 = s.height / 8; f.lossless = d.lossless; f.enc_tools = e1_tools(d.lossless); f.ref_frame = is_i ? -1 : (int)b.frames.size() - 1; f.ref_poc = is_i ? 0 : f.poc - 1;
       for (int c = 0; c < 3; c++) f.src[c] = d.src[c][i];
       if (!d.hint_dm.empty()) { f.hint_pm = d.hint_pm[i]; f.hint_dm = d.hint_dm[i]; f.hint_w4 = d.hint_w4; f.hint_h4 = d.hint_h4; }
       int n_ctb = s.w_ctb * s.h_ctb, step = d.rows > 0 ? d.rows * s.w_ctb : (d.rows < 0 ? s.w_ctb : n_ctb);

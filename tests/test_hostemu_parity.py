@@ -272,7 +272,7 @@ def test_transform_skip_blocks_are_chosen_and_mirrored(ctx, monkeypatch):
     monkeypatch.setenv("RBT_ENC_TS", "0")
     off, _ = O.encode(fr, w, h, 10, 24, gop=2, log2_ctb=5, rows_per_slice=-1)
     monkeypatch.delenv("RBT_ENC_TS")
-    assert off != on and len(on) < len(off)
+    assert off != on          # transform skip blocks were chosen (the choice is by distortion + lambda * rate per block: a few bytes either way on this clip)
     dec, _, _, _, chk, fail = ctx.decode(bs)
     assert (chk, fail) == (2, 0) and np.array_equal(dec, rec)
     # lossless streams have no transform to skip: the flag stays off
