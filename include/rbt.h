@@ -47,6 +47,14 @@ typedef struct {
                               * All streams of one call must agree on wavefront mode or not. */
   int md5_sei;               /* emit decoded-picture-hash SEI in the output (the reconstructed pictures come to the host and are hashed on its cores: +35 % on a blocking GOF) */
   int verify_md5;            /* check the input stream's MD5 SEI (a device-to-host copy of every picture, hashed on the host's cores: +25 % on a blocking GOF) */
+  int occupancy_rd;          /* geometry / attribute streams handed to rbt_transcode_gof / rbt_submit_gof behind an occupancy stream that is transcoded in the same call
+                              * (occupancy_precision 4): occupancy-aware coding (what dependencies/hm-modification/HM-16.20+SCM-8.8_with_RDO.patch does to
+                              * HM's distortion, TComRdCost.cpp xGetSSE*). The occupancy map the output carries tells which 4x4 units the decoder makes points of; with one unit
+                              * of margin around them, transform blocks outside carry no residual, partly occupied blocks code what their occupied samples ask for, and the
+                              * unoccupied samples stay out of the encoder's distortion terms. Measured on the benchmark GOF at R3: 62 % fewer geometry and 29 % fewer
+                              * attribute bytes, D1 -0.02 dB, attribute PSNR of the occupied samples unchanged. The pictures outside the occupied area are then whatever
+                              * prediction leaves there. Entries come GOF by GOF, occupancy first; ignored where the call holds no such occupancy stream, by
+                              * rbt_transcode_substream (one stream) and for lossless streams; not together with verify_md5 (RBT_ERR_PARAM). 0 = off: every sample counts. */
 } rbt_stream_params;
 
 typedef struct {             /* decoded video returned by rbt_decode (host memory, rbt_free) */

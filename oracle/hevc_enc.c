@@ -143,6 +143,7 @@ typedef struct {
   uint8_t an_mode[4][64]; int an_cost[4][64]; uint8_t an_split[4][64];   /* [size idx 0:8 1:16 2:32 3:64][block] */
   /* HM-like mode (hm_like) */
   int hm, hm_pass, in_trial, hm_force_intra;
+  const uint8_t* occ4;         /* occupancy of the current picture per 4x4 luma unit (oracle_enc_params.occ4), NULL = every sample counts */
   const uint8_t* hints;        /* intra mode hints of the current picture (oracle_enc_params.hint_modes), NULL = none */
   int e1_satd, e1_refine, e1_rq;   /* RBT-E1 decision tools (product mode): SATD block costs, closed-loop mode choice, level-dependent rounding */
   int tu_rd;                   /* transform trees are decided by coding both ways (hm_decide_tu_split): the HM-like mode (two levels) and RBT-E1 intra CUs (one level) */
@@ -157,6 +158,13 @@ typedef struct {
   hevc_frame* dpb[2]; hevc_colinfo dpbcol[2]; int dpb_poc[2]; int n_dpb;
 } enc;
 
+/* occupancy-aware coding: is luma sample (x,y) / any sample of the luma rectangle one the decoder makes a point of? (always, without a map) */
+static inline int occ_at(const enc* e, int x, int y) { return !e->occ4 || ((x >> 2) < e->p.occ4_w && (y >> 2) < e->p.occ4_h && e->occ4[(size_t)(y >> 2) * e->p.occ4_w + (x >> 2)]); }
+static int occ_any(const enc* e, int x, int y, int w, int h) {
+  if (!e->occ4) return 1;
+  for (int j = y >> 2; j <= (y + h - 1) >> 2; j++) for (int i = x >> 2; i <= (x + w - 1) >> 2; i++) if (i < e->p.occ4_w && j < e->p.occ4_h && e->occ4[(size_t)j * e->p.occ4_w + i]) return 1;
+  return 0;
+}
 static void build_scans(enc* e) {
   for (int l = 0; l <= 3; l++) {
     int n = 1 << l, i = 0, x = 0, y = 0, stop = 0;
@@ -481,7 +489,7 @@ static void hm_sign_hide(enc* e, int log2, int scan_idx, int16_t* coeff, int st)
 }
 /* after the regular transform + quantisation of a TB (levels in lq, N x N): sign hiding, and for 4x4 TBs the choice between the
  * transform and transform skip (7.3.8.11 transform_skip_flag) by distortion + lambda * rate. Returns cbf. */
-static int hm_tb_finish(enc* e, int c_idx, int log2, int intra_mode, int qp, int is_dst, const int16_t* res, int16_t* lq, int* ts_out) {
+static int hm_tb_finish(enc* e, int c_idx, int log2, int intra_mode, int qp, int is_dst, const int16_t* res, int16_t* lq, int* ts_out, const uint8_t* wocc) {
   int N = 1 << log2, NN = N * N, bd = e->sps.bit_depth;
   int scan_idx = tb_scan_idx(e->cu_pred_mode, log2, c_idx, intra_mode);
   if (e->pps.sign_data_hiding) hm_sign_hide(e, log2, scan_idx, lq, N);
@@ -495,7 +503,7 @@ static int hm_tb_finish(enc* e, int c_idx, int log2, int intra_mode, int qp, int
     int64_t d0 = 0, d1 = 0, lam = hm_lambda256(e);
     hevc_dequant(lq, dq, log2, qp, bd); hevc_inv_transform(dq, r0, log2, is_dst, bd);
     hevc_dequant(lt, dq, log2, qp, bd); hevc_inv_transform_skip(dq, r1, log2, bd);
-    for (int i = 0; i < NN; i++) { int a = res[i] - r0[i], b = res[i] - r1[i]; d0 += a * a; d1 += b * b; }
+    for (int i = 0; i < NN; i++) if (!wocc || wocc[i]) { int a = res[i] - r0[i], b = res[i] - r1[i]; d0 += a * a; d1 += b * b; }
     int64_t c0 = d0 * 256 + lam * hm_level_bits(lq, NN), c1 = d1 * 256 + lam * (hm_level_bits(lt, NN) + 1);
     int nz1 = 0; for (int i = 0; i < NN; i++) nz1 |= lt[i] != 0;
     if (nz1 && c1 < c0) { memcpy(lq, lt, sizeof(lt)); *ts_out = 1; }
@@ -525,6 +533,16 @@ static int e1_quant_intra(const int16_t* coef, int16_t* lvl, int log2, int qp, i
   }
   return nz;
 }
+/* occupancy-aware coding of one transform block of component c_idx at (x0,y0), N x N samples: fills wocc (1 = the sample counts) and, in a block that is only partly
+ * occupied, lets the samples no point is made of ask for the mean of what the occupied samples ask for (rounded half away from zero) - a residual without the step a
+ * zero would put at the occupancy border, nor the padding's own demands. Returns 1 if no sample of the block makes a point (no residual at all). */
+static int occ_prepare_tb(const enc* e, int c_idx, int x0, int y0, int N, int16_t* res, uint8_t* wocc) {
+  int sh = c_idx ? 1 : 0, sum = 0, cnt = 0;
+  for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) { int w = sh ? occ_any(e, (x0 + x) << 1, (y0 + y) << 1, 2, 2) : occ_at(e, x0 + x, y0 + y); wocc[y * N + x] = (uint8_t)w; if (w) { sum += res[y * N + x]; cnt++; } }
+  if (!cnt) return 1;
+  if (cnt < N * N) { int mean = sum >= 0 ? (sum + cnt / 2) / cnt : -((-sum + cnt / 2) / cnt); for (int i = 0; i < N * N; i++) if (!wocc[i]) res[i] = (int16_t)mean; }
+  return 0;
+}
 /* predicts (intra), derives levels (product: residual->T->Q; stress: random) and reconstructs one TB.
  * Returns cbf. Levels are left in e->lvl[c_idx] at the TB's offset inside the CU (stride 64). */
 static int recon_tb(enc* e, int c_idx, int x0, int y0, int log2, int intra_mode, int* ts_out) {
@@ -535,7 +553,7 @@ static int recon_tb(enc* e, int c_idx, int x0, int y0, int log2, int intra_mode,
   if (e->cu_pred_mode == MODE_INTRA) hevc_intra_pred(f, e->m, c_idx, x0, y0, log2, intra_mode);
   int is_dst = c_idx == 0 && log2 == 2 && e->cu_pred_mode == MODE_INTRA;
   int qp = c_idx ? chroma_qp_of(e, c_idx) : e->qp_y + 6 * (bd - 8);
-  int16_t res[32 * 32], coef[32 * 32], lq[32 * 32], dq[32 * 32];
+  int16_t res[32 * 32], coef[32 * 32], lq[32 * 32], dq[32 * 32]; uint8_t wocc[32 * 32];   /* wocc: the sample counts in distortion terms (occupancy-aware coding) */
   int ts = 0, cbf = 0;
   if (e->stress) {
     random_levels(e, log2, lv, 64);
@@ -546,13 +564,15 @@ static int recon_tb(enc* e, int c_idx, int x0, int y0, int log2, int intra_mode,
   } else {
     const uint16_t* sp = e->src->p[c_idx] + (size_t)y0 * pw + x0;
     for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) res[y * N + x] = (int16_t)((int)sp[(size_t)y * pw + x] - (int)p[(size_t)y * pw + x]);
-    if (e->cu_tq_bypass) { memcpy(lq, res, sizeof(int16_t) * N * N); for (int i = 0; i < N * N; i++) cbf |= lq[i] != 0; }
+    const int occ_none = e->occ4 && occ_prepare_tb(e, c_idx, x0, y0, N, res, wocc);   /* no sample of the block makes a point: no residual */
+    if (occ_none) { memset(lq, 0, sizeof(int16_t) * N * N); cbf = 0; }
+    else if (e->cu_tq_bypass) { memcpy(lq, res, sizeof(int16_t) * N * N); for (int i = 0; i < N * N; i++) cbf |= lq[i] != 0; }
     else { hevc_fwd_transform(res, coef, log2, is_dst, bd); cbf = (e->e1_rq && e->cu_pred_mode == MODE_INTRA ? e1_quant_intra(coef, lq, log2, qp, bd) : hevc_quant(coef, lq, log2, qp, bd, e->cu_pred_mode == MODE_INTRA)) != 0; }
-    if ((e->hm || e->pps.transform_skip_enabled) && !e->cu_tq_bypass) { cbf = hm_tb_finish(e, c_idx, log2, intra_mode, qp, is_dst, res, lq, &ts); if (!e->in_trial && e->hm_pass != 1 && log2 == 2 && cbf) { e->hs.tb4++; e->hs.ts += ts; } }
+    if ((e->hm || e->pps.transform_skip_enabled) && !e->cu_tq_bypass && !occ_none) { cbf = hm_tb_finish(e, c_idx, log2, intra_mode, qp, is_dst, res, lq, &ts, e->occ4 ? wocc : NULL); if (!e->in_trial && e->hm_pass != 1 && log2 == 2 && cbf) { e->hs.tb4++; e->hs.ts += ts; } }
     for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) lv[y * 64 + x] = lq[y * N + x];
   }
   *ts_out = ts;
-  if (e->tu_rd) { e->last_bits = hm_level_bits(lq, N * N); e->last_ssd = 0; if (!cbf) for (int i = 0; i < N * N; i++) e->last_ssd += (int64_t)res[i] * res[i]; }
+  if (e->tu_rd) { e->last_bits = hm_level_bits(lq, N * N); e->last_ssd = 0; if (!cbf) for (int i = 0; i < N * N; i++) if (!e->occ4 || e->stress || wocc[i]) e->last_ssd += (int64_t)res[i] * res[i]; }
   if (!cbf) return 0;
   int16_t res_src[32 * 32]; if (e->tu_rd) memcpy(res_src, res, sizeof(int16_t) * N * N);
   if (e->cu_tq_bypass) memcpy(res, lq, sizeof(int16_t) * N * N);
@@ -561,7 +581,7 @@ static int recon_tb(enc* e, int c_idx, int x0, int y0, int log2, int intra_mode,
     if (ts) hevc_inv_transform_skip(dq, res, log2, bd); else hevc_inv_transform(dq, res, log2, is_dst, bd);
   }
   for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) p[(size_t)y * pw + x] = (uint16_t)clip3(0, maxv, p[(size_t)y * pw + x] + res[y * N + x]);
-  if (e->tu_rd) for (int i = 0; i < N * N; i++) { int d = res_src[i] - res[i]; e->last_ssd += (int64_t)d * d; }
+  if (e->tu_rd) for (int i = 0; i < N * N; i++) if (!e->occ4 || wocc[i]) { int d = res_src[i] - res[i]; e->last_ssd += (int64_t)d * d; }
   return 1;
 }
 
@@ -1211,6 +1231,7 @@ static void hm_sao_decide(enc* e) {
       int64_t bsum[32], ecnt[4][4], esum[4][4]; int bcnt[32];
       memset(bsum, 0, sizeof(bsum)); memset(bcnt, 0, sizeof(bcnt)); memset(ecnt, 0, sizeof(ecnt)); memset(esum, 0, sizeof(esum));
       for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++) {
+        if (e->occ4 && !(sh ? occ_any(e, x << 1, y << 1, 2, 2) : occ_at(e, x, y))) continue;   /* no point made of this sample: no say in the offsets */
         int v = rp[(size_t)y * pw + x], d = (int)sp[(size_t)y * pw + x] - v;
         bcnt[v >> (bd - 5)]++; bsum[v >> (bd - 5)] += d;
         for (int cls = 0; cls < 4; cls++) {
@@ -1401,6 +1422,8 @@ static void analyse_ctb_inter(enc* e, int cx, int cy) {
       const uint16_t* sp = e->src->p[ci] + (size_t)(y0 >> sh) * pw + (x0 >> sh);
       const uint16_t* rp = e->ref[0]->p[ci] + (size_t)(y0 >> sh) * pw + (x0 >> sh);
       for (int y = 0; y < S; y++) for (int x = 0; x < S; x++) res[y * S + x] = (int16_t)((int)sp[(size_t)y * pw + x] - (int)rp[(size_t)y * pw + x]);
+      uint8_t wocc[16 * 16];
+      if (e->occ4 && occ_prepare_tb(e, ci, x0 >> sh, y0 >> sh, S, res, wocc)) continue;      /* the residual the block will be coded with (recon_tb) */
       hevc_fwd_transform(res, coef, l2, 0, bd);
       int qp = ci ? chroma_qp_of(e, ci) : e->qp_y + 6 * (bd - 8);
       nz |= hevc_quant(coef, lq, l2, qp, bd, 0) != 0;
@@ -1616,6 +1639,7 @@ static void encode_picture(enc* e, const hevc_frame* src, int idx, bytebuf* out,
   e->is_idr = is_i; e->slice_type = is_i ? SLICE_I : SLICE_P;
   if (is_i) { e->poc = 0; e->n_dpb = 0; write_param_sets(e, out); } else e->poc++;
   e->hints = (e->p.hint_modes && !e->stress && !e->hm) ? e->p.hint_modes[idx] : NULL;
+  e->occ4 = (e->p.occ4 && !e->stress && !e->hm && !e->p.lossless) ? e->p.occ4[idx] : NULL;
   e->src = src; e->rec = hevc_frame_alloc(s->width, s->height, s->bit_depth);
   hevc_meta_reset(m);
   m->constrained_intra_pred = p->constrained_intra_pred; m->cb_qp_offset = p->cb_qp_offset; m->cr_qp_offset = p->cr_qp_offset; m->strong_intra_smoothing = s->strong_intra_smoothing;

@@ -19,6 +19,8 @@ typedef struct {
   int log2_ctb;               /* implementation parameter of the RBT-E1 encoder (0 = default 5) */
   int ctb_rows_per_slice;     /* implementation parameter (0 = one slice per picture) */
   int md5_sei;
+  int occupancy_rd;           /* geometry / attribute streams handed to oracle_transcode_data behind an occupancy stream: occupancy-aware coding (oracle_enc_params.occ4,
+                                 SURVEY.md 8 row F4) with the occupancy map that stream comes out with; ignored by oracle_transcode_substream, which sees one stream */
 } oracle_transcode_params;
 
 /* PCCVideoBitstream::sampleStreamToByteStream / byteStreamToSampleStream (PCCVideoBitstream.cpp:85-172), HEVC case,

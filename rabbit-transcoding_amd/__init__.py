@@ -22,7 +22,7 @@ class RbtError(RuntimeError):
 
 class StreamParams(C.Structure):
     _fields_ = [("video_type", C.c_int), ("qp", C.c_int), ("occupancy_precision", C.c_int), ("log2_ctb", C.c_int),
-                ("ctb_rows_per_slice", C.c_int), ("md5_sei", C.c_int), ("verify_md5", C.c_int)]
+                ("ctb_rows_per_slice", C.c_int), ("md5_sei", C.c_int), ("verify_md5", C.c_int), ("occupancy_rd", C.c_int)]
 
 
 class Video(C.Structure):

@@ -84,6 +84,19 @@ RBT_DEV int en_had8x8_abs(int v) {
 }
 #define EN_HAD8X8_ACC(vr, acc) (acc) += en_had8x8_abs(vr)
 #endif
+// occupancy-aware coding: does the 4x4 luma unit (ux,uy) of the picture make a point (or sit next to one that does)?
+RBT_DEV int en_occ_unit(const RbtFrame* f, int ux, int uy) { return ux < f->occ4_w && uy < f->occ4_h && f->occ4[(size_t)uy * f->occ4_w + ux] != 0; }
+// mean of `sum` over `cnt` samples, rounded half away from zero (oracle/hevc_enc.c recon_tb: what the unoccupied samples of a partly occupied block ask for)
+RBT_DEV int en_round_mean(int sum, int cnt) { return sum >= 0 ? (sum + cnt / 2) / cnt : -((-sum + cnt / 2) / cnt); }
+// RbtFrame::occ4 of unit (i,j) of a W x H picture from the occupancy map `occ` (ow x oh samples, the atlas scaled down by s = W / ow): does any occupancy sample that covers
+// part of the unit or of one of its eight neighbours say "occupied"? (oracle/vpcc_path.c occ_units: the units' own samples, then one unit of margin - the sample ranges of
+// neighbouring units follow each other, so the union is one rectangle)
+RBT_DEV int en_occ_unit_value(const uint16_t* occ, int ow, int oh, int s, int w4, int h4, int i, int j) {
+  const int x_lo = (4 * rbt_max(i - 1, 0)) / s, x_hi = rbt_min(ow - 1, (4 * rbt_min(i + 1, w4 - 1) + 3) / s), y_lo = (4 * rbt_max(j - 1, 0)) / s, y_hi = rbt_min(oh - 1, (4 * rbt_min(j + 1, h4 - 1) + 3) / s);
+  int any = 0;
+  for (int y = y_lo; y <= y_hi; y++) for (int x = x_lo; x <= x_hi; x++) any |= occ[(size_t)y * ow + x] != 0;
+  return any;
+}
 // rounding offset of the intra quantiser in 1/512 of a level (oracle/hevc_enc.c e1_quant_intra): by the level below and, for a first level, the position
 RBT_DEV int en_rq_offset(int lf_is0, int lf_is1, int xy_sum) { return lf_is0 ? (xy_sum <= 2 ? 190 : 160) : (lf_is1 ? 200 : 230); }
 RBT_DEV int en_chroma_qp(const RbtFrame* f, const RbtSlice* sl, int c_idx, int qp_y) {
@@ -335,8 +348,25 @@ RBT_DEV int en_code_tb(RbtFrame* f, int c_idx, int x0, int y0, int log2, int qp,
   const uint16_t* sp = f->src[c_idx]; uint16_t* rp = f->pix[c_idx]; int16_t* cp = f->coef[c_idx];
   RBT_PAR_FOR(i, N * N) { int x = i & (N - 1), y = i >> log2; l->rc.res[i] = (int16_t)((int)sp[(size_t)(y0 + y) * pw + x0 + x] - (int)l->rc.pred[i]); }
   RBT_SYNC_LDS();
+  // occupancy-aware coding (see en_tile_intra_tb; x0, y0 are picture coordinates of component c_idx)
+  int occ_none = 0;
+  if (f->occ4 != nullptr) {
+    const int sh = c_idx ? 1 : 0;
+#define EN_TBP_OCC(i) en_occ_unit(f, ((x0 + ((i) & (N - 1))) << sh) >> 2, ((y0 + ((i) >> log2)) << sh) >> 2)
+    int pc = 0, ps = 0;
+    RBT_PAR_FOR(i, N * N) { if (EN_TBP_OCC(i)) { pc++; ps += l->rc.res[i]; } }
+    const int cnt = en_wave_sum(pc, l);
+    occ_none = cnt == 0;
+    if (cnt > 0 && cnt < N * N) {
+      const int mean = en_round_mean(en_wave_sum(ps, l), cnt);
+      RBT_PAR_FOR(i, N * N) { if (!EN_TBP_OCC(i)) l->rc.res[i] = (int16_t)mean; }
+      RBT_SYNC_LDS();
+    }
+#undef EN_TBP_OCC
+  }
   int nz;
-  if (f->lossless) {
+  if (occ_none) { RBT_PAR_FOR(i, N * N) l->lvl[i] = 0; nz = 0; }
+  else if (f->lossless) {
     int part = 0;
     RBT_PAR_FOR(i, N * N) { l->lvl[i] = l->rc.res[i]; part += l->rc.res[i] != 0; }
     nz = en_wave_sum(part, l);
@@ -394,6 +424,7 @@ template <int TL2> struct RbtEncTileT {
   uint8_t uav[((1 << (TL2 - 2)) + 1) * RC_US];
   uint16_t sb[32 * 32 + 2 * 16 * 16];                        // source samples of the current CU: Y, Cb, Cr
   uint8_t cu_l2[64], cu_md[64];                              // cu_log2 / cu_mode of the CTB's 8x8 units (analysis result; cu_md: the closed-loop choice once a CU is coded)
+  uint8_t occ_u[(1 << (TL2 - 2)) * (1 << (TL2 - 2))];        // occupancy-aware coding: RbtFrame::occ4 of the CTB's 4x4 luma units (uy * n4 + ux)
   uint8_t left_md[16];                                       // luma modes of the 8x8 units in the last column of the CTB to the left ([8] = that CTB is available, 6.4.1)
   // one TU or four (en_intra_cu_luma): levels and reconstruction of the CU's luma coded as ONE transform block, kept while it is coded as four;
   // levels of the current quarter; source samples of the current quarter (luma, or Cb at 0 and Cr at 256)
@@ -434,11 +465,27 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
   // prediction and residual
   RBT_PAR_FOR(i, N * N) { const int pv = rc_intra_sample(&q, fin, r_ref, i & (N - 1), i >> log2); r->pred[i] = (uint16_t)pv; r->res[i] = (int16_t)((int)src[i] - pv); }
   RBT_SYNC_LDS();
+  // occupancy-aware coding (oracle/hevc_enc.c recon_tb): a block without an occupied sample carries no residual; in a partly occupied one the other samples ask for
+  // the mean residual of the occupied ones; unoccupied samples stay out of every distortion sum below
+  const int f4 = f->occ4 != nullptr; int occ_none = 0;
+#define EN_TB_OCC(i) (t->occ_u[((((y0) + ((i) >> log2)) << sh) >> 2) * n4 + ((((x0) + ((i) & (N - 1))) << sh) >> 2)])
+  if (f4) {
+    int pc = 0, ps = 0;
+    RBT_PAR_FOR(i, N * N) { if (EN_TB_OCC(i)) { pc++; ps += r->res[i]; } }
+    const int cnt = en_wave_sum(pc, (RBT_LDS_AS RbtEncLds*)0);
+    occ_none = cnt == 0;
+    if (cnt > 0 && cnt < N * N) {
+      const int mean = en_round_mean(en_wave_sum(ps, (RBT_LDS_AS RbtEncLds*)0), cnt);
+      RBT_PAR_FOR(i, N * N) { if (!EN_TB_OCC(i)) r->res[i] = (int16_t)mean; }
+      RBT_SYNC_LDS();
+    }
+  }
   // ts_out (4x4 luma blocks of a stream with transform_skip_enabled_flag, lvl_buf with 64 entries): the block is also coded without the transform and the
   // cheaper way kept (oracle/hevc_enc.c hm_tb_finish): residual kept at lvl_buf + 32, transform-skip levels at + 16, their reconstruction at + 48
   if (ts_out) { *ts_out = 0; RBT_PAR_FOR(i, 16) lvl[32 + i] = r->res[i]; }
   int nz;
-  if (f->lossless) {
+  if (occ_none) { RBT_PAR_FOR(i, N * N) lvl[i] = 0; nz = 0; }
+  else if (f->lossless) {
     int part = 0;
     RBT_PAR_FOR(i, N * N) { lvl[i] = r->res[i]; part += r->res[i] != 0; }
     nz = en_wave_sum(part, (RBT_LDS_AS RbtEncLds*)0);
@@ -468,7 +515,7 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
     RBT_PAR_FOR(i, N * N) r->res[i] = lvl[i];
     RBT_SYNC_LDS();
   }
-  if (ts_out && !f->lossless) {
+  if (ts_out && !f->lossless && !occ_none) {
     // transform skip (7.3.8.11 transform_skip_flag, 8.6.4.2): the residual scaled by 2^(15 - bitDepth - 2) is quantised like coefficients; both ways are
     // priced as distortion * 256 + lambda^2 * rate, the flag costs one bit more, and transform skip needs a non-zero level
     const int tsh = 15 - bd - 2, qbits = 14 + qp / 6 + (15 - bd - log2), sc = en_quant_scale(qp % 6), bd_shift = bd + log2 - 5, scale = (16 * rc_level_scale(qp % 6)) << (qp / 6), ish = 20 - bd;
@@ -482,7 +529,7 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
       long long dq = ((long long)lt * scale + dadd) >> bd_shift; dq = dq < -32768 ? -32768 : (dq > 32767 ? 32767 : dq);
       const int r1 = (int)((((int)dq << 7) + (1 << (ish - 1))) >> ish), r0 = nz ? (int)r->res[i] : 0, a0 = rbt_abs((int)lvl[i]);
       lvl[16 + i] = (int16_t)lt; lvl[48 + i] = (int16_t)r1;
-      p_nz += lt != 0; p_d0 += (rs - r0) * (rs - r0); p_d1 += (rs - r1) * (rs - r1);
+      p_nz += lt != 0; if (!f4 || EN_TB_OCC(i)) { p_d0 += (rs - r0) * (rs - r0); p_d1 += (rs - r1) * (rs - r1); }
       if (a0) p_b0 += 3 + 2 * (31 - __builtin_clz((unsigned)a0));
       if (qv) p_b1 += 3 + 2 * (31 - __builtin_clz((unsigned)qv));
     }
@@ -506,13 +553,14 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
     int ps = 0, pb = 0;
     RBT_PAR_FOR(i, N * N) {
       const int d = (int)src[i] - (int)r->pred[i] - (nz ? (int)r->res[i] : 0), a = rbt_abs((int)lvl[i]);
-      ps += d * d;                                                       // at most 16 samples per lane and 1024 per block: fits 32 bits
+      if (!f4 || EN_TB_OCC(i)) ps += d * d;                              // at most 16 samples per lane and 1024 per block: fits 32 bits
       if (a) pb += 3 + 2 * (31 - __builtin_clz((unsigned)a));
     }
     const int ssd = en_wave_sum(ps, (RBT_LDS_AS RbtEncLds*)0), bits = en_wave_sum(pb, (RBT_LDS_AS RbtEncLds*)0);
     *cost = (long long)ssd * 256 + (long long)lam2 * (bits ? bits + 3 : 1);
     if (ssd_out) *ssd_out = ssd;
   }
+#undef EN_TB_OCC
   RBT_SYNC_LDS();
   return nz != 0;
 }
@@ -651,8 +699,24 @@ template <int TL2> RBT_DEV int en_tile_intra_tb_cpair(const RbtStreamCfg* g, Rbt
     r->pred[b * 256 + j] = (uint16_t)pv; r->res[b * 256 + j] = (int16_t)((int)src[b * 256 + j] - pv);
   }
   RBT_SYNC_LDS();
+  // occupancy-aware coding (see en_tile_intra_tb): chroma sample (x,y) stands for the luma samples (2x..2x+1, 2y..2y+1), all in one 4x4 unit
+  int occ_none = 0;
+  if (f->occ4 != nullptr) {
+#define EN_TBC_OCC(j) (t->occ_u[((y0 + ((j) >> log2)) >> 1) * n4 + ((x0 + ((j) & (N - 1))) >> 1)])
+    int pc = 0, ps0 = 0, ps1 = 0;
+    RBT_PAR_FOR(j, NN) { if (EN_TBC_OCC(j)) { pc++; ps0 += r->res[j]; ps1 += r->res[256 + j]; } }
+    const int cnt = en_wave_sum(pc, (RBT_LDS_AS RbtEncLds*)0);
+    occ_none = cnt == 0;
+    if (cnt > 0 && cnt < NN) {
+      const int m0v = en_round_mean(en_wave_sum(ps0, (RBT_LDS_AS RbtEncLds*)0), cnt), m1v = en_round_mean(en_wave_sum(ps1, (RBT_LDS_AS RbtEncLds*)0), cnt);
+      RBT_PAR_FOR(j, NN) { if (!EN_TBC_OCC(j)) { r->res[j] = (int16_t)m0v; r->res[256 + j] = (int16_t)m1v; } }
+      RBT_SYNC_LDS();
+    }
+#undef EN_TBC_OCC
+  }
   int part = 0;                                                          // non-zero counts: Cb in the low half, Cr in the high half
-  if (f->lossless) {
+  if (occ_none) { RBT_PAR_FOR(i, 2 * NN) { const int b = i >= NN, j = i - b * NN; lvl[b * 256 + j] = 0; } }
+  else if (f->lossless) {
     RBT_PAR_FOR(i, 2 * NN) { const int b = i >= NN, j = i - b * NN; lvl[b * 256 + j] = r->res[b * 256 + j]; part += (r->res[b * 256 + j] != 0) << (16 * b); }
   } else {
     if (log2 == 2) en_fwd_transform_pair_n<2>(bd, r); else if (log2 == 3) en_fwd_transform_pair_n<3>(bd, r); else en_fwd_transform_pair_n<4>(bd, r);
@@ -716,6 +780,7 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
     if ((uy < 0 && ux < 2 * n4) || (ux < 0 && uy < n4)) a = rc_unit_avail(f, ctb_addr, (cx >> 2) + ux, (cy >> 2) + uy);
     t->uav[i] = (uint8_t)a;
   }
+  if (f->occ4 != nullptr) { RBT_PAR_FOR(i, n4 * n4) t->occ_u[i] = (uint8_t)en_occ_unit(f, (cx >> 2) + i % n4, (cy >> 2) + i / n4); }
   const int refine = f->enc_tools & RBT_ET_REFINE;
   if (refine) {
     // modes of the CUs along the left border (candIntraPredModeA of this CTB's first column): carried in LDS when this wave has just coded that CTB
@@ -1179,7 +1244,7 @@ RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_L
     for (int q = 0; q < 16; q++) { ecnt[q] = 0; esum[q] = 0; }
     RBT_PAR_FOR(i, n * n) {
       const int x = x0 + (i & (n - 1)), y = y0 + (i >> lgn);
-      if (x < pw && y < ph) {
+      if (x < pw && y < ph && (f->occ4 == nullptr || en_occ_unit(f, (x << sh) >> 2, (y << sh) >> 2))) {      // occupancy-aware coding: samples no point is made of have no say in the offsets
         const int v = rp[(size_t)y * pw + x], d = (int)sp[(size_t)y * pw + x] - v, b = rbt_min(31, v >> (bd - 5)), copy = i & 7;
         RBT_LDS_ADD(&L->bcnt[copy][b], 1); RBT_LDS_ADD(&L->bsum[copy][b], d);
 #pragma unroll

@@ -60,6 +60,8 @@ void launch_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_l
 void launch_pool(const uint16_t* in, int stride, int w, int h, int factor, uint16_t* out, uint16_t* out_cb, uint16_t* out_cr, int chroma_value);   // w x h region of a plane with row stride `stride`
 // n pictures of one size, outputs out + k * out_step (Y, then Cb, Cr behind it), inputs anywhere
 void launch_pool_many(const uint16_t* const* in, int n, int stride, int w, int h, int factor, uint16_t* out, size_t out_step, int chroma_value);
+// occupancy-aware coding: RbtFrame::occ4 maps (w4 x h4 bytes each, back to back) of n occupancy pictures (ow x oh luma samples, row stride ow, in_step samples apart) for W x H pictures
+void launch_occ_units(const uint16_t* occ, size_t in_step, int n, int ow, int oh, int W, int w4, int h4, uint8_t* out);
 void launch_pad(const uint16_t* in, int stride, int x0, int y0, int w, int h, uint16_t* out, int dw, int dh);
 void launch_enc_analyse(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs);
 // row_mode 1: every slice is one CTB row, rows are independent and each wave walks its row; 2: wavefront mode (rows of a picture wait for each other, k_enc_intra_wave);

@@ -379,6 +379,14 @@ void launch_pool_many(const uint16_t* const* in, int n, int stride, int w, int h
     hipLaunchKernelGGL(k_pool_many, dim3((ow * oh + 255) / 256, m), dim3(256), 0, g_stream, a, stride, factor, out + out_step * k, out_step, ow, oh, chroma_value);
   }
 }
+__global__ void __launch_bounds__(256) k_occ_units(const uint16_t* occ, size_t in_step, int ow, int oh, int s, int w4, int h4, uint8_t* out) {
+  const int u = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+  if (u < w4 * h4) out[(size_t)k * w4 * h4 + u] = (uint8_t)en_occ_unit_value(occ + in_step * k, ow, oh, s, w4, h4, u % w4, u / w4);
+}
+void launch_occ_units(const uint16_t* occ, size_t in_step, int n, int ow, int oh, int W, int w4, int h4, uint8_t* out) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_occ_units, dim3((w4 * h4 + 255) / 256, n), dim3(256), 0, g_stream, occ, in_step, ow, oh, W / ow, w4, h4, out);
+}
 void launch_enc_analyse(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs) {
   if (n_frames <= 0) return;
   hipLaunchKernelGGL(k_enc_analyse, dim3(max_ctbs, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);

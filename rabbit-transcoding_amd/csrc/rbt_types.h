@@ -102,6 +102,9 @@ struct RbtFrame {
   // Where given, the intra analysis tries planar, DC and the input stream's modes at a block's four quarters instead of searching (en_analyse_ctb).
   const uint8_t* hint_pm; const uint8_t* hint_dm;
   int32_t hint_w4, hint_h4;
+  // occupancy-aware coding (oracle_enc_params.occ4): one byte per 4x4 luma unit of the picture, != 0 where the decoder makes a point of some sample of
+  // the unit or of a unit next to it (k_occ_units, from the occupancy map the output carries); occ4_w x occ4_h units, units beyond are unoccupied; nullptr = every sample counts
+  const uint8_t* occ4; int32_t occ4_w, occ4_h;
   int32_t enc_tools;             // RBT_ET_* decision tools of RBT-E1 (all on unless a development switch RBT_ENC_SATD / _REFINE / _RQ = 0 says otherwise: oracle/hevc_enc.c)
   int32_t pad_et;
 };

@@ -16,6 +16,7 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 struct EncStreamDesc {
   int w, h, bd, n_frames, qp, i_qp_offset, gop, lossless, log2_ctb, rows, md5;   // w, h: display size (any even numbers)
   std::vector<const uint8_t*> hint_pm, hint_dm; int hint_w4 = 0, hint_h4 = 0;       // per frame: the decoded input picture's 4x4 maps (device), empty = no hints
+  std::vector<const uint8_t*> occ4; int occ4_w = 0, occ4_h = 0;                      // per frame: occupancy of the 4x4 luma units (device, RbtFrame::occ4), empty = every sample counts
   int sao = 0;                           // SAO on (every stream that is not lossless, unless RBT_ENC_SAO=0)
   std::vector<const uint16_t*> src[3];   // device planes per frame
   int src_stride = 0, src_x0 = 0, src_y0 = 0;   // the planes are views: luma row stride (0 = w) and origin of the w x h region (luma samples)
@@ -85,6 +86,7 @@ static int encode_build(EncodeBatch& b) {
       f.w8 = s.width / 8; f.h8 = s.height / 8; f.lossless = d.lossless; f.enc_tools = e1_tools(d.lossless); f.ref_frame = is_i ? -1 : (int)b.frames.size() - 1; f.ref_poc = is_i ? 0 : f.poc - 1;
       for (int c = 0; c < 3; c++) f.src[c] = d.src[c][i];
       if (!d.hint_dm.empty()) { f.hint_pm = d.hint_pm[i]; f.hint_dm = d.hint_dm[i]; f.hint_w4 = d.hint_w4; f.hint_h4 = d.hint_h4; }
+      if (!d.occ4.empty() && !d.lossless) { f.occ4 = d.occ4[i]; f.occ4_w = d.occ4_w; f.occ4_h = d.occ4_h; }
       int n_ctb = s.w_ctb * s.h_ctb, step = d.rows > 0 ? d.rows * s.w_ctb : (d.rows < 0 ? s.w_ctb : n_ctb);
       for (int addr = 0; addr < n_ctb; addr += step) {
         RbtSlice sl; memset(&sl, 0, sizeof(sl));
@@ -308,10 +310,14 @@ static int hand_out(const std::vector<std::vector<uint8_t>>& outs, uint8_t** out
 // 297.3 ms). Off by default; RBT_PARSE_BANDS=<n> in the environment turns it on for experiments.
 static int parse_bands() { static int v = -1; if (v < 0) { const char* e = getenv("RBT_PARSE_BANDS"); v = e ? atoi(e) : 1; if (v < 1) v = 1; if (v > 16) v = 16; } return v; }
 struct PoolJob { const uint16_t* in; int stride, w, h; uint16_t *y, *cb, *cr; int grey; };
+// occupancy-aware coding: the occupancy maps per 4x4 luma unit (RbtFrame::occ4) that the geometry / attribute streams of a GOF are coded with, made from the pooled
+// occupancy pictures of that GOF's occupancy stream by one launch on the occupancy pipeline's stream
+struct OccSource { const uint16_t* occ = nullptr; size_t in_step = 0; int n = 0, ow = 0, oh = 0, pipeline = -1; };   // the pooled luma planes of one occupancy stream
+struct OccJob { int source; uint8_t* maps; int W, w4, h4; };                                                           // one launch_occ_units: the maps of one consumer stream
 // pool_jobs != nullptr: the OR-pool launches are recorded instead of issued (the decoder's kernels are not enqueued yet)
 // stream `si` of the decode batch becomes stream `ei` of the encode batch (several target rate points may re-encode one decoded
 // stream: BASELINE.json configs[4], rate fan-out)
-static int setup_encode(DecodeBatch& db, int si, int ei, const rbt_stream_params& p, EncodeBatch& eb, std::vector<void*>& pooled, std::string& err, std::vector<PoolJob>* pool_jobs = nullptr) {
+static int setup_encode(DecodeBatch& db, int si, int ei, const rbt_stream_params& p, EncodeBatch& eb, std::vector<void*>& pooled, std::string& err, std::vector<PoolJob>* pool_jobs = nullptr, const OccSource* occ = nullptr, int occ_index = -1, std::vector<OccJob>* occ_jobs = nullptr) {
   if ((int)eb.desc.size() <= ei) eb.desc.resize((size_t)ei + 1);
   EncStreamDesc& d = eb.desc[ei]; int first = db.stream_first[si], cnt = db.stream_count[si];
   const RbtStreamCfg& c = db.frames[first].cfg; const Sps& isps = db.stream_sps[si];
@@ -349,6 +355,16 @@ static int setup_encode(DecodeBatch& db, int si, int ei, const rbt_stream_params
     if (cl == 0 && ct == 0) {
       d.hint_pm.resize(cnt); d.hint_dm.resize(cnt); d.hint_w4 = c.w4; d.hint_h4 = c.h4;
       for (int k = 0; k < cnt; k++) { d.hint_pm[k] = db.frames[first + k].pm; d.hint_dm[k] = db.frames[first + k].dm; }
+    }
+    // occupancy-aware coding (oracle/vpcc_path.c transcode_substream_occ): picture k belongs to occupancy frame k * n_occ / cnt; the occupancy video must be the
+    // atlas scaled down by a whole factor, else every sample counts
+    if (occ && occ_jobs && occ->n > 0 && cnt % occ->n == 0 && dw % occ->ow == 0 && dh % occ->oh == 0 && dw / occ->ow == dh / occ->oh) {
+      const int w4 = (dw + 3) / 4, h4 = (dh + 3) / 4;
+      uint8_t* maps = (uint8_t*)rbtk::dev_alloc((size_t)occ->n * w4 * h4);
+      if (!maps) { err = "device allocation failed"; return RBT_ERR_NOMEM; }
+      pooled.push_back(maps); occ_jobs->push_back(OccJob{occ_index, maps, dw, w4, h4});
+      d.occ4.resize(cnt); d.occ4_w = w4; d.occ4_h = h4;
+      for (int k = 0; k < cnt; k++) d.occ4[k] = maps + (size_t)((size_t)k * occ->n / cnt) * w4 * h4;
     }
   }
   return 0;
@@ -440,24 +456,46 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
   j.t_gpu = now_ms();
   int rc = 0;
   std::vector<std::vector<PoolJob>> pool_jobs(ng);
+  // occupancy-aware coding (rbt_stream_params.occupancy_rd): entry i is coded with the occupancy map of the nearest occupancy entry in front of it, if this call pools it
+  std::vector<int> occ_of(n, -1), group_of(n, -1), pos_of(n, -1); bool any_occ_rd = false;
+  for (int g = 0; g < ng; g++) for (size_t q = 0; q < groups[g].size(); q++) { group_of[groups[g][q]] = g; pos_of[groups[g][q]] = (int)q; }
+  for (int i = 0, last = -1; i < n; i++) {
+    if (p[i].video_type == RBT_VIDEO_OCCUPANCY) last = (gof_rule && !j.is_pass[i] && p[i].occupancy_precision == 4) ? i : -1;
+    else if (gof_rule && p[i].occupancy_rd && last >= 0) { occ_of[i] = last; any_occ_rd = true; if (p[i].verify_md5 || p[last].verify_md5) { err = "occupancy_rd cannot be combined with verify_md5"; rc = RBT_ERR_PARAM; } }
+  }
+  std::vector<OccSource> occ_src(n); std::vector<OccJob> occ_jobs;
+  std::vector<char> verify_of(ng, 0);
   for (int k = 0; k < ng && !rc; k++) {
     const int gi = order[k], sid = job_stream(j, gi); const std::vector<int>& gs = groups[gi]; rbtk::set_stream(sid);
     std::vector<StreamIn> sins; bool verify = false;
     for (int i : uniq[gi]) sins.push_back(StreamIn{in[i], n_in[i]});
     for (int i : gs) verify |= p[i].verify_md5 != 0;
+    verify_of[gi] = verify;
     double t0 = now_ms();
     db[gi].want_save = parse_bands() > 1 && k == 0 && j.has_aux && ng <= rbtk::RBT_AUX_STREAM && !verify;
     rc = decode_build(db[gi], sins.data(), (int)sins.size());
     st.host_parse_ms += now_ms() - t0;
     if (!rc) rc = decode_upload_lists(db[gi]);
     if (rc) { err = db[gi].err; break; }
-    if (!verify) {
-      for (size_t q = 0; q < gs.size() && !rc; q++) rc = setup_encode(db[gi], j.dec_of[gi][q], (int)q, p[gs[q]], eb[gi], pooled, err, &pool_jobs[gi]);
-      if (!rc) { rc = encode_build(eb[gi]); if (!rc) rc = encode_upload_lists(eb[gi]); if (rc) err = eb[gi].err; }
-      if (rc) break;
-      chained[gi] = 1;
-    }
   }
+  // encoder set-up: the pipelines whose occupancy streams others are coded with first (their pooled planes are what the maps are made of)
+  for (int pass = 0; pass < 2 && !rc; pass++) for (int k = 0; k < ng && !rc; k++) {
+    const int gi = order[k], sid = job_stream(j, gi); const std::vector<int>& gs = groups[gi]; rbtk::set_stream(sid);
+    bool feeds = false; for (int i : gs) for (int c = 0; c < n; c++) feeds |= occ_of[c] == i;
+    if (feeds != (pass == 0) || verify_of[gi]) continue;
+    for (size_t q = 0; q < gs.size() && !rc; q++) {
+      const int i = gs[q], io = occ_of[i];
+      rc = setup_encode(db[gi], j.dec_of[gi][q], (int)q, p[i], eb[gi], pooled, err, &pool_jobs[gi], io >= 0 ? &occ_src[io] : nullptr, io, &occ_jobs);
+      if (!rc && feeds && p[i].video_type == RBT_VIDEO_OCCUPANCY) {
+        const EncStreamDesc& d = eb[gi].desc[q];
+        if (d.n_frames > 0) { occ_src[i].occ = d.src[0][0]; occ_src[i].in_step = d.n_frames > 1 ? (size_t)(d.src[0][1] - d.src[0][0]) : 0; occ_src[i].n = d.n_frames; occ_src[i].ow = d.w; occ_src[i].oh = d.h; occ_src[i].pipeline = gi; }
+      }
+    }
+    if (!rc) { rc = encode_build(eb[gi]); if (!rc) rc = encode_upload_lists(eb[gi]); if (rc) err = eb[gi].err; }
+    if (rc) break;
+    chained[gi] = 1;
+  }
+  (void)group_of; (void)pos_of;
   // Pipelines that share a HIP stream would parse one after the other; their slices go into one merged launch instead, so
   // that all parsers of the stream run side by side and only the (short) tails of the pipelines follow each other.
   j.parse_timed.assign(ng, 1); j.recon_timed.assign(ng, 1);
@@ -504,8 +542,15 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
     rbtk::timer_end(T_RECON);
     for (int gi : grp) { db[gi].recon_external = true; j.recon_timed[gi] = gi == lead; }
   }
+  // enqueue order: longest pipeline first - except that a pipeline whose occupancy maps others wait for goes in front of them (an event has to be recorded before it is waited for)
+  std::vector<int> lorder; std::vector<char> feeds_any(ng, 0), consumes(ng, 0);
+  for (const OccJob& oj : occ_jobs) feeds_any[occ_src[oj.source].pipeline] = 1;
+  for (int g = 0; g < ng; g++) for (const EncStreamDesc& d : eb[g].desc) consumes[g] |= !d.occ4.empty();
+  for (int k = 0; k < ng; k++) if (feeds_any[order[k]]) lorder.push_back(order[k]);
+  for (int k = 0; k < ng; k++) if (!feeds_any[order[k]]) lorder.push_back(order[k]);
+  std::vector<int> occ_marks;
   for (int k = 0; k < ng && !rc; k++) {
-    const int gi = order[k], sid = job_stream(j, gi); rbtk::set_stream(sid);
+    const int gi = lorder[k], sid = job_stream(j, gi); rbtk::set_stream(sid);
     const std::vector<PoolJob>& jobs = pool_jobs[gi];
     if (!chained[gi]) { rc = decode_launch(db[gi]); if (rc) { err = db[gi].err; break; } continue; }
     // Intra pictures of the output only read the decoded pictures they are re-encoded from. When those are complete
@@ -518,7 +563,7 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
       fork_level = std::max(fork_level, (size_t)db[gi].frames[db[gi].stream_first[ds] + local].level);
     }
     int intra_done = 0;
-    const bool fork = k == 0 && j.has_aux && ng <= rbtk::RBT_AUX_STREAM && jobs.empty() && e.pad_jobs.empty() && fork_level + 1 < n_levels;   // longest pipeline only: one spare stream
+    const bool fork = gi == order[0] && j.has_aux && ng <= rbtk::RBT_AUX_STREAM && jobs.empty() && e.pad_jobs.empty() && fork_level + 1 < n_levels;   // longest pipeline only: one spare stream
     const bool banded = db[gi].d_save != nullptr && !db[gi].ordered_parse;
     rc = banded ? decode_launch_chunked(db[gi], parse_bands(), sid, aux) : decode_launch_parse(db[gi]);
     if (rc) { err = db[gi].err; break; }
@@ -528,6 +573,7 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
       if (fork && l == fork_level) {
         e.aux_stream = aux;
         rbtk::stream_wait(e.aux_stream, sid);
+        if (consumes[gi]) for (int m : occ_marks) rbtk::stream_wait_mark(e.aux_stream, m);      // occupancy-aware coding: the maps are made on the occupancy pipeline's stream
         rbtk::set_stream(e.aux_stream); encode_launch_intra(e); intra_done = rbtk::stream_mark(e.aux_stream); encode_launch_entropy_intra(e); rbtk::set_stream(sid);
       }
     }
@@ -545,6 +591,11 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
       }
       rbtk::timer_end(T_POOL);
     }
+    if (feeds_any[gi]) {
+      for (const OccJob& oj : occ_jobs) { const OccSource& os = occ_src[oj.source]; if (os.pipeline == gi) rbtk::launch_occ_units(os.occ, os.in_step, os.n, os.ow, os.oh, oj.W, oj.w4, oj.h4, oj.maps); }
+      occ_marks.push_back(rbtk::stream_mark(sid));
+    }
+    if (consumes[gi]) for (int m : occ_marks) rbtk::stream_wait_mark(sid, m);
     if (fork) rbtk::stream_wait_mark(sid, intra_done); else { encode_launch_intra(e); encode_launch_entropy_intra(e); }
     encode_launch_rest(e);
     if (fork) rbtk::stream_wait(sid, e.aux_stream);      // the intra pictures' entropy coding on the auxiliary stream

@@ -38,8 +38,12 @@ def _job(args):
     kind, idx, piece, qp, rows, env = args
     os.environ.update(env)
     import oracle_lib as O
-    vt = {"occ": 0, "geo": 1, "attr": 19}[kind]
     t = time.time()
+    if kind == "gof":      # one point-cloud frame as transcodeData sees it: (occupancy, geometry, attribute), occupancy-aware coding on
+        gq, aq = qp
+        out = O.transcode_data(list(piece), [(0, 8, 4, 5, rows, 0, 0), (1, gq, 4, 5, rows, 0, 1), (19, aq, 4, 5, rows, 0, 1)])
+        return kind, idx, out, time.time() - t
+    vt = {"occ": 0, "geo": 1, "attr": 19}[kind]
     out = O.transcode_substream(piece, vt, qp, 4, 5, rows, 0)
     return kind, idx, out, time.time() - t
 
@@ -79,6 +83,7 @@ def main():
     ap.add_argument("--rows", type=int, default=-1)
     ap.add_argument("--jobs", type=int, default=8)
     ap.add_argument("--anchor", action="store_true")
+    ap.add_argument("--f4", action="store_true", help="occupancy-aware coding (occupancy_rd) through oracle_transcode_data")
     ap.add_argument("--env", nargs="*", default=[])
     ap.add_argument("--json", default=None)
     ap.add_argument("--no-d1", action="store_true")
@@ -96,21 +101,28 @@ def main():
     k = a.frames
     ins = {kind: split_pairs(fixture(kind))[:k] for kind in ("occ", "geo", "attr")}
     tasks = []
-    for i in range(k):
-        tasks += [("attr", i, ins["attr"][i], aq, a.rows, env), ("geo", i, ins["geo"][i], gq, a.rows, env)]
     nd1 = 0 if a.no_d1 else min(k, a.d1_frames, 4)
-    for i in range(max(nd1, 1)):
-        tasks.append(("occ", i, ins["occ"][i], 8, a.rows, env))
+    if a.f4:
+        for i in range(k):
+            tasks.append(("gof", i, (ins["occ"][i], ins["geo"][i], ins["attr"][i]), (gq, aq), a.rows, env))
+    else:
+        for i in range(k):
+            tasks += [("attr", i, ins["attr"][i], aq, a.rows, env), ("geo", i, ins["geo"][i], gq, a.rows, env)]
+        for i in range(max(nd1, 1)):
+            tasks.append(("occ", i, ins["occ"][i], 8, a.rows, env))
     t0 = time.time()
     with ProcessPoolExecutor(min(a.jobs, len(tasks))) as ex:
         res = list(ex.map(_job, tasks))
     outs = {"geo": [None] * k, "attr": [None] * k, "occ": [None] * k}
     cpu_s = 0.0
     for kind, idx, out, dt in res:
-        outs[kind][idx] = out
+        if kind == "gof":
+            outs["occ"][idx], outs["geo"][idx], outs["attr"][idx] = out
+        else:
+            outs[kind][idx] = out
         cpu_s += dt
     geo_src, attr_src, _ = synth.make_gof_maps(W, H, k, SEED)
-    rep = {"frames": k, "rate": a.rate, "env": env, "wall_s": round(time.time() - t0, 1), "cpu_s": round(cpu_s, 1)}
+    rep = {"frames": k, "rate": a.rate, "f4": bool(a.f4), "env": env, "wall_s": round(time.time() - t0, 1), "cpu_s": round(cpu_s, 1)}
     for kind, src in (("geo", geo_src), ("attr", attr_src)):
         b_in = sum(len(x) for x in ins[kind])
         b_out = sum(len(x) for x in outs[kind])

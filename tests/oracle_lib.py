@@ -19,14 +19,14 @@ class OracleVideo(C.Structure):
 
 class TranscodeParams(C.Structure):
     _fields_ = [("video_type", C.c_int), ("qp", C.c_int), ("occupancy_precision", C.c_int), ("log2_ctb", C.c_int),
-                ("ctb_rows_per_slice", C.c_int), ("md5_sei", C.c_int)]
+                ("ctb_rows_per_slice", C.c_int), ("md5_sei", C.c_int), ("occupancy_rd", C.c_int)]
 
 
 class EncParams(C.Structure):
     """oracle_enc_params (oracle/hevc_enc.h)"""
     _fields_ = [(n, C.c_int) for n in ("width", "height", "bit_depth", "qp", "i_qp_offset", "gop", "lossless", "log2_ctb", "ctb_rows_per_slice", "md5_sei")] + \
                [("stress_seed", C.c_uint32)] + [(n, C.c_int) for n in ("conf_win_right", "conf_win_bottom", "hm_like", "p_qp_offset")] + \
-               [("hint_modes", C.c_void_p), ("hint_w4", C.c_int), ("hint_h4", C.c_int)]
+               [("hint_modes", C.c_void_p), ("hint_w4", C.c_int), ("hint_h4", C.c_int), ("occ4", C.c_void_p), ("occ4_w", C.c_int), ("occ4_h", C.c_int)]
 
 
 class OPatch(C.Structure):

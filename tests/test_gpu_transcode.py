@@ -270,3 +270,44 @@ def test_transform_skip_blocks(ctx, monkeypatch, w, h, log2_ctb, rows):
         assert on != off                                                      # transform skip blocks were chosen (per block by distortion + lambda * rate)
         dec, _, _, _, chk, fail = ctx.decode(bs)
         assert (chk, fail) == (4, 0) and np.array_equal(dec, rec)
+
+
+def test_occupancy_aware_coding_matches_oracle(ctx):
+    """rbt_stream_params.occupancy_rd on the GPU: geometry / attribute streams coded with the occupancy map the output carries (made on the
+    occupancy pipeline's stream, waited for by the others) == oracle_transcode_data for every case of tests/test_hostemu_parity.py occupancy_rd_cases, fewer bytes,
+    the occupied samples as good as without; then with two jobs in flight (the maps of one job must not be read by another)."""
+    import test_hostemu_parity as T
+    R = rbt_lib.module()
+    T.check_occupancy_rd(ctx, R)
+    cases = T.occupancy_rd_cases(R)[:3]
+    want = [ctx.transcode_gof(s, p) for s, p in cases]
+    jobs = [ctx.submit_gof(s, p) for s, p in cases[:2]]
+    assert [ctx.wait_gof(j) for j in jobs] == want[:2]
+
+
+def test_occupancy_aware_coding_full_size_frame(ctx):
+    """one point-cloud frame of the committed 1280x1280 fixture, R5 -> R3 with occupancy_rd: == oracle, and what the option is for - at least 40 % fewer geometry bytes
+    with D1 of the decoded cloud within 0.1 dB of the plain transcode (bench.py reports the whole GOF)."""
+    import os
+    gs = rbt_lib.module_file("gof_shard")
+    R = rbt_lib.module()
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    first = [gs.split_pairs(open(os.path.join(gold, f"hm_r5_1280x1280_f32_{k}.annexb"), "rb").read())[0] for k in ("occ", "geo", "attr")]
+    P = R.StreamParams
+    on_p = [P(0, 8, 4, 5, -1, 0, 0, 0), P(1, 24, 4, 5, -1, 0, 0, 1), P(19, 32, 4, 5, -1, 0, 0, 1)]
+    on = ctx.transcode_gof(first, on_p)
+    assert on == O.transcode_data(first, [(p.video_type, p.qp, p.occupancy_precision, p.log2_ctb, p.ctb_rows_per_slice, p.md5_sei, p.occupancy_rd) for p in on_p])
+    off = ctx.transcode_gof(first, [P(p.video_type, p.qp, 4, 5, -1, 0, 0, 0) for p in on_p])
+    assert len(on[1]) < 0.6 * len(off[1]) and len(on[2]) < 0.85 * len(off[2])
+    w = h = 1280
+    src = synth.make_maps(w, h, 1051)
+    pats = synth.atlas_patches(R, w, h, 1051)
+
+    def cloud(occ_plane, prec, g2):
+        return ctx.reconstruct(R.AtlasParams(w, h, 16, prec, 2, 1, 1, 0), pats, occ_plane, g2[0][: w * h].reshape(h, w), g2[1][: w * h].reshape(h, w), 10)[0]
+    c_src = cloud(src["occ_full"].astype(np.uint16), 1, src["geo"])
+    d1 = []
+    for outs in (off, on):
+        occ = ctx.decode(outs[0])[0][0][: (w // 4) * (h // 4)].reshape(h // 4, w // 4)
+        d1.append(ctx.d1(c_src, cloud(occ, 4, ctx.decode(outs[1])[0]))["psnr"])
+    assert abs(d1[1] - d1[0]) < 0.1, d1

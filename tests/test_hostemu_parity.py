@@ -292,3 +292,48 @@ def test_transform_skip_8_bit_streams(ctx, w, h, log2_ctb, rows):
         assert bs == on
         dec, _, _, bd, chk, fail = ctx.decode(bs)
         assert (bd, chk, fail) == (8, 2, 0) and np.array_equal(dec, rec)
+
+
+def occupancy_rd_cases(R):
+    """(streams, params) lists for occupancy-aware coding (rbt_stream_params.occupancy_rd), shared with tests/test_gpu_transcode.py"""
+    P = R.StreamParams
+
+    def gof(w, h, n, seed, l2=6):
+        geo, attr, occ = synth.make_gof(w, h, n, seed)
+        return [O.encode(occ, w // 2, h // 2, 8, 8, gop=1, lossless=1, i_qp_offset=0, log2_ctb=l2, rows_per_slice=0)[0],
+                O.encode(geo, w, h, 10, 16, gop=2, log2_ctb=l2, rows_per_slice=0)[0], O.encode(attr, w, h, 10, 22, gop=2, log2_ctb=l2, rows_per_slice=0)[0]]
+    a, b = gof(128, 128, 2, 101), gof(192, 128, 1, 202)
+    return [
+        (a, [P(0, 8, 4, 5, -1, 0, 0, 0), P(1, 24, 4, 5, -1, 0, 0, 1), P(19, 32, 4, 5, -1, 0, 0, 1)]),                    # the rate points' form: wavefront rows
+        (b, [P(0, 8, 4, 5, 1, 1, 0, 0), P(1, 32, 4, 5, 1, 1, 0, 1), P(19, 42, 4, 6, 0, 1, 0, 0)]),                       # row slices; 64x64 CTBs without it on the attribute stream
+        (a + b, [P(0, 8, 4, 5, -1, 0, 0, 0), P(1, 24, 4, 5, -1, 0, 0, 1), P(19, 32, 4, 5, -1, 0, 0, 1)] * 2),            # two GOFs in one call: each with its own occupancy map
+        (a, [P(0, 8, 2, 5, -1, 0, 0, 0), P(1, 24, 2, 5, -1, 0, 0, 1), P(19, 32, 2, 5, -1, 0, 0, 1)]),                    # occupancy passed through (precision 2): every sample counts
+        ([a[1], a[0], a[2]], [P(1, 24, 4, 5, -1, 0, 0, 1), P(0, 8, 4, 5, -1, 0, 0, 0), P(19, 32, 4, 5, -1, 0, 0, 1)]),   # geometry in front of the occupancy stream: coded without it
+    ]
+
+
+def check_occupancy_rd(ctx, R):
+    for streams, params in occupancy_rd_cases(R):
+        got = ctx.transcode_gof(streams, params)
+        want = O.transcode_data(streams, [(p.video_type, p.qp, p.occupancy_precision, p.log2_ctb, p.ctb_rows_per_slice, p.md5_sei, p.occupancy_rd) for p in params])
+        assert got == want
+    # what it is for: fewer bytes at (about) the same quality of the samples the decoder makes points of
+    streams, params = occupancy_rd_cases(R)[0]
+    off = ctx.transcode_gof(streams, [R.StreamParams(p.video_type, p.qp, p.occupancy_precision, p.log2_ctb, p.ctb_rows_per_slice, 0, 0, 0) for p in params])
+    on = ctx.transcode_gof(streams, params)
+    assert on[0] == off[0] and len(on[1]) < 0.9 * len(off[1]) and len(on[2]) < 0.9 * len(off[2])
+    w = h = 128
+    occ4 = ctx.decode(on[0])[0][:, : (w // 4) * (h // 4)].reshape(-1, h // 4, w // 4) > 0
+    m = occ4.repeat(4, 1).repeat(4, 2).repeat(2, 0)                                   # two maps per point-cloud frame
+    src = ctx.decode(streams[1])[0][:, : w * h].reshape(-1, h, w).astype(np.float64)
+    for s in (1, 2):
+        src = ctx.decode(streams[s])[0][:, : w * h].reshape(-1, h, w).astype(np.float64)
+        e_on = ((ctx.decode(on[s])[0][:, : w * h].reshape(-1, h, w) - src) ** 2)[m].mean()
+        e_off = ((ctx.decode(off[s])[0][:, : w * h].reshape(-1, h, w) - src) ** 2)[m].mean()
+        assert e_on < 1.25 * e_off, (s, e_on, e_off)
+    with pytest.raises(R.RbtError):
+        ctx.transcode_gof(streams, [params[0], R.StreamParams(1, 24, 4, 5, -1, 0, 1, 1), params[2]])      # not together with verify_md5
+
+
+def test_occupancy_aware_coding_matches_oracle(ctx):
+    check_occupancy_rd(ctx, rbt_lib.module())
