@@ -81,7 +81,8 @@ int rbt_owns_gof(const rbt_ctx* ctx, int gof_index);
 int rbt_world(const rbt_ctx* ctx, int* world_rank, int* world_size);
 void rbt_destroy(rbt_ctx* ctx);
 const char* rbt_strerror(int code);
-const char* rbt_last_error(rbt_ctx* ctx);   /* what the last failing call on this context had to say (e.g. which syntax element it rejected); "" if none */
+const char* rbt_last_error(rbt_ctx* ctx);   /* what the LAST call on this context had to say if it failed (e.g. which syntax element it rejected); "" if it succeeded or gave no
+                                              * detail: every entry point that takes the context starts by clearing the text. The pointer is valid until the next call on the context. */
 void rbt_free(void* p);
 const char* rbt_version(void);
 

@@ -363,6 +363,7 @@ int oracle_v3c_transcode(const uint8_t* in, size_t n, int occupancy_precision, i
     int prec = (int)((cl + 7) / 8); if (cl <= 0) prec = 0;      /* ceil(cl / 8.0) for cl = -1, 0 is 0 */
     if (prec < 1) prec = 1;
     if (prec > 8) prec = 8;
+    while (prec < 8 && ((uint64_t)max_unit >> (8 * prec)) != 0) prec++;   /* not the reference: its rule is one byte short for a largest unit of exactly 256^k bytes (the library deviates the same way, rbt_v3c_write) */
     if (prec < forced_precision_bytes) prec = forced_precision_bytes;
     bytebuf b = {0, 0, 0};
     bb_put(&b, (uint8_t)((prec - 1) << 5));

@@ -72,7 +72,8 @@ void launch_enc_inter(RbtFrame* frames, const RbtSlice* slices, const int32_t* f
 void launch_enc_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs);
 void launch_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list, int n_slices, int max_log2_ctb);
 // wavefront mode: every slice segment (one per CTB row) of the listed pictures; rows of a picture hand their context variables down (rbt_kernels.hip k_entropy_wave)
-void set_jobs_in_flight(int depth);   // hint: how many transcode jobs the caller keeps in flight (sizes the wavefront launches)
+void set_jobs_in_flight(int depth);   // hint: how many transcode jobs the caller keeps in flight on the selected device (sizes the wavefront launches); kept per device
+int jobs_in_flight();                 // ... as last announced for the selected device
 void launch_entropy_wave(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int max_log2_ctb, uint32_t* ticket);
 // gathers the slice data of every slice segment into one contiguous buffer (dst_off = exclusive prefix sum of out_size)
 void launch_pack(const uint8_t* out, const RbtSlice* slices, const uint32_t* dst_off, uint8_t* packed, int n_slices);

@@ -26,6 +26,7 @@ struct Dev {
   hipEvent_t ev[RBT_N_LANES][16][2];
   char name[256] = "";
   std::vector<PoolBlock> pool_free, pool_live; std::mutex pool_mu;
+  int depth = 1, wave_div = 2;          // jobs the caller keeps in flight on THIS device (set_jobs_in_flight) and what follows from it (contexts on other devices have their own)
 };
 static Dev* g_devs[RBT_MAX_DEVICES] = {};
 static std::mutex g_devs_mu;
@@ -395,9 +396,9 @@ void launch_enc_analyse(RbtFrame* frames, const RbtSlice* slices, const int32_t*
 // rows ramp up and the last ramp down those waves wait, holding their LDS. With many jobs in flight the GPU is full anyway and idle residents only take
 // room from the other jobs' kernels: an eighth of the width then (measured with 16 GOFs in flight, 1280 x 1280, 40 CTBs wide: 625 / 642 / 660 / 631 / 548
 // frames/s with 20 / 10 / 5 / 4 / 2 waves per picture). set_jobs_in_flight; RBT_WAVE_DIV overrides the divisor.
-static int g_wave_div = 2;
-void set_jobs_in_flight(int depth) { static int env = -1; if (env < 0) { const char* e = getenv("RBT_WAVE_DIV"); env = e ? atoi(e) : 0; } g_wave_div = env > 0 ? env : (depth > 4 ? 8 : 2); }
-static int wave_rows_in_flight(int max_w_ctb, int max_h_ctb) { int K = (max_w_ctb + g_wave_div - 1) / g_wave_div; if (K < 1) K = 1; return K > max_h_ctb ? max_h_ctb : K; }
+void set_jobs_in_flight(int depth) { static int env = -1; if (env < 0) { const char* e = getenv("RBT_WAVE_DIV"); env = e ? atoi(e) : 0; } if (!t_dev) return; t_dev->depth = depth; t_dev->wave_div = env > 0 ? env : (depth > 4 ? 8 : 2); }
+int jobs_in_flight() { return t_dev ? t_dev->depth : 1; }
+static int wave_rows_in_flight(int max_w_ctb, int max_h_ctb) { const int g_wave_div = t_dev ? t_dev->wave_div : 2; int K = (max_w_ctb + g_wave_div - 1) / g_wave_div; if (K < 1) K = 1; return K > max_h_ctb ? max_h_ctb : K; }
 void launch_enc_intra(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int row_mode, int max_log2_ctb, uint32_t* ticket) {
   if (n_frames <= 0) return;
   const bool small = max_log2_ctb <= 5;

@@ -1046,6 +1046,7 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
   // row task: this wave starts at a CTB row of a wavefront stream whose upper neighbour another wave parses
   int import_row = -1;                                       // set before the CTB loop
   int ctb_limit = RBT_UNI(gs->ctb_limit); uint32_t seg_first = 0;   // of the segment being read: CTBs it may hold (0: to its end), value of `count` at its start
+  int seg_end = RBT_UNI(gs->end_addr);                       // ... and the CTB address it has to end at (RbtSlice::end_addr)
   uint32_t seen_above = 0;
   s.L = lds; s.left_ok = 0; s.corner_ok = 0; s.corner_pm = s.corner_dm = s.corner_ref = s.corner_mv = 0; s.ctb_x = s.ctb_y = 0;
   if (phase == 0) { RBT_LDS_AS uint16_t* a_slice = pz_above_slice(lds, cap4); RBT_PAR_FOR(i, cap4 / 4) a_slice[i] = 0xFFFF; }
@@ -1082,7 +1083,7 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
   int prefix_row = wpp && addr % pzc_w_ctb(&s) ? addr / pzc_w_ctb(&s) : -1; const int prefix_need = addr % pzc_w_ctb(&s);
   uint32_t count = 0;
   s.qp_key = 0x7FFFFFFF; s.qp_packed = 0;
-  if (phase != 0) seg = RBT_UNI(sv->sc[22]);
+  if (phase != 0) { seg = RBT_UNI(sv->sc[22]); seg_end = RBT_UNI(slices[seg].end_addr); }
   rbt_cd_start(&s.c, rbsp + (uint32_t)RBT_UNI(slices[seg].data_off), (uint32_t)RBT_UNI(slices[seg].data_size));
   if (phase == 0) {
     rbt_ctx_init(&s.c.cs, init_type, pzs_qp(&s));
@@ -1139,6 +1140,8 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
       // needs of that row: its own column at the start of the row, the next column always
       const int wc = pzc_w_ctb(&s);
       seen_above = rbt_flag_wait_seen(&s.f->prow_done[ry - 1], (uint32_t)(rx + 2 < wc ? rx + 2 : wc), seen_above, &s.f->error);
+      // the wait ran out, or the picture went bad meanwhile (the wave of the row above gave up and released its rows): what it would hand over is not there
+      { const int32_t pe = rbt_err_peek(&s.f->error); if (pe) { s.error = pe; break; } }
       if (rx == 0) pz_import_above(&s, 0, ry);
       pz_import_above(&s, rx + 1, ry);
     }
@@ -1187,11 +1190,14 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
       rbt_cd_restart_aligned(&s.c);
     }
     if (!end && ctb_limit > 0 && (int)(count - seg_first) >= ctb_limit) { s.error = 1; break; }   // the substream should have ended here
+    // every entry covers exactly the CTBs up to where the next one of the picture starts: ending early leaves a hole (and a row task below waiting for a row nobody
+    // parses), going on runs into CTBs another wave writes
+    if ((end || (ctb_limit > 0 && (int)(count - seg_first) == ctb_limit)) ? addr != seg_end : addr >= seg_end) { s.error = 3; break; }
     if (end) {
       const int nxt = RBT_UNI(slices[seg].next_seg);
       if (nxt >= 0) {   // dependent slice segment: same slice, the context variables and the QpY predictor go on (9.3.1, 8.6.1); its own arithmetic codeword
         if (RBT_UNI(slices[nxt].ctb_addr) != addr) { s.error = 1; break; }
-        seg = nxt; end = 0; ctb_limit = RBT_UNI(slices[seg].ctb_limit); seg_first = count;
+        seg = nxt; end = 0; ctb_limit = RBT_UNI(slices[seg].ctb_limit); seg_first = count; seg_end = RBT_UNI(slices[seg].end_addr);
         rbt_cd_start(&s.c, rbsp + (uint32_t)RBT_UNI(slices[seg].data_off), (uint32_t)RBT_UNI(slices[seg].data_size));
       }
     }

@@ -114,6 +114,14 @@ RBT_DEV uint32_t rbt_flag_wait_seen(const uint32_t* p, uint32_t need, uint32_t s
 }
 #endif
 
+// the picture's error word as other waves have left it (a wave that waited in vain, or for a row whose wave gave up, must not go on with what it did not get)
+RBT_DEV int32_t rbt_err_peek(const int32_t* err) {
+#ifdef RBT_HOSTEMU
+  return *err;
+#else
+  return __builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#endif
+}
 // Bit-field read of a packed wave-uniform word. On the GPU it is one scalar instruction the compiler may neither hoist nor
 // keep alive: rarely used parameters then cost one SGPR per word instead of one (spilled) SGPR per field.
 template <int SH, int N> RBT_DEV uint32_t rbt_bfe(uint32_t w) {

@@ -142,6 +142,8 @@ struct RbtSlice {                // one per slice segment, parsed on the host (7
                                  // above (context variables after its second CTB, bottom line of its units) from the wave that parses that row (rbt_parse.h)
   int32_t next_seg;              // decoder: the next dependent segment of the same slice that is NOT a row task (-1: none); the same wave goes on with it
   int32_t head;                  // decoder: index of the independent segment that heads this segment's slice (= own index for an independent one)
+  int32_t end_addr;              // decoder: the CTB address this entry has to end at: where the next slice segment (or substream entry) of the picture starts, or the picture's CTB
+                                 // count - the host knows the starts, only the parser finds the ends: an entry that ends anywhere else leaves a hole or runs into its successor
   int32_t ctb_limit;             // decoder: > 0: this entry is ONE substream (CTB row) of a segment with entry points: stop after that many CTBs, at end_of_subset_one_bit
   int32_t ref_frame[RBT_MAX_REFS];   // batch frame index of RefPicList0[i]
   int32_t ref_poc[RBT_MAX_REFS];

@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include "rbt_batch.h"
 #include "rbt_transcode.h"
 #include "rbt_pcc.h"
@@ -16,7 +17,10 @@ struct rbt_job { rbt::GofJob* j; rbt_ctx* owner; };
 struct DevState { rbt_job* jobs[RBT_MAX_JOBS] = {}; int depth = 4; std::mutex mu; };
 static DevState g_dev[16];
 static_assert(RBT_MAX_JOBS == rbtk::RBT_JOB_SLOTS, "job slots");
-#define RBT_ENTER(ctx) DevState& D = g_dev[(ctx)->device]; std::lock_guard<std::mutex> lk(D.mu); if (rbtk::dev_select((ctx)->device)) return RBT_ERR_NO_DEVICE
+// every context entry point starts with an empty error text (rbt_last_error describes the LAST call; the pointer it returns is valid until the next call on the context)
+#define RBT_ENTER(ctx) DevState& D = g_dev[(ctx)->device]; std::lock_guard<std::mutex> lk(D.mu); (ctx)->last_err.clear(); if (rbtk::dev_select((ctx)->device)) return RBT_ERR_NO_DEVICE
+// no exception crosses the C ABI: allocation failures of the host side (std::vector, std::string, the hashing threads) come back as error codes
+#define RBT_CATCH catch (const std::bad_alloc&) { return RBT_ERR_NOMEM; } catch (...) { return RBT_ERR_NO_DEVICE; }
 
 extern "C" {
 
@@ -38,7 +42,7 @@ const char* rbt_strerror(int code) {
 }
 void rbt_free(void* p) { free(p); }
 
-int rbt_create(rbt_ctx** ctx, int device, int world_rank, int world_size) {
+int rbt_create(rbt_ctx** ctx, int device, int world_rank, int world_size) try {
   if (!ctx) return RBT_ERR_PARAM;
   *ctx = nullptr;
   if (world_size < 1 || world_rank < 0 || world_rank >= world_size) return RBT_ERR_PARAM;
@@ -48,7 +52,7 @@ int rbt_create(rbt_ctx** ctx, int device, int world_rank, int world_size) {
   rbt_ctx* c = new rbt_ctx(); c->device = device; c->rank = world_rank; c->world = world_size; memset(&c->stats, 0, sizeof(c->stats));
   *ctx = c;
   return RBT_OK;
-}
+} RBT_CATCH
 void rbt_destroy(rbt_ctx* ctx) {
   if (ctx) {
     DevState& D = g_dev[ctx->device]; std::lock_guard<std::mutex> lk(D.mu);
@@ -65,7 +69,7 @@ int rbt_owns_gof(const rbt_ctx* ctx, int gof_index) { return ctx && gof_index >=
 int rbt_world(const rbt_ctx* ctx, int* rank, int* size) { if (!ctx) return RBT_ERR_PARAM; if (rank) *rank = ctx->rank; if (size) *size = ctx->world; return RBT_OK; }
 int rbt_get_stats(rbt_ctx* ctx, rbt_stats* out) { if (!ctx || !out) return RBT_ERR_PARAM; *out = ctx->stats; return RBT_OK; }
 
-int rbt_decode(rbt_ctx* ctx, const uint8_t* annexb, size_t n, int verify_md5, rbt_video* out) {
+int rbt_decode(rbt_ctx* ctx, const uint8_t* annexb, size_t n, int verify_md5, rbt_video* out) try {
   if (!ctx || !annexb || !out) return RBT_ERR_PARAM;
   RBT_ENTER(ctx);
   memset(out, 0, sizeof(*out));
@@ -77,7 +81,7 @@ int rbt_decode(rbt_ctx* ctx, const uint8_t* annexb, size_t n, int verify_md5, rb
   ctx->stats.k_parse_ms = rbtk::timer_ms(rbt::T_PARSE); ctx->stats.k_recon_ms = rbtk::timer_ms(rbt::T_RECON);
   if (verify_md5 && out->md5_failed) return RBT_ERR_MD5;
   return RBT_OK;
-}
+} RBT_CATCH
 
 // PCCVideoBitstream.cpp:174-184
 static size_t end_of_nalu(const uint8_t* d, size_t size, size_t start) {
@@ -87,7 +91,7 @@ static size_t end_of_nalu(const uint8_t* d, size_t size, size_t start) {
   return size;
 }
 // PCCVideoBitstream::byteStreamToSampleStream (PCCVideoBitstream.cpp:85-112), precision 4, no emulation prevention handling
-int rbt_byte_to_sample_stream(const uint8_t* in, size_t n, uint8_t** out, size_t* n_out) {
+int rbt_byte_to_sample_stream(const uint8_t* in, size_t n, uint8_t** out, size_t* n_out) try {
   if (!in || !out || !n_out || n < 4) return RBT_ERR_PARAM;
   std::vector<uint8_t> v; v.reserve(n + 64);
   size_t start = 0, end = 0;
@@ -102,9 +106,9 @@ int rbt_byte_to_sample_stream(const uint8_t* in, size_t n, uint8_t** out, size_t
   *out = (uint8_t*)malloc(v.size() ? v.size() : 1); if (!*out) return RBT_ERR_NOMEM;
   memcpy(*out, v.data(), v.size()); *n_out = v.size();
   return RBT_OK;
-}
+} RBT_CATCH
 // PCCVideoBitstream::sampleStreamToByteStream (PCCVideoBitstream.cpp:114-172), HEVC, precision 4
-int rbt_sample_to_byte_stream(const uint8_t* in, size_t n, uint8_t** out, size_t* n_out) {
+int rbt_sample_to_byte_stream(const uint8_t* in, size_t n, uint8_t** out, size_t* n_out) try {
   if (!in || !out || !n_out || n < 4) return RBT_ERR_PARAM;
   std::vector<uint8_t> v; v.reserve(n + 64);
   size_t sc = 4, start = 0, end = 0;
@@ -121,24 +125,24 @@ int rbt_sample_to_byte_stream(const uint8_t* in, size_t n, uint8_t** out, size_t
   *out = (uint8_t*)malloc(v.size() ? v.size() : 1); if (!*out) return RBT_ERR_NOMEM;
   memcpy(*out, v.data(), v.size()); *n_out = v.size();
   return RBT_OK;
-}
+} RBT_CATCH
 
 static int submit(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, rbt_job** job, bool gof_rule);
 // transcodeVideo re-encodes whatever it is handed (an occupancy stream with occupancyPrecision != 4 is re-encoded without pooling)
-int rbt_transcode_substream(rbt_ctx* ctx, const uint8_t* annexb_in, size_t n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out) {
+int rbt_transcode_substream(rbt_ctx* ctx, const uint8_t* annexb_in, size_t n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out) try {
   if (!ctx || !annexb_in || !p || !annexb_out || !n_out) return RBT_ERR_PARAM;
   rbt_job* job = nullptr;
   int rc = submit(ctx, 1, &annexb_in, &n_in, p, &job, false);
   if (rc) return rc;
   return rbt_wait_gof(ctx, job, annexb_out, n_out);
-}
-int rbt_transcode_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out) {
+} RBT_CATCH
+int rbt_transcode_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, uint8_t** annexb_out, size_t* n_out) try {
   if (!ctx || n < 1 || n > RBT_MAX_STREAMS || !annexb_in || !n_in || !p || !annexb_out || !n_out) return RBT_ERR_PARAM;
   rbt_job* job = nullptr;
   int rc = rbt_submit_gof(ctx, n, annexb_in, n_in, p, &job);
   if (rc) return rc;
   return rbt_wait_gof(ctx, job, annexb_out, n_out);
-}
+} RBT_CATCH
 int rbt_submit_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, rbt_job** job) { return submit(ctx, n, annexb_in, n_in, p, job, true); }
 static int submit(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, rbt_job** job, bool gof_rule) {
   if (!ctx || n < 1 || n > RBT_MAX_STREAMS || !annexb_in || !n_in || !p || !job) return RBT_ERR_PARAM;
@@ -151,21 +155,21 @@ static int submit(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const si
   D.jobs[slot] = j; *job = j;
   return RBT_OK;                       // errors of the build surface in rbt_wait_gof, which also releases the job
 }
-int rbt_set_depth(rbt_ctx* ctx, int max_in_flight) {
+int rbt_set_depth(rbt_ctx* ctx, int max_in_flight) try {
   if (!ctx || max_in_flight < 1 || max_in_flight > RBT_MAX_JOBS) return RBT_ERR_PARAM;
   RBT_ENTER(ctx);
   for (int s = 0; s < RBT_MAX_JOBS; s++) if (D.jobs[s]) return RBT_ERR_BUSY;
   D.depth = max_in_flight;
   return RBT_OK;
-}
-int rbt_get_depth(rbt_ctx* ctx) {
+} RBT_CATCH
+int rbt_get_depth(rbt_ctx* ctx) try {
   if (!ctx) return RBT_ERR_PARAM;
   RBT_ENTER(ctx);
   return D.depth;
-}
+} RBT_CATCH
 // Measured on one MI355X (tools/short_run_sweep.sh, tools/walk_shape_sweep.sh): a long walk keeps max_jobs jobs of 2 GOFs in flight; a walk shorter than 48 GOFs
 // is all ramp-up and drain and runs as at most 7 jobs (2 up to 12 GOFs), which then own several hardware queues each. Same rule as gof_shard.job_shape.
-int rbt_job_shape(int n_gofs, int max_jobs, int* gofs_per_job, int* jobs_in_flight) {
+int rbt_job_shape(int n_gofs, int max_jobs, int* gofs_per_job, int* jobs_in_flight) try {
   if (n_gofs < 0 || max_jobs < 1 || !gofs_per_job || !jobs_in_flight) return RBT_ERR_PARAM;
   if (max_jobs > RBT_MAX_JOBS) max_jobs = RBT_MAX_JOBS;
   if (n_gofs >= 48) { *gofs_per_job = 2; *jobs_in_flight = max_jobs; return RBT_OK; }
@@ -174,15 +178,15 @@ int rbt_job_shape(int n_gofs, int max_jobs, int* gofs_per_job, int* jobs_in_flig
   int d = (n_gofs + g - 1) / g; if (d > max_jobs) d = max_jobs; if (d < 1) d = 1;
   *gofs_per_job = g; *jobs_in_flight = d;
   return RBT_OK;
-}
-int rbt_trim(rbt_ctx* ctx) {
+} RBT_CATCH
+int rbt_trim(rbt_ctx* ctx) try {
   if (!ctx) return RBT_ERR_PARAM;
   RBT_ENTER(ctx);
   for (int s = 0; s < RBT_MAX_JOBS; s++) if (D.jobs[s]) return RBT_ERR_BUSY;
   rbtk::dev_release_pool();
   return RBT_OK;
-}
-int rbt_wait_gof(rbt_ctx* ctx, rbt_job* job, uint8_t** annexb_out, size_t* n_out) {
+} RBT_CATCH
+int rbt_wait_gof(rbt_ctx* ctx, rbt_job* job, uint8_t** annexb_out, size_t* n_out) try {
   if (!ctx || !job || !annexb_out || !n_out) return RBT_ERR_PARAM;
   RBT_ENTER(ctx);
   int slot = -1;
@@ -191,37 +195,37 @@ int rbt_wait_gof(rbt_ctx* ctx, rbt_job* job, uint8_t** annexb_out, size_t* n_out
   int rc = rbt::gof_wait(job->j, ctx->stats, ctx->last_err, annexb_out, n_out);
   D.jobs[slot] = nullptr; delete job;
   return rc;
-}
+} RBT_CATCH
 int rbt_encode(rbt_ctx* ctx, const uint16_t* yuv, int width, int height, int bit_depth, int n_frames, int qp, int gop, int lossless,
-               int log2_ctb, int ctb_rows_per_slice, int md5_sei, uint8_t** annexb_out, size_t* n_out) {
+               int log2_ctb, int ctb_rows_per_slice, int md5_sei, uint8_t** annexb_out, size_t* n_out) try {
   if (!ctx || !yuv || !annexb_out || !n_out || n_frames < 1) return RBT_ERR_PARAM;
   RBT_ENTER(ctx);
   return rbt::encode_yuv(ctx->stats, ctx->last_err, yuv, width, height, bit_depth, n_frames, qp, gop, lossless, log2_ctb, ctb_rows_per_slice, md5_sei, annexb_out, n_out);
-}
-int rbt_or_pool(rbt_ctx* ctx, const uint16_t* plane, int width, int height, int factor, uint16_t* out) {
+} RBT_CATCH
+int rbt_or_pool(rbt_ctx* ctx, const uint16_t* plane, int width, int height, int factor, uint16_t* out) try {
   if (!ctx || !plane || !out || factor < 1 || width % factor || height % factor) return RBT_ERR_PARAM;
   RBT_ENTER(ctx);
   return rbt::or_pool_host(plane, width, height, factor, out);
-}
+} RBT_CATCH
 
-int rbt_selftest_transform32(rbt_ctx* ctx, const int16_t* blocks, int n_blocks, int bit_depth, uint32_t* n_mismatch) {
+int rbt_selftest_transform32(rbt_ctx* ctx, const int16_t* blocks, int n_blocks, int bit_depth, uint32_t* n_mismatch) try {
   if (!ctx || !blocks || n_blocks < 1 || bit_depth < 8 || bit_depth > 12 || !n_mismatch) return RBT_ERR_PARAM;
   RBT_ENTER(ctx);
   return rbtk::selftest_transform32(blocks, n_blocks, bit_depth, n_mismatch) ? RBT_ERR_NO_DEVICE : RBT_OK;
-}
+} RBT_CATCH
 int rbt_reconstruct(rbt_ctx* ctx, const rbt_atlas_params* atlas, const rbt_patch* patches, int n_patches, const uint16_t* occ_luma, const uint16_t* geo_d0,
-                    const uint16_t* geo_d1, int geo_bit_depth, const uint16_t* attr_t0, const uint16_t* attr_t1, int attr_bit_depth, rbt_cloud* out) {
+                    const uint16_t* geo_d1, int geo_bit_depth, const uint16_t* attr_t0, const uint16_t* attr_t1, int attr_bit_depth, rbt_cloud* out) try {
   if (!ctx || !atlas || (!patches && n_patches) || !occ_luma || !geo_d0 || !out) return RBT_ERR_PARAM;
   RBT_ENTER(ctx);
   int rc = rbt::pcc_reconstruct(ctx->last_err, atlas, patches, n_patches, occ_luma, geo_d0, geo_d1, geo_bit_depth, attr_t0, attr_t1, attr_bit_depth, out);
   if (rc) rbt_cloud_free(out);
   return rc;
-}
+} RBT_CATCH
 void rbt_cloud_free(rbt_cloud* c) { if (!c) return; free(c->xyz); free(c->yuv); free(c->occupancy_map); free(c->block_to_patch); memset(c, 0, sizeof(*c)); }
-int rbt_d1(rbt_ctx* ctx, const int16_t* xyz_a, int n_a, const int16_t* xyz_b, int n_b, int peak, rbt_d1_result* out) {
+int rbt_d1(rbt_ctx* ctx, const int16_t* xyz_a, int n_a, const int16_t* xyz_b, int n_b, int peak, rbt_d1_result* out) try {
   if (!ctx || !xyz_a || !xyz_b || !out) return RBT_ERR_PARAM;
   RBT_ENTER(ctx);
   return rbt::pcc_d1(ctx->last_err, xyz_a, n_a, xyz_b, n_b, peak, out);
-}
+} RBT_CATCH
 
 }  // extern "C"

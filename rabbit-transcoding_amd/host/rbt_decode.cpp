@@ -59,6 +59,11 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
           head_idx = -1;
         } else if (cur < 0) { delete ps; b.err = "slice segment before the first picture"; return b.err_code = RBT_ERR_BITSTREAM; }
         else h.poc = b.frames[cur].poc;
+        // slice segments of a picture come in increasing address order (7.4.7.1), the first one at 0: with that, segment i has to cover exactly the CTBs up to the
+        // start of segment i + 1 (RbtSlice::end_addr, checked by the parser where the segment ends) - no overlap, no hole, nothing for a row task to wait for in vain
+        { const int n_ctb = sps.w_ctb * sps.h_ctb, prev = b.frames[cur].n_slices ? b.slices.back().ctb_addr : -1;
+          if ((int)h.segment_addr <= prev || (int)h.segment_addr >= n_ctb || (prev < 0 && h.segment_addr != 0)) { delete ps; b.err = "slice segment address out of order"; return b.err_code = RBT_ERR_BITSTREAM; }
+          if (prev >= 0) b.slices.back().end_addr = (int32_t)h.segment_addr; }
         RbtSlice s; memset(&s, 0, sizeof(s));
         s.frame = cur; s.data_off = (uint32_t)(nal.rbsp_off + h.data_byte_offset);
         if (h.data_byte_offset > nal.rbsp_size) { delete ps; b.err = "empty slice data"; return b.err_code = RBT_ERR_BITSTREAM; }
@@ -108,12 +113,13 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
           std::vector<size_t> u(1, h.data_byte_offset); size_t e = e0;
           for (uint32_t sz : h.entry_sizes) { e += sz; const size_t x = sent_to_rbsp(e); if (x <= u.back() || x >= nal.rbsp_size) { ok = false; break; } u.push_back(x); }
           if (ok && (size_t)h.segment_addr + first_row_ctbs + (h.entry_sizes.size() - 1) * (size_t)wc < (size_t)wc * sps.h_ctb) {
-            s.data_size = (uint32_t)(u[1] - u[0]); s.ctb_limit = first_row_ctbs;
+            s.data_size = (uint32_t)(u[1] - u[0]); s.ctb_limit = first_row_ctbs; s.end_addr = (int32_t)h.segment_addr + first_row_ctbs;
             for (size_t i = 1; i < u.size(); i++) {
               RbtSlice t = s; t.dependent = 1; t.row_task = 1; t.next_seg = -1; t.head = s.head;
               t.ctb_addr = h.segment_addr + first_row_ctbs + (int)(i - 1) * wc;
               t.data_off = (uint32_t)(nal.rbsp_off + u[i]); t.data_size = (uint32_t)((i + 1 < u.size() ? u[i + 1] : nal.rbsp_size) - u[i]);
               t.ctb_limit = i + 1 < u.size() ? wc : 0;               // the last substream ends with the segment
+              t.end_addr = t.ctb_limit ? t.ctb_addr + wc : 0;        // (the last one: where the next segment starts, filled in when that is known)
               rows.push_back(t);
             }
             b.has_row_tasks = true;
@@ -127,6 +133,7 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
     delete ps;
   }
   if (b.frames.empty()) { b.err = "no pictures in the input"; return b.err_code = RBT_ERR_BITSTREAM; }
+  for (size_t i = 0; i < b.slices.size(); i++) if (!b.slices[i].end_addr) { const RbtStreamCfg& c = b.frames[b.slices[i].frame].cfg; b.slices[i].end_addr = c.w_ctb * c.h_ctb; }   // the last entry of a picture ends with the picture
   if (b.has_row_tasks) b.want_save = false;                              // banded (resumable) parsing re-launches the list; row tasks need one ordered launch
   if (b.slices.size() >= 0xFFFF) { b.err = "too many slice segments"; return b.err_code = RBT_ERR_UNSUPPORTED; }
   int n_levels = 0; for (auto& f : b.frames) n_levels = std::max(n_levels, f.level + 1);
@@ -157,11 +164,13 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
     o_sao[i] = a.reserve(nc * sizeof(RbtSao)); o_cmds[i] = a.reserve(nc * (size_t)b.frames[i].cmd_cap * sizeof(RbtCmd));
   }
   std::vector<size_t> o_prow_line(nf, 0);
+  const size_t prow_begin = a.reserve(0);     // the rows' hand-over records (one block, zeroed per job: recycled pool memory must not pass for the state of a row nobody parsed)
   for (size_t i = 0; i < nf; i++) if (wpp_frame[i]) {
     const RbtStreamCfg& c = b.frames[i].cfg;
     b.frames[i].prow_line_bytes = (int32_t)(((size_t)c.w4 * 7 + (size_t)c.w_ctb * (2 + sizeof(RbtSao)) + 255) & ~(size_t)255);
     o_prow_ctx[i] = a.reserve((size_t)c.h_ctb * 256 + 256); o_prow_line[i] = a.reserve((size_t)c.h_ctb * b.frames[i].prow_line_bytes + 256);
   }
+  const size_t prow_end = a.reserve(0);
   size_t o_frames = a.reserve(nf * sizeof(RbtFrame)), o_slices = a.reserve(b.slices.size() * sizeof(RbtSlice));
   size_t o_rbsp = a.reserve(b.rbsp.size() + 64), o_lists = a.reserve((nf + b.slices.size()) * 2 * sizeof(int32_t));
   // CTB dependency order (anti-diagonals x + 2y ascending, top to bottom inside one) per distinct picture geometry, and the pictures of every level as RbtFrameRef
@@ -194,7 +203,7 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
   if (b.level_frames.size() > 32) { b.err = "too many dependency levels"; return b.err_code = RBT_ERR_UNSUPPORTED; }
   b.d_save = b.want_save ? (void*)(base + o_save) : nullptr;
   b.d_frames = (RbtFrame*)(base + o_frames); b.d_slices = (RbtSlice*)(base + o_slices); b.d_rbsp = base + o_rbsp; b.d_lists = (int32_t*)(base + o_lists);
-  if (rbtk::dev_memset(base, 0, zero_end) || rbtk::dev_memset(base + pm_begin, RBT_MODE_NONE, pm_end - pm_begin) || rbtk::dev_memset(base + cs_begin, 0xFF, cs_end - cs_begin) ||
+  if (rbtk::dev_memset(base, 0, zero_end) || (prow_end > prow_begin && rbtk::dev_memset(base + prow_begin, 0, prow_end - prow_begin)) || rbtk::dev_memset(base + pm_begin, RBT_MODE_NONE, pm_end - pm_begin) || rbtk::dev_memset(base + cs_begin, 0xFF, cs_end - cs_begin) ||
       rbtk::h2d(b.d_frames, b.frames.data(), nf * sizeof(RbtFrame)) || rbtk::h2d(b.d_slices, b.slices.data(), b.slices.size() * sizeof(RbtSlice)) ||
       rbtk::h2d(b.d_rbsp, b.rbsp.data(), b.rbsp.size()) || rbtk::h2d(b.d_order, b.order_keep.data(), b.order_keep.size() * 4) ||
       rbtk::h2d(b.d_refs, b.refs_keep.data(), b.refs_keep.size() * sizeof(RbtFrameRef))) { b.err = "device transfer failed"; return b.err_code = RBT_ERR_NO_DEVICE; }
@@ -206,12 +215,11 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
 // but with 16 GOFs in flight its resident waiting workgroups hold LDS and wave slots the other jobs' analysis / intra-coding kernels need (those go from 25-27 / 31 ms
 // to 40 / 49 ms per job): 598 against 635 frames/s. So: flags while few jobs are in flight (<= 4: the GPU is mostly idle), diagonals beyond.
 // RBT_RECON_DIAG=1 / RBT_RECON_LEVEL=1 force one or the other.
-static int g_jobs_in_flight_hint = 1;
-void recon_set_depth(int depth) { g_jobs_in_flight_hint = depth; }
+void recon_set_depth(int depth) { rbtk::set_jobs_in_flight(depth); }      // kept with the device (rbt_kernels.hip Dev): contexts on different devices do not share it
 bool recon_by_diagonals() {
   static int force = -1;
   if (force < 0) { const char* d = getenv("RBT_RECON_DIAG"); const char* l = getenv("RBT_RECON_LEVEL"); force = d && atoi(d) ? 1 : (l && atoi(l) ? 2 : 0); }
-  return force == 1 || (force == 0 && g_jobs_in_flight_hint > 4);
+  return force == 1 || (force == 0 && rbtk::jobs_in_flight() > 4);
 }
 
 int decode_run(DecodeBatch& b) { int rc = decode_launch(b); return rc ? rc : decode_finish(b); }

@@ -19,9 +19,13 @@ struct Buf { uint8_t* p = nullptr; size_t n = 0; };
 int ceil_log2(uint32_t x) { if (x == 0) return -1; x -= 1; int r = -1; while (x) { r++; x >>= 1; } return r + 1; }
 }
 
+#include <new>
+#ifndef RBT_CATCH
+#define RBT_CATCH catch (const std::bad_alloc&) { return RBT_ERR_NOMEM; } catch (...) { return RBT_ERR_NO_DEVICE; }
+#endif
 extern "C" {
 
-int rbt_v3c_index(const uint8_t* in, size_t n, rbt_v3c_unit** units, int* n_units) {
+int rbt_v3c_index(const uint8_t* in, size_t n, rbt_v3c_unit** units, int* n_units) try {
   if (!in || !units || !n_units || n < 1) return RBT_ERR_PARAM;
   *units = nullptr; *n_units = 0;
   const int prec = (in[0] >> 5) + 1;                                          // ssvh_unit_size_precision_bytes_minus1 u(3), 5 reserved bits
@@ -51,9 +55,9 @@ int rbt_v3c_index(const uint8_t* in, size_t n, rbt_v3c_unit** units, int* n_unit
   if (!v.empty()) memcpy(*units, v.data(), sizeof(rbt_v3c_unit) * v.size());
   *n_units = (int)v.size();
   return RBT_OK;
-}
+} RBT_CATCH
 
-int rbt_v3c_write(const uint8_t* const* unit, const size_t* unit_size, int n_units, int forced_precision_bytes, uint8_t** out, size_t* n_out) {
+int rbt_v3c_write(const uint8_t* const* unit, const size_t* unit_size, int n_units, int forced_precision_bytes, uint8_t** out, size_t* n_out) try {
   if (!out || !n_out || n_units < 0 || (n_units && (!unit || !unit_size)) || forced_precision_bytes < 0 || forced_precision_bytes > 8) return RBT_ERR_PARAM;
   uint32_t max_size = 0; size_t total = 1;                                    // the reference keeps the maximum in 32 bits (:66-69)
   for (int i = 0; i < n_units; i++) { if (!unit[i] || unit_size[i] > 0xFFFFFFFFull) return RBT_ERR_PARAM; if (max_size < (uint32_t)unit_size[i]) max_size = (uint32_t)unit_size[i]; total += unit_size[i]; }
@@ -62,6 +66,9 @@ int rbt_v3c_write(const uint8_t* const* unit, const size_t* unit_size, int n_uni
   if (bits < 0) prec = 0;
   if (prec < 1) prec = 1;
   if (prec > 8) prec = 8;
+  // DEVIATION from the reference, on purpose: its rule gives a largest unit of exactly 256^k bytes k bytes, which cannot hold 256^k - the size field would carry the low
+  // bits (0) and the file could not be read back, not by the reference's own reader either (PCCBitstreamReader.cpp:58-63). One byte more there.
+  while (prec < 8 && ((uint64_t)max_size >> (8 * prec)) != 0) prec++;
   if (prec < forced_precision_bytes) prec = forced_precision_bytes;
   total += (size_t)prec * (size_t)n_units;
   uint8_t* o = (uint8_t*)malloc(total); if (!o) return RBT_ERR_NOMEM;
@@ -73,9 +80,9 @@ int rbt_v3c_write(const uint8_t* const* unit, const size_t* unit_size, int n_uni
   }
   *out = o; *n_out = pos;
   return RBT_OK;
-}
+} RBT_CATCH
 
-int rbt_v3c_stats(const uint8_t* in, size_t n, rbt_v3c_stat* out) {
+int rbt_v3c_stats(const uint8_t* in, size_t n, rbt_v3c_stat* out) try {
   if (!in || !out || n < 1) return RBT_ERR_PARAM;
   memset(out, 0, sizeof(*out));
   rbt_v3c_unit* u = nullptr; int nu = 0;
@@ -98,9 +105,9 @@ int rbt_v3c_stats(const uint8_t* in, size_t n, rbt_v3c_stat* out) {
   out->total_metadata = all - out->total_geometry - out->total_attribute + out->header;
   out->total = out->total_metadata + out->total_geometry + out->total_attribute;
   return RBT_OK;
-}
+} RBT_CATCH
 
-int rbt_transcode_v3c_stream(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_params* p, rbt_v3c_sink sink, void* user) {
+int rbt_transcode_v3c_stream(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_params* p, rbt_v3c_sink sink, void* user) try {
   if (!ctx || !in || !p || !sink) return RBT_ERR_PARAM;
   rbt_v3c_unit* units = nullptr; int nu = 0;
   int rc = rbt_v3c_index(in, n, &units, &nu);
@@ -202,7 +209,7 @@ int rbt_transcode_v3c_stream(rbt_ctx* ctx, const uint8_t* in, size_t n, const rb
   if (!rc) rc = deliver(n_gofs);                                              // GOFs behind the last job (no video units of their own)
   cleanup();
   return rc;
-}
+} RBT_CATCH
 
 // the whole file at once: the stream walk with a sink that keeps every unit, then PCCBitstreamWriter::write over all of them
 namespace { struct Keep { std::vector<std::vector<uint8_t>> unit; };
@@ -211,7 +218,7 @@ int keep_units(void* user, int, int n_units, const uint8_t* const* unit, const s
   for (int i = 0; i < n_units; i++) k->unit.emplace_back(unit[i], unit[i] + unit_size[i]);
   return 0;
 } }
-int rbt_transcode_v3c(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_params* p, uint8_t** out, size_t* n_out) {
+int rbt_transcode_v3c(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_params* p, uint8_t** out, size_t* n_out) try {
   if (!ctx || !in || !p || !out || !n_out) return RBT_ERR_PARAM;
   *out = nullptr; *n_out = 0;
   Keep k;
@@ -220,6 +227,6 @@ int rbt_transcode_v3c(rbt_ctx* ctx, const uint8_t* in, size_t n, const rbt_v3c_p
   std::vector<const uint8_t*> up; std::vector<size_t> un;
   for (auto& u : k.unit) { up.push_back(u.data()); un.push_back(u.size()); }
   return rbt_v3c_write(up.data(), un.data(), (int)up.size(), p->forced_unit_size_precision_bytes, out, n_out);
-}
+} RBT_CATCH
 
 }  // extern "C"

@@ -33,7 +33,9 @@ void dev_release_pool() {}
 int h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); return 0; }
 int d2h(void* h, const void* d, size_t n) { memcpy(h, d, n); return 0; }
 int dev_memset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
-void set_jobs_in_flight(int) {}
+static int g_depth = 1;
+void set_jobs_in_flight(int d) { g_depth = d; }
+int jobs_in_flight() { return g_depth; }
 int dev_sync() { return 0; }
 void timer_begin(int id) { g_t[id][0] = now_ms(); }
 void timer_end(int id) { g_t[id][1] = now_ms(); }

@@ -68,3 +68,13 @@ def test_wide_pictures_use_the_larger_parser_variants(ctx, w):
         bs, rec = O.encode(fr, w, h, 10, qp=34, gop=2, stress_seed=seed, log2_ctb=log2_ctb)
         dec, dw, dh, dbd, chk, fail = ctx.decode(bs)
         assert (dw, dh, fail) == (w, h, 0) and np.array_equal(dec, rec)
+
+
+def test_slice_segments_must_tile_the_picture(ctx):
+    """missing / repeated / swapped slice segments on the GPU: refused by the first wave that sees the hole or the overlap (RbtSlice::end_addr), row tasks below do not
+    wait out their bound, the context stays usable (tests/test_hostemu_parity.py slice_segment_damage)"""
+    import time
+    import test_hostemu_parity as T
+    t0 = time.time()
+    T.slice_segment_damage(ctx, rbt_lib.module())
+    assert time.time() - t0 < 60

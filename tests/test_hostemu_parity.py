@@ -337,3 +337,37 @@ def check_occupancy_rd(ctx, R):
 
 def test_occupancy_aware_coding_matches_oracle(ctx):
     check_occupancy_rd(ctx, rbt_lib.module())
+
+
+def split_nals(bs):
+    """Annex-B stream -> list of NAL units with their start codes"""
+    pos, i = [], bs.find(b"\x00\x00\x01")
+    while i >= 0:
+        pos.append(i - 1 if i > 0 and bs[i - 1] == 0 else i)
+        i = bs.find(b"\x00\x00\x01", i + 3)
+    return [bs[a:b] for a, b in zip(pos, pos[1:] + [len(bs)])]
+
+
+def slice_segment_damage(ctx, R):
+    """Slice segments that do not tile their picture (round-2 advisor findings): the host knows where segments start, only the parser finds where they end. A missing
+    segment (a hole: in a wavefront stream the row task below would wait for a row nobody parses), a repeated one and two in the wrong order must all be refused -
+    quickly, by the first wave that sees it, not after a poll bound - and the context stays usable. Shared with tests/test_gpu_decode.py."""
+    geo, attr, occ = synth.make_gof(128, 128, 1, 17)
+    for rows in (1, -1):                                   # independent row slices; wavefront rows (dependent segments, one row task per row)
+        bs, _ = O.encode(geo, 128, 128, 10, 24, gop=2, log2_ctb=5, rows_per_slice=rows)
+        nals = split_nals(bs)
+        vcl = [k for k, n in enumerate(nals) if (n[4 if n[:4] == b"\x00\x00\x00\x01" else 3] >> 1) & 63 < 32]
+        assert len(vcl) == 8 and ctx.decode(bs)[5] == 0     # two pictures of four CTB rows
+        hole = b"".join(n for k, n in enumerate(nals) if k != vcl[2])
+        twice = b"".join(n + (n if k == vcl[1] else b"") for k, n in enumerate(nals))
+        order = list(range(len(nals))); order[vcl[1]], order[vcl[2]] = order[vcl[2]], order[vcl[1]]
+        swapped = b"".join(nals[k] for k in order)
+        early = b"".join(n for k, n in enumerate(nals) if k != vcl[3])            # the last row of the first picture is missing
+        for bad in (hole, twice, swapped, early):
+            with pytest.raises(R.RbtError):
+                ctx.decode(bad)
+        assert ctx.decode(bs)[5] == 0
+
+
+def test_slice_segments_must_tile_the_picture(ctx):
+    slice_segment_damage(ctx, rbt_lib.module())

@@ -71,13 +71,14 @@ def test_write_precision_follows_the_largest_unit(R, hlib, largest, forced, want
     assert V.parse(data) == (want, units)
 
 
-def test_write_keeps_the_reference_rule_at_powers_of_256(R, hlib):
-    """ceilLog2(256) = 8 -> one byte, which cannot hold 256: the reference's rule as written (PCCBitstreamWriter.cpp:71-72). Restated as it is (a caller who meets it
-    forces the precision, forcedSsvhUnitSizePrecisionBytes_); the size byte wraps to 0."""
-    units = [V.unit_header(V.AD) + bytes(252)]
+@pytest.mark.parametrize("largest,want", [(256, 2), (65536, 3), (1 << 24, 4)])
+def test_write_at_powers_of_256_takes_one_byte_more_than_the_reference(R, hlib, largest, want):
+    """ceilLog2(256) = 8 -> one byte by the reference's rule (PCCBitstreamWriter.cpp:71-72), which cannot hold 256: the size field would wrap to 0 and nothing could read the
+    file back. The library deviates there (round-2 advisor finding): the precision that holds the largest unit."""
+    units = [V.unit_header(V.AD) + bytes(largest - 4)]
     data = R.v3c_write(units, 0, hlib)
-    assert data[0] == 0 and data[1] == 0 and len(data) == 2 + 256
-    assert V.parse(R.v3c_write(units, 2, hlib)) == (2, units)
+    assert V.parse(data) == (want, units)
+    assert V.parse(R.v3c_write(units, want + 1, hlib)) == (want + 1, units)
 
 
 def test_transcode_v3c_equals_oracle_and_manual_walk(R, ctx, container):
