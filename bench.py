@@ -427,14 +427,17 @@ def main():
 
             def cloud(occ_plane, prec, g2):
                 return ctx.reconstruct(R.AtlasParams(w, h, 16, prec, 2, 1, 1, 0), pats, occ_plane, g2[0][: w * h].reshape(h, w), g2[1][: w * h].reshape(h, w), 10)[0]
-            c_src = cloud(src["occ_full"].astype(np.uint16), 1, src["geo"])
+            c_src, n_src = synth.source_normals(R, ctx.reconstruct, w, h, 1051, src["occ_full"], src["geo"])     # the source cloud with one normal per point: its patch's projection axis
             c_in = cloud(ctx.decode(first(so, 1))[0][0][: (w // 2) * (h // 2)].reshape(h // 2, w // 2), 2, ctx.decode(first(sg, 1))[0])
             c_out = cloud(ctx.decode(first(outs[0], 1))[0][0][: (w // 4) * (h // 4)].reshape(h // 4, w // 4), 4, ctx.decode(first(outs[1], 1))[0])
             r_in, r_out, r_io = ctx.d1(c_src, c_in), ctx.d1(c_src, c_out), ctx.d1(c_in, c_out)
-            d1_tools = (cloud, c_src, first)
+            p_in, p_out = ctx.d2(c_src, n_src, c_in), ctx.d2(c_src, n_src, c_out)          # D2 (point-to-plane, PCCMetrics.cpp:100-124): rbt_d2
+            d1_tools = (cloud, c_src, first, n_src)
             d1 = {"points_source": int(c_src.shape[0]), "points_r5_input": int(c_in.shape[0]), "points_r3_output": int(c_out.shape[0]),
                   "d1_psnr_r5_input_vs_source_db": round(r_in["psnr"], 3), "d1_psnr_r3_output_vs_source_db": round(r_out["psnr"], 3), "d1_psnr_r3_output_vs_r5_input_db": round(r_io["psnr"], 3),
-                  "note": "point-cloud frame 0, synthetic atlas (tests/synth.py atlas_patches), symmetric point-to-point PSNR, peak 1023; D2 needs normals (none here)"}
+                  "d2_psnr_r5_input_vs_source_db": round(p_in["psnr"], 3), "d2_psnr_r3_output_vs_source_db": round(p_out["psnr"], 3),
+                  "note": "point-cloud frame 0, synthetic atlas (tests/synth.py atlas_patches), symmetric PSNR, peak 1023; D1 point-to-point (rbt_d1), D2 point-to-plane (rbt_d2) with "
+                          "the source's normals = the projection axis of each point's patch (tests/synth.py source_normals), the decoded cloud's by scaleNormals"}
         except Exception as e:   # the metric stage is informative: never lose the benchmark line over it
             d1 = {"error": str(e)}
         # Occupancy-aware coding (rbt_stream_params.occupancy_rd) on top: the same GOF with the geometry / attribute maps coded for the samples the
@@ -456,10 +459,12 @@ def main():
                       "occupied_psnr_y_vs_r5_input_db": {"geometry": psnr_occ(sg, o_on[1]), "attribute": psnr_occ(sa, o_on[2])},
                       "plain_occupied_psnr_y_vs_r5_input_db": {"geometry": psnr_occ(sg, outs[1]), "attribute": psnr_occ(sa, outs[2])}}
             if d1 and "error" not in d1:
-                cloud, c_src, first = d1_tools
+                cloud, c_src, first, n_src = d1_tools
                 c_on = cloud(ctx.decode(first(o_on[0], 1))[0][0][: (w // 4) * (h // 4)].reshape(h // 4, w // 4), 4, ctx.decode(first(o_on[1], 1))[0])
                 occ_rd["d1_psnr_vs_source_db"] = round(ctx.d1(c_src, c_on)["psnr"], 3)
                 occ_rd["plain_d1_psnr_vs_source_db"] = d1["d1_psnr_r3_output_vs_source_db"]
+                occ_rd["d2_psnr_vs_source_db"] = round(ctx.d2(c_src, n_src, c_on)["psnr"], 3)
+                occ_rd["plain_d2_psnr_vs_source_db"] = d1["d2_psnr_r3_output_vs_source_db"]
             ctx.set_depth(D)
             k_on = min(args.steps, 32)
             job_cache.clear(); params_keep = list(params); params[:] = p_on

@@ -184,6 +184,19 @@ typedef struct {
 } rbt_d1_result;
 /* point-to-point (D1) metric between two clouds; coordinates 0..1023 (peak = 1023 in the CTC). */
 int rbt_d1(rbt_ctx* ctx, const int16_t* xyz_a, int n_a, const int16_t* xyz_b, int n_b, int peak, rbt_d1_result* out);
+/* point-to-plane (D2) metric, the other half of BASELINE's "D1/D2 geom PSNR": QualityMetrics::compute with computeC2p_ (PCCMetrics.cpp:100-124, :213-215), symmetric (:299-309),
+ * between a source cloud A that comes with normals (three per point, fixed point Q14: 16384 = 1.0) and a decoded cloud B that gets its normals from A the way
+ * PCCMetrics::compute arranges it (:371-376: copyNormals on the source, scaleNormals on the reconstruction, PCCPointSet.cpp:2322-2380: every source point gives its normal to
+ * the points of B nearest to it, a point of B that got none takes the mean of the source points nearest to it). Per point of one cloud: the mean, over the other cloud's points
+ * at the nearest distance, of the squared projection of the difference on that point's normal. Where the reference depends on the order its kd-tree returns equidistant points
+ * in, this is defined instead: duplicates are merged first and a merged point keeps the normal of its lowest-index duplicate; ALL points at exactly the nearest squared
+ * distance count (the reference looks at up to 30 results). */
+typedef struct {
+  int n_a, n_b;
+  double sse_ab, sse_ba, max_ab, max_ba;              /* sum / maximum of the per-point values, A -> B and B -> A */
+  float mse_ab, mse_ba, psnr_ab, psnr_ba, psnr;       /* psnr = 10 log10(3 peak^2 / max(mse_ab, mse_ba)) */
+} rbt_d2_result;
+int rbt_d2(rbt_ctx* ctx, const int16_t* xyz_a, const int16_t* normals_a, int n_a, const int16_t* xyz_b, int n_b, int peak, rbt_d2_result* out);
 
 /* ---- V3C sample stream: the container either side of the path ----
  * What PccAppTranscoder's decompressVideo does around transcodeData (PccAppTranscoder.cpp:277-349): read the sample stream (PCCBitstreamReader::read,

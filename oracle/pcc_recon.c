@@ -198,3 +198,95 @@ int oracle_d1(const int16_t* a, int na, const int16_t* b, int nb, int peak, orac
   out->psnr_ab = 10 * log10f(3 * p * p / mse_ab); out->psnr_ba = 10 * log10f(3 * p * p / mse_ba); out->psnr = 10 * log10f(3 * p * p / m);
   return 0;
 }
+
+/* ---- D2 (point-to-plane) ---- */
+typedef struct { int n; int16_t* p; int* orig; int D; int* start; int* order; } pset;   /* merged points (sorted), the original index each one stands for, cell grid */
+static const int16_t* g_sort_pts;
+static int cmp_idx(const void* a, const void* b) {
+  int i = *(const int*)a, j = *(const int*)b, c = cmp_pt(g_sort_pts + 3 * i, g_sort_pts + 3 * j);
+  return c ? c : i - j;
+}
+#define PCELL(s, x, y, z) ((((size_t)(z) * (s)->D) + (y)) * (s)->D + (x))
+static void pset_build(pset* s, const int16_t* p, int n, int gmax) {
+  int* idx = (int*)malloc(sizeof(int) * (size_t)n); for (int i = 0; i < n; i++) idx[i] = i;
+  g_sort_pts = p; qsort(idx, (size_t)n, sizeof(int), cmp_idx);
+  s->p = (int16_t*)malloc((size_t)n * 6); s->orig = (int*)malloc(sizeof(int) * (size_t)n); s->n = 0;
+  for (int k = 0; k < n; k++) if (!s->n || memcmp(s->p + 3 * (s->n - 1), p + 3 * idx[k], 6)) { memcpy(s->p + 3 * s->n, p + 3 * idx[k], 6); s->orig[s->n++] = idx[k]; }   /* ties sorted by index: the lowest stands for the point */
+  free(idx);
+  s->D = gmax + 1;
+  size_t nc = (size_t)s->D * s->D * s->D;
+  s->start = (int*)calloc(nc + 1, sizeof(int)); s->order = (int*)malloc(sizeof(int) * (size_t)s->n);
+  for (int i = 0; i < s->n; i++) s->start[PCELL(s, s->p[3 * i] >> 3, s->p[3 * i + 1] >> 3, s->p[3 * i + 2] >> 3) + 1]++;
+  for (size_t i = 0; i < nc; i++) s->start[i + 1] += s->start[i];
+  int* fill = (int*)malloc(sizeof(int) * nc); memcpy(fill, s->start, sizeof(int) * nc);
+  for (int i = 0; i < s->n; i++) s->order[fill[PCELL(s, s->p[3 * i] >> 3, s->p[3 * i + 1] >> 3, s->p[3 * i + 2] >> 3)]++] = i;
+  free(fill);
+}
+static void pset_free(pset* s) { free(s->p); free(s->orig); free(s->start); free(s->order); }
+/* every point of s at the nearest squared distance from q: their indices into s->p (up to cap), returns how many; *d2 = that distance */
+static int pset_nearest_ties(const pset* s, const int16_t* q, int* out, int cap, int64_t* d2) {
+  const int cx = q[0] >> 3, cy = q[1] >> 3, cz = q[2] >> 3; int64_t best = INT64_MAX; int n = 0;
+  for (int r = 0; r < s->D + 1; r++) {
+    for (int z = cz - r; z <= cz + r; z++) for (int y = cy - r; y <= cy + r; y++) for (int x = cx - r; x <= cx + r; x++) {
+      if (x < 0 || y < 0 || z < 0 || x >= s->D || y >= s->D || z >= s->D) continue;
+      if (abs(x - cx) != r && abs(y - cy) != r && abs(z - cz) != r) continue;
+      for (int k = s->start[PCELL(s, x, y, z)]; k < s->start[PCELL(s, x, y, z) + 1]; k++) {
+        const int16_t* b = s->p + 3 * s->order[k]; int64_t dx = b[0] - q[0], dy = b[1] - q[1], dz = b[2] - q[2], d = dx * dx + dy * dy + dz * dz;
+        if (d < best) { best = d; n = 0; }
+        if (d == best && n < cap) out[n++] = s->order[k];
+      }
+    }
+    if (best != INT64_MAX && best < (int64_t)(r << 3) * (r << 3)) break;   /* strictly: a point in a later ring may still TIE at r * 8 */
+  }
+  *d2 = best;
+  return n;
+}
+/* sum over the points of A of the mean, over B's points at the nearest distance, of the squared projection of (a - b) on b's normal; B's normals are acc / cnt (Q14) */
+static double d2_a_to_b(const pset* A, const pset* B, const int64_t* accB, const int32_t* cntB, double* mx) {
+  double sse = 0, m = 0; int ties[4096];
+  for (int i = 0; i < A->n; i++) {
+    int64_t d2; int nt = pset_nearest_ties(B, A->p + 3 * i, ties, 4096, &d2); double sum = 0;
+    for (int t = 0; t < nt; t++) {
+      const int j = ties[t]; const int16_t* b = B->p + 3 * j; const int16_t* a = A->p + 3 * i;
+      const int64_t dot = (int64_t)(a[0] - b[0]) * accB[3 * j] + (int64_t)(a[1] - b[1]) * accB[3 * j + 1] + (int64_t)(a[2] - b[2]) * accB[3 * j + 2];
+      const double v = (double)dot / (double)cntB[j];
+      sum += v * v;
+    }
+    const double dist = sum / nt / (16384.0 * 16384.0);
+    sse += dist; if (dist > m) m = dist;
+  }
+  *mx = m;
+  return sse;
+}
+int oracle_d2(const int16_t* a, const int16_t* normals_a, int na, const int16_t* b, int nb, int peak, oracle_d2_result* out) {
+  memset(out, 0, sizeof(*out));
+  if (na <= 0 || nb <= 0) return -1;
+  int gmax = 0;
+  for (int i = 0; i < 3 * na; i++) { if (a[i] < 0) return -1; if ((a[i] >> 3) > gmax) gmax = a[i] >> 3; }
+  for (int i = 0; i < 3 * nb; i++) { if (b[i] < 0) return -1; if ((b[i] >> 3) > gmax) gmax = b[i] >> 3; }
+  pset A, B; pset_build(&A, a, na, gmax); pset_build(&B, b, nb, gmax);
+  out->n_a = A.n; out->n_b = B.n;
+  /* normals: A's are given (copyNormals); B's by scaleNormals - every source point gives its normal to the points of B nearest to it, a point of B that got none
+   * takes the mean of the source points nearest to it. Kept as integer sum and count: the mean is formed where it is used. */
+  int64_t* accA = (int64_t*)calloc((size_t)A.n * 3, sizeof(int64_t)); int32_t* cntA = (int32_t*)calloc((size_t)A.n, sizeof(int32_t));
+  int64_t* accB = (int64_t*)calloc((size_t)B.n * 3, sizeof(int64_t)); int32_t* cntB = (int32_t*)calloc((size_t)B.n, sizeof(int32_t));
+  for (int i = 0; i < A.n; i++) { for (int c = 0; c < 3; c++) accA[3 * i + c] = normals_a[3 * A.orig[i] + c]; cntA[i] = 1; }
+  int ties[4096]; int64_t d2;
+  for (int i = 0; i < A.n; i++) {
+    int nt = pset_nearest_ties(&B, A.p + 3 * i, ties, 4096, &d2);
+    for (int t = 0; t < nt; t++) { for (int c = 0; c < 3; c++) accB[3 * ties[t] + c] += accA[3 * i + c]; cntB[ties[t]]++; }
+  }
+  for (int j = 0; j < B.n; j++) if (!cntB[j]) {
+    int nt = pset_nearest_ties(&A, B.p + 3 * j, ties, 4096, &d2);
+    for (int t = 0; t < nt; t++) { for (int c = 0; c < 3; c++) accB[3 * j + c] += accA[3 * ties[t] + c]; cntB[j]++; }
+  }
+  out->sse_ab = d2_a_to_b(&A, &B, accB, cntB, &out->max_ab);
+  out->sse_ba = d2_a_to_b(&B, &A, accA, cntA, &out->max_ba);
+  free(accA); free(cntA); free(accB); free(cntB);
+  float mse_ab = (float)(out->sse_ab / A.n), mse_ba = (float)(out->sse_ba / B.n);
+  out->mse_ab = mse_ab; out->mse_ba = mse_ba;
+  float p = (float)peak, m = mse_ab > mse_ba ? mse_ab : mse_ba;
+  out->psnr_ab = 10 * log10f(3 * p * p / mse_ab); out->psnr_ba = 10 * log10f(3 * p * p / mse_ba); out->psnr = 10 * log10f(3 * p * p / m);
+  pset_free(&A); pset_free(&B);
+  return 0;
+}

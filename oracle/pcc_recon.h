@@ -28,4 +28,12 @@ int oracle_reconstruct(const oracle_atlas* a, const oracle_patch* patches, int n
                        const uint16_t* t0, const uint16_t* t1, int attr_bd, oracle_cloud* out);
 void oracle_cloud_free(oracle_cloud* c);
 int oracle_d1(const int16_t* a, int na, const int16_t* b, int nb, int peak, oracle_d1_result* out);
+/* Point-to-plane (D2) metric, QualityMetrics::compute with computeC2p_ (PCCMetrics.cpp:100-124, :213-215, symmetric :299-309) between a source cloud A that comes
+ * with normals and a decoded cloud B that gets its normals from A the way PCCMetrics::compute arranges it (PCCMetrics.cpp:371-376: copyNormals on the source,
+ * scaleNormals on the reconstruction, PCCPointSet.cpp:2322-2380). Normals are fixed point, Q14 (16384 = 1.0), three per point of A.
+ * Differences from the reference, all of them where it depends on the order its kd-tree returns equidistant points in: duplicates are merged first (as for D1) and
+ * a merged point keeps the normal of its lowest-index duplicate (the reference copies normals by index into the deduplicated cloud); "the points at the same
+ * distance" are ALL points at exactly the nearest squared distance (the reference looks at 5, 10, .. 30 results and stops there). */
+typedef struct { int n_a, n_b; double sse_ab, sse_ba, max_ab, max_ba; float mse_ab, mse_ba, psnr_ab, psnr_ba, psnr; } oracle_d2_result;
+int oracle_d2(const int16_t* a, const int16_t* normals_a, int na, const int16_t* b, int nb, int peak, oracle_d2_result* out);
 #endif

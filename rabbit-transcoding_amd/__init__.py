@@ -53,6 +53,11 @@ class D1Result(C.Structure):
                 ("mse_ab", C.c_float), ("mse_ba", C.c_float), ("psnr_ab", C.c_float), ("psnr_ba", C.c_float), ("psnr", C.c_float)]
 
 
+class D2Result(C.Structure):
+    _fields_ = [("n_a", C.c_int), ("n_b", C.c_int), ("sse_ab", C.c_double), ("sse_ba", C.c_double), ("max_ab", C.c_double), ("max_ba", C.c_double),
+                ("mse_ab", C.c_float), ("mse_ba", C.c_float), ("psnr_ab", C.c_float), ("psnr_ba", C.c_float), ("psnr", C.c_float)]
+
+
 class V3CUnit(C.Structure):
     """rbt_v3c_unit: one unit of a V3C sample stream"""
     _fields_ = [(n, C.c_int) for n in ("type", "gof", "parameter_set_id", "atlas_id", "attribute_index", "attribute_dimension_index", "map_index", "auxiliary_video", "video_type")] + \
@@ -108,6 +113,7 @@ def load(path=None):
     L.rbt_reconstruct.argtypes = [C.c_void_p, C.POINTER(AtlasParams), C.POINTER(Patch), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Cloud)]
     L.rbt_cloud_free.argtypes = [C.POINTER(Cloud)]
     L.rbt_d1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(D1Result)]
+    L.rbt_d2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(D2Result)]
     L.rbt_v3c_index.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(V3CUnit)), C.POINTER(C.c_int)]
     L.rbt_v3c_write.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rbt_v3c_stats.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(V3CStat)]
@@ -325,6 +331,15 @@ class Context:
         r = D1Result()
         self._chk(self.L.rbt_d1(self.h, a.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0], peak, C.byref(r)))
         return {n: getattr(r, n) for n, _ in D1Result._fields_}
+
+    def d2(self, a, normals_a, b, peak=1023):
+        """rbt_d2: point-to-plane metric; a, b int16 [n,3]; normals_a int16 [n_a,3] in Q14 (16384 = 1.0) -> dict"""
+        a = np.ascontiguousarray(a, dtype=np.int16); b = np.ascontiguousarray(b, dtype=np.int16); na = np.ascontiguousarray(normals_a, dtype=np.int16)
+        if na.shape != a.shape:
+            raise ValueError("one normal per point of a")
+        r = D2Result()
+        self._chk(self.L.rbt_d2(self.h, a.ctypes.data, na.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0], peak, C.byref(r)))
+        return {n: getattr(r, n) for n, _ in D2Result._fields_}
 
     def selftest_transform32(self, blocks, bit_depth=10):
         """rbt_selftest_transform32: matrix-core vs vector-ALU 32-point transforms on int16 blocks [n, 1024]; returns the number of differing samples"""

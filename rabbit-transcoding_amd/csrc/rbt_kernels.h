@@ -88,4 +88,9 @@ void launch_pcc_emit(const RbtPccParams* P, const rbt_patch* patches, const uint
                      const uint32_t* b2p, const uint32_t* offsets, int16_t* xyz, uint16_t* yuv);
 void launch_vol_set(const int16_t* xyz, int n, uint32_t* vol, uint8_t* first, uint32_t* n_unique);
 void launch_vol_nn(const int16_t* xyz, const uint8_t* first, int n, const uint32_t* vol_other, unsigned long long* sse, uint32_t* max_d2);
+// D2 (csrc/rbt_pcc.h): bit volume + voxel -> lowest index map of a cloud; normals of the reconstruction (sum, count) from the source's; point-to-plane sums
+void launch_d2_insert(const int16_t* xyz, int n, uint32_t* vol, uint32_t* keys, uint32_t* vals, int lg);
+void launch_d2_give(const RbtD2Set* A, const int16_t* normals_a, const RbtD2Set* B, long long* acc_b, int32_t* cnt_b);
+void launch_d2_take(const RbtD2Set* B, const RbtD2Set* A, const int16_t* normals_a, long long* acc_b, int32_t* cnt_b);
+void launch_d2_dist(const RbtD2Set* P, const RbtD2Set* Q, const long long* acc_q, const int32_t* cnt_q, const int16_t* normals_q, double* out);
 }  // namespace rbtk

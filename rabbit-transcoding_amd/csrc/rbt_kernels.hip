@@ -545,6 +545,28 @@ __global__ void __launch_bounds__(256) k_vol_nn(const int16_t* xyz, const uint8_
   for (int o = 32; o; o >>= 1) { s += __shfl_down(s, o, 64); const uint32_t t = __shfl_down(m, o, 64); m = t > m ? t : m; }
   if ((threadIdx.x & 63) == 0 && s) { atomicAdd(sse, s); atomicMax(max_d2, m); }
 }
+__global__ void __launch_bounds__(256) k_d2_insert(const int16_t* xyz, int n, uint32_t* vol, uint32_t* keys, uint32_t* vals, int lg) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+  atomicOr(&vol[pc_voxel_word(x, y, z)], 1u << (x & 31));
+  pc_hash_insert(keys, vals, lg, pc_voxel_id(x, y, z), (uint32_t)i);
+}
+__global__ void __launch_bounds__(256) k_d2_give(RbtD2Set A, const int16_t* normals_a, RbtD2Set B, long long* acc_b, int32_t* cnt_b) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < A.n) pc_d2_give(&A, normals_a, &B, acc_b, cnt_b, i); }
+__global__ void __launch_bounds__(256) k_d2_take(RbtD2Set B, RbtD2Set A, const int16_t* normals_a, long long* acc_b, int32_t* cnt_b) { const int j = blockIdx.x * 256 + threadIdx.x; if (j < B.n) pc_d2_take(&B, &A, normals_a, acc_b, cnt_b, j); }
+// out: [0] sum of the values (double), [1] their maximum (double, compared as its bit pattern: the values are >= 0), [2] number of representatives (u64)
+__global__ void __launch_bounds__(256) k_d2_dist(RbtD2Set P, RbtD2Set Q, const long long* acc_q, const int32_t* cnt_q, const int16_t* normals_q, double* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double v = i < P.n ? pc_d2_value(&P, &Q, acc_q, cnt_q, normals_q, i) : -1.0;
+  unsigned long long cnt = v >= 0; if (v < 0) v = 0;
+  double s = v, m = v;
+  for (int o = 32; o; o >>= 1) { s += __shfl_down(s, o, 64); const double t = __shfl_down(m, o, 64); m = t > m ? t : m; cnt += __shfl_down(cnt, o, 64); }
+  if ((threadIdx.x & 63) == 0 && cnt) { atomicAdd(&out[0], s); atomicMax((unsigned long long*)&out[1], (unsigned long long)__double_as_longlong(m)); atomicAdd((unsigned long long*)&out[2], cnt); }
+}
+void launch_d2_insert(const int16_t* xyz, int n, uint32_t* vol, uint32_t* keys, uint32_t* vals, int lg) { if (n > 0) hipLaunchKernelGGL(k_d2_insert, dim3((n + 255) / 256), dim3(256), 0, g_stream, xyz, n, vol, keys, vals, lg); }
+void launch_d2_give(const RbtD2Set* A, const int16_t* normals_a, const RbtD2Set* B, long long* acc_b, int32_t* cnt_b) { if (A->n > 0) hipLaunchKernelGGL(k_d2_give, dim3((A->n + 255) / 256), dim3(256), 0, g_stream, *A, normals_a, *B, acc_b, cnt_b); }
+void launch_d2_take(const RbtD2Set* B, const RbtD2Set* A, const int16_t* normals_a, long long* acc_b, int32_t* cnt_b) { if (B->n > 0) hipLaunchKernelGGL(k_d2_take, dim3((B->n + 255) / 256), dim3(256), 0, g_stream, *B, *A, normals_a, acc_b, cnt_b); }
+void launch_d2_dist(const RbtD2Set* P, const RbtD2Set* Q, const long long* acc_q, const int32_t* cnt_q, const int16_t* normals_q, double* out) { if (P->n > 0) hipLaunchKernelGGL(k_d2_dist, dim3((P->n + 255) / 256), dim3(256), 0, g_stream, *P, *Q, acc_q, cnt_q, normals_q, out); }
 void launch_pcc_occmap(const RbtPccParams* P, const uint16_t* occ, uint8_t* om) { hipLaunchKernelGGL(k_pcc_occmap, dim3((P->w * P->h + 255) / 256), dim3(256), 0, g_stream, *P, occ, om); }
 void launch_pcc_owner(const RbtPccParams* P, const rbt_patch* patches, const uint32_t* items, int n_items, const uint16_t* occ, uint32_t* b2p) {
   if (n_items > 0) hipLaunchKernelGGL(k_pcc_owner, dim3(n_items), dim3(256), 0, g_stream, *P, patches, items, occ, b2p);

@@ -115,3 +115,86 @@ RBT_DEV uint32_t pc_nearest_d2(const uint32_t* vol, int x, int y, int z) {
   }
   return best;
 }
+
+// ---- D2 (point-to-plane): QualityMetrics::compute with computeC2p_ (PCCMetrics.cpp:100-124, :213-215), normals by copyNormals / scaleNormals (:371-376, PCCPointSet.cpp:2322-2380) ----
+// Duplicates are merged as for D1; a merged point is stood for by its lowest original index (hash map voxel -> index), its normal is that point's. "The points at the same
+// distance" are all points at exactly the nearest squared distance: the shell of voxels at that distance is walked in the other cloud's bit volume. Normals are Q14 integers;
+// the reconstruction's normals are kept as integer sum and count (scaleNormals' mean is formed where it is used), so the only floating point is the final per-point value.
+RBT_DEV uint32_t pc_voxel_id(int x, int y, int z) { return ((uint32_t)z << (2 * RBT_PCC_BITS)) | ((uint32_t)y << RBT_PCC_BITS) | (uint32_t)x; }
+RBT_DEV uint32_t pc_hash_slot(uint32_t id, int lg) { return (id * 2654435761u) >> (32 - lg); }
+// voxel -> lowest point index; keys: voxel id + 1 (0 = empty), vals start at 0xFFFFFFFF
+RBT_DEV void pc_hash_insert(uint32_t* keys, uint32_t* vals, int lg, uint32_t id, uint32_t index) {
+  const uint32_t mask = (1u << lg) - 1;
+  for (uint32_t s = pc_hash_slot(id, lg);; s = (s + 1) & mask) {
+#ifdef RBT_HOSTEMU
+    if (keys[s] == 0) keys[s] = id + 1;
+    if (keys[s] == id + 1) { if (index < vals[s]) vals[s] = index; return; }
+#else
+    const uint32_t old = atomicCAS(&keys[s], 0u, id + 1);
+    if (old == 0 || old == id + 1) { atomicMin(&vals[s], index); return; }
+#endif
+  }
+}
+RBT_DEV uint32_t pc_hash_find(const uint32_t* keys, const uint32_t* vals, int lg, uint32_t id) {
+  const uint32_t mask = (1u << lg) - 1;
+  for (uint32_t s = pc_hash_slot(id, lg);; s = (s + 1) & mask) { if (keys[s] == id + 1) return vals[s]; if (keys[s] == 0) return 0xFFFFFFFFu; }
+}
+RBT_DEV int pc_isqrt(uint32_t v) { int r = (int)__builtin_sqrtf((float)v); while ((uint32_t)(r * r) > v) r--; while ((uint32_t)((r + 1) * (r + 1)) <= v) r++; return r; }
+// every set voxel of vol at squared distance exactly d2 from (x,y,z): f(voxel id)
+template <class F> RBT_DEV void pc_for_ties(const uint32_t* vol, int x, int y, int z, uint32_t d2, F f) {
+  const int r = pc_isqrt(d2);
+  for (int dz = -r; dz <= r; dz++) {
+    const int zz = z + dz; if (zz < 0 || zz >= RBT_PCC_DIM) continue;
+    for (int dy = -r; dy <= r; dy++) {
+      const int yy = y + dy; if (yy < 0 || yy >= RBT_PCC_DIM) continue;
+      const int rem = (int)d2 - dz * dz - dy * dy; if (rem < 0) continue;
+      const int dx = pc_isqrt((uint32_t)rem); if (dx * dx != rem) continue;
+      if (x + dx < RBT_PCC_DIM && pc_voxel_set(vol, x + dx, yy, zz)) f(pc_voxel_id(x + dx, yy, zz));
+      if (dx && x - dx >= 0 && pc_voxel_set(vol, x - dx, yy, zz)) f(pc_voxel_id(x - dx, yy, zz));
+    }
+  }
+}
+RBT_DEV int pc_d2_is_rep(const RbtD2Set* s, int i) { return pc_hash_find(s->keys, s->vals, s->lg, pc_voxel_id(s->xyz[3 * i], s->xyz[3 * i + 1], s->xyz[3 * i + 2])) == (uint32_t)i; }
+// scaleNormals, first half: source point i (a representative) gives its normal to the points of B nearest to it
+RBT_DEV void pc_d2_give(const RbtD2Set* A, const int16_t* normals_a, const RbtD2Set* B, long long* acc_b, int32_t* cnt_b, int i) {
+  if (!pc_d2_is_rep(A, i)) return;
+  const int x = A->xyz[3 * i], y = A->xyz[3 * i + 1], z = A->xyz[3 * i + 2];
+  const uint32_t d2 = pc_nearest_d2(B->vol, x, y, z);
+  pc_for_ties(B->vol, x, y, z, d2, [&](uint32_t id) {
+    const uint32_t j = pc_hash_find(B->keys, B->vals, B->lg, id);
+#ifdef RBT_HOSTEMU
+    for (int c = 0; c < 3; c++) acc_b[3 * j + c] += normals_a[3 * i + c];
+    cnt_b[j]++;
+#else
+    for (int c = 0; c < 3; c++) atomicAdd((unsigned long long*)&acc_b[3 * j + c], (unsigned long long)(long long)normals_a[3 * i + c]);
+    atomicAdd(&cnt_b[j], 1);
+#endif
+  });
+}
+// second half: a point of B that got no normal takes the mean of the source points nearest to it (sum and count)
+RBT_DEV void pc_d2_take(const RbtD2Set* B, const RbtD2Set* A, const int16_t* normals_a, long long* acc_b, int32_t* cnt_b, int j) {
+  if (!pc_d2_is_rep(B, j) || cnt_b[j] != 0) return;
+  const int x = B->xyz[3 * j], y = B->xyz[3 * j + 1], z = B->xyz[3 * j + 2];
+  const uint32_t d2 = pc_nearest_d2(A->vol, x, y, z);
+  long long s0 = 0, s1 = 0, s2 = 0; int n = 0;
+  pc_for_ties(A->vol, x, y, z, d2, [&](uint32_t id) { const uint32_t i = pc_hash_find(A->keys, A->vals, A->lg, id); s0 += normals_a[3 * i]; s1 += normals_a[3 * i + 1]; s2 += normals_a[3 * i + 2]; n++; });
+  acc_b[3 * j] = s0; acc_b[3 * j + 1] = s1; acc_b[3 * j + 2] = s2; cnt_b[j] = n;
+}
+// point-to-plane value of point i of P against Q: mean over Q's points at the nearest distance of ((p - q) . normal(q))^2; Q's normals are acc_q / cnt_q (Q14), or
+// normals_q with count 1 where acc_q is null. Returns -1 for a point that is not a representative.
+RBT_DEV double pc_d2_value(const RbtD2Set* P, const RbtD2Set* Q, const long long* acc_q, const int32_t* cnt_q, const int16_t* normals_q, int i) {
+  if (!pc_d2_is_rep(P, i)) return -1.0;
+  const int x = P->xyz[3 * i], y = P->xyz[3 * i + 1], z = P->xyz[3 * i + 2];
+  const uint32_t d2 = pc_nearest_d2(Q->vol, x, y, z);
+  double sum = 0; int n = 0;
+  pc_for_ties(Q->vol, x, y, z, d2, [&](uint32_t id) {
+    const uint32_t j = pc_hash_find(Q->keys, Q->vals, Q->lg, id);
+    const int ex = x - (int)(id & (RBT_PCC_DIM - 1)), ey = y - (int)((id >> RBT_PCC_BITS) & (RBT_PCC_DIM - 1)), ez = z - (int)(id >> (2 * RBT_PCC_BITS));
+    long long dot; int cnt;
+    if (acc_q) { dot = ex * acc_q[3 * j] + ey * acc_q[3 * j + 1] + ez * acc_q[3 * j + 2]; cnt = cnt_q[j]; }
+    else { dot = (long long)ex * normals_q[3 * j] + (long long)ey * normals_q[3 * j + 1] + (long long)ez * normals_q[3 * j + 2]; cnt = 1; }
+    const double v = (double)dot / (double)cnt;
+    sum += v * v; n++;
+  });
+  return sum / n / (16384.0 * 16384.0);
+}

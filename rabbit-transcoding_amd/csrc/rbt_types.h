@@ -122,6 +122,8 @@ struct RbtFrame {
 
 struct RbtSlice;
 struct RbtFrame;
+// D2 metric (csrc/rbt_pcc.h): one cloud - points, bit volume of its voxels, hash map voxel -> lowest point index (keys: voxel id + 1, 0 = empty)
+struct RbtD2Set { const int16_t* xyz; int n; const uint32_t* vol; const uint32_t* keys; const uint32_t* vals; int lg; };
 // One slice segment of a merged entropy-decoding launch (slices of several batches in one grid: rbt_kernels.h launch_parse_tasks)
 struct RbtParseTask { RbtFrame* frames; RbtSlice* slices; const uint8_t* rbsp; int32_t slice; int32_t pad; };   // handed to waves in list order (a row task waits for the task of the row above it)
 // One picture of a merged reconstruction launch (pictures of several batches on the same wavefront: launch_recon_refs)

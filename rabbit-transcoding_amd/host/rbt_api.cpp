@@ -227,5 +227,10 @@ int rbt_d1(rbt_ctx* ctx, const int16_t* xyz_a, int n_a, const int16_t* xyz_b, in
   RBT_ENTER(ctx);
   return rbt::pcc_d1(ctx->last_err, xyz_a, n_a, xyz_b, n_b, peak, out);
 } RBT_CATCH
+int rbt_d2(rbt_ctx* ctx, const int16_t* xyz_a, const int16_t* normals_a, int n_a, const int16_t* xyz_b, int n_b, int peak, rbt_d2_result* out) try {
+  if (!ctx || !xyz_a || !normals_a || !xyz_b || !out) return RBT_ERR_PARAM;
+  RBT_ENTER(ctx);
+  return rbt::pcc_d2(ctx->last_err, xyz_a, normals_a, n_a, xyz_b, n_b, peak, out);
+} RBT_CATCH
 
 }  // extern "C"

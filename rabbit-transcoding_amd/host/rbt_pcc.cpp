@@ -105,4 +105,38 @@ int pcc_d1(std::string& err, const int16_t* a, int na, const int16_t* b, int nb,
   out->psnr_ab = 10 * log10f(3 * p * p / out->mse_ab); out->psnr_ba = 10 * log10f(3 * p * p / out->mse_ba); out->psnr = 10 * log10f(3 * p * p / m);
   return RBT_OK;
 }
+
+// QualityMetrics::compute with computeC2p_ (PCCMetrics.cpp:100-124, :213-215) both ways (:299-309), normals as PCCMetrics::compute arranges them (:371-376): csrc/rbt_pcc.h
+int pcc_d2(std::string& err, const int16_t* a, const int16_t* normals_a, int na, const int16_t* b, int nb, int peak, rbt_d2_result* out) {
+  memset(out, 0, sizeof(*out));
+  if (na <= 0 || nb <= 0 || peak <= 0 || !normals_a) { err = "empty point cloud or no normals"; return RBT_ERR_PARAM; }
+  for (int i = 0; i < 3 * na; i++) if (a[i] < 0 || a[i] >= RBT_PCC_DIM) { err = "coordinate outside 0..1023"; return RBT_ERR_PARAM; }
+  for (int i = 0; i < 3 * nb; i++) if (b[i] < 0 || b[i] >= RBT_PCC_DIM) { err = "coordinate outside 0..1023"; return RBT_ERR_PARAM; }
+  const size_t vol_bytes = (size_t)1 << (3 * RBT_PCC_BITS - 3);
+  auto lg_of = [](int n) { int lg = 4; while (((size_t)1 << lg) < 2 * (size_t)n) lg++; return lg; };
+  const int lga = lg_of(na), lgb = lg_of(nb);
+  DevBuf va, vb, pa, pb, na_, ka, kb, wa, wb, accb, cntb, res;
+  if (!va.alloc(vol_bytes) || !vb.alloc(vol_bytes) || !pa.alloc(6 * (size_t)na) || !pb.alloc(6 * (size_t)nb) || !na_.alloc(6 * (size_t)na) || !ka.alloc((size_t)4 << lga) || !wa.alloc((size_t)4 << lga) ||
+      !kb.alloc((size_t)4 << lgb) || !wb.alloc((size_t)4 << lgb) || !accb.alloc(24 * (size_t)nb) || !cntb.alloc(4 * (size_t)nb) || !res.alloc(64)) { err = "device allocation failed"; return RBT_ERR_NOMEM; }
+  int bad = rbtk::dev_memset(va.p, 0, vol_bytes) | rbtk::dev_memset(vb.p, 0, vol_bytes) | rbtk::dev_memset(ka.p, 0, (size_t)4 << lga) | rbtk::dev_memset(kb.p, 0, (size_t)4 << lgb) |
+            rbtk::dev_memset(wa.p, 0xFF, (size_t)4 << lga) | rbtk::dev_memset(wb.p, 0xFF, (size_t)4 << lgb) | rbtk::dev_memset(accb.p, 0, 24 * (size_t)nb) | rbtk::dev_memset(cntb.p, 0, 4 * (size_t)nb) |
+            rbtk::dev_memset(res.p, 0, 64) | rbtk::h2d(pa.p, a, 6 * (size_t)na) | rbtk::h2d(pb.p, b, 6 * (size_t)nb) | rbtk::h2d(na_.p, normals_a, 6 * (size_t)na);
+  if (bad) { err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
+  rbtk::launch_d2_insert(pa.as<int16_t>(), na, va.as<uint32_t>(), ka.as<uint32_t>(), wa.as<uint32_t>(), lga);
+  rbtk::launch_d2_insert(pb.as<int16_t>(), nb, vb.as<uint32_t>(), kb.as<uint32_t>(), wb.as<uint32_t>(), lgb);
+  RbtD2Set A{pa.as<int16_t>(), na, va.as<uint32_t>(), ka.as<uint32_t>(), wa.as<uint32_t>(), lga}, B{pb.as<int16_t>(), nb, vb.as<uint32_t>(), kb.as<uint32_t>(), wb.as<uint32_t>(), lgb};
+  rbtk::launch_d2_give(&A, na_.as<int16_t>(), &B, accb.as<long long>(), cntb.as<int32_t>());
+  rbtk::launch_d2_take(&B, &A, na_.as<int16_t>(), accb.as<long long>(), cntb.as<int32_t>());
+  double* r = res.as<double>();
+  rbtk::launch_d2_dist(&A, &B, accb.as<long long>(), cntb.as<int32_t>(), nullptr, r);
+  rbtk::launch_d2_dist(&B, &A, nullptr, nullptr, na_.as<int16_t>(), r + 4);
+  double h[8];
+  if (rbtk::d2h(h, res.p, 64) || rbtk::dev_sync()) { err = "kernel execution failed"; return RBT_ERR_NO_DEVICE; }
+  uint64_t cnt_a, cnt_b; memcpy(&cnt_a, &h[2], 8); memcpy(&cnt_b, &h[6], 8);
+  out->n_a = (int)cnt_a; out->n_b = (int)cnt_b; out->sse_ab = h[0]; out->max_ab = h[1]; out->sse_ba = h[4]; out->max_ba = h[5];
+  out->mse_ab = (float)(out->sse_ab / out->n_a); out->mse_ba = (float)(out->sse_ba / out->n_b);
+  const float p = (float)peak, m = out->mse_ab > out->mse_ba ? out->mse_ab : out->mse_ba;
+  out->psnr_ab = 10 * log10f(3 * p * p / out->mse_ab); out->psnr_ba = 10 * log10f(3 * p * p / out->mse_ba); out->psnr = 10 * log10f(3 * p * p / m);
+  return RBT_OK;
+}
 }  // namespace rbt

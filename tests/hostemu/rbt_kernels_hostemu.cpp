@@ -128,6 +128,14 @@ void launch_vol_set(const int16_t* xyz, int n, uint32_t* vol, uint8_t* first, ui
   for (int i = 0; i < n; i++) { const int x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2]; uint32_t* w = &vol[pc_voxel_word(x, y, z)]; const uint32_t bit = 1u << (x & 31);
     first[i] = !(*w & bit); *w |= bit; if (first[i]) (*n_unique)++; }
 }
+void launch_d2_insert(const int16_t* xyz, int n, uint32_t* vol, uint32_t* keys, uint32_t* vals, int lg) {
+  for (int i = 0; i < n; i++) { const int x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2]; vol[pc_voxel_word(x, y, z)] |= 1u << (x & 31); pc_hash_insert(keys, vals, lg, pc_voxel_id(x, y, z), (uint32_t)i); }
+}
+void launch_d2_give(const RbtD2Set* A, const int16_t* normals_a, const RbtD2Set* B, long long* acc_b, int32_t* cnt_b) { for (int i = 0; i < A->n; i++) pc_d2_give(A, normals_a, B, acc_b, cnt_b, i); }
+void launch_d2_take(const RbtD2Set* B, const RbtD2Set* A, const int16_t* normals_a, long long* acc_b, int32_t* cnt_b) { for (int j = 0; j < B->n; j++) pc_d2_take(B, A, normals_a, acc_b, cnt_b, j); }
+void launch_d2_dist(const RbtD2Set* P, const RbtD2Set* Q, const long long* acc_q, const int32_t* cnt_q, const int16_t* normals_q, double* out) {
+  for (int i = 0; i < P->n; i++) { const double v = pc_d2_value(P, Q, acc_q, cnt_q, normals_q, i); if (v < 0) continue; out[0] += v; if (v > out[1]) out[1] = v; ((unsigned long long*)out)[2]++; }
+}
 void launch_vol_nn(const int16_t* xyz, const uint8_t* first, int n, const uint32_t* vol_other, unsigned long long* sse, uint32_t* max_d2) {
   for (int i = 0; i < n; i++) if (first[i]) { const uint32_t d = pc_nearest_d2(vol_other, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]); *sse += d; if (d > *max_d2) *max_d2 = d; }
 }

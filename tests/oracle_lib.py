@@ -46,6 +46,11 @@ class OD1(C.Structure):
                 ("mse_ab", C.c_float), ("mse_ba", C.c_float), ("psnr_ab", C.c_float), ("psnr_ba", C.c_float), ("psnr", C.c_float)]
 
 
+class OD2(C.Structure):
+    _fields_ = [("n_a", C.c_int), ("n_b", C.c_int), ("sse_ab", C.c_double), ("sse_ba", C.c_double), ("max_ab", C.c_double), ("max_ba", C.c_double),
+                ("mse_ab", C.c_float), ("mse_ba", C.c_float), ("psnr_ab", C.c_float), ("psnr_ba", C.c_float), ("psnr", C.c_float)]
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"])
 
@@ -65,6 +70,7 @@ def lib():
         L.oracle_reconstruct.argtypes = [C.POINTER(OAtlas), C.POINTER(OPatch), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(OCloud)]
         L.oracle_cloud_free.argtypes = [C.POINTER(OCloud)]
         L.oracle_d1.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(OD1)]
+        L.oracle_d2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(OD2)]
         L.oracle_sample_to_byte_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.oracle_byte_to_sample_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.oracle_or_pool.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -210,6 +216,16 @@ def d1(a, b, peak=1023):
     if lib().oracle_d1(a.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0], peak, C.byref(r)) != 0:
         raise RuntimeError("oracle d1 failed")
     return {n: getattr(r, n) for n, _ in OD1._fields_}
+
+
+def d2(a, normals_a, b, peak=1023):
+    """oracle_d2: point-to-plane metric; normals_a int16 Q14 (16384 = 1.0), three per point of a"""
+    a = np.ascontiguousarray(a, dtype=np.int16); b = np.ascontiguousarray(b, dtype=np.int16); na = np.ascontiguousarray(normals_a, dtype=np.int16)
+    assert na.shape == a.shape
+    r = OD2()
+    if lib().oracle_d2(a.ctypes.data, na.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0], peak, C.byref(r)) != 0:
+        raise RuntimeError("oracle d2 failed")
+    return {n: getattr(r, n) for n, _ in OD2._fields_}
 
 
 def sps_fields(stream: bytes):

@@ -136,3 +136,26 @@ def atlas_patches(R, w, h, seed):
     for i, (x, y, pw, ph) in enumerate(rects):
         out.append(R.Patch(x // 16, y // 16, pw // 16, ph // 16, (i * 97) % (1023 - pw), (i * 53) % (1023 - ph), (i * 31) % 700, i % 3, (i + 1) % 3, (i + 2) % 3, 0, 0, 1, 1))
     return out
+
+
+def atlas_index_picture(w, h, seed):
+    """a 4:2:0 picture whose luma carries, at every pixel of a patch rectangle of make_maps(w, h, seed), that patch's index: handed to the reconstruction as
+    "attribute" it comes back as the patch index of every point (the colour fetch reads the point's pixel)"""
+    _, rects = atlas_layout(w, h, seed)
+    y = np.zeros((h, w), np.uint16)
+    for i, (x, yy, pw, ph) in enumerate(rects):
+        y[yy:yy + ph, x:x + pw] = i
+    return np.concatenate([y.ravel(), np.zeros(w * h // 2, np.uint16)])
+
+
+def source_normals(R, reconstruct, w, h, seed, occ_full, geo):
+    """the source cloud of make_maps(w, h, seed) with one normal per point: the projection axis of the point's patch (Q14, 16384 = 1.0), pointing the way the
+    depth grows. reconstruct: ctx.reconstruct of the library or of the oracle (same signature)."""
+    pats = atlas_patches(R, w, h, seed)
+    idx = atlas_index_picture(w, h, seed)
+    xyz, yuv, _, _ = reconstruct(R.AtlasParams(w, h, 16, 1, 2, 1, 1, 0), pats, occ_full.astype(np.uint16), geo[0][: w * h].reshape(h, w), geo[1][: w * h].reshape(h, w), 10, idx, idx, 10)
+    axes = np.array([p.normal_axis for p in pats]); sign = np.array([1 if p.projection_mode == 0 else -1 for p in pats])
+    pi = yuv[:, 0].astype(np.int64)
+    n = np.zeros((xyz.shape[0], 3), np.int16)
+    n[np.arange(xyz.shape[0]), axes[pi]] = 16384 * sign[pi]
+    return xyz, n

@@ -70,3 +70,27 @@ def test_full_size_frame_after_transcode(ctx):
     for k in ("n_a", "n_b", "sse_ab", "sse_ba", "max_ab", "max_ba"):
         assert got[k] == want[k], k
     assert 40 < got["psnr"] < 100
+
+
+def test_d2_matches_oracle_and_brute_force(ctx):
+    """rbt_d2 on the GPU (hash map voxel -> lowest index, ties walked in the bit volume, integer normal sums, double atomics) == oracle == brute force (tests/test_pcc_recon.py)"""
+    import test_pcc_recon as T
+    T.check_d2(ctx)
+
+
+def test_d2_of_a_synthetic_frame(ctx):
+    """source cloud of a 256x256 synthetic atlas with patch-axis normals against the cloud of perturbed depth maps: GPU == oracle, D2 PSNR >= D1 PSNR"""
+    R = rbt_lib.module()
+    w = h = 256
+    src = synth.make_maps(w, h, 77)
+    xyz, n = synth.source_normals(R, ctx.reconstruct, w, h, 77, src["occ_full"], src["geo"])
+    x2, n2 = synth.source_normals(R, O.reconstruct, w, h, 77, src["occ_full"], src["geo"])
+    assert np.array_equal(xyz, x2) and np.array_equal(n, n2) and xyz.shape[0] > 1000
+    r = np.random.default_rng(1)
+    g = src["geo"].copy(); g[:, : w * h] = np.clip(g[:, : w * h].astype(int) + 4 * r.integers(-1, 2, (2, w * h)), 0, 1023)
+    pats = synth.atlas_patches(R, w, h, 77)
+    occ4 = src["occ_full"].reshape(h // 4, 4, w // 4, 4).max(axis=(1, 3)).astype(np.uint16)
+    dec = ctx.reconstruct(R.AtlasParams(w, h, 16, 4, 2, 1, 1, 0), pats, occ4, g[0][: w * h].reshape(h, w), g[1][: w * h].reshape(h, w), 10)[0]
+    got, want = ctx.d2(xyz, n, dec), O.d2(xyz, n, dec)
+    assert (got["n_a"], got["n_b"]) == (want["n_a"], want["n_b"]) and got["sse_ab"] == pytest.approx(want["sse_ab"], rel=1e-9) and got["sse_ba"] == pytest.approx(want["sse_ba"], rel=1e-9)
+    assert got["psnr"] >= ctx.d1(xyz, dec)["psnr"] - 1e-3

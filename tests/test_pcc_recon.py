@@ -88,3 +88,62 @@ def test_bad_arguments(ctx):
     z = np.zeros((32, 32), np.uint16)
     with pytest.raises(R.RbtError):
         ctx.reconstruct(atlas, [R.Patch(1, 1, 2, 1, 0, 0, 0, 2, 0, 1, 0, 0, 1, 1)], z, z, z)     # patch leaves the atlas
+
+
+def d2_cases():
+    """(a, normals_a, b) clouds for the point-to-plane metric, shared with tests/test_gpu_pcc.py: axis normals and slanted ones, duplicates on both sides, a sparse
+    reconstruction (points of B that no source point is nearest to take their normal from the source) and an outlier"""
+    out = []
+    for seed in range(4):
+        r = np.random.default_rng(40 + seed)
+        a = r.integers(100, 140, (3000, 3)).astype(np.int16)
+        if seed % 2:
+            n = np.zeros((3000, 3), np.int16); n[np.arange(3000), r.integers(0, 3, 3000)] = 16384 * r.choice([-1, 1], 3000)
+        else:
+            v = r.normal(size=(3000, 3)); n = np.round(16384 * v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.int16)
+        b = np.clip(a[r.permutation(3000)[:2500 if seed < 3 else 300]] + r.integers(-2, 3, (2500 if seed < 3 else 300, 3)), 0, 1023).astype(np.int16)
+        if seed == 2: b = np.concatenate([b, np.array([[230, 40, 300]], np.int16)])
+        out.append((a, n, b))
+    return out
+
+
+def d2_brute_force(a, n, b):
+    """the definition, by brute force on the merged points: (sum A -> B, sum B -> A, unique A, unique B)"""
+    ua, ia = np.unique(a, axis=0, return_index=True); ub = np.unique(b, axis=0)
+    na = n[ia].astype(np.float64)          # np.unique returns the FIRST occurrence: the lowest original index
+    A, B = ua.astype(np.int64), ub.astype(np.int64)
+    d = ((A[:, None, :] - B[None, :, :]) ** 2).sum(-1)
+    tie_ab = d == d.min(1, keepdims=True); tie_ba = d == d.min(0, keepdims=True)
+    acc = tie_ab.T.astype(np.float64) @ na; cnt = tie_ab.sum(0).astype(np.float64)
+    for j in np.nonzero(cnt == 0)[0]:
+        acc[j] = na[tie_ba[:, j]].sum(0); cnt[j] = tie_ba[:, j].sum()
+    nb = acc / cnt[:, None]
+    s_ab = s_ba = 0.0
+    for i in range(len(A)):
+        js = np.nonzero(tie_ab[i])[0]
+        s_ab += np.mean(((A[i] - B[js]) * nb[js]).sum(1) ** 2)
+    for j in range(len(B)):
+        ii = np.nonzero(tie_ba[:, j])[0]
+        s_ba += np.mean(((B[j] - A[ii]) * na[ii]).sum(1) ** 2)
+    q = 16384.0 ** 2
+    return s_ab / q, s_ba / q, len(A), len(B)
+
+
+def check_d2(ctx):
+    for a, n, b in d2_cases():
+        got, want = ctx.d2(a, n, b), O.d2(a, n, b)
+        assert (got["n_a"], got["n_b"]) == (want["n_a"], want["n_b"])
+        for k in ("sse_ab", "sse_ba", "max_ab", "max_ba"):
+            assert got[k] == pytest.approx(want[k], rel=1e-9), k          # sums of doubles in another order
+        assert got["psnr"] == pytest.approx(want["psnr"], abs=1e-4) and got["psnr_ab"] == pytest.approx(want["psnr_ab"], abs=1e-4)
+        s_ab, s_ba, n_a, n_b = d2_brute_force(a, n, b)
+        assert (n_a, n_b) == (want["n_a"], want["n_b"]) and want["sse_ab"] == pytest.approx(s_ab, rel=1e-9) and want["sse_ba"] == pytest.approx(s_ba, rel=1e-9)
+        # planes cannot be further away than points: D2 <= D1 per direction
+        d1 = ctx.d1(a, b)
+        assert got["sse_ab"] <= d1["sse_ab"] * (1 + 1e-9) and got["sse_ba"] <= d1["sse_ba"] * (1 + 1e-9)
+    a, n, _ = d2_cases()[0]
+    assert ctx.d2(a, n, a)["sse_ab"] == 0
+
+
+def test_d2_matches_oracle_and_brute_force(ctx):
+    check_d2(ctx)
