@@ -71,6 +71,7 @@ def main():
                     "0 = choose by the length of the run (gof_shard.job_shape): 2 for a long run (16 jobs x 2 GOFs keep the GPU full); a run shorter than 48 steps is all ramp-up and "
                     "drain and does better with few jobs (7, or 2 up to 12 steps) that own several hardware queues each than with many that own one)")
     ap.add_argument("--sweep", type=int, default=64, help="also time K GOFs at every in-flight depth 1..4 (extra field in_flight_sweep; 0/1 = skip)")
+    ap.add_argument("--steady-steps", type=int, default=256, help="when --steps is smaller: also time a walk of this many GOFs (extra top-level field steady_state_fps_256; 0 = skip)")
     ap.add_argument("--quality", type=int, default=1, help="report picture PSNR of the output vs the input (extra field quality; 0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (with --backend gloo)")
@@ -402,6 +403,15 @@ def main():
             assert so_ == outs
             sweep.append({"in_flight": d, "gofs": args.sweep, "value": round(n_pc / pt, 3), "ms_per_gof": round(1000 * pt, 3)})
         ctx.set_depth(D)
+    # the headline of a short run (the driver's --steps 20) is all ramp-up and drain: the steady state of a long walk beside it (the same job shape rule as a 256-step run)
+    steady = None
+    if world == 1 and args.steady_steps > 0 and args.steps < args.steady_steps:
+        g_s = gs.job_shape(args.steady_steps)[0]; d_s = max(1, min(args.in_flight, 16, (args.steady_steps + g_s - 1) // g_s))
+        ctx.set_depth(d_s)
+        run(d_s * g_s, d_s, None, g_s)
+        p0 = time.perf_counter(); run(args.steady_steps, d_s, None, g_s); pt = time.perf_counter() - p0
+        steady = {"steps": args.steady_steps, "value": round(n_pc * args.steady_steps / pt, 3), "unit": "point-cloud frames/s", "jobs_in_flight": d_s, "gofs_per_job": g_s}
+        ctx.set_depth(D)
 
     # informative: what the re-encode did to the pictures (luma PSNR of the R3 output's pictures against the R5 input's,
     # both decoded by this library), and that the occupancy output is exactly the 2x2 OR-pool of the input occupancy
@@ -474,7 +484,27 @@ def main():
             occ_rd["value"] = round(n_pc * k_on / dt, 2); occ_rd["unit"] = "point-cloud frames/s"; occ_rd["steps"] = k_on
         except Exception as e:   # informative leg: never lose the benchmark line over it
             occ_rd = {"error": str(e)}
-        quality = {"d1": d1, "occupancy_rd": occ_rd, "geometry_psnr_y_db": psnr_y(sg, outs[1], w, h, 1023), "attribute_psnr_y_db": psnr_y(sa, outs[2], w, h, 1023),
+        # the same-data anchor (tests/golden/make_anchor.py, made in the build container): the SOURCE maps of this GOF coded directly at the target QPs by the oracle's HM-like
+        # mode - what BASELINE.md's R3 row is for 8i data - next to what the transcode of the R5 stream comes out at, both against the uncoded source maps
+        anchor = None
+        try:
+            an = json.load(open(os.path.join(ROOT, "tests", "golden", "anchor_direct_encode.json")))
+            if fixture and (an["width"], an["height"], an["frames"]) == (w, h, n_pc) and "R3" in an["rates"]:
+                import synth
+                g_src, a_src, _ = synth.make_gof_maps(w, h, n_pc, 1051)
+
+                def psnr_src(maps, stream):
+                    d_ = ctx.decode(stream)[0][:, : w * h].astype(np.float64)
+                    return round(10 * np.log10(1023.0 * 1023.0 / float(np.mean((maps[:, : w * h].astype(np.float64) - d_) ** 2))), 3)
+                anchor = {"direct_encode_R3": an["rates"]["R3"], "encoder": an["encoder"],
+                          "transcode_R5_to_R3": {"bytes": {"occupancy": len(outs[0]), "geometry": len(outs[1]), "attribute": len(outs[2]), "total": out_bytes},
+                                                 "geometry_psnr_y_vs_source_db": psnr_src(g_src, outs[1]), "attribute_psnr_y_vs_source_db": psnr_src(a_src, outs[2]),
+                                                 "d1_psnr_frame0_vs_source_db": (d1 or {}).get("d1_psnr_r3_output_vs_source_db"), "d2_psnr_frame0_vs_source_db": (d1 or {}).get("d2_psnr_r3_output_vs_source_db")},
+                          "r5_input": {"bytes": in_bytes, "geometry_psnr_y_vs_source_db": psnr_src(g_src, sg), "attribute_psnr_y_vs_source_db": psnr_src(a_src, sa)},
+                          "note": "same maps, same QPs: the direct encode sees the uncoded source (first generation), the transcode the decoded R5 stream (second generation)"}
+        except Exception as e:
+            anchor = {"error": str(e)}
+        quality = {"d1": d1, "anchor_direct_encode": anchor, "occupancy_rd": occ_rd, "geometry_psnr_y_db": psnr_y(sg, outs[1], w, h, 1023), "attribute_psnr_y_db": psnr_y(sa, outs[2], w, h, 1023),
                    "occupancy_is_or_pool": bool(np.array_equal(oo[:, :(ow // 2) * (oh // 2)].reshape(-1, oh // 2, ow // 2) > 0, pooled)),
                    "note": "picture PSNR: R3 output pictures vs R5 input pictures"}
 
@@ -516,6 +546,8 @@ def main():
         line = {"metric": "transcoded point-cloud frames/sec, R5->R3", "value": round(fps, 3), "unit": "point-cloud frames/s", "n_gpus": world,
                 "steps": steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "u16/i32", "data": "synthetic",
+                "latency_ms_one_gof": (sweep[0]["ms_per_gof"] if sweep else None),                # one GOF alone (blocking call): the headline is a throughput with GOFs in flight, not this
+                "steady_state_fps_256": (steady["value"] if steady else (round(fps, 3) if steps >= 256 else None)), "steady_state": steady,
                 "config": {"workload": f"{n_pc}-frame GOF, {w}x{h} V-PCC maps (2x{n_pc} geometry + 2x{n_pc} attribute yuv420p10 I/P pairs, {n_pc} occupancy {w // 2}x{h // 2} lossless), "
                                        f"R5 (QP16/22, prec 2) -> R3 (QP24/32, prec 4), synthetic longdress-like atlas", "input": input_kind,
                            "encoder": ("RBT-E1, wavefront mode (one slice per picture, a dependent slice segment per CTB row, entropy_coding_sync)" if args.rows < 0 else f"RBT-E1, {args.rows or 'all'} CTB row(s) per slice")

@@ -238,6 +238,8 @@ typedef struct {
   int log2_ctb, ctb_rows_per_slice, md5_sei, verify_md5;   /* as in rbt_stream_params */
   int gofs_per_job;          /* GOFs handed to the GPU per job; 0 = by rbt_job_shape from the number of GOFs this context owns, which also lowers the announced depth for
                               * the duration of the call when the walk is short (the depth announced with rbt_set_depth is the cap and is restored) */
+  int occupancy_rd;          /* occupancy-aware coding of the geometry / attribute units of every GOF (rbt_stream_params.occupancy_rd): with the occupancy map that GOF's
+                              * occupancy unit comes out with, when occupancy_precision is 4 */
 } rbt_v3c_params;
 /* The whole walk: index, per GOF the video units through rbt_submit_gof / rbt_wait_gof with as many jobs in flight as rbt_set_depth announced (fewer for a short walk
  * with gofs_per_job = 0), write.

@@ -318,8 +318,9 @@ static int v3c_floor_log2(uint32_t x) { int r = -1; while (x) { r++; x >>= 1; } 
 static int v3c_ceil_log2(uint32_t x) { return x == 0 ? -1 : v3c_floor_log2(x - 1) + 1; }
 typedef struct { int type; uint8_t* d; size_t n; } v3c_unit_t;
 int oracle_v3c_transcode(const uint8_t* in, size_t n, int occupancy_precision, int geometry_qp, int attribute_qp, int forced_precision_bytes,
-                         int log2_ctb, int ctb_rows_per_slice, int md5_sei, uint8_t** out, size_t* n_out) {
+                         int log2_ctb, int ctb_rows_per_slice, int md5_sei, int occupancy_rd, uint8_t** out, size_t* n_out) {
   *out = NULL; *n_out = 0;
+  occ_video ov; memset(&ov, 0, sizeof(ov));      /* occupancy_rd: the occupancy video of the current GOF as it leaves (units of a GOF follow its V3C_VPS, occupancy first) */
   if (n < 1) return -1;
   /* PCCBitstreamReader::read (:51-70): u(3) precision - 1, u(5); then size u(8 * precision) + unit while data is left */
   int prec_in = (in[0] >> 5) + 1, rc = 0;
@@ -338,6 +339,7 @@ int oracle_v3c_transcode(const uint8_t* in, size_t n, int occupancy_precision, i
   /* per unit (the GOF loop of :307-341 only groups them; no state crosses units here): transcodeData (PCCTranscoder.cpp:145-168) on the three videos it names */
   for (size_t k = 0; k < cnt && !rc; k++) {
     uint32_t h = ((uint32_t)u[k].d[0] << 24) | ((uint32_t)u[k].d[1] << 16) | ((uint32_t)u[k].d[2] << 8) | u[k].d[3];
+    if (u[k].type == 0) occ_video_free(&ov);                       /* V3C_VPS: a new GOF */
     oracle_transcode_params tp; memset(&tp, 0, sizeof(tp));
     tp.occupancy_precision = occupancy_precision; tp.log2_ctb = log2_ctb; tp.ctb_rows_per_slice = ctb_rows_per_slice; tp.md5_sei = md5_sei;
     if (u[k].type == 2) { if (occupancy_precision != 4) continue; tp.video_type = 0; tp.qp = 8; }                       /* V3C_OVD; :150 */
@@ -347,7 +349,8 @@ int oracle_v3c_transcode(const uint8_t* in, size_t n, int occupancy_precision, i
     if (u[k].n <= 4) continue;
     uint8_t *bs = NULL, *tr = NULL, *ss = NULL; size_t bn = 0, tn = 0, sn = 0;
     rc = oracle_sample_to_byte_stream(u[k].d + 4, u[k].n - 4, &bs, &bn);
-    if (!rc) rc = oracle_transcode_substream(bs, bn, &tp, &tr, &tn);
+    if (!rc) rc = transcode_substream_occ(bs, bn, &tp, (occupancy_rd && tp.video_type != 0 && ov.n) ? &ov : NULL, &tr, &tn);
+    if (!rc && occupancy_rd && tp.video_type == 0) { occ_video_free(&ov); rc = occ_video_decode(tr, tn, &ov); }
     if (!rc) rc = oracle_byte_to_sample_stream(tr, tn, &ss, &sn);
     if (!rc) {
       uint8_t* nd = (uint8_t*)malloc(4 + sn); memcpy(nd, u[k].d, 4); memcpy(nd + 4, ss, sn);
@@ -374,7 +377,7 @@ int oracle_v3c_transcode(const uint8_t* in, size_t n, int occupancy_precision, i
     *out = b.d; *n_out = b.n;
   }
   for (size_t k = 0; k < cnt; k++) free(u[k].d);
-  free(u);
+  free(u); occ_video_free(&ov);
   return rc;
 }
 

@@ -44,7 +44,8 @@ int oracle_transcode_data(int n, const uint8_t* const* in, const size_t* n_in, c
  * :1369-1387), GOF by GOF (:72-96), video units replaced by their transcodes (payload = sub-bitstream in sample stream form, PCCBitstream.cpp:88-111),
  * all units written as one sample stream (PCCBitstreamWriter.cpp:57-91, :1492-1507). V3C_VPS / V3C_AD units are carried over as bytes.
  * geometry / attribute: params of those two videos; occupancy transcoded (qp 8, lossless) only when occupancy_precision == 4. */
+/* (occupancy_rd: the geometry / attribute units of a GOF are coded with the occupancy map its occupancy unit comes out with, oracle_transcode_params.occupancy_rd) */
 int oracle_v3c_transcode(const uint8_t* in, size_t n, int occupancy_precision, int geometry_qp, int attribute_qp, int forced_precision_bytes,
-                         int log2_ctb, int ctb_rows_per_slice, int md5_sei, uint8_t** out, size_t* n_out);
+                         int log2_ctb, int ctb_rows_per_slice, int md5_sei, int occupancy_rd, uint8_t** out, size_t* n_out);
 void oracle_free(void* p);
 #endif

@@ -66,7 +66,7 @@ class V3CUnit(C.Structure):
 
 class V3CParams(C.Structure):
     """rbt_v3c_params: PCCTranscoderParameters as the container walk needs them"""
-    _fields_ = [(n, C.c_int) for n in ("occupancy_precision", "geometry_qp", "attribute_qp", "forced_unit_size_precision_bytes", "log2_ctb", "ctb_rows_per_slice", "md5_sei", "verify_md5", "gofs_per_job")]
+    _fields_ = [(n, C.c_int) for n in ("occupancy_precision", "geometry_qp", "attribute_qp", "forced_unit_size_precision_bytes", "log2_ctb", "ctb_rows_per_slice", "md5_sei", "verify_md5", "gofs_per_job", "occupancy_rd")]
 
 
 class V3CStat(C.Structure):
@@ -255,9 +255,9 @@ class Context:
         return res
 
     def transcode_v3c(self, data: bytes, geometry_qp, attribute_qp, occupancy_precision=4, forced_precision_bytes=0, log2_ctb=5, rows_per_slice=-1, md5_sei=0,
-                      verify_md5=0, gofs_per_job=1):
+                      verify_md5=0, gofs_per_job=1, occupancy_rd=0):
         """rbt_transcode_v3c: a whole V3C sample stream (every GOF this context owns) -> transcoded sample stream; gofs_per_job=0: job shape by rbt_job_shape"""
-        p = V3CParams(occupancy_precision, geometry_qp, attribute_qp, forced_precision_bytes, log2_ctb, rows_per_slice, md5_sei, verify_md5, gofs_per_job)
+        p = V3CParams(occupancy_precision, geometry_qp, attribute_qp, forced_precision_bytes, log2_ctb, rows_per_slice, md5_sei, verify_md5, gofs_per_job, occupancy_rd)
         out, n = C.c_void_p(), C.c_size_t()
         self._chk(self.L.rbt_transcode_v3c(self.h, data, len(data), C.byref(p), C.byref(out), C.byref(n)))
         return self._take(out, n)

@@ -76,7 +76,7 @@ def lib():
         L.oracle_or_pool.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.oracle_md5.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
         L.oracle_free.argtypes = [C.c_void_p]
-        L.oracle_v3c_transcode.argtypes = [C.c_char_p, C.c_size_t] + [C.c_int] * 7 + [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.oracle_v3c_transcode.argtypes = [C.c_char_p, C.c_size_t] + [C.c_int] * 8 + [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         _LIB = L
     return _LIB
 
@@ -156,10 +156,10 @@ def transcode_data(streams, params):
     return res
 
 
-def v3c_transcode(data: bytes, geometry_qp, attribute_qp, occupancy_precision=4, forced_precision_bytes=0, log2_ctb=5, rows_per_slice=-1, md5_sei=0):
+def v3c_transcode(data: bytes, geometry_qp, attribute_qp, occupancy_precision=4, forced_precision_bytes=0, log2_ctb=5, rows_per_slice=-1, md5_sei=0, occupancy_rd=0):
     """oracle_v3c_transcode: the V3C sample stream walk of PccAppTranscoder around transcodeData"""
     out, n = C.c_void_p(), C.c_size_t()
-    rc = lib().oracle_v3c_transcode(data, len(data), occupancy_precision, geometry_qp, attribute_qp, forced_precision_bytes, log2_ctb, rows_per_slice, md5_sei, C.byref(out), C.byref(n))
+    rc = lib().oracle_v3c_transcode(data, len(data), occupancy_precision, geometry_qp, attribute_qp, forced_precision_bytes, log2_ctb, rows_per_slice, md5_sei, occupancy_rd, C.byref(out), C.byref(n))
     if rc != 0:
         raise RuntimeError(f"oracle v3c transcode failed rc={rc}")
     return _take(out, n)

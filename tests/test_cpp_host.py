@@ -90,3 +90,37 @@ def test_cpp_host_v3c_fails_loudly_without_a_gpu(tmp_path):
     (tmp_path / "in.bin").write_bytes(bytes([0x40]))
     r = subprocess.run([_exe(), "--v3c", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
     assert r.returncode == 1 and "no usable HIP device" in r.stderr and not (tmp_path / "out.bin").exists()
+
+
+MULTI = os.path.join(ROOT, "rabbit-transcoding_amd", "rbt_multi_gpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("occupancy_rd", [0, 1])
+def test_cpp_multi_gpu_host_one_rank_equals_oracle(tmp_path, occupancy_rd):
+    """examples/rbt_multi_gpu.cpp --ranks 1: a parent that never touches the GPU starts the rank as a fresh process; the rank transcodes the GOFs its context owns
+    (rbt_transcode_v3c), the parts are gathered on rank 0 through RCCL (ncclAllGather of sizes, grouped ncclSend / ncclRecv - here a communicator of one) and merged
+    with rbt_v3c_index + rbt_v3c_write. Output == the oracle's walk of the same file, with and without occupancy-aware coding. More ranks need more GPUs than a box has."""
+    if not os.path.exists(MULTI):
+        pytest.skip("rbt_multi_gpu not built (make -C rabbit-transcoding_amd)")
+    import v3c_synth as V
+    units = []
+    for g, s in enumerate(_gofs(5)):
+        units += V.gof_units(s, 60 + g)
+    data = V.sample_stream(units, 3)
+    (tmp_path / "in.bin").write_bytes(data)
+    r = subprocess.run([MULTI, "--ranks", "1", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "4", "24", "32", "4", str(occupancy_rd)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "out.bin").read_bytes() == O.v3c_transcode(data, 24, 32, 4, occupancy_rd=occupancy_rd)
+    assert r.stdout.startswith("1 ranks, 5 GOFs:")
+
+
+def test_cpp_multi_gpu_host_fails_loudly_without_a_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    if not os.path.exists(MULTI):
+        pytest.skip("rbt_multi_gpu not built")
+    (tmp_path / "in.bin").write_bytes(bytes([0x40]))
+    r = subprocess.run([MULTI, "--ranks", "2", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no usable HIP device" in r.stderr and not (tmp_path / "out.bin").exists()
