@@ -608,7 +608,7 @@ static int hm_decide_tu_split(enc* e, int x0, int y0, int log2) {
   int part = nxn ? ((y0 - e->cu_y) >= half_cu ? 2 : 0) + ((x0 - e->cu_x) >= half_cu ? 1 : 0) : 0;
   recon_tb(e, 0, x0, y0, log2, e->intra_luma[part], &ts);
   c_whole = e->last_ssd * 256 + lam * e->last_bits;
-  if (!e->hm && e->last_ssd * 256 < (lam >> 2) * N * N) {   /* RBT-E1: a block that one transform codes to within lambda^2 / 4 per sample is not tried as four */
+  if (!e->hm && !e->p.lossless && e->last_ssd * 256 < (lam >> 2) * N * N) {   /* RBT-E1: a block that one transform codes to within lambda^2 / 4 per sample is not tried as four */
     for (int y = 0; y < N; y++) { memcpy(f->p[0] + (size_t)(y0 + y) * f->w + x0, save + y * N, (size_t)N * 2); memcpy(lv0 + y * 64, lsave + y * N, (size_t)N * 2); }
     e->in_trial = 0; return 0;
   }
@@ -1499,7 +1499,8 @@ static void setup_stream(enc* e) {
   if (!e->stress && !e->hm && !q->lossless && e1_sao_on()) s->sao_enabled = 1;
   e->tu_rd = e->hm;
   if (!e->stress && !e->hm) { e->e1_satd = e1_satd_on(); e->e1_refine = e1_refine_on(); e->e1_rq = !q->lossless && e1_rq_on(); }
-  if (!e->stress && !e->hm && !q->lossless) { s->max_th_depth_intra = 1; e->tu_rd = 1; p->transform_skip_enabled = e1_ts_on(); }   /* RBT-E1: an intra CU is one transform unit or four, whichever codes its luma cheaper */
+  if (!e->stress && !e->hm && !q->lossless) { s->max_th_depth_intra = 1; e->tu_rd = 1; p->transform_skip_enabled = e1_ts_on(); }
+  if (!e->stress && !e->hm && q->lossless) { s->max_th_depth_intra = 1; e->tu_rd = 1; }   /* lossless (occupancy) too: four blocks predict from closer neighbours - 9 % fewer bytes on the benchmark's occupancy maps; distortion is 0 either way, the level bits decide */   /* RBT-E1: an intra CU is one transform unit or four, whichever codes its luma cheaper */
   if (!e->stress && !e->hm && q->ctb_rows_per_slice < 0) { p->entropy_coding_sync = 1; p->dependent_slice_segments_enabled = q->ctb_rows_per_slice == -1; }   /* wavefront rows, one dependent slice segment each */
   if (e->hm) {   /* cfg/hm/ctc-hm-geometry-ai.cfg:10-16,47,68,69 + HM defaults (SignHideFlag, TMVPMode, MaxNumMergeCand) */
     s->log2_ctb = q->log2_ctb ? q->log2_ctb : 6; s->log2_diff_max_min_cb = s->log2_ctb - 3;

@@ -624,7 +624,7 @@ template <int TL2> RBT_DEV int en_intra_cu_luma(const RbtStreamCfg* g, RbtFrame*
   int ssd0 = 0;
   const int cbf0 = en_tile_intra_tb(g, f, L, 0, x0, y0, gx, gy, lg, mode, qp, t->sb, -1, 0, 0, t->lv0, &c_whole, lam2, &ssd0);
   *split = 0; *ts_bits = 0;
-  if ((long long)ssd0 * 256 < (long long)(lam2 >> 2) * N * N) {     // coded to within lambda^2 / 4 per sample by one transform: not tried as four
+  if (!f->lossless && (long long)ssd0 * 256 < (long long)(lam2 >> 2) * N * N) {     // coded to within lambda^2 / 4 per sample by one transform: not tried as four (lossless: the bits alone decide)
     RBT_PAR_FOR(i, 1 << (2 * (lg - 2))) t->uav[((y0 >> 2) + (i >> (lg - 2)) + 1) * RC_US + (x0 >> 2) + (i & ((1 << (lg - 2)) - 1)) + 1] = 1;
     RBT_SYNC_LDS();
     return cbf0;
@@ -766,7 +766,7 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
   const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
   const int qp_y = sl->qp, bd = g->bit_depth;
   const int qp_l = qp_y + 6 * (bd - 8), qp_cb = en_chroma_qp(f, sl, 1, qp_y), qp_cr = en_chroma_qp(f, sl, 2, qp_y);
-  const int tu_rd = !f->lossless && g->th_depth_intra > 0, lam16 = k_lambda16[rbt_clip3(0, 75, qp_l)], lam2 = lam16 * lam16;
+  const int tu_rd = g->th_depth_intra > 0, lam16 = k_lambda16[rbt_clip3(0, 75, qp_l)], lam2 = lam16 * lam16;
   // ---- borders, unit availability, analysis results ----
   for (int c = 0; c < 3; c++) {
     const int sh = c ? 1 : 0, nn = ctb >> sh, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, ox = cx >> sh, oy = cy >> sh, S = c ? RbtEncTileT<TL2>::TS_C : RbtEncTileT<TL2>::TS_Y;

@@ -58,7 +58,7 @@ static void make_param_sets(const EncStreamDesc& d, Sps& s, Pps& p) {
   s.valid = true; s.width = cw; s.height = ch; s.conf_win[1] = (cw - d.w) / 2; s.conf_win[3] = (ch - d.h) / 2; s.bit_depth = d.bd; s.log2_max_poc_lsb = 8; s.max_dec_pic_buffering = 3;
   s.log2_ctb = d.log2_ctb ? d.log2_ctb : 5; s.log2_min_cb = 3; s.log2_diff_max_min_cb = s.log2_ctb - 3;
   s.log2_min_tb = 2; s.log2_max_tb = std::min(5, s.log2_ctb); s.log2_diff_max_min_tb = s.log2_max_tb - 2;
-  s.num_st_rps = 1; s.sao = d.sao; s.max_th_depth_intra = d.lossless ? 0 : 1;   // an intra CU is one transform unit or four (oracle/hevc_enc.c setup_stream)
+  s.num_st_rps = 1; s.sao = d.sao; s.max_th_depth_intra = 1;   // an intra CU is one transform unit or four (oracle/hevc_enc.c setup_stream)
   s.w_ctb = (cw + (1 << s.log2_ctb) - 1) >> s.log2_ctb; s.h_ctb = (ch + (1 << s.log2_ctb) - 1) >> s.log2_ctb;
   p.valid = true; p.num_ref_idx_default = 1; p.init_qp = std::min(51, std::max(0, d.qp)); p.loop_filter_across_slices = 1;
   p.transform_skip = !d.lossless && e1_ts_on();   // the 4x4 luma blocks are coded with or without the transform, whichever is cheaper (oracle/hevc_enc.c hm_tb_finish)
