@@ -245,7 +245,8 @@ def main():
     # runs of this same command: profiles/r02_pmc_traffic.json, tools/refresh_profiles.py); counters cannot be read live from inside the benchmark
     traffic = None
     try:
-        pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")     # HM-like input; the round-1 file belongs to the RBT-E1-coded input
+        pmc_file = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")     # HM-like input, this round's code; else the round-2 file (the round-1 file belongs to the RBT-E1-coded input)
+        if not os.path.exists(pmc_file): pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if not fixture or not os.path.exists(pmc_file): pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         pmc = json.load(open(pmc_file))["kernels"]
         kmap = {"cabac_parse": ["k_parse"], "intra_analysis": ["k_enc_analyse"], "cabac_encode": ["k_entropy"]}

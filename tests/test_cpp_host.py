@@ -112,7 +112,7 @@ def test_cpp_multi_gpu_host_one_rank_equals_oracle(tmp_path, occupancy_rd):
     r = subprocess.run([MULTI, "--ranks", "1", str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "4", "24", "32", "4", str(occupancy_rd)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "out.bin").read_bytes() == O.v3c_transcode(data, 24, 32, 4, occupancy_rd=occupancy_rd)
-    assert r.stdout.startswith("1 ranks, 5 GOFs:")
+    assert "1 ranks, 5 GOFs:" in r.stdout          # (RCCL prints its version banner first)
 
 
 def test_cpp_multi_gpu_host_fails_loudly_without_a_gpu(tmp_path):
