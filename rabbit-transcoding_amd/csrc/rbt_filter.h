@@ -30,16 +30,15 @@ RBT_DEV int fl_bs(const RbtFrame* f, const RbtSlice* slices, int x, int y, int d
   return 0;
 }
 
-RBT_DEV void fl_luma_segment(RbtFrame* f, const RbtSlice* slices, int x, int y, int dir, int bs) {
+// one 4-sample luma edge segment: q = the first q0 sample, sa = step across the edge, sl = step along it (a plane in HBM or a tile in LDS)
+template <class PTR> RBT_DEV void fl_luma_core(const RbtFrame* f, const RbtSlice* slices, int x, int y, int dir, int bs, PTR q, int sa, int sl) {
   const RbtStreamCfg* g = &f->cfg;
-  int bd = g->bit_depth, maxv = (1 << bd) - 1, st = g->w;
-  int sa = dir == 0 ? 1 : st, sl = dir == 0 ? st : 1;
+  int bd = g->bit_depth, maxv = (1 << bd) - 1;
   int iq = (y >> 2) * g->w4 + (x >> 2), ip = dir == 0 ? iq - 1 : iq - g->w4;
   const RbtSlice* s = &slices[fl_slice_at(f, x, y)];
   int qpl = (f->qp[iq] + f->qp[ip] + 1) >> 1;
   int beta = k_beta_table[rbt_clip3(0, 51, qpl + (s->beta_offset_div2 << 1))] * (1 << (bd - 8));
   int tc = k_tc_table[rbt_clip3(0, 53, qpl + 2 * (bs - 1) + (s->tc_offset_div2 << 1))] * (1 << (bd - 8));
-  uint16_t* q = f->pix[0] + (size_t)y * st + x;
 #define FP(i, k) ((int)q[-((i) + 1) * sa + (k) * sl])
 #define FQ(i, k) ((int)q[(i) * sa + (k) * sl])
   int dp0 = rbt_abs(FP(2, 0) - 2 * FP(1, 0) + FP(0, 0)), dp3 = rbt_abs(FP(2, 3) - 2 * FP(1, 3) + FP(0, 3));
@@ -53,7 +52,7 @@ RBT_DEV void fl_luma_segment(RbtFrame* f, const RbtSlice* slices, int x, int y, 
   int no_p = f->pm[ip] & RBT_PM_TQ_BYPASS, no_q = f->pm[iq] & RBT_PM_TQ_BYPASS;
   for (int k = 0; k < 4; k++) {
     int p0 = FP(0, k), p1 = FP(1, k), p2 = FP(2, k), p3 = FP(3, k), q0 = FQ(0, k), q1 = FQ(1, k), q2 = FQ(2, k), q3 = FQ(3, k);
-    uint16_t* c = q + k * sl;
+    PTR c = q + k * sl;
     if (strong) {
       if (!no_p) {
         c[-1 * sa] = (uint16_t)rbt_clip3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
@@ -83,24 +82,31 @@ RBT_DEV void fl_luma_segment(RbtFrame* f, const RbtSlice* slices, int x, int y, 
 #undef FP
 #undef FQ
 }
-RBT_DEV void fl_chroma_segment(RbtFrame* f, const RbtSlice* slices, int c_idx, int xl, int yl, int dir) {
+RBT_DEV void fl_luma_segment(RbtFrame* f, const RbtSlice* slices, int x, int y, int dir, int bs) {
+  const int st = f->cfg.w;
+  fl_luma_core(f, slices, x, y, dir, bs, f->pix[0] + (size_t)y * st + x, dir == 0 ? 1 : st, dir == 0 ? st : 1);
+}
+// one chroma edge segment (two samples along the edge) of plane c_idx at luma position (xl,yl): q = the first q0 sample
+template <class PTR> RBT_DEV void fl_chroma_core(const RbtFrame* f, const RbtSlice* slices, int c_idx, int xl, int yl, int dir, PTR q, int sa, int sl) {
   const RbtStreamCfg* g = &f->cfg;
-  int bd = g->bit_depth, maxv = (1 << bd) - 1, st = g->cw;
-  int sa = dir == 0 ? 1 : st, sl = dir == 0 ? st : 1;
+  int bd = g->bit_depth, maxv = (1 << bd) - 1;
   int iq = (yl >> 2) * g->w4 + (xl >> 2), ip = dir == 0 ? iq - 1 : iq - g->w4;
   const RbtSlice* s = &slices[fl_slice_at(f, xl, yl)];
   int off = c_idx == 1 ? g->cb_qp_offset : g->cr_qp_offset;
   int qpc = rbt_chroma_qp(((f->qp[iq] + f->qp[ip] + 1) >> 1) + off);
   int tc = k_tc_table[rbt_clip3(0, 53, qpc + 2 + (s->tc_offset_div2 << 1))] * (1 << (bd - 8));
-  uint16_t* q = f->pix[c_idx] + (size_t)(yl >> 1) * st + (xl >> 1);
   int no_p = f->pm[ip] & RBT_PM_TQ_BYPASS, no_q = f->pm[iq] & RBT_PM_TQ_BYPASS;
   for (int k = 0; k < 2; k++) {
-    uint16_t* c = q + k * sl;
+    PTR c = q + k * sl;
     int p0 = c[-sa], p1 = c[-2 * sa], q0 = c[0], q1 = c[sa];
     int delta = rbt_clip3(-tc, tc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
     if (!no_p) c[-sa] = (uint16_t)rbt_clip3(0, maxv, p0 + delta);
     if (!no_q) c[0] = (uint16_t)rbt_clip3(0, maxv, q0 - delta);
   }
+}
+RBT_DEV void fl_chroma_segment(RbtFrame* f, const RbtSlice* slices, int c_idx, int xl, int yl, int dir) {
+  const int st = f->cfg.cw;
+  fl_chroma_core(f, slices, c_idx, xl, yl, dir, f->pix[c_idx] + (size_t)(yl >> 1) * st + (xl >> 1), dir == 0 ? 1 : st, dir == 0 ? st : 1);
 }
 // one 4x4 unit of one picture for edge direction `dir`
 RBT_DEV void rbt_deblock_unit(RbtFrame* f, const RbtSlice* slices, int unit, int dir) {
@@ -115,14 +121,14 @@ RBT_DEV void rbt_deblock_unit(RbtFrame* f, const RbtSlice* slices, int unit, int
 
 // SAO of one sample of component c: reads f->pix (deblocked), writes f->out
 // SAO of one sample with the parameters *s of its CTB (the encoder applies them right after deciding them: en_sao_ctb)
-RBT_DEV void rbt_sao_sample_p(RbtFrame* f, const RbtSlice* slices, int c, int x, int y, const RbtSao* s) {
+// (FETCH: the deblocked sample of plane c at (x,y) - from the plane in HBM, or from a tile in LDS)
+template <class FETCH> RBT_DEV int rbt_sao_value(const RbtFrame* f, const RbtSlice* slices, int c, int x, int y, const RbtSao* s, FETCH fetch) {
   const RbtStreamCfg* g = &f->cfg;
   int sh = c ? 1 : 0, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, bd = g->bit_depth, maxv = (1 << bd) - 1;
   int xl = x << sh, yl = y << sh;
   int ctb = (yl >> g->log2_ctb) * g->w_ctb + (xl >> g->log2_ctb);
   const RbtSlice* sl = &slices[fl_slice_of_ctb(f, ctb)];
-  const uint16_t* sp = f->pix[c];
-  int v = sp[(size_t)y * pw + x], outv = v;
+  int v = fetch(x, y), outv = v;
   int type = s->type[c];
   if ((c ? sl->sao_chroma : sl->sao_luma) && type && !(f->pm[(yl >> 2) * g->w4 + (xl >> 2)] & RBT_PM_TQ_BYPASS)) {
     if (type == 1) {
@@ -136,7 +142,7 @@ RBT_DEV void rbt_sao_sample_p(RbtFrame* f, const RbtSlice* slices, int c, int x,
         int sa_ = fl_slice_at(f, xa << sh, ya << sh), sb_ = fl_slice_at(f, xb << sh, yb << sh), sc_ = fl_slice_of_ctb(f, ctb);
         int ok = !((sa_ != sc_ && !slices[sa_ > sc_ ? sa_ : sc_].lf_across) || (sb_ != sc_ && !slices[sb_ > sc_ ? sb_ : sc_].lf_across));
         if (ok) {
-          int va = sp[(size_t)ya * pw + xa], vb = sp[(size_t)yb * pw + xb];
+          int va = fetch(xa, ya), vb = fetch(xb, yb);
           int e = 2 + (v > va) - (v < va) + (v > vb) - (v < vb);
           if (e == 0 || e == 1 || e == 2) e = (e == 2) ? 0 : e + 1;
           if (e) outv = rbt_clip3(0, maxv, v + s->offset[c][e - 1]);
@@ -144,9 +150,63 @@ RBT_DEV void rbt_sao_sample_p(RbtFrame* f, const RbtSlice* slices, int c, int x,
       }
     }
   }
-  f->out[c][(size_t)y * pw + x] = (uint16_t)outv;
+  return outv;
+}
+RBT_DEV void rbt_sao_sample_p(RbtFrame* f, const RbtSlice* slices, int c, int x, int y, const RbtSao* s) {
+  const int pw = c ? f->cfg.cw : f->cfg.w; const uint16_t* sp = f->pix[c];
+  f->out[c][(size_t)y * pw + x] = (uint16_t)rbt_sao_value(f, slices, c, x, y, s, [&](int xx, int yy) { return (int)sp[(size_t)yy * pw + xx]; });
 }
 RBT_DEV void rbt_sao_sample(RbtFrame* f, const RbtSlice* slices, int c, int x, int y) {
   const RbtStreamCfg* g = &f->cfg; const int sh = c ? 1 : 0;
   rbt_sao_sample_p(f, slices, c, x, y, &f->sao[(((y << sh) >> g->log2_ctb)) * g->w_ctb + ((x << sh) >> g->log2_ctb)]);
+}
+
+// ---- deblocking + SAO of one 64x64 luma tile in LDS (round 3: one read of the reconstruction and one write of the output per sample instead of four full-picture passes) ----
+// The tile's outputs need the deblocked samples one sample beyond it (SAO's neighbours); a deblocked sample needs the horizontal-edge filter of its row group, which reads the
+// vertically-filtered samples up to 4 rows away; those need the reconstruction up to 4 columns away. So a workgroup loads the tile with a halo of 4 luma (2 chroma) samples,
+// filters every vertical edge x0 + 8k (k = 0..8) over the 72 rows, then every horizontal edge y0 + 8k over the 72 columns - each edge moves at most 3 samples either side and
+// reads 4, so edges 8 apart never touch each other's samples and everything the tile's outputs depend on is exact - applies SAO from LDS and writes ITS 64x64 samples of `out`.
+// The halo is computed again by the neighbouring tiles ((72 / 64)^2 = 1.27x the filter arithmetic) instead of waited for. Needs out != pix (pictures with SAO).
+#define RBT_LF_TILE 64
+#define RBT_LF_R (RBT_LF_TILE + 8)
+#define RBT_LF_RC (RBT_LF_TILE / 2 + 4)
+struct RbtLoopLds { uint16_t y[RBT_LF_R * RBT_LF_R]; uint16_t c[2][RBT_LF_RC * RBT_LF_RC]; };
+RBT_DEV void rbt_loopfilter_tile(RbtFrame* f, const RbtSlice* slices, int tile, RBT_LDS_AS RbtLoopLds* L) {
+  const RbtStreamCfg* g = &f->cfg;
+  const int tw = (g->w + RBT_LF_TILE - 1) / RBT_LF_TILE, x0 = (tile % tw) * RBT_LF_TILE, y0 = (tile / tw) * RBT_LF_TILE, ox = x0 - 4, oy = y0 - 4, cox = x0 / 2 - 2, coy = y0 / 2 - 2;
+  RBT_BLK_FOR(i, RBT_LF_R * RBT_LF_R) { const int x = ox + i % RBT_LF_R, y = oy + i / RBT_LF_R; L->y[i] = (x >= 0 && y >= 0 && x < g->w && y < g->h) ? f->pix[0][(size_t)y * g->w + x] : 0; }
+  RBT_BLK_FOR(i, 2 * RBT_LF_RC * RBT_LF_RC) {
+    const int c = i / (RBT_LF_RC * RBT_LF_RC), j = i % (RBT_LF_RC * RBT_LF_RC), x = cox + j % RBT_LF_RC, y = coy + j / RBT_LF_RC;
+    L->c[c][j] = (x >= 0 && y >= 0 && x < g->cw && y < g->ch) ? f->pix[1 + c][(size_t)y * g->cw + x] : 0;
+  }
+  RBT_SYNC();
+  for (int dir = 0; dir < 2; dir++) {
+    RBT_BLK_FOR(i, 9 * 18) {
+      const int e = i / 18, sg = i % 18;                                              // edge e of the tile, 4-sample segment sg along it
+      const int x = dir == 0 ? x0 + 8 * e : ox + 4 * sg, y = dir == 0 ? oy + 4 * sg : y0 + 8 * e;
+      if (x >= 0 && y >= 0 && x < g->w && y < g->h) {
+        const int bs = fl_bs(f, slices, x, y, dir);
+        if (bs) {
+          fl_luma_core(f, slices, x, y, dir, bs, &L->y[(y - oy) * RBT_LF_R + (x - ox)], dir == 0 ? 1 : RBT_LF_R, dir == 0 ? RBT_LF_R : 1);
+          if (bs == 2 && !(dir == 0 ? (x & 15) : (y & 15)))
+            for (int c = 0; c < 2; c++) fl_chroma_core(f, slices, 1 + c, x, y, dir, &L->c[c][((y >> 1) - coy) * RBT_LF_RC + ((x >> 1) - cox)], dir == 0 ? 1 : RBT_LF_RC, dir == 0 ? RBT_LF_RC : 1);
+        }
+      }
+    }
+    RBT_SYNC();
+  }
+  RBT_BLK_FOR(i, RBT_LF_TILE * RBT_LF_TILE) {
+    const int x = x0 + i % RBT_LF_TILE, y = y0 + i / RBT_LF_TILE;
+    if (x < g->w && y < g->h) {
+      const RbtSao* sp = &f->sao[(y >> g->log2_ctb) * g->w_ctb + (x >> g->log2_ctb)];
+      f->out[0][(size_t)y * g->w + x] = (uint16_t)rbt_sao_value(f, slices, 0, x, y, sp, [&](int xx, int yy) { return (int)L->y[(yy - oy) * RBT_LF_R + (xx - ox)]; });
+    }
+  }
+  RBT_BLK_FOR(i, 2 * (RBT_LF_TILE / 2) * (RBT_LF_TILE / 2)) {
+    const int c = i / ((RBT_LF_TILE / 2) * (RBT_LF_TILE / 2)), j = i % ((RBT_LF_TILE / 2) * (RBT_LF_TILE / 2)), x = x0 / 2 + j % (RBT_LF_TILE / 2), y = y0 / 2 + j / (RBT_LF_TILE / 2);
+    if (x < g->cw && y < g->ch) {
+      const RbtSao* sp = &f->sao[((y << 1) >> g->log2_ctb) * g->w_ctb + ((x << 1) >> g->log2_ctb)];
+      f->out[1 + c][(size_t)y * g->cw + x] = (uint16_t)rbt_sao_value(f, slices, 1 + c, x, y, sp, [&](int xx, int yy) { return (int)L->c[c][(yy - coy) * RBT_LF_RC + (xx - cox)]; });
+    }
+  }
 }

@@ -55,6 +55,8 @@ size_t parse_save_bytes();
 void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int y_begin = 0, int y_end = 1 << 30);
 void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_units);
 void launch_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_luma_samples);
+// deblocking + SAO in one launch through LDS tiles (pictures whose out planes are not their pix planes: those with SAO); max_w / max_h: the largest picture of the list
+void launch_loopfilter(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w, int max_h);
 
 // encode (RBT-E1)
 void launch_pool(const uint16_t* in, int stride, int w, int h, int factor, uint16_t* out, uint16_t* out_cb, uint16_t* out_cr, int chroma_value);   // w x h region of a plane with row stride `stride`

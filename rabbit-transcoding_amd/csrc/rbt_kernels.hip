@@ -204,6 +204,14 @@ __global__ void __launch_bounds__(256) k_deblock(RbtFrame* frames, const RbtSlic
   if (unit >= f->cfg.w4 * f->cfg.h4) return;
   rbt_deblock_unit(f, slices, unit, dir);
 }
+// deblocking (both edge directions) + SAO of one 64x64 tile through LDS (rbt_filter.h rbt_loopfilter_tile): pictures with SAO, whose output is a plane of its own
+__global__ void __launch_bounds__(256) k_loopfilter(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
+  __shared__ RbtLoopLds lds;
+  RbtFrame* f = &frames[frame_list[blockIdx.y]];
+  const int tw = (f->cfg.w + RBT_LF_TILE - 1) / RBT_LF_TILE, th = (f->cfg.h + RBT_LF_TILE - 1) / RBT_LF_TILE;
+  if ((int)blockIdx.x >= tw * th) return;
+  rbt_loopfilter_tile(f, slices, blockIdx.x, RBT_LDS_CAST(RbtLoopLds, &lds));
+}
 __global__ void __launch_bounds__(256) k_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   int c = blockIdx.z, pw = c ? f->cfg.cw : f->cfg.w, ph = c ? f->cfg.ch : f->cfg.h;
@@ -241,6 +249,10 @@ void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* fra
   if (n_frames <= 0) return;
   for (int dir = 0; dir < 2; dir++)
     hipLaunchKernelGGL(k_deblock, dim3((max_units + 255) / 256, n_frames), dim3(256), 0, g_stream, frames, slices, frame_list, dir);
+}
+void launch_loopfilter(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w, int max_h) {
+  if (n_frames <= 0) return;
+  hipLaunchKernelGGL(k_loopfilter, dim3(((max_w + RBT_LF_TILE - 1) / RBT_LF_TILE) * ((max_h + RBT_LF_TILE - 1) / RBT_LF_TILE), n_frames), dim3(256), 0, g_stream, frames, slices, frame_list);
 }
 void launch_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_luma_samples) {
   if (n_frames <= 0) return;

@@ -15,6 +15,7 @@
 #define RBT_DEV static inline
 #define RBT_CONST static const
 #define RBT_PAR_FOR(i, n) for (int i = 0; i < (int)(n); i++)
+#define RBT_BLK_FOR(i, n) for (int i = 0; i < (int)(n); i++)
 #define RBT_SYNC() do { } while (0)
 #define RBT_SYNC_LDS() do { } while (0)
 #define RBT_LANE0 1
@@ -46,6 +47,8 @@ static __device__ __forceinline__ int rbt_writelane(int old, int v, int lane) { 
 #define RBT_CONST static __device__ const
 // (wave-local: kernels that use it run single-wave workgroups, or one wave per role - k_recon_diag)
 #define RBT_PAR_FOR(i, n) for (int i = (int)threadIdx.x & 63; i < (int)(n); i += 64)
+// the same over all threads of a workgroup of any size (separated by RBT_SYNC())
+#define RBT_BLK_FOR(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += (int)blockDim.x)
 #define RBT_SYNC() __syncthreads()
 // single-wave workgroups only: orders LDS traffic between the lanes of the wave without waiting for outstanding global
 // stores (a __syncthreads() would wait for every store round trip to HBM)

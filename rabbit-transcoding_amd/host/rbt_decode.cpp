@@ -269,13 +269,20 @@ void decode_launch_filters(DecodeBatch& b, size_t l) {
   const std::vector<int>& lf = b.level_frames[l];
   int mu = 0, ml = 0;
   for (int fi : lf) { const RbtStreamCfg& c = b.frames[fi].cfg; mu = std::max(mu, c.w4 * c.h4); ml = std::max(ml, c.w * c.h); }
-  rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l], (int)lf.size(), mu);
-  // SAO frames of this level are a contiguous sub-list only if all (or none) use SAO; otherwise launch per frame run
+  // Pictures with SAO (their `out` planes are not their `pix` planes) take deblocking and SAO in ONE launch through LDS tiles (rbt_loopfilter_tile: one read of the
+  // reconstruction, one write of the output, instead of deblocking twice in place and a third pass for SAO); the others are deblocked in place, one launch per edge
+  // direction. Runs of either kind inside the level's list get their own launches.
+  static const int fused = [] { const char* e = getenv("RBT_FUSED_LF"); return !e || atoi(e) != 0; }();
   size_t k = 0;
   while (k < lf.size()) {
-    if (!b.info[lf[k]].sao) { k++; continue; }
-    size_t e = k; while (e < lf.size() && b.info[lf[e]].sao) e++;
-    rbtk::launch_sao(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l] + k, (int)(e - k), ml);
+    const bool sao = b.info[lf[k]].sao;
+    size_t e = k; while (e < lf.size() && b.info[lf[e]].sao == sao) e++;
+    int mw_ = 0, mh_ = 0; for (size_t q = k; q < e; q++) { mw_ = std::max(mw_, (int)b.frames[lf[q]].cfg.w); mh_ = std::max(mh_, (int)b.frames[lf[q]].cfg.h); }
+    if (sao && fused) rbtk::launch_loopfilter(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l] + k, (int)(e - k), mw_, mh_);
+    else {
+      rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l] + k, (int)(e - k), mu);
+      if (sao) rbtk::launch_sao(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l] + k, (int)(e - k), ml);
+    }
     k = e;
   }
 }

@@ -96,6 +96,11 @@ void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* fra
   for (int dir = 0; dir < 2; dir++)
     for (int k = 0; k < n_frames; k++) { RbtFrame* f = &frames[frame_list[k]]; for (int u = 0; u < f->cfg.w4 * f->cfg.h4; u++) rbt_deblock_unit(f, slices, u, dir); }
 }
+void launch_loopfilter(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int, int) {
+  static RbtLoopLds lds;
+  for (int k = 0; k < n_frames; k++) { RbtFrame* f = &frames[frame_list[k]]; const int nt = ((f->cfg.w + RBT_LF_TILE - 1) / RBT_LF_TILE) * ((f->cfg.h + RBT_LF_TILE - 1) / RBT_LF_TILE);
+    for (int t = 0; t < nt; t++) rbt_loopfilter_tile(f, slices, t, &lds); }
+}
 void launch_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int) {
   for (int k = 0; k < n_frames; k++) {
     RbtFrame* f = &frames[frame_list[k]];
