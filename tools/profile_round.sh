@@ -3,7 +3,7 @@
 # Counter passes are separate runs with --kernel-trace only (no other trace domain), the program itself after `--`.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O
-QUIET="--cpu-sample 0 --multi-gof 0 --quality 0 --sweep 0 --walk-frames 0 --fanout-gofs 0"
+QUIET="--cpu-sample 0 --multi-gof 0 --quality 0 --sweep 0 --walk-frames 0 --fanout-gofs 0 --steady-steps 0"
 timeout -k 10 900 python3 $R/bench.py > $O/bench_line.json 2> $O/bench_line.err || exit 1
 # the command the driver times at round end (a run that is all ramp-up and drain: DESIGN.md 5)
 timeout -k 10 900 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line_driver.json 2> $O/bench_line_driver.err || exit 1
