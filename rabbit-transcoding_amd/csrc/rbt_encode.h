@@ -1218,7 +1218,10 @@ RBT_DEV void en_write_quadtree(RbtEnt* s, int x0, int y0, int log2) {
 // band, a single table would serialise the adds of the whole wave), the offsets are computed with the lanes over the table entries (one division per lane).
 // Measured on MI355X, encoder stages per job with 16 GOFs in flight: no SAO 33 ms; one LDS table + decision on every lane 62 ms; this version 48 ms;
 // staging the CTB and its halo in LDS with packed 8 / 16-bit register statistics 57 ms (11 KB of LDS per wave cost more residency than the loads it saved).
-struct RbtSaoLds { int32_t bcnt[8][32], bsum[8][32]; int32_t ecnt[16], esum[16]; int32_t off[3][48], gain[48]; long long tgain[3][5]; int32_t bpos[3]; };   // candidates of all three components stay in LDS: private arrays indexed at run time would live in scratch memory
+struct RbtSaoLds { int32_t bcnt[8][32], bsum[8][32]; int32_t ecnt[16], esum[16]; int32_t off[3][48], gain[48]; long long tgain[3][5]; int32_t bpos[3];
+                   // round 3: the CTB and 4 luma (2 chroma) samples around it, deblocked HERE (rbt_filter.h: the scheme of rbt_loopfilter_tile with the CTB as the tile) - the
+                   // reconstruction is read once, the statistics, the decision and the offsets work on LDS, the output is written once; no deblocking pass over the picture
+                   uint16_t ry[RBT_LF_R * RBT_LF_R]; uint16_t rc[2][RBT_LF_RC * RBT_LF_RC]; };   // candidates of all three components stay in LDS: private arrays indexed at run time would live in scratch memory
 RBT_DEV int en_sao_round_div(int sum, int cnt) { return cnt ? (sum >= 0 ? sum + cnt / 2 : sum - cnt / 2) / cnt : 0; }
 RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtSaoLds* L) {
   const RbtStreamCfg gcopy = f->cfg; const RbtStreamCfg* g = &gcopy;
@@ -1233,10 +1236,36 @@ RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_L
     m1 = n8 * n8 >= 64 ? ~0ull : (1ull << (n8 * n8)) - 1;
     all_skip = m0 == m1;
   }
+  // ---- the CTB's reconstruction + halo into LDS, deblocked there: vertical edges, then horizontal ones (8.7.2; see rbt_loopfilter_tile for why a halo of 4 is exact)
+  const int lx0 = cxi * ctb, ly0 = cyi * ctb, ox = lx0 - 4, oy = ly0 - 4, cox = lx0 / 2 - 2, coy = ly0 / 2 - 2, RS = ctb + 8, RSC = ctb / 2 + 4;
+  RBT_PAR_FOR(i, RS * RS) { const int x = ox + i % RS, y = oy + i / RS; L->ry[(i / RS) * RBT_LF_R + i % RS] = (x >= 0 && y >= 0 && x < g->w && y < g->h) ? f->pix[0][(size_t)y * g->w + x] : 0; }
+  RBT_PAR_FOR(i, 2 * RSC * RSC) {
+    const int c = i / (RSC * RSC), j = i % (RSC * RSC), x = cox + j % RSC, y = coy + j / RSC;
+    L->rc[c][(j / RSC) * RBT_LF_RC + j % RSC] = (x >= 0 && y >= 0 && x < g->cw && y < g->ch) ? f->pix[1 + c][(size_t)y * g->cw + x] : 0;
+  }
+  RBT_SYNC_LDS();
+  for (int dir = 0; dir < 2; dir++) {
+    const int ne = ctb / 8 + 1, ns = RS / 4;
+    RBT_PAR_FOR(i, ne * ns) {
+      const int e = i / ns, sg = i % ns;
+      const int x = dir == 0 ? lx0 + 8 * e : ox + 4 * sg, y = dir == 0 ? oy + 4 * sg : ly0 + 8 * e;
+      if (x >= 0 && y >= 0 && x < g->w && y < g->h) {
+        const int bs = fl_bs(f, slices, x, y, dir);
+        if (bs) {
+          fl_luma_core(f, slices, x, y, dir, bs, &L->ry[(y - oy) * RBT_LF_R + (x - ox)], dir == 0 ? 1 : RBT_LF_R, dir == 0 ? RBT_LF_R : 1);
+          if (bs == 2 && !(dir == 0 ? (x & 15) : (y & 15)))
+            for (int c = 0; c < 2; c++) fl_chroma_core(f, slices, 1 + c, x, y, dir, &L->rc[c][((y >> 1) - coy) * RBT_LF_RC + ((x >> 1) - cox)], dir == 0 ? 1 : RBT_LF_RC, dir == 0 ? RBT_LF_RC : 1);
+        }
+      }
+    }
+    RBT_SYNC_LDS();
+  }
+  // deblocked sample of plane c at picture position (x,y) (inside the CTB or one sample around it)
+#define EN_SAO_RP(c, x, y) ((c) == 0 ? (int)L->ry[((y) - oy) * RBT_LF_R + ((x) - ox)] : (int)L->rc[(c) - 1][((y) - coy) * RBT_LF_RC + ((x) - cox)])
   for (int c = 0; c < 3 && !all_skip; c++) {
     const int sh = c ? 1 : 0, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, n = ctb >> sh, lgn = g->log2_ctb - sh;
     const int x0 = (cxi * ctb) >> sh, y0 = (cyi * ctb) >> sh;
-    const uint16_t* rp = f->pix[c]; const uint16_t* sp = f->src[c];
+    const uint16_t* sp = f->src[c];
     RBT_PAR_FOR(i, 8 * 32) { L->bcnt[i >> 5][i & 31] = 0; L->bsum[i >> 5][i & 31] = 0; }
     RBT_SYNC_LDS();
     int ecnt[16], esum[16];
@@ -1245,13 +1274,13 @@ RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_L
     RBT_PAR_FOR(i, n * n) {
       const int x = x0 + (i & (n - 1)), y = y0 + (i >> lgn);
       if (x < pw && y < ph && (f->occ4 == nullptr || en_occ_unit(f, (x << sh) >> 2, (y << sh) >> 2))) {      // occupancy-aware coding: samples no point is made of have no say in the offsets
-        const int v = rp[(size_t)y * pw + x], d = (int)sp[(size_t)y * pw + x] - v, b = rbt_min(31, v >> (bd - 5)), copy = i & 7;
+        const int v = EN_SAO_RP(c, x, y), d = (int)sp[(size_t)y * pw + x] - v, b = rbt_min(31, v >> (bd - 5)), copy = i & 7;
         RBT_LDS_ADD(&L->bcnt[copy][b], 1); RBT_LDS_ADD(&L->bsum[copy][b], d);
 #pragma unroll
         for (int cls = 0; cls < 4; cls++) {
           const int dxa = cls == 1 ? 0 : (cls == 3 ? 1 : -1), dya = cls == 0 ? 0 : -1, xa = x + dxa, ya = y + dya, xb = x - dxa, yb = y - dya;
           const int inside = !(xa < 0 || ya < 0 || xb < 0 || yb < 0 || xa >= pw || xb >= pw || ya >= ph || yb >= ph);
-          const int va = rp[(size_t)rbt_clip3(0, ph - 1, ya) * pw + rbt_clip3(0, pw - 1, xa)], vb = rp[(size_t)rbt_clip3(0, ph - 1, yb) * pw + rbt_clip3(0, pw - 1, xb)];
+          const int va = EN_SAO_RP(c, rbt_clip3(0, pw - 1, xa), rbt_clip3(0, ph - 1, ya)), vb = EN_SAO_RP(c, rbt_clip3(0, pw - 1, xb), rbt_clip3(0, ph - 1, yb));
           const int k = 2 + (v > va) - (v < va) + (v > vb) - (v < vb), cat = k < 2 ? k : k - 1;       // k == 2: no category
 #pragma unroll
           for (int q = 0; q < 4; q++) { const int hit = inside && k != 2 && cat == q; ecnt[cls * 4 + q] += hit; esum[cls * 4 + q] += hit ? d : 0; }
@@ -1299,8 +1328,12 @@ RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_L
   // ... and applied on the spot (8.7.3): the CTB's samples go from the deblocked picture to the output picture with the parameters still in registers
   for (int c = 0; c < 3; c++) {
     const int sh = c ? 1 : 0, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, n = ctb >> sh, lgn = g->log2_ctb - sh, x0 = (cxi * ctb) >> sh, y0 = (cyi * ctb) >> sh;
-    RBT_PAR_FOR(i, n * n) { const int x = x0 + (i & (n - 1)), y = y0 + (i >> lgn); if (x < pw && y < ph) rbt_sao_sample_p(f, slices, c, x, y, &out); }
+    RBT_PAR_FOR(i, n * n) {
+      const int x = x0 + (i & (n - 1)), y = y0 + (i >> lgn);
+      if (x < pw && y < ph) f->out[c][(size_t)y * pw + x] = (uint16_t)rbt_sao_value(f, slices, c, x, y, &out, [&](int xx, int yy) { return EN_SAO_RP(c, xx, yy); });
+    }
   }
+#undef EN_SAO_RP
   RBT_SYNC_LDS();
 }
 // sao() of one CTB (7.3.8.3) from the decided parameters: merged with the left / upper CTB of the same slice when they carry the same parameters

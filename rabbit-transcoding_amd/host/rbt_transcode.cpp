@@ -36,7 +36,7 @@ struct EncodeBatch {
   std::vector<std::vector<uint16_t>> cs_keep;   // host staging of the ctb->slice maps, alive until the copies have completed
   uint8_t* d_zero = nullptr; size_t zero_bytes = 0; bool wpp = false;   // launch tickets (3 words) + row progress of the wavefront mode
   int main_stream = 0, aux_stream = -1;          // aux_stream >= 0: the intra part was enqueued there (its timers live there)
-  std::vector<int32_t> lists_keep; size_t off_i = 0, off_ideb = 0, off_p = 0, off_sl = 0, off_sl_p = 0, off_isao = 0, off_psao = 0; int n_i = 0, n_ideb = 0, n_p = 0, n_sl_i = 0, n_sl_p = 0, n_isao = 0, n_psao = 0;   // index lists (encode_upload_lists)
+  std::vector<int32_t> lists_keep; size_t off_i = 0, off_ideb = 0, off_p = 0, off_sl = 0, off_sl_p = 0, off_isao = 0, off_psao = 0, off_pdeb = 0; int n_pdeb = 0, n_i = 0, n_ideb = 0, n_p = 0, n_sl_i = 0, n_sl_p = 0, n_isao = 0, n_psao = 0;   // index lists (encode_upload_lists)
   std::string err;
   ~EncodeBatch() { rbtk::dev_free(arena); }
 };
@@ -174,7 +174,9 @@ static int encode_upload_lists(EncodeBatch& b) {
   size_t nf = b.frames.size(), ns = b.slices.size();
   std::vector<int32_t>& lists = b.lists_keep; lists.clear(); b.n_i = b.n_ideb = b.n_p = 0;
   b.off_i = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i]) { lists.push_back((int)i); b.n_i++; }
-  b.off_ideb = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i] && !b.frames[i].lossless) { lists.push_back((int)i); b.n_ideb++; }
+  // pictures with SAO are deblocked inside the SAO kernel (en_sao_ctb: the CTB and a halo in LDS); only pictures without it (RBT_ENC_SAO=0) take the in-place deblocking launches
+  b.off_ideb = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i] && !b.frames[i].lossless && !b.desc[b.frame_stream[i]].sao) { lists.push_back((int)i); b.n_ideb++; }
+  b.n_pdeb = 0; b.off_pdeb = lists.size(); for (size_t i = 0; i < nf; i++) if (!b.frame_is_idr[i] && !b.frames[i].lossless && !b.desc[b.frame_stream[i]].sao) { lists.push_back((int)i); b.n_pdeb++; }
   b.off_p = lists.size(); for (size_t i = 0; i < nf; i++) if (!b.frame_is_idr[i]) { lists.push_back((int)i); b.n_p++; }
   b.n_isao = b.n_psao = 0;
   b.off_isao = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i] && b.desc[b.frame_stream[i]].sao) { lists.push_back((int)i); b.n_isao++; }
@@ -222,7 +224,7 @@ static void encode_launch_rest(EncodeBatch& b) {
   for (size_t i = 0; i < nf; i++) { const RbtStreamCfg& c = b.frames[i].cfg; mu = std::max(mu, c.w4 * c.h4); mc = std::max(mc, c.w_ctb * c.h_ctb); ml = std::max(ml, c.w * c.h); }
   rbtk::timer_begin(T_INTER);
   rbtk::launch_enc_inter(b.d_frames, b.d_slices, b.d_lists + b.off_p, b.n_p, mc);
-  rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_p, b.n_p, mu);
+  rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_pdeb, b.n_pdeb, mu);
   rbtk::launch_enc_sao(b.d_frames, b.d_slices, b.d_lists + b.off_psao, b.n_psao, mc);
   rbtk::timer_end(T_INTER);
   rbtk::timer_begin(T_ENTROPY);
