@@ -337,11 +337,13 @@ __global__ void __launch_bounds__(64) k_enc_inter(RbtFrame* frames, const RbtSli
   rc_stage_tables(&RBT_LDS_CAST(RbtEncLds, &lds)->rc);
   en_inter_ctb(frames, f, slices, blockIdx.x, RBT_LDS_CAST(RbtEncLds, &lds));
 }
+template <int TL2>
 __global__ void __launch_bounds__(64) k_enc_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
   __shared__ RbtSaoLds lds;
+  __shared__ RbtSaoRegionT<TL2> reg;
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   if ((int)blockIdx.x >= f->cfg.w_ctb * f->cfg.h_ctb) return;
-  en_sao_ctb(f, slices, blockIdx.x, RBT_LDS_CAST(RbtSaoLds, &lds));
+  en_sao_ctb(f, slices, blockIdx.x, RBT_LDS_CAST(RbtSaoLds, &lds), RBT_LDS_CAST(uint16_t, reg.ry), RBT_LDS_CAST(uint16_t, reg.rc[0]), RBT_LDS_CAST(uint16_t, reg.rc[1]));
 }
 template <int TL2>
 __global__ void __launch_bounds__(64) k_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list) {
@@ -436,9 +438,10 @@ void launch_enc_inter(RbtFrame* frames, const RbtSlice* slices, const int32_t* f
   if (n_frames <= 0) return;
   hipLaunchKernelGGL(k_enc_inter, dim3(max_ctbs, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
 }
-void launch_enc_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs) {
+void launch_enc_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs, int max_log2_ctb) {
   if (n_frames <= 0) return;
-  hipLaunchKernelGGL(k_enc_sao, dim3(max_ctbs, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
+  if (max_log2_ctb <= 5) hipLaunchKernelGGL(k_enc_sao<5>, dim3(max_ctbs, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
+  else hipLaunchKernelGGL(k_enc_sao<6>, dim3(max_ctbs, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
 }
 void launch_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list, int n_slices, int max_log2_ctb) {
   if (n_slices <= 0) return;

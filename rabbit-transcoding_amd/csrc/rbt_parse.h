@@ -69,12 +69,6 @@ struct RbtParse {
   // Units around the CTB: lane 0 above-left corner, lanes 1..17 the row above (16 units + the first above-right one),
   // lanes 32..47 the column to the left. Availability is folded in: an unavailable unit reads pm = RBT_MODE_NONE.
   RBT_VEC(uint32_t, n_pm); RBT_VEC(uint32_t, n_dm); RBT_VEC(uint32_t, n_ref); RBT_VEC(uint32_t, n_mv);
-  // Scan tables of residual_coding, one value per lane, built once per slice (pz_scan_tables): a transform block then needs no LDS read and no ballot to set up
-  // (round 3; the setup was 7.5 % of the largest slice's chain). t_sc: sub-block scan entry p (x | y << 4) of the 8x8 blocks in bytes 0..2 (scan 0, 1, 2) and of the
-  // 16x16 block in byte 3. t_sc5: entry p of the 32x32 block in byte 0; position (x | y << 2) of scan index p & 15 inside a sub-block in nibbles 2..4 (scan 0, 1, 2);
-  // lane q < 16: the scan index of position q inside a sub-block in nibbles 5..7. t_inv: the sub-block scan index of the sub-block at lane = xs | ys << 3 (32x32, byte 0),
-  // xs | ys << 2 (16x16, byte 1), xs | ys << 1 (8x8: two bits per scan from bit 16).
-  RBT_VEC(uint32_t, t_sc); RBT_VEC(uint32_t, t_sc5); RBT_VEC(uint32_t, t_inv);
 #ifdef RBT_PROFILE
   unsigned long long t_res, t_ctb, t_cu, t_a, t_b, t_c, t_d, t_tu, t_hdr, t_fill, t_mpm, t_last; uint32_t n_res, n_cu;
 #endif
@@ -438,22 +432,6 @@ RBT_DEV void pz_sao(RbtParse* s, int rx, int ry) {
 }
 
 // 4x4 scan positions packed 4 bits per entry (x | y << 2): diagonal, horizontal, vertical; and ctxIdxMap of 4x4 TBs
-RBT_DEV void pz_scan_tables(RbtParse* s) {
-  RBT_VFOR(p, 64) {
-    uint32_t a = 0, b = (uint32_t)k_scan[0][3][p], c = 0;
-    for (int sc = 0; sc < 3; sc++) {
-      a |= (uint32_t)(p < 4 ? k_scan[sc][1][p] : 0xFF) << (8 * sc);
-      const int e = k_scan[sc][2][p & 15];
-      b |= (uint32_t)((e & 3) | ((e >> 4) << 2)) << (8 + 4 * sc);
-      if (p < 16) for (int n = 0; n < 16; n++) { const int en = k_scan[sc][2][n]; if (((en & 3) | ((en >> 4) << 2)) == p) b |= (uint32_t)n << (20 + 4 * sc); }
-      if (p < 4) for (int i = 0; i < 4; i++) if (k_scan[sc][1][i] == ((p & 1) | ((p >> 1) << 4))) c |= (uint32_t)i << (16 + 2 * sc);
-    }
-    a |= (uint32_t)(p < 16 ? k_scan[0][2][p] : 0xFF) << 24;
-    for (int i = 0; i < 64; i++) if (k_scan[0][3][i] == ((p & 7) | ((p >> 3) << 4))) c |= (uint32_t)i;
-    if (p < 16) for (int i = 0; i < 16; i++) if (k_scan[0][2][i] == ((p & 3) | ((p >> 2) << 4))) c |= (uint32_t)i << 8;
-    RBT_V(s->t_sc, p) = a; RBT_V(s->t_sc5, p) = b; RBT_V(s->t_inv, p) = c;
-  }
-}
 RBT_DEV uint64_t pz_scan4_const(int scan_idx) { return scan_idx == 0 ? 0xFBE7AD369C258140ull : (scan_idx == 1 ? 0xFEDCBA9876543210ull : 0xFB73EA62D951C840ull); }
 #define PZ_SIGCTX4 0x8877886654325410ull
 // ------------------------------------------------------------------------------------------------ residual_coding (7.3.8.11)
@@ -490,17 +468,15 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
   // (p < 16) the position of scan index p inside a 4x4 sub-block, its sig_coeff_flag context and, after the bins of a
   // sub-block are known, the level / sign / address of the coefficient at that scan index.
   PZ_STAMP(s, 2);
-  // sub-block scan, positions inside a sub-block and the scan indices of the last significant coefficient from the per-slice lane tables (pz_scan_tables)
-  RBT_VEC(int, v_sbscan); RBT_VEC(int, v_pos); RBT_VEC(int, v_inv);
-  const int sb_sh = log2 == 3 ? 8 * scan_idx : 24, inv_sh = log2 == 5 ? 0 : (log2 == 4 ? 8 : 16 + 2 * scan_idx), inv_mask = log2 == 5 ? 63 : (log2 == 4 ? 15 : 3);
-  RBT_VFOR(p, 64) {
-    const uint32_t t5 = RBT_V(s->t_sc5, p);
-    RBT_V(v_sbscan, p) = log2 == 2 ? 0 : (log2 == 5 ? (int)(t5 & 255u) : (int)((RBT_V(s->t_sc, p) >> sb_sh) & 255u));
-    RBT_V(v_pos, p) = (int)((t5 >> (8 + 4 * scan_idx)) & 15u);
-    RBT_V(v_inv, p) = p < 16 ? (int)((t5 >> (20 + 4 * scan_idx)) & 15u) | ((int)((RBT_V(s->t_inv, p) >> inv_sh) & (uint32_t)inv_mask) << 8) : (int)((RBT_V(s->t_inv, p) >> inv_sh) & (uint32_t)inv_mask) << 8;
-  }
-  const int last_pos = RBT_VGET(v_inv, (lx & 3) | ((ly & 3) << 2)) & 15;
-  const int last_sb = log2 == 2 ? 0 : RBT_VGET(v_inv, (lx >> 2) | ((ly >> 2) << (log2 - 2))) >> 8;
+  // (round 3: per-slice lane tables with shifts and lane reads instead of this LDS read and the two ballots were measured SLOWER - 321 against 188 cycles per block)
+  const RBT_LDS_AS uint8_t* sb_scan = s->L->scan[scan_idx][log2 - 2];
+  const int n_sb = 1 << (2 * (log2 - 2));
+  RBT_VEC(int, v_sbscan); RBT_VEC(int, v_pos);
+  RBT_VFOR(p, 64) { RBT_V(v_sbscan, p) = p < n_sb ? (int)sb_scan[p] : 0xFFFF; RBT_V(v_pos, p) = PZ_POS(p & 15); }
+  int last_sb, last_pos;
+  { uint64_t mb; const int key = (lx >> 2) | ((ly >> 2) << 4), ikey = (lx & 3) | ((ly & 3) << 2);
+    RBT_VBALLOT(mb, p, 64, RBT_V(v_sbscan, p) == key); last_sb = mb ? __builtin_ctzll(mb) : 0;
+    RBT_VBALLOT(mb, p, 16, RBT_V(v_pos, p) == ikey); last_pos = mb ? __builtin_ctzll(mb) : 0; }
   PZ_STAMP(s, 3);
   uint64_t csbf = 0;   // bit (ys*8+xs)
   const int sbw = 1 << (log2 - 2);
@@ -860,11 +836,14 @@ RBT_DEV void pz_prediction_unit(RbtParse* s, int x0, int y0, int w, int h, int p
 }
 
 // ------------------------------------------------------------------------------------------------ coding unit (7.3.8.5)
-RBT_DEV void pz_intra_mpm(const RbtParse* s, int xp, int yp, int cand[3]) {
+// known_left / known_above >= 0: the neighbour is a prediction unit of the SAME coding unit (NxN: units 1 and 3 have unit 0 / 2 to their left, units 2 and 3 have
+// unit 0 / 1 above) whose mode was derived a moment ago - no neighbour lookup (two lane reads and their VALU -> SALU hand-over each)
+RBT_DEV void pz_intra_mpm(const RbtParse* s, int xp, int yp, int cand[3], int known_left = -1, int known_above = -1) {
   int ca = 1, cb = 1;
-  int nl = pz_nb(s, xp - 1, yp);
-  if (nl >= 0 && (nl & RBT_PM_MODE_MASK) == RBT_MODE_INTRA) ca = (nl >> 8) & 63;
-  if (((yp - 1) >> pzc_log2_ctb(s)) == (yp >> pzc_log2_ctb(s))) { int na = pz_nb(s, xp, yp - 1); if (na >= 0 && (na & RBT_PM_MODE_MASK) == RBT_MODE_INTRA) cb = (na >> 8) & 63; }
+  if (known_left >= 0) ca = known_left;
+  else { int nl = pz_nb(s, xp - 1, yp); if (nl >= 0 && (nl & RBT_PM_MODE_MASK) == RBT_MODE_INTRA) ca = (nl >> 8) & 63; }
+  if (known_above >= 0) cb = known_above;
+  else if (((yp - 1) >> pzc_log2_ctb(s)) == (yp >> pzc_log2_ctb(s))) { int na = pz_nb(s, xp, yp - 1); if (na >= 0 && (na & RBT_PM_MODE_MASK) == RBT_MODE_INTRA) cb = (na >> 8) & 63; }
   if (ca == cb) {
     if (ca < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
     else { cand[0] = ca; cand[1] = 2 + ((ca + 29) % 32); cand[2] = 2 + ((ca - 2 + 1) % 32); }
@@ -937,7 +916,7 @@ RBT_DEV void pz_coding_unit(RbtParse* s, int x0, int y0, int log2, int depth) {
 #ifdef RBT_PROFILE
       unsigned long long tm_ = __builtin_readcyclecounter();
 #endif
-      int cand[3]; pz_intra_mpm(s, xp, yp, cand);
+      int cand[3]; pz_intra_mpm(s, xp, yp, cand, (np == 4 && (i & 1)) ? pz_il(s, i - 1) : -1, (np == 4 && (i & 2)) ? pz_il(s, i - 2) : -1);
 #ifdef RBT_PROFILE
       s->t_mpm += __builtin_readcyclecounter() - tm_;
 #endif
@@ -1085,7 +1064,6 @@ RBT_DEV void rbt_parse_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, 
   s.s_poc = RBT_UNI(gs->poc);
   RBT_PAR_FOR(i, RBT_MAX_REFS) { lds->ref_poc[i] = gs->ref_poc[i]; lds->ref_frame[i] = gs->ref_frame[i]; }
   RBT_PAR_FOR(i, 3 * 4 * 64) lds->scan[i / 256][(i / 64) & 3][i & 63] = k_scan[i / 256][(i / 64) & 3][i & 63];
-  pz_scan_tables(&s);
   { const RbtFrame* f = s.f; const RbtStreamCfg* g = &f->cfg;
     s.m_cmds = rbt_uni_ptr(f->cmds); s.m_coef0 = rbt_uni_ptr(f->coef[0]); s.m_coef1 = rbt_uni_ptr(f->coef[1]); s.m_coef2 = rbt_uni_ptr(f->coef[2]); s.m_cap = RBT_UNI(f->cmd_cap);
     s.c_dim = (uint32_t)RBT_UNI((uint32_t)g->w | ((uint32_t)g->h << 16));

@@ -204,7 +204,7 @@ static void encode_launch_intra(EncodeBatch& b) {
   rbtk::timer_begin(T_ENCODE);
   rbtk::launch_enc_intra(b.d_frames, b.d_slices, b.d_lists + b.off_i, b.n_i, mw, mh, row_mode, ml2, (uint32_t*)b.d_zero);
   rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_ideb, b.n_ideb, mu);
-  rbtk::launch_enc_sao(b.d_frames, b.d_slices, b.d_lists + b.off_isao, b.n_isao, mc);   // decides and applies
+  rbtk::launch_enc_sao(b.d_frames, b.d_slices, b.d_lists + b.off_isao, b.n_isao, mc, ml2);   // decides and applies
   rbtk::timer_end(T_ENCODE);
 }
 // entropy coding of the intra pictures' slices: needs nothing but their levels and CU data
@@ -225,7 +225,7 @@ static void encode_launch_rest(EncodeBatch& b) {
   rbtk::timer_begin(T_INTER);
   rbtk::launch_enc_inter(b.d_frames, b.d_slices, b.d_lists + b.off_p, b.n_p, mc);
   rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_pdeb, b.n_pdeb, mu);
-  rbtk::launch_enc_sao(b.d_frames, b.d_slices, b.d_lists + b.off_psao, b.n_psao, mc);
+  rbtk::launch_enc_sao(b.d_frames, b.d_slices, b.d_lists + b.off_psao, b.n_psao, mc, max_log2_ctb(b));
   rbtk::timer_end(T_INTER);
   rbtk::timer_begin(T_ENTROPY);
   if (b.wpp) rbtk::launch_entropy_wave(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_p, b.n_p, max_w_ctb(b), max_h_ctb(b), max_log2_ctb(b), (uint32_t*)b.d_zero + 2);
