@@ -1246,7 +1246,7 @@ RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_L
     (c ? rc1 : rc0)[j] = (x >= 0 && y >= 0 && x < g->cw && y < g->ch) ? f->pix[1 + c][(size_t)y * g->cw + x] : 0;
   }
   RBT_SYNC_LDS();
-  for (int dir = 0; dir < 2; dir++) {
+  for (int dir = 0; dir < 2 && !(f->enc_tools & RBT_ET_LF_OUTSIDE); dir++) {
     const int ne = ctb / 8 + 1, ns = RS / 4;
     RBT_PAR_FOR(i, ne * ns) {
       const int e = i / ns, sg = i % ns;

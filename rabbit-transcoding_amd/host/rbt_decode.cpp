@@ -269,10 +269,11 @@ void decode_launch_filters(DecodeBatch& b, size_t l) {
   const std::vector<int>& lf = b.level_frames[l];
   int mu = 0, ml = 0;
   for (int fi : lf) { const RbtStreamCfg& c = b.frames[fi].cfg; mu = std::max(mu, c.w4 * c.h4); ml = std::max(ml, c.w * c.h); }
-  // Pictures with SAO (their `out` planes are not their `pix` planes) take deblocking and SAO in ONE launch through LDS tiles (rbt_loopfilter_tile: one read of the
-  // reconstruction, one write of the output, instead of deblocking twice in place and a third pass for SAO); the others are deblocked in place, one launch per edge
-  // direction. Runs of either kind inside the level's list get their own launches.
-  static const int fused = [] { const char* e = getenv("RBT_FUSED_LF"); return !e || atoi(e) != 0; }();
+  // Deblocking in place, one launch per edge direction, then SAO from `pix` to `out`. RBT_FUSED_LF=1 (round 3) gives pictures with SAO ONE launch through LDS tiles instead
+  // (rbt_loopfilter_tile: one read of the reconstruction, one write of the output; same samples): 1-2 % faster for a lone GOF, 3-6 % slower with 16+ GOFs in flight, where the
+  // kernels queue for LDS (the reconstruction holds a CTB there) and the LDS-free filter launches fill the gaps - measured in tools/lf_probe.sh, so it is off by default.
+  // Runs of pictures with / without SAO inside the level's list get their own launches.
+  static const int fused = [] { const char* e = getenv("RBT_FUSED_LF"); return e && atoi(e) != 0; }();
   size_t k = 0;
   while (k < lf.size()) {
     const bool sao = b.info[lf[k]].sao;

@@ -51,6 +51,10 @@ static int e1_tools(int lossless) {
   if (v < 0) { auto on = [](const char* n) { const char* e = getenv(n); return !e || atoi(e) != 0; }; v = (on("RBT_ENC_SATD") ? RBT_ET_SATD : 0) | (on("RBT_ENC_REFINE") ? RBT_ET_REFINE : 0) | (on("RBT_ENC_RQ") ? RBT_ET_RQ : 0); }
   return lossless ? v & ~RBT_ET_RQ : v;
 }
+// Every picture takes the in-place deblocking launches before the SAO kernel; RBT_FUSED_ENC_LF=1 deblocks inside the SAO kernel instead (en_sao_ctb: the CTB and its halo
+// in LDS; same samples, ~2 GB less HBM traffic per GOF). Off by default: the driver's 20-GOF run is 3 % slower with it, 5 % with the decoder's fused form as well
+// (tools/lf_probe.sh: 763 / 741 / 725 point-cloud frames/s) - the path is not HBM-bound, and the LDS-free filter launches fill gaps the LDS-holding kernels leave.
+static int e1_fused_lf() { static int v = -1; if (v < 0) { const char* e = getenv("RBT_FUSED_ENC_LF"); v = e && atoi(e) != 0; } return v; }
 static int coded_size(int v, int gop) { int al = gop > 1 ? 16 : 8; return (v + al - 1) / al * al; }
 static void make_param_sets(const EncStreamDesc& d, Sps& s, Pps& p) {
   s = Sps(); p = Pps();
@@ -83,7 +87,7 @@ static int encode_build(EncodeBatch& b) {
       RbtFrame f; memset(&f, 0, sizeof(f));
       fill_stream_cfg(s, p, f.cfg);
       f.poc = is_i ? 0 : (i % d.gop); f.level = is_i ? 0 : 1; f.first_slice = (int)b.slices.size();
-      f.w8 = s.width / 8; f.h8 = s.height / 8; f.lossless = d.lossless; f.enc_tools = e1_tools(d.lossless); f.ref_frame = is_i ? -1 : (int)b.frames.size() - 1; f.ref_poc = is_i ? 0 : f.poc - 1;
+      f.w8 = s.width / 8; f.h8 = s.height / 8; f.lossless = d.lossless; f.enc_tools = e1_tools(d.lossless) | (e1_fused_lf() ? 0 : RBT_ET_LF_OUTSIDE); f.ref_frame = is_i ? -1 : (int)b.frames.size() - 1; f.ref_poc = is_i ? 0 : f.poc - 1;
       for (int c = 0; c < 3; c++) f.src[c] = d.src[c][i];
       if (!d.hint_dm.empty()) { f.hint_pm = d.hint_pm[i]; f.hint_dm = d.hint_dm[i]; f.hint_w4 = d.hint_w4; f.hint_h4 = d.hint_h4; }
       if (!d.occ4.empty() && !d.lossless) { f.occ4 = d.occ4[i]; f.occ4_w = d.occ4_w; f.occ4_h = d.occ4_h; }
@@ -174,9 +178,9 @@ static int encode_upload_lists(EncodeBatch& b) {
   size_t nf = b.frames.size(), ns = b.slices.size();
   std::vector<int32_t>& lists = b.lists_keep; lists.clear(); b.n_i = b.n_ideb = b.n_p = 0;
   b.off_i = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i]) { lists.push_back((int)i); b.n_i++; }
-  // pictures with SAO are deblocked inside the SAO kernel (en_sao_ctb: the CTB and a halo in LDS); only pictures without it (RBT_ENC_SAO=0) take the in-place deblocking launches
-  b.off_ideb = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i] && !b.frames[i].lossless && !b.desc[b.frame_stream[i]].sao) { lists.push_back((int)i); b.n_ideb++; }
-  b.n_pdeb = 0; b.off_pdeb = lists.size(); for (size_t i = 0; i < nf; i++) if (!b.frame_is_idr[i] && !b.frames[i].lossless && !b.desc[b.frame_stream[i]].sao) { lists.push_back((int)i); b.n_pdeb++; }
+  // with RBT_FUSED_ENC_LF=1 pictures with SAO are deblocked inside the SAO kernel (en_sao_ctb: the CTB and a halo in LDS) and only pictures without it (RBT_ENC_SAO=0) take the in-place deblocking launches
+  b.off_ideb = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i] && !b.frames[i].lossless && (!b.desc[b.frame_stream[i]].sao || !e1_fused_lf())) { lists.push_back((int)i); b.n_ideb++; }
+  b.n_pdeb = 0; b.off_pdeb = lists.size(); for (size_t i = 0; i < nf; i++) if (!b.frame_is_idr[i] && !b.frames[i].lossless && (!b.desc[b.frame_stream[i]].sao || !e1_fused_lf())) { lists.push_back((int)i); b.n_pdeb++; }
   b.off_p = lists.size(); for (size_t i = 0; i < nf; i++) if (!b.frame_is_idr[i]) { lists.push_back((int)i); b.n_p++; }
   b.n_isao = b.n_psao = 0;
   b.off_isao = lists.size(); for (size_t i = 0; i < nf; i++) if (b.frame_is_idr[i] && b.desc[b.frame_stream[i]].sao) { lists.push_back((int)i); b.n_isao++; }

@@ -1,11 +1,14 @@
 #!/bin/bash
-# Development probe (GPU box): kernel stats of a short benchmark run with the fused loop filter and with the decoder's unfused path (RBT_FUSED_LF=0)
+# Development probe (GPU box): throughput with the loop filters fused (decoder k_loopfilter: RBT_FUSED_LF=1; encoder en_sao_ctb: default) and with the separate in-place
+# deblocking launches (decoder: default; encoder: RBT_FUSED_ENC_LF=0). No profiler; every variant three times, interleaved. $1 = steps (20: the driver's command), $2 = warmup
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O
 QUIET="--cpu-sample 0 --multi-gof 0 --quality 0 --sweep 0 --walk-frames 0 --fanout-gofs 0 --steady-steps 0"
-cd /tmp && export TMPDIR=/tmp
-for v in 1 0; do
-  export RBT_FUSED_LF=$v
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lf$v -o lf -- python3 $R/bench.py --steps 32 --warmup 16 --gofs-per-job 2 $QUIET > $O/prof_lf$v.log 2>&1 || exit 2
-  tail -1 $O/prof_lf$v.log | cut -c1-200
-  head -14 $O/prof_lf$v/lf_kernel_stats.csv | cut -c1-160
-done
+for rep in 1 2 3; do for v in "1 1" "0 1" "0 0"; do
+  set -- $v; export RBT_FUSED_LF=$1 RBT_FUSED_ENC_LF=$2
+  timeout -k 10 200 python3 $R/bench.py --steps ${STEPS:-20} --warmup ${WARM:-5} $QUIET > $O/lfp.json 2> $O/lfp.err || exit 2
+  python3 - "$1" "$2" $O/lfp.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
+print("decoder fused", sys.argv[1], "encoder fused", sys.argv[2], "fps", d["value"], {k: round(v, 1) for k, v in d["roofline"]["kernel_ms"].items()}, flush=True)
+PY
+done; done
