@@ -479,7 +479,7 @@ def main():
             ctx.set_depth(D)
             k_on = min(args.steps, 32)
             job_cache.clear(); params_keep = list(params); params[:] = p_on
-            run(max(min(args.warmup, 8), D + 1), D, None)        # untimed: every job slot has held this parameter set once (first-use allocations stay outside)
+            run(D * G, D, None)        # untimed: one job per slot with this parameter set (the occupancy maps' arenas are first-use allocations: they stay outside)
             t1 = time.perf_counter(); run(k_on, D, None); dt = time.perf_counter() - t1
             params[:] = params_keep; job_cache.clear()
             occ_rd["value"] = round(n_pc * k_on / dt, 2); occ_rd["unit"] = "point-cloud frames/s"; occ_rd["steps"] = k_on

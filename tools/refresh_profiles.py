@@ -21,20 +21,32 @@ def agg(path, name):
         if r["Counter_Name"] != name: continue
         k = kname(r["Kernel_Name"]); d[k][0] += 1; d[k][1] += float(r["Counter_Value"])
     return d
-F = agg("gpurun_out/prof_f/f_counter_collection.csv", "FETCH_SIZE"); W = agg("gpurun_out/prof_w/w_counter_collection.csv", "WRITE_SIZE")
-out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two separate passes, --kernel-trace only), python3 bench.py --steps 1 --warmup 0 --in-flight 1 --cpu-sample 0 "
-               "--multi-gof 0 --quality 0 --sweep 0 --walk-frames 0 --fanout-gofs 0 on MI355X: one transcode step of the HM-like 32-frame 1280x1280 GOF, nothing else in the "
-               "process. Values are KB summed over every dispatch of the kernel in that step. FETCH_SIZE is reported as counted: on gfx950 it tallies 128-B requests at 64 B, "
-               "i.e. exactly half the bytes of wide coalesced streaming reads (MI355X_MICROARCH.md, HBM section) - FETCH_SIZE_KB_x2 is that correction, an upper bound for the "
-               "kernels here, whose accesses are mostly narrower than 16 B per lane (uncalibrated widths). kernel_ms / HBM_GBps: time of the dispatches in the FETCH_SIZE pass "
-               "and (FETCH + WRITE) / time; MI355X peak 8000 GB/s.", "kernels": {}}
-dur = collections.defaultdict(float)     # kernel time of the same (FETCH_SIZE) pass; counter collection serialises the dispatches
-for r in csv.DictReader(open("gpurun_out/prof_f/f_kernel_trace.csv")): dur[kname(r["Kernel_Name"])] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-for k in sorted(set(F) | set(W)):
-    if k.startswith("__"): continue
-    out["kernels"][k] = {"dispatches": F[k][0] or W[k][0], "FETCH_SIZE_KB": round(F[k][1], 1), "FETCH_SIZE_KB_x2": round(2 * F[k][1], 1), "WRITE_SIZE_KB": round(W[k][1], 1), "kernel_ms": round(dur[k], 3),
-                         "HBM_GBps": round((F[k][1] + W[k][1]) * 1024 / (dur[k] * 1e-3) / 1e9, 1) if dur[k] > 0 else None}
-json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
+NOTE = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two separate passes, --kernel-trace only), python3 bench.py --steps 1 --warmup 0 --in-flight 1 --cpu-sample 0 "
+        "--multi-gof 0 --quality 0 --sweep 0 --walk-frames 0 --fanout-gofs 0 on MI355X: one transcode step of the HM-like 32-frame 1280x1280 GOF, nothing else in the "
+        "process. Values are KB summed over every dispatch of the kernel in that step. FETCH_SIZE is reported as counted: on gfx950 it tallies 128-B requests at 64 B, "
+        "i.e. exactly half the bytes of wide coalesced streaming reads (MI355X_MICROARCH.md, HBM section) - FETCH_SIZE_KB_x2 is that correction, an upper bound for the "
+        "kernels here, whose accesses are mostly narrower than 16 B per lane (uncalibrated widths). kernel_ms / HBM_GBps: time of the dispatches in the FETCH_SIZE pass "
+        "and (FETCH + WRITE) / time; MI355X peak 8000 GB/s.")
+
+def traffic(fdir, wdir, dst, extra=""):
+    F = agg(f"gpurun_out/{fdir}/f_counter_collection.csv", "FETCH_SIZE"); W = agg(f"gpurun_out/{wdir}/w_counter_collection.csv", "WRITE_SIZE")
+    out = {"note": NOTE + extra, "kernels": {}}
+    dur = collections.defaultdict(float)     # kernel time of the same (FETCH_SIZE) pass; counter collection serialises the dispatches
+    for r in csv.DictReader(open(f"gpurun_out/{fdir}/f_kernel_trace.csv")): dur[kname(r["Kernel_Name"])] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    tf = tw = 0.0
+    for k in sorted(set(F) | set(W)):
+        if k.startswith("__"): continue
+        out["kernels"][k] = {"dispatches": F[k][0] or W[k][0], "FETCH_SIZE_KB": round(F[k][1], 1), "FETCH_SIZE_KB_x2": round(2 * F[k][1], 1), "WRITE_SIZE_KB": round(W[k][1], 1), "kernel_ms": round(dur[k], 3),
+                             "HBM_GBps": round((F[k][1] + W[k][1]) * 1024 / (dur[k] * 1e-3) / 1e9, 1) if dur[k] > 0 else None}
+        tf += F[k][1]; tw += W[k][1]
+    out["total"] = {"FETCH_SIZE_GB": round(tf * 1024 / 1e9, 3), "WRITE_SIZE_GB": round(tw * 1024 / 1e9, 3), "FETCH_plus_WRITE_GB": round((tf + tw) * 1024 / 1e9, 3),
+                    "FETCH_x2_plus_WRITE_GB": round((2 * tf + tw) * 1024 / 1e9, 3),
+                    "filter_dispatches": sum(v["dispatches"] for k, v in out["kernels"].items() if k in ("k_deblock", "k_sao", "k_loopfilter", "k_enc_sao"))}
+    json.dump(out, open(dst, "w"), indent=1)
+traffic("prof_f", "prof_w", f"profiles/{tag}_pmc_traffic.json")
+if os.path.exists("gpurun_out/prof_ff/f_counter_collection.csv"):
+    traffic("prof_ff", "prof_wf", f"profiles/{tag}_pmc_traffic_fused_lf.json", " THIS FILE: the same step with RBT_FUSED_LF=1 RBT_FUSED_ENC_LF=1 (deblocking + SAO of the decoder in one launch "
+            "through LDS tiles, the encoder's deblocking inside its SAO kernel) - not the default, see DESIGN.md 2.")
 
 # SQ pass: instruction mix per kernel and what the matrix cores did (SURVEY / north star: MFMA only for the dense 32x32 transform tiles)
 names = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_I8", "SQ_INSTS_VALU_MFMA_MOPS_I8", "SQ_VALU_MFMA_BUSY_CYCLES"]
