@@ -26,8 +26,11 @@ __global__ void __launch_bounds__(64) k_parse(RbtFrame* frames, RbtSlice* slices
   rbt_parse_slice(frames, slices, slice_list[parse_index(ticket)], rbsp, RBT_LDS_CAST(RbtParseLds, lds), CAP4, save, row_limit);
 }
 // the same over slices of several batches (each task names its batch's tables)
+#ifndef RBT_PARSE_TASKS_ATTR
+#define RBT_PARSE_TASKS_ATTR
+#endif
 template <int CAP4>
-__global__ void __launch_bounds__(64) k_parse_tasks(const RbtParseTask* tasks, uint32_t* ticket) {
+__global__ void __launch_bounds__(64) RBT_PARSE_TASKS_ATTR k_parse_tasks(const RbtParseTask* tasks, uint32_t* ticket) {
   __shared__ alignas(16) uint32_t lds[(RBT_PARSE_LDS_BYTES(CAP4) + 3) / 4];
   const RbtParseTask t = tasks[parse_index(ticket)];
   rbt_parse_slice(t.frames, t.slices, t.slice, t.rbsp, RBT_LDS_CAST(RbtParseLds, lds), CAP4, nullptr, 0);
