@@ -485,6 +485,27 @@ def main():
             occ_rd["value"] = round(n_pc * k_on / dt, 2); occ_rd["unit"] = "point-cloud frames/s"; occ_rd["steps"] = k_on
         except Exception as e:   # informative leg: never lose the benchmark line over it
             occ_rd = {"error": str(e)}
+        # RBT_PRESET_FAST (rbt_stream_params.preset: what the reference's x265 preset strings "ultrafast".."fast" select): the open-loop decisions only
+        preset_fast = None
+        try:
+            p_fast = [P(q.video_type, q.qp, q.occupancy_precision, q.log2_ctb, q.ctb_rows_per_slice, 0, 0, 0, R.RBT_PRESET_FAST) for q in params]
+            ctx.set_depth(1)
+            o_f = ctx.transcode_gof(streams, p_fast)
+            preset_fast = {"out_bytes": sum(len(o) for o in o_f), "out_over_in": round(sum(len(o) for o in o_f) / in_bytes, 4),
+                           "geometry_psnr_y_db": psnr_y(sg, o_f[1], w, h, 1023), "attribute_psnr_y_db": psnr_y(sa, o_f[2], w, h, 1023)}
+            if d1 and "error" not in d1:
+                cloud, c_src, first, n_src = d1_tools
+                c_f = cloud(ctx.decode(first(o_f[0], 1))[0][0][: (w // 4) * (h // 4)].reshape(h // 4, w // 4), 4, ctx.decode(first(o_f[1], 1))[0])
+                preset_fast["d1_psnr_vs_source_db"] = round(ctx.d1(c_src, c_f)["psnr"], 3)
+            ctx.set_depth(D)
+            k_f = min(args.steps, 32)
+            job_cache.clear(); params_keep = list(params); params[:] = p_fast
+            run(D * G, D, None)
+            t1 = time.perf_counter(); run(k_f, D, None); dt = time.perf_counter() - t1
+            params[:] = params_keep; job_cache.clear()
+            preset_fast["value"] = round(n_pc * k_f / dt, 2); preset_fast["unit"] = "point-cloud frames/s"; preset_fast["steps"] = k_f
+        except Exception as e:   # informative leg
+            preset_fast = {"error": str(e)}
         # the same-data anchor (tests/golden/make_anchor.py, made in the build container): the SOURCE maps of this GOF coded directly at the target QPs by the oracle's HM-like
         # mode - what BASELINE.md's R3 row is for 8i data - next to what the transcode of the R5 stream comes out at, both against the uncoded source maps
         anchor = None
@@ -505,7 +526,7 @@ def main():
                           "note": "same maps, same QPs: the direct encode sees the uncoded source (first generation), the transcode the decoded R5 stream (second generation)"}
         except Exception as e:
             anchor = {"error": str(e)}
-        quality = {"d1": d1, "anchor_direct_encode": anchor, "occupancy_rd": occ_rd, "geometry_psnr_y_db": psnr_y(sg, outs[1], w, h, 1023), "attribute_psnr_y_db": psnr_y(sa, outs[2], w, h, 1023),
+        quality = {"d1": d1, "anchor_direct_encode": anchor, "occupancy_rd": occ_rd, "preset_fast": preset_fast, "geometry_psnr_y_db": psnr_y(sg, outs[1], w, h, 1023), "attribute_psnr_y_db": psnr_y(sa, outs[2], w, h, 1023),
                    "occupancy_is_or_pool": bool(np.array_equal(oo[:, :(ow // 2) * (oh // 2)].reshape(-1, oh // 2, ow // 2) > 0, pooled)),
                    "note": "picture PSNR: R3 output pictures vs R5 input pictures"}
 

@@ -55,7 +55,12 @@ typedef struct {
                               * attribute bytes, D1 -0.02 dB, attribute PSNR of the occupied samples unchanged. The pictures outside the occupied area are then whatever
                               * prediction leaves there. Entries come GOF by GOF, occupancy first; ignored where the call holds no such occupancy stream, by
                               * rbt_transcode_substream (one stream) and for lossless streams; not together with verify_md5 (RBT_ERR_PARAM). 0 = off: every sample counts. */
+  int preset;                /* RBT_PRESET_*: what the reference's `preset` (PCCTranscoderParameters.h:58, handed to libx265 at PCCTranscoder.cpp:877,883) selects here.
+                              * RBT_PRESET_DEFAULT (0, x265 "medium" and slower): every decision tool of RBT-E1. RBT_PRESET_FAST (1, "ultrafast" .. "fast"):
+                              * the open-loop decisions only - no SATD block costs, no closed-loop mode choice, fixed rounding: 11 % more bytes at the same QP (benchmark
+                              * GOF: out / in 0.375 instead of 0.338) for less work in the intra stage. rbt_preset_from_name maps the reference's strings. */
 } rbt_stream_params;
+enum { RBT_PRESET_DEFAULT = 0, RBT_PRESET_FAST = 1 };
 
 typedef struct {             /* decoded video returned by rbt_decode (host memory, rbt_free) */
   int width, height, bit_depth, n_frames;
@@ -118,6 +123,9 @@ int rbt_get_depth(rbt_ctx* ctx);   /* the announced depth (> 0) or RBT_ERR_PARAM
 /* How to cut a walk of n_gofs GOFs into jobs on one GPU, as measured: 16 jobs of 2 GOFs for a long walk; a walk shorter than 48 GOFs is all ramp-up and
  * drain and does better as at most 7 jobs (2 jobs up to 12 GOFs) of ceil(n / jobs) GOFs, which then own several hardware queues each. max_jobs caps the jobs in flight. */
 int rbt_job_shape(int n_gofs, int max_jobs, int* gofs_per_job, int* jobs_in_flight);
+/* The reference's `preset` string (an x265 preset name, PCCTranscoderParameters.h:58) as RBT_PRESET_*: "ultrafast", "superfast", "veryfast", "faster", "fast" ->
+ * RBT_PRESET_FAST; "medium", "slow", "slower", "veryslow", "placebo" and NULL / "" -> RBT_PRESET_DEFAULT; anything else -> RBT_ERR_PARAM. */
+int rbt_preset_from_name(const char* name);
 int rbt_submit_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, rbt_job** job);
 int rbt_wait_gof(rbt_ctx* ctx, rbt_job* job, uint8_t** annexb_out, size_t* n_out);
 /* The library keeps the device memory of collected jobs for the next job of the same shape (hipMalloc / hipFree of GOF-sized arenas cost milliseconds
@@ -240,6 +248,7 @@ typedef struct {
                               * the duration of the call when the walk is short (the depth announced with rbt_set_depth is the cap and is restored) */
   int occupancy_rd;          /* occupancy-aware coding of the geometry / attribute units of every GOF (rbt_stream_params.occupancy_rd): with the occupancy map that GOF's
                               * occupancy unit comes out with, when occupancy_precision is 4 */
+  int preset;                /* RBT_PRESET_* for the geometry / attribute units (rbt_stream_params.preset) */
 } rbt_v3c_params;
 /* The whole walk: index, per GOF the video units through rbt_submit_gof / rbt_wait_gof with as many jobs in flight as rbt_set_depth announced (fewer for a short walk
  * with gofs_per_job = 0), write.

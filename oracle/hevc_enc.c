@@ -1498,7 +1498,7 @@ static void setup_stream(enc* e) {
   if (q->lossless) { p->transquant_bypass_enabled = 1; p->deblocking_control_present = 1; p->pps_deblocking_disabled = 1; p->loop_filter_across_slices = 0; }
   if (!e->stress && !e->hm && !q->lossless && e1_sao_on()) s->sao_enabled = 1;
   e->tu_rd = e->hm;
-  if (!e->stress && !e->hm) { e->e1_satd = e1_satd_on(); e->e1_refine = e1_refine_on(); e->e1_rq = !q->lossless && e1_rq_on(); }
+  if (!e->stress && !e->hm) { e->e1_satd = e1_satd_on() && !(q->tools_off & 1); e->e1_refine = e1_refine_on() && !(q->tools_off & 2); e->e1_rq = !q->lossless && e1_rq_on() && !(q->tools_off & 4); }
   if (!e->stress && !e->hm && !q->lossless) { s->max_th_depth_intra = 1; e->tu_rd = 1; p->transform_skip_enabled = e1_ts_on(); }
   if (!e->stress && !e->hm && q->lossless) { s->max_th_depth_intra = 1; e->tu_rd = 1; }   /* lossless (occupancy) too: four blocks predict from closer neighbours - 9 % fewer bytes on the benchmark's occupancy maps; distortion is 0 either way, the level bits decide */   /* RBT-E1: an intra CU is one transform unit or four, whichever codes its luma cheaper */
   if (!e->stress && !e->hm && q->ctb_rows_per_slice < 0) { p->entropy_coding_sync = 1; p->dependent_slice_segments_enabled = q->ctb_rows_per_slice == -1; }   /* wavefront rows, one dependent slice segment each */

@@ -238,7 +238,7 @@ static int transcode_substream_occ(const uint8_t* annexb, size_t n, const oracle
   for (int i = 0; i < nf; i++) dec[i] = has_crop(crop) ? frame_crop(oracle_hevc_dec_frame(d, i), crop) : (hevc_frame*)oracle_hevc_dec_frame(d, i);
   const hevc_frame* f0 = dec[0];
   oracle_enc_params ep; memset(&ep, 0, sizeof(ep));
-  ep.bit_depth = f0->bit_depth; ep.qp = p->qp; ep.log2_ctb = p->log2_ctb; ep.ctb_rows_per_slice = p->ctb_rows_per_slice; ep.md5_sei = p->md5_sei;
+  ep.bit_depth = f0->bit_depth; ep.qp = p->qp; ep.log2_ctb = p->log2_ctb; ep.ctb_rows_per_slice = p->ctb_rows_per_slice; ep.md5_sei = p->md5_sei; ep.tools_off = p->preset == 1 ? 7 : 0;
   hevc_frame** src = (hevc_frame**)calloc((size_t)nf, sizeof(void*));
   int own = 0;
   if (p->video_type == 0) {
@@ -318,7 +318,7 @@ static int v3c_floor_log2(uint32_t x) { int r = -1; while (x) { r++; x >>= 1; } 
 static int v3c_ceil_log2(uint32_t x) { return x == 0 ? -1 : v3c_floor_log2(x - 1) + 1; }
 typedef struct { int type; uint8_t* d; size_t n; } v3c_unit_t;
 int oracle_v3c_transcode(const uint8_t* in, size_t n, int occupancy_precision, int geometry_qp, int attribute_qp, int forced_precision_bytes,
-                         int log2_ctb, int ctb_rows_per_slice, int md5_sei, int occupancy_rd, uint8_t** out, size_t* n_out) {
+                         int log2_ctb, int ctb_rows_per_slice, int md5_sei, int occupancy_rd, int preset, uint8_t** out, size_t* n_out) {
   *out = NULL; *n_out = 0;
   occ_video ov; memset(&ov, 0, sizeof(ov));      /* occupancy_rd: the occupancy video of the current GOF as it leaves (units of a GOF follow its V3C_VPS, occupancy first) */
   if (n < 1) return -1;
@@ -341,7 +341,7 @@ int oracle_v3c_transcode(const uint8_t* in, size_t n, int occupancy_precision, i
     uint32_t h = ((uint32_t)u[k].d[0] << 24) | ((uint32_t)u[k].d[1] << 16) | ((uint32_t)u[k].d[2] << 8) | u[k].d[3];
     if (u[k].type == 0) occ_video_free(&ov);                       /* V3C_VPS: a new GOF */
     oracle_transcode_params tp; memset(&tp, 0, sizeof(tp));
-    tp.occupancy_precision = occupancy_precision; tp.log2_ctb = log2_ctb; tp.ctb_rows_per_slice = ctb_rows_per_slice; tp.md5_sei = md5_sei;
+    tp.occupancy_precision = occupancy_precision; tp.log2_ctb = log2_ctb; tp.ctb_rows_per_slice = ctb_rows_per_slice; tp.md5_sei = md5_sei; tp.preset = preset;
     if (u[k].type == 2) { if (occupancy_precision != 4) continue; tp.video_type = 0; tp.qp = 8; }                       /* V3C_OVD; :150 */
     else if (u[k].type == 3) { if ((h >> 12) & 1) continue; tp.video_type = 1; tp.qp = geometry_qp; }                   /* V3C_GVD, no auxiliary video -> VIDEO_GEOMETRY */
     else if (u[k].type == 4) { if ((h & 1) || ((h >> 5) & 31)) continue; tp.video_type = 19; tp.qp = attribute_qp; }    /* V3C_AVD, no auxiliary video, partition 0 -> VIDEO_ATTRIBUTE */

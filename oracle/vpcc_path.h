@@ -21,6 +21,7 @@ typedef struct {
   int md5_sei;
   int occupancy_rd;           /* geometry / attribute streams handed to oracle_transcode_data behind an occupancy stream: occupancy-aware coding (oracle_enc_params.occ4,
                                  SURVEY.md 8 row F4) with the occupancy map that stream comes out with; ignored by oracle_transcode_substream, which sees one stream */
+  int preset;                 /* 0 = every decision tool of RBT-E1; 1 = "fast": the open-loop decisions only (oracle_enc_params.tools_off = 7); the library's rbt_stream_params.preset */
 } oracle_transcode_params;
 
 /* PCCVideoBitstream::sampleStreamToByteStream / byteStreamToSampleStream (PCCVideoBitstream.cpp:85-172), HEVC case,
@@ -46,6 +47,6 @@ int oracle_transcode_data(int n, const uint8_t* const* in, const size_t* n_in, c
  * geometry / attribute: params of those two videos; occupancy transcoded (qp 8, lossless) only when occupancy_precision == 4. */
 /* (occupancy_rd: the geometry / attribute units of a GOF are coded with the occupancy map its occupancy unit comes out with, oracle_transcode_params.occupancy_rd) */
 int oracle_v3c_transcode(const uint8_t* in, size_t n, int occupancy_precision, int geometry_qp, int attribute_qp, int forced_precision_bytes,
-                         int log2_ctb, int ctb_rows_per_slice, int md5_sei, int occupancy_rd, uint8_t** out, size_t* n_out);
+                         int log2_ctb, int ctb_rows_per_slice, int md5_sei, int occupancy_rd, int preset, uint8_t** out, size_t* n_out);
 void oracle_free(void* p);
 #endif

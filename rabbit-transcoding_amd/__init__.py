@@ -22,7 +22,7 @@ class RbtError(RuntimeError):
 
 class StreamParams(C.Structure):
     _fields_ = [("video_type", C.c_int), ("qp", C.c_int), ("occupancy_precision", C.c_int), ("log2_ctb", C.c_int),
-                ("ctb_rows_per_slice", C.c_int), ("md5_sei", C.c_int), ("verify_md5", C.c_int), ("occupancy_rd", C.c_int)]
+                ("ctb_rows_per_slice", C.c_int), ("md5_sei", C.c_int), ("verify_md5", C.c_int), ("occupancy_rd", C.c_int), ("preset", C.c_int)]
 
 
 class Video(C.Structure):
@@ -66,7 +66,7 @@ class V3CUnit(C.Structure):
 
 class V3CParams(C.Structure):
     """rbt_v3c_params: PCCTranscoderParameters as the container walk needs them"""
-    _fields_ = [(n, C.c_int) for n in ("occupancy_precision", "geometry_qp", "attribute_qp", "forced_unit_size_precision_bytes", "log2_ctb", "ctb_rows_per_slice", "md5_sei", "verify_md5", "gofs_per_job", "occupancy_rd")]
+    _fields_ = [(n, C.c_int) for n in ("occupancy_precision", "geometry_qp", "attribute_qp", "forced_unit_size_precision_bytes", "log2_ctb", "ctb_rows_per_slice", "md5_sei", "verify_md5", "gofs_per_job", "occupancy_rd", "preset")]
 
 
 class V3CStat(C.Structure):
@@ -104,6 +104,7 @@ def load(path=None):
     L.rbt_trim.argtypes = [C.c_void_p]
     L.rbt_get_depth.argtypes = [C.c_void_p]
     L.rbt_job_shape.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.rbt_preset_from_name.argtypes = [C.c_char_p]
     L.rbt_wait_gof.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rbt_or_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.rbt_sample_to_byte_stream.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
@@ -130,6 +131,18 @@ def _convert(fn, data, L):
     res = C.string_at(out, n.value)
     L.rbt_free(out)
     return res
+
+
+RBT_PRESET_DEFAULT, RBT_PRESET_FAST = 0, 1
+
+
+def preset_from_name(name, lib=None):
+    """rbt_preset_from_name: the reference's `preset` string (an x265 preset name) as RBT_PRESET_*"""
+    L = lib or load()
+    rc = L.rbt_preset_from_name(name.encode() if name is not None else None)
+    if rc < 0:
+        raise RbtError(rc, L.rbt_strerror(rc).decode())
+    return rc
 
 
 def job_shape(n_gofs, max_jobs=16, lib=None):
@@ -234,8 +247,8 @@ class Context:
         self._chk(self.L.rbt_encode(self.h, frames.ctypes.data, w, h, bit_depth, frames.shape[0], qp, gop, lossless, log2_ctb, rows_per_slice, md5_sei, C.byref(out), C.byref(n)))
         return self._take(out, n)
 
-    def transcode_substream(self, stream: bytes, video_type, qp, occupancy_precision=4, log2_ctb=5, rows_per_slice=1, md5_sei=1, verify_md5=0):
-        p = StreamParams(video_type, qp, occupancy_precision, log2_ctb, rows_per_slice, md5_sei, verify_md5)
+    def transcode_substream(self, stream: bytes, video_type, qp, occupancy_precision=4, log2_ctb=5, rows_per_slice=1, md5_sei=1, verify_md5=0, preset=0):
+        p = StreamParams(video_type, qp, occupancy_precision, log2_ctb, rows_per_slice, md5_sei, verify_md5, 0, preset)
         out, n = C.c_void_p(), C.c_size_t()
         self._chk(self.L.rbt_transcode_substream(self.h, stream, len(stream), C.byref(p), C.byref(out), C.byref(n)))
         return self._take(out, n)
@@ -255,9 +268,9 @@ class Context:
         return res
 
     def transcode_v3c(self, data: bytes, geometry_qp, attribute_qp, occupancy_precision=4, forced_precision_bytes=0, log2_ctb=5, rows_per_slice=-1, md5_sei=0,
-                      verify_md5=0, gofs_per_job=1, occupancy_rd=0):
+                      verify_md5=0, gofs_per_job=1, occupancy_rd=0, preset=0):
         """rbt_transcode_v3c: a whole V3C sample stream (every GOF this context owns) -> transcoded sample stream; gofs_per_job=0: job shape by rbt_job_shape"""
-        p = V3CParams(occupancy_precision, geometry_qp, attribute_qp, forced_precision_bytes, log2_ctb, rows_per_slice, md5_sei, verify_md5, gofs_per_job, occupancy_rd)
+        p = V3CParams(occupancy_precision, geometry_qp, attribute_qp, forced_precision_bytes, log2_ctb, rows_per_slice, md5_sei, verify_md5, gofs_per_job, occupancy_rd, preset)
         out, n = C.c_void_p(), C.c_size_t()
         self._chk(self.L.rbt_transcode_v3c(self.h, data, len(data), C.byref(p), C.byref(out), C.byref(n)))
         return self._take(out, n)

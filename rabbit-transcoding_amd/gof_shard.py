@@ -36,13 +36,13 @@ def rates_of_rank(rates: Sequence[int], rank: int, world: int) -> List[int]:
     return [r for i, r in enumerate(rates) if i % world == rank]
 
 
-def rate_params(R, rate: int, log2_ctb: int = 5, rows_per_slice: int = DEFAULT_ROWS, md5_sei: int = 0, occupancy_rd: int = 0):
+def rate_params(R, rate: int, log2_ctb: int = 5, rows_per_slice: int = DEFAULT_ROWS, md5_sei: int = 0, occupancy_rd: int = 0, preset: int = 0):
     """rbt_stream_params of the [occupancy, geometry, attribute] sub-bitstreams for CTC rate point `rate` (1..5).
-    R = the rabbit_transcoding_amd module (StreamParams). occupancy_rd: occupancy-aware coding of the geometry and attribute maps (include/rbt.h)."""
+    R = the rabbit_transcoding_amd module (StreamParams). occupancy_rd: occupancy-aware coding of the geometry and attribute maps; preset: RBT_PRESET_* (include/rbt.h)."""
     gq, aq, prec = RATE_POINTS[rate]
     P = R.StreamParams
-    return [P(VIDEO_OCCUPANCY, 8, prec, log2_ctb, rows_per_slice, md5_sei, 0, 0), P(VIDEO_GEOMETRY, gq, prec, log2_ctb, rows_per_slice, md5_sei, 0, occupancy_rd),
-            P(VIDEO_ATTRIBUTE, aq, prec, log2_ctb, rows_per_slice, md5_sei, 0, occupancy_rd)]
+    return [P(VIDEO_OCCUPANCY, 8, prec, log2_ctb, rows_per_slice, md5_sei, 0, 0), P(VIDEO_GEOMETRY, gq, prec, log2_ctb, rows_per_slice, md5_sei, 0, occupancy_rd, preset),
+            P(VIDEO_ATTRIBUTE, aq, prec, log2_ctb, rows_per_slice, md5_sei, 0, occupancy_rd, preset)]
 
 
 def gather_streams(local: Sequence[bytes], group=None, device="cpu") -> List[List[bytes]]:

@@ -18,6 +18,7 @@ struct EncStreamDesc {
   std::vector<const uint8_t*> hint_pm, hint_dm; int hint_w4 = 0, hint_h4 = 0;       // per frame: the decoded input picture's 4x4 maps (device), empty = no hints
   std::vector<const uint8_t*> occ4; int occ4_w = 0, occ4_h = 0;                      // per frame: occupancy of the 4x4 luma units (device, RbtFrame::occ4), empty = every sample counts
   int sao = 0;                           // SAO on (every stream that is not lossless, unless RBT_ENC_SAO=0)
+  int tools_off = 0;                     // RBT_ET_* decision tools left out (rbt_stream_params.preset)
   std::vector<const uint16_t*> src[3];   // device planes per frame
   int src_stride = 0, src_x0 = 0, src_y0 = 0;   // the planes are views: luma row stride (0 = w) and origin of the w x h region (luma samples)
 };
@@ -87,7 +88,7 @@ static int encode_build(EncodeBatch& b) {
       RbtFrame f; memset(&f, 0, sizeof(f));
       fill_stream_cfg(s, p, f.cfg);
       f.poc = is_i ? 0 : (i % d.gop); f.level = is_i ? 0 : 1; f.first_slice = (int)b.slices.size();
-      f.w8 = s.width / 8; f.h8 = s.height / 8; f.lossless = d.lossless; f.enc_tools = e1_tools(d.lossless) | (e1_fused_lf() ? 0 : RBT_ET_LF_OUTSIDE); f.ref_frame = is_i ? -1 : (int)b.frames.size() - 1; f.ref_poc = is_i ? 0 : f.poc - 1;
+      f.w8 = s.width / 8; f.h8 = s.height / 8; f.lossless = d.lossless; f.enc_tools = (e1_tools(d.lossless) & ~d.tools_off) | (e1_fused_lf() ? 0 : RBT_ET_LF_OUTSIDE); f.ref_frame = is_i ? -1 : (int)b.frames.size() - 1; f.ref_poc = is_i ? 0 : f.poc - 1;
       for (int c = 0; c < 3; c++) f.src[c] = d.src[c][i];
       if (!d.hint_dm.empty()) { f.hint_pm = d.hint_pm[i]; f.hint_dm = d.hint_dm[i]; f.hint_w4 = d.hint_w4; f.hint_h4 = d.hint_h4; }
       if (!d.occ4.empty() && !d.lossless) { f.occ4 = d.occ4[i]; f.occ4_w = d.occ4_w; f.occ4_h = d.occ4_h; }
@@ -330,7 +331,8 @@ static int setup_encode(DecodeBatch& db, int si, int ei, const rbt_stream_params
   // what a player shows of the input: the coded picture minus its conformance window
   const int cl = 2 * isps.conf_win[0], ct = 2 * isps.conf_win[2], dw = c.w - cl - 2 * isps.conf_win[1], dh = c.h - ct - 2 * isps.conf_win[3];
   if (dw <= 0 || dh <= 0) { err = "empty conformance window"; return RBT_ERR_BITSTREAM; }
-  d.bd = c.bit_depth; d.n_frames = cnt; d.qp = p.qp; d.log2_ctb = p.log2_ctb; d.rows = p.ctb_rows_per_slice; d.md5 = p.md5_sei;
+  if (p.preset != RBT_PRESET_DEFAULT && p.preset != RBT_PRESET_FAST) { err = "preset must be RBT_PRESET_DEFAULT or RBT_PRESET_FAST"; return RBT_ERR_PARAM; }
+  d.bd = c.bit_depth; d.n_frames = cnt; d.qp = p.qp; d.log2_ctb = p.log2_ctb; d.rows = p.ctb_rows_per_slice; d.md5 = p.md5_sei; d.tools_off = p.preset == RBT_PRESET_FAST ? (RBT_ET_SATD | RBT_ET_REFINE | RBT_ET_RQ) : 0;
   for (int k = 0; k < 3; k++) d.src[k].resize(cnt);
   auto view = [&](int k, int q) { return (const uint16_t*)db.frames[first + k].out[q]; };
   if (p.video_type == RBT_VIDEO_OCCUPANCY) {

@@ -191,7 +191,7 @@ int rbt_transcode_v3c_stream(rbt_ctx* ctx, const uint8_t* in, size_t n, const rb
         conv.push_back(c); jb.unit.push_back(pk.unit);
         rbt_stream_params s; memset(&s, 0, sizeof(s));
         s.video_type = pk.video_type; s.qp = pk.video_type == RBT_VIDEO_GEOMETRY ? p->geometry_qp : (pk.video_type == RBT_VIDEO_ATTRIBUTE ? p->attribute_qp : 8);
-        s.occupancy_precision = p->occupancy_precision; s.log2_ctb = p->log2_ctb; s.ctb_rows_per_slice = p->ctb_rows_per_slice; s.md5_sei = p->md5_sei; s.verify_md5 = p->verify_md5; s.occupancy_rd = pk.video_type != RBT_VIDEO_OCCUPANCY ? p->occupancy_rd : 0;
+        s.occupancy_precision = p->occupancy_precision; s.log2_ctb = p->log2_ctb; s.ctb_rows_per_slice = p->ctb_rows_per_slice; s.md5_sei = p->md5_sei; s.verify_md5 = p->verify_md5; s.occupancy_rd = pk.video_type != RBT_VIDEO_OCCUPANCY ? p->occupancy_rd : 0; s.preset = p->preset;
         sp.push_back(s);
       }
     for (auto& c : conv) { ip.push_back(c.p); in_n.push_back(c.n); }

@@ -19,14 +19,14 @@ class OracleVideo(C.Structure):
 
 class TranscodeParams(C.Structure):
     _fields_ = [("video_type", C.c_int), ("qp", C.c_int), ("occupancy_precision", C.c_int), ("log2_ctb", C.c_int),
-                ("ctb_rows_per_slice", C.c_int), ("md5_sei", C.c_int), ("occupancy_rd", C.c_int)]
+                ("ctb_rows_per_slice", C.c_int), ("md5_sei", C.c_int), ("occupancy_rd", C.c_int), ("preset", C.c_int)]
 
 
 class EncParams(C.Structure):
     """oracle_enc_params (oracle/hevc_enc.h)"""
     _fields_ = [(n, C.c_int) for n in ("width", "height", "bit_depth", "qp", "i_qp_offset", "gop", "lossless", "log2_ctb", "ctb_rows_per_slice", "md5_sei")] + \
                [("stress_seed", C.c_uint32)] + [(n, C.c_int) for n in ("conf_win_right", "conf_win_bottom", "hm_like", "p_qp_offset")] + \
-               [("hint_modes", C.c_void_p), ("hint_w4", C.c_int), ("hint_h4", C.c_int), ("occ4", C.c_void_p), ("occ4_w", C.c_int), ("occ4_h", C.c_int)]
+               [("hint_modes", C.c_void_p), ("hint_w4", C.c_int), ("hint_h4", C.c_int), ("occ4", C.c_void_p), ("occ4_w", C.c_int), ("occ4_h", C.c_int), ("tools_off", C.c_int)]
 
 
 class OPatch(C.Structure):
@@ -76,7 +76,7 @@ def lib():
         L.oracle_or_pool.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.oracle_md5.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
         L.oracle_free.argtypes = [C.c_void_p]
-        L.oracle_v3c_transcode.argtypes = [C.c_char_p, C.c_size_t] + [C.c_int] * 8 + [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.oracle_v3c_transcode.argtypes = [C.c_char_p, C.c_size_t] + [C.c_int] * 9 + [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         _LIB = L
     return _LIB
 
@@ -128,8 +128,8 @@ def encode_hm(frames: np.ndarray, w, h, bit_depth, qp, gop=2, i_qp_offset=-3, p_
     return _take(out, n_out), recon
 
 
-def transcode_substream(stream: bytes, video_type, qp, occupancy_precision=4, log2_ctb=5, rows_per_slice=1, md5_sei=1):
-    p = TranscodeParams(video_type, qp, occupancy_precision, log2_ctb, rows_per_slice, md5_sei)
+def transcode_substream(stream: bytes, video_type, qp, occupancy_precision=4, log2_ctb=5, rows_per_slice=1, md5_sei=1, preset=0):
+    p = TranscodeParams(video_type, qp, occupancy_precision, log2_ctb, rows_per_slice, md5_sei, 0, preset)
     out = C.c_void_p()
     n_out = C.c_size_t()
     rc = lib().oracle_transcode_substream(stream, len(stream), C.byref(p), C.byref(out), C.byref(n_out))
@@ -156,10 +156,10 @@ def transcode_data(streams, params):
     return res
 
 
-def v3c_transcode(data: bytes, geometry_qp, attribute_qp, occupancy_precision=4, forced_precision_bytes=0, log2_ctb=5, rows_per_slice=-1, md5_sei=0, occupancy_rd=0):
+def v3c_transcode(data: bytes, geometry_qp, attribute_qp, occupancy_precision=4, forced_precision_bytes=0, log2_ctb=5, rows_per_slice=-1, md5_sei=0, occupancy_rd=0, preset=0):
     """oracle_v3c_transcode: the V3C sample stream walk of PccAppTranscoder around transcodeData"""
     out, n = C.c_void_p(), C.c_size_t()
-    rc = lib().oracle_v3c_transcode(data, len(data), occupancy_precision, geometry_qp, attribute_qp, forced_precision_bytes, log2_ctb, rows_per_slice, md5_sei, occupancy_rd, C.byref(out), C.byref(n))
+    rc = lib().oracle_v3c_transcode(data, len(data), occupancy_precision, geometry_qp, attribute_qp, forced_precision_bytes, log2_ctb, rows_per_slice, md5_sei, occupancy_rd, preset, C.byref(out), C.byref(n))
     if rc != 0:
         raise RuntimeError(f"oracle v3c transcode failed rc={rc}")
     return _take(out, n)

@@ -285,6 +285,26 @@ def test_occupancy_aware_coding_matches_oracle(ctx):
     assert [ctx.wait_gof(j) for j in jobs] == want[:2]
 
 
+def test_preset_matches_oracle(ctx):
+    """rbt_stream_params.preset on the GPU: RBT_PRESET_FAST == the oracle without the round-3 decision tools, the default == the oracle with them, both in one call"""
+    import test_hostemu_parity as T
+    T.check_preset(ctx, rbt_lib.module())
+
+
+def test_preset_fast_full_size_frame(ctx):
+    """one point-cloud frame of the committed 1280x1280 fixture, R5 -> R3 at RBT_PRESET_FAST: == oracle; more bytes than the default (which the other full-size tests pin)"""
+    import os
+    gs = rbt_lib.module_file("gof_shard")
+    R = rbt_lib.module()
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    first = [gs.split_pairs(open(os.path.join(gold, f"hm_r5_1280x1280_f32_{k}.annexb"), "rb").read())[0] for k in ("occ", "geo", "attr")]
+    fast_p = gs.rate_params(R, 3, preset=R.RBT_PRESET_FAST)
+    fast = ctx.transcode_gof(first, fast_p)
+    assert fast == O.transcode_data(first, [(p.video_type, p.qp, p.occupancy_precision, p.log2_ctb, p.ctb_rows_per_slice, p.md5_sei, 0, p.preset) for p in fast_p])
+    full = ctx.transcode_gof(first, gs.rate_params(R, 3))
+    assert fast[0] == full[0] and len(fast[1]) > len(full[1]) and len(fast[2]) > 1.05 * len(full[2])
+
+
 def test_occupancy_aware_coding_full_size_frame(ctx):
     """one point-cloud frame of the committed 1280x1280 fixture, R5 -> R3 with occupancy_rd: == oracle, and what the option is for - at least 40 % fewer geometry bytes
     with D1 of the decoded cloud within 0.1 dB of the plain transcode (bench.py reports the whole GOF)."""

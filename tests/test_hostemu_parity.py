@@ -339,6 +339,30 @@ def test_occupancy_aware_coding_matches_oracle(ctx):
     check_occupancy_rd(ctx, rbt_lib.module())
 
 
+def check_preset(ctx, R):
+    """rbt_stream_params.preset (the reference's x265 preset string, PCCTranscoderParameters.h:58): RBT_PRESET_FAST leaves the round-3 decision tools out, in the library and in
+    the oracle alike; HM-like input (the input's modes as candidates), every slice structure, one GOF call with both presets side by side. Shared with tests/test_gpu_transcode.py."""
+    assert [R.preset_from_name(n) for n in ("ultrafast", "superfast", "veryfast", "faster", "fast", "medium", "slow", "slower", "veryslow", "placebo", "", None)] == [1] * 5 + [0] * 7
+    with pytest.raises(R.RbtError):
+        R.preset_from_name("quick")
+    m = synth.make_maps(192, 128, 9)
+    for key, vt, q0, q1 in (("geo", R.RBT_VIDEO_GEOMETRY, 16, 24), ("attr", R.RBT_VIDEO_ATTRIBUTE, 22, 32)):
+        bs, _ = O.encode_hm(m[key], 192, 128, 10, q0)
+        for ctb, rows in ((5, -1), (6, 0), (4, 1)):
+            fast = ctx.transcode_substream(bs, vt, q1, log2_ctb=ctb, rows_per_slice=rows, md5_sei=0, preset=R.RBT_PRESET_FAST)
+            full = ctx.transcode_substream(bs, vt, q1, log2_ctb=ctb, rows_per_slice=rows, md5_sei=0)
+            assert fast == O.transcode_substream(bs, int(vt), q1, 4, ctb, rows, 0, preset=1) and full == O.transcode_substream(bs, int(vt), q1, 4, ctb, rows, 0) and fast != full
+            assert ctx.decode(fast)[5] == 0
+        both = ctx.transcode_gof([bs, bs], [R.StreamParams(vt, q1, 4, 5, -1, 0, 0, 0, 1), R.StreamParams(vt, q1, 4, 5, -1, 0, 0, 0, 0)])     # one decode, two encoders
+        assert both[0] == O.transcode_substream(bs, int(vt), q1, 4, 5, -1, 0, preset=1) and both[1] == O.transcode_substream(bs, int(vt), q1, 4, 5, -1, 0)
+    with pytest.raises(R.RbtError):
+        ctx.transcode_substream(bs, R.RBT_VIDEO_GEOMETRY, 24, preset=2)
+
+
+def test_preset_matches_oracle(ctx):
+    check_preset(ctx, rbt_lib.module())
+
+
 def split_nals(bs):
     """Annex-B stream -> list of NAL units with their start codes"""
     pos, i = [], bs.find(b"\x00\x00\x01")

@@ -115,6 +115,17 @@ def test_transcode_v3c_leaves_occupancy_alone_unless_precision_4(R, ctx, contain
     assert prec == 4 and out_units[2] == units[2] and out_units[:2] == units[:2] and out_units[3] != units[3]
 
 
+def test_transcode_v3c_options_reach_the_encoder(R, ctx, container):
+    """rbt_v3c_params.preset and .occupancy_rd: the walk hands them to every GOF's geometry / attribute units, as the oracle's walk does"""
+    gofs, units = container
+    data = V.sample_stream(units[:5], 4)
+    plain = ctx.transcode_v3c(data, 24, 32)
+    fast = ctx.transcode_v3c(data, 24, 32, preset=R.RBT_PRESET_FAST)
+    assert fast == O.v3c_transcode(data, 24, 32, preset=1) and fast != plain
+    both = ctx.transcode_v3c(data, 24, 32, preset=R.RBT_PRESET_FAST, occupancy_rd=1)
+    assert both == O.v3c_transcode(data, 24, 32, preset=1, occupancy_rd=1) and len(both) < len(fast)
+
+
 @pytest.mark.parametrize("depth,per", [(1, 1), (2, 1), (3, 2), (16, 2), (16, 0), (1, 0)])   # per 0: job shape by rbt_job_shape (3 GOFs: 2 jobs of 2 + 1)
 def test_transcode_v3c_same_bytes_at_every_depth(R, ctx, container, depth, per):
     gofs, units = container
