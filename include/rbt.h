@@ -57,8 +57,10 @@ typedef struct {
                               * rbt_transcode_substream (one stream) and for lossless streams; not together with verify_md5 (RBT_ERR_PARAM). 0 = off: every sample counts. */
   int preset;                /* RBT_PRESET_*: what the reference's `preset` (PCCTranscoderParameters.h:58, handed to libx265 at PCCTranscoder.cpp:877,883) selects here.
                               * RBT_PRESET_DEFAULT (0, x265 "medium" and slower): every decision tool of RBT-E1. RBT_PRESET_FAST (1, "ultrafast" .. "fast"):
-                              * the open-loop decisions only - no SATD block costs, no closed-loop mode choice, fixed rounding: 11 % more bytes at the same QP (benchmark
-                              * GOF: out / in 0.375 instead of 0.338) for less work in the intra stage. rbt_preset_from_name maps the reference's strings. */
+                              * the open-loop decisions only - no SATD block costs, no closed-loop mode choice, fixed rounding: 13 % more bytes at the same QP (benchmark
+                              * GOF: out / in 0.382 instead of 0.338, D1 67.80 instead of 67.88 dB) for less work in the intra stage - which this GPU hides: the rate measured
+                              * the same (757 against 762 point-cloud frames/s), so the fast preset exists for the reference's interface, not for speed.
+                              * rbt_preset_from_name maps the reference's strings. */
 } rbt_stream_params;
 enum { RBT_PRESET_DEFAULT = 0, RBT_PRESET_FAST = 1 };
 
