@@ -145,7 +145,7 @@ typedef struct {
   int hm, hm_pass, in_trial, hm_force_intra;
   const uint8_t* occ4;         /* occupancy of the current picture per 4x4 luma unit (oracle_enc_params.occ4), NULL = every sample counts */
   const uint8_t* hints;        /* intra mode hints of the current picture (oracle_enc_params.hint_modes), NULL = none */
-  int e1_satd, e1_refine, e1_rq;   /* RBT-E1 decision tools (product mode): SATD block costs, closed-loop mode choice, level-dependent rounding */
+  int e1_satd, e1_refine, e1_rq, e1_rdm;   /* RBT-E1 decision tools (product mode): SATD block costs, closed-loop mode choice, level-dependent rounding, coded trial of the two cheapest modes */
   int tu_rd;                   /* transform trees are decided by coding both ways (hm_decide_tu_split): the HM-like mode (two levels) and RBT-E1 intra CUs (one level) */
   struct { long ts, tb4, nxn, cu_intra, cu_inter, cu_skip, tu_split, part2, amp, merge, amvp, frac_mv, nonzero_mv, sao_band, sao_edge, sao_merge, sao_off, intra_in_p; } hs;   /* tool usage (ORACLE_HM_STATS=1 prints it) */
   struct { uint8_t split, intra, part; int16_t mv[2][2]; } hn[4][64];   /* P pictures: decision per CU node [size idx][block] */
@@ -516,17 +516,18 @@ static int hm_tb_finish(enc* e, int c_idx, int log2, int intra_mode, int qp, int
 static int e1_env(const char* n) { const char* v = getenv(n); return !v || atoi(v) != 0; }
 static int e1_satd_on(void) { return e1_env("RBT_ENC_SATD"); }       /* block costs of the intra analysis by SATD instead of SAD */
 static int e1_refine_on(void) { return e1_env("RBT_ENC_REFINE"); }   /* closed-loop choice of the intra mode among the analysis' mode, the most probable modes, planar and DC */
+static int e1_rdm_on(void) { return e1_env("RBT_ENC_RDM"); }         /* the two cheapest candidates of the closed-loop mode choice coded as one transform block each, the cheaper kept */
 static int e1_rq_on(void) { return e1_env("RBT_ENC_RQ"); }           /* rounding offset of the intra quantiser by level and position instead of 171 / 512 */
 /* RBT-E1 quantiser of intra blocks: the dead zone follows what the next level costs. A level that would be the block's only reason to code a position (floor
- * level 0) needs more than 0.63 of a step near the DC corner (x + y <= 2: such positions are usually significant anyway) and more than 0.69 elsewhere;
- * going from 1 to 2 needs 0.61, higher levels 0.55 (their extra bits are few, the distortion saved is not). Offsets in 1/512 of a level: 190, 160, 200,
- * 230; the fixed 171 / 512 (HM's intra default) stays for inter blocks' 85 / 512 and for transform-skip blocks, which have no frequency positions. */
+ * level 0) needs more than 0.65 of a step near the DC corner (x + y <= 2: such positions are usually significant anyway) and more than 0.72 elsewhere;
+ * going from 1 to 2 needs 0.62, higher levels 0.55 (their extra bits are few, the distortion saved is not). Offsets in 1/512 of a level: 180, 145, 195,
+ * 230 (190 / 160 / 200 / 230 before the coded mode trial: what it gained in quality is handed on as bytes, at the PSNR of before); the fixed 171 / 512 (HM's intra default) stays for inter blocks' 85 / 512 and for transform-skip blocks, which have no frequency positions. */
 static int e1_quant_intra(const int16_t* coef, int16_t* lvl, int log2, int qp, int bd) {
   int N = 1 << log2, nz = 0, qbits = 14 + qp / 6 + (15 - bd - log2), sc = k_quant_scale[qp % 6];
   for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) {
     int i = y * N + x, a = iabs(coef[i]);
     int64_t t = (int64_t)a * sc, lf = t >> qbits;
-    int off = lf == 0 ? (x + y <= 2 ? 190 : 160) : (lf == 1 ? 200 : 230);
+    int off = lf == 0 ? (x + y <= 2 ? 180 : 145) : (lf == 1 ? 195 : 230);
     int64_t l = (t + ((int64_t)off << (qbits - 9))) >> qbits;
     if (l > 32767) l = 32767;
     lvl[i] = (int16_t)(coef[i] < 0 ? -l : l); nz += l != 0;
@@ -1309,19 +1310,36 @@ static void hm_write_sao(enc* e, int rx, int ry) {
 /* RBT-E1, closed-loop choice of a CU's luma intra mode: the analysis' mode (chosen open loop, from source neighbours), the three most probable modes
  * (8.4.2: known here, the neighbouring CUs are coded), planar and DC - distinct ones, in that order - predicted from the RECONSTRUCTED neighbours;
  * cost = 16 * SATD + lambda * bits, bits = 2 for the first most probable mode, 3 for the other two, 6 for any other mode; ties keep the earlier candidate */
-static int e1_refine_mode(enc* e, int x0, int y0, int log2, int an_mode) {
+static int e1_refine_mode(enc* e, int x0, int y0, int log2, int an_mode, int* second, int* bits_best, int* bits_second) {
   hevc_meta* m = e->m; int N = 1 << log2, mpm[3], cand[6], nc = 0, lam = k_lambda16[clip3(0, 75, e->slice_qp + 6 * (e->sps.bit_depth - 8))];
   hevc_intra_mpm(m, x0, y0, mpm);
   int pre[6] = {an_mode, mpm[0], mpm[1], mpm[2], 0, 1};
   for (int i = 0; i < 6; i++) { int dup = 0; for (int t = 0; t < nc; t++) dup |= cand[t] == pre[i]; if (!dup) cand[nc++] = pre[i]; }
-  static uint16_t pred[32 * 32]; int best = 0x7FFFFFFF, bm = an_mode;
+  static uint16_t pred[32 * 32]; int best = 0x7FFFFFFF, bm = an_mode, sec = 0x7FFFFFFF, sm = -1, bb = 6, sb = 6;
   const uint16_t* sp = e->src->p[0] + (size_t)y0 * e->src->w + x0;
   for (int i = 0; i < nc; i++) {
     hevc_intra_pred_buf(e->rec, m, 0, x0, y0, log2, cand[i], pred);
-    int c = satd_block(sp, e->src->w, pred, N) * 16 + lam * (cand[i] == mpm[0] ? 2 : (cand[i] == mpm[1] || cand[i] == mpm[2]) ? 3 : 6);
-    if (c < best) { best = c; bm = cand[i]; }
+    int bits = cand[i] == mpm[0] ? 2 : (cand[i] == mpm[1] || cand[i] == mpm[2]) ? 3 : 6;
+    int c = satd_block(sp, e->src->w, pred, N) * 16 + lam * bits;
+    if (c < best) { sec = best; sm = bm; sb = bb; best = c; bm = cand[i]; bb = bits; }     /* the runner-up: the first of the cheapest among the others (for the coded trial) */
+    else if (c < sec) { sec = c; sm = cand[i]; sb = bits; }
   }
+  *second = nc >= 2 ? sm : -1; *bits_best = bb; *bits_second = sb;
   return bm;
+}
+/* RBT-E1, coded trial of a luma mode (round 3): the CU's luma as ONE transform block with this mode, exactly as the transform-unit decision codes it (recon_tb:
+ * occupancy-aware coding included), distortion * 256 + lambda^2 * (level bits + mode bits); picture and levels are put back */
+static int64_t e1_mode_trial(enc* e, int x0, int y0, int log2, int mode, int mode_bits) {
+  hevc_frame* f = e->rec; int N = 1 << log2, ts;
+  static uint16_t save[32 * 32]; static int16_t lsave[32 * 32];
+  e->cu_x = x0; e->cu_y = y0; e->cu_log2 = log2; e->cu_pred_mode = MODE_INTRA; e->cu_part_mode = PART_2Nx2N; e->cu_tq_bypass = 0;
+  for (int y = 0; y < N; y++) { memcpy(save + y * N, f->p[0] + (size_t)(y0 + y) * f->w + x0, (size_t)N * 2); memcpy(lsave + y * N, e->lvl[0] + y * 64, (size_t)N * 2); }
+  e->in_trial = 1;
+  recon_tb(e, 0, x0, y0, log2, mode, &ts);
+  int64_t c = e->last_ssd * 256 + hm_lambda256(e) * (e->last_bits + mode_bits);
+  e->in_trial = 0;
+  for (int y = 0; y < N; y++) { memcpy(f->p[0] + (size_t)(y0 + y) * f->w + x0, save + y * N, (size_t)N * 2); memcpy(e->lvl[0] + y * 64, lsave + y * N, (size_t)N * 2); }
+  return c;
 }
 
 /* ================================================================================================ quadtree */
@@ -1390,7 +1408,12 @@ static void encode_quadtree(enc* e, int x0, int y0, int log2, int depth, int cx,
   } else if (e->sh.slice_type == SLICE_I || e->hm_force_intra) {
     int S = N, nb = (1 << sps->log2_ctb) / S;
     d.intra_luma[0] = e->an_mode[log2 - 3][((y0 - cy) / S) * nb + (x0 - cx) / S];
-    if (e->e1_refine) d.intra_luma[0] = e1_refine_mode(e, x0, y0, log2, d.intra_luma[0]);
+    if (e->e1_refine) {
+      int second, b1, b2;
+      d.intra_luma[0] = e1_refine_mode(e, x0, y0, log2, d.intra_luma[0], &second, &b1, &b2);
+      /* the SATD says which two modes to look at, the coded block which of them to take (ties: the SATD's choice) */
+      if (e->e1_rdm && e->tu_rd && second >= 0) { const int64_t c2 = e1_mode_trial(e, x0, y0, log2, second, b2), c1 = e1_mode_trial(e, x0, y0, log2, d.intra_luma[0], b1); if (c2 < c1) d.intra_luma[0] = second; }
+    }
     if (e->hm) {
       d.intra_chroma_idx = e->hm_chroma[hsi][hbi];
       if (log2 == 3 && e->hm_nxn[hbi]) { d.part_mode = PART_NxN; for (int i = 0; i < 4; i++) d.intra_luma[i] = e->hm_nxn_mode[hbi][i]; }
@@ -1498,7 +1521,7 @@ static void setup_stream(enc* e) {
   if (q->lossless) { p->transquant_bypass_enabled = 1; p->deblocking_control_present = 1; p->pps_deblocking_disabled = 1; p->loop_filter_across_slices = 0; }
   if (!e->stress && !e->hm && !q->lossless && e1_sao_on()) s->sao_enabled = 1;
   e->tu_rd = e->hm;
-  if (!e->stress && !e->hm) { e->e1_satd = e1_satd_on() && !(q->tools_off & 1); e->e1_refine = e1_refine_on() && !(q->tools_off & 2); e->e1_rq = !q->lossless && e1_rq_on() && !(q->tools_off & 4); }
+  if (!e->stress && !e->hm) { e->e1_satd = e1_satd_on() && !(q->tools_off & 1); e->e1_refine = e1_refine_on() && !(q->tools_off & 2); e->e1_rq = !q->lossless && e1_rq_on() && !(q->tools_off & 4); e->e1_rdm = e->e1_refine && !q->lossless && e1_rdm_on() && !(q->tools_off & 16); }
   if (!e->stress && !e->hm && !q->lossless) { s->max_th_depth_intra = 1; e->tu_rd = 1; p->transform_skip_enabled = e1_ts_on(); }
   if (!e->stress && !e->hm && q->lossless) { s->max_th_depth_intra = 1; e->tu_rd = 1; }   /* lossless (occupancy) too: four blocks predict from closer neighbours - 9 % fewer bytes on the benchmark's occupancy maps; distortion is 0 either way, the level bits decide */   /* RBT-E1: an intra CU is one transform unit or four, whichever codes its luma cheaper */
   if (!e->stress && !e->hm && q->ctb_rows_per_slice < 0) { p->entropy_coding_sync = 1; p->dependent_slice_segments_enabled = q->ctb_rows_per_slice == -1; }   /* wavefront rows, one dependent slice segment each */

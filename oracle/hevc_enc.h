@@ -31,7 +31,7 @@ typedef struct {
    * transform-skip decisions and of the SAO statistics. Mode and split decisions look at every sample: the closer the unoccupied area stays to the
    * source's padding, the better the occupied blocks next to it predict (measured: masking them as well costs 35 % more geometry bytes and 0.3 dB D1). */
   const uint8_t* const* occ4; int occ4_w, occ4_h;
-  int tools_off;            /* RBT-E1 decision tools to leave out: 1 SATD block costs, 2 closed-loop mode choice, 4 rounding by level and position (the library's RBT_ET_* bits; oracle_transcode_params.preset) */
+  int tools_off;            /* RBT-E1 decision tools to leave out: 1 SATD block costs, 2 closed-loop mode choice, 4 rounding by level and position, 16 coded trial of the two cheapest modes (the library's RBT_ET_* bits; oracle_transcode_params.preset) */
 } oracle_enc_params;
 
 /* Encodes n frames; appends an Annex-B stream to out. If recon != NULL it receives n newly allocated reconstructed

@@ -238,7 +238,7 @@ static int transcode_substream_occ(const uint8_t* annexb, size_t n, const oracle
   for (int i = 0; i < nf; i++) dec[i] = has_crop(crop) ? frame_crop(oracle_hevc_dec_frame(d, i), crop) : (hevc_frame*)oracle_hevc_dec_frame(d, i);
   const hevc_frame* f0 = dec[0];
   oracle_enc_params ep; memset(&ep, 0, sizeof(ep));
-  ep.bit_depth = f0->bit_depth; ep.qp = p->qp; ep.log2_ctb = p->log2_ctb; ep.ctb_rows_per_slice = p->ctb_rows_per_slice; ep.md5_sei = p->md5_sei; ep.tools_off = p->preset == 1 ? 7 : 0;
+  ep.bit_depth = f0->bit_depth; ep.qp = p->qp; ep.log2_ctb = p->log2_ctb; ep.ctb_rows_per_slice = p->ctb_rows_per_slice; ep.md5_sei = p->md5_sei; ep.tools_off = p->preset == 1 ? 23 : 0;
   hevc_frame** src = (hevc_frame**)calloc((size_t)nf, sizeof(void*));
   int own = 0;
   if (p->video_type == 0) {

@@ -21,7 +21,7 @@ typedef struct {
   int md5_sei;
   int occupancy_rd;           /* geometry / attribute streams handed to oracle_transcode_data behind an occupancy stream: occupancy-aware coding (oracle_enc_params.occ4,
                                  SURVEY.md 8 row F4) with the occupancy map that stream comes out with; ignored by oracle_transcode_substream, which sees one stream */
-  int preset;                 /* 0 = every decision tool of RBT-E1; 1 = "fast": the open-loop decisions only (oracle_enc_params.tools_off = 7); the library's rbt_stream_params.preset */
+  int preset;                 /* 0 = every decision tool of RBT-E1; 1 = "fast": the open-loop decisions only (oracle_enc_params.tools_off = 23); the library's rbt_stream_params.preset */
 } oracle_transcode_params;
 
 /* PCCVideoBitstream::sampleStreamToByteStream / byteStreamToSampleStream (PCCVideoBitstream.cpp:85-172), HEVC case,

@@ -98,7 +98,7 @@ RBT_DEV int en_occ_unit_value(const uint16_t* occ, int ow, int oh, int s, int w4
   return any;
 }
 // rounding offset of the intra quantiser in 1/512 of a level (oracle/hevc_enc.c e1_quant_intra): by the level below and, for a first level, the position
-RBT_DEV int en_rq_offset(int lf_is0, int lf_is1, int xy_sum) { return lf_is0 ? (xy_sum <= 2 ? 190 : 160) : (lf_is1 ? 200 : 230); }
+RBT_DEV int en_rq_offset(int lf_is0, int lf_is1, int xy_sum) { return lf_is0 ? (xy_sum <= 2 ? 180 : 145) : (lf_is1 ? 195 : 230); }
 RBT_DEV int en_chroma_qp(const RbtFrame* f, const RbtSlice* sl, int c_idx, int qp_y) {
   int off = c_idx == 1 ? f->cfg.cb_qp_offset + sl->cb_qp_offset : f->cfg.cr_qp_offset + sl->cr_qp_offset;
   int bdo = 6 * (f->cfg.bit_depth - 8);
@@ -568,7 +568,8 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
 // most probable modes (8.4.2: ca / cb = candIntraPredModeA / B, the modes of the coded CUs to the left and above, DC where there is none in reach), planar
 // and DC - distinct ones, in that order - predicted from the RECONSTRUCTED neighbours in the tile; cost = 16 * SATD + lambda * bits (2 for the first most
 // probable mode, 3 for the other two, 6 otherwise), ties keep the earlier candidate. src: the CU's source samples, row stride N.
-template <int TL2> RBT_DEV int en_refine_mode(const RbtStreamCfg* g, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int x0, int y0, int lg, int an_mode, int ca, int cb, int lam16, const RBT_LDS_AS uint16_t* src) {
+// *second: the runner-up (the first of the cheapest among the other candidates; -1 if there is only one), *bits_best / *bits_second: their mode bits - for the coded trial
+template <int TL2> RBT_DEV int en_refine_mode(const RbtStreamCfg* g, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int x0, int y0, int lg, int an_mode, int ca, int cb, int lam16, const RBT_LDS_AS uint16_t* src, int* second, int* bits_best, int* bits_second) {
   RBT_LDS_AS RbtEncIntraScratch* r = &L->rc; RBT_LDS_AS RbtEncTileT<TL2>* t = &L->t;
   RBT_LDS_AS int32_t* const r_nbf = (RBT_LDS_AS int32_t*)r->tmp; RBT_LDS_AS int32_t* const r_ref = r_nbf + 132;
   const int N = 1 << lg, bd = g->bit_depth, n4 = (1 << g->log2_ctb) >> 2, S = RbtEncTileT<TL2>::TS_Y;
@@ -593,7 +594,7 @@ template <int TL2> RBT_DEV int en_refine_mode(const RbtStreamCfg* g, RBT_LDS_AS 
   }
   RBT_SYNC_LDS();
   rc_intra_filter_apply(g, lg, r->nb, r_nbf);
-  int best = 0x7FFFFFFF, bm = an_mode; const int tw = N >> 3;
+  int best = 0x7FFFFFFF, bm = an_mode, sec = 0x7FFFFFFF, sm = -1, bb = 6, sb = 6; const int tw = N >> 3;
   for (int k = 0; k < nc; k++) {
     const int mode = (int)((cand >> (6 * k)) & 63);
     RBT_LDS_AS int32_t* fin = rc_intra_filter_needed(0, lg, mode) ? r_nbf : r->nb;
@@ -605,10 +606,13 @@ template <int TL2> RBT_DEV int en_refine_mode(const RbtStreamCfg* g, RBT_LDS_AS 
       RBT_VFOR(p, 64) { const int x = tx + (p & 7), y = ty + (p >> 3); RBT_V(v_r, p) = (int)src[y * N + x] - rc_intra_sample(&q, fin, r_ref, x, y); }
       EN_HAD8X8_ACC(v_r, acc);
     }
-    const int c = ((en_wave_sum(acc, (RBT_LDS_AS RbtEncLds*)0) + 4) >> 3) * 16 + lam16 * (mode == m0 ? 2 : (mode == m1 || mode == m2) ? 3 : 6);
-    if (c < best) { best = c; bm = mode; }
+    const int bits = mode == m0 ? 2 : (mode == m1 || mode == m2) ? 3 : 6;
+    const int c = ((en_wave_sum(acc, (RBT_LDS_AS RbtEncLds*)0) + 4) >> 3) * 16 + lam16 * bits;
+    if (c < best) { sec = best; sm = bm; sb = bb; best = c; bm = mode; bb = bits; }
+    else if (c < sec) { sec = c; sm = mode; sb = bits; }
     RBT_SYNC_LDS();                                     // r_ref is rebuilt by the next candidate
   }
+  *second = nc >= 2 ? sm : -1; *bits_best = bb; *bits_second = sb;
   return bm;
 }
 // Luma of one intra CU of a stream with max_transform_hierarchy_depth_intra = 1 (RBT-E1, not lossless): coded as one transform block, then as four
@@ -617,12 +621,14 @@ template <int TL2> RBT_DEV int en_refine_mode(const RbtStreamCfg* g, RBT_LDS_AS 
 // hm_decide_tu_split: luma only, distortion * 256 + lambda^2 * rate, 3 lambda^2 for the split). Returns the luma cbf of the CU, or with *split = 1 the
 // cbf of quarter i in bit i. On return the tile holds the chosen reconstruction, the coefficient plane the chosen levels and every 4x4 unit of the CU
 // is marked available.
-template <int TL2> RBT_DEV int en_intra_cu_luma(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int x0, int y0, int gx, int gy, int lg, int mode, int qp, int lam2, int* split, int* ts_bits) {
+// have_whole: the coded mode trial has just coded the CU as one block with this mode (levels in lv0, reconstruction in the tile, cost / distortion / cbf handed in)
+template <int TL2> RBT_DEV int en_intra_cu_luma(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int x0, int y0, int gx, int gy, int lg, int mode, int qp, int lam2, int* split, int* ts_bits,
+                                              int have_whole = 0, long long c_whole_in = 0, int ssd0_in = 0, int cbf0_in = 0) {
   RBT_LDS_AS RbtEncTileT<TL2>* t = &L->t;
   const int N = 1 << lg, h = N >> 1, S = RbtEncTileT<TL2>::TS_Y;
-  long long c_whole = 0, c_split = 3ll * lam2, cq = 0;
-  int ssd0 = 0;
-  const int cbf0 = en_tile_intra_tb(g, f, L, 0, x0, y0, gx, gy, lg, mode, qp, t->sb, -1, 0, 0, t->lv0, &c_whole, lam2, &ssd0);
+  long long c_whole = c_whole_in, c_split = 3ll * lam2, cq = 0;
+  int ssd0 = ssd0_in, cbf0 = cbf0_in;
+  if (!have_whole) cbf0 = en_tile_intra_tb(g, f, L, 0, x0, y0, gx, gy, lg, mode, qp, t->sb, -1, 0, 0, t->lv0, &c_whole, lam2, &ssd0);
   *split = 0; *ts_bits = 0;
   if (!f->lossless && (long long)ssd0 * 256 < (long long)(lam2 >> 2) * N * N) {     // coded to within lambda^2 / 4 per sample by one transform: not tried as four (lossless: the bits alone decide)
     RBT_PAR_FOR(i, 1 << (2 * (lg - 2))) t->uav[((y0 >> 2) + (i >> (lg - 2)) + 1) * RC_US + (x0 >> 2) + (i & ((1 << (lg - 2)) - 1)) + 1] = 1;
@@ -781,7 +787,7 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
     t->uav[i] = (uint8_t)a;
   }
   if (f->occ4 != nullptr) { RBT_PAR_FOR(i, n4 * n4) t->occ_u[i] = (uint8_t)en_occ_unit(f, (cx >> 2) + i % n4, (cy >> 2) + i / n4); }
-  const int refine = f->enc_tools & RBT_ET_REFINE;
+  const int refine = f->enc_tools & RBT_ET_REFINE, rdm = refine && tu_rd && !f->lossless && (f->enc_tools & RBT_ET_RDM);
   if (refine) {
     // modes of the CUs along the left border (candIntraPredModeA of this CTB's first column): carried in LDS when this wave has just coded that CTB
     const int left_ok = rx > 0 && f->ctb_slice[ctb_addr - 1] == f->ctb_slice[ctb_addr];
@@ -810,15 +816,25 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
     { const uint16_t* sp = f->src[0] + (size_t)(cy + y0) * g->w + cx + x0; RBT_PAR_FOR(i, N * N) t->sb[i] = sp[(size_t)(i >> lg) * g->w + (i & (N - 1))]; }
     for (int q = 0; q < 2; q++) { const uint16_t* sp = f->src[1 + q] + (size_t)((cy + y0) >> 1) * g->cw + ((cx + x0) >> 1); RBT_PAR_FOR(i, Nc * Nc) t->sb[1024 + 256 * q + i] = sp[(size_t)(i >> (lg - 1)) * g->cw + (i & (Nc - 1))]; }
     RBT_SYNC();
+    int have_w = 0, ssd_w = 0, cbf_w = 0; long long c_w = 0;
     if (refine) {
       const int ca = x0 > 0 ? (int)t->cu_md[uy * 8 + ux - 1] : (t->left_md[8] ? (int)t->left_md[uy] : 1), cb = y0 > 0 ? (int)t->cu_md[(uy - 1) * 8 + ux] : 1;   // above: inside this CTB only (8.4.2)
-      mode = en_refine_mode<TL2>(g, L, x0, y0, lg, mode, RBT_UNI(ca), RBT_UNI(cb), lam16, t->sb);
+      int second, b1, b2;
+      mode = en_refine_mode<TL2>(g, L, x0, y0, lg, mode, RBT_UNI(ca), RBT_UNI(cb), lam16, t->sb, &second, &b1, &b2);
+      if (rdm && second >= 0) {
+        // the SATD says which two modes to look at, the coded block which of them to take (oracle/hevc_enc.c e1_mode_trial; ties: the SATD's choice). The runner-up first:
+        // when the SATD's choice stands - most of the time - its block is already coded and en_intra_cu_luma goes straight on to the four-way form
+        long long c2 = 0;
+        en_tile_intra_tb(g, f, L, 0, x0, y0, cx + x0, cy + y0, lg, second, qp_l, t->sb, -1, 0, 0, t->lv0, &c2, lam2);
+        cbf_w = en_tile_intra_tb(g, f, L, 0, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, t->sb, -1, 0, 0, t->lv0, &c_w, lam2, &ssd_w);
+        if (c2 + (long long)lam2 * b2 < c_w + (long long)lam2 * b1) mode = second; else have_w = 1;
+      }
       const int nu = N >> 3;
       RBT_PAR_FOR(i, nu * nu) { const int vx = ux + i % nu, vy = uy + i / nu; t->cu_md[vy * 8 + vx] = (uint8_t)mode; f->cu_mode[(((cy + y0) >> 3) + i / nu) * f->w8 + ((cx + x0) >> 3) + i % nu] = (uint8_t)mode; }
       RBT_SYNC_LDS();
     }
     int split = 0, cbf = 0, cy4 = 0, ts_bits = 0;
-    if (tu_rd) cy4 = en_intra_cu_luma(g, f, L, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, lam2, &split, &ts_bits);
+    if (tu_rd) cy4 = en_intra_cu_luma(g, f, L, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, lam2, &split, &ts_bits, have_w, c_w, ssd_w, cbf_w);
     else cy4 = en_tile_intra_tb(g, f, L, 0, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, t->sb, lg - 2, x0 >> 2, y0 >> 2);
     if (split && lg >= 4) {
       // four transform units, each with its own Cb / Cr blocks: chroma block b is predicted when the units 0..b of the CU are reconstructed, not more

@@ -46,11 +46,11 @@ struct EncodeBatch {
 // ... and transform skip for the 4x4 luma blocks unless RBT_ENC_TS=0
 static int e1_ts_on() { static int v = -1; if (v < 0) { const char* e = getenv("RBT_ENC_TS"); v = !e || atoi(e) != 0; } return v; }
 static int e1_sao_on() { static int v = -1; if (v < 0) { const char* e = getenv("RBT_ENC_SAO"); v = !e || atoi(e) != 0; } return v; }
-// ... and the decision tools of round 3 (RBT_ET_*): SATD block costs, closed-loop mode choice, level-dependent rounding unless RBT_ENC_SATD / _REFINE / _RQ = 0
+// ... and the decision tools of round 3 (RBT_ET_*): SATD block costs, closed-loop mode choice, level-dependent rounding, coded mode trial unless RBT_ENC_SATD / _REFINE / _RQ / _RDM = 0
 static int e1_tools(int lossless) {
   static int v = -1;
-  if (v < 0) { auto on = [](const char* n) { const char* e = getenv(n); return !e || atoi(e) != 0; }; v = (on("RBT_ENC_SATD") ? RBT_ET_SATD : 0) | (on("RBT_ENC_REFINE") ? RBT_ET_REFINE : 0) | (on("RBT_ENC_RQ") ? RBT_ET_RQ : 0); }
-  return lossless ? v & ~RBT_ET_RQ : v;
+  if (v < 0) { auto on = [](const char* n) { const char* e = getenv(n); return !e || atoi(e) != 0; }; v = (on("RBT_ENC_SATD") ? RBT_ET_SATD : 0) | (on("RBT_ENC_REFINE") ? RBT_ET_REFINE : 0) | (on("RBT_ENC_RQ") ? RBT_ET_RQ : 0) | (on("RBT_ENC_RDM") ? RBT_ET_RDM : 0); }
+  return lossless ? v & ~(RBT_ET_RQ | RBT_ET_RDM) : v;
 }
 // Every picture takes the in-place deblocking launches before the SAO kernel; RBT_FUSED_ENC_LF=1 deblocks inside the SAO kernel instead (en_sao_ctb: the CTB and its halo
 // in LDS; same samples, ~2 GB less HBM traffic per GOF). Off by default: the driver's 20-GOF run is 3 % slower with it, 5 % with the decoder's fused form as well
@@ -332,7 +332,7 @@ static int setup_encode(DecodeBatch& db, int si, int ei, const rbt_stream_params
   const int cl = 2 * isps.conf_win[0], ct = 2 * isps.conf_win[2], dw = c.w - cl - 2 * isps.conf_win[1], dh = c.h - ct - 2 * isps.conf_win[3];
   if (dw <= 0 || dh <= 0) { err = "empty conformance window"; return RBT_ERR_BITSTREAM; }
   if (p.preset != RBT_PRESET_DEFAULT && p.preset != RBT_PRESET_FAST) { err = "preset must be RBT_PRESET_DEFAULT or RBT_PRESET_FAST"; return RBT_ERR_PARAM; }
-  d.bd = c.bit_depth; d.n_frames = cnt; d.qp = p.qp; d.log2_ctb = p.log2_ctb; d.rows = p.ctb_rows_per_slice; d.md5 = p.md5_sei; d.tools_off = p.preset == RBT_PRESET_FAST ? (RBT_ET_SATD | RBT_ET_REFINE | RBT_ET_RQ) : 0;
+  d.bd = c.bit_depth; d.n_frames = cnt; d.qp = p.qp; d.log2_ctb = p.log2_ctb; d.rows = p.ctb_rows_per_slice; d.md5 = p.md5_sei; d.tools_off = p.preset == RBT_PRESET_FAST ? (RBT_ET_SATD | RBT_ET_REFINE | RBT_ET_RQ | RBT_ET_RDM) : 0;
   for (int k = 0; k < 3; k++) d.src[k].resize(cnt);
   auto view = [&](int k, int q) { return (const uint16_t*)db.frames[first + k].out[q]; };
   if (p.video_type == RBT_VIDEO_OCCUPANCY) {
