@@ -1411,8 +1411,9 @@ static void encode_quadtree(enc* e, int x0, int y0, int log2, int depth, int cx,
     if (e->e1_refine) {
       int second, b1, b2;
       d.intra_luma[0] = e1_refine_mode(e, x0, y0, log2, d.intra_luma[0], &second, &b1, &b2);
-      /* the SATD says which two modes to look at, the coded block which of them to take (ties: the SATD's choice) */
-      if (e->e1_rdm && e->tu_rd && second >= 0) { const int64_t c2 = e1_mode_trial(e, x0, y0, log2, second, b2), c1 = e1_mode_trial(e, x0, y0, log2, d.intra_luma[0], b1); if (c2 < c1) d.intra_luma[0] = second; }
+      /* the SATD says which two modes to look at, the coded block which of them to take (ties: the SATD's choice). CUs of 16x16 and 32x32 only: on 8x8 CUs - more than
+       * half of all CUs - the trial moved nothing (lab: 0.3157 against 0.3156 out / in at the same PSNR) */
+      if (e->e1_rdm && e->tu_rd && second >= 0 && log2 >= 4) { const int64_t c2 = e1_mode_trial(e, x0, y0, log2, second, b2), c1 = e1_mode_trial(e, x0, y0, log2, d.intra_luma[0], b1); if (c2 < c1) d.intra_luma[0] = second; }
     }
     if (e->hm) {
       d.intra_chroma_idx = e->hm_chroma[hsi][hbi];

@@ -821,8 +821,9 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
       const int ca = x0 > 0 ? (int)t->cu_md[uy * 8 + ux - 1] : (t->left_md[8] ? (int)t->left_md[uy] : 1), cb = y0 > 0 ? (int)t->cu_md[(uy - 1) * 8 + ux] : 1;   // above: inside this CTB only (8.4.2)
       int second, b1, b2;
       mode = en_refine_mode<TL2>(g, L, x0, y0, lg, mode, RBT_UNI(ca), RBT_UNI(cb), lam16, t->sb, &second, &b1, &b2);
-      if (rdm && second >= 0) {
-        // the SATD says which two modes to look at, the coded block which of them to take (oracle/hevc_enc.c e1_mode_trial; ties: the SATD's choice). The runner-up first:
+      if (rdm && second >= 0 && lg >= 4) {
+        // the SATD says which two modes to look at, the coded block which of them to take (oracle/hevc_enc.c e1_mode_trial; ties: the SATD's choice; 16x16 and 32x32 CUs
+        // only: on 8x8 CUs, more than half of all, the trial moved nothing). The runner-up first:
         // when the SATD's choice stands - most of the time - its block is already coded and en_intra_cu_luma goes straight on to the four-way form
         long long c2 = 0;
         en_tile_intra_tb(g, f, L, 0, x0, y0, cx + x0, cy + y0, lg, second, qp_l, t->sb, -1, 0, 0, t->lv0, &c2, lam2);
