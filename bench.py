@@ -381,6 +381,7 @@ def main():
     # informative extra (not the headline): G GOFs handed over in one call. One GOF's critical path is a few hundred serial
     # waves, so the GPU has room for several at once; a sequence of GOFs (configs[3]) can use that inside each GPU.
     multi = None
+    ctx.trim()
     if world == 1 and args.multi_gof > 1:
         MG = args.multi_gof
         ms, mp = [bytes(bytearray(s_)) for _ in range(MG) for s_ in streams], params * MG     # distinct buffers: identical ones would be decoded once
@@ -393,6 +394,7 @@ def main():
 
     # informative extra: the same loop with ONE GOF per job at every depth (D = 1 is the blocking call: its ms_per_gof is the latency of one GOF)
     sweep = None
+    ctx.trim()
     if world == 1 and args.sweep > 1:
         sweep = []
         for d in (1, 2, 4, 8, 16):
@@ -406,6 +408,7 @@ def main():
         ctx.set_depth(D)
     # the headline of a short run (the driver's --steps 20) is all ramp-up and drain: the steady state of a long walk beside it (the same job shape rule as a 256-step run)
     steady = None
+    ctx.trim()
     if world == 1 and args.steady_steps > 0 and args.steps < args.steady_steps:
         g_s = gs.job_shape(args.steady_steps)[0]; d_s = max(1, min(args.in_flight, 16, (args.steady_steps + g_s - 1) // g_s))
         ctx.set_depth(d_s)
@@ -417,6 +420,7 @@ def main():
     # informative: what the re-encode did to the pictures (luma PSNR of the R3 output's pictures against the R5 input's,
     # both decoded by this library), and that the occupancy output is exactly the 2x2 OR-pool of the input occupancy
     quality = None
+    ctx.trim()        # every leg above ran another job shape and left its arenas cached
     if rank == 0 and world == 1 and args.quality:
         def psnr_y(a_stream, b_stream, ww, hh, peak):
             da, db = ctx.decode(a_stream)[0], ctx.decode(b_stream)[0]

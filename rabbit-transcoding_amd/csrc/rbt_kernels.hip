@@ -83,6 +83,7 @@ void stream_wait(int waiter, int signaller) {
 // Device allocations are recycled: hipMalloc / hipFree of GOF-sized arenas cost milliseconds each (hipFree also drains the
 // device), and a transcoder calls with the same sizes over and over. Freed blocks go to a small best-fit pool; at most
 // RBT_POOL_KEEP blocks are kept, the rest is returned to the driver.
+#define RBT_HBM_RESERVE ((size_t)8 << 30)
 void* dev_alloc(size_t n) {
   if (!n) n = 1;
   Dev* D = t_dev; if (!D) return nullptr;
@@ -94,6 +95,17 @@ void* dev_alloc(size_t n) {
   if (best >= 0) { b = D->pool_free[(size_t)best]; D->pool_free.erase(D->pool_free.begin() + best); }
   else {
     b.p = nullptr; b.n = n;
+    // Arenas must not take the last of the HBM: the runtime allocates too (scratch memory of a queue the first time a kernel with a private segment runs on it, ~27 MB per
+    // queue and kernel variant), and when IT finds nothing left the process is aborted (HSA_STATUS_ERROR_OUT_OF_RESOURCES - seen in round 3 with ~280 GB of cached arenas of
+    // five job shapes). A new arena therefore leaves RBT_HBM_RESERVE free: cached blocks go back to the driver first, and if that is not enough the call fails (RBT_ERR_NOMEM).
+    if (n >= ((size_t)64 << 20)) {
+      size_t fr = 0, tot = 0;
+      if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr < n + RBT_HBM_RESERVE) {
+        for (auto& f : D->pool_free) (void)hipFree(f.p);
+        D->pool_free.clear();
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr < n + RBT_HBM_RESERVE) return nullptr;
+      }
+    }
     if (hipMalloc(&b.p, n) != hipSuccess) {
       (void)hipGetLastError();                                        // the failed allocation is handled here: it must not surface later as a "kernel" error
       for (auto& f : D->pool_free) (void)hipFree(f.p);                 // give everything back and try once more
