@@ -513,7 +513,7 @@ def main():
             occ_rd["value"] = round(n_pc * k_on / dt, 2); occ_rd["unit"] = "point-cloud frames/s"; occ_rd["steps"] = k_on
         except Exception as e:   # informative leg: never lose the benchmark line over it
             occ_rd = {"error": str(e)}
-        # RBT_PRESET_FAST (rbt_stream_params.preset: what the reference's x265 preset strings "ultrafast".."fast" select): the open-loop decisions only
+        # RBT_PRESET_FAST (rbt_stream_params.preset: what the reference's x265 preset strings "ultrafast" / "superfast" select): the open-loop decisions only
         preset_fast = None
         try:
             p_fast = [P(q.video_type, q.qp, q.occupancy_precision, q.log2_ctb, q.ctb_rows_per_slice, 0, 0, 0, R.RBT_PRESET_FAST) for q in params]

@@ -51,15 +51,15 @@ typedef struct {
                               * (occupancy_precision 4): occupancy-aware coding (what dependencies/hm-modification/HM-16.20+SCM-8.8_with_RDO.patch does to
                               * HM's distortion, TComRdCost.cpp xGetSSE*). The occupancy map the output carries tells which 4x4 units the decoder makes points of; with one unit
                               * of margin around them, transform blocks outside carry no residual, partly occupied blocks code what their occupied samples ask for, and the
-                              * unoccupied samples stay out of the encoder's distortion terms. Measured on the benchmark GOF at R3: 62 % fewer geometry and 29 % fewer
-                              * attribute bytes, D1 -0.02 dB, attribute PSNR of the occupied samples unchanged. The pictures outside the occupied area are then whatever
+                              * unoccupied samples stay out of the encoder's distortion terms. Measured on the benchmark GOF at R3: 67 % fewer geometry and 30 % fewer
+                              * attribute bytes, D1 -0.05 dB (frame 0; -0.08 dB over four frames), PSNR of the occupied samples -0.04 / -0.02 dB. The pictures outside the occupied area are then whatever
                               * prediction leaves there. Entries come GOF by GOF, occupancy first; ignored where the call holds no such occupancy stream, by
                               * rbt_transcode_substream (one stream) and for lossless streams; not together with verify_md5 (RBT_ERR_PARAM). 0 = off: every sample counts. */
   int preset;                /* RBT_PRESET_*: what the reference's `preset` (PCCTranscoderParameters.h:58, handed to libx265 at PCCTranscoder.cpp:877,883) selects here.
-                              * RBT_PRESET_DEFAULT (0, x265 "medium" and slower): every decision tool of RBT-E1. RBT_PRESET_FAST (1, "ultrafast" .. "fast"):
-                              * the open-loop decisions only - no SATD block costs, no closed-loop mode choice, fixed rounding: 13 % more bytes at the same QP (benchmark
-                              * GOF: out / in 0.382 instead of 0.338, D1 67.80 instead of 67.88 dB) for less work in the intra stage - which this GPU hides: the rate measured
-                              * the same (757 against 762 point-cloud frames/s), so the fast preset exists for the reference's interface, not for speed.
+                              * RBT_PRESET_DEFAULT (0, x265 "veryfast" and slower): every decision tool of RBT-E1. RBT_PRESET_FAST (1, "ultrafast", "superfast"):
+                              * the open-loop decisions only - no SATD block costs, no closed-loop mode choice, no coded mode trial, fixed rounding: 16 % more bytes at the same
+                              * QP (benchmark GOF: out / in 0.382 instead of 0.329, D1 67.80 instead of 67.94 dB), 5 % faster (759 against 721 point-cloud frames/s for a
+                              * 20-GOF run).
                               * rbt_preset_from_name maps the reference's strings. */
 } rbt_stream_params;
 enum { RBT_PRESET_DEFAULT = 0, RBT_PRESET_FAST = 1 };
@@ -125,8 +125,9 @@ int rbt_get_depth(rbt_ctx* ctx);   /* the announced depth (> 0) or RBT_ERR_PARAM
 /* How to cut a walk of n_gofs GOFs into jobs on one GPU, as measured: 16 jobs of 2 GOFs for a long walk; a walk shorter than 48 GOFs is all ramp-up and
  * drain and does better as at most 7 jobs (2 jobs up to 12 GOFs) of ceil(n / jobs) GOFs, which then own several hardware queues each. max_jobs caps the jobs in flight. */
 int rbt_job_shape(int n_gofs, int max_jobs, int* gofs_per_job, int* jobs_in_flight);
-/* The reference's `preset` string (an x265 preset name, PCCTranscoderParameters.h:58) as RBT_PRESET_*: "ultrafast", "superfast", "veryfast", "faster", "fast" ->
- * RBT_PRESET_FAST; "medium", "slow", "slower", "veryslow", "placebo" and NULL / "" -> RBT_PRESET_DEFAULT; anything else -> RBT_ERR_PARAM. */
+/* The reference's `preset` string (an x265 preset name, PCCTranscoderParameters.h:58) as RBT_PRESET_*: "ultrafast", "superfast" -> RBT_PRESET_FAST; "veryfast"
+ * (what the reference's scripts pass, transcode.sh:18), "faster", "fast", "medium", "slow", "slower", "veryslow", "placebo" and NULL / "" -> RBT_PRESET_DEFAULT (even x265's
+ * "veryfast" decides by rate-distortion cost, which RBT_PRESET_FAST does not); anything else -> RBT_ERR_PARAM. */
 int rbt_preset_from_name(const char* name);
 int rbt_submit_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, rbt_job** job);
 int rbt_wait_gof(rbt_ctx* ctx, rbt_job* job, uint8_t** annexb_out, size_t* n_out);

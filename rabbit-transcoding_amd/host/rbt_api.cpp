@@ -181,8 +181,8 @@ int rbt_job_shape(int n_gofs, int max_jobs, int* gofs_per_job, int* jobs_in_flig
 } RBT_CATCH
 int rbt_preset_from_name(const char* name) try {
   if (!name || !*name) return RBT_PRESET_DEFAULT;
-  for (const char* f : {"ultrafast", "superfast", "veryfast", "faster", "fast"}) if (!strcmp(name, f)) return RBT_PRESET_FAST;
-  for (const char* d : {"medium", "slow", "slower", "veryslow", "placebo"}) if (!strcmp(name, d)) return RBT_PRESET_DEFAULT;
+  for (const char* f : {"ultrafast", "superfast"}) if (!strcmp(name, f)) return RBT_PRESET_FAST;
+  for (const char* d : {"veryfast", "faster", "fast", "medium", "slow", "slower", "veryslow", "placebo"}) if (!strcmp(name, d)) return RBT_PRESET_DEFAULT;
   return RBT_ERR_PARAM;
 } RBT_CATCH
 int rbt_trim(rbt_ctx* ctx) try {
