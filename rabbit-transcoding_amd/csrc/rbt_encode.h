@@ -543,10 +543,12 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
       RBT_SYNC_LDS();
     }
   }
-  { int16_t* cp = f->coef[c_idx] + (size_t)gy * pw + gx; RBT_PAR_FOR(i, N * N) cp[(size_t)(i >> log2) * pw + (i & (N - 1))] = lvl[i]; }
-  RBT_PAR_FOR(i, N * N) {
-    const int x = i & (N - 1), y = i >> log2;
-    tile[(y0 + y) * S + x0 + x + 1] = (uint16_t)(nz ? rbt_clip3(0, maxv, (int)r->pred[i] + r->res[i]) : r->pred[i]);
+  if (mark_l4 != -2) {                                  // -2: a trial whose block is coded again, or replaced, before anything reads it (the coded mode trial's runner-up): only its cost
+    { int16_t* cp = f->coef[c_idx] + (size_t)gy * pw + gx; RBT_PAR_FOR(i, N * N) cp[(size_t)(i >> log2) * pw + (i & (N - 1))] = lvl[i]; }
+    RBT_PAR_FOR(i, N * N) {
+      const int x = i & (N - 1), y = i >> log2;
+      tile[(y0 + y) * S + x0 + x + 1] = (uint16_t)(nz ? rbt_clip3(0, maxv, (int)r->pred[i] + r->res[i]) : r->pred[i]);
+    }
   }
   if (mark_l4 >= 0) { RBT_PAR_FOR(i, 1 << (2 * mark_l4)) t->uav[(muy + (i >> mark_l4) + 1) * RC_US + mux + (i & ((1 << mark_l4) - 1)) + 1] = 1; }
   if (cost) {
@@ -826,7 +828,7 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
         // only: on 8x8 CUs, more than half of all, the trial moved nothing). The runner-up first:
         // when the SATD's choice stands - most of the time - its block is already coded and en_intra_cu_luma goes straight on to the four-way form
         long long c2 = 0;
-        en_tile_intra_tb(g, f, L, 0, x0, y0, cx + x0, cy + y0, lg, second, qp_l, t->sb, -1, 0, 0, t->lv0, &c2, lam2);
+        en_tile_intra_tb(g, f, L, 0, x0, y0, cx + x0, cy + y0, lg, second, qp_l, t->sb, -2, 0, 0, t->lv0, &c2, lam2);
         cbf_w = en_tile_intra_tb(g, f, L, 0, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, t->sb, -1, 0, 0, t->lv0, &c_w, lam2, &ssd_w);
         if (c2 + (long long)lam2 * b2 < c_w + (long long)lam2 * b1) mode = second; else have_w = 1;
       }
