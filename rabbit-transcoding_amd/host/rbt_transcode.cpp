@@ -514,9 +514,19 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
     for (int q = k; q < ng; q++) { const int gi = order[q]; if (j.phys[gi] == j.phys[lead] && chained[gi] && !db[gi].ordered_parse && !db[gi].d_save) grp.push_back(gi); }
     if (grp.size() < 2 || grp[0] != lead) continue;
     j.tasks_keep.emplace_back(); std::vector<RbtParseTask>& tasks = j.tasks_keep.back(); int mw4 = 0;
+    std::vector<uint32_t> task_bytes; bool any_row_tasks = false;
     for (int gi : grp) {
-      for (size_t i = 0; i < db[gi].slices.size(); i++) tasks.push_back(RbtParseTask{db[gi].d_frames, db[gi].d_slices, db[gi].d_rbsp, db[gi].lists_keep[i], 0});
-      mw4 = std::max(mw4, decode_max_w4(db[gi])); db[gi].parse_external = true; j.parse_timed[gi] = gi == lead;
+      for (size_t i = 0; i < db[gi].slices.size(); i++) { tasks.push_back(RbtParseTask{db[gi].d_frames, db[gi].d_slices, db[gi].d_rbsp, db[gi].lists_keep[i], 0}); task_bytes.push_back(db[gi].slices[(size_t)db[gi].lists_keep[i]].data_size); }
+      mw4 = std::max(mw4, decode_max_w4(db[gi])); db[gi].parse_external = true; j.parse_timed[gi] = gi == lead; any_row_tasks |= db[gi].has_row_tasks;
+    }
+    // Longest first: a launch's waves start in list order, and when more slices are in flight than the GPU holds waves (several jobs' launches side by side) the ones that
+    // wait should be the short ones - the launch lasts as long as its largest slice (an attribute IDR) however late that one starts. Not for lists with row tasks of
+    // wavefront streams: there a task must come after the task of the row above it.
+    if (!any_row_tasks) {
+      std::vector<size_t> ord(tasks.size()); for (size_t i = 0; i < ord.size(); i++) ord[i] = i;
+      std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return task_bytes[a] > task_bytes[b]; });
+      std::vector<RbtParseTask> sorted; sorted.reserve(tasks.size()); for (size_t i : ord) sorted.push_back(tasks[i]);
+      tasks.swap(sorted);
     }
     // ... and the pictures of one dependency level of all of them go on one wavefront (58 launches per level instead of 58
     // per level and pipeline, one after the other)
