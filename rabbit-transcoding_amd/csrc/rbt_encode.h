@@ -1243,8 +1243,10 @@ struct RbtSaoLds { int32_t bcnt[8][32], bsum[8][32]; int32_t ecnt[16], esum[16];
 // with the 64x64 size for every stream a wave held 18.6 KB and two waves fitted a SIMD, which cost more than the fusion saved (k_enc_sao 3.8 -> 35 ms per launch under load)
 template <int TL2> struct RbtSaoRegionT { uint16_t ry[((1 << TL2) + 8) * ((1 << TL2) + 8)]; uint16_t rc[2][((1 << TL2) / 2 + 4) * ((1 << TL2) / 2 + 4)]; };
 RBT_DEV int en_sao_round_div(int sum, int cnt) { return cnt ? (sum >= 0 ? sum + cnt / 2 : sum - cnt / 2) / cnt : 0; }
-// ry / rc0 / rc1: the region of RbtSaoRegionT (rows of ctb + 8 luma, ctb / 2 + 4 chroma samples)
-RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtSaoLds* L, RBT_LDS_AS uint16_t* ry, RBT_LDS_AS uint16_t* rc0, RBT_LDS_AS uint16_t* rc1) {
+// REGION (RBT_FUSED_ENC_LF=1): the CTB is deblocked here, in LDS - ry / rc0 / rc1: the region of RbtSaoRegionT (rows of ctb + 8 luma, ctb / 2 + 4 chroma samples). Otherwise (the
+// default) the picture was deblocked in place by k_deblock and the samples are read where they lie (neighbours of a sample come from L2): a third less instructions than
+// staging the region, and no LDS beyond the statistics
+template <bool REGION> RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtSaoLds* L, RBT_LDS_AS uint16_t* ry, RBT_LDS_AS uint16_t* rc0, RBT_LDS_AS uint16_t* rc1) {
   const RbtStreamCfg gcopy = f->cfg; const RbtStreamCfg* g = &gcopy;
   const int ctb = 1 << g->log2_ctb, cxi = ctb_addr % g->w_ctb, cyi = ctb_addr / g->w_ctb, bd = g->bit_depth;
   const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
@@ -1259,30 +1261,32 @@ RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_L
   }
   // ---- the CTB's reconstruction + halo into LDS, deblocked there: vertical edges, then horizontal ones (8.7.2; see rbt_loopfilter_tile for why a halo of 4 is exact)
   const int lx0 = cxi * ctb, ly0 = cyi * ctb, ox = lx0 - 4, oy = ly0 - 4, cox = lx0 / 2 - 2, coy = ly0 / 2 - 2, RS = ctb + 8, RSC = ctb / 2 + 4;
-  RBT_PAR_FOR(i, RS * RS) { const int x = ox + i % RS, y = oy + i / RS; ry[i] = (x >= 0 && y >= 0 && x < g->w && y < g->h) ? f->pix[0][(size_t)y * g->w + x] : 0; }
-  RBT_PAR_FOR(i, 2 * RSC * RSC) {
-    const int c = i / (RSC * RSC), j = i % (RSC * RSC), x = cox + j % RSC, y = coy + j / RSC;
-    (c ? rc1 : rc0)[j] = (x >= 0 && y >= 0 && x < g->cw && y < g->ch) ? f->pix[1 + c][(size_t)y * g->cw + x] : 0;
-  }
-  RBT_SYNC_LDS();
-  for (int dir = 0; dir < 2 && !(f->enc_tools & RBT_ET_LF_OUTSIDE); dir++) {
-    const int ne = ctb / 8 + 1, ns = RS / 4;
-    RBT_PAR_FOR(i, ne * ns) {
-      const int e = i / ns, sg = i % ns;
-      const int x = dir == 0 ? lx0 + 8 * e : ox + 4 * sg, y = dir == 0 ? oy + 4 * sg : ly0 + 8 * e;
-      if (x >= 0 && y >= 0 && x < g->w && y < g->h) {
-        const int bs = fl_bs(f, slices, x, y, dir);
-        if (bs) {
-          fl_luma_core(f, slices, x, y, dir, bs, &ry[(y - oy) * RS + (x - ox)], dir == 0 ? 1 : RS, dir == 0 ? RS : 1);
-          if (bs == 2 && !(dir == 0 ? (x & 15) : (y & 15)))
-            for (int c = 0; c < 2; c++) fl_chroma_core(f, slices, 1 + c, x, y, dir, &(c ? rc1 : rc0)[((y >> 1) - coy) * RSC + ((x >> 1) - cox)], dir == 0 ? 1 : RSC, dir == 0 ? RSC : 1);
-        }
-      }
+  if constexpr (REGION) {
+    RBT_PAR_FOR(i, RS * RS) { const int x = ox + i % RS, y = oy + i / RS; ry[i] = (x >= 0 && y >= 0 && x < g->w && y < g->h) ? f->pix[0][(size_t)y * g->w + x] : 0; }
+    RBT_PAR_FOR(i, 2 * RSC * RSC) {
+      const int c = i / (RSC * RSC), j = i % (RSC * RSC), x = cox + j % RSC, y = coy + j / RSC;
+      (c ? rc1 : rc0)[j] = (x >= 0 && y >= 0 && x < g->cw && y < g->ch) ? f->pix[1 + c][(size_t)y * g->cw + x] : 0;
     }
     RBT_SYNC_LDS();
+    for (int dir = 0; dir < 2 && REGION; dir++) {
+      const int ne = ctb / 8 + 1, ns = RS / 4;
+      RBT_PAR_FOR(i, ne * ns) {
+        const int e = i / ns, sg = i % ns;
+        const int x = dir == 0 ? lx0 + 8 * e : ox + 4 * sg, y = dir == 0 ? oy + 4 * sg : ly0 + 8 * e;
+        if (x >= 0 && y >= 0 && x < g->w && y < g->h) {
+          const int bs = fl_bs(f, slices, x, y, dir);
+          if (bs) {
+            fl_luma_core(f, slices, x, y, dir, bs, &ry[(y - oy) * RS + (x - ox)], dir == 0 ? 1 : RS, dir == 0 ? RS : 1);
+            if (bs == 2 && !(dir == 0 ? (x & 15) : (y & 15)))
+              for (int c = 0; c < 2; c++) fl_chroma_core(f, slices, 1 + c, x, y, dir, &(c ? rc1 : rc0)[((y >> 1) - coy) * RSC + ((x >> 1) - cox)], dir == 0 ? 1 : RSC, dir == 0 ? RSC : 1);
+          }
+        }
+      }
+      RBT_SYNC_LDS();
+    }
   }
   // deblocked sample of plane c at picture position (x,y) (inside the CTB or one sample around it)
-#define EN_SAO_RP(c, x, y) ((c) == 0 ? (int)ry[((y) - oy) * RS + ((x) - ox)] : (int)((c) == 1 ? rc0 : rc1)[((y) - coy) * RSC + ((x) - cox)])
+#define EN_SAO_RP(c, x, y) (REGION ? ((c) == 0 ? (int)ry[((y) - oy) * RS + ((x) - ox)] : (int)((c) == 1 ? rc0 : rc1)[((y) - coy) * RSC + ((x) - cox)]) : (int)f->pix[c][(size_t)(y) * pw + (x)])
   for (int c = 0; c < 3 && !all_skip; c++) {
     const int sh = c ? 1 : 0, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, n = ctb >> sh, lgn = g->log2_ctb - sh;
     const int x0 = (cxi * ctb) >> sh, y0 = (cyi * ctb) >> sh;

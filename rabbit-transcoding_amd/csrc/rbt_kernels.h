@@ -70,8 +70,9 @@ void launch_enc_analyse(RbtFrame* frames, const RbtSlice* slices, const int32_t*
 // otherwise CTBs are scheduled on anti-diagonals like the decoder's reconstruction
 void launch_enc_intra(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int row_mode, int max_log2_ctb, uint32_t* ticket = nullptr);
 void launch_enc_inter(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs);
-// deblocking (in LDS), SAO parameters from source-vs-reconstruction statistics and their application for every CTB of the listed pictures (en_sao_ctb)
-void launch_enc_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs, int max_log2_ctb);
+// SAO parameters from source-vs-reconstruction statistics and their application for every CTB of the listed pictures (en_sao_ctb); deblock_inside: the pictures have not
+// been through launch_deblock, the kernel deblocks each CTB and its halo in LDS first (RBT_FUSED_ENC_LF=1)
+void launch_enc_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs, int max_log2_ctb, int deblock_inside);
 void launch_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list, int n_slices, int max_log2_ctb);
 // wavefront mode: every slice segment (one per CTB row) of the listed pictures; rows of a picture hand their context variables down (rbt_kernels.hip k_entropy_wave)
 void set_jobs_in_flight(int depth);   // hint: how many transcode jobs the caller keeps in flight on the selected device (sizes the wavefront launches); kept per device

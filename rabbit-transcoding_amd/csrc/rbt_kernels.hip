@@ -349,13 +349,13 @@ __global__ void __launch_bounds__(64) k_enc_inter(RbtFrame* frames, const RbtSli
   rc_stage_tables(&RBT_LDS_CAST(RbtEncLds, &lds)->rc);
   en_inter_ctb(frames, f, slices, blockIdx.x, RBT_LDS_CAST(RbtEncLds, &lds));
 }
-template <int TL2>
+template <int TL2, bool REGION>
 __global__ void __launch_bounds__(64) k_enc_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
   __shared__ RbtSaoLds lds;
-  __shared__ RbtSaoRegionT<TL2> reg;
+  __shared__ RbtSaoRegionT<REGION ? TL2 : 2> reg;      // REGION: the CTB + halo, deblocked here (RBT_FUSED_ENC_LF=1); otherwise a stub
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   if ((int)blockIdx.x >= f->cfg.w_ctb * f->cfg.h_ctb) return;
-  en_sao_ctb(f, slices, blockIdx.x, RBT_LDS_CAST(RbtSaoLds, &lds), RBT_LDS_CAST(uint16_t, reg.ry), RBT_LDS_CAST(uint16_t, reg.rc[0]), RBT_LDS_CAST(uint16_t, reg.rc[1]));
+  en_sao_ctb<REGION>(f, slices, blockIdx.x, RBT_LDS_CAST(RbtSaoLds, &lds), RBT_LDS_CAST(uint16_t, reg.ry), RBT_LDS_CAST(uint16_t, reg.rc[0]), RBT_LDS_CAST(uint16_t, reg.rc[1]));
 }
 template <int TL2>
 __global__ void __launch_bounds__(64) k_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list) {
@@ -450,10 +450,11 @@ void launch_enc_inter(RbtFrame* frames, const RbtSlice* slices, const int32_t* f
   if (n_frames <= 0) return;
   hipLaunchKernelGGL(k_enc_inter, dim3(max_ctbs, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
 }
-void launch_enc_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs, int max_log2_ctb) {
+void launch_enc_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs, int max_log2_ctb, int deblock_inside) {
   if (n_frames <= 0) return;
-  if (max_log2_ctb <= 5) hipLaunchKernelGGL(k_enc_sao<5>, dim3(max_ctbs, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
-  else hipLaunchKernelGGL(k_enc_sao<6>, dim3(max_ctbs, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
+  if (!deblock_inside) hipLaunchKernelGGL((k_enc_sao<5, false>), dim3(max_ctbs, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
+  else if (max_log2_ctb <= 5) hipLaunchKernelGGL((k_enc_sao<5, true>), dim3(max_ctbs, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
+  else hipLaunchKernelGGL((k_enc_sao<6, true>), dim3(max_ctbs, n_frames), dim3(64), 0, g_stream, frames, slices, frame_list);
 }
 void launch_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list, int n_slices, int max_log2_ctb) {
   if (n_slices <= 0) return;

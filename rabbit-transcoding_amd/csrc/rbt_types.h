@@ -112,7 +112,6 @@ struct RbtFrame {
 #define RBT_ET_REFINE 2    // closed-loop choice of the luma intra mode (en_refine_mode)
 #define RBT_ET_RQ 4        // rounding offset of the intra quantiser by level and position (en_rq_offset)
 #define RBT_ET_RDM 16      // the two cheapest candidates of the closed-loop mode choice coded as one transform block each, the cheaper kept (en_intra_ctb; oracle e1_mode_trial)
-#define RBT_ET_LF_OUTSIDE 8 // the picture was deblocked in place by k_deblock before the SAO kernel (the default; without it - RBT_FUSED_ENC_LF=1 - en_sao_ctb runs the edge passes itself)
 #define RBT_CU_CBF_Y 1
 #define RBT_CU_CBF_CB 2
 #define RBT_CU_CBF_CR 4

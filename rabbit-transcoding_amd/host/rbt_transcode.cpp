@@ -88,7 +88,7 @@ static int encode_build(EncodeBatch& b) {
       RbtFrame f; memset(&f, 0, sizeof(f));
       fill_stream_cfg(s, p, f.cfg);
       f.poc = is_i ? 0 : (i % d.gop); f.level = is_i ? 0 : 1; f.first_slice = (int)b.slices.size();
-      f.w8 = s.width / 8; f.h8 = s.height / 8; f.lossless = d.lossless; f.enc_tools = (e1_tools(d.lossless) & ~d.tools_off) | (e1_fused_lf() ? 0 : RBT_ET_LF_OUTSIDE); f.ref_frame = is_i ? -1 : (int)b.frames.size() - 1; f.ref_poc = is_i ? 0 : f.poc - 1;
+      f.w8 = s.width / 8; f.h8 = s.height / 8; f.lossless = d.lossless; f.enc_tools = e1_tools(d.lossless) & ~d.tools_off; f.ref_frame = is_i ? -1 : (int)b.frames.size() - 1; f.ref_poc = is_i ? 0 : f.poc - 1;
       for (int c = 0; c < 3; c++) f.src[c] = d.src[c][i];
       if (!d.hint_dm.empty()) { f.hint_pm = d.hint_pm[i]; f.hint_dm = d.hint_dm[i]; f.hint_w4 = d.hint_w4; f.hint_h4 = d.hint_h4; }
       if (!d.occ4.empty() && !d.lossless) { f.occ4 = d.occ4[i]; f.occ4_w = d.occ4_w; f.occ4_h = d.occ4_h; }
@@ -209,7 +209,7 @@ static void encode_launch_intra(EncodeBatch& b) {
   rbtk::timer_begin(T_ENCODE);
   rbtk::launch_enc_intra(b.d_frames, b.d_slices, b.d_lists + b.off_i, b.n_i, mw, mh, row_mode, ml2, (uint32_t*)b.d_zero);
   rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_ideb, b.n_ideb, mu);
-  rbtk::launch_enc_sao(b.d_frames, b.d_slices, b.d_lists + b.off_isao, b.n_isao, mc, ml2);   // decides and applies
+  rbtk::launch_enc_sao(b.d_frames, b.d_slices, b.d_lists + b.off_isao, b.n_isao, mc, ml2, e1_fused_lf());   // decides and applies
   rbtk::timer_end(T_ENCODE);
 }
 // entropy coding of the intra pictures' slices: needs nothing but their levels and CU data
@@ -230,7 +230,7 @@ static void encode_launch_rest(EncodeBatch& b) {
   rbtk::timer_begin(T_INTER);
   rbtk::launch_enc_inter(b.d_frames, b.d_slices, b.d_lists + b.off_p, b.n_p, mc);
   rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.off_pdeb, b.n_pdeb, mu);
-  rbtk::launch_enc_sao(b.d_frames, b.d_slices, b.d_lists + b.off_psao, b.n_psao, mc, max_log2_ctb(b));
+  rbtk::launch_enc_sao(b.d_frames, b.d_slices, b.d_lists + b.off_psao, b.n_psao, mc, max_log2_ctb(b), e1_fused_lf());
   rbtk::timer_end(T_INTER);
   rbtk::timer_begin(T_ENTROPY);
   if (b.wpp) rbtk::launch_entropy_wave(b.d_frames, b.d_slices, b.d_out, b.d_lists + b.off_p, b.n_p, max_w_ctb(b), max_h_ctb(b), max_log2_ctb(b), (uint32_t*)b.d_zero + 2);
