@@ -51,6 +51,14 @@ def test_transcode_v3c_depths(R, ctx, container, depth, per):
         ctx.set_depth(4)
 
 
+@pytest.mark.parametrize("occupancy_rd,preset", [(1, 0), (0, 1), (1, 1)])
+def test_transcode_v3c_options(R, ctx, container, occupancy_rd, preset):
+    """rbt_v3c_params.occupancy_rd / .preset through the walk with several jobs in flight: every GOF's geometry / attribute units are coded with THAT GOF's occupancy map"""
+    ctx.set_depth(4)
+    got = ctx.transcode_v3c(container, 24, 32, gofs_per_job=2, occupancy_rd=occupancy_rd, preset=preset)
+    assert got == O.v3c_transcode(container, 24, 32, occupancy_rd=occupancy_rd, preset=preset) and got != ctx.transcode_v3c(container, 24, 32)
+
+
 def test_sharded_contexts_merge_to_the_unsharded_file(R, ctx, container):
     gs = rbt_lib.module_file("gof_shard")
     parts = []
