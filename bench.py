@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--pc-frames", type=int, default=32)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=1280)
-    ap.add_argument("--cpu-sample", type=int, default=16, help="point-cloud frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=10, help="point-cloud frames of the CPU baseline sample (0 = skip; 10 frames are ~27 s of one core with the round-3 encoder)")
     ap.add_argument("--multi-gof", type=int, default=8, help="also time G GOFs per call (extra field multi_gof; 0/1 = skip)")
     ap.add_argument("--in-flight", type=int, default=16, help="GOFs in flight (rbt_submit_gof ahead of rbt_wait_gof), 1..16; 1 = blocking calls")
     ap.add_argument("--gofs-per-job", type=int, default=0, help="GOFs handed over per rbt_submit_gof call (a step stays one GOF; the K steps are spread evenly over ceil(K / G) jobs). "
