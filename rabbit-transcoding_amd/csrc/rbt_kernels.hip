@@ -210,10 +210,21 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if ((threadIdx.x & 63) == 0) __hip_atomic_store(&done[2 * addr + role], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// XCD-aware tile order for the kernels whose workgroups are independent. Workgroups go to the 8 XCDs round-robin in launch order, so neighbouring tiles of a picture - which
+// share cache lines (a 32-sample CTB row is half a 128-byte line) and halo rows - would sit behind eight different L2s and every shared line would be fetched from memory once
+// per L2. Tile = the b-th workgroup's position in a CONTIGUOUS eighth of the picture's tiles instead: workgroup b (XCD b % 8) takes tile (b % 8) * (n / 8) + b / 8, the
+// remainder of an n that is no multiple of 8 keeps its place. Only when the grid's x extent is a multiple of 8 (then the XCD of a workgroup is blockIdx.x % 8 in every row of the grid).
+__device__ __forceinline__ int xcd_tile(int b, int n) {
+  const int per = n >> 3;
+  if ((gridDim.x & 7) || per == 0 || b >= per * 8) return b;
+  return (b & 7) * per + (b >> 3);
+}
 __global__ void __launch_bounds__(256) k_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int dir) {
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
-  int unit = blockIdx.x * 256 + threadIdx.x;
-  if (unit >= f->cfg.w4 * f->cfg.h4) return;
+  const int n_units = f->cfg.w4 * f->cfg.h4, n_blk = (n_units + 255) >> 8;
+  if ((int)blockIdx.x >= n_blk) return;
+  int unit = xcd_tile(blockIdx.x, n_blk) * 256 + threadIdx.x;
+  if (unit >= n_units) return;
   rbt_deblock_unit(f, slices, unit, dir);
 }
 // deblocking (both edge directions) + SAO of one 64x64 tile through LDS (rbt_filter.h rbt_loopfilter_tile): pictures with SAO, whose output is a plane of its own
@@ -222,12 +233,14 @@ __global__ void __launch_bounds__(256) k_loopfilter(RbtFrame* frames, const RbtS
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   const int tw = (f->cfg.w + RBT_LF_TILE - 1) / RBT_LF_TILE, th = (f->cfg.h + RBT_LF_TILE - 1) / RBT_LF_TILE;
   if ((int)blockIdx.x >= tw * th) return;
-  rbt_loopfilter_tile(f, slices, blockIdx.x, RBT_LDS_CAST(RbtLoopLds, &lds));
+  rbt_loopfilter_tile(f, slices, xcd_tile(blockIdx.x, tw * th), RBT_LDS_CAST(RbtLoopLds, &lds));
 }
 __global__ void __launch_bounds__(256) k_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   int c = blockIdx.z, pw = c ? f->cfg.cw : f->cfg.w, ph = c ? f->cfg.ch : f->cfg.h;
-  int i = blockIdx.x * 256 + threadIdx.x;
+  const int n_blk = (pw * ph + 255) >> 8;
+  if ((int)blockIdx.x >= n_blk) return;
+  int i = xcd_tile(blockIdx.x, n_blk) * 256 + threadIdx.x;
   if (i >= pw * ph) return;
   rbt_sao_sample(f, slices, c, i % pw, i / pw);
 }
@@ -290,7 +303,7 @@ __global__ void __launch_bounds__(64) k_enc_analyse(RbtFrame* frames, const RbtS
   __shared__ RbtAnalyseLds lds;
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   if ((int)blockIdx.x >= f->cfg.w_ctb * f->cfg.h_ctb) return;
-  en_analyse_ctb(f, slices, blockIdx.x, RBT_LDS_CAST(RbtAnalyseLds, &lds));
+  en_analyse_ctb(f, slices, xcd_tile(blockIdx.x, f->cfg.w_ctb * f->cfg.h_ctb), RBT_LDS_CAST(RbtAnalyseLds, &lds));
 }
 // (TL2: log2 of the largest CTB of the launch; fixes the size of the reconstruction tile in LDS)
 template <int TL2>
@@ -347,7 +360,7 @@ __global__ void __launch_bounds__(64) k_enc_inter(RbtFrame* frames, const RbtSli
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   if ((int)blockIdx.x >= f->cfg.w_ctb * f->cfg.h_ctb) return;
   rc_stage_tables(&RBT_LDS_CAST(RbtEncLds, &lds)->rc);
-  en_inter_ctb(frames, f, slices, blockIdx.x, RBT_LDS_CAST(RbtEncLds, &lds));
+  en_inter_ctb(frames, f, slices, xcd_tile(blockIdx.x, f->cfg.w_ctb * f->cfg.h_ctb), RBT_LDS_CAST(RbtEncLds, &lds));
 }
 template <int TL2, bool REGION>
 __global__ void __launch_bounds__(64) k_enc_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
@@ -355,7 +368,7 @@ __global__ void __launch_bounds__(64) k_enc_sao(RbtFrame* frames, const RbtSlice
   __shared__ RbtSaoRegionT<REGION ? TL2 : 2> reg;      // REGION: the CTB + halo, deblocked here (RBT_FUSED_ENC_LF=1); otherwise a stub
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   if ((int)blockIdx.x >= f->cfg.w_ctb * f->cfg.h_ctb) return;
-  en_sao_ctb<REGION>(f, slices, blockIdx.x, RBT_LDS_CAST(RbtSaoLds, &lds), RBT_LDS_CAST(uint16_t, reg.ry), RBT_LDS_CAST(uint16_t, reg.rc[0]), RBT_LDS_CAST(uint16_t, reg.rc[1]));
+  en_sao_ctb<REGION>(f, slices, xcd_tile(blockIdx.x, f->cfg.w_ctb * f->cfg.h_ctb), RBT_LDS_CAST(RbtSaoLds, &lds), RBT_LDS_CAST(uint16_t, reg.ry), RBT_LDS_CAST(uint16_t, reg.rc[0]), RBT_LDS_CAST(uint16_t, reg.rc[1]));
 }
 template <int TL2>
 __global__ void __launch_bounds__(64) k_entropy(RbtFrame* frames, RbtSlice* slices, uint8_t* out, const int32_t* slice_list) {
