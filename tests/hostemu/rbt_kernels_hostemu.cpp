@@ -27,7 +27,8 @@ void stream_wait(int, int) {}
 int stream_mark(int) { return 0; }
 void stream_wait_mark(int, int) {}
 const char* dev_name() { return "host emulation (test only)"; }
-void* dev_alloc(size_t n) { return malloc(n ? n : 1); }
+// poisoned: the product recycles device arenas, so whatever a kernel body reads without having written it is another job's data - the parity tests run on a pattern that shows it
+void* dev_alloc(size_t n) { void* p = malloc(n ? n : 1); if (p) memset(p, 0xA5, n ? n : 1); return p; }
 void dev_free(void* p) { free(p); }
 void dev_release_pool() {}
 int h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); return 0; }
