@@ -1065,14 +1065,24 @@ RBT_DEV void en_stage_ctb(RbtEnt* s, int cx, int cy) {
   const RbtFrame* f = s->f; RBT_LDS_AS RbtEntropyLds* l = s->l;
   s->cx = cx; s->cy = cy;
   const int L = s->log2_ctb, wc = (s->w + (1 << L) - 1) >> L, ac = (cy >> L) * wc + (cx >> L), my = f->ctb_slice[ac];
+  int coded = 0;                                                     // some block of THIS CTB has levels (its cbf bits)
   RBT_PAR_FOR(i, 81) {
     const int ux = i % 9 - 1, uy = i / 9 - 1, x = cx + ux * 8, y = cy + uy * 8;
     int l2 = 0xFF, md = 1, fl = 0;
     if (x >= 0 && y >= 0 && x < s->w && y < s->h && ux < (1 << (L - 3)) && uy < (1 << (L - 3))) {
       const int an = (y >> L) * wc + (x >> L);
       if (an == ac || f->ctb_slice[an] == my) { const int k = (y >> 3) * f->w8 + (x >> 3); l2 = f->cu_log2[k]; md = f->cu_mode[k]; fl = f->cu_flags[k]; }
+      if (an == ac) coded |= (fl & (RBT_CU_CBF_Y | RBT_CU_CBF_CB | RBT_CU_CBF_CR | 7 * RBT_CU_CBF_Y1)) != 0;
     }
     l->cu_l2[i] = (uint8_t)l2; l->cu_md[i] = (uint8_t)md; l->cu_fl[i] = (uint8_t)fl;
+  }
+  // a CTB without a coded block (P pictures: most of them are skipped CUs throughout) has no levels to fetch
+  if (s->is_p && en_wave_sum(coded, (RBT_LDS_AS RbtEncLds*)0) == 0) {
+    RBT_SYNC();
+#ifdef RBT_PROFILE
+    s->t_stage += __builtin_readcyclecounter() - ts_;
+#endif
+    return;
   }
   // the CTB's levels: 8-byte groups of four, several loads in flight (one HBM round trip per CTB instead of one per CU)
   for (int c = 0; c < 3; c++) {
