@@ -601,7 +601,7 @@ def main():
                 "config": {"workload": f"{n_pc}-frame GOF, {w}x{h} V-PCC maps (2x{n_pc} geometry + 2x{n_pc} attribute yuv420p10 I/P pairs, {n_pc} occupancy {w // 2}x{h // 2} lossless), "
                                        f"R5 (QP16/22, prec 2) -> R3 (QP24/32, prec 4), synthetic longdress-like atlas", "input": input_kind,
                            "encoder": ("RBT-E1, wavefront mode (one slice per picture, a dependent slice segment per CTB row, entropy_coding_sync)" if args.rows < 0 else f"RBT-E1, {args.rows or 'all'} CTB row(s) per slice")
-                                      + ", 35 intra modes, one-or-four transform units per intra CU (4x4 luma blocks with the DST or transform skip), SAO, closed (I,P) pairs, CQP",
+                                      + ", 35 intra modes, SATD block costs, closed-loop mode choice with a coded trial of the two cheapest modes, rounding by level and position, one-or-four transform units per intra CU (4x4 luma blocks with the DST or transform skip), SAO, closed (I,P) pairs, CQP, preset default",
                            "gof_per_gpu": 1, "jobs_in_flight": D, "gofs_per_job": round(gpj, 3), "gofs_in_flight": round(D * gpj), "setup_jobs_before_warmup": primed, "in_bytes": in_bytes, "out_bytes": out_bytes, "parallelism": f"gof-shard x{world}"},
                 "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                              "traffic": traffic, "kernel_ms": {k_: round(v, 3) for k_, v in groups.items()},
