@@ -439,7 +439,7 @@ template <int TL2> struct RbtEncTileLdsT { RbtEncIntraScratch rc; RbtEncTileT<TL
 RBT_DEV int en_quant_scale(int r) { const uint64_t lo = 26214ull | (23302ull << 16) | (20560ull << 32) | (18396ull << 48), hi = 16384ull | (14564ull << 16); return (int)(((r < 4 ? lo : hi) >> (16 * (r & 3))) & 0xFFFF); }
 // one intra TB: (x0,y0) relative to the CTB and (gx,gy) in the picture, both in samples of component c_idx; returns cbf
 template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int c_idx, int x0, int y0, int gx, int gy, int log2, int mode, int qp,
-                             const RBT_LDS_AS uint16_t* src, int mark_l4, int mux, int muy, RBT_LDS_AS int16_t* lvl_buf = nullptr, long long* cost = nullptr, int lam2 = 0, int* ssd_out = nullptr, int* ts_out = nullptr) {
+                             const RBT_LDS_AS uint16_t* src, int mark_l4, int mux, int muy, RBT_LDS_AS int16_t* lvl_buf = nullptr, long long* cost = nullptr, int lam2 = 0, int* ssd_out = nullptr, int* ts_out = nullptr, int reuse_nb = 0) {
   RBT_LDS_AS RbtEncIntraScratch* r = &L->rc; RBT_LDS_AS RbtEncTileT<TL2>* t = &L->t;
   // lvl_buf: where the levels go (default: over the luma part of `sb`, i.e. over the source once the residual is formed). cost (needs a lvl_buf that leaves
   // `src` alone): distortion * 256 + lam2 * rate of the block as the oracle's recon_tb / hm_decide_tu_split count them - squared error of the residual
@@ -450,17 +450,19 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
   const RBT_LDS_AS uint16_t* top = c_idx == 0 ? t->top_y : t->top_c[c_idx - 1];
   // reference samples: availability masks, substitution while gathering, smoothing, mode set-up
   const int tot = 4 * N + 1;
-  uint64_t m0, m1 = 0; int m2 = 0;
-  RBT_VBALLOT(m0, p, rbt_min(tot, 64), rc_nb_av(t->uav, p, x0, y0, N, sh, n4));
-  if (tot > 64) { RBT_VBALLOT(m1, p, rbt_min(tot - 64, 64), rc_nb_av(t->uav, 64 + p, x0, y0, N, sh, n4)); }
-  if (tot > 128) m2 = rc_nb_av(t->uav, 128, x0, y0, N, sh, n4);
-  const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : (m2 ? 128 : -1));
-  RBT_PAR_FOR(i, tot) {
-    int v = 1 << (bd - 1);
-    if (first >= 0) { int j = rc_last_avail(i, m0, m1, m2); if (j < 0) j = first; int xn, yn; rc_nb_xy(j, x0, y0, N, &xn, &yn); v = yn < 0 ? top[xn + 1] : tile[yn * S + xn + 1]; }
-    r->nb[i] = v;
+  if (!reuse_nb) {          // reuse_nb: r->nb still holds this block's references (en_refine_mode gathered them for the same position and size, nothing has gathered since)
+    uint64_t m0, m1 = 0; int m2 = 0;
+    RBT_VBALLOT(m0, p, rbt_min(tot, 64), rc_nb_av(t->uav, p, x0, y0, N, sh, n4));
+    if (tot > 64) { RBT_VBALLOT(m1, p, rbt_min(tot - 64, 64), rc_nb_av(t->uav, 64 + p, x0, y0, N, sh, n4)); }
+    if (tot > 128) m2 = rc_nb_av(t->uav, 128, x0, y0, N, sh, n4);
+    const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : (m2 ? 128 : -1));
+    RBT_PAR_FOR(i, tot) {
+      int v = 1 << (bd - 1);
+      if (first >= 0) { int j = rc_last_avail(i, m0, m1, m2); if (j < 0) j = first; int xn, yn; rc_nb_xy(j, x0, y0, N, &xn, &yn); v = yn < 0 ? top[xn + 1] : tile[yn * S + xn + 1]; }
+      r->nb[i] = v;
+    }
+    RBT_SYNC_LDS();
   }
-  RBT_SYNC_LDS();
   RBT_LDS_AS int32_t* fin = rc_intra_filter(g, c_idx, log2, mode, r->nb, r_nbf);
   RcIntraCtx q; rc_intra_setup(g, c_idx, log2, mode, fin, r_ref, &q);
   // prediction and residual
@@ -626,12 +628,12 @@ template <int TL2> RBT_DEV int en_refine_mode(const RbtStreamCfg* g, RBT_LDS_AS 
 // is marked available.
 // have_whole: the coded mode trial has just coded the CU as one block with this mode (levels in lv0, reconstruction in the tile, cost / distortion / cbf handed in)
 template <int TL2> RBT_DEV int en_intra_cu_luma(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int x0, int y0, int gx, int gy, int lg, int mode, int qp, int lam2, int* split, int* ts_bits,
-                                              int have_whole = 0, long long c_whole_in = 0, int ssd0_in = 0, int cbf0_in = 0) {
+                                              int have_whole = 0, long long c_whole_in = 0, int ssd0_in = 0, int cbf0_in = 0, int reuse_nb = 0) {
   RBT_LDS_AS RbtEncTileT<TL2>* t = &L->t;
   const int N = 1 << lg, h = N >> 1, S = RbtEncTileT<TL2>::TS_Y;
   long long c_whole = c_whole_in, c_split = 3ll * lam2, cq = 0;
   int ssd0 = ssd0_in, cbf0 = cbf0_in;
-  if (!have_whole) cbf0 = en_tile_intra_tb(g, f, L, 0, x0, y0, gx, gy, lg, mode, qp, t->sb, -1, 0, 0, t->lv0, &c_whole, lam2, &ssd0);
+  if (!have_whole) cbf0 = en_tile_intra_tb(g, f, L, 0, x0, y0, gx, gy, lg, mode, qp, t->sb, -1, 0, 0, t->lv0, &c_whole, lam2, &ssd0, nullptr, reuse_nb);
   *split = 0; *ts_bits = 0;
   if (!f->lossless && (long long)ssd0 * 256 < (long long)(lam2 >> 2) * N * N) {     // coded to within lambda^2 / 4 per sample by one transform: not tried as four (lossless: the bits alone decide)
     RBT_PAR_FOR(i, 1 << (2 * (lg - 2))) t->uav[((y0 >> 2) + (i >> (lg - 2)) + 1) * RC_US + (x0 >> 2) + (i & ((1 << (lg - 2)) - 1)) + 1] = 1;
@@ -829,8 +831,8 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
         // only: on 8x8 CUs, more than half of all, the trial moved nothing). The runner-up first:
         // when the SATD's choice stands - most of the time - its block is already coded and en_intra_cu_luma goes straight on to the four-way form
         long long c2 = 0;
-        en_tile_intra_tb(g, f, L, 0, x0, y0, cx + x0, cy + y0, lg, second, qp_l, t->sb, -2, 0, 0, t->lv0, &c2, lam2);
-        cbf_w = en_tile_intra_tb(g, f, L, 0, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, t->sb, -1, 0, 0, t->lv0, &c_w, lam2, &ssd_w);
+        en_tile_intra_tb(g, f, L, 0, x0, y0, cx + x0, cy + y0, lg, second, qp_l, t->sb, -2, 0, 0, t->lv0, &c2, lam2, nullptr, nullptr, 1);
+        cbf_w = en_tile_intra_tb(g, f, L, 0, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, t->sb, -1, 0, 0, t->lv0, &c_w, lam2, &ssd_w, nullptr, 1);
         if (c2 + (long long)lam2 * b2 < c_w + (long long)lam2 * b1) mode = second; else have_w = 1;
       }
       const int nu = N >> 3;
@@ -838,7 +840,7 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
       RBT_SYNC_LDS();
     }
     int split = 0, cbf = 0, cy4 = 0, ts_bits = 0;
-    if (tu_rd) cy4 = en_intra_cu_luma(g, f, L, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, lam2, &split, &ts_bits, have_w, c_w, ssd_w, cbf_w);
+    if (tu_rd) cy4 = en_intra_cu_luma(g, f, L, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, lam2, &split, &ts_bits, have_w, c_w, ssd_w, cbf_w, refine != 0);      // after the mode choice r->nb holds the CU's references
     else cy4 = en_tile_intra_tb(g, f, L, 0, x0, y0, cx + x0, cy + y0, lg, mode, qp_l, t->sb, lg - 2, x0 >> 2, y0 >> 2);
     if (split && lg >= 4) {
       // four transform units, each with its own Cb / Cr blocks: chroma block b is predicted when the units 0..b of the CU are reconstructed, not more
