@@ -58,7 +58,7 @@ typedef struct {
   int preset;                /* RBT_PRESET_*: what the reference's `preset` (PCCTranscoderParameters.h:58, handed to libx265 at PCCTranscoder.cpp:877,883) selects here.
                               * RBT_PRESET_DEFAULT (0, x265 "veryfast" and slower): every decision tool of RBT-E1. RBT_PRESET_FAST (1, "ultrafast", "superfast"):
                               * the open-loop decisions only - no SATD block costs, no closed-loop mode choice, no coded mode trial, fixed rounding: 16 % more bytes at the same
-                              * QP (benchmark GOF: out / in 0.382 instead of 0.329, D1 67.80 instead of 67.94 dB), 2-5 % faster (785 against 769 point-cloud frames/s for a
+                              * QP (benchmark GOF: out / in 0.382 instead of 0.329, D1 67.80 instead of 67.94 dB), 2-3 % faster (805 against 779 point-cloud frames/s for a
                               * 20-GOF run).
                               * rbt_preset_from_name maps the reference's strings. */
 } rbt_stream_params;
