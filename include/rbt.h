@@ -122,7 +122,8 @@ int rbt_transcode_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, cons
 typedef struct rbt_job rbt_job;
 int rbt_set_depth(rbt_ctx* ctx, int max_in_flight);
 int rbt_get_depth(rbt_ctx* ctx);   /* the announced depth (> 0) or RBT_ERR_PARAM */
-/* How to cut a walk of n_gofs GOFs into jobs on one GPU, as measured: 16 jobs of 2 GOFs for a long walk; a walk shorter than 48 GOFs is all ramp-up and
+/* How to cut a walk of n_gofs GOFs into jobs on one GPU, as measured on 1280x1280 maps: 16 jobs of 3 GOFs for a long walk (96 GOFs and more; 2 GOFs from 48: the
+ * arenas of 48 GOFs in flight are 216 GB at that size - a caller with larger atlases passes its own gofs_per_job, an arena that does not fit fails with RBT_ERR_NOMEM); a walk shorter than 48 GOFs is all ramp-up and
  * drain and does better as at most 7 jobs (2 jobs up to 12 GOFs) of ceil(n / jobs) GOFs, which then own several hardware queues each. max_jobs caps the jobs in flight. */
 int rbt_job_shape(int n_gofs, int max_jobs, int* gofs_per_job, int* jobs_in_flight);
 /* The reference's `preset` string (an x265 preset name, PCCTranscoderParameters.h:58) as RBT_PRESET_*: "ultrafast", "superfast" -> RBT_PRESET_FAST; "veryfast"

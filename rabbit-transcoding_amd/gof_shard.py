@@ -113,13 +113,15 @@ def _walk(ctx, jobs, depth):
 
 
 def job_shape(n_gofs: int, max_depth: int = 16):
-    """(GOFs per job, jobs in flight) for a walk of n_gofs GOFs on one GPU. A long walk keeps 16 jobs of 2 GOFs in flight (every job owns one hardware queue,
-    two GOFs per launch fill the GPU: DESIGN.md 5); a walk shorter than 48 GOFs is all ramp-up and drain and does better as at most 7 jobs (2 up to 12 GOFs), which then own two
+    """(GOFs per job, jobs in flight) for a walk of n_gofs GOFs on one GPU. A long walk keeps 16 jobs of 3 GOFs in flight (2 GOFs below 96: every job owns one hardware queue,
+    several GOFs per launch fill the GPU: DESIGN.md 5); a walk shorter than 48 GOFs is all ramp-up and drain and does better as at most 7 jobs (2 up to 12 GOFs), which then own two
     or more queues each (rbt_set_depth), so that a job's geometry and attribute pipelines run side by side. Measured with tools/short_run_sweep.sh."""
     import os
     if os.environ.get("RBT_WALK_SHAPE"):                         # experiments: "G,D"
         g, d = (int(x) for x in os.environ["RBT_WALK_SHAPE"].split(","))
         return g, d
+    if n_gofs >= 96:                                             # round 3: 16 x 3 GOFs 905-909 fps, 16 x 2 874-882, 12 x 4 897 (192-GOF walks); 48 GOFs of arenas are 216 GB at 1280x1280
+        return 3, max(1, min(max_depth, 16))
     if n_gofs >= 48:
         return 2, max(1, min(max_depth, 16))
     jobs = 2 if n_gofs <= 12 else 7                              # measured on one MI355X: 10 GOFs 470 / 544 / 573 / 601 / 563 fps as 10 / 5 / 3 / 2 / 1 jobs; 20 GOFs 484 / 650 / 798 / 784 / 731

@@ -68,7 +68,7 @@ def test_job_shapes(hostemu):
     gs = rbt_lib.module_file("gof_shard")
     assert gs.spread(20, 3) == [3, 3, 3, 3, 3, 3, 2] and gs.spread(20, 2) == [2] * 10 and gs.spread(5, 3) == [3, 2] and gs.spread(0, 2) == [] and gs.spread(1, 4) == [1]
     assert all(sum(gs.spread(n, g)) == n and max(gs.spread(n, g)) <= g for n in range(1, 70) for g in range(1, 9))
-    assert gs.job_shape(256) == (2, 16) and gs.job_shape(48) == (2, 16) and gs.job_shape(20) == (3, 7) and gs.job_shape(10) == (5, 2) and gs.job_shape(1) == (1, 1) and gs.job_shape(40) == (6, 7)
+    assert gs.job_shape(256) == (3, 16) and gs.job_shape(96) == (3, 16) and gs.job_shape(95) == (2, 16) and gs.job_shape(48) == (2, 16) and gs.job_shape(20) == (3, 7) and gs.job_shape(10) == (5, 2) and gs.job_shape(1) == (1, 1) and gs.job_shape(40) == (6, 7)
     R = rbt_lib.module(); L = R.load(rbt_lib.HOSTEMU_LIB)      # the library's copy of the rule (rbt_job_shape)
     assert all(R.job_shape(n, d, L) == gs.job_shape(n, d) for n in range(1, 130) for d in (1, 2, 4, 7, 16))
     assert gs.job_shape(20, 4) == (3, 4) and gs.job_shape(2) == (1, 2) and gs.job_shape(13) == (2, 7)
