@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--multi-gof", type=int, default=8, help="also time G GOFs per call (extra field multi_gof; 0/1 = skip)")
     ap.add_argument("--in-flight", type=int, default=16, help="GOFs in flight (rbt_submit_gof ahead of rbt_wait_gof), 1..16; 1 = blocking calls")
     ap.add_argument("--gofs-per-job", type=int, default=0, help="GOFs handed over per rbt_submit_gof call (a step stays one GOF; the K steps are spread evenly over ceil(K / G) jobs). "
-                    "0 = choose by the length of the run (gof_shard.job_shape): 2 for a long run (16 jobs x 2 GOFs keep the GPU full); a run shorter than 48 steps is all ramp-up and "
+                    "0 = choose by the length of the run (gof_shard.job_shape): 3 for a long run (16 jobs x 3 GOFs keep the GPU full; 2 below 96 steps); a run shorter than 48 steps is all ramp-up and "
                     "drain and does better with few jobs (7, or 2 up to 12 steps) that own several hardware queues each than with many that own one)")
     ap.add_argument("--sweep", type=int, default=64, help="also time K GOFs at every in-flight depth 1..4 (extra field in_flight_sweep; 0/1 = skip)")
     ap.add_argument("--steady-steps", type=int, default=256, help="when --steps is smaller: also time a walk of this many GOFs (extra top-level field steady_state_fps_256; 0 = skip)")
