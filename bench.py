@@ -78,8 +78,10 @@ def main():
     ap.add_argument("--save-input", default=None, help="write the generated R5 input streams to this .npz file and exit")
     ap.add_argument("--load-input", default=None, help="read the R5 input streams from a file written by --save-input (keeps the input "
                     "encoder's kernels out of a profile of the transcode step); the file must come from the same size / seed")
-    ap.add_argument("--input", default="auto", choices=["auto", "hm", "e1"], help="R5 input: hm = the committed HM-like fixture (tests/golden/hm_r5_*.annexb: CTC toolset, "
-                    "coded by the oracle's HM-like encoder, tests/golden/make_hm_gof.py); e1 = coded on the fly by this library's own encoder (any size); auto = hm when the fixture fits")
+    ap.add_argument("--input", default="auto", choices=["auto", "hm", "hm-closed", "e1"], help="R5 input: hm = the committed HM-like fixture in the stream structure of the CTC's HM encoder "
+                    "(tests/golden/hm_r5ctc_*.annexb: CTC toolset AND structure - one IDR per sub-bitstream, then TRAIL_N P / TRAIL_R intra pictures with reference picture sets, POC 0..63; coded by the "
+                    "oracle's HM-like encoder, tests/golden/make_hm_gof.py --ctc 1); hm-closed = the same maps and decisions as closed (IDR, P) pairs with repeated parameter sets (hm_r5_*.annexb, the "
+                    "input of rounds 2-3); e1 = coded on the fly by this library's own encoder (any size); auto = hm when the fixture fits")
     ap.add_argument("--rows", type=int, default=-1, help="encoder slice structure (rbt_stream_params.ctb_rows_per_slice): -1 = wavefront mode, one slice per picture coded as one "
                     "dependent slice segment per CTB row (entropy_coding_sync); 1 = one independent slice per CTB row; 0 = one slice per picture")
     ap.add_argument("--walk-frames", type=int, default=300, help="also walk a sequence of this many point-cloud frames GOF-sharded over the ranks "
@@ -122,12 +124,16 @@ def main():
     fixture = None
     man_path = os.path.join(ROOT, "tests", "golden", "hm_r5_manifest.json")
     if args.input != "e1" and not args.load_input and os.path.exists(man_path):
-        man = json.load(open(man_path)).get(f"{w}x{h}_f32")
-        if man and n_pc <= 32:
-            fixture = {k: b"".join(gs.split_pairs(open(os.path.join(ROOT, "tests", "golden", v["file"]), "rb").read())[:n_pc]) for k, v in man["streams"].items()}
-    if args.input == "hm" and fixture is None:
-        sys.exit("--input hm: no committed fixture for this size (tests/golden/make_hm_gof.py)")
-    input_kind = "hm-like fixture (oracle HM-like encoder: SAO, TS, AMP, quarter-pel ME, TU trees, 35 intra modes)" if fixture else "RBT-E1 (this library's encoder, CTB 64, one slice per picture)"
+        mans = json.load(open(man_path))
+        man = mans.get(f"{w}x{h}_f32" + ("" if args.input == "hm-closed" else "_ctc")) or (mans.get(f"{w}x{h}_f32") if args.input == "auto" else None)
+        if man and n_pc <= 32:      # a prefix of a sub-bitstream is a sub-bitstream in either structure: the first n_pc point-cloud frames
+            fixture = {k: gs.first_pictures(open(os.path.join(ROOT, "tests", "golden", v["file"]), "rb").read(), n_pc * (1 if k == "occ" else 2)) for k, v in man["streams"].items()}
+    if args.input in ("hm", "hm-closed") and fixture is None:
+        sys.exit(f"--input {args.input}: no committed fixture for this size (tests/golden/make_hm_gof.py)")
+    ctc_structure = bool(fixture) and not gs.is_closed_pairs(fixture["geo"])
+    input_kind = ("hm-like fixture (oracle HM-like encoder: SAO, TS, AMP, quarter-pel ME, TU trees, 35 intra modes), " +
+                  ("stream structure of the CTC's HM encoder: one IDR per sub-bitstream, TRAIL_N P / TRAIL_R intra pictures with reference picture sets, POC running on, parameter sets at the IDR only"
+                   if ctc_structure else "closed (IDR, P) pairs with repeated parameter sets")) if fixture else "RBT-E1 (this library's encoder, CTB 64, one slice per picture)"
     if fixture:
         sg, sa, so = fixture["geo"], fixture["attr"], fixture["occ"]
         geo = attr = occ = None
@@ -293,7 +299,7 @@ def main():
             c1 = R.Context(device=dev, rank=0, world=1) if world > 1 else ctx
             alone = gs.transcode_sequence(c1, seq, params, depth=WD)
             if c1 is not ctx: c1.close()
-            walk = {"frames": args.walk_frames, "gofs": [len(gs.split_pairs(g[0])) for g in seq], "ranks": world, "value": round(args.walk_frames / wt, 3), "unit": "point-cloud frames/s",
+            walk = {"frames": args.walk_frames, "gofs": [len(gs.access_units(g[0])) for g in seq], "ranks": world, "value": round(args.walk_frames / wt, 3), "unit": "point-cloud frames/s",
                     "seconds": round(wt, 4), "scaling": "strong", "out_bytes": sum(len(s_) for g in stitched for s_ in g), "stitched_equals_unsharded": stitched == alone,
                     "job_shape": dict(zip(("gofs_per_job", "jobs_in_flight"), gs.job_shape(len(gs.gofs_of_rank(len(seq), 0, world)), WD)))}
         # the same sequence as a V3C sample stream, file in -> file out (rbt_transcode_v3c: the loop of PccAppTranscoder.cpp:277-349 around transcodeData;
@@ -438,13 +444,13 @@ def main():
             import synth
             src = synth.make_maps(w, h, 1051)
             pats = synth.atlas_patches(R, w, h, 1051)
-            first = lambda s_, k_: b"".join(gs.split_pairs(s_)[:k_])
+            first = lambda s_, k_, maps=1: gs.first_pictures(s_, k_ * maps)      # the first k_ point-cloud frames of a sub-bitstream (maps: pictures per frame)
 
             def cloud(occ_plane, prec, g2):
                 return ctx.reconstruct(R.AtlasParams(w, h, 16, prec, 2, 1, 1, 0), pats, occ_plane, g2[0][: w * h].reshape(h, w), g2[1][: w * h].reshape(h, w), 10)[0]
             c_src, n_src = synth.source_normals(R, ctx.reconstruct, w, h, 1051, src["occ_full"], src["geo"])     # the source cloud with one normal per point: its patch's projection axis
-            c_in = cloud(ctx.decode(first(so, 1))[0][0][: (w // 2) * (h // 2)].reshape(h // 2, w // 2), 2, ctx.decode(first(sg, 1))[0])
-            c_out = cloud(ctx.decode(first(outs[0], 1))[0][0][: (w // 4) * (h // 4)].reshape(h // 4, w // 4), 4, ctx.decode(first(outs[1], 1))[0])
+            c_in = cloud(ctx.decode(first(so, 1))[0][0][: (w // 2) * (h // 2)].reshape(h // 2, w // 2), 2, ctx.decode(first(sg, 1, 2))[0])
+            c_out = cloud(ctx.decode(first(outs[0], 1))[0][0][: (w // 4) * (h // 4)].reshape(h // 4, w // 4), 4, ctx.decode(first(outs[1], 1, 2))[0])
             r_in, r_out, r_io = ctx.d1(c_src, c_in), ctx.d1(c_src, c_out), ctx.d1(c_in, c_out)
             p_in, p_out = ctx.d2(c_src, n_src, c_in), ctx.d2(c_src, n_src, c_out)          # D2 (point-to-plane, PCCMetrics.cpp:100-124): rbt_d2
             d1_tools = (cloud, c_src, first, n_src)
@@ -454,7 +460,7 @@ def main():
                 """D1 / D2 of point-cloud frames 0..nfr-1 (the GOF's four base atlases, tests/synth.py make_gof_maps) against their source clouds: one frame's D1 scatters by
                 +-0.3 dB with any change of the encoder (a depth error of 1 on a few thousand of 600 000 points), the mean of four is what comparisons should read"""
                 ow_, oh_ = w // prec, h // prec
-                occ_d, geo_d = ctx.decode(first(occ_stream, nfr))[0], ctx.decode(first(geo_stream, nfr))[0]
+                occ_d, geo_d = ctx.decode(first(occ_stream, nfr))[0], ctx.decode(first(geo_stream, nfr, 2))[0]
                 res = []
                 for k in range(nfr):
                     if k not in src_cache:
@@ -496,7 +502,7 @@ def main():
                       "plain_occupied_psnr_y_vs_r5_input_db": {"geometry": psnr_occ(sg, outs[1]), "attribute": psnr_occ(sa, outs[2])}}
             if d1 and "error" not in d1:
                 cloud, c_src, first, n_src = d1_tools
-                c_on = cloud(ctx.decode(first(o_on[0], 1))[0][0][: (w // 4) * (h // 4)].reshape(h // 4, w // 4), 4, ctx.decode(first(o_on[1], 1))[0])
+                c_on = cloud(ctx.decode(first(o_on[0], 1))[0][0][: (w // 4) * (h // 4)].reshape(h // 4, w // 4), 4, ctx.decode(first(o_on[1], 1, 2))[0])
                 occ_rd["d1_psnr_vs_source_db"] = round(ctx.d1(c_src, c_on)["psnr"], 3)
                 occ_rd["plain_d1_psnr_vs_source_db"] = d1["d1_psnr_r3_output_vs_source_db"]
                 occ_rd["d2_psnr_vs_source_db"] = round(ctx.d2(c_src, n_src, c_on)["psnr"], 3)
@@ -523,7 +529,7 @@ def main():
                            "geometry_psnr_y_db": psnr_y(sg, o_f[1], w, h, 1023), "attribute_psnr_y_db": psnr_y(sa, o_f[2], w, h, 1023)}
             if d1 and "error" not in d1:
                 cloud, c_src, first, n_src = d1_tools
-                c_f = cloud(ctx.decode(first(o_f[0], 1))[0][0][: (w // 4) * (h // 4)].reshape(h // 4, w // 4), 4, ctx.decode(first(o_f[1], 1))[0])
+                c_f = cloud(ctx.decode(first(o_f[0], 1))[0][0][: (w // 4) * (h // 4)].reshape(h // 4, w // 4), 4, ctx.decode(first(o_f[1], 1, 2))[0])
                 preset_fast["d1_psnr_vs_source_db"] = round(ctx.d1(c_src, c_f)["psnr"], 3)
             ctx.set_depth(D)
             k_f = min(args.steps, 32)
@@ -564,8 +570,8 @@ def main():
         import oracle_lib as O   # CPU checker, used here only as the timed CPU baseline ("port")
         k = min(args.cpu_sample, n_pc)
         # bounded sample of the same workload: the first k point-cloud frames of the same GOF
-        pairs = [gs.split_pairs(s_) for s_ in streams]      # every point-cloud frame is a closed GOP in all three sub-bitstreams
-        sub = [b"".join(p_[:k]) for p_ in pairs]
+        pairs = [gs.frame_pieces(s_, m_) for s_, m_ in zip(streams, (1, 2, 2))]      # the pictures of a point-cloud frame reference nothing outside it (CTC structure: parameter sets put in front of each piece)
+        sub = [gs.first_pictures(s_, k * m_) for s_, m_ in zip(streams, (1, 2, 2))]
         c0 = time.perf_counter()
         cpu_out = [O.transcode_substream(sub[0], 0, 8, md5_sei=0, rows_per_slice=args.rows), O.transcode_substream(sub[1], 1, 24, md5_sei=0, rows_per_slice=args.rows), O.transcode_substream(sub[2], 19, 32, md5_sei=0, rows_per_slice=args.rows)]
         ct = time.perf_counter() - c0

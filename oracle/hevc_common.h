@@ -19,6 +19,9 @@ enum { NAL_TRAIL_N = 0, NAL_TRAIL_R = 1, NAL_IDR_W_RADL = 19, NAL_IDR_N_LP = 20,
        NAL_VPS = 32, NAL_SPS = 33, NAL_PPS = 34, NAL_AUD = 35, NAL_EOS = 36, NAL_EOB = 37, NAL_FD = 38,
        NAL_SEI_PREFIX = 39, NAL_SEI_SUFFIX = 40 };
 enum { SLICE_B = 0, SLICE_P = 1, SLICE_I = 2 };
+/* 8.3.1: prevTid0Pic is the previous picture with TemporalId 0 that is not a RASL / RADL picture or a sub-layer non-reference picture (the even types up to
+ * RSV_VCL_N14, Table 7-1) - such pictures leave the POC anchor alone (HM marks the P pictures of the CTC structure TRAIL_N) */
+static inline int nal_keeps_poc_anchor(int nal_type) { return (nal_type <= 14 && (nal_type & 1) == 0) || (nal_type >= 6 && nal_type <= 9); }
 enum { PART_2Nx2N = 0, PART_2NxN, PART_Nx2N, PART_NxN, PART_2NxnU, PART_2NxnD, PART_nLx2N, PART_nRx2N };
 enum { MODE_INTER = 0, MODE_INTRA = 1, MODE_SKIP = 2 };
 

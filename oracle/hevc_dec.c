@@ -751,7 +751,8 @@ static int start_picture(oracle_hevc_decoder* d, const hevc_sps* sps, const hevc
     if (h->nal_type >= 16 && h->nal_type <= 23 && h->nal_type != NAL_CRA) msb = 0;
     h->poc = msb + h->poc_lsb;
   }
-  d->prev_tid0_poc = h->poc; d->cur_poc = h->poc;
+  if (!nal_keeps_poc_anchor(h->nal_type)) d->prev_tid0_poc = h->poc;
+  d->cur_poc = h->poc;
   if (d->n_out == d->cap_out) {
     d->cap_out = d->cap_out ? d->cap_out * 2 : 64;
     d->out = (hevc_frame**)realloc(d->out, sizeof(void*) * d->cap_out); d->col = (hevc_colinfo*)realloc(d->col, sizeof(hevc_colinfo) * d->cap_out);
@@ -883,11 +884,12 @@ int oracle_slice_headers(const uint8_t* p, size_t n, int* out, int cap) {
           if (h.poc_lsb < prev_lsb && prev_lsb - h.poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb; else if (h.poc_lsb > prev_lsb && h.poc_lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
           h.poc = msb + h.poc_lsb; }
       }
-      if (!rc && k < cap) { int* o = out + 19 * k; int intra = h.slice_type == SLICE_I; o[18] = h.dependent;
+      if (!rc && k < cap) { int* o = out + 28 * k; int intra = h.slice_type == SLICE_I; o[18] = h.dependent;
         o[0] = type; o[1] = h.segment_addr; o[2] = h.slice_type; o[3] = h.poc; o[4] = h.temporal_mvp; o[5] = h.sao_luma; o[6] = h.sao_chroma; o[7] = intra ? 0 : h.num_ref_idx[0];
         o[8] = h.cabac_init_flag; o[9] = intra ? 0 : h.collocated_ref_idx; o[10] = intra ? 0 : h.max_merge_cand; o[11] = h.qp; o[12] = h.cb_qp_offset; o[13] = h.cr_qp_offset;
-        o[14] = h.deblocking_disabled; o[15] = h.beta_offset_div2; o[16] = h.tc_offset_div2; o[17] = h.loop_filter_across_slices; }
-      if (!rc) { k++; d->prev_tid0_poc = h.poc; if (!h.dependent) { d->last_sh = h; d->have_last_sh = 1; } }
+        o[14] = h.deblocking_disabled; o[15] = h.beta_offset_div2; o[16] = h.tc_offset_div2; o[17] = h.loop_filter_across_slices;
+        { const int has_rps = type != NAL_IDR_W_RADL && type != NAL_IDR_N_LP; o[19] = has_rps ? h.rps_num : 0; for (int q = 0; q < 4; q++) { o[20 + 2 * q] = has_rps && q < h.rps_num ? h.rps_delta[q] : 0; o[21 + 2 * q] = has_rps && q < h.rps_num ? h.rps_used[q] : 0; } } }
+      if (!rc) { k++; if (!nal_keeps_poc_anchor(type)) d->prev_tid0_poc = h.poc; if (!h.dependent) { d->last_sh = h; d->have_last_sh = 1; } }
     }
     free(rb);
     if (rc) { free(d); return -1; }

@@ -127,6 +127,7 @@ typedef struct {
   const hevc_frame* src; hevc_frame* rec; hevc_meta* m;
   const hevc_frame* ref[2]; const hevc_colinfo* refcol[2]; int ref_poc[2]; int n_ref;
   int poc, slice_type, slice_qp, slice_idx, is_idr;
+  int nal_type, rps_explicit, rps_inter;   /* of the current picture (ctc_gop): NAL unit type; reference picture set coded in the slice header rather than taken from the SPS, there with inter-set prediction */
   hevc_slice_hdr sh;
   hevc_mvpred mp;
   cabac_enc c;
@@ -205,6 +206,23 @@ static void write_rps_set(bitwriter* w, int idx, int nneg) {
   bw_ue(w, nneg); bw_ue(w, 0);
   for (int i = 0; i < nneg; i++) { bw_ue(w, 0); bw_bit(w, 1); }
 }
+/* the sets of the CTC structure (ctc_gop), 7.3.7: 0 = {-1}, 1 = {-2}, 2 = {-1, -2}, every picture used by the current one */
+static void write_rps_ctc(bitwriter* w, int idx, int set) {
+  if (idx) bw_bit(w, 0);                                   /* inter_ref_pic_set_prediction_flag */
+  bw_ue(w, set == 2 ? 2 : 1); bw_ue(w, 0);                 /* num_negative_pics, num_positive_pics */
+  if (set == 2) { bw_ue(w, 0); bw_bit(w, 1); bw_ue(w, 0); bw_bit(w, 1); }
+  else { bw_ue(w, (uint32_t)set); bw_bit(w, 1); }         /* delta_poc_s0_minus1, used_by_curr_pic_s0_flag */
+}
+/* the same sets predicted from set 0 = {-1} of the SPS (slice header form, idx = num_short_term_ref_pic_sets: delta_idx_minus1 picks the set, 7.4.8):
+ * deltaRps = -1: candidates are dPoc = -1 + deltaRps = -2 (j = 0) and deltaRps itself = -1 (j = 1) */
+static void write_rps_ctc_inter(bitwriter* w, int num_sps_sets, int set) {
+  bw_bit(w, 1);                                            /* inter_ref_pic_set_prediction_flag */
+  bw_ue(w, (uint32_t)(num_sps_sets - 1));                  /* delta_idx_minus1: RefRpsIdx = num_sps_sets - (delta_idx_minus1 + 1) = 0 */
+  bw_bit(w, 1); bw_ue(w, 0);                               /* delta_rps_sign, abs_delta_rps_minus1: deltaRps = -1 */
+  const int use_m2 = set != 0, use_m1 = set != 1;
+  bw_bit(w, use_m2); if (!use_m2) bw_bit(w, 0);            /* j = 0: used_by_curr_pic_flag, else use_delta_flag = 0 (not in the set at all) */
+  bw_bit(w, use_m1); if (!use_m1) bw_bit(w, 0);            /* j = NumDeltaPocs = 1 */
+}
 static void write_param_sets(enc* e, bytebuf* out) {
   hevc_sps* s = &e->sps; hevc_pps* p = &e->pps;
   bitwriter w; memset(&w, 0, sizeof(w));
@@ -226,7 +244,7 @@ static void write_param_sets(enc* e, bytebuf* out) {
   bw_ue(&w, s->max_th_depth_inter); bw_ue(&w, s->max_th_depth_intra);
   bw_bit(&w, 0); bw_bit(&w, s->amp_enabled); bw_bit(&w, s->sao_enabled); bw_bit(&w, 0);
   bw_ue(&w, s->num_st_rps);
-  for (int i = 0; i < s->num_st_rps; i++) write_rps_set(&w, i, i + 1);
+  for (int i = 0; i < s->num_st_rps; i++) { if (e->p.ctc_gop) write_rps_ctc(&w, i, i); else write_rps_set(&w, i, i + 1); }
   bw_bit(&w, 0); bw_bit(&w, s->temporal_mvp_enabled); bw_bit(&w, s->strong_intra_smoothing);
   bw_bit(&w, 0); bw_bit(&w, 0); bw_trailing(&w);
   emit_nal(out, NAL_SPS, w.bb.d, w.bb.n, 1);
@@ -280,8 +298,8 @@ static void write_slice_header(enc* e, bitwriter* w, int first, int ctb_addr, in
   bw_ue(w, h->slice_type);
   if (!e->is_idr) {
     bw_u(w, e->poc & ((1 << s->log2_max_poc_lsb) - 1), s->log2_max_poc_lsb);
-    bw_bit(w, 1);
-    if (s->num_st_rps > 1) bw_u(w, h->st_rps_idx, ceil_log2(s->num_st_rps));
+    if (e->rps_explicit) { bw_bit(w, 0); if (e->rps_inter) write_rps_ctc_inter(w, s->num_st_rps, h->st_rps_idx); else write_rps_ctc(w, s->num_st_rps, h->st_rps_idx); }
+    else { bw_bit(w, 1); if (s->num_st_rps > 1) bw_u(w, h->st_rps_idx, ceil_log2(s->num_st_rps)); }
     if (s->temporal_mvp_enabled) bw_bit(w, h->temporal_mvp);
   }
   if (s->sao_enabled) { bw_bit(w, h->sao_luma); bw_bit(w, h->sao_chroma); }
@@ -1512,7 +1530,7 @@ static void setup_stream(enc* e) {
   memset(s, 0, sizeof(*s)); memset(p, 0, sizeof(*p));
   s->width = q->width; s->height = q->height; s->bit_depth = s->bit_depth_c = q->bit_depth; s->chroma_format_idc = 1;
   s->conf_win[0] = s->conf_win[2] = 0; s->conf_win[1] = q->conf_win_right; s->conf_win[3] = q->conf_win_bottom;
-  s->log2_max_poc_lsb = 8; s->max_dec_pic_buffering = 3;
+  s->log2_max_poc_lsb = q->log2_max_poc_lsb ? clip3(4, 16, q->log2_max_poc_lsb) : 8; s->max_dec_pic_buffering = 3;
   s->log2_ctb = q->log2_ctb ? q->log2_ctb : 5;
   s->log2_min_cb = 3; s->log2_diff_max_min_cb = s->log2_ctb - 3;
   s->log2_min_tb = 2; s->log2_max_tb = imin(5, s->log2_ctb); s->log2_diff_max_min_tb = s->log2_max_tb - 2;
@@ -1559,6 +1577,7 @@ static void setup_stream(enc* e) {
     p->num_ref_idx_default[0] = 1 + (e->two_refs && rndp(r, 50));
     p->entropy_coding_sync = rndp(r, 40); p->dependent_slice_segments_enabled = rndp(r, 40);
   }
+  if (q->ctc_gop) { s->num_st_rps = e->two_refs ? 3 : (!e->stress && q->gop <= 1) ? 1 : 2; if (s->max_dec_pic_buffering < 4) s->max_dec_pic_buffering = 4; }   /* {-1}, {-2} as in the GOP table of the CTC (+ {-1,-2}) */
   s->pic_w_ctb = (s->width + (1 << s->log2_ctb) - 1) >> s->log2_ctb; s->pic_h_ctb = (s->height + (1 << s->log2_ctb) - 1) >> s->log2_ctb;
 }
 
@@ -1600,7 +1619,7 @@ static void encode_slices(enc* e, int is_i, int st_rps_idx, bytebuf* out) {
         if (p->deblocking_override_enabled && rndp(r, 50)) { h->deblocking_disabled = rndp(r, 20); if (!h->deblocking_disabled) { h->beta_offset_div2 = rndn(r, 9) - 4; h->tc_offset_div2 = rndn(r, 9) - 4; } else { h->beta_offset_div2 = p->beta_offset_div2; h->tc_offset_div2 = p->tc_offset_div2; } }
         if (p->loop_filter_across_slices && (h->sao_luma || h->sao_chroma || !h->deblocking_disabled)) h->loop_filter_across_slices = rndp(r, 70);
       } else h->qp = clip3(0, 51, is_i ? e->p.qp + e->p.i_qp_offset : e->p.qp + (e->hm ? e->p.p_qp_offset : 0));
-      if (e->hm && !is_i) { h->temporal_mvp = s->temporal_mvp_enabled; h->collocated_ref_idx = 0; }
+      if (e->hm && (!is_i || (e->p.ctc_gop && !e->is_idr))) { h->temporal_mvp = s->temporal_mvp_enabled; h->collocated_ref_idx = 0; }   /* HM (TMVPMode 1) sets the flag on every slice that carries it, I slices of trailing pictures included */
       if (!e->stress && e->hm_pass == 2) { h->sao_luma = 1; h->sao_chroma = 1; }
       e->slice_qp = h->qp; e->slice_idx = m->n_slices++;
       hevc_slice_meta* sm = &m->slices[e->slice_idx]; memset(sm, 0, sizeof(*sm));
@@ -1649,7 +1668,7 @@ static void encode_slices(enc* e, int is_i, int st_rps_idx, bytebuf* out) {
     write_slice_header(e, &hw, addr == 0, addr, dependent, sub_size, n_sub);
     size_t tot = hw.bb.n + e->c.w.bb.n; uint8_t* nal = (uint8_t*)malloc(tot ? tot : 1);
     memcpy(nal, hw.bb.d, hw.bb.n); memcpy(nal + hw.bb.n, e->c.w.bb.d, e->c.w.bb.n);
-    emit_nal(out, is_i ? NAL_IDR_W_RADL : NAL_TRAIL_R, nal, tot, addr == 0);
+    emit_nal(out, e->nal_type, nal, tot, addr == 0);
     free(nal); free(hw.bb.d);
     addr = end_addr; seg_no++;
   }
@@ -1661,8 +1680,20 @@ static void encode_picture(enc* e, const hevc_frame* src, int idx, bytebuf* out,
   int is_i;
   if (e->stress) is_i = idx == 0 || (idx % 5 == 0 && (e->p.stress_seed & 1));
   else is_i = e->p.gop <= 1 || (idx % e->p.gop) == 0;
-  e->is_idr = is_i; e->slice_type = is_i ? SLICE_I : SLICE_P;
-  if (is_i) { e->poc = 0; e->n_dpb = 0; write_param_sets(e, out); } else e->poc++;
+  const int ctc = e->p.ctc_gop, sidx = idx + (ctc ? e->p.first_idx : 0);   /* ctc_gop: index inside the stream */
+  if (ctc) { const int g = e->stress ? 2 + (int)((e->p.stress_seed >> 1) & 1) : (e->p.gop > 1 ? e->p.gop : 1); is_i = sidx % g == 0; }   /* random-syntax streams: I P I P or I P P I P P */
+  e->is_idr = is_i && (!ctc || sidx == 0); e->slice_type = is_i ? SLICE_I : SLICE_P;
+  e->nal_type = e->is_idr ? NAL_IDR_W_RADL : NAL_TRAIL_R; e->rps_explicit = e->rps_inter = 0;
+  if (e->is_idr) { e->poc = 0; e->n_dpb = 0; write_param_sets(e, out); }
+  else if (ctc && idx == 0) { e->poc = sidx; e->n_dpb = 0; }   /* a piece of a longer stream: nothing before it is referenced (first_idx starts a group) */
+  else e->poc++;
+  if (ctc == 1 && !e->is_idr) {
+    /* HM: a picture no entry of the GOP table references is a sub-layer non-reference picture (TRAIL_N). Structural, like HM's rule: the next picture is a P picture
+     * (references POC - 1), or the one after it is a P picture with two references */
+    const int g = e->stress ? 2 + (int)((e->p.stress_seed >> 1) & 1) : (e->p.gop > 1 ? e->p.gop : 1);
+    const int next_p = (sidx + 1) % g != 0, next2_p = (sidx + 2) % g != 0;
+    if (g > 1 && !next_p && !(e->two_refs && next2_p)) e->nal_type = NAL_TRAIL_N;   /* (all-intra occupancy, ctc-hm-occupancy-map-ai-main10.cfg:22-29: the one GOP entry lists -1, so every picture counts as referenced) */
+  }
   e->hints = (e->p.hint_modes && !e->stress && !e->hm) ? e->p.hint_modes[idx] : NULL;
   e->occ4 = (e->p.occ4 && !e->stress && !e->hm && !e->p.lossless) ? e->p.occ4[idx] : NULL;
   e->src = src; e->rec = hevc_frame_alloc(s->width, s->height, s->bit_depth);
@@ -1674,9 +1705,11 @@ static void encode_picture(enc* e, const hevc_frame* src, int idx, bytebuf* out,
   if (!is_i) {
     int nref_avail = imin(e->n_dpb, e->two_refs ? 2 : 1);
     st_rps_idx = nref_avail - 1;
+    if (ctc) { nref_avail = (e->two_refs && e->n_dpb >= 2 && e->dpb_poc[1] == e->poc - 2) ? 2 : 1; st_rps_idx = nref_avail == 2 ? 2 : 0; }   /* {-1} or {-1,-2} */
     for (int i = 0; i < nref_avail; i++) { e->ref[i] = e->dpb[i]; e->refcol[i] = &e->dpbcol[i]; e->ref_poc[i] = e->dpb_poc[i]; }
     e->n_ref = nref_avail;
-  }
+  } else if (ctc && !e->is_idr) st_rps_idx = s->num_st_rps == 1 ? 0 : e->two_refs ? 2 : 1;   /* the GOP table's set of the I picture, {-2}: kept in the buffer, not used ({-1,-2} where P pictures take two references: a set must hold what later pictures reference) */
+  if (ctc && e->stress && !e->is_idr) { e->rps_explicit = ((e->p.stress_seed >> 2) + sidx) % 3 == 0; e->rps_inter = e->rps_explicit && (sidx & 1) == ((e->p.stress_seed >> 4) & 1); }
   if (!e->stress && s->sao_enabled) {
     /* SAO parameters come from the deblocked reconstruction but are coded in front of each CTB: code the picture once without SAO to get
      * that reconstruction, decide the parameters, then code it again (the CU decisions use no entropy-coder state, so they repeat exactly) */

@@ -31,6 +31,16 @@ typedef struct {
    * transform-skip decisions and of the SAO statistics. Mode and split decisions look at every sample: the closer the unoccupied area stays to the
    * source's padding, the better the occupied blocks next to it predict (measured: masking them as well costs 35 % more geometry bytes and 0.3 dB D1). */
   const uint8_t* const* occ4; int occ4_w, occ4_h;
+  /* Stream structure of the CTC's HM encoder (cfg/hm/ctc-hm-geometry-ai.cfg:21-30, same in ctc-hm-attribute-ai.cfg: IntraPeriod -1, GOPSize 2, Frame1: P ref -1,
+   * Frame2: I with RPS -2, ReWriteParamSetsFlag at IRAPs only): 0 = closed groups (every I picture an IDR with parameter sets, POC restarts);
+   * 1 = ONE IDR_W_RADL with the parameter sets, every later picture a trailing picture with POC running on: I pictures are TRAIL_R with slice_type I and the
+   * GOP table's reference picture set, pictures nobody references are TRAIL_N (HM: TemporalLayerNonReferenceFlag from the GOP entry's m_refPic), P pictures
+   * reference POC - 1 (and POC - 2 with two references); 2 = the same with every trailing picture a TRAIL_R. The SPS carries the sets {-1}, {-2} (and {-1,-2}).
+   * Random-syntax streams in this structure (stress_seed) also code sets explicitly in the slice header, with and without inter-set prediction. */
+  int ctc_gop;
+  int log2_max_poc_lsb;     /* 0 = 8 (HM's default); 4..16: pic_order_cnt_lsb wraps every 2^n pictures */
+  int first_idx;            /* ctc_gop: index inside the stream of frames[0] (frames are independent of each other but for the headers: a long stream can be made
+                               in pieces by parallel workers and concatenated; first_idx must start a group) */
   int tools_off;            /* RBT-E1 decision tools to leave out: 1 SATD block costs, 2 closed-loop mode choice, 4 rounding by level and position, 16 coded trial of the two cheapest modes (the library's RBT_ET_* bits; oracle_transcode_params.preset) */
 } oracle_enc_params;
 

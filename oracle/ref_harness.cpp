@@ -102,6 +102,7 @@ int main(int argc, char** argv) {
     // short-term RPS i of the SPS = the i + 1 preceding pictures, all used (what oracle/hevc_enc.c writes). The PPS is the reference's own parse.
     std::vector<uint8_t> buf = readFile(argv[2]);
     const int bitsPoc = atoi(argv[3]), log2Ctb = atoi(argv[4]), sao = atoi(argv[5]), tmvp = atoi(argv[6]), nRps = atoi(argv[7]);
+    const int ctcSets = argc >= 9 ? atoi(argv[8]) : 0;   // 1: the sets of the CTC structure (oracle_enc_params.ctc_gop): {-1}, {-2}, {-1,-2}
     const int size = (int)buf.size(); const uint8_t* data = buf.data();
     TDecCavlc* dec = new TDecCavlc();
     ParameterSetManager psm;
@@ -122,6 +123,12 @@ int main(int argc, char** argv) {
           s->createRPSList(nRps);
           for (int r = 0; r < nRps; r++) {
             TComReferencePictureSet* rps = s->getRPSList()->getReferencePictureSet(r);
+            if (ctcSets) {
+              const int np = r == 2 ? 2 : 1;
+              rps->setInterRPSPrediction(false); rps->setNumberOfNegativePictures(np); rps->setNumberOfPositivePictures(0); rps->setNumberOfPictures(np);
+              if (r == 2) { rps->setDeltaPOC(0, -1); rps->setDeltaPOC(1, -2); rps->setUsed(0, true); rps->setUsed(1, true); } else { rps->setDeltaPOC(0, -(r + 1)); rps->setUsed(0, true); }
+              continue;
+            }
             rps->setInterRPSPrediction(false); rps->setNumberOfNegativePictures(r + 1); rps->setNumberOfPositivePictures(0); rps->setNumberOfPictures(r + 1);
             for (int j = 0; j <= r; j++) { rps->setDeltaPOC(j, -(j + 1)); rps->setUsed(j, true); }
           }
@@ -133,7 +140,7 @@ int main(int argc, char** argv) {
           dec->parseSliceHeader(&slice, &psm, prevPoc);
           // a dependent slice segment carries nothing but its address: parseSliceHeader leaves the slice object as initSlice made it and the reference's
           // caller fills it from the previous segment (TDecTop, copySliceInfo); the same is done here with the values of the slice's independent segment
-          static int v[16];
+          static int v[16]; static char rpsText[128] = "[]";
           const int dep = slice.getDependentSliceSegmentFlag() ? 1 : 0;
           if (!dep) {
             v[0] = (int)slice.getSliceType(); v[1] = slice.getPOC(); v[2] = (int)slice.getEnableTMVPFlag(); v[3] = (int)slice.getSaoEnabledFlag(CHANNEL_TYPE_LUMA);
@@ -141,13 +148,19 @@ int main(int argc, char** argv) {
             v[7] = slice.isIntra() ? 0 : (int)slice.getColRefIdx(); v[8] = slice.isIntra() ? 0 : (int)slice.getMaxNumMergeCand(); v[9] = slice.getSliceQp();
             v[10] = slice.getSliceChromaQpDelta(COMPONENT_Cb); v[11] = slice.getSliceChromaQpDelta(COMPONENT_Cr); v[12] = (int)slice.getDeblockingFilterDisable();
             v[13] = slice.getDeblockingFilterBetaOffsetDiv2(); v[14] = slice.getDeblockingFilterTcOffsetDiv2(); v[15] = (int)slice.getLFCrossSliceBoundaryFlag();
+            // the slice's short-term reference picture set as parseSliceHeader left it (from the SPS by index, or parseShortTermRefPicSet on the header's own set)
+            int o = snprintf(rpsText, sizeof(rpsText), "[");
+            const TComReferencePictureSet* rps = slice.getRPS();
+            if (!slice.getIdrPicFlag() && rps) for (int j = 0; j < rps->getNumberOfPictures() && j < 4; j++) o += snprintf(rpsText + o, sizeof(rpsText) - o, "%s[%d,%d]", j ? "," : "", rps->getDeltaPOC(j), (int)rps->getUsed(j));
+            snprintf(rpsText + o, sizeof(rpsText) - o, "]");
           }
           printf("%s{\"nal_type\":%d,\"address\":%d,\"dependent\":%d,\"slice_type\":%d,\"poc\":%d,\"tmvp\":%d,\"sao_luma\":%d,\"sao_chroma\":%d,\"num_ref_idx\":%d,\"cabac_init\":%d,"
                  "\"col_ref_idx\":%d,\"max_merge_cand\":%d,\"qp\":%d,\"cb_qp_offset\":%d,\"cr_qp_offset\":%d,\"deblocking_disabled\":%d,\"beta_offset_div2\":%d,"
-                 "\"tc_offset_div2\":%d,\"lf_across\":%d}\n", n++ ? "," : "", type, (int)slice.getSliceSegmentCurStartCtuTsAddr(), dep, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9],
-                 v[10], v[11], v[12], v[13], v[14], v[15]);
-          if (dep) { prevPoc = v[1]; if (i < size) { sc = data[i + 2] == 0 ? 4 : 3; index = i; i += sc; } continue; }
-          prevPoc = slice.getPOC();
+                 "\"tc_offset_div2\":%d,\"lf_across\":%d,\"rps\":%s}\n", n++ ? "," : "", type, (int)slice.getSliceSegmentCurStartCtuTsAddr(), dep, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9],
+                 v[10], v[11], v[12], v[13], v[14], v[15], rpsText);
+          const bool keepsAnchor = (type <= 14 && (type & 1) == 0) || (type >= 6 && type <= 9);   // 8.3.1: RASL / RADL / sub-layer non-reference pictures are not prevTid0Pic
+          if (dep) { if (!keepsAnchor) prevPoc = v[1]; if (i < size) { sc = data[i + 2] == 0 ? 4 : 3; index = i; i += sc; } continue; }
+          if (!keepsAnchor) prevPoc = slice.getPOC();
         }
         if (i < size) { sc = data[i + 2] == 0 ? 4 : 3; index = i; i += sc; }
       }
@@ -155,6 +168,6 @@ int main(int argc, char** argv) {
     printf("]\n");
     return 0;
   }
-  fprintf(stderr, "usage: %s tables | hls <annexb> | slices <annexb> <log2_max_poc_lsb> <log2_ctb> <sao> <tmvp> <num_st_rps>\n", argv[0]);
+  fprintf(stderr, "usage: %s tables | hls <annexb> | slices <annexb> <log2_max_poc_lsb> <log2_ctb> <sao> <tmvp> <num_st_rps> [ctc_sets]\n", argv[0]);
   return 1;
 }

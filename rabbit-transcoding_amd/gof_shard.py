@@ -251,15 +251,74 @@ def split_pairs(stream: bytes) -> List[bytes]:
         if (stream[i + 3] >> 1) & 63 == 32:          # VPS
             cuts.append(i - 1 if i > 0 and stream[i - 1] == 0 else i)
         i = stream.find(b"\x00\x00\x01", i + 3)
-    assert cuts and cuts[0] == 0, "stream does not start with a VPS"
+    if not cuts or cuts[0] != 0: raise ValueError("stream does not start with a VPS")
     cuts.append(len(stream))
     return [stream[a:b] for a, b in zip(cuts, cuts[1:])]
+
+
+def access_units(stream: bytes) -> List[bytes]:
+    """An Annex-B sub-bitstream cut into access units (7.4.2.4.4): a unit starts at the first parameter set / AUD / prefix SEI after the last slice segment of the
+    picture before it, or at a slice segment with first_slice_segment_in_pic_flag; suffix SEI (the hash of the CTC streams) stay with their picture."""
+    starts, i = [], stream.find(b"\x00\x00\x01")
+    while i >= 0:
+        starts.append(i)
+        i = stream.find(b"\x00\x00\x01", i + 3)
+    cuts, have_vcl = [], False
+    for i in starts:
+        t = (stream[i + 3] >> 1) & 63
+        at = i - 1 if i > 0 and stream[i - 1] == 0 else i            # a four-byte start code belongs to its NAL unit
+        if t < 32:
+            if i + 5 < len(stream) and stream[i + 5] & 0x80 and (have_vcl or not cuts): cuts.append(at)
+            have_vcl = True
+        elif t in (32, 33, 34, 35, 39) or 41 <= t <= 44 or 48 <= t <= 55:
+            if have_vcl or not cuts: cuts.append(at); have_vcl = False
+    cuts = sorted(set(cuts)) + [len(stream)]
+    return [stream[a:b] for a, b in zip(cuts, cuts[1:])]
+
+
+def parameter_sets(stream: bytes) -> bytes:
+    """The VPS / SPS / PPS NAL units in front of the first picture."""
+    i, end = stream.find(b"\x00\x00\x01"), 0
+    while i >= 0:
+        if not 32 <= ((stream[i + 3] >> 1) & 63) <= 34: break
+        nxt = stream.find(b"\x00\x00\x01", i + 3)
+        end = len(stream) if nxt < 0 else (nxt - 1 if stream[nxt - 1] == 0 else nxt)
+        i = nxt
+    return stream[:end]
+
+
+def is_closed_pairs(stream: bytes) -> bool:
+    """True for a stream of closed groups that each bring their parameter sets (what split_pairs cuts); False for the structure of the CTC's HM encoder - ONE IDR
+    with the parameter sets, then trailing pictures with POC running on (cfg/hm/ctc-hm-geometry-ai.cfg:21-30): such a stream has no cut points."""
+    return stream.count(b"\x00\x00\x01\x40\x01") > 1
+
+
+def first_pictures(stream: bytes, n: int) -> bytes:
+    """The first n pictures of a sub-bitstream (whole access units). A prefix of a stream is a stream in either structure."""
+    return b"".join(access_units(stream)[:n])
+
+
+def frame_pieces(stream: bytes, pictures_per_frame: int) -> List[bytes]:
+    """One byte string per point-cloud frame (pictures_per_frame pictures: 2 maps, 1 occupancy picture), each handed to a decoder on its own: the closed groups of a
+    closed stream as they are; for the CTC structure (pictures reference nothing outside their frame, but only the first frame carries parameter sets and an IRAP
+    picture) the parameter sets are put in front of every later frame - a decoder that does not insist on an IRAP start (this library, the oracle) reads them alike."""
+    if is_closed_pairs(stream):
+        return split_pairs(stream)
+    aus, ps = access_units(stream), parameter_sets(stream)
+    return [(b"" if k == 0 else ps) + b"".join(aus[k:k + pictures_per_frame]) for k in range(0, len(aus), pictures_per_frame)]
 
 
 def make_sequence(gof: Sequence[bytes], n_frames: int, gof_size: int = 32) -> List[List[bytes]]:
     """A synthetic sequence of ceil(n_frames / gof_size) GOFs from ONE [occupancy, geometry, attribute] GOF of gof_size frames:
     GOF g holds the point-cloud frames (7 g + i) mod gof_size, i < its length - every GOF differs and the last one is shorter
-    (300 frames -> 9 x 32 + 12). Valid because every point-cloud frame is a closed GOP in all three sub-bitstreams."""
+    (300 frames -> 9 x 32 + 12). Valid because every point-cloud frame is a closed GOP in all three sub-bitstreams.
+    A GOF in the structure of the CTC's HM encoder (one IDR per sub-bitstream, is_closed_pairs false) cannot be re-ordered: there GOF g is the first
+    min(gof_size, frames left) frames of the given one (the GOFs only differ in length)."""
+    if not any(is_closed_pairs(s) for s in gof):
+        pics = [len(access_units(s)) for s in gof]
+        if any(p % gof_size for p in pics): raise ValueError(f"sub-bitstreams of {pics} pictures do not hold {gof_size} point-cloud frames")
+        return [[first_pictures(s, n * (p // gof_size)) for s, p in zip(gof, pics)] for n in gof_lengths(n_frames, gof_size)]
+    if not all(is_closed_pairs(s) for s in gof): raise ValueError("sub-bitstreams of one GOF in different structures (closed groups and the CTC encoder's)")
     parts = [split_pairs(s) for s in gof]
     assert all(len(p) == gof_size for p in parts), [len(p) for p in parts]
     seq = []

@@ -33,17 +33,7 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
         if (rc) { delete ps; b.err_code = rc == -3 ? RBT_ERR_UNSUPPORTED : RBT_ERR_BITSTREAM; return b.err_code; }
         const Pps& pps = ps->pps[h.pps_id]; const Sps& sps = ps->sps[pps.sps_id];
         if (h.first_slice_in_pic) {
-          bool idr = nal.type == NAL_IDR_W_RADL || nal.type == NAL_IDR_N_LP;
-          if (idr) h.poc = 0;
-          else {
-            int max_lsb = 1 << sps.log2_max_poc_lsb, prev_lsb = prev_tid0_poc & (max_lsb - 1), prev_msb = prev_tid0_poc - prev_lsb, msb;
-            if (h.poc_lsb < prev_lsb && prev_lsb - h.poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb;
-            else if (h.poc_lsb > prev_lsb && h.poc_lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
-            else msb = prev_msb;
-            if (nal.type >= 16 && nal.type <= 23 && nal.type != NAL_CRA) msb = 0;
-            h.poc = msb + h.poc_lsb;
-          }
-          prev_tid0_poc = h.poc;
+          h.poc = slice_poc(sps, nal.type, h.poc_lsb, prev_tid0_poc);
           RbtFrame f; memset(&f, 0, sizeof(f));
           fill_stream_cfg(sps, pps, f.cfg); f.poc = h.poc; f.first_slice = (int)b.slices.size();
           int ctb = 1 << sps.log2_ctb; f.cmd_cap = 2 * (ctb / 4) * (ctb / 4);

@@ -151,6 +151,20 @@ int parse_pps(ParamSets& ps, const uint8_t* rbsp, size_t n, std::string& err) {
   return 0;
 }
 
+int slice_poc(const Sps& s, int nal_type, int poc_lsb, int& prev_tid0_poc) {
+  int poc = 0;
+  if (nal_type != NAL_IDR_W_RADL && nal_type != NAL_IDR_N_LP) {
+    const int max_lsb = 1 << s.log2_max_poc_lsb, prev_lsb = prev_tid0_poc & (max_lsb - 1), prev_msb = prev_tid0_poc - prev_lsb; int msb = prev_msb;
+    if (poc_lsb < prev_lsb && prev_lsb - poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb;
+    else if (poc_lsb > prev_lsb && poc_lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
+    if (nal_type >= 16 && nal_type <= 18) msb = 0;                                      // BLA pictures
+    poc = msb + poc_lsb;
+  }
+  const bool leading_or_slnr = (nal_type <= 14 && (nal_type & 1) == 0) || (nal_type >= 6 && nal_type <= 9);
+  if (!leading_or_slnr) prev_tid0_poc = poc;
+  return poc;
+}
+
 int parse_slice_header(ParamSets& ps, const uint8_t* rbsp, size_t n, int nal_type, SliceHdr& h, std::string& err, const SliceHdr* head) {
   BitReader b{rbsp, n, 16};
   h = SliceHdr(); h.nal_type = nal_type;

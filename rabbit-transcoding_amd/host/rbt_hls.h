@@ -73,6 +73,9 @@ int parse_pps(ParamSets& ps, const uint8_t* rbsp, size_t n, std::string& err);
 // `head`: the header of the slice's independent segment (what a dependent slice segment repeats), nullptr when there is none yet
 int parse_slice_header(ParamSets& ps, const uint8_t* rbsp, size_t n, int nal_type, SliceHdr& h, std::string& err, const SliceHdr* head = nullptr);
 bool parse_md5_sei(const uint8_t* rbsp, size_t n, uint8_t md5[3][16]);
+// PicOrderCntVal of a picture (8.3.1) from slice_pic_order_cnt_lsb; `prev_tid0_poc` is the POC anchor (prevTid0Pic), moved on unless the picture is a RASL / RADL
+// or sub-layer non-reference picture (the even NAL types up to 14: HM codes the P pictures of the CTC structure as TRAIL_N, cfg/hm/ctc-hm-geometry-ai.cfg:29)
+int slice_poc(const Sps& s, int nal_type, int poc_lsb, int& prev_tid0_poc);
 
 void fill_stream_cfg(const Sps& s, const Pps& p, RbtStreamCfg& c);
 

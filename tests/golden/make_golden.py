@@ -41,6 +41,7 @@ def main():
     slice_goldens()
 
 
+CTC_SEEDS = (2, 5, 6, 9, 11, 16)   # random-syntax streams in the CTC structure: 2, 6: I P P groups; 5, 9, 11: every trailing picture TRAIL_R; explicit / predicted sets
 WAVE_SEEDS = (13, 17)    # random-syntax streams with entropy_coding_sync (13: with dependent slice segments as well)
 
 
@@ -58,6 +59,19 @@ def slice_goldens():
         bs = O.encode(zeros, 96, 64, 10, qp=30, gop=2, stress_seed=seed, log2_ctb=0)[0]
         sps = O.sps_fields(bs)
         cases[f"stress{seed}"] = (bs, [sps["log2_max_poc_lsb"], sps["log2_ctb"], sps["sao"], sps["tmvp"], sps["num_st_rps"]])
+    # The structure of the CTC's HM encoder (cfg/hm/ctc-hm-geometry-ai.cfg:21-30: one IDR, then TRAIL_N P pictures and TRAIL_R intra pictures with the GOP
+    # table's reference picture sets, POC running on and wrapping its lsb, parameter sets only at the IDR): the HM-like mode in both NAL type variants, and
+    # random-syntax streams (I P I P / I P P, two references, sets coded in the slice header with and without inter-set prediction). Last argument 1: the
+    # harness builds the SPS's sets {-1}, {-2}, {-1,-2} (the reference's parseSPS does not keep them).
+    geo20 = np.concatenate([m["geo"]] * 10)
+    attr20 = np.concatenate([m["attr"]] * 10)
+    cases["ctc_hm_geo"] = (O.encode_ctc(geo20, 128, 128, 10, 16, ctc_gop=1, log2_max_poc_lsb=4, p_qp_offset=-3)[0], [4, 6, 1, 1, 2, 1])
+    cases["ctc_hm_attr_trail_r"] = (O.encode_ctc(attr20, 128, 128, 10, 22, ctc_gop=2, log2_max_poc_lsb=5)[0], [5, 6, 1, 1, 2, 1])
+    zeros23 = np.zeros((23, 96 * 64 * 3 // 2), np.uint16)
+    for seed in CTC_SEEDS:
+        bs = O.encode_ctc(zeros23, 96, 64, 10, 30, ctc_gop=1 + seed % 2, log2_max_poc_lsb=4 + seed % 3, hm=0, stress_seed=seed)[0]
+        sps = O.sps_fields(bs)
+        cases[f"ctc_stress{seed}"] = (bs, [sps["log2_max_poc_lsb"], sps["log2_ctb"], sps["sao"], sps["tmvp"], sps["num_st_rps"], 1])
     for name, (bs, a) in cases.items():
         p = os.path.join(HERE, f"slices_{name}.annexb")
         open(p, "wb").write(bs)

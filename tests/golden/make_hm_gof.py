@@ -21,8 +21,18 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 
 def _encode(args):
-    kind, frames, w, h = args
+    kind, frames, w, h, ctc, first = args
     import oracle_lib as O
+    if ctc:
+        # the CTC encoder's stream structure (oracle_enc_params.ctc_gop = 1): one IDR with the parameter sets, then TRAIL_N P pictures / TRAIL_R intra pictures with the
+        # GOP table's reference picture sets, POC running on (5 lsb bits: it wraps once in 64 pictures; HM's default of 8 would not); the occupancy stream
+        # (IntraPeriod 1, DecodingRefreshType 0) is one IDR and TRAIL_R intra pictures. A piece only depends on its position (first_idx): same bytes as one serial run.
+        kw = dict(ctc_gop=1, log2_max_poc_lsb=5, first_idx=first, want_recon=False)
+        if kind == "geo":
+            return O.encode_ctc(frames, w, h, 10, 16, i_qp_offset=-3, p_qp_offset=-3, md5_sei=1, **kw)[0]
+        if kind == "attr":
+            return O.encode_ctc(frames, w, h, 10, 22, i_qp_offset=-3, p_qp_offset=0, md5_sei=1, **kw)[0]
+        return O.encode_ctc(frames, w, h, 8, 8, gop=1, i_qp_offset=0, lossless=1, md5_sei=0, **kw)[0]
     if kind == "geo":
         return O.encode_hm(frames, w, h, 10, 16, gop=2, i_qp_offset=-3, p_qp_offset=-3, md5_sei=1, want_recon=False)[0]
     if kind == "attr":
@@ -37,6 +47,7 @@ def main():
     ap.add_argument("--height", type=int, default=1280)
     ap.add_argument("--jobs", type=int, default=7)
     ap.add_argument("--seed", type=int, default=1051)
+    ap.add_argument("--ctc", type=int, default=0, help="1: the stream structure of the CTC's HM encoder (cfg/hm/ctc-hm-geometry-ai.cfg:21-30) instead of closed (IDR, P) pairs; files hm_r5ctc_*")
     a = ap.parse_args()
     import oracle_lib as O
     import synth
@@ -45,19 +56,19 @@ def main():
     geo, attr, occ = synth.make_gof_maps(w, h, n, a.seed)
     tasks = []
     for i in range(n):
-        tasks += [("attr", attr[2 * i:2 * i + 2], w, h), ("geo", geo[2 * i:2 * i + 2], w, h), ("occ", occ[i:i + 1], w // 2, h // 2)]
+        tasks += [("attr", attr[2 * i:2 * i + 2], w, h, a.ctc, 2 * i), ("geo", geo[2 * i:2 * i + 2], w, h, a.ctc, 2 * i), ("occ", occ[i:i + 1], w // 2, h // 2, a.ctc, i)]
     with ProcessPoolExecutor(a.jobs) as ex:
         res = list(ex.map(_encode, tasks))
     streams = {"attr": b"".join(res[0::3]), "geo": b"".join(res[1::3]), "occ": b"".join(res[2::3])}
-    man = {"generator": "tests/golden/make_hm_gof.py", "frames": n, "width": w, "height": h, "seed": a.seed, "streams": {}}
+    man = {"generator": "tests/golden/make_hm_gof.py" + (" --ctc 1" if a.ctc else ""), "frames": n, "width": w, "height": h, "seed": a.seed, "streams": {}}
     for k, v in streams.items():
-        name = f"hm_r5_{w}x{h}_f{n}_{k}.annexb"
+        name = f"hm_r5{'ctc' if a.ctc else ''}_{w}x{h}_f{n}_{k}.annexb"
         open(os.path.join(HERE, name), "wb").write(v)
         man["streams"][k] = {"file": name, "bytes": len(v), "md5": hashlib.md5(v).hexdigest()}
         print(name, len(v), man["streams"][k]["md5"])
     mpath = os.path.join(HERE, "hm_r5_manifest.json")
     allm = json.load(open(mpath)) if os.path.exists(mpath) else {}
-    allm[f"{w}x{h}_f{n}"] = man
+    allm[f"{w}x{h}_f{n}" + ("_ctc" if a.ctc else "")] = man
     json.dump(allm, open(mpath, "w"), indent=1)
 
 

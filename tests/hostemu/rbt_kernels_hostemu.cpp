@@ -184,19 +184,15 @@ extern "C" int rbt_hostemu_slice_headers(const uint8_t* annexb, size_t n, int* o
       static thread_local rbt::SliceHdr head; static thread_local bool have_head = false; if (k == 0) have_head = false;
       rbt::SliceHdr h; if (rbt::parse_slice_header(*ps, r, nal.rbsp_size, nal.type, h, err, have_head ? &head : nullptr)) { delete ps; return -1; }
       if (h.dependent) { h.poc = head.poc; h.poc_lsb = head.poc_lsb; }
-      { // PicOrderCntVal (8.3.1) the way host/rbt_decode.cpp derives it from slice_pic_order_cnt_lsb
+      { // PicOrderCntVal (8.3.1) by the function host/rbt_decode.cpp uses
         const rbt::Sps& sp = ps->sps[ps->pps[h.pps_id].sps_id];
-        if (nal.type == 19 || nal.type == 20) h.poc = 0;
-        else { const int max_lsb = 1 << sp.log2_max_poc_lsb, prev_lsb = prev_poc & (max_lsb - 1), prev_msb = prev_poc - prev_lsb; int msb = prev_msb;
-          if (h.poc_lsb < prev_lsb && prev_lsb - h.poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb; else if (h.poc_lsb > prev_lsb && h.poc_lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
-          h.poc = msb + h.poc_lsb; }
-        if (h.dependent) h.poc = head.poc;
-        prev_poc = h.poc; }
+        if (h.dependent) h.poc = head.poc; else h.poc = rbt::slice_poc(sp, nal.type, h.poc_lsb, prev_poc); }
       if (!h.dependent) { head = h; have_head = true; }
-      if (k < cap) { int* o = out + 19 * k; const int intra = h.slice_type == RBT_SLICE_I; o[18] = h.dependent;
+      if (k < cap) { int* o = out + 28 * k; const int intra = h.slice_type == RBT_SLICE_I; o[18] = h.dependent;
         o[0] = nal.type; o[1] = h.segment_addr; o[2] = h.slice_type; o[3] = h.poc; o[4] = h.temporal_mvp; o[5] = h.sao_luma; o[6] = h.sao_chroma; o[7] = intra ? 0 : h.num_ref_idx;
         o[8] = h.cabac_init_flag; o[9] = intra ? 0 : h.collocated_ref_idx; o[10] = intra ? 0 : h.max_merge_cand; o[11] = h.qp; o[12] = h.cb_qp_offset; o[13] = h.cr_qp_offset;
-        o[14] = h.deblocking_disabled; o[15] = h.beta_offset_div2; o[16] = h.tc_offset_div2; o[17] = h.lf_across; }
+        o[14] = h.deblocking_disabled; o[15] = h.beta_offset_div2; o[16] = h.tc_offset_div2; o[17] = h.lf_across;
+        const bool has_rps = nal.type != 19 && nal.type != 20; o[19] = has_rps ? h.rps.num : 0; for (int q = 0; q < 4; q++) { o[20 + 2 * q] = has_rps && q < h.rps.num ? h.rps.delta_poc[q] : 0; o[21 + 2 * q] = has_rps && q < h.rps.num ? h.rps.used[q] : 0; } }
       k++;
     }
   }

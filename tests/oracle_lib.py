@@ -26,7 +26,7 @@ class EncParams(C.Structure):
     """oracle_enc_params (oracle/hevc_enc.h)"""
     _fields_ = [(n, C.c_int) for n in ("width", "height", "bit_depth", "qp", "i_qp_offset", "gop", "lossless", "log2_ctb", "ctb_rows_per_slice", "md5_sei")] + \
                [("stress_seed", C.c_uint32)] + [(n, C.c_int) for n in ("conf_win_right", "conf_win_bottom", "hm_like", "p_qp_offset")] + \
-               [("hint_modes", C.c_void_p), ("hint_w4", C.c_int), ("hint_h4", C.c_int), ("occ4", C.c_void_p), ("occ4_w", C.c_int), ("occ4_h", C.c_int), ("tools_off", C.c_int)]
+               [("hint_modes", C.c_void_p), ("hint_w4", C.c_int), ("hint_h4", C.c_int), ("occ4", C.c_void_p), ("occ4_w", C.c_int), ("occ4_h", C.c_int), ("ctc_gop", C.c_int), ("log2_max_poc_lsb", C.c_int), ("first_idx", C.c_int), ("tools_off", C.c_int)]
 
 
 class OPatch(C.Structure):
@@ -112,6 +112,31 @@ def encode(frames: np.ndarray, w, h, bit_depth, qp, gop=2, i_qp_offset=-3, lossl
     if rc != 0:
         raise RuntimeError(f"oracle encode failed rc={rc}")
     return _take(out, n_out), recon
+
+
+def encode_ex(frames: np.ndarray, want_recon=True, **kw):
+    """oracle_encode_ex with oracle_enc_params fields by name (width, height, bit_depth, qp, ..., ctc_gop, log2_max_poc_lsb, first_idx)"""
+    frames = np.ascontiguousarray(frames, dtype=np.uint16)
+    p = EncParams()
+    for k, v in kw.items():
+        assert hasattr(p, k), k
+        setattr(p, k, v)
+    assert frames.shape[1] == p.width * p.height * 3 // 2
+    out, n_out = C.c_void_p(), C.c_size_t()
+    recon = np.zeros_like(frames) if want_recon else None
+    rc = lib().oracle_encode_ex(C.byref(p), frames.ctypes.data, frames.shape[0], C.byref(out), C.byref(n_out), recon.ctypes.data if want_recon else None)
+    if rc != 0:
+        raise RuntimeError(f"oracle encode failed rc={rc}")
+    return _take(out, n_out), recon
+
+
+def encode_ctc(frames, w, h, bit_depth, qp, ctc_gop=1, log2_max_poc_lsb=0, first_idx=0, hm=1, gop=2, i_qp_offset=-3, p_qp_offset=0, lossless=0, log2_ctb=0,
+               md5_sei=1, stress_seed=0, rows_per_slice=0, want_recon=True):
+    """Streams in the structure of the CTC's HM encoder (oracle_enc_params.ctc_gop: one IDR, then trailing pictures with reference picture sets, POC running on):
+    hm=1 the HM-like toolset, stress_seed != 0 random syntax, otherwise RBT-E1."""
+    return encode_ex(frames, want_recon, width=w, height=h, bit_depth=bit_depth, qp=qp, i_qp_offset=i_qp_offset, gop=gop, lossless=lossless,
+                     log2_ctb=log2_ctb or (0 if stress_seed else 6 if hm else 5), ctb_rows_per_slice=rows_per_slice, md5_sei=md5_sei, stress_seed=stress_seed,
+                     hm_like=1 if (hm and not stress_seed) else 0, p_qp_offset=p_qp_offset, ctc_gop=ctc_gop, log2_max_poc_lsb=log2_max_poc_lsb, first_idx=first_idx)
 
 
 def encode_hm(frames: np.ndarray, w, h, bit_depth, qp, gop=2, i_qp_offset=-3, p_qp_offset=0, lossless=0, log2_ctb=6, md5_sei=1, want_recon=True):
@@ -242,9 +267,15 @@ SLICE_FIELDS = ("nal_type", "address", "slice_type", "poc", "tmvp", "sao_luma", 
 def slice_headers(stream: bytes, fn=None):
     """every slice segment header as the oracle's parser reads it (fn: another library's accessor with the same signature, e.g. the product's host parser)"""
     cap = 4096
-    out = (C.c_int * (19 * cap))()
+    out = (C.c_int * (28 * cap))()
     f = fn or lib().oracle_slice_headers
     n = f(stream, C.c_size_t(len(stream)), out, cap)
     if n < 0:
         raise RuntimeError("slice header parse failed")
-    return [dict(zip(SLICE_FIELDS, out[19 * k:19 * k + 19])) for k in range(n)]
+    res = []
+    for k in range(n):
+        r = out[28 * k:28 * k + 28]
+        d = dict(zip(SLICE_FIELDS, r[:19]))
+        d["rps"] = [[r[20 + 2 * q], r[21 + 2 * q]] for q in range(min(r[19], 4))]   # the slice's short-term reference picture set: [delta POC, used by the current picture]
+        res.append(d)
+    return res
