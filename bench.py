@@ -50,9 +50,27 @@ def launch_ranks(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
+    # supervise (round-3 review: a rank that fails must not leave its peers in a barrier or a collective for ever, nor this parent in wait()): the first rank that
+    # ends non-zero - or the deadline - gives the others a few seconds to end by themselves, then they are killed; the exit code says so
+    deadline = time.time() + float(os.environ.get("RBT_BENCH_RANK_TIMEOUT", "3000"))
+    rc, kill_at = 0, None
+    while any(p_.poll() is None for p_ in procs):
+        for r, p_ in enumerate(procs):
+            if p_.poll() not in (None, 0) and not rc:
+                rc = abs(p_.returncode) or 1
+                print(f"bench.py: rank {r} ended with status {p_.returncode}: stopping the other ranks", file=sys.stderr)
+                kill_at = time.time() + 5
+        if not rc and time.time() > deadline:
+            rc = 124
+            print("bench.py: the ranks did not finish before the deadline (RBT_BENCH_RANK_TIMEOUT): stopping them", file=sys.stderr)
+            kill_at = time.time()
+        if kill_at is not None and time.time() >= kill_at:
+            for p_ in procs:
+                if p_.poll() is None: p_.kill()
+            kill_at = None
+        time.sleep(0.05)
     for p_ in procs:
-        rc = max(rc, abs(p_.wait()))
+        if p_.returncode and not rc: rc = abs(p_.returncode)
     return rc
 
 
@@ -102,14 +120,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    st_ = os.environ.get("RBT_BENCH_SELFTEST", "")          # test hook of the launcher's supervision (tests/test_gof_shard.py): "fail:R" rank R ends with status 3, the others never end
+    if st_.startswith("fail:") and world > 1:
+        if rank == int(st_[5:]): sys.exit(3)
+        time.sleep(3600)
     if world > 1:
+        import datetime
         import torch
         import torch.distributed as dist
+        tmo = datetime.timedelta(seconds=float(os.environ.get("RBT_BENCH_COLLECTIVE_TIMEOUT", "900")))     # a collective whose peer is gone fails after this, it does not wait for ever
         if args.backend == "nccl":
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:
-            dist.init_process_group(backend=args.backend)
+            dist.init_process_group(backend=args.backend, timeout=tmo)
     import rbt_lib
     R = rbt_lib.module()
     dev = 0 if args.share_device else local_rank
@@ -620,4 +644,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush(); sys.stdout.flush()
+        os._exit(1)          # a failed rank leaves at once: interpreter shutdown would run the process group's destructor, which waits for peers that are waiting for this rank

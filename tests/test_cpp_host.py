@@ -124,3 +124,35 @@ def test_cpp_multi_gpu_host_fails_loudly_without_a_gpu(tmp_path):
     (tmp_path / "in.bin").write_bytes(bytes([0x40]))
     r = subprocess.run([MULTI, "--ranks", "2", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "no usable HIP device" in r.stderr and not (tmp_path / "out.bin").exists()
+
+
+def _multi():
+    if not os.path.exists(MULTI):
+        pytest.skip("rbt_multi_gpu not built")
+    return MULTI
+
+
+@pytest.mark.parametrize("mode,ranks,want_rc,needle", [("ok", 3, 0, ""), ("fail:1", 2, 1, "rank 1 failed"), ("fail:0", 4, 1, "rank 0 failed"), ("hang:2", 3, 1, "deadline of 2 s passed")])
+def test_cpp_multi_gpu_host_never_hangs_on_a_failed_or_silent_rank(tmp_path, mode, ranks, want_rc, needle):
+    """round-3 review: a rank that failed before ncclCommInitRank left its peers blocked there and the parent in waitpid for ever. Now every rank publishes a status
+    before anything of RCCL and enters the communicator only when all said ok; the parent reaps with waitpid(-1), raises an abort flag on the first failure or at its
+    deadline and kills what is left. Exercised without a device through --selftest (status round, abort flag and supervision only): everything ends within seconds."""
+    import time
+    t0 = time.time()
+    r = subprocess.run([_multi(), "--ranks", str(ranks), "--timeout", "2", "--selftest", mode, "x", "y"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == want_rc, (r.returncode, r.stderr)
+    assert needle in r.stderr and time.time() - t0 < 15
+    assert not [d for d in os.listdir("/tmp") if d.startswith("rbt_multi_gpu_") and os.path.exists(os.path.join("/tmp", d, "status.0"))]      # the scratch directory is cleaned up
+
+
+@pytest.mark.gpu
+def test_cpp_multi_gpu_host_reports_a_damaged_input(tmp_path):
+    """--ranks 1 on a file whose geometry unit is damaged: non-zero exit with the library's message, no output file"""
+    import v3c_synth as V
+    units = []
+    for g, s in enumerate(_gofs(2)):
+        units += V.gof_units(s, 90 + g)
+    bad = bytearray(units[3]); bad[40:len(bad) // 2] = bytes(len(bad) // 2 - 40); units[3] = bytes(bad)          # the first GOF's geometry video: slice data zeroed
+    (tmp_path / "in.bin").write_bytes(V.sample_stream(units, 3))
+    r = subprocess.run([_multi(), "--ranks", "1", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "rbt_transcode_v3c:" in r.stderr and not (tmp_path / "out.bin").exists()

@@ -117,3 +117,13 @@ def test_sequence_and_fanout_world2_equal_unsharded_and_oracle(hostemu):
     assert v3c == O.v3c_transcode(_container(seq), 24, 32, 4)
     c = R.Context(lib_path=rbt_lib.HOSTEMU_LIB); assert v3c == c.transcode_v3c(_container(seq), 24, 32); c.close()
     assert fan[5][0][0] == seq[2][0]       # R5 keeps occupancy precision 2: the reference does not touch the occupancy stream (:150)
+
+
+def test_bench_launcher_stops_all_ranks_when_one_fails():
+    """python bench.py --gpus N (self-launched ranks): when a rank ends non-zero the parent stops the others and exits non-zero within seconds instead of waiting for ranks
+    that sit in a barrier (round-3 review). The hook makes rank 1 fail and the other ranks never end; no GPU is touched."""
+    import subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--backend", "gloo"], env=dict(os.environ, RBT_BENCH_SELFTEST="fail:1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "rank 1 ended with status 3" in r.stderr and time.time() - t0 < 60
