@@ -52,7 +52,7 @@ typedef struct {
                               * HM's distortion, TComRdCost.cpp xGetSSE*). The occupancy map the output carries tells which 4x4 units the decoder makes points of; with one unit
                               * of margin around them, transform blocks outside carry no residual, partly occupied blocks code what their occupied samples ask for, and the
                               * unoccupied samples stay out of the encoder's distortion terms. Measured on the benchmark GOF at R3: 67 % fewer geometry and 30 % fewer
-                              * attribute bytes, D1 -0.05 dB (frame 0; -0.08 dB over four frames), PSNR of the occupied samples -0.04 / -0.02 dB. The pictures outside the occupied area are then whatever
+                              * attribute bytes, mean D1 over the GOF's four base atlases -0.08 dB (67.14 -> 67.06 dB; a single frame scatters by +-0.3 dB either way, frame 0: -0.05 dB), PSNR of the occupied samples -0.04 / -0.02 dB (tests/test_gpu_transcode.py holds both within 0.1 dB). The pictures outside the occupied area are then whatever
                               * prediction leaves there. Entries come GOF by GOF, occupancy first; ignored where the call holds no such occupancy stream, by
                               * rbt_transcode_substream (one stream) and for lossless streams; not together with verify_md5 (RBT_ERR_PARAM). 0 = off: every sample counts. */
   int preset;                /* RBT_PRESET_*: what the reference's `preset` (PCCTranscoderParameters.h:58, handed to libx265 at PCCTranscoder.cpp:877,883) selects here.
@@ -123,7 +123,9 @@ typedef struct rbt_job rbt_job;
 int rbt_set_depth(rbt_ctx* ctx, int max_in_flight);
 int rbt_get_depth(rbt_ctx* ctx);   /* the announced depth (> 0) or RBT_ERR_PARAM */
 /* How to cut a walk of n_gofs GOFs into jobs on one GPU, as measured on 1280x1280 maps: 16 jobs of 3 GOFs for a long walk (96 GOFs and more; 2 GOFs from 48: the
- * arenas of 48 GOFs in flight are 216 GB at that size - a caller with larger atlases passes its own gofs_per_job, an arena that does not fit fails with RBT_ERR_NOMEM); a walk shorter than 48 GOFs is all ramp-up and
+ * arenas of 48 GOFs in flight are 216 GB at that size. The shape looks at the length of the walk only; rbt_transcode_v3c bounds the jobs it keeps in flight by the memory the
+ * first job took (rbt_job_memory against rbt_device_memory) and falls back to one GOF per job, one job at a time, when a job still fails with RBT_ERR_NOMEM; a caller
+ * that drives rbt_submit_gof itself does the same or passes its own shape); a walk shorter than 48 GOFs is all ramp-up and
  * drain and does better as at most 7 jobs (2 jobs up to 12 GOFs) of ceil(n / jobs) GOFs, which then own several hardware queues each. max_jobs caps the jobs in flight. */
 int rbt_job_shape(int n_gofs, int max_jobs, int* gofs_per_job, int* jobs_in_flight);
 /* The reference's `preset` string (an x265 preset name, PCCTranscoderParameters.h:58) as RBT_PRESET_*: "ultrafast", "superfast" -> RBT_PRESET_FAST; "veryfast"
@@ -131,6 +133,14 @@ int rbt_job_shape(int n_gofs, int max_jobs, int* gofs_per_job, int* jobs_in_flig
  * "veryfast" decides by rate-distortion cost, which RBT_PRESET_FAST does not); anything else -> RBT_ERR_PARAM. */
 int rbt_preset_from_name(const char* name);
 int rbt_submit_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, rbt_job** job);
+/* Device memory as the library sees it, for callers that size their own pipelines (rbt_transcode_v3c does: jobs in flight are bounded by it). free_bytes / total_bytes: the
+ * driver's figures; cached_bytes: arenas of collected jobs kept for the next job of the same shape (handed back before an allocation fails; rbt_trim); in_use_bytes: arenas
+ * of jobs in flight; reserve_bytes: what a new arena leaves free for the HIP runtime's own allocations (scratch memory of the hardware queues: 3 GB unless the environment
+ * variable RBT_HBM_RESERVE_MB says otherwise) - an arena that would cut into it fails with RBT_ERR_NOMEM and the context stays usable. */
+typedef struct { size_t total_bytes, free_bytes, cached_bytes, in_use_bytes, reserve_bytes; } rbt_memory;
+int rbt_device_memory(rbt_ctx* ctx, rbt_memory* out);
+/* Device memory a submitted job holds (its decoder and encoder arenas); what the next job of the same shape will take. */
+int rbt_job_memory(rbt_ctx* ctx, const rbt_job* job, size_t* bytes);
 int rbt_wait_gof(rbt_ctx* ctx, rbt_job* job, uint8_t** annexb_out, size_t* n_out);
 /* The library keeps the device memory of collected jobs for the next job of the same shape (hipMalloc / hipFree of GOF-sized arenas cost milliseconds
  * and hipFree drains the device). rbt_trim hands that cache back to the driver: worth calling when the workload changes shape (other picture sizes, other

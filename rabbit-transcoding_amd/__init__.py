@@ -20,6 +20,11 @@ class RbtError(RuntimeError):
         self.code = code
 
 
+class Memory(C.Structure):
+    """rbt_memory (include/rbt.h)"""
+    _fields_ = [(n, C.c_size_t) for n in ("total_bytes", "free_bytes", "cached_bytes", "in_use_bytes", "reserve_bytes")]
+
+
 class StreamParams(C.Structure):
     _fields_ = [("video_type", C.c_int), ("qp", C.c_int), ("occupancy_precision", C.c_int), ("log2_ctb", C.c_int),
                 ("ctb_rows_per_slice", C.c_int), ("md5_sei", C.c_int), ("verify_md5", C.c_int), ("occupancy_rd", C.c_int), ("preset", C.c_int)]
@@ -118,6 +123,8 @@ def load(path=None):
     L.rbt_v3c_index.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(V3CUnit)), C.POINTER(C.c_int)]
     L.rbt_v3c_write.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rbt_v3c_stats.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(V3CStat)]
+    L.rbt_device_memory.argtypes = [C.c_void_p, C.POINTER(Memory)]
+    L.rbt_job_memory.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
     L.rbt_transcode_v3c_stream.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(V3CParams), V3C_SINK, C.c_void_p]
     L.rbt_transcode_v3c.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(V3CParams), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     return L
@@ -283,6 +290,18 @@ class Context:
         def cb(_user, gof, n_units, unit, unit_size):
             return 1 if sink(gof, [C.string_at(unit[i], unit_size[i]) for i in range(n_units)]) else 0
         self._chk(self.L.rbt_transcode_v3c_stream(self.h, data, len(data), C.byref(p), V3C_SINK(cb), None))
+
+    def device_memory(self):
+        """rbt_device_memory: {total, free, cached, in_use, reserve} bytes as the library sees the device"""
+        m = Memory()
+        self._chk(self.L.rbt_device_memory(self.h, C.byref(m)))
+        return {"total": m.total_bytes, "free": m.free_bytes, "cached": m.cached_bytes, "in_use": m.in_use_bytes, "reserve": m.reserve_bytes}
+
+    def job_memory(self, job):
+        """rbt_job_memory: device bytes a submitted job holds"""
+        b = C.c_size_t()
+        self._chk(self.L.rbt_job_memory(self.h, job[0] if isinstance(job, tuple) else job, C.byref(b)))
+        return b.value
 
     def set_depth(self, n):
         """rbt_set_depth: how many GOFs the caller will keep in flight (1..16 = RBT_MAX_JOBS, default 4)"""

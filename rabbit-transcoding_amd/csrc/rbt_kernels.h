@@ -30,6 +30,10 @@ const char* dev_name();
 void* dev_alloc(size_t n);                // nullptr on failure
 void dev_free(void* p);                   // returns the block to a recycling pool
 void dev_release_pool();                  // hands pooled blocks back to the driver (rbt_destroy)
+size_t dev_reserve_bytes();               // HBM a new arena must leave free for the runtime's own allocations (RBT_HBM_RESERVE_MB, read once)
+// free / total: the driver's view (hipMemGetInfo); cached: blocks the recycling pool holds (given back before an allocation fails); live: blocks handed out
+int dev_mem_info(size_t* free_b, size_t* total_b, size_t* cached_b, size_t* live_b);
+size_t dev_alloc_total();                 // bytes dev_alloc has handed out on this thread so far (a job's footprint = the difference around its build)
 int h2d(void* d, const void* h, size_t n);
 int d2h(void* h, const void* d, size_t n);
 int dev_memset(void* d, int v, size_t n);

@@ -83,7 +83,26 @@ void stream_wait(int waiter, int signaller) {
 // Device allocations are recycled: hipMalloc / hipFree of GOF-sized arenas cost milliseconds each (hipFree also drains the
 // device), and a transcoder calls with the same sizes over and over. Freed blocks go to a small best-fit pool; at most
 // RBT_POOL_KEEP blocks are kept, the rest is returned to the driver.
-#define RBT_HBM_RESERVE ((size_t)8 << 30)
+// HBM a new arena leaves free. The runtime allocates too, and when IT finds nothing left the process is aborted (HSA_STATUS_ERROR_OUT_OF_RESOURCES, seen in round 3 with
+// ~280 GB of cached arenas): scratch memory of a hardware queue the first time a kernel with a private segment runs on it. What this library's kernels need: the largest
+// private segment is 68 bytes per lane (the slice parsers; intra analysis 40, entropy coders 52, encoder SAO 28, intra coder 8 - llvm-readelf --notes of the code objects),
+// i.e. 64 x 68 B rounded up to 5 KB per wave, x 256 CUs x 32 wave slots = 42 MB per queue, x 16 queues = 0.66 GB; plus code objects, signals and the copy engines' staging
+// (measured on MI355X with tools/scratch_probe.py: the figure is in DESIGN.md 5). Default 3 GB - four times the computed need; RBT_HBM_RESERVE_MB overrides (read once).
+static size_t g_reserve = (size_t)-1;
+size_t dev_reserve_bytes() {
+  if (g_reserve == (size_t)-1) { const char* e = getenv("RBT_HBM_RESERVE_MB"); long long mb = e && *e ? atoll(e) : 3072; if (mb < 0) mb = 0; g_reserve = (size_t)mb << 20; }
+  return g_reserve;
+}
+static thread_local size_t t_alloc_total = 0;
+size_t dev_alloc_total() { return t_alloc_total; }
+int dev_mem_info(size_t* free_b, size_t* total_b, size_t* cached_b, size_t* live_b) {
+  Dev* D = t_dev; if (!D) return -1;
+  size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  std::lock_guard<std::mutex> lk(D->pool_mu);
+  size_t c = 0, l = 0; for (auto& f : D->pool_free) c += f.n; for (auto& f : D->pool_live) l += f.n;
+  if (free_b) *free_b = fr; if (total_b) *total_b = tot; if (cached_b) *cached_b = c; if (live_b) *live_b = l;
+  return 0;
+}
 void* dev_alloc(size_t n) {
   if (!n) n = 1;
   Dev* D = t_dev; if (!D) return nullptr;
@@ -95,15 +114,15 @@ void* dev_alloc(size_t n) {
   if (best >= 0) { b = D->pool_free[(size_t)best]; D->pool_free.erase(D->pool_free.begin() + best); }
   else {
     b.p = nullptr; b.n = n;
-    // Arenas must not take the last of the HBM: the runtime allocates too (scratch memory of a queue the first time a kernel with a private segment runs on it, ~27 MB per
-    // queue and kernel variant), and when IT finds nothing left the process is aborted (HSA_STATUS_ERROR_OUT_OF_RESOURCES - seen in round 3 with ~280 GB of cached arenas of
-    // five job shapes). A new arena therefore leaves RBT_HBM_RESERVE free: cached blocks go back to the driver first, and if that is not enough the call fails (RBT_ERR_NOMEM).
-    if (n >= ((size_t)64 << 20)) {
+    // Arenas must not take the last of the HBM (dev_reserve_bytes above): a new block of a megabyte or more leaves the reserve free - cached blocks go back to the driver
+    // first, and if that is not enough the call fails (RBT_ERR_NOMEM) and the context stays usable (tests/test_gpu_memory.py).
+    if (n >= ((size_t)1 << 20)) {
+      const size_t reserve = dev_reserve_bytes();
       size_t fr = 0, tot = 0;
-      if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr < n + RBT_HBM_RESERVE) {
+      if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr < n + reserve) {
         for (auto& f : D->pool_free) (void)hipFree(f.p);
         D->pool_free.clear();
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr < n + RBT_HBM_RESERVE) return nullptr;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr < n + reserve) return nullptr;
       }
     }
     if (hipMalloc(&b.p, n) != hipSuccess) {
@@ -114,6 +133,7 @@ void* dev_alloc(size_t n) {
     }
   }
   D->pool_live.push_back(b);
+  t_alloc_total += b.n;
   return b.p;
 }
 void dev_free(void* p) {

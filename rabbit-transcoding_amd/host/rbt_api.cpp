@@ -7,6 +7,7 @@
 #include "rbt_batch.h"
 #include "rbt_transcode.h"
 #include "rbt_pcc.h"
+#include "rbt_internal.h"
 
 struct rbt_ctx { int device, rank, world; rbt_stats stats; std::string last_err; };
 struct rbt_job { rbt::GofJob* j; rbt_ctx* owner; };
@@ -27,6 +28,7 @@ extern "C" {
 const char* rbt_version(void) { return "rabbit-transcoding_amd 0.1 (RBT-E1 encoder, gfx950)"; }
 
 const char* rbt_last_error(rbt_ctx* ctx) { return ctx ? ctx->last_err.c_str() : ""; }
+void rbt_internal_set_error(rbt_ctx* ctx, const char* text) { if (ctx) { try { ctx->last_err = text ? text : ""; } catch (...) {} } }
 const char* rbt_strerror(int code) {
   switch (code) {
     case RBT_OK: return "ok";
@@ -143,7 +145,7 @@ int rbt_transcode_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, cons
   if (rc) return rc;
   return rbt_wait_gof(ctx, job, annexb_out, n_out);
 } RBT_CATCH
-int rbt_submit_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, rbt_job** job) { return submit(ctx, n, annexb_in, n_in, p, job, true); }
+int rbt_submit_gof(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, rbt_job** job) try { return submit(ctx, n, annexb_in, n_in, p, job, true); } RBT_CATCH
 static int submit(rbt_ctx* ctx, int n, const uint8_t* const* annexb_in, const size_t* n_in, const rbt_stream_params* p, rbt_job** job, bool gof_rule) {
   if (!ctx || n < 1 || n > RBT_MAX_STREAMS || !annexb_in || !n_in || !p || !job) return RBT_ERR_PARAM;
   *job = nullptr;
@@ -185,6 +187,22 @@ int rbt_preset_from_name(const char* name) try {
   for (const char* f : {"ultrafast", "superfast"}) if (!strcmp(name, f)) return RBT_PRESET_FAST;
   for (const char* d : {"veryfast", "faster", "fast", "medium", "slow", "slower", "veryslow", "placebo"}) if (!strcmp(name, d)) return RBT_PRESET_DEFAULT;
   return RBT_ERR_PARAM;
+} RBT_CATCH
+int rbt_device_memory(rbt_ctx* ctx, rbt_memory* out) try {
+  if (!ctx || !out) return RBT_ERR_PARAM;
+  RBT_ENTER(ctx);
+  memset(out, 0, sizeof(*out));
+  if (rbtk::dev_mem_info(&out->free_bytes, &out->total_bytes, &out->cached_bytes, &out->in_use_bytes)) return RBT_ERR_NO_DEVICE;
+  out->reserve_bytes = rbtk::dev_reserve_bytes();
+  return RBT_OK;
+} RBT_CATCH
+int rbt_job_memory(rbt_ctx* ctx, const rbt_job* job, size_t* bytes) try {
+  if (!ctx || !job || !bytes) return RBT_ERR_PARAM;
+  RBT_ENTER(ctx);
+  bool mine = false; for (int s = 0; s < RBT_MAX_JOBS; s++) if (D.jobs[s] == job && job->owner == ctx) mine = true;
+  if (!mine) return RBT_ERR_PARAM;
+  *bytes = rbt::gof_memory(job->j);
+  return RBT_OK;
 } RBT_CATCH
 int rbt_trim(rbt_ctx* ctx) try {
   if (!ctx) return RBT_ERR_PARAM;

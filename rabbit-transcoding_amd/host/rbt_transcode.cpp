@@ -400,7 +400,7 @@ struct GofJob {
   std::vector<std::vector<uint8_t>> passthrough;   // transcodeData (PCCTranscoder.cpp:150): occupancy is only transcoded when occupancyPrecision == 4; else the stream stays as it is
   std::vector<char> is_pass;
   std::vector<std::vector<int>> dec_of;            // per pipeline: decode stream of each of its (encode) streams - identical inputs are decoded once
-  rbt_stats st; std::string err; double t_all = 0, t_gpu = 0;
+  rbt_stats st; std::string err; double t_all = 0, t_gpu = 0; size_t dev_bytes = 0;
   ~GofJob() { for (void* q : pooled) rbtk::dev_free(q); }
 };
 static int job_stream(const GofJob& j, int pipeline) { return j.slot * rbtk::RBT_STREAMS_PER_JOB + pipeline; }
@@ -416,8 +416,10 @@ static void bind_streams(GofJob& j, int depth) {
   rbtk::map_lane(job_stream(j, rbtk::RBT_AUX_STREAM), base + spj - 1);
 }
 
+size_t gof_memory(const GofJob* j) { return j ? j->dev_bytes : 0; }
 GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const size_t* n_in, const rbt_stream_params* p, bool gof_rule) {
   GofJob* J = new GofJob(); GofJob& j = *J;
+  struct Footprint { GofJob& j; size_t a0; ~Footprint() { j.dev_bytes = rbtk::dev_alloc_total() - a0; } } footprint{j, rbtk::dev_alloc_total()};
   j.t_all = now_ms(); j.n = n; j.slot = slot; memset(&j.st, 0, sizeof(j.st));
   j.params.assign(p, p + n); j.n_in.assign(n_in, n_in + n);
   rbt_stats& st = j.st; std::string& err = j.err;

@@ -7,6 +7,7 @@
 //   PCCBitstreamWriter::encode / write  PCCBitstreamWriter.cpp:96-237, :57-91, :1492-1507
 // V3C_VPS and V3C_AD units are copied, not parsed (include/rbt.h).
 #include "../../include/rbt.h"
+#include "rbt_internal.h"
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -132,7 +133,6 @@ int rbt_transcode_v3c_stream(rbt_ctx* ctx, const uint8_t* in, size_t n, const rb
     if (n_geo > 1 || n_attr > 1) return RBT_ERR_UNSUPPORTED;                                          // separate map streams: VIDEO_GEOMETRY_D0.. / VIDEO_ATTRIBUTE_T0.., which transcodeData never asks for
   }
   std::vector<Buf> repl(nu);                                                                           // new payloads (sample stream form) of the picked units
-  auto cleanup = [&]() { for (auto& b : repl) { free(b.p); b.p = nullptr; } };
   // PCCBitstreamWriter::encode, GOF by GOF: the units of every owned GOF below `upto` that has not been handed over yet, in order, video units with their 4 header
   // bytes in front of the new payload
   int next_gof = 0;
@@ -156,37 +156,75 @@ int rbt_transcode_v3c_stream(rbt_ctx* ctx, const uint8_t* in, size_t n, const rb
     }
     return RBT_OK;
   };
-  // jobs: the picked units of `per` consecutive owned GOFs each, as many in flight as the context allows (RBT_ERR_BUSY tells)
-  struct Job { rbt_job* j; std::vector<int> unit; int last_gof; };
+  // jobs: the picked units of `per` consecutive owned GOFs each, as many in flight as the context allows (RBT_ERR_BUSY tells) AND as the device memory holds
+  struct Job { rbt_job* j; std::vector<int> unit; int last_gof; size_t a, a_end; size_t others; };   // [a, a_end) of `owned`; others: jobs in flight when it was submitted
   std::deque<Job> q;
+  std::string first_err;                                                      // text of the call that failed (every later call on the context clears rbt_last_error)
+  auto note = [&](int r) { if (r && first_err.empty()) { const char* t = rbt_last_error(ctx); first_err = (t && *t) ? t : rbt_strerror(r); } return r; };
+  std::vector<int> owned; for (int g = 0; g < n_gofs; g++) if (rbt_owns_gof(ctx, g) && !picks[g].empty()) owned.push_back(g);
+  int per = p->gofs_per_job > 1 ? p->gofs_per_job : 1, announced = 0;
+  // whatever way this function is left - error, exception - the jobs still in flight are collected, the caller's depth is put back and the buffers are freed
+  struct Guard { rbt_ctx* ctx; std::deque<Job>& q; int& announced; std::vector<Buf>& repl;
+    ~Guard() {
+      while (!q.empty()) { Job jb = q.front(); q.pop_front(); std::vector<uint8_t*> o(jb.unit.size(), nullptr); std::vector<size_t> on(jb.unit.size(), 0);
+        rbt_wait_gof(ctx, jb.j, o.data(), on.data()); for (uint8_t* x : o) rbt_free(x); }
+      if (announced) rbt_set_depth(ctx, announced);
+      for (auto& b : repl) { free(b.p); b.p = nullptr; }
+    } } guard{ctx, q, announced, repl};
+  if (p->gofs_per_job <= 0) {                                                 // job shape by the length of the walk; a short one runs with fewer, larger jobs
+    int d = 0; announced = rbt_get_depth(ctx);
+    if (announced < 1 || rbt_job_shape((int)owned.size(), announced, &per, &d) != RBT_OK) { announced = 0; return RBT_ERR_PARAM; }
+    if (d == announced || rbt_set_depth(ctx, d) != RBT_OK) announced = 0;    // nothing to restore (jobs of another walk in flight: keep the caller's depth)
+  }
+  // the owned GOFs spread evenly over ceil(n / per) jobs (20 GOFs, 3 per job: 3 3 3 3 3 3 2)
+  std::deque<std::pair<size_t, size_t>> todo;
+  { const size_t n_own = owned.size(), nj = (n_own + per - 1) / per; size_t at = 0;
+    for (size_t i = 0; i < nj; i++) { const size_t len = n_own / nj + (i < n_own % nj ? 1 : 0); todo.push_back({at, at + len}); at += len; } }
+  // Memory. The shape above knows the length of the walk, not the size of the atlases: the first job tells what a job of this walk takes (rbt_job_memory), and from then
+  // on a job is submitted only while free + cached - reserve holds another one (older results are collected first). A job that still fails with RBT_ERR_NOMEM - another
+  // process on the device, a later GOF with larger maps - does not end the walk: everything in flight is collected, and its GOFs (and those of any job that failed with
+  // it) are run again one GOF per job, one job at a time (`tight`); only a lone single-GOF job that does not fit is an error.
+  size_t job_bytes = 0; bool tight = false;
+  auto fits = [&]() { rbt_memory m; if (!job_bytes || rbt_device_memory(ctx, &m) != RBT_OK) return true;
+                      const size_t have = m.free_bytes + m.cached_bytes; return have >= m.reserve_bytes && have - m.reserve_bytes >= job_bytes + job_bytes / 8; };
   auto collect = [&](bool hand_over) -> int {
     Job jb = q.front(); q.pop_front();
     std::vector<uint8_t*> o(jb.unit.size(), nullptr); std::vector<size_t> on(jb.unit.size(), 0);
     int r = rbt_wait_gof(ctx, jb.j, o.data(), on.data());
+    if (r == RBT_ERR_NOMEM && (jb.a_end - jb.a > 1 || jb.others > 0)) {
+      // run its GOFs again, alone; jobs behind it are collected first (they hold the memory), failed ones among them join the list, in GOF order
+      std::vector<std::pair<size_t, size_t>> again{{jb.a, jb.a_end}};
+      for (uint8_t* x : o) rbt_free(x);
+      int rr = RBT_OK;
+      while (!q.empty() && !rr) {
+        Job k = q.front(); q.pop_front();
+        std::vector<uint8_t*> ko(k.unit.size(), nullptr); std::vector<size_t> kn(k.unit.size(), 0);
+        int r2 = rbt_wait_gof(ctx, k.j, ko.data(), kn.data());
+        if (r2 == RBT_ERR_NOMEM) again.push_back({k.a, k.a_end}); else if (r2) rr = note(r2);
+        for (size_t u = 0; u < k.unit.size(); u++) { if (!r2 && !rr) rr = note(rbt_byte_to_sample_stream(ko[u], kn[u], &repl[k.unit[u]].p, &repl[k.unit[u]].n)); rbt_free(ko[u]); }
+      }
+      if (rr) return rr;
+      tight = true;
+      for (size_t x = again.size(); x-- > 0;) for (size_t g = again[x].second; g-- > again[x].first;) todo.push_front({g, g + 1});
+      return RBT_OK;
+    }
+    note(r);
     for (size_t k = 0; k < jb.unit.size(); k++) {
-      if (!r) r = rbt_byte_to_sample_stream(o[k], on[k], &repl[jb.unit[k]].p, &repl[jb.unit[k]].n);   // transcodeVideo ends with it (PCCTranscoder.cpp:517)
+      if (!r) r = note(rbt_byte_to_sample_stream(o[k], on[k], &repl[jb.unit[k]].p, &repl[jb.unit[k]].n));   // transcodeVideo ends with it (PCCTranscoder.cpp:517)
       rbt_free(o[k]);
     }
     if (!r && hand_over) r = deliver(jb.last_gof + 1);                                               // jobs are collected in order: everything up to this job's last GOF is complete
     return r;
   };
-  std::vector<int> owned; for (int g = 0; g < n_gofs; g++) if (rbt_owns_gof(ctx, g) && !picks[g].empty()) owned.push_back(g);
-  int per = p->gofs_per_job > 1 ? p->gofs_per_job : 1, announced = 0;
-  if (p->gofs_per_job <= 0) {                                                 // job shape by the length of the walk; a short one runs with fewer, larger jobs
-    int d = 0; announced = rbt_get_depth(ctx);
-    if (announced < 1 || rbt_job_shape((int)owned.size(), announced, &per, &d) != RBT_OK) { cleanup(); return RBT_ERR_PARAM; }
-    if (d == announced || rbt_set_depth(ctx, d) != RBT_OK) announced = 0;    // nothing to restore (jobs of another walk in flight: keep the caller's depth)
-  }
-  // the owned GOFs spread evenly over ceil(n / per) jobs (20 GOFs, 3 per job: 3 3 3 3 3 3 2)
-  std::vector<size_t> cut{0};
-  { const size_t n_own = owned.size(), nj = (n_own + per - 1) / per;
-    for (size_t i = 0; i < nj; i++) cut.push_back(cut.back() + n_own / nj + (i < n_own % nj ? 1 : 0)); }
-  for (size_t ji = 0; ji + 1 < cut.size() && !rc; ji++) {
-    const size_t a = cut[ji], a_end = cut[ji + 1];
-    std::vector<Buf> conv; std::vector<const uint8_t*> ip; std::vector<size_t> in_n; std::vector<rbt_stream_params> sp; Job jb{nullptr, {}, owned[a_end - 1]};
+  while (!rc && (!todo.empty() || !q.empty())) {
+    if (todo.empty()) { rc = collect(true); continue; }
+    if (!q.empty() && (tight || !fits())) { rc = collect(true); continue; }   // make room first
+    const size_t a = todo.front().first, a_end = todo.front().second; todo.pop_front();
+    std::vector<Buf> conv; std::vector<const uint8_t*> ip; std::vector<size_t> in_n; std::vector<rbt_stream_params> sp; Job jb{nullptr, {}, owned[a_end - 1], a, a_end, 0};
+    struct FreeConv { std::vector<Buf>& c; ~FreeConv() { for (auto& b : c) free(b.p); } } free_conv{conv};   // the inputs may go as soon as submit returns
     for (size_t b = a; b < a_end && !rc; b++)
       for (const Pick& pk : picks[owned[b]]) {
-        Buf c; rc = rbt_sample_to_byte_stream(in + U[pk.unit].offset + 4, U[pk.unit].size - 4, &c.p, &c.n);   // transcodeData :152,159,164
+        Buf c; rc = note(rbt_sample_to_byte_stream(in + U[pk.unit].offset + 4, U[pk.unit].size - 4, &c.p, &c.n));   // transcodeData :152,159,164
         if (rc) break;
         conv.push_back(c); jb.unit.push_back(pk.unit);
         rbt_stream_params s; memset(&s, 0, sizeof(s));
@@ -199,15 +237,18 @@ int rbt_transcode_v3c_stream(rbt_ctx* ctx, const uint8_t* in, size_t n, const rb
     while (!rc) {
       rc = rbt_submit_gof(ctx, (int)ip.size(), ip.data(), in_n.data(), sp.data(), &jb.j);
       if (rc == RBT_ERR_BUSY && !q.empty()) { rc = collect(true); continue; }  // every slot taken: take the oldest result first (and hand its GOFs over)
+      note(rc);
       break;
     }
-    for (auto& c : conv) free(c.p);                                            // the inputs may go as soon as submit returns
-    if (!rc) q.push_back(jb);
+    if (!rc) {
+      jb.others = q.size(); q.push_back(jb);
+      size_t b = 0; if (rbt_job_memory(ctx, jb.j, &b) == RBT_OK && b > job_bytes) job_bytes = b;
+    }
   }
-  while (!q.empty()) { int r = collect(!rc); if (!rc) rc = r; }               // after an error the remaining jobs are only drained
-  if (announced) rbt_set_depth(ctx, announced);
+  while (!q.empty()) { int r = collect(false); if (!rc) rc = r; }             // after an error the remaining jobs are only drained
+  if (announced) { rbt_set_depth(ctx, announced); announced = 0; }
   if (!rc) rc = deliver(n_gofs);                                              // GOFs behind the last job (no video units of their own)
-  cleanup();
+  if (rc) rbt_internal_set_error(ctx, first_err.empty() ? rbt_strerror(rc) : first_err.c_str());
   return rc;
 } RBT_CATCH
 

@@ -8,6 +8,8 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include "../../rabbit-transcoding_amd/csrc/rbt_kernels.h"
 #include "../../rabbit-transcoding_amd/csrc/rbt_parse.h"
 #include "../../rabbit-transcoding_amd/csrc/rbt_recon.h"
@@ -28,8 +30,26 @@ int stream_mark(int) { return 0; }
 void stream_wait_mark(int, int) {}
 const char* dev_name() { return "host emulation (test only)"; }
 // poisoned: the product recycles device arenas, so whatever a kernel body reads without having written it is another job's data - the parity tests run on a pattern that shows it
-void* dev_alloc(size_t n) { void* p = malloc(n ? n : 1); if (p) memset(p, 0xA5, n ? n : 1); return p; }
-void dev_free(void* p) { free(p); }
+// RBT_HOSTEMU_HBM_MB (read at every call, so a test can change it): a device memory of that many megabytes - what is handed out is counted, an allocation that does not fit
+// next to the reserve fails like the product's dev_alloc does (RBT_ERR_NOMEM paths of the host code: tests/test_memory_bound.py)
+static std::mutex g_mem_mu; static std::map<void*, size_t> g_mem_live; static size_t g_mem_used = 0; static thread_local size_t t_alloc_total = 0;
+static size_t hbm_total() { const char* e = getenv("RBT_HOSTEMU_HBM_MB"); return e && *e ? (size_t)atoll(e) << 20 : (size_t)288 << 30; }
+size_t dev_reserve_bytes() { const char* e = getenv("RBT_HBM_RESERVE_MB"); return e && *e ? (size_t)atoll(e) << 20 : 0; }
+size_t dev_alloc_total() { return t_alloc_total; }
+int dev_mem_info(size_t* free_b, size_t* total_b, size_t* cached_b, size_t* live_b) {
+  std::lock_guard<std::mutex> lk(g_mem_mu); const size_t tot = hbm_total();
+  if (free_b) *free_b = tot > g_mem_used ? tot - g_mem_used : 0; if (total_b) *total_b = tot; if (cached_b) *cached_b = 0; if (live_b) *live_b = g_mem_used;
+  return 0;
+}
+void* dev_alloc(size_t n) {
+  if (!n) n = 1;
+  { std::lock_guard<std::mutex> lk(g_mem_mu); if (n >= ((size_t)1 << 20) && g_mem_used + n + dev_reserve_bytes() > hbm_total()) return nullptr; }
+  void* p = malloc(n); if (!p) return nullptr;
+  memset(p, 0xA5, n);
+  std::lock_guard<std::mutex> lk(g_mem_mu); g_mem_live[p] = n; g_mem_used += n; t_alloc_total += n;
+  return p;
+}
+void dev_free(void* p) { if (!p) return; { std::lock_guard<std::mutex> lk(g_mem_mu); auto it = g_mem_live.find(p); if (it != g_mem_live.end()) { g_mem_used -= it->second; g_mem_live.erase(it); } } free(p); }
 void dev_release_pool() {}
 int h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); return 0; }
 int d2h(void* h, const void* d, size_t n) { memcpy(h, d, n); return 0; }

@@ -265,9 +265,14 @@ def test_transform_skip_blocks(ctx, monkeypatch, w, h, log2_ctb, rows):
         on, rec = O.encode(fr, w, h, 10, qp, gop=2, log2_ctb=log2_ctb, rows_per_slice=rows)
         assert bs == on
         monkeypatch.setenv("RBT_ENC_TS", "0")
-        off, _ = O.encode(fr, w, h, 10, qp, gop=2, log2_ctb=log2_ctb, rows_per_slice=rows)
+        off, rec_off = O.encode(fr, w, h, 10, qp, gop=2, log2_ctb=log2_ctb, rows_per_slice=rows)
         monkeypatch.delenv("RBT_ENC_TS")
         assert on != off                                                      # transform skip blocks were chosen (per block by distortion + lambda * rate)
+        # ... and the choice pays: the rate-distortion cost of the whole stream (squared error of the reconstruction + lambda * bits, lambda of the I slices' QP as HM
+        # defines it, 0.57 * 2^((QP - 12) / 3)) is no greater with the tool than without it - neither bytes nor distortion alone need to go down
+        lam = 0.57 * 2.0 ** ((qp - 3 - 12) / 3.0)
+        cost = lambda stream, r_: float(((r_.astype(np.int64) - fr.astype(np.int64)) ** 2).sum()) + lam * 8 * len(stream)
+        assert cost(on, rec) <= cost(off, rec_off), (qp, len(on), len(off), cost(on, rec), cost(off, rec_off))
         dec, _, _, _, chk, fail = ctx.decode(bs)
         assert (chk, fail) == (4, 0) and np.array_equal(dec, rec)
 
@@ -306,34 +311,39 @@ def test_preset_fast_full_size_frame(ctx):
 
 
 def test_occupancy_aware_coding_full_size_frame(ctx):
-    """one point-cloud frame of the committed 1280x1280 fixture, R5 -> R3 with occupancy_rd: == oracle, and what the option is for - at least 40 % fewer geometry bytes
-    with the samples the decoder makes points of as good as without (luma PSNR of the occupied samples within 0.15 dB) and D1 of the decoded cloud in the same place
-    (within 0.5 dB: ONE frame's D1 scatters by +-0.3 dB between any two encoder variants - bench.py reports four frames and the whole GOF's bytes)."""
+    """the committed 1280x1280 fixture, R5 -> R3 with occupancy_rd. Frame 0: == oracle, and what the option is for - at least 40 % fewer geometry bytes. Quality where the
+    claim of include/rbt.h and DESIGN.md stands - on the MEAN over the GOF's four base atlases (frames 0..3), because one frame's D1 scatters by +-0.3 dB between any
+    two encoder variants (a depth error of 1 on a few thousand of 600 000 points; round 3 saw 0.34 dB on frame 0 alone): mean D1 within 0.1 dB of the plain transcode's,
+    luma PSNR of the samples the decoder makes points of within 0.1 dB (geometry and attribute, all eight pictures)."""
     import os
     gs = rbt_lib.module_file("gof_shard")
     R = rbt_lib.module()
     gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    first = [gs.split_pairs(open(os.path.join(gold, f"hm_r5_1280x1280_f32_{k}.annexb"), "rb").read())[0] for k in ("occ", "geo", "attr")]
+    fixture = [open(os.path.join(gold, f"hm_r5_1280x1280_f32_{k}.annexb"), "rb").read() for k in ("occ", "geo", "attr")]
+    first = [gs.split_pairs(s)[0] for s in fixture]
     P = R.StreamParams
     on_p = [P(0, 8, 4, 5, -1, 0, 0, 0), P(1, 24, 4, 5, -1, 0, 0, 1), P(19, 32, 4, 5, -1, 0, 0, 1)]
+    off_p = [P(p.video_type, p.qp, 4, 5, -1, 0, 0, 0) for p in on_p]
     on = ctx.transcode_gof(first, on_p)
     assert on == O.transcode_data(first, [(p.video_type, p.qp, p.occupancy_precision, p.log2_ctb, p.ctb_rows_per_slice, p.md5_sei, p.occupancy_rd) for p in on_p])
-    off = ctx.transcode_gof(first, [P(p.video_type, p.qp, 4, 5, -1, 0, 0, 0) for p in on_p])
+    off = ctx.transcode_gof(first, off_p)
     assert len(on[1]) < 0.6 * len(off[1]) and len(on[2]) < 0.85 * len(off[2])
-    w = h = 1280
-    src = synth.make_maps(w, h, 1051)
-    pats = synth.atlas_patches(R, w, h, 1051)
-
-    def cloud(occ_plane, prec, g2):
-        return ctx.reconstruct(R.AtlasParams(w, h, 16, prec, 2, 1, 1, 0), pats, occ_plane, g2[0][: w * h].reshape(h, w), g2[1][: w * h].reshape(h, w), 10)[0]
-    c_src = cloud(src["occ_full"].astype(np.uint16), 1, src["geo"])
-    d1 = []
-    for outs in (off, on):
-        occ = ctx.decode(outs[0])[0][0][: (w // 4) * (h // 4)].reshape(h // 4, w // 4)
-        d1.append(ctx.d1(c_src, cloud(occ, 4, ctx.decode(outs[1])[0]))["psnr"])
-    assert abs(d1[1] - d1[0]) < 0.5, d1
-    m = (ctx.decode(on[0])[0][0][: (w // 4) * (h // 4)].reshape(h // 4, w // 4) > 0).repeat(4, 0).repeat(4, 1)
+    w = h = 1280; nfr = 4
+    four = [b"".join(gs.split_pairs(s)[:nfr]) for s in fixture]
+    on4, off4 = ctx.transcode_gof(four, on_p), ctx.transcode_gof(four, off_p)
+    d1 = {"off": [], "on": []}
+    for key, outs in (("off", off4), ("on", on4)):
+        occ_d, geo_d = ctx.decode(outs[0])[0], ctx.decode(outs[1])[0]
+        for k in range(nfr):
+            src = synth.make_maps(w, h, 1051 + k)
+            pats = synth.atlas_patches(R, w, h, 1051 + k)
+            cloud = lambda occ_plane, prec, g0, g1: ctx.reconstruct(R.AtlasParams(w, h, 16, prec, 2, 1, 1, 0), pats, occ_plane, g0[: w * h].reshape(h, w), g1[: w * h].reshape(h, w), 10)[0]
+            c_src = cloud(src["occ_full"].astype(np.uint16), 1, src["geo"][0], src["geo"][1])
+            d1[key].append(ctx.d1(c_src, cloud(occ_d[k][: (w // 4) * (h // 4)].reshape(h // 4, w // 4), 4, geo_d[2 * k], geo_d[2 * k + 1]))["psnr"])
+    mean = lambda v: sum(v) / len(v)
+    assert abs(mean(d1["on"]) - mean(d1["off"])) <= 0.1, d1
+    m = (ctx.decode(on4[0])[0][:, : (w // 4) * (h // 4)].reshape(-1, h // 4, w // 4) > 0).repeat(4, 1).repeat(4, 2).repeat(2, 0)      # two maps per point-cloud frame
     for k in (1, 2):
-        ref = ctx.decode(first[k])[0][:, : w * h].reshape(-1, h, w).astype(np.float64)
-        e = [float(np.mean(((ctx.decode(o[k])[0][:, : w * h].reshape(-1, h, w) - ref) ** 2)[:, m])) for o in (off, on)]
-        assert abs(10 * np.log10(e[1] / e[0])) < 0.15, (k, e)
+        ref = ctx.decode(four[k])[0][:, : w * h].reshape(-1, h, w).astype(np.float64)
+        e = [float(np.mean(((ctx.decode(o[k])[0][:, : w * h].reshape(-1, h, w) - ref) ** 2)[m])) for o in (off4, on4)]
+        assert abs(10 * np.log10(e[1] / e[0])) <= 0.1, (k, e)
