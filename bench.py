@@ -600,8 +600,8 @@ def main():
         cpu_out = [O.transcode_substream(sub[0], 0, 8, md5_sei=0, rows_per_slice=args.rows), O.transcode_substream(sub[1], 1, 24, md5_sei=0, rows_per_slice=args.rows), O.transcode_substream(sub[2], 19, 32, md5_sei=0, rows_per_slice=args.rows)]
         ct = time.perf_counter() - c0
         cpu_parity = cpu_out == ctx.transcode_gof(sub, params)     # full-size parity for free: the GPU path on the same sample, byte for byte
-        import shutil
-        x265 = "ffmpeg present" if shutil.which("ffmpeg") else "libx265 / ffmpeg unavailable on this box"
+        import external_tools
+        x265 = "ffmpeg with libx265 present" if external_tools.have_libx265() else "libx265 / ffmpeg unavailable on this box"
         cpu = {"value": round(k / ct, 4), "unit": "point-cloud frames/s", "cores": 1, "kind": "port",
                "sample": f"first {k} point-cloud frames of the same GOF, oracle/liboracle.so (scalar C restatement; {x265}), {ct:.1f} s",
                "output_equals_gpu_path": bool(cpu_parity)}
@@ -623,6 +623,8 @@ def main():
                        "sample": f"all {n_pc} point-cloud frames of the same GOF, one oracle process per core, slowest worker {mt:.1f} s"}
 
     if rank == 0:
+        import external_tools
+        ext = external_tools.describe()
         line = {"metric": "transcoded point-cloud frames/sec, R5->R3", "value": round(fps, 3), "unit": "point-cloud frames/s", "n_gpus": world,
                 "steps": steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "u16/i32", "data": "synthetic",
@@ -636,6 +638,7 @@ def main():
                 "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                              "traffic": traffic, "kernel_ms": {k_: round(v, 3) for k_, v in groups.items()},
                              "path_achieved_GBs": round(path_achieved, 3), "path_frac": round(path_achieved / HBM_PEAK_GBS, 6)},
+                "external_decoder": ext["external_decoder"], "libx265": ext["libx265"],      # third-party HEVC tools on this box (tests/external_tools.py): absent on every box so far - parity with one is unpinned
                 "cabac": cabac, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "sequence_walk": walk, "v3c_file": v3c_file, "rate_fanout": fanout, "multi_gof": multi, "in_flight_sweep": sweep, "quality": quality,
                 "host_ms": {"parse": round(st["host_parse_ms"], 3), "pack": round(st["host_pack_ms"], 3), "submit_call": round(host_submit_ms, 3), "wait_call": round(host_wait_ms, 3), "job_gpu_span": round(st["gpu_ms"], 3), "job_span": round(st["total_ms"], 3)}}
         print(json.dumps(line))
