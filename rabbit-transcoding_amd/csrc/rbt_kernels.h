@@ -51,6 +51,11 @@ void launch_recon_refs(const RbtFrameRef* refs, int n_frames, int max_w_ctb, int
 // pictures' CTBs in dependency order, a CTB waits for the done flags of its left and above-right neighbours (RbtFrame::ctb_done, zeroed beforehand).
 // max_ctbs = CTBs of the largest picture. Tickets are handed out in start order, so every flag a workgroup waits for belongs to one that already runs.
 void launch_recon_level(const RbtFrameRef* refs, int n_frames, int max_ctbs, uint32_t* ticket);
+// One launch per dependency level with a device-side READY queue: persistent workgroups take the next ready CTB, a finished CTB counts itself in at its successors
+// (RbtFrame::ctb_done[2 * addr], zeroed beforehand) and queues those that are complete. qmem: recon_queue_words(total) zeroed 32-bit words; total = CTBs of all pictures of
+// the launch (each picture < 2^18 CTBs, n_frames < 8192); n_wgs workgroups (0: chosen from the pictures).
+void launch_recon_queue(const RbtFrameRef* refs, int n_frames, uint32_t total_ctbs, uint32_t* qmem, int n_wgs);
+inline size_t recon_queue_words(size_t total_ctbs) { return 16 + total_ctbs; }
 // slices of several batches in one launch (pipelines that share a HIP stream: their parsers then run side by side)
 void launch_parse_tasks(const RbtParseTask* tasks, int n_tasks, int max_w4, uint32_t* ticket = nullptr);   // ticket: a zeroed word; hands the list out in start order (needed when it holds row tasks)
 // max_w4: width of the widest picture of the launch in 4-sample units (<= 2048; selects the LDS footprint of the parser)

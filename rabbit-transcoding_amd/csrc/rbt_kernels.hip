@@ -230,6 +230,60 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if ((threadIdx.x & 63) == 0) __hip_atomic_store(&done[2 * addr + role], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// ---- one launch per dependency level with a device-side ready queue (round 4) ----
+// k_recon_level above gives every CTB a workgroup that waits for its neighbours' flags: whatever is resident beyond the CTBs that can run holds LDS and wave slots (with 16
+// jobs in flight that cost more than the shorter level gained), and the static ticket order is only the order of readiness when every CTB takes the same time (the
+// per-diagonal launches show sigma > mean). Here a FEW persistent workgroups - about as many as the level's wavefront is wide - each take the next entry of a queue that is
+// filled in the order CTBs BECOME ready: a finished CTB adds itself to its successors' arrival counts (ctb_done[2 * addr]) and appends the ones whose count is complete.
+// qmem: [0] head (next slot to hand out), [1] tail (next slot to fill, counted from n_frames), [16 + s] slot n_frames + s = (picture << 18 | CTB) + 1; the first n_frames
+// slots are the pictures' CTB 0 and need no memory. A workgroup that has reserved slot s waits until it is filled - by a workgroup that runs and waits for nobody, so the
+// grid drains however few workgroups are resident; all waits are bounded. Hand-off as above: producer stores -> agent-scope release -> s_waitcnt vmcnt(0) -> relaxed
+// atomics; consumer relaxed agent-scope poll -> agent-scope acquire -> its own loads (the arrival counts are a chain of relaxed agent-scope atomics: every producer's
+// stores have reached memory before its count does, and the consumer invalidates after it has seen the last of them).
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) k_recon_queue(const RbtFrameRef* refs, int n_frames, uint32_t total, uint32_t* qmem) {
+  __shared__ RbtReconCtbLds lds;
+  __shared__ uint32_t s_task;
+  uint32_t* head = qmem; uint32_t* tail = qmem + 1; uint32_t* q = qmem + 16;
+  for (;;) {
+    if (threadIdx.x == 0) {
+      uint32_t task = 0;
+      const uint32_t slot = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (slot < total) {
+        if (slot < (uint32_t)n_frames) task = (slot << 18) + 1;
+        else {
+          const uint32_t* p = &q[slot - (uint32_t)n_frames]; int spins = 0;
+          while ((task = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > (1 << 20)) { refs[0].frames[refs[0].frame].error = 92; break; }     // seconds: whoever fills the slot is running; something is broken - leave, the level ends incomplete with the error set
+          }
+        }
+      }
+      s_task = task;
+    }
+    __syncthreads();
+    const uint32_t task = s_task;
+    if (!task) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int fr = (int)((task - 1) >> 18), addr = (int)((task - 1) & 0x3FFFF);
+    const RbtFrameRef r = refs[fr];
+    RbtFrame* f = &r.frames[r.frame];
+    if (f->ctb_slice[addr] != 0xFFFF) recon_ctb_roles(r.frames, r.slices, r.frame, addr, RBT_LDS_CAST(RbtReconCtbLds, &lds));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                             // both halves of the CTB are in memory (and nobody reads s_task or the tile any more)
+    if (threadIdx.x == 0) {
+      const int w = f->cfg.w_ctb, h = f->cfg.h_ctb, x = addr % w, y = addr / w;
+      int succ[3]; const int ns = rc_ctb_successors(w, h, x, y, succ);
+      for (int k = 0; k < ns; k++) {
+        const int a2 = succ[k], need = rc_ctb_need(a2 % w, a2 / w);
+        if ((int)__hip_atomic_fetch_add(&f->ctb_done[2 * a2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == need) {
+          const uint32_t s2 = __hip_atomic_fetch_add(tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&q[s2], ((uint32_t)fr << 18 | (uint32_t)a2) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  }
+}
 // XCD-aware tile order for the kernels whose workgroups are independent. Workgroups go to the 8 XCDs round-robin in launch order, so neighbouring tiles of a picture - which
 // share cache lines (a 32-sample CTB row is half a 128-byte line) and halo rows - would sit behind eight different L2s and every shared line would be fetched from memory once
 // per L2. Tile = the b-th workgroup's position in a CONTIGUOUS eighth of the picture's tiles instead: workgroup b (XCD b % 8) takes tile (b % 8) * (n / 8) + b / 8, the
@@ -289,6 +343,16 @@ void launch_recon_refs(const RbtFrameRef* refs, int n_frames, int max_w_ctb, int
 void launch_recon_level(const RbtFrameRef* refs, int n_frames, int max_ctbs, uint32_t* ticket) {
   if (n_frames <= 0 || max_ctbs <= 0) return;
   hipLaunchKernelGGL(k_recon_level, dim3((unsigned)n_frames * (unsigned)max_ctbs), dim3(128), 0, g_stream, refs, n_frames, ticket);
+}
+// Workgroups of the queue kernel: about what the level's wavefronts are wide. A picture of w x h CTBs has w + 2 (h - 1) anti-diagonals x + 2y = d, so on average
+// w h / (w + 2h - 2) of its CTBs can run side by side (1280x1280 with 64x64 CTBs: 400 / 58 = 7); RBT_RECON_QUEUE_WIDTH=<percent> scales it (experiments).
+static int g_queue_width_pct = -1;
+void launch_recon_queue(const RbtFrameRef* refs, int n_frames, uint32_t total_ctbs, uint32_t* qmem, int n_wgs) {
+  if (n_frames <= 0 || total_ctbs == 0) return;
+  if (g_queue_width_pct < 0) { const char* e = getenv("RBT_RECON_QUEUE_WIDTH"); g_queue_width_pct = e && atoi(e) > 0 ? atoi(e) : 100; }
+  long long n = (long long)n_wgs * g_queue_width_pct / 100;
+  if (n < n_frames) n = n_frames; if (n > (long long)total_ctbs) n = total_ctbs; if (n > 65535 * 16) n = 65535 * 16;
+  hipLaunchKernelGGL(k_recon_queue, dim3((unsigned)n), dim3(128), 0, g_stream, refs, n_frames, total_ctbs, qmem);
 }
 void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_units) {
   if (n_frames <= 0) return;

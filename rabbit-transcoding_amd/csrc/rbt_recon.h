@@ -564,3 +564,17 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
     RBT_PAR_FOR(i, nn * nn) { int x = i & (nn - 1), y = i >> lnn; if (ox + x < pw && oy + y < ph) p[(size_t)(oy + y) * pw + ox + x] = tile[y * S + x + 1]; }
   }
 }
+
+// ---- the dependency graph of a picture's CTBs inside one level (k_recon_queue; the same rule k_recon_level waits by): CTB (x, y) needs its left neighbour and its
+// above-right neighbour - which needed the one above, which needed the one above-left - or, in the last column, the one above. rc_ctb_need: how many of the two exist;
+// rc_ctb_successors: the CTBs that count (x, y) among theirs (at most three: right; below-left; below when x is the last column), returns how many.
+RBT_DEV int rc_ctb_need(int x, int y) { return (x > 0) + (y > 0); }
+RBT_DEV int rc_ctb_successors(int w, int h, int x, int y, int* succ) {
+  int n = 0;
+  if (x + 1 < w) succ[n++] = y * w + x + 1;
+  if (y + 1 < h) {
+    if (x >= 1) succ[n++] = (y + 1) * w + x - 1;
+    if (x == w - 1) succ[n++] = (y + 1) * w + x;
+  }
+  return n;
+}

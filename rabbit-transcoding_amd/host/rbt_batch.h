@@ -36,6 +36,7 @@ struct DecodeBatch {
   std::vector<uint32_t> order_keep; std::vector<size_t> order_off;   // CTB dependency order per picture (host staging, offset per frame)
   std::vector<RbtFrameRef> refs_keep; std::vector<size_t> refs_off;   // the pictures of each level as RbtFrameRef (launch_recon_level)
   bool has_row_tasks = false;      // some segment of a wavefront stream is parsed by a wave of its own (ordered hand-out of the parse tasks, no banded parsing)
+  uint32_t* d_queue = nullptr; std::vector<size_t> queue_off; std::vector<uint32_t> queue_total; std::vector<int> queue_wgs;   // ready queues of the levels (launch_recon_queue): offset in words, CTBs, workgroups
   uint32_t* d_order = nullptr; RbtFrameRef* d_refs = nullptr; uint32_t* d_tickets = nullptr;   // one ticket counter per level + spare ones for merged launches
   void* d_save = nullptr;              // RbtParseSave per slice (resumable parsing), zero-initialised; nullptr when not requested
   bool want_save = false;              // set before decode_build to reserve d_save
@@ -47,6 +48,8 @@ struct DecodeBatch {
 
 int decode_build(DecodeBatch& b, const StreamIn* streams, int n);
 bool recon_by_diagonals();           // per-diagonal launches instead of the flag kernel (see rbt_decode.cpp)
+int recon_mode();                    // 0 = one launch per anti-diagonal, 1 = one launch per level with neighbour flags, 2 = one launch per level with a ready queue (rbt_decode.cpp)
+int recon_queue_width(const RbtStreamCfg& c);   // CTBs of a picture that can be reconstructed side by side, on average (workgroups the ready-queue launch gets per picture)
 void recon_set_depth(int depth);     // jobs the caller keeps in flight (rbt_set_depth)
 int decode_launch(DecodeBatch& b);   // enqueue every decode kernel of the batch on the current stream (no wait)
 int decode_launch_parse(DecodeBatch& b);            // index lists + entropy decoding

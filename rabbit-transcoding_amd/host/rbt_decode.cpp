@@ -137,6 +137,15 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
   for (size_t i = 0; i < nf; i++) { const RbtStreamCfg& c = b.frames[i].cfg; size_t u = (size_t)c.w4 * c.h4, nc = (size_t)c.w_ctb * c.h_ctb;
     o_coef[i] = a.reserve(frame_samples(c) * 2); o_edges[i] = a.reserve(u); o_cnt[i] = a.reserve(nc * 4); o_done[i] = a.reserve(nc * 8); }
   size_t o_tickets = a.reserve(128 * 4);
+  // ready queues of the reconstruction levels (launch_recon_queue), zeroed with the rest of this region
+  b.queue_off.clear(); b.queue_total.clear(); b.queue_wgs.clear();
+  size_t queue_words = 0;
+  for (auto& lf : b.level_frames) {
+    uint32_t tot = 0; int wg = 0;
+    for (int fi : lf) { const RbtStreamCfg& c = b.frames[fi].cfg; tot += (uint32_t)(c.w_ctb * c.h_ctb); wg += recon_queue_width(c); }
+    b.queue_off.push_back(queue_words); b.queue_total.push_back(tot); b.queue_wgs.push_back(wg); queue_words += rbtk::recon_queue_words(tot);
+  }
+  size_t o_queue = a.reserve(queue_words * 4);
   // wavefront streams: progress counters of the CTB rows (zeroed with the rest of this region)
   std::vector<size_t> o_prow_done(nf, 0), o_prow_ctx(nf, 0); std::vector<int> wpp_frame(nf, 0);
   for (size_t i = 0; i < nf; i++) { wpp_frame[i] = b.stream_pps[b.info[i].stream].entropy_coding_sync; if (wpp_frame[i]) o_prow_done[i] = a.reserve((size_t)b.frames[i].cfg.h_ctb * 4); }
@@ -187,7 +196,7 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
     if (wpp_frame[i]) { f.prow_done = (uint32_t*)(base + o_prow_done[i]); f.prow_ctx = (uint8_t*)(((uintptr_t)(base + o_prow_ctx[i]) + 255) & ~(uintptr_t)255);
                         f.prow_line = (uint8_t*)(((uintptr_t)(base + o_prow_line[i]) + 255) & ~(uintptr_t)255); }
   }
-  b.d_order = (uint32_t*)(base + o_order); b.d_refs = (RbtFrameRef*)(base + o_refs); b.d_tickets = (uint32_t*)(base + o_tickets);
+  b.d_order = (uint32_t*)(base + o_order); b.d_refs = (RbtFrameRef*)(base + o_refs); b.d_tickets = (uint32_t*)(base + o_tickets); b.d_queue = (uint32_t*)(base + o_queue);
   b.refs_keep.clear(); b.refs_off.clear();
   for (auto& lf : b.level_frames) { b.refs_off.push_back(b.refs_keep.size()); for (int fi : lf) b.refs_keep.push_back(RbtFrameRef{(RbtFrame*)(base + o_frames), (const RbtSlice*)(base + o_slices), b.d_order + b.order_off[fi], fi, 0}); }
   if (b.level_frames.size() > 32) { b.err = "too many dependency levels"; return b.err_code = RBT_ERR_UNSUPPORTED; }
@@ -206,11 +215,19 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
 // to 40 / 49 ms per job): 598 against 635 frames/s. So: flags while few jobs are in flight (<= 4: the GPU is mostly idle), diagonals beyond.
 // RBT_RECON_DIAG=1 / RBT_RECON_LEVEL=1 force one or the other.
 void recon_set_depth(int depth) { rbtk::set_jobs_in_flight(depth); }      // kept with the device (rbt_kernels.hip Dev): contexts on different devices do not share it
-bool recon_by_diagonals() {
+// Round 4: one launch per level with a device-side READY queue (launch_recon_queue): a few persistent workgroups - about as many as the level's wavefronts are wide -
+// take CTBs in the order they become ready. RBT_RECON_QUEUE=1 / =0 forces it on / off.
+int recon_mode() {
   static int force = -1;
-  if (force < 0) { const char* d = getenv("RBT_RECON_DIAG"); const char* l = getenv("RBT_RECON_LEVEL"); force = d && atoi(d) ? 1 : (l && atoi(l) ? 2 : 0); }
-  return force == 1 || (force == 0 && rbtk::jobs_in_flight() > 4);
+  if (force < 0) { const char* d = getenv("RBT_RECON_DIAG"); const char* l = getenv("RBT_RECON_LEVEL"); const char* q = getenv("RBT_RECON_QUEUE");
+                   force = d && atoi(d) ? 1 : (l && atoi(l) ? 2 : (q && *q ? (atoi(q) ? 3 : 4) : 0)); }
+  if (force == 1) return 0;
+  if (force == 2) return 1;
+  if (force == 3) return 2;
+  return rbtk::jobs_in_flight() > 4 ? 0 : 1;                     // (force 4: the queue off, the round-3 rule)
 }
+bool recon_by_diagonals() { return recon_mode() == 0; }
+int recon_queue_width(const RbtStreamCfg& c) { const int w = c.w_ctb, h = c.h_ctb, d = w + 2 * h - 2; return d > 0 ? std::max(1, (w * h + d - 1) / d) : 1; }
 
 int decode_run(DecodeBatch& b) { int rc = decode_launch(b); return rc ? rc : decode_finish(b); }
 
@@ -305,8 +322,10 @@ void decode_launch_level(DecodeBatch& b, size_t l) {
   const std::vector<int>& lf = b.level_frames[l];
   int mw = 0, mh = 0;
   for (int fi : lf) { const RbtStreamCfg& c = b.frames[fi].cfg; mw = std::max(mw, c.w_ctb); mh = std::max(mh, c.h_ctb); }
-  if (recon_by_diagonals()) rbtk::launch_recon(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l], (int)lf.size(), mw, mh);
-  else rbtk::launch_recon_level(b.d_refs + b.refs_off[l], (int)lf.size(), mw * mh, b.d_tickets + l);
+  const int mode = (lf.size() >= 8192 || (size_t)mw * mh >= ((size_t)1 << 18)) && recon_mode() == 2 ? 0 : recon_mode();      // the queue packs (picture, CTB) into 31 bits
+  if (mode == 0) rbtk::launch_recon(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l], (int)lf.size(), mw, mh);
+  else if (mode == 1) rbtk::launch_recon_level(b.d_refs + b.refs_off[l], (int)lf.size(), mw * mh, b.d_tickets + l);
+  else rbtk::launch_recon_queue(b.d_refs + b.refs_off[l], (int)lf.size(), b.queue_total[l], b.d_queue + b.queue_off[l], b.queue_wgs[l]);
   decode_launch_filters(b, l);
 }
 

@@ -535,28 +535,38 @@ GofJob* gof_submit(int slot, int depth, int n, const uint8_t* const* in, const s
     size_t n_levels = 0; for (int gi : grp) n_levels = std::max(n_levels, db[gi].level_frames.size());
     j.refs_keep.emplace_back(); std::vector<RbtFrameRef>& refs = j.refs_keep.back();
     std::vector<size_t> lv_off(n_levels + 1, 0); std::vector<int> lv_w(n_levels, 0), lv_h(n_levels, 0);
+    std::vector<size_t> lq_off(n_levels + 1, 0); std::vector<uint32_t> lq_total(n_levels, 0); std::vector<int> lq_wgs(n_levels, 0);      // ready queues of the merged levels
     for (size_t l = 0; l < n_levels; l++) {
       lv_off[l] = refs.size();
       for (int gi : grp) if (l < db[gi].level_frames.size()) for (int fi : db[gi].level_frames[l]) {
         refs.push_back(RbtFrameRef{db[gi].d_frames, db[gi].d_slices, db[gi].d_order + db[gi].order_off[fi], fi, 0});
-        lv_w[l] = std::max(lv_w[l], (int)db[gi].frames[fi].cfg.w_ctb); lv_h[l] = std::max(lv_h[l], (int)db[gi].frames[fi].cfg.h_ctb);
+        const RbtStreamCfg& c = db[gi].frames[fi].cfg;
+        lv_w[l] = std::max(lv_w[l], (int)c.w_ctb); lv_h[l] = std::max(lv_h[l], (int)c.h_ctb);
+        lq_total[l] += (uint32_t)(c.w_ctb * c.h_ctb); lq_wgs[l] += recon_queue_width(c);
       }
+      lq_off[l + 1] = lq_off[l] + rbtk::recon_queue_words(lq_total[l]);
     }
     lv_off[n_levels] = refs.size();
+    int rmode = recon_mode();
+    for (size_t l = 0; l < n_levels; l++) if (lv_off[l + 1] - lv_off[l] >= 8192 || (size_t)lv_w[l] * lv_h[l] >= ((size_t)1 << 18)) { if (rmode == 2) rmode = 0; }
     RbtParseTask* d_tasks = (RbtParseTask*)rbtk::dev_alloc(tasks.size() * sizeof(RbtParseTask));
     RbtFrameRef* d_refs = (RbtFrameRef*)rbtk::dev_alloc(refs.size() * sizeof(RbtFrameRef));
     if (d_tasks) pooled.push_back(d_tasks);
     if (d_refs) pooled.push_back(d_refs);
-    if (!d_tasks || !d_refs) { err = "device allocation failed"; rc = RBT_ERR_NOMEM; break; }
+    uint32_t* d_queue = rmode == 2 ? (uint32_t*)rbtk::dev_alloc(lq_off[n_levels] * 4) : nullptr;
+    if (d_queue) pooled.push_back(d_queue);
+    if (!d_tasks || !d_refs || (rmode == 2 && !d_queue)) { err = "device allocation failed"; rc = RBT_ERR_NOMEM; break; }
     rbtk::set_stream(job_stream(j, lead));
+    if (d_queue && rbtk::dev_memset(d_queue, 0, lq_off[n_levels] * 4)) { err = "device transfer failed"; rc = RBT_ERR_NO_DEVICE; break; }
     if (rbtk::h2d(d_tasks, tasks.data(), tasks.size() * sizeof(RbtParseTask)) || rbtk::h2d(d_refs, refs.data(), refs.size() * sizeof(RbtFrameRef))) { err = "device transfer failed"; rc = RBT_ERR_NO_DEVICE; break; }
     bool row_tasks = false; for (int gi : grp) row_tasks |= db[gi].has_row_tasks;
     rbtk::timer_begin(T_PARSE); rbtk::launch_parse_tasks(d_tasks, (int)tasks.size(), mw4, row_tasks ? db[lead].d_tickets + 96 : nullptr); rbtk::timer_end(T_PARSE);
     rbtk::timer_begin(T_RECON);
     for (size_t l = 0; l < n_levels; l++) {
       // the merged launch of level l uses the lead batch's spare ticket counter 32 + l (its own levels use 0..31)
-      if (recon_by_diagonals()) rbtk::launch_recon_refs(d_refs + lv_off[l], (int)(lv_off[l + 1] - lv_off[l]), lv_w[l], lv_h[l]);
-      else rbtk::launch_recon_level(d_refs + lv_off[l], (int)(lv_off[l + 1] - lv_off[l]), lv_w[l] * lv_h[l], db[lead].d_tickets + 32 + l);
+      if (rmode == 0) rbtk::launch_recon_refs(d_refs + lv_off[l], (int)(lv_off[l + 1] - lv_off[l]), lv_w[l], lv_h[l]);
+      else if (rmode == 1) rbtk::launch_recon_level(d_refs + lv_off[l], (int)(lv_off[l + 1] - lv_off[l]), lv_w[l] * lv_h[l], db[lead].d_tickets + 32 + l);
+      else rbtk::launch_recon_queue(d_refs + lv_off[l], (int)(lv_off[l + 1] - lv_off[l]), lq_total[l], d_queue + lq_off[l], lq_wgs[l]);
       for (int gi : grp) if (l < db[gi].level_frames.size()) decode_launch_filters(db[gi], l);
     }
     rbtk::timer_end(T_RECON);

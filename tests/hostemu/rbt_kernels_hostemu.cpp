@@ -98,6 +98,26 @@ void launch_recon_level(const RbtFrameRef* refs, int n_frames, int max_ctbs, uin
     rbt_recon_ctb<RC_ROLE_CHROMA>(frames, refs[k].slices, fi, addr, &lds.t, &lds.role[1]);
   }
 }
+void launch_recon_queue(const RbtFrameRef* refs, int n_frames, uint32_t total, uint32_t* qmem, int) {
+  // the kernel's queue discipline with one worker: seeds first, then whatever becomes ready, in that order; arrival counts in ctb_done as on the device.
+  // Ends short (pictures incomplete, caught by the callers' comparisons) if the graph ever failed to make a CTB ready.
+  static RbtReconCtbLds lds;
+  uint32_t* q = qmem + 16; uint32_t head = 0, tail = 0;
+  while (head < total) {
+    uint32_t task;
+    if (head < (uint32_t)n_frames) task = (head << 18) + 1; else { if (head - (uint32_t)n_frames >= tail) break; task = q[head - (uint32_t)n_frames]; }
+    head++;
+    const int fr = (int)((task - 1) >> 18), addr = (int)((task - 1) & 0x3FFFF);
+    RbtFrame* frames = refs[fr].frames; const int fi = refs[fr].frame; RbtFrame* f = &frames[fi];
+    if (f->ctb_slice[addr] != 0xFFFF) {
+      rbt_recon_ctb<RC_ROLE_LUMA>(frames, refs[fr].slices, fi, addr, &lds.t, &lds.role[0]);
+      rbt_recon_ctb<RC_ROLE_CHROMA>(frames, refs[fr].slices, fi, addr, &lds.t, &lds.role[1]);
+    }
+    const int w = f->cfg.w_ctb, h = f->cfg.h_ctb; int succ[3]; const int ns = rc_ctb_successors(w, h, addr % w, addr / w, succ);
+    for (int k = 0; k < ns; k++) if ((int)++f->ctb_done[2 * succ[k]] == rc_ctb_need(succ[k] % w, succ[k] / w)) q[tail++] = ((uint32_t)fr << 18 | (uint32_t)succ[k]) + 1;
+  }
+  qmem[0] = head; qmem[1] = tail;
+}
 void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int y_begin, int y_end) {
   static RbtReconCtbLds lds;
   if (y_end > max_h_ctb) y_end = max_h_ctb;

@@ -78,3 +78,13 @@ def test_slice_segments_must_tile_the_picture(ctx):
     t0 = time.time()
     T.slice_segment_damage(ctx, rbt_lib.module())
     assert time.time() - t0 < 60
+
+
+@pytest.mark.parametrize("mode", ["RBT_RECON_QUEUE", "RBT_RECON_LEVEL", "RBT_RECON_DIAG"])
+def test_every_reconstruction_mode_on_the_gpu(mode):
+    """one launch per anti-diagonal / per level with neighbour flags / per level with a device-side ready queue (k_recon_queue, round 4: persistent workgroups, arrival
+    counts, no host involvement): same pictures, same streams, at depths 1, 4 and 16, incl. a full-size picture pair (tests/recon_mode_worker.py in a child process, the
+    mode is read once per process). The default mixes the first two by depth; the ready queue measured slower under load (profiles/r04_recon_mode_sweep.txt) and stays opt-in."""
+    import os, subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "recon_mode_worker.py"), "gpu"], env=dict(os.environ, **{mode: "1"}), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("OK 13"), (r.stdout[-500:], r.stderr[-3000:])

@@ -395,3 +395,13 @@ def slice_segment_damage(ctx, R):
 
 def test_slice_segments_must_tile_the_picture(ctx):
     slice_segment_damage(ctx, rbt_lib.module())
+
+
+@pytest.mark.parametrize("mode", ["RBT_RECON_QUEUE", "RBT_RECON_LEVEL", "RBT_RECON_DIAG"])
+def test_every_reconstruction_mode_gives_the_same_pictures(mode):
+    """the three ways a dependency level is launched (one launch per anti-diagonal; one per level with neighbour flags; one per level with a ready queue, round 4): the host
+    build walks each one's order serially - the ready queue by the kernel's own rules (rc_ctb_successors / rc_ctb_need, first in first out) - and all must reproduce the
+    oracle. The mode is read once per process, hence the child process (tests/recon_mode_worker.py); the GPU run of the same cases: tests/test_gpu_decode.py"""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "recon_mode_worker.py"), "hostemu"], env=dict(os.environ, **{mode: "1"}), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("OK 12"), (r.stdout[-500:], r.stderr[-3000:])
