@@ -184,6 +184,11 @@ typedef struct {
   int32_t occupancy_resolution;          /* 16 in the CTC (cfg/common/ctc-common.cfg) */
   int32_t occupancy_precision;           /* atlas size / occupancy video size: 2 at R5, 4 after the transcoder's OR-pool */
   int32_t map_count, absolute_d1, remove_duplicate_points, threshold_lossy_om;
+  /* Geometry smoothing of the decoder's post-processing, which the CTC switches on (cfg/common/ctc-common.cfg:57-60: flagGeometrySmoothing 1, gridSmoothing 1, gridSize 8,
+   * thresholdSmoothing 64; PCCDecoder.cpp:434-437 -> PCCCodec::smoothPointCloudPostprocess, PCCCodec.cpp:52-145, :980-1104): boundary points (identifyBoundaryPoints, :266-325)
+   * next to cells that hold points of more than one patch move towards the tri-linear blend of the 8 surrounding cell centroids. geometry_smoothing 0 = off (the cloud as
+   * generatePointCloud leaves it); grid_size 2..255, even (the reference's cfg uses 8). Exact for cells of fewer than 16384 points (the reference sums centroids in float). */
+  int32_t geometry_smoothing, grid_size, threshold_smoothing;
 } rbt_atlas_params;
 typedef struct {             /* host memory, released with rbt_cloud_free */
   int n_points;
@@ -192,6 +197,7 @@ typedef struct {             /* host memory, released with rbt_cloud_free */
                                 converts to 4:4:4 first, PccLibColorConverter, out of scope) */
   uint8_t* occupancy_map;    /* width x height: the up-scaled, binarised occupancy map */
   uint32_t* block_to_patch;  /* (width / res) x (height / res): patch index + 1 */
+  int n_smoothed;            /* points the geometry smoothing moved */
 } rbt_cloud;
 /* occ_luma: occupancy video luma, (width / precision) x (height / precision); geo_d0 / geo_d1: luma of the near / far geometry map, width x
  * height samples of geo_bit_depth bits (mapped to 8 bits like PCCImage::set, PCCImage.h:107-124); attr_t0 / attr_t1: planar 4:2:0 attribute

@@ -13,6 +13,9 @@
  *   PCCCodec::colorPointCloud                            :1308-1449 (the `f < mapCount` fetch :1417-1421)
  *   QualityMetrics::compute                              source/lib/PccLibMetrics/source/PCCMetrics.cpp:75-231 (point-to-point part), getPSNR :44-48,
  *                                                        symmetric result :299-309, duplicate points merged first (PCCMetricsParameters.cpp:50)
+ *   PCCCodec::identifyBoundaryPoints                     :266-325, called per point at :962-972
+ *   PCCCodec::smoothPointCloudPostprocess (gridSmoothing) :52-145 with addGridCentroid :980-998, gridFiltering :1000-1063, smoothPointCloudGrid :1065-1104
+ *                                                        (oracle_atlas.geometry_smoothing; call site PCCDecoder.cpp:434-437, parameters cfg/common/ctc-common.cfg:57-60)
  * PARITY UNPINNED: PccLibCommon / PccLibMetrics need a cmake-generated PCCConfig.h (plus TBB and nanoflann) and the reference holds no
  * fixtures for this stage; the restatement follows the source text. The 4:2:0 -> 4:4:4 conversion of the attribute video in front of
  * colorPointCloud is PccLibColorConverter (out of scope): chroma is fetched at the co-sited half-resolution sample here.
@@ -69,6 +72,103 @@ static void gen_point(const oracle_patch* p, int u, int v, int depth, int16_t ou
   out[p->bitangent_axis] = (int16_t)(v * p->lod_y + p->v1);
 }
 
+/* PCCCodec::identifyBoundaryPoints (:266-325) for an occupied pixel: 1 when the point ends with boundary point type 1. First layer: an unoccupied pixel among the 8
+ * neighbours (each test only for pixels off the respective picture border, as written) or the pixel on the picture border; second layer: an unoccupied pixel in the ring two
+ * away, or the pixel one off the picture border. */
+static int boundary_point(const uint8_t* om, int x, int y, int W, int H) {
+#define OM(xx, yy) om[(size_t)(yy) * W + (xx)]
+  int t = 0;
+  if (y > 0 && y < H - 1) if (OM(x, y - 1) == 0 || OM(x, y + 1) == 0) t = 1;
+  if (x > 0 && x < W - 1 && !t) if (OM(x + 1, y) == 0 || OM(x - 1, y) == 0) t = 1;
+  if (y > 0 && y < H - 1 && x > 0 && !t) if (OM(x - 1, y - 1) == 0 || OM(x - 1, y + 1) == 0) t = 1;
+  if (y > 0 && y < H - 1 && x < W - 1 && !t) if (OM(x + 1, y - 1) == 0 || OM(x + 1, y + 1) == 0) t = 1;
+  if (y == 0 || y == H - 1 || x == 0 || x == W - 1) t = 1;
+  if (!t) {
+    for (int ix = -2; ix <= 2 && !t; ix++) for (int iy = -2; iy <= 2 && !t; iy++)
+      if ((ix > 1 || ix < -1 || iy > 1 || iy < -1) && y + iy >= 0 && y + iy < H && x + ix >= 0 && x + ix < W && OM(x + ix, y + iy) == 0) t = 1;
+    if (y == 1 || y == H - 2 || x == 1 || x == W - 2) t = 1;
+  }
+#undef OM
+  return t;
+}
+/* PCCCodec::smoothPointCloudPostprocess with gridSmoothing (:52-145) + smoothPointCloudGrid (:1065-1104), arithmetic types as in the reference: cell centres are float
+ * sums divided by a uint16_t count, the filter works in double. Returns the number of points moved. */
+static int smooth_grid(int16_t* xyz, int n, const uint8_t* btype, const uint32_t* part, int g, int threshold) {
+  int maxv = xyz[0] > xyz[1] ? xyz[0] : xyz[1]; if (xyz[2] > maxv) maxv = xyz[2];          /* bounding box :70-80: only max_ is used (:81) */
+  int bmax[3] = {xyz[0], xyz[1], xyz[2]};
+  for (int j = 0; j < n; j++) for (int k = 0; k < 3; k++) if (xyz[3 * j + k] > bmax[k]) bmax[k] = xyz[3 * j + k];
+  maxv = bmax[0] > bmax[1] ? bmax[0] : bmax[1]; if (bmax[2] > maxv) maxv = bmax[2];
+  const int w = (maxv + g - 1) / g, disth = g / 2 > 1 ? g / 2 : 1, th = g * w;
+  if (w <= 0) return 0;
+  const size_t w3 = (size_t)w * w * w;
+  int* cell = (int*)malloc(w3 * sizeof(int)); for (size_t i = 0; i < w3; i++) cell[i] = -1;
+  int n_cells = 0;
+#define SKIP(P) ((P)[0] < disth || (P)[1] < disth || (P)[2] < disth || th <= (P)[0] + disth || th <= (P)[1] + disth || th <= (P)[2] + disth)
+  for (int i = 0; i < n; i++) if (btype[i] == 1) {                                      /* boundary cells :88-113 */
+    const int P[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    if (SKIP(P)) continue;
+    int Q[3]; for (int k = 0; k < 3; k++) Q[k] = P[k] / g + ((P[k] % g < g / 2) ? -1 : 0);
+    for (int ix = 0; ix < 2; ix++) for (int iy = 0; iy < 2; iy++) for (int iz = 0; iz < 2; iz++) {
+      const size_t id = (size_t)(Q[0] + ix) + (size_t)(Q[1] + iy) * w + (size_t)(Q[2] + iz) * w * w;
+      if (cell[id] == -1) cell[id] = n_cells++;
+    }
+  }
+  float* centre = (float*)calloc((size_t)(n_cells ? n_cells : 1) * 3, sizeof(float)); uint16_t* count = (uint16_t*)calloc((size_t)(n_cells ? n_cells : 1), 2);
+  uint32_t* cpart = (uint32_t*)calloc((size_t)(n_cells ? n_cells : 1), 4); uint8_t* do_smooth = (uint8_t*)calloc((size_t)(n_cells ? n_cells : 1), 1);
+  for (int j = 0; j < n; j++) {                                                         /* centroids :122-137, addGridCentroid :980-998 */
+    const int P[3] = {xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2]};
+    if (SKIP(P)) continue;
+    const size_t id = (size_t)(P[0] / g) + (size_t)(P[1] / g) * w + (size_t)(P[2] / g) * w * w;
+    const int c = cell[id]; if (c == -1) continue;
+    const uint32_t pidx = part[j] + 1;
+    if (count[c] == 0) { cpart[c] = pidx; centre[3 * c] = centre[3 * c + 1] = centre[3 * c + 2] = 0.f; do_smooth[c] = 0; }
+    else if (!do_smooth[c] && cpart[c] != pidx) do_smooth[c] = 1;
+    for (int k = 0; k < 3; k++) centre[3 * c + k] += (float)P[k];
+    count[c]++;
+  }
+  for (int c = 0; c < n_cells; c++) if (count[c] != 0) for (int k = 0; k < 3; k++) centre[3 * c + k] /= (float)count[c];   /* :138-140 */
+  int moved = 0;
+  for (int ci = 0; ci < n; ci++) {                                                      /* smoothPointCloudGrid :1065-1104 */
+    const int P[3] = {xyz[3 * ci], xyz[3 * ci + 1], xyz[3 * ci + 2]};
+    if (SKIP(P) || btype[ci] != 1) continue;
+    /* gridFiltering :1000-1063 */
+    const int half = g / 2;
+    int S[3], Wt[3], idx[2][2][2], other = 0;
+    for (int k = 0; k < 3; k++) { const int P2 = P[k] / g, P3 = P[k] - P2 * g; S[k] = P2 + (P3 < half ? -1 : 0); }
+    for (int dz = 0; dz < 2; dz++) for (int dy = 0; dy < 2; dy++) for (int dx = 0; dx < 2; dx++) {
+      const int tmp = (S[0] + dx) + (S[1] + dy) * w + (S[2] + dz) * w * w; idx[dz][dy][dx] = tmp;
+      if (do_smooth[cell[tmp]] && count[cell[tmp]] != 0) other = 1;
+    }
+    if (!other) continue;
+    double c3[2][2][2][3]; const double cur[3] = {(double)P[0], (double)P[1], (double)P[2]};
+    const int g2 = g * 2;
+    for (int k = 0; k < 3; k++) Wt[k] = (P[k] - S[k] * g - half) * 2 + 1;
+    for (int dz = 0; dz < 2; dz++) for (int dy = 0; dy < 2; dy++) for (int dx = 0; dx < 2; dx++) {
+      const int c = cell[idx[dz][dy][dx]];
+      for (int k = 0; k < 3; k++) c3[dz][dy][dx][k] = count[c] > 0 ? (double)centre[3 * c + k] : cur[k];
+    }
+    const int Q[3] = {g2 - Wt[0], g2 - Wt[1], g2 - Wt[2]};
+    int cnt = 0; double c4[3] = {0.0, 0.0, 0.0};
+    for (int dz = 0, cc = Q[2]; dz < 2; dz++, cc = Wt[2]) for (int dy = 0, bb = Q[1]; dy < 2; dy++, bb = Wt[1]) for (int dx = 0, aa = Q[0]; dx < 2; dx++, aa = Wt[0]) {
+      for (int k = 0; k < 3; k++) { c3[dz][dy][dx][k] *= (double)(aa * bb * cc); c4[k] += c3[dz][dy][dx][k]; }
+      cnt += aa * bb * cc * (int)count[cell[idx[dz][dy][dx]]];
+    }
+    for (int k = 0; k < 3; k++) c4[k] /= (double)(g2 * g2 * g2);
+    cnt /= g2 * g2 * g2;
+    double centroid[3]; for (int k = 0; k < 3; k++) centroid[k] = c4[k] * (double)cnt;
+    if (cnt == 0) continue;                                                             /* the reference divides by zero here: NaN, and the comparison below is false */
+    double d[3]; for (int k = 0; k < 3; k++) d[k] = cur[k] * (double)cnt - centroid[k];
+    const double dist2 = (d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) / (double)cnt + 0.5;
+    if (dist2 >= (double)((threshold > cnt ? threshold : cnt) * 2)) {
+      for (int k = 0; k < 3; k++) { const double v = centroid[k] / (double)cnt + 0.5; xyz[3 * ci + k] = (int16_t)(double)(int64_t)v; }
+      moved++;
+    }
+  }
+#undef SKIP
+  free(cell); free(centre); free(count); free(cpart); free(do_smooth);
+  return moved;
+}
+
 int oracle_reconstruct(const oracle_atlas* a, const oracle_patch* patches, int n_patches, const uint16_t* occ, const uint16_t* d0, const uint16_t* d1, int geo_bd,
                        const uint16_t* t0, const uint16_t* t1, int attr_bd, oracle_cloud* out) {
   const int W = a->width, H = a->height, res = a->occupancy_resolution, prec = a->occupancy_precision, ow = W / prec;
@@ -96,6 +196,7 @@ int oracle_reconstruct(const oracle_atlas* a, const oracle_patch* patches, int n
   /* generatePointCloud (:628-838) */
   size_t cap = 1024, n = 0;
   int16_t* xyz = (int16_t*)malloc(cap * 6); uint16_t* col = (uint16_t*)malloc(cap * 6);
+  uint8_t* btype = (uint8_t*)malloc(cap); uint32_t* part = (uint32_t*)malloc(cap * 4);      /* getBoundaryPointType == 1 (identifyBoundaryPoints on the point's pixel, :962-972), partition[] (:819) */
   const int cw = W / 2;
   for (int pi = 0; pi < n_patches; pi++) {
     const oracle_patch* p = &patches[pi];
@@ -115,8 +216,9 @@ int oracle_reconstruct(const oracle_atlas* a, const oracle_patch* patches, int n
         }
         for (int i = 0; i < np; i++) {
           if (a->remove_duplicate_points && i > 0 && !memcmp(pt[i], pt[0], 6)) continue;   /* :793-794 */
-          if (n == cap) { cap *= 2; xyz = (int16_t*)realloc(xyz, cap * 6); col = (uint16_t*)realloc(col, cap * 6); }
+          if (n == cap) { cap *= 2; xyz = (int16_t*)realloc(xyz, cap * 6); col = (uint16_t*)realloc(col, cap * 6); btype = (uint8_t*)realloc(btype, cap); part = (uint32_t*)realloc(part, cap * 4); }
           memcpy(xyz + 3 * n, pt[i], 6);
+          btype[n] = (uint8_t)boundary_point(om, x, y, W, H); part[n] = (uint32_t)pi;
           const uint16_t* t = i == 0 ? t0 : t1;    /* colorPointCloud :1417-1421: frame shift + f, pixel (x,y) */
           if (t) { col[3 * n] = t[(size_t)y * W + x]; col[3 * n + 1] = t[(size_t)W * H + (size_t)(y / 2) * cw + x / 2]; col[3 * n + 2] = t[(size_t)W * H + (size_t)cw * (H / 2) + (size_t)(y / 2) * cw + x / 2]; }
           else col[3 * n] = col[3 * n + 1] = col[3 * n + 2] = (uint16_t)(1 << (attr_bd - 1));
@@ -126,6 +228,11 @@ int oracle_reconstruct(const oracle_atlas* a, const oracle_patch* patches, int n
     }
   }
   out->n = (int)n; out->xyz = xyz; out->yuv = col; out->occupancy_map = om; out->block_to_patch = b2p;
+  if (a->geometry_smoothing && n > 0) {
+    if (a->grid_size < 2 || a->grid_size > 255) { free(btype); free(part); return -3; }
+    out->n_smoothed = smooth_grid(xyz, (int)n, btype, part, a->grid_size, a->threshold_smoothing);
+  }
+  free(btype); free(part);
   return 0;
 }
 void oracle_cloud_free(oracle_cloud* c) { free(c->xyz); free(c->yuv); free(c->occupancy_map); free(c->block_to_patch); memset(c, 0, sizeof(*c)); }

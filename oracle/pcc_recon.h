@@ -18,8 +18,11 @@ typedef struct {
   int32_t occupancy_resolution;          /* 16 (cfg/common/ctc-common.cfg) */
   int32_t occupancy_precision;           /* atlas size / occupancy video size */
   int32_t map_count, absolute_d1, remove_duplicate_points, threshold_lossy_om;
+  /* geometry smoothing of the decoder's post-processing (PCCDecoder.cpp:434-437 -> PCCCodec::smoothPointCloudPostprocess with gridSmoothing, PCCCodec.cpp:52-145, :980-1104;
+   * the CTC switches it on: cfg/common/ctc-common.cfg:57-60 flagGeometrySmoothing 1, gridSmoothing 1, gridSize 8, thresholdSmoothing 64). 0 = off. */
+  int32_t geometry_smoothing, grid_size, threshold_smoothing;
 } oracle_atlas;
-typedef struct { int n; int16_t* xyz; uint16_t* yuv; uint8_t* occupancy_map; uint32_t* block_to_patch; } oracle_cloud;
+typedef struct { int n; int16_t* xyz; uint16_t* yuv; uint8_t* occupancy_map; uint32_t* block_to_patch; int n_smoothed; } oracle_cloud;   /* n_smoothed: points the geometry smoothing moved */
 typedef struct { int n_a, n_b; uint64_t sse_ab, sse_ba, max_ab, max_ba; float mse_ab, mse_ba, psnr_ab, psnr_ba, psnr; } oracle_d1_result;
 
 /* occ: occupancy video luma (width / precision x height / precision); d0, d1: luma of the two geometry maps (width x height samples of geo_bd

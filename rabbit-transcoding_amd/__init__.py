@@ -46,11 +46,19 @@ class Patch(C.Structure):
 
 
 class AtlasParams(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("width", "height", "occupancy_resolution", "occupancy_precision", "map_count", "absolute_d1", "remove_duplicate_points", "threshold_lossy_om")]
+    _fields_ = [(n, C.c_int32) for n in ("width", "height", "occupancy_resolution", "occupancy_precision", "map_count", "absolute_d1", "remove_duplicate_points", "threshold_lossy_om",
+                                            "geometry_smoothing", "grid_size", "threshold_smoothing")]      # the last three default to 0 = no smoothing; CTC: 1, 8, 64
+
+
+def ctc_smoothing(atlas):
+    """the same atlas with the geometry smoothing of the CTC switched on (cfg/common/ctc-common.cfg:57-60: gridSmoothing, gridSize 8, thresholdSmoothing 64)"""
+    a = AtlasParams(*[getattr(atlas, n) for n, _ in AtlasParams._fields_])
+    a.geometry_smoothing, a.grid_size, a.threshold_smoothing = 1, 8, 64
+    return a
 
 
 class Cloud(C.Structure):
-    _fields_ = [("n_points", C.c_int), ("xyz", C.POINTER(C.c_int16)), ("yuv", C.POINTER(C.c_uint16)), ("occupancy_map", C.POINTER(C.c_uint8)), ("block_to_patch", C.POINTER(C.c_uint32))]
+    _fields_ = [("n_points", C.c_int), ("xyz", C.POINTER(C.c_int16)), ("yuv", C.POINTER(C.c_uint16)), ("occupancy_map", C.POINTER(C.c_uint8)), ("block_to_patch", C.POINTER(C.c_uint32)), ("n_smoothed", C.c_int)]
 
 
 class D1Result(C.Structure):
@@ -354,6 +362,7 @@ class Context:
         n, w, h, res = c.n_points, atlas.width, atlas.height, atlas.occupancy_resolution
         xyz = np.ctypeslib.as_array(c.xyz, shape=(max(n, 1), 3))[:n].copy(); yuv = np.ctypeslib.as_array(c.yuv, shape=(max(n, 1), 3))[:n].copy()
         om = np.ctypeslib.as_array(c.occupancy_map, shape=(h, w)).copy(); b2p = np.ctypeslib.as_array(c.block_to_patch, shape=(h // res, w // res)).copy()
+        self.n_smoothed = c.n_points and c.n_smoothed      # points the geometry smoothing moved in this call
         self.L.rbt_cloud_free(C.byref(c))
         return xyz, yuv, om, b2p
 

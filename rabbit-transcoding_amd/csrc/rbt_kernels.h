@@ -8,6 +8,7 @@
 #include "../../include/rbt.h"
 
 struct RbtPccParams;
+struct RbtSmooth;
 namespace rbtk {
 int dev_init(int device);                 // 0 = ok; creates the device's streams / events on first use and selects the device for this thread
 int dev_select(int device);               // makes an initialised device the calling thread's current one (every C-ABI entry point calls it)
@@ -97,7 +98,10 @@ void launch_pcc_owner(const RbtPccParams* P, const rbt_patch* patches, const uin
 void launch_pcc_count(const RbtPccParams* P, const rbt_patch* patches, const uint32_t* items, int n_items, const uint16_t* occ, const uint16_t* d0, const uint16_t* d1, const uint32_t* b2p, uint32_t* counts);
 void launch_scan_u32(const uint32_t* in, uint32_t* out, int n);      // out[i] = sum of in[0..i), out[n] = total
 void launch_pcc_emit(const RbtPccParams* P, const rbt_patch* patches, const uint32_t* items, int n_items, const uint16_t* occ, const uint16_t* d0, const uint16_t* d1, const uint16_t* t0, const uint16_t* t1,
-                     const uint32_t* b2p, const uint32_t* offsets, int16_t* xyz, uint16_t* yuv);
+                     const uint32_t* b2p, const uint32_t* offsets, int16_t* xyz, uint16_t* yuv, const uint8_t* om = nullptr, uint32_t* meta = nullptr);   // meta (with om): per point, patch index | boundary point << 31
+// geometry smoothing (rbt_pcc.h RbtSmooth): the largest coordinate of the cloud (*out zeroed beforehand), then the three passes mark / accum / filter over dense cell arrays
+void launch_sm_max(const int16_t* xyz, int n_points, uint32_t* out);
+void launch_sm_passes(const RbtSmooth* G, int16_t* xyz, const uint32_t* meta);
 void launch_vol_set(const int16_t* xyz, int n, uint32_t* vol, uint8_t* first, uint32_t* n_unique);
 void launch_vol_nn(const int16_t* xyz, const uint8_t* first, int n, const uint32_t* vol_other, unsigned long long* sse, uint32_t* max_d2);
 // D2 (csrc/rbt_pcc.h): bit volume + voxel -> lowest index map of a cloud; normals of the reconstruction (sum, count) from the source's; point-to-plane sums

@@ -628,7 +628,7 @@ __global__ void __launch_bounds__(256) k_pcc_count(RbtPccParams P, const rbt_pat
   if (threadIdx.x == 0) counts[blockIdx.x] = (uint32_t)total;
 }
 __global__ void __launch_bounds__(256) k_pcc_emit(RbtPccParams P, const rbt_patch* patches, const uint32_t* items, const uint16_t* occ, const uint16_t* d0, const uint16_t* d1, const uint16_t* t0, const uint16_t* t1,
-                                                  const uint32_t* b2p, const uint32_t* offsets, int16_t* xyz, uint16_t* yuv) {
+                                                  const uint32_t* b2p, const uint32_t* offsets, int16_t* xyz, uint16_t* yuv, const uint8_t* om, uint32_t* meta) {
   const uint32_t it = items[blockIdx.x]; const int pi = (int)(it >> 16), blk = (int)(it & 0xFFFF);
   const rbt_patch* p = &patches[pi]; const int ub = blk % p->size_u0, vb = blk / p->size_u0;
   if (b2p[pc_block2canvas(p, ub, vb, P.bw)] != (uint32_t)pi + 1) return;         // uniform over the workgroup
@@ -639,8 +639,26 @@ __global__ void __launch_bounds__(256) k_pcc_emit(RbtPccParams P, const rbt_patc
     const int n = q < P.res * P.res ? pc_pixel_points(&P, p, occ, d0, d1, t0, t1, ub, vb, q, pts, col) : 0;
     int total; const int off = pcc_block_scan(n, &total);
     for (int i = 0; i < n; i++) for (int c = 0; c < 3; c++) { xyz[3 * (size_t)(base + off + i) + c] = pts[3 * i + c]; yuv[3 * (size_t)(base + off + i) + c] = col[3 * i + c]; }
+    if (meta && n) {                                                               // geometry smoothing: the point's patch and whether its pixel is a boundary pixel
+      int x, y; pc_patch2canvas(p, P.res, ub * P.res + q % P.res, vb * P.res + q / P.res, &x, &y);
+      const uint32_t m = (uint32_t)pi | ((uint32_t)pc_boundary_point(om, x, y, P.w, P.h) << 31);
+      for (int i = 0; i < n; i++) meta[base + off + i] = m;
+    }
     base += (uint32_t)total;
   }
+}
+// geometry smoothing (rbt_pcc.h): one lane per point; max of all coordinates first (the grid's extent)
+__global__ void __launch_bounds__(256) k_sm_max(const int16_t* xyz, int n3, uint32_t* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  int v = i < n3 ? xyz[i] : 0; if (v < 0) v = 0;
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(out, (uint32_t)v);
+}
+__global__ void __launch_bounds__(256) k_sm_mark(RbtSmooth G, const int16_t* xyz, const uint32_t* meta) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < G.n_points) pc_sm_mark(&G, xyz, meta, i); }
+__global__ void __launch_bounds__(256) k_sm_accum(RbtSmooth G, const int16_t* xyz, const uint32_t* meta) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < G.n_points) pc_sm_accum(&G, xyz, meta, i); }
+__global__ void __launch_bounds__(256) k_sm_filter(RbtSmooth G, int16_t* xyz, const uint32_t* meta) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < G.n_points && pc_sm_filter(&G, xyz, meta, i)) atomicAdd(G.moved, 1u);
 }
 // exclusive prefix sum of n <= a few 10^4 counts in one workgroup: every thread sums a contiguous chunk, the chunk sums are scanned in LDS
 __global__ void __launch_bounds__(1024) k_scan_u32(const uint32_t* in, uint32_t* out, int n) {
@@ -701,8 +719,16 @@ void launch_pcc_count(const RbtPccParams* P, const rbt_patch* patches, const uin
 }
 void launch_scan_u32(const uint32_t* in, uint32_t* out, int n) { hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, g_stream, in, out, n); }
 void launch_pcc_emit(const RbtPccParams* P, const rbt_patch* patches, const uint32_t* items, int n_items, const uint16_t* occ, const uint16_t* d0, const uint16_t* d1, const uint16_t* t0, const uint16_t* t1,
-                     const uint32_t* b2p, const uint32_t* offsets, int16_t* xyz, uint16_t* yuv) {
-  if (n_items > 0) hipLaunchKernelGGL(k_pcc_emit, dim3(n_items), dim3(256), 0, g_stream, *P, patches, items, occ, d0, d1, t0, t1, b2p, offsets, xyz, yuv);
+                     const uint32_t* b2p, const uint32_t* offsets, int16_t* xyz, uint16_t* yuv, const uint8_t* om, uint32_t* meta) {
+  if (n_items > 0) hipLaunchKernelGGL(k_pcc_emit, dim3(n_items), dim3(256), 0, g_stream, *P, patches, items, occ, d0, d1, t0, t1, b2p, offsets, xyz, yuv, om, meta);
+}
+void launch_sm_max(const int16_t* xyz, int n_points, uint32_t* out) { if (n_points > 0) hipLaunchKernelGGL(k_sm_max, dim3((3 * n_points + 255) / 256), dim3(256), 0, g_stream, xyz, 3 * n_points, out); }
+void launch_sm_passes(const RbtSmooth* G, int16_t* xyz, const uint32_t* meta) {
+  if (G->n_points <= 0) return;
+  const dim3 grid((G->n_points + 255) / 256);
+  hipLaunchKernelGGL(k_sm_mark, grid, dim3(256), 0, g_stream, *G, xyz, meta);
+  hipLaunchKernelGGL(k_sm_accum, grid, dim3(256), 0, g_stream, *G, xyz, meta);
+  hipLaunchKernelGGL(k_sm_filter, grid, dim3(256), 0, g_stream, *G, xyz, meta);
 }
 void launch_vol_set(const int16_t* xyz, int n, uint32_t* vol, uint8_t* first, uint32_t* n_unique) { if (n > 0) hipLaunchKernelGGL(k_vol_set, dim3((n + 255) / 256), dim3(256), 0, g_stream, xyz, n, vol, first, n_unique); }
 void launch_vol_nn(const int16_t* xyz, const uint8_t* first, int n, const uint32_t* vol_other, unsigned long long* sse, uint32_t* max_d2) {

@@ -198,3 +198,97 @@ RBT_DEV double pc_d2_value(const RbtD2Set* P, const RbtD2Set* Q, const long long
   });
   return sum / n / (16384.0 * 16384.0);
 }
+
+// ---- geometry smoothing (rbt_atlas_params.geometry_smoothing): PCCCodec::identifyBoundaryPoints (PCCCodec.cpp:266-325) and smoothPointCloudPostprocess with gridSmoothing
+// (:52-145, addGridCentroid :980-998, gridFiltering :1000-1063, smoothPointCloudGrid :1065-1104) ----
+// The reference walks the point list three times and numbers the cells it meets; nothing in its result depends on that numbering or on the order of the points (centroid
+// sums are exact in float below 2^24, "a second patch in the cell" is min != max of the patch indices), so here every pass is one lane per point over dense w^3 cell arrays:
+//   mark   boundary points flag the 8 cells around them                       (cellIndex != -1)
+//   accum  every point adds itself to its own cell if that is flagged          (atomicAdd of coordinates and count, atomicMin / atomicMax of patch index + 1)
+//   filter boundary points next to a cell with two patches move to the tri-linear blend of the 8 cell centroids when they are far enough from it - the reference's
+//          float / double arithmetic operation for operation (no contraction into fused multiply-adds), so the moved points are bit-identical
+// identifyBoundaryPoints for an occupied pixel (x, y) of the up-scaled occupancy map: 1 when the point gets boundary point type 1
+RBT_DEV int pc_boundary_point(const uint8_t* om, int x, int y, int W, int H) {
+#define RBT_OM(xx, yy) om[(size_t)(yy) * W + (xx)]
+  int t = 0;
+  if (y > 0 && y < H - 1 && (RBT_OM(x, y - 1) == 0 || RBT_OM(x, y + 1) == 0)) t = 1;
+  if (!t && x > 0 && x < W - 1 && (RBT_OM(x + 1, y) == 0 || RBT_OM(x - 1, y) == 0)) t = 1;
+  if (!t && y > 0 && y < H - 1 && x > 0 && (RBT_OM(x - 1, y - 1) == 0 || RBT_OM(x - 1, y + 1) == 0)) t = 1;
+  if (!t && y > 0 && y < H - 1 && x < W - 1 && (RBT_OM(x + 1, y - 1) == 0 || RBT_OM(x + 1, y + 1) == 0)) t = 1;
+  if (y == 0 || y == H - 1 || x == 0 || x == W - 1) t = 1;
+  if (!t) {                                                                   // second layer: the ring two away
+    for (int ix = -2; ix <= 2 && !t; ix++) for (int iy = -2; iy <= 2 && !t; iy++)
+      if ((ix > 1 || ix < -1 || iy > 1 || iy < -1) && y + iy >= 0 && y + iy < H && x + ix >= 0 && x + ix < W && RBT_OM(x + ix, y + iy) == 0) t = 1;
+    if (y == 1 || y == H - 2 || x == 1 || x == W - 2) t = 1;
+  }
+#undef RBT_OM
+  return t;
+}
+struct RbtSmooth {               // grid of the smoothing pass and its dense cell arrays (w^3 cells)
+  int32_t g, w, disth, th, threshold, n_points;
+  uint8_t* flag; uint32_t* sum; uint32_t* cnt; uint32_t* pmin; uint32_t* pmax;     // sum: 3 per cell; pmin starts at 0xFFFFFFFF
+  uint32_t* moved;
+};
+RBT_DEV int pc_sm_skip(const RbtSmooth* G, int x, int y, int z) { return x < G->disth || y < G->disth || z < G->disth || G->th <= x + G->disth || G->th <= y + G->disth || G->th <= z + G->disth; }
+// per point: meta = patch index | boundary flag << 31
+RBT_DEV void pc_sm_mark(const RbtSmooth* G, const int16_t* xyz, const uint32_t* meta, int i) {
+  if (!(meta[i] >> 31)) return;
+  const int P[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+  if (pc_sm_skip(G, P[0], P[1], P[2])) return;
+  int Q[3]; for (int k = 0; k < 3; k++) Q[k] = P[k] / G->g + ((P[k] % G->g < G->g / 2) ? -1 : 0);
+  for (int iz = 0; iz < 2; iz++) for (int iy = 0; iy < 2; iy++) for (int ix = 0; ix < 2; ix++) G->flag[(size_t)(Q[0] + ix) + (size_t)(Q[1] + iy) * G->w + (size_t)(Q[2] + iz) * G->w * G->w] = 1;
+}
+RBT_DEV void pc_sm_accum(const RbtSmooth* G, const int16_t* xyz, const uint32_t* meta, int i) {
+  const int P[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+  if (pc_sm_skip(G, P[0], P[1], P[2])) return;
+  const size_t c = (size_t)(P[0] / G->g) + (size_t)(P[1] / G->g) * G->w + (size_t)(P[2] / G->g) * G->w * G->w;
+  if (!G->flag[c]) return;
+  const uint32_t pidx = (meta[i] & 0x7FFFFFFFu) + 1;
+#ifdef RBT_HOSTEMU
+  for (int k = 0; k < 3; k++) G->sum[3 * c + k] += (uint32_t)P[k];
+  G->cnt[c]++; if (pidx < G->pmin[c]) G->pmin[c] = pidx; if (pidx > G->pmax[c]) G->pmax[c] = pidx;
+#else
+  for (int k = 0; k < 3; k++) atomicAdd(&G->sum[3 * c + k], (uint32_t)P[k]);
+  atomicAdd(&G->cnt[c], 1u); atomicMin(&G->pmin[c], pidx); atomicMax(&G->pmax[c], pidx);
+#endif
+}
+// gridFiltering + the decision of smoothPointCloudGrid for boundary point i: writes the new position and returns 1 when the point moves
+RBT_DEV int pc_sm_filter(const RbtSmooth* G, int16_t* xyz, const uint32_t* meta, int i) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  if (!(meta[i] >> 31)) return 0;
+  const int P[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+  if (pc_sm_skip(G, P[0], P[1], P[2])) return 0;
+  const int g = G->g, w = G->w, half = g / 2, g2 = g * 2;
+  int S[3], Wt[3]; size_t idx[8]; int other = 0;
+  for (int k = 0; k < 3; k++) { const int P2 = P[k] / g, P3 = P[k] - P2 * g; S[k] = P2 + (P3 < half ? -1 : 0); Wt[k] = (P[k] - S[k] * g - half) * 2 + 1; }
+  for (int dz = 0; dz < 2; dz++) for (int dy = 0; dy < 2; dy++) for (int dx = 0; dx < 2; dx++) {
+    const size_t c = (size_t)(S[0] + dx) + (size_t)(S[1] + dy) * w + (size_t)(S[2] + dz) * w * w; idx[dz * 4 + dy * 2 + dx] = c;
+    if ((G->cnt[c] & 0xFFFFu) != 0 && G->pmin[c] != G->pmax[c]) other = 1;                     // doSmooth && count != 0 (the reference counts in 16 bits)
+  }
+  if (!other) return 0;
+  const double cur[3] = {(double)P[0], (double)P[1], (double)P[2]};
+  const int Q[3] = {g2 - Wt[0], g2 - Wt[1], g2 - Wt[2]};
+  int cnt = 0; double c4[3] = {0.0, 0.0, 0.0};
+  for (int dz = 0; dz < 2; dz++) for (int dy = 0; dy < 2; dy++) for (int dx = 0; dx < 2; dx++) {
+    const size_t c = idx[dz * 4 + dy * 2 + dx]; const int n = (int)(G->cnt[c] & 0xFFFFu);
+    const int abc = (dx ? Wt[0] : Q[0]) * (dy ? Wt[1] : Q[1]) * (dz ? Wt[2] : Q[2]);
+    for (int k = 0; k < 3; k++) {
+      // the cell centre as the reference holds it: a float sum divided by the count in float (division in double and rounding once is the correctly rounded float quotient)
+      const double centre = n > 0 ? (double)(float)((double)(float)G->sum[3 * c + k] / (double)(float)n) : cur[k];
+      c4[k] = c4[k] + centre * (double)abc;
+    }
+    cnt += abc * n;
+  }
+  const double vol = (double)(g2 * g2 * g2);
+  cnt /= g2 * g2 * g2;
+  if (cnt == 0) return 0;                                                                    // (the reference divides by zero here and its comparison is false)
+  double centroid[3], d[3];
+  for (int k = 0; k < 3; k++) { centroid[k] = (c4[k] / vol) * (double)cnt; d[k] = cur[k] * (double)cnt - centroid[k]; }
+  const double dist2 = (d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) / (double)cnt + 0.5;
+  if (!(dist2 >= (double)((G->threshold > cnt ? G->threshold : cnt) * 2))) return 0;
+  for (int k = 0; k < 3; k++) xyz[3 * i + k] = (int16_t)(double)(long long)(centroid[k] / (double)cnt + 0.5);
+  return 1;
+}
+

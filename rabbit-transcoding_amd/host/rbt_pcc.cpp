@@ -31,8 +31,10 @@ int pcc_reconstruct(std::string& err, const rbt_atlas_params* a, const rbt_patch
   memset(out, 0, sizeof(*out));
   const int W = a->width, H = a->height, res = a->occupancy_resolution, prec = a->occupancy_precision;
   if (W <= 0 || H <= 0 || res < 1 || prec < 1 || W % res || H % res || W % prec || H % prec || W % 2 || H % 2 || W > 8192 || H > 8192 || n_patches < 0 || n_patches > 65535 ||
-      geo_bd < 8 || geo_bd > 16 || attr_bd < 8 || attr_bd > 16 || a->map_count < 1 || a->map_count > 2 || (a->map_count > 1 && !d1) || ((t0 != nullptr) != (t1 != nullptr) && a->map_count > 1)) {
+      geo_bd < 8 || geo_bd > 16 || attr_bd < 8 || attr_bd > 16 || a->map_count < 1 || a->map_count > 2 || (a->map_count > 1 && !d1) || ((t0 != nullptr) != (t1 != nullptr) && a->map_count > 1) ||
+      (a->geometry_smoothing && (a->grid_size < 2 || a->grid_size > 255 || a->threshold_smoothing < 0))) {
     err = "bad atlas parameters"; return RBT_ERR_PARAM; }
+  const bool smooth = a->geometry_smoothing != 0;
   RbtPccParams P; memset(&P, 0, sizeof(P));
   P.w = W; P.h = H; P.res = res; P.prec = prec; P.map_count = a->map_count; P.absolute_d1 = a->absolute_d1; P.remove_dup = a->remove_duplicate_points; P.threshold = a->threshold_lossy_om;
   P.geo_bd = geo_bd; P.attr_bd = attr_bd; P.bw = W / res; P.bh = H / res; P.ow = W / prec; P.n_patches = n_patches; P.has_attr = t0 != nullptr;
@@ -50,7 +52,7 @@ int pcc_reconstruct(std::string& err, const rbt_atlas_params* a, const rbt_patch
   }
   const int n_items = (int)items.size();
   const size_t ys = (size_t)W * H, os = (size_t)(W / prec) * (H / prec), fs = ys * 3 / 2;
-  DevBuf b_occ, b_d0, b_d1, b_t0, b_t1, b_patches, b_items, b_b2p, b_counts, b_off, b_om, b_xyz, b_yuv;
+  DevBuf b_occ, b_d0, b_d1, b_t0, b_t1, b_patches, b_items, b_b2p, b_counts, b_off, b_om, b_xyz, b_yuv, b_meta, b_cells, b_scal;
   if (!b_occ.alloc(os * 2) || !b_d0.alloc(ys * 2) || !b_d1.alloc(ys * 2) || !b_patches.alloc(sizeof(rbt_patch) * (size_t)(n_patches ? n_patches : 1)) || !b_items.alloc(4 * (size_t)(n_items ? n_items : 1)) ||
       !b_b2p.alloc(4 * (size_t)P.bw * P.bh) || !b_counts.alloc(4 * (size_t)(n_items + 1)) || !b_off.alloc(4 * (size_t)(n_items + 1)) || !b_om.alloc(ys) ||
       (t0 && (!b_t0.alloc(fs * 2) || !b_t1.alloc(fs * 2)))) { err = "device allocation failed"; return RBT_ERR_NOMEM; }
@@ -66,10 +68,31 @@ int pcc_reconstruct(std::string& err, const rbt_atlas_params* a, const rbt_patch
   rbtk::launch_scan_u32(b_counts.as<uint32_t>(), b_off.as<uint32_t>(), n_items);
   uint32_t total = 0;
   if (rbtk::d2h(&total, b_off.as<uint32_t>() + n_items, 4)) { err = "kernel execution failed"; return RBT_ERR_NO_DEVICE; }
-  if (!b_xyz.alloc(6 * (size_t)(total ? total : 1)) || !b_yuv.alloc(6 * (size_t)(total ? total : 1))) { err = "device allocation failed"; return RBT_ERR_NOMEM; }
+  if (!b_xyz.alloc(6 * (size_t)(total ? total : 1)) || !b_yuv.alloc(6 * (size_t)(total ? total : 1)) || (smooth && (!b_meta.alloc(4 * (size_t)(total ? total : 1)) || !b_scal.alloc(64)))) { err = "device allocation failed"; return RBT_ERR_NOMEM; }
   rbtk::launch_pcc_emit(&P, b_patches.as<rbt_patch>(), b_items.as<uint32_t>(), n_items, b_occ.as<uint16_t>(), b_d0.as<uint16_t>(), b_d1.as<uint16_t>(), b_t0.as<uint16_t>(), b_t1.as<uint16_t>(),
-                        b_b2p.as<uint32_t>(), b_off.as<uint32_t>(), b_xyz.as<int16_t>(), b_yuv.as<uint16_t>());
+                        b_b2p.as<uint32_t>(), b_off.as<uint32_t>(), b_xyz.as<int16_t>(), b_yuv.as<uint16_t>(), smooth ? b_om.as<uint8_t>() : nullptr, smooth ? b_meta.as<uint32_t>() : nullptr);
   out->n_points = (int)total;
+  // geometry smoothing (PCCCodec::smoothPointCloudPostprocess with gridSmoothing, PCCCodec.cpp:52-145): the grid spans the largest coordinate of the cloud (:70-83)
+  if (smooth && total) {
+    uint32_t* scal = b_scal.as<uint32_t>();                        // [0] largest coordinate, [1] points moved
+    uint32_t maxv = 0;
+    if (rbtk::dev_memset(scal, 0, 64)) { err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
+    rbtk::launch_sm_max(b_xyz.as<int16_t>(), (int)total, scal);
+    if (rbtk::d2h(&maxv, scal, 4)) { err = "kernel execution failed"; return RBT_ERR_NO_DEVICE; }
+    RbtSmooth G; memset(&G, 0, sizeof(G));
+    G.g = a->grid_size; G.w = ((int)maxv + G.g - 1) / G.g; G.disth = std::max(G.g / 2, 1); G.th = G.g * G.w; G.threshold = a->threshold_smoothing; G.n_points = (int)total;
+    if (G.w > 0) {
+      const size_t w3 = (size_t)G.w * G.w * G.w, o_sum = (w3 + 255) & ~(size_t)255, o_cnt = o_sum + 12 * w3, o_min = o_cnt + 4 * w3, o_max = o_min + 4 * w3, bytes = o_max + 4 * w3;
+      if (!b_cells.alloc(bytes)) { err = "device allocation failed"; return RBT_ERR_NOMEM; }
+      uint8_t* base = b_cells.as<uint8_t>();
+      G.flag = base; G.sum = (uint32_t*)(base + o_sum); G.cnt = (uint32_t*)(base + o_cnt); G.pmin = (uint32_t*)(base + o_min); G.pmax = (uint32_t*)(base + o_max); G.moved = scal + 1;
+      if (rbtk::dev_memset(base, 0, bytes) || rbtk::dev_memset(G.pmin, 0xFF, 4 * w3)) { err = "device transfer failed"; return RBT_ERR_NO_DEVICE; }
+      rbtk::launch_sm_passes(&G, b_xyz.as<int16_t>(), b_meta.as<uint32_t>());
+      uint32_t moved = 0;
+      if (rbtk::d2h(&moved, scal + 1, 4)) { err = "kernel execution failed"; return RBT_ERR_NO_DEVICE; }
+      out->n_smoothed = (int)moved;
+    }
+  }
   out->xyz = (int16_t*)malloc(6 * (size_t)(total ? total : 1)); out->yuv = (uint16_t*)malloc(6 * (size_t)(total ? total : 1));
   out->occupancy_map = (uint8_t*)malloc(ys); out->block_to_patch = (uint32_t*)malloc(4 * (size_t)P.bw * P.bh);
   if (!out->xyz || !out->yuv || !out->occupancy_map || !out->block_to_patch) { err = "out of memory"; return RBT_ERR_NOMEM; }

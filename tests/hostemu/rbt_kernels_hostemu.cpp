@@ -164,11 +164,21 @@ void launch_pcc_count(const RbtPccParams* P, const rbt_patch* patches, const uin
 }
 void launch_scan_u32(const uint32_t* in, uint32_t* out, int n) { uint32_t r = 0; for (int i = 0; i < n; i++) { out[i] = r; r += in[i]; } out[n] = r; }
 void launch_pcc_emit(const RbtPccParams* P, const rbt_patch* patches, const uint32_t* items, int n_items, const uint16_t* occ, const uint16_t* d0, const uint16_t* d1, const uint16_t* t0, const uint16_t* t1,
-                     const uint32_t* b2p, const uint32_t* offsets, int16_t* xyz, uint16_t* yuv) {
+                     const uint32_t* b2p, const uint32_t* offsets, int16_t* xyz, uint16_t* yuv, const uint8_t* om, uint32_t* meta) {
   for (int k = 0; k < n_items; k++) { const int pi = (int)(items[k] >> 16), blk = (int)(items[k] & 0xFFFF); const rbt_patch* p = &patches[pi]; const int ub = blk % p->size_u0, vb = blk / p->size_u0;
     if (b2p[pc_block2canvas(p, ub, vb, P->bw)] != (uint32_t)pi + 1) continue;
     size_t o = offsets[k];
-    for (int q = 0; q < P->res * P->res; q++) o += (size_t)pc_pixel_points(P, p, occ, d0, d1, t0, t1, ub, vb, q, xyz + 3 * o, yuv + 3 * o); }
+    for (int q = 0; q < P->res * P->res; q++) {
+      const int n = pc_pixel_points(P, p, occ, d0, d1, t0, t1, ub, vb, q, xyz + 3 * o, yuv + 3 * o);
+      if (meta && n) { int x, y; pc_patch2canvas(p, P->res, ub * P->res + q % P->res, vb * P->res + q / P->res, &x, &y);
+        const uint32_t m = (uint32_t)pi | ((uint32_t)pc_boundary_point(om, x, y, P->w, P->h) << 31); for (int i = 0; i < n; i++) meta[o + i] = m; }
+      o += (size_t)n; } }
+}
+void launch_sm_max(const int16_t* xyz, int n_points, uint32_t* out) { for (int i = 0; i < 3 * n_points; i++) if (xyz[i] > 0 && (uint32_t)xyz[i] > *out) *out = (uint32_t)xyz[i]; }
+void launch_sm_passes(const RbtSmooth* G, int16_t* xyz, const uint32_t* meta) {
+  for (int i = 0; i < G->n_points; i++) pc_sm_mark(G, xyz, meta, i);
+  for (int i = 0; i < G->n_points; i++) pc_sm_accum(G, xyz, meta, i);
+  for (int i = 0; i < G->n_points; i++) if (pc_sm_filter(G, xyz, meta, i)) (*G->moved)++;
 }
 void launch_vol_set(const int16_t* xyz, int n, uint32_t* vol, uint8_t* first, uint32_t* n_unique) {
   for (int i = 0; i < n; i++) { const int x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2]; uint32_t* w = &vol[pc_voxel_word(x, y, z)]; const uint32_t bit = 1u << (x & 31);

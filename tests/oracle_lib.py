@@ -34,11 +34,15 @@ class OPatch(C.Structure):
 
 
 class OAtlas(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("width", "height", "occupancy_resolution", "occupancy_precision", "map_count", "absolute_d1", "remove_duplicate_points", "threshold_lossy_om")]
+    _fields_ = [(n, C.c_int32) for n in ("width", "height", "occupancy_resolution", "occupancy_precision", "map_count", "absolute_d1", "remove_duplicate_points", "threshold_lossy_om",
+                                            "geometry_smoothing", "grid_size", "threshold_smoothing")]
 
 
 class OCloud(C.Structure):
-    _fields_ = [("n", C.c_int), ("xyz", C.POINTER(C.c_int16)), ("yuv", C.POINTER(C.c_uint16)), ("occupancy_map", C.POINTER(C.c_uint8)), ("block_to_patch", C.POINTER(C.c_uint32))]
+    _fields_ = [("n", C.c_int), ("xyz", C.POINTER(C.c_int16)), ("yuv", C.POINTER(C.c_uint16)), ("occupancy_map", C.POINTER(C.c_uint8)), ("block_to_patch", C.POINTER(C.c_uint32)), ("n_smoothed", C.c_int)]
+
+
+LAST_SMOOTHED = 0      # points the geometry smoothing moved in the last reconstruct() call
 
 
 class OD1(C.Structure):
@@ -231,6 +235,8 @@ def reconstruct(atlas, patches, occ, d0, d1, geo_bd=10, t0=None, t1=None, attr_b
     n, w, h, res = c.n, a.width, a.height, a.occupancy_resolution
     xyz = np.ctypeslib.as_array(c.xyz, shape=(max(n, 1), 3))[:n].copy(); yuv = np.ctypeslib.as_array(c.yuv, shape=(max(n, 1), 3))[:n].copy()
     om = np.ctypeslib.as_array(c.occupancy_map, shape=(h, w)).copy(); b2p = np.ctypeslib.as_array(c.block_to_patch, shape=(h // res, w // res)).copy()
+    global LAST_SMOOTHED
+    LAST_SMOOTHED = c.n_smoothed
     lib().oracle_cloud_free(C.byref(c))
     return xyz, yuv, om, b2p
 

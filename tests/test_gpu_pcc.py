@@ -94,3 +94,31 @@ def test_d2_of_a_synthetic_frame(ctx):
     got, want = ctx.d2(xyz, n, dec), O.d2(xyz, n, dec)
     assert (got["n_a"], got["n_b"]) == (want["n_a"], want["n_b"]) and got["sse_ab"] == pytest.approx(want["sse_ab"], rel=1e-9) and got["sse_ba"] == pytest.approx(want["sse_ba"], rel=1e-9)
     assert got["psnr"] >= ctx.d1(xyz, dec)["psnr"] - 1e-3
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_geometry_smoothing_matches_oracle_on_the_gpu(ctx, seed):
+    """rbt_atlas_params.geometry_smoothing on the GPU (k_sm_mark / k_sm_accum / k_sm_filter: one lane per point, cell centroids by atomics, the filter in the reference's
+    float / double arithmetic without contraction): == oracle for every point of seam atlases (patches that meet in space; tests/pcc_cases.py), seed 9 at 1280 x 1280"""
+    R = rbt_lib.module()
+    case = pcc_cases.seam_atlas(R, seed, tiles=40 if seed == 9 else 3 + seed % 3, prec=[1, 2, 4][seed % 3], two_axes=seed % 2 == 1)
+    if seed == 9:      # 40 x 40 tiles of 28 points would leave the 1024^3 volume: fold the grid of patches back into it
+        for k, p in enumerate(case[1]): p.u1 = 40 + 28 * (k % 30); p.v1 = 40 + 28 * ((k // 30) % 30); p.d1 = 30 + 200 * (k // 900)
+    got, want = ctx.reconstruct(*case), O.reconstruct(*case)
+    assert got[0].shape == want[0].shape and got[0].shape[0] > 5000
+    for g, w_ in zip(got, want):
+        assert np.array_equal(g, w_)
+    assert ctx.n_smoothed == O.LAST_SMOOTHED and (ctx.n_smoothed > 100 or case[0].grid_size == 4)
+
+
+def test_geometry_smoothing_random_atlases_and_off_switch(ctx):
+    """random atlases (every orientation, sparse points: the smoothing has nothing to blend and must leave the cloud alone, as the oracle does); grid_size out of range is refused"""
+    R = rbt_lib.module()
+    for seed in range(8):
+        case = pcc_cases.random_atlas(R, seed)
+        a = R.ctc_smoothing(case[0])
+        got, want = ctx.reconstruct(a, *case[1:]), O.reconstruct(a, *case[1:])
+        assert all(np.array_equal(g, w_) for g, w_ in zip(got, want)) and ctx.n_smoothed == O.LAST_SMOOTHED
+    bad = R.ctc_smoothing(case[0]); bad.grid_size = 1
+    with pytest.raises(R.RbtError):
+        ctx.reconstruct(bad, *case[1:])

@@ -147,3 +147,49 @@ def check_d2(ctx):
 
 def test_d2_matches_oracle_and_brute_force(ctx):
     check_d2(ctx)
+
+
+def _no_smoothing(R, atlas):
+    a = R.AtlasParams(*[getattr(atlas, n) for n, _ in R.AtlasParams._fields_]); a.geometry_smoothing = 0
+    return a
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_geometry_smoothing_matches_oracle_point_for_point(ctx, seed):
+    """rbt_atlas_params.geometry_smoothing (PCCCodec::smoothPointCloudPostprocess with gridSmoothing, what the CTC switches on): dense surfaces cut into patches that meet
+    in space (pcc_cases.seam_atlas: grid sizes 4 / 6 / 8 / 16, thresholds 1 / 16 / 64, precisions 1 / 2 / 4, one or two projection axes). Product == oracle for every
+    point, the count of moved points included; the smoothing moves points in most cases and only boundary points; everything else of the cloud is untouched."""
+    R = rbt_lib.module()
+    case = pcc_cases.seam_atlas(R, seed, tiles=3 + seed % 3, prec=[1, 2, 4][seed % 3], two_axes=seed % 2 == 1)
+    got, want = ctx.reconstruct(*case), O.reconstruct(*case)
+    assert got[0].shape == want[0].shape and got[0].shape[0] > 5000
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert ctx.n_smoothed == O.LAST_SMOOTHED
+    plain = ctx.reconstruct(_no_smoothing(R, case[0]), *case[1:])
+    assert ctx.n_smoothed == 0 and np.array_equal(plain[1], got[1]) and np.array_equal(plain[2], got[2])
+    moved = (plain[0] != got[0]).any(axis=1)
+    assert int(moved.sum()) <= O.LAST_SMOOTHED and (int(moved.sum()) > 100 or case[0].grid_size == 4)
+
+
+@pytest.mark.parametrize("seed", [0, 3, 4, 8])
+def test_geometry_smoothing_against_a_second_writing_of_the_reference_text(ctx, seed):
+    """the same result from an independent numpy / Python transcription of the reference's loops (pcc_cases.smooth_reference / boundary_reference), fed with the
+    boundary flags and patch indices recomputed from the maps: guards the oracle's restatement against slips of the pen (both are by the same reader: parity with the
+    reference itself stays unpinned, PccLibCommon cannot be built here)"""
+    R = rbt_lib.module()
+    case = pcc_cases.seam_atlas(R, seed, tiles=3, prec=[1, 2, 4][seed % 3], two_axes=seed % 2 == 1)
+    atlas, patches, occ = case[0], case[1], case[2]
+    w = atlas.width
+    idx = np.zeros((w, w), np.uint16)
+    for k, p in enumerate(patches): idx[32 * p.v0 // 2:32 * p.v0 // 2 + 32, 32 * p.u0 // 2:32 * p.u0 // 2 + 32] = k
+    plain = ctx.reconstruct(_no_smoothing(R, atlas), *case[1:6], np.concatenate([idx.ravel(), np.zeros(w * w // 2, np.uint16)]), np.concatenate([idx.ravel(), np.zeros(w * w // 2, np.uint16)]), 10)
+    part = plain[1][:, 0].astype(np.int64)
+    # the pixel of every point: reconstruct twice with pictures that carry x and y
+    xs = ctx.reconstruct(_no_smoothing(R, atlas), *case[1:6], np.concatenate([np.tile(np.arange(w, dtype=np.uint16), w), np.zeros(w * w // 2, np.uint16)]), np.concatenate([np.tile(np.arange(w, dtype=np.uint16), w), np.zeros(w * w // 2, np.uint16)]), 10)[1][:, 0]
+    ys = ctx.reconstruct(_no_smoothing(R, atlas), *case[1:6], np.concatenate([np.repeat(np.arange(w, dtype=np.uint16), w), np.zeros(w * w // 2, np.uint16)]), np.concatenate([np.repeat(np.arange(w, dtype=np.uint16), w), np.zeros(w * w // 2, np.uint16)]), 10)[1][:, 0]
+    om = plain[2]
+    boundary = np.array([pcc_cases.boundary_reference(om, int(x), int(y)) for x, y in zip(xs, ys)])
+    want = pcc_cases.smooth_reference(plain[0], boundary, part, atlas.grid_size, atlas.threshold_smoothing)
+    got = ctx.reconstruct(*case)[0]
+    assert np.array_equal(got, want) and (got != plain[0]).any()
