@@ -275,9 +275,9 @@ def test_transform_skip_blocks(ctx, monkeypatch, w, h, log2_ctb, rows):
         cost = lambda stream, r_: float(((r_.astype(np.int64) - fr.astype(np.int64)) ** 2).sum()) + lam * 8 * len(stream)
         ratios.append(cost(on, rec) / cost(off, rec_off))
         assert ratios[-1] <= 1.001, (qp, len(on), len(off), ratios)            # the choice is made block by block on the block's own cost: one case of the eight here ends 0.03 % above
-    assert sum(ratios) / len(ratios) < 1.0, ratios                              # ... and over the two QPs the tool is a gain in every case (0.2 - 1 %)
         dec, _, _, _, chk, fail = ctx.decode(bs)
         assert (chk, fail) == (4, 0) and np.array_equal(dec, rec)
+    assert sum(ratios) / len(ratios) < 1.0, ratios                              # ... and over the two QPs the tool is a gain in every case (0.2 - 1 %)
 
 
 def test_occupancy_aware_coding_matches_oracle(ctx):
