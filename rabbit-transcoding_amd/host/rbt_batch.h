@@ -28,6 +28,7 @@ struct DecodeBatch {
   std::vector<Sps> stream_sps; std::vector<Pps> stream_pps;
   std::vector<std::vector<int>> level_frames;
   bool ordered_parse = false, lists_uploaded = false;
+  std::vector<char> alias_taken;       // per stream: its pictures' dead buffers (coefficient levels, pre-SAO samples) have been handed to an encoder stream (setup_encode)
   bool recon_external = false;         // ... and reconstructed by merged per-level launches (launch_recon_refs + decode_launch_filters)
   bool parse_external = false;         // the batch's slices are parsed by a merged launch of the caller (launch_parse_tasks)
   std::vector<int32_t> lists_keep;     // host staging of the index lists, alive until the copy has completed

@@ -20,6 +20,10 @@ struct EncStreamDesc {
   int sao = 0;                           // SAO on (every stream that is not lossless, unless RBT_ENC_SAO=0)
   int tools_off = 0;                     // RBT_ET_* decision tools left out (rbt_stream_params.preset)
   std::vector<const uint16_t*> src[3];   // device planes per frame
+  // Arena sharing (round 4): per frame, buffers of the DECODED input picture that are dead by the time this picture is encoded and have the encoder's geometry - its
+  // coefficient levels (read by the reconstruction of that picture only) and its pre-SAO samples (read by that picture's own loop filters only): the encoder keeps its own
+  // levels and reconstruction there instead of in memory of its own (9.8 MB per 1280x1280 picture, 1.26 GB per GOF). Empty / null = the encoder allocates.
+  std::vector<uint16_t*> alias_pix; std::vector<int16_t*> alias_coef;
   int src_stride = 0, src_x0 = 0, src_y0 = 0;   // the planes are views: luma row stride (0 = w) and origin of the w x h region (luma samples)
 };
 // Pictures are coded at the display size rounded up to 8 (all-intra) or 16 (I,P pairs: 16x16 inter CUs) and the padding is
@@ -102,9 +106,13 @@ static int encode_build(EncodeBatch& b) {
         sl.deblocking_disabled = (uint8_t)p.pps_deblocking_disabled; sl.lf_across = (uint8_t)p.loop_filter_across_slices;
         sl.max_merge_cand = 1; sl.num_ref_idx = 1; sl.poc = f.poc; sl.sao_luma = sl.sao_chroma = (uint8_t)b.desc[si].sao;
         if (!is_i) { sl.ref_frame[0] = f.ref_frame; sl.ref_poc[0] = f.ref_poc; }
-        // worst-case slice data: raw samples of the slice at 2 bytes each plus slack
+        // slice data buffer, by the slice's QP, sized for full-range noise (the most a picture can cost: log2(2^bit_depth / Qstep) bits per sample, 1.5 samples per luma
+        // sample in 4:2:0): 3 bytes per luma sample of the slice (the raw samples at 2 bytes each) below QP 16 and for lossless streams, 2 below QP 34 (Qstep >= 4: at most
+        // 8 bits x 1.5), 1 from there on (Qstep >= 32: 5 bits x 1.5), + slack. A slice that does not fit ends the call with an error (RbtSlice::out_size = 0xFFFFFFFF), it
+        // is never cut short. Round 3 gave every slice 3: 7.6 of the 17 MB an encoded 1280x1280 picture took.
         size_t rows = (size_t)(sl.n_ctbs + s.w_ctb - 1) / s.w_ctb;
-        sl.out_cap = (uint32_t)(rows * ((size_t)s.width << s.log2_ctb) * 3 + 4096);
+        const int bytes_per_sample = (d.lossless || sl.qp < 16) ? 3 : (sl.qp < 34 ? 2 : 1);
+        sl.out_cap = (uint32_t)(rows * ((size_t)s.width << s.log2_ctb) * bytes_per_sample + 4096);
         f.n_slices++;
         b.slices.push_back(sl);
       }
@@ -125,8 +133,10 @@ static int encode_build(EncodeBatch& b) {
     const RbtStreamCfg& c = b.frames[i].cfg; size_t u = (size_t)c.w4 * c.h4, nc = (size_t)c.w_ctb * c.h_ctb, u8 = (size_t)b.frames[i].w8 * b.frames[i].h8;
     { const EncStreamDesc& d = b.desc[b.frame_stream[i]];
       if (c.w != d.w || c.h != d.h || d.src_x0 || d.src_y0 || (d.src_stride && d.src_stride != d.w)) o_src[i] = a.reserve(frame_samples(c) * 2); }
-    o_pix[i] = a.reserve(frame_samples(c) * 2); o_coef[i] = a.reserve(frame_samples(c) * 2);
-    o_sout[i] = b.desc[b.frame_stream[i]].sao ? a.reserve(frame_samples(c) * 2) : o_pix[i]; o_sao[i] = a.reserve(nc * sizeof(RbtSao));
+    { const EncStreamDesc& d = b.desc[b.frame_stream[i]]; const size_t k = i - (size_t)b.stream_first[b.frame_stream[i]];
+      o_pix[i] = (!d.alias_pix.empty() && d.alias_pix[k]) ? (size_t)-1 : a.reserve(frame_samples(c) * 2);
+      o_coef[i] = (!d.alias_coef.empty() && d.alias_coef[k]) ? (size_t)-1 : a.reserve(frame_samples(c) * 2); }
+    o_sout[i] = b.desc[b.frame_stream[i]].sao ? a.reserve(frame_samples(c) * 2) : o_pix[i]; o_sao[i] = a.reserve(nc * sizeof(RbtSao));      // (no SAO: out = pix, wherever that is)
     o_pm[i] = a.reserve(u); o_edges[i] = a.reserve(u); o_qp[i] = a.reserve(u); o_mv[i] = a.reserve(u * 4); o_ref[i] = a.reserve(u); o_refpoc[i] = a.reserve(u * 4);
     o_cul[i] = a.reserve(u8); o_cum[i] = a.reserve(u8); o_cuf[i] = a.reserve(u8); o_cut[i] = a.reserve(u8);
   }
@@ -146,15 +156,16 @@ static int encode_build(EncodeBatch& b) {
   for (size_t i = 0; i < nf; i++) {
     uint16_t* cs_host = b.cs_keep[0].data() + o_cs[i];
     RbtFrame& f = b.frames[i]; const RbtStreamCfg& c = f.cfg; size_t ys = (size_t)c.w * c.h, cs = (size_t)c.cw * c.ch;
-    f.pix[0] = (uint16_t*)(base + o_pix[i]); f.pix[1] = f.pix[0] + ys; f.pix[2] = f.pix[1] + cs;
-    f.out[0] = (uint16_t*)(base + o_sout[i]); f.out[1] = f.out[0] + ys; f.out[2] = f.out[1] + cs; f.sao = (RbtSao*)(base + o_sao[i]);
+    const EncStreamDesc& ds = b.desc[b.frame_stream[i]]; const size_t ks = i - (size_t)b.stream_first[b.frame_stream[i]];
+    f.pix[0] = o_pix[i] == (size_t)-1 ? ds.alias_pix[ks] : (uint16_t*)(base + o_pix[i]); f.pix[1] = f.pix[0] + ys; f.pix[2] = f.pix[1] + cs;
+    f.out[0] = o_sout[i] == (size_t)-1 ? f.pix[0] : (uint16_t*)(base + o_sout[i]); f.out[1] = f.out[0] + ys; f.out[2] = f.out[1] + cs; f.sao = (RbtSao*)(base + o_sao[i]);
     if (o_src[i] != (size_t)-1) {
       const EncStreamDesc& d = b.desc[b.frame_stream[i]]; const int st = d.src_stride ? d.src_stride : d.w;
       uint16_t* pl[3] = {(uint16_t*)(base + o_src[i]), nullptr, nullptr}; pl[1] = pl[0] + ys; pl[2] = pl[1] + cs;
       for (int k = 0; k < 3; k++) { const int sh = k ? 1 : 0;
         b.pad_jobs.push_back(PadJob{f.src[k], st >> sh, d.src_x0 >> sh, d.src_y0 >> sh, d.w >> sh, d.h >> sh, pl[k], c.w >> sh, c.h >> sh}); f.src[k] = pl[k]; }
     }
-    f.coef[0] = (int16_t*)(base + o_coef[i]); f.coef[1] = f.coef[0] + ys; f.coef[2] = f.coef[1] + cs;
+    f.coef[0] = o_coef[i] == (size_t)-1 ? ds.alias_coef[ks] : (int16_t*)(base + o_coef[i]); f.coef[1] = f.coef[0] + ys; f.coef[2] = f.coef[1] + cs;
     f.pm = base + o_pm[i]; f.edges = base + o_edges[i]; f.qp = (int8_t*)(base + o_qp[i]); f.mv = (int16_t*)(base + o_mv[i]); f.ref = (int8_t*)(base + o_ref[i]);
     f.refpoc = (int32_t*)(base + o_refpoc[i]); f.ctb_slice = (uint16_t*)(base + o_cs_all) + o_cs[i];
     f.cu_log2 = base + o_cul[i]; f.cu_mode = base + o_cum[i]; f.cu_flags = base + o_cuf[i]; f.cu_ts = base + o_cut[i];
@@ -359,6 +370,20 @@ static int setup_encode(DecodeBatch& db, int si, int ei, const rbt_stream_params
     d.gop = 2; d.lossless = 0; d.i_qp_offset = -3; d.w = dw; d.h = dh;
     d.src_stride = c.w; d.src_x0 = cl; d.src_y0 = ct;
     for (int k = 0; k < cnt; k++) for (int q = 0; q < 3; q++) d.src[q][k] = view(k, q);
+    // arena sharing: the encoder's levels and reconstruction of picture k live in the decoded picture k's dead buffers when the two pictures have one geometry (coded size
+    // = the input's coded size, no window offset) and no other target rate of a fan-out took them already. RBT_ARENA_SHARE=0 switches it off.
+    { static const int share = [] { const char* e = getenv("RBT_ARENA_SHARE"); return !e || atoi(e) != 0; }();
+      if (db.alias_taken.size() < db.stream_first.size()) db.alias_taken.resize(db.stream_first.size(), 0);
+      if (share && cl == 0 && ct == 0 && coded_size(dw, 2) == c.w && coded_size(dh, 2) == c.h && !db.alias_taken[si]) {
+        db.alias_taken[si] = 1;
+        d.alias_pix.assign(cnt, nullptr); d.alias_coef.assign(cnt, nullptr);
+        for (int k = 0; k < cnt; k++) {
+          const RbtFrame& fr = db.frames[first + k];
+          if (fr.cfg.w != c.w || fr.cfg.h != c.h) continue;
+          d.alias_coef[k] = fr.coef[0];
+          if (fr.out[0] != fr.pix[0]) d.alias_pix[k] = fr.pix[0];        // pictures with SAO: the deblocked samples are dead once the SAO output exists
+        }
+      } }
     // the input stream's intra modes come along as hints for the re-encode (same sample grid: not with a window offset at the left / top; oracle/vpcc_path.c)
     if (cl == 0 && ct == 0) {
       d.hint_pm.resize(cnt); d.hint_dm.resize(cnt); d.hint_w4 = c.w4; d.hint_h4 = c.h4;

@@ -35,6 +35,20 @@ def walk():
     return mk(small), mk(mixed)
 
 
+@pytest.fixture(scope="module")
+def sizes(R):
+    """(small, big): device megabytes one GOF of the walks takes (128x128 and 256x256 maps, 2 frames) - measured, the tests below place the stand-in device's size around them"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(__file__), "hostemu")])
+    gs = rbt_lib.module_file("gof_shard")
+    c = R.Context(lib_path=rbt_lib.HOSTEMU_LIB)
+    out = []
+    for w in (128, 256):
+        j = c.submit_gof(V.gof_streams(w, w, 2, 5), gs.rate_params(R, 3)); out.append(c.job_memory(j) / MB); c.wait_gof(j)
+    c.close()
+    assert 1.5 < out[0] < 8 and out[1] > 3 * out[0], out
+    return out
+
+
 def test_memory_figures(ctx, R):
     gs = rbt_lib.module_file("gof_shard")
     os.environ["RBT_HOSTEMU_HBM_MB"] = "64"; os.environ["RBT_HBM_RESERVE_MB"] = "8"
@@ -43,24 +57,24 @@ def test_memory_figures(ctx, R):
     j = ctx.submit_gof(V.gof_streams(128, 128, 2, 5), gs.rate_params(R, 3))
     b = ctx.job_memory(j)
     m1 = ctx.device_memory()
-    assert 2 * MB < b < 8 * MB and m1["in_use"] == b and m1["free"] == 64 * MB - b
+    assert 1 * MB < b < 8 * MB and m1["in_use"] == b and m1["free"] == 64 * MB - b
     ctx.wait_gof(j)
     assert ctx.device_memory()["in_use"] == 0
 
 
-@pytest.mark.parametrize("hbm_mb,depth,per", [(7, 4, 1), (12, 4, 0), (12, 16, 2), (1000, 4, 0)])
-def test_walk_is_bounded_by_device_memory_not_only_by_its_length(ctx, walk, hbm_mb, depth, per):
-    """a device that holds one, two or three jobs of the walk's shape where the announced depth asks for 4 or 16: same bytes as the oracle, no error"""
-    os.environ["RBT_HOSTEMU_HBM_MB"] = str(hbm_mb)
+@pytest.mark.parametrize("jobs_that_fit,depth,per", [(1.3, 4, 1), (2.5, 4, 0), (1.2, 16, 2), (300, 4, 0)])
+def test_walk_is_bounded_by_device_memory_not_only_by_its_length(ctx, walk, sizes, jobs_that_fit, depth, per):
+    """a device that holds one or two jobs of the walk's shape where the announced depth asks for 4 or 16: same bytes as the oracle, no error"""
+    os.environ["RBT_HOSTEMU_HBM_MB"] = str(int(jobs_that_fit * sizes[0] * max(per, 1)) + 1)
     ctx.set_depth(depth)
     assert ctx.transcode_v3c(walk[0], 24, 32, gofs_per_job=per) == O.v3c_transcode(walk[0], 24, 32, 4)
     assert ctx.device_memory()["in_use"] == 0
 
 
-def test_job_that_does_not_fit_next_to_others_runs_again_alone(ctx, walk):
+def test_job_that_does_not_fit_next_to_others_runs_again_alone(ctx, walk, sizes):
     """the fourth GOF has larger maps than the first job's footprint promised: its job fails with RBT_ERR_NOMEM while others are in flight; the walk collects them, runs
     the GOFs of the failed job one at a time and ends with the oracle's bytes, GOFs in order"""
-    os.environ["RBT_HOSTEMU_HBM_MB"] = "20"
+    os.environ["RBT_HOSTEMU_HBM_MB"] = str(int(sizes[1] + 0.5 * sizes[0]) + 1)      # the large GOF fits alone, not in one job with a small one (gofs_per_job 2), let alone next to another job
     ctx.set_depth(4)
     seen = []
     want = O.v3c_transcode(walk[1], 24, 32, 4)
@@ -69,8 +83,8 @@ def test_job_that_does_not_fit_next_to_others_runs_again_alone(ctx, walk):
     assert seen == list(range(7))
 
 
-def test_a_gof_that_fits_nowhere_is_an_error_and_the_context_lives_on(ctx, R, walk):
-    os.environ["RBT_HOSTEMU_HBM_MB"] = "12"                   # the 256x256 GOF needs 15 MB
+def test_a_gof_that_fits_nowhere_is_an_error_and_the_context_lives_on(ctx, R, walk, sizes):
+    os.environ["RBT_HOSTEMU_HBM_MB"] = str(int(sizes[1]) - 1)                 # less than the 256x256 GOF needs
     ctx.set_depth(4)
     with pytest.raises(R.RbtError) as e:
         ctx.transcode_v3c(walk[1], 24, 32, gofs_per_job=1)
