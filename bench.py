@@ -277,7 +277,8 @@ def main():
     # runs of this same command: profiles/r02_pmc_traffic.json, tools/refresh_profiles.py); counters cannot be read live from inside the benchmark
     traffic = None
     try:
-        pmc_file = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")     # HM-like input, this round's code; else the round-2 file (the round-1 file belongs to the RBT-E1-coded input)
+        pmc_file = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")     # HM-like input, this round's code; else the files of the rounds before (the round-1 file belongs to the RBT-E1-coded input)
+        if not os.path.exists(pmc_file): pmc_file = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
         if not os.path.exists(pmc_file): pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if not fixture or not os.path.exists(pmc_file): pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         pmc = json.load(open(pmc_file))["kernels"]
@@ -301,6 +302,21 @@ def main():
              "Mbit_per_s_through_largest_slice": round(max(sl_sizes) * 8 / 1e6 / (st["k_parse_ms"] * 1e-3), 2) if D > 8 and st["k_parse_ms"] > 0 else None,
              "note": "largest slice's bits / duration of the entropy-decoding launch that contains it (about 1.17 bins per bit)"}
     path_achieved = st["algorithmic_bytes"] / gpj / (elapsed / steps) / 1e9   # whole path: SURVEY.md 8(d) bytes of one GOF over the time one GOF takes
+    # The roofline this path lives under is not HBM but instruction issue: a CU issues at most one scalar and one vector instruction per cycle (each SIMD gets a turn every
+    # 4 cycles), 256 CUs x 2.4 GHz = 614 G/s of each kind, and the codec's serial work runs on the scalar unit on purpose. Instructions per GOF from the
+    # committed counter pass of this code (rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU, profiles/r0N_pmc_sq.json) x GOFs per second of the timed run.
+    issue = None
+    try:
+        sq_file = next(f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_sq.json", "r03_pmc_sq.json")) if os.path.exists(f))
+        if fixture and n_pc == 32 and (w, h) == (1280, 1280):
+            ks = json.load(open(sq_file))["kernels"]
+            salu, valu = sum(v["SQ_INSTS_SALU"] for v in ks.values()), sum(v["SQ_INSTS_VALU"] for v in ks.values())
+            gofs_per_s = world * steps / elapsed; peak = 256 * 2.4e9
+            issue = {"salu_G_per_gof": round(salu / 1e9, 2), "valu_G_per_gof": round(valu / 1e9, 2), "peak_G_per_s_each": round(peak / 1e9), "scalar_issue_frac": round(salu * gofs_per_s / world / peak, 3),
+                     "vector_issue_frac": round(valu * gofs_per_s / world / peak, 3), "counters": os.path.basename(sq_file),
+                     "note": "one scalar + one vector instruction per CU and cycle at most; waves here are dependency chains (a lone wave issues every ~4.6 cycles), and two scalar-heavy waves on one SIMD already contend for its scalar turn"}
+    except Exception:
+        issue = None
 
     # configs[3]: a sequence of --walk-frames point-cloud frames (300 = 9 GOFs of 32 + one of 12), GOF g on rank g mod world, D GOFs in flight
     # per GPU, re-encoded NAL units gathered on rank 0 (strong scaling: the sequence is fixed). Rank 0 then walks the whole sequence alone
@@ -652,7 +668,7 @@ def main():
                            "gof_per_gpu": 1, "arena_MB_per_gof": round(arena_gof / 1e6, 1), "jobs_in_flight": D, "gofs_per_job": round(gpj, 3), "gofs_in_flight": round(D * gpj), "setup_jobs_before_warmup": primed, "in_bytes": in_bytes, "out_bytes": out_bytes, "parallelism": f"gof-shard x{world}"},
                 "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                              "traffic": traffic, "kernel_ms": {k_: round(v, 3) for k_, v in groups.items()},
-                             "path_achieved_GBs": round(path_achieved, 3), "path_frac": round(path_achieved / HBM_PEAK_GBS, 6)},
+                             "path_achieved_GBs": round(path_achieved, 3), "path_frac": round(path_achieved / HBM_PEAK_GBS, 6), "instruction_issue": issue},
                 "external_decoder": ext["external_decoder"], "libx265": ext["libx265"],      # third-party HEVC tools on this box (tests/external_tools.py): absent on every box so far - parity with one is unpinned
                 "cabac": cabac, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "sequence_walk": walk, "v3c_file": v3c_file, "rate_fanout": fanout, "multi_gof": multi, "in_flight_sweep": sweep, "quality": quality,
                 "host_ms": {"parse": round(st["host_parse_ms"], 3), "pack": round(st["host_pack_ms"], 3), "submit_call": round(host_submit_ms, 3), "wait_call": round(host_wait_ms, 3), "job_gpu_span": round(st["gpu_ms"], 3), "job_span": round(st["total_ms"], 3)}}

@@ -123,7 +123,7 @@ typedef struct rbt_job rbt_job;
 int rbt_set_depth(rbt_ctx* ctx, int max_in_flight);
 int rbt_get_depth(rbt_ctx* ctx);   /* the announced depth (> 0) or RBT_ERR_PARAM */
 /* How to cut a walk of n_gofs GOFs into jobs on one GPU, as measured on 1280x1280 maps: 16 jobs of 3 GOFs for a long walk (96 GOFs and more; 2 GOFs from 48: the
- * arenas of 48 GOFs in flight are 216 GB at that size. The shape looks at the length of the walk only; rbt_transcode_v3c bounds the jobs it keeps in flight by the memory the
+ * arenas of 48 GOFs in flight are 198 GB at that size (4.12 GB per GOF since round 4, rbt_job_memory; 64 in flight fit too and run no faster). The shape looks at the length of the walk only; rbt_transcode_v3c bounds the jobs it keeps in flight by the memory the
  * first job took (rbt_job_memory against rbt_device_memory) and falls back to one GOF per job, one job at a time, when a job still fails with RBT_ERR_NOMEM; a caller
  * that drives rbt_submit_gof itself does the same or passes its own shape); a walk shorter than 48 GOFs is all ramp-up and
  * drain and does better as at most 7 jobs (2 jobs up to 12 GOFs) of ceil(n / jobs) GOFs, which then own several hardware queues each. max_jobs caps the jobs in flight. */
