@@ -4,9 +4,11 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O
 QUIET="--cpu-sample 0 --multi-gof 0 --quality 0 --sweep 0 --walk-frames 0 --fanout-gofs 0 --steady-steps 0"
+if [ -z "$RBT_PROFILE_SKIP_BENCH" ]; then      # (set it to take the profiler passes only, next to bench lines that exist)
 timeout -k 10 900 python3 $R/bench.py > $O/bench_line.json 2> $O/bench_line.err || exit 1
 # the command the driver times at round end (a run that is all ramp-up and drain: DESIGN.md 5)
 timeout -k 10 900 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line_driver.json 2> $O/bench_line_driver.err || exit 1
+fi
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -o kt -- python3 $R/bench.py --steps 32 --warmup 16 --gofs-per-job 2 $QUIET > $O/prof_kt.log 2>&1 || exit 2
 ONE="--steps 1 --warmup 0 --in-flight 1 --gofs-per-job 1 $QUIET"
