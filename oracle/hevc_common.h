@@ -156,6 +156,10 @@ typedef struct {
   int loop_filter_across_slices;
   int num_entry_points;
   int qp;                                      /* SliceQpY */
+  /* pred_weight_table (7.3.6.3, P slices of a PPS with weighted_pred_flag): the syntax elements per entry of RefPicList0 and what 7.4.7.3 derives from them */
+  int wp_luma_denom, wp_chroma_denom;          /* luma_log2_weight_denom, ChromaLog2WeightDenom */
+  int wp_luma_flag[16], wp_chroma_flag[16];
+  int wp_w[16][3], wp_o[16][3];                /* LumaWeightL0 / ChromaWeightL0, luma_offset_l0 / ChromaOffsetL0 (before the shift by BitDepth - 8) */
   int nal_type;
   size_t data_bit_offset;                      /* bit offset of slice_segment_data() in the RBSP */
 } hevc_slice_hdr;

@@ -9,7 +9,8 @@
  * and wavefront streams (entropy_coding_sync_enabled_flag: what libx265 writes by default, and RBT-E1's wavefront mode) - context
  * variables of the CTB above-right at the start of a CTB row (9.3.1), end_of_subset_one_bit and a new arithmetic codeword per row
  * (entry point offsets are read and not needed by a decoder that reads the rows one after the other).
- * Not supported (rejected with an error): B slices, tiles, PCM, scaling lists, weighted prediction, long-term reference pictures.
+ * Not supported (rejected with an error): B slices, tiles, PCM, scaling lists, long-term reference pictures. Weighted prediction of P slices (what libx265 writes from its
+ * preset "veryfast" up: the reference's own output as an input) is decoded since round 4 (pred_weight_table 7.3.6.3, 8.5.3.3.4.3).
  * PARITY: unpinned against libavcodec (not available here). Self-checks: MD5 SEI, encoder-recon == decoder output.
  */
 #include <limits.h>
@@ -161,7 +162,7 @@ static int parse_pps(oracle_hevc_decoder* d, bitreader* b) {
   p.weighted_pred = br_bit(b); p.weighted_bipred = br_bit(b);
   p.transquant_bypass_enabled = br_bit(b); p.tiles_enabled = br_bit(b); p.entropy_coding_sync = br_bit(b);
   if (p.tiles_enabled) { DEC_ERR("tiles unsupported"); return -1; }
-  if (p.weighted_pred) { DEC_ERR("weighted prediction unsupported"); return -1; }
+
   p.loop_filter_across_slices = br_bit(b);
   p.deblocking_control_present = br_bit(b);
   if (p.deblocking_control_present) {
@@ -220,6 +221,23 @@ static int parse_slice_header(oracle_hevc_decoder* d, bitreader* b, int nal_type
     if (pps->cabac_init_present) h->cabac_init_flag = br_bit(b);
     h->collocated_from_l0 = 1;
     if (h->temporal_mvp && h->num_ref_idx[0] > 1) h->collocated_ref_idx = br_ue(b);
+    if (pps->weighted_pred) {   /* pred_weight_table() 7.3.6.3, semantics 7.4.7.3 (no high_precision_offsets: wpOffsetHalfRangeC = 128) */
+      const int n = h->num_ref_idx[0]; if (n > 16) return -1;
+      h->wp_luma_denom = (int)br_ue(b); h->wp_chroma_denom = h->wp_luma_denom + br_se(b);
+      if (h->wp_luma_denom > 7 || h->wp_chroma_denom < 0 || h->wp_chroma_denom > 7) { DEC_ERR("pred_weight_table: weight denominator out of range"); return -1; }
+      for (int i = 0; i < n; i++) h->wp_luma_flag[i] = br_bit(b);
+      for (int i = 0; i < n; i++) h->wp_chroma_flag[i] = br_bit(b);
+      for (int i = 0; i < n; i++) {
+        h->wp_w[i][0] = 1 << h->wp_luma_denom; h->wp_o[i][0] = 0;
+        h->wp_w[i][1] = h->wp_w[i][2] = 1 << h->wp_chroma_denom; h->wp_o[i][1] = h->wp_o[i][2] = 0;
+        if (h->wp_luma_flag[i]) { const int dw = br_se(b), o = br_se(b); if (dw < -128 || dw > 127 || o < -128 || o > 127) return -1; h->wp_w[i][0] += dw; h->wp_o[i][0] = o; }
+        if (h->wp_chroma_flag[i]) for (int j = 1; j < 3; j++) {
+          const int dw = br_se(b), dof = br_se(b); if (dw < -128 || dw > 127 || dof < -512 || dof > 511) return -1;
+          h->wp_w[i][j] += dw;
+          h->wp_o[i][j] = clip3(-128, 127, 128 + dof - ((128 * h->wp_w[i][j]) >> h->wp_chroma_denom));
+        }
+      }
+    }
     h->max_merge_cand = 5 - (int)br_ue(b);
     if (h->max_merge_cand < 1 || h->max_merge_cand > 5) return -1;
   }
@@ -300,6 +318,7 @@ typedef struct {
   cabac_dec c;
   hevc_frame* f; hevc_meta* m;
   const hevc_frame* ref[16]; const hevc_colinfo* refcol[16]; int ref_poc[16];
+  int wp_on;                   /* P slice of a PPS with weighted_pred_flag: explicit weighted sample prediction with the slice header's table */
   int slice_idx;
   int qp_y, qp_y_prev;         /* current CU QpY; QpY of the last CU of the previous quantisation group */
   int is_cu_qp_delta_coded, cu_qp_delta_val, qp_pred;
@@ -594,7 +613,12 @@ static void prediction_unit(sdec* s, int xcb, int ycb, int x0, int y0, int w, in
     }
   for (int i = 0; i < h; i += 4) m->edge_v[meta_idx(m, x0, y0 + i)] |= 2;
   for (int i = 0; i < w; i += 4) m->edge_h[meta_idx(m, x0 + i, y0)] |= 2;
-  hevc_inter_pred(s->f, s->ref[mv.ref], x0, y0, w, h, mv.x, mv.y);
+  if (s->wp_on) {   /* explicit weighted sample prediction (8.5.3.3.4.3): log2WD = denominator + shift1 (14 - bitDepth), offsets at the sample bit depth */
+    const int bd = s->f->bit_depth; hevc_wp wp;
+    for (int c = 0; c < 3; c++) { wp.w[c] = s->sh.wp_w[mv.ref][c]; wp.o[c] = s->sh.wp_o[mv.ref][c] * (1 << (bd - 8)); }
+    wp.shift[0] = s->sh.wp_luma_denom + 14 - bd; wp.shift[1] = s->sh.wp_chroma_denom + 14 - bd;
+    hevc_inter_pred_wp(s->f, s->ref[mv.ref], x0, y0, w, h, mv.x, mv.y, &wp);
+  } else hevc_inter_pred(s->f, s->ref[mv.ref], x0, y0, w, h, mv.x, mv.y);
 }
 
 /* ------------------------------------------------------------------------------------------------ coding unit (7.3.8.5) */
@@ -809,6 +833,7 @@ static int decode_slice(oracle_hevc_decoder* d, const uint8_t* rbsp, size_t n, i
   else { cabac_init_ctx(s->c.st, init_type, s->sh.qp); s->qp_y = s->sh.qp; }
   cabac_start(&s->c, rbsp, n, s->sh.data_bit_offset);
   s->qp_pred = s->sh.qp;
+  s->wp_on = pps->weighted_pred && s->sh.slice_type == SLICE_P;
   s->mp.m = m; s->mp.max_merge_cand = s->sh.max_merge_cand; s->mp.num_ref_idx = s->sh.num_ref_idx[0]; s->mp.ref_poc = s->ref_poc;
   s->mp.cur_poc = d->cur_poc; s->mp.col = (s->sh.temporal_mvp && s->sh.slice_type == SLICE_P) ? s->refcol[s->sh.collocated_ref_idx] : NULL;
   s->mp.log2_ctb = sps->log2_ctb; s->mp.pic_w = sps->width; s->mp.pic_h = sps->height;
@@ -884,11 +909,14 @@ int oracle_slice_headers(const uint8_t* p, size_t n, int* out, int cap) {
           if (h.poc_lsb < prev_lsb && prev_lsb - h.poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb; else if (h.poc_lsb > prev_lsb && h.poc_lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
           h.poc = msb + h.poc_lsb; }
       }
-      if (!rc && k < cap) { int* o = out + 28 * k; int intra = h.slice_type == SLICE_I; o[18] = h.dependent;
+      if (!rc && k < cap) { int* o = out + 64 * k; int intra = h.slice_type == SLICE_I; o[18] = h.dependent;
         o[0] = type; o[1] = h.segment_addr; o[2] = h.slice_type; o[3] = h.poc; o[4] = h.temporal_mvp; o[5] = h.sao_luma; o[6] = h.sao_chroma; o[7] = intra ? 0 : h.num_ref_idx[0];
         o[8] = h.cabac_init_flag; o[9] = intra ? 0 : h.collocated_ref_idx; o[10] = intra ? 0 : h.max_merge_cand; o[11] = h.qp; o[12] = h.cb_qp_offset; o[13] = h.cr_qp_offset;
         o[14] = h.deblocking_disabled; o[15] = h.beta_offset_div2; o[16] = h.tc_offset_div2; o[17] = h.loop_filter_across_slices;
-        { const int has_rps = type != NAL_IDR_W_RADL && type != NAL_IDR_N_LP; o[19] = has_rps ? h.rps_num : 0; for (int q = 0; q < 4; q++) { o[20 + 2 * q] = has_rps && q < h.rps_num ? h.rps_delta[q] : 0; o[21 + 2 * q] = has_rps && q < h.rps_num ? h.rps_used[q] : 0; } } }
+        { const int has_rps = type != NAL_IDR_W_RADL && type != NAL_IDR_N_LP; o[19] = has_rps ? h.rps_num : 0; for (int q = 0; q < 4; q++) { o[20 + 2 * q] = has_rps && q < h.rps_num ? h.rps_delta[q] : 0; o[21 + 2 * q] = has_rps && q < h.rps_num ? h.rps_used[q] : 0; } }
+        { const int wp = !intra && pps->weighted_pred; o[28] = wp; o[29] = wp ? h.wp_luma_denom : 0; o[30] = wp ? h.wp_chroma_denom : 0; o[31] = 0;      /* pred_weight_table: per RefPicList0 entry (up to 4) flags, then weight and offset per component */
+          for (int q = 0; q < 4; q++) { const int on = wp && q < h.num_ref_idx[0]; int* e = o + 32 + 8 * q; e[0] = on ? h.wp_luma_flag[q] : 0; e[1] = on ? h.wp_chroma_flag[q] : 0;
+            for (int c = 0; c < 3; c++) { e[2 + 2 * c] = on ? h.wp_w[q][c] : 0; e[3 + 2 * c] = on ? h.wp_o[q][c] : 0; } } } }
       if (!rc) { k++; if (!nal_keeps_poc_anchor(type)) d->prev_tid0_poc = h.poc; if (!h.dependent) { d->last_sh = h; d->have_last_sh = 1; } }
     }
     free(rb);

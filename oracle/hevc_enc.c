@@ -127,6 +127,7 @@ typedef struct {
   const hevc_frame* src; hevc_frame* rec; hevc_meta* m;
   const hevc_frame* ref[2]; const hevc_colinfo* refcol[2]; int ref_poc[2]; int n_ref;
   int poc, slice_type, slice_qp, slice_idx, is_idr;
+  int wp_dw[16][3], wp_dof[16][3];   /* pred_weight_table as written: delta weights and, for chroma, delta_chroma_offset_l0 (sh.wp_* hold what 7.4.7.3 derives) */
   int nal_type, rps_explicit, rps_inter;   /* of the current picture (ctc_gop): NAL unit type; reference picture set coded in the slice header rather than taken from the SPS, there with inter-set prediction */
   hevc_slice_hdr sh;
   hevc_mvpred mp;
@@ -256,7 +257,7 @@ static void write_param_sets(enc* e, bytebuf* out) {
   bw_se(&w, p->init_qp - 26); bw_bit(&w, p->constrained_intra_pred); bw_bit(&w, p->transform_skip_enabled);
   bw_bit(&w, p->cu_qp_delta_enabled); if (p->cu_qp_delta_enabled) bw_ue(&w, p->diff_cu_qp_delta_depth);
   bw_se(&w, p->cb_qp_offset); bw_se(&w, p->cr_qp_offset); bw_bit(&w, p->slice_chroma_qp_offsets_present);
-  bw_bit(&w, 0); bw_bit(&w, 0);
+  bw_bit(&w, p->weighted_pred); bw_bit(&w, 0);
   bw_bit(&w, p->transquant_bypass_enabled); bw_bit(&w, 0); bw_bit(&w, p->entropy_coding_sync);
   bw_bit(&w, p->loop_filter_across_slices);
   bw_bit(&w, p->deblocking_control_present);
@@ -308,6 +309,16 @@ static void write_slice_header(enc* e, bitwriter* w, int first, int ctb_addr, in
     bw_bit(w, ovr); if (ovr) bw_ue(w, h->num_ref_idx[0] - 1);
     if (p->cabac_init_present) bw_bit(w, h->cabac_init_flag);
     if (h->temporal_mvp && h->num_ref_idx[0] > 1) bw_ue(w, h->collocated_ref_idx);
+    if (p->weighted_pred) {   /* pred_weight_table() 7.3.6.3 */
+      const int n = h->num_ref_idx[0];
+      bw_ue(w, (uint32_t)h->wp_luma_denom); bw_se(w, h->wp_chroma_denom - h->wp_luma_denom);
+      for (int i = 0; i < n; i++) bw_bit(w, h->wp_luma_flag[i]);
+      for (int i = 0; i < n; i++) bw_bit(w, h->wp_chroma_flag[i]);
+      for (int i = 0; i < n; i++) {
+        if (h->wp_luma_flag[i]) { bw_se(w, e->wp_dw[i][0]); bw_se(w, h->wp_o[i][0]); }
+        if (h->wp_chroma_flag[i]) for (int j = 1; j < 3; j++) { bw_se(w, e->wp_dw[i][j]); bw_se(w, e->wp_dof[i][j]); }
+      }
+    }
     bw_ue(w, 5 - h->max_merge_cand);
   }
   bw_se(w, h->qp - p->init_qp);
@@ -785,7 +796,12 @@ static void pu_decide_predict(enc* e, pu_t* pu, int part_idx, int skip, const in
     }
   for (int i = 0; i < pu->h; i += 4) m->edge_v[meta_idx(m, pu->x, pu->y + i)] |= 2;
   for (int i = 0; i < pu->w; i += 4) m->edge_h[meta_idx(m, pu->x + i, pu->y)] |= 2;
-  hevc_inter_pred(e->rec, e->ref[pu->mv.ref], pu->x, pu->y, pu->w, pu->h, pu->mv.x, pu->mv.y);
+  if (e->pps.weighted_pred) {
+    const int bd = e->rec->bit_depth; hevc_wp wp;
+    for (int c = 0; c < 3; c++) { wp.w[c] = e->sh.wp_w[pu->mv.ref][c]; wp.o[c] = e->sh.wp_o[pu->mv.ref][c] * (1 << (bd - 8)); }
+    wp.shift[0] = e->sh.wp_luma_denom + 14 - bd; wp.shift[1] = e->sh.wp_chroma_denom + 14 - bd;
+    hevc_inter_pred_wp(e->rec, e->ref[pu->mv.ref], pu->x, pu->y, pu->w, pu->h, pu->mv.x, pu->mv.y, &wp);
+  } else hevc_inter_pred(e->rec, e->ref[pu->mv.ref], pu->x, pu->y, pu->w, pu->h, pu->mv.x, pu->mv.y);
 }
 static void pu_write(enc* e, const pu_t* pu, int skip) {
   cabac_enc* c = &e->c;
@@ -1576,6 +1592,7 @@ static void setup_stream(enc* e) {
     e->max_merge_cand = 1 + rndn(r, 5);
     p->num_ref_idx_default[0] = 1 + (e->two_refs && rndp(r, 50));
     p->entropy_coding_sync = rndp(r, 40); p->dependent_slice_segments_enabled = rndp(r, 40);
+    p->weighted_pred = q->weighted_pred != 0;
   }
   if (q->ctc_gop) { s->num_st_rps = e->two_refs ? 3 : (!e->stress && q->gop <= 1) ? 1 : 2; if (s->max_dec_pic_buffering < 4) s->max_dec_pic_buffering = 4; }   /* {-1}, {-2} as in the GOP table of the CTC (+ {-1,-2}) */
   s->pic_w_ctb = (s->width + (1 << s->log2_ctb) - 1) >> s->log2_ctb; s->pic_h_ctb = (s->height + (1 << s->log2_ctb) - 1) >> s->log2_ctb;
@@ -1619,6 +1636,20 @@ static void encode_slices(enc* e, int is_i, int st_rps_idx, bytebuf* out) {
         if (p->deblocking_override_enabled && rndp(r, 50)) { h->deblocking_disabled = rndp(r, 20); if (!h->deblocking_disabled) { h->beta_offset_div2 = rndn(r, 9) - 4; h->tc_offset_div2 = rndn(r, 9) - 4; } else { h->beta_offset_div2 = p->beta_offset_div2; h->tc_offset_div2 = p->tc_offset_div2; } }
         if (p->loop_filter_across_slices && (h->sao_luma || h->sao_chroma || !h->deblocking_disabled)) h->loop_filter_across_slices = rndp(r, 70);
       } else h->qp = clip3(0, 51, is_i ? e->p.qp + e->p.i_qp_offset : e->p.qp + (e->hm ? e->p.p_qp_offset : 0));
+      if (p->weighted_pred && !is_i) {   /* a table of its own per slice, from a generator of its own (the other choices of a seed stay what they were) */
+        rng w2; w2.s = e->p.stress_seed * 2654435761u + (uint32_t)(e->poc * 977 + addr * 31 + 1); if (!w2.s) w2.s = 1;
+        h->wp_luma_denom = rndn(&w2, 8); h->wp_chroma_denom = clip3(0, 7, h->wp_luma_denom + rndn(&w2, 5) - 2);
+        for (int i = 0; i < h->num_ref_idx[0]; i++) {
+          h->wp_luma_flag[i] = rndp(&w2, 70); h->wp_chroma_flag[i] = rndp(&w2, 60);
+          h->wp_w[i][0] = 1 << h->wp_luma_denom; h->wp_o[i][0] = 0; h->wp_w[i][1] = h->wp_w[i][2] = 1 << h->wp_chroma_denom; h->wp_o[i][1] = h->wp_o[i][2] = 0;
+          if (h->wp_luma_flag[i]) { e->wp_dw[i][0] = rndp(&w2, 10) ? rndn(&w2, 256) - 128 : rndn(&w2, 17) - 8; h->wp_w[i][0] += e->wp_dw[i][0]; h->wp_o[i][0] = rndp(&w2, 10) ? rndn(&w2, 256) - 128 : rndn(&w2, 41) - 20; }
+          if (h->wp_chroma_flag[i]) for (int j = 1; j < 3; j++) {
+            e->wp_dw[i][j] = rndp(&w2, 10) ? rndn(&w2, 256) - 128 : rndn(&w2, 17) - 8; e->wp_dof[i][j] = rndp(&w2, 10) ? rndn(&w2, 1024) - 512 : rndn(&w2, 61) - 30;
+            h->wp_w[i][j] += e->wp_dw[i][j];
+            h->wp_o[i][j] = clip3(-128, 127, 128 + e->wp_dof[i][j] - ((128 * h->wp_w[i][j]) >> h->wp_chroma_denom));
+          }
+        }
+      }
       if (e->hm && (!is_i || (e->p.ctc_gop && !e->is_idr))) { h->temporal_mvp = s->temporal_mvp_enabled; h->collocated_ref_idx = 0; }   /* HM (TMVPMode 1) sets the flag on every slice that carries it, I slices of trailing pictures included */
       if (!e->stress && e->hm_pass == 2) { h->sao_luma = 1; h->sao_chroma = 1; }
       e->slice_qp = h->qp; e->slice_idx = m->n_slices++;

@@ -41,6 +41,8 @@ typedef struct {
   int log2_max_poc_lsb;     /* 0 = 8 (HM's default); 4..16: pic_order_cnt_lsb wraps every 2^n pictures */
   int first_idx;            /* ctc_gop: index inside the stream of frames[0] (frames are independent of each other but for the headers: a long stream can be made
                                in pieces by parallel workers and concatenated; first_idx must start a group) */
+  int weighted_pred;        /* random-syntax streams (stress_seed): PPS weighted_pred_flag with a pred_weight_table of random weights and offsets in every P slice
+                               (what libx265 writes from its preset "veryfast" up); the weighting is applied to the generator's own prediction */
   int tools_off;            /* RBT-E1 decision tools to leave out: 1 SATD block costs, 2 closed-loop mode choice, 4 rounding by level and position, 16 coded trial of the two cheapest modes (the library's RBT_ET_* bits; oracle_transcode_params.preset) */
 } oracle_enc_params;
 

@@ -237,7 +237,7 @@ void hevc_intra_mpm(const hevc_meta* m, int xp, int yp, int cand[3]) {
 static inline int refpix(const uint16_t* p, int w, int h, int x, int y) { return p[(size_t)clip3(0, h - 1, y) * w + clip3(0, w - 1, x)]; }
 
 static void mc_block(uint16_t* dst, int dw, const uint16_t* ref, int rw, int rh, int x0, int y0, int bw, int bh,
-                     int xint, int yint, int xf, int yf, int taps, const int8_t* fx, const int8_t* fy, int bd) {
+                     int xint, int yint, int xf, int yf, int taps, const int8_t* fx, const int8_t* fy, int bd, const int* wp) {   /* wp: {w0, o0, log2WD} or NULL */
   int sh1 = imin(4, bd - 8), sh2 = 6, sh3 = 14 - bd;
   int half = taps / 2 - 1;   /* taps before the integer position */
   int maxv = (1 << bd) - 1;
@@ -260,16 +260,23 @@ static void mc_block(uint16_t* dst, int dw, const uint16_t* ref, int rw, int rh,
         v = s >> sh2;
       }
       (void)tmp;
+      if (wp) {   /* 8.5.3.3.4.3 (8-265): explicit weighting of the 14-bit intermediate */
+        const int r = wp[2] >= 1 ? ((v * wp[0] + (1 << (wp[2] - 1))) >> wp[2]) + wp[1] : v * wp[0] + wp[1];
+        dst[(size_t)(y0 + y) * dw + x0 + x] = (uint16_t)clip3(0, maxv, r);
+      } else
       dst[(size_t)(y0 + y) * dw + x0 + x] = (uint16_t)clip3(0, maxv, (v + fadd) >> fsh);
     }
 }
-void hevc_inter_pred(hevc_frame* f, const hevc_frame* ref, int x0, int y0, int w, int h, int mvx, int mvy) {
+void hevc_inter_pred_wp(hevc_frame* f, const hevc_frame* ref, int x0, int y0, int w, int h, int mvx, int mvy, const hevc_wp* wp) {
+  int t[3][3];
+  if (wp) for (int c = 0; c < 3; c++) { t[c][0] = wp->w[c]; t[c][1] = wp->o[c]; t[c][2] = wp->shift[c != 0]; }
   mc_block(f->p[0], f->w, ref->p[0], ref->w, ref->h, x0, y0, w, h, mvx >> 2, mvy >> 2, mvx & 3, mvy & 3, 8,
-           k_luma_filter[mvx & 3], k_luma_filter[mvy & 3], f->bit_depth);
+           k_luma_filter[mvx & 3], k_luma_filter[mvy & 3], f->bit_depth, wp ? t[0] : NULL);
   for (int c = 1; c < 3; c++)
     mc_block(f->p[c], f->cw, ref->p[c], ref->cw, ref->ch, x0 / 2, y0 / 2, w / 2, h / 2, mvx >> 3, mvy >> 3, mvx & 7, mvy & 7, 4,
-             k_chroma_filter[mvx & 7], k_chroma_filter[mvy & 7], f->bit_depth);
+             k_chroma_filter[mvx & 7], k_chroma_filter[mvy & 7], f->bit_depth, wp ? t[c] : NULL);
 }
+void hevc_inter_pred(hevc_frame* f, const hevc_frame* ref, int x0, int y0, int w, int h, int mvx, int mvy) { hevc_inter_pred_wp(f, ref, x0, y0, w, h, mvx, mvy, NULL); }
 
 /* luma prediction block (8.5.3.3.3 + the uni-directional weighting of 8.5.3.3.4.2) into out[w*h]; separable evaluation of the same
  * arithmetic as mc_block (row filter >> shift1, column filter >> 6), used by the HM-like encoder's motion search */

@@ -74,6 +74,10 @@ void hevc_intra_mpm(const hevc_meta* m, int xp, int yp, int cand[3]);
 
 /* uni-directional inter prediction of a luma block + its chroma, writes final clipped samples into f */
 void hevc_inter_pred(hevc_frame* f, const hevc_frame* ref, int x0, int y0, int w, int h, int mvx, int mvy);
+/* the same with explicit weighted sample prediction (8.5.3.3.4.3, uni-prediction): per component c the weight w[c], the offset o[c] already shifted to the sample bit depth
+ * and log2WD = the weight denominator + 14 - bitDepth in shift[c != 0]; wp == NULL: default weighting */
+typedef struct { int w[3], o[3], shift[2]; } hevc_wp;
+void hevc_inter_pred_wp(hevc_frame* f, const hevc_frame* ref, int x0, int y0, int w, int h, int mvx, int mvy, const hevc_wp* wp);
 
 /* the luma block hevc_inter_pred would write, into out[w*h] (w, h <= 64) */
 void hevc_mc_luma_buf(const hevc_frame* ref, int x0, int y0, int w, int h, int mvx, int mvy, uint16_t* out);

@@ -140,7 +140,7 @@ int main(int argc, char** argv) {
           dec->parseSliceHeader(&slice, &psm, prevPoc);
           // a dependent slice segment carries nothing but its address: parseSliceHeader leaves the slice object as initSlice made it and the reference's
           // caller fills it from the previous segment (TDecTop, copySliceInfo); the same is done here with the values of the slice's independent segment
-          static int v[16]; static char rpsText[128] = "[]";
+          static int v[16]; static char rpsText[128] = "[]"; static char wpText[512] = "[]";
           const int dep = slice.getDependentSliceSegmentFlag() ? 1 : 0;
           if (!dep) {
             v[0] = (int)slice.getSliceType(); v[1] = slice.getPOC(); v[2] = (int)slice.getEnableTMVPFlag(); v[3] = (int)slice.getSaoEnabledFlag(CHANNEL_TYPE_LUMA);
@@ -153,11 +153,22 @@ int main(int argc, char** argv) {
             const TComReferencePictureSet* rps = slice.getRPS();
             if (!slice.getIdrPicFlag() && rps) for (int j = 0; j < rps->getNumberOfPictures() && j < 4; j++) o += snprintf(rpsText + o, sizeof(rpsText) - o, "%s[%d,%d]", j ? "," : "", rps->getDeltaPOC(j), (int)rps->getUsed(j));
             snprintf(rpsText + o, sizeof(rpsText) - o, "]");
+            // pred_weight_table as xParsePredWeightTable (:2094) left it: denominators, then per RefPicList0 entry the flags and weight / offset per component
+            const TComPPS* pp = psm.getPPS(slice.getPPSId());
+            if (pp && pp->getUseWP() && slice.getSliceType() == P_SLICE) {
+              WPScalingParam* wp = NULL; slice.getWpScaling(REF_PIC_LIST_0, 0, wp);
+              int q = snprintf(wpText, sizeof(wpText), "[%d,%d", (int)wp[0].uiLog2WeightDenom, (int)wp[1].uiLog2WeightDenom);
+              for (int r = 0; r < slice.getNumRefIdx(REF_PIC_LIST_0) && r < 4; r++) {
+                slice.getWpScaling(REF_PIC_LIST_0, r, wp);
+                q += snprintf(wpText + q, sizeof(wpText) - q, ",[%d,%d,%d,%d,%d,%d,%d,%d]", (int)wp[0].bPresentFlag, (int)wp[1].bPresentFlag, wp[0].iWeight, wp[0].iOffset, wp[1].iWeight, wp[1].iOffset, wp[2].iWeight, wp[2].iOffset);
+              }
+              snprintf(wpText + q, sizeof(wpText) - q, "]");
+            } else snprintf(wpText, sizeof(wpText), "[]");
           }
           printf("%s{\"nal_type\":%d,\"address\":%d,\"dependent\":%d,\"slice_type\":%d,\"poc\":%d,\"tmvp\":%d,\"sao_luma\":%d,\"sao_chroma\":%d,\"num_ref_idx\":%d,\"cabac_init\":%d,"
                  "\"col_ref_idx\":%d,\"max_merge_cand\":%d,\"qp\":%d,\"cb_qp_offset\":%d,\"cr_qp_offset\":%d,\"deblocking_disabled\":%d,\"beta_offset_div2\":%d,"
-                 "\"tc_offset_div2\":%d,\"lf_across\":%d,\"rps\":%s}\n", n++ ? "," : "", type, (int)slice.getSliceSegmentCurStartCtuTsAddr(), dep, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9],
-                 v[10], v[11], v[12], v[13], v[14], v[15], rpsText);
+                 "\"tc_offset_div2\":%d,\"lf_across\":%d,\"rps\":%s,\"wp\":%s}\n", n++ ? "," : "", type, (int)slice.getSliceSegmentCurStartCtuTsAddr(), dep, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9],
+                 v[10], v[11], v[12], v[13], v[14], v[15], rpsText, wpText);
           const bool keepsAnchor = (type <= 14 && (type & 1) == 0) || (type >= 6 && type <= 9);   // 8.3.1: RASL / RADL / sub-layer non-reference pictures are not prevTid0Pic
           if (dep) { if (!keepsAnchor) prevPoc = v[1]; if (i < size) { sc = data[i + 2] == 0 ? 4 : 3; index = i; i += sc; } continue; }
           if (!keepsAnchor) prevPoc = slice.getPOC();

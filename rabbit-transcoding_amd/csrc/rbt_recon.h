@@ -241,13 +241,15 @@ RBT_DEV int rc_refpix(const uint16_t* p, int w, int h, int x, int y) { return p[
 // dst(x,y) = dst[(dy0 + y) * dstride + dx0 + x]: a picture plane in HBM or the CTB tile in LDS
 // add_res: dst holds the residual of the block (int16 bit patterns, 0 where nothing is coded); the sample is completed in place
 template <int TAPS, class DP> RBT_DEV void rc_mc_plane(DP dst, int dstride, int dx0, int dy0, const uint16_t* ref, int pw, int ph, int x0, int y0, int bw, int bh, int xint, int yint, int xf, int yf,
-                         const int8_t* fx, const int8_t* fy, int bd, int add_res, RBT_LDS_AS RbtReconLdsCore* l) {
+                         const int8_t* fx, const int8_t* fy, int bd, int add_res, RBT_LDS_AS RbtReconLdsCore* l, int wp_w = 0, int wp_o = 0, int wp_shift = -1) {
+  // wp_shift >= 0: explicit weighted sample prediction (8.5.3.3.4.3, (8-265)) of the 14-bit intermediate v: ((v * w + 2^(log2WD - 1)) >> log2WD) + o, log2WD = wp_shift
   constexpr int HALF = TAPS / 2 - 1, SBW = 32, SBH = 16;
   static_assert((SBW + 7) * (SBH + 7) <= 32 * 32 && SBW * (SBH + 7) <= 32 * 32, "window and intermediate fit the TB scratch");
   const int sh1 = rbt_min(4, bd - 8), maxv = (1 << bd) - 1, fsh = 14 - bd, fadd = fsh ? 1 << (fsh - 1) : 0;
   if (!xf && !yf) {                                                         // integer vector: (ref << shift3 + round) >> shift3 == ref
     RBT_PAR_FOR(i, bw * bh) {
-      const int y = i / bw, x = i - y * bw, o = (dy0 + y) * dstride + dx0 + x, pr = rc_refpix(ref, pw, ph, x0 + xint + x, y0 + yint + y);
+      const int y = i / bw, x = i - y * bw, o = (dy0 + y) * dstride + dx0 + x; int pr = rc_refpix(ref, pw, ph, x0 + xint + x, y0 + yint + y);
+      if (wp_shift >= 0) { const int v = pr << fsh; pr = rbt_clip3(0, maxv, (wp_shift >= 1 ? ((v * wp_w + (1 << (wp_shift - 1))) >> wp_shift) : v * wp_w) + wp_o); }
       dst[o] = (uint16_t)(add_res ? rbt_clip3(0, maxv, pr + (int16_t)dst[o]) : pr);
     }
     return;
@@ -279,7 +281,8 @@ template <int TAPS, class DP> RBT_DEV void rc_mc_plane(DP dst, int dstride, int 
         for (int j = 0; j < TAPS; j++) s += cy[j] * mid[(y + j) * sw + x];
         v = xf ? s >> 6 : s >> sh1; }
       else v = mid[i];
-      const int o = (dy0 + sy + y) * dstride + dx0 + sx + x, pr = rbt_clip3(0, maxv, (v + fadd) >> fsh);
+      const int o = (dy0 + sy + y) * dstride + dx0 + sx + x;
+      const int pr = wp_shift < 0 ? rbt_clip3(0, maxv, (v + fadd) >> fsh) : rbt_clip3(0, maxv, (wp_shift >= 1 ? ((v * wp_w + (1 << (wp_shift - 1))) >> wp_shift) : v * wp_w) + wp_o);
       dst[o] = (uint16_t)(add_res ? rbt_clip3(0, maxv, pr + (int16_t)dst[o]) : pr);
     }
     RBT_SYNC_LDS();                                                         // the next sub-block reuses window and intermediate
@@ -538,10 +541,12 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
     if (c.type == RBT_CMD_PU) {
       const RbtFrame* ref = &frames[sl->ref_frame[c.c]];
       const int w = c.a * 4, h = c.b * 4, mvx = c.mvx, mvy = c.mvy;
-      if (DO_Y) rc_mc_plane<8>(t->y, RC_TS_Y, x0 + 1, y0, ref->out[0], g->w, g->h, cx + x0, cy + y0, w, h, mvx >> 2, mvy >> 2, mvx & 3, mvy & 3, k_luma_filter[mvx & 3], k_luma_filter[mvy & 3], g->bit_depth, 1, &R->rc);
+      const int wpn = sl->wp_on, ri = c.c;                                 // explicit weights of this reference index (slices of a PPS with weighted_pred_flag)
+      if (DO_Y) rc_mc_plane<8>(t->y, RC_TS_Y, x0 + 1, y0, ref->out[0], g->w, g->h, cx + x0, cy + y0, w, h, mvx >> 2, mvy >> 2, mvx & 3, mvy & 3, k_luma_filter[mvx & 3], k_luma_filter[mvy & 3], g->bit_depth, 1, &R->rc,
+                               wpn ? sl->wp_w[ri][0] : 0, wpn ? sl->wp_o[ri][0] : 0, wpn ? sl->wp_shift[0] : -1);
       if (DO_C) for (int cc = 1; cc < 3; cc++)
         rc_mc_plane<4>(t->c[cc - 1], RC_TS_C, (x0 >> 1) + 1, y0 >> 1, ref->out[cc], g->cw, g->ch, (cx + x0) >> 1, (cy + y0) >> 1, w >> 1, h >> 1, mvx >> 3, mvy >> 3, mvx & 7, mvy & 7,
-                       k_chroma_filter[mvx & 7], k_chroma_filter[mvy & 7], g->bit_depth, 1, &R->rc);
+                       k_chroma_filter[mvx & 7], k_chroma_filter[mvy & 7], g->bit_depth, 1, &R->rc, wpn ? sl->wp_w[ri][cc] : 0, wpn ? sl->wp_o[ri][cc] : 0, wpn ? sl->wp_shift[1] : -1);
       rc_tile_mark(R->uav, c.x4, c.y4, c.a, c.b, !g->cip);
     } else if (c.type == RBT_CMD_TU && (c.a & RBT_TU_INTRA)) {
       const int fl = c.a, log2 = c.log2;

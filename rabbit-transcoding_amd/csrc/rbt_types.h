@@ -150,6 +150,10 @@ struct RbtSlice {                // one per slice segment, parsed on the host (7
   int32_t ctb_limit;             // decoder: > 0: this entry is ONE substream (CTB row) of a segment with entry points: stop after that many CTBs, at end_of_subset_one_bit
   int32_t ref_frame[RBT_MAX_REFS];   // batch frame index of RefPicList0[i]
   int32_t ref_poc[RBT_MAX_REFS];
+  // explicit weighted sample prediction (8.5.3.3.4.3) of a P slice under weighted_pred_flag, per RefPicList0 entry and component: weight, offset at the sample bit depth;
+  // wp_shift = log2WD = weight denominator + 14 - bitDepth for luma / chroma; wp_on = 0: default weighting
+  int16_t wp_w[RBT_MAX_REFS][3], wp_o[RBT_MAX_REFS][3];
+  int8_t wp_shift[2]; uint8_t wp_on, wp_pad;
   int32_t poc;
   uint32_t n_ctbs_decoded;       // out: CTBs the slice covered
   // ---- encoder side ----

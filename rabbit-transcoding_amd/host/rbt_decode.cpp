@@ -63,6 +63,10 @@ int decode_build(DecodeBatch& b, const StreamIn* streams, int n_streams) {
         s.beta_offset_div2 = (int8_t)h.beta_offset_div2; s.tc_offset_div2 = (int8_t)h.tc_offset_div2; s.temporal_mvp = (uint8_t)h.temporal_mvp;
         s.cabac_init_flag = (uint8_t)h.cabac_init_flag; s.max_merge_cand = (uint8_t)h.max_merge_cand; s.num_ref_idx = (uint8_t)h.num_ref_idx;
         s.collocated_ref_idx = (uint8_t)h.collocated_ref_idx; s.poc = h.poc;
+        if (h.slice_type == RBT_SLICE_P && h.wp_on) {
+          s.wp_on = 1; s.wp_shift[0] = (int8_t)(h.wp_luma_denom + 14 - sps.bit_depth); s.wp_shift[1] = (int8_t)(h.wp_chroma_denom + 14 - sps.bit_depth);
+          for (int i = 0; i < h.num_ref_idx && i < RBT_MAX_REFS; i++) for (int c = 0; c < 3; c++) { s.wp_w[i][c] = (int16_t)h.wp_w[i][c]; s.wp_o[i][c] = (int16_t)(h.wp_o[i][c] * (1 << (sps.bit_depth - 8))); }
+        }
         if (h.qp < -6 * (sps.bit_depth - 8) || h.qp > 51) { delete ps; b.err = "slice QP out of range"; return b.err_code = RBT_ERR_BITSTREAM; }
         if (h.slice_type == RBT_SLICE_P) {
           int cand[16], nc = 0;

@@ -134,10 +134,9 @@ int parse_pps(ParamSets& ps, const uint8_t* rbsp, size_t n, std::string& err) {
   p.init_qp = 26 + b.se(); p.constrained_intra_pred = b.bit(); p.transform_skip = b.bit();
   p.cu_qp_delta = b.bit(); if (p.cu_qp_delta) p.diff_cu_qp_delta_depth = b.ue();
   p.cb_qp_offset = b.se(); p.cr_qp_offset = b.se(); p.slice_chroma_qp_offsets_present = b.bit();
-  int wp = b.bit(); b.bit();
+  p.weighted_pred = b.bit(); b.bit();                  // weighted_bipred_flag concerns B slices, which are refused where they appear
   p.transquant_bypass = b.bit(); int tiles = b.bit(); p.entropy_coding_sync = b.bit();
   if (tiles) { err = "tiles are not supported"; return -3; }
-  if (wp) { err = "weighted prediction is not supported"; return -3; }
   p.loop_filter_across_slices = b.bit(); p.deblocking_control_present = b.bit();
   if (p.deblocking_control_present) {
     p.deblocking_override_enabled = b.bit(); p.pps_deblocking_disabled = b.bit();
@@ -201,6 +200,23 @@ int parse_slice_header(ParamSets& ps, const uint8_t* rbsp, size_t n, int nal_typ
     if (p.lists_modification_present && ntot > 1 && b.bit()) { err = "ref_pic_lists_modification is not supported"; return -3; }
     if (p.cabac_init_present) h.cabac_init_flag = b.bit();
     if (h.temporal_mvp && h.num_ref_idx > 1) h.collocated_ref_idx = b.ue();
+    if (p.weighted_pred) {   // pred_weight_table() 7.3.6.3; derivations 7.4.7.3 without high_precision_offsets (wpOffsetHalfRangeC = 128)
+      if (h.num_ref_idx > RBT_MAX_REFS) { err = "slice header range"; return -2; }
+      h.wp_on = 1;
+      h.wp_luma_denom = (int)b.ue(); h.wp_chroma_denom = h.wp_luma_denom + b.se();
+      if (h.wp_luma_denom > 7 || h.wp_chroma_denom < 0 || h.wp_chroma_denom > 7) { err = "pred_weight_table: weight denominator out of range"; return -2; }
+      for (int i = 0; i < h.num_ref_idx; i++) h.wp_luma_flag[i] = b.bit();
+      for (int i = 0; i < h.num_ref_idx; i++) h.wp_chroma_flag[i] = b.bit();
+      for (int i = 0; i < h.num_ref_idx; i++) {
+        h.wp_w[i][0] = 1 << h.wp_luma_denom; h.wp_w[i][1] = h.wp_w[i][2] = 1 << h.wp_chroma_denom;
+        if (h.wp_luma_flag[i]) { const int dw = b.se(), o = b.se(); if (dw < -128 || dw > 127 || o < -128 || o > 127) { err = "pred_weight_table range"; return -2; } h.wp_w[i][0] += dw; h.wp_o[i][0] = o; }
+        if (h.wp_chroma_flag[i]) for (int j = 1; j < 3; j++) {
+          const int dw = b.se(), dof = b.se(); if (dw < -128 || dw > 127 || dof < -512 || dof > 511) { err = "pred_weight_table range"; return -2; }
+          h.wp_w[i][j] += dw;
+          h.wp_o[i][j] = std::min(127, std::max(-128, 128 + dof - ((128 * h.wp_w[i][j]) >> h.wp_chroma_denom)));
+        }
+      }
+    }
     h.max_merge_cand = 5 - (int)b.ue();
     if (h.max_merge_cand < 1 || h.max_merge_cand > 5 || h.num_ref_idx > RBT_MAX_REFS || h.collocated_ref_idx >= h.num_ref_idx) { err = "slice header range"; return -2; }
   }

@@ -51,12 +51,15 @@ struct Pps {
   int cu_qp_delta = 0, diff_cu_qp_delta_depth = 0, cb_qp_offset = 0, cr_qp_offset = 0, slice_chroma_qp_offsets_present = 0;
   int transquant_bypass = 0, loop_filter_across_slices = 0, deblocking_control_present = 0, deblocking_override_enabled = 0;
   int pps_deblocking_disabled = 0, beta_offset_div2 = 0, tc_offset_div2 = 0, lists_modification_present = 0, slice_header_extension_present = 0;
+  int weighted_pred = 0;               // weighted_pred_flag: P slices carry a pred_weight_table (libx265 from preset "veryfast" up)
 };
 struct SliceHdr {
   int nal_type = 0, first_slice_in_pic = 0, pps_id = 0, segment_addr = 0, slice_type = RBT_SLICE_I, dependent = 0, num_entry_points = 0;
   int poc_lsb = 0, poc = 0; Rps rps; int temporal_mvp = 0, sao_luma = 0, sao_chroma = 0, num_ref_idx = 1, cabac_init_flag = 0;
   int collocated_ref_idx = 0, max_merge_cand = 5, qp = 26, cb_qp_offset = 0, cr_qp_offset = 0;
   int deblocking_disabled = 0, beta_offset_div2 = 0, tc_offset_div2 = 0, lf_across = 0;
+  // pred_weight_table (7.3.6.3 / 7.4.7.3) of a P slice under weighted_pred_flag: per RefPicList0 entry the flags, LumaWeightL0 / ChromaWeightL0 and luma_offset_l0 / ChromaOffsetL0
+  int wp_on = 0, wp_luma_denom = 0, wp_chroma_denom = 0, wp_luma_flag[RBT_MAX_REFS] = {}, wp_chroma_flag[RBT_MAX_REFS] = {}, wp_w[RBT_MAX_REFS][3] = {}, wp_o[RBT_MAX_REFS][3] = {};
   size_t data_byte_offset = 0;      // of slice_segment_data() inside the RBSP
   std::vector<uint32_t> entry_sizes; // entry_point_offset_minus1[i] + 1: bytes of substream i as sent (emulation prevention bytes included)
 };

@@ -51,3 +51,25 @@ def check_gof(ctx, R, gs, w, h, n_pc, seed, ctc_gop, rate=3):
     out = ctx.transcode_gof(streams, gs.rate_params(R, rate))
     assert out == O.transcode_data(streams, [(0, 8, prec, 5, gs.DEFAULT_ROWS, 0), (1, gq, prec, 5, gs.DEFAULT_ROWS, 0), (19, aq, prec, 5, gs.DEFAULT_ROWS, 0)])
     return streams, out
+
+
+WP_SEEDS = list(range(1, 21))
+
+
+def wp_case(seed):
+    """random-syntax stream with weighted prediction (PPS weighted_pred_flag, a pred_weight_table of random weights and offsets per P slice - what libx265 writes from its
+    preset "veryfast" up, i.e. the reference's own output handed back as an input), on noise so that the weights matter; odd seeds in the CTC stream structure"""
+    w = [64, 96, 128, 80][seed % 4]; h = [64, 80, 48, 128][(seed // 4) % 4]
+    bd = 10 if seed % 3 else 8
+    fr = np.random.default_rng(900 + seed).integers(0, 1 << bd, (7, w * h * 3 // 2)).astype(np.uint16)
+    ctc = seed % 2
+    bs, rec = O.encode_ex(fr, True, width=w, height=h, bit_depth=bd, qp=28, gop=2, stress_seed=seed, weighted_pred=1, ctc_gop=ctc, log2_max_poc_lsb=4 if ctc else 0, md5_sei=1)
+    return bs, rec, w, h, bd, 7
+
+
+def check_decode_wp(ctx, seed):
+    bs, rec, w, h, bd, n = wp_case(seed)
+    dec, dw, dh, dbd, chk, fail = ctx.decode(bs)
+    assert (dw, dh, dbd, chk, fail) == (w, h, bd, n, 0) and np.array_equal(dec, rec)
+    plain = O.encode_ex(np.zeros((7, w * h * 3 // 2), np.uint16), False, width=w, height=h, bit_depth=bd, qp=28, gop=2, stress_seed=seed, weighted_pred=0, md5_sei=1)[0]
+    assert any(x["wp"] for x in O.slice_headers(bs)) and not any(x["wp"] for x in O.slice_headers(plain))

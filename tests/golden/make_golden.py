@@ -42,6 +42,7 @@ def main():
 
 
 CTC_SEEDS = (2, 5, 6, 9, 11, 16)   # random-syntax streams in the CTC structure: 2, 6: I P P groups; 5, 9, 11: every trailing picture TRAIL_R; explicit / predicted sets
+WP_SEEDS = (4, 7, 9, 10, 15, 22)   # random-syntax streams with weighted prediction (odd: in the CTC structure)
 WAVE_SEEDS = (13, 17)    # random-syntax streams with entropy_coding_sync (13: with dependent slice segments as well)
 
 
@@ -72,6 +73,14 @@ def slice_goldens():
         bs = O.encode_ctc(zeros23, 96, 64, 10, 30, ctc_gop=1 + seed % 2, log2_max_poc_lsb=4 + seed % 3, hm=0, stress_seed=seed)[0]
         sps = O.sps_fields(bs)
         cases[f"ctc_stress{seed}"] = (bs, [sps["log2_max_poc_lsb"], sps["log2_ctb"], sps["sao"], sps["tmvp"], sps["num_st_rps"], 1])
+    # weighted prediction (PPS weighted_pred_flag, pred_weight_table in every P slice: what libx265 writes from preset "veryfast" up): random-syntax streams with random
+    # tables - luma / chroma flags per reference, weights around 2^denominator, offsets, the chroma offset prediction of 7.4.7.3 - in closed groups and in the CTC structure
+    noise = np.random.default_rng(77).integers(0, 1024, (9, 96 * 64 * 3 // 2)).astype(np.uint16)
+    for seed in WP_SEEDS:
+        ctc = seed % 2
+        bs = O.encode_ex(noise, False, width=96, height=64, bit_depth=10, qp=30, gop=2, stress_seed=seed, weighted_pred=1, ctc_gop=ctc, log2_max_poc_lsb=4 if ctc else 0, md5_sei=1)[0]
+        sps = O.sps_fields(bs)
+        cases[f"wp_stress{seed}"] = (bs, [sps["log2_max_poc_lsb"], sps["log2_ctb"], sps["sao"], sps["tmvp"], sps["num_st_rps"], ctc])
     for name, (bs, a) in cases.items():
         p = os.path.join(HERE, f"slices_{name}.annexb")
         open(p, "wb").write(bs)

@@ -238,11 +238,14 @@ extern "C" int rbt_hostemu_slice_headers(const uint8_t* annexb, size_t n, int* o
         const rbt::Sps& sp = ps->sps[ps->pps[h.pps_id].sps_id];
         if (h.dependent) h.poc = head.poc; else h.poc = rbt::slice_poc(sp, nal.type, h.poc_lsb, prev_poc); }
       if (!h.dependent) { head = h; have_head = true; }
-      if (k < cap) { int* o = out + 28 * k; const int intra = h.slice_type == RBT_SLICE_I; o[18] = h.dependent;
+      if (k < cap) { int* o = out + 64 * k; const int intra = h.slice_type == RBT_SLICE_I; o[18] = h.dependent;
         o[0] = nal.type; o[1] = h.segment_addr; o[2] = h.slice_type; o[3] = h.poc; o[4] = h.temporal_mvp; o[5] = h.sao_luma; o[6] = h.sao_chroma; o[7] = intra ? 0 : h.num_ref_idx;
         o[8] = h.cabac_init_flag; o[9] = intra ? 0 : h.collocated_ref_idx; o[10] = intra ? 0 : h.max_merge_cand; o[11] = h.qp; o[12] = h.cb_qp_offset; o[13] = h.cr_qp_offset;
         o[14] = h.deblocking_disabled; o[15] = h.beta_offset_div2; o[16] = h.tc_offset_div2; o[17] = h.lf_across;
-        const bool has_rps = nal.type != 19 && nal.type != 20; o[19] = has_rps ? h.rps.num : 0; for (int q = 0; q < 4; q++) { o[20 + 2 * q] = has_rps && q < h.rps.num ? h.rps.delta_poc[q] : 0; o[21 + 2 * q] = has_rps && q < h.rps.num ? h.rps.used[q] : 0; } }
+        const bool has_rps = nal.type != 19 && nal.type != 20; o[19] = has_rps ? h.rps.num : 0; for (int q = 0; q < 4; q++) { o[20 + 2 * q] = has_rps && q < h.rps.num ? h.rps.delta_poc[q] : 0; o[21 + 2 * q] = has_rps && q < h.rps.num ? h.rps.used[q] : 0; }
+        { const int wp = !intra && h.wp_on; o[28] = wp; o[29] = wp ? h.wp_luma_denom : 0; o[30] = wp ? h.wp_chroma_denom : 0; o[31] = 0;
+          for (int q = 0; q < 4; q++) { const int on = wp && q < h.num_ref_idx; int* e = o + 32 + 8 * q; e[0] = on ? h.wp_luma_flag[q] : 0; e[1] = on ? h.wp_chroma_flag[q] : 0;
+            for (int c = 0; c < 3; c++) { e[2 + 2 * c] = on ? h.wp_w[q][c] : 0; e[3 + 2 * c] = on ? h.wp_o[q][c] : 0; } } } }
       k++;
     }
   }

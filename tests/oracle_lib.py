@@ -26,7 +26,7 @@ class EncParams(C.Structure):
     """oracle_enc_params (oracle/hevc_enc.h)"""
     _fields_ = [(n, C.c_int) for n in ("width", "height", "bit_depth", "qp", "i_qp_offset", "gop", "lossless", "log2_ctb", "ctb_rows_per_slice", "md5_sei")] + \
                [("stress_seed", C.c_uint32)] + [(n, C.c_int) for n in ("conf_win_right", "conf_win_bottom", "hm_like", "p_qp_offset")] + \
-               [("hint_modes", C.c_void_p), ("hint_w4", C.c_int), ("hint_h4", C.c_int), ("occ4", C.c_void_p), ("occ4_w", C.c_int), ("occ4_h", C.c_int), ("ctc_gop", C.c_int), ("log2_max_poc_lsb", C.c_int), ("first_idx", C.c_int), ("tools_off", C.c_int)]
+               [("hint_modes", C.c_void_p), ("hint_w4", C.c_int), ("hint_h4", C.c_int), ("occ4", C.c_void_p), ("occ4_w", C.c_int), ("occ4_h", C.c_int), ("ctc_gop", C.c_int), ("log2_max_poc_lsb", C.c_int), ("first_idx", C.c_int), ("weighted_pred", C.c_int), ("tools_off", C.c_int)]
 
 
 class OPatch(C.Structure):
@@ -273,15 +273,17 @@ SLICE_FIELDS = ("nal_type", "address", "slice_type", "poc", "tmvp", "sao_luma", 
 def slice_headers(stream: bytes, fn=None):
     """every slice segment header as the oracle's parser reads it (fn: another library's accessor with the same signature, e.g. the product's host parser)"""
     cap = 4096
-    out = (C.c_int * (28 * cap))()
+    out = (C.c_int * (64 * cap))()
     f = fn or lib().oracle_slice_headers
     n = f(stream, C.c_size_t(len(stream)), out, cap)
     if n < 0:
         raise RuntimeError("slice header parse failed")
     res = []
     for k in range(n):
-        r = out[28 * k:28 * k + 28]
+        r = out[64 * k:64 * k + 64]
         d = dict(zip(SLICE_FIELDS, r[:19]))
         d["rps"] = [[r[20 + 2 * q], r[21 + 2 * q]] for q in range(min(r[19], 4))]   # the slice's short-term reference picture set: [delta POC, used by the current picture]
+        # pred_weight_table of a P slice under weighted_pred_flag: [luma denominator, chroma denominator, per RefPicList0 entry [luma flag, chroma flag, wY, oY, wCb, oCb, wCr, oCr]]
+        d["wp"] = [r[29], r[30]] + [list(r[32 + 8 * q:40 + 8 * q]) for q in range(min(d["num_ref_idx"], 4))] if r[28] else []
         res.append(d)
     return res

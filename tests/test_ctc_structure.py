@@ -95,3 +95,16 @@ def test_v3c_walk_over_ctc_gofs_equals_the_oracle(ctx, R, gs):
         c = R.Context(lib_path=rbt_lib.HOSTEMU_LIB, rank=r, world=2)
         parts.append(c.transcode_v3c(data, 24, 32)); c.close()
     assert gs.merge_v3c(R, parts, lib=ctx.L) == want
+
+
+@pytest.mark.parametrize("seed", CC.WP_SEEDS)
+def test_decode_streams_with_weighted_prediction(ctx, seed):
+    """what libx265 writes from its preset "veryfast" up (the value the reference's scripts pass): P slices with explicit weighted sample prediction. Round 3 refused the
+    PPS flag; now the table is parsed on the host (pinned through the reference's parser: tests/test_slice_headers.py wp_*) and applied in the motion compensation
+    (rc_mc_plane); == the oracle's decoder == the generating encoder's reconstruction, hash SEI of every picture green"""
+    CC.check_decode_wp(ctx, seed)
+
+
+def test_transcode_of_a_weighted_prediction_stream(ctx, R):
+    bs, rec, w, h, bd, n = CC.wp_case(12)      # 128 x 48, 10 bit: the coded size is the decoded size (multiples of 16)
+    assert ctx.transcode_substream(bs, R.RBT_VIDEO_GEOMETRY, 30, log2_ctb=5, rows_per_slice=-1) == O.transcode_substream(bs, 1, 30, 4, 5, -1)

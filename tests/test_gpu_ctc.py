@@ -100,3 +100,15 @@ def test_ctc_fixture_in_a_container(ctx, R, gs):
     data = V.sample_stream(units, 4)
     got = ctx.transcode_v3c(data, 24, 32)
     assert got == O.v3c_transcode(data, 24, 32, 4) and len(got) < len(data) // 2
+
+
+@pytest.mark.parametrize("seed", CC.WP_SEEDS)
+def test_decode_streams_with_weighted_prediction(ctx, seed):
+    """explicit weighted sample prediction of P slices (libx265's output from preset "veryfast" up as an input: PPS weighted_pred_flag, pred_weight_table) on the GPU:
+    the weights applied to the 14-bit intermediate of rc_mc_plane, integer and fractional vectors, luma and both chroma planes == oracle"""
+    CC.check_decode_wp(ctx, seed)
+
+
+def test_transcode_of_a_weighted_prediction_stream(ctx, R):
+    bs, rec, w, h, bd, n = CC.wp_case(12)
+    assert ctx.transcode_substream(bs, R.RBT_VIDEO_GEOMETRY, 30, log2_ctb=5, rows_per_slice=-1) == O.transcode_substream(bs, 1, 30, 4, 5, -1)

@@ -49,6 +49,7 @@ def test_slice_headers_match_reference_parser(product_parser, name):
             if r["deblocking_disabled"] and f in ("beta_offset_div2", "tc_offset_div2"): continue   # not coded (and not used) when the slice switches the filter off
             assert r[f] == o[f] == p[f], (name, k, f, r[f], o[f], p[f])
         if "rps" in r: assert r["rps"] == o["rps"] == p["rps"], (name, k, r["rps"], o["rps"], p["rps"])
+        if "wp" in r: assert r["wp"] == o["wp"] == p["wp"], (name, k, r["wp"], o["wp"], p["wp"])
 
 
 def test_ctc_goldens_hold_the_structure_of_the_ctc_encoder():
@@ -67,3 +68,24 @@ def test_ctc_goldens_hold_the_structure_of_the_ctc_encoder():
             if len(r["rps"]) == 2: seen.add("two entries")
             if r["rps"] == [[-2, 1]]: seen.add("the GOP table's {-2}")
     assert seen == {"intra TRAIL_R with a set", "TRAIL_N P", "two entries", "the GOP table's {-2}"}, seen
+
+
+def test_wp_goldens_hold_weight_tables():
+    """the wp_* goldens, by the REFERENCE parser's reading (xParsePredWeightTable): P slices with tables whose flags, weights and offsets vary - luma and chroma flags both
+    set and unset, weights off 2^denominator, non-zero luma offsets, chroma offsets moved by the prediction of 7.4.7.3, one and two references"""
+    seen = set()
+    for name in CASES:
+        if not name.startswith("wp_"): continue
+        for r in json.load(open(os.path.join(GOLD, f"slices_{name}.json"))):
+            if r["slice_type"] != 1: assert r["wp"] == []; continue
+            ld, cd = r["wp"][0], r["wp"][1]
+            assert len(r["wp"]) == 2 + r["num_ref_idx"]
+            if r["num_ref_idx"] == 2: seen.add("two references")
+            for lf, cf, wy, oy, wcb, ocb, wcr, ocr in r["wp"][2:]:
+                seen.add("luma on" if lf else "luma off"); seen.add("chroma on" if cf else "chroma off")
+                if not lf: assert (wy, oy) == (1 << ld, 0)
+                if not cf: assert (wcb, ocb, wcr, ocr) == (1 << cd, 0, 1 << cd, 0)
+                if lf and wy != 1 << ld: seen.add("luma weight")
+                if lf and oy: seen.add("luma offset")
+                if cf and (ocb or ocr): seen.add("chroma offset")
+    assert seen == {"two references", "luma on", "luma off", "chroma on", "chroma off", "luma weight", "luma offset", "chroma offset"}, seen
