@@ -1364,7 +1364,9 @@ template <bool REGION> RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slic
   if (out.type[1] != 2) out.eo_class[1] = out.eo_class[2] = 0;
   if (RBT_LANE0) f->sao[ctb_addr] = out;
   // ... and applied on the spot (8.7.3): the CTB's samples go from the deblocked picture to the output picture with the parameters still in registers
-  for (int c = 0; c < 3; c++) {
+  // (round 4: the picture-resident form through rbt_sao_ctb_p - inner samples of the CTB without the per-sample slice and border look-ups; the LDS-region form as before)
+  if constexpr (!REGION) rbt_sao_ctb_p(f, slices, ctb_addr, &out);
+  else for (int c = 0; c < 3; c++) {
     const int sh = c ? 1 : 0, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, n = ctb >> sh, lgn = g->log2_ctb - sh, x0 = (cxi * ctb) >> sh, y0 = (cyi * ctb) >> sh;
     RBT_PAR_FOR(i, n * n) {
       const int x = x0 + (i & (n - 1)), y = y0 + (i >> lgn);

@@ -65,6 +65,8 @@ size_t parse_save_bytes();
 void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w_ctb, int max_h_ctb, int y_begin = 0, int y_end = 1 << 30);
 void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_units);
 void launch_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_luma_samples);
+// SAO with one workgroup per CTB (rbt_sao_ctb: the CTB's parameters read once, neighbourhood tests only on the CTB's border); max_ctbs: CTBs of the largest picture
+void launch_sao_ctb(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs);
 // deblocking + SAO in one launch through LDS tiles (pictures whose out planes are not their pix planes: those with SAO); max_w / max_h: the largest picture of the list
 void launch_loopfilter(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w, int max_h);
 

@@ -309,6 +309,12 @@ __global__ void __launch_bounds__(256) k_loopfilter(RbtFrame* frames, const RbtS
   if ((int)blockIdx.x >= tw * th) return;
   rbt_loopfilter_tile(f, slices, xcd_tile(blockIdx.x, tw * th), RBT_LDS_CAST(RbtLoopLds, &lds));
 }
+__global__ void __launch_bounds__(256) k_sao_ctb(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
+  RbtFrame* f = &frames[frame_list[blockIdx.y]];
+  const int n_ctb = f->cfg.w_ctb * f->cfg.h_ctb;
+  if ((int)blockIdx.x >= n_ctb) return;
+  rbt_sao_ctb(f, slices, xcd_tile(blockIdx.x, n_ctb));
+}
 __global__ void __launch_bounds__(256) k_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
   int c = blockIdx.z, pw = c ? f->cfg.cw : f->cfg.w, ph = c ? f->cfg.ch : f->cfg.h;
@@ -366,6 +372,10 @@ void launch_loopfilter(RbtFrame* frames, const RbtSlice* slices, const int32_t* 
 void launch_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_luma_samples) {
   if (n_frames <= 0) return;
   hipLaunchKernelGGL(k_sao, dim3((max_luma_samples + 255) / 256, n_frames, 3), dim3(256), 0, g_stream, frames, slices, frame_list);
+}
+void launch_sao_ctb(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_ctbs) {
+  if (n_frames <= 0 || max_ctbs <= 0) return;
+  hipLaunchKernelGGL(k_sao_ctb, dim3((unsigned)max_ctbs, n_frames), dim3(256), 0, g_stream, frames, slices, frame_list);
 }
 
 // ---------------------------------------------------------------------------------------------- encode kernels

@@ -278,8 +278,10 @@ int decode_launch_parse(DecodeBatch& b) {
 }
 void decode_launch_filters(DecodeBatch& b, size_t l) {
   const std::vector<int>& lf = b.level_frames[l];
-  int mu = 0, ml = 0;
-  for (int fi : lf) { const RbtStreamCfg& c = b.frames[fi].cfg; mu = std::max(mu, c.w4 * c.h4); ml = std::max(ml, c.w * c.h); }
+  int mu = 0, ml = 0, mc = 0;
+  for (int fi : lf) { const RbtStreamCfg& c = b.frames[fi].cfg; mu = std::max(mu, c.w4 * c.h4); ml = std::max(ml, c.w * c.h); mc = std::max(mc, c.w_ctb * c.h_ctb); }
+  // SAO: one workgroup per CTB (round 4: a third of the per-sample kernel's instructions); RBT_SAO_PER_SAMPLE=1 keeps the round-1 form
+  static const int sao_per_sample = [] { const char* e = getenv("RBT_SAO_PER_SAMPLE"); return e && atoi(e) != 0; }();
   // Deblocking in place, one launch per edge direction, then SAO from `pix` to `out`. RBT_FUSED_LF=1 (round 3) gives pictures with SAO ONE launch through LDS tiles instead
   // (rbt_loopfilter_tile: one read of the reconstruction, one write of the output; same samples): 1-2 % faster for a lone GOF, 3-6 % slower with 16+ GOFs in flight, where the
   // kernels queue for LDS (the reconstruction holds a CTB there) and the LDS-free filter launches fill the gaps - measured in tools/lf_probe.sh, so it is off by default.
@@ -293,7 +295,8 @@ void decode_launch_filters(DecodeBatch& b, size_t l) {
     if (sao && fused) rbtk::launch_loopfilter(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l] + k, (int)(e - k), mw_, mh_);
     else {
       rbtk::launch_deblock(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l] + k, (int)(e - k), mu);
-      if (sao) rbtk::launch_sao(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l] + k, (int)(e - k), ml);
+      if (sao && sao_per_sample) rbtk::launch_sao(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l] + k, (int)(e - k), ml);
+      else if (sao) rbtk::launch_sao_ctb(b.d_frames, b.d_slices, b.d_lists + b.fr_off[l] + k, (int)(e - k), mc);
     }
     k = e;
   }

@@ -142,6 +142,9 @@ void launch_loopfilter(RbtFrame* frames, const RbtSlice* slices, const int32_t* 
   for (int k = 0; k < n_frames; k++) { RbtFrame* f = &frames[frame_list[k]]; const int nt = ((f->cfg.w + RBT_LF_TILE - 1) / RBT_LF_TILE) * ((f->cfg.h + RBT_LF_TILE - 1) / RBT_LF_TILE);
     for (int t = 0; t < nt; t++) rbt_loopfilter_tile(f, slices, t, &lds); }
 }
+void launch_sao_ctb(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int) {
+  for (int k = 0; k < n_frames; k++) { RbtFrame* f = &frames[frame_list[k]]; for (int ctb = 0; ctb < f->cfg.w_ctb * f->cfg.h_ctb; ctb++) rbt_sao_ctb(f, slices, ctb); }
+}
 void launch_sao(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int) {
   for (int k = 0; k < n_frames; k++) {
     RbtFrame* f = &frames[frame_list[k]];
