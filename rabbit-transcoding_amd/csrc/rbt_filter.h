@@ -108,6 +108,14 @@ RBT_DEV void fl_chroma_segment(RbtFrame* f, const RbtSlice* slices, int c_idx, i
   const int st = f->cfg.cw;
   fl_chroma_core(f, slices, c_idx, xl, yl, dir, f->pix[c_idx] + (size_t)(yl >> 1) * st + (xl >> 1), dir == 0 ? 1 : st, dir == 0 ? st : 1);
 }
+// Edges lie on the 8x8 grid: only every second column (dir 0) / row (dir 1) of 4x4 units can carry one. rbt_deblock_edge_count / rbt_deblock_edge_unit enumerate exactly
+// those units, so that every lane of the deblocking launch has an edge segment to look at (round 4: the launch over all units left every second lane idle and paid for it in
+// whole-wave instructions).
+RBT_DEV int rbt_deblock_edge_count(const RbtStreamCfg* g, int dir) { return dir == 0 ? ((g->w4 + 1) >> 1) * g->h4 : g->w4 * ((g->h4 + 1) >> 1); }
+RBT_DEV int rbt_deblock_edge_unit(const RbtStreamCfg* g, int dir, int e) {
+  if (dir == 0) { const int hw = (g->w4 + 1) >> 1; return (e / hw) * g->w4 + 2 * (e % hw); }
+  return 2 * (e / g->w4) * g->w4 + e % g->w4;
+}
 // one 4x4 unit of one picture for edge direction `dir`
 RBT_DEV void rbt_deblock_unit(RbtFrame* f, const RbtSlice* slices, int unit, int dir) {
   const RbtStreamCfg* g = &f->cfg;

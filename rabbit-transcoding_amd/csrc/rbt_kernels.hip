@@ -295,11 +295,11 @@ __device__ __forceinline__ int xcd_tile(int b, int n) {
 }
 __global__ void __launch_bounds__(256) k_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int dir) {
   RbtFrame* f = &frames[frame_list[blockIdx.y]];
-  const int n_units = f->cfg.w4 * f->cfg.h4, n_blk = (n_units + 255) >> 8;
+  const int n_edge = rbt_deblock_edge_count(&f->cfg, dir), n_blk = (n_edge + 255) >> 8;      // the units that can carry an edge of this direction (every second column / row)
   if ((int)blockIdx.x >= n_blk) return;
-  int unit = xcd_tile(blockIdx.x, n_blk) * 256 + threadIdx.x;
-  if (unit >= n_units) return;
-  rbt_deblock_unit(f, slices, unit, dir);
+  const int e = xcd_tile(blockIdx.x, n_blk) * 256 + threadIdx.x;
+  if (e >= n_edge) return;
+  rbt_deblock_unit(f, slices, rbt_deblock_edge_unit(&f->cfg, dir, e), dir);
 }
 // deblocking (both edge directions) + SAO of one 64x64 tile through LDS (rbt_filter.h rbt_loopfilter_tile): pictures with SAO, whose output is a plane of its own
 __global__ void __launch_bounds__(256) k_loopfilter(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list) {
@@ -363,7 +363,7 @@ void launch_recon_queue(const RbtFrameRef* refs, int n_frames, uint32_t total_ct
 void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_units) {
   if (n_frames <= 0) return;
   for (int dir = 0; dir < 2; dir++)
-    hipLaunchKernelGGL(k_deblock, dim3((max_units + 255) / 256, n_frames), dim3(256), 0, g_stream, frames, slices, frame_list, dir);
+    hipLaunchKernelGGL(k_deblock, dim3((max_units / 2 + 1024 + 255) / 256, n_frames), dim3(256), 0, g_stream, frames, slices, frame_list, dir);   // edge units: at most units / 2 + max(w4, h4) / 2, pictures are at most 2048 units wide / high
 }
 void launch_loopfilter(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int max_w, int max_h) {
   if (n_frames <= 0) return;

@@ -472,10 +472,16 @@ RBT_DEV int pz_residual(RbtParse* s, int c_idx, int x0, int y0, int log2, int sc
   const RBT_LDS_AS uint8_t* sb_scan = s->L->scan[scan_idx][log2 - 2];
   const int n_sb = 1 << (2 * (log2 - 2));
   RBT_VEC(int, v_sbscan); RBT_VEC(int, v_pos);
-  RBT_VFOR(p, 64) { RBT_V(v_sbscan, p) = p < n_sb ? (int)sb_scan[p] : 0xFFFF; RBT_V(v_pos, p) = PZ_POS(p & 15); }
   int last_sb, last_pos;
-  { uint64_t mb; const int key = (lx >> 2) | ((ly >> 2) << 4), ikey = (lx & 3) | ((ly & 3) << 2);
+  if (log2 == 2) {     // (round 4) a 4x4 block - most blocks of an intra stream - is its only sub-block: no scan table to fetch from LDS, no search for the last sub-block
+    RBT_VFOR(p, 64) { RBT_V(v_sbscan, p) = p == 0 ? 0 : 0xFFFF; RBT_V(v_pos, p) = PZ_POS(p & 15); }
+    last_sb = 0;
+  } else {
+    RBT_VFOR(p, 64) { RBT_V(v_sbscan, p) = p < n_sb ? (int)sb_scan[p] : 0xFFFF; RBT_V(v_pos, p) = PZ_POS(p & 15); }
+    uint64_t mb; const int key = (lx >> 2) | ((ly >> 2) << 4);
     RBT_VBALLOT(mb, p, 64, RBT_V(v_sbscan, p) == key); last_sb = mb ? __builtin_ctzll(mb) : 0;
+  }
+  { uint64_t mb; const int ikey = (lx & 3) | ((ly & 3) << 2);
     RBT_VBALLOT(mb, p, 16, RBT_V(v_pos, p) == ikey); last_pos = mb ? __builtin_ctzll(mb) : 0; }
   PZ_STAMP(s, 3);
   uint64_t csbf = 0;   // bit (ys*8+xs)

@@ -135,7 +135,7 @@ void launch_recon(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame
 }
 void launch_deblock(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int) {
   for (int dir = 0; dir < 2; dir++)
-    for (int k = 0; k < n_frames; k++) { RbtFrame* f = &frames[frame_list[k]]; for (int u = 0; u < f->cfg.w4 * f->cfg.h4; u++) rbt_deblock_unit(f, slices, u, dir); }
+    for (int k = 0; k < n_frames; k++) { RbtFrame* f = &frames[frame_list[k]]; for (int e = 0; e < rbt_deblock_edge_count(&f->cfg, dir); e++) rbt_deblock_unit(f, slices, rbt_deblock_edge_unit(&f->cfg, dir, e), dir); }
 }
 void launch_loopfilter(RbtFrame* frames, const RbtSlice* slices, const int32_t* frame_list, int n_frames, int, int) {
   static RbtLoopLds lds;
