@@ -99,14 +99,21 @@ def stitch(gathered: List[List[bytes]], n_gofs: int, streams_per_gof: int) -> Li
 
 
 def _walk(ctx, jobs, depth):
-    """Runs (streams, params) jobs through rbt_submit_gof / rbt_wait_gof with `depth` of them in flight, in order."""
+    """Runs (streams, params) jobs through rbt_submit_gof / rbt_wait_gof with `depth` of them in flight, in order - fewer when the device memory does not hold that many:
+    like rbt_transcode_v3c, a job is submitted only while free + cached - reserve holds another one of the size the largest so far took (rbt_job_memory / rbt_device_memory)."""
     depth = max(1, min(depth, 16, len(jobs) or 1))
     ctx.set_depth(depth)
-    q, outs = [], []
+    q, outs, job_bytes = [], [], 0
+
+    def room():
+        if not job_bytes: return True
+        m = ctx.device_memory()
+        return m["free"] + m["cached"] - m["reserve"] >= job_bytes + job_bytes // 8
     for streams, params in jobs:
-        if len(q) == depth:
+        while q and (len(q) == depth or not room()):
             outs.append(ctx.wait_gof(q.pop(0)))
         q.append(ctx.submit_gof(streams, params))
+        job_bytes = max(job_bytes, ctx.job_memory(q[-1]))
     while q:
         outs.append(ctx.wait_gof(q.pop(0)))
     return outs

@@ -108,3 +108,14 @@ def test_error_text_and_context_state_survive_a_failed_walk(ctx, R, walk):
         assert ctx.get_depth() == depth
         ctx.set_depth(3); ctx.trim()
     assert ctx.transcode_v3c(walk[0], 24, 32) == O.v3c_transcode(walk[0], 24, 32, 4)
+
+
+def test_python_sequence_walk_is_bounded_by_memory_too(ctx, R, sizes):
+    """gof_shard.transcode_sequence (bench.py's sequence_walk, the multi-rank Python host): its job loop waits for results before it submits what the device cannot hold"""
+    gs = rbt_lib.module_file("gof_shard")
+    seq = [V.gof_streams(128, 128, 2, 60 + g) for g in range(5)]
+    P = gs.rate_params(R, 3)
+    want = [[O.transcode_substream(s[0], 0, 8, rows_per_slice=-1, md5_sei=0), O.transcode_substream(s[1], 1, 24, rows_per_slice=-1, md5_sei=0), O.transcode_substream(s[2], 19, 32, rows_per_slice=-1, md5_sei=0)] for s in seq]
+    os.environ["RBT_HOSTEMU_HBM_MB"] = str(int(1.4 * sizes[0]) + 1)                    # one job at a time fits
+    assert gs.transcode_sequence(ctx, seq, P, depth=4, gofs_per_job=1) == want
+    assert ctx.device_memory()["in_use"] == 0
