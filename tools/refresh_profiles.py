@@ -68,6 +68,17 @@ try:
         sq["parser_per_bit"] = {"slice_data_bits_per_gof": bits, "instructions_per_bit": round((e["SQ_INSTS_VALU"] + e["SQ_INSTS_SALU"]) / bits, 2),
                                 "note": "VALU + SALU instructions of all 160 parser waves of the GOF per bit of input (about 1.17 bins per bit)"}
     json.dump(sq, open(f"profiles/{tag}_pmc_sq.json", "w"), indent=1)
+    # the bench lines of this round carry roofline.instruction_issue computed from whatever counter file was committed when they ran: put this round's counts in
+    salu = sum(v["SQ_INSTS_SALU"] for v in sq["kernels"].values()); valu = sum(v["SQ_INSTS_VALU"] for v in sq["kernels"].values())
+    for name in (f"profiles/{tag}_bench_line.json", f"profiles/{tag}_bench_line_driver.json"):
+        if not os.path.exists(name): continue
+        d = json.loads(open(name).read().strip().splitlines()[-1])
+        ii = d.get("roofline", {}).get("instruction_issue")
+        if ii:
+            gofs_per_s = d["steps"] / (d["ms_per_step"] * d["steps"] / 1000.0); peak = 256 * 2.4e9
+            ii.update({"salu_G_per_gof": round(salu / 1e9, 2), "valu_G_per_gof": round(valu / 1e9, 2), "scalar_issue_frac": round(salu * gofs_per_s / peak, 3), "vector_issue_frac": round(valu * gofs_per_s / peak, 3),
+                       "counters": f"{tag}_pmc_sq.json (same round; recomputed by tools/refresh_profiles.py)"})
+            open(name, "w").write(json.dumps(d) + "\n")
 except FileNotFoundError:
     print("no prof_sq pass: profiles/%s_pmc_sq.json not written" % tag)
 
