@@ -43,21 +43,8 @@ struct RbtEntropyLds {         // entropy coder (k_entropy): every slice of a 64
 #define RBT_ENTROPY_LDS_BYTES(tl2) (sizeof(RbtEntropyLds) - sizeof(int16_t) * (64 * 64 * 3 / 2 - (3 << (2 * (tl2) - 1))))
 RBT_DEV RBT_LDS_AS int16_t* en_lv(RBT_LDS_AS RbtEntropyLds* l, int c, int log2_ctb) { const int nn = 1 << (2 * log2_ctb); return l->lv + (c == 0 ? 0 : c == 1 ? nn : nn + (nn >> 2)); }
 
-// sum of v over the lanes of the wave (host emulation: the PAR_FOR already accumulated everything)
-RBT_DEV int en_wave_sum(int v, RBT_LDS_AS RbtEncLds* l) {
-#ifdef RBT_HOSTEMU
-  (void)l; return v;
-#else
-  (void)l;
-  // DPP butterflies inside each row of 16 lanes (quad swaps, half-row mirror, row mirror), then the four row sums
-  int x = v;
-  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);    // quad_perm:[1,0,3,2]
-  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);    // quad_perm:[2,3,0,1]
-  x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false);   // row_half_mirror
-  x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false);   // row_mirror
-  return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
-#endif
-}
+// sum of v over the lanes of the wave (rbt_recon.h rbt_wave_sum; the second argument is a leftover of the LDS form)
+RBT_DEV int en_wave_sum(int v, RBT_LDS_AS RbtEncLds* l) { (void)l; return rbt_wave_sum(v); }
 // SATD building block (oracle/hevc_enc.c satd_block): absolute 8x8 Hadamard coefficients of one 8x8 tile of residuals, lane p = sample (p & 7, p >> 3).
 // Six butterfly stages over the lane index bits without touching LDS: the mirror inside 8 lanes (pairs i and 7 - i instead of i and i + 4: applied to the
 // samples, a pairing that is linear in the index bits only permutes the coefficients, and only the SUM of magnitudes is used; it has to come first), quad
@@ -117,7 +104,7 @@ RBT_DEV int en_avail(const EnCtbNb* q, int xc, int yc, int xn, int yn) {
   if (dy < 0) return dx < 0 ? q->above_left : (dx < q->ctb ? q->above : q->above_right);
   if (dx < 0) return q->left;
   if (dx >= q->ctb) return 0;
-  return rc_morton(dx >> 2, dy >> 2) < rc_morton((xc - q->cx) >> 2, (yc - q->cy) >> 2);
+  return rc_z_before(dx >> 2, dy >> 2, (xc - q->cx) >> 2, (yc - q->cy) >> 2);
 }
 // The analysis kernel is throughput work (one wave per CTB, 400 CTBs per picture): what it keeps in LDS decides how many
 // waves share a SIMD and hide each other's LDS latency. 10 KB instead of the 30 KB of RbtEncLds: 14 workgroups per CU.
@@ -125,10 +112,11 @@ struct RbtAnalyseLds {
   int32_t nb[132], nbf[132], ref[100];   // reference samples of the current block (plain / smoothed), angular reference array
   uint16_t src[65 * 66];                 // source samples of a 32x32 quadrant and what its blocks reference around it: (yy + 1) * 66 + xx + 1
   int32_t cost[3][16]; uint8_t mode[3][16], split[3][16];
+  uint8_t hint[64];                      // transcoder: the input stream's luma intra mode of the quadrant's 4x4 units (uy * 8 + ux; 255 = not intra / outside)
 };
-RBT_DEV int en_nb_av(const EnCtbNb* q, int i, int x0, int y0, int S) { int xn, yn; rc_nb_xy(i, x0, y0, S, &xn, &yn); return en_avail(q, x0, y0, xn, yn); }
+RBT_DEV int en_nb_unit_av(const EnCtbNb* q, int p, int x0, int y0, int S) { int xn, yn; rc_nb_unit_xy(p, x0, y0, S, 0, &xn, &yn); return en_avail(q, x0, y0, xn, yn); }   // unit p of the block at (x0,y0) of the picture (rc_nb_unit_xy)
 RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtAnalyseLds* l) {
-  const RbtStreamCfg gcopy = f->cfg; const RbtStreamCfg* g = &gcopy;
+  const RbtStreamCfg gcopy = rc_cfg_uni(&f->cfg); const RbtStreamCfg* g = &gcopy;
   int ctb = 1 << g->log2_ctb, rx = ctb_addr % g->w_ctb, ry = ctb_addr / g->w_ctb, cx = rx << g->log2_ctb, cy = ry << g->log2_ctb;
   const int my_slice = f->ctb_slice[ctb_addr];
   const RbtSlice* sl = &slices[my_slice];
@@ -147,6 +135,7 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
     if (nq > 1 && (qx >= g->w || qy >= g->h)) continue;
     // source samples of the quadrant and of everything its blocks can reference (one row / column before it, 2 * 32 beyond)
     // rows yy = -1..63, columns 0..63 as 8-byte groups of four samples (qx is a multiple of 32, the width a multiple of 8), several loads in flight
+    if (!(RBT_ABLATE & 0x100))
 #pragma unroll 4
     RBT_PAR_FOR(i, 65 * 16) {
       const int x4 = i & 15, yy = (i >> 4) - 1, x = qx + 4 * x4, y = qy + yy;
@@ -156,6 +145,11 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
       d[0] = (uint16_t)v.x; d[1] = (uint16_t)(v.x >> 16); d[2] = (uint16_t)v.y; d[3] = (uint16_t)(v.y >> 16);
     }
     RBT_PAR_FOR(i, 65) { const int x = qx - 1, y = qy + i - 1; l->src[i * 66] = (x >= 0 && y >= 0 && y < g->h) ? srcp[(size_t)y * g->w + x] : 0; }
+    if (hints && !(RBT_ABLATE & 0x400)) RBT_PAR_FOR(u, 64) {                // once per quadrant instead of two dependent loads per quarter of every block
+      const int hx = (qx >> 2) + (u & 7), hy = (qy >> 2) + (u >> 3); int v = 255;
+      if (hx < hint_w4 && hy < hint_h4) { const size_t hk = (size_t)hy * hint_w4 + hx; if ((f->hint_pm[hk] & RBT_PM_MODE_MASK) == RBT_MODE_INTRA) v = f->hint_dm[hk] & 63; }
+      l->hint[u] = (uint8_t)v;
+    }
     RBT_SYNC_LDS();
     for (int si = 2; si >= 0; si--) {                      // largest blocks first: the 8x8 blocks take their candidates from the 16x16 block around them
       int S = 8 << si; if (S > qs) continue;
@@ -169,18 +163,17 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
         else {
           // reference samples once per block: availability masks, substitution (8.4.4.2.2) while gathering, and the smoothed copy
           const int tot = 4 * S + 1, bx0 = x0 - qx, by0 = y0 - qy;
-          uint64_t m0, m1 = 0; int m2 = 0;
-          { RBT_VBALLOT(m0, p, rbt_min(tot, 64), en_nb_av(&nbq, p, x0, y0, S)); }
-          if (tot > 64) { RBT_VBALLOT(m1, p, rbt_min(tot - 64, 64), en_nb_av(&nbq, 64 + p, x0, y0, S)); }
-          if (tot > 128) m2 = en_nb_av(&nbq, 128, x0, y0, S);
-          const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : (m2 ? 128 : -1));
+          if (!(RBT_ABLATE & 0x200)) {
+          uint64_t m; RBT_VBALLOT(m, p, rc_nb_units(S, 0), en_nb_unit_av(&nbq, p, x0, y0, S));
+          RcNbMap nm; rc_nb_map(&nm, m, S, 0);
           RBT_PAR_FOR(i, tot) {
             int v = 1 << (g->bit_depth - 1);
-            if (first >= 0) { int j = rc_last_avail(i, m0, m1, m2); if (j < 0) j = first; int xn, yn; rc_nb_xy(j, bx0, by0, S, &xn, &yn); v = l->src[(yn + 1) * 66 + xn + 1]; }
+            if (m) { const int j = rc_nb_source(&nm, i); v = j < 2 * S ? l->src[(by0 + 2 * S - j) * 66 + bx0] : l->src[by0 * 66 + bx0 + j - 2 * S]; }
             rl->nb[i] = v;
           }
           RBT_SYNC_LDS();
           rc_intra_filter_apply(g, lg, rl->nb, rl->nbf);
+          }
           // 16x16 / 32x32: 11 coarse candidates, then the angular modes within two of the best coarse one; 8x8 inside a complete 16x16 block: planar, DC,
           // vertical, horizontal and the angular modes within two of the 16x16 block's mode (2, 18, 34 when that is not angular) (oracle/hevc_enc.c analyse_ctb_intra)
           int parent = -1;
@@ -191,10 +184,8 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
           if (hints) {
             int any = 0;
             hc = 1ull << 6; nh = 2;
-            for (int q = 0; q < 4; q++) {
-              const int hx = (x0 + (q & 1) * (S >> 1)) >> 2, hy = (y0 + (q >> 1) * (S >> 1)) >> 2;
-              int v = 255;
-              if (hx < hint_w4 && hy < hint_h4) { const size_t hk = (size_t)hy * hint_w4 + hx; if ((RBT_UNI(f->hint_pm[hk]) & RBT_PM_MODE_MASK) == RBT_MODE_INTRA) v = RBT_UNI(f->hint_dm[hk]) & 63; }
+            if (!(RBT_ABLATE & 0x400)) for (int q = 0; q < 4; q++) {
+              const int v = RBT_UNI(l->hint[((by0 + (q >> 1) * (S >> 1)) >> 2) * 8 + ((bx0 + (q & 1) * (S >> 1)) >> 2)]);
               if (v < 35) {
                 any = 1;
                 int dup = 0; for (int t = 0; t < nh; t++) dup |= (int)((hc >> (6 * t)) & 63) == v;
@@ -216,14 +207,14 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
             } else if (k < 11) mode = k_intra_cand[k];
             else { if (k == 11) coarse = bmode; if (coarse < 2) break; mode = coarse + (k == 11 ? -2 : k == 12 ? -1 : k == 13 ? 1 : 2); if (mode < 2 || mode > 34) continue; }
             RBT_LDS_AS int32_t* fin = rc_intra_filter_needed(0, lg, mode) ? rl->nbf : rl->nb;
-            RcIntraCtx qc; rc_intra_setup(g, 0, lg, mode, fin, rl->ref, &qc);
-            int part = 0;
-            RBT_PAR_FOR(i, S * S) { int x = i & (S - 1), y = i >> lg; part += rbt_abs((int)l->src[(by0 + y + 1) * 66 + bx0 + x + 1] - rc_intra_sample(&qc, fin, rl->ref, x, y)); }
+            RcIntraCtx qc; if (!(RBT_ABLATE & 0x800)) rc_intra_setup(g, 0, lg, mode, fin, rl->ref, &qc); else { qc.N = S; qc.log2 = lg; qc.mode = mode; qc.c_idx = 0; qc.maxv = 1023; qc.ang = 1; qc.ver = mode >= 18; qc.dc = 1; qc.edge = 0; }
+            int part = (RBT_ABLATE & 0x1000) ? 1 + k : 0;
+            if (!(RBT_ABLATE & 0x1000)) RBT_PAR_FOR(i, S * S) { int x = i & (S - 1), y = i >> lg; part += rbt_abs((int)l->src[(by0 + y + 1) * 66 + bx0 + x + 1] - rc_intra_sample(&qc, fin, rl->ref, x, y)); }
             int sad = en_wave_sum(part, (RBT_LDS_AS RbtEncLds*)0);
             if (sad < best) { best = sad; bmode = mode; }
             RBT_SYNC_LDS();                                     // rl->ref is rebuilt by the next mode
           }
-          if (satd_on && best > 0) {
+          if (satd_on && best > 0 && !(RBT_ABLATE & 0x2000)) {
             // the mode by SAD, the block's cost (what the split decisions compare) by the SATD of that mode (oracle/hevc_enc.c analyse_ctb_intra, satd_block)
             RBT_LDS_AS int32_t* fin = rc_intra_filter_needed(0, lg, bmode) ? rl->nbf : rl->nb;
             RcIntraCtx qc; rc_intra_setup(g, 0, lg, bmode, fin, rl->ref, &qc);
@@ -451,14 +442,12 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
   // reference samples: availability masks, substitution while gathering, smoothing, mode set-up
   const int tot = 4 * N + 1;
   if (!reuse_nb) {          // reuse_nb: r->nb still holds this block's references (en_refine_mode gathered them for the same position and size, nothing has gathered since)
-    uint64_t m0, m1 = 0; int m2 = 0;
-    RBT_VBALLOT(m0, p, rbt_min(tot, 64), rc_nb_av(t->uav, p, x0, y0, N, sh, n4));
-    if (tot > 64) { RBT_VBALLOT(m1, p, rbt_min(tot - 64, 64), rc_nb_av(t->uav, 64 + p, x0, y0, N, sh, n4)); }
-    if (tot > 128) m2 = rc_nb_av(t->uav, 128, x0, y0, N, sh, n4);
-    const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : (m2 ? 128 : -1));
+    uint64_t m; RBT_VBALLOT(m, p, rc_nb_units(N, sh), rc_nb_unit_av(t->uav, p, x0, y0, N, sh, n4));
+    RcNbMap nm; rc_nb_map(&nm, m, N, sh);
+    const RBT_LDS_AS uint16_t* trow = y0 ? tile + (y0 - 1) * S : top;        // the row above the TB, from its corner on: trow[x0 + k]
     RBT_PAR_FOR(i, tot) {
       int v = 1 << (bd - 1);
-      if (first >= 0) { int j = rc_last_avail(i, m0, m1, m2); if (j < 0) j = first; int xn, yn; rc_nb_xy(j, x0, y0, N, &xn, &yn); v = yn < 0 ? top[xn + 1] : tile[yn * S + xn + 1]; }
+      if (m) { const int j = rc_nb_source(&nm, i); v = j < 2 * N ? tile[(y0 + 2 * N - 1 - j) * S + x0] : trow[x0 + j - 2 * N]; }
       r->nb[i] = v;
     }
     RBT_SYNC_LDS();
@@ -587,14 +576,12 @@ template <int TL2> RBT_DEV int en_refine_mode(const RbtStreamCfg* g, RBT_LDS_AS 
     for (int i = 0; i < 6; i++) { int dup = 0; for (int k = 0; k < nc; k++) dup |= (int)((cand >> (6 * k)) & 63) == pre[i]; if (!dup) { cand |= (uint64_t)pre[i] << (6 * nc); nc++; } } }
   // reference samples from the reconstruction (as en_tile_intra_tb gathers them) and their smoothed copy, once for all candidates
   const int tot = 4 * N + 1;
-  uint64_t b0, b1 = 0; int b2 = 0;
-  RBT_VBALLOT(b0, p, rbt_min(tot, 64), rc_nb_av(t->uav, p, x0, y0, N, 0, n4));
-  if (tot > 64) { RBT_VBALLOT(b1, p, rbt_min(tot - 64, 64), rc_nb_av(t->uav, 64 + p, x0, y0, N, 0, n4)); }
-  if (tot > 128) b2 = rc_nb_av(t->uav, 128, x0, y0, N, 0, n4);
-  const int first = b0 ? __builtin_ctzll(b0) : (b1 ? 64 + __builtin_ctzll(b1) : (b2 ? 128 : -1));
+  uint64_t m; RBT_VBALLOT(m, p, rc_nb_units(N, 0), rc_nb_unit_av(t->uav, p, x0, y0, N, 0, n4));
+  RcNbMap nm; rc_nb_map(&nm, m, N, 0);
+  const RBT_LDS_AS uint16_t* trow = y0 ? t->y + (y0 - 1) * S : t->top_y;
   RBT_PAR_FOR(i, tot) {
     int v = 1 << (bd - 1);
-    if (first >= 0) { int j = rc_last_avail(i, b0, b1, b2); if (j < 0) j = first; int xn, yn; rc_nb_xy(j, x0, y0, N, &xn, &yn); v = yn < 0 ? t->top_y[xn + 1] : t->y[yn * S + xn + 1]; }
+    if (m) { const int j = rc_nb_source(&nm, i); v = j < 2 * N ? t->y[(y0 + 2 * N - 1 - j) * S + x0] : trow[x0 + j - 2 * N]; }
     r->nb[i] = v;
   }
   RBT_SYNC_LDS();
@@ -666,25 +653,23 @@ template <int TL2> RBT_DEV int en_tile_intra_tb_cpair(const RbtStreamCfg* g, Rbt
   RBT_LDS_AS int32_t* const r_ref = (RBT_LDS_AS int32_t*)r->tmp + 132; RBT_LDS_AS int32_t* const r_ref2 = r_ref + 100; RBT_LDS_AS int16_t* const lvl = (RBT_LDS_AS int16_t*)t->sb;
   const int N = 1 << log2, NN = N * N, bd = g->bit_depth, maxv = (1 << bd) - 1, n4 = (1 << g->log2_ctb) >> 2, pw = g->cw, S = RbtEncTileT<TL2>::TS_C;
   const int tot = 4 * N + 1;
-  uint64_t m0, m1 = 0; const int m2 = 0;
-  RBT_VBALLOT(m0, p, rbt_min(tot, 64), rc_nb_av(t->uav, p, x0, y0, N, 1, n4));
-  if (tot > 64) { RBT_VBALLOT(m1, p, tot - 64, rc_nb_av(t->uav, 64 + p, x0, y0, N, 1, n4)); }
-  const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : -1);
+  uint64_t m; RBT_VBALLOT(m, p, rc_nb_units(N, 1), rc_nb_unit_av(t->uav, p, x0, y0, N, 1, n4));
+  RcNbMap nm; rc_nb_map(&nm, m, N, 1);
   RBT_PAR_FOR(i, 2 * tot) {
     const int b = i >= tot, idx = i - b * tot;
     int v = 1 << (bd - 1);
-    if (first >= 0) { int j = rc_last_avail(idx, m0, m1, m2); if (j < 0) j = first; int xn, yn; rc_nb_xy(j, x0, y0, N, &xn, &yn); v = yn < 0 ? t->top_c[b][xn + 1] : t->c[b][yn * S + xn + 1]; }
+    if (m) {
+      const int j = rc_nb_source(&nm, idx);
+      const RBT_LDS_AS uint16_t* tile = t->c[b]; const RBT_LDS_AS uint16_t* trow = y0 ? tile + (y0 - 1) * S : t->top_c[b];
+      v = j < 2 * N ? tile[(y0 + 2 * N - 1 - j) * S + x0] : trow[x0 + j - 2 * N];
+    }
     r->nb[b * 66 + idx] = v;
   }
   RBT_SYNC_LDS();
   RcIntraCtx q0, q1;
   q0.N = N; q0.log2 = log2; q0.mode = mode; q0.c_idx = 1; q0.maxv = maxv; q0.ang = 0; q0.ver = mode >= 18; q0.dc = 0; q0.edge = 0; q1 = q0; q1.c_idx = 2;
   if (mode == 1) {
-    int s0 = N, s1 = N;
-    for (int bit = 0; bit < bd; bit++) {
-      uint64_t m; RBT_VBALLOT(m, p, 4 * N, (r->nb[(p >= 2 * N ? 66 : 0) + ((p & (2 * N - 1)) < N ? 2 * N + 1 + (p & (2 * N - 1)) : 2 * N - 1 - ((p & (2 * N - 1)) - N))] >> bit) & 1);
-      s0 += __builtin_popcountll(m & ((1ull << (2 * N)) - 1)) << bit; s1 += __builtin_popcountll(m >> (2 * N)) << bit;
-    }
+    int s0, s1; rc_dc_pair(r->nb, N, bd, &s0, &s1);
     q0.dc = s0 >> (log2 + 1); q1.dc = s1 >> (log2 + 1);
   } else if (mode >= 2) {
     const int ang = rc_intra_angle(mode), ver = mode >= 18, last = (N * ang) >> 5, inv = (mode >= 11 && mode <= 25) ? rc_intra_inv_angle(mode) : 0;
@@ -771,7 +756,7 @@ template <int TL2> RBT_DEV int en_tile_intra_tb_cpair(const RbtStreamCfg* g, Rbt
 // carry_left: the CTB to the left was coded by this wave just before (its reconstruction is still in the tile): take the
 // left border from LDS instead of reading back stores that may still be in flight
 template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int carry_left) {
-  const RbtStreamCfg gcopy = f->cfg; const RbtStreamCfg* g = &gcopy;
+  const RbtStreamCfg gcopy = rc_cfg_uni(&f->cfg); const RbtStreamCfg* g = &gcopy;
   RBT_LDS_AS RbtEncTileT<TL2>* t = &L->t;
   const int ctb = 1 << g->log2_ctb, n4 = ctb >> 2, n8 = ctb >> 3, rx = ctb_addr % g->w_ctb, ry = ctb_addr / g->w_ctb, cx = rx << g->log2_ctb, cy = ry << g->log2_ctb;
   const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
@@ -814,9 +799,9 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
     for (int b = 0; b < 3; b++) { ux |= ((z >> (2 * b)) & 1) << b; uy |= ((z >> (2 * b + 1)) & 1) << b; }
     const int x0 = ux * 8, y0 = uy * 8;                              // relative to the CTB
     if (cx + x0 >= g->w || cy + y0 >= g->h) continue;
-    const int lg = t->cu_l2[uy * 8 + ux], N = 1 << lg, Nc = N >> 1;
+    const int lg = RBT_UNI(t->cu_l2[uy * 8 + ux]), N = 1 << lg, Nc = N >> 1;   // wave-uniform by construction; said so, or sizes, positions and every trip count below live in vector registers
     if ((x0 & (N - 1)) || (y0 & (N - 1))) continue;
-    int mode = t->cu_md[uy * 8 + ux];
+    int mode = RBT_UNI(t->cu_md[uy * 8 + ux]);
     // source samples of the CU's three TBs: one HBM round trip
     { const uint16_t* sp = f->src[0] + (size_t)(cy + y0) * g->w + cx + x0; RBT_PAR_FOR(i, N * N) t->sb[i] = sp[(size_t)(i >> lg) * g->w + (i & (N - 1))]; }
     for (int q = 0; q < 2; q++) { const uint16_t* sp = f->src[1 + q] + (size_t)((cy + y0) >> 1) * g->cw + ((cx + x0) >> 1); RBT_PAR_FOR(i, Nc * Nc) t->sb[1024 + 256 * q + i] = sp[(size_t)(i >> (lg - 1)) * g->cw + (i & (Nc - 1))]; }
@@ -1260,7 +1245,7 @@ RBT_DEV int en_sao_round_div(int sum, int cnt) { return cnt ? (sum >= 0 ? sum + 
 // default) the picture was deblocked in place by k_deblock and the samples are read where they lie (neighbours of a sample come from L2): a third less instructions than
 // staging the region, and no LDS beyond the statistics
 template <bool REGION> RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtSaoLds* L, RBT_LDS_AS uint16_t* ry, RBT_LDS_AS uint16_t* rc0, RBT_LDS_AS uint16_t* rc1) {
-  const RbtStreamCfg gcopy = f->cfg; const RbtStreamCfg* g = &gcopy;
+  const RbtStreamCfg gcopy = rc_cfg_uni(&f->cfg); const RbtStreamCfg* g = &gcopy;
   const int ctb = 1 << g->log2_ctb, cxi = ctb_addr % g->w_ctb, cyi = ctb_addr / g->w_ctb, bd = g->bit_depth;
   const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
   const long long lam16 = k_lambda16[rbt_clip3(0, 75, sl->qp + 6 * (bd - 8))], lam = lam16 * lam16;

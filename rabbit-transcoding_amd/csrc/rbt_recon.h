@@ -33,6 +33,11 @@ RBT_DEV int rc_morton(int x4, int y4) {
   for (int b = 0; b < 4; b++) z |= (((x4 >> b) & 1) << (2 * b)) | (((y4 >> b) & 1) << (2 * b + 1));
   return z;
 }
+// rc_morton(ax, ay) < rc_morton(bx, by) without interleaving anything: the coordinate whose difference has the higher top bit decides (y on a tie: its bits are the upper ones)
+RBT_DEV int rc_z_before(int ax, int ay, int bx, int by) {
+  const int dx = ax ^ bx, dy = ay ^ by, x_decides = dy < dx && dy < (dx ^ dy);
+  return x_decides ? ax < bx : ay < by;
+}
 // z-scan availability (6.4.1) of luma sample (xn,yn) for the block whose first 4x4 unit is at (xc,yc)
 RBT_DEV int rc_avail(const RbtFrame* f, int xc, int yc, int xn, int yn) {
   const RbtStreamCfg* g = &f->cfg;
@@ -62,12 +67,53 @@ RBT_DEV int rc_intra_inv_angle(int mode) {       // modes 11..25
   return -(int)(((d < 4 ? lo : hi) >> (16 * (d & 3))) & 0xFFFF);
 }
 RBT_DEV int rc_level_scale(int r) { return (int)((0x484039332D28ull >> (8 * r)) & 255); }      // {40,45,51,57,64,72}[r]
-// index of the nearest available neighbour at or below i (-1: none), from the availability masks of indices 0..63, 64..127, 128
-RBT_DEV int rc_last_avail(int i, uint64_t m0, uint64_t m1, int m2) {
-  if (i >= 128) { if (m2) return 128; i = 127; }
-  if (i >= 64) { uint64_t t = m1 & (~0ull >> (127 - i)); if (t) return 127 - __builtin_clzll(t); i = 63; }
-  uint64_t t = m0 & (~0ull >> (63 - i));
-  return t ? 63 - __builtin_clzll(t) : -1;
+// sum of v over the lanes of the wave (host emulation: the PAR_FOR around the call already accumulated everything)
+RBT_DEV int rbt_wave_sum(int v) {
+#ifdef RBT_HOSTEMU
+  return v;
+#else
+  // DPP butterflies inside each row of 16 lanes (quad swaps, half-row mirror, row mirror), then the four row sums
+  int x = v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);    // quad_perm:[1,0,3,2]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);    // quad_perm:[2,3,0,1]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false);   // row_half_mirror
+  x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false);   // row_mirror
+  return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
+#endif
+}
+// ---- the 4N+1 reference samples of a TB: which one each is taken from (8.4.4.2.2) ----
+// Availability is a property of 4x4 luma units, so the neighbours come in UNITS of us = 4 >> sh samples (sh = 1 for chroma) that share one flag: nu = 2N / us units up the
+// left column (unit 0 at the bottom), the corner (unit nu), nu units along the row above (up to unit 2 nu <= 32). One ballot over the units gives the whole picture; the
+// substitution rule - a sample that is not available takes the nearest available one below it in index order, the ones before the first available one take that one -
+// is then one median per sample whenever the available units form ONE run (always, but for slices that begin inside a CTB row and constrained intra prediction), and a
+// find-last-set on the unit mask otherwise. (Rounds 1-3 tested every sample's unit and searched three 64-bit sample masks per lane: 0.6 G of the reconstruction's
+// 3.1 G instructions per GOF, tools/ablate_run.sh.)
+struct RcNbMap { uint64_t m; int two_n, usl, nu, lo, hi, run; };   // m: the units' availability; lo / hi: first / last available sample index; run: one run of units
+RBT_DEV int rc_nb_unit_of(const RcNbMap* q, int i) { return i < q->two_n ? i >> q->usl : (i == q->two_n ? q->nu : q->nu + 1 + ((i - q->two_n - 1) >> q->usl)); }
+RBT_DEV int rc_nb_unit_lo(const RcNbMap* q, int u) { return u < q->nu ? u << q->usl : (u == q->nu ? q->two_n : q->two_n + 1 + ((u - q->nu - 1) << q->usl)); }
+RBT_DEV int rc_nb_unit_hi(const RcNbMap* q, int u) { return u < q->nu ? (u << q->usl) + (1 << q->usl) - 1 : (u == q->nu ? q->two_n : q->two_n + ((u - q->nu) << q->usl)); }
+// position (relative to the TB's plane origin, like x0 / y0) of one sample of unit p
+RBT_DEV void rc_nb_unit_xy(int p, int x0, int y0, int N, int sh, int* xn, int* yn) {
+  const int usl = 2 - sh, nu = (2 * N) >> usl;
+  if (p < nu) { *xn = x0 - 1; *yn = y0 + 2 * N - 1 - (p << usl); }
+  else if (p == nu) { *xn = x0 - 1; *yn = y0 - 1; }
+  else { *xn = x0 + ((p - nu - 1) << usl); *yn = y0 - 1; }
+}
+RBT_DEV int rc_nb_units(int N, int sh) { return ((4 * N) >> (2 - sh)) + 1; }
+RBT_DEV void rc_nb_map(RcNbMap* q, uint64_t m, int N, int sh) {
+  q->m = m; q->two_n = 2 * N; q->usl = 2 - sh; q->nu = (2 * N) >> q->usl; q->lo = q->hi = -1; q->run = 0;
+  if (m) {
+    const int ua = __builtin_ctzll(m), ub = 63 - __builtin_clzll(m); const uint64_t t = m >> ua;
+    q->lo = rc_nb_unit_lo(q, ua); q->hi = rc_nb_unit_hi(q, ub); q->run = (t & (t + 1)) == 0;
+  }
+}
+// index of the sample that reference sample i is taken from (itself when available); the caller has checked q->m != 0
+RBT_DEV int rc_nb_source(const RcNbMap* q, int i) {
+  if (q->run) return rbt_clip3(q->lo, q->hi, i);
+  const int u = rc_nb_unit_of(q, i); const uint64_t t = q->m & ((2ull << u) - 1);
+  if (!t) return q->lo;
+  const int uj = 63 - __builtin_clzll(t);
+  return uj == u ? i : rc_nb_unit_hi(q, uj);
 }
 // Substitution (8.4.4.2.2) + smoothing (8.4.4.2.3) of the gathered neighbours; `have_nb` = 0 when the caller wants the
 // substituted samples fetched through `fetch(j)` semantics instead (tile variant fills l->nb itself). Returns the array that
@@ -97,7 +143,7 @@ RBT_DEV void rc_intra_filter_apply(const RbtStreamCfg* g, int log2, RBT_LDS_AS i
 }
 RBT_DEV RBT_LDS_AS int32_t* rc_intra_filter(const RbtStreamCfg* g, int c_idx, int log2, int mode, RBT_LDS_AS int32_t* nb, RBT_LDS_AS int32_t* alt) {
   if (!rc_intra_filter_needed(c_idx, log2, mode)) return nb;
-  rc_intra_filter_apply(g, log2, nb, alt);
+  if (!(RBT_ABLATE & 4)) rc_intra_filter_apply(g, log2, nb, alt);
   return alt;
 }
 // Prediction value of sample (x,y) of the TB from the final reference samples `nb` (planar / DC / angular incl. edge
@@ -109,16 +155,16 @@ RBT_DEV void rc_intra_setup(const RbtStreamCfg* g, int c_idx, int log2, int mode
 #define RC_LEFT(y) nb[2 * N - 1 - (y)]
 #define RC_TOP(x) nb[2 * N + 1 + (x)]
   if (mode == 1) {
-    // sum of the 2N neighbours (lanes 0..N-1 hold the top row, N..2N-1 the left column), one ballot per bit plane
-    int sum = N;
-    for (int b = 0; b < bd; b++) { uint64_t m; RBT_VBALLOT(m, p, 2 * N, ((p < N ? RC_TOP(p) : RC_LEFT(p - N)) >> b) & 1); sum += __builtin_popcountll(m) << b; }
-    q->dc = sum >> (log2 + 1); q->edge = c_idx == 0 && N < 32;
+    // sum of the 2N neighbours (lanes 0..N-1 hold the top row, N..2N-1 the left column)
+    int part = 0;
+    if (!(RBT_ABLATE & 8)) RBT_PAR_FOR(p, 2 * N) part += p < N ? RC_TOP(p) : RC_LEFT(p - N);
+    q->dc = (N + rbt_wave_sum(part)) >> (log2 + 1); q->edge = c_idx == 0 && N < 32;
   } else if (mode >= 2) {
     const int ang = rc_intra_angle(mode), ver = mode >= 18, last = (N * ang) >> 5;
     const int inv = (mode >= 11 && mode <= 25) ? rc_intra_inv_angle(mode) : 0;
     q->ang = ang; q->edge = c_idx == 0 && N < 32 && (mode == 26 || mode == 10);
     // ref[x], x = -N .. 2N  (stored at index x + 32)
-    RBT_PAR_FOR(i, 3 * N + 1) {
+    if (!(RBT_ABLATE & 8)) RBT_PAR_FOR(i, 3 * N + 1) {
       int x = i - N, v = 0;
       if (x >= 0 && x <= N) v = ver ? RC_TOP(x - 1) : RC_LEFT(x - 1);
       else if (x < 0) { if (ang < 0 && last < -1 && x >= last) { int k = -1 + ((x * inv + 128) >> 8); v = ver ? RC_LEFT(k) : RC_TOP(k); } }
@@ -314,14 +360,9 @@ enum { RC_ROLE_ALL = 0, RC_ROLE_LUMA = 1, RC_ROLE_CHROMA = 2 };
 struct RbtReconRole { RbtReconLdsCore rc; uint8_t uav[17 * RC_US]; };   // uav: 4x4 luma unit (ux,uy) usable as intra reference: (uy + 1) * RC_US + ux + 1
 struct RbtReconCtbLds { RbtCtbTile t; RbtReconRole role[2]; };
 
-// neighbour index i of a TB at (x0,y0): 0 .. 2N-1 left column bottom-up, 2N corner, 2N+1 .. 4N top row left to right
-RBT_DEV void rc_nb_xy(int i, int x0, int y0, int N, int* xn, int* yn) {
-  if (i < 2 * N) { *xn = x0 - 1; *yn = y0 + (2 * N - 1 - i); }
-  else if (i == 2 * N) { *xn = x0 - 1; *yn = y0 - 1; }
-  else { *xn = x0 + (i - 2 * N - 1); *yn = y0 - 1; }
-}
-RBT_DEV int rc_nb_av(const RBT_LDS_AS uint8_t* uav, int i, int x0, int y0, int N, int sh, int n4) {
-  int xn, yn; rc_nb_xy(i, x0, y0, N, &xn, &yn);
+// availability of unit p of the TB at (x0,y0) (plane samples relative to the CTB) from the CTB's unit flags
+RBT_DEV int rc_nb_unit_av(const RBT_LDS_AS uint8_t* uav, int p, int x0, int y0, int N, int sh, int n4) {
+  int xn, yn; rc_nb_unit_xy(p, x0, y0, N, sh, &xn, &yn);
   const int ux = (xn << sh) >> 2, uy = (yn << sh) >> 2;                  // -1 for the border column / row
   return uy < n4 && uav[(uy + 1) * RC_US + ux + 1];
 }
@@ -336,7 +377,7 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtCtbTile* t, RBT_LDS
   const RBT_LDS_AS uint16_t* top = c_idx == 0 ? t->top_y : t->top_c[c_idx - 1];
   const RBT_LDS_AS int16_t* coef = (const RBT_LDS_AS int16_t*)tile + 1;      // levels of the TB: where its samples will be (row stride S)
   // residual first: it does not depend on the prediction, and the prediction pass can then add it on the fly
-  if (cbf) {
+  if (cbf && !(RBT_ABLATE & 1)) {
     if (tq_bypass) {
       if (!intra) return;                                                    // inter + bypass: the levels are the residual already
       RBT_PAR_FOR(i, N * N) { int x = i & (N - 1), y = i >> log2; l->res[i] = coef[(y0 + y) * S + x0 + x]; }
@@ -351,22 +392,22 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtCtbTile* t, RBT_LDS
     // availability of the 4N+1 neighbours straight from the unit flags (no LDS round trip), then every lane fetches the
     // sample its index is substituted from (8.4.4.2.2) - gather and substitution in one pass
     const int tot = 4 * N + 1;
-    uint64_t m0 = 0, m1 = 0; int m2 = 0;
-    RBT_VBALLOT(m0, p, rbt_min(tot, 64), rc_nb_av(uav, p, x0, y0, N, sh, n4));
-    if (tot > 64) { RBT_VBALLOT(m1, p, rbt_min(tot - 64, 64), rc_nb_av(uav, 64 + p, x0, y0, N, sh, n4)); }
-    if (tot > 128) m2 = rc_nb_av(uav, 128, x0, y0, N, sh, n4);
-    const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : (m2 ? 128 : -1));
-    RBT_PAR_FOR(i, tot) {
-      int v = 1 << (bd - 1);
-      if (first >= 0) { int j = rc_last_avail(i, m0, m1, m2); if (j < 0) j = first; int xn, yn; rc_nb_xy(j, x0, y0, N, &xn, &yn); v = yn < 0 ? top[xn + 1] : tile[yn * S + xn + 1]; }
-      l->nb[i] = v;
+    if (!(RBT_ABLATE & 2)) {
+      uint64_t m; RBT_VBALLOT(m, p, rc_nb_units(N, sh), rc_nb_unit_av(uav, p, x0, y0, N, sh, n4));
+      RcNbMap nm; rc_nb_map(&nm, m, N, sh);
+      const RBT_LDS_AS uint16_t* trow = y0 ? tile + (y0 - 1) * S : top;      // the row above the TB, from its corner on: trow[x0 + k]
+      RBT_PAR_FOR(i, tot) {
+        int v = 1 << (bd - 1);
+        if (m) { const int j = rc_nb_source(&nm, i); v = j < 2 * N ? tile[(y0 + 2 * N - 1 - j) * S + x0] : trow[x0 + j - 2 * N]; }
+        l->nb[i] = v;
+      }
     }
     RBT_SYNC_LDS();
     fin = rc_intra_filter(g, c_idx, log2, mode, l->nb, l_nbf);
     rc_intra_setup(g, c_idx, log2, mode, fin, l_ref, &q);
   }
   if (intra) {
-    RBT_PAR_FOR(i, N * N) {
+    if (!(RBT_ABLATE & 16)) RBT_PAR_FOR(i, N * N) {
       int x = i & (N - 1), y = i >> log2, o = (y0 + y) * S + x0 + x + 1;
       int base = rc_intra_sample(&q, fin, l_ref, x, y);
       tile[o] = (uint16_t)(cbf ? rbt_clip3(0, maxv, base + l->res[i]) : base);
@@ -377,13 +418,21 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtCtbTile* t, RBT_LDS
   if (mark_l4 >= 0) { RBT_PAR_FOR(i, 1 << (2 * mark_l4)) uav[(muy + (i >> mark_l4) + 1) * RC_US + mux + (i & ((1 << mark_l4) - 1)) + 1] = (uint8_t)mark_flag; }
   RBT_SYNC_LDS();
 }
+// DC sums (incl. the rounding term N) of two planes whose references sit at nb[0..] and nb[66..]: lanes 0..2N-1 take plane 0 (top row, then left column), 2N..4N-1 plane 1;
+// one reduction for both - plane 1 in the high half of the word - while 2N samples fit 16 bits (N <= 16: up to 11-bit video), two otherwise
+RBT_DEV void rc_dc_pair(const RBT_LDS_AS int32_t* nb, int N, int bd, int* s0, int* s1) {
+  int p0 = 0, p1 = 0;
+  if (!(RBT_ABLATE & 8)) RBT_PAR_FOR(p, 4 * N) { const int b = p >= 2 * N, k = p - b * 2 * N, v = nb[b * 66 + (k < N ? 2 * N + 1 + k : 2 * N - 1 - (k - N))]; if (b) p1 += v; else p0 += v; }
+  if (bd <= 11) { const uint32_t both = (uint32_t)rbt_wave_sum((int)((uint32_t)p0 + ((uint32_t)p1 << 16))); *s0 = N + (int)(both & 0xFFFF); *s1 = N + (int)(both >> 16); }
+  else { *s0 = N + rbt_wave_sum(p0); *s1 = N + rbt_wave_sum(p1); }
+}
 // Cb and Cr TB of one TU in the same passes. The two blocks share position, size, prediction mode and availability and
 // differ only in data, so every phase (and every wait for LDS) is paid once for both; chroma is never smoothed (8.4.4.2.3).
 RBT_DEV void rc_tile_tb_cpair(const RbtStreamCfg* g, RBT_LDS_AS RbtCtbTile* t, RBT_LDS_AS RbtReconRole* R, int x0, int y0, int log2, int intra, int mode, int cbf_cb, int cbf_cr, int tq_bypass, int qp_cb, int qp_cr) {
   RBT_LDS_AS RbtReconLdsCore* l = &R->rc; RBT_LDS_AS uint8_t* uav = R->uav;
   RBT_LDS_AS int32_t* const l_ref = (RBT_LDS_AS int32_t*)l->tmp + 132; RBT_LDS_AS int32_t* const l_ref2 = l_ref + 100;   // alias tmp (dead after the transform)
   const int N = 1 << log2, NN = N * N, bd = g->bit_depth, maxv = (1 << bd) - 1, n4 = (1 << g->log2_ctb) >> 2, S = RC_TS_C;
-  if (cbf_cb | cbf_cr) {
+  if ((cbf_cb | cbf_cr) && !(RBT_ABLATE & 1)) {
     if (tq_bypass) {
       if (!intra) return;                                                    // inter + bypass: the levels are the residual already
       RBT_PAR_FOR(i, 2 * NN) { const int b = i >= NN, j = i - b * NN, x = j & (N - 1), y = j >> log2; if (b ? cbf_cr : cbf_cb) l->res[b * 256 + j] = ((const RBT_LDS_AS int16_t*)t->c[b])[(y0 + y) * S + x0 + x + 1]; }
@@ -408,30 +457,30 @@ RBT_DEV void rc_tile_tb_cpair(const RbtStreamCfg* g, RBT_LDS_AS RbtCtbTile* t, R
   RcIntraCtx q0, q1;
   if (intra) {
     const int tot = 4 * N + 1;                                           // <= 65: plane b keeps its references at nb[b * 66 ..]
-    uint64_t m0 = 0, m1 = 0; int m2 = 0;
-    RBT_VBALLOT(m0, p, rbt_min(tot, 64), rc_nb_av(uav, p, x0, y0, N, 1, n4));
-    if (tot > 64) { RBT_VBALLOT(m1, p, tot - 64, rc_nb_av(uav, 64 + p, x0, y0, N, 1, n4)); }
-    const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : -1);
-    RBT_PAR_FOR(i, 2 * tot) {
-      const int b = i >= tot, idx = i - b * tot;
-      int v = 1 << (bd - 1);
-      if (first >= 0) { int j = rc_last_avail(idx, m0, m1, m2); if (j < 0) j = first; int xn, yn; rc_nb_xy(j, x0, y0, N, &xn, &yn); v = yn < 0 ? t->top_c[b][xn + 1] : t->c[b][yn * S + xn + 1]; }
-      l->nb[b * 66 + idx] = v;
+    if (!(RBT_ABLATE & 2)) {
+      uint64_t m; RBT_VBALLOT(m, p, rc_nb_units(N, 1), rc_nb_unit_av(uav, p, x0, y0, N, 1, n4));
+      RcNbMap nm; rc_nb_map(&nm, m, N, 1);
+      RBT_PAR_FOR(i, 2 * tot) {
+        const int b = i >= tot, idx = i - b * tot;
+        int v = 1 << (bd - 1);
+        if (m) {
+          const int j = rc_nb_source(&nm, idx);
+          const RBT_LDS_AS uint16_t* tile = t->c[b]; const RBT_LDS_AS uint16_t* trow = y0 ? tile + (y0 - 1) * S : t->top_c[b];
+          v = j < 2 * N ? tile[(y0 + 2 * N - 1 - j) * S + x0] : trow[x0 + j - 2 * N];
+        }
+        l->nb[b * 66 + idx] = v;
+      }
     }
     RBT_SYNC_LDS();
     // mode set-up of both planes (rc_intra_setup, two at a time)
     q0.N = N; q0.log2 = log2; q0.mode = mode; q0.c_idx = 1; q0.maxv = maxv; q0.ang = 0; q0.ver = mode >= 18; q0.dc = 0; q0.edge = 0; q1 = q0; q1.c_idx = 2;
     if (mode == 1) {
-      int s0 = N, s1 = N;                                                // lanes 0..2N-1: plane 0 (top row then left column), 2N..4N-1: plane 1
-      for (int bit = 0; bit < bd; bit++) {
-        uint64_t m; RBT_VBALLOT(m, p, 4 * N, (l->nb[(p >= 2 * N ? 66 : 0) + ((p & (2 * N - 1)) < N ? 2 * N + 1 + (p & (2 * N - 1)) : 2 * N - 1 - ((p & (2 * N - 1)) - N))] >> bit) & 1);
-        s0 += __builtin_popcountll(m & ((1ull << (2 * N)) - 1)) << bit; s1 += __builtin_popcountll(m >> (2 * N)) << bit;
-      }
+      int s0, s1; rc_dc_pair(l->nb, N, bd, &s0, &s1);
       q0.dc = s0 >> (log2 + 1); q1.dc = s1 >> (log2 + 1);
     } else if (mode >= 2) {
       const int ang = rc_intra_angle(mode), ver = mode >= 18, last = (N * ang) >> 5, inv = (mode >= 11 && mode <= 25) ? rc_intra_inv_angle(mode) : 0;
       q0.ang = q1.ang = ang;
-      RBT_PAR_FOR(i, 2 * (3 * N + 1)) {
+      if (!(RBT_ABLATE & 8)) RBT_PAR_FOR(i, 2 * (3 * N + 1)) {
         const int b = i >= 3 * N + 1, x = i - b * (3 * N + 1) - N; int v = 0;
         const RBT_LDS_AS int32_t* nb = l->nb + b * 66;
 #define RC_LEFT(y) nb[2 * N - 1 - (y)]
@@ -446,7 +495,7 @@ RBT_DEV void rc_tile_tb_cpair(const RbtStreamCfg* g, RBT_LDS_AS RbtCtbTile* t, R
       RBT_SYNC_LDS();
     }
   }
-  if (intra || cbf_cb || cbf_cr) {
+  if ((intra || cbf_cb || cbf_cr) && !(RBT_ABLATE & 16)) {
     RBT_PAR_FOR(i, 2 * NN) {
       const int b = i >= NN, j = i - b * NN, x = j & (N - 1), y = j >> log2, o = (y0 + y) * S + x0 + x + 1, cbf = b ? cbf_cr : cbf_cb;
       RBT_LDS_AS uint16_t* tile = t->c[b];
@@ -475,21 +524,42 @@ RBT_DEV int rc_unit_avail(const RbtFrame* f, int ac, int gxu, int gyu) {
   if (g->cip && (f->pm[gyu * g->w4 + gxu] & RBT_PM_MODE_MASK) != RBT_MODE_INTRA) return 0;
   return 1;
 }
+// The picture's stream parameters as wave-uniform words (same reason as rc_cmd_uni below: what a vector load delivered would keep every size, shift and bound derived
+// from it in vector registers)
+RBT_DEV RbtStreamCfg rc_cfg_uni(const RbtStreamCfg* p) {
+  static_assert(sizeof(RbtStreamCfg) % 4 == 0, "whole words");
+  int32_t w[sizeof(RbtStreamCfg) / 4]; __builtin_memcpy(w, p, sizeof w);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(RbtStreamCfg) / 4); i++) w[i] = RBT_UNI(w[i]);
+  RbtStreamCfg c; __builtin_memcpy(&c, w, sizeof c);
+  return c;
+}
+// A command as wave-uniform words: every lane of the wave reads the same one, but what arrives through a vector load sits in vector registers and everything derived
+// from it - block size, position, flags, the loops' trip counts, every branch - would be computed per lane and branched on as if lanes could disagree.
+// (Applied where the command is USED: the load of the next command stays in flight while the current one is processed.)
+struct alignas(16) RbtCmdRaw { int32_t w[4]; };
+RBT_DEV RbtCmdRaw rc_cmd_load(const RbtCmd* p) { return *(const RbtCmdRaw*)p; }
+RBT_DEV RbtCmd rc_cmd_uni(const RbtCmdRaw& raw) {
+  union { RbtCmdRaw r; RbtCmd c; } u;
+  u.r.w[0] = RBT_UNI(raw.w[0]); u.r.w[1] = RBT_UNI(raw.w[1]); u.r.w[2] = RBT_UNI(raw.w[2]); u.r.w[3] = RBT_UNI(raw.w[3]);
+  return u.c;
+}
 // ROLE: RC_ROLE_LUMA / RC_ROLE_CHROMA = the calling wave's half of the CTB (see RbtReconRole); RC_ROLE_ALL = everything on one wave.
 template <int ROLE>
 RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_idx, int ctb_addr, RBT_LDS_AS RbtCtbTile* t, RBT_LDS_AS RbtReconRole* R) {
   constexpr bool DO_Y = ROLE != RC_ROLE_CHROMA, DO_C = ROLE != RC_ROLE_LUMA;
+  frame_idx = RBT_UNI(frame_idx); ctb_addr = RBT_UNI(ctb_addr);
   RbtFrame* f = &frames[frame_idx];
-  const RbtStreamCfg gcopy = f->cfg;                                     // private copy: not reloaded after every store
+  const RbtStreamCfg gcopy = rc_cfg_uni(&f->cfg);                        // private copy: not reloaded after every store, and in scalar registers
   const RbtStreamCfg* g = &gcopy;
   const int ctb = 1 << g->log2_ctb, n4 = ctb >> 2, cx = (ctb_addr % g->w_ctb) << g->log2_ctb, cy = (ctb_addr / g->w_ctb) << g->log2_ctb;
-  uint32_t n = f->cmd_count[ctb_addr];
+  uint32_t n = (uint32_t)RBT_UNI(f->cmd_count[ctb_addr]);
   if ((int)n > f->cmd_cap) n = (uint32_t)f->cmd_cap;
   const RbtCmd* cmds = f->cmds + (size_t)ctb_addr * f->cmd_cap;
   const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
   rc_stage_tables(&R->rc);
   // ---- fetch: borders, unit availability, coefficient levels (one HBM round trip for everything) ----
-  for (int c = DO_Y ? 0 : 1; c < (DO_C ? 3 : 1); c++) {
+  if (!(RBT_ABLATE & 32)) for (int c = DO_Y ? 0 : 1; c < (DO_C ? 3 : 1); c++) {
     const int sh = c ? 1 : 0, nn = ctb >> sh, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, ox = cx >> sh, oy = cy >> sh, S = c ? RC_TS_C : RC_TS_Y;
     const uint16_t* p = f->pix[c]; RBT_LDS_AS uint16_t* tile = c == 0 ? t->y : t->c[c - 1]; RBT_LDS_AS uint16_t* top = c == 0 ? t->top_y : t->top_c[c - 1];
     RBT_PAR_FOR(i, 2 * nn + 1) { int x = ox + i - 1, y = oy - 1; top[i] = (x >= 0 && y >= 0 && x < pw) ? p[(size_t)y * pw + x] : 0; }
@@ -515,10 +585,10 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
   // ---- inter TBs first (P slices): levels -> residual in place ----
   const int has_inter = sl->slice_type != RBT_SLICE_I;
   if (has_inter) {
-    RbtCmd nx0; if (n) nx0 = cmds[0];
+    RbtCmdRaw nx0; if (n) nx0 = rc_cmd_load(&cmds[0]);
     for (uint32_t k = 0; k < n; k++) {
-      const RbtCmd c = nx0;
-      if (k + 1 < n) nx0 = cmds[k + 1];
+      const RbtCmd c = rc_cmd_uni(nx0);
+      if (k + 1 < n) nx0 = rc_cmd_load(&cmds[k + 1]);
       if (c.type != RBT_CMD_TU || (c.a & RBT_TU_INTRA)) continue;
       const int x0 = c.x4 * 4, y0 = c.y4 * 4, fl = c.a, log2 = c.log2;
       if (DO_Y && (fl & RBT_TU_CBF_Y)) rc_tile_tb(g, t, R, 0, x0, y0, log2, 0, c.b, 1, (fl & RBT_TU_TS_Y) != 0, c.d, c.qp[0], -1, 0, 0, 0);
@@ -533,10 +603,10 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
     RBT_SYNC_LDS();
   }
   // ---- the CTB's commands, in decoding order: prediction units complete pred + residual, intra TBs predict and add ----
-  RbtCmd nxt; if (n) nxt = cmds[0];
+  RbtCmdRaw nxt; if (n) nxt = rc_cmd_load(&cmds[0]);
   for (uint32_t k = 0; k < n; k++) {
-    const RbtCmd c = nxt;
-    if (k + 1 < n) nxt = cmds[k + 1];                                     // fetched while command k is processed
+    const RbtCmd c = rc_cmd_uni(nxt);
+    if (k + 1 < n) nxt = rc_cmd_load(&cmds[k + 1]);                       // fetched while command k is processed
     const int x0 = c.x4 * 4, y0 = c.y4 * 4;                               // relative to the CTB
     if (c.type == RBT_CMD_PU) {
       const RbtFrame* ref = &frames[sl->ref_frame[c.c]];
@@ -566,7 +636,7 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
     const int sh = c ? 1 : 0, nn = ctb >> sh, pw = c ? g->cw : g->w, ph = c ? g->ch : g->h, ox = cx >> sh, oy = cy >> sh, S = c ? RC_TS_C : RC_TS_Y;
     uint16_t* p = f->pix[c]; RBT_LDS_AS uint16_t* tile = c == 0 ? t->y : t->c[c - 1];
     const int lnn = g->log2_ctb - sh;
-    RBT_PAR_FOR(i, nn * nn) { int x = i & (nn - 1), y = i >> lnn; if (ox + x < pw && oy + y < ph) p[(size_t)(oy + y) * pw + ox + x] = tile[y * S + x + 1]; }
+    RBT_PAR_FOR(i, nn * nn) { int x = i & (nn - 1), y = i >> lnn; if (ox + x < pw && oy + y < ph) p[(size_t)(oy + y) * pw + ox + x] = RBT_ABLATE ? (uint16_t)(tile[y * S + x + 1] & ((1 << g->bit_depth) - 1)) : tile[y * S + x + 1]; }
   }
 }
 

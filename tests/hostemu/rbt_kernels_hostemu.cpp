@@ -87,6 +87,22 @@ void launch_recon_refs(const RbtFrameRef* refs, int n_frames, int max_w_ctb, int
       }
     }
 }
+// RBT_HOSTEMU_CMD_STATS=1: what the decoder's command lists hold (tools/cmd_stats.py): per transform unit size x prediction kind x coded planes, printed at exit
+static long long g_cmd_stats[2][6][3][8]; static bool g_cmd_stats_on = false;
+static void cmd_stats_print() {
+  for (int in = 0; in < 2; in++) for (int l = 2; l < 6; l++) for (int m = 0; m < 3; m++) for (int c = 0; c < 8; c++)
+    if (g_cmd_stats[in][l][m][c]) fprintf(stderr, "cmd_stats intra=%d log2=%d mode=%s cbf_y=%d chroma=%d cbf_c=%d n=%lld\n", in, l, m == 0 ? "planar" : m == 1 ? "dc" : "angular", c & 1, (c >> 1) & 1, (c >> 2) & 1, g_cmd_stats[in][l][m][c]);
+}
+static void cmd_stats_ctb(const RbtFrame* f, int addr) {
+  static int init = 0;
+  if (!init) { init = 1; const char* e = getenv("RBT_HOSTEMU_CMD_STATS"); g_cmd_stats_on = e && *e == '1'; if (g_cmd_stats_on) atexit(cmd_stats_print); }
+  if (!g_cmd_stats_on) return;
+  const RbtCmd* c = f->cmds + (size_t)addr * f->cmd_cap; uint32_t n = f->cmd_count[addr];
+  for (uint32_t k = 0; k < n; k++) if (c[k].type == RBT_CMD_TU) {
+    const int fl = c[k].a, in = (fl & RBT_TU_INTRA) != 0, m = c[k].b == 0 ? 0 : c[k].b == 1 ? 1 : 2;
+    g_cmd_stats[in][c[k].log2][m][(fl & RBT_TU_CBF_Y ? 1 : 0) | (fl & RBT_TU_CHROMA ? 2 : 0) | (fl & (RBT_TU_CBF_CB | RBT_TU_CBF_CR) ? 4 : 0)]++;
+  }
+}
 void launch_recon_level(const RbtFrameRef* refs, int n_frames, int max_ctbs, uint32_t*) {
   static RbtReconCtbLds lds;
   for (int i = 0; i < max_ctbs; i++) for (int k = 0; k < n_frames; k++) {      // ticket order: CTB i of every picture, then CTB i + 1
@@ -94,6 +110,7 @@ void launch_recon_level(const RbtFrameRef* refs, int n_frames, int max_ctbs, uin
     if (i >= g->w_ctb * g->h_ctb) continue;
     int xy = (int)refs[k].order[i], addr = (xy >> 16) * g->w_ctb + (xy & 0xFFFF);
     if (frames[fi].ctb_slice[addr] == 0xFFFF) continue;
+    cmd_stats_ctb(&frames[fi], addr);
     rbt_recon_ctb<RC_ROLE_LUMA>(frames, refs[k].slices, fi, addr, &lds.t, &lds.role[0]);
     rbt_recon_ctb<RC_ROLE_CHROMA>(frames, refs[k].slices, fi, addr, &lds.t, &lds.role[1]);
   }
