@@ -209,7 +209,9 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
             RBT_LDS_AS int32_t* fin = rc_intra_filter_needed(0, lg, mode) ? rl->nbf : rl->nb;
             RcIntraCtx qc; if (!(RBT_ABLATE & 0x800)) rc_intra_setup(g, 0, lg, mode, fin, rl->ref, &qc); else { qc.N = S; qc.log2 = lg; qc.mode = mode; qc.c_idx = 0; qc.maxv = 1023; qc.ang = 1; qc.ver = mode >= 18; qc.dc = 1; qc.edge = 0; }
             int part = (RBT_ABLATE & 0x1000) ? 1 + k : 0;
-            if (!(RBT_ABLATE & 0x1000)) RBT_PAR_FOR(i, S * S) { int x = i & (S - 1), y = i >> lg; part += rbt_abs((int)l->src[(by0 + y + 1) * 66 + bx0 + x + 1] - rc_intra_sample(&qc, fin, rl->ref, x, y)); }
+#define EN_BODY(PV) RBT_PAR_FOR(i, S * S) { const int x = i & (S - 1), y = i >> lg; part += rbt_abs((int)l->src[(by0 + y + 1) * 66 + bx0 + x + 1] - (PV)); }
+            if (!(RBT_ABLATE & 0x1000)) RC_INTRA_KINDS(&qc, fin, rl->ref, EN_BODY);
+#undef EN_BODY
             int sad = en_wave_sum(part, (RBT_LDS_AS RbtEncLds*)0);
             if (sad < best) { best = sad; bmode = mode; }
             RBT_SYNC_LDS();                                     // rl->ref is rebuilt by the next mode
@@ -219,12 +221,13 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
             RBT_LDS_AS int32_t* fin = rc_intra_filter_needed(0, lg, bmode) ? rl->nbf : rl->nb;
             RcIntraCtx qc; rc_intra_setup(g, 0, lg, bmode, fin, rl->ref, &qc);
             int acc = 0; const int tw = S >> 3;
-            for (int tix = 0; tix < tw * tw; tix++) {
-              const int tx = (tix % tw) * 8, ty = (tix / tw) * 8;
-              RBT_VEC(int, v_r);
-              RBT_VFOR(p, 64) { const int x = tx + (p & 7), y = ty + (p >> 3); RBT_V(v_r, p) = (int)l->src[(by0 + y + 1) * 66 + bx0 + x + 1] - rc_intra_sample(&qc, fin, rl->ref, x, y); }
-              EN_HAD8X8_ACC(v_r, acc);
-            }
+#define EN_BODY(PV) for (int tix = 0; tix < tw * tw; tix++) { \
+              const int tx = (tix % tw) * 8, ty = (tix / tw) * 8; \
+              RBT_VEC(int, v_r); \
+              RBT_VFOR(p, 64) { const int x = tx + (p & 7), y = ty + (p >> 3); RBT_V(v_r, p) = (int)l->src[(by0 + y + 1) * 66 + bx0 + x + 1] - (PV); } \
+              EN_HAD8X8_ACC(v_r, acc); }
+            RC_INTRA_KINDS(&qc, fin, rl->ref, EN_BODY);
+#undef EN_BODY
             best = (en_wave_sum(acc, (RBT_LDS_AS RbtEncLds*)0) + 4) >> 3;
             RBT_SYNC_LDS();
           }
@@ -455,7 +458,9 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
   RBT_LDS_AS int32_t* fin = rc_intra_filter(g, c_idx, log2, mode, r->nb, r_nbf);
   RcIntraCtx q; rc_intra_setup(g, c_idx, log2, mode, fin, r_ref, &q);
   // prediction and residual
-  RBT_PAR_FOR(i, N * N) { const int pv = rc_intra_sample(&q, fin, r_ref, i & (N - 1), i >> log2); r->pred[i] = (uint16_t)pv; r->res[i] = (int16_t)((int)src[i] - pv); }
+#define EN_BODY(PV) RBT_PAR_FOR(i, N * N) { const int x = i & (N - 1), y = i >> log2, pv = (PV); r->pred[i] = (uint16_t)pv; r->res[i] = (int16_t)((int)src[i] - pv); }
+  RC_INTRA_KINDS(&q, fin, r_ref, EN_BODY);
+#undef EN_BODY
   RBT_SYNC_LDS();
   // occupancy-aware coding (oracle/hevc_enc.c recon_tb): a block without an occupied sample carries no residual; in a partly occupied one the other samples ask for
   // the mean residual of the occupied ones; unoccupied samples stay out of every distortion sum below
@@ -592,12 +597,13 @@ template <int TL2> RBT_DEV int en_refine_mode(const RbtStreamCfg* g, RBT_LDS_AS 
     RBT_LDS_AS int32_t* fin = rc_intra_filter_needed(0, lg, mode) ? r_nbf : r->nb;
     RcIntraCtx q; rc_intra_setup(g, 0, lg, mode, fin, r_ref, &q);
     int acc = 0;
-    for (int tix = 0; tix < tw * tw; tix++) {
-      const int tx = (tix % tw) * 8, ty = (tix / tw) * 8;
-      RBT_VEC(int, v_r);
-      RBT_VFOR(p, 64) { const int x = tx + (p & 7), y = ty + (p >> 3); RBT_V(v_r, p) = (int)src[y * N + x] - rc_intra_sample(&q, fin, r_ref, x, y); }
-      EN_HAD8X8_ACC(v_r, acc);
-    }
+#define EN_BODY(PV) for (int tix = 0; tix < tw * tw; tix++) { \
+      const int tx = (tix % tw) * 8, ty = (tix / tw) * 8; \
+      RBT_VEC(int, v_r); \
+      RBT_VFOR(p, 64) { const int x = tx + (p & 7), y = ty + (p >> 3); RBT_V(v_r, p) = (int)src[y * N + x] - (PV); } \
+      EN_HAD8X8_ACC(v_r, acc); }
+    RC_INTRA_KINDS(&q, fin, r_ref, EN_BODY);
+#undef EN_BODY
     const int bits = mode == m0 ? 2 : (mode == m1 || mode == m2) ? 3 : 6;
     const int c = ((en_wave_sum(acc, (RBT_LDS_AS RbtEncLds*)0) + 4) >> 3) * 16 + lam16 * bits;
     if (c < best) { sec = best; sm = bm; sb = bb; best = c; bm = mode; bb = bits; }
@@ -688,12 +694,13 @@ template <int TL2> RBT_DEV int en_tile_intra_tb_cpair(const RbtStreamCfg* g, Rbt
     }
     RBT_SYNC_LDS();
   }
-  // prediction and residual of both planes
-  RBT_PAR_FOR(i, 2 * NN) {
-    const int b = i >= NN, j = i - b * NN;
-    const int pv = rc_intra_sample(b ? &q1 : &q0, r->nb + b * 66, b ? r_ref2 : r_ref, j & (N - 1), j >> log2);
-    r->pred[b * 256 + j] = (uint16_t)pv; r->res[b * 256 + j] = (int16_t)((int)src[b * 256 + j] - pv);
-  }
+  // prediction and residual of both planes (lane i: sample j of plane b; plane 1's references 66, its angular array 100 entries behind plane 0's)
+#define EN_BODY(PV) RBT_PAR_FOR(i, 2 * NN) { \
+    const int b = i >= NN, j = i - b * NN, x = j & (N - 1), y = j >> log2; \
+    const RcIntraCtx* qp = b ? &q1 : &q0; const RBT_LDS_AS int32_t* nbp = r->nb + b * 66; const RBT_LDS_AS int32_t* refp = r_ref + b * 100; \
+    const int pv = (PV); r->pred[b * 256 + j] = (uint16_t)pv; r->res[b * 256 + j] = (int16_t)((int)src[b * 256 + j] - pv); }
+  RC_INTRA_KINDS_PAIR(&q0, qp, nbp, refp, EN_BODY);
+#undef EN_BODY
   RBT_SYNC_LDS();
   // occupancy-aware coding (see en_tile_intra_tb): chroma sample (x,y) stands for the luma samples (2x..2x+1, 2y..2y+1), all in one 4x4 unit
   int occ_none = 0;

@@ -13,7 +13,7 @@
 // MEASUREMENT builds only (tools/ablate.sh, never the product): RBT_ABLATE is a mask of phases LEFT OUT of the CTB chains, so that a counter pass shows what each
 // one costs in instructions; what such a build computes is wrong by design. 0 in the product: every `if (RBT_ABLATE & bit)` folds away.
 // Reconstruction: 1 residual (scaling + inverse transform), 2 reference-sample gather, 4 reference smoothing, 8 mode set-up (DC sum / angular reference array),
-// 16 prediction + store, 32 the CTB's fetch into LDS. Analysis: 0x100 source fetch, 0x200 gather + smoothing per block, 0x400 the input's modes (hints),
+// 16 prediction + store, 32 the CTB's fetch into LDS, 64 prediction units (motion compensation), 128 the residual pass of inter blocks. Analysis: 0x100 source fetch, 0x200 gather + smoothing per block, 0x400 the input's modes (hints),
 // 0x800 candidate set-up, 0x1000 candidate SAD, 0x2000 SATD of the chosen mode.
 #ifndef RBT_ABLATE
 #define RBT_ABLATE 0

@@ -174,27 +174,45 @@ RBT_DEV void rc_intra_setup(const RbtStreamCfg* g, int c_idx, int log2, int mode
     RBT_SYNC_LDS();
   }
 }
-RBT_DEV int rc_intra_sample(const RcIntraCtx* q, const RBT_LDS_AS int32_t* nb, const RBT_LDS_AS int32_t* ref, int x, int y) {
-  const int N = q->N, mode = q->mode;
-  if (mode == 0) return ((N - 1 - x) * RC_LEFT(y) + (x + 1) * RC_TOP(N) + (N - 1 - y) * RC_TOP(x) + (y + 1) * RC_LEFT(N) + N) >> (q->log2 + 1);
-  if (mode == 1) {
-    int v = q->dc;
-    if (q->edge) {
-      if (x == 0 && y == 0) v = (RC_LEFT(0) + 2 * q->dc + RC_TOP(0) + 2) >> 2;
-      else if (y == 0) v = (RC_TOP(x) + 3 * q->dc + 2) >> 2;
-      else if (x == 0) v = (RC_LEFT(y) + 3 * q->dc + 2) >> 2;
-    }
-    return v;
-  }
-  const int a = q->ver ? y : x, b = q->ver ? x : y;
-  const int idx = ((a + 1) * q->ang) >> 5, fr = ((a + 1) * q->ang) & 31;
-  int v = fr ? ((32 - fr) * ref[32 + b + idx + 1] + fr * ref[32 + b + idx + 2] + 16) >> 5 : ref[32 + b + idx + 1];
-  if (q->edge) {
-    if (mode == 26 && x == 0) v = rbt_clip3(0, q->maxv, RC_TOP(0) + ((RC_LEFT(y) - RC_LEFT(-1)) >> 1));
-    if (mode == 10 && y == 0) v = rbt_clip3(0, q->maxv, RC_LEFT(0) + ((RC_TOP(x) - RC_TOP(-1)) >> 1));
-  }
+// The prediction of sample (x,y), one routine per KIND of mode so that a loop over the samples of a block holds nothing but its own kind's arithmetic (the one routine
+// that switched on the mode per sample cost every iteration ~30 scalar instructions of branching around ~20 of work: tools/ablate_run.sh, round 4). `nb`: the final
+// reference samples (smoothed or not), `ref`: the angular reference array of rc_intra_setup.
+RBT_DEV int rc_pred_planar(const RcIntraCtx* q, const RBT_LDS_AS int32_t* nb, int x, int y) {
+  const int N = q->N;
+  return ((N - 1 - x) * RC_LEFT(y) + (x + 1) * RC_TOP(N) + (N - 1 - y) * RC_TOP(x) + (y + 1) * RC_LEFT(N) + N) >> (q->log2 + 1);
+}
+RBT_DEV int rc_pred_dc_edge(const RcIntraCtx* q, const RBT_LDS_AS int32_t* nb, int x, int y) {      // DC of a luma block below 32x32: first row and column smoothed (8.4.4.2.5)
+  const int N = q->N; int v = q->dc;
+  if (x == 0 && y == 0) v = (RC_LEFT(0) + 2 * q->dc + RC_TOP(0) + 2) >> 2;
+  else if (y == 0) v = (RC_TOP(x) + 3 * q->dc + 2) >> 2;
+  else if (x == 0) v = (RC_LEFT(y) + 3 * q->dc + 2) >> 2;
   return v;
 }
+// angular (8.4.4.2.6): VER = mode >= 18. A zero fraction needs no case of its own: (32 * a + 0 * b + 16) >> 5 == a, and the second sample read then lies inside the array
+template <int VER> RBT_DEV int rc_pred_angular(const RcIntraCtx* q, const RBT_LDS_AS int32_t* ref, int x, int y) {
+  const int a = VER ? y : x, b = VER ? x : y, t = (a + 1) * q->ang, idx = t >> 5, fr = t & 31;
+  return ((32 - fr) * ref[32 + b + idx + 1] + fr * ref[32 + b + idx + 2] + 16) >> 5;
+}
+RBT_DEV int rc_pred_angular_edge(const RcIntraCtx* q, const RBT_LDS_AS int32_t* nb, const RBT_LDS_AS int32_t* ref, int x, int y) {   // pure vertical / horizontal of a luma block below 32x32 (angle 0): first column / row corrected
+  const int N = q->N; int v = ref[32 + (q->ver ? x : y) + 1];
+  if (q->mode == 26 && x == 0) v = rbt_clip3(0, q->maxv, RC_TOP(0) + ((RC_LEFT(y) - RC_LEFT(-1)) >> 1));
+  if (q->mode == 10 && y == 0) v = rbt_clip3(0, q->maxv, RC_LEFT(0) + ((RC_TOP(x) - RC_TOP(-1)) >> 1));
+  return v;
+}
+// RC_INTRA_KINDS(q, nb, ref, BODY): BODY(PV) once per kind, PV = the expression of the prediction of (x,y) - BODY declares x and y (and may declare nb / ref per lane,
+// two planes at a time: the names are only expanded inside it). q decides the kind and must be wave-uniform in mode / edge / ver.
+#define RC_INTRA_KINDS(q, nb, ref, BODY) do { \
+    if ((q)->mode == 0) { BODY(rc_pred_planar((q), (nb), x, y)) } \
+    else if ((q)->mode == 1) { if ((q)->edge) { BODY(rc_pred_dc_edge((q), (nb), x, y)) } else { BODY((q)->dc) } } \
+    else if ((q)->edge) { BODY(rc_pred_angular_edge((q), (nb), (ref), x, y)) } \
+    else if ((q)->ver) { BODY(rc_pred_angular<1>((q), (ref), x, y)) } \
+    else { BODY(rc_pred_angular<0>((q), (ref), x, y)) } } while (0)
+// two planes at a time (Cb / Cr): `qu` (wave-uniform) decides the kind, `ql` / nb / ref are the lane's own plane's, declared by BODY
+#define RC_INTRA_KINDS_PAIR(qu, ql, nb, ref, BODY) do { \
+    if ((qu)->mode == 0) { BODY(rc_pred_planar((ql), (nb), x, y)) } \
+    else if ((qu)->mode == 1) { BODY((ql)->dc) } \
+    else if ((qu)->ver) { BODY(rc_pred_angular<1>((ql), (ref), x, y)) } \
+    else { BODY(rc_pred_angular<0>((ql), (ref), x, y)) } } while (0)
 #undef RC_LEFT
 #undef RC_TOP
 // ---- scaling (8.6.3, flat lists) of the TB's levels from the coefficient plane into lds->res ----
@@ -407,11 +425,9 @@ RBT_DEV void rc_tile_tb(const RbtStreamCfg* g, RBT_LDS_AS RbtCtbTile* t, RBT_LDS
     rc_intra_setup(g, c_idx, log2, mode, fin, l_ref, &q);
   }
   if (intra) {
-    if (!(RBT_ABLATE & 16)) RBT_PAR_FOR(i, N * N) {
-      int x = i & (N - 1), y = i >> log2, o = (y0 + y) * S + x0 + x + 1;
-      int base = rc_intra_sample(&q, fin, l_ref, x, y);
-      tile[o] = (uint16_t)(cbf ? rbt_clip3(0, maxv, base + l->res[i]) : base);
-    }
+#define RC_BODY(PV) RBT_PAR_FOR(i, N * N) { const int x = i & (N - 1), y = i >> log2, o = (y0 + y) * S + x0 + x + 1, base = (PV); tile[o] = (uint16_t)(cbf ? rbt_clip3(0, maxv, base + l->res[i]) : base); }
+    if (!(RBT_ABLATE & 16)) RC_INTRA_KINDS(&q, fin, l_ref, RC_BODY);
+#undef RC_BODY
   } else if (cbf) {                                                          // inter: leave the residual where the levels were
     RBT_PAR_FOR(i, N * N) { int x = i & (N - 1), y = i >> log2; tile[(y0 + y) * S + x0 + x + 1] = (uint16_t)l->res[i]; }
   }
@@ -495,14 +511,18 @@ RBT_DEV void rc_tile_tb_cpair(const RbtStreamCfg* g, RBT_LDS_AS RbtCtbTile* t, R
       RBT_SYNC_LDS();
     }
   }
-  if ((intra || cbf_cb || cbf_cr) && !(RBT_ABLATE & 16)) {
+  if (intra && !(RBT_ABLATE & 16)) {
+    // lane i: sample j of plane b; plane 1 keeps its references 66 and its angular array 100 entries behind plane 0's; the kind is the same for both
+#define RC_BODY(PV) RBT_PAR_FOR(i, 2 * NN) { \
+      const int b = i >= NN, j = i - b * NN, x = j & (N - 1), y = j >> log2, o = (y0 + y) * S + x0 + x + 1, cbf = b ? cbf_cr : cbf_cb; \
+      const RcIntraCtx* qp = b ? &q1 : &q0; const RBT_LDS_AS int32_t* nbp = l->nb + b * 66; const RBT_LDS_AS int32_t* refp = l_ref + b * 100; \
+      const int base = (PV); t->c[b][o] = (uint16_t)(cbf ? rbt_clip3(0, maxv, base + l->res[b * 256 + j]) : base); }
+    RC_INTRA_KINDS_PAIR(&q0, qp, nbp, refp, RC_BODY);
+#undef RC_BODY
+  } else if (!intra && (cbf_cb || cbf_cr)) {
     RBT_PAR_FOR(i, 2 * NN) {
-      const int b = i >= NN, j = i - b * NN, x = j & (N - 1), y = j >> log2, o = (y0 + y) * S + x0 + x + 1, cbf = b ? cbf_cr : cbf_cb;
-      RBT_LDS_AS uint16_t* tile = t->c[b];
-      if (intra) {
-        const int base = rc_intra_sample(b ? &q1 : &q0, l->nb + b * 66, b ? l_ref2 : l_ref, x, y);
-        tile[o] = (uint16_t)(cbf ? rbt_clip3(0, maxv, base + l->res[b * 256 + j]) : base);
-      } else if (cbf) tile[o] = (uint16_t)l->res[b * 256 + j];           // inter: leave the residual where the levels were
+      const int b = i >= NN, j = i - b * NN, x = j & (N - 1), y = j >> log2, o = (y0 + y) * S + x0 + x + 1;
+      if (b ? cbf_cr : cbf_cb) t->c[b][o] = (uint16_t)l->res[b * 256 + j];   // inter: leave the residual where the levels were
     }
   }
   RBT_SYNC_LDS();
@@ -584,7 +604,7 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
   RBT_SYNC_LDS();                                                         // everything a wave reads below it fetched itself
   // ---- inter TBs first (P slices): levels -> residual in place ----
   const int has_inter = sl->slice_type != RBT_SLICE_I;
-  if (has_inter) {
+  if (has_inter && !(RBT_ABLATE & 128)) {
     RbtCmdRaw nx0; if (n) nx0 = rc_cmd_load(&cmds[0]);
     for (uint32_t k = 0; k < n; k++) {
       const RbtCmd c = rc_cmd_uni(nx0);
@@ -609,6 +629,7 @@ RBT_DEV void rbt_recon_ctb(RbtFrame* frames, const RbtSlice* slices, int frame_i
     if (k + 1 < n) nxt = rc_cmd_load(&cmds[k + 1]);                       // fetched while command k is processed
     const int x0 = c.x4 * 4, y0 = c.y4 * 4;                               // relative to the CTB
     if (c.type == RBT_CMD_PU) {
+      if (RBT_ABLATE & 64) continue;
       const RbtFrame* ref = &frames[sl->ref_frame[c.c]];
       const int w = c.a * 4, h = c.b * 4, mvx = c.mvx, mvy = c.mvy;
       const int wpn = sl->wp_on, ri = c.c;                                 // explicit weights of this reference index (slices of a PPS with weighted_pred_flag)
