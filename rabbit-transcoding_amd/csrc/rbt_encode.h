@@ -431,9 +431,33 @@ template <int TL2> struct RbtEncTileT {
 struct RbtEncIntraScratch : RbtReconLdsCore { uint16_t pred[32 * 32]; };
 template <int TL2> struct RbtEncTileLdsT { RbtEncIntraScratch rc; RbtEncTileT<TL2> t; };
 RBT_DEV int en_quant_scale(int r) { const uint64_t lo = 26214ull | (23302ull << 16) | (20560ull << 32) | (18396ull << 48), hi = 16384ull | (14564ull << 16); return (int)(((r < 4 ? lo : hi) >> (16 * (r & 3))) & 0xFFFF); }
+// What the intra chain asks of the picture over and over, read once per CTB into scalar registers. Through the RbtFrame pointer every use was a load from HBM with a wait
+// behind it - nothing lets the compiler keep a value across the stores in between - in the middle of a serial chain: six per transform block.
+struct EnCtbCtx : RbtStreamCfg { int lossless, enc_tools, f4, w8; int16_t* coef[3]; uint8_t *pm, *edges, *cu_flags, *cu_mode, *cu_ts; int8_t* qp; const uint16_t* src[3]; };
+RBT_DEV void en_ctb_ctx(EnCtbCtx* e, const RbtFrame* f) {
+  *(RbtStreamCfg*)e = rc_cfg_uni(&f->cfg);
+  e->lossless = RBT_UNI(f->lossless); e->enc_tools = RBT_UNI(f->enc_tools); e->f4 = RBT_UNI(f->occ4 != nullptr);
+  for (int c = 0; c < 3; c++) e->coef[c] = rbt_uni_ptr(f->coef[c]);
+  e->w8 = RBT_UNI(f->w8); e->pm = rbt_uni_ptr(f->pm); e->edges = rbt_uni_ptr(f->edges); e->cu_flags = rbt_uni_ptr(f->cu_flags); e->cu_mode = rbt_uni_ptr(f->cu_mode); e->qp = rbt_uni_ptr(f->qp);
+  e->cu_ts = rbt_uni_ptr(f->cu_ts); for (int c = 0; c < 3; c++) e->src[c] = rbt_uni_ptr(f->src[c]);
+}
+// en_fill_cu_maps for the intra chain: the maps' addresses from the CTB's context
+RBT_DEV void en_fill_cu_maps_ctx(const EnCtbCtx* e, int x0, int y0, int N, int pm_val, int qp_y, int flags) {
+  const int n4 = N >> 2, n8 = N >> 3;
+  RBT_PAR_FOR(i, n4 * n4) {
+    const int k = ((y0 >> 2) + i / n4) * e->w4 + (x0 >> 2) + i % n4;
+    e->pm[k] = (uint8_t)pm_val; e->qp[k] = (int8_t)qp_y;
+    int ev = 0;
+    if (i % n4 == 0) ev |= RBT_EV_TU | RBT_EV_PU;
+    if (i / n4 == 0) ev |= RBT_EH_TU | RBT_EH_PU;
+    e->edges[k] = (uint8_t)ev;
+  }
+  RBT_PAR_FOR(i, n8 * n8) { const int k = ((y0 >> 3) + i / n8) * e->w8 + (x0 >> 3) + i % n8; e->cu_flags[k] = (uint8_t)flags; }
+}
 // one intra TB: (x0,y0) relative to the CTB and (gx,gy) in the picture, both in samples of component c_idx; returns cbf
 template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int c_idx, int x0, int y0, int gx, int gy, int log2, int mode, int qp,
                              const RBT_LDS_AS uint16_t* src, int mark_l4, int mux, int muy, RBT_LDS_AS int16_t* lvl_buf = nullptr, long long* cost = nullptr, int lam2 = 0, int* ssd_out = nullptr, int* ts_out = nullptr, int reuse_nb = 0) {
+  const EnCtbCtx* e = static_cast<const EnCtbCtx*>(g);                 // every caller hands an EnCtbCtx in (en_intra_ctb)
   RBT_LDS_AS RbtEncIntraScratch* r = &L->rc; RBT_LDS_AS RbtEncTileT<TL2>* t = &L->t;
   // lvl_buf: where the levels go (default: over the luma part of `sb`, i.e. over the source once the residual is formed). cost (needs a lvl_buf that leaves
   // `src` alone): distortion * 256 + lam2 * rate of the block as the oracle's recon_tb / hm_decide_tu_split count them - squared error of the residual
@@ -464,7 +488,7 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
   RBT_SYNC_LDS();
   // occupancy-aware coding (oracle/hevc_enc.c recon_tb): a block without an occupied sample carries no residual; in a partly occupied one the other samples ask for
   // the mean residual of the occupied ones; unoccupied samples stay out of every distortion sum below
-  const int f4 = f->occ4 != nullptr; int occ_none = 0;
+  const int f4 = e->f4; int occ_none = 0;
 #define EN_TB_OCC(i) (t->occ_u[((((y0) + ((i) >> log2)) << sh) >> 2) * n4 + ((((x0) + ((i) & (N - 1))) << sh) >> 2)])
   if (f4) {
     int pc = 0, ps = 0;
@@ -482,14 +506,14 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
   if (ts_out) { *ts_out = 0; RBT_PAR_FOR(i, 16) lvl[32 + i] = r->res[i]; }
   int nz;
   if (occ_none) { RBT_PAR_FOR(i, N * N) lvl[i] = 0; nz = 0; }
-  else if (f->lossless) {
+  else if (e->lossless) {
     int part = 0;
     RBT_PAR_FOR(i, N * N) { lvl[i] = r->res[i]; part += r->res[i] != 0; }
     nz = en_wave_sum(part, (RBT_LDS_AS RbtEncLds*)0);
   } else {
     en_fwd_transform(log2, c_idx == 0 && log2 == 2, bd, r);
     const int qbits = 14 + qp / 6 + (15 - bd - log2), sc = en_quant_scale(qp % 6); int part = 0;
-    const int rq = f->enc_tools & RBT_ET_RQ;
+    const int rq = e->enc_tools & RBT_ET_RQ;
     RBT_PAR_FOR(i, N * N) {
       const int cv = r->res[i], a = rbt_abs(cv);
       const long long tq = (long long)a * sc; const int lf = (int)(tq >> qbits);
@@ -502,7 +526,7 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
     nz = en_wave_sum(part, (RBT_LDS_AS RbtEncLds*)0);
   }
   RBT_SYNC_LDS();
-  if (nz && !f->lossless) {
+  if (nz && !e->lossless) {
     const int bd_shift = bd + log2 - 5, scale = (16 * rc_level_scale(qp % 6)) << (qp / 6);
     const long long add = 1ll << (bd_shift - 1);
     RBT_PAR_FOR(i, N * N) { long long v = ((long long)lvl[i] * scale + add) >> bd_shift; r->res[i] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
@@ -512,7 +536,7 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
     RBT_PAR_FOR(i, N * N) r->res[i] = lvl[i];
     RBT_SYNC_LDS();
   }
-  if (ts_out && !f->lossless && !occ_none) {
+  if (ts_out && !e->lossless && !occ_none) {
     // transform skip (7.3.8.11 transform_skip_flag, 8.6.4.2): the residual scaled by 2^(15 - bitDepth - 2) is quantised like coefficients; both ways are
     // priced as distortion * 256 + lambda^2 * rate, the flag costs one bit more, and transform skip needs a non-zero level
     const int tsh = 15 - bd - 2, qbits = 14 + qp / 6 + (15 - bd - log2), sc = en_quant_scale(qp % 6), bd_shift = bd + log2 - 5, scale = (16 * rc_level_scale(qp % 6)) << (qp / 6), ish = 20 - bd;
@@ -541,7 +565,7 @@ template <int TL2> RBT_DEV int en_tile_intra_tb(const RbtStreamCfg* g, RbtFrame*
     }
   }
   if (mark_l4 != -2) {                                  // -2: a trial whose block is coded again, or replaced, before anything reads it (the coded mode trial's runner-up): only its cost
-    { int16_t* cp = f->coef[c_idx] + (size_t)gy * pw + gx; RBT_PAR_FOR(i, N * N) cp[(size_t)(i >> log2) * pw + (i & (N - 1))] = lvl[i]; }
+    { int16_t* cp = e->coef[c_idx] + (size_t)gy * pw + gx; RBT_PAR_FOR(i, N * N) cp[(size_t)(i >> log2) * pw + (i & (N - 1))] = lvl[i]; }
     RBT_PAR_FOR(i, N * N) {
       const int x = i & (N - 1), y = i >> log2;
       tile[(y0 + y) * S + x0 + x + 1] = (uint16_t)(nz ? rbt_clip3(0, maxv, (int)r->pred[i] + r->res[i]) : r->pred[i]);
@@ -622,13 +646,14 @@ template <int TL2> RBT_DEV int en_refine_mode(const RbtStreamCfg* g, RBT_LDS_AS 
 // have_whole: the coded mode trial has just coded the CU as one block with this mode (levels in lv0, reconstruction in the tile, cost / distortion / cbf handed in)
 template <int TL2> RBT_DEV int en_intra_cu_luma(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int x0, int y0, int gx, int gy, int lg, int mode, int qp, int lam2, int* split, int* ts_bits,
                                               int have_whole = 0, long long c_whole_in = 0, int ssd0_in = 0, int cbf0_in = 0, int reuse_nb = 0) {
+  const EnCtbCtx* e = static_cast<const EnCtbCtx*>(g);                 // every caller hands an EnCtbCtx in (en_intra_ctb)
   RBT_LDS_AS RbtEncTileT<TL2>* t = &L->t;
   const int N = 1 << lg, h = N >> 1, S = RbtEncTileT<TL2>::TS_Y;
   long long c_whole = c_whole_in, c_split = 3ll * lam2, cq = 0;
   int ssd0 = ssd0_in, cbf0 = cbf0_in;
   if (!have_whole) cbf0 = en_tile_intra_tb(g, f, L, 0, x0, y0, gx, gy, lg, mode, qp, t->sb, -1, 0, 0, t->lv0, &c_whole, lam2, &ssd0, nullptr, reuse_nb);
   *split = 0; *ts_bits = 0;
-  if (!f->lossless && (long long)ssd0 * 256 < (long long)(lam2 >> 2) * N * N) {     // coded to within lambda^2 / 4 per sample by one transform: not tried as four (lossless: the bits alone decide)
+  if (!e->lossless && (long long)ssd0 * 256 < (long long)(lam2 >> 2) * N * N) {     // coded to within lambda^2 / 4 per sample by one transform: not tried as four (lossless: the bits alone decide)
     RBT_PAR_FOR(i, 1 << (2 * (lg - 2))) t->uav[((y0 >> 2) + (i >> (lg - 2)) + 1) * RC_US + (x0 >> 2) + (i & ((1 << (lg - 2)) - 1)) + 1] = 1;
     RBT_SYNC_LDS();
     return cbf0;
@@ -648,13 +673,14 @@ template <int TL2> RBT_DEV int en_intra_cu_luma(const RbtStreamCfg* g, RbtFrame*
   *split = c_split < c_whole;
   if (*split) { *ts_bits = tsm; return cbf1; }
   RBT_PAR_FOR(i, N * N) t->y[(y0 + (i >> lg)) * S + x0 + (i & (N - 1)) + 1] = t->rec0[i];
-  { int16_t* cp = f->coef[0] + (size_t)gy * g->w + gx; RBT_PAR_FOR(i, N * N) cp[(size_t)(i >> lg) * g->w + (i & (N - 1))] = t->lv0[i]; }
+  { int16_t* cp = e->coef[0] + (size_t)gy * g->w + gx; RBT_PAR_FOR(i, N * N) cp[(size_t)(i >> lg) * g->w + (i & (N - 1))] = t->lv0[i]; }
   RBT_SYNC_LDS();
   return cbf0;
 }
 // Cb and Cr TB of one CU in the same passes (see rc_tile_tb_cpair); returns cbf_cb | cbf_cr << 1. src: Cb block, then Cr at +256.
 template <int TL2> RBT_DEV int en_tile_intra_tb_cpair(const RbtStreamCfg* g, RbtFrame* f, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int x0, int y0, int gx, int gy, int log2, int mode, int qp_cb, int qp_cr,
                                    const RBT_LDS_AS uint16_t* src) {
+  const EnCtbCtx* e = static_cast<const EnCtbCtx*>(g);                 // every caller hands an EnCtbCtx in (en_intra_ctb)
   RBT_LDS_AS RbtEncIntraScratch* r = &L->rc; RBT_LDS_AS RbtEncTileT<TL2>* t = &L->t;
   RBT_LDS_AS int32_t* const r_ref = (RBT_LDS_AS int32_t*)r->tmp + 132; RBT_LDS_AS int32_t* const r_ref2 = r_ref + 100; RBT_LDS_AS int16_t* const lvl = (RBT_LDS_AS int16_t*)t->sb;
   const int N = 1 << log2, NN = N * N, bd = g->bit_depth, maxv = (1 << bd) - 1, n4 = (1 << g->log2_ctb) >> 2, pw = g->cw, S = RbtEncTileT<TL2>::TS_C;
@@ -704,7 +730,7 @@ template <int TL2> RBT_DEV int en_tile_intra_tb_cpair(const RbtStreamCfg* g, Rbt
   RBT_SYNC_LDS();
   // occupancy-aware coding (see en_tile_intra_tb): chroma sample (x,y) stands for the luma samples (2x..2x+1, 2y..2y+1), all in one 4x4 unit
   int occ_none = 0;
-  if (f->occ4 != nullptr) {
+  if (e->f4) {
 #define EN_TBC_OCC(j) (t->occ_u[((y0 + ((j) >> log2)) >> 1) * n4 + ((x0 + ((j) & (N - 1))) >> 1)])
     int pc = 0, ps0 = 0, ps1 = 0;
     RBT_PAR_FOR(j, NN) { if (EN_TBC_OCC(j)) { pc++; ps0 += r->res[j]; ps1 += r->res[256 + j]; } }
@@ -719,12 +745,12 @@ template <int TL2> RBT_DEV int en_tile_intra_tb_cpair(const RbtStreamCfg* g, Rbt
   }
   int part = 0;                                                          // non-zero counts: Cb in the low half, Cr in the high half
   if (occ_none) { RBT_PAR_FOR(i, 2 * NN) { const int b = i >= NN, j = i - b * NN; lvl[b * 256 + j] = 0; } }
-  else if (f->lossless) {
+  else if (e->lossless) {
     RBT_PAR_FOR(i, 2 * NN) { const int b = i >= NN, j = i - b * NN; lvl[b * 256 + j] = r->res[b * 256 + j]; part += (r->res[b * 256 + j] != 0) << (16 * b); }
   } else {
     if (log2 == 2) en_fwd_transform_pair_n<2>(bd, r); else if (log2 == 3) en_fwd_transform_pair_n<3>(bd, r); else en_fwd_transform_pair_n<4>(bd, r);
     const int qb_cb = 14 + qp_cb / 6 + (15 - bd - log2), qb_cr = 14 + qp_cr / 6 + (15 - bd - log2), sc_cb = en_quant_scale(qp_cb % 6), sc_cr = en_quant_scale(qp_cr % 6);
-    const int rq = f->enc_tools & RBT_ET_RQ;
+    const int rq = e->enc_tools & RBT_ET_RQ;
     RBT_PAR_FOR(i, 2 * NN) {
       const int b = i >= NN, j = i - b * NN, qbits = b ? qb_cr : qb_cb;
       const int cv = r->res[b * 256 + j], a = rbt_abs(cv);
@@ -738,8 +764,8 @@ template <int TL2> RBT_DEV int en_tile_intra_tb_cpair(const RbtStreamCfg* g, Rbt
   }
   const int nzp = en_wave_sum(part, (RBT_LDS_AS RbtEncLds*)0), nz0 = nzp & 0xFFFF, nz1 = nzp >> 16;
   RBT_SYNC_LDS();
-  RBT_PAR_FOR(i, 2 * NN) { const int b = i >= NN, j = i - b * NN; f->coef[1 + b][(size_t)(gy + (j >> log2)) * pw + gx + (j & (N - 1))] = lvl[b * 256 + j]; }
-  if ((nz0 | nz1) && !f->lossless) {
+  RBT_PAR_FOR(i, 2 * NN) { const int b = i >= NN, j = i - b * NN; (b ? e->coef[2] : e->coef[1])[(size_t)(gy + (j >> log2)) * pw + gx + (j & (N - 1))] = lvl[b * 256 + j]; }
+  if ((nz0 | nz1) && !e->lossless) {
     const int bd_shift = bd + log2 - 5, sc_cb = (16 * rc_level_scale(qp_cb % 6)) << (qp_cb / 6), sc_cr = (16 * rc_level_scale(qp_cr % 6)) << (qp_cr / 6);
     const long long add = 1ll << (bd_shift - 1);
     RBT_PAR_FOR(i, 2 * NN) {
@@ -763,7 +789,7 @@ template <int TL2> RBT_DEV int en_tile_intra_tb_cpair(const RbtStreamCfg* g, Rbt
 // carry_left: the CTB to the left was coded by this wave just before (its reconstruction is still in the tile): take the
 // left border from LDS instead of reading back stores that may still be in flight
 template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtEncTileLdsT<TL2>* L, int carry_left) {
-  const RbtStreamCfg gcopy = rc_cfg_uni(&f->cfg); const RbtStreamCfg* g = &gcopy;
+  EnCtbCtx gcopy; en_ctb_ctx(&gcopy, f); const RbtStreamCfg* g = &gcopy; const EnCtbCtx* e = &gcopy;
   RBT_LDS_AS RbtEncTileT<TL2>* t = &L->t;
   const int ctb = 1 << g->log2_ctb, n4 = ctb >> 2, n8 = ctb >> 3, rx = ctb_addr % g->w_ctb, ry = ctb_addr / g->w_ctb, cx = rx << g->log2_ctb, cy = ry << g->log2_ctb;
   const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
@@ -783,8 +809,8 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
     if ((uy < 0 && ux < 2 * n4) || (ux < 0 && uy < n4)) a = rc_unit_avail(f, ctb_addr, (cx >> 2) + ux, (cy >> 2) + uy);
     t->uav[i] = (uint8_t)a;
   }
-  if (f->occ4 != nullptr) { RBT_PAR_FOR(i, n4 * n4) t->occ_u[i] = (uint8_t)en_occ_unit(f, (cx >> 2) + i % n4, (cy >> 2) + i / n4); }
-  const int refine = f->enc_tools & RBT_ET_REFINE, rdm = refine && tu_rd && !f->lossless && (f->enc_tools & RBT_ET_RDM);
+  if (e->f4) { RBT_PAR_FOR(i, n4 * n4) t->occ_u[i] = (uint8_t)en_occ_unit(f, (cx >> 2) + i % n4, (cy >> 2) + i / n4); }
+  const int refine = e->enc_tools & RBT_ET_REFINE, rdm = refine && tu_rd && !e->lossless && (e->enc_tools & RBT_ET_RDM);
   if (refine) {
     // modes of the CUs along the left border (candIntraPredModeA of this CTB's first column): carried in LDS when this wave has just coded that CTB
     const int left_ok = rx > 0 && f->ctb_slice[ctb_addr - 1] == f->ctb_slice[ctb_addr];
@@ -810,8 +836,8 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
     if ((x0 & (N - 1)) || (y0 & (N - 1))) continue;
     int mode = RBT_UNI(t->cu_md[uy * 8 + ux]);
     // source samples of the CU's three TBs: one HBM round trip
-    { const uint16_t* sp = f->src[0] + (size_t)(cy + y0) * g->w + cx + x0; RBT_PAR_FOR(i, N * N) t->sb[i] = sp[(size_t)(i >> lg) * g->w + (i & (N - 1))]; }
-    for (int q = 0; q < 2; q++) { const uint16_t* sp = f->src[1 + q] + (size_t)((cy + y0) >> 1) * g->cw + ((cx + x0) >> 1); RBT_PAR_FOR(i, Nc * Nc) t->sb[1024 + 256 * q + i] = sp[(size_t)(i >> (lg - 1)) * g->cw + (i & (Nc - 1))]; }
+    { const uint16_t* sp = e->src[0] + (size_t)(cy + y0) * g->w + cx + x0; RBT_PAR_FOR(i, N * N) t->sb[i] = sp[(size_t)(i >> lg) * g->w + (i & (N - 1))]; }
+    for (int q = 0; q < 2; q++) { const uint16_t* sp = (q ? e->src[2] : e->src[1]) + (size_t)((cy + y0) >> 1) * g->cw + ((cx + x0) >> 1); RBT_PAR_FOR(i, Nc * Nc) t->sb[1024 + 256 * q + i] = sp[(size_t)(i >> (lg - 1)) * g->cw + (i & (Nc - 1))]; }
     RBT_SYNC();
     int have_w = 0, ssd_w = 0, cbf_w = 0; long long c_w = 0;
     if (refine) {
@@ -828,7 +854,7 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
         if (c2 + (long long)lam2 * b2 < c_w + (long long)lam2 * b1) mode = second; else have_w = 1;
       }
       const int nu = N >> 3;
-      RBT_PAR_FOR(i, nu * nu) { const int vx = ux + i % nu, vy = uy + i / nu; t->cu_md[vy * 8 + vx] = (uint8_t)mode; f->cu_mode[(((cy + y0) >> 3) + i / nu) * f->w8 + ((cx + x0) >> 3) + i % nu] = (uint8_t)mode; }
+      RBT_PAR_FOR(i, nu * nu) { const int vx = ux + i % nu, vy = uy + i / nu; t->cu_md[vy * 8 + vx] = (uint8_t)mode; e->cu_mode[(((cy + y0) >> 3) + i / nu) * e->w8 + ((cx + x0) >> 3) + i % nu] = (uint8_t)mode; }
       RBT_SYNC_LDS();
     }
     int split = 0, cbf = 0, cy4 = 0, ts_bits = 0;
@@ -846,7 +872,7 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
         RBT_SYNC_LDS();
         const int cc = en_tile_intra_tb_cpair(g, f, L, (x0 + ox) >> 1, (y0 + oy) >> 1, (cx + x0 + ox) >> 1, (cy + y0 + oy) >> 1, lg - 2, mode, qp_cb, qp_cr, t->ss);
         const int fl = RBT_CU_TU_SPLIT | ((cy4 >> b) & 1 ? RBT_CU_CBF_Y : 0) | ((cc & 1) ? RBT_CU_CBF_CB : 0) | ((cc & 2) ? RBT_CU_CBF_CR : 0);
-        en_fill_cu_maps(f, cx + x0 + ox, cy + y0 + oy, hh, RBT_MODE_INTRA | ((fl & RBT_CU_CBF_Y) ? RBT_PM_NZ : 0), qp_y, fl, 1);
+        en_fill_cu_maps_ctx(e, cx + x0 + ox, cy + y0 + oy, hh, RBT_MODE_INTRA | ((fl & RBT_CU_CBF_Y) ? RBT_PM_NZ : 0), qp_y, fl);
       }
       continue;
     }
@@ -855,8 +881,8 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
       if (cc & 2) cbf |= RBT_CU_CBF_CR; }
     if (split) cbf |= RBT_CU_TU_SPLIT | ((cy4 & 1) ? RBT_CU_CBF_Y : 0) | ((cy4 >> 1) * RBT_CU_CBF_Y1);   // 8x8 CU as four 4x4 luma blocks: their cbf bits
     else if (cy4) cbf |= RBT_CU_CBF_Y;
-    en_fill_cu_maps(f, cx + x0, cy + y0, N, RBT_MODE_INTRA | (f->lossless ? RBT_PM_TQ_BYPASS : 0) | (cy4 ? RBT_PM_NZ : 0), qp_y, cbf, 1);
-    if (lg == 3 && g->transform_skip && RBT_LANE0) f->cu_ts[((cy + y0) >> 3) * f->w8 + ((cx + x0) >> 3)] = (uint8_t)ts_bits;   // transform_skip_flag of the four 4x4 luma blocks
+    en_fill_cu_maps_ctx(e, cx + x0, cy + y0, N, RBT_MODE_INTRA | (e->lossless ? RBT_PM_TQ_BYPASS : 0) | (cy4 ? RBT_PM_NZ : 0), qp_y, cbf);
+    if (lg == 3 && g->transform_skip && RBT_LANE0) e->cu_ts[((cy + y0) >> 3) * e->w8 + ((cx + x0) >> 3)] = (uint8_t)ts_bits;   // transform_skip_flag of the four 4x4 luma blocks
   }
   // ---- write the CTB back (clipped to the picture) ----
   for (int c = 0; c < 3; c++) {
@@ -1253,7 +1279,7 @@ RBT_DEV int en_sao_round_div(int sum, int cnt) { return cnt ? (sum >= 0 ? sum + 
 // staging the region, and no LDS beyond the statistics
 template <bool REGION> RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtSaoLds* L, RBT_LDS_AS uint16_t* ry, RBT_LDS_AS uint16_t* rc0, RBT_LDS_AS uint16_t* rc1) {
   const RbtStreamCfg gcopy = rc_cfg_uni(&f->cfg); const RbtStreamCfg* g = &gcopy;
-  const int ctb = 1 << g->log2_ctb, cxi = ctb_addr % g->w_ctb, cyi = ctb_addr / g->w_ctb, bd = g->bit_depth;
+  const int ctb = 1 << g->log2_ctb, cxi = ctb_addr % g->w_ctb, cyi = ctb_addr / g->w_ctb, bd = g->bit_depth, has_occ = RBT_UNI(f->occ4 != nullptr);
   const RbtSlice* sl = &slices[f->ctb_slice[ctb_addr]];
   const long long lam16 = k_lambda16[rbt_clip3(0, 75, sl->qp + 6 * (bd - 8))], lam = lam16 * lam16;
   // a CTB made of skipped CUs only is a copy of the (already filtered) reference: no statistics, no offsets (P pictures are mostly that)
@@ -1318,7 +1344,7 @@ template <bool REGION> RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slic
       const uint16_t* rp = f->pix[c];
       RBT_PAR_FOR(i, n * n) {
         const int x = x0 + (i & (n - 1)), y = y0 + (i >> lgn);
-        if (f->occ4 == nullptr || en_occ_unit(f, (x << sh) >> 2, (y << sh) >> 2)) {
+        if (!has_occ || en_occ_unit(f, (x << sh) >> 2, (y << sh) >> 2)) {
           const size_t o = (size_t)y * pw + x;
           const int v = rp[o], d = (int)sp[o] - v, b = rbt_min(31, v >> (bd - 5)), copy = i & 7; const EnSaoAcc dp = (EnSaoAcc)d * (1 << ash) + 1;
           RBT_LDS_ADD(&L->bcnt[copy][b], 1); RBT_LDS_ADD(&L->bsum[copy][b], d);
@@ -1337,7 +1363,7 @@ template <bool REGION> RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slic
     } else
     RBT_PAR_FOR(i, n * n) {
       const int x = x0 + (i & (n - 1)), y = y0 + (i >> lgn);
-      if (x < pw && y < ph && (f->occ4 == nullptr || en_occ_unit(f, (x << sh) >> 2, (y << sh) >> 2))) {      // occupancy-aware coding: samples no point is made of have no say in the offsets
+      if (x < pw && y < ph && (!has_occ || en_occ_unit(f, (x << sh) >> 2, (y << sh) >> 2))) {      // occupancy-aware coding: samples no point is made of have no say in the offsets
         const int v = EN_SAO_RP(c, x, y), d = (int)sp[(size_t)y * pw + x] - v, b = rbt_min(31, v >> (bd - 5)), copy = i & 7;
         RBT_LDS_ADD(&L->bcnt[copy][b], 1); RBT_LDS_ADD(&L->bsum[copy][b], d);
 #pragma unroll
