@@ -653,7 +653,7 @@ template <int TL2> RBT_DEV int en_intra_cu_luma(const RbtStreamCfg* g, RbtFrame*
   int ssd0 = ssd0_in, cbf0 = cbf0_in;
   if (!have_whole) cbf0 = en_tile_intra_tb(g, f, L, 0, x0, y0, gx, gy, lg, mode, qp, t->sb, -1, 0, 0, t->lv0, &c_whole, lam2, &ssd0, nullptr, reuse_nb);
   *split = 0; *ts_bits = 0;
-  if (!e->lossless && (long long)ssd0 * 256 < (long long)(lam2 >> 2) * N * N) {     // coded to within lambda^2 / 4 per sample by one transform: not tried as four (lossless: the bits alone decide)
+  if ((RBT_ABLATE & 0x10000) || (!e->lossless && (long long)ssd0 * 256 < (long long)(lam2 >> 2) * N * N)) {     // coded to within lambda^2 / 4 per sample by one transform: not tried as four (lossless: the bits alone decide)
     RBT_PAR_FOR(i, 1 << (2 * (lg - 2))) t->uav[((y0 >> 2) + (i >> (lg - 2)) + 1) * RC_US + (x0 >> 2) + (i & ((1 << (lg - 2)) - 1)) + 1] = 1;
     RBT_SYNC_LDS();
     return cbf0;
@@ -810,7 +810,7 @@ template <int TL2> RBT_DEV void en_intra_ctb(RbtFrame* f, const RbtSlice* slices
     t->uav[i] = (uint8_t)a;
   }
   if (e->f4) { RBT_PAR_FOR(i, n4 * n4) t->occ_u[i] = (uint8_t)en_occ_unit(f, (cx >> 2) + i % n4, (cy >> 2) + i / n4); }
-  const int refine = e->enc_tools & RBT_ET_REFINE, rdm = refine && tu_rd && !e->lossless && (e->enc_tools & RBT_ET_RDM);
+  const int refine = (e->enc_tools & RBT_ET_REFINE) && !(RBT_ABLATE & 0x4000), rdm = refine && tu_rd && !e->lossless && (e->enc_tools & RBT_ET_RDM) && !(RBT_ABLATE & 0x8000);
   if (refine) {
     // modes of the CUs along the left border (candIntraPredModeA of this CTB's first column): carried in LDS when this wave has just coded that CTB
     const int left_ok = rx > 0 && f->ctb_slice[ctb_addr - 1] == f->ctb_slice[ctb_addr];

@@ -14,7 +14,8 @@
 // one costs in instructions; what such a build computes is wrong by design. 0 in the product: every `if (RBT_ABLATE & bit)` folds away.
 // Reconstruction: 1 residual (scaling + inverse transform), 2 reference-sample gather, 4 reference smoothing, 8 mode set-up (DC sum / angular reference array),
 // 16 prediction + store, 32 the CTB's fetch into LDS, 64 prediction units (motion compensation), 128 the residual pass of inter blocks. Analysis: 0x100 source fetch, 0x200 gather + smoothing per block, 0x400 the input's modes (hints),
-// 0x800 candidate set-up, 0x1000 candidate SAD, 0x2000 SATD of the chosen mode.
+// 0x800 candidate set-up, 0x1000 candidate SAD, 0x2000 SATD of the chosen mode. Intra coding (decisions only: the output stays a valid stream): 0x4000 the closed-loop mode
+// choice, 0x8000 its coded trial, 0x10000 the four-way form of a CU's luma.
 #ifndef RBT_ABLATE
 #define RBT_ABLATE 0
 #endif
@@ -61,6 +62,8 @@ static __device__ __forceinline__ int rbt_writelane(int old, int v, int lane) { 
 #define RBT_SYNC() __syncthreads()
 // single-wave workgroups only: orders LDS traffic between the lanes of the wave without waiting for outstanding global
 // stores (a __syncthreads() would wait for every store round trip to HBM)
+// (Round 4 tried a compiler-only barrier here - the LDS executes one wave's instructions in issue order, and all 221 GPU parity tests passed that way - and measured no
+// gain, 988-1005 against 983-999 fps: the compiler waits before the first use of the data anyway. The explicit wait stays.)
 #define RBT_SYNC_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define RBT_LANE0 ((threadIdx.x & 63) == 0)
 #define RBT_NTHREADS ((int)blockDim.x)

@@ -2,7 +2,7 @@
 # Development probe (GPU box): the benchmark with two builds of the library (RBT_LIB_PATH), interleaved repeats. $1 = the other build, relative to the repo
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O
 QUIET="--cpu-sample 0 --multi-gof 0 --quality 0 --sweep 0 --walk-frames 0 --fanout-gofs 0 --steady-steps 0"
-for shape in "--steps 20 --warmup 5" "--steps 128 --warmup 32 --gofs-per-job 2"; do for rep in 1 2 3; do for lib in rabbit-transcoding_amd/librbt.so $1; do
+for shape in "--steps 20 --warmup 5" "--steps 256 --warmup 48"; do for rep in 1 2 3; do for lib in rabbit-transcoding_amd/librbt.so $1; do
   RBT_LIB_PATH=$R/$lib timeout -k 10 200 python3 $R/bench.py $shape $QUIET > $O/ab.json 2> $O/ab.err || exit 2
   python3 - "$lib" "$shape" $O/ab.json <<'PY'
 import json, sys
