@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O
 QUIET="--cpu-sample 0 --multi-gof 0 --quality 0 --sweep 0 --walk-frames 0 --fanout-gofs 0 --steady-steps 0"
 VAR=$1; shift
-for shape in "--steps 20 --warmup 5" "--steps 128 --warmup 32 --gofs-per-job 2" "--steps 4 --warmup 1 --in-flight 1 --gofs-per-job 1"; do for rep in 1 2; do for val in "$@"; do
+for shape in "--steps 20 --warmup 5" "--steps 256 --warmup 48" "--steps 4 --warmup 1 --in-flight 1 --gofs-per-job 1"; do for rep in 1 2 3; do for val in "$@"; do
   env $VAR=$val timeout -k 10 200 python3 $R/bench.py $shape $QUIET > $O/ab.json 2> $O/ab.err || exit 2
   python3 - "$VAR=$val" "$shape" $O/ab.json <<'PY'
 import json, sys
