@@ -376,11 +376,7 @@ struct RbtCtbTile {
 // of the longer chain instead of the sum (Cb/Cr were 46 % of a CTB).
 enum { RC_ROLE_ALL = 0, RC_ROLE_LUMA = 1, RC_ROLE_CHROMA = 2 };
 struct RbtReconRole { RbtReconLdsCore rc; uint8_t uav[17 * RC_US]; };   // uav: 4x4 luma unit (ux,uy) usable as intra reference: (uy + 1) * RC_US + ux + 1
-#ifdef RBT_RECON_PAD
-struct RbtReconCtbLds { RbtCtbTile t; RbtReconRole role[2]; uint8_t pad[RBT_RECON_PAD]; };   // experiment: what a larger footprint costs
-#else
 struct RbtReconCtbLds { RbtCtbTile t; RbtReconRole role[2]; };
-#endif
 
 // availability of unit p of the TB at (x0,y0) (plane samples relative to the CTB) from the CTB's unit flags
 RBT_DEV int rc_nb_unit_av(const RBT_LDS_AS uint8_t* uav, int p, int x0, int y0, int N, int sh, int n4) {
