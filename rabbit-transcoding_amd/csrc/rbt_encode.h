@@ -1277,6 +1277,32 @@ RBT_DEV int en_sao_round_div(int sum, int cnt) { return cnt ? (sum >= 0 ? sum + 
 // REGION (RBT_FUSED_ENC_LF=1): the CTB is deblocked here, in LDS - ry / rc0 / rc1: the region of RbtSaoRegionT (rows of ctb + 8 luma, ctb / 2 + 4 chroma samples). Otherwise (the
 // default) the picture was deblocked in place by k_deblock and the samples are read where they lie (neighbours of a sample come from L2): a third less instructions than
 // staging the region, and no LDS beyond the statistics
+// Wave totals of sixteen per-lane values at once, left in dst[0..15] (LDS). Sixteen separate reductions were 27 % of the SAO kernel (4 DPP adds, 4 lane reads and 3 scalar
+// adds each); here the lanes of a pair keep half of the values each and hand the other half over (twice: 16 -> 8 -> 4 values per lane, summed over a quad), the quads of a
+// row are added by two rotations, the four rows through the LDS crossbar: ~60 instructions for all sixteen. Lane l < 4 ends with the totals of values (l & 1) * 8 + (l & 2) * 2 + 0..3.
+RBT_DEV void en_wave_sum16(const int (&v)[16], RBT_LDS_AS int32_t* dst) {
+#ifdef RBT_HOSTEMU
+  for (int q = 0; q < 16; q++) dst[q] = v[q];                        // the serial PAR_FOR already accumulated everything
+#else
+  const int lane = (int)threadIdx.x & 63, b0 = lane & 1, b1 = lane & 2;
+  int a[8], b[4];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { const int keep = b0 ? v[k + 8] : v[k], send = b0 ? v[k] : v[k + 8]; a[k] = keep + __builtin_amdgcn_update_dpp(0, send, 0xB1, 0xF, 0xF, false); }   // quad_perm:[1,0,3,2]
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const int keep = b1 ? a[k + 4] : a[k], send = b1 ? a[k] : a[k + 4]; b[k] = keep + __builtin_amdgcn_update_dpp(0, send, 0x4E, 0xF, 0xF, false); }   // quad_perm:[2,3,0,1]
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    b[k] += __builtin_amdgcn_update_dpp(0, b[k], 0x124, 0xF, 0xF, false);      // row_ror:4
+    b[k] += __builtin_amdgcn_update_dpp(0, b[k], 0x128, 0xF, 0xF, false);      // row_ror:8: every lane of a row holds the row's sum of its four values
+    b[k] += __builtin_amdgcn_ds_swizzle(b[k], 0x401F);                         // lane ^ 16
+    b[k] += __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, b[k]);
+  }
+  if (lane < 4) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) dst[(lane & 1) * 8 + (lane & 2) * 2 + k] = b[k];
+  }
+#endif
+}
 template <bool REGION> RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, RBT_LDS_AS RbtSaoLds* L, RBT_LDS_AS uint16_t* ry, RBT_LDS_AS uint16_t* rc0, RBT_LDS_AS uint16_t* rc1) {
   const RbtStreamCfg gcopy = rc_cfg_uni(&f->cfg); const RbtStreamCfg* g = &gcopy;
   const int ctb = 1 << g->log2_ctb, cxi = ctb_addr % g->w_ctb, cyi = ctb_addr / g->w_ctb, bd = g->bit_depth, has_occ = RBT_UNI(f->occ4 != nullptr);
@@ -1377,8 +1403,7 @@ template <bool REGION> RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slic
         }
       }
     }
-#pragma unroll
-    for (int q = 0; q < 16; q++) { const int cn = en_wave_sum(ecnt[q], (RBT_LDS_AS RbtEncLds*)0), sm = en_wave_sum(esum[q], (RBT_LDS_AS RbtEncLds*)0); if (RBT_LANE0) { L->ecnt[q] = cn; L->esum[q] = sm; } }
+    en_wave_sum16(ecnt, L->ecnt); en_wave_sum16(esum, L->esum);
     RBT_SYNC_LDS();
     // offsets and distortion reductions, lanes over the 32 bands and the 16 (class, category) pairs
     RBT_PAR_FOR(j, 48) {
