@@ -195,6 +195,8 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
             if (!any) { hc |= (26ull << 12) | (10ull << 18); nh = 4; }
           }
           int coarse = 0;
+          RBT_VEC(int, v_last); RBT_VEC(int, v_keep);           // 8x8 blocks (one sample per lane): the residual of the candidate just tried / of the best so far - the SATD below needs no second prediction
+          RBT_VFOR(p, 64) { RBT_V(v_last, p) = 0; RBT_V(v_keep, p) = 0; }
           for (int k = 0; k < 15; k++) {
             int mode;
             if (best == 0) break;                               // cannot get better
@@ -209,14 +211,17 @@ RBT_DEV void en_analyse_ctb(RbtFrame* f, const RbtSlice* slices, int ctb_addr, R
             RBT_LDS_AS int32_t* fin = rc_intra_filter_needed(0, lg, mode) ? rl->nbf : rl->nb;
             RcIntraCtx qc; if (!(RBT_ABLATE & 0x800)) rc_intra_setup(g, 0, lg, mode, fin, rl->ref, &qc); else { qc.N = S; qc.log2 = lg; qc.mode = mode; qc.c_idx = 0; qc.maxv = 1023; qc.ang = 1; qc.ver = mode >= 18; qc.dc = 1; qc.edge = 0; }
             int part = (RBT_ABLATE & 0x1000) ? 1 + k : 0;
-#define EN_BODY(PV) RBT_PAR_FOR(i, S * S) { const int x = i & (S - 1), y = i >> lg; part += rbt_abs((int)l->src[(by0 + y + 1) * 66 + bx0 + x + 1] - (PV)); }
+#define EN_BODY(PV) RBT_PAR_FOR(i, S * S) { const int x = i & (S - 1), y = i >> lg, r = (int)l->src[(by0 + y + 1) * 66 + bx0 + x + 1] - (PV); part += rbt_abs(r); RBT_V(v_last, i & 63) = r; }
             if (!(RBT_ABLATE & 0x1000)) RC_INTRA_KINDS(&qc, fin, rl->ref, EN_BODY);
 #undef EN_BODY
             int sad = en_wave_sum(part, (RBT_LDS_AS RbtEncLds*)0);
-            if (sad < best) { best = sad; bmode = mode; }
+            if (sad < best) { best = sad; bmode = mode; if (S == 8) { RBT_VFOR(p, 64) RBT_V(v_keep, p) = RBT_V(v_last, p); } }
             RBT_SYNC_LDS();                                     // rl->ref is rebuilt by the next mode
           }
-          if (satd_on && best > 0 && !(RBT_ABLATE & 0x2000)) {
+          if (satd_on && best > 0 && S == 8 && !(RBT_ABLATE & (0x2000 | 0x1000))) {
+            int acc = 0; EN_HAD8X8_ACC(v_keep, acc);             // lane p = sample (p & 7, p >> 3) in the SAD pass and in the transform alike
+            best = (en_wave_sum(acc, (RBT_LDS_AS RbtEncLds*)0) + 4) >> 3;
+          } else if (satd_on && best > 0 && !(RBT_ABLATE & 0x2000)) {
             // the mode by SAD, the block's cost (what the split decisions compare) by the SATD of that mode (oracle/hevc_enc.c analyse_ctb_intra, satd_block)
             RBT_LDS_AS int32_t* fin = rc_intra_filter_needed(0, lg, bmode) ? rl->nbf : rl->nb;
             RcIntraCtx qc; rc_intra_setup(g, 0, lg, bmode, fin, rl->ref, &qc);
