@@ -1459,27 +1459,39 @@ template <bool REGION> RBT_DEV void en_sao_ctb(RbtFrame* f, const RbtSlice* slic
   RBT_SYNC_LDS();
 }
 // sao() of one CTB (7.3.8.3) from the decided parameters: merged with the left / upper CTB of the same slice when they carry the same parameters
-RBT_DEV int en_sao_same(const RbtSao* a, const RbtSao* b) { int same = 1; for (int i = 0; i < (int)sizeof(RbtSao); i++) same &= ((const uint8_t*)a)[i] == ((const uint8_t*)b)[i]; return same; }
+// A CTB's SAO record as three wave-uniform 64-bit words, fields picked out with shifts: a private copy of the struct indexed by run-time (component, offset) lives in scratch
+// memory on this hardware - eight round trips to it per CTB on the entropy coder's serial chain (round 4).
+struct EnSaoWords { uint64_t q[3]; };
+RBT_DEV EnSaoWords en_sao_words(const RbtSao* p) {
+  static_assert(sizeof(RbtSao) == 24, "three 64-bit words");
+  const uint32_t* w = (const uint32_t*)p; EnSaoWords r;
+  r.q[0] = (uint64_t)(uint32_t)RBT_UNI(w[0]) | ((uint64_t)(uint32_t)RBT_UNI(w[1]) << 32);       // written out: compiled for size the loop stays a loop, and an array indexed by its counter goes to scratch
+  r.q[1] = (uint64_t)(uint32_t)RBT_UNI(w[2]) | ((uint64_t)(uint32_t)RBT_UNI(w[3]) << 32);
+  r.q[2] = (uint64_t)(uint32_t)RBT_UNI(w[4]) | ((uint64_t)(uint32_t)RBT_UNI(w[5]) << 32);
+  return r;
+}
+RBT_DEV int en_sao_byte(const EnSaoWords& r, int k) { const uint64_t q = k < 8 ? r.q[0] : (k < 16 ? r.q[1] : r.q[2]); return (int)((q >> (8 * (k & 7))) & 255u); }   // byte k of the record: type 0..2, band_pos 3..5, eo_class 6..8, offset 9..20
+RBT_DEV int en_sao_same(const EnSaoWords& a, const EnSaoWords& b) { return a.q[0] == b.q[0] && a.q[1] == b.q[1] && a.q[2] == b.q[2]; }
 RBT_DEV void en_write_sao(RbtCabacEnc* c, const RbtFrame* f, int addr, int rx, int ry, int wc, int bd) {
-  const RbtSao p = f->sao[addr];
+  const EnSaoWords p = en_sao_words(&f->sao[addr]);
   const int my = f->ctb_slice[addr], can_left = rx > 0 && f->ctb_slice[addr - 1] == my, can_up = ry > 0 && f->ctb_slice[addr - wc] == my;
   int merge_left = 0, merge_up = 0;
-  if (can_left) { const RbtSao q = f->sao[addr - 1]; merge_left = en_sao_same(&p, &q); }
-  if (can_up && !merge_left) { const RbtSao q = f->sao[addr - wc]; merge_up = en_sao_same(&p, &q); }
+  if (can_left) merge_left = en_sao_same(p, en_sao_words(&f->sao[addr - 1]));
+  if (can_up && !merge_left) merge_up = en_sao_same(p, en_sao_words(&f->sao[addr - wc]));
   merge_left = RBT_UNI(merge_left); merge_up = RBT_UNI(merge_up);
   if (can_left) rbt_ce_bin0(c, CTX_SAO_MERGE, merge_left);
   if (can_up && !merge_left) rbt_ce_bin0(c, CTX_SAO_MERGE, merge_up);
   if (merge_left || merge_up) return;
   const int cmax = (1 << (rbt_min(bd, 10) - 5)) - 1;
   for (int ci = 0; ci < 3; ci++) {
-    const int t = RBT_UNI(p.type[ci]);
+    const int t = en_sao_byte(p, ci);
     if (ci < 2) { rbt_ce_bin0(c, CTX_SAO_TYPE, t != 0); if (t) rbt_ce_bypass(c, t == 2); }
     if (!t) continue;
-    for (int i = 0; i < 4; i++) { const int a = RBT_UNI(rbt_abs(p.offset[ci][i])); if (a) rbt_ce_bypass_n(c, (1u << a) - 1u, a); if (a < cmax) rbt_ce_bypass(c, 0); }
+    for (int i = 0; i < 4; i++) { const int a = rbt_abs((int)(int8_t)en_sao_byte(p, 9 + 4 * ci + i)); if (a) rbt_ce_bypass_n(c, (1u << a) - 1u, a); if (a < cmax) rbt_ce_bypass(c, 0); }
     if (t == 1) {
-      for (int i = 0; i < 4; i++) { const int o = RBT_UNI(p.offset[ci][i]); if (o) rbt_ce_bypass(c, o < 0); }
-      rbt_ce_bypass_n(c, (uint32_t)RBT_UNI(p.band_pos[ci]), 5);
-    } else if (ci < 2) rbt_ce_bypass_n(c, (uint32_t)RBT_UNI(p.eo_class[ci]), 2);
+      for (int i = 0; i < 4; i++) { const int o = (int)(int8_t)en_sao_byte(p, 9 + 4 * ci + i); if (o) rbt_ce_bypass(c, o < 0); }
+      rbt_ce_bypass_n(c, (uint32_t)en_sao_byte(p, 3 + ci), 5);
+    } else if (ci < 2) rbt_ce_bypass_n(c, (uint32_t)en_sao_byte(p, 6 + ci), 2);
   }
 }
 RBT_DEV void en_entropy_slice(RbtFrame* frames, RbtSlice* slices, int slice_idx, uint8_t* out, RBT_LDS_AS RbtEntropyLds* l) {
